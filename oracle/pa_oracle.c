@@ -1,0 +1,86 @@
+/*
+ * pa_oracle.c -- C twins of the oracle's hot loops (TEST INFRASTRUCTURE ONLY).
+ *
+ * Same loops as oracle/pa_oracle.py, compiled with -O3 -ffp-contract=off so that every
+ * product and every sum is rounded separately, in the reference's order.  Used (a) for
+ * parity at sizes python loops cannot reach and (b) as bench.py's `cpu_baseline` ("port").
+ * Never linked into, or loaded by, the product.
+ *
+ * All indices are 1-based Int32 as in SparseMatrixCSR{1,Float64,Int32}
+ * (/root/reference/HPCG/src/sparse_matrix.jl:115).
+ */
+#include <stdint.h>
+
+/* src/sparse_utils.jl:649-669  spmv_csr!(b,x,rowptr,colval,nzval) */
+void orc_spmv_csr(double *b, const double *x, const int32_t *rowptr, const int32_t *colval,
+                  const double *nzval, int64_t nrows) {
+  for (int64_t row = 0; row < nrows; ++row) {
+    int64_t pini = rowptr[row], pend = rowptr[row + 1];
+    double bi = 0.0;
+    for (int64_t p = pini; p < pend; ++p) {
+      double aij = nzval[p - 1];
+      double xj = x[colval[p - 1] - 1];
+      bi += aij * xj;
+    }
+    b[row] = bi;
+  }
+}
+
+/* SparseMatricesCSR.mul!(y,A,x,alpha,beta) (v0.6, third-party; called from
+ * src/p_sparse_matrix.jl:2088,2119,2126,2133,2137): beta-scale, then
+ * y[row] += nzval*x[col]*alpha, entry by entry. */
+void orc_mul5_csr(double *y, const double *x, const int32_t *rowptr, const int32_t *colval,
+                  const double *nzval, int64_t nrows, double alpha, double beta) {
+  if (beta != 1.0) {
+    if (beta != 0.0) { for (int64_t r = 0; r < nrows; ++r) y[r] *= beta; }
+    else             { for (int64_t r = 0; r < nrows; ++r) y[r] = 0.0; }
+  }
+  for (int64_t row = 0; row < nrows; ++row) {
+    int64_t pini = rowptr[row], pend = rowptr[row + 1];
+    for (int64_t p = pini; p < pend; ++p)
+      y[row] += nzval[p - 1] * x[colval[p - 1] - 1] * alpha;
+  }
+}
+
+/* src/p_vector.jl:595-599  buffer_snd.data[p] = values[lid] */
+void orc_pack(double *buf, const double *values, const int32_t *lids, int64_t n) {
+  for (int64_t p = 0; p < n; ++p) buf[p] = values[lids[p] - 1];
+}
+/* src/p_vector.jl:605-609 with f = insert (:755) */
+void orc_unpack_insert(double *values, const double *buf, const int32_t *lids, int64_t n) {
+  for (int64_t p = 0; p < n; ++p) values[lids[p] - 1] = buf[p];
+}
+/* src/p_vector.jl:605-609 with f = + (:695-697); ascending p, duplicates allowed */
+void orc_unpack_add(double *values, const double *buf, const int32_t *lids, int64_t n) {
+  for (int64_t p = 0; p < n; ++p) values[lids[p] - 1] = values[lids[p] - 1] + buf[p];
+}
+
+/* HPCG/src/sparse_matrix.jl:27-80 restricted to what the CPU baseline needs: the local CSR
+ * (columns [own|ghost], 1-based) of ONE part that owns the whole grid (npx=npy=npz=1), written
+ * directly in row order.  With a single part there are no ghosts and the COO stream is already
+ * row-major with ascending columns, so COO->CSR is the identity on the stream. */
+int64_t orc_hpcg_csr_single(int32_t nx, int32_t ny, int32_t nz, int32_t *rowptr, int32_t *colval,
+                            double *nzval) {
+  int64_t k = 0, row = 0;
+  rowptr[0] = 1;
+  for (int32_t iz = 0; iz < nz; ++iz)
+    for (int32_t iy = 0; iy < ny; ++iy)
+      for (int32_t ix = 0; ix < nx; ++ix) {
+        int64_t cur = (int64_t)iz * nx * ny + (int64_t)iy * nx + ix;
+        for (int sz = -1; sz <= 1; ++sz) {
+          if (iz + sz < 0 || iz + sz >= nz) continue;
+          for (int sy = -1; sy <= 1; ++sy) {
+            if (iy + sy < 0 || iy + sy >= ny) continue;
+            for (int sx = -1; sx <= 1; ++sx) {
+              if (ix + sx < 0 || ix + sx >= nx) continue;
+              int64_t col = cur + (int64_t)sz * nx * ny + (int64_t)sy * nx + sx;
+              if (colval) { colval[k] = (int32_t)(col + 1); nzval[k] = (col == cur) ? 26.0 : -1.0; }
+              ++k;
+            }
+          }
+        }
+        ++row;
+        rowptr[row] = (int32_t)(k + 1);
+      }
+  return k;
+}

@@ -1,0 +1,975 @@
+"""
+pa_oracle -- CPU restatement of the PartitionedArrays.jl hot path (TEST INFRASTRUCTURE ONLY).
+
+This file is the *oracle*: a plain numpy / pure-Python restatement of the reference's
+algorithm for `mul!(c::PVector, A::PSparseMatrix, b::PVector)` and the ghost exchange
+(`consistent!`, `assemble!`, `exchange!`) it depends on, plus the host-side set-up that
+defines the data those loops run on (partitions, ghost numbering, neighbour lists, COO->CSR).
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import it.
+The product (`partitionedarrays.jl_amd/`) never does.
+
+Parity pinning: there is no Julia in this image, so the reference itself cannot be run.
+The oracle is pinned against every literal golden value the reference's own tests and
+docstrings hold for this path (tests/golden/*.json, checked by tests/test_oracle_golden.py).
+What is NOT pinned by a literal golden is the *value* of `mul!` on a CSR-split
+PSparseMatrix for general x (the reference has only type-level smoke tests there);
+it is pinned by the diagonal-matrix known answers, by `A*1 == b` for the HPCG matrix
+(HPCG/src/sparse_matrix.jl:60-75) and by distributed == centralised products.
+The third-party `SparseMatricesCSR.mul!(y,A,x,a,b)` (v0.6, not in /root/reference) is
+restated from its published source: `y[row] += nzval*x[col]*alpha` row by row.
+
+Conventions: EVERYTHING is 1-based exactly as in the reference's data (part ids, global ids,
+local ids, `ptrs`), stored in 0-based numpy arrays.  "parts" are python lists (DebugArray
+semantics: `map` is a sequential loop, src/debug_array.jl:110-117).
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+"""
+from __future__ import annotations
+
+import ctypes
+import itertools
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+I64 = np.int64
+I32 = np.int32
+F64 = np.float64
+
+
+# --------------------------------------------------------------------------------------
+# src/jagged_array.jl
+# --------------------------------------------------------------------------------------
+def length_to_ptrs(ptrs):
+    """src/jagged_array.jl:11-18 -- in: ptrs[i+1] = len(i); out: 1-based start offsets."""
+    ptrs[0] = 1
+    for i in range(len(ptrs) - 1):
+        ptrs[i + 1] += ptrs[i]
+    return ptrs
+
+
+def rewind_ptrs(ptrs):
+    """src/jagged_array.jl:26-32."""
+    for i in range(len(ptrs) - 2, -1, -1):
+        ptrs[i + 1] = ptrs[i]
+    ptrs[0] = 1
+    return ptrs
+
+
+@dataclass
+class Jagged:
+    """src/jagged_array.jl:107-122: data + 1-based ptrs; slice i = data[ptrs[i]-1 : ptrs[i+1]-1]."""
+    data: np.ndarray
+    ptrs: np.ndarray
+
+    @staticmethod
+    def from_lists(vv, dtype=None, ptr_dtype=I32):
+        """src/jagged_array.jl:130-152 (JaggedArray(a) for a vector of vectors)."""
+        ptrs = np.zeros(len(vv) + 1, dtype=ptr_dtype)
+        for i, v in enumerate(vv):
+            ptrs[i + 1] = len(v)
+        length_to_ptrs(ptrs)
+        flat = [x for v in vv for x in v]
+        if dtype is None:
+            data = np.array(flat) if flat else np.zeros(0, dtype=I64)
+        else:
+            data = np.array(flat, dtype=dtype)
+        return Jagged(data, ptrs)
+
+    def __len__(self):
+        return len(self.ptrs) - 1
+
+    def __getitem__(self, i):  # 0-based slot i
+        return self.data[self.ptrs[i] - 1: self.ptrs[i + 1] - 1]
+
+    def tolists(self):
+        return [self[i].tolist() for i in range(len(self))]
+
+
+# --------------------------------------------------------------------------------------
+# src/p_range.jl -- block sizes, index sets
+# --------------------------------------------------------------------------------------
+def local_range(p, np_, n, ghost=False, periodic=False):
+    """src/p_range.jl:806-818. Returns inclusive 1-based (start, stop)."""
+    l, rem = divmod(n, np_)
+    offset = l * (p - 1)
+    if rem >= (np_ - p + 1):
+        l += 1
+        offset += p - (np_ - rem) - 1
+    g = 1 if ghost else 0
+    start = 1 + offset - g
+    stop = l + offset + g
+    if periodic:
+        return start, stop
+    return max(1, start), min(n, stop)
+
+
+def _cartesian(rank, np_):
+    """CartesianIndices(np)[rank], column-major, 1-based (src/p_range.jl:617)."""
+    r = rank - 1
+    out = []
+    for d in np_:
+        out.append(r % d + 1)
+        r //= d
+    return tuple(out)
+
+
+def _linear(ci, n):
+    """LinearIndices(n)[ci], column-major, 1-based."""
+    lin, stride = 0, 1
+    for c, d in zip(ci, n):
+        lin += (c - 1) * stride
+        stride *= d
+    return lin + 1
+
+
+@dataclass
+class Indices:
+    """One part of an index partition (the AbstractLocalIndices interface, src/p_range.jl:32-160).
+
+    Covers LocalIndicesWithConstantBlockSize / VariableBlockSize (own ids first, ghosts after:
+    src/p_range.jl:1711-1720), PermutedLocalIndices (:1372) and LocalIndices (:1100).
+    """
+    n_global: int
+    part: int                         # 1-based owner id
+    local_to_global: np.ndarray       # int64, 1-based gids
+    local_to_owner: np.ndarray        # int32, 1-based part ids
+    kind: str = "generic"             # "block" when a block partition (find_owner by arithmetic)
+    np_: tuple = ()
+    n: tuple = ()
+    ranges: tuple = ()                # own box ((lo,hi),...) inclusive, block partitions only
+    starts: tuple = ()                # per-dim block starts (+ n+1), for find_owner
+    cache: dict = field(default_factory=dict)   # AssemblyCache, src/p_range.jl:354-359
+
+    def __post_init__(self):
+        self.local_to_global = np.asarray(self.local_to_global, dtype=I64)
+        self.local_to_owner = np.asarray(self.local_to_owner, dtype=I32)
+        own = self.local_to_owner == self.part
+        # src/p_range.jl:1121-1128 (findall; perm)
+        self.own_to_local = (np.nonzero(own)[0] + 1).astype(I32)
+        self.ghost_to_local = (np.nonzero(~own)[0] + 1).astype(I32)
+        n_own = len(self.own_to_local)
+        self.perm = np.zeros(len(own), dtype=I32)
+        self.perm[self.own_to_local - 1] = np.arange(1, n_own + 1)
+        self.perm[self.ghost_to_local - 1] = np.arange(1, len(self.ghost_to_local) + 1) + n_own
+        self._g2l = None
+
+    # lengths
+    @property
+    def n_own(self):
+        return len(self.own_to_local)
+
+    @property
+    def n_ghost(self):
+        return len(self.ghost_to_local)
+
+    @property
+    def n_local(self):
+        return len(self.local_to_global)
+
+    @property
+    def own_to_global(self):
+        return self.local_to_global[self.own_to_local - 1]
+
+    @property
+    def ghost_to_global(self):
+        return self.local_to_global[self.ghost_to_local - 1]
+
+    @property
+    def ghost_to_owner(self):
+        return self.local_to_owner[self.ghost_to_local - 1]
+
+    def global_to_local(self, gids):
+        """global_to_local(indices)[gid]; 0 when gid is not local (VectorFromDict default)."""
+        if self._g2l is None:
+            order = np.argsort(self.local_to_global, kind="stable")
+            self._g2l = (self.local_to_global[order], order)
+        srt, order = self._g2l
+        g = np.asarray(gids, dtype=I64).ravel()
+        if len(srt) == 0:
+            return np.zeros(len(g), dtype=I32)
+        pos = np.clip(np.searchsorted(srt, g), 0, len(srt) - 1)
+        hit = srt[pos] == g
+        return np.where(hit, order[pos] + 1, 0).astype(I32)
+
+
+def _block_starts(np_, n):
+    """src/p_range.jl:1611-1615: per-dim first(local_range(p)) for p=1..np, then n+1."""
+    return tuple(
+        np.array([local_range(p, npd, nd)[0] for p in range(1, npd + 1)] + [nd + 1], dtype=I64)
+        for npd, nd in zip(np_, n)
+    )
+
+
+def _box_gids(ranges, n):
+    """Column-major enumeration of a box inside the global grid (src/p_range.jl:1471-1481)."""
+    axes = [np.arange(lo, hi + 1, dtype=I64) for lo, hi in ranges]
+    gid = np.zeros((), dtype=I64)
+    stride = 1
+    for d, ax in enumerate(axes):
+        shape = [1] * len(axes)
+        shape[d] = len(ax)
+        gid = gid + (ax.reshape(shape) - 1) * stride
+        stride *= n[d]
+    # column-major: first axis fastest -> transpose then ravel in C order
+    return (gid + 1).transpose(tuple(reversed(range(len(axes))))).ravel()
+
+
+def uniform_partition(np_, n, ghost=None, periodic=None):
+    """src/p_range.jl:585-671.  np_, n tuples (or ints for 1-D).  Returns a list of Indices."""
+    if isinstance(np_, int):
+        np_, n = (np_,), (n,)
+        if ghost is not None and not isinstance(ghost, tuple):
+            ghost = (ghost,)
+        if periodic is not None and not isinstance(periodic, tuple):
+            periodic = (periodic,)
+    np_, n = tuple(np_), tuple(n)
+    P = int(np.prod(np_))
+    starts = _block_starts(np_, n)
+    parts = []
+    for rank in range(1, P + 1):
+        p = _cartesian(rank, np_)
+        own_ranges = tuple(local_range(pd, npd, nd) for pd, npd, nd in zip(p, np_, n))
+        if ghost is None:
+            # block_with_constant_size(rank,np,n): src/p_range.jl:615-620
+            l2g = _box_gids(own_ranges, n)
+            l2o = np.full(len(l2g), rank, dtype=I32)
+            ind = Indices(int(np.prod(n)), rank, l2g, l2o, "block", np_, n, own_ranges, starts)
+            # src/p_range.jl:590-594: an EMPTY assembly cache is installed
+            ind.cache = dict(neighbors_snd=np.zeros(0, I32), neighbors_rcv=np.zeros(0, I32),
+                             local_indices_snd=Jagged(np.zeros(0, I32), np.array([1], I32)),
+                             local_indices_rcv=Jagged(np.zeros(0, I32), np.array([1], I32)))
+            parts.append(ind)
+            continue
+        per = periodic if periodic is not None else tuple(False for _ in ghost)
+        # block_with_constant_size(rank,np,n,ghost,periodic): src/p_range.jl:622-671
+        local_ranges = tuple(local_range(pd, npd, nd, g, pr)
+                             for pd, npd, nd, g, pr in zip(p, np_, n, ghost, per))
+        owners = []
+        for pd, npd, nd, lr in zip(p, np_, n, local_ranges):
+            lo, hi = lr
+            lrv = list(range(lo, hi + 1))
+            my = [0] * len(lrv)
+            i = 0
+            done = False
+            for q in itertools.cycle(range(1, npd + 1)):     # :630
+                plo, phi = local_range(q, npd, nd)
+                while plo <= ((lrv[i] - 1) % nd) + 1 <= phi:
+                    my[i] = q
+                    i += 1
+                    if i >= len(my):
+                        done = True
+                        break
+                if done:
+                    break
+            owners.append(my)
+        lens = [hi - lo + 1 for lo, hi in local_ranges]
+        l2g, l2o = [], []
+        for ci0 in itertools.product(*[range(L) for L in reversed(lens)]):
+            ci = tuple(reversed(ci0))                         # column-major enumeration (:648)
+            is_own = all(own_ranges[d][0] <= local_ranges[d][0] + ci[d] <= own_ranges[d][1]
+                         for d in range(len(n)))
+            gci = tuple(((local_ranges[d][0] + ci[d] - 1) % n[d]) + 1 for d in range(len(n)))  # CircularArray
+            l2g.append(_linear(gci, n))
+            if is_own:
+                l2o.append(rank)
+            else:
+                o = tuple(owners[d][ci[d]] for d in range(len(n)))
+                l2o.append(_linear(o, np_))
+        ind = Indices(int(np.prod(n)), rank, np.array(l2g, I64), np.array(l2o, I32),
+                      "block-permuted", np_, n, own_ranges, starts)
+        parts.append(ind)
+    if ghost is not None:
+        assembly_neighbors(parts, symmetric=True)             # src/p_range.jl:596
+    return parts
+
+
+def variable_partition(n_own, n_global):
+    """src/p_range.jl:705-733 (1-D, no ghost). start = exclusive scan with init 1."""
+    P = len(n_own)
+    start = [1]
+    for k in n_own[:-1]:
+        start.append(start[-1] + k)
+    starts = (np.array(start + [n_global + 1], dtype=I64),)
+    parts = []
+    for rank in range(1, P + 1):
+        lo = start[rank - 1]
+        hi = lo + n_own[rank - 1] - 1
+        l2g = np.arange(lo, hi + 1, dtype=I64)
+        ind = Indices(n_global, rank, l2g, np.full(len(l2g), rank, I32), "block",
+                      (P,), (n_global,), ((lo, hi),), starts)
+        ind.cache = dict(neighbors_snd=np.zeros(0, I32), neighbors_rcv=np.zeros(0, I32),
+                         local_indices_snd=Jagged(np.zeros(0, I32), np.array([1], I32)),
+                         local_indices_rcv=Jagged(np.zeros(0, I32), np.array([1], I32)))
+        parts.append(ind)
+    return parts
+
+
+def local_indices(n_global, owner, local_to_global, local_to_owner):
+    """LocalIndices(n_global,owner,local_to_global,local_to_owner), src/p_range.jl:1119-1143."""
+    return Indices(n_global, owner, local_to_global, local_to_owner)
+
+
+def find_owner(indices, global_ids):
+    """src/p_range.jl:346-348,1609-1619,1502-1513: owner = LinearIndices(np)[searchsortedlast per dim]."""
+    out = []
+    for ind, gids in zip(indices, global_ids):
+        assert ind.kind.startswith("block")
+        gids = np.asarray(gids, dtype=I64)
+        r = gids - 1
+        owner = np.zeros(len(gids), dtype=I64)
+        stride = 1
+        for d, nd in enumerate(ind.n):
+            c = r % nd + 1
+            r = r // nd
+            j = np.searchsorted(ind.starts[d], c, side="right")  # searchsortedlast (1-based result)
+            owner += (j - 1) * stride
+            stride *= ind.np_[d]
+        out.append((owner + 1).astype(I32))
+    return out
+
+
+def filter_ghost(ind, gids, owners):
+    """src/p_range.jl:205-241: unseen non-own gids in FIRST-SEEN order; gid<1 skipped."""
+    gids = np.asarray(gids, dtype=I64)
+    owners = np.asarray(owners, dtype=I32)
+    existing = set(int(g) for g in ind.ghost_to_global)
+    mask = (gids >= 1) & (owners != ind.part)
+    cand_g = gids[mask]
+    cand_o = owners[mask]
+    if existing:
+        keep = np.array([int(g) not in existing for g in cand_g], dtype=bool)
+        cand_g, cand_o = cand_g[keep], cand_o[keep]
+    _, first = np.unique(cand_g, return_index=True)
+    first.sort()
+    return cand_g[first], cand_o[first]
+
+
+def union_ghost(ind, gids, owners):
+    """src/p_range.jl:252-259 (+replace_ghost :1603): same own ids, ghosts = old ++ new."""
+    assert ind.kind == "block", "replace_ghost only makes sense for un-permuted local indices"
+    extra_g, extra_o = filter_ghost(ind, gids, owners)
+    own_g = ind.own_to_global
+    l2g = np.concatenate([own_g, ind.ghost_to_global, extra_g])
+    l2o = np.concatenate([np.full(len(own_g), ind.part, I32), ind.ghost_to_owner, extra_o])
+    return Indices(ind.n_global, ind.part, l2g, l2o, "block", ind.np_, ind.n, ind.ranges, ind.starts)
+
+
+# --------------------------------------------------------------------------------------
+# src/primitives.jl -- ExchangeGraph, exchange
+# --------------------------------------------------------------------------------------
+def find_rcv_ids_gather_scatter(snd_ids):
+    """src/primitives.jl:826-859: rcv[j] = ascending list of i with j in snd[i] (CSC order)."""
+    P = len(snd_ids)
+    rcv = [[] for _ in range(P)]
+    for i in range(1, P + 1):
+        for j in sorted(set(int(x) for x in snd_ids[i - 1])):
+            rcv[j - 1].append(i)
+    # adjmat = sparse(I,J,...) iterated column by column, rows ascending inside a column
+    return [np.array(sorted(r), dtype=I32) for r in rcv]
+
+
+def exchange_graph(snd, rcv=None, symmetric=False):
+    """ExchangeGraph(snd;rcv,symmetric,...) src/primitives.jl:768-783."""
+    if rcv is not None:
+        return snd, rcv
+    if symmetric:
+        return snd, snd
+    return snd, find_rcv_ids_gather_scatter(snd)
+
+
+def is_consistent(snd, rcv):
+    """src/primitives.jl:861-874."""
+    for part in range(1, len(rcv) + 1):
+        for i in rcv[part - 1]:
+            if sum(1 for k in snd[i - 1] if k == part) != 1:
+                return False
+        for i in snd[part - 1]:
+            if sum(1 for k in rcv[i - 1] if k == part) != 1:
+                return False
+    return True
+
+
+def exchange_scalar(snd_data, snd_ids, rcv_ids):
+    """src/primitives.jl:1005-1018: rcv[r][i] = snd[s][j], s = rcv_ids[r][i], snd_ids[s][j] == r."""
+    assert is_consistent(snd_ids, rcv_ids)
+    out = []
+    for r in range(1, len(rcv_ids) + 1):
+        row = []
+        for s in rcv_ids[r - 1]:
+            j = [k for k, v in enumerate(snd_ids[s - 1]) if v == r][0]
+            row.append(snd_data[s - 1][j])
+        out.append(row)
+    return out
+
+
+def exchange_jagged(rcv, snd, snd_ids, rcv_ids):
+    """src/primitives.jl:1020-1042 (in-place on rcv[r].data). rcv/snd: lists of Jagged."""
+    assert is_consistent(snd_ids, rcv_ids)
+    for r in range(1, len(rcv_ids) + 1):
+        for i, s in enumerate(rcv_ids[r - 1]):
+            j = [k for k, v in enumerate(snd_ids[s - 1]) if v == r][0]
+            pr, ps = rcv[r - 1].ptrs, snd[s - 1].ptrs
+            assert pr[i + 1] - pr[i] == ps[j + 1] - ps[j]
+            rcv[r - 1].data[pr[i] - 1: pr[i + 1] - 1] = snd[s - 1].data[ps[j] - 1: ps[j + 1] - 1]
+    return rcv
+
+
+def allocate_exchange_jagged(snd, snd_ids, rcv_ids, dtype=None):
+    """src/primitives.jl:953-983: exchange the slice lengths first, then allocate."""
+    n_snd = [[int(s.ptrs[j + 1] - s.ptrs[j]) for j in range(len(s))] for s in snd]
+    n_rcv = exchange_scalar(n_snd, snd_ids, rcv_ids)
+    out = []
+    for r, counts in enumerate(n_rcv):
+        ptrs = np.zeros(len(counts) + 1, dtype=I32)
+        ptrs[1:] = counts
+        length_to_ptrs(ptrs)
+        out.append(Jagged(np.zeros(ptrs[-1] - 1, dtype=dtype or snd[r].data.dtype), ptrs))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# src/p_range.jl -- assembly neighbours / local indices
+# --------------------------------------------------------------------------------------
+def assembly_neighbors(indices, symmetric=False):
+    """src/p_range.jl:417-450 (cached; snd = sorted unique non-own owners)."""
+    if all("neighbors_snd" in ind.cache for ind in indices):
+        return [i.cache["neighbors_snd"] for i in indices], [i.cache["neighbors_rcv"] for i in indices]
+    parts_snd = []
+    for ind in indices:
+        s = sorted(set(int(o) for o in ind.local_to_owner if o != ind.part))
+        parts_snd.append(np.array(s, dtype=I32))
+    snd, rcv = exchange_graph(parts_snd, symmetric=symmetric)
+    for ind, s, r in zip(indices, snd, rcv):
+        ind.cache["neighbors_snd"] = s
+        ind.cache["neighbors_rcv"] = r
+    return snd, rcv
+
+
+def assembly_local_indices(indices, neighbors_snd=None, neighbors_rcv=None):
+    """src/p_range.jl:466-531."""
+    if neighbors_snd is None:
+        neighbors_snd, neighbors_rcv = assembly_neighbors(indices)
+    if all("local_indices_snd" in ind.cache for ind in indices):
+        return ([i.cache["local_indices_snd"] for i in indices],
+                [i.cache["local_indices_rcv"] for i in indices])
+    lids_snd, gids_snd = [], []
+    for ind, parts_snd in zip(indices, neighbors_snd):
+        owner_to_i = {int(o): i for i, o in enumerate(parts_snd)}
+        ptrs = np.zeros(len(parts_snd) + 1, dtype=I32)
+        for o in ind.local_to_owner:
+            if o != ind.part:
+                ptrs[owner_to_i[int(o)] + 1] += 1
+        length_to_ptrs(ptrs)
+        data_l = np.zeros(ptrs[-1] - 1, dtype=I32)
+        data_g = np.zeros(ptrs[-1] - 1, dtype=I64)
+        for lid0, o in enumerate(ind.local_to_owner):
+            if o != ind.part:
+                k = owner_to_i[int(o)]
+                p = ptrs[k]
+                data_l[p - 1] = lid0 + 1
+                data_g[p - 1] = ind.local_to_global[lid0]
+                ptrs[k] += 1
+        rewind_ptrs(ptrs)
+        lids_snd.append(Jagged(data_l, ptrs))
+        gids_snd.append(Jagged(data_g, ptrs.copy()))
+    gids_rcv = allocate_exchange_jagged(gids_snd, neighbors_snd, neighbors_rcv, dtype=I64)
+    exchange_jagged(gids_rcv, gids_snd, neighbors_snd, neighbors_rcv)
+    lids_rcv = []
+    for g, ind in zip(gids_rcv, indices):
+        lids_rcv.append(Jagged(ind.global_to_local(g.data).astype(I32), g.ptrs))
+    for ind, s, r in zip(indices, lids_snd, lids_rcv):
+        ind.cache["local_indices_snd"] = s
+        ind.cache["local_indices_rcv"] = r
+    return lids_snd, lids_rcv
+
+
+# --------------------------------------------------------------------------------------
+# src/p_vector.jl -- cache, assemble!, consistent!
+# --------------------------------------------------------------------------------------
+@dataclass
+class VectorAssemblyCache:
+    """src/p_vector.jl:418-426."""
+    neighbors_snd: list
+    neighbors_rcv: list
+    local_indices_snd: list
+    local_indices_rcv: list
+    buffer_snd: list
+    buffer_rcv: list
+
+    def reverse(self):
+        """src/p_vector.jl:427-437."""
+        return VectorAssemblyCache(self.neighbors_rcv, self.neighbors_snd,
+                                   self.local_indices_rcv, self.local_indices_snd,
+                                   self.buffer_rcv, self.buffer_snd)
+
+
+def p_vector_cache(values, indices, dtype=F64):
+    """src/p_vector.jl:451-468."""
+    ns, nr = assembly_neighbors(indices)
+    ls, lr = assembly_local_indices(indices, ns, nr)
+    bs = [Jagged(np.zeros(l.ptrs[-1] - 1, dtype=dtype), l.ptrs) for l in ls]
+    br = [Jagged(np.zeros(l.ptrs[-1] - 1, dtype=dtype), l.ptrs) for l in lr]
+    return VectorAssemblyCache(ns, nr, ls, lr, bs, br)
+
+
+def assemble_impl(f, values, cache):
+    """src/p_vector.jl:587-612: pack, exchange!, unpack with f(old, rcv). f in {'insert', '+'}."""
+    for v, lids, buf in zip(values, cache.local_indices_snd, cache.buffer_snd):
+        for p, lid in enumerate(lids.data):                  # :595-599
+            buf.data[p] = v[lid - 1]
+    exchange_jagged(cache.buffer_rcv, cache.buffer_snd, cache.neighbors_snd, cache.neighbors_rcv)
+    for v, lids, buf in zip(values, cache.local_indices_rcv, cache.buffer_rcv):
+        for p, lid in enumerate(lids.data):                  # :605-609
+            if f == "insert":
+                v[lid - 1] = buf.data[p]
+            else:
+                v[lid - 1] = v[lid - 1] + buf.data[p]
+    return values
+
+
+def consistent(values, indices, cache=None):
+    """consistent!(a), src/p_vector.jl:747-755: reversed cache + insert."""
+    cache = cache or p_vector_cache(values, indices, values[0].dtype)
+    return assemble_impl("insert", values, cache.reverse())
+
+
+def assemble(values, indices, cache=None):
+    """assemble!(+,a), src/p_vector.jl:695-708: add into owners, then zero the ghosts."""
+    cache = cache or p_vector_cache(values, indices, values[0].dtype)
+    assemble_impl("+", values, cache)
+    for v, ind in zip(values, indices):
+        v[ind.ghost_to_local - 1] = 0
+    return values
+
+
+def pvector_collect(values, indices):
+    """collect(v): own values scattered to global positions."""
+    out = np.zeros(indices[0].n_global, dtype=values[0].dtype)
+    for v, ind in zip(values, indices):
+        out[ind.own_to_global - 1] = v[ind.own_to_local - 1]
+    return out
+
+
+def dot(a, b, indices):
+    """src/p_vector.jl:1189-1192: own-values dots, then sum over parts (left to right)."""
+    s = 0.0
+    for x, y, ind in zip(a, b, indices):
+        s = s + float(np.dot(x[ind.own_to_local - 1], y[ind.own_to_local - 1]))
+    return s
+
+
+def norm2(a, indices):
+    """src/p_vector.jl:1201-1206 with p=2."""
+    s = 0.0
+    for x, ind in zip(a, indices):
+        s = s + float(np.linalg.norm(x[ind.own_to_local - 1])) ** 2
+    return s ** 0.5
+
+
+# --------------------------------------------------------------------------------------
+# src/sparse_utils.jl -- COO -> CSR, local kernels
+# --------------------------------------------------------------------------------------
+@dataclass
+class CSR:
+    """SparseMatrixCSR{1,Float64,Int32}: 1-based rowptr/colval, columns sorted per row."""
+    m: int
+    n: int
+    rowptr: np.ndarray
+    colval: np.ndarray
+    nzval: np.ndarray
+
+    @property
+    def nnz(self):
+        return len(self.nzval)
+
+    def to_dense(self):
+        A = np.zeros((self.m, self.n))
+        for r in range(self.m):
+            for p in range(self.rowptr[r] - 1, self.rowptr[r + 1] - 1):
+                A[r, self.colval[p] - 1] += self.nzval[p]
+        return A
+
+
+def compresscoo_csr(I, J, V, m, n, skip=True, index_dtype=I32):
+    """src/sparse_utils.jl:313-350 -> sparsecsr(Val(1),I,J,V,m,n,+) (SparseMatricesCSR 0.6).
+
+    Per-row sorted columns; duplicates combined with + in input order; with skip=true the
+    entries with i<1||j<1 are NOT dropped for CSR but rewritten to (1,1,0.0)
+    (FilteredCooVector, :330-342,370-390); m*n==0 -> empty (:334-337).
+    """
+    I = np.asarray(I, dtype=I64).copy()
+    J = np.asarray(J, dtype=I64).copy()
+    V = np.asarray(V, dtype=F64).copy()
+    if skip and m * n == 0:
+        I, J, V = I[:0], J[:0], V[:0]
+    elif skip:
+        bad = (I < 1) | (J < 1)
+        I[bad] = 1
+        J[bad] = 1
+        V[bad] = 0.0
+    order = np.lexsort((J, I))                 # stable: duplicates keep input order
+    Is, Js, Vs = I[order], J[order], V[order]
+    if len(Is):
+        new = np.ones(len(Is), dtype=bool)
+        new[1:] = (Is[1:] != Is[:-1]) | (Js[1:] != Js[:-1])
+    else:
+        new = np.zeros(0, dtype=bool)
+    slot = np.cumsum(new) - 1
+    nz = int(new.sum())
+    nzval = np.zeros(nz, dtype=F64)
+    nzval[slot[new]] = Vs[new]
+    if (~new).any():
+        np.add.at(nzval, slot[~new], Vs[~new])   # sequential, input order
+    colval = Js[new].astype(index_dtype)
+    rowptr = np.zeros(m + 1, dtype=index_dtype)
+    np.add.at(rowptr, Is[new], 1)
+    rowptr[0] = 1
+    np.cumsum(rowptr, out=rowptr)
+    return CSR(m, n, rowptr, colval, nzval)
+
+
+def spmv_csr(b, x, rowptr, colval, nzval):
+    """src/sparse_utils.jl:649-669, literal: bi = 0; bi += aij*xj ascending p; unfused."""
+    for row in range(len(b)):
+        bi = 0.0
+        for p in range(rowptr[row] - 1, rowptr[row + 1] - 1):
+            bi = bi + nzval[p] * x[colval[p] - 1]
+        b[row] = bi
+    return b
+
+
+def spmv_csc(b, x, colptr, rowval, nzval):
+    """src/sparse_utils.jl:671-690 (default CSC storage): b=0; b[row] += aij*xj column by column."""
+    b[:] = 0.0
+    for col in range(len(x)):
+        xj = x[col]
+        for p in range(colptr[col] - 1, colptr[col + 1] - 1):
+            b[rowval[p] - 1] = b[rowval[p] - 1] + nzval[p] * xj
+    return b
+
+
+def mul5_csr(y, A: CSR, x, alpha, beta):
+    """SparseMatricesCSR.mul!(y,A,x,alpha,beta) (v0.6, third-party; restated):
+    beta-scale y (rmul! / fill! 0), then y[row] += nzval*x[col]*alpha row by row."""
+    if beta != 1:
+        if beta != 0:
+            y *= beta
+        else:
+            y[:] = 0.0
+    for row in range(A.m):
+        for p in range(A.rowptr[row] - 1, A.rowptr[row + 1] - 1):
+            y[row] = y[row] + A.nzval[p] * x[A.colval[p] - 1] * alpha
+    return y
+
+
+def csr_to_csc(A: CSR):
+    """Same matrix in CSC (1-based); rows ascending inside a column."""
+    rows = np.repeat(np.arange(1, A.m + 1), np.diff(A.rowptr.astype(I64)))
+    order = np.lexsort((rows, A.colval))
+    colptr = np.zeros(A.n + 1, dtype=I64)
+    np.add.at(colptr, A.colval, 1)
+    colptr[0] = 1
+    np.cumsum(colptr, out=colptr)
+    return colptr, rows[order], A.nzval[order]
+
+
+# --------------------------------------------------------------------------------------
+# src/p_sparse_matrix.jl -- psparse(assembled=true), split format, mul!
+# --------------------------------------------------------------------------------------
+@dataclass
+class SplitBlocks:
+    """src/p_sparse_matrix.jl:588-627: own_own (n x n), own_ghost (n x g), ghost_own, ghost_ghost."""
+    own_own: CSR
+    own_ghost: CSR
+    ghost_own: CSR
+    ghost_ghost: CSR
+
+
+def split_format_locally(A: CSR, rows: Indices, cols: Indices):
+    """src/p_sparse_matrix.jl:823-899. Routes each stored entry by (perm[i]<=n_own, perm[j]<=n_own).
+
+    The ghost-row branches of the reference carry latent index bugs (:872,:877-878);
+    they are restated as evidently intended (ip-n_own_rows, jp-n_own_cols) and only reachable
+    for non-assembled matrices.
+    """
+    rp, cp = rows.perm, cols.perm
+    nor, noc = rows.n_own, cols.n_own
+    ri = np.repeat(np.arange(1, A.m + 1), np.diff(A.rowptr.astype(I64)))
+    ip = rp[ri - 1].astype(I64)
+    jp = cp[A.colval - 1].astype(I64)
+    v = A.nzval
+    oo = (ip <= nor) & (jp <= noc)
+    og = (ip <= nor) & ~(jp <= noc)
+    go = ~(ip <= nor) & (jp <= noc)
+    gg = ~(ip <= nor) & ~(jp <= noc)
+    idt = A.rowptr.dtype
+    return SplitBlocks(
+        compresscoo_csr(ip[oo], jp[oo], v[oo], nor, noc, skip=False, index_dtype=idt),
+        compresscoo_csr(ip[og], jp[og] - noc, v[og], nor, cols.n_ghost, skip=False, index_dtype=idt),
+        compresscoo_csr(ip[go] - nor, jp[go], v[go], rows.n_ghost, noc, skip=False, index_dtype=idt),
+        compresscoo_csr(ip[gg] - nor, jp[gg] - noc, v[gg], rows.n_ghost, cols.n_ghost, skip=False, index_dtype=idt),
+    )
+
+
+@dataclass
+class PSparse:
+    matrix_partition: list      # list of CSR (local, n_local_rows x n_local_cols)
+    blocks: list                # list of SplitBlocks
+    rows: list
+    cols: list
+    assembled: bool
+
+
+def psparse_assembled(I, J, V, rows, cols, index_dtype=I32):
+    """psparse(T,I,J,V,rows,cols;assembled=true), src/p_sparse_matrix.jl:1249-1270:
+    map_global_to_local! (src/p_range.jl:287,298) -> sparse_matrix -> compresscoo (skip=true)."""
+    mats, blocks = [], []
+    for Ii, Ji, Vi, r, c in zip(I, J, V, rows, cols):
+        li = r.global_to_local(Ii)
+        lj = c.global_to_local(Ji)
+        A = compresscoo_csr(li, lj, Vi, r.n_local, c.n_local, skip=True, index_dtype=index_dtype)
+        mats.append(A)
+        blocks.append(split_format_locally(A, r, c))
+    return PSparse(mats, blocks, rows, cols, True)
+
+
+def mul(c, A: PSparse, b, cache=None):
+    """mul!(c,a,b), src/p_sparse_matrix.jl:2090-2103 (assembled): consistent!(b);
+    c_own = A_oo*b_own (spmv!); wait; c_own += A_oh*b_ghost (muladd!)."""
+    assert A.assembled
+    consistent(b, A.cols, cache)
+    for ci, bi, blk, r, col in zip(c, b, A.blocks, A.rows, A.cols):
+        co = np.zeros(r.n_own)
+        oracle_c().spmv_csr(co, bi[col.own_to_local - 1].copy(), blk.own_own)
+        oracle_c().mul5_csr(co, blk.own_ghost, bi[col.ghost_to_local - 1].copy(), 1.0, 1.0)
+        ci[r.own_to_local - 1] = co
+    return c
+
+
+def mul5(c, A: PSparse, b, alpha, beta, cache_b=None, cache_c=None):
+    """mul!(c,a,b,alpha,beta), src/p_sparse_matrix.jl:2105-2142 (both assembled and sub-assembled)."""
+    consistent(b, A.cols, cache_b)
+    K = oracle_c()
+    for ci, bi, blk, r, col in zip(c, b, A.blocks, A.rows, A.cols):
+        bo = bi[col.own_to_local - 1].copy()
+        bh = bi[col.ghost_to_local - 1].copy()
+        co = ci[r.own_to_local - 1].copy()
+        K.mul5_csr(co, blk.own_own, bo, alpha, beta)            # beta-scale then += alpha*A_oo*bo
+        if not A.assembled:
+            ch = ci[r.ghost_to_local - 1].copy()
+            K.mul5_csr(ch, blk.ghost_own, bo, alpha, beta)
+        K.mul5_csr(co, blk.own_ghost, bh, alpha, 1.0)
+        ci[r.own_to_local - 1] = co
+        if not A.assembled:
+            K.mul5_csr(ch, blk.ghost_ghost, bh, alpha, 1.0)
+            ci[r.ghost_to_local - 1] = ch
+    if not A.assembled:
+        assemble(c, A.rows, cache_c)
+    return c
+
+
+def mul_no_lat(c, A: PSparse, b, cache=None):
+    """HPCG/src/hpcg_utils.jl:6-17: blocking consistent!, then ONE unsplit local CSR spmv!."""
+    consistent(b, A.cols, cache)
+    for ci, bi, M, r in zip(c, b, A.matrix_partition, A.rows):
+        co = np.zeros(r.n_own)
+        oracle_c().spmv_csr(co, bi, CSR(r.n_own, M.n, M.rowptr[:r.n_own + 1], M.colval, M.nzval))
+        ci[r.own_to_local - 1] = co
+    return c
+
+
+# --------------------------------------------------------------------------------------
+# Workload generators
+# --------------------------------------------------------------------------------------
+def hpcg_build_matrix(nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0):
+    """HPCG/src/sparse_matrix.jl:27-80 (vectorised; same COO stream order: iz,iy,ix then sz,sy,sx)."""
+    ix = np.arange(nx, dtype=I64)
+    iy = np.arange(ny, dtype=I64)
+    iz = np.arange(nz, dtype=I64)
+    gix = (gix0 + ix)[None, None, :, None, None, None]
+    giy = (giy0 + iy)[None, :, None, None, None, None]
+    giz = (giz0 + iz)[:, None, None, None, None, None]
+    s = np.array([-1, 0, 1], dtype=I64)
+    sx = s[None, None, None, None, None, :]
+    sy = s[None, None, None, None, :, None]
+    sz = s[None, None, None, :, None, None]
+    row = (giz - 1) * gnx * gny + (giy - 1) * gnx + (gix - 1) + 1
+    col = row + sz * gnx * gny + sy * gnx + sx
+    ok = ((giz + sz > 0) & (giz + sz < gnz + 1) & (giy + sy > 0) & (giy + sy < gny + 1)
+          & (gix + sx > 0) & (gix + sx < gnx + 1))
+    shape = (nz, ny, nx, 3, 3, 3)
+    row_b = np.broadcast_to(row, shape)[ok]
+    col_b = np.broadcast_to(col, shape)[ok]
+    val = np.where(col_b == row_b, 26.0, -1.0)
+    cnt = np.broadcast_to(ok, shape).reshape(nz * ny * nx, 27).sum(axis=1)
+    b = 27.0 - cnt
+    rows_b = np.broadcast_to(row, shape)[..., 0, 0, 0].reshape(-1).copy()
+    return row_b.copy(), col_b.copy(), val, b.astype(F64), rows_b
+
+
+def compute_optimal_shape_xyz(np_):
+    """HPCG/src/compute_optimal_xyz.jl:8-64, restricted to the prime-power / small cases used here."""
+    table = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2), 3: (3, 1, 1),
+             16: (4, 2, 2), 6: (2, 3, 1)}
+    return table[np_]
+
+
+def hpcg_build_p_matrix(nx, ny, nz, npx, npy, npz, index_dtype=I32):
+    """HPCG/src/sparse_matrix.jl:105-122. Returns (PSparse, b values, row partition)."""
+    gnx, gny, gnz = npx * nx, npy * ny, npz * nz
+    row_partition = uniform_partition((npx, npy, npz), (gnx, gny, gnz))
+    I, J, V, B, IB = [], [], [], [], []
+    for rows in row_partition:
+        g0 = int(rows.own_to_global[0])
+        cx, cy, cz = _cartesian(g0, (gnx, gny, gnz))
+        i, j, v, b, ib = hpcg_build_matrix(nx, ny, nz, gnx, gny, gnz, cx, cy, cz)
+        I.append(i); J.append(j); V.append(v); B.append(b); IB.append(ib)
+    J_owner = find_owner(row_partition, J)
+    col_partition = [union_ghost(r, j, o) for r, j, o in zip(row_partition, J, J_owner)]
+    A = psparse_assembled(I, J, V, row_partition, col_partition, index_dtype)
+    # b = pvector(I_b,b,row_partition): values land on own rows (all I_b are own)
+    bvals = []
+    for rows, b, ib in zip(col_partition, B, IB):
+        v = np.zeros(rows.n_local)
+        np.add.at(v, rows.global_to_local(ib) - 1, b)
+        bvals.append(v)
+    return A, bvals, row_partition
+
+
+def laplacian_fdm(nodes_per_dir, parts_per_dir):
+    """src/gallery.jl:12-86: per part COO of the (2D+1)-point Laplacian, alpha = prod(n_d+1)."""
+    D = len(nodes_per_dir)
+    alpha = float(np.prod([n + 1 for n in nodes_per_dir]))
+    node_partition = uniform_partition(tuple(parts_per_dir), tuple(nodes_per_dir))
+    Is, Js, Vs = [], [], []
+    for nodes in node_partition:
+        I, J, V = [], [], []
+        lens = [hi - lo + 1 for lo, hi in nodes.ranges]
+        for ci0 in itertools.product(*[range(L) for L in reversed(lens)]):
+            ci = tuple(nodes.ranges[d][0] + c for d, c in enumerate(reversed(ci0)))
+            node_i = _linear(ci, nodes_per_dir)
+            I.append(node_i); J.append(node_i); V.append(alpha * 2 * D)
+            for d in range(D):
+                for i in (-1, 1):
+                    cj = list(ci)
+                    cj[d] += i
+                    if not (1 <= cj[d] <= nodes_per_dir[d]):
+                        continue
+                    I.append(node_i); J.append(_linear(cj, nodes_per_dir)); V.append(-alpha)
+        Is.append(np.array(I, I64)); Js.append(np.array(J, I64)); Vs.append(np.array(V, F64))
+    return Is, Js, Vs, node_partition, node_partition
+
+
+def laplacian_fdm_fast(nodes_per_dir, parts_per_dir):
+    """Vectorised twin of laplacian_fdm (same COO stream order), for 64^3-size cases."""
+    D = len(nodes_per_dir)
+    n = tuple(nodes_per_dir)
+    alpha = float(np.prod([k + 1 for k in n]))
+    node_partition = uniform_partition(tuple(parts_per_dir), n)
+    strides = [int(np.prod(n[:d])) for d in range(D)]
+    Is, Js, Vs = [], [], []
+    for nodes in node_partition:
+        gid = nodes.own_to_global                                   # column-major over own box
+        r = gid - 1
+        coords = []
+        for d in range(D):
+            coords.append(r % n[d] + 1)
+            r = r // n[d]
+        cols = [gid]
+        oks = [np.ones(len(gid), dtype=bool)]
+        vals = [np.full(len(gid), alpha * 2 * D)]
+        for d in range(D):
+            for i in (-1, 1):
+                c = coords[d] + i
+                oks.append((c >= 1) & (c <= n[d]))
+                cols.append(gid + i * strides[d])
+                vals.append(np.full(len(gid), -alpha))
+        ok = np.stack(oks, axis=1)
+        Jm = np.stack(cols, axis=1)
+        Vm = np.stack(vals, axis=1)
+        Im = np.broadcast_to(gid[:, None], Jm.shape)
+        Is.append(Im[ok].copy()); Js.append(Jm[ok].copy()); Vs.append(Vm[ok].copy())
+    return Is, Js, Vs, node_partition, node_partition
+
+
+def psparse_from_coo(I, J, V, row_partition, index_dtype=I32):
+    """The assembled=true route used by HPCG and test/gallery_tests.jl:33:
+    find_owner -> union_ghost (cols) -> psparse(...;assembled=true)."""
+    J_owner = find_owner(row_partition, J)
+    cols = [union_ghost(r, j, o) for r, j, o in zip(row_partition, J, J_owner)]
+    return psparse_assembled(I, J, V, row_partition, cols, index_dtype)
+
+
+def hash_x(gids):
+    """x[gid] = ((gid*2654435761) mod 2^32)/2^32, stateless and partition independent."""
+    g = np.asarray(gids, dtype=np.uint64)
+    return ((g * np.uint64(2654435761)) % np.uint64(2 ** 32)).astype(F64) / float(2 ** 32)
+
+
+# --------------------------------------------------------------------------------------
+# C kernels of the oracle (oracle/pa_oracle.c): same loops, used for mid-size parity and timing
+# --------------------------------------------------------------------------------------
+class _OracleC:
+    def __init__(self, path):
+        self.lib = ctypes.CDLL(path)
+        L = self.lib
+        P = ctypes.c_void_p
+        L.orc_spmv_csr.argtypes = [P, P, P, P, P, ctypes.c_int64]
+        L.orc_mul5_csr.argtypes = [P, P, P, P, P, ctypes.c_int64, ctypes.c_double, ctypes.c_double]
+        L.orc_pack.argtypes = [P, P, P, ctypes.c_int64]
+        L.orc_unpack_insert.argtypes = [P, P, P, ctypes.c_int64]
+        L.orc_unpack_add.argtypes = [P, P, P, ctypes.c_int64]
+        for f in (L.orc_spmv_csr, L.orc_mul5_csr, L.orc_pack, L.orc_unpack_insert, L.orc_unpack_add):
+            f.restype = None
+
+    @staticmethod
+    def _p(a):
+        return a.ctypes.data_as(ctypes.c_void_p)
+
+    def spmv_csr(self, b, x, A: CSR):
+        assert A.rowptr.dtype == I32 and A.colval.dtype == I32
+        assert b.flags.c_contiguous and x.flags.c_contiguous and b.dtype == F64 and x.dtype == F64
+        self.lib.orc_spmv_csr(self._p(b), self._p(x), self._p(A.rowptr), self._p(A.colval),
+                              self._p(A.nzval), len(b))
+        return b
+
+    def mul5_csr(self, y, A: CSR, x, alpha, beta):
+        assert A.rowptr.dtype == I32 and A.colval.dtype == I32
+        assert y.flags.c_contiguous and x.flags.c_contiguous
+        self.lib.orc_mul5_csr(self._p(y), self._p(x), self._p(A.rowptr), self._p(A.colval),
+                              self._p(A.nzval), A.m, float(alpha), float(beta))
+        return y
+
+    def pack(self, buf, values, lids):
+        self.lib.orc_pack(self._p(buf), self._p(values), self._p(lids), len(lids))
+
+    def unpack_insert(self, values, buf, lids):
+        self.lib.orc_unpack_insert(self._p(values), self._p(buf), self._p(lids), len(lids))
+
+    def unpack_add(self, values, buf, lids):
+        self.lib.orc_unpack_add(self._p(values), self._p(buf), self._p(lids), len(lids))
+
+
+class _OraclePy:
+    """Pure-python fallbacks with the same interface (tiny cases; also cross-checks the C)."""
+
+    def spmv_csr(self, b, x, A: CSR):
+        return spmv_csr(b, x, A.rowptr, A.colval, A.nzval)
+
+    def mul5_csr(self, y, A: CSR, x, alpha, beta):
+        return mul5_csr(y, A, x, alpha, beta)
+
+
+_ORACLE_C = None
+
+
+def oracle_c():
+    """Load oracle/libpa_oracle.so (built by oracle/Makefile); pure python if it is absent."""
+    global _ORACLE_C
+    if _ORACLE_C is None:
+        so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpa_oracle.so")
+        _ORACLE_C = _OracleC(so) if os.path.exists(so) else _OraclePy()
+    return _ORACLE_C
