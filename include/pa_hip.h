@@ -1,0 +1,199 @@
+/*
+ * pa_hip.h -- C ABI of libpa_hip.so: the MI355X (gfx950) device path for
+ * PartitionedArrays.jl's  mul!(c::PVector, A::PSparseMatrix, b::PVector)  and the ghost exchange
+ * (consistent! / assemble! / exchange!) it depends on.
+ *
+ * The reference (100 % Julia) has no FFI; its extension points are multiple dispatch on the local
+ * vector type, the local matrix type and the backend array type.  Each entry point
+ * below names the reference method it replaces (paths relative to /root/reference).  The Julia glue
+ * that `ccall`s these symbols is partitionedarrays.jl_amd/julia/PartitionedArraysHIP.jl; the
+ * Python/ctypes host mirror used by the tests is partitionedarrays.jl_amd/.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every function returns 0 on success, <0 on error
+ *    (pa_last_error() gives the message of the calling thread's last failure);
+ *    nothing throws or aborts.  The reference raises Julia exceptions at the same places
+ *    (@assert / @boundscheck / error(...)); the glue turns a non-zero status into error(...).
+ *  - host index arrays are handed over exactly as the reference stores them: 1-based Int32/Int64
+ *    (`index_base` = 1); the library converts to 0-based Int32 in HBM.
+ *  - all device work is asynchronous on the two streams a pa_ctx owns ("compute" and "comm").
+ *    A pa_ctx is driven by one host thread at a time (the reference is single-threaded per rank).
+ *  - the caller keeps ownership of every host array; the library copies what it needs.
+ *  - fp64 values; the per-row summation order of pa_spmv is the reference's (ascending p, one
+ *    rounding per multiply and per add, no FMA) for every row of at most PA_SPMV_CHUNK_NNZ-3
+ *    stored entries, so results are bit-identical to spmv_csr! / SparseMatricesCSR.mul!.
+ */
+#ifndef PA_HIP_H
+#define PA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PA_OK 0
+#define PA_ERR_HIP -1      /* a HIP runtime call failed */
+#define PA_ERR_ARG -2      /* invalid argument (the reference's @assert / @boundscheck) */
+#define PA_ERR_RCCL -3     /* an RCCL call failed or librccl could not be loaded */
+#define PA_ERR_STATE -4    /* call sequence violated (e.g. exchange_end without exchange_begin) */
+
+#define PA_SEG_OWN 0       /* own_values(v)   src/p_vector.jl:20-22  */
+#define PA_SEG_GHOST 1     /* ghost_values(v) src/p_vector.jl:24-26  */
+#define PA_SEG_LOCAL 2     /* local_values(v): the whole [own|ghost] array */
+
+#define PA_CONSISTENT 0    /* consistent!(v): ghost <- owner, `insert`  src/p_vector.jl:747-755 */
+#define PA_ASSEMBLE 1      /* assemble!(v):   owner += ghosts, then ghosts := 0  src/p_vector.jl:695-708 */
+
+#define PA_STREAM_COMPUTE 0
+#define PA_STREAM_COMM 1
+
+#define PA_SPMV_CHUNK_NNZ 2048   /* LDS-staged products per workgroup (16 KiB of fp64) */
+
+typedef struct pa_ctx pa_ctx;     /* one device + its two streams                                  */
+typedef struct pa_vec pa_vec;     /* local values of one part of a PVector, layout [own | ghost]   */
+typedef struct pa_csr pa_csr;     /* one CSR block of a SplitMatrix (own_own, own_ghost, ...)       */
+typedef struct pa_plan pa_plan;   /* VectorAssemblyCache of one part (src/p_vector.jl:418-426)      */
+typedef struct pa_comm pa_comm;   /* RCCL communicator: one rank per part (MPIArray analogue)       */
+typedef struct pa_event pa_event; /* HIP event on one of the ctx streams                            */
+
+/* ---- library ------------------------------------------------------------------------------- */
+int pa_version(void);
+const char *pa_last_error(void);
+int pa_device_count(int *count);
+
+/* ---- context (with_mpi / with_debug lifecycle: src/mpi_array.jl:64-83, src/debug_array.jl:7) - */
+int pa_ctx_create(int device, pa_ctx **ctx);
+int pa_ctx_destroy(pa_ctx *ctx);
+int pa_ctx_sync(pa_ctx *ctx);                        /* both streams */
+int pa_ctx_stream(pa_ctx *ctx, int which, void **hip_stream);
+int pa_ctx_device_info(pa_ctx *ctx, int *cus, int *xcds, size_t *hbm_bytes, char *name, size_t name_len);
+
+/* ---- events / timing (replaces PTimer, src/p_timer.jl; HIP events on the launching stream) --- */
+int pa_event_create(pa_ctx *ctx, pa_event **ev);
+int pa_event_destroy(pa_event *ev);
+int pa_event_record(pa_event *ev, int which_stream);
+int pa_event_elapsed_ms(pa_event *start, pa_event *stop, float *ms);   /* synchronises `stop` */
+
+/* ---- device vectors: the local vector type V of PVector{V} (src/p_vector.jl:8-26,324-345) ---- */
+int pa_vec_create(pa_ctx *ctx, int64_t n_own, int64_t n_ghost, pa_vec **v);   /* zero-filled */
+int pa_vec_wrap(pa_ctx *ctx, void *device_ptr, int64_t n_own, int64_t n_ghost, pa_vec **v);
+int pa_vec_destroy(pa_vec *v);
+int pa_vec_sizes(const pa_vec *v, int64_t *n_own, int64_t *n_ghost);
+int pa_vec_data(pa_vec *v, void **device_ptr);
+int pa_vec_upload(pa_vec *v, const double *host, int64_t offset, int64_t len);     /* local offset */
+int pa_vec_download(const pa_vec *v, double *host, int64_t offset, int64_t len);
+int pa_vec_fill(pa_vec *v, int segment, double value);                  /* fill!(…_values(v), value) */
+int pa_vec_copy(pa_vec *dst, const pa_vec *src, int segment);           /* copy!  */
+/* own-values BLAS-1 (src/p_vector.jl:1189-1206, broadcast :1216-1277): y = a*x + b*y on a segment */
+int pa_vec_axpby(pa_vec *y, double a, const pa_vec *x, double b, int segment);
+/* local dot over OWN values (the per-part term of dot(a,b), src/p_vector.jl:1190); deterministic
+ * two-pass reduction; result left in a device scalar (pa_vec_dot_result) and, if host_out != NULL,
+ * copied back (synchronises the compute stream). */
+int pa_vec_dot(const pa_vec *x, const pa_vec *y, double *host_out);
+int pa_vec_dot_result(pa_ctx *ctx, void **device_scalar);
+
+/* ---- CSR blocks: the local matrix type (src/sparse_utils.jl:609-669; SplitMatrix blocks
+ *      src/p_sparse_matrix.jl:588-627,670-681) ------------------------------------------------- */
+/* rowptr has n_rows+1 entries, colval/nzval nnz entries, columns sorted inside a row (what
+ * compresscoo / sparsecsr produce).  index_bytes in {4,8}, index_base in {0,1}. */
+int pa_csr_create(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr,
+                  const void *colval, int index_bytes, int index_base, const double *nzval, pa_csr **A);
+/* CSC input (the reference's default SparseMatrixCSC storage); converted to CSR at upload:
+ * spmv_csc! and spmv_csr! give bit-identical results (same per-row add order). */
+int pa_csr_create_from_csc(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr,
+                           const void *rowval, int index_bytes, int index_base, const double *nzval,
+                           pa_csr **A);
+int pa_csr_update_values(pa_csr *A, const double *nzval);   /* same pattern, new nonzeros(A) */
+int pa_csr_destroy(pa_csr *A);
+int pa_csr_info(const pa_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int64_t *n_chunks,
+                int64_t *n_nonempty_rows, int64_t *n_long_rows);
+/* y_seg = beta*y_seg + alpha*A*x_seg.
+ *   spmv!(b,A,x)            (src/sparse_utils.jl:617-623,649-669)  <=> alpha=1, beta=0
+ *   muladd!(b,A,x)          (src/p_sparse_matrix.jl:2088)            <=> alpha=1, beta=1
+ *   mul!(b,A,x,alpha,beta)  (SparseMatricesCSR 0.6)                  <=> general
+ * Launched on the compute stream.  x and y must not alias. */
+int pa_spmv(const pa_csr *A, const pa_vec *x, int x_segment, pa_vec *y, int y_segment, double alpha,
+            double beta);
+
+/* ---- exchange plans: p_vector_cache_impl / VectorAssemblyCache (src/p_vector.jl:418-468) ------ */
+/* The arrays are the cache fields in ASSEMBLY orientation, as the reference builds them
+ * (src/p_range.jl:417-531):
+ *   nbr_snd/ptrs_snd/idx_snd : owners of my ghosts (sorted), and my ghost local ids grouped by owner
+ *   nbr_rcv/ptrs_rcv/idx_rcv : parts that ghost my owns, and the own local ids they hold
+ * ptrs are JaggedArray.ptrs (n+1 entries).  consistent! uses the reversed cache (src/p_vector.jl:748).
+ * `part` is this part's id in the same base as the neighbour ids. */
+int pa_plan_create(pa_ctx *ctx, int32_t part, int64_t n_local, int32_t n_snd, const int32_t *nbr_snd,
+                   const int32_t *ptrs_snd, const int32_t *idx_snd, int32_t n_rcv, const int32_t *nbr_rcv,
+                   const int32_t *ptrs_rcv, const int32_t *idx_rcv, int index_base, pa_plan **plan);
+int pa_plan_destroy(pa_plan *plan);
+/* Device send/receive buffers of the given mode (JaggedArray.data of buffer_snd / buffer_rcv after
+ * the reverse() of consistent!), for callers that move the bytes themselves. */
+int pa_plan_buffers(pa_plan *plan, int mode, void **snd, int64_t *snd_len, void **rcv, int64_t *rcv_len);
+
+/* Split-phase exchange, mirroring  t = exchange!(…)  …  wait(t)  (src/p_vector.jl:587-612):
+ *   pa_exchange_pack   : comm stream waits for the compute stream, then
+ *                        buffer_snd.data[p] = values[idx[p]]                      (:595-599)
+ *   <transport>        : one of pa_exchange_local / pa_exchange_rccl / caller-driven copies
+ *   pa_exchange_finish : compute stream waits for the comm stream, then
+ *                        values[idx[p]] = f(values[idx[p]], buffer_rcv.data[p])   (:605-609)
+ *                        f = insert (PA_CONSISTENT) or + in ascending p (PA_ASSEMBLE, deterministic,
+ *                        bit-identical to the reference's loop) followed by ghost := 0 (:703-705). */
+int pa_exchange_pack(pa_plan *plan, const pa_vec *v, int mode);
+int pa_exchange_finish(pa_plan *plan, pa_vec *v, int mode);
+/* Transport A: every part lives in this process (DebugArray analogue, src/debug_array.jl:250-255,
+ * src/primitives.jl:1020-1042): device-to-device slice copies between the plans' buffers.
+ * plans[i] must be the plan of part (i + index_base). Call after pa_exchange_pack on ALL parts. */
+int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mode);
+/* Transport B: one process per part over RCCL (MPIArray analogue, src/mpi_array.jl:575-614):
+ * one ncclGroup of ncclSend/ncclRecv per neighbour on the comm stream; rank = part - index_base. */
+int pa_exchange_rccl(pa_plan *plan, pa_comm *comm, int mode);
+
+/* ---- RCCL communicator (MPI.Init / Comm_dup analogue, src/mpi_array.jl:42-53) ---------------- */
+#define PA_UNIQUE_ID_BYTES 128
+int pa_comm_unique_id(char id[PA_UNIQUE_ID_BYTES]);           /* on one rank; broadcast it yourself */
+int pa_comm_create(pa_ctx *ctx, const char id[PA_UNIQUE_ID_BYTES], int rank, int nranks, pa_comm **comm);
+int pa_comm_destroy(pa_comm *comm);
+/* reduction(+,…;destination=:all) of device doubles (src/mpi_array.jl:494): in place, given stream */
+int pa_comm_allreduce_sum(pa_comm *comm, void *device_ptr, int64_t count, int which_stream);
+int pa_comm_barrier(pa_comm *comm);
+
+/* ---- host-side set-up helpers (native twins of the reference's set-up loops) ----------------- */
+/* All ids 1-based Int64/Int32 exactly as the reference stores them. */
+/* HPCG/src/sparse_matrix.jl:27-80 build_matrix: COO stream (row,col,val) + b + row ids. Returns nnz
+ * through *nnz_out; pass NULL arrays to only count. */
+int pa_host_hpcg_build_matrix(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz,
+                              int64_t gix0, int64_t giy0, int64_t giz0, int64_t *I, int64_t *J, double *V,
+                              double *b, int64_t *row_b, int64_t *nnz_out);
+/* src/gallery.jl:12-86 laplacian_fdm `setup` for one part's own box [lo,hi] per dimension (D<=3). */
+int pa_host_laplacian_fdm(int32_t D, const int64_t *nodes_per_dir, const int64_t *lo, const int64_t *hi,
+                          int64_t *I, int64_t *J, double *V, int64_t *nnz_out);
+/* src/p_range.jl:1609-1619 find_owner for block partitions: starts[d] has np[d]+1 entries. */
+int pa_host_find_owner_block(int32_t D, const int64_t *n, const int32_t *np, const int64_t *const *starts,
+                             const int64_t *gids, int64_t count, int32_t *owners);
+/* src/p_range.jl:205-241 filter_ghost: unseen non-own gids in first-seen order. out arrays sized by
+ * a first call with out_gids == NULL (returns the count in *n_new). */
+int pa_host_filter_ghost(int32_t part, const int64_t *gids, const int32_t *owners, int64_t count,
+                         const int64_t *known_ghost_gids, int64_t n_known, int64_t *out_gids,
+                         int32_t *out_owners, int64_t *n_new);
+/* map_global_to_local! for a block partition: own box + ghost list (src/p_range.jl:287,298,1729). */
+int pa_host_global_to_local_block(int32_t D, const int64_t *n, const int64_t *lo, const int64_t *hi,
+                                  const int64_t *ghost_gids, int64_t n_ghost, const int64_t *gids,
+                                  int64_t count, int32_t *lids);
+/* compresscoo(SparseMatrixCSR{1,Float64,Int32},I,J,V,m,n;combine=+,skip) src/sparse_utils.jl:313-350.
+ * rowptr has m+1 entries; colval/nzval sized by a first call with colval == NULL (*nnz_out). */
+int pa_host_compresscoo_csr(const int32_t *I, const int32_t *J, const double *V, int64_t count, int64_t m,
+                            int64_t n, int skip, int32_t *rowptr, int32_t *colval, double *nzval,
+                            int64_t *nnz_out);
+/* split_format_locally for an assembled matrix whose local ids are [own|ghost] (perm = identity):
+ * src/p_sparse_matrix.jl:823-899, own-row branches. Two-call protocol like above. */
+int pa_host_split_csr(int64_t n_own_rows, int64_t n_own_cols, int64_t n_ghost_cols, const int32_t *rowptr,
+                      const int32_t *colval, const double *nzval, int32_t *oo_rowptr, int32_t *oo_colval,
+                      double *oo_nzval, int32_t *oh_rowptr, int32_t *oh_colval, double *oh_nzval,
+                      int64_t *nnz_oo, int64_t *nnz_oh);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PA_HIP_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of libpa_hip.so (the C ABI of include/pa_hip.h).
+
+The library is the product: if it is missing or cannot be loaded this module raises -- there is
+no CPU or PyTorch fallback for the device path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+# torch is imported first on purpose: it ships its own libamdhip64.so.7 / librccl.so.1 and the
+# dynamic loader then resolves libpa_hip.so's dependencies to those already-loaded copies
+# (one HIP runtime per process).  torch is plumbing here (torch.distributed bootstrap), not compute.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpa_hip.so")
+
+
+class PAError(RuntimeError):
+    """Non-zero status from libpa_hip (the reference raises a Julia exception at the same places)."""
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C partitionedarrays.jl_amd/csrc`). The HIP library is required; there is no fallback.")
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+P = C.c_void_p
+PP = C.POINTER(C.c_void_p)
+i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
+cint = C.c_int
+
+lib.pa_last_error.restype = C.c_char_p
+lib.pa_last_error.argtypes = []
+lib.pa_version.restype = cint
+
+_SIGS = {
+    "pa_device_count": [C.POINTER(cint)],
+    "pa_ctx_create": [cint, PP],
+    "pa_ctx_destroy": [P],
+    "pa_ctx_sync": [P],
+    "pa_ctx_stream": [P, cint, PP],
+    "pa_ctx_device_info": [P, C.POINTER(cint), C.POINTER(cint), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t],
+    "pa_event_create": [P, PP],
+    "pa_event_destroy": [P],
+    "pa_event_record": [P, cint],
+    "pa_event_elapsed_ms": [P, P, C.POINTER(C.c_float)],
+    "pa_vec_create": [P, i64, i64, PP],
+    "pa_vec_wrap": [P, P, i64, i64, PP],
+    "pa_vec_destroy": [P],
+    "pa_vec_sizes": [P, C.POINTER(i64), C.POINTER(i64)],
+    "pa_vec_data": [P, PP],
+    "pa_vec_upload": [P, P, i64, i64],
+    "pa_vec_download": [P, P, i64, i64],
+    "pa_vec_fill": [P, cint, f64],
+    "pa_vec_copy": [P, P, cint],
+    "pa_vec_axpby": [P, f64, P, f64, cint],
+    "pa_vec_dot": [P, P, C.POINTER(f64)],
+    "pa_vec_dot_result": [P, PP],
+    "pa_csr_create": [P, i64, i64, i64, P, P, cint, cint, P, PP],
+    "pa_csr_create_from_csc": [P, i64, i64, i64, P, P, cint, cint, P, PP],
+    "pa_csr_update_values": [P, P],
+    "pa_csr_destroy": [P],
+    "pa_csr_info": [P] + [C.POINTER(i64)] * 6,
+    "pa_spmv": [P, P, cint, P, cint, f64, f64],
+    "pa_plan_create": [P, i32, i64, i32, P, P, P, i32, P, P, P, cint, PP],
+    "pa_plan_destroy": [P],
+    "pa_plan_buffers": [P, cint, PP, C.POINTER(i64), PP, C.POINTER(i64)],
+    "pa_exchange_pack": [P, P, cint],
+    "pa_exchange_finish": [P, P, cint],
+    "pa_exchange_local": [PP, i32, cint],
+    "pa_exchange_rccl": [P, P, cint],
+    "pa_comm_unique_id": [C.c_char_p],
+    "pa_comm_create": [P, C.c_char_p, cint, cint, PP],
+    "pa_comm_destroy": [P],
+    "pa_comm_allreduce_sum": [P, P, i64, cint],
+    "pa_comm_barrier": [P],
+    "pa_host_hpcg_build_matrix": [i64] * 9 + [P, P, P, P, P, C.POINTER(i64)],
+    "pa_host_laplacian_fdm": [i32, P, P, P, P, P, P, C.POINTER(i64)],
+    "pa_host_find_owner_block": [i32, P, P, PP, P, i64, P],
+    "pa_host_filter_ghost": [i32, P, P, i64, P, i64, P, P, C.POINTER(i64)],
+    "pa_host_global_to_local_block": [i32, P, P, P, P, i64, P, i64, P],
+    "pa_host_compresscoo_csr": [P, P, P, i64, i64, i64, cint, P, P, P, C.POINTER(i64)],
+    "pa_host_split_csr": [i64, i64, i64, P, P, P, P, P, P, P, P, P, C.POINTER(i64), C.POINTER(i64)],
+}
+# every symbol the header declares (tests/test_abi.py checks this list against include/pa_hip.h)
+EXPORTS = ["pa_version", "pa_last_error"] + list(_SIGS)
+
+for _name, _args in _SIGS.items():
+    _f = getattr(lib, _name)          # AttributeError here == the library does not export the symbol
+    _f.argtypes = _args
+    _f.restype = cint
+
+SEG_OWN, SEG_GHOST, SEG_LOCAL = 0, 1, 2
+CONSISTENT, ASSEMBLE = 0, 1
+STREAM_COMPUTE, STREAM_COMM = 0, 1
+UNIQUE_ID_BYTES = 128
+
+
+def check(status: int):
+    if status != 0:
+        raise PAError(f"libpa_hip status {status}: {lib.pa_last_error().decode()}")
+
+
+def call(name: str, *args):
+    check(getattr(lib, name)(*args))
+
+
+def ptr(a):
+    """Host pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.flags.c_contiguous, "need a C-contiguous numpy array"
+    return a.ctypes.data_as(P)

@@ -1,0 +1,834 @@
+// pa_device.hip -- gfx950 kernels and the device half of the C ABI declared in include/pa_hip.h.
+//
+// Hot path (reference file:line in /root/reference):
+//   K1/K2  k_spmv_rowsplit   spmv_csr! src/sparse_utils.jl:649-669, muladd! src/p_sparse_matrix.jl:2088
+//   K3     k_pack            src/p_vector.jl:595-599
+//   K4     k_unpack_insert   src/p_vector.jl:605-609 with f = insert (:755)
+//   K5     k_unpack_add      same loop with f = + (:695-697), deterministic (ascending p per target)
+//   K6     k_zero_at         src/p_vector.jl:703-705
+//   K8     k_axpby / k_dot_* src/p_vector.jl:1189-1277
+//
+// This file is compiled with -ffp-contract=off: every product and every sum is rounded once, in
+// the reference's order, so SpMV is bit-identical to the CPU loop (no FMA contraction).
+//
+// SpMV design (bandwidth-bound; no MFMA on purpose):
+//   * host-side "row split": consecutive rows are grouped into chunks of <= 2048 stored entries
+//     (PA_SPMV_CHUNK_NNZ); one 256-thread workgroup per chunk.
+//   * load phase: every lane streams 16-byte value pairs + 8-byte column pairs (fully coalesced,
+//     non-temporal: the matrix is read once and must not evict x from L2), gathers x through
+//     L1/L2, multiplies, and stages the products in LDS (16 KiB per workgroup).
+//   * reduce phase: one lane per row walks its products in LDS in ascending p -- the reference's
+//     left-to-right order -- and writes y.  64-wide wavefronts: lanes of a wave own consecutive rows,
+//     so their LDS reads are stride-(row length) apart: conflict-free for 27 (odd), 2-way for 18.
+//   * blockIdx -> chunk map is XCD-aware: block b runs on XCD b%8, so XCD i gets the i-th contiguous
+//     eighth of the rows; neighbouring workgroups of one XCD share x lines in that XCD's 4 MiB L2.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "pa_internal.h"
+
+thread_local std::string g_pa_err;
+
+void pa_set_err(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_pa_err = buf;
+}
+
+extern "C" const char *pa_last_error(void) { return g_pa_err.c_str(); }
+extern "C" int pa_version(void) { return 100; }
+
+extern "C" int pa_device_count(int *count) {
+  PA_REQUIRE(count != nullptr, "count is NULL");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef int i2 __attribute__((ext_vector_type(2)));
+
+constexpr int SPMV_BLK = 256;
+constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (8)
+static_assert(SPMV_NPT % 2 == 0, "pairs");
+
+// y[row] = beta*y[row] + sum_p (val[p]*x[col[p]])*alpha, products summed in ascending p.
+__global__ __launch_bounds__(SPMV_BLK) void k_spmv_rowsplit(
+    const int *__restrict__ crp, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ chunk_row,
+    const int *__restrict__ row_ids, int n_chunks, int chunks_per_xcd, double alpha, double beta) {
+  __shared__ double prod[PA_SPMV_CHUNK_NNZ];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int chunk = (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
+  if (chunk >= n_chunks || (b >> 3) >= chunks_per_xcd) return;
+  const int r0 = chunk_row[chunk];
+  const int r1 = chunk_row[chunk + 1];
+  const int p0 = crp[r0];
+  const int p1 = crp[r1];
+  const int base = p0 & ~1;  // 16-byte aligned value pairs
+
+  if (p1 - base <= PA_SPMV_CHUNK_NNZ) {
+    // my first row's extent, fetched early so the latency hides under the matrix stream
+    int ra = 0, re = 0;
+    if (r0 + tid < r1) {
+      ra = crp[r0 + tid];
+      re = crp[r0 + tid + 1];
+    }
+    d2 v[SPMV_NPT / 2];
+    i2 c[SPMV_NPT / 2];
+#pragma unroll
+    for (int k = 0; k < SPMV_NPT / 2; ++k) {
+      const int idx = base + (k * SPMV_BLK + tid) * 2;
+      if (idx < p1) {
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(val + idx));
+        c[k] = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(col + idx));
+      } else {
+        v[k] = d2{0.0, 0.0};
+        c[k] = i2{0, 0};
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < SPMV_NPT / 2; ++k) {
+      d2 pr;
+      pr.x = v[k].x * x[c[k].x];
+      pr.y = v[k].y * x[c[k].y];
+      if (alpha != 1.0) {
+        pr.x = pr.x * alpha;
+        pr.y = pr.y * alpha;
+      }
+      *reinterpret_cast<d2 *>(&prod[(k * SPMV_BLK + tid) * 2]) = pr;
+    }
+    __syncthreads();
+    for (int r = r0 + tid; r < r1; r += SPMV_BLK) {
+      if (r != r0 + tid) {
+        ra = crp[r];
+        re = crp[r + 1];
+      }
+      const int row = row_ids ? row_ids[r] : r;
+      double acc = (beta == 0.0) ? 0.0 : beta * y[row];
+      const int a = ra - base, e = re - base;
+#pragma unroll 4
+      for (int p = a; p < e; ++p) acc = acc + prod[p];
+      y[row] = acc;
+    }
+  } else {
+    // one long row (more stored entries than a chunk holds): windows of 2048 products, summed by
+    // lane 0 in ascending p so that even this path keeps the reference's order.
+    const int row = row_ids ? row_ids[r0] : r0;
+    double acc = 0.0;
+    if (tid == 0) acc = (beta == 0.0) ? 0.0 : beta * y[row];
+    for (int w = p0; w < p1; w += PA_SPMV_CHUNK_NNZ) {
+      const int wend = min(w + PA_SPMV_CHUNK_NNZ, p1);
+      for (int idx = w + tid; idx < wend; idx += SPMV_BLK) {
+        double pr = val[idx] * x[col[idx]];
+        if (alpha != 1.0) pr = pr * alpha;
+        prod[idx - w] = pr;
+      }
+      __syncthreads();
+      if (tid == 0)
+        for (int p = 0; p < wend - w; ++p) acc = acc + prod[p];
+      __syncthreads();
+    }
+    if (tid == 0) y[row] = acc;
+  }
+}
+
+__global__ void k_scale(double *__restrict__ y, int64_t n, double beta) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = (beta == 0.0) ? 0.0 : y[i] * beta;
+}
+
+__global__ void k_fill(double *__restrict__ y, int64_t n, double v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = v;
+}
+
+__global__ void k_pack(double *__restrict__ buf, const double *__restrict__ v, const int *__restrict__ idx,
+                       int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) buf[p] = v[idx[p]];
+}
+
+__global__ void k_unpack_insert(double *__restrict__ v, const double *__restrict__ buf,
+                                const int *__restrict__ idx, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) v[idx[p]] = buf[p];
+}
+
+// one lane per distinct target; its contributions are added in ascending p (the reference's order)
+__global__ void k_unpack_add(double *__restrict__ v, const double *__restrict__ buf, const int *__restrict__ tgt,
+                             const int *__restrict__ tptr, const int *__restrict__ tp, int n_tgt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_tgt) {
+    const int lid = tgt[k];
+    double acc = v[lid];
+    for (int j = tptr[k]; j < tptr[k + 1]; ++j) acc = acc + buf[tp[j]];
+    v[lid] = acc;
+  }
+}
+
+__global__ void k_zero_at(double *__restrict__ v, const int *__restrict__ idx, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) v[idx[p]] = 0.0;
+}
+
+__global__ void k_axpby(double *__restrict__ y, const double *__restrict__ x, int64_t n, double a, double b) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = a * x[i] + b * y[i];
+}
+
+__device__ inline double block_sum_256(double s, double *sh) {
+  // 64-wide wavefront shuffle tree, then 4 wave sums through LDS; fixed order => deterministic
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = s;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) t = ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+  return t;
+}
+
+__global__ __launch_bounds__(256) void k_dot_partial(const double *__restrict__ x, const double *__restrict__ y,
+                                                     int64_t n, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += x[i] * y[i];
+  const double t = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_dot_final(const double *__restrict__ partial, int n, double *out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  const double t = block_sum_256(s, sh);
+  if (threadIdx.x == 0) *out = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" int pa_ctx_create(int device, pa_ctx **out) {
+  PA_REQUIRE(out != nullptr, "ctx out pointer is NULL");
+  int n = 0;
+  PA_HIP(hipGetDeviceCount(&n));
+  PA_REQUIRE(device >= 0 && device < n, "device %d out of range (have %d)", device, n);
+  PA_HIP(hipSetDevice(device));
+  pa_ctx *c = new pa_ctx();
+  c->device = device;
+  PA_HIP(hipStreamCreateWithFlags(&c->s[0], hipStreamNonBlocking));
+  PA_HIP(hipStreamCreateWithFlags(&c->s[1], hipStreamNonBlocking));
+  PA_HIP(hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming));
+  hipDeviceProp_t prop;
+  PA_HIP(hipGetDeviceProperties(&prop, device));
+  c->cus = prop.multiProcessorCount;
+  c->xcds = 8;  // gfx950: 8 XCDs x 32 CUs
+  c->hbm = prop.totalGlobalMem;
+  snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+  c->n_partials = 1024;
+  PA_HIP(hipMalloc(&c->d_partials, sizeof(double) * c->n_partials));
+  PA_HIP(hipMalloc(&c->d_scalar, sizeof(double) * 8));
+  PA_HIP(hipMemset(c->d_scalar, 0, sizeof(double) * 8));
+  *out = c;
+  return PA_OK;
+}
+
+extern "C" int pa_ctx_destroy(pa_ctx *c) {
+  if (!c) return PA_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->s[0]);
+  (void)hipStreamSynchronize(c->s[1]);
+  (void)hipFree(c->d_partials);
+  (void)hipFree(c->d_scalar);
+  (void)hipEventDestroy(c->ev_compute);
+  (void)hipStreamDestroy(c->s[0]);
+  (void)hipStreamDestroy(c->s[1]);
+  delete c;
+  return PA_OK;
+}
+
+extern "C" int pa_ctx_sync(pa_ctx *c) {
+  PA_REQUIRE(c != nullptr, "ctx is NULL");
+  PA_HIP(hipSetDevice(c->device));
+  PA_HIP(hipStreamSynchronize(c->s[1]));
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  return PA_OK;
+}
+
+extern "C" int pa_ctx_stream(pa_ctx *c, int which, void **s) {
+  PA_REQUIRE(c && s && (which == 0 || which == 1), "bad arguments");
+  *s = (void *)c->s[which];
+  return PA_OK;
+}
+
+extern "C" int pa_ctx_device_info(pa_ctx *c, int *cus, int *xcds, size_t *hbm, char *name, size_t name_len) {
+  PA_REQUIRE(c != nullptr, "ctx is NULL");
+  if (cus) *cus = c->cus;
+  if (xcds) *xcds = c->xcds;
+  if (hbm) *hbm = c->hbm;
+  if (name && name_len) snprintf(name, name_len, "%s", c->name);
+  return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// events
+// ------------------------------------------------------------------------------------------------
+extern "C" int pa_event_create(pa_ctx *c, pa_event **ev) {
+  PA_REQUIRE(c && ev, "bad arguments");
+  PA_HIP(hipSetDevice(c->device));
+  pa_event *e = new pa_event();
+  e->ctx = c;
+  PA_HIP(hipEventCreate(&e->ev));
+  *ev = e;
+  return PA_OK;
+}
+extern "C" int pa_event_destroy(pa_event *e) {
+  if (!e) return PA_OK;
+  (void)hipEventDestroy(e->ev);
+  delete e;
+  return PA_OK;
+}
+extern "C" int pa_event_record(pa_event *e, int which) {
+  PA_REQUIRE(e && (which == 0 || which == 1), "bad arguments");
+  PA_HIP(hipSetDevice(e->ctx->device));
+  PA_HIP(hipEventRecord(e->ev, e->ctx->s[which]));
+  return PA_OK;
+}
+extern "C" int pa_event_elapsed_ms(pa_event *a, pa_event *b, float *ms) {
+  PA_REQUIRE(a && b && ms, "bad arguments");
+  PA_HIP(hipEventSynchronize(b->ev));
+  PA_HIP(hipEventElapsedTime(ms, a->ev, b->ev));
+  return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// vectors
+// ------------------------------------------------------------------------------------------------
+static inline int seg_range(const pa_vec *v, int seg, int64_t *off, int64_t *len) {
+  switch (seg) {
+    case PA_SEG_OWN: *off = 0; *len = v->n_own; return PA_OK;
+    case PA_SEG_GHOST: *off = v->n_own; *len = v->n_ghost; return PA_OK;
+    case PA_SEG_LOCAL: *off = 0; *len = v->n_own + v->n_ghost; return PA_OK;
+  }
+  pa_set_err("unknown segment %d", seg);
+  return PA_ERR_ARG;
+}
+
+extern "C" int pa_vec_create(pa_ctx *c, int64_t n_own, int64_t n_ghost, pa_vec **out) {
+  PA_REQUIRE(c && out && n_own >= 0 && n_ghost >= 0, "bad arguments");
+  PA_HIP(hipSetDevice(c->device));
+  pa_vec *v = new pa_vec();
+  v->ctx = c; v->n_own = n_own; v->n_ghost = n_ghost; v->owned = true;
+  const size_t bytes = sizeof(double) * (size_t)(n_own + n_ghost + 2);
+  PA_HIP(hipMalloc(&v->d, bytes));
+  PA_HIP(hipMemsetAsync(v->d, 0, bytes, c->s[0]));
+  *out = v;
+  return PA_OK;
+}
+
+extern "C" int pa_vec_wrap(pa_ctx *c, void *ptr, int64_t n_own, int64_t n_ghost, pa_vec **out) {
+  PA_REQUIRE(c && out && (ptr || n_own + n_ghost == 0) && n_own >= 0 && n_ghost >= 0, "bad arguments");
+  pa_vec *v = new pa_vec();
+  v->ctx = c; v->n_own = n_own; v->n_ghost = n_ghost; v->owned = false; v->d = (double *)ptr;
+  *out = v;
+  return PA_OK;
+}
+
+extern "C" int pa_vec_destroy(pa_vec *v) {
+  if (!v) return PA_OK;
+  if (v->owned) {
+    (void)hipSetDevice(v->ctx->device);
+    (void)hipStreamSynchronize(v->ctx->s[0]);
+    (void)hipStreamSynchronize(v->ctx->s[1]);
+    (void)hipFree(v->d);
+  }
+  delete v;
+  return PA_OK;
+}
+
+extern "C" int pa_vec_sizes(const pa_vec *v, int64_t *n_own, int64_t *n_ghost) {
+  PA_REQUIRE(v != nullptr, "vec is NULL");
+  if (n_own) *n_own = v->n_own;
+  if (n_ghost) *n_ghost = v->n_ghost;
+  return PA_OK;
+}
+extern "C" int pa_vec_data(pa_vec *v, void **p) {
+  PA_REQUIRE(v && p, "bad arguments");
+  *p = v->d;
+  return PA_OK;
+}
+
+extern "C" int pa_vec_upload(pa_vec *v, const double *host, int64_t off, int64_t len) {
+  PA_REQUIRE(v && (host || len == 0), "bad arguments");
+  PA_REQUIRE(off >= 0 && len >= 0 && off + len <= v->n_own + v->n_ghost, "range [%lld,+%lld) outside the local vector",
+             (long long)off, (long long)len);
+  if (len == 0) return PA_OK;
+  PA_HIP(hipSetDevice(v->ctx->device));
+  PA_HIP(hipMemcpyAsync(v->d + off, host, sizeof(double) * len, hipMemcpyHostToDevice, v->ctx->s[0]));
+  PA_HIP(hipStreamSynchronize(v->ctx->s[0]));
+  return PA_OK;
+}
+
+extern "C" int pa_vec_download(const pa_vec *v, double *host, int64_t off, int64_t len) {
+  PA_REQUIRE(v && (host || len == 0), "bad arguments");
+  PA_REQUIRE(off >= 0 && len >= 0 && off + len <= v->n_own + v->n_ghost, "range [%lld,+%lld) outside the local vector",
+             (long long)off, (long long)len);
+  PA_HIP(hipSetDevice(v->ctx->device));
+  PA_HIP(hipStreamSynchronize(v->ctx->s[1]));
+  if (len) PA_HIP(hipMemcpyAsync(host, v->d + off, sizeof(double) * len, hipMemcpyDeviceToHost, v->ctx->s[0]));
+  PA_HIP(hipStreamSynchronize(v->ctx->s[0]));
+  return PA_OK;
+}
+
+static inline int grid_for(int64_t n, int threads, int cap = 4096) {
+  int64_t g = (n + threads - 1) / threads;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+extern "C" int pa_vec_fill(pa_vec *v, int seg, double value) {
+  PA_REQUIRE(v != nullptr, "vec is NULL");
+  int64_t off, len;
+  PA_TRY(seg_range(v, seg, &off, &len));
+  if (len == 0) return PA_OK;
+  PA_HIP(hipSetDevice(v->ctx->device));
+  hipLaunchKernelGGL(k_fill, dim3(grid_for(len, 256)), dim3(256), 0, v->ctx->s[0], v->d + off, len, value);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_vec_copy(pa_vec *dst, const pa_vec *src, int seg) {
+  PA_REQUIRE(dst && src, "bad arguments");
+  PA_REQUIRE(dst->n_own == src->n_own && dst->n_ghost == src->n_ghost, "size mismatch");
+  int64_t off, len;
+  PA_TRY(seg_range(dst, seg, &off, &len));
+  if (len == 0) return PA_OK;
+  PA_HIP(hipSetDevice(dst->ctx->device));
+  PA_HIP(hipMemcpyAsync(dst->d + off, src->d + off, sizeof(double) * len, hipMemcpyDeviceToDevice, dst->ctx->s[0]));
+  return PA_OK;
+}
+
+extern "C" int pa_vec_axpby(pa_vec *y, double a, const pa_vec *x, double b, int seg) {
+  PA_REQUIRE(y && x, "bad arguments");
+  PA_REQUIRE(y->n_own == x->n_own && y->n_ghost == x->n_ghost, "size mismatch");
+  int64_t off, len;
+  PA_TRY(seg_range(y, seg, &off, &len));
+  if (len == 0) return PA_OK;
+  PA_HIP(hipSetDevice(y->ctx->device));
+  hipLaunchKernelGGL(k_axpby, dim3(grid_for(len, 256)), dim3(256), 0, y->ctx->s[0], y->d + off, x->d + off, len, a, b);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_vec_dot(const pa_vec *x, const pa_vec *y, double *host_out) {
+  PA_REQUIRE(x && y, "bad arguments");
+  PA_REQUIRE(x->n_own == y->n_own, "own-size mismatch (%lld vs %lld)", (long long)x->n_own, (long long)y->n_own);
+  pa_ctx *c = x->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  const int nb = grid_for(x->n_own, 256 * 8, c->n_partials);
+  hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, c->s[0], x->d, y->d, x->n_own, c->d_partials);
+  hipLaunchKernelGGL(k_dot_final, dim3(1), dim3(256), 0, c->s[0], c->d_partials, nb, c->d_scalar);
+  PA_HIP(hipGetLastError());
+  if (host_out) {
+    PA_HIP(hipMemcpyAsync(host_out, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, c->s[0]));
+    PA_HIP(hipStreamSynchronize(c->s[0]));
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_vec_dot_result(pa_ctx *c, void **p) {
+  PA_REQUIRE(c && p, "bad arguments");
+  *p = c->d_scalar;
+  return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR blocks
+// ------------------------------------------------------------------------------------------------
+static inline int64_t read_index(const void *a, int bytes, int64_t i) {
+  return bytes == 4 ? (int64_t)((const int32_t *)a)[i] : ((const int64_t *)a)[i];
+}
+
+static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
+                     const int32_t *col0 /*0-based, host*/, const double *nzval, pa_csr **out) {
+  // non-empty rows; compact when most rows are empty (the own_ghost block: only boundary rows)
+  std::vector<int32_t> row_ids;
+  int64_t n_nonempty = 0;
+  for (int64_t r = 0; r < n_rows; ++r) n_nonempty += rp[r + 1] > rp[r];
+  const bool compact = n_rows > 0 && n_nonempty * 2 < n_rows;
+  std::vector<int32_t> crp;
+  if (compact) {
+    row_ids.reserve(n_nonempty);
+    crp.reserve(n_nonempty + 1);
+    crp.push_back(0);
+    for (int64_t r = 0; r < n_rows; ++r)
+      if (rp[r + 1] > rp[r]) {
+        row_ids.push_back((int32_t)r);
+        crp.push_back(rp[r + 1]);
+      }
+  } else {
+    crp.swap(rp);
+  }
+  const int64_t nc = (int64_t)crp.size() - 1;
+  // row split: greedy chunks of consecutive rows with <= PA_SPMV_CHUNK_NNZ entries after 2-alignment
+  std::vector<int32_t> chunk_row;
+  chunk_row.push_back(0);
+  int64_t n_long = 0;
+  const int max_rows = 4096;
+  int64_t r = 0;
+  while (r < nc) {
+    const int64_t base = crp[r] & ~1;
+    int64_t e = r + 1;
+    if ((int64_t)crp[e] - base > PA_SPMV_CHUNK_NNZ) {
+      ++n_long;  // one long row on its own
+    } else {
+      while (e < nc && (int64_t)crp[e + 1] - base <= PA_SPMV_CHUNK_NNZ && e - r < max_rows) ++e;
+    }
+    chunk_row.push_back((int32_t)e);
+    r = e;
+  }
+  pa_csr *A = new pa_csr();
+  A->ctx = c; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
+  A->n_crows = nc; A->n_chunks = (int64_t)chunk_row.size() - 1; A->n_nonempty = n_nonempty; A->n_long = n_long;
+  A->compact = compact;
+  PA_HIP(hipSetDevice(c->device));
+  const size_t pad = 8;
+  PA_HIP(hipMalloc(&A->d_crp, sizeof(int32_t) * (nc + 1)));
+  PA_HIP(hipMalloc(&A->d_col, sizeof(int32_t) * (nnz + pad)));
+  PA_HIP(hipMalloc(&A->d_val, sizeof(double) * (nnz + pad)));
+  PA_HIP(hipMalloc(&A->d_chunk_row, sizeof(int32_t) * chunk_row.size()));
+  PA_HIP(hipMemset(A->d_col + nnz, 0, sizeof(int32_t) * pad));
+  PA_HIP(hipMemset(A->d_val + nnz, 0, sizeof(double) * pad));
+  PA_HIP(hipMemcpy(A->d_crp, crp.data(), sizeof(int32_t) * (nc + 1), hipMemcpyHostToDevice));
+  if (nnz) {
+    PA_HIP(hipMemcpy(A->d_col, col0, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    PA_HIP(hipMemcpy(A->d_val, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
+  }
+  PA_HIP(hipMemcpy(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size(), hipMemcpyHostToDevice));
+  if (compact) {
+    PA_HIP(hipMalloc(&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc)));
+    if (nc) PA_HIP(hipMemcpy(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice));
+  }
+  *out = A;
+  return PA_OK;
+}
+
+extern "C" int pa_csr_create(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr,
+                             const void *colval, int index_bytes, int index_base, const double *nzval, pa_csr **out) {
+  PA_REQUIRE(c && out && rowptr, "bad arguments");
+  PA_REQUIRE(index_bytes == 4 || index_bytes == 8, "index_bytes must be 4 or 8");
+  PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  PA_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "negative size");
+  PA_REQUIRE(nnz < (int64_t)2147483000 && n_rows < (int64_t)2147483000 && n_cols < (int64_t)2147483000,
+             "block too large for Int32 device indices");
+  PA_REQUIRE(nnz == 0 || (colval && nzval), "colval/nzval are NULL");
+  std::vector<int32_t> rp(n_rows + 1);
+  for (int64_t r = 0; r <= n_rows; ++r) rp[r] = (int32_t)(read_index(rowptr, index_bytes, r) - index_base);
+  PA_REQUIRE(rp[0] == 0 && rp[n_rows] == nnz, "rowptr does not span [base, base+nnz]");
+  for (int64_t r = 0; r < n_rows; ++r) PA_REQUIRE(rp[r + 1] >= rp[r], "rowptr not monotone at row %lld", (long long)r);
+  std::vector<int32_t> col(nnz);
+  for (int64_t p = 0; p < nnz; ++p) {
+    const int64_t j = read_index(colval, index_bytes, p) - index_base;
+    PA_REQUIRE(j >= 0 && j < n_cols, "column index out of range at entry %lld", (long long)p);
+    col[p] = (int32_t)j;
+  }
+  return csr_build(c, n_rows, n_cols, nnz, rp, col.data(), nzval, out);
+}
+
+extern "C" int pa_csr_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr,
+                                      const void *rowval, int index_bytes, int index_base, const double *nzval,
+                                      pa_csr **out) {
+  PA_REQUIRE(c && out && colptr, "bad arguments");
+  PA_REQUIRE(index_bytes == 4 || index_bytes == 8, "index_bytes must be 4 or 8");
+  PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  PA_REQUIRE(nnz == 0 || (rowval && nzval), "rowval/nzval are NULL");
+  PA_REQUIRE(nnz < (int64_t)2147483000, "block too large for Int32 device indices");
+  // counting transpose; columns end up ascending inside each row because we sweep columns in order
+  std::vector<int32_t> rp(n_rows + 1, 0);
+  for (int64_t p = 0; p < nnz; ++p) {
+    const int64_t i = read_index(rowval, index_bytes, p) - index_base;
+    PA_REQUIRE(i >= 0 && i < n_rows, "row index out of range at entry %lld", (long long)p);
+    rp[i + 1]++;
+  }
+  for (int64_t r = 0; r < n_rows; ++r) rp[r + 1] += rp[r];
+  std::vector<int32_t> col(nnz), fill(rp.begin(), rp.end() - 1);
+  std::vector<double> val(nnz);
+  for (int64_t j = 0; j < n_cols; ++j) {
+    const int64_t a = read_index(colptr, index_bytes, j) - index_base, e = read_index(colptr, index_bytes, j + 1) - index_base;
+    for (int64_t p = a; p < e; ++p) {
+      const int64_t i = read_index(rowval, index_bytes, p) - index_base;
+      const int32_t q = fill[i]++;
+      col[q] = (int32_t)j;
+      val[q] = nzval[p];
+    }
+  }
+  return csr_build(c, n_rows, n_cols, nnz, rp, col.data(), val.data(), out);
+}
+
+extern "C" int pa_csr_update_values(pa_csr *A, const double *nzval) {
+  PA_REQUIRE(A && (nzval || A->nnz == 0), "bad arguments");
+  if (A->nnz == 0) return PA_OK;
+  PA_HIP(hipSetDevice(A->ctx->device));
+  PA_HIP(hipMemcpyAsync(A->d_val, nzval, sizeof(double) * A->nnz, hipMemcpyHostToDevice, A->ctx->s[0]));
+  PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
+  return PA_OK;
+}
+
+extern "C" int pa_csr_destroy(pa_csr *A) {
+  if (!A) return PA_OK;
+  (void)hipSetDevice(A->ctx->device);
+  (void)hipStreamSynchronize(A->ctx->s[0]);
+  (void)hipFree(A->d_crp);
+  (void)hipFree(A->d_col);
+  (void)hipFree(A->d_val);
+  (void)hipFree(A->d_chunk_row);
+  if (A->d_row_ids) (void)hipFree(A->d_row_ids);
+  delete A;
+  return PA_OK;
+}
+
+extern "C" int pa_csr_info(const pa_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int64_t *n_chunks,
+                           int64_t *n_nonempty, int64_t *n_long) {
+  PA_REQUIRE(A != nullptr, "csr is NULL");
+  if (n_rows) *n_rows = A->n_rows;
+  if (n_cols) *n_cols = A->n_cols;
+  if (nnz) *nnz = A->nnz;
+  if (n_chunks) *n_chunks = A->n_chunks;
+  if (n_nonempty) *n_nonempty = A->n_nonempty;
+  if (n_long) *n_long = A->n_long;
+  return PA_OK;
+}
+
+extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int yseg, double alpha, double beta) {
+  PA_REQUIRE(A && x && y, "bad arguments");
+  int64_t xoff, xlen, yoff, ylen;
+  PA_TRY(seg_range(x, xseg, &xoff, &xlen));
+  PA_TRY(seg_range(y, yseg, &yoff, &ylen));
+  // @boundscheck of spmv! (src/sparse_utils.jl:618-621)
+  PA_REQUIRE(ylen == A->n_rows, "length(b)=%lld != size(A,1)=%lld", (long long)ylen, (long long)A->n_rows);
+  PA_REQUIRE(xlen == A->n_cols, "length(x)=%lld != size(A,2)=%lld", (long long)xlen, (long long)A->n_cols);
+  PA_REQUIRE(x->d != y->d || xseg != yseg, "x and y alias");
+  pa_ctx *c = A->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  double kbeta = beta;
+  if (A->compact && beta != 1.0) {
+    // rows without stored entries still get beta*y (rmul!/fill! of the reference); the kernel then accumulates
+    if (ylen) hipLaunchKernelGGL(k_scale, dim3(grid_for(ylen, 256)), dim3(256), 0, c->s[0], y->d + yoff, ylen, beta);
+    kbeta = 1.0;
+  }
+  if (A->n_chunks > 0) {
+    const int cpx = (int)((A->n_chunks + 7) / 8);
+    hipLaunchKernelGGL(k_spmv_rowsplit, dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], A->d_crp, A->d_col, A->d_val,
+                       x->d + xoff, y->d + yoff, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta);
+  }
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exchange plans
+// ------------------------------------------------------------------------------------------------
+static int upload_i32(const std::vector<int32_t> &h, int32_t **d) {
+  PA_HIP(hipMalloc(d, sizeof(int32_t) * std::max<size_t>(1, h.size())));
+  if (!h.empty()) PA_HIP(hipMemcpy(*d, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice));
+  return PA_OK;
+}
+
+extern "C" int pa_plan_create(pa_ctx *c, int32_t part, int64_t n_local, int32_t n_snd, const int32_t *nbr_snd,
+                              const int32_t *ptrs_snd, const int32_t *idx_snd, int32_t n_rcv, const int32_t *nbr_rcv,
+                              const int32_t *ptrs_rcv, const int32_t *idx_rcv, int index_base, pa_plan **out) {
+  PA_REQUIRE(c && out && ptrs_snd && ptrs_rcv, "bad arguments");
+  PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  PA_REQUIRE(n_snd >= 0 && n_rcv >= 0 && n_local >= 0, "negative size");
+  PA_REQUIRE((n_snd == 0 || nbr_snd) && (n_rcv == 0 || nbr_rcv), "neighbour arrays are NULL");
+  pa_plan *p = new pa_plan();
+  p->ctx = c; p->part = part - index_base; p->n_local = n_local;
+  auto side = [&](pa_plan::side &s, int32_t n, const int32_t *nbr, const int32_t *ptrs, const int32_t *idx) -> int {
+    s.nbr.assign(nbr, nbr + n);
+    for (auto &q : s.nbr) q -= index_base;
+    s.ptrs.resize(n + 1);
+    for (int i = 0; i <= n; ++i) s.ptrs[i] = ptrs[i] - index_base;
+    PA_REQUIRE(s.ptrs[0] == 0, "ptrs[1] must be the index base");
+    for (int i = 0; i < n; ++i) PA_REQUIRE(s.ptrs[i + 1] >= s.ptrs[i], "ptrs not monotone");
+    s.n = s.ptrs[n];
+    PA_REQUIRE(s.n == 0 || idx, "index array is NULL");
+    s.idx.resize(s.n);
+    for (int64_t k = 0; k < s.n; ++k) {
+      s.idx[k] = idx[k] - index_base;
+      PA_REQUIRE(s.idx[k] >= 0 && s.idx[k] < n_local, "local index out of range at position %lld", (long long)k);
+    }
+    return PA_OK;
+  };
+  PA_TRY(side(p->snd, n_snd, nbr_snd, ptrs_snd, idx_snd));
+  PA_TRY(side(p->rcv, n_rcv, nbr_rcv, ptrs_rcv, idx_rcv));
+  PA_HIP(hipSetDevice(c->device));
+  for (pa_plan::side *s : {&p->snd, &p->rcv}) {
+    PA_TRY(upload_i32(s->idx, &s->d_idx));
+    PA_HIP(hipMalloc(&s->d_buf, sizeof(double) * std::max<int64_t>(1, s->n)));
+    PA_HIP(hipMemset(s->d_buf, 0, sizeof(double) * std::max<int64_t>(1, s->n)));
+  }
+  // inverse map of the rcv side for the deterministic assemble!(+): target lid -> its p's, ascending
+  {
+    std::vector<int32_t> order(p->rcv.n);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return p->rcv.idx[a] < p->rcv.idx[b]; });
+    std::vector<int32_t> tgt, tptr;
+    tptr.push_back(0);
+    for (int64_t k = 0; k < p->rcv.n; ++k) {
+      if (k == 0 || p->rcv.idx[order[k]] != p->rcv.idx[order[k - 1]]) {
+        if (k) tptr.push_back((int32_t)k);
+        tgt.push_back(p->rcv.idx[order[k]]);
+      }
+    }
+    if (p->rcv.n) tptr.push_back((int32_t)p->rcv.n);
+    p->n_tgt = (int64_t)tgt.size();
+    PA_TRY(upload_i32(tgt, &p->d_tgt));
+    PA_TRY(upload_i32(tptr, &p->d_tptr));
+    PA_TRY(upload_i32(order, &p->d_tp));
+  }
+  PA_HIP(hipEventCreateWithFlags(&p->ev_packed, hipEventDisableTiming));
+  PA_HIP(hipEventCreateWithFlags(&p->ev_arrived, hipEventDisableTiming));
+  *out = p;
+  return PA_OK;
+}
+
+extern "C" int pa_plan_destroy(pa_plan *p) {
+  if (!p) return PA_OK;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->s[0]);
+  (void)hipStreamSynchronize(p->ctx->s[1]);
+  for (pa_plan::side *s : {&p->snd, &p->rcv}) {
+    (void)hipFree(s->d_idx);
+    (void)hipFree(s->d_buf);
+  }
+  (void)hipFree(p->d_tgt);
+  (void)hipFree(p->d_tptr);
+  (void)hipFree(p->d_tp);
+  (void)hipEventDestroy(p->ev_packed);
+  (void)hipEventDestroy(p->ev_arrived);
+  delete p;
+  return PA_OK;
+}
+
+// Roles of the two sides per mode (reverse(cache), src/p_vector.jl:427-437,748):
+//   PA_ASSEMBLE  : pack from snd side (ghost lids), receive into rcv side (own lids)
+//   PA_CONSISTENT: pack from rcv side (own lids),   receive into snd side (ghost lids)
+static inline pa_plan::side &out_side(pa_plan *p, int mode) { return mode == PA_ASSEMBLE ? p->snd : p->rcv; }
+static inline pa_plan::side &in_side(pa_plan *p, int mode) { return mode == PA_ASSEMBLE ? p->rcv : p->snd; }
+
+extern "C" int pa_plan_buffers(pa_plan *p, int mode, void **snd, int64_t *snd_len, void **rcv, int64_t *rcv_len) {
+  PA_REQUIRE(p && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  if (snd) *snd = out_side(p, mode).d_buf;
+  if (snd_len) *snd_len = out_side(p, mode).n;
+  if (rcv) *rcv = in_side(p, mode).d_buf;
+  if (rcv_len) *rcv_len = in_side(p, mode).n;
+  return PA_OK;
+}
+
+extern "C" int pa_exchange_pack(pa_plan *p, const pa_vec *v, int mode) {
+  PA_REQUIRE(p && v && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector has %lld local values, plan expects %lld",
+             (long long)(v->n_own + v->n_ghost), (long long)p->n_local);
+  PA_REQUIRE(p->phase == 0, "exchange already in flight on this plan (missing pa_exchange_finish)");
+  pa_ctx *c = p->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  // the comm stream must see everything the compute stream wrote into v so far
+  PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
+  PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+  pa_plan::side &o = out_side(p, mode);
+  if (o.n) hipLaunchKernelGGL(k_pack, dim3((o.n + 255) / 256), dim3(256), 0, c->s[1], o.d_buf, v->d, o.d_idx, (int)o.n);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipEventRecord(p->ev_packed, c->s[1]));
+  p->phase = 1;
+  p->mode = mode;
+  return PA_OK;
+}
+
+extern "C" int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mode) {
+  PA_REQUIRE(plans && n_parts > 0 && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  for (int r = 0; r < n_parts; ++r) {
+    PA_REQUIRE(plans[r] && plans[r]->part == r, "plans[%d] is not the plan of part %d", r, r);
+    PA_REQUIRE(plans[r]->phase == 1 && plans[r]->mode == mode, "part %d: pa_exchange_pack(mode) must come first", r);
+  }
+  // src/primitives.jl:1020-1042: rcv[r].data[ptrs_rcv[i]..] = snd[s].data[ptrs_snd[j]..], snd_ids[s][j] == r
+  for (int r = 0; r < n_parts; ++r) {
+    pa_plan *pr = plans[r];
+    pa_plan::side &in = in_side(pr, mode);
+    PA_HIP(hipSetDevice(pr->ctx->device));
+    for (size_t i = 0; i < in.nbr.size(); ++i) {
+      const int s = in.nbr[i];
+      PA_REQUIRE(s >= 0 && s < n_parts, "part %d: neighbour %d out of range", r, s);
+      pa_plan *ps = plans[s];
+      pa_plan::side &o = out_side(ps, mode);
+      auto it = std::find(o.nbr.begin(), o.nbr.end(), r);
+      PA_REQUIRE(it != o.nbr.end(), "inconsistent ExchangeGraph: part %d receives from %d, which does not send to it", r, s);
+      const size_t j = it - o.nbr.begin();
+      const int64_t len = in.ptrs[i + 1] - in.ptrs[i];
+      PA_REQUIRE(len == o.ptrs[j + 1] - o.ptrs[j], "slice length mismatch between parts %d and %d", s, r);
+      PA_HIP(hipStreamWaitEvent(pr->ctx->s[1], ps->ev_packed, 0));
+      if (len)
+        PA_HIP(hipMemcpyAsync(in.d_buf + in.ptrs[i], o.d_buf + o.ptrs[j], sizeof(double) * len, hipMemcpyDeviceToDevice,
+                              pr->ctx->s[1]));
+    }
+    PA_HIP(hipEventRecord(pr->ev_arrived, pr->ctx->s[1]));
+    pr->phase = 2;
+  }
+  return PA_OK;
+}
+
+int pa_plan_mark_arrived(pa_plan *p) {
+  PA_HIP(hipEventRecord(p->ev_arrived, p->ctx->s[1]));
+  p->phase = 2;
+  return PA_OK;
+}
+
+extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
+  PA_REQUIRE(p && v && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  PA_REQUIRE(p->phase >= 1 && p->mode == mode, "pa_exchange_finish without a matching pa_exchange_pack");
+  PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector/plan size mismatch");
+  pa_ctx *c = p->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  if (p->phase == 1) {  // caller-driven transport on the comm stream: everything queued there so far counts
+    PA_HIP(hipEventRecord(p->ev_arrived, c->s[1]));
+  }
+  PA_HIP(hipStreamWaitEvent(c->s[0], p->ev_arrived, 0));  // wait(t)
+  pa_plan::side &in = in_side(p, mode);
+  if (mode == PA_CONSISTENT) {
+    if (in.n) hipLaunchKernelGGL(k_unpack_insert, dim3((in.n + 255) / 256), dim3(256), 0, c->s[0], v->d, in.d_buf, in.d_idx, (int)in.n);
+  } else {
+    if (p->n_tgt)
+      hipLaunchKernelGGL(k_unpack_add, dim3((p->n_tgt + 255) / 256), dim3(256), 0, c->s[0], v->d, in.d_buf, p->d_tgt, p->d_tptr,
+                         p->d_tp, (int)p->n_tgt);
+    // fill!(ghost_values(a),0): the snd side lists every ghost local id exactly once
+    if (p->snd.n) hipLaunchKernelGGL(k_zero_at, dim3((p->snd.n + 255) / 256), dim3(256), 0, c->s[0], v->d, p->snd.d_idx, (int)p->snd.n);
+  }
+  PA_HIP(hipGetLastError());
+  // the next pack (on the comm stream) must not overwrite buffers this unpack still reads
+  PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
+  PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+  p->phase = 0;
+  return PA_OK;
+}

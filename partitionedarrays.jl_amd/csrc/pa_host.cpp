@@ -1,0 +1,246 @@
+// pa_host.cpp -- native host-side set-up helpers of libpa_hip.so (no device code).
+//
+// The reference does its set-up in compiled Julia loops; these are their native twins so that a
+// 256^3-per-part problem (4.5e8 stored entries) is set up in seconds.  They run once, on the host,
+// and produce exactly the arrays the reference would hand to the device path (1-based ids).
+// Each function cites the reference loop it restates (paths relative to /root/reference).
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "pa_internal.h"
+
+// HPCG/src/sparse_matrix.jl:27-80 build_matrix
+extern "C" int pa_host_hpcg_build_matrix(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz,
+                                         int64_t gix0, int64_t giy0, int64_t giz0, int64_t *I, int64_t *J, double *V,
+                                         double *b, int64_t *row_b, int64_t *nnz_out) {
+  PA_REQUIRE(nx > 0 && ny > 0 && nz > 0, "row_count must be > 0");  // @assert row_count > 0 (:30)
+  PA_REQUIRE(nnz_out != nullptr, "nnz_out is NULL");
+  const bool fill = I && J && V;
+  int64_t k = 0;
+  for (int64_t iz = 1; iz <= nz; ++iz) {
+    const int64_t giz = giz0 + iz - 1;
+    for (int64_t iy = 1; iy <= ny; ++iy) {
+      const int64_t giy = giy0 + iy - 1;
+      for (int64_t ix = 1; ix <= nx; ++ix) {
+        const int64_t gix = gix0 + ix - 1;
+        const int64_t cur_row = (iz - 1) * nx * ny + (iy - 1) * nx + (ix - 1);  // 0-based slot
+        const int64_t cur_g = (giz - 1) * gnx * gny + (giy - 1) * gnx + (gix - 1) + 1;
+        int64_t cnt = 0;
+        for (int sz = -1; sz <= 1; ++sz) {
+          if (!(giz + sz > 0 && giz + sz < gnz + 1)) continue;
+          for (int sy = -1; sy <= 1; ++sy) {
+            if (!(giy + sy > 0 && giy + sy < gny + 1)) continue;
+            for (int sx = -1; sx <= 1; ++sx) {
+              if (!(gix + sx > 0 && gix + sx < gnx + 1)) continue;
+              if (fill) {
+                const int64_t col = cur_g + sz * gnx * gny + sy * gnx + sx;
+                V[k] = (col == cur_g) ? 26.0 : -1.0;
+                I[k] = cur_g;
+                J[k] = col;
+              }
+              ++k;
+              ++cnt;
+            }
+          }
+        }
+        if (row_b) row_b[cur_row] = cur_g;
+        if (b) b[cur_row] = 27.0 - (double)cnt;
+      }
+    }
+  }
+  *nnz_out = k;
+  return PA_OK;
+}
+
+// src/gallery.jl:40-84 `setup`: diag first (alpha*2D), then d = 1..D, i in (-1,+1): -alpha
+extern "C" int pa_host_laplacian_fdm(int32_t D, const int64_t *n, const int64_t *lo, const int64_t *hi, int64_t *I,
+                                     int64_t *J, double *V, int64_t *nnz_out) {
+  PA_REQUIRE(D >= 1 && D <= 3 && n && lo && hi && nnz_out, "bad arguments");
+  double alpha = 1.0;
+  for (int d = 0; d < D; ++d) alpha *= (double)(n[d] + 1);
+  int64_t stride[3] = {1, 1, 1}, l[3] = {1, 1, 1}, h[3] = {1, 1, 1}, nn[3] = {1, 1, 1};
+  for (int d = 0; d < D; ++d) { l[d] = lo[d]; h[d] = hi[d]; nn[d] = n[d]; }
+  for (int d = 1; d < D; ++d) stride[d] = stride[d - 1] * n[d - 1];
+  const bool fill = I && J && V;
+  int64_t t = 0;
+  int64_t c[3];
+  for (c[2] = l[2]; c[2] <= h[2]; ++c[2])
+    for (c[1] = l[1]; c[1] <= h[1]; ++c[1])
+      for (c[0] = l[0]; c[0] <= h[0]; ++c[0]) {  // CartesianIndices(ranges): first index fastest
+        const int64_t node_i = (c[0] - 1) + (c[1] - 1) * (D > 1 ? stride[1] : 0) + (c[2] - 1) * (D > 2 ? stride[2] : 0) + 1;
+        if (fill) { I[t] = node_i; J[t] = node_i; V[t] = alpha * 2 * D; }
+        ++t;
+        for (int d = 0; d < D; ++d)
+          for (int i = -1; i <= 1; i += 2) {
+            const int64_t cj = c[d] + i;
+            if (cj < 1 || cj > nn[d]) continue;
+            if (fill) { I[t] = node_i; J[t] = node_i + i * stride[d]; V[t] = -alpha; }
+            ++t;
+          }
+      }
+  *nnz_out = t;
+  return PA_OK;
+}
+
+// src/p_range.jl:1502-1513,1609-1619: owner = LinearIndices(np)[searchsortedlast(start_d, c_d) ...]
+extern "C" int pa_host_find_owner_block(int32_t D, const int64_t *n, const int32_t *np, const int64_t *const *starts,
+                                        const int64_t *gids, int64_t count, int32_t *owners) {
+  PA_REQUIRE(D >= 1 && D <= 8 && n && np && starts && (count == 0 || (gids && owners)), "bad arguments");
+  for (int64_t k = 0; k < count; ++k) {
+    int64_t r = gids[k] - 1;
+    int64_t owner = 0, stride = 1;
+    for (int d = 0; d < D; ++d) {
+      const int64_t c = r % n[d] + 1;
+      r /= n[d];
+      const int64_t *s = starts[d];
+      const int64_t j = (std::upper_bound(s, s + np[d] + 1, c) - s);  // searchsortedlast, 1-based
+      owner += (j - 1) * stride;
+      stride *= np[d];
+    }
+    owners[k] = (int32_t)(owner + 1);
+  }
+  return PA_OK;
+}
+
+// src/p_range.jl:205-241 filter_ghost
+extern "C" int pa_host_filter_ghost(int32_t part, const int64_t *gids, const int32_t *owners, int64_t count,
+                                    const int64_t *known, int64_t n_known, int64_t *out_gids, int32_t *out_owners,
+                                    int64_t *n_new) {
+  PA_REQUIRE((count == 0 || (gids && owners)) && n_new, "bad arguments");
+  std::unordered_set<int64_t> seen;
+  if (known) seen.insert(known, known + n_known);
+  int64_t m = 0;
+  for (int64_t k = 0; k < count; ++k) {
+    const int64_t g = gids[k];
+    if (g < 1) continue;
+    if (owners[k] == part) continue;
+    if (seen.insert(g).second) {
+      if (out_gids) out_gids[m] = g;
+      if (out_owners) out_owners[m] = owners[k];
+      ++m;
+    }
+  }
+  *n_new = m;
+  return PA_OK;
+}
+
+// global_to_local of a block partition with appended ghosts: own box by arithmetic
+// (BlockPartitionGlobalToOwn, src/p_range.jl:1483-1500) else ghost lookup (+n_own), else 0.
+extern "C" int pa_host_global_to_local_block(int32_t D, const int64_t *n, const int64_t *lo, const int64_t *hi,
+                                             const int64_t *ghost_gids, int64_t n_ghost, const int64_t *gids, int64_t count,
+                                             int32_t *lids) {
+  PA_REQUIRE(D >= 1 && D <= 8 && n && lo && hi && (count == 0 || (gids && lids)), "bad arguments");
+  int64_t n_own = 1;
+  for (int d = 0; d < D; ++d) n_own *= (hi[d] - lo[d] + 1);
+  std::unordered_map<int64_t, int32_t> g2g;
+  g2g.reserve((size_t)n_ghost * 2 + 1);
+  for (int64_t k = 0; k < n_ghost; ++k) g2g.emplace(ghost_gids[k], (int32_t)(k + 1));
+  for (int64_t k = 0; k < count; ++k) {
+    const int64_t g = gids[k];
+    if (g < 1) { lids[k] = (int32_t)g; continue; }  // map_x_to_y! leaves ids < 1 untouched (src/p_range.jl:300-309)
+    int64_t r = g - 1, own = 0, stride = 1;
+    bool inside = true;
+    for (int d = 0; d < D; ++d) {
+      const int64_t c = r % n[d] + 1;
+      r /= n[d];
+      if (c < lo[d] || c > hi[d]) { inside = false; break; }
+      own += (c - lo[d]) * stride;
+      stride *= (hi[d] - lo[d] + 1);
+    }
+    if (inside) { lids[k] = (int32_t)(own + 1); continue; }
+    auto it = g2g.find(g);
+    lids[k] = it == g2g.end() ? 0 : (int32_t)(it->second + n_own);
+  }
+  return PA_OK;
+}
+
+// compresscoo(SparseMatrixCSR{1,Float64,Int32},...;combine=+,skip): src/sparse_utils.jl:313-350.
+// colval/nzval must have room for `count` entries; *nnz_out is the number actually stored.
+extern "C" int pa_host_compresscoo_csr(const int32_t *I, const int32_t *J, const double *V, int64_t count, int64_t m,
+                                       int64_t n, int skip, int32_t *rowptr, int32_t *colval, double *nzval,
+                                       int64_t *nnz_out) {
+  PA_REQUIRE(rowptr && nnz_out && m >= 0 && n >= 0 && (count == 0 || (I && J && V && colval && nzval)), "bad arguments");
+  if (skip && m * n == 0) count = 0;  // :334-337
+  // counting sort by row (stable), ids < 1 rewritten to (1,1,0.0) when skip (FilteredCooVector :370-390)
+  std::vector<int64_t> start(m + 2, 0);
+  auto row_of = [&](int64_t k) -> int64_t { return (skip && (I[k] < 1 || J[k] < 1)) ? 1 : I[k]; };
+  for (int64_t k = 0; k < count; ++k) {
+    const int64_t r = row_of(k);
+    PA_REQUIRE(r >= 1 && r <= m, "row id %lld outside 1:%lld at entry %lld", (long long)r, (long long)m, (long long)k);
+    start[r + 1]++;
+  }
+  for (int64_t r = 1; r <= m + 1; ++r) start[r] += start[r - 1];   // start[r] = first slot of row r (1-based rows)
+  std::vector<int32_t> cj(count);
+  std::vector<double> cv(count);
+  {
+    std::vector<int64_t> pos(start.begin(), start.end());
+    for (int64_t k = 0; k < count; ++k) {
+      const bool bad = skip && (I[k] < 1 || J[k] < 1);
+      const int64_t r = bad ? 1 : I[k];
+      const int64_t q = pos[r]++;
+      cj[q] = bad ? 1 : J[k];
+      cv[q] = bad ? 0.0 : V[k];
+      PA_REQUIRE(cj[q] >= 1 && cj[q] <= n, "column id %d outside 1:%lld at entry %lld", cj[q], (long long)n, (long long)k);
+    }
+  }
+  // per row: stable sort by column, combine duplicates with + in input order
+  int64_t out = 0;
+  rowptr[0] = 1;
+  std::vector<std::pair<int32_t, double>> tmp;
+  for (int64_t r = 1; r <= m; ++r) {
+    const int64_t a = start[r], e = start[r + 1];
+    bool sorted = true;
+    for (int64_t q = a + 1; q < e; ++q)
+      if (cj[q] <= cj[q - 1]) { sorted = false; break; }
+    if (sorted) {
+      for (int64_t q = a; q < e; ++q) { colval[out] = cj[q]; nzval[out] = cv[q]; ++out; }
+    } else {
+      tmp.clear();
+      for (int64_t q = a; q < e; ++q) tmp.emplace_back(cj[q], cv[q]);
+      std::stable_sort(tmp.begin(), tmp.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+      for (size_t q = 0; q < tmp.size(); ++q) {
+        if (q > 0 && tmp[q].first == tmp[q - 1].first) {
+          nzval[out - 1] = nzval[out - 1] + tmp[q].second;
+        } else {
+          colval[out] = tmp[q].first; nzval[out] = tmp[q].second; ++out;
+        }
+      }
+    }
+    rowptr[r] = (int32_t)(out + 1);
+  }
+  *nnz_out = out;
+  return PA_OK;
+}
+
+// split_format_locally (src/p_sparse_matrix.jl:823-899), own-row branches, identity permutations:
+// an entry (i,j) of the local CSR goes to own_own if j <= n_own_cols else to own_ghost (column j-n_own_cols).
+extern "C" int pa_host_split_csr(int64_t n_own_rows, int64_t n_own_cols, int64_t n_ghost_cols, const int32_t *rowptr,
+                                 const int32_t *colval, const double *nzval, int32_t *oo_rowptr, int32_t *oo_colval,
+                                 double *oo_nzval, int32_t *oh_rowptr, int32_t *oh_colval, double *oh_nzval,
+                                 int64_t *nnz_oo, int64_t *nnz_oh) {
+  PA_REQUIRE(rowptr && nnz_oo && nnz_oh && n_own_rows >= 0, "bad arguments");
+  const bool fill = oo_rowptr && oh_rowptr;
+  int64_t a = 0, b = 0;
+  if (fill) { oo_rowptr[0] = 1; oh_rowptr[0] = 1; }
+  for (int64_t r = 0; r < n_own_rows; ++r) {
+    for (int64_t p = rowptr[r] - 1; p < rowptr[r + 1] - 1; ++p) {
+      const int32_t j = colval[p];
+      if (j <= n_own_cols) {
+        if (fill && oo_colval) { oo_colval[a] = j; oo_nzval[a] = nzval[p]; }
+        ++a;
+      } else {
+        PA_REQUIRE(j - n_own_cols <= n_ghost_cols, "column %d beyond the ghost columns", j);
+        if (fill && oh_colval) { oh_colval[b] = (int32_t)(j - n_own_cols); oh_nzval[b] = nzval[p]; }
+        ++b;
+      }
+    }
+    if (fill) { oo_rowptr[r + 1] = (int32_t)(a + 1); oh_rowptr[r + 1] = (int32_t)(b + 1); }
+  }
+  *nnz_oo = a;
+  *nnz_oh = b;
+  return PA_OK;
+}

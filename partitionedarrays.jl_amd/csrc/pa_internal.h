@@ -1,0 +1,96 @@
+// pa_internal.h -- private definitions shared by the translation units of libpa_hip.so.
+#ifndef PA_INTERNAL_H
+#define PA_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <vector>
+
+#include "pa_hip.h"
+
+void pa_set_err(const char *fmt, ...);
+
+#define PA_HIP(call)                                                                          \
+  do {                                                                                        \
+    hipError_t pa_e_ = (call);                                                                \
+    if (pa_e_ != hipSuccess) {                                                                \
+      pa_set_err("%s failed: %s (%s:%d)", #call, hipGetErrorString(pa_e_), __FILE__, __LINE__); \
+      return PA_ERR_HIP;                                                                      \
+    }                                                                                         \
+  } while (0)
+
+#define PA_REQUIRE(cond, ...)     \
+  do {                            \
+    if (!(cond)) {                \
+      pa_set_err(__VA_ARGS__);    \
+      return PA_ERR_ARG;          \
+    }                             \
+  } while (0)
+
+#define PA_TRY(call)              \
+  do {                            \
+    int pa_s_ = (call);           \
+    if (pa_s_ != PA_OK) return pa_s_; \
+  } while (0)
+
+struct pa_ctx {
+  int device = 0;
+  hipStream_t s[2] = {nullptr, nullptr};  // [0] compute, [1] comm
+  hipEvent_t ev_compute = nullptr;
+  int cus = 0, xcds = 8;
+  size_t hbm = 0;
+  char name[128] = {0};
+  double *d_partials = nullptr;
+  int n_partials = 0;
+  double *d_scalar = nullptr;
+};
+
+struct pa_event {
+  pa_ctx *ctx = nullptr;
+  hipEvent_t ev = nullptr;
+};
+
+struct pa_vec {
+  pa_ctx *ctx = nullptr;
+  double *d = nullptr;
+  int64_t n_own = 0, n_ghost = 0;
+  bool owned = true;
+};
+
+struct pa_csr {
+  pa_ctx *ctx = nullptr;
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  int64_t n_crows = 0, n_chunks = 0, n_nonempty = 0, n_long = 0;
+  bool compact = false;
+  int32_t *d_crp = nullptr;        // (compacted) row pointer, 0-based
+  int32_t *d_col = nullptr;        // 0-based columns, padded
+  double *d_val = nullptr;         // padded
+  int32_t *d_chunk_row = nullptr;  // n_chunks+1 row boundaries of the row split
+  int32_t *d_row_ids = nullptr;    // compacted row -> row, or NULL
+};
+
+struct pa_plan {
+  struct side {
+    std::vector<int32_t> nbr;   // 0-based part ids
+    std::vector<int32_t> ptrs;  // 0-based offsets, n+1
+    std::vector<int32_t> idx;   // 0-based local ids
+    int64_t n = 0;
+    int32_t *d_idx = nullptr;
+    double *d_buf = nullptr;    // JaggedArray.data of buffer_snd (snd side) / buffer_rcv (rcv side)
+  };
+  pa_ctx *ctx = nullptr;
+  int32_t part = 0;  // 0-based
+  int64_t n_local = 0;
+  side snd, rcv;     // assembly orientation (src/p_vector.jl:418-426)
+  int64_t n_tgt = 0;
+  int32_t *d_tgt = nullptr, *d_tptr = nullptr, *d_tp = nullptr;
+  hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
+  int phase = 0;     // 0 idle, 1 packed, 2 arrived
+  int mode = 0;
+};
+
+int pa_plan_mark_arrived(pa_plan *p);
+
+#endif

@@ -1,0 +1,158 @@
+// pa_rccl.cpp -- RCCL transport of the ghost exchange: one process per part / GPU, point-to-point
+// over xGMI.  Replaces the MPI backend's exchange_impl! (src/mpi_array.jl:575-614: Irecv!/Isend per
+// neighbour, Waitall at wait(t)) with ONE ncclGroup of ncclRecv/ncclSend per neighbour on the comm
+// stream; "Waitall" is the event the compute stream waits on in pa_exchange_finish.
+//
+// librccl is dlopen'ed at first use: inside a PyTorch process that resolves to the librccl torch
+// already loaded (same SONAME, librccl.so.1), in a Julia process to /opt/rocm/lib/librccl.so.1.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "pa_internal.h"
+
+namespace {
+struct Api {
+  void *h = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  bool ok = false;
+};
+Api g_api;
+std::once_flag g_once;
+
+void load_api() {
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char *n : names) {
+    g_api.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (g_api.h) break;
+  }
+  if (!g_api.h) return;
+#define PA_SYM(field, sym) g_api.field = (decltype(g_api.field))dlsym(g_api.h, #sym)
+  PA_SYM(GetUniqueId, ncclGetUniqueId);
+  PA_SYM(CommInitRank, ncclCommInitRank);
+  PA_SYM(CommDestroy, ncclCommDestroy);
+  PA_SYM(GroupStart, ncclGroupStart);
+  PA_SYM(GroupEnd, ncclGroupEnd);
+  PA_SYM(Send, ncclSend);
+  PA_SYM(Recv, ncclRecv);
+  PA_SYM(AllReduce, ncclAllReduce);
+  PA_SYM(GetErrorString, ncclGetErrorString);
+#undef PA_SYM
+  g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.GroupStart && g_api.GroupEnd &&
+             g_api.Send && g_api.Recv && g_api.AllReduce && g_api.GetErrorString;
+}
+
+int need_api() {
+  std::call_once(g_once, load_api);
+  if (!g_api.ok) {
+    pa_set_err("librccl could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+    return PA_ERR_RCCL;
+  }
+  return PA_OK;
+}
+}  // namespace
+
+#define PA_NCCL(call)                                                                              \
+  do {                                                                                             \
+    ncclResult_t pa_r_ = (call);                                                                   \
+    if (pa_r_ != ncclSuccess) {                                                                    \
+      pa_set_err("%s failed: %s (%s:%d)", #call, g_api.GetErrorString(pa_r_), __FILE__, __LINE__); \
+      return PA_ERR_RCCL;                                                                          \
+    }                                                                                              \
+  } while (0)
+
+struct pa_comm {
+  pa_ctx *ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+  double *d_token = nullptr;
+};
+
+static_assert(sizeof(ncclUniqueId) == PA_UNIQUE_ID_BYTES, "ncclUniqueId size");
+
+extern "C" int pa_comm_unique_id(char id[PA_UNIQUE_ID_BYTES]) {
+  PA_REQUIRE(id != nullptr, "id is NULL");
+  PA_TRY(need_api());
+  ncclUniqueId u;
+  PA_NCCL(g_api.GetUniqueId(&u));
+  memcpy(id, &u, sizeof u);
+  return PA_OK;
+}
+
+extern "C" int pa_comm_create(pa_ctx *c, const char id[PA_UNIQUE_ID_BYTES], int rank, int nranks, pa_comm **out) {
+  PA_REQUIRE(c && id && out, "bad arguments");
+  PA_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d outside [0,%d)", rank, nranks);
+  PA_TRY(need_api());
+  PA_HIP(hipSetDevice(c->device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  pa_comm *m = new pa_comm();
+  m->ctx = c; m->rank = rank; m->nranks = nranks;
+  PA_NCCL(g_api.CommInitRank(&m->comm, nranks, u, rank));
+  PA_HIP(hipMalloc(&m->d_token, sizeof(double)));
+  PA_HIP(hipMemset(m->d_token, 0, sizeof(double)));
+  *out = m;
+  return PA_OK;
+}
+
+extern "C" int pa_comm_destroy(pa_comm *m) {
+  if (!m) return PA_OK;
+  if (need_api() != PA_OK) return PA_ERR_RCCL;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->s[0]);
+  (void)hipStreamSynchronize(m->ctx->s[1]);
+  (void)hipFree(m->d_token);
+  g_api.CommDestroy(m->comm);
+  delete m;
+  return PA_OK;
+}
+
+extern "C" int pa_comm_allreduce_sum(pa_comm *m, void *ptr, int64_t count, int which) {
+  PA_REQUIRE(m && ptr && count >= 0 && (which == 0 || which == 1), "bad arguments");
+  PA_TRY(need_api());
+  PA_HIP(hipSetDevice(m->ctx->device));
+  PA_NCCL(g_api.AllReduce(ptr, ptr, (size_t)count, ncclDouble, ncclSum, m->comm, m->ctx->s[which]));
+  return PA_OK;
+}
+
+extern "C" int pa_comm_barrier(pa_comm *m) {
+  PA_REQUIRE(m != nullptr, "comm is NULL");
+  PA_TRY(pa_comm_allreduce_sum(m, m->d_token, 1, PA_STREAM_COMM));
+  PA_HIP(hipStreamSynchronize(m->ctx->s[1]));
+  return PA_OK;
+}
+
+extern "C" int pa_exchange_rccl(pa_plan *p, pa_comm *m, int mode) {
+  PA_REQUIRE(p && m && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  PA_REQUIRE(p->phase == 1 && p->mode == mode, "pa_exchange_pack(mode) must come first");
+  PA_REQUIRE(p->ctx == m->ctx, "plan and communicator live on different contexts");
+  PA_REQUIRE(p->part == m->rank, "plan of part %d driven by rank %d", p->part, m->rank);
+  PA_TRY(need_api());
+  pa_plan::side &o = (mode == PA_ASSEMBLE) ? p->snd : p->rcv;
+  pa_plan::side &in = (mode == PA_ASSEMBLE) ? p->rcv : p->snd;
+  hipStream_t st = p->ctx->s[1];
+  PA_HIP(hipSetDevice(p->ctx->device));
+  for (int32_t q : o.nbr) PA_REQUIRE(q >= 0 && q < m->nranks, "bad send neighbour %d", q);
+  for (int32_t q : in.nbr) PA_REQUIRE(q >= 0 && q < m->nranks, "bad receive neighbour %d", q);
+  PA_NCCL(g_api.GroupStart());
+  for (size_t i = 0; i < in.nbr.size(); ++i) {
+    const size_t len = (size_t)(in.ptrs[i + 1] - in.ptrs[i]);
+    if (len) PA_NCCL(g_api.Recv(in.d_buf + in.ptrs[i], len, ncclDouble, in.nbr[i], m->comm, st));
+  }
+  for (size_t j = 0; j < o.nbr.size(); ++j) {
+    const size_t len = (size_t)(o.ptrs[j + 1] - o.ptrs[j]);
+    if (len) PA_NCCL(g_api.Send(o.d_buf + o.ptrs[j], len, ncclDouble, o.nbr[j], m->comm, st));
+  }
+  PA_NCCL(g_api.GroupEnd());
+  return pa_plan_mark_arrived(p);
+}

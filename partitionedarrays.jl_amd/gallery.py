@@ -1,0 +1,90 @@
+"""Workload generators (host side, native loops): the gallery Laplacian and the HPCG 27-point problem.
+
+Mirrors /root/reference/src/gallery.jl:12-86 (laplacian_fdm) and HPCG/src/sparse_matrix.jl:27-122
+(build_matrix / build_p_matrix), HPCG/src/compute_optimal_xyz.jl:8-64.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .primitives import pmap, tuple_of_arrays
+from .p_range import uniform_partition, _cartesian
+from .p_sparse_matrix import psparse_from_coo
+from .p_vector import pvector
+
+I64, F64 = np.int64, np.float64
+
+
+def laplacian_fdm(nodes_per_dir, parts_per_dir, parts):
+    """laplacian_fdm(nodes_per_dir,parts_per_dir,parts) -> I,J,V,row_partition,col_partition (src/gallery.jl:12-86)."""
+    n = np.array(nodes_per_dir, dtype=I64)
+    D = len(n)
+    node_partition = uniform_partition(parts, tuple(parts_per_dir), tuple(nodes_per_dir))
+
+    def setup(nodes):
+        lo = np.array([r[0] for r in nodes.ranges], dtype=I64)
+        hi = np.array([r[1] for r in nodes.ranges], dtype=I64)
+        nnz = C.c_int64()
+        L.call("pa_host_laplacian_fdm", D, L.ptr(n), L.ptr(lo), L.ptr(hi), None, None, None, C.byref(nnz))
+        I, J, V = np.zeros(nnz.value, I64), np.zeros(nnz.value, I64), np.zeros(nnz.value, F64)
+        L.call("pa_host_laplacian_fdm", D, L.ptr(n), L.ptr(lo), L.ptr(hi), L.ptr(I), L.ptr(J), L.ptr(V), C.byref(nnz))
+        return I, J, V
+
+    I, J, V = tuple_of_arrays(pmap(setup, node_partition))
+    return I, J, V, node_partition, node_partition
+
+
+def build_matrix(nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0):
+    """HPCG build_matrix (HPCG/src/sparse_matrix.jl:27-80) -> I, J, V, b, row_b."""
+    nnz = C.c_int64()
+    args = [int(x) for x in (nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0)]
+    L.call("pa_host_hpcg_build_matrix", *args, None, None, None, None, None, C.byref(nnz))
+    I, J, V = np.zeros(nnz.value, I64), np.zeros(nnz.value, I64), np.zeros(nnz.value, F64)
+    b, row_b = np.zeros(nx * ny * nz, F64), np.zeros(nx * ny * nz, I64)
+    L.call("pa_host_hpcg_build_matrix", *args, L.ptr(I), L.ptr(J), L.ptr(V), L.ptr(b), L.ptr(row_b), C.byref(nnz))
+    return I, J, V, b, row_b
+
+
+def compute_optimal_shape_XYZ(np_):
+    """HPCG/src/compute_optimal_xyz.jl:8-64 for np with one or two distinct prime factors / powers of a prime."""
+    if np_ == 1:
+        return 1, 1, 1
+    f, m, d = {}, np_, 2
+    while m > 1:
+        while m % d == 0:
+            f[d] = f.get(d, 0) + 1
+            m //= d
+        d += 1
+    primes = sorted(f)
+    x = primes[0]
+    if len(primes) == 1:
+        e = f[x]
+        z = x ** (e // 3)
+        y = x ** (e // 3 + (1 if e % 3 >= 2 else 0))
+        x = x ** (e // 3 + (1 if e % 3 >= 1 else 0))
+        return x, y, z
+    y = primes[1]
+    if len(primes) == 2 and f[x] == 1 and f[y] == 1:
+        return x, y, 1
+    if len(primes) == 2 and f[x] + f[y] == 3:
+        return x, y, (x if f[x] == 2 else y)
+    if len(primes) == 3 and all(f[p] == 1 for p in primes):
+        return x, y, primes[2]
+    raise NotImplementedError("compute_optimal_shape_XYZ: general 3-subset search not needed for 1..8 parts")
+
+
+def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=False):
+    """HPCG build_p_matrix (HPCG/src/sparse_matrix.jl:105-122) -> A (device PSparseMatrix), b (PVector)."""
+    row_partition = uniform_partition(ranks, (npx, npy, npz), (gnx, gny, gnz))
+
+    def gen(my_rows):
+        g0 = int(my_rows.ranges[0][0]), int(my_rows.ranges[1][0]), int(my_rows.ranges[2][0])   # Tuple(cis[first(my_rows)])
+        return build_matrix(nx, ny, nz, gnx, gny, gnz, *g0)
+
+    I, J, V, b, I_b = tuple_of_arrays(pmap(gen, row_partition))
+    A = psparse_from_coo(I, J, V, row_partition, keep_host=keep_host)
+    pb = pvector(I_b, b, A.col_partition)        # row_partition = partition(axes(A,2)) (:119)
+    return A, pb

@@ -1,0 +1,228 @@
+"""PSparseMatrix on the device and the distributed product mul!.
+
+Mirrors /root/reference/src/p_sparse_matrix.jl for the hot path:
+    PSparseMatrix (:971), SplitMatrix blocks (:588-627), psparse(...;assembled=true) (:1249-1270),
+    split_format_locally (:823-899), mul!(c,a,b) (:2090-2103), mul!(c,a,b,alpha,beta) (:2105-2142),
+and the local kernels of src/sparse_utils.jl (compresscoo :313-350, spmv! :609-669), which here are
+native host code (csrc/pa_host.cpp) and HIP kernels (csrc/pa_device.hip).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+from .primitives import pmap, local_items
+from .p_range import PRange, find_owner, union_ghost
+from .p_vector import PVector, Task, consistent_, assemble_, context
+
+I32, I64, F64 = np.int32, np.int64, np.float64
+
+
+@dataclass
+class HostCSR:
+    """SparseMatrixCSR{1,Float64,Int32} on the host: 1-based rowptr/colval, columns sorted per row."""
+    m: int
+    n: int
+    rowptr: np.ndarray
+    colval: np.ndarray
+    nzval: np.ndarray
+
+    @property
+    def nnz(self):
+        return len(self.nzval)
+
+
+def compresscoo(I, J, V, m, n, skip=False) -> HostCSR:
+    """compresscoo(SparseMatrixCSR{1,Float64,Int32},I,J,V,m,n;combine=+,skip) (src/sparse_utils.jl:313-350)."""
+    I = np.ascontiguousarray(I, dtype=I32)
+    J = np.ascontiguousarray(J, dtype=I32)
+    V = np.ascontiguousarray(V, dtype=F64)
+    assert len(I) == len(J) == len(V)
+    rowptr = np.zeros(m + 1, dtype=I32)
+    colval = np.zeros(len(I), dtype=I32)
+    nzval = np.zeros(len(I), dtype=F64)
+    nnz = C.c_int64()
+    L.call("pa_host_compresscoo_csr", L.ptr(I), L.ptr(J), L.ptr(V), len(I), m, n, int(skip), L.ptr(rowptr),
+           L.ptr(colval), L.ptr(nzval), C.byref(nnz))
+    k = nnz.value
+    if k != len(I):
+        colval, nzval = colval[:k].copy(), nzval[:k].copy()
+    return HostCSR(m, n, rowptr, colval, nzval)
+
+
+def sparse_matrix(I, J, V, m, n) -> HostCSR:
+    """sparse_matrix(T,I,J,V,m,n;skip=true) (src/sparse_utils.jl:398-410)."""
+    return compresscoo(I, J, V, m, n, skip=True)
+
+
+def split_format_locally(A: HostCSR, rows, cols):
+    """split_format_locally(A,rows,cols) (src/p_sparse_matrix.jl:823-899) for own rows of a matrix whose
+    local ids are [own|ghost] (block partitions: identity permutation).  Returns (own_own, own_ghost)."""
+    assert rows.own_is_contiguous_prefix and cols.own_is_contiguous_prefix, \
+        "the device SpMV needs [own|ghost] local ids (block partitions)"
+    a, b = C.c_int64(), C.c_int64()
+    n_or, n_oc, n_gc = rows.n_own, cols.n_own, cols.n_ghost
+    L.call("pa_host_split_csr", n_or, n_oc, n_gc, L.ptr(A.rowptr), L.ptr(A.colval), L.ptr(A.nzval),
+           None, None, None, None, None, None, C.byref(a), C.byref(b))
+    oo = HostCSR(n_or, n_oc, np.zeros(n_or + 1, I32), np.zeros(a.value, I32), np.zeros(a.value, F64))
+    oh = HostCSR(n_or, n_gc, np.zeros(n_or + 1, I32), np.zeros(b.value, I32), np.zeros(b.value, F64))
+    L.call("pa_host_split_csr", n_or, n_oc, n_gc, L.ptr(A.rowptr), L.ptr(A.colval), L.ptr(A.nzval),
+           L.ptr(oo.rowptr), L.ptr(oo.colval), L.ptr(oo.nzval), L.ptr(oh.rowptr), L.ptr(oh.colval), L.ptr(oh.nzval),
+           C.byref(a), C.byref(b))
+    return oo, oh
+
+
+class DeviceCSR:
+    """One CSR block in HBM (pa_csr): Int32 0-based indices + fp64 values + the row-split chunk table."""
+
+    def __init__(self, A: HostCSR, ctx=None):
+        self.ctx = ctx or context()
+        self.m, self.n, self.nnz = A.m, A.n, A.nnz
+        self.h = C.c_void_p()
+        assert A.rowptr.dtype == I32 and A.colval.dtype == I32
+        L.call("pa_csr_create", self.ctx.h, A.m, A.n, A.nnz, L.ptr(A.rowptr), L.ptr(A.colval), 4, 1,
+               L.ptr(A.nzval), C.byref(self.h))
+
+    def info(self):
+        v = [C.c_int64() for _ in range(6)]
+        L.call("pa_csr_info", self.h, *[C.byref(x) for x in v])
+        keys = ["n_rows", "n_cols", "nnz", "n_chunks", "n_nonempty_rows", "n_long_rows"]
+        return dict(zip(keys, [x.value for x in v]))
+
+    def update_values(self, nzval):
+        nzval = np.ascontiguousarray(nzval, F64)
+        assert len(nzval) == self.nnz
+        L.call("pa_csr_update_values", self.h, L.ptr(nzval))
+
+    def __del__(self):
+        try:
+            L.lib.pa_csr_destroy(self.h)
+        except Exception:
+            pass
+
+
+def spmv_(b, A: DeviceCSR, x, x_segment=L.SEG_OWN, b_segment=L.SEG_OWN, alpha=1.0, beta=0.0):
+    """spmv!(b,A,x) / mul!(b,A,x,alpha,beta) on device vectors (src/sparse_utils.jl:609-669)."""
+    L.call("pa_spmv", A.h, x.h, x_segment, b.h, b_segment, float(alpha), float(beta))
+    return b
+
+
+@dataclass
+class SplitMatrixBlocks:
+    """SplitMatrix blocks of one part (src/p_sparse_matrix.jl:588-627); ghost rows only when sub-assembled."""
+    own_own: DeviceCSR
+    own_ghost: DeviceCSR
+    ghost_own: DeviceCSR = None
+    ghost_ghost: DeviceCSR = None
+
+
+class PSparseMatrix:
+    """PSparseMatrix(matrix_partition,row_partition,col_partition,assembled) (src/p_sparse_matrix.jl:971-991)
+    with the split format living in HBM."""
+
+    def __init__(self, matrix_partition, row_partition, col_partition, assembled, host_blocks=None):
+        self.matrix_partition = matrix_partition      # DebugArray/TorchDistArray of SplitMatrixBlocks
+        self.row_partition = row_partition
+        self.col_partition = col_partition
+        self.assembled = assembled
+        self.host_blocks = host_blocks                # optional (own_own, own_ghost) HostCSR per part
+
+    @property
+    def axes(self):
+        return (PRange(self.row_partition), PRange(self.col_partition))
+
+    def nnz_local(self):
+        return pmap(lambda b: b.own_own.nnz + b.own_ghost.nnz, self.matrix_partition)
+
+
+def psparse(I, J, V, rows, cols, assembled=True, keep_host=False) -> PSparseMatrix:
+    """psparse(SparseMatrixCSR{1,Float64,Int32},I,J,V,rows,cols;assembled=true)|>fetch
+    (src/p_sparse_matrix.jl:1150,1249-1270): global->local ids, COO->CSR, split, upload."""
+    assert assembled, "this build covers the assembled=true route (the one HPCG and the gallery tests use)"
+
+    def build(Ii, Ji, Vi, r, c):
+        li = r.global_to_local(Ii)                   # map_global_to_local! (:1253-1254)
+        lj = c.global_to_local(Ji)
+        A = sparse_matrix(li, lj, Vi, r.n_local, c.n_local)
+        del li, lj
+        oo, oh = split_format_locally(A, r, c)
+        del A
+        blk = SplitMatrixBlocks(DeviceCSR(oo), DeviceCSR(oh))
+        return (blk, (oo, oh) if keep_host else None)
+
+    both = pmap(build, I, J, V, rows, cols)
+    blocks = pmap(lambda t: t[0], both)
+    host = pmap(lambda t: t[1], both) if keep_host else None
+    return PSparseMatrix(blocks, rows, cols, True, host)
+
+
+def psparse_from_coo(I, J, V, row_partition, keep_host=False) -> PSparseMatrix:
+    """The route of HPCG.build_p_matrix / test/gallery_tests.jl:33: find_owner -> union_ghost -> psparse."""
+    J_owner = find_owner(row_partition, J)
+    cols = pmap(union_ghost, row_partition, J, J_owner)
+    return psparse(I, J, V, row_partition, cols, assembled=True, keep_host=keep_host)
+
+
+def _check_axes(c: PVector, a: PSparseMatrix, b: PVector):
+    """@boundscheck matching_own_indices / matching_ghost_indices (src/p_sparse_matrix.jl:2091-2093)."""
+
+    def chk(ci, ri, coli, bi):
+        if ci.n_own != ri.n_own:
+            raise L.PAError("matching_own_indices(axes(c,1),axes(a,1)) failed")
+        if bi.n_own != coli.n_own or bi.n_ghost != coli.n_ghost:
+            raise L.PAError("matching_own/ghost_indices(axes(a,2),axes(b,1)) failed")
+
+    pmap(chk, c.index_partition, a.row_partition, a.col_partition, b.index_partition)
+
+
+def mul_(c: PVector, a: PSparseMatrix, b: PVector) -> PVector:
+    """mul!(c,a,b) (src/p_sparse_matrix.jl:2090-2103):
+        t = consistent!(b)                         pack + exchange on the comm stream
+        c_own  = A_oo * b_own      (spmv!)         overlaps with the exchange on the compute stream
+        wait(t)                                    compute stream waits, unpack ghosts
+        c_own += A_oh * b_ghost    (muladd!)
+    """
+    _check_axes(c, a, b)
+    if not a.assembled:
+        return mul5_(c, a, b, 1.0, 0.0)
+    t = consistent_(b)
+    pmap(lambda cv, blk, bv: spmv_(cv, blk.own_own, bv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0),
+         c.vector_partition, a.matrix_partition, b.vector_partition)
+    t.wait()
+    pmap(lambda cv, blk, bv: spmv_(cv, blk.own_ghost, bv, L.SEG_GHOST, L.SEG_OWN, 1.0, 1.0),
+         c.vector_partition, a.matrix_partition, b.vector_partition)
+    return c
+
+
+def mul5_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PVector:
+    """mul!(c,a,b,alpha,beta) (src/p_sparse_matrix.jl:2105-2142), assembled and sub-assembled."""
+    _check_axes(c, a, b)
+    t = consistent_(b)
+    pmap(lambda cv, blk, bv: spmv_(cv, blk.own_own, bv, L.SEG_OWN, L.SEG_OWN, alpha, beta),
+         c.vector_partition, a.matrix_partition, b.vector_partition)
+    if not a.assembled:
+        pmap(lambda cv, blk, bv: spmv_(cv, blk.ghost_own, bv, L.SEG_OWN, L.SEG_GHOST, alpha, beta),
+             c.vector_partition, a.matrix_partition, b.vector_partition)
+    t.wait()
+    pmap(lambda cv, blk, bv: spmv_(cv, blk.own_ghost, bv, L.SEG_GHOST, L.SEG_OWN, alpha, 1.0),
+         c.vector_partition, a.matrix_partition, b.vector_partition)
+    if not a.assembled:
+        pmap(lambda cv, blk, bv: spmv_(cv, blk.ghost_ghost, bv, L.SEG_GHOST, L.SEG_GHOST, alpha, 1.0),
+             c.vector_partition, a.matrix_partition, b.vector_partition)
+        assemble_(c).wait()
+    return c
+
+
+def mul_no_overlap_(c: PVector, a: PSparseMatrix, b: PVector) -> PVector:
+    """HPCG.mul_no_lat! ordering (HPCG/src/hpcg_utils.jl:6-17): blocking consistent!, then the product.
+    (Same blocks, same per-row order own-then-ghost, so same bits; kept for the overlap on/off comparison.)"""
+    _check_axes(c, a, b)
+    consistent_(b).wait()
+    pmap(lambda cv, blk, bv: spmv_(cv, blk.own_own, bv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0),
+         c.vector_partition, a.matrix_partition, b.vector_partition)
+    pmap(lambda cv, blk, bv: spmv_(cv, blk.own_ghost, bv, L.SEG_GHOST, L.SEG_OWN, 1.0, 1.0),
+         c.vector_partition, a.matrix_partition, b.vector_partition)
+    return c

@@ -1,0 +1,372 @@
+"""PVector on the device: local values in HBM, ghost exchange through HIP kernels.
+
+Mirrors /root/reference/src/p_vector.jl for the hot path:
+    PVector (:324), p_vector_cache_impl / VectorAssemblyCache (:418-468), assemble_impl! (:587-612),
+    assemble! (:695-708), consistent! (:747-755), dot (:1189), norm (:1201), broadcast axpy (:1216-1277).
+The local vector type is `DeviceVector` (a pa_vec of libpa_hip); this plays the role of the
+`V` in `PVector{V}` that the reference dispatches on.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _lib as L
+from .primitives import DebugArray, TorchDistArray, getany, local_items, pmap, preduce
+from .p_range import PRange, assembly_local_indices, assembly_neighbors
+
+F64 = np.float64
+
+
+# ----------------------------------------------------------------------------------------------
+# device context (one per process; all parts of a DebugArray share it)
+# ----------------------------------------------------------------------------------------------
+class Context:
+    def __init__(self, device=None):
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+            n = C.c_int(0)
+            L.call("pa_device_count", C.byref(n))
+            if n.value == 0:
+                raise L.PAError("no HIP device visible: the device path needs a GPU (there is no CPU fallback)")
+            device %= n.value
+        h = C.c_void_p()
+        L.call("pa_ctx_create", device, C.byref(h))
+        self.h = h
+        self.device = device
+        self.comm = None        # RcclComm, set by init_comm()
+
+    def sync(self):
+        L.call("pa_ctx_sync", self.h)
+
+    def info(self):
+        cus, xcds, hbm = C.c_int(), C.c_int(), C.c_size_t()
+        name = C.create_string_buffer(128)
+        L.call("pa_ctx_device_info", self.h, C.byref(cus), C.byref(xcds), C.byref(hbm), name, 128)
+        return dict(cus=cus.value, xcds=xcds.value, hbm_bytes=hbm.value, name=name.value.decode())
+
+    def event(self):
+        return Event(self)
+
+
+class Event:
+    """HIP event on one of the context's streams (PTimer replacement, src/p_timer.jl)."""
+
+    def __init__(self, ctx):
+        self.h = C.c_void_p()
+        L.call("pa_event_create", ctx.h, C.byref(self.h))
+
+    def record(self, stream=L.STREAM_COMPUTE):
+        L.call("pa_event_record", self.h, stream)
+        return self
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float()
+        L.call("pa_event_elapsed_ms", self.h, stop.h, C.byref(ms))
+        return ms.value
+
+    def __del__(self):
+        try:
+            L.lib.pa_event_destroy(self.h)
+        except Exception:
+            pass
+
+
+_CTX = None
+
+
+def context() -> Context:
+    global _CTX
+    if _CTX is None:
+        _CTX = Context()
+    return _CTX
+
+
+class RcclComm:
+    """RCCL communicator, one rank per part (src/mpi_array.jl:42-53 analogue)."""
+
+    def __init__(self, ctx: Context, group=None):
+        import torch.distributed as dist
+        rank, size = dist.get_rank(group), dist.get_world_size(group)
+        idbuf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+        if rank == 0:
+            L.call("pa_comm_unique_id", idbuf)
+        box = [idbuf.raw if rank == 0 else None]
+        src = 0 if group is None else dist.get_global_rank(group, 0)
+        dist.broadcast_object_list(box, src=src, group=group)
+        self.h = C.c_void_p()
+        L.call("pa_comm_create", ctx.h, box[0], rank, size, C.byref(self.h))
+        self.rank, self.size, self.ctx = rank, size, ctx
+
+    def allreduce_sum(self, device_ptr, count, stream=L.STREAM_COMPUTE):
+        L.call("pa_comm_allreduce_sum", self.h, device_ptr, count, stream)
+
+    def barrier(self):
+        L.call("pa_comm_barrier", self.h)
+
+
+def init_comm(group=None):
+    """Create (once) the RCCL communicator used by the device exchange of TorchDistArray back-ends."""
+    ctx = context()
+    if ctx.comm is None:
+        ctx.comm = RcclComm(ctx, group)
+    return ctx.comm
+
+
+# ----------------------------------------------------------------------------------------------
+# local vector type
+# ----------------------------------------------------------------------------------------------
+class DeviceVector:
+    """Local values of one part in HBM (allocate_local_values, src/p_vector.jl:8-14)."""
+
+    def __init__(self, n_own, n_ghost, ctx=None):
+        self.ctx = ctx or context()
+        self.n_own, self.n_ghost = int(n_own), int(n_ghost)
+        self.h = C.c_void_p()
+        L.call("pa_vec_create", self.ctx.h, self.n_own, self.n_ghost, C.byref(self.h))
+
+    def __len__(self):
+        return self.n_own + self.n_ghost
+
+    def upload(self, host, offset=0):
+        host = np.ascontiguousarray(host, dtype=F64)
+        L.call("pa_vec_upload", self.h, L.ptr(host), offset, len(host))
+        return self
+
+    def download(self, offset=0, length=None):
+        length = len(self) - offset if length is None else length
+        out = np.empty(length, dtype=F64)
+        L.call("pa_vec_download", self.h, L.ptr(out), offset, length)
+        return out
+
+    def own(self):
+        return self.download(0, self.n_own)
+
+    def ghost(self):
+        return self.download(self.n_own, self.n_ghost)
+
+    def fill(self, value, segment=L.SEG_LOCAL):
+        L.call("pa_vec_fill", self.h, segment, float(value))
+        return self
+
+    def data_ptr(self):
+        p = C.c_void_p()
+        L.call("pa_vec_data", self.h, C.byref(p))
+        return p.value
+
+    def __del__(self):
+        try:
+            L.lib.pa_vec_destroy(self.h)
+        except Exception:
+            pass
+
+
+# ----------------------------------------------------------------------------------------------
+# VectorAssemblyCache on the device
+# ----------------------------------------------------------------------------------------------
+class DeviceAssemblyCache:
+    """p_vector_cache_impl for DeviceVector (src/p_vector.jl:451-468): the neighbours and index lists of
+    every part, uploaded once into a pa_plan that also owns buffer_snd / buffer_rcv in HBM."""
+
+    def __init__(self, index_partition):
+        self.index_partition = index_partition
+        self.neighbors_snd, self.neighbors_rcv = assembly_neighbors(index_partition)
+        self.local_indices_snd, self.local_indices_rcv = assembly_local_indices(
+            index_partition, self.neighbors_snd, self.neighbors_rcv)
+
+        def make(ind, ns, nr, ls, lr):
+            h = C.c_void_p()
+            ns32, nr32 = np.ascontiguousarray(ns, np.int32), np.ascontiguousarray(nr, np.int32)
+            L.call("pa_plan_create", context().h, ind.part, ind.n_local, len(ns32), L.ptr(ns32), L.ptr(ls.ptrs),
+                   L.ptr(np.ascontiguousarray(ls.data, np.int32)), len(nr32), L.ptr(nr32), L.ptr(lr.ptrs),
+                   L.ptr(np.ascontiguousarray(lr.data, np.int32)), 1, C.byref(h))
+            return h
+
+        self.plans = pmap(make, index_partition, self.neighbors_snd, self.neighbors_rcv,
+                          self.local_indices_snd, self.local_indices_rcv)
+
+    def __del__(self):
+        try:
+            for h in local_items(self.plans):
+                L.lib.pa_plan_destroy(h)
+        except Exception:
+            pass
+
+
+class Task:
+    """What `exchange!`/`consistent!`/`assemble!` return: call wait() exactly once (FakeTask,
+    src/primitives.jl:119-141).  wait() queues the unpack on the compute stream; it does not block the host."""
+
+    def __init__(self, fn, result=None):
+        self._fn, self._done, self._result = fn, False, result
+
+    def wait(self):
+        if not self._done:
+            self._fn()
+            self._done = True
+        return self._result
+
+    fetch = wait
+
+
+def _transport(plans, mode):
+    """exchange!(buffer_rcv,buffer_snd,graph) on the device (src/p_vector.jl:601):
+    DebugArray -> device-to-device slice copies (src/debug_array.jl:250);
+    TorchDistArray -> RCCL send/recv group on the comm stream (src/mpi_array.jl:575-614)."""
+    if isinstance(plans, DebugArray):
+        hs = plans.items
+        arr = (C.c_void_p * len(hs))(*[h.value for h in hs])
+        L.call("pa_exchange_local", arr, len(hs), mode)
+    else:
+        comm = context().comm
+        if comm is None:
+            raise L.PAError("no RCCL communicator: call init_comm() before exchanging on a TorchDistArray")
+        L.call("pa_exchange_rccl", plans.item, comm.h, mode)
+
+
+def assemble_impl(mode, vector_partition, cache: DeviceAssemblyCache) -> Task:
+    """assemble_impl!(f,vector_partition,cache) (src/p_vector.jl:587-612): pack, start the exchange,
+    return a task whose wait() unpacks with f = insert (CONSISTENT) or + (ASSEMBLE)."""
+    pmap(lambda v, p: L.call("pa_exchange_pack", p, v.h, mode), vector_partition, cache.plans)
+    _transport(cache.plans, mode)
+
+    def finish():
+        pmap(lambda v, p: L.call("pa_exchange_finish", p, v.h, mode), vector_partition, cache.plans)
+
+    return Task(finish)
+
+
+class PVector:
+    """PVector(vector_partition,index_partition[,cache]) (src/p_vector.jl:324-345)."""
+
+    def __init__(self, vector_partition, index_partition, cache=None):
+        self.vector_partition = vector_partition
+        self.index_partition = index_partition
+        self._cache = cache
+
+    @property
+    def cache(self):
+        if self._cache is None:
+            self._cache = DeviceAssemblyCache(self.index_partition)     # p_vector_cache (:414)
+        return self._cache
+
+    @property
+    def axes(self):
+        return (PRange(self.index_partition),)
+
+    def local_values(self):
+        """Host copies of the local values (own and ghost) of every part."""
+        return pmap(lambda v: v.download(), self.vector_partition)
+
+    def own_values(self):
+        return pmap(lambda v, i: v.download()[i.own_to_local - 1], self.vector_partition, self.index_partition)
+
+    def ghost_values(self):
+        return pmap(lambda v, i: v.download()[i.ghost_to_local - 1], self.vector_partition, self.index_partition)
+
+    def collect(self):
+        """collect(v): the global vector on the host (every process gets it)."""
+        from .primitives import gather
+        pieces = gather(pmap(lambda v, i: (i.own_to_global, v.download()[i.own_to_local - 1]),
+                             self.vector_partition, self.index_partition), destination="all")
+        out = np.zeros(getany(pmap(lambda i: i.n_global, self.index_partition)), dtype=F64)
+        for g, vals in getany(pieces):
+            out[g - 1] = vals
+        return out
+
+
+def partition(a):
+    return a.vector_partition if isinstance(a, PVector) else a.partition
+
+
+def pvector_from_function(f, index_partition, cache=None) -> PVector:
+    """pvector(f,index_partition): f(indices) gives the host local values to upload (src/p_vector.jl:815)."""
+
+    def make(ind):
+        v = DeviceVector(ind.n_own, ind.n_ghost) if ind.own_is_contiguous_prefix else DeviceVector(ind.n_local, 0)
+        vals = np.ascontiguousarray(f(ind), dtype=F64)
+        assert len(vals) == ind.n_local
+        v.upload(vals)
+        return v
+
+    return PVector(pmap(make, index_partition), index_partition, cache)
+
+
+def pfill(value, index_partition) -> PVector:
+    """pfill(v,index_partition) (src/p_vector.jl:1047)."""
+    return pvector_from_function(lambda ind: np.full(ind.n_local, value, F64), index_partition)
+
+
+def pzeros(index_partition) -> PVector:
+    return pfill(0.0, index_partition)
+
+
+def pones(index_partition) -> PVector:
+    return pfill(1.0, index_partition)
+
+
+def similar(a: PVector, index_partition=None) -> PVector:
+    ip = a.index_partition if index_partition is None else index_partition
+    return pzeros(ip)
+
+
+def pvector(I, V, index_partition) -> PVector:
+    """pvector(I,V,rows)|>fetch for own entries (dense_vector!, src/p_vector.jl:866-875): a[lid] += v."""
+
+    def vals(ind, gi, v):
+        out = np.zeros(ind.n_local, F64)
+        lid = ind.global_to_local(gi)
+        keep = lid >= 1
+        np.add.at(out, lid[keep] - 1, np.asarray(v, F64)[keep])
+        return out
+
+    host = pmap(vals, index_partition, I, V)
+    parts = pmap(lambda ind, h: (DeviceVector(ind.n_own, ind.n_ghost) if ind.own_is_contiguous_prefix
+                                 else DeviceVector(ind.n_local, 0)).upload(h), index_partition, host)
+    return PVector(parts, index_partition)
+
+
+def consistent_(a: PVector) -> Task:
+    """consistent!(a) (src/p_vector.jl:747-755): ghost <- owner.  Returns a task; wait() it."""
+    t = assemble_impl(L.CONSISTENT, a.vector_partition, a.cache)
+    return Task(t.wait, a)
+
+
+def assemble_(a: PVector) -> Task:
+    """assemble!(a) (src/p_vector.jl:695-708): owner += ghost copies (ascending p), then ghosts := 0."""
+    t = assemble_impl(L.ASSEMBLE, a.vector_partition, a.cache)
+    return Task(t.wait, a)
+
+
+def _part_sum(parts_values, scalar_on_device=False):
+    return preduce(lambda x, y: x + y, parts_values, init=0.0)
+
+
+def dot(a: PVector, b: PVector) -> float:
+    """dot(a,b) (src/p_vector.jl:1189-1192): per-part own-value dot on the device, then sum over parts."""
+
+    def local(x, y):
+        out = C.c_double()
+        L.call("pa_vec_dot", x.h, y.h, C.byref(out))
+        return out.value
+
+    return _part_sum(pmap(local, a.vector_partition, b.vector_partition))
+
+
+def norm(a: PVector) -> float:
+    """norm(a,2) (src/p_vector.jl:1201-1206)."""
+    return dot(a, a) ** 0.5
+
+
+def axpby_(y: PVector, alpha, x: PVector, beta) -> PVector:
+    """y .= alpha .* x .+ beta .* y on own values (the broadcasts of a CG loop, src/p_vector.jl:1216-1277)."""
+    pmap(lambda yv, xv: L.call("pa_vec_axpby", yv.h, float(alpha), xv.h, float(beta), L.SEG_OWN),
+         y.vector_partition, x.vector_partition)
+    return y
+
+
+def copy_(dst: PVector, src: PVector) -> PVector:
+    pmap(lambda d, s: L.call("pa_vec_copy", d.h, s.h, L.SEG_LOCAL), dst.vector_partition, src.vector_partition)
+    return dst

@@ -1,0 +1,286 @@
+"""Parallel primitives on an "array of parts" and the two back-ends (host side).
+
+Mirrors /root/reference/src/primitives.jl, src/debug_array.jl and src/mpi_array.jl for what the
+mul!/consistent!/assemble! path needs at set-up time:
+
+  DebugArray      all parts in this process, `map` is a sequential loop (src/debug_array.jl:34,110-117)
+  TorchDistArray  one part per process / GPU (MPIArray analogue, src/mpi_array.jl:105); collectives go
+                  through torch.distributed (gloo on CPU, RCCL = backend "nccl" on GPUs)
+
+Part ids, MAIN and every id inside the data are 1-based, as in the reference (MAIN = 1,
+src/primitives.jl:152; MPI rank = part - 1, src/mpi_array.jl:51).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+MAIN = 1
+
+
+# ----------------------------------------------------------------------------------------------
+# back-end arrays
+# ----------------------------------------------------------------------------------------------
+class DebugArray:
+    """src/debug_array.jl:34-65: immutable wrapper; scalar indexing is an error on purpose."""
+
+    def __init__(self, items):
+        self.items = list(items)
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        raise IndexError("Scalar indexing on DebugArray is not allowed for performance reasons "
+                         "(src/debug_array.jl:56-65); use pmap / gather / getany")
+
+    def __iter__(self):
+        raise TypeError("DebugArray is not iterable; use pmap (src/debug_array.jl:110)")
+
+    def __eq__(self, other):
+        return isinstance(other, DebugArray) and self.items == other.items
+
+    def __repr__(self):
+        return f"DebugArray({self.items!r})"
+
+
+class TorchDistArray:
+    """One item per process (MPIArray, src/mpi_array.jl:105-126)."""
+
+    def __init__(self, item, group=None):
+        import torch.distributed as dist
+        self.item = item
+        self.group = group
+        self.rank = dist.get_rank(group)      # 0-based; part id = rank + 1
+        self.size = dist.get_world_size(group)
+
+    def __len__(self):
+        return self.size
+
+    def __getitem__(self, i):
+        raise IndexError("Scalar indexing on TorchDistArray is not allowed (src/mpi_array.jl:155-157)")
+
+    def __repr__(self):
+        return f"TorchDistArray(part {self.rank + 1}/{self.size}: {self.item!r})"
+
+
+def with_debug(f):
+    """with_debug(f) = f(DebugArray) (src/debug_array.jl:7-9)."""
+    return f(lambda a: DebugArray(list(a)))
+
+
+def with_torchdist(f, group=None):
+    """with_mpi analogue (src/mpi_array.jl:64-83): `distribute` keeps this rank's item of `a`;
+    an exception on any rank tears the job down (MPI.Abort analogue: re-raised after destroying the group)."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        raise RuntimeError("torch.distributed is not initialised (call dist.init_process_group first)")
+
+    def distribute(a):
+        a = list(a)
+        if len(a) != dist.get_world_size(group):
+            raise AssertionError("number of parts must equal the number of ranks (src/mpi_array.jl:46)")
+        return TorchDistArray(a[dist.get_rank(group)], group)
+
+    return f(distribute)
+
+
+def linear_indices(a):
+    """Part ids 1..P distributed like `a` (src/primitives.jl linear_indices)."""
+    if isinstance(a, DebugArray):
+        return DebugArray(range(1, len(a) + 1))
+    return TorchDistArray(a.rank + 1, a.group)
+
+
+def pmap(f, *arrays):
+    """`map(f, a, b, ...)` over parts (src/debug_array.jl:110-117, src/mpi_array.jl:221-279)."""
+    a0 = arrays[0]
+    if isinstance(a0, DebugArray):
+        n = len(a0)
+        for a in arrays:
+            assert isinstance(a, DebugArray) and len(a) == n
+        return DebugArray([f(*[a.items[i] for a in arrays]) for i in range(n)])
+    for a in arrays:
+        assert isinstance(a, TorchDistArray)
+    return TorchDistArray(f(*[a.item for a in arrays]), a0.group)
+
+
+def pforeach(f, *arrays):
+    pmap(f, *arrays)
+    return None
+
+
+def tuple_of_arrays(a):
+    """Array of tuples -> tuple of arrays (src/primitives.jl tuple_of_arrays)."""
+    if isinstance(a, DebugArray):
+        k = len(a.items[0])
+        return tuple(DebugArray([t[j] for t in a.items]) for j in range(k))
+    return tuple(TorchDistArray(x, a.group) for x in a.item)
+
+
+def getany(a):
+    """Any item (they are assumed equal), src/primitives.jl getany."""
+    return a.items[0] if isinstance(a, DebugArray) else a.item
+
+
+def local_items(a):
+    """The items that live in THIS process (all of them for DebugArray, one for TorchDistArray)."""
+    return list(a.items) if isinstance(a, DebugArray) else [a.item]
+
+
+def map_main(f, *arrays, main=MAIN):
+    """src/primitives.jl:185-194."""
+    ranks = linear_indices(arrays[0])
+    return pmap(lambda r, *xs: f(*xs) if r == main else None, ranks, *arrays)
+
+
+# ----------------------------------------------------------------------------------------------
+# collectives (set-up only; the per-iteration exchange runs on the device, see p_vector.py)
+# ----------------------------------------------------------------------------------------------
+def gather(snd, destination=MAIN):
+    """src/primitives.jl:234-252: MAIN (or every part for :all) gets the list of all items."""
+    if isinstance(snd, DebugArray):
+        allv = list(snd.items)
+        if destination == "all":
+            return DebugArray([list(allv) for _ in allv])
+        return DebugArray([list(allv) if p == destination else [] for p in range(1, len(allv) + 1)])
+    import torch.distributed as dist
+    out = [None] * snd.size
+    dist.all_gather_object(out, snd.item, group=snd.group)
+    if destination == "all" or snd.rank + 1 == destination:
+        return TorchDistArray(out, snd.group)
+    return TorchDistArray([], snd.group)
+
+
+def scatter(snd, source=MAIN):
+    """src/primitives.jl:357-372: part p receives snd[source][p]."""
+    if isinstance(snd, DebugArray):
+        src = snd.items[source - 1]
+        return DebugArray([src[p] for p in range(len(snd))])
+    import torch.distributed as dist
+    out = [None]
+    lst = list(snd.item) if snd.rank + 1 == source else None
+    dist.scatter_object_list(out, lst, src=_global_rank(snd.group, source - 1), group=snd.group)
+    return TorchDistArray(out[0], snd.group)
+
+
+def _global_rank(group, group_rank):
+    import torch.distributed as dist
+    if group is None:
+        return group_rank
+    return dist.get_global_rank(group, group_rank)
+
+
+def reduction(op, a, init=None, destination=MAIN):
+    """src/primitives.jl:681-693: fold over parts in part order 1..P."""
+    g = gather(a, destination="all")
+
+    def fold(vals):
+        acc = init
+        for v in vals:
+            acc = v if acc is None else op(acc, v)
+        return acc
+
+    r = pmap(fold, g)
+    if destination == "all":
+        return r
+    return map_main(lambda x: x, r, main=destination)
+
+
+def preduce(op, a, init=None):
+    """reduce(op,a;init) -> plain value on every part."""
+    return getany(reduction(op, a, init=init, destination="all"))
+
+
+def scan(op, a, type="inclusive", init=None):
+    """src/primitives.jl:599-611."""
+    g = gather(a, destination="all")
+    ranks = linear_indices(a)
+
+    def f(r, vals):
+        acc = init
+        out = []
+        for v in vals:
+            if type == "exclusive":
+                out.append(acc)
+            acc = v if acc is None else op(acc, v)
+            if type == "inclusive":
+                out.append(acc)
+        return out[r - 1]
+
+    return pmap(f, ranks, g)
+
+
+@dataclass
+class ExchangeGraph:
+    """src/primitives.jl:728-741: snd[i] / rcv[i] neighbour id lists (1-based part ids)."""
+    snd: object
+    rcv: object
+
+    def reverse(self):
+        return ExchangeGraph(self.rcv, self.snd)
+
+
+def find_rcv_ids_gather_scatter(snd_ids):
+    """src/primitives.jl:826-859: gather the graph on MAIN, transpose it, scatter the receivers back.
+    The receivers of a part come out in ascending order."""
+    snd_main = gather(pmap(lambda s: [int(x) for x in s], snd_ids))
+
+    def transpose(all_snd):
+        if not all_snd:
+            return []
+        npart = len(all_snd)
+        rcv = [[] for _ in range(npart)]
+        for p, lst in enumerate(all_snd, start=1):
+            for j in sorted(set(lst)):
+                rcv[j - 1].append(p)
+        return [np.array(r, dtype=np.int32) for r in rcv]
+
+    return scatter(pmap(transpose, snd_main))
+
+
+def exchange_graph(snd, rcv=None, symmetric=False):
+    """ExchangeGraph(snd; rcv, symmetric, find_rcv_ids) (src/primitives.jl:768-783)."""
+    if rcv is not None:
+        return ExchangeGraph(snd, rcv)
+    if symmetric:
+        return ExchangeGraph(snd, snd)
+    return ExchangeGraph(snd, find_rcv_ids_gather_scatter(snd))
+
+
+def is_consistent(graph: ExchangeGraph) -> bool:
+    """src/primitives.jl:861-874."""
+    snd = getany(gather(pmap(lambda s: [int(x) for x in s], graph.snd), destination="all"))
+    rcv = getany(gather(pmap(lambda s: [int(x) for x in s], graph.rcv), destination="all"))
+    for part in range(1, len(rcv) + 1):
+        for i in rcv[part - 1]:
+            if sum(1 for k in snd[i - 1] if k == part) != 1:
+                return False
+        for i in snd[part - 1]:
+            if sum(1 for k in rcv[i - 1] if k == part) != 1:
+                return False
+    return True
+
+
+def exchange(snd, graph: ExchangeGraph):
+    """exchange(snd,graph)|>fetch for HOST data (src/primitives.jl:921-935,1005-1042).
+
+    snd[i][j] (a scalar, or a sequence -> jagged exchange) goes to part graph.snd[i][j];
+    the result rcv[i][j] is what part graph.rcv[i][j] sent to i.  Used at set-up (global ids of the
+    ghosts, slice lengths); the per-iteration exchange of values is the device path.
+    """
+    assert is_consistent(graph)
+    packed = pmap(lambda ids, data: ([int(x) for x in ids], list(data)), graph.snd, snd)
+    everything = gather(packed, destination="all")
+    ranks = linear_indices(snd)
+
+    def pick(r, rcv_ids, allv):
+        out = []
+        for s in rcv_ids:
+            ids, data = allv[int(s) - 1]
+            j = ids.index(r)
+            out.append(data[j])
+        return out
+
+    return pmap(pick, ranks, graph.rcv, everything)

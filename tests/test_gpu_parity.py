@@ -1,0 +1,309 @@
+"""Parity of the HIP path against the oracle, through the C ABI (needs a real MI355X: -m gpu).
+
+Bars: index/ghost data, consistent!, assemble!: bit-exact.  mul!: bit-exact as well --
+the row-split kernel sums each row's products in the reference's order with unfused multiply/add --
+so every comparison below is np.array_equal; dot/norm: relative 1e-13 (tree reduction).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+pa = load_package()
+
+
+def ranks(n):
+    return pa.DebugArray(range(1, n + 1))
+
+
+def upload(host_parts, index_partition):
+    it = iter(host_parts)
+    return pa.pvector_from_function(lambda ind: next(it), index_partition)
+
+
+# ---------------------------------------------------------------- consistent! / assemble! goldens
+def _hand(golden):
+    c = golden["p_vector_local_indices"]
+    return c, pa.DebugArray([pa.LocalIndices(c["n"], p + 1, local_to_global=g, local_to_owner=o)
+                             for p, (g, o) in enumerate(zip(c["local_to_global"], c["local_to_owner"]))])
+
+
+def test_consistent_hand_partition(golden):
+    c, parts = _hand(golden)
+    v = pa.pvector_from_function(lambda i: 10.0 * i.part * (i.get_local_to_owner() == i.part), parts)
+    pa.consistent_(v).wait()
+    for vals, ind in zip(v.local_values().items, parts.items):
+        assert vals.tolist() == (10.0 * ind.get_local_to_owner()).tolist()      # test/p_vector_tests.jl:116-124
+
+
+def test_assemble_hand_partition(golden):
+    c, parts = _hand(golden)
+    v = pa.pfill(c["assemble_input"], parts)
+    pa.assemble_(v).wait()
+    assert [x.tolist() for x in v.local_values().items] == c["assemble_local_values"]   # :126-141
+    assert v.collect().tolist() == c["assemble_collect"]                                  # :142
+
+
+def test_doc_examples(golden):
+    c = golden["doc_consistent"]
+    parts = pa.uniform_partition(ranks(2), tuple(c["np"]), tuple(c["n"]), tuple(c["ghost"]))
+    v = upload([np.array(b, float) for b in c["before"]], parts)
+    pa.consistent_(v).wait()
+    assert [x.tolist() for x in v.local_values().items] == c["after"]
+    c = golden["doc_assemble"]
+    v = upload([np.array(b, float) for b in c["before"]], parts)
+    pa.assemble_(v).wait()
+    assert [x.tolist() for x in v.local_values().items] == c["after"]
+
+
+def test_repeated_exchanges_and_periodic_partition(orc):
+    """Jacobi-style use (docs/jacobi_tutorial.jl:239-263): ghosted, periodic partition; many consistent! in a row."""
+    parts = pa.uniform_partition(ranks(4), (2, 2), (6, 6), (True, True), (True, True))
+    oparts = orc.uniform_partition((2, 2), (6, 6), (True, True), (True, True))
+    host = [orc.hash_x(o.local_to_global) * (o.local_to_owner == o.part) for o in oparts]
+    v = upload([h.copy() for h in host], parts)
+    for _ in range(3):
+        pa.consistent_(v).wait()
+    orc.consistent(host, oparts)
+    for a, b in zip(v.local_values().items, host):
+        assert np.array_equal(a, b)
+    pa.assemble_(v).wait()
+    orc.assemble(host, oparts)
+    for a, b in zip(v.local_values().items, host):
+        assert np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------- mul!
+def _oracle_mul(orc, Ao, xo):
+    yo = [np.zeros(r.n_local) for r in Ao.rows]
+    orc.mul(yo, Ao, [v.copy() for v in xo])
+    return yo
+
+
+@pytest.mark.parametrize("n,parts", [((4, 4, 4), (2, 2, 2)), ((8, 8, 8), (2, 2, 1)), ((16, 8, 4), (2, 1, 1)),
+                                     ((16, 16, 16), (1, 1, 1)), ((3, 5, 7), (2, 2, 2))])
+def test_mul_hpcg_bit_exact(orc, n, parts):
+    nx, ny, nz = n
+    px, py, pz = parts
+    P = px * py * pz
+    A, b = pa.build_p_matrix(ranks(P), nx, ny, nz, px * nx, py * ny, pz * nz, px, py, pz)
+    Ao, bo, _ = orc.hpcg_build_p_matrix(nx, ny, nz, px, py, pz)
+    # G12: A*1 == b exactly
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, pa.pones(A.col_partition))
+    for got, exp in zip(y.own_values().items, b.own_values().items):
+        assert np.array_equal(got, exp)
+    # general x: only own values set; consistent! inside mul! must fill the ghosts
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = upload([v.copy() for v in xo], A.col_partition)
+    pa.mul_(y, A, x)
+    yo = _oracle_mul(orc, Ao, xo)
+    for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+    # the ghosts of x are now consistent, bit for bit
+    orc.consistent(xo, Ao.cols)
+    for got, exp in zip(x.local_values().items, xo):
+        assert np.array_equal(got, exp)
+    # no-overlap ordering gives the same bits
+    y2 = pa.pzeros(A.row_partition)
+    pa.mul_no_overlap_(y2, A, x)
+    for a_, b_ in zip(y.own_values().items, y2.own_values().items):
+        assert np.array_equal(a_, b_)
+
+
+def test_mul_diag_golden(golden):
+    c = golden["mul_diag"]                                   # test/p_sparse_matrix_tests.jl:207-248
+    rows = pa.uniform_partition(ranks(4), tuple(c["np"]), tuple(c["n"]))
+    I = pa.pmap(lambda r: r.own_to_global.copy(), rows)
+    V = pa.pmap(lambda i: np.full(len(i), c["diag"]), I)
+    A = pa.psparse_from_coo(I, pa.pmap(lambda i: i.copy(), I), V, rows, keep_host=True)
+    x = pa.pfill(c["x"], A.col_partition)
+    b = pa.pzeros(A.row_partition)
+    pa.mul_(b, A, x)
+    for v in b.own_values().items:
+        assert np.all(v == c["y"])
+    pa.consistent_(b).wait()
+    for v in b.local_values().items:
+        assert np.all(v == c["y"])
+    # fillstored!(A,1): :285-291
+    pa.pmap(lambda blk, h: blk.own_own.update_values(np.full(h[0].nnz, c["fillstored"])), A.matrix_partition, A.host_blocks)
+    pa.mul_(b, A, x)
+    for v in b.own_values().items:
+        assert np.all(v == c["y_fillstored"])
+
+
+def test_mul5_alpha_beta(orc):
+    A, _ = pa.build_p_matrix(ranks(2), 6, 5, 4, 12, 5, 4, 2, 1, 1)
+    Ao, _, _ = orc.hpcg_build_p_matrix(6, 5, 4, 2, 1, 1)
+    for alpha, beta in [(1.0, 0.0), (1.0, 1.0), (-0.75, 0.5), (2.0, 0.0), (0.3, -1.25)]:
+        xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+        yo = [orc.hash_x(r.local_to_global + 11) for r in Ao.rows]
+        x = upload([v.copy() for v in xo], A.col_partition)
+        y = upload([v.copy() for v in yo], A.row_partition)
+        pa.mul5_(y, A, x, alpha, beta)
+        orc.mul5(yo, Ao, xo, alpha, beta)
+        for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+            assert np.array_equal(got, exp[:r.n_own]), (alpha, beta)
+
+
+def test_config1_laplacian_64_cubed_4_parts(orc):
+    """BASELINE config 1: 7-pt 64^3 on (2,2,1) parts: the reference's CPU-runnable case, vs the oracle."""
+    n, parts = (64, 64, 64), (2, 2, 1)
+    I, J, V, rows, _ = pa.laplacian_fdm(n, parts, ranks(4))
+    A = pa.psparse_from_coo(I, J, V, rows)
+    Io, Jo, Vo, orows, _ = orc.laplacian_fdm_fast(n, parts)
+    Ao = orc.psparse_from_coo(Io, Jo, Vo, orows)
+    assert pa.pmap(lambda b: (b.own_own.nnz, b.own_ghost.nnz), A.matrix_partition).items == [(448512, 4096)] * 4
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = upload([v.copy() for v in xo], A.col_partition)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x)
+    yo = _oracle_mul(orc, Ao, xo)
+    for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+    # A*1 = alpha*(2D - #neighbours) exactly
+    pa.mul_(y, A, pa.pones(A.col_partition))
+    yo = _oracle_mul(orc, Ao, [np.ones(c.n_local) for c in Ao.cols])
+    for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+
+
+# ---------------------------------------------------------------- local SpMV on irregular matrices
+def _random_csr(rng, m, n, row_len):
+    I = np.repeat(np.arange(1, m + 1), row_len)
+    J = np.concatenate([rng.choice(n, size=k, replace=False) + 1 if k else np.zeros(0, int) for k in row_len])
+    V = rng.standard_normal(len(I))
+    return pa.compresscoo(I, J, V, m, n)
+
+
+@pytest.mark.parametrize("case", ["empty_rows", "ragged", "long_rows", "one_row", "all_empty", "wide"])
+def test_spmv_irregular_bit_exact(orc, case):
+    rng = np.random.default_rng(42)
+    if case == "empty_rows":
+        m, n = 5000, 300
+        row_len = rng.integers(0, 4, m) * (rng.random(m) < 0.2)       # most rows empty -> compacted path
+    elif case == "ragged":
+        m, n = 3000, 4000
+        row_len = rng.integers(0, 60, m)
+    elif case == "long_rows":
+        m, n = 40, 9000
+        row_len = rng.integers(0, 50, m)
+        row_len[[3, 17, 39]] = [2049, 5000, 8999]                      # longer than one 2048-entry chunk
+    elif case == "one_row":
+        m, n, row_len = 1, 10, np.array([7])
+    elif case == "all_empty":
+        m, n, row_len = 100, 10, np.zeros(100, int)
+    else:
+        m, n = 700, 100000
+        row_len = rng.integers(1, 300, m)
+    A = _random_csr(rng, m, n, row_len.astype(int))
+    dA = pa.DeviceCSR(A)
+    x = pa.DeviceVector(n, 0).upload(rng.standard_normal(n))
+    oA = orc.CSR(A.m, A.n, A.rowptr, A.colval, A.nzval)
+    for alpha, beta in [(1.0, 0.0), (1.0, 1.0), (0.5, -2.0)]:
+        y0 = rng.standard_normal(m)
+        y = pa.DeviceVector(m, 0).upload(y0)
+        pa.spmv_(y, dA, x, alpha=alpha, beta=beta)
+        exp = orc.oracle_c().mul5_csr(y0.copy(), oA, x.download(), alpha, beta)
+        assert np.array_equal(y.download(), exp), (case, alpha, beta)
+    # 3-arg spmv! == spmv_csr! loop
+    y = pa.DeviceVector(m, 0).upload(rng.standard_normal(m))
+    pa.spmv_(y, dA, x)
+    assert np.array_equal(y.download(), orc.oracle_c().spmv_csr(np.zeros(m), x.download(), oA))
+
+
+def test_csc_upload_gives_same_bits(orc):
+    rng = np.random.default_rng(1)
+    A = _random_csr(rng, 400, 300, rng.integers(0, 30, 400))
+    oA = orc.CSR(A.m, A.n, A.rowptr, A.colval, A.nzval)
+    colptr, rowval, nzval = orc.csr_to_csc(oA)
+    import pa_amd._lib as L
+    h = C.c_void_p()
+    colptr, rowval = np.ascontiguousarray(colptr, np.int64), np.ascontiguousarray(rowval, np.int64)
+    L.call("pa_csr_create_from_csc", pa.context().h, A.m, A.n, A.nnz, L.ptr(colptr), L.ptr(rowval), 8, 1,
+           L.ptr(np.ascontiguousarray(nzval)), C.byref(h))
+    x = pa.DeviceVector(A.n, 0).upload(rng.standard_normal(A.n))
+    y1, y2 = pa.DeviceVector(A.m, 0), pa.DeviceVector(A.m, 0)
+    pa.spmv_(y1, pa.DeviceCSR(A), x)
+    L.call("pa_spmv", h, x.h, 0, y2.h, 0, 1.0, 0.0)
+    assert np.array_equal(y1.download(), y2.download())
+    L.call("pa_csr_destroy", h)
+
+
+def test_argument_errors_are_reported():
+    A = pa.DeviceCSR(pa.compresscoo([1, 2], [1, 2], [1.0, 1.0], 2, 2))
+    x, y = pa.DeviceVector(3, 0), pa.DeviceVector(2, 0)
+    with pytest.raises(pa.PAError, match="size"):        # @boundscheck of spmv! (src/sparse_utils.jl:618-621)
+        pa.spmv_(y, A, x)
+
+
+# ---------------------------------------------------------------- BLAS-1
+def test_dot_norm_axpby(orc):
+    parts = pa.uniform_partition(ranks(3), (3,), (100003,))
+    oparts = orc.uniform_partition((3,), (100003,))
+    xo = [orc.hash_x(o.local_to_global) - 0.5 for o in oparts]
+    yo = [orc.hash_x(o.local_to_global + 3) for o in oparts]
+    x, y = upload([v.copy() for v in xo], parts), upload([v.copy() for v in yo], parts)
+    d, dref = pa.dot(x, y), orc.dot(xo, yo, oparts)
+    assert abs(d - dref) <= 1e-13 * abs(dref) * 10 + 1e-13 * sum(float(np.abs(a * b).sum()) for a, b in zip(xo, yo))
+    assert abs(pa.norm(x) - orc.norm2(xo, oparts)) <= 1e-13 * orc.norm2(xo, oparts)
+    pa.axpby_(y, 0.25, x, -2.0)
+    for got, a, b in zip(y.local_values().items, xo, yo):
+        assert np.array_equal(got, 0.25 * a + -2.0 * b)
+
+
+# ---------------------------------------------------------------- RCCL transport plumbing (1 rank)
+def test_rccl_single_rank_loopback():
+    """librccl is dlopen'ed, a 1-rank communicator works, and a self-addressed exchange moves the bytes.
+    (Multi-GPU runs are the driver's; this pins the API plumbing on the 1-GPU box.)"""
+    import pa_amd._lib as L
+    ctx = pa.context()
+    idbuf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+    L.call("pa_comm_unique_id", idbuf)
+    comm = C.c_void_p()
+    L.call("pa_comm_create", ctx.h, idbuf.raw, 0, 1, C.byref(comm))
+    v = pa.DeviceVector(6, 3).upload(np.arange(9, dtype=float))
+    # part 1 "ghosts" three of its own values: snd side = ghost lids 7..9, rcv side = own lids 2,4,6
+    one, ptrs = np.array([1], np.int32), np.array([1, 4], np.int32)
+    plan = C.c_void_p()
+    L.call("pa_plan_create", ctx.h, 1, 9, 1, L.ptr(one), L.ptr(ptrs), L.ptr(np.array([7, 8, 9], np.int32)),
+           1, L.ptr(one), L.ptr(ptrs), L.ptr(np.array([2, 4, 6], np.int32)), 1, C.byref(plan))
+    L.call("pa_exchange_pack", plan, v.h, L.CONSISTENT)
+    L.call("pa_exchange_rccl", plan, comm, L.CONSISTENT)
+    L.call("pa_exchange_finish", plan, v.h, L.CONSISTENT)
+    assert v.download().tolist() == [0, 1, 2, 3, 4, 5, 1, 3, 5]
+    L.call("pa_exchange_pack", plan, v.h, L.ASSEMBLE)
+    L.call("pa_exchange_rccl", plan, comm, L.ASSEMBLE)
+    L.call("pa_exchange_finish", plan, v.h, L.ASSEMBLE)
+    assert v.download().tolist() == [0, 2, 2, 6, 4, 10, 0, 0, 0]
+    d = pa.DeviceVector(4, 0).upload(np.array([1.5, 2.0, 0.0, -1.0]))
+    L.call("pa_comm_allreduce_sum", comm, C.c_void_p(d.data_ptr()), 4, L.STREAM_COMPUTE)
+    assert d.download().tolist() == [1.5, 2.0, 0.0, -1.0]
+    L.call("pa_comm_barrier", comm)
+    L.call("pa_plan_destroy", plan)
+    L.call("pa_comm_destroy", comm)
+
+
+# ---------------------------------------------------------------- full-size properties (BASELINE sizes)
+def test_full_size_27pt_128_two_parts_properties():
+    """BASELINE config 3 (27-pt 128^3 per part, 2 parts, here both on one GPU): size-independent properties.
+    A*1 == b bit-exactly (G12), ghost values == owner values, linearity in x for power-of-two scalings."""
+    A, b = pa.build_p_matrix(ranks(2), 128, 128, 128, 256, 128, 128, 2, 1, 1)
+    assert pa.pmap(lambda m: (m.own_own.nnz, m.own_ghost.nnz), A.matrix_partition).items == [(55742968, 145924)] * 2
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, pa.pones(A.col_partition))
+    for got, exp in zip(y.own_values().items, b.own_values().items):
+        assert np.array_equal(got, exp)
+    g = A.col_partition
+    x = pa.pvector_from_function(lambda i: ((i.get_local_to_global() % 7) - 3.0) * (i.get_local_to_owner() == i.part), g)
+    pa.mul_(y, A, x)
+    for vals, ind in zip(x.local_values().items, g.items):
+        assert np.array_equal(vals, (ind.get_local_to_global() % 7) - 3.0)       # consistent!: ghosts == owners
+    y4 = pa.pzeros(A.row_partition)
+    x4 = pa.pvector_from_function(lambda i: 4.0 * ((i.get_local_to_global() % 7) - 3.0), g)
+    pa.mul_(y4, A, x4)
+    for a_, b_ in zip(y.own_values().items, y4.own_values().items):
+        assert np.array_equal(4.0 * a_, b_)

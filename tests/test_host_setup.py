@@ -1,0 +1,161 @@
+"""Host-side set-up of the product (native helpers + python mirror) against the oracle, bit-exact.
+No GPU needed: nothing here touches the device path."""
+import numpy as np
+import pytest
+
+from __graft_entry__ import load_package
+
+pa = load_package()
+
+
+def ranks(n):
+    return pa.DebugArray(range(1, n + 1))
+
+
+def test_local_range_goldens(golden):
+    for p, np_, n, g, per, lo, hi in golden["local_range"]["cases"]:
+        assert pa.local_range(p, np_, n, g, per) == (lo, hi)
+
+
+def test_uniform_partition_goldens(golden):
+    for case in golden["uniform_partition"]:
+        gh = tuple(case["ghost"]) if case["ghost"] else None
+        pe = tuple(case["periodic"]) if case["periodic"] else None
+        P = int(np.prod(case["np"]))
+        parts = pa.uniform_partition(ranks(P), tuple(case["np"]), tuple(case["n"]), gh, pe)
+        got = [i.get_local_to_global().tolist() for i in parts.items]
+        assert got == case["local_to_global"], case["src"]
+
+
+def test_variable_partition_goldens(golden):
+    for case in golden["variable_partition"]:
+        parts = pa.variable_partition(pa.DebugArray(case["n_own"]), sum(case["n_own"]))
+        assert [i.get_local_to_global().tolist() for i in parts.items] == case["local_to_global"]
+
+
+def test_find_owner_golden(golden):
+    c = golden["find_owner"]
+    parts = pa.uniform_partition(ranks(4), tuple(c["np"]), tuple(c["n"]))
+    got = pa.find_owner(parts, pa.DebugArray([np.array(g) for g in c["gids"]]))
+    assert [g.tolist() for g in got.items] == c["owners"]
+
+
+def test_exchange_goldens(golden):
+    for c in golden["exchange"]:
+        snd_ids = pa.DebugArray(c["snd_ids"])
+        graph = pa.exchange_graph(snd_ids, None if c["rcv_ids"] is None else pa.DebugArray(c["rcv_ids"]))
+        disc = pa.find_rcv_ids_gather_scatter(snd_ids)
+        if c["rcv_ids"] is not None:
+            assert [list(map(int, r)) for r in disc.items] == c["rcv_ids"]
+        rcv = pa.exchange(pa.DebugArray(c["snd_literal"]), graph)
+        assert rcv.items == c["rcv"]
+    c = golden["exchange_jagged"]
+    graph = pa.ExchangeGraph(pa.DebugArray(c["snd_ids"]), pa.DebugArray(c["rcv_ids"]))
+    rcv = pa.exchange(pa.DebugArray(c["snd"]), graph)
+    assert rcv.items == c["rcv"]
+
+
+def test_scalar_indexing_is_an_error():
+    a = ranks(3)
+    with pytest.raises(IndexError):
+        a[0]
+
+
+@pytest.mark.parametrize("shape,parts", [((4, 4, 4), (2, 2, 2)), ((4, 4, 4), (2, 1, 1)), ((3, 5, 4), (2, 2, 1)),
+                                         ((4, 4, 4), (1, 1, 1))])
+def test_hpcg_setup_matches_oracle(orc, shape, parts):
+    nx, ny, nz = shape
+    px, py, pz = parts
+    P = px * py * pz
+    Ao, bo, _ = orc.hpcg_build_p_matrix(nx, ny, nz, px, py, pz)
+    row_partition = pa.uniform_partition(ranks(P), parts, (px * nx, py * ny, pz * nz))
+
+    def gen(r):
+        return pa.build_matrix(nx, ny, nz, px * nx, py * ny, pz * nz, r.ranges[0][0], r.ranges[1][0], r.ranges[2][0])
+
+    I, J, V, b, Ib = pa.tuple_of_arrays(pa.pmap(gen, row_partition))
+    owners = pa.find_owner(row_partition, J)
+    cols = pa.pmap(pa.union_ghost, row_partition, J, owners)
+    ns, nr = pa.assembly_neighbors(cols)
+    ls, lr = pa.assembly_local_indices(cols, ns, nr)
+    ons, onr = orc.assembly_neighbors(Ao.cols)
+    ols, olr = orc.assembly_local_indices(Ao.cols, ons, onr)
+    for k in range(P):
+        c, oc = cols.items[k], Ao.cols[k]
+        assert np.array_equal(c.get_local_to_global(), oc.local_to_global)       # ghost numbering: first-seen
+        assert np.array_equal(c.get_local_to_owner(), oc.local_to_owner)
+        assert np.array_equal(ns.items[k], ons[k]) and np.array_equal(nr.items[k], onr[k])
+        assert np.array_equal(ls.items[k].data, ols[k].data) and np.array_equal(ls.items[k].ptrs, ols[k].ptrs)
+        assert np.array_equal(lr.items[k].data, olr[k].data) and np.array_equal(lr.items[k].ptrs, olr[k].ptrs)
+        r = row_partition.items[k]
+        A = pa.sparse_matrix(r.global_to_local(I.items[k]), c.global_to_local(J.items[k]), V.items[k], r.n_local, c.n_local)
+        M = Ao.matrix_partition[k]
+        assert np.array_equal(A.rowptr, M.rowptr) and np.array_equal(A.colval, M.colval) and np.array_equal(A.nzval, M.nzval)
+        oo, oh = pa.split_format_locally(A, r, c)
+        for mine, ref in ((oo, Ao.blocks[k].own_own), (oh, Ao.blocks[k].own_ghost)):
+            assert (mine.m, mine.n) == (ref.m, ref.n)
+            assert np.array_equal(mine.rowptr, ref.rowptr) and np.array_equal(mine.colval, ref.colval)
+            assert np.array_equal(mine.nzval, ref.nzval)
+        assert np.array_equal(b.items[k], bo[k][:r.n_own])
+
+
+def test_laplacian_fdm_matches_oracle(orc):
+    n, parts = (5, 4, 3), (2, 2, 1)
+    I, J, V, rows, _ = pa.laplacian_fdm(n, parts, ranks(4))
+    Io, Jo, Vo, _, _ = orc.laplacian_fdm(n, parts)
+    for k in range(4):
+        assert np.array_equal(I.items[k], Io[k]) and np.array_equal(J.items[k], Jo[k]) and np.array_equal(V.items[k], Vo[k])
+    # 2-D and 1-D too
+    for n, parts in (((6, 5), (2, 2)), ((9,), (3,))):
+        P = int(np.prod(parts))
+        I, J, V, _, _ = pa.laplacian_fdm(n, parts, ranks(P))
+        Io, Jo, Vo, _, _ = orc.laplacian_fdm(n, parts)
+        for k in range(P):
+            assert np.array_equal(J.items[k], Jo[k]) and np.array_equal(V.items[k], Vo[k])
+
+
+def test_compresscoo_duplicates_and_skip(orc, golden):
+    c = golden["sparse_utils_mat"]
+    A = pa.compresscoo(c["I"], c["J"], c["V"], c["m"], c["n"])
+    O = orc.compresscoo_csr(c["I"], c["J"], c["V"], c["m"], c["n"])
+    assert np.array_equal(A.rowptr, O.rowptr) and np.array_equal(A.colval, O.colval) and np.array_equal(A.nzval, O.nzval)
+    rng = np.random.default_rng(0)
+    I = rng.integers(0, 9, 200)      # some ids < 1: rewritten to (1,1,0.0) for CSR (Appendix A of SURVEY.md)
+    J = rng.integers(0, 7, 200)
+    V = rng.standard_normal(200)
+    A = pa.compresscoo(I, J, V, 8, 6, skip=True)
+    O = orc.compresscoo_csr(I, J, V, 8, 6, skip=True)
+    assert np.array_equal(A.rowptr, O.rowptr) and np.array_equal(A.colval, O.colval) and np.array_equal(A.nzval, O.nzval)
+    E = pa.compresscoo(I[:0], J[:0], V[:0], 0, 5, skip=True)
+    assert E.nnz == 0 and E.rowptr.tolist() == [1]
+
+
+def test_hand_partition_plans_match_oracle(orc, golden):
+    c = golden["p_vector_local_indices"]
+    parts = pa.DebugArray([pa.LocalIndices(c["n"], p + 1, local_to_global=g, local_to_owner=o)
+                           for p, (g, o) in enumerate(zip(c["local_to_global"], c["local_to_owner"]))])
+    oparts = [orc.local_indices(c["n"], p + 1, g, o)
+              for p, (g, o) in enumerate(zip(c["local_to_global"], c["local_to_owner"]))]
+    ns, nr = pa.assembly_neighbors(parts)
+    ls, lr = pa.assembly_local_indices(parts, ns, nr)
+    ons, onr = orc.assembly_neighbors(oparts)
+    ols, olr = orc.assembly_local_indices(oparts, ons, onr)
+    for k in range(4):
+        assert np.array_equal(ns.items[k], ons[k]) and np.array_equal(nr.items[k], onr[k])
+        assert ls.items[k].tolists() == ols[k].tolists() and lr.items[k].tolists() == olr[k].tolists()
+
+
+def test_compute_optimal_shape():
+    assert [pa.compute_optimal_shape_XYZ(p) for p in (1, 2, 4, 8, 6, 3)] == \
+        [(1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 2, 2), (2, 3, 1), (3, 1, 1)]
+
+
+def test_device_path_fails_loudly_without_gpu():
+    import ctypes
+    n = ctypes.c_int()
+    import pa_amd._lib as L
+    L.call("pa_device_count", ctypes.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(pa.PAError):
+        pa.Context()
