@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- HPCG 27-point distributed SpMV (mul!) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one mul!(c, A, b) of the reference (src/p_sparse_matrix.jl:2090-2103) on the HPCG 27-point
+matrix, 256^3 rows per part (BASELINE.json: the size the metric is quoted on): consistent!(b) [pack ->
+RCCL neighbour exchange -> unpack] overlapped with own x own, then own x ghost.  Weak scaling: part p of an
+(npx,npy,npz) = compute_optimal_shape_XYZ(N) grid lives on GPU p-1.  Inputs are resident in HBM before the
+timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=256, help="grid points per direction per part")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(n):
+    """The reference's spmv_csr! loop (src/sparse_utils.jl:649-669) restated in C (oracle/pa_oracle.c,
+    -O3 -ffp-contract=off), one core, on a bounded sample: the same 27-point matrix at n^3 rows."""
+    import ctypes as C
+    from __graft_entry__ import load_oracle
+    orc = load_oracle()
+    K = orc.oracle_c()
+    if not hasattr(K, "lib"):
+        return None
+    lib = K.lib
+    lib.orc_hpcg_csr_single.restype = C.c_int64
+    lib.orc_hpcg_csr_single.argtypes = [C.c_int32] * 3 + [C.c_void_p] * 3
+    rows = n ** 3
+    rowptr = np.zeros(rows + 1, np.int32)
+    nnz = lib.orc_hpcg_csr_single(n, n, n, rowptr.ctypes.data, None, None)
+    colval, nzval = np.zeros(nnz, np.int32), np.zeros(nnz, np.float64)
+    lib.orc_hpcg_csr_single(n, n, n, rowptr.ctypes.data, colval.ctypes.data, nzval.ctypes.data)
+    x = orc.hash_x(np.arange(1, rows + 1))
+    y = np.zeros(rows)
+    A = orc.CSR(rows, rows, rowptr, colval, nzval)
+    K.spmv_csr(y, x, A)                       # warm
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        K.spmv_csr(y, x, A)
+        reps += 1
+        dt = time.perf_counter() - t0
+        if dt > 12.0 or reps >= 200:
+            break
+    t = dt / reps
+    return {"value": round(2.0 * nnz / t / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"27-pt HPCG matrix {n}^3 rows ({nnz} nnz), {reps} x spmv_csr! (oracle/pa_oracle.c) in {dt:.1f} s",
+            "gbps_algorithmic": round((nnz * 12 + (rows + 1) * 4 + rows * 16) / t / 1e9, 3)}
+
+
+def main():
+    args = parse()
+    N = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    if N > 1 or world > 1:
+        assert world == N, f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {N}"
+        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        torch.cuda.set_device(local)
+        dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    pa = load_package()
+    ctx = pa.context()
+
+    n = args.n
+    npx, npy, npz = pa.compute_optimal_shape_XYZ(N)
+    gn = (npx * n, npy * n, npz * n)
+    if N > 1:
+        pa.init_comm()
+        ranks = pa.with_torchdist(lambda distribute: distribute(range(1, N + 1)))
+    else:
+        ranks = pa.DebugArray([1])
+
+    t_setup = time.perf_counter()
+    A, b = pa.build_p_matrix(ranks, n, n, n, *gn, npx, npy, npz)
+    # x[gid] = ((gid*2654435761) mod 2^32)/2^32 on OWN entries only: mul! must bring the ghosts
+    def xfun(ind):
+        g = ind.get_local_to_global().astype(np.uint64)
+        v = ((g * np.uint64(2654435761)) % np.uint64(2 ** 32)).astype(np.float64) / float(2 ** 32)
+        v[ind.n_own:] = 0.0
+        return v
+    x = pa.pvector_from_function(xfun, A.col_partition)
+    y = pa.pzeros(A.row_partition)
+    ctx.sync()
+    t_setup = time.perf_counter() - t_setup
+
+    # ---- parity gate before any timing counts: A*1 == b bit-exactly; ghosts == owner values
+    ones = pa.pones(A.col_partition)
+    pa.mul_(y, A, ones)
+    ok = all(np.array_equal(g, e) for g, e in zip(pa.local_items(y.own_values()), pa.local_items(b.own_values())))
+    pa.mul_(y, A, x)
+    for vals, ind in zip(pa.local_items(x.local_values()), pa.local_items(A.col_partition)):
+        g = ind.get_local_to_global().astype(np.uint64)
+        want = ((g * np.uint64(2654435761)) % np.uint64(2 ** 32)).astype(np.float64) / float(2 ** 32)
+        ok = ok and np.array_equal(vals, want)
+    if N > 1:
+        flag = torch.tensor([1 if ok else 0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+    if not ok:
+        raise SystemExit("parity gate failed: A*1 != b or ghost values differ from their owners")
+
+    blk = pa.local_items(A.matrix_partition)[0]
+    ind = pa.local_items(A.col_partition)[0]
+    nnz_oo, nnz_oh, n_own, n_ghost = blk.own_own.nnz, blk.own_ghost.nnz, ind.n_own, ind.n_ghost
+
+    # ---- HIP events around the dominant kernel (own x own SpMV) inside the timed region, compute stream
+    import pa_amd._lib as L
+    xv, yv = pa.local_items(x.vector_partition)[0], pa.local_items(y.vector_partition)[0]
+    ev0 = [ctx.event() for _ in range(args.steps)]
+    ev1 = [ctx.event() for _ in range(args.steps)]
+
+    def step(k=None):
+        # mul!(c,a,b): src/p_sparse_matrix.jl:2098-2101
+        t = pa.consistent_(x)
+        if k is not None:
+            ev0[k].record(L.STREAM_COMPUTE)
+        pa.spmv_(yv, blk.own_own, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
+        if k is not None:
+            ev1[k].record(L.STREAM_COMPUTE)
+        t.wait()
+        pa.spmv_(yv, blk.own_ghost, xv, L.SEG_GHOST, L.SEG_OWN, 1.0, 1.0)
+
+    def barrier():
+        ctx.sync()
+        if N > 1:
+            dist.barrier()
+            ctx.sync()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if N > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms_per_step = dt / args.steps * 1e3
+    kern_ms = float(np.mean([a.elapsed_ms(b_) for a, b_ in zip(ev0, ev1)]))
+
+    nnz = nnz_oo + nnz_oh
+    if N > 1:
+        tot = torch.tensor([nnz], dtype=torch.int64)
+        dist.all_reduce(tot)
+        nnz_total = int(tot.item())
+    else:
+        nnz_total = nnz
+    flops_total = 2.0 * nnz_total
+    value = flops_total / (ms_per_step * 1e-3) / 1e9
+
+    # algorithmic bytes: whole mul! per part, and the dominant kernel's share
+    bytes_mul = nnz * 12 + (n_own + 1) * 4 + (n_own + n_ghost) * 8 + n_own * 8
+    bytes_oo = nnz_oo * 12 + (n_own + 1) * 4 + n_own * 8 + n_own * 8
+    ach = bytes_oo / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            "metric": "HPCG 27-pt SpMV GFLOP/s + achieved HBM GB/s per GPU",
+            "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"HPCG 27-pt stencil {n}^3 rows per part, {N} part(s) as ({npx},{npy},{npz}), "
+                                   "mul! = consistent!(pack+exchange+unpack) overlapped with own*own, then own*ghost",
+                       "rows_per_part": n_own, "nnz_per_part": nnz, "nnz_own_own": nnz_oo, "nnz_own_ghost": nnz_oh,
+                       "ghosts_per_part": n_ghost, "index_type": "Int32", "transport": "rccl-p2p" if N > 1 else "none(1 part)"},
+            "gflops_per_gpu": round(value / N, 2),
+            "hbm_gbps_per_gpu_algorithmic": round(bytes_mul / (ms_per_step * 1e-3) / 1e9, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_rowsplit (own x own)", "achieved": round(ach, 1),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_oo, "avg_launch_ms": round(kern_ms, 4)},
+            "parity_gate": "A*1==b bit-exact; ghosts==owners bit-exact",
+            "setup_s": round(t_setup, 1),
+        }
+        if N == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.cpu_n)
+            if cb:
+                out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if N > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

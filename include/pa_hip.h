@@ -193,6 +193,18 @@ int pa_host_split_csr(int64_t n_own_rows, int64_t n_own_cols, int64_t n_ghost_co
                       double *oo_nzval, int32_t *oh_rowptr, int32_t *oh_colval, double *oh_nzval,
                       int64_t *nnz_oo, int64_t *nnz_oh);
 
+/* Fused HPCG set-up for large parts: the same arrays as the chain above (build_matrix -> find_owner ->
+ * union_ghost -> map_global_to_local! -> compresscoo -> split_format_locally, HPCG/src/sparse_matrix.jl:105-122)
+ * without materialising the Int64 COO triplets.  Pass 1 returns the ghost gids in first-seen order
+ * (src/p_range.jl:205-241) and the block sizes; pass 2 writes own_own / own_ghost (1-based Int32) and b. */
+int pa_host_hpcg_ghosts(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                        int64_t giy0, int64_t giz0, int64_t *ghost_gids, int64_t *n_ghost, int64_t *nnz_oo,
+                        int64_t *nnz_oh);
+int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                           int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost, int32_t *oo_rowptr,
+                           int32_t *oo_colval, double *oo_nzval, int32_t *oh_rowptr, int32_t *oh_colval,
+                           double *oh_nzval, double *b);
+
 #ifdef __cplusplus
 }
 #endif

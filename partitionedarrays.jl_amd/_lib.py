@@ -87,6 +87,8 @@ _SIGS = {
     "pa_host_global_to_local_block": [i32, P, P, P, P, i64, P, i64, P],
     "pa_host_compresscoo_csr": [P, P, P, i64, i64, i64, cint, P, P, P, C.POINTER(i64)],
     "pa_host_split_csr": [i64, i64, i64, P, P, P, P, P, P, P, P, P, C.POINTER(i64), C.POINTER(i64)],
+    "pa_host_hpcg_ghosts": [i64] * 9 + [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
+    "pa_host_hpcg_split_csr": [i64] * 9 + [P, i64, P, P, P, P, P, P, P],
 }
 # every symbol the header declares (tests/test_abi.py checks this list against include/pa_hip.h)
 EXPORTS = ["pa_version", "pa_last_error"] + list(_SIGS)

@@ -244,3 +244,151 @@ extern "C" int pa_host_split_csr(int64_t n_own_rows, int64_t n_own_cols, int64_t
   *nnz_oh = b;
   return PA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Fused HPCG set-up for large parts (256^3 per part = 4.5e8 stored entries).
+//
+// Same result, bit for bit, as the generic chain  build_matrix -> find_owner -> union_ghost ->
+// map_global_to_local! -> compresscoo -> split_format_locally  (HPCG/src/sparse_matrix.jl:105-122),
+// but without materialising the Int64 COO triplets (3 x 3.6 GB per part at 256^3): the ghost numbering
+// only depends on the boundary rows of the COO stream, and each CSR row can be written directly.
+// tests/test_host_setup.py checks fused == generic == oracle on small grids.
+// ------------------------------------------------------------------------------------------------
+#include <thread>
+
+namespace {
+struct HpcgGeom {
+  int64_t nx, ny, nz, gnx, gny, gnz, x0, y0, z0;  // x0.. = global coords (1-based) of the first own node
+  inline bool in_grid(int64_t gx, int64_t gy, int64_t gz) const {
+    return gx > 0 && gx < gnx + 1 && gy > 0 && gy < gny + 1 && gz > 0 && gz < gnz + 1;
+  }
+  inline bool in_own(int64_t gx, int64_t gy, int64_t gz) const {
+    return gx >= x0 && gx < x0 + nx && gy >= y0 && gy < y0 + ny && gz >= z0 && gz < z0 + nz;
+  }
+  inline int64_t gid(int64_t gx, int64_t gy, int64_t gz) const { return (gz - 1) * gnx * gny + (gy - 1) * gnx + (gx - 1) + 1; }
+  inline int64_t own_id(int64_t gx, int64_t gy, int64_t gz) const {  // 1-based own id, column-major in the own box
+    return (gx - x0) + (gy - y0) * nx + (gz - z0) * nx * ny + 1;
+  }
+};
+
+// per dimension: how many of s in {-1,0,1} land inside the own box (a) / inside the grid but outside the box (b)
+inline void dim_counts(int64_t g, int64_t lo, int64_t n_own, int64_t gn, int &a, int &b) {
+  a = 0; b = 0;
+  for (int s = -1; s <= 1; ++s) {
+    const int64_t c = g + s;
+    if (c < 1 || c > gn) continue;
+    if (c >= lo && c < lo + n_own) ++a; else ++b;
+  }
+}
+
+int n_threads_for(int64_t work) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int t = hw ? (int)hw : 4;
+  if (const char *e = getenv("PA_HOST_THREADS")) t = atoi(e);
+  if (t < 1) t = 1;
+  if (t > 32) t = 32;
+  if (work < (int64_t)1 << 20) t = 1;
+  return t;
+}
+}  // namespace
+
+// Pass 1: ghost gids in first-seen order of the COO stream (iz,iy,ix ; sz,sy,sx) and the block sizes.
+// ghost_gids may be NULL (count only); otherwise it must hold *n_ghost entries from a previous call.
+extern "C" int pa_host_hpcg_ghosts(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                                   int64_t giy0, int64_t giz0, int64_t *ghost_gids, int64_t *n_ghost, int64_t *nnz_oo,
+                                   int64_t *nnz_oh) {
+  PA_REQUIRE(nx > 0 && ny > 0 && nz > 0 && n_ghost && nnz_oo && nnz_oh, "bad arguments");
+  const HpcgGeom G{nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0};
+  std::unordered_set<int64_t> seen;
+  int64_t m = 0, oo = 0, oh = 0;
+  for (int64_t iz = 0; iz < nz; ++iz) {
+    int az, bz; dim_counts(giz0 + iz, giz0, nz, gnz, az, bz);
+    for (int64_t iy = 0; iy < ny; ++iy) {
+      int ay, by; dim_counts(giy0 + iy, giy0, ny, gny, ay, by);
+      for (int64_t ix = 0; ix < nx; ++ix) {
+        int ax, bx; dim_counts(gix0 + ix, gix0, nx, gnx, ax, bx);
+        const int64_t tot = (int64_t)(ax + bx) * (ay + by) * (az + bz), own = (int64_t)ax * ay * az;
+        oo += own; oh += tot - own;
+        if (tot == own) continue;  // interior row: no ghost column
+        const int64_t gx = gix0 + ix, gy = giy0 + iy, gz = giz0 + iz;
+        for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
+          if (!G.in_grid(gx + sx, gy + sy, gz + sz) || G.in_own(gx + sx, gy + sy, gz + sz)) continue;
+          const int64_t g = G.gid(gx + sx, gy + sy, gz + sz);
+          if (seen.insert(g).second) { if (ghost_gids) ghost_gids[m] = g; ++m; }
+        }
+      }
+    }
+  }
+  *n_ghost = m; *nnz_oo = oo; *nnz_oh = oh;
+  return PA_OK;
+}
+
+// Pass 2: own_own / own_ghost CSR (1-based Int32, sorted columns) and b, written row by row in parallel.
+extern "C" int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                                      int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost,
+                                      int32_t *oo_rowptr, int32_t *oo_colval, double *oo_nzval, int32_t *oh_rowptr,
+                                      int32_t *oh_colval, double *oh_nzval, double *b) {
+  PA_REQUIRE(nx > 0 && ny > 0 && nz > 0 && oo_rowptr && oh_rowptr && oo_colval && oo_nzval && b, "bad arguments");
+  PA_REQUIRE(n_ghost == 0 || (ghost_gids && oh_colval && oh_nzval), "ghost arrays are NULL");
+  const HpcgGeom G{nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0};
+  const int64_t nrows = nx * ny * nz;
+  std::unordered_map<int64_t, int32_t> g2g;
+  g2g.reserve((size_t)n_ghost * 2 + 1);
+  for (int64_t k = 0; k < n_ghost; ++k) g2g.emplace(ghost_gids[k], (int32_t)(k + 1));
+  // row pointers by closed-form counts
+  {
+    int64_t a = 1, c = 1, row = 0;
+    oo_rowptr[0] = 1; oh_rowptr[0] = 1;
+    for (int64_t iz = 0; iz < nz; ++iz) {
+      int az, bz; dim_counts(giz0 + iz, giz0, nz, gnz, az, bz);
+      for (int64_t iy = 0; iy < ny; ++iy) {
+        int ay, by; dim_counts(giy0 + iy, giy0, ny, gny, ay, by);
+        for (int64_t ix = 0; ix < nx; ++ix) {
+          int ax, bx; dim_counts(gix0 + ix, gix0, nx, gnx, ax, bx);
+          const int64_t tot = (int64_t)(ax + bx) * (ay + by) * (az + bz), own = (int64_t)ax * ay * az;
+          a += own; c += tot - own; ++row;
+          PA_REQUIRE(a < 2147483647 && c < 2147483647, "block too large for Int32 row pointers");
+          oo_rowptr[row] = (int32_t)a; oh_rowptr[row] = (int32_t)c;
+          b[row - 1] = 27.0 - (double)tot;
+        }
+      }
+    }
+  }
+  const int T = n_threads_for(nrows * 27);
+  bool bad = false;
+  auto work = [&](int t) {
+    const int64_t z_lo = nz * t / T, z_hi = nz * (t + 1) / T;
+    for (int64_t iz = z_lo; iz < z_hi; ++iz)
+      for (int64_t iy = 0; iy < ny; ++iy)
+        for (int64_t ix = 0; ix < nx; ++ix) {
+          const int64_t row = iz * nx * ny + iy * nx + ix;
+          const int64_t gx = gix0 + ix, gy = giy0 + iy, gz = giz0 + iz;
+          const int64_t cur = G.gid(gx, gy, gz);
+          int64_t p = oo_rowptr[row] - 1, q0 = oh_rowptr[row] - 1, q = q0;
+          for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
+            const int64_t cx = gx + sx, cy = gy + sy, cz = gz + sz;
+            if (!G.in_grid(cx, cy, cz)) continue;
+            const double v = (G.gid(cx, cy, cz) == cur) ? 26.0 : -1.0;
+            if (G.in_own(cx, cy, cz)) {
+              oo_colval[p] = (int32_t)G.own_id(cx, cy, cz);  // ascending in (sz,sy,sx) order
+              oo_nzval[p] = v; ++p;
+            } else {
+              auto it = g2g.find(G.gid(cx, cy, cz));
+              if (it == g2g.end()) { bad = true; continue; }
+              // insertion sort by ghost id inside the row (compresscoo sorts columns)
+              int64_t k = q;
+              while (k > q0 && oh_colval[k - 1] > it->second) { oh_colval[k] = oh_colval[k - 1]; oh_nzval[k] = oh_nzval[k - 1]; --k; }
+              oh_colval[k] = it->second; oh_nzval[k] = v; ++q;
+            }
+          }
+        }
+  };
+  if (T == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  PA_REQUIRE(!bad, "a ghost column is missing from ghost_gids (call pa_host_hpcg_ghosts first)");
+  return PA_OK;
+}

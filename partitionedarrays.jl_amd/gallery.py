@@ -76,9 +76,52 @@ def compute_optimal_shape_XYZ(np_):
     raise NotImplementedError("compute_optimal_shape_XYZ: general 3-subset search not needed for 1..8 parts")
 
 
-def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=False):
-    """HPCG build_p_matrix (HPCG/src/sparse_matrix.jl:105-122) -> A (device PSparseMatrix), b (PVector)."""
+def build_split_blocks_fused(my_rows, nx, ny, nz, gnx, gny, gnz):
+    """One part of build_p_matrix without the Int64 COO triplets (csrc/pa_host.cpp, "Fused HPCG set-up"):
+    returns (col LocalIndices with first-seen ghosts, own_own HostCSR, own_ghost HostCSR, b)."""
+    from .p_range import LocalIndices, find_owner
+    from .p_sparse_matrix import HostCSR
+    from .primitives import DebugArray
+    g0 = [int(my_rows.ranges[d][0]) for d in range(3)]
+    args = [int(v) for v in (nx, ny, nz, gnx, gny, gnz, *g0)]
+    ng, noo, noh = C.c_int64(), C.c_int64(), C.c_int64()
+    L.call("pa_host_hpcg_ghosts", *args, None, C.byref(ng), C.byref(noo), C.byref(noh))
+    ghosts = np.zeros(ng.value, I64)
+    L.call("pa_host_hpcg_ghosts", *args, L.ptr(ghosts), C.byref(ng), C.byref(noo), C.byref(noh))
+    owners = find_owner(DebugArray([my_rows]), DebugArray([ghosts])).items[0]
+    cols = LocalIndices(my_rows.n_global, my_rows.part, np_=my_rows.np_, n=my_rows.n, ranges=my_rows.ranges,
+                        starts=my_rows.starts, ghost_to_global=ghosts, ghost_to_owner=owners)
+    n = nx * ny * nz
+    oo = HostCSR(n, n, np.zeros(n + 1, np.int32), np.zeros(noo.value, np.int32), np.zeros(noo.value, F64))
+    oh = HostCSR(n, ng.value, np.zeros(n + 1, np.int32), np.zeros(noh.value, np.int32), np.zeros(noh.value, F64))
+    b = np.zeros(n, F64)
+    L.call("pa_host_hpcg_split_csr", *args, L.ptr(ghosts), ng.value, L.ptr(oo.rowptr), L.ptr(oo.colval), L.ptr(oo.nzval),
+           L.ptr(oh.rowptr), L.ptr(oh.colval), L.ptr(oh.nzval), L.ptr(b))
+    return cols, oo, oh, b
+
+
+def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=False, fused=None):
+    """HPCG build_p_matrix (HPCG/src/sparse_matrix.jl:105-122) -> A (device PSparseMatrix), b (PVector).
+
+    fused=False: the reference's chain, step by step (build_matrix -> find_owner -> union_ghost -> psparse).
+    fused=True : the same arrays produced by the fused native generator (no COO triplets in host memory);
+                 default for parts of >= 2^18 rows.  tests/test_host_setup.py pins fused == chain == oracle."""
+    from .p_sparse_matrix import PSparseMatrix, SplitMatrixBlocks, DeviceCSR
+    from .p_vector import PVector, DeviceVector
     row_partition = uniform_partition(ranks, (npx, npy, npz), (gnx, gny, gnz))
+    if fused is None:
+        fused = nx * ny * nz >= (1 << 18)
+    if fused:
+        def one(my_rows):
+            cols, oo, oh, b = build_split_blocks_fused(my_rows, nx, ny, nz, gnx, gny, gnz)
+            blk = SplitMatrixBlocks(DeviceCSR(oo), DeviceCSR(oh))
+            v = DeviceVector(cols.n_own, cols.n_ghost)
+            v.upload(b, 0)
+            return cols, blk, v, ((oo, oh) if keep_host else None)
+
+        cols, blocks, bvals, host = tuple_of_arrays(pmap(one, row_partition))
+        A = PSparseMatrix(blocks, row_partition, cols, True, host if keep_host else None)
+        return A, PVector(bvals, cols)
 
     def gen(my_rows):
         g0 = int(my_rows.ranges[0][0]), int(my_rows.ranges[1][0]), int(my_rows.ranges[2][0])   # Tuple(cis[first(my_rows)])

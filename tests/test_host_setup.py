@@ -159,3 +159,23 @@ def test_device_path_fails_loudly_without_gpu():
         pytest.skip("a GPU is visible")
     with pytest.raises(pa.PAError):
         pa.Context()
+
+
+@pytest.mark.parametrize("shape,parts", [((4, 4, 4), (2, 2, 2)), ((5, 3, 6), (2, 2, 1)), ((6, 4, 2), (2, 1, 1)),
+                                         ((4, 4, 4), (1, 1, 1)), ((2, 2, 2), (3, 2, 2)), ((64, 64, 64), (1, 2, 1))])
+def test_fused_hpcg_setup_equals_oracle(orc, shape, parts):
+    """The fused generator used for 256^3 parts writes exactly the arrays of the step-by-step chain."""
+    nx, ny, nz = shape
+    px, py, pz = parts
+    P = px * py * pz
+    Ao, bo, _ = orc.hpcg_build_p_matrix(nx, ny, nz, px, py, pz)
+    rows = pa.uniform_partition(ranks(P), parts, (px * nx, py * ny, pz * nz))
+    for k, r in enumerate(rows.items):
+        cols, oo, oh, b = pa.build_split_blocks_fused(r, nx, ny, nz, px * nx, py * ny, pz * nz)
+        assert np.array_equal(cols.get_local_to_global(), Ao.cols[k].local_to_global)
+        assert np.array_equal(cols.get_local_to_owner(), Ao.cols[k].local_to_owner)
+        for mine, ref in ((oo, Ao.blocks[k].own_own), (oh, Ao.blocks[k].own_ghost)):
+            assert (mine.m, mine.n) == (ref.m, ref.n)
+            assert np.array_equal(mine.rowptr, ref.rowptr) and np.array_equal(mine.colval, ref.colval)
+            assert np.array_equal(mine.nzval, ref.nzval)
+        assert np.array_equal(b, bo[k][:r.n_own])
