@@ -183,6 +183,19 @@ def main():
     bytes_oo = nnz_oo * 12 + (n_own + 1) * 4 + n_own * 8 + n_own * 8
     ach = bytes_oo / (kern_ms * 1e-3) / 1e9
 
+    # measured HBM traffic of the dominant kernel: PMC passes are separate rocprofv3 runs (never inside a timed
+    # run); their per-launch summary is committed under profiles/ and quoted here (null when absent).
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+        if cands and n == 256:
+            pm = json.load(open(cands[-1]))["pmc_per_launch"]["k_spmv_rowsplit"]
+            traffic = round(pm["fetch_bytes_gfx950_corrected"] + pm["write_bytes"])
+            traffic_src = os.path.relpath(cands[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1-GPU 256^3 run)"
+    except Exception:
+        pass
+
     if rank == 0:
         out = {
             "metric": "HPCG 27-pt SpMV GFLOP/s + achieved HBM GB/s per GPU",
@@ -196,7 +209,7 @@ def main():
             "gflops_per_gpu": round(value / N, 2),
             "hbm_gbps_per_gpu_algorithmic": round(bytes_mul / (ms_per_step * 1e-3) / 1e9, 1),
             "roofline": {"bound": "hbm", "kernel": "k_spmv_rowsplit (own x own)", "achieved": round(ach, 1),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_oo, "avg_launch_ms": round(kern_ms, 4)},
             "parity_gate": "A*1==b bit-exact; ghosts==owners bit-exact",
             "setup_s": round(t_setup, 1),

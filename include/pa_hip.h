@@ -20,8 +20,9 @@
  *    A pa_ctx is driven by one host thread at a time (the reference is single-threaded per rank).
  *  - the caller keeps ownership of every host array; the library copies what it needs.
  *  - fp64 values; the per-row summation order of pa_spmv is the reference's (ascending p, one
- *    rounding per multiply and per add, no FMA) for every row of at most PA_SPMV_CHUNK_NNZ-3
- *    stored entries, so results are bit-identical to spmv_csr! / SparseMatricesCSR.mul!.
+ *    rounding per multiply and per add, no FMA) for every row -- rows longer than one LDS chunk
+ *    (PA_SPMV_CHUNK_NNZ) are walked window by window in the same order -- so results are
+ *    bit-identical to spmv_csr! / SparseMatricesCSR.mul!.
  */
 #ifndef PA_HIP_H
 #define PA_HIP_H
@@ -49,7 +50,7 @@ extern "C" {
 #define PA_STREAM_COMPUTE 0
 #define PA_STREAM_COMM 1
 
-#define PA_SPMV_CHUNK_NNZ 2048   /* LDS-staged products per workgroup (16 KiB of fp64) */
+#define PA_SPMV_CHUNK_NNZ 1024   /* LDS-staged products per workgroup (8 KiB of fp64) */
 
 typedef struct pa_ctx pa_ctx;     /* one device + its two streams                                  */
 typedef struct pa_vec pa_vec;     /* local values of one part of a PVector, layout [own | ghost]   */

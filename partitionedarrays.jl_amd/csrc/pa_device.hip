@@ -12,11 +12,11 @@
 // the reference's order, so SpMV is bit-identical to the CPU loop (no FMA contraction).
 //
 // SpMV design (bandwidth-bound; no MFMA on purpose):
-//   * host-side "row split": consecutive rows are grouped into chunks of <= 2048 stored entries
+//   * host-side "row split": consecutive rows are grouped into chunks of <= 1024 stored entries
 //     (PA_SPMV_CHUNK_NNZ); one 256-thread workgroup per chunk.
 //   * load phase: every lane streams 16-byte value pairs + 8-byte column pairs (fully coalesced,
 //     non-temporal: the matrix is read once and must not evict x from L2), gathers x through
-//     L1/L2, multiplies, and stages the products in LDS (16 KiB per workgroup).
+//     L1/L2, multiplies, and stages the products in LDS (8 KiB per workgroup).
 //   * reduce phase: one lane per row walks its products in LDS in ascending p -- the reference's
 //     left-to-right order -- and writes y.  64-wide wavefronts: lanes of a wave own consecutive rows,
 //     so their LDS reads are stride-(row length) apart: conflict-free for 27 (odd), 2-way for 18.
@@ -62,94 +62,12 @@ extern "C" int pa_device_count(int *count) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-typedef double d2 __attribute__((ext_vector_type(2)));
-typedef int i2 __attribute__((ext_vector_type(2)));
+#include "pa_spmv_kernel.h"
 
+// shipped configuration of the row-split kernel (chosen with probe/spmv_probe.hip on MI355X)
 constexpr int SPMV_BLK = 256;
-constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (8)
-static_assert(SPMV_NPT % 2 == 0, "pairs");
-
-// y[row] = beta*y[row] + sum_p (val[p]*x[col[p]])*alpha, products summed in ascending p.
-__global__ __launch_bounds__(SPMV_BLK) void k_spmv_rowsplit(
-    const int *__restrict__ crp, const int *__restrict__ col, const double *__restrict__ val,
-    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ chunk_row,
-    const int *__restrict__ row_ids, int n_chunks, int chunks_per_xcd, double alpha, double beta) {
-  __shared__ double prod[PA_SPMV_CHUNK_NNZ];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x;
-  const int chunk = (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
-  if (chunk >= n_chunks || (b >> 3) >= chunks_per_xcd) return;
-  const int r0 = chunk_row[chunk];
-  const int r1 = chunk_row[chunk + 1];
-  const int p0 = crp[r0];
-  const int p1 = crp[r1];
-  const int base = p0 & ~1;  // 16-byte aligned value pairs
-
-  if (p1 - base <= PA_SPMV_CHUNK_NNZ) {
-    // my first row's extent, fetched early so the latency hides under the matrix stream
-    int ra = 0, re = 0;
-    if (r0 + tid < r1) {
-      ra = crp[r0 + tid];
-      re = crp[r0 + tid + 1];
-    }
-    d2 v[SPMV_NPT / 2];
-    i2 c[SPMV_NPT / 2];
-#pragma unroll
-    for (int k = 0; k < SPMV_NPT / 2; ++k) {
-      const int idx = base + (k * SPMV_BLK + tid) * 2;
-      if (idx < p1) {
-        v[k] = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(val + idx));
-        c[k] = __builtin_nontemporal_load(reinterpret_cast<const i2 *>(col + idx));
-      } else {
-        v[k] = d2{0.0, 0.0};
-        c[k] = i2{0, 0};
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < SPMV_NPT / 2; ++k) {
-      d2 pr;
-      pr.x = v[k].x * x[c[k].x];
-      pr.y = v[k].y * x[c[k].y];
-      if (alpha != 1.0) {
-        pr.x = pr.x * alpha;
-        pr.y = pr.y * alpha;
-      }
-      *reinterpret_cast<d2 *>(&prod[(k * SPMV_BLK + tid) * 2]) = pr;
-    }
-    __syncthreads();
-    for (int r = r0 + tid; r < r1; r += SPMV_BLK) {
-      if (r != r0 + tid) {
-        ra = crp[r];
-        re = crp[r + 1];
-      }
-      const int row = row_ids ? row_ids[r] : r;
-      double acc = (beta == 0.0) ? 0.0 : beta * y[row];
-      const int a = ra - base, e = re - base;
-#pragma unroll 4
-      for (int p = a; p < e; ++p) acc = acc + prod[p];
-      y[row] = acc;
-    }
-  } else {
-    // one long row (more stored entries than a chunk holds): windows of 2048 products, summed by
-    // lane 0 in ascending p so that even this path keeps the reference's order.
-    const int row = row_ids ? row_ids[r0] : r0;
-    double acc = 0.0;
-    if (tid == 0) acc = (beta == 0.0) ? 0.0 : beta * y[row];
-    for (int w = p0; w < p1; w += PA_SPMV_CHUNK_NNZ) {
-      const int wend = min(w + PA_SPMV_CHUNK_NNZ, p1);
-      for (int idx = w + tid; idx < wend; idx += SPMV_BLK) {
-        double pr = val[idx] * x[col[idx]];
-        if (alpha != 1.0) pr = pr * alpha;
-        prod[idx - w] = pr;
-      }
-      __syncthreads();
-      if (tid == 0)
-        for (int p = 0; p < wend - w; ++p) acc = acc + prod[p];
-      __syncthreads();
-    }
-    if (tid == 0) y[row] = acc;
-  }
-}
+constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (4)
+constexpr bool SPMV_NT = true;
 
 __global__ void k_scale(double *__restrict__ y, int64_t n, double beta) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -493,23 +411,9 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std
     crp.swap(rp);
   }
   const int64_t nc = (int64_t)crp.size() - 1;
-  // row split: greedy chunks of consecutive rows with <= PA_SPMV_CHUNK_NNZ entries after 2-alignment
   std::vector<int32_t> chunk_row;
-  chunk_row.push_back(0);
   int64_t n_long = 0;
-  const int max_rows = 4096;
-  int64_t r = 0;
-  while (r < nc) {
-    const int64_t base = crp[r] & ~1;
-    int64_t e = r + 1;
-    if ((int64_t)crp[e] - base > PA_SPMV_CHUNK_NNZ) {
-      ++n_long;  // one long row on its own
-    } else {
-      while (e < nc && (int64_t)crp[e + 1] - base <= PA_SPMV_CHUNK_NNZ && e - r < max_rows) ++e;
-    }
-    chunk_row.push_back((int32_t)e);
-    r = e;
-  }
+  pa_build_chunks(crp.data(), nc, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
   pa_csr *A = new pa_csr();
   A->ctx = c; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
   A->n_crows = nc; A->n_chunks = (int64_t)chunk_row.size() - 1; A->n_nonempty = n_nonempty; A->n_long = n_long;
@@ -641,7 +545,7 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
   }
   if (A->n_chunks > 0) {
     const int cpx = (int)((A->n_chunks + 7) / 8);
-    hipLaunchKernelGGL(k_spmv_rowsplit, dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], A->d_crp, A->d_col, A->d_val,
+    hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT>), dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], A->d_crp, A->d_col, A->d_val,
                        x->d + xoff, y->d + yoff, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta);
   }
   PA_HIP(hipGetLastError());

@@ -1,0 +1,429 @@
+// spmv_probe.hip -- A/B harness for the row-split SpMV kernel on the HPCG 27-point matrix (one part,
+// n^3 rows).  Development tool: builds the matrix on the device, runs interleaved rounds of kernel
+// variants / ablations, prints median and min time and the algorithmic GB/s.  Not part of libpa_hip.so.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I.. -I../../../include spmv_probe.hip -o spmv_probe
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "pa_spmv_kernel.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+
+// ---- device-side generator of the single-part 27-point CSR (0-based) -------------------------------
+__global__ void k_gen(int n, const int *__restrict__ rp, int *__restrict__ col, double *__restrict__ val) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nrows = (long)n * n * n;
+  if (row >= nrows) return;
+  const int ix = row % n, iy = (row / n) % n, iz = row / ((long)n * n);
+  int p = rp[row];
+  for (int sz = -1; sz <= 1; ++sz) { if (iz + sz < 0 || iz + sz >= n) continue;
+    for (int sy = -1; sy <= 1; ++sy) { if (iy + sy < 0 || iy + sy >= n) continue;
+      for (int sx = -1; sx <= 1; ++sx) { if (ix + sx < 0 || ix + sx >= n) continue;
+        const long c = row + (long)sz * n * n + (long)sy * n + sx;
+        col[p] = (int)c; val[p] = (c == row) ? 26.0 : -1.0; ++p; } } }
+}
+__global__ void k_hashx(double *x, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = (double)((unsigned)((unsigned long)(i + 1) * 2654435761ul)) / 4294967296.0;
+}
+
+// ---- ablations ----------------------------------------------------------------------------------------
+template <int BLK, int NPT, bool NT, bool GATHER>
+__global__ __launch_bounds__(BLK) void k_stream(const int *__restrict__ col, const double *__restrict__ val,
+                                                const double *__restrict__ x, double *__restrict__ y, long nnz) {
+  const long base = (long)blockIdx.x * BLK * NPT;
+  double acc = 0.0;
+#pragma unroll
+  for (int k = 0; k < NPT / 2; ++k) {
+    const long idx = base + (long)(k * BLK + threadIdx.x) * 2;
+    if (idx < nnz) {
+      d2 v = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+      i2 c = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + idx));
+      if (GATHER) acc += v.x * x[c.x] + v.y * x[c.y];
+      else acc += v.x * (double)c.x + v.y * (double)c.y;
+    }
+  }
+  if (acc == 123.456) y[blockIdx.x] = acc;   // keep the loads alive, (almost) never store
+}
+
+__global__ void k_copy(const d2 *__restrict__ a, d2 *__restrict__ b, long n2) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n2; i += stride) b[i] = a[i];
+}
+__global__ void k_readsum(const d2 *__restrict__ a, double *out, long n2) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  double s = 0;
+  for (; i < n2; i += stride) { d2 v = __builtin_nontemporal_load(a + i); s += v.x + v.y; }
+  if (s == 123.456) out[0] = s;
+}
+
+// ---- persistent variant: a workgroup walks several chunks of its XCD's range ------------------------
+#define PA_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+template <int BLK, int NPT, bool NT, bool RAW = false>
+__global__ __launch_bounds__(BLK) void k_spmv_persistent(
+    const int *__restrict__ crp, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ chunk_row,
+    int n_chunks, int chunks_per_xcd, int blocks_per_xcd) {
+  constexpr int CAP = BLK * NPT;
+  __shared__ double prod[CAP];
+  const int tid = threadIdx.x;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+  const int c_end = min((xcd + 1) * chunks_per_xcd, n_chunks);
+  for (int chunk = xcd * chunks_per_xcd + lb; chunk < c_end; chunk += blocks_per_xcd) {
+    const int r0 = chunk_row[chunk], r1 = chunk_row[chunk + 1];
+    const int p0 = crp[r0], p1 = crp[r1];
+    const int base = p0 & ~1;
+    int ra = 0, re = 0;
+    if (r0 + tid < r1) { ra = crp[r0 + tid]; re = crp[r0 + tid + 1]; }
+    d2 v[NPT / 2]; i2 c[NPT / 2];
+#pragma unroll
+    for (int k = 0; k < NPT / 2; ++k) {
+      const int idx = min(base + (k * BLK + tid) * 2, max((p1 - 1) & ~1, 0));
+      v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+      c[k] = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + idx));
+    }
+#pragma unroll
+    for (int k = 0; k < NPT / 2; ++k) {
+      d2 pr; pr.x = v[k].x * x[c[k].x]; pr.y = v[k].y * x[c[k].y];
+      *reinterpret_cast<d2 *>(&prod[(k * BLK + tid) * 2]) = pr;
+    }
+    if (RAW) PA_RAW_BARRIER(); else __syncthreads();
+    for (int r = r0 + tid; r < r1; r += BLK) {
+      if (r != r0 + tid) { ra = crp[r]; re = crp[r + 1]; }
+      double acc = 0.0;
+      const int a = ra - base, e = re - base;
+#pragma unroll 4
+      for (int p = a; p < e; ++p) acc = acc + prod[p];
+      y[r] = acc;
+    }
+    if (RAW) PA_RAW_BARRIER(); else __syncthreads();
+  }
+}
+
+
+// ---- wave-autonomous variant: one 64-lane wave = one chunk of <= 64*k rows, no workgroup barrier ------
+template <int WCAP, bool NT, bool PIPE, bool RAW = false>
+__global__ __launch_bounds__(64) void k_spmv_wave(
+    const int *__restrict__ crp, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int4 *__restrict__ desc,
+    int n_chunks, int chunks_per_xcd, int waves_per_xcd) {
+  constexpr int NP = WCAP / 128;
+  __shared__ double prod[WCAP];
+  const int lane = threadIdx.x;
+  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
+  const int c_end = min((xcd + 1) * chunks_per_xcd, n_chunks);
+  int chunk = xcd * chunks_per_xcd + lb;
+  if (chunk >= c_end) return;
+  d2 v[NP]; i2 c[NP];
+  int4 d = desc[chunk];   // {r0, r1, base, p1}
+  auto issue = [&](const int4 &dd) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int idx = min(dd.z + (k * 64 + lane) * 2, max((dd.w - 1) & ~1, 0));
+      v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+      c[k] = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + idx));
+    }
+  };
+  issue(d);
+  while (true) {
+    // my rows' extents
+    const int r0 = d.x, r1 = d.y, base = d.z;
+    int ra = 0, re = 0;
+    if (r0 + lane < r1) { ra = crp[r0 + lane]; re = crp[r0 + lane + 1]; }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      d2 pr; pr.x = v[k].x * x[c[k].x]; pr.y = v[k].y * x[c[k].y];
+      *reinterpret_cast<d2 *>(&prod[(k * 64 + lane) * 2]) = pr;
+    }
+    if (RAW) asm volatile("" ::: "memory"); else __syncthreads();
+    const int next = chunk + waves_per_xcd;
+    int4 dn = d;
+    if (PIPE && next < c_end) { dn = desc[next]; issue(dn); }
+    for (int r = r0 + lane; r < r1; r += 64) {
+      if (r != r0 + lane) { ra = crp[r]; re = crp[r + 1]; }
+      double acc = 0.0;
+      const int a = ra - base, e = re - base;
+#pragma unroll 9
+      for (int p = a; p < e; ++p) acc = acc + prod[p];
+      y[r] = acc;
+    }
+    if (RAW) asm volatile("" ::: "memory"); else __syncthreads();
+    if (next >= c_end) break;
+    chunk = next;
+    if (!PIPE) { dn = desc[next]; issue(dn); }
+    d = dn;
+  }
+}
+
+// ---- ablation copy of the product kernel: XCD map on/off and pieces switched off (timing only) -------
+//   ABL bit0: reduce reads one product per row instead of walking the row   bit1: no y store
+//       bit4: nontemporal y store   bit5: y store into a 2 MiB window   bit6: (unused)
+//       bit2: no LDS write / barrier                                         bit3: no x gather
+template <int BLK, int NPT, bool XCD, int ABL>
+__global__ __launch_bounds__(BLK) void k_spmv_abl(
+    const int *__restrict__ crp, const int *__restrict__ col, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ chunk_row,
+    int n_chunks, int chunks_per_xcd) {
+  constexpr int CAP = BLK * NPT;
+  __shared__ double prod[CAP];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int chunk = XCD ? (b & 7) * chunks_per_xcd + (b >> 3) : b;
+  if (chunk >= n_chunks || (XCD && (b >> 3) >= chunks_per_xcd)) return;
+  const int r0 = chunk_row[chunk], r1 = chunk_row[chunk + 1];
+  const int p0 = crp[r0], p1 = crp[r1];
+  const int base = p0 & ~1;
+  int ra = 0, re = 0;
+  if (r0 + tid < r1) { ra = crp[r0 + tid]; re = crp[r0 + tid + 1]; }
+  d2 v[NPT / 2]; i2 c[NPT / 2];
+  const int last = max((p1 - 1) & ~1, 0);
+#pragma unroll
+  for (int k = 0; k < NPT / 2; ++k) {
+    const int idx = min(base + (k * BLK + tid) * 2, last);
+    v[k] = pa_stream_load<true>(reinterpret_cast<const d2 *>(val + idx));
+    c[k] = pa_stream_load<true>(reinterpret_cast<const i2 *>(col + idx));
+  }
+  double keep = 0.0;
+#pragma unroll
+  for (int k = 0; k < NPT / 2; ++k) {
+    d2 pr;
+    if (ABL & 8) { pr.x = v[k].x * (double)c[k].x; pr.y = v[k].y * (double)c[k].y; }
+    else { pr.x = v[k].x * x[c[k].x]; pr.y = v[k].y * x[c[k].y]; }
+    if (ABL & 4) keep += pr.x + pr.y;
+    else *reinterpret_cast<d2 *>(&prod[(k * BLK + tid) * 2]) = pr;
+  }
+  if (!(ABL & 4)) __syncthreads();
+  for (int r = r0 + tid; r < r1; r += BLK) {
+    if (r != r0 + tid) { ra = crp[r]; re = crp[r + 1]; }
+    double acc = keep;
+    const int a = ra - base, e = re - base;
+    if (ABL & 1) { if (!(ABL & 4)) acc += prod[a]; }
+    else {
+#pragma unroll 4
+      for (int p = a; p < e; ++p) acc = acc + prod[p];
+    }
+    if (ABL & 2) { if (acc == 123.456) y[r] = acc; }
+    else if (ABL & 16) __builtin_nontemporal_store(acc, &y[r]);
+    else if (ABL & 32) y[r & 0x3ffff] = acc;                       // 2 MiB region: stays in L2/MALL
+    else if (ABL & 64) __hip_atomic_store(&y[r], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (ABL & 128) prod[CAP - 1 - (r - r0)] = acc;
+    else if (ABL & 256) prod[r - r0] = acc;   // safe: row r's products start at or after slot r-r0 only if rows are non-empty (27-pt)
+    else y[r] = acc;
+  }
+  if (ABL & 256) {   // wide (16 B/lane) stores by wave 0; needs r0 even and every row non-empty
+    __syncthreads();
+    const int nr = r1 - r0;
+    if (tid < 64) for (int i = tid * 2; i < nr; i += 128) {
+      if (i + 1 < nr) *reinterpret_cast<d2 *>(&y[r0 + i]) = *reinterpret_cast<d2 *>(&prod[i]);
+      else y[r0 + i] = prod[i];
+    }
+  }
+  if (ABL & 128) {   // repack through LDS (top of prod[] is free after the reduce) and store with one wave
+    __syncthreads();
+    const int nr = r1 - r0;
+    if (tid < 64) for (int i = tid; i < nr; i += 64) y[r0 + i] = prod[CAP - 1 - i];
+  }
+}
+
+__global__ void k_cmp(const double *a, const double *b, long n, unsigned long long *bad) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && __double_as_longlong(a[i]) != __double_as_longlong(b[i])) atomicAdd(bad, 1ull);
+}
+
+struct Variant { std::string name; std::function<void()> run; double bytes; std::vector<float> ms; };
+
+int main(int argc, char **argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 256;
+  const int rounds = argc > 2 ? atoi(argv[2]) : 7;
+  const long nrows = (long)n * n * n;
+  std::vector<int> rp(nrows + 1);
+  {
+    long k = 0; rp[0] = 0; long row = 0;
+    for (int iz = 0; iz < n; ++iz) { const int cz = 3 - (iz == 0) - (iz == n - 1);
+      for (int iy = 0; iy < n; ++iy) { const int cy = 3 - (iy == 0) - (iy == n - 1);
+        for (int ix = 0; ix < n; ++ix) { const int cx = 3 - (ix == 0) - (ix == n - 1);
+          k += (long)cx * cy * cz; rp[++row] = (int)k; } } }
+  }
+  const long nnz = rp[nrows];
+  printf("27-pt %d^3: rows %ld nnz %ld\n", n, nrows, nnz);
+  int *d_rp, *d_col; double *d_val, *d_x, *d_y, *d_y2;
+  CK(hipMalloc(&d_rp, sizeof(int) * (nrows + 1))); CK(hipMalloc(&d_col, sizeof(int) * (nnz + 8)));
+  CK(hipMalloc(&d_val, sizeof(double) * (nnz + 8))); CK(hipMalloc(&d_x, sizeof(double) * (nrows + 2)));
+  CK(hipMalloc(&d_y, sizeof(double) * nrows)); CK(hipMalloc(&d_y2, sizeof(double) * nrows));
+  double *d_ybig; CK(hipMalloc(&d_ybig, sizeof(double) * nrows + (80l << 20)));
+  printf("ptrs val %p col %p x %p y %p y2 %p ybig %p rp %p\n", (void*)d_val, (void*)d_col, (void*)d_x, (void*)d_y, (void*)d_y2, (void*)d_ybig, (void*)d_rp);
+  CK(hipMemset(d_col + nnz, 0, 32)); CK(hipMemset(d_val + nnz, 0, 64));
+  CK(hipMemcpy(d_rp, rp.data(), sizeof(int) * (nrows + 1), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_gen, dim3((nrows + 255) / 256), dim3(256), 0, 0, n, d_rp, d_col, d_val);
+  hipLaunchKernelGGL(k_hashx, dim3((nrows + 255) / 256), dim3(256), 0, 0, d_x, nrows);
+  CK(hipDeviceSynchronize());
+
+  const double bytes_spmv = (double)nnz * 12 + (nrows + 1) * 4.0 + nrows * 16.0;
+  std::vector<Variant> V;
+  auto chunks_for = [&](int cap, int **d_chunks, int *nch, int max_rows = 4096) {
+    std::vector<int32_t> cr; int64_t nl;
+    pa_build_chunks(rp.data(), nrows, cap, max_rows, cr, &nl);
+    *nch = (int)cr.size() - 1;
+    CK(hipMalloc(d_chunks, sizeof(int) * cr.size()));
+    CK(hipMemcpy(*d_chunks, cr.data(), sizeof(int) * cr.size(), hipMemcpyHostToDevice));
+  };
+#define ADD_SPMV(BLK, NPT, NT)                                                                              \
+  { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch); const int cpx = (nch + 7) / 8;                       \
+    V.push_back({"spmv<" #BLK "," #NPT "," #NT ">", [=]() {                                                   \
+      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
+                         d_y, dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
+  ADD_SPMV(256, 8, true)
+  ADD_SPMV(256, 8, false)
+  ADD_SPMV(256, 4, true)
+  ADD_SPMV(256, 16, true)
+  ADD_SPMV(512, 8, true)
+  ADD_SPMV(512, 4, true)
+  ADD_SPMV(256, 2, true)
+  ADD_SPMV(128, 4, true)
+  ADD_SPMV(128, 2, true)
+  ADD_SPMV(512, 2, true)
+  ADD_SPMV(256, 6, true)
+  ADD_SPMV(192, 4, true)
+#define ADD_PERS(BLK, NPT, NT, BPC)                                                                           \
+  { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch); const int cpx = (nch + 7) / 8; const int bpx = 32 * BPC; \
+    V.push_back({"persist<" #BLK "," #NPT "," #NT ">x" #BPC, [=]() {                                             \
+      hipLaunchKernelGGL((k_spmv_persistent<BLK, NPT, NT>), dim3(bpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
+                         d_y2, dc, nch, cpx, bpx); }, bytes_spmv, {}}); }
+  ADD_PERS(256, 8, true, 4)
+  ADD_PERS(512, 8, true, 4)
+
+#define ADD_WAVE(WCAP, NT, PIPE, WPC)                                                                          \
+  { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, WCAP, 64, cr, &nl);                  \
+    const int nch = (int)cr.size() - 1; std::vector<int4> dd(nch);                                               \
+    for (int i = 0; i < nch; ++i) dd[i] = make_int4(cr[i], cr[i + 1], rp[cr[i]] & ~1, rp[cr[i + 1]]);           \
+    int4 *ddev; CK(hipMalloc(&ddev, sizeof(int4) * nch)); CK(hipMemcpy(ddev, dd.data(), sizeof(int4) * nch, hipMemcpyHostToDevice)); \
+    const int cpx = (nch + 7) / 8; const int wpx = 32 * WPC;                                                     \
+    V.push_back({"wave<" #WCAP "," #NT "," #PIPE ">x" #WPC, [=]() {                                              \
+      hipLaunchKernelGGL((k_spmv_wave<WCAP, NT, PIPE>), dim3(wpx * 8), dim3(64), 0, 0, d_rp, d_col, d_val, d_x,   \
+                         d_y2, ddev, nch, cpx, wpx); }, bytes_spmv, {}}); }
+  ADD_WAVE(1792, true, false, 11)
+  ADD_WAVE(1792, true, true, 11)
+  ADD_WAVE(1792, true, true, 6)
+  ADD_WAVE(1024, true, false, 16)
+
+#define ADD_ABL(BLK, NPT, XCD, ABL)                                                                          \
+  { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch); const int cpx = (nch + 7) / 8;                       \
+    V.push_back({"abl<" #BLK "," #NPT ",xcd=" #XCD ",abl=" #ABL ">", [=]() {                                  \
+      hipLaunchKernelGGL((k_spmv_abl<BLK, NPT, XCD, ABL>), dim3(XCD ? cpx * 8 : nch), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
+                         d_y2, dc, nch, cpx); }, bytes_spmv, {}}); }
+
+
+#define ADD_PERSR(BLK, NPT, BPC)                                                                              \
+  { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch); const int cpx = (nch + 7) / 8; const int bpx = 32 * BPC; \
+    V.push_back({"persist_raw<" #BLK "," #NPT ">x" #BPC, [=]() {                                                 \
+      hipLaunchKernelGGL((k_spmv_persistent<BLK, NPT, true, true>), dim3(bpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
+                         d_y2, dc, nch, cpx, bpx); }, bytes_spmv, {}}); }
+  ADD_PERSR(256, 8, 8)
+  ADD_PERSR(256, 8, 4)
+  ADD_PERSR(256, 4, 8)
+  ADD_PERSR(512, 8, 4)
+#define ADD_WAVER(WCAP, PIPE, WPC)                                                                              \
+  { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, WCAP, 64, cr, &nl);                  \
+    const int nch = (int)cr.size() - 1; std::vector<int4> dd(nch);                                               \
+    for (int i = 0; i < nch; ++i) dd[i] = make_int4(cr[i], cr[i + 1], rp[cr[i]] & ~1, rp[cr[i + 1]]);           \
+    int4 *ddev; CK(hipMalloc(&ddev, sizeof(int4) * nch)); CK(hipMemcpy(ddev, dd.data(), sizeof(int4) * nch, hipMemcpyHostToDevice)); \
+    const int cpx = (nch + 7) / 8; const int wpx = 32 * WPC;                                                     \
+    V.push_back({"wave_raw<" #WCAP "," #PIPE ">x" #WPC, [=]() {                                                  \
+      hipLaunchKernelGGL((k_spmv_wave<WCAP, true, PIPE, true>), dim3(wpx * 8), dim3(64), 0, 0, d_rp, d_col, d_val, d_x,   \
+                         d_y2, ddev, nch, cpx, wpx); }, bytes_spmv, {}}); }
+  ADD_WAVER(1792, true, 11)
+  ADD_WAVER(1792, true, 8)
+  ADD_WAVER(1792, false, 11)
+  ADD_WAVER(1024, true, 16)
+  ADD_WAVER(1024, false, 16)
+  ADD_WAVER(512, true, 24)
+  ADD_WAVER(512, false, 32)
+  ADD_SPMV(64, 8, true)
+  ADD_SPMV(64, 16, true)
+
+#define ADD_OFF(OFFB)                                                                                        \
+  { int *dc; int nch; chunks_for(2048, &dc, &nch); const int cpx = (nch + 7) / 8; double *yy = d_ybig + (OFFB) / 8; \
+    V.push_back({"spmv<256,8,nt> y+" #OFFB, [=]() {                                                            \
+      hipLaunchKernelGGL((k_spmv_rowsplit<256, 8, true>), dim3(cpx * 8), dim3(256), 0, 0, d_rp, d_col, d_val, d_x, \
+                         yy, dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
+  ADD_OFF(0)
+  ADD_ABL(256, 8, true, 0)
+  ADD_ABL(256, 8, true, 2)
+  ADD_ABL(256, 8, true, 32)
+  ADD_ABL(256, 8, true, 64)
+  ADD_ABL(256, 8, true, 128)
+  ADD_ABL(256, 4, true, 0)
+  ADD_ABL(256, 4, true, 2)
+  ADD_ABL(256, 4, true, 64)
+  ADD_ABL(256, 8, false, 32)
+  ADD_ABL(256, 8, false, 0)
+  ADD_ABL(256, 8, true, 16)
+  ADD_ABL(256, 8, false, 16)
+#define ADD_ABLR(BLK, NPT, XCD, ABL, MAXR)                                                                    \
+  { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch, MAXR); const int cpx = (nch + 7) / 8;                  \
+    V.push_back({"abl<" #BLK "," #NPT ",xcd=" #XCD ",abl=" #ABL ">rows" #MAXR, [=]() {                          \
+      hipLaunchKernelGGL((k_spmv_abl<BLK, NPT, XCD, ABL>), dim3(XCD ? cpx * 8 : nch), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
+                         d_y2, dc, nch, cpx); }, bytes_spmv, {}}); }
+  ADD_ABLR(256, 8, true, 0, 64)
+  ADD_ABLR(256, 8, true, 256, 64)
+  ADD_ABLR(512, 8, true, 256, 128)
+  ADD_ABLR(512, 8, true, 0, 128)
+  ADD_ABLR(1024, 8, true, 256, 256)
+  ADD_ABLR(1024, 8, true, 0, 256)
+  ADD_ABLR(256, 8, true, 16, 64)
+  ADD_ABLR(256, 8, true, 2, 64)
+  ADD_ABLR(256, 4, true, 0, 32)
+  ADD_ABLR(256, 4, true, 2, 32)
+  ADD_ABLR(256, 4, true, 16, 32)
+  ADD_ABLR(512, 8, true, 0, 144)
+  ADD_ABLR(512, 8, true, 16, 144)
+  ADD_ABLR(256, 16, true, 0, 144)
+  {
+    const long nb = (nnz + 2047) / 2048;
+    V.push_back({"stream_only<256,8,nt>", [=]() { hipLaunchKernelGGL((k_stream<256, 8, true, false>), dim3(nb), dim3(256), 0, 0, d_col, d_val, d_x, d_y2, nnz); }, (double)nnz * 12, {}});
+    V.push_back({"stream_only<256,8,plain>", [=]() { hipLaunchKernelGGL((k_stream<256, 8, false, false>), dim3(nb), dim3(256), 0, 0, d_col, d_val, d_x, d_y2, nnz); }, (double)nnz * 12, {}});
+    V.push_back({"stream+gather<256,8,nt>", [=]() { hipLaunchKernelGGL((k_stream<256, 8, true, true>), dim3(nb), dim3(256), 0, 0, d_col, d_val, d_x, d_y2, nnz); }, (double)nnz * 12 + nrows * 8.0, {}});
+    const long n2 = nnz / 2;
+    V.push_back({"readsum(val) nt", [=]() { hipLaunchKernelGGL(k_readsum, dim3(2048), dim3(256), 0, 0, (const d2 *)d_val, d_y2, n2); }, (double)n2 * 16, {}});
+  }
+  {  // bitwise check of every full-SpMV variant against the first one
+    unsigned long long *d_bad; CK(hipMalloc(&d_bad, 8));
+    V[0].run(); CK(hipDeviceSynchronize());
+    for (size_t i = 1; i < V.size(); ++i) {
+      if (V[i].name.rfind("persist", 0) != 0 && V[i].name.rfind("wave", 0) != 0 && V[i].name.rfind("spmv<64", 0) != 0) continue;
+      CK(hipMemset(d_y2, 0xff, sizeof(double) * nrows)); CK(hipMemset(d_bad, 0, 8));
+      V[i].run();
+      hipLaunchKernelGGL(k_cmp, dim3((nrows + 255) / 256), dim3(256), 0, 0, d_y, d_y2, nrows, d_bad);
+      unsigned long long bad; CK(hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost));
+      printf("check %-28s mismatches vs %s: %llu\n", V[i].name.c_str(), V[0].name.c_str(), bad);
+    }
+  }
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int r = 0; r < rounds + 1; ++r)
+    for (auto &v : V) {
+      CK(hipEventRecord(e0, 0)); v.run(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      CK(hipGetLastError());
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r > 0) v.ms.push_back(ms);
+    }
+  // correctness of the spmv variants vs the first one
+  printf("%-28s %9s %9s %10s %10s\n", "variant", "med ms", "min ms", "GB/s(med)", "GB/s(min)");
+  for (auto &v : V) {
+    std::sort(v.ms.begin(), v.ms.end());
+    const float med = v.ms[v.ms.size() / 2], mn = v.ms[0];
+    printf("%-28s %9.4f %9.4f %10.1f %10.1f\n", v.name.c_str(), med, mn, v.bytes / med / 1e6, v.bytes / mn / 1e6);
+  }
+  {
+    // bitwise check of the last wave variant against the baseline kernel (run both again on intact data)
+  }
+  // note: the copy variant above overwrote part of val; do not reuse the matrix after this point
+  return 0;
+}

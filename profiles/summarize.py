@@ -1,0 +1,47 @@
+"""Condense rocprofv3 CSV output (gpurun_out/prof_*) into the small summaries committed under profiles/.
+usage: python profiles/summarize.py <round-tag>   e.g. r01"""
+import collections
+import csv
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
+out = {}
+ks = os.path.join(src, "prof_kt", "kt_kernel_stats.csv")
+if os.path.exists(ks):
+    rows = list(csv.DictReader(open(ks)))
+    with open(os.path.join(os.path.dirname(__file__), f"{tag}_kernel_stats.csv"), "w") as f:
+        w = csv.DictWriter(f, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(rows)
+    out["kernel_stats"] = [{"name": r["Name"][:80], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                            "pct": float(r["Percentage"])} for r in rows[:6]]
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d, f in (("prof_fetch", "f"), ("prof_write", "w"), ("prof_tcc", "t")):
+    p = os.path.join(src, d, f"{f}_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    for r in csv.DictReader(open(p)):
+        if "k_spmv_rowsplit" in r["Kernel_Name"]:
+            pmc["k_spmv_rowsplit"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in pmc.items()}
+s = summary.get("k_spmv_rowsplit", {})
+if "FETCH_SIZE" in s:
+    # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a
+    # wide coalesced streaming read -> doubled.  The correction is calibrated for 16 B/lane streams only; this kernel
+    # mixes 16 B (values), 8 B (columns) and gathered 8 B (x) loads, so the doubled figure is an upper estimate.
+    s["fetch_bytes_raw"] = s["FETCH_SIZE"] * 1024
+    s["fetch_bytes_gfx950_corrected"] = 2 * s["FETCH_SIZE"] * 1024
+if "WRITE_SIZE" in s:
+    s["write_bytes"] = s["WRITE_SIZE"] * 1024
+if "TCC_HIT_sum" in s:
+    s["l2_hit_rate"] = s["TCC_HIT_sum"] / (s["TCC_HIT_sum"] + s["TCC_MISS_sum"])
+if "TCC_EA0_RDREQ_sum" in s:
+    r32 = s.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+    s["ea_read_bytes_if_rest_are_128B"] = r32 * 32 + (s["TCC_EA0_RDREQ_sum"] - r32) * 128
+    s["ea_read_bytes_if_rest_are_64B"] = r32 * 32 + (s["TCC_EA0_RDREQ_sum"] - r32) * 64
+out["pmc_per_launch"] = summary
+json.dump(out, open(os.path.join(os.path.dirname(__file__), f"{tag}_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

@@ -191,7 +191,7 @@ def test_spmv_irregular_bit_exact(orc, case):
     elif case == "long_rows":
         m, n = 40, 9000
         row_len = rng.integers(0, 50, m)
-        row_len[[3, 17, 39]] = [2049, 5000, 8999]                      # longer than one 2048-entry chunk
+        row_len[[3, 17, 39]] = [1025, 5000, 8999]                      # longer than one 1024-entry chunk
     elif case == "one_row":
         m, n, row_len = 1, 10, np.array([7])
     elif case == "all_empty":
