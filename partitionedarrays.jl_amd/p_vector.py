@@ -182,6 +182,9 @@ class DeviceAssemblyCache:
             L.call("pa_plan_create", context().h, ind.part, ind.n_local, len(ns32), L.ptr(ns32), L.ptr(ls.ptrs),
                    L.ptr(np.ascontiguousarray(ls.data, np.int32)), len(nr32), L.ptr(nr32), L.ptr(lr.ptrs),
                    L.ptr(np.ascontiguousarray(lr.data, np.int32)), 1, C.byref(h))
+            plan_info[h.value] = dict(
+                snd=[(int(q), int(ls.ptrs[k]) - 1, int(ls.ptrs[k + 1]) - 1) for k, q in enumerate(ns32)],
+                rcv=[(int(q), int(lr.ptrs[k]) - 1, int(lr.ptrs[k + 1]) - 1) for k, q in enumerate(nr32)])
             return h
 
         self.plans = pmap(make, index_partition, self.neighbors_snd, self.neighbors_rcv,
@@ -211,6 +214,82 @@ class Task:
     fetch = wait
 
 
+class _DevMem:
+    """Zero-copy view of a device buffer for torch (CUDA array interface); used only by the fallback transport."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+TRANSPORT = os.environ.get("PA_TRANSPORT", "rccl")   # "rccl": ncclSend/ncclRecv issued by libpa_hip on its comm stream
+                                                     # "torch": torch.distributed batch_isend_irecv (same RCCL underneath)
+
+
+def _transport_torch(plan, mode, group=None):
+    """Fallback transport: the same per-neighbour slices moved by torch.distributed's NCCL(=RCCL) p2p ops.
+    Host-synchronous (two stream syncs per exchange), so it does not overlap with own*own; it exists so a
+    multi-GPU run still completes if the direct RCCL path cannot be initialised."""
+    import torch
+    import torch.distributed as dist
+    snd, rcv = C.c_void_p(), C.c_void_p()
+    ns, nr = C.c_int64(), C.c_int64()
+    L.call("pa_plan_buffers", plan, mode, C.byref(snd), C.byref(ns), C.byref(rcv), C.byref(nr))
+    context().sync()
+    ops = []
+    info = plan_info[plan.value]
+    o, i = (info["snd"], info["rcv"]) if mode == L.ASSEMBLE else (info["rcv"], info["snd"])
+    dev = torch.device("cuda", context().device)
+    ts = torch.as_tensor(_DevMem(snd.value, max(ns.value, 1)), device=dev) if ns.value else None
+    tr = torch.as_tensor(_DevMem(rcv.value, max(nr.value, 1)), device=dev) if nr.value else None
+    for nbr, a, e in i:
+        if e > a:
+            ops.append(dist.P2POp(dist.irecv, tr[a:e], _grank(group, nbr - 1), group))
+    for nbr, a, e in o:
+        if e > a:
+            ops.append(dist.P2POp(dist.isend, ts[a:e], _grank(group, nbr - 1), group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        torch.cuda.current_stream(dev).synchronize()
+
+
+def _transport_host(plan, mode, group=None):
+    """Host-staged transport over any torch.distributed backend with CPU tensors (gloo): device -> host -> p2p ->
+    device.  Slow by construction; lets several ranks share ONE GPU (RCCL refuses that), which is how the
+    one-part-per-process path is exercised end to end on a single-GPU box."""
+    import torch
+    import torch.distributed as dist
+    snd, rcv = C.c_void_p(), C.c_void_p()
+    ns, nr = C.c_int64(), C.c_int64()
+    L.call("pa_plan_buffers", plan, mode, C.byref(snd), C.byref(ns), C.byref(rcv), C.byref(nr))
+    context().sync()
+    info = plan_info[plan.value]
+    o, i = (info["snd"], info["rcv"]) if mode == L.ASSEMBLE else (info["rcv"], info["snd"])
+    dev = torch.device("cuda", context().device)
+    hs = torch.as_tensor(_DevMem(snd.value, ns.value), device=dev).cpu() if ns.value else None
+    hr = torch.zeros(nr.value, dtype=torch.float64)
+    reqs = []
+    for nbr, a, e in i:
+        if e > a:
+            reqs.append(dist.irecv(hr[a:e], _grank(group, nbr - 1), group))
+    for nbr, a, e in o:
+        if e > a:
+            reqs.append(dist.isend(hs[a:e].contiguous(), _grank(group, nbr - 1), group))
+    for r in reqs:
+        r.wait()
+    if nr.value:
+        torch.as_tensor(_DevMem(rcv.value, nr.value), device=dev).copy_(hr)
+        torch.cuda.current_stream(dev).synchronize()
+
+
+def _grank(group, r):
+    import torch.distributed as dist
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+plan_info = {}   # plan handle -> neighbour slices (1-based part id, start, stop), for the fallback transport
+
+
 def _transport(plans, mode):
     """exchange!(buffer_rcv,buffer_snd,graph) on the device (src/p_vector.jl:601):
     DebugArray -> device-to-device slice copies (src/debug_array.jl:250);
@@ -220,6 +299,12 @@ def _transport(plans, mode):
         arr = (C.c_void_p * len(hs))(*[h.value for h in hs])
         L.call("pa_exchange_local", arr, len(hs), mode)
     else:
+        if TRANSPORT == "torch":
+            _transport_torch(plans.item, mode, plans.group)
+            return
+        if TRANSPORT == "host":
+            _transport_host(plans.item, mode, plans.group)
+            return
         comm = context().comm
         if comm is None:
             raise L.PAError("no RCCL communicator: call init_comm() before exchanging on a TorchDistArray")

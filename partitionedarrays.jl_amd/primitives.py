@@ -70,9 +70,10 @@ def with_debug(f):
     return f(lambda a: DebugArray(list(a)))
 
 
-def with_torchdist(f, group=None):
-    """with_mpi analogue (src/mpi_array.jl:64-83): `distribute` keeps this rank's item of `a`;
-    an exception on any rank tears the job down (MPI.Abort analogue: re-raised after destroying the group)."""
+def with_torchdist(f, group=None, abort_on_error=True):
+    """with_mpi analogue (src/mpi_array.jl:64-83): `distribute` keeps this rank's item of `a`.
+    An exception on any rank tears the whole job down, like with_mpi's MPI.Abort(comm,1) (:72-79): the
+    traceback is printed and the process exits with status 1 (torch.distributed.run then kills the peers)."""
     import torch.distributed as dist
     if not dist.is_initialized():
         raise RuntimeError("torch.distributed is not initialised (call dist.init_process_group first)")
@@ -83,7 +84,18 @@ def with_torchdist(f, group=None):
             raise AssertionError("number of parts must equal the number of ranks (src/mpi_array.jl:46)")
         return TorchDistArray(a[dist.get_rank(group)], group)
 
-    return f(distribute)
+    if not abort_on_error:
+        return f(distribute)
+    try:
+        return f(distribute)
+    except BaseException:
+        import os
+        import sys
+        import traceback
+        traceback.print_exc()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)
 
 
 def linear_indices(a):

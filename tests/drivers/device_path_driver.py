@@ -1,0 +1,56 @@
+"""One part per process (torch.distributed), every rank on the SAME GPU, host-staged transport (PA_TRANSPORT=host):
+the full N>1 device path -- pack kernel, exchange, unpack kernel, own*own / own*ghost SpMV, dot -- against the
+sequential oracle, bit-exact.  Run by tests/test_gpu_multiprocess.py on the 1-GPU box."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ["PA_TRANSPORT"] = "host"
+from __graft_entry__ import load_package, load_oracle  # noqa: E402
+
+pa = load_package()
+orc = load_oracle()
+
+
+def body(distribute):
+    P, me = dist.get_world_size(), dist.get_rank() + 1
+    ranks = distribute(range(1, P + 1))
+    npx, npy, npz = pa.compute_optimal_shape_XYZ(P)
+    nx, ny, nz = 8, 6, 5
+    for fused in (False, True):
+        A, b = pa.build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, fused=fused)
+        Ao, bo, _ = orc.hpcg_build_p_matrix(nx, ny, nz, npx, npy, npz)
+        k = me - 1
+        y = pa.pzeros(A.row_partition)
+        pa.mul_(y, A, pa.pones(A.col_partition))
+        assert np.array_equal(pa.getany(y.own_values()), pa.getany(b.own_values()))          # A*1 == b
+        xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+        x = pa.pvector_from_function(lambda ind: xo[ind.part - 1].copy(), A.col_partition)
+        pa.mul_(y, A, x)
+        yo = [np.zeros(r.n_local) for r in Ao.rows]
+        orc.mul(yo, Ao, [v.copy() for v in xo])
+        assert np.array_equal(pa.getany(y.own_values()), yo[k][:Ao.rows[k].n_own]), "mul! differs from the oracle"
+        orc.consistent(xo, Ao.cols)
+        assert np.array_equal(pa.getany(x.local_values()), xo[k]), "ghosts differ after consistent!"
+        # assemble!: ghost contributions travel back and are added in the reference's order
+        v = pa.pvector_from_function(lambda ind: orc.hash_x(ind.get_local_to_global() + 5 * ind.part), A.col_partition)
+        vo = [orc.hash_x(c.local_to_global + 5 * c.part) for c in Ao.cols]
+        pa.assemble_(v).wait()
+        orc.assemble(vo, Ao.cols)
+        assert np.array_equal(pa.getany(v.local_values()), vo[k]), "assemble! differs from the oracle"
+        d = pa.dot(x, x)
+        dref = orc.dot(xo, xo, Ao.cols)
+        assert abs(d - dref) <= 1e-13 * abs(dref)
+        assert np.array_equal(y.collect(), orc.pvector_collect(yo, Ao.rows))
+    return True
+
+
+if __name__ == "__main__":
+    dist.init_process_group("gloo")
+    pa.with_torchdist(body)
+    dist.barrier()
+    dist.destroy_process_group()
