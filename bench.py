@@ -80,10 +80,13 @@ def main():
     from __graft_entry__ import load_package
     if N > 1 or world > 1:
         assert world == N, f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {N}"
-        local = int(os.environ.get("LOCAL_RANK", str(rank)))
+        local = int(os.environ.get("LOCAL_RANK", str(rank))) % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        backend = os.environ.get("PA_BENCH_BACKEND", "cpu:gloo,cuda:nccl")   # "gloo" + PA_TRANSPORT=host: ranks may share a GPU
+        if "nccl" in backend:
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     pa = load_package()
     ctx = pa.context()
 

@@ -1,0 +1,212 @@
+# PartitionedArraysHIP.jl -- Julia glue: PartitionedArrays.jl types on top of libpa_hip.so (MI355X / gfx950).
+#
+# STATUS: shipped as source, NOT executed in this repo's CI -- there is no Julia toolchain in the build image
+# (see DESIGN.md "Host language").  It is deliberately thin and mechanical: every method below is a `ccall`
+# of one entry point of include/pa_hip.h, and the same entry points are exercised, in the same order, by the
+# Python host mirror and its tests (tests/test_gpu_parity.py).
+#
+# What it plugs into (reference file:line, PartitionedArrays.jl v0.5.7):
+#   local vector type  V of PVector{V}        src/p_vector.jl:8-26 (allocate_local_values, own_values, ghost_values)
+#   vector cache       p_vector_cache_impl    src/p_vector.jl:451-468
+#   ghost exchange     assemble_impl!         src/p_vector.jl:587-612   (used by assemble! :695 and consistent! :747)
+#   local SpMV         spmv!, mul!(…,α,β)     src/sparse_utils.jl:609-669, src/p_sparse_matrix.jl:2088
+# With these methods defined, the reference's own `mul!(c::PVector,a::PSparseMatrix,b::PVector)`
+# (src/p_sparse_matrix.jl:2090-2103) runs unchanged: pack/exchange on the comm stream, own*own on the compute
+# stream, wait(t), own*ghost.
+module PartitionedArraysHIP
+
+using PartitionedArrays
+using LinearAlgebra
+using SparseArrays
+using SparseMatricesCSR
+import MPI
+
+const libpa = get(ENV, "LIBPA_HIP", "libpa_hip.so")
+
+const PA_SEG_OWN, PA_SEG_GHOST, PA_SEG_LOCAL = Cint(0), Cint(1), Cint(2)
+const PA_CONSISTENT, PA_ASSEMBLE = Cint(0), Cint(1)
+
+function check(status::Cint)
+    status == 0 && return nothing
+    error("libpa_hip: " * unsafe_string(ccall((:pa_last_error, libpa), Cstring, ())))
+end
+
+# ---------------------------------------------------------------- context (one per process / GPU)
+mutable struct HIPContext
+    handle::Ptr{Cvoid}
+    comm::Ptr{Cvoid}
+end
+const CTX = Ref{Union{Nothing,HIPContext}}(nothing)
+function context(device::Integer=parse(Int, get(ENV, "LOCAL_RANK", "0")))
+    if CTX[] === nothing
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pa_ctx_create, libpa), Cint, (Cint, Ref{Ptr{Cvoid}}), device, h))
+        CTX[] = HIPContext(h[], C_NULL)
+    end
+    CTX[]
+end
+synchronize() = check(ccall((:pa_ctx_sync, libpa), Cint, (Ptr{Cvoid},), context().handle))
+
+"RCCL communicator: rank = MPI rank = part-1 (src/mpi_array.jl:51); the unique id travels over MPI.bcast."
+function init_comm!(comm::MPI.Comm=MPI.COMM_WORLD)
+    c = context()
+    c.comm != C_NULL && return c.comm
+    id = zeros(UInt8, 128)
+    MPI.Comm_rank(comm) == 0 && check(ccall((:pa_comm_unique_id, libpa), Cint, (Ptr{UInt8},), id))
+    MPI.Bcast!(id, 0, comm)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pa_comm_create, libpa), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Cint, Cint, Ref{Ptr{Cvoid}}),
+                c.handle, id, MPI.Comm_rank(comm), MPI.Comm_size(comm), h))
+    c.comm = h[]
+end
+
+# ---------------------------------------------------------------- local vector type
+mutable struct HIPVector <: AbstractVector{Float64}
+    handle::Ptr{Cvoid}
+    n_own::Int
+    n_ghost::Int
+    function HIPVector(n_own::Integer, n_ghost::Integer)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pa_vec_create, libpa), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}),
+                    context().handle, n_own, n_ghost, h))
+        v = new(h[], n_own, n_ghost)
+        finalizer(x -> ccall((:pa_vec_destroy, libpa), Cint, (Ptr{Cvoid},), x.handle), v)
+    end
+end
+Base.size(v::HIPVector) = (v.n_own + v.n_ghost,)
+Base.getindex(::HIPVector, ::Int) = error("scalar indexing of a HIPVector is not allowed; use Array(v)")
+function HIPVector(host::Vector{Float64}, n_own::Integer)
+    v = HIPVector(n_own, length(host) - n_own)
+    check(ccall((:pa_vec_upload, libpa), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), v.handle, host, 0, length(host)))
+    v
+end
+function Base.Array(v::HIPVector)
+    host = Vector{Float64}(undef, length(v))
+    check(ccall((:pa_vec_download, libpa), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), v.handle, host, 0, length(host)))
+    host
+end
+
+"own_values / ghost_values of a HIPVector: a segment tag instead of a SubArray (src/p_vector.jl:20-26)."
+struct HIPSegment <: AbstractVector{Float64}
+    parent::HIPVector
+    seg::Cint
+end
+Base.size(s::HIPSegment) = (s.seg == PA_SEG_OWN ? s.parent.n_own : s.parent.n_ghost,)
+PartitionedArrays.allocate_local_values(::Type{HIPVector}, indices) =
+    HIPVector(own_length(indices), ghost_length(indices))
+PartitionedArrays.allocate_local_values(v::HIPVector, ::Type{Float64}, indices) =
+    HIPVector(own_length(indices), ghost_length(indices))
+PartitionedArrays.own_values(v::HIPVector, indices) = HIPSegment(v, PA_SEG_OWN)
+PartitionedArrays.ghost_values(v::HIPVector, indices) = HIPSegment(v, PA_SEG_GHOST)
+Base.fill!(s::HIPSegment, x) =
+    (check(ccall((:pa_vec_fill, libpa), Cint, (Ptr{Cvoid}, Cint, Float64), s.parent.handle, s.seg, x)); s)
+function LinearAlgebra.dot(a::HIPSegment, b::HIPSegment)
+    out = Ref{Float64}(0.0)
+    check(ccall((:pa_vec_dot, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), a.parent.handle, b.parent.handle, out))
+    out[]
+end
+
+# ---------------------------------------------------------------- local matrix type
+mutable struct HIPCSR <: AbstractSparseMatrix{Float64,Int32}
+    handle::Ptr{Cvoid}
+    m::Int
+    n::Int
+end
+Base.size(A::HIPCSR) = (A.m, A.n)
+function _adopt(h, m, n)
+    A = HIPCSR(h, m, n)
+    finalizer(x -> ccall((:pa_csr_destroy, libpa), Cint, (Ptr{Cvoid},), x.handle), A)
+end
+"Upload a SparseMatrixCSR{1} block as the reference stores it (1-based rowptr/colval): HPCG/src/sparse_matrix.jl:115."
+function HIPCSR(A::SparseMatrixCSR{1,Float64,Ti}) where Ti<:Union{Int32,Int64}
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pa_csr_create, libpa), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                context().handle, size(A, 1), size(A, 2), nnz(A), A.rowptr, A.colval, sizeof(Ti), 1, A.nzval, h))
+    _adopt(h[], size(A)...)
+end
+"Upload the default SparseMatrixCSC storage; converted to CSR on the way (spmv_csc! == spmv_csr! bit for bit)."
+function HIPCSR(A::SparseMatrixCSC{Float64,Ti}) where Ti<:Union{Int32,Int64}
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pa_csr_create_from_csc, libpa), Cint,
+                (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                context().handle, size(A, 1), size(A, 2), nnz(A), A.colptr, A.rowval, sizeof(Ti), 1, A.nzval, h))
+    _adopt(h[], size(A)...)
+end
+
+# spmv!(b,A,x) (src/sparse_utils.jl:617-623) and muladd!(b,A,x) = mul!(b,A,x,1,1) (src/p_sparse_matrix.jl:2088)
+function PartitionedArrays.spmv!(b::HIPSegment, A::HIPCSR, x::HIPSegment)
+    check(ccall((:pa_spmv, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64, Float64),
+                A.handle, x.parent.handle, x.seg, b.parent.handle, b.seg, 1.0, 0.0))
+    b
+end
+function LinearAlgebra.mul!(b::HIPSegment, A::HIPCSR, x::HIPSegment, α::Number, β::Number)
+    check(ccall((:pa_spmv, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64, Float64),
+                A.handle, x.parent.handle, x.seg, b.parent.handle, b.seg, Float64(α), Float64(β)))
+    b
+end
+
+# ---------------------------------------------------------------- vector assembly cache (the exchange plan)
+struct HIPAssemblyCache{A}
+    plans::A            # one pa_plan* per part (same back-end array type as the partition)
+    reversed::Bool      # reverse(cache) of consistent! (src/p_vector.jl:427-437,748)
+end
+Base.reverse(c::HIPAssemblyCache) = HIPAssemblyCache(c.plans, !c.reversed)
+
+function PartitionedArrays.p_vector_cache_impl(::Type{HIPVector}, vector_partition, index_partition)
+    neighbors_snd, neighbors_rcv = assembly_neighbors(index_partition)
+    indices_snd, indices_rcv = assembly_local_indices(index_partition, neighbors_snd, neighbors_rcv)
+    plans = map(index_partition, neighbors_snd, neighbors_rcv, indices_snd, indices_rcv) do ids, ns, nr, is, ir
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pa_plan_create, libpa), Cint,
+                    (Ptr{Cvoid}, Int32, Int64, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32},
+                     Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
+                    context().handle, part_id(ids), local_length(ids),
+                    length(ns), ns, is.ptrs, is.data, length(nr), nr, ir.ptrs, ir.data, 1, h))
+        h[]
+    end
+    HIPAssemblyCache(plans, false)
+end
+
+_transport!(plans::DebugArray, mode) =        # all parts in this process (src/debug_array.jl:250)
+    check(ccall((:pa_exchange_local, libpa), Cint, (Ptr{Ptr{Cvoid}}, Int32, Cint), plans.items, length(plans.items), mode))
+_transport!(plans::MPIArray, mode) =          # one part per rank (src/mpi_array.jl:575-614) -> RCCL p2p over xGMI
+    check(ccall((:pa_exchange_rccl, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), plans.item, init_comm!(plans.comm), mode))
+
+function PartitionedArrays.assemble_impl!(f, vector_partition, cache::HIPAssemblyCache)
+    mode = cache.reversed ? PA_CONSISTENT : PA_ASSEMBLE
+    (mode == PA_CONSISTENT) == (f === PartitionedArrays.insert) || error("HIP path supports insert (consistent!) and + (assemble!)")
+    foreach(vector_partition, cache.plans) do v, p       # pack: src/p_vector.jl:595-599
+        check(ccall((:pa_exchange_pack, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), p, v.handle, mode))
+    end
+    _transport!(cache.plans, mode)                        # exchange!: :601
+    PartitionedArrays.@fake_async begin                   # wait(t) + unpack: :603-611 (+ ghost zeroing of assemble!: :703-705)
+        foreach(vector_partition, cache.plans) do v, p
+            check(ccall((:pa_exchange_finish, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), p, v.handle, mode))
+        end
+        nothing
+    end
+end
+# assemble!(o,a) zero-fills the ghosts after the task (src/p_vector.jl:703-705); pa_exchange_finish already did,
+# and fill!(::HIPSegment,0) above keeps that line of the reference valid.
+
+# ---------------------------------------------------------------- conversions
+"Device twin of a host PVector{Vector{Float64}} whose local ids are [own | ghost] (block partitions)."
+function to_hip(v::PVector)
+    vals = map(partition(v), partition(axes(v, 1))) do x, ids
+        HIPVector(collect(Float64, x), own_length(ids))
+    end
+    PVector(vals, partition(axes(v, 1)))
+end
+"Device twin of an assembled, split-format PSparseMatrix (src/p_sparse_matrix.jl:588-627,670-681)."
+function to_hip(A::PSparseMatrix)
+    @assert A.assembled
+    mats = map(partition(A)) do a
+        blocks = PartitionedArrays.split_matrix_blocks(HIPCSR(a.blocks.own_own), HIPCSR(a.blocks.own_ghost),
+                                                       HIPCSR(a.blocks.ghost_own), HIPCSR(a.blocks.ghost_ghost))
+        PartitionedArrays.split_matrix(blocks, a.row_permutation, a.col_permutation)
+    end
+    PSparseMatrix(mats, partition(axes(A, 1)), partition(axes(A, 2)), true)
+end
+
+end # module
