@@ -30,7 +30,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=256, help="grid points per direction per part")
+    ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per direction per part")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
     return ap.parse_args()

@@ -903,6 +903,167 @@ def psparse_from_coo(I, J, V, row_partition, index_dtype=I32):
     return psparse_assembled(I, J, V, row_partition, cols, index_dtype)
 
 
+def ref_cg(x, A: PSparse, b, maxiter=50, tolerance=0.0, history=None):
+    """HPCG/src/ref_cg.jl:40-134 with Pl = Identity(): x, residual0, residual, iters (lists of local arrays)."""
+    ind = A.cols
+    u = [np.zeros_like(v) for v in x]
+    r = [v.copy() for v in b]
+    c = [np.zeros_like(v) for v in x]
+    mul_no_lat(c, A, x)
+    for ri, ci, i in zip(r, c, ind):
+        ri[:i.n_own] -= ci[:i.n_own]
+    residual0 = residual = norm2(r, ind)
+    rho, iters = 1.0, 0
+    while not (iters >= maxiter or residual / residual0 <= tolerance):
+        for ci, ri in zip(c, r):
+            ci[:] = ri
+        rho_prev = rho
+        rho = dot(c, r, ind)
+        beta = rho / rho_prev
+        for ui, ci, i in zip(u, c, ind):
+            ui[:i.n_own] = ci[:i.n_own] + beta * ui[:i.n_own]
+        mul_no_lat(c, A, u)
+        alpha = rho / dot(u, c, ind)
+        for xi, ui, ri, ci, i in zip(x, u, r, c, ind):
+            xi[:i.n_own] += alpha * ui[:i.n_own]
+            ri[:i.n_own] -= alpha * ci[:i.n_own]
+        residual = norm2(r, ind)
+        iters += 1
+        if history is not None:
+            history.append(residual)
+    return x, residual0, residual, iters
+
+
+# --------------------------------------------------------------------------------------
+# Disassembled COO -> assembled split matrix (BASELINE config 5: FEM-style, ghost-heavy)
+# --------------------------------------------------------------------------------------
+def _coo_of(A: CSR):
+    """nziterator / findnz of a CSR block: row-major, columns ascending (src/sparse_utils.jl:96-123)."""
+    rows = np.repeat(np.arange(1, A.m + 1, dtype=I64), np.diff(A.rowptr.astype(I64)))
+    return rows, A.colval.astype(I64), A.nzval.copy()
+
+
+def _jag_by_owner(owner, parts_snd, arrays):
+    """Group entries by destination part (order of parts_snd), stable inside a group."""
+    slot = np.searchsorted(parts_snd, owner)
+    order = np.argsort(slot, kind="stable")
+    ptrs = np.zeros(len(parts_snd) + 1, dtype=I32)
+    np.add.at(ptrs, slot + 1, 1)
+    length_to_ptrs(ptrs)
+    return [Jagged(a[order], ptrs) for a in arrays]
+
+
+def psparse_disassembled(I, J, V, rows, cols, index_dtype=I32):
+    """psparse(I,J,V,rows,cols) with the default flags (disassembled input, assemble=true, split format):
+    src/p_sparse_matrix.jl:1183-1219, then assemble(B,rows) = psparse_assemble_impl :1590-1756."""
+    I_owner = find_owner(rows, I)
+    J_owner = find_owner(cols, J)
+    rows_sa = [union_ghost(r, i, o) for r, i, o in zip(rows, I, I_owner)]
+    cols_sa = [union_ghost(c, j, o) for c, j, o in zip(cols, J, J_owner)]
+    blocks = []
+    for Ii, Ji, Vi, r, c in zip(I, J, V, rows_sa, cols_sa):
+        A = compresscoo_csr(r.global_to_local(Ii), c.global_to_local(Ji), Vi, r.n_local, c.n_local,
+                            skip=True, index_dtype=index_dtype)
+        blocks.append(split_format_locally(A, r, c))
+    return psparse_assemble(blocks, rows_sa, cols_sa, rows, index_dtype), (blocks, rows_sa, cols_sa)
+
+
+def psparse_assemble(blocks, rows_sa, cols_sa, rows, index_dtype=I32):
+    """psparse_assemble_impl (src/p_sparse_matrix.jl:1590-1756): ship ghost-row triplets to the owners,
+    concatenate own + received COO, renumber the ghost columns (union_ghost), compress with +."""
+    parts_snd, parts_rcv = assembly_neighbors(rows_sa)
+    I_snd, J_snd, V_snd = [], [], []
+    for blk, ps, r, c in zip(blocks, parts_snd, rows_sa, cols_sa):          # setup_cache_snd :1598-1650
+        gi, gj, gv = _coo_of(blk.ghost_own)
+        hi, hj, hv = _coo_of(blk.ghost_ghost)
+        gI = r.ghost_to_global[np.concatenate([gi, hi]) - 1]
+        gJ = np.concatenate([c.own_to_global[gj - 1], c.ghost_to_global[hj - 1]])
+        gV = np.concatenate([gv, hv])
+        owner = r.ghost_to_owner[np.concatenate([gi, hi]) - 1]
+        a, b, v = _jag_by_owner(owner, ps, [gI, gJ, gV])
+        I_snd.append(a); J_snd.append(b); V_snd.append(v)
+    I_rcv = allocate_exchange_jagged(I_snd, parts_snd, parts_rcv, I64)
+    J_rcv = allocate_exchange_jagged(J_snd, parts_snd, parts_rcv, I64)
+    V_rcv = allocate_exchange_jagged(V_snd, parts_snd, parts_rcv, F64)
+    exchange_jagged(I_rcv, I_snd, parts_snd, parts_rcv)
+    exchange_jagged(J_rcv, J_snd, parts_snd, parts_rcv)
+    exchange_jagged(V_rcv, V_snd, parts_snd, parts_rcv)
+    trip, Jg = [], []
+    for blk, Ir, Jr, Vr, r, c in zip(blocks, I_rcv, J_rcv, V_rcv, rows_sa, cols_sa):   # setup_own_triplets :1656-1689
+        ooI, ooJ, ooV = _coo_of(blk.own_own)
+        ohI, ohJ, ohV = _coo_of(blk.own_ghost)
+        lj = c.global_to_local(Jr.data).astype(I64)
+        is_own = (lj >= 1) & (lj <= c.n_own)
+        li = r.global_to_local(Ir.data).astype(I64)                  # received rows are own rows here
+        oo = (np.concatenate([ooI, li[is_own]]), np.concatenate([ooJ, lj[is_own]]), np.concatenate([ooV, Vr.data[is_own]]))
+        ohJ_g = c.ghost_to_global[ohJ - 1]
+        og = (np.concatenate([ohI, li[~is_own]]), np.concatenate([ohJ_g, Jr.data[~is_own]]),
+              np.concatenate([ohV, Vr.data[~is_own]]))
+        trip.append((oo, og)); Jg.append(og[1])
+    J_owner = find_owner(cols_sa, Jg)
+    cols0 = [Indices(c.n_global, c.part, c.own_to_global, np.full(c.n_own, c.part, I32), "block", c.np_, c.n, c.ranges, c.starts)
+             for c in cols_sa]                                       # remove_ghost :1727
+    cols_fa = [union_ghost(c, j, o) for c, j, o in zip(cols0, Jg, J_owner)]
+    out_blocks = []
+    for (oo, og), r, c in zip(trip, rows, cols_fa):                                     # finalize_values :1690-1723
+        gj = c.global_to_local(og[1]).astype(I64) - c.n_own           # map_global_to_ghost!
+        A1 = compresscoo_csr(oo[0], oo[1], oo[2], r.n_own, c.n_own, skip=False, index_dtype=index_dtype)
+        A2 = compresscoo_csr(og[0], gj, og[2], r.n_own, c.n_ghost, skip=False, index_dtype=index_dtype)
+        E1 = compresscoo_csr([], [], [], 0, c.n_own, skip=False, index_dtype=index_dtype)
+        E2 = compresscoo_csr([], [], [], 0, c.n_ghost, skip=False, index_dtype=index_dtype)
+        out_blocks.append(SplitBlocks(A1, A2, E1, E2))
+    return PSparse([None] * len(rows), out_blocks, rows, cols_fa, True)
+
+
+def laplacian_fem(nodes_per_dir, parts_per_dir):
+    """src/gallery.jl:110-239: Q1 Laplacian on the unit cube, free (interior) nodes only; each part loops over ITS
+    CELLS (uniform cell partition) and emits element entries in global node ids -> rows of other parts appear."""
+    D = len(nodes_per_dir)
+    cells_per_dir = tuple(n + 1 for n in nodes_per_dir)
+    h = [1.0 / (n + 1) for n in nodes_per_dir]
+    gp = np.array([-np.sqrt(3.0) / 3.0, np.sqrt(3.0) / 3.0])
+    sf = np.zeros((2, 2)); sf[:, 0] = 0.5 * (1 - gp); sf[:, 1] = 0.5 * (gp + 1)
+    sg1 = np.zeros((2, 2)); sg1[:, 0] = -0.5; sg1[:, 1] = 0.5
+    nloc = 2 ** D
+    loc = [tuple(reversed(t)) for t in itertools.product(*[range(1, 3)] * D)]       # column-major local nodes / points
+    sg = np.zeros((nloc, nloc, D))
+    for ln, lt in enumerate(loc):
+        for pt, ptt in enumerate(loc):
+            for d in range(D):
+                v = 1.0
+                for i in range(D):                                  # prod(1:D) in index order (:141-147)
+                    v = v * ((2.0 / h[d]) * sg1[lt[d] - 1, ptt[d] - 1] if i == d else sf[lt[i] - 1, ptt[i] - 1])
+                sg[ln, pt, d] = v
+    # NOTE restated literally, index order included: sf_1d/sg_1d are filled as [gauss point, shape function] but read
+    # as [local_node, point] (:143-145), and sg is filled as [local_node, point] but summed over its FIRST index
+    # (Aref[i,j] += dV*dot(sg[k,i],sg[k,j]), :154-160).
+    Aref = np.zeros((nloc, nloc))
+    dV = float(np.prod(h)) / (2 ** D)
+    for i in range(nloc):
+        for j in range(nloc):
+            for k in range(nloc):
+                Aref[i, j] += dV * float(np.dot(sg[k, i], sg[k, j]))
+    node_partition = uniform_partition(tuple(parts_per_dir), tuple(nodes_per_dir))
+    cell_partition = uniform_partition(tuple(parts_per_dir), cells_per_dir)
+    Is, Js, Vs = [], [], []
+    for cells in cell_partition:
+        I, J, V = [], [], []
+        lens = [hi - lo + 1 for lo, hi in cells.ranges]
+        for c0 in itertools.product(*[range(L) for L in reversed(lens)]):
+            cell = tuple(cells.ranges[d][0] + c for d, c in enumerate(reversed(c0)))
+            for li, lti in enumerate(loc):
+                ni = tuple(cell[d] + lti[d] - 2 for d in range(D))
+                if any(not (1 <= ni[d] <= nodes_per_dir[d]) for d in range(D)):
+                    continue
+                for lj, ltj in enumerate(loc):
+                    nj = tuple(cell[d] + ltj[d] - 2 for d in range(D))
+                    if any(not (1 <= nj[d] <= nodes_per_dir[d]) for d in range(D)):
+                        continue
+                    I.append(_linear(ni, nodes_per_dir)); J.append(_linear(nj, nodes_per_dir)); V.append(Aref[li, lj])
+        Is.append(np.array(I, I64)); Js.append(np.array(J, I64)); Vs.append(np.array(V, F64))
+    return Is, Js, Vs, node_partition, node_partition
+
+
 def hash_x(gids):
     """x[gid] = ((gid*2654435761) mod 2^32)/2^32, stateless and partition independent."""
     g = np.asarray(gids, dtype=np.uint64)

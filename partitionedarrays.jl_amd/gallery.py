@@ -131,3 +131,60 @@ def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=Fa
     A = psparse_from_coo(I, J, V, row_partition, keep_host=keep_host)
     pb = pvector(I_b, b, A.col_partition)        # row_partition = partition(axes(A,2)) (:119)
     return A, pb
+
+
+def laplacian_fem(nodes_per_dir, parts_per_dir, parts):
+    """laplacian_fem(nodes_per_dir,parts_per_dir,parts) (src/gallery.jl:110-239): Q1 Laplacian, interior nodes only.
+    Each part loops over ITS CELLS, so the COO it returns contains rows owned by other parts (disassembled input
+    for psparse).  Same entry order as the reference: cells column-major, local node i, then local node j."""
+    import itertools
+    D = len(nodes_per_dir)
+    nodes = tuple(int(k) for k in nodes_per_dir)
+    cells_per_dir = tuple(k + 1 for k in nodes)
+    h = [1.0 / (k + 1) for k in nodes]
+    # ref_matrix (:123-162), literal including its index conventions
+    gp = np.array([-np.sqrt(3.0) / 3.0, np.sqrt(3.0) / 3.0])
+    sf = np.stack([0.5 * (1 - gp), 0.5 * (gp + 1)], axis=1)
+    sg1 = np.array([[-0.5, 0.5], [-0.5, 0.5]])
+    loc = [tuple(reversed(t)) for t in itertools.product(*[range(2)] * D)]         # column-major 2^D corner offsets
+    nloc = len(loc)
+    sg = np.zeros((nloc, nloc, D))
+    for a, la in enumerate(loc):
+        for b, pb in enumerate(loc):
+            for d in range(D):
+                v = 1.0
+                for i in range(D):
+                    v = v * ((2.0 / h[d]) * sg1[la[d], pb[d]] if i == d else sf[la[i], pb[i]])
+                sg[a, b, d] = v
+    dV = float(np.prod(h)) / (2 ** D)
+    Aref = np.zeros((nloc, nloc))
+    for i in range(nloc):
+        for j in range(nloc):
+            for k in range(nloc):
+                Aref[i, j] += dV * float(np.dot(sg[k, i], sg[k, j]))
+    node_partition = uniform_partition(parts, tuple(parts_per_dir), nodes)
+    cell_partition = uniform_partition(parts, tuple(parts_per_dir), cells_per_dir)
+    strides = [int(np.prod(nodes[:d])) for d in range(D)]
+
+    def setup(cells):
+        axes = [np.arange(lo, hi + 1, dtype=I64) for lo, hi in cells.ranges]
+        grids = np.meshgrid(*axes, indexing="ij")
+        cc = [g.transpose(tuple(reversed(range(D)))).ravel() for g in grids]    # cells in column-major order
+        ncell = len(cc[0])
+        Im = np.zeros((ncell, nloc, nloc), I64)
+        Jm = np.zeros((ncell, nloc, nloc), I64)
+        ok = np.ones((ncell, nloc, nloc), bool)
+        node_id, node_ok = [], []
+        for a, la in enumerate(loc):
+            coord = [cc[d] + la[d] - 1 for d in range(D)]                           # cell + local_node - offset(2)
+            node_ok.append(np.all([(coord[d] >= 1) & (coord[d] <= nodes[d]) for d in range(D)], axis=0))
+            node_id.append(sum((coord[d] - 1) * strides[d] for d in range(D)) + 1)
+        for a in range(nloc):
+            for b in range(nloc):
+                Im[:, a, b], Jm[:, a, b] = node_id[a], node_id[b]
+                ok[:, a, b] = node_ok[a] & node_ok[b]
+        Vm = np.broadcast_to(Aref[None, :, :], ok.shape)
+        return Im[ok], Jm[ok], Vm[ok].copy()
+
+    I, J, V = tuple_of_arrays(pmap(setup, cell_partition))
+    return I, J, V, node_partition, node_partition

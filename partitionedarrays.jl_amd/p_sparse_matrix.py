@@ -226,3 +226,98 @@ def mul_no_overlap_(c: PVector, a: PSparseMatrix, b: PVector) -> PVector:
     pmap(lambda cv, blk, bv: spmv_(cv, blk.own_ghost, bv, L.SEG_GHOST, L.SEG_OWN, 1.0, 1.0),
          c.vector_partition, a.matrix_partition, b.vector_partition)
     return c
+
+
+# ----------------------------------------------------------------------------------------------
+# disassembled COO -> assembled split matrix (the default psparse route; FEM-style, BASELINE config 5)
+# ----------------------------------------------------------------------------------------------
+def _coo(A: HostCSR):
+    """findnz / nziterator of a CSR block: row-major, ascending columns (src/sparse_utils.jl:96-123)."""
+    rows = np.repeat(np.arange(1, A.m + 1, dtype=I64), np.diff(A.rowptr.astype(I64)))
+    return rows, A.colval.astype(I64), A.nzval
+
+
+def _split4(A: HostCSR, rows, cols):
+    """split_format_locally with ghost rows (src/p_sparse_matrix.jl:823-899): own_own, own_ghost, ghost_own, ghost_ghost."""
+    oo, oh = split_format_locally(A, rows, cols)
+    i, j, v = _coo(A)
+    g = i > rows.n_own
+    i, j, v = i[g] - rows.n_own, j[g], v[g]
+    own = j <= cols.n_own
+    ho = compresscoo(i[own], j[own], v[own], rows.n_ghost, cols.n_own)
+    hh = compresscoo(i[~own], j[~own] - cols.n_own, v[~own], rows.n_ghost, cols.n_ghost)
+    return oo, oh, ho, hh
+
+
+def _group_by_owner(owner, parts_snd, arrays):
+    slot = np.searchsorted(parts_snd, owner)
+    order = np.argsort(slot, kind="stable")
+    cuts = np.searchsorted(slot[order], np.arange(len(parts_snd) + 1))
+    return [[a[order][cuts[k]:cuts[k + 1]] for k in range(len(parts_snd))] for a in arrays]
+
+
+def psparse_assemble_host(blocks4, rows_sa, cols_sa, rows):
+    """assemble(B,rows) for a split-format sub-assembled matrix, first time (psparse_assemble_impl,
+    src/p_sparse_matrix.jl:1590-1756): ghost-row triplets travel to the owners of their rows, are appended to the
+    owners' COO lists, the ghost columns are renumbered (union_ghost) and everything is compressed with +.
+    Host-side set-up; returns (own_own, own_ghost) HostCSR per part and the final column partition."""
+    from .primitives import exchange, ExchangeGraph
+    from .p_range import assembly_neighbors, LocalIndices
+    parts_snd, parts_rcv = assembly_neighbors(rows_sa)
+
+    def setup_snd(blk, ps, r, c):                                   # setup_cache_snd :1598-1650
+        gi, gj, gv = _coo(blk[2])
+        hi, hj, hv = _coo(blk[3])
+        ii = np.concatenate([gi, hi])
+        gI = r.ghost_to_global[ii - 1]
+        gJ = np.concatenate([c.own_to_global[gj - 1], c.ghost_to_global[hj - 1]])
+        gV = np.concatenate([gv, hv])
+        return tuple(_group_by_owner(r.ghost_to_owner[ii - 1], np.asarray(ps), [gI, gJ, gV]))
+
+    from .primitives import tuple_of_arrays
+    I_snd, J_snd, V_snd = tuple_of_arrays(pmap(setup_snd, blocks4, parts_snd, rows_sa, cols_sa))
+    graph = ExchangeGraph(parts_snd, parts_rcv)
+    I_rcv, J_rcv, V_rcv = exchange(I_snd, graph), exchange(J_snd, graph), exchange(V_snd, graph)   # :1734-1736
+
+    def own_triplets(blk, Ir, Jr, Vr, r, c):                        # setup_own_triplets :1656-1689
+        cat = lambda xs, dt: np.concatenate([np.asarray(x, dt) for x in xs]) if len(xs) else np.zeros(0, dt)  # noqa: E731
+        Ir, Jr, Vr = cat(Ir, I64), cat(Jr, I64), cat(Vr, F64)
+        ooI, ooJ, ooV = _coo(blk[0])
+        ohI, ohJ, ohV = _coo(blk[1])
+        lj = c.global_to_local(Jr).astype(I64)
+        is_own = (lj >= 1) & (lj <= c.n_own)
+        li = r.global_to_local(Ir).astype(I64)
+        oo = (np.concatenate([ooI, li[is_own]]), np.concatenate([ooJ, lj[is_own]]), np.concatenate([ooV, Vr[is_own]]))
+        og = (np.concatenate([ohI, li[~is_own]]), np.concatenate([c.ghost_to_global[ohJ - 1], Jr[~is_own]]),
+              np.concatenate([ohV, Vr[~is_own]]))
+        return oo, og, og[1]
+
+    oo, og, Jg = tuple_of_arrays(pmap(own_triplets, blocks4, I_rcv, J_rcv, V_rcv, rows_sa, cols_sa))
+    J_owner = find_owner(cols_sa, Jg)
+    cols0 = pmap(lambda c: LocalIndices(c.n_global, c.part, np_=c.np_, n=c.n, ranges=c.ranges, starts=c.starts), cols_sa)  # remove_ghost
+    cols_fa = pmap(union_ghost, cols0, Jg, J_owner)
+
+    def finalize(oo_, og_, r, c):                                   # finalize_values :1690-1723
+        gj = c.global_to_local(og_[1]).astype(I64) - c.n_own        # map_global_to_ghost!
+        return (compresscoo(oo_[0], oo_[1], oo_[2], r.n_own, c.n_own), compresscoo(og_[0], gj, og_[2], r.n_own, c.n_ghost))
+
+    return pmap(finalize, oo, og, rows, cols_fa), cols_fa
+
+
+def psparse_disassembled(I, J, V, rows, cols, keep_host=False) -> PSparseMatrix:
+    """psparse(SparseMatrixCSR{1,Float64,Int32},I,J,V,rows,cols)|>fetch with the DEFAULT flags
+    (src/p_sparse_matrix.jl:1150-1219): every part may hold entries of rows it does not own (FEM assembly loops);
+    find_owner/union_ghost for rows and columns, local compress + split, then assemble onto `rows`."""
+    I_owner = find_owner(rows, I)
+    J_owner = find_owner(cols, J)
+    rows_sa = pmap(union_ghost, rows, I, I_owner)
+    cols_sa = pmap(union_ghost, cols, J, J_owner)
+
+    def local(Ii, Ji, Vi, r, c):
+        A = sparse_matrix(r.global_to_local(Ii), c.global_to_local(Ji), Vi, r.n_local, c.n_local)
+        return _split4(A, r, c)
+
+    blocks4 = pmap(local, I, J, V, rows_sa, cols_sa)
+    host, cols_fa = psparse_assemble_host(blocks4, rows_sa, cols_sa, rows)
+    dev = pmap(lambda h: SplitMatrixBlocks(DeviceCSR(h[0]), DeviceCSR(h[1])), host)
+    return PSparseMatrix(dev, rows, cols_fa, True, host if keep_host else None)

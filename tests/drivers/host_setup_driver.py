@@ -84,6 +84,24 @@ def main():
         assert np.array_equal(c2.get_local_to_global(), Ao.cols[k].local_to_global)
         assert np.array_equal(oo.colval, Ao.blocks[k].own_own.colval) and np.array_equal(oh.colval, Ao.blocks[k].own_ghost.colval)
         assert np.array_equal(oh.rowptr, Ao.blocks[k].own_ghost.rowptr) and np.array_equal(b2, bo[k][:c2.n_own])
+        # disassembled COO -> assembled (config 5 route): the triplet exchange crosses processes
+        if P in (2, 4):
+            fparts = {2: (2, 1), 4: (2, 2)}[P]
+            nodes = (7, 5)
+            I, J, V, frows, fcols = pa.laplacian_fem(nodes, fparts, ranks)
+            Io, Jo, Vo, orows, ocols = orc.laplacian_fem(nodes, fparts)
+            Af, _ = orc.psparse_disassembled(Io, Jo, Vo, orows, ocols)
+            rows_sa = pa.pmap(pa.union_ghost, frows, I, pa.find_owner(frows, I))
+            cols_sa = pa.pmap(pa.union_ghost, fcols, J, pa.find_owner(fcols, J))
+            import pa_amd.p_sparse_matrix as psm
+            b4 = pa.pmap(lambda Ii, Ji, Vi, r, c: psm._split4(
+                pa.sparse_matrix(r.global_to_local(Ii), c.global_to_local(Ji), Vi, r.n_local, c.n_local), r, c),
+                I, J, V, rows_sa, cols_sa)
+            host, cols_fa = pa.psparse_assemble_host(b4, rows_sa, cols_sa, frows)
+            assert np.array_equal(pa.getany(cols_fa).get_local_to_global(), Af.cols[k].local_to_global)
+            for mine, ref in zip(pa.getany(host), (Af.blocks[k].own_own, Af.blocks[k].own_ghost)):
+                assert np.array_equal(mine.rowptr, ref.rowptr) and np.array_equal(mine.colval, ref.colval)
+                assert np.array_equal(mine.nzval, ref.nzval)
         return True
 
     ok = pa.with_torchdist(body)

@@ -307,3 +307,51 @@ def test_full_size_27pt_128_two_parts_properties():
     pa.mul_(y4, A, x4)
     for a_, b_ in zip(y.own_values().items, y4.own_values().items):
         assert np.array_equal(4.0 * a_, b_)
+
+
+# ---------------------------------------------------------------- CG loop (BASELINE config 4 shape, small)
+def test_ref_cg_identity_preconditioner(orc):
+    """HPCG/src/ref_cg.jl with Pl = Identity(): consistent!+mul!, 2 dots + norm, 3 axpys per iteration, on 8 parts.
+    dot() reassociates, so the trajectory is compared within 1e-10 relative; the solve itself must converge to x = 1
+    (b = A*1 by construction, HPCG/src/sparse_matrix.jl:75)."""
+    A, b = pa.build_p_matrix(ranks(8), 8, 8, 8, 16, 16, 16, 2, 2, 2)
+    Ao, bo, _ = orc.hpcg_build_p_matrix(8, 8, 8, 2, 2, 2)
+    for overlap in (True, False):
+        x = pa.pzeros(A.col_partition)
+        hist = []
+        x, r0, r, it = pa.ref_cg_(x, A, b, maxiter=25, overlap=overlap, history=hist)
+        ho = []
+        xo, r0o, ro, ito = orc.ref_cg([np.zeros(c.n_local) for c in Ao.cols], Ao, [v.copy() for v in bo], maxiter=25, history=ho)
+        assert it == ito == 25 and abs(r0 - r0o) <= 1e-13 * r0o
+        assert np.allclose(hist, ho, rtol=1e-9, atol=1e-14 * r0o)
+        assert r / r0 < 1e-8
+        for vals, ind in zip(x.own_values().items, A.col_partition.items):
+            assert np.allclose(vals, 1.0, atol=1e-8)
+
+
+# ---------------------------------------------------------------- BASELINE config 5 (FEM, ghost-heavy, irregular rows)
+@pytest.mark.parametrize("nodes,parts", [((63, 47), (4, 2)), ((11, 9, 10), (2, 2, 2))])
+def test_config5_fem_disassembled_assemble_mul(orc, nodes, parts):
+    """gallery laplacian_fem: rows of 4/6/9 (2-D) or 8..27 (3-D) entries plus assembled interface rows; 8 parts.
+    psparse default route (disassembled -> assemble) then mul!: bit-exact against the oracle; CG converges."""
+    P = int(np.prod(parts))
+    I, J, V, rows, cols = pa.laplacian_fem(nodes, parts, ranks(P))
+    A = pa.psparse_disassembled(I, J, V, rows, cols)
+    Io, Jo, Vo, orows, ocols = orc.laplacian_fem(nodes, parts)
+    Ao, _ = orc.psparse_disassembled(Io, Jo, Vo, orows, ocols)
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = upload([v.copy() for v in xo], A.col_partition)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x)
+    yo = _oracle_mul(orc, Ao, xo)
+    for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+    # solve A u = A*1: CG must recover u = 1 (test/fem_example.jl:285-289 style end-to-end check)
+    ones = pa.pones(A.col_partition)
+    b = pa.pzeros(A.col_partition)
+    pa.mul_(b, A, ones)
+    u = pa.pzeros(A.col_partition)
+    u, r0, r, it = pa.ref_cg_(u, A, b, maxiter=400, tolerance=1e-12)
+    assert r / r0 <= 1e-12
+    for vals in u.own_values().items:
+        assert np.allclose(vals, 1.0, atol=1e-8)

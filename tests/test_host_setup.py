@@ -179,3 +179,29 @@ def test_fused_hpcg_setup_equals_oracle(orc, shape, parts):
             assert np.array_equal(mine.rowptr, ref.rowptr) and np.array_equal(mine.colval, ref.colval)
             assert np.array_equal(mine.nzval, ref.nzval)
         assert np.array_equal(b, bo[k][:r.n_own])
+
+
+@pytest.mark.parametrize("nodes,parts", [((6, 5), (2, 2)), ((4, 3, 3), (2, 1, 2)), ((7,), (3,)), ((9, 8), (4, 2))])
+def test_fem_disassembled_to_assembled_matches_oracle(orc, nodes, parts):
+    """BASELINE config 5 shape: laplacian_fem COO (rows of other parts included) -> psparse default route
+    (find_owner, union_ghost rows+cols, compress, split, assemble to owners, ghost renumbering): bit-exact."""
+    P = int(np.prod(parts))
+    I, J, V, rows, cols = pa.laplacian_fem(nodes, parts, ranks(P))
+    Io, Jo, Vo, orows, ocols = orc.laplacian_fem(nodes, parts)
+    for k in range(P):
+        assert np.array_equal(I.items[k], Io[k]) and np.array_equal(J.items[k], Jo[k]) and np.array_equal(V.items[k], Vo[k])
+    Ao, _ = orc.psparse_disassembled(Io, Jo, Vo, orows, ocols)
+    # host part of the product route (no device upload here)
+    rows_sa = pa.pmap(pa.union_ghost, rows, I, pa.find_owner(rows, I))
+    cols_sa = pa.pmap(pa.union_ghost, cols, J, pa.find_owner(cols, J))
+    import pa_amd.p_sparse_matrix as psm
+    blocks4 = pa.pmap(lambda Ii, Ji, Vi, r, c: psm._split4(
+        pa.sparse_matrix(r.global_to_local(Ii), c.global_to_local(Ji), Vi, r.n_local, c.n_local), r, c), I, J, V, rows_sa, cols_sa)
+    host, cols_fa = pa.psparse_assemble_host(blocks4, rows_sa, cols_sa, rows)
+    for k in range(P):
+        assert np.array_equal(cols_fa.items[k].get_local_to_global(), Ao.cols[k].local_to_global)
+        assert np.array_equal(cols_fa.items[k].get_local_to_owner(), Ao.cols[k].local_to_owner)
+        for mine, ref in zip(host.items[k], (Ao.blocks[k].own_own, Ao.blocks[k].own_ghost)):
+            assert (mine.m, mine.n) == (ref.m, ref.n)
+            assert np.array_equal(mine.rowptr, ref.rowptr) and np.array_equal(mine.colval, ref.colval)
+            assert np.array_equal(mine.nzval, ref.nzval)
