@@ -12,11 +12,11 @@
 // the reference's order, so SpMV is bit-identical to the CPU loop (no FMA contraction).
 //
 // SpMV design (bandwidth-bound; no MFMA on purpose):
-//   * host-side "row split": consecutive rows are grouped into chunks of <= 1024 stored entries
+//   * host-side "row split": consecutive rows are grouped into chunks of <= 1536 stored entries
 //     (PA_SPMV_CHUNK_NNZ); one 256-thread workgroup per chunk.
 //   * load phase: every lane streams 16-byte value pairs + 8-byte column pairs (fully coalesced,
 //     non-temporal: the matrix is read once and must not evict x from L2), gathers x through
-//     L1/L2, multiplies, and stages the products in LDS (8 KiB per workgroup).
+//     L1/L2, multiplies, and stages the products in LDS (12 KiB per workgroup).
 //   * reduce phase: one lane per row walks its products in LDS in ascending p -- the reference's
 //     left-to-right order -- and writes y.  64-wide wavefronts: lanes of a wave own consecutive rows,
 //     so their LDS reads are stride-(row length) apart: conflict-free for 27 (odd), 2-way for 18.
@@ -26,6 +26,8 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <cstring>
 #include <numeric>
 #include <string>
@@ -66,8 +68,18 @@ extern "C" int pa_device_count(int *count) {
 
 // shipped configuration of the row-split kernel (chosen with probe/spmv_probe.hip on MI355X)
 constexpr int SPMV_BLK = 256;
-constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (4)
+constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (6)
 constexpr bool SPMV_NT = true;
+
+static int host_threads(int64_t work) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int t = hw ? (int)hw : 4;
+  if (const char *e = getenv("PA_HOST_THREADS")) t = atoi(e);
+  if (t < 1) t = 1;
+  if (t > 32) t = 32;
+  if (work < ((int64_t)1 << 20)) t = 1;
+  return t;
+}
 
 __global__ void k_scale(double *__restrict__ y, int64_t n, double beta) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -432,6 +444,20 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std
     PA_HIP(hipMemcpy(A->d_val, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
   }
   PA_HIP(hipMemcpy(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size(), hipMemcpyHostToDevice));
+  // 16-bit windowed column stream (index compression; see pa_spmv_kernel.h). PA_SPMV_COL16=0 disables it.
+  {
+    const char *e = getenv("PA_SPMV_COL16");
+    A->use_c16 = !(e && atoi(e) == 0) && nnz > 0;
+    if (A->use_c16) {
+      std::vector<uint16_t> c16(nnz + pad, 0);
+      std::vector<int32_t> win((size_t)A->n_chunks * PA_C16_WINDOWS, 0);
+      A->n_c16_fallback = pa_encode_col16(crp.data(), col0, chunk_row, PA_SPMV_CHUNK_NNZ, c16.data(), win.data(), host_threads(nnz));
+      PA_HIP(hipMalloc(&A->d_col16, sizeof(uint16_t) * (nnz + pad)));
+      PA_HIP(hipMalloc(&A->d_win, sizeof(int32_t) * std::max<size_t>(1, win.size())));
+      PA_HIP(hipMemcpy(A->d_col16, c16.data(), sizeof(uint16_t) * (nnz + pad), hipMemcpyHostToDevice));
+      if (!win.empty()) PA_HIP(hipMemcpy(A->d_win, win.data(), sizeof(int32_t) * win.size(), hipMemcpyHostToDevice));
+    }
+  }
   if (compact) {
     PA_HIP(hipMalloc(&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc)));
     if (nc) PA_HIP(hipMemcpy(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice));
@@ -510,6 +536,8 @@ extern "C" int pa_csr_destroy(pa_csr *A) {
   (void)hipFree(A->d_val);
   (void)hipFree(A->d_chunk_row);
   if (A->d_row_ids) (void)hipFree(A->d_row_ids);
+  if (A->d_col16) (void)hipFree(A->d_col16);
+  if (A->d_win) (void)hipFree(A->d_win);
   delete A;
   return PA_OK;
 }
@@ -545,8 +573,14 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
   }
   if (A->n_chunks > 0) {
     const int cpx = (int)((A->n_chunks + 7) / 8);
-    hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT>), dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], A->d_crp, A->d_col, A->d_val,
-                       x->d + xoff, y->d + yoff, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta);
+    if (A->use_c16)
+      hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true>), dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], A->d_crp,
+                         A->d_col, A->d_col16, A->d_win, A->d_val, x->d + xoff, y->d + yoff, A->d_chunk_row, A->d_row_ids,
+                         (int)A->n_chunks, cpx, alpha, kbeta);
+    else
+      hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], A->d_crp,
+                         A->d_col, (const unsigned short *)nullptr, (const int *)nullptr, A->d_val, x->d + xoff, y->d + yoff,
+                         A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta);
   }
   PA_HIP(hipGetLastError());
   return PA_OK;

@@ -69,6 +69,10 @@ struct pa_csr {
   double *d_val = nullptr;         // padded
   int32_t *d_chunk_row = nullptr;  // n_chunks+1 row boundaries of the row split
   int32_t *d_row_ids = nullptr;    // compacted row -> row, or NULL
+  bool use_c16 = false;            // 16-bit windowed column stream present
+  int64_t n_c16_fallback = 0;      // chunks that keep 32-bit columns
+  uint16_t *d_col16 = nullptr;     // (slot << 12) | (col & 4095), padded
+  int32_t *d_win = nullptr;        // n_chunks * 16 window bases; [c*16] < 0 => 32-bit chunk
 };
 
 struct pa_plan {

@@ -275,11 +275,39 @@ int main(int argc, char **argv) {
     CK(hipMalloc(d_chunks, sizeof(int) * cr.size()));
     CK(hipMemcpy(*d_chunks, cr.data(), sizeof(int) * cr.size(), hipMemcpyHostToDevice));
   };
-#define ADD_SPMV(BLK, NPT, NT)                                                                              \
-  { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch); const int cpx = (nch + 7) / 8;                       \
-    V.push_back({"spmv<" #BLK "," #NPT "," #NT ">", [=]() {                                                   \
-      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
-                         d_y, dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
+  // host copy of the columns for the c16 encoder
+  std::vector<int> hcol(nnz);
+  CK(hipMemcpy(hcol.data(), d_col, sizeof(int) * nnz, hipMemcpyDeviceToHost));
+#define ADD_SPMV4(BLK, NPT, NT, C16)                                                                          \
+  { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, BLK * NPT, 4096, cr, &nl);           \
+    const int nch = (int)cr.size() - 1; int *dc; CK(hipMalloc(&dc, sizeof(int) * cr.size()));                   \
+    CK(hipMemcpy(dc, cr.data(), sizeof(int) * cr.size(), hipMemcpyHostToDevice));                               \
+    unsigned short *d16 = nullptr; int *dwin = nullptr;                                                         \
+    if (C16) { std::vector<uint16_t> c16(nnz + 8, 0); std::vector<int32_t> win((size_t)nch * 16, 0);            \
+      const int64_t nf = pa_encode_col16(rp.data(), hcol.data(), cr, BLK * NPT, c16.data(), win.data(), 32);    \
+      printf("c16<%d,%d>: %d chunks, %lld fall back to 32-bit columns\n", BLK, NPT, nch, (long long)nf);        \
+      CK(hipMalloc(&d16, 2 * (nnz + 8))); CK(hipMalloc(&dwin, 4 * win.size()));                                 \
+      CK(hipMemcpy(d16, c16.data(), 2 * (nnz + 8), hipMemcpyHostToDevice));                                     \
+      CK(hipMemcpy(dwin, win.data(), 4 * win.size(), hipMemcpyHostToDevice)); }                                 \
+    const int cpx = (nch + 7) / 8;                                                                              \
+    V.push_back({"spmv<" #BLK "," #NPT "," #NT ",c16=" #C16 ">", [=]() {                                        \
+      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, C16>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d16, dwin, \
+                         d_val, d_x, (C16 ? d_y2 : d_y), dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
+  ADD_SPMV4(256, 4, true, false)
+  ADD_SPMV4(256, 4, false, false)
+  ADD_SPMV4(256, 4, true, true)
+  ADD_SPMV4(256, 4, false, true)
+  ADD_SPMV4(256, 6, true, true)
+  ADD_SPMV4(256, 6, false, true)
+  ADD_SPMV4(256, 8, true, true)
+  ADD_SPMV4(256, 8, false, true)
+  ADD_SPMV4(256, 8, true, false)
+  ADD_SPMV4(512, 4, true, true)
+  ADD_SPMV4(128, 4, true, true)
+  ADD_SPMV4(128, 8, true, true)
+  ADD_SPMV4(256, 12, true, true)
+  ADD_SPMV4(256, 16, true, true)
+#if 0
   ADD_SPMV(256, 8, true)
   ADD_SPMV(256, 8, false)
   ADD_SPMV(256, 4, true)
@@ -386,6 +414,7 @@ int main(int argc, char **argv) {
   ADD_ABLR(512, 8, true, 0, 144)
   ADD_ABLR(512, 8, true, 16, 144)
   ADD_ABLR(256, 16, true, 0, 144)
+#endif
   {
     const long nb = (nnz + 2047) / 2048;
     V.push_back({"stream_only<256,8,nt>", [=]() { hipLaunchKernelGGL((k_stream<256, 8, true, false>), dim3(nb), dim3(256), 0, 0, d_col, d_val, d_x, d_y2, nnz); }, (double)nnz * 12, {}});
@@ -398,7 +427,7 @@ int main(int argc, char **argv) {
     unsigned long long *d_bad; CK(hipMalloc(&d_bad, 8));
     V[0].run(); CK(hipDeviceSynchronize());
     for (size_t i = 1; i < V.size(); ++i) {
-      if (V[i].name.rfind("persist", 0) != 0 && V[i].name.rfind("wave", 0) != 0 && V[i].name.rfind("spmv<64", 0) != 0) continue;
+      if (V[i].name.find("c16=true") == std::string::npos) continue;
       CK(hipMemset(d_y2, 0xff, sizeof(double) * nrows)); CK(hipMemset(d_bad, 0, 8));
       V[i].run();
       hipLaunchKernelGGL(k_cmp, dim3((nrows + 255) / 256), dim3(256), 0, 0, d_y, d_y2, nrows, d_bad);

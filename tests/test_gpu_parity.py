@@ -191,7 +191,7 @@ def test_spmv_irregular_bit_exact(orc, case):
     elif case == "long_rows":
         m, n = 40, 9000
         row_len = rng.integers(0, 50, m)
-        row_len[[3, 17, 39]] = [1025, 5000, 8999]                      # longer than one 1024-entry chunk
+        row_len[[3, 17, 39]] = [1537, 5000, 8999]                      # longer than one 1536-entry chunk
     elif case == "one_row":
         m, n, row_len = 1, 10, np.array([7])
     elif case == "all_empty":
@@ -355,3 +355,22 @@ def test_config5_fem_disassembled_assemble_mul(orc, nodes, parts):
     assert r / r0 <= 1e-12
     for vals in u.own_values().items:
         assert np.allclose(vals, 1.0, atol=1e-8)
+
+
+def test_col16_fallback_chunks_and_env_switch(orc, monkeypatch):
+    """Chunks whose columns need more than 16 windows of 4096 keep 32-bit columns; both encodings give the same bits,
+    and PA_SPMV_COL16=0 disables the 16-bit stream altogether."""
+    rng = np.random.default_rng(7)
+    m, n = 600, 400000
+    row_len = rng.integers(20, 60, m)
+    row_len[::3] = 3                                   # some rows cluster (few windows), most scatter over 400k columns
+    A = _random_csr(rng, m, n, row_len.astype(int))
+    oA = orc.CSR(A.m, A.n, A.rowptr, A.colval, A.nzval)
+    xh = rng.standard_normal(n)
+    exp = orc.oracle_c().spmv_csr(np.zeros(m), xh, oA)
+    x = pa.DeviceVector(n, 0).upload(xh)
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PA_SPMV_COL16", flag)
+        y = pa.DeviceVector(m, 0)
+        pa.spmv_(y, pa.DeviceCSR(A), x)
+        assert np.array_equal(y.download(), exp), flag
