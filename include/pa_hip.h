@@ -50,7 +50,7 @@ extern "C" {
 #define PA_STREAM_COMPUTE 0
 #define PA_STREAM_COMM 1
 
-#define PA_SPMV_CHUNK_NNZ 1536   /* LDS-staged products per workgroup (12 KiB of fp64) */
+#define PA_SPMV_CHUNK_NNZ 2048   /* LDS-staged products per workgroup (16 KiB of fp64) */
 
 typedef struct pa_ctx pa_ctx;     /* one device + its two streams                                  */
 typedef struct pa_vec pa_vec;     /* local values of one part of a PVector, layout [own | ghost]   */
@@ -110,6 +110,9 @@ int pa_csr_update_values(pa_csr *A, const double *nzval);   /* same pattern, new
 int pa_csr_destroy(pa_csr *A);
 int pa_csr_info(const pa_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int64_t *n_chunks,
                 int64_t *n_nonempty_rows, int64_t *n_long_rows);
+/* How the row-split chunks of A get their column indices (library-internal index compression; the values, the
+ * results and pa_csr_update_values are unaffected): recomputed from row patterns / 16-bit windowed stream / 32-bit. */
+int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern_chunks, int64_t *n_c16_chunks, int64_t *n_c32_chunks);
 /* y_seg = beta*y_seg + alpha*A*x_seg.
  *   spmv!(b,A,x)            (src/sparse_utils.jl:617-623,649-669)  <=> alpha=1, beta=0
  *   muladd!(b,A,x)          (src/p_sparse_matrix.jl:2088)            <=> alpha=1, beta=1

@@ -67,6 +67,7 @@ _SIGS = {
     "pa_csr_update_values": [P, P],
     "pa_csr_destroy": [P],
     "pa_csr_info": [P] + [C.POINTER(i64)] * 6,
+    "pa_csr_encoding": [P] + [C.POINTER(i64)] * 3,
     "pa_spmv": [P, P, cint, P, cint, f64, f64],
     "pa_plan_create": [P, i32, i64, i32, P, P, P, i32, P, P, P, cint, PP],
     "pa_plan_destroy": [P],

@@ -12,11 +12,11 @@
 // the reference's order, so SpMV is bit-identical to the CPU loop (no FMA contraction).
 //
 // SpMV design (bandwidth-bound; no MFMA on purpose):
-//   * host-side "row split": consecutive rows are grouped into chunks of <= 1536 stored entries
+//   * host-side "row split": consecutive rows are grouped into chunks of <= 2048 stored entries
 //     (PA_SPMV_CHUNK_NNZ); one 256-thread workgroup per chunk.
 //   * load phase: every lane streams 16-byte value pairs + 8-byte column pairs (fully coalesced,
 //     non-temporal: the matrix is read once and must not evict x from L2), gathers x through
-//     L1/L2, multiplies, and stages the products in LDS (12 KiB per workgroup).
+//     L1/L2, multiplies, and stages the products in LDS (16 KiB per workgroup).
 //   * reduce phase: one lane per row walks its products in LDS in ascending p -- the reference's
 //     left-to-right order -- and writes y.  64-wide wavefronts: lanes of a wave own consecutive rows,
 //     so their LDS reads are stride-(row length) apart: conflict-free for 27 (odd), 2-way for 18.
@@ -68,7 +68,7 @@ extern "C" int pa_device_count(int *count) {
 
 // shipped configuration of the row-split kernel (chosen with probe/spmv_probe.hip on MI355X)
 constexpr int SPMV_BLK = 256;
-constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (6)
+constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (8)
 constexpr bool SPMV_NT = true;
 
 static int host_threads(int64_t work) {
@@ -458,6 +458,25 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std
       if (!win.empty()) PA_HIP(hipMemcpy(A->d_win, win.data(), sizeof(int32_t) * win.size(), hipMemcpyHostToDevice));
     }
   }
+  // row-pattern descriptors (no column stream at all) for square, uncompacted blocks. PA_SPMV_PATTERN=0 disables.
+  {
+    const char *e = getenv("PA_SPMV_PATTERN");
+    const bool want = !(e && atoi(e) == 0) && nnz > 0 && !compact && n_rows == n_cols;
+    if (want) {
+      std::vector<int32_t> pdesc, pdelta;
+      A->n_pattern_chunks = pa_encode_patterns(crp.data(), col0, nc, chunk_row, PA_SPMV_CHUNK_NNZ, pdesc, pdelta, host_threads(nnz));
+      // worth it only when it covers most of the matrix
+      if (A->n_pattern_chunks * 2 >= A->n_chunks) {
+        A->use_pattern = true;
+        PA_HIP(hipMalloc(&A->d_pdesc, sizeof(int32_t) * pdesc.size()));
+        PA_HIP(hipMalloc(&A->d_pdelta, sizeof(int32_t) * pdelta.size()));
+        PA_HIP(hipMemcpy(A->d_pdesc, pdesc.data(), sizeof(int32_t) * pdesc.size(), hipMemcpyHostToDevice));
+        PA_HIP(hipMemcpy(A->d_pdelta, pdelta.data(), sizeof(int32_t) * pdelta.size(), hipMemcpyHostToDevice));
+      } else {
+        A->n_pattern_chunks = 0;
+      }
+    }
+  }
   if (compact) {
     PA_HIP(hipMalloc(&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc)));
     if (nc) PA_HIP(hipMemcpy(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice));
@@ -538,6 +557,8 @@ extern "C" int pa_csr_destroy(pa_csr *A) {
   if (A->d_row_ids) (void)hipFree(A->d_row_ids);
   if (A->d_col16) (void)hipFree(A->d_col16);
   if (A->d_win) (void)hipFree(A->d_win);
+  if (A->d_pdesc) (void)hipFree(A->d_pdesc);
+  if (A->d_pdelta) (void)hipFree(A->d_pdelta);
   delete A;
   return PA_OK;
 }
@@ -551,6 +572,19 @@ extern "C" int pa_csr_info(const pa_csr *A, int64_t *n_rows, int64_t *n_cols, in
   if (n_chunks) *n_chunks = A->n_chunks;
   if (n_nonempty) *n_nonempty = A->n_nonempty;
   if (n_long) *n_long = A->n_long;
+  return PA_OK;
+}
+
+extern "C" int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern, int64_t *n_c16, int64_t *n_c32) {
+  PA_REQUIRE(A != nullptr, "csr is NULL");
+  const int64_t pat = A->use_pattern ? A->n_pattern_chunks : 0;
+  // chunks without a pattern descriptor use the 16-bit stream when they encode, else 32-bit columns
+  int64_t c16 = 0;
+  if (A->use_c16) c16 = (A->n_chunks - A->n_c16_fallback) - pat;
+  if (c16 < 0) c16 = 0;
+  if (n_pattern) *n_pattern = pat;
+  if (n_c16) *n_c16 = c16;
+  if (n_c32) *n_c32 = A->n_chunks - pat - c16;
   return PA_OK;
 }
 
@@ -573,14 +607,15 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
   }
   if (A->n_chunks > 0) {
     const int cpx = (int)((A->n_chunks + 7) / 8);
-    if (A->use_c16)
-      hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true>), dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], A->d_crp,
-                         A->d_col, A->d_col16, A->d_win, A->d_val, x->d + xoff, y->d + yoff, A->d_chunk_row, A->d_row_ids,
-                         (int)A->n_chunks, cpx, alpha, kbeta);
-    else
-      hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], A->d_crp,
-                         A->d_col, (const unsigned short *)nullptr, (const int *)nullptr, A->d_val, x->d + xoff, y->d + yoff,
-                         A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta);
+#define PA_LAUNCH_SPMV(C16, PAT)                                                                                     \
+  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT>), dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], \
+                     A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val, x->d + xoff,       \
+                     y->d + yoff, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta)
+    if (A->use_pattern && A->use_c16) PA_LAUNCH_SPMV(true, true);
+    else if (A->use_pattern) PA_LAUNCH_SPMV(false, true);
+    else if (A->use_c16) PA_LAUNCH_SPMV(true, false);
+    else PA_LAUNCH_SPMV(false, false);
+#undef PA_LAUNCH_SPMV
   }
   PA_HIP(hipGetLastError());
   return PA_OK;

@@ -73,6 +73,10 @@ struct pa_csr {
   int64_t n_c16_fallback = 0;      // chunks that keep 32-bit columns
   uint16_t *d_col16 = nullptr;     // (slot << 12) | (col & 4095), padded
   int32_t *d_win = nullptr;        // n_chunks * 16 window bases; [c*16] < 0 => 32-bit chunk
+  bool use_pattern = false;        // row-pattern descriptors present
+  int64_t n_pattern_chunks = 0;    // chunks whose columns are recomputed from a pattern
+  int32_t *d_pdesc = nullptr;      // n_chunks * 16 descriptor ints; [c*16] = #segments or 0
+  int32_t *d_pdelta = nullptr;     // 32 deltas per pattern
 };
 
 struct pa_plan {

@@ -9,7 +9,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -30,14 +32,43 @@ typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 //            stored entry instead of 4.  Pure index compression: values stay fp64, pa_csr_update_values is unaffected,
 //            and a chunk whose columns need more windows keeps the 32-bit path (win[chunk][0] < 0).
 #define PA_C16_WINDOWS 16
+//   "row patterns": no per-entry column at all.  A row's pattern is its list of (col - row) deltas; stencil / FEM
+//            matrices on structured grids have a handful of distinct patterns (27-pt: 27).  A chunk made of at most
+//            PA_PAT_SEGMENTS runs of consecutive rows with one pattern each is described by 16 ints (pdesc) and its
+//            columns are recomputed: col = first_row(seg) + (t / L) + delta[pat(seg)][t % L], t = entry index inside
+//            the segment.  Chunks that do not fit (more runs, rows longer than PA_PAT_MAXLEN) use c16 / 32-bit columns.
+#define PA_PAT_SEGMENTS 4
+#define PA_PAT_MAXLEN 32
+
+// column of entry q (relative to the chunk's first entry) from the chunk's pattern descriptor
+__device__ __forceinline__ int pa_pattern_col(int q, int nq, int q1, int q2, int q3, int L0, int L1, int L2, int L3,
+                                              int s0r, int s1r, int s2r, int s3r, int dA, int dB) {
+  q = max(0, min(q, nq));
+  const bool g1 = q >= q1, g2 = q >= q2, g3 = q >= q3;  // chained selects (a runtime-indexed array would go to scratch)
+  int qs = g1 ? q1 : 0, L = g1 ? L1 : L0, rs = g1 ? s1r : s0r;
+  qs = g2 ? q2 : qs; L = g2 ? L2 : L; rs = g2 ? s2r : rs;
+  qs = g3 ? q3 : qs; L = g3 ? L3 : L; rs = g3 ? s3r : rs;
+  const int s = (int)g1 + (int)g2 + (int)g3;
+  const int t = q - qs;
+  const int rr = L == 1 ? t : (int)__umulhi((unsigned)t, 0xFFFFFFFFu / (unsigned)L + 1u);  // t / L, exact for t < 2^32 / L
+  const int kk = t - rr * L;
+  // lanes 0-31 / 32-63 of dA hold the deltas of segment 0 / 1, of dB those of segment 2 / 3.  ds_bpermute reads the
+  // SOURCE lane's register, so both are fetched and the requesting lane selects.
+  const int sel = (((s & 1) << 5) + kk) << 2;
+  const int delA = __builtin_amdgcn_ds_bpermute(sel, dA);
+  const int delB = __builtin_amdgcn_ds_bpermute(sel, dB);
+  return rs + rr + ((s & 2) ? delB : delA);
+}
 
 // y[row] = beta*y[row] + sum_p (val[p]*x[col[p]])*alpha, products summed in ascending p.
 //   BLK  threads per workgroup, NPT stored entries per lane (chunk capacity CAP = BLK*NPT products in LDS),
-//   NT   non-temporal matrix loads, C16 use the 16-bit column stream where the chunk has one.
-template <int BLK, int NPT, bool NT, bool C16>
+//   NT   non-temporal matrix loads, C16 use the 16-bit column stream where the chunk has one,
+//   PAT  use row-pattern descriptors where the chunk has one (pdesc/pdelta may be NULL when PAT is false).
+template <int BLK, int NPT, bool NT, bool C16, bool PAT>
 __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
-    const int *__restrict__ win, const double *__restrict__ val, const double *__restrict__ x,
+    const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
+    const double *__restrict__ val, const double *__restrict__ x,
     double *__restrict__ y, const int *__restrict__ chunk_row, const int *__restrict__ row_ids, int n_chunks,
     int chunks_per_xcd, double alpha, double beta) {
   constexpr int CAP = BLK * NPT;
@@ -65,12 +96,35 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     // each load before issuing the next (one HBM round trip per k instead of one per chunk).
     // Every load instruction is contiguous across the 64 lanes (16 B, 8 B or 4 B per lane).
     const int last = max((p1 - 1) & ~1, 0);
-    int mywin = 0;
-    if (C16) mywin = win[chunk * PA_C16_WINDOWS + (tid & (PA_C16_WINDOWS - 1))];
-    const bool use16 = C16 && (__builtin_amdgcn_readfirstlane(mywin) >= 0);   // lane 0 holds window 0
+    int nseg = 0;
+    if (PAT) nseg = pdesc[chunk * 16];
+    int mywin = -1;
+    if (C16 && nseg <= 0) mywin = win[chunk * PA_C16_WINDOWS + (tid & (PA_C16_WINDOWS - 1))];
+    const bool use16 = C16 && nseg <= 0 && (__builtin_amdgcn_readfirstlane(mywin) >= 0);   // lane 0 holds window 0
     d2 v[NPT / 2];
     int c0[NPT / 2], c1[NPT / 2];
-    if (use16) {
+    if (PAT && nseg > 0) {
+      const int *d = pdesc + chunk * 16;
+      const int q1 = d[1], q2 = d[2], q3 = d[3];
+      const int s0r = d[4], s1r = d[5], s2r = d[6], s3r = d[7];
+      const int L0 = d[8], L1 = d[9], L2 = d[10], L3 = d[11];
+      const int pt0 = d[12], pt1 = d[13], pt2 = d[14], pt3 = d[15];
+      const int lane = tid & 63;
+      const int dA = pdelta[((lane >> 5) ? pt1 : pt0) * PA_PAT_MAXLEN + (lane & 31)];
+      const int dB = pdelta[((lane >> 5) ? pt3 : pt2) * PA_PAT_MAXLEN + (lane & 31)];
+#pragma unroll
+      for (int k = 0; k < NPT / 2; ++k) {
+        const int idx = min(base + (k * BLK + tid) * 2, last);
+        v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+      }
+      const int nq = p1 - p0 - 1;
+#pragma unroll
+      for (int k = 0; k < NPT / 2; ++k) {
+        const int idx = min(base + (k * BLK + tid) * 2, last);
+        c0[k] = pa_pattern_col(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
+        c1[k] = pa_pattern_col(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
+      }
+    } else if (use16) {
       unsigned q[NPT / 2];
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
@@ -198,6 +252,94 @@ inline int64_t pa_encode_col16(const int32_t *crp, const int32_t *col, const std
   int64_t nf = 0;
   for (auto v : fallback) nf += v;
   return nf;
+}
+
+// Host-side row-pattern analysis.  pdesc: n_chunks*16 ints ({nseg | 0, q1..q3, r0..r3, L0..L3, pat0..pat3});
+// pdelta: PA_PAT_MAXLEN ints per pattern.  Returns the number of chunks that got a descriptor (0: give up, e.g. an
+// unstructured matrix where every row is its own pattern).
+inline int64_t pa_encode_patterns(const int32_t *crp, const int32_t *col, int64_t n_rows,
+                                  const std::vector<int32_t> &chunk_row, int cap, std::vector<int32_t> &pdesc,
+                                  std::vector<int32_t> &pdelta, int n_threads, int max_patterns = 4096) {
+  const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
+  pdesc.assign((size_t)n_chunks * 16, 0);
+  pdelta.clear();
+  if (n_threads < 1) n_threads = 1;
+  // phase A (parallel): a 64-bit hash of every row's delta list
+  std::vector<uint64_t> h(n_rows);
+  auto hash_rows = [&](int t) {
+    for (int64_t r = n_rows * t / n_threads; r < n_rows * (t + 1) / n_threads; ++r) {
+      uint64_t x = 1469598103934665603ull ^ (uint64_t)(crp[r + 1] - crp[r]);
+      for (int64_t p = crp[r]; p < crp[r + 1]; ++p) { x ^= (uint64_t)(uint32_t)(col[p] - (int32_t)r); x *= 1099511628211ull; x ^= x >> 29; }
+      h[r] = x;
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(hash_rows, t);
+    hash_rows(0);
+    for (auto &x : th) x.join();
+  }
+  // phase B (sequential, one map lookup per row): pattern ids, verified against the stored deltas
+  std::vector<int32_t> rowpat(n_rows);
+  std::vector<int32_t> plen;
+  std::unordered_map<uint64_t, std::vector<int32_t>> ids;
+  for (int64_t r = 0; r < n_rows; ++r) {
+    const int len = crp[r + 1] - crp[r];
+    if (len > PA_PAT_MAXLEN) { rowpat[r] = -1; continue; }
+    auto &cand = ids[h[r]];
+    int32_t id = -1;
+    for (int32_t c : cand) {
+      if (plen[c] != len) continue;
+      bool same = true;
+      for (int k = 0; k < len && same; ++k) same = pdelta[(size_t)c * PA_PAT_MAXLEN + k] == col[crp[r] + k] - (int32_t)r;
+      if (same) { id = c; break; }
+    }
+    if (id < 0) {
+      if ((int)plen.size() >= max_patterns) { pdesc.assign((size_t)n_chunks * 16, 0); pdelta.assign(PA_PAT_MAXLEN, 0); return 0; }
+      id = (int32_t)plen.size();
+      plen.push_back(len);
+      pdelta.resize((size_t)(id + 1) * PA_PAT_MAXLEN, 0);
+      for (int k = 0; k < len; ++k) pdelta[(size_t)id * PA_PAT_MAXLEN + k] = col[crp[r] + k] - (int32_t)r;
+      cand.push_back(id);
+    }
+    rowpat[r] = id;
+  }
+  if (pdelta.empty()) pdelta.assign(PA_PAT_MAXLEN, 0);
+  // phase C (parallel): runs of equal patterns inside every chunk
+  std::vector<int64_t> good(n_threads, 0);
+  auto segs = [&](int t) {
+    for (int64_t c = n_chunks * t / n_threads; c < n_chunks * (t + 1) / n_threads; ++c) {
+      int32_t *d = &pdesc[(size_t)c * 16];
+      const int64_t r0 = chunk_row[c], r1 = chunk_row[c + 1];
+      const int64_t p0 = crp[r0], p1 = crp[r1];
+      bool ok = (p1 - (p0 & ~1)) <= cap && p1 > p0;
+      int ns = 0;
+      for (int64_t r = r0; ok && r < r1; ++r) {
+        if (rowpat[r] < 0) { ok = false; break; }
+        if (ns == 0 || rowpat[r] != d[12 + ns - 1]) {
+          if (ns == PA_PAT_SEGMENTS) { ok = false; break; }
+          if (ns) d[ns] = (int32_t)(crp[r] - p0);
+          d[4 + ns] = (int32_t)r;
+          d[8 + ns] = crp[r + 1] - crp[r] > 0 ? crp[r + 1] - crp[r] : 1;
+          d[12 + ns] = rowpat[r];
+          ++ns;
+        }
+      }
+      if (!ok) { for (int k = 0; k < 16; ++k) d[k] = 0; continue; }
+      for (int s = ns; s < PA_PAT_SEGMENTS; ++s) { if (s) d[s] = 1 << 30; d[4 + s] = 0; d[8 + s] = 1; d[12 + s] = 0; }
+      d[0] = ns;
+      ++good[t];
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(segs, t);
+    segs(0);
+    for (auto &x : th) x.join();
+  }
+  int64_t ng = 0;
+  for (auto v : good) ng += v;
+  return ng;
 }
 
 #endif

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_abl(
   }
 }
 
+
 __global__ void k_cmp(const double *a, const double *b, long n, unsigned long long *bad) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && __double_as_longlong(a[i]) != __double_as_longlong(b[i])) atomicAdd(bad, 1ull);
@@ -291,22 +293,60 @@ int main(int argc, char **argv) {
       CK(hipMemcpy(dwin, win.data(), 4 * win.size(), hipMemcpyHostToDevice)); }                                 \
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"spmv<" #BLK "," #NPT "," #NT ",c16=" #C16 ">", [=]() {                                        \
-      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, C16>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d16, dwin, \
-                         d_val, d_x, (C16 ? d_y2 : d_y), dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
+      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, C16, false>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d16, dwin, \
+                         (const int *)nullptr, (const int *)nullptr, d_val, d_x, (C16 ? d_y2 : d_y), dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
   ADD_SPMV4(256, 4, true, false)
-  ADD_SPMV4(256, 4, false, false)
-  ADD_SPMV4(256, 4, true, true)
-  ADD_SPMV4(256, 4, false, true)
   ADD_SPMV4(256, 6, true, true)
-  ADD_SPMV4(256, 6, false, true)
-  ADD_SPMV4(256, 8, true, true)
-  ADD_SPMV4(256, 8, false, true)
-  ADD_SPMV4(256, 8, true, false)
-  ADD_SPMV4(512, 4, true, true)
-  ADD_SPMV4(128, 4, true, true)
-  ADD_SPMV4(128, 8, true, true)
-  ADD_SPMV4(256, 12, true, true)
-  ADD_SPMV4(256, 16, true, true)
+  ADD_SPMV4(256, 6, true, false)
+  ADD_SPMV4(256, 10, true, true)
+  ADD_SPMV4(192, 8, true, true)
+  // ---- allocation-attribute experiments: matrix stream and/or y in "uncached" (MTYPE_UC) memory -----------
+  {
+    std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, 256 * 6, 4096, cr, &nl);
+    const int nch = (int)cr.size() - 1; int *dc; CK(hipMalloc(&dc, sizeof(int) * cr.size()));
+    CK(hipMemcpy(dc, cr.data(), sizeof(int) * cr.size(), hipMemcpyHostToDevice));
+    std::vector<uint16_t> c16(nnz + 8, 0); std::vector<int32_t> win((size_t)nch * 16, 0);
+    pa_encode_col16(rp.data(), hcol.data(), cr, 256 * 6, c16.data(), win.data(), 32);
+    unsigned short *d16, *u16; int *dwin; double *uval, *uy;
+    CK(hipMalloc(&d16, 2 * (nnz + 8))); CK(hipMalloc(&dwin, 4 * win.size()));
+    CK(hipMemcpy(d16, c16.data(), 2 * (nnz + 8), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dwin, win.data(), 4 * win.size(), hipMemcpyHostToDevice));
+    CK(hipExtMallocWithFlags((void **)&u16, 2 * (nnz + 8), hipDeviceMallocUncached));
+    CK(hipExtMallocWithFlags((void **)&uval, 8 * (nnz + 8), hipDeviceMallocUncached));
+    CK(hipExtMallocWithFlags((void **)&uy, 8 * nrows, hipDeviceMallocUncached));
+    CK(hipMemcpy(u16, d16, 2 * (nnz + 8), hipMemcpyDeviceToDevice));
+    CK(hipMemcpy(uval, d_val, 8 * (nnz + 8), hipMemcpyDeviceToDevice));
+    const int cpx = (nch + 7) / 8;
+#define ADD_ATTR(NAME, VALP, C16P, YP, NT)                                                                   \
+    V.push_back({NAME, [=]() {                                                                                 \
+      hipLaunchKernelGGL((k_spmv_rowsplit<256, 6, NT, true, false>), dim3(cpx * 8), dim3(256), 0, 0, d_rp, d_col, C16P, dwin, \
+                         (const int *)nullptr, (const int *)nullptr, VALP, d_x, YP, dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}});
+    ADD_ATTR("c16 base (cached all, nt)", d_val, d16, d_y2, true)
+    ADD_ATTR("c16 matrix uncached, nt", uval, u16, d_y2, true)
+    ADD_ATTR("c16 matrix uncached, plain", uval, u16, d_y2, false)
+    ADD_ATTR("c16 y uncached, nt", d_val, d16, uy, true)
+    ADD_ATTR("c16 matrix+y uncached, nt", uval, u16, uy, true)
+  }
+
+  // ---- row-pattern mode of the product kernel ------------------------------------------------------------------
+#define ADD_PAT(BLK, NPT)                                                                                     \
+  { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, BLK * NPT, 4096, cr, &nl);           \
+    const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
+    const int64_t ng = pa_encode_patterns(rp.data(), hcol.data(), nrows, cr, BLK * NPT, pdesc, pdelta, 32);     \
+    printf("pattern<%d,%d>: %d chunks, %lld with a descriptor, %zu patterns\n", BLK, NPT, nch, (long long)ng, pdelta.size() / 32); \
+    int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
+    const int cpx = (nch + 7) / 8;                                                                              \
+    V.push_back({"pattern<" #BLK "," #NPT ">c16=true", [=]() {                                                  \
+      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, true, false, true>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, \
+                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
+                         (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
+  ADD_PAT(256, 8)
+  ADD_PAT(256, 6)
+  ADD_PAT(256, 10)
+  ADD_PAT(256, 12)
+  ADD_PAT(512, 8)
 #if 0
   ADD_SPMV(256, 8, true)
   ADD_SPMV(256, 8, false)

@@ -92,6 +92,12 @@ class DeviceCSR:
         keys = ["n_rows", "n_cols", "nnz", "n_chunks", "n_nonempty_rows", "n_long_rows"]
         return dict(zip(keys, [x.value for x in v]))
 
+    def encoding(self):
+        """Chunks by column encoding: recomputed from row patterns / 16-bit windowed stream / 32-bit columns."""
+        v = [C.c_int64() for _ in range(3)]
+        L.call("pa_csr_encoding", self.h, *[C.byref(x) for x in v])
+        return dict(zip(["pattern", "c16", "c32"], [x.value for x in v]))
+
     def update_values(self, nzval):
         nzval = np.ascontiguousarray(nzval, F64)
         assert len(nzval) == self.nnz

@@ -191,7 +191,7 @@ def test_spmv_irregular_bit_exact(orc, case):
     elif case == "long_rows":
         m, n = 40, 9000
         row_len = rng.integers(0, 50, m)
-        row_len[[3, 17, 39]] = [1537, 5000, 8999]                      # longer than one 1536-entry chunk
+        row_len[[3, 17, 39]] = [2049, 5000, 8999]                      # longer than one 2048-entry chunk
     elif case == "one_row":
         m, n, row_len = 1, 10, np.array([7])
     elif case == "all_empty":
@@ -357,20 +357,52 @@ def test_config5_fem_disassembled_assemble_mul(orc, nodes, parts):
         assert np.allclose(vals, 1.0, atol=1e-8)
 
 
-def test_col16_fallback_chunks_and_env_switch(orc, monkeypatch):
-    """Chunks whose columns need more than 16 windows of 4096 keep 32-bit columns; both encodings give the same bits,
-    and PA_SPMV_COL16=0 disables the 16-bit stream altogether."""
+def test_column_encodings_agree_bit_for_bit(orc, monkeypatch):
+    """The three per-chunk column encodings (row patterns / 16-bit windows / 32-bit) give the same bits, on a matrix
+    that mixes them: banded structured rows (patterns), rows longer than 32 (no pattern), >4 pattern runs in a chunk,
+    columns scattered over 400k (no 16-bit windows).  PA_SPMV_PATTERN / PA_SPMV_COL16 switch the encodings off."""
     rng = np.random.default_rng(7)
-    m, n = 600, 400000
-    row_len = rng.integers(20, 60, m)
-    row_len[::3] = 3                                   # some rows cluster (few windows), most scatter over 400k columns
-    A = _random_csr(rng, m, n, row_len.astype(int))
+    n = 400000
+    I, J = [], []
+    for r in range(1, 3001):                              # structured band: 5 deltas, boundary rows cut
+        for dlt in (-700, -1, 0, 1, 700):
+            if 1 <= r + dlt <= n:
+                I.append(r); J.append(r + dlt)
+    for r in range(3001, 3400):                           # alternating short patterns: many runs per chunk
+        for dlt in ((0, 3) if r % 2 else (0, 5, 9)):
+            I.append(r); J.append(r + dlt)
+    for r in range(3400, 3500):                           # rows of 40 entries (longer than a pattern may be)
+        for dlt in range(40):
+            I.append(r); J.append(r + 2 * dlt)
+    for r in range(3500, 4000):                           # scattered columns
+        for c in rng.choice(n, size=rng.integers(20, 60), replace=False):
+            I.append(r); J.append(int(c) + 1)
+    V = rng.standard_normal(len(I))
+    A = pa.compresscoo(I, J, V, n, n)
     oA = orc.CSR(A.m, A.n, A.rowptr, A.colval, A.nzval)
     xh = rng.standard_normal(n)
-    exp = orc.oracle_c().spmv_csr(np.zeros(m), xh, oA)
+    exp = orc.oracle_c().mul5_csr(np.full(n, 0.5), oA, xh, -1.5, 2.0)
     x = pa.DeviceVector(n, 0).upload(xh)
-    for flag in ("1", "0"):
-        monkeypatch.setenv("PA_SPMV_COL16", flag)
-        y = pa.DeviceVector(m, 0)
-        pa.spmv_(y, pa.DeviceCSR(A), x)
-        assert np.array_equal(y.download(), exp), flag
+    seen = set()
+    for pat, c16 in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("PA_SPMV_PATTERN", pat)
+        monkeypatch.setenv("PA_SPMV_COL16", c16)
+        dA = pa.DeviceCSR(A)
+        enc = dA.encoding()
+        seen.add((enc["pattern"] > 0, enc["c16"] > 0, enc["c32"] > 0))
+        y = pa.DeviceVector(n, 0).upload(np.full(n, 0.5))
+        pa.spmv_(y, dA, x, alpha=-1.5, beta=2.0)
+        assert np.array_equal(y.download(), exp), (pat, c16, enc)
+    assert (False, False, True) in seen                   # everything 32-bit when both are off
+    # the default build of an HPCG matrix with long x-lines is (almost) all patterns; short lines put more than 4
+    # pattern runs in a chunk and use the 16-bit stream instead
+    monkeypatch.delenv("PA_SPMV_PATTERN"); monkeypatch.delenv("PA_SPMV_COL16")
+    A27, b27 = pa.build_p_matrix(ranks(1), 128, 6, 5, 128, 6, 5, 1, 1, 1)
+    e = A27.matrix_partition.items[0].own_own.encoding()
+    assert e["pattern"] > 0 and e["c32"] == 0
+    y = pa.pzeros(A27.row_partition)
+    pa.mul_(y, A27, pa.pones(A27.col_partition))
+    assert np.array_equal(y.own_values().items[0], b27.own_values().items[0])
+    A16, _ = pa.build_p_matrix(ranks(1), 16, 16, 16, 16, 16, 16, 1, 1, 1)
+    e = A16.matrix_partition.items[0].own_own.encoding()
+    assert e["pattern"] == 0 and e["c16"] > 0 and e["c32"] == 0
