@@ -94,6 +94,9 @@ int pa_vec_axpby(pa_vec *y, double a, const pa_vec *x, double b, int segment);
  * copied back (synchronises the compute stream). */
 int pa_vec_dot(const pa_vec *x, const pa_vec *y, double *host_out);
 int pa_vec_dot_result(pa_ctx *ctx, void **device_scalar);
+/* Read the device scalar back (synchronises the compute stream): the value of the last pa_vec_dot, or of its
+ * all-reduce over the parts after pa_comm_allreduce_sum(comm, device_scalar, 1, PA_STREAM_COMPUTE). */
+int pa_ctx_read_scalar(pa_ctx *ctx, double *host_out);
 
 /* ---- CSR blocks: the local matrix type (src/sparse_utils.jl:609-669; SplitMatrix blocks
  *      src/p_sparse_matrix.jl:588-627,670-681) ------------------------------------------------- */

@@ -62,6 +62,7 @@ _SIGS = {
     "pa_vec_axpby": [P, f64, P, f64, cint],
     "pa_vec_dot": [P, P, C.POINTER(f64)],
     "pa_vec_dot_result": [P, PP],
+    "pa_ctx_read_scalar": [P, C.POINTER(f64)],
     "pa_csr_create": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_create_from_csc": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_update_values": [P, P],

@@ -389,6 +389,14 @@ extern "C" int pa_vec_dot(const pa_vec *x, const pa_vec *y, double *host_out) {
   return PA_OK;
 }
 
+extern "C" int pa_ctx_read_scalar(pa_ctx *c, double *host_out) {
+  PA_REQUIRE(c && host_out, "bad arguments");
+  PA_HIP(hipSetDevice(c->device));
+  PA_HIP(hipMemcpyAsync(host_out, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, c->s[0]));
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  return PA_OK;
+}
+
 extern "C" int pa_vec_dot_result(pa_ctx *c, void **p) {
   PA_REQUIRE(c && p, "bad arguments");
   *p = c->d_scalar;

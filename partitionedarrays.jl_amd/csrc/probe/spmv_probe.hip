@@ -66,109 +66,11 @@ __global__ void k_readsum(const d2 *__restrict__ a, double *out, long n2) {
   if (s == 123.456) out[0] = s;
 }
 
-// ---- persistent variant: a workgroup walks several chunks of its XCD's range ------------------------
-#define PA_RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-template <int BLK, int NPT, bool NT, bool RAW = false>
-__global__ __launch_bounds__(BLK) void k_spmv_persistent(
-    const int *__restrict__ crp, const int *__restrict__ col, const double *__restrict__ val,
-    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ chunk_row,
-    int n_chunks, int chunks_per_xcd, int blocks_per_xcd) {
-  constexpr int CAP = BLK * NPT;
-  __shared__ double prod[CAP];
-  const int tid = threadIdx.x;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
-  const int c_end = min((xcd + 1) * chunks_per_xcd, n_chunks);
-  for (int chunk = xcd * chunks_per_xcd + lb; chunk < c_end; chunk += blocks_per_xcd) {
-    const int r0 = chunk_row[chunk], r1 = chunk_row[chunk + 1];
-    const int p0 = crp[r0], p1 = crp[r1];
-    const int base = p0 & ~1;
-    int ra = 0, re = 0;
-    if (r0 + tid < r1) { ra = crp[r0 + tid]; re = crp[r0 + tid + 1]; }
-    d2 v[NPT / 2]; i2 c[NPT / 2];
-#pragma unroll
-    for (int k = 0; k < NPT / 2; ++k) {
-      const int idx = min(base + (k * BLK + tid) * 2, max((p1 - 1) & ~1, 0));
-      v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
-      c[k] = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + idx));
-    }
-#pragma unroll
-    for (int k = 0; k < NPT / 2; ++k) {
-      d2 pr; pr.x = v[k].x * x[c[k].x]; pr.y = v[k].y * x[c[k].y];
-      *reinterpret_cast<d2 *>(&prod[(k * BLK + tid) * 2]) = pr;
-    }
-    if (RAW) PA_RAW_BARRIER(); else __syncthreads();
-    for (int r = r0 + tid; r < r1; r += BLK) {
-      if (r != r0 + tid) { ra = crp[r]; re = crp[r + 1]; }
-      double acc = 0.0;
-      const int a = ra - base, e = re - base;
-#pragma unroll 4
-      for (int p = a; p < e; ++p) acc = acc + prod[p];
-      y[r] = acc;
-    }
-    if (RAW) PA_RAW_BARRIER(); else __syncthreads();
-  }
-}
-
-
-// ---- wave-autonomous variant: one 64-lane wave = one chunk of <= 64*k rows, no workgroup barrier ------
-template <int WCAP, bool NT, bool PIPE, bool RAW = false>
-__global__ __launch_bounds__(64) void k_spmv_wave(
-    const int *__restrict__ crp, const int *__restrict__ col, const double *__restrict__ val,
-    const double *__restrict__ x, double *__restrict__ y, const int4 *__restrict__ desc,
-    int n_chunks, int chunks_per_xcd, int waves_per_xcd) {
-  constexpr int NP = WCAP / 128;
-  __shared__ double prod[WCAP];
-  const int lane = threadIdx.x;
-  const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3;
-  const int c_end = min((xcd + 1) * chunks_per_xcd, n_chunks);
-  int chunk = xcd * chunks_per_xcd + lb;
-  if (chunk >= c_end) return;
-  d2 v[NP]; i2 c[NP];
-  int4 d = desc[chunk];   // {r0, r1, base, p1}
-  auto issue = [&](const int4 &dd) {
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const int idx = min(dd.z + (k * 64 + lane) * 2, max((dd.w - 1) & ~1, 0));
-      v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
-      c[k] = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + idx));
-    }
-  };
-  issue(d);
-  while (true) {
-    // my rows' extents
-    const int r0 = d.x, r1 = d.y, base = d.z;
-    int ra = 0, re = 0;
-    if (r0 + lane < r1) { ra = crp[r0 + lane]; re = crp[r0 + lane + 1]; }
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      d2 pr; pr.x = v[k].x * x[c[k].x]; pr.y = v[k].y * x[c[k].y];
-      *reinterpret_cast<d2 *>(&prod[(k * 64 + lane) * 2]) = pr;
-    }
-    if (RAW) asm volatile("" ::: "memory"); else __syncthreads();
-    const int next = chunk + waves_per_xcd;
-    int4 dn = d;
-    if (PIPE && next < c_end) { dn = desc[next]; issue(dn); }
-    for (int r = r0 + lane; r < r1; r += 64) {
-      if (r != r0 + lane) { ra = crp[r]; re = crp[r + 1]; }
-      double acc = 0.0;
-      const int a = ra - base, e = re - base;
-#pragma unroll 9
-      for (int p = a; p < e; ++p) acc = acc + prod[p];
-      y[r] = acc;
-    }
-    if (RAW) asm volatile("" ::: "memory"); else __syncthreads();
-    if (next >= c_end) break;
-    chunk = next;
-    if (!PIPE) { dn = desc[next]; issue(dn); }
-    d = dn;
-  }
-}
-
 // ---- ablation copy of the product kernel: XCD map on/off and pieces switched off (timing only) -------
 //   ABL bit0: reduce reads one product per row instead of walking the row   bit1: no y store
 //       bit4: nontemporal y store   bit5: y store into a 2 MiB window   bit6: (unused)
 //       bit2: no LDS write / barrier                                         bit3: no x gather
-template <int BLK, int NPT, bool XCD, int ABL>
+template <int BLK, int NPT, bool XCD, int ABL, int SL = 0>
 __global__ __launch_bounds__(BLK) void k_spmv_abl(
     const int *__restrict__ crp, const int *__restrict__ col, const double *__restrict__ val,
     const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ chunk_row,
@@ -211,7 +113,14 @@ __global__ __launch_bounds__(BLK) void k_spmv_abl(
 #pragma unroll 4
       for (int p = a; p < e; ++p) acc = acc + prod[p];
     }
-    if (ABL & 2) { if (acc == 123.456) y[r] = acc; }
+    if (ABL & 512) {            // staggered store: at most 256 B (4 write requests) leave the CU at a time
+      const int lane = tid & 63, wave = tid >> 6;
+      for (int w = 0; w < wave; ++w) { __builtin_amdgcn_s_sleep(SL); __builtin_amdgcn_s_sleep(SL); }
+      if (lane < 32) y[r] = acc;
+      __builtin_amdgcn_s_sleep(SL);
+      if (lane >= 32) y[r] = acc;
+    }
+    else if (ABL & 2) { if (acc == 123.456) y[r] = acc; }
     else if (ABL & 16) __builtin_nontemporal_store(acc, &y[r]);
     else if (ABL & 32) y[r & 0x3ffff] = acc;                       // 2 MiB region: stays in L2/MALL
     else if (ABL & 64) __hip_atomic_store(&y[r], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -343,118 +252,21 @@ int main(int argc, char **argv) {
                          (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
                          (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
   ADD_PAT(256, 8)
-  ADD_PAT(256, 6)
-  ADD_PAT(256, 10)
-  ADD_PAT(256, 12)
-  ADD_PAT(512, 8)
-#if 0
-  ADD_SPMV(256, 8, true)
-  ADD_SPMV(256, 8, false)
-  ADD_SPMV(256, 4, true)
-  ADD_SPMV(256, 16, true)
-  ADD_SPMV(512, 8, true)
-  ADD_SPMV(512, 4, true)
-  ADD_SPMV(256, 2, true)
-  ADD_SPMV(128, 4, true)
-  ADD_SPMV(128, 2, true)
-  ADD_SPMV(512, 2, true)
-  ADD_SPMV(256, 6, true)
-  ADD_SPMV(192, 4, true)
-#define ADD_PERS(BLK, NPT, NT, BPC)                                                                           \
-  { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch); const int cpx = (nch + 7) / 8; const int bpx = 32 * BPC; \
-    V.push_back({"persist<" #BLK "," #NPT "," #NT ">x" #BPC, [=]() {                                             \
-      hipLaunchKernelGGL((k_spmv_persistent<BLK, NPT, NT>), dim3(bpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
-                         d_y2, dc, nch, cpx, bpx); }, bytes_spmv, {}}); }
-  ADD_PERS(256, 8, true, 4)
-  ADD_PERS(512, 8, true, 4)
 
-#define ADD_WAVE(WCAP, NT, PIPE, WPC)                                                                          \
-  { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, WCAP, 64, cr, &nl);                  \
-    const int nch = (int)cr.size() - 1; std::vector<int4> dd(nch);                                               \
-    for (int i = 0; i < nch; ++i) dd[i] = make_int4(cr[i], cr[i + 1], rp[cr[i]] & ~1, rp[cr[i + 1]]);           \
-    int4 *ddev; CK(hipMalloc(&ddev, sizeof(int4) * nch)); CK(hipMemcpy(ddev, dd.data(), sizeof(int4) * nch, hipMemcpyHostToDevice)); \
-    const int cpx = (nch + 7) / 8; const int wpx = 32 * WPC;                                                     \
-    V.push_back({"wave<" #WCAP "," #NT "," #PIPE ">x" #WPC, [=]() {                                              \
-      hipLaunchKernelGGL((k_spmv_wave<WCAP, NT, PIPE>), dim3(wpx * 8), dim3(64), 0, 0, d_rp, d_col, d_val, d_x,   \
-                         d_y2, ddev, nch, cpx, wpx); }, bytes_spmv, {}}); }
-  ADD_WAVE(1792, true, false, 11)
-  ADD_WAVE(1792, true, true, 11)
-  ADD_WAVE(1792, true, true, 6)
-  ADD_WAVE(1024, true, false, 16)
-
-#define ADD_ABL(BLK, NPT, XCD, ABL)                                                                          \
+#define ADD_ABLS(BLK, NPT, ABL, SL)                                                                          \
   { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch); const int cpx = (nch + 7) / 8;                       \
-    V.push_back({"abl<" #BLK "," #NPT ",xcd=" #XCD ",abl=" #ABL ">", [=]() {                                  \
-      hipLaunchKernelGGL((k_spmv_abl<BLK, NPT, XCD, ABL>), dim3(XCD ? cpx * 8 : nch), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
+    V.push_back({"abl<" #BLK "," #NPT ",abl=" #ABL ",sleep=" #SL ">", [=]() {                                  \
+      hipLaunchKernelGGL((k_spmv_abl<BLK, NPT, true, ABL, SL>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
                          d_y2, dc, nch, cpx); }, bytes_spmv, {}}); }
-
-
-#define ADD_PERSR(BLK, NPT, BPC)                                                                              \
-  { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch); const int cpx = (nch + 7) / 8; const int bpx = 32 * BPC; \
-    V.push_back({"persist_raw<" #BLK "," #NPT ">x" #BPC, [=]() {                                                 \
-      hipLaunchKernelGGL((k_spmv_persistent<BLK, NPT, true, true>), dim3(bpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
-                         d_y2, dc, nch, cpx, bpx); }, bytes_spmv, {}}); }
-  ADD_PERSR(256, 8, 8)
-  ADD_PERSR(256, 8, 4)
-  ADD_PERSR(256, 4, 8)
-  ADD_PERSR(512, 8, 4)
-#define ADD_WAVER(WCAP, PIPE, WPC)                                                                              \
-  { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, WCAP, 64, cr, &nl);                  \
-    const int nch = (int)cr.size() - 1; std::vector<int4> dd(nch);                                               \
-    for (int i = 0; i < nch; ++i) dd[i] = make_int4(cr[i], cr[i + 1], rp[cr[i]] & ~1, rp[cr[i + 1]]);           \
-    int4 *ddev; CK(hipMalloc(&ddev, sizeof(int4) * nch)); CK(hipMemcpy(ddev, dd.data(), sizeof(int4) * nch, hipMemcpyHostToDevice)); \
-    const int cpx = (nch + 7) / 8; const int wpx = 32 * WPC;                                                     \
-    V.push_back({"wave_raw<" #WCAP "," #PIPE ">x" #WPC, [=]() {                                                  \
-      hipLaunchKernelGGL((k_spmv_wave<WCAP, true, PIPE, true>), dim3(wpx * 8), dim3(64), 0, 0, d_rp, d_col, d_val, d_x,   \
-                         d_y2, ddev, nch, cpx, wpx); }, bytes_spmv, {}}); }
-  ADD_WAVER(1792, true, 11)
-  ADD_WAVER(1792, true, 8)
-  ADD_WAVER(1792, false, 11)
-  ADD_WAVER(1024, true, 16)
-  ADD_WAVER(1024, false, 16)
-  ADD_WAVER(512, true, 24)
-  ADD_WAVER(512, false, 32)
-  ADD_SPMV(64, 8, true)
-  ADD_SPMV(64, 16, true)
-
-#define ADD_OFF(OFFB)                                                                                        \
-  { int *dc; int nch; chunks_for(2048, &dc, &nch); const int cpx = (nch + 7) / 8; double *yy = d_ybig + (OFFB) / 8; \
-    V.push_back({"spmv<256,8,nt> y+" #OFFB, [=]() {                                                            \
-      hipLaunchKernelGGL((k_spmv_rowsplit<256, 8, true>), dim3(cpx * 8), dim3(256), 0, 0, d_rp, d_col, d_val, d_x, \
-                         yy, dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
-  ADD_OFF(0)
-  ADD_ABL(256, 8, true, 0)
-  ADD_ABL(256, 8, true, 2)
-  ADD_ABL(256, 8, true, 32)
-  ADD_ABL(256, 8, true, 64)
-  ADD_ABL(256, 8, true, 128)
-  ADD_ABL(256, 4, true, 0)
-  ADD_ABL(256, 4, true, 2)
-  ADD_ABL(256, 4, true, 64)
-  ADD_ABL(256, 8, false, 32)
-  ADD_ABL(256, 8, false, 0)
-  ADD_ABL(256, 8, true, 16)
-  ADD_ABL(256, 8, false, 16)
-#define ADD_ABLR(BLK, NPT, XCD, ABL, MAXR)                                                                    \
-  { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch, MAXR); const int cpx = (nch + 7) / 8;                  \
-    V.push_back({"abl<" #BLK "," #NPT ",xcd=" #XCD ",abl=" #ABL ">rows" #MAXR, [=]() {                          \
-      hipLaunchKernelGGL((k_spmv_abl<BLK, NPT, XCD, ABL>), dim3(XCD ? cpx * 8 : nch), dim3(BLK), 0, 0, d_rp, d_col, d_val, d_x, \
-                         d_y2, dc, nch, cpx); }, bytes_spmv, {}}); }
-  ADD_ABLR(256, 8, true, 0, 64)
-  ADD_ABLR(256, 8, true, 256, 64)
-  ADD_ABLR(512, 8, true, 256, 128)
-  ADD_ABLR(512, 8, true, 0, 128)
-  ADD_ABLR(1024, 8, true, 256, 256)
-  ADD_ABLR(1024, 8, true, 0, 256)
-  ADD_ABLR(256, 8, true, 16, 64)
-  ADD_ABLR(256, 8, true, 2, 64)
-  ADD_ABLR(256, 4, true, 0, 32)
-  ADD_ABLR(256, 4, true, 2, 32)
-  ADD_ABLR(256, 4, true, 16, 32)
-  ADD_ABLR(512, 8, true, 0, 144)
-  ADD_ABLR(512, 8, true, 16, 144)
-  ADD_ABLR(256, 16, true, 0, 144)
-#endif
+  ADD_ABLS(256, 8, 0, 0)
+  ADD_ABLS(256, 8, 2, 0)
+  ADD_ABLS(256, 8, 512, 1)
+  ADD_ABLS(256, 8, 512, 2)
+  ADD_ABLS(256, 8, 512, 4)
+  ADD_ABLS(256, 8, 512, 8)
+  ADD_ABLS(256, 8, 512, 16)
+  ADD_ABLS(256, 4, 0, 0)
+  ADD_ABLS(256, 4, 512, 4)
   {
     const long nb = (nnz + 2047) / 2048;
     V.push_back({"stream_only<256,8,nt>", [=]() { hipLaunchKernelGGL((k_stream<256, 8, true, false>), dim3(nb), dim3(256), 0, 0, d_col, d_val, d_x, d_y2, nnz); }, (double)nnz * 12, {}});

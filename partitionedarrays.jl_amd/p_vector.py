@@ -430,7 +430,19 @@ def _part_sum(parts_values, scalar_on_device=False):
 
 
 def dot(a: PVector, b: PVector) -> float:
-    """dot(a,b) (src/p_vector.jl:1189-1192): per-part own-value dot on the device, then sum over parts."""
+    """dot(a,b) (src/p_vector.jl:1189-1192): per-part own-value dot on the device, then sum over parts
+    (reduction(+,...;destination=:all), src/mpi_array.jl:494): one process per part with an RCCL communicator ->
+    ncclAllReduce of the device scalar on the compute stream; otherwise a host sum in part order."""
+    vp = a.vector_partition
+    if isinstance(vp, TorchDistArray) and TRANSPORT == "rccl" and context().comm is not None:
+        ctx = context()
+        L.call("pa_vec_dot", vp.item.h, b.vector_partition.item.h, None)
+        ptr = C.c_void_p()
+        L.call("pa_vec_dot_result", ctx.h, C.byref(ptr))
+        ctx.comm.allreduce_sum(ptr, 1, L.STREAM_COMPUTE)
+        out = C.c_double()
+        L.call("pa_ctx_read_scalar", ctx.h, C.byref(out))
+        return out.value
 
     def local(x, y):
         out = C.c_double()

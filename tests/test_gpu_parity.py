@@ -282,6 +282,15 @@ def test_rccl_single_rank_loopback():
     d = pa.DeviceVector(4, 0).upload(np.array([1.5, 2.0, 0.0, -1.0]))
     L.call("pa_comm_allreduce_sum", comm, C.c_void_p(d.data_ptr()), 4, L.STREAM_COMPUTE)
     assert d.download().tolist() == [1.5, 2.0, 0.0, -1.0]
+    # dot -> device scalar -> all-reduce -> read back (the N>1 route of dot())
+    a = pa.DeviceVector(4, 0).upload(np.array([1.0, 2.0, 3.0, 4.0]))
+    L.call("pa_vec_dot", a.h, a.h, None)
+    sp = C.c_void_p()
+    L.call("pa_vec_dot_result", ctx.h, C.byref(sp))
+    L.call("pa_comm_allreduce_sum", comm, sp, 1, L.STREAM_COMPUTE)
+    out = C.c_double()
+    L.call("pa_ctx_read_scalar", ctx.h, C.byref(out))
+    assert out.value == 30.0
     L.call("pa_comm_barrier", comm)
     L.call("pa_plan_destroy", plan)
     L.call("pa_comm_destroy", comm)
@@ -406,3 +415,27 @@ def test_column_encodings_agree_bit_for_bit(orc, monkeypatch):
     A16, _ = pa.build_p_matrix(ranks(1), 16, 16, 16, 16, 16, 16, 1, 1, 1)
     e = A16.matrix_partition.items[0].own_own.encoding()
     assert e["pattern"] == 0 and e["c16"] > 0 and e["c32"] == 0
+
+
+def test_config2_laplacian_256_cubed_single_part(orc):
+    """BASELINE config 2: 7-point Laplacian 256^3, one part, fp64 CSR SpMV only (no exchange), through the
+    step-by-step set-up chain.  Size-independent properties: A*1 == alpha*(2D - #neighbours) bit-exactly
+    (src/gallery.jl:36,65,75), and exact scaling by powers of two."""
+    n = (256, 256, 256)
+    I, J, V, rows, _ = pa.laplacian_fdm(n, (1, 1, 1), ranks(1))
+    A = pa.psparse_from_coo(I, J, V, rows)
+    blk = A.matrix_partition.items[0]
+    assert (blk.own_own.nnz, blk.own_ghost.nnz) == (117047296, 0)
+    del I, J, V
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, pa.pones(A.col_partition))
+    alpha = float(257 ** 3)
+    ax = np.arange(256)
+    nb = sum(np.meshgrid(*[2 - (ax == 0) - (ax == 255)] * 3, indexing="ij")).transpose(2, 1, 0).ravel()
+    assert np.array_equal(y.own_values().items[0], alpha * (6 - nb))
+    x = pa.pvector_from_function(lambda i: (i.get_local_to_global() % 5) - 2.0, A.col_partition)
+    x8 = pa.pvector_from_function(lambda i: 8.0 * ((i.get_local_to_global() % 5) - 2.0), A.col_partition)
+    y8 = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x)
+    pa.mul_(y8, A, x8)
+    assert np.array_equal(8.0 * y.own_values().items[0], y8.own_values().items[0])
