@@ -200,6 +200,13 @@ int pa_host_split_csr(int64_t n_own_rows, int64_t n_own_cols, int64_t n_ghost_co
                       double *oo_nzval, int32_t *oh_rowptr, int32_t *oh_colval, double *oh_nzval,
                       int64_t *nnz_oo, int64_t *nnz_oh);
 
+/* Host-only self-check of the SpMV row split and of the library-internal column encodings (row patterns, 16-bit
+ * windows): encodes the given CSR pattern as pa_csr_create would and decodes every entry with the kernel's arithmetic.
+ * Returns PA_ERR_ARG on any mismatch; the counters report how many chunks each encoding covers. */
+int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr,
+                                 const int32_t *colval, int index_base, int64_t *n_chunks, int64_t *n_pattern_chunks,
+                                 int64_t *n_c16_chunks, int64_t *n_patterns);
+
 /* Fused HPCG set-up for large parts: the same arrays as the chain above (build_matrix -> find_owner ->
  * union_ghost -> map_global_to_local! -> compresscoo -> split_format_locally, HPCG/src/sparse_matrix.jl:105-122)
  * without materialising the Int64 COO triplets.  Pass 1 returns the ghost gids in first-seen order

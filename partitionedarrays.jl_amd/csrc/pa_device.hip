@@ -583,6 +583,51 @@ extern "C" int pa_csr_info(const pa_csr *A, int64_t *n_rows, int64_t *n_cols, in
   return PA_OK;
 }
 
+// Host-only self-check of the row split and of the two column encoders: build them exactly as csr_build does and
+// decode every entry on the host with the kernel's arithmetic; any mismatch with colval is an error.
+extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr,
+                                            const int32_t *colval, int index_base, int64_t *n_chunks, int64_t *n_pattern,
+                                            int64_t *n_c16, int64_t *n_patterns) {
+  PA_REQUIRE(rowptr && (nnz == 0 || colval) && (index_base == 0 || index_base == 1), "bad arguments");
+  std::vector<int32_t> crp(n_rows + 1), col(nnz);
+  for (int64_t r = 0; r <= n_rows; ++r) crp[r] = rowptr[r] - index_base;
+  for (int64_t p = 0; p < nnz; ++p) col[p] = colval[p] - index_base;
+  std::vector<int32_t> chunk_row;
+  int64_t n_long = 0;
+  pa_build_chunks(crp.data(), n_rows, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
+  const int64_t nch = (int64_t)chunk_row.size() - 1;
+  std::vector<uint16_t> c16(nnz + 8, 0);
+  std::vector<int32_t> win((size_t)nch * PA_C16_WINDOWS, 0), pdesc, pdelta;
+  const int64_t nfall = pa_encode_col16(crp.data(), col.data(), chunk_row, PA_SPMV_CHUNK_NNZ, c16.data(), win.data(), 1);
+  const int64_t npat = pa_encode_patterns(crp.data(), col.data(), n_rows, chunk_row, PA_SPMV_CHUNK_NNZ, pdesc, pdelta, 1);
+  for (int64_t c = 0; c < nch; ++c) {
+    const int64_t r0 = chunk_row[c], r1 = chunk_row[c + 1], p0 = crp[r0], p1 = crp[r1];
+    PA_REQUIRE(r1 > r0, "empty chunk %lld", (long long)c);
+    PA_REQUIRE((p1 - (p0 & ~1)) <= PA_SPMV_CHUNK_NNZ || r1 - r0 == 1, "chunk %lld overflows the LDS stage", (long long)c);
+    if (win[c * PA_C16_WINDOWS] >= 0 && (p1 - (p0 & ~1)) <= PA_SPMV_CHUNK_NNZ)
+      for (int64_t p = p0; p < p1; ++p) {
+        const int32_t dec = win[c * PA_C16_WINDOWS + (c16[p] >> 12)] + (c16[p] & 4095);
+        PA_REQUIRE(dec == col[p], "c16 decode mismatch at entry %lld", (long long)p);
+      }
+    const int32_t *d = &pdesc[(size_t)c * 16];
+    if (npat > 0 && d[0] > 0)
+      for (int64_t p = p0; p < p1; ++p) {
+        const int q = (int)(p - p0);
+        const int s = (q >= d[1]) + (q >= d[2]) + (q >= d[3]);
+        const int t = q - (s ? d[s] : 0), L = d[8 + s];
+        const int rr = L == 1 ? t : (int)(((uint64_t)(uint32_t)t * (uint64_t)(0xFFFFFFFFu / (uint32_t)L + 1u)) >> 32);
+        const int32_t dec = d[4 + s] + rr + pdelta[(size_t)d[12 + s] * PA_PAT_MAXLEN + (t - rr * L)];
+        PA_REQUIRE(dec == col[p], "pattern decode mismatch at entry %lld (chunk %lld)", (long long)p, (long long)c);
+      }
+  }
+  if (n_chunks) *n_chunks = nch;
+  if (n_pattern) *n_pattern = npat;
+  if (n_c16) *n_c16 = nch - nfall;
+  if (n_patterns) *n_patterns = (int64_t)pdelta.size() / PA_PAT_MAXLEN;
+  (void)n_cols;
+  return PA_OK;
+}
+
 extern "C" int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern, int64_t *n_c16, int64_t *n_c32) {
   PA_REQUIRE(A != nullptr, "csr is NULL");
   const int64_t pat = A->use_pattern ? A->n_pattern_chunks : 0;
@@ -735,6 +780,11 @@ extern "C" int pa_exchange_pack(pa_plan *p, const pa_vec *v, int mode) {
              (long long)(v->n_own + v->n_ghost), (long long)p->n_local);
   PA_REQUIRE(p->phase == 0, "exchange already in flight on this plan (missing pa_exchange_finish)");
   pa_ctx *c = p->ctx;
+  if (p->snd.n == 0 && p->rcv.n == 0) {  // a part without neighbours (e.g. the only part): nothing to move, no stream traffic
+    p->phase = 1;
+    p->mode = mode;
+    return PA_OK;
+  }
   PA_HIP(hipSetDevice(c->device));
   // the comm stream must see everything the compute stream wrote into v so far
   PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
@@ -774,7 +824,7 @@ extern "C" int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mod
         PA_HIP(hipMemcpyAsync(in.d_buf + in.ptrs[i], o.d_buf + o.ptrs[j], sizeof(double) * len, hipMemcpyDeviceToDevice,
                               pr->ctx->s[1]));
     }
-    PA_HIP(hipEventRecord(pr->ev_arrived, pr->ctx->s[1]));
+    if (in.n || out_side(pr, mode).n) PA_HIP(hipEventRecord(pr->ev_arrived, pr->ctx->s[1]));
     pr->phase = 2;
   }
   return PA_OK;
@@ -791,6 +841,10 @@ extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
   PA_REQUIRE(p->phase >= 1 && p->mode == mode, "pa_exchange_finish without a matching pa_exchange_pack");
   PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector/plan size mismatch");
   pa_ctx *c = p->ctx;
+  if (p->snd.n == 0 && p->rcv.n == 0) {
+    p->phase = 0;
+    return PA_OK;
+  }
   PA_HIP(hipSetDevice(c->device));
   if (p->phase == 1) {  // caller-driven transport on the comm stream: everything queued there so far counts
     PA_HIP(hipEventRecord(p->ev_arrived, c->s[1]));

@@ -137,6 +137,7 @@ extern "C" int pa_exchange_rccl(pa_plan *p, pa_comm *m, int mode) {
   PA_REQUIRE(p->phase == 1 && p->mode == mode, "pa_exchange_pack(mode) must come first");
   PA_REQUIRE(p->ctx == m->ctx, "plan and communicator live on different contexts");
   PA_REQUIRE(p->part == m->rank, "plan of part %d driven by rank %d", p->part, m->rank);
+  if (p->snd.n == 0 && p->rcv.n == 0) { p->phase = 2; return PA_OK; }
   PA_TRY(need_api());
   pa_plan::side &o = (mode == PA_ASSEMBLE) ? p->snd : p->rcv;
   pa_plan::side &in = (mode == PA_ASSEMBLE) ? p->rcv : p->snd;

@@ -205,3 +205,38 @@ def test_fem_disassembled_to_assembled_matches_oracle(orc, nodes, parts):
             assert (mine.m, mine.n) == (ref.m, ref.n)
             assert np.array_equal(mine.rowptr, ref.rowptr) and np.array_equal(mine.colval, ref.colval)
             assert np.array_equal(mine.nzval, ref.nzval)
+
+
+def _check_enc(A):
+    import ctypes as C
+    import pa_amd._lib as L
+    v = [C.c_int64() for _ in range(4)]
+    L.call("pa_host_check_spmv_encodings", A.m, A.n, A.nnz, L.ptr(A.rowptr), L.ptr(A.colval), 1, *[C.byref(x) for x in v])
+    return dict(zip(["chunks", "pattern", "c16", "patterns"], [x.value for x in v]))
+
+
+def test_spmv_row_split_and_column_encodings_decode_exactly(orc):
+    """Host logic of the device SpMV: the row split covers every row once, and both column encodings (row patterns,
+    16-bit windows) decode to the original columns, on stencil, FEM, ragged and scattered matrices."""
+    rows = pa.uniform_partition(ranks(1), (1, 1, 1), (130, 9, 7)).items[0]
+    _, oo, _, _ = pa.build_split_blocks_fused(rows, 130, 9, 7, 130, 9, 7)
+    e = _check_enc(oo)
+    assert e["pattern"] >= 0.9 * e["chunks"] and e["c16"] == e["chunks"] and e["patterns"] == 27   # 27-pt: 27 row patterns
+    rows = pa.uniform_partition(ranks(1), (1, 1, 1), (12, 12, 12)).items[0]
+    _, oo, _, _ = pa.build_split_blocks_fused(rows, 12, 12, 12, 12, 12, 12)
+    e = _check_enc(oo)
+    assert e["pattern"] < e["chunks"] and e["c16"] == e["chunks"]       # short grid lines: too many pattern runs per chunk
+    I, J, V, r, c = orc.laplacian_fem((150, 40), (1, 1))
+    Af, _ = orc.psparse_disassembled(I, J, V, r, c)
+    fem = Af.blocks[0].own_own
+    e = _check_enc(pa.HostCSR(fem.m, fem.n, fem.rowptr, fem.colval, fem.nzval))
+    assert e["pattern"] > 0 and e["patterns"] == 9
+    rng = np.random.default_rng(3)
+    m, n = 2500, 300000
+    lens = rng.integers(0, 70, m)
+    lens[[5, 77]] = [2100, 4500]                                                               # rows longer than a chunk
+    Irow = np.repeat(np.arange(1, m + 1), lens)
+    Jcol = np.concatenate([np.sort(rng.choice(n, size=k, replace=False)) + 1 for k in lens])
+    A = pa.compresscoo(Irow, Jcol, np.ones(len(Irow)), m, n)
+    e = _check_enc(A)
+    assert e["pattern"] == 0 and e["c16"] < e["chunks"]
