@@ -110,6 +110,9 @@ int pa_csr_create_from_csc(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t 
                            const void *rowval, int index_bytes, int index_base, const double *nzval,
                            pa_csr **A);
 int pa_csr_update_values(pa_csr *A, const double *nzval);   /* same pattern, new nonzeros(A) */
+/* nonzeros(A) .= src_local[offset : offset+nnz) -- device to device, on the compute stream (K7: the re-assembled
+ * values of psparse!/assemble!(B,A,cache), src/p_sparse_matrix.jl:1291-1305,1762-1816, never leave HBM). */
+int pa_csr_update_values_from(pa_csr *A, const pa_vec *src, int64_t offset);
 int pa_csr_destroy(pa_csr *A);
 int pa_csr_info(const pa_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int64_t *n_chunks,
                 int64_t *n_nonempty_rows, int64_t *n_long_rows);
@@ -156,6 +159,15 @@ int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mode);
 /* Transport B: one process per part over RCCL (MPIArray analogue, src/mpi_array.jl:575-614):
  * one ncclGroup of ncclSend/ncclRecv per neighbour on the comm stream; rank = part - index_base. */
 int pa_exchange_rccl(pa_plan *plan, pa_comm *comm, int mode);
+
+/* ---- deterministic scatter-add maps: sparse_matrix!(A,V,K) (src/sparse_utils.jl:454-466) -------------------- */
+/* dst[dest[p]] += src[p] for p ascending (entries with dest[p] < index_base are skipped, as `k < 1` is there);
+ * one lane per distinct destination adds its sources in ascending p: the reference's order, no atomics.
+ * zero_first != 0 does fillstored!(dst,0) first.  dst/src are whole local vectors. */
+typedef struct pa_scatter pa_scatter;
+int pa_scatter_create(pa_ctx *ctx, int64_t n_dst, int64_t n_src, const int32_t *dest, int index_base, pa_scatter **s);
+int pa_scatter_destroy(pa_scatter *s);
+int pa_scatter_add(pa_scatter *s, pa_vec *dst, const pa_vec *src, int zero_first);
 
 /* ---- RCCL communicator (MPI.Init / Comm_dup analogue, src/mpi_array.jl:42-53) ---------------- */
 #define PA_UNIQUE_ID_BYTES 128

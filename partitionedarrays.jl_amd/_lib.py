@@ -66,7 +66,11 @@ _SIGS = {
     "pa_csr_create": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_create_from_csc": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_update_values": [P, P],
+    "pa_csr_update_values_from": [P, P, i64],
     "pa_csr_destroy": [P],
+    "pa_scatter_create": [P, i64, i64, P, cint, PP],
+    "pa_scatter_destroy": [P],
+    "pa_scatter_add": [P, P, P, cint],
     "pa_csr_info": [P] + [C.POINTER(i64)] * 6,
     "pa_csr_encoding": [P] + [C.POINTER(i64)] * 3,
     "pa_spmv": [P, P, cint, P, cint, f64, f64],

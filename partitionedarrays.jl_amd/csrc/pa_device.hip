@@ -554,6 +554,16 @@ extern "C" int pa_csr_update_values(pa_csr *A, const double *nzval) {
   return PA_OK;
 }
 
+extern "C" int pa_csr_update_values_from(pa_csr *A, const pa_vec *src, int64_t offset) {
+  PA_REQUIRE(A && src && offset >= 0, "bad arguments");
+  PA_REQUIRE(offset + A->nnz <= src->n_own + src->n_ghost, "source vector too short for nnz=%lld at offset %lld",
+             (long long)A->nnz, (long long)offset);
+  if (A->nnz == 0) return PA_OK;
+  PA_HIP(hipSetDevice(A->ctx->device));
+  PA_HIP(hipMemcpyAsync(A->d_val, src->d + offset, sizeof(double) * A->nnz, hipMemcpyDeviceToDevice, A->ctx->s[0]));
+  return PA_OK;
+}
+
 extern "C" int pa_csr_destroy(pa_csr *A) {
   if (!A) return PA_OK;
   (void)hipSetDevice(A->ctx->device);
@@ -670,6 +680,65 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
     else PA_LAUNCH_SPMV(false, false);
 #undef PA_LAUNCH_SPMV
   }
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic scatter-add maps (sparse_matrix!(A,V,K), src/sparse_utils.jl:454-466)
+// ------------------------------------------------------------------------------------------------
+static int upload_i32(const std::vector<int32_t> &h, int32_t **d);
+
+extern "C" int pa_scatter_create(pa_ctx *c, int64_t n_dst, int64_t n_src, const int32_t *dest, int index_base, pa_scatter **out) {
+  PA_REQUIRE(c && out && n_dst >= 0 && n_src >= 0 && (n_src == 0 || dest), "bad arguments");
+  PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  std::vector<int32_t> order;
+  order.reserve(n_src);
+  for (int64_t p = 0; p < n_src; ++p) {
+    const int64_t k = (int64_t)dest[p] - index_base;
+    if (k < 0) continue;  // `if k < 1 continue` (src/sparse_utils.jl:461)
+    PA_REQUIRE(k < n_dst, "destination %lld out of range at source %lld", (long long)k, (long long)p);
+    order.push_back((int32_t)p);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return dest[a] < dest[b]; });
+  std::vector<int32_t> tgt, tptr;
+  tptr.push_back(0);
+  for (size_t k = 0; k < order.size(); ++k)
+    if (k == 0 || dest[order[k]] != dest[order[k - 1]]) {
+      if (k) tptr.push_back((int32_t)k);
+      tgt.push_back(dest[order[k]] - index_base);
+    }
+  if (!order.empty()) tptr.push_back((int32_t)order.size());
+  pa_scatter *s = new pa_scatter();
+  s->ctx = c; s->n_dst = n_dst; s->n_src = n_src; s->n_tgt = (int64_t)tgt.size();
+  PA_HIP(hipSetDevice(c->device));
+  PA_TRY(upload_i32(tgt, &s->d_tgt));
+  PA_TRY(upload_i32(tptr, &s->d_tptr));
+  PA_TRY(upload_i32(order, &s->d_tp));
+  *out = s;
+  return PA_OK;
+}
+
+extern "C" int pa_scatter_destroy(pa_scatter *s) {
+  if (!s) return PA_OK;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->s[0]);
+  (void)hipFree(s->d_tgt);
+  (void)hipFree(s->d_tptr);
+  (void)hipFree(s->d_tp);
+  delete s;
+  return PA_OK;
+}
+
+extern "C" int pa_scatter_add(pa_scatter *s, pa_vec *dst, const pa_vec *src, int zero_first) {
+  PA_REQUIRE(s && dst && src, "bad arguments");
+  PA_REQUIRE(dst->n_own + dst->n_ghost == s->n_dst && src->n_own + src->n_ghost == s->n_src, "vector sizes do not match the map");
+  pa_ctx *c = s->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  if (zero_first && s->n_dst) PA_HIP(hipMemsetAsync(dst->d, 0, sizeof(double) * s->n_dst, c->s[0]));
+  if (s->n_tgt)
+    hipLaunchKernelGGL(k_unpack_add, dim3((s->n_tgt + 255) / 256), dim3(256), 0, c->s[0], dst->d, src->d, s->d_tgt, s->d_tptr,
+                       s->d_tp, (int)s->n_tgt);
   PA_HIP(hipGetLastError());
   return PA_OK;
 }

@@ -99,6 +99,12 @@ struct pa_plan {
   int mode = 0;
 };
 
+struct pa_scatter {
+  pa_ctx *ctx = nullptr;
+  int64_t n_dst = 0, n_src = 0, n_tgt = 0;
+  int32_t *d_tgt = nullptr, *d_tptr = nullptr, *d_tp = nullptr;
+};
+
 int pa_plan_mark_arrived(pa_plan *p);
 
 #endif

@@ -255,14 +255,26 @@ def _split4(A: HostCSR, rows, cols):
     return oo, oh, ho, hh
 
 
-def _group_by_owner(owner, parts_snd, arrays):
+def _group_by_owner(owner, parts_snd, arrays, with_order=False):
     slot = np.searchsorted(parts_snd, owner)
     order = np.argsort(slot, kind="stable")
     cuts = np.searchsorted(slot[order], np.arange(len(parts_snd) + 1))
-    return [[a[order][cuts[k]:cuts[k + 1]] for k in range(len(parts_snd))] for a in arrays]
+    out = [[a[order][cuts[k]:cuts[k + 1]] for k in range(len(parts_snd))] for a in arrays]
+    return (out, order, cuts) if with_order else out
 
 
-def psparse_assemble_host(blocks4, rows_sa, cols_sa, rows):
+def _nzindex(A: HostCSR, i, j):
+    """nzindex(A,i,j) (src/sparse_utils.jl:256-278), vectorised: 1-based position of (i,j) in nonzeros(A), 0 if absent."""
+    ri, cj, _ = _coo(A)
+    keys = (ri - 1) * max(A.n, 1) + (cj - 1)                       # ascending: rows ascending, columns sorted inside a row
+    q = (np.asarray(i, I64) - 1) * max(A.n, 1) + (np.asarray(j, I64) - 1)
+    if len(keys) == 0:
+        return np.zeros(len(q), I64)
+    pos = np.clip(np.searchsorted(keys, q), 0, len(keys) - 1)
+    return np.where(keys[pos] == q, pos + 1, 0)
+
+
+def psparse_assemble_host(blocks4, rows_sa, cols_sa, rows, reuse=False):
     """assemble(B,rows) for a split-format sub-assembled matrix, first time (psparse_assemble_impl,
     src/p_sparse_matrix.jl:1590-1756): ghost-row triplets travel to the owners of their rows, are appended to the
     owners' COO lists, the ghost columns are renumbered (union_ghost) and everything is compressed with +.
@@ -278,15 +290,17 @@ def psparse_assemble_host(blocks4, rows_sa, cols_sa, rows):
         gI = r.ghost_to_global[ii - 1]
         gJ = np.concatenate([c.own_to_global[gj - 1], c.ghost_to_global[hj - 1]])
         gV = np.concatenate([gv, hv])
-        return tuple(_group_by_owner(r.ghost_to_owner[ii - 1], np.asarray(ps), [gI, gJ, gV]))
+        (a, b, v), order, cuts = _group_by_owner(r.ghost_to_owner[ii - 1], np.asarray(ps), [gI, gJ, gV], with_order=True)
+        return a, b, v, (order + 1, cuts + 1)            # k_snd (1-based position in [ghost_own|ghost_ghost] nz), ptrs
 
     from .primitives import tuple_of_arrays
-    I_snd, J_snd, V_snd = tuple_of_arrays(pmap(setup_snd, blocks4, parts_snd, rows_sa, cols_sa))
+    I_snd, J_snd, V_snd, ksnd = tuple_of_arrays(pmap(setup_snd, blocks4, parts_snd, rows_sa, cols_sa))
     graph = ExchangeGraph(parts_snd, parts_rcv)
     I_rcv, J_rcv, V_rcv = exchange(I_snd, graph), exchange(J_snd, graph), exchange(V_snd, graph)   # :1734-1736
 
     def own_triplets(blk, Ir, Jr, Vr, r, c):                        # setup_own_triplets :1656-1689
         cat = lambda xs, dt: np.concatenate([np.asarray(x, dt) for x in xs]) if len(xs) else np.zeros(0, dt)  # noqa: E731
+        Ir_lists = list(Ir)
         Ir, Jr, Vr = cat(Ir, I64), cat(Jr, I64), cat(Vr, F64)
         ooI, ooJ, ooV = _coo(blk[0])
         ohI, ohJ, ohV = _coo(blk[1])
@@ -296,9 +310,10 @@ def psparse_assemble_host(blocks4, rows_sa, cols_sa, rows):
         oo = (np.concatenate([ooI, li[is_own]]), np.concatenate([ooJ, lj[is_own]]), np.concatenate([ooV, Vr[is_own]]))
         og = (np.concatenate([ohI, li[~is_own]]), np.concatenate([c.ghost_to_global[ohJ - 1], Jr[~is_own]]),
               np.concatenate([ohV, Vr[~is_own]]))
-        return oo, og, og[1]
+        rcv_ptrs = np.concatenate([[1], 1 + np.cumsum([len(np.atleast_1d(x)) for x in Ir_lists])]).astype(I32)
+        return oo, og, og[1], (li, Jr, rcv_ptrs)
 
-    oo, og, Jg = tuple_of_arrays(pmap(own_triplets, blocks4, I_rcv, J_rcv, V_rcv, rows_sa, cols_sa))
+    oo, og, Jg, rcvinfo = tuple_of_arrays(pmap(own_triplets, blocks4, I_rcv, J_rcv, V_rcv, rows_sa, cols_sa))
     J_owner = find_owner(cols_sa, Jg)
     cols0 = pmap(lambda c: LocalIndices(c.n_global, c.part, np_=c.np_, n=c.n, ranges=c.ranges, starts=c.starts), cols_sa)  # remove_ghost
     cols_fa = pmap(union_ghost, cols0, Jg, J_owner)
@@ -307,10 +322,29 @@ def psparse_assemble_host(blocks4, rows_sa, cols_sa, rows):
         gj = c.global_to_local(og_[1]).astype(I64) - c.n_own        # map_global_to_ghost!
         return (compresscoo(oo_[0], oo_[1], oo_[2], r.n_own, c.n_own), compresscoo(og_[0], gj, og_[2], r.n_own, c.n_ghost))
 
-    return pmap(finalize, oo, og, rows, cols_fa), cols_fa
+    host = pmap(finalize, oo, og, rows, cols_fa)
+    if not reuse:
+        return host, cols_fa
+    info = dict(parts_snd=parts_snd, parts_rcv=parts_rcv, ksnd=ksnd, rcvinfo=rcvinfo)
+    return host, cols_fa, info
 
 
-def psparse_disassembled(I, J, V, rows, cols, keep_host=False) -> PSparseMatrix:
+class MatrixReassemblyCache:
+    """cache of psparse(...;reuse=true) for the device path: what psparse!(C,V,cache) needs to turn new COO values
+    into the values of the assembled blocks WITHOUT leaving HBM (K7).  The stored values of one part are treated as a
+    vector  W = [ nonzeros(C.own_own) | nonzeros(C.own_ghost) || nonzeros(B.ghost_own) | nonzeros(B.ghost_ghost) ]
+    so that the reference's three steps are existing device primitives:
+      sparse_matrix!(A,V,K) + split_format! + setup_sa  -> one deterministic scatter-add  W[dest[p]] += V[p]   (pa_scatter)
+      psparse_assemble_impl! (:1762-1816)               -> assemble! of W over a pa_plan with idx_snd = ghost-row slots
+                                                           (k_snd) and idx_rcv = own slots (k_rcv): pack, exchange, += in
+                                                           ascending p
+      nonzeros(C.blocks) .= W[own part]                 -> pa_csr_update_values_from."""
+
+    def __init__(self, plans, scatters, W, Vdev, nnz_oo):
+        self.plans, self.scatters, self.W, self.Vdev, self.nnz_oo = plans, scatters, W, Vdev, nnz_oo
+
+
+def psparse_disassembled(I, J, V, rows, cols, keep_host=False, reuse=False):
     """psparse(SparseMatrixCSR{1,Float64,Int32},I,J,V,rows,cols)|>fetch with the DEFAULT flags
     (src/p_sparse_matrix.jl:1150-1219): every part may hold entries of rows it does not own (FEM assembly loops);
     find_owner/union_ghost for rows and columns, local compress + split, then assemble onto `rows`."""
@@ -324,6 +358,85 @@ def psparse_disassembled(I, J, V, rows, cols, keep_host=False) -> PSparseMatrix:
         return _split4(A, r, c)
 
     blocks4 = pmap(local, I, J, V, rows_sa, cols_sa)
-    host, cols_fa = psparse_assemble_host(blocks4, rows_sa, cols_sa, rows)
+    if not reuse:
+        host, cols_fa = psparse_assemble_host(blocks4, rows_sa, cols_sa, rows)
+        dev = pmap(lambda h: SplitMatrixBlocks(DeviceCSR(h[0]), DeviceCSR(h[1])), host)
+        return PSparseMatrix(dev, rows, cols_fa, True, host if keep_host else None)
+    host, cols_fa, info = psparse_assemble_host(blocks4, rows_sa, cols_sa, rows, reuse=True)
     dev = pmap(lambda h: SplitMatrixBlocks(DeviceCSR(h[0]), DeviceCSR(h[1])), host)
-    return PSparseMatrix(dev, rows, cols_fa, True, host if keep_host else None)
+    C_ = PSparseMatrix(dev, rows, cols_fa, True, host if keep_host else None)
+    from .p_vector import DeviceVector, plan_info
+
+    def slot_in_C(h, c_fa, li, gj):
+        """1-based position of entry (own row li, global column gj) in [nonzeros(own_own) | nonzeros(own_ghost)]."""
+        lc = c_fa.global_to_local(gj).astype(I64)
+        own = lc <= c_fa.n_own
+        out = np.zeros(len(li), I64)
+        out[own] = _nzindex(h[0], li[own], lc[own])
+        out[~own] = h[0].nnz + _nzindex(h[1], li[~own], lc[~own] - c_fa.n_own)
+        return out
+
+    def build(Ii, Ji, b4, h, r_sa, c_sa, c_fa, ps, pr, ks, rcv):
+        n_own_vals = h[0].nnz + h[1].nnz
+        n_ghost_vals = b4[2].nnz + b4[3].nnz
+        li = r_sa.global_to_local(Ii).astype(I64)
+        lj = c_sa.global_to_local(Ji).astype(I64)
+        dest = np.zeros(len(li), I64)
+        ok = (li >= 1) & (lj >= 1)
+        ownrow = ok & (li <= r_sa.n_own)
+        dest[ownrow] = slot_in_C(h, c_fa, li[ownrow], np.asarray(Ji, I64)[ownrow])
+        gr = ok & ~ownrow
+        gi = li[gr] - r_sa.n_own
+        gl = lj[gr]
+        d = np.zeros(len(gi), I64)
+        oc = gl <= c_sa.n_own
+        d[oc] = n_own_vals + _nzindex(b4[2], gi[oc], gl[oc])
+        d[~oc] = n_own_vals + b4[2].nnz + _nzindex(b4[3], gi[~oc], gl[~oc] - c_sa.n_own)
+        dest[gr] = d
+        assert np.all(dest[ok] > 0)
+        sc = C.c_void_p()
+        d32 = np.ascontiguousarray(dest, I32)
+        L.call("pa_scatter_create", context().h, n_own_vals + n_ghost_vals, len(d32), L.ptr(d32), 1, C.byref(sc))
+        k_snd, ptrs_snd = ks
+        rli, rJ, ptrs_rcv = rcv
+        k_rcv = slot_in_C(h, c_fa, rli, rJ)
+        assert np.all(k_rcv > 0)
+        ns32, nr32 = np.ascontiguousarray(ps, I32), np.ascontiguousarray(pr, I32)
+        idx_snd = np.ascontiguousarray(n_own_vals + k_snd, I32)
+        idx_rcv = np.ascontiguousarray(k_rcv, I32)
+        p_snd, p_rcv = np.ascontiguousarray(ptrs_snd, I32), np.ascontiguousarray(ptrs_rcv, I32)
+        plan = C.c_void_p()
+        L.call("pa_plan_create", context().h, r_sa.part, n_own_vals + n_ghost_vals, len(ns32), L.ptr(ns32), L.ptr(p_snd),
+               L.ptr(idx_snd), len(nr32), L.ptr(nr32), L.ptr(p_rcv), L.ptr(idx_rcv), 1, C.byref(plan))
+        plan_info[plan.value] = dict(
+            snd=[(int(q), int(p_snd[k]) - 1, int(p_snd[k + 1]) - 1) for k, q in enumerate(ns32)],
+            rcv=[(int(q), int(p_rcv[k]) - 1, int(p_rcv[k + 1]) - 1) for k, q in enumerate(nr32)])
+        return plan, sc, DeviceVector(n_own_vals, n_ghost_vals), DeviceVector(len(d32), 0), h[0].nnz
+
+    from .primitives import tuple_of_arrays
+    plans, scs, W, Vd, nnz_oo = tuple_of_arrays(pmap(build, I, J, blocks4, host, rows_sa, cols_sa, cols_fa,
+                                                     info["parts_snd"], info["parts_rcv"], info["ksnd"], info["rcvinfo"]))
+    return C_, MatrixReassemblyCache(plans, scs, W, Vd, nnz_oo)
+
+
+def psparse_(C_: PSparseMatrix, V, cache: MatrixReassemblyCache) -> Task:
+    """psparse!(C,V,cache) (src/p_sparse_matrix.jl:1291-1305): same pattern, new COO values; everything after the
+    upload of V runs on the device (see MatrixReassemblyCache).  Returns a task; wait() it before using C."""
+    from .p_vector import assemble_impl
+
+    class _P:                      # what assemble_impl needs from a cache
+        pass
+
+    pc = _P()
+    pc.plans = cache.plans
+    pmap(lambda vd, v: vd.upload(np.ascontiguousarray(v, F64)), cache.Vdev, V)
+    pmap(lambda sc, w, vd: L.call("pa_scatter_add", sc, w.h, vd.h, 1), cache.scatters, cache.W, cache.Vdev)
+    t = assemble_impl(L.ASSEMBLE, cache.W, pc)
+
+    def finish():
+        t.wait()
+        pmap(lambda blk, w, k: (L.call("pa_csr_update_values_from", blk.own_own.h, w.h, 0),
+                                L.call("pa_csr_update_values_from", blk.own_ghost.h, w.h, int(k))),
+             C_.matrix_partition, cache.W, cache.nnz_oo)
+
+    return Task(finish, C_)

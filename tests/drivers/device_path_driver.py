@@ -46,6 +46,18 @@ def body(distribute):
         dref = orc.dot(xo, xo, Ao.cols)
         assert abs(d - dref) <= 1e-13 * abs(dref)
         assert np.array_equal(y.collect(), orc.pvector_collect(yo, Ao.rows))
+    # K7 across processes: psparse!(C,V2,cache) with the triplet values exchanged by the device plan
+    if P in (2, 4):
+        fparts = {2: (2, 1), 4: (2, 2)}[P]
+        nodes = (13, 9)
+        I, J, V, frows, fcols = pa.laplacian_fem(nodes, fparts, ranks)
+        C_, cache = pa.psparse_disassembled(I, J, V, frows, fcols, reuse=True)
+        Io, Jo, Vo, orows, ocols = orc.laplacian_fem(nodes, fparts)
+        V2o = [v * 3.0 + orc.hash_x(np.arange(len(v))) * 1e-2 for v in Vo]
+        pa.psparse_(C_, pa.pmap(lambda v: v * 3.0 + orc.hash_x(np.arange(len(v))) * 1e-2, V), cache).wait()
+        Af, _ = orc.psparse_disassembled(Io, Jo, V2o, orows, ocols)
+        exp = np.concatenate([Af.blocks[k].own_own.nzval, Af.blocks[k].own_ghost.nzval])
+        assert np.array_equal(pa.getany(cache.W).download()[:len(exp)], exp), "psparse! differs from a fresh assembly"
     return True
 
 

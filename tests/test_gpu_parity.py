@@ -439,3 +439,31 @@ def test_config2_laplacian_256_cubed_single_part(orc):
     pa.mul_(y, A, x)
     pa.mul_(y8, A, x8)
     assert np.array_equal(8.0 * y.own_values().items[0], y8.own_values().items[0])
+
+
+# ---------------------------------------------------------------- K7: matrix value re-assembly on the device
+@pytest.mark.parametrize("nodes,parts", [((23, 17), (2, 2)), ((9, 7, 8), (2, 2, 2)), ((30,), (3,))])
+def test_psparse_reassembly_on_device(orc, nodes, parts):
+    """psparse(...;reuse=true) then psparse!(C,V2,cache) (src/p_sparse_matrix.jl:1291-1305,1762-1816): new COO values on
+    the same pattern are scattered, exchanged and added on the device; the stored values must be bit-identical to a
+    from-scratch assembly of V2 by the oracle (test/fem_example.jl:291-329 re-assembles this way)."""
+    P = int(np.prod(parts))
+    I, J, V, rows, cols = pa.laplacian_fem(nodes, parts, ranks(P))
+    A, cache = pa.psparse_disassembled(I, J, V, rows, cols, reuse=True)
+    Io, Jo, Vo, orows, ocols = orc.laplacian_fem(nodes, parts)
+    for rep in range(2):
+        V2 = pa.pmap(lambda v, i: v * (1.0 + rep) + orc.hash_x(np.arange(len(v)) + 13 * int(i[0])) * 1e-3, V, I)
+        pa.psparse_(A, V2, cache).wait()
+        Ao, _ = orc.psparse_disassembled(Io, Jo, [v.copy() for v in V2.items], orows, ocols)
+        for w, blk in zip(cache.W.items, Ao.blocks):
+            vals = w.download()
+            exp = np.concatenate([blk.own_own.nzval, blk.own_ghost.nzval])
+            assert np.array_equal(vals[:len(exp)], exp)
+            assert np.all(vals[len(exp):] == 0.0)                     # ghost-row slots are zeroed after the exchange
+        xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+        x = upload([v.copy() for v in xo], A.col_partition)
+        y = pa.pzeros(A.row_partition)
+        pa.mul_(y, A, x)
+        yo = _oracle_mul(orc, Ao, xo)
+        for got, e, r in zip(y.own_values().items, yo, Ao.rows):
+            assert np.array_equal(got, e[:r.n_own])
