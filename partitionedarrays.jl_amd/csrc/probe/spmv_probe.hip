@@ -113,7 +113,13 @@ __global__ __launch_bounds__(BLK) void k_spmv_abl(
 #pragma unroll 4
       for (int p = a; p < e; ++p) acc = acc + prod[p];
     }
-    if (ABL & 1024) reinterpret_cast<float *>(y)[r] = (float)acc;                 // half the bytes
+    if (ABL & 8192) {      // burst emulation: only every SL-th dispatch wave of 2048 blocks stores, SL times as much
+      if (((b >> 11) % SL) == SL - 1) {
+        const long o = ((long)(r0 / 64) * 64 * SL) % 16000000l;
+        for (int g = 0; g < SL; ++g) y[o + (long)g * (r1 - r0) + (r - r0)] = acc;
+      }
+    }
+    else if (ABL & 1024) reinterpret_cast<float *>(y)[r] = (float)acc;                 // half the bytes
     else if (ABL & 2048) unsafeAtomicAdd(&y[r], acc);                            // L2 atomic instead of a store
     else if (ABL & 4096) y[(long)chunk * 512 + (r - r0)] = acc;                   // every chunk writes into its own 4 KiB
     else if (ABL & 512) {            // staggered store: at most 256 B (4 write requests) leave the CU at a time
@@ -241,7 +247,7 @@ int main(int argc, char **argv) {
   }
 
   // ---- row-pattern mode of the product kernel ------------------------------------------------------------------
-#define ADD_PAT(BLK, NPT)                                                                                     \
+#define ADD_PAT(BLK, NPT, NT)                                                                                     \
   { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, BLK * NPT, 4096, cr, &nl);           \
     const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
     const int64_t ng = pa_encode_patterns(rp.data(), hcol.data(), nrows, cr, BLK * NPT, pdesc, pdelta, 32);     \
@@ -250,11 +256,16 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
     CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
     const int cpx = (nch + 7) / 8;                                                                              \
-    V.push_back({"pattern<" #BLK "," #NPT ">c16=true", [=]() {                                                  \
-      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, true, false, true>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, \
+    V.push_back({"pattern<" #BLK "," #NPT ",nt=" #NT ">c16=true", [=]() {                                                  \
+      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, false, true>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, \
                          (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
                          (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
-  ADD_PAT(256, 8)
+  ADD_PAT(256, 8, true)
+  ADD_PAT(256, 8, false)
+  ADD_PAT(256, 12, true)
+  ADD_PAT(256, 16, true)
+  ADD_PAT(128, 16, true)
+  ADD_PAT(512, 8, true)
 
 #define ADD_ABLS(BLK, NPT, ABL, SL)                                                                          \
   { int *dc; int nch; chunks_for(BLK * NPT, &dc, &nch); const int cpx = (nch + 7) / 8;                       \
@@ -263,9 +274,11 @@ int main(int argc, char **argv) {
                          d_y2, dc, nch, cpx); }, bytes_spmv, {}}); }
   ADD_ABLS(256, 8, 0, 0)
   ADD_ABLS(256, 8, 2, 0)
-  ADD_ABLS(256, 8, 1024, 0)
-  ADD_ABLS(256, 8, 2048, 0)
-  ADD_ABLS(256, 8, 4096, 0)
+  ADD_ABLS(256, 8, 8192, 2)
+  ADD_ABLS(256, 8, 8192, 4)
+  ADD_ABLS(256, 8, 8192, 8)
+  ADD_ABLS(256, 8, 8192, 16)
+  ADD_ABLS(256, 8, 8192, 32)
   {
     const long nb = (nnz + 2047) / 2048;
     V.push_back({"stream_only<256,8,nt>", [=]() { hipLaunchKernelGGL((k_stream<256, 8, true, false>), dim3(nb), dim3(256), 0, 0, d_col, d_val, d_x, d_y2, nnz); }, (double)nnz * 12, {}});

@@ -344,7 +344,7 @@ class MatrixReassemblyCache:
         self.plans, self.scatters, self.W, self.Vdev, self.nnz_oo = plans, scatters, W, Vdev, nnz_oo
 
 
-def psparse_disassembled(I, J, V, rows, cols, keep_host=False, reuse=False):
+def psparse_disassembled(I, J, V, rows, cols, keep_host=False, reuse=False, assemble=True):
     """psparse(SparseMatrixCSR{1,Float64,Int32},I,J,V,rows,cols)|>fetch with the DEFAULT flags
     (src/p_sparse_matrix.jl:1150-1219): every part may hold entries of rows it does not own (FEM assembly loops);
     find_owner/union_ghost for rows and columns, local compress + split, then assemble onto `rows`."""
@@ -358,6 +358,11 @@ def psparse_disassembled(I, J, V, rows, cols, keep_host=False, reuse=False):
         return _split4(A, r, c)
 
     blocks4 = pmap(local, I, J, V, rows_sa, cols_sa)
+    if not assemble:
+        # psparse(...;assemble=false): the sub-assembled matrix itself (ghost rows kept; mul! assembles the product,
+        # src/p_sparse_matrix.jl:2121-2139; test/fem_example.jl:331-338)
+        dev = pmap(lambda b: SplitMatrixBlocks(DeviceCSR(b[0]), DeviceCSR(b[1]), DeviceCSR(b[2]), DeviceCSR(b[3])), blocks4)
+        return PSparseMatrix(dev, rows_sa, cols_sa, False, blocks4 if keep_host else None)
     if not reuse:
         host, cols_fa = psparse_assemble_host(blocks4, rows_sa, cols_sa, rows)
         dev = pmap(lambda h: SplitMatrixBlocks(DeviceCSR(h[0]), DeviceCSR(h[1])), host)

@@ -467,3 +467,36 @@ def test_psparse_reassembly_on_device(orc, nodes, parts):
         yo = _oracle_mul(orc, Ao, xo)
         for got, e, r in zip(y.own_values().items, yo, Ao.rows):
             assert np.array_equal(got, e[:r.n_own])
+
+
+def test_mul_sub_assembled_matrix(orc):
+    """mul!(c,a,b) with !a.assembled (src/p_sparse_matrix.jl:2094-2097,2121-2139): own and ghost rows are multiplied,
+    then assemble!(c) sends the ghost-row results to their owners (test/fem_example.jl:331-338)."""
+    nodes, parts = (17, 13), (2, 2)
+    I, J, V, rows, cols = pa.laplacian_fem(nodes, parts, ranks(4))
+    A = pa.psparse_disassembled(I, J, V, rows, cols, assemble=False)
+    assert not A.assembled
+    Io, Jo, Vo, orows, ocols = orc.laplacian_fem(nodes, parts)
+    _, (oblocks, orows_sa, ocols_sa) = orc.psparse_disassembled(Io, Jo, Vo, orows, ocols)
+    Ao = orc.PSparse([None] * 4, oblocks, orows_sa, ocols_sa, False)
+    for alpha, beta in [(1.0, 0.0), (0.5, -1.0)]:
+        xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in ocols_sa]
+        yo = [orc.hash_x(r.local_to_global + 3) for r in orows_sa]
+        x = upload([v.copy() for v in xo], A.col_partition)
+        y = upload([v.copy() for v in yo], A.row_partition)
+        if (alpha, beta) == (1.0, 0.0):
+            pa.mul_(y, A, x)                       # forwards to the 5-argument method
+        else:
+            pa.mul5_(y, A, x, alpha, beta)
+        orc.mul5(yo, Ao, xo, alpha, beta)
+        for got, exp in zip(y.local_values().items, yo):
+            assert np.array_equal(got, exp), (alpha, beta)
+    # and it agrees with the assembled operator up to rounding (different summation order)
+    B = pa.psparse_disassembled(I, J, V, rows, cols)
+    xb = pa.pvector_from_function(lambda i: orc.hash_x(i.get_local_to_global()) * (i.get_local_to_owner() == i.part), B.col_partition)
+    yb = pa.pzeros(B.row_partition)
+    pa.mul_(yb, B, xb)
+    xs = pa.pvector_from_function(lambda i: orc.hash_x(i.get_local_to_global()) * (i.get_local_to_owner() == i.part), A.col_partition)
+    ys = pa.pzeros(A.row_partition)
+    pa.mul_(ys, A, xs)
+    assert np.allclose(yb.collect(), ys.collect(), rtol=0, atol=1e-12)
