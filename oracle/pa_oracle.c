@@ -42,6 +42,19 @@ void orc_mul5_csr(double *y, const double *x, const int32_t *rowptr, const int32
   }
 }
 
+/* SparseMatricesCSR.mul!(y,transpose(A),x,alpha,beta) (v0.6, third-party; called from
+ * src/p_sparse_matrix.jl:2150,2159): beta-scale, then for every row of A, y[col] += nzval*x[row]*alpha. */
+void orc_mul5_csr_t(double *y, const double *x, const int32_t *rowptr, const int32_t *colval,
+                    const double *nzval, int64_t nrows_A, int64_t ncols_A, double alpha, double beta) {
+  if (beta != 1.0) {
+    if (beta != 0.0) { for (int64_t c = 0; c < ncols_A; ++c) y[c] *= beta; }
+    else             { for (int64_t c = 0; c < ncols_A; ++c) y[c] = 0.0; }
+  }
+  for (int64_t row = 0; row < nrows_A; ++row)
+    for (int64_t p = rowptr[row]; p < rowptr[row + 1]; ++p)
+      y[colval[p - 1] - 1] += nzval[p - 1] * x[row] * alpha;
+}
+
 /* src/p_vector.jl:595-599  buffer_snd.data[p] = values[lid] */
 void orc_pack(double *buf, const double *values, const int32_t *lids, int64_t n) {
   for (int64_t p = 0; p < n; ++p) buf[p] = values[lids[p] - 1];

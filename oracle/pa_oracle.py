@@ -771,6 +771,23 @@ def mul5(c, A: PSparse, b, alpha, beta, cache_b=None, cache_c=None):
     return c
 
 
+def mul5_transpose(c, A: PSparse, b, alpha, beta, cache_c=None):
+    """mul!(c,transpose(a),b,alpha,beta), src/p_sparse_matrix.jl:2144-2162 (assembled a): ghost(c) = alpha*A_oh'*b_own,
+    assemble!(c) started, own(c) = beta*own(c) + alpha*A_oo'*b_own, then the ghost contributions arrive (+)."""
+    assert A.assembled
+    K = oracle_c()
+    for ci, bi, blk, r, col in zip(c, b, A.blocks, A.rows, A.cols):
+        bo = bi[r.own_to_local - 1].copy()
+        ch = np.zeros(col.n_ghost)
+        K.mul5_csr_t(ch, blk.own_ghost, bo, alpha, 1.0)
+        co = ci[col.own_to_local - 1].copy()
+        K.mul5_csr_t(co, blk.own_own, bo, alpha, beta)
+        ci[col.ghost_to_local - 1] = ch
+        ci[col.own_to_local - 1] = co
+    assemble(c, A.cols, cache_c)          # unpack adds into the already updated own values, then ghosts := 0
+    return c
+
+
 def mul_no_lat(c, A: PSparse, b, cache=None):
     """HPCG/src/hpcg_utils.jl:6-17: blocking consistent!, then ONE unsplit local CSR spmv!."""
     consistent(b, A.cols, cache)
@@ -1080,6 +1097,8 @@ class _OracleC:
         P = ctypes.c_void_p
         L.orc_spmv_csr.argtypes = [P, P, P, P, P, ctypes.c_int64]
         L.orc_mul5_csr.argtypes = [P, P, P, P, P, ctypes.c_int64, ctypes.c_double, ctypes.c_double]
+        L.orc_mul5_csr_t.argtypes = [P, P, P, P, P, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, ctypes.c_double]
+        L.orc_mul5_csr_t.restype = None
         L.orc_pack.argtypes = [P, P, P, ctypes.c_int64]
         L.orc_unpack_insert.argtypes = [P, P, P, ctypes.c_int64]
         L.orc_unpack_add.argtypes = [P, P, P, ctypes.c_int64]
@@ -1104,6 +1123,12 @@ class _OracleC:
                               self._p(A.nzval), A.m, float(alpha), float(beta))
         return y
 
+    def mul5_csr_t(self, y, A: CSR, x, alpha, beta):
+        assert A.rowptr.dtype == I32 and A.colval.dtype == I32 and y.flags.c_contiguous and x.flags.c_contiguous
+        self.lib.orc_mul5_csr_t(self._p(y), self._p(x), self._p(A.rowptr), self._p(A.colval), self._p(A.nzval),
+                                A.m, A.n, float(alpha), float(beta))
+        return y
+
     def pack(self, buf, values, lids):
         self.lib.orc_pack(self._p(buf), self._p(values), self._p(lids), len(lids))
 
@@ -1122,6 +1147,16 @@ class _OraclePy:
 
     def mul5_csr(self, y, A: CSR, x, alpha, beta):
         return mul5_csr(y, A, x, alpha, beta)
+
+    def mul5_csr_t(self, y, A: CSR, x, alpha, beta):
+        if beta != 1:
+            y *= beta
+            if beta == 0:
+                y[:] = 0.0
+        for row in range(A.m):
+            for p in range(A.rowptr[row] - 1, A.rowptr[row + 1] - 1):
+                y[A.colval[p] - 1] = y[A.colval[p] - 1] + A.nzval[p] * x[row] * alpha
+        return y
 
 
 _ORACLE_C = None

@@ -86,6 +86,19 @@ class DeviceCSR:
         L.call("pa_csr_create", self.ctx.h, A.m, A.n, A.nnz, L.ptr(A.rowptr), L.ptr(A.colval), 4, 1,
                L.ptr(A.nzval), C.byref(self.h))
 
+    @staticmethod
+    def transposed(A: HostCSR, ctx=None) -> "DeviceCSR":
+        """transpose(A) as a device CSR block: A's (rowptr, colval) ARE the CSC arrays of A'; the upload keeps, inside
+        every row of A', the entries in ascending row of A -- the order SparseMatricesCSR.mul!(y,transpose(A),x,..)
+        adds them in -- so the row-split kernel reproduces it bit for bit."""
+        self = DeviceCSR.__new__(DeviceCSR)
+        self.ctx = ctx or context()
+        self.m, self.n, self.nnz = A.n, A.m, A.nnz
+        self.h = C.c_void_p()
+        L.call("pa_csr_create_from_csc", self.ctx.h, A.n, A.m, A.nnz, L.ptr(A.rowptr), L.ptr(A.colval), 4, 1,
+               L.ptr(A.nzval), C.byref(self.h))
+        return self
+
     def info(self):
         v = [C.c_int64() for _ in range(6)]
         L.call("pa_csr_info", self.h, *[C.byref(x) for x in v])
@@ -219,6 +232,23 @@ def mul5_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PVector:
         pmap(lambda cv, blk, bv: spmv_(cv, blk.ghost_ghost, bv, L.SEG_GHOST, L.SEG_GHOST, alpha, 1.0),
              c.vector_partition, a.matrix_partition, b.vector_partition)
         assemble_(c).wait()
+    return c
+
+
+def mul5_transpose_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PVector:
+    """mul!(c,transpose(a),b,alpha,beta) (src/p_sparse_matrix.jl:2144-2162), a assembled; c lives on axes(a,2), b on
+    axes(a,1).  The transposed blocks are built once (needs psparse(...,keep_host=True)) and cached on `a`."""
+    if not a.assembled:
+        raise L.PAError("mul!(c,transpose(a),b,...) needs an assembled matrix (@assert a.assembled, :2146)")
+    if getattr(a, "_t_blocks", None) is None:
+        if a.host_blocks is None:
+            raise L.PAError("transpose product needs the host blocks: build the matrix with keep_host=True")
+        a._t_blocks = pmap(lambda h: (DeviceCSR.transposed(h[0]), DeviceCSR.transposed(h[1])), a.host_blocks)
+    # ghost_values(c) = alpha * A_oh' * b_own   (fill!(ch,0); mul!(ch,atoh,bo,alpha,1))
+    pmap(lambda cv, t, bv: spmv_(cv, t[1], bv, L.SEG_OWN, L.SEG_GHOST, alpha, 0.0), c.vector_partition, a._t_blocks, b.vector_partition)
+    tsk = assemble_(c)
+    pmap(lambda cv, t, bv: spmv_(cv, t[0], bv, L.SEG_OWN, L.SEG_OWN, alpha, beta), c.vector_partition, a._t_blocks, b.vector_partition)
+    tsk.wait()
     return c
 
 

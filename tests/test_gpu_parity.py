@@ -500,3 +500,51 @@ def test_mul_sub_assembled_matrix(orc):
     ys = pa.pzeros(A.row_partition)
     pa.mul_(ys, A, xs)
     assert np.allclose(yb.collect(), ys.collect(), rtol=0, atol=1e-12)
+
+
+def test_transpose_product(orc):
+    """mul!(c,transpose(a),b,alpha,beta) (src/p_sparse_matrix.jl:2144-2162): ghost(c) = A_oh'*b, assemble!(c) overlapped
+    with own(c) = A_oo'*b.  Bit-exact against the oracle; A = A' for the HPCG matrix, so it also equals A*b to rounding."""
+    A, _ = pa.build_p_matrix(ranks(4), 6, 5, 4, 12, 10, 4, 2, 2, 1, keep_host=True, fused=True)
+    Ao, _, _ = orc.hpcg_build_p_matrix(6, 5, 4, 2, 2, 1)
+    for alpha, beta in [(1.0, 0.0), (-0.5, 2.0)]:
+        bo = [orc.hash_x(r.local_to_global + 1) for r in Ao.rows]
+        co = [orc.hash_x(c.local_to_global + 9) for c in Ao.cols]
+        b = upload([v.copy() for v in bo], A.row_partition)
+        c = upload([v.copy() for v in co], A.col_partition)
+        pa.mul5_transpose_(c, A, b, alpha, beta)
+        orc.mul5_transpose(co, Ao, bo, alpha, beta)
+        for got, exp in zip(c.local_values().items, co):
+            assert np.array_equal(got, exp), (alpha, beta)
+    # symmetry: A'*b == A*b up to rounding
+    bo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, upload([v.copy() for v in bo], A.col_partition))
+    c = pa.pzeros(A.col_partition)
+    pa.mul5_transpose_(c, A, upload([v[:r.n_own].copy() for v, r in zip(bo, Ao.rows)], A.row_partition), 1.0, 0.0)
+    assert np.allclose(y.collect(), c.collect(), rtol=0, atol=1e-12)
+
+
+def test_config4_shape_cg_iteration_8_parts_96_cubed():
+    """BASELINE config 4's loop at 8 parts x 96^3 (7.1M rows, 190M stored entries, all parts on this GPU):
+    assemble!(b) once, then CG iterations = {consistent! + mul!, 2 dots + norm, 3 axpys}, identity preconditioner
+    (HPCG/src/ref_cg.jl:40-71).  Properties: A*1 == b bit-exactly on every part; assemble! leaves own values of an
+    already assembled b untouched and zeroes its ghosts; the residual norm decreases monotonically for this SPD
+    system and x converges to 1."""
+    n = 96
+    A, b = pa.build_p_matrix(ranks(8), n, n, n, 2 * n, 2 * n, 2 * n, 2, 2, 2)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, pa.pones(A.col_partition))
+    for got, exp in zip(y.own_values().items, b.own_values().items):
+        assert np.array_equal(got, exp)
+    before = [v.copy() for v in b.own_values().items]
+    pa.assemble_(b).wait()
+    for v0, v1, g in zip(before, b.own_values().items, b.ghost_values().items):
+        assert np.array_equal(v0, v1) and not g.any()
+    hist = []
+    x = pa.pzeros(A.col_partition)
+    x, r0, r, it = pa.ref_cg_(x, A, b, maxiter=30, history=hist)
+    assert it == 30 and all(h1 < h0 for h0, h1 in zip([r0] + hist[:-1], hist))
+    assert r / r0 < 1e-6
+    for vals in x.own_values().items:
+        assert np.allclose(vals, 1.0, atol=1e-5)
