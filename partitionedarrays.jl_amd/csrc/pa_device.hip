@@ -181,6 +181,7 @@ extern "C" int pa_ctx_create(int device, pa_ctx **out) {
   PA_HIP(hipMalloc(&c->d_partials, sizeof(double) * c->n_partials));
   PA_HIP(hipMalloc(&c->d_scalar, sizeof(double) * 8));
   PA_HIP(hipMemset(c->d_scalar, 0, sizeof(double) * 8));
+  PA_HIP(hipDeviceSynchronize());  // the context's streams are non-blocking: do not race with default-stream set-up
   *out = c;
   return PA_OK;
 }
@@ -806,6 +807,7 @@ extern "C" int pa_plan_create(pa_ctx *c, int32_t part, int64_t n_local, int32_t 
   }
   PA_HIP(hipEventCreateWithFlags(&p->ev_packed, hipEventDisableTiming));
   PA_HIP(hipEventCreateWithFlags(&p->ev_arrived, hipEventDisableTiming));
+  PA_HIP(hipStreamSynchronize(nullptr));  // buffers were zeroed on the default stream; the ctx streams do not wait for it
   *out = p;
   return PA_OK;
 }

@@ -232,6 +232,7 @@ int main(int argc, char **argv) {
     CK(hipExtMallocWithFlags((void **)&u16, 2 * (nnz + 8), hipDeviceMallocUncached));
     CK(hipExtMallocWithFlags((void **)&uval, 8 * (nnz + 8), hipDeviceMallocUncached));
     CK(hipExtMallocWithFlags((void **)&uy, 8 * nrows, hipDeviceMallocUncached));
+    double *fy; CK(hipExtMallocWithFlags((void **)&fy, 8 * nrows, hipDeviceMallocFinegrained));
     CK(hipMemcpy(u16, d16, 2 * (nnz + 8), hipMemcpyDeviceToDevice));
     CK(hipMemcpy(uval, d_val, 8 * (nnz + 8), hipMemcpyDeviceToDevice));
     const int cpx = (nch + 7) / 8;
@@ -244,6 +245,7 @@ int main(int argc, char **argv) {
     ADD_ATTR("c16 matrix uncached, plain", uval, u16, d_y2, false)
     ADD_ATTR("c16 y uncached, nt", d_val, d16, uy, true)
     ADD_ATTR("c16 matrix+y uncached, nt", uval, u16, uy, true)
+    ADD_ATTR("c16 y finegrained, nt", d_val, d16, fy, true)
   }
 
   // ---- row-pattern mode of the product kernel ------------------------------------------------------------------
