@@ -169,6 +169,28 @@ int pa_scatter_create(pa_ctx *ctx, int64_t n_dst, int64_t n_src, const int32_t *
 int pa_scatter_destroy(pa_scatter *s);
 int pa_scatter_add(pa_scatter *s, pa_vec *dst, const pa_vec *src, int zero_first);
 
+/* ---- Gauss-Seidel smoother and grid transfer of the HPCG multigrid preconditioner ----------- */
+/* gauss_seidel_sweep! / gauss_seidel_sweep_zero! (PartitionedSolvers/src/smoothers.jl:144-160,236-259) on the
+ * UNSPLIT local CSR of one part (n_own rows, n_local columns [own|ghost], as HPCG builds it: split_format=false).
+ * The reference sweeps rows sequentially; here rows are grouped into dependency levels (level(i) = 1 + max level of
+ * the own columns j < i of row i) and one kernel per level runs its rows in parallel.  With a structurally symmetric
+ * own x own pattern (checked at creation) every row still sees exactly the values the sequential sweep gives it, and
+ * each row's arithmetic is the reference's (s = b; s -= a*x[col] in stored order; s += d*x[row]; s /= d), so the
+ * sweep is bit-identical to the CPU loop.  backward != 0 walks the levels in reverse (rows n:-1:1). */
+typedef struct pa_gs pa_gs;
+int pa_gs_create(pa_ctx *ctx, int64_t n_own, int64_t n_local, int64_t nnz, const int32_t *rowptr,
+                 const int32_t *colval, const double *nzval, int index_base, pa_gs **gs);
+int pa_gs_destroy(pa_gs *gs);
+int pa_gs_info(const pa_gs *gs, int64_t *n_levels, int64_t *max_rows_per_level);
+int pa_gs_sweep(pa_gs *gs, pa_vec *x, const pa_vec *b, int backward, int zero_guess);
+/* restrict! / prolongate! (HPCG/src/mg_preconditioner.jl:224-251): f2c[i] = fine row of coarse row i.
+ *   restrict  : r_c[i] = r_f[f2c[i]] - Axf[f2c[i]]          prolongate: x_f[f2c[i]] += x_c[i] */
+typedef struct pa_transfer pa_transfer;
+int pa_transfer_create(pa_ctx *ctx, int64_t n_coarse, const int32_t *f2c, int index_base, pa_transfer **t);
+int pa_transfer_destroy(pa_transfer *t);
+int pa_transfer_restrict(pa_transfer *t, pa_vec *r_c, const pa_vec *r_f, const pa_vec *Axf);
+int pa_transfer_prolongate(pa_transfer *t, pa_vec *x_f, const pa_vec *x_c);
+
 /* ---- RCCL communicator (MPI.Init / Comm_dup analogue, src/mpi_array.jl:42-53) ---------------- */
 #define PA_UNIQUE_ID_BYTES 128
 int pa_comm_unique_id(char id[PA_UNIQUE_ID_BYTES]);           /* on one rank; broadcast it yourself */

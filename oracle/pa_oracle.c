@@ -97,3 +97,23 @@ int64_t orc_hpcg_csr_single(int32_t nx, int32_t ny, int32_t nz, int32_t *rowptr,
       }
   return k;
 }
+
+/* PartitionedSolvers/src/smoothers.jl:144-160 gauss_seidel_sweep!(x,A::SparseMatrixCSR,diagA,b,rows) and
+ * :236-259 gauss_seidel_sweep_zero! (only columns < row, no diagonal correction).  A is the UNSPLIT local CSR of one
+ * part (n_own x n_local, 1-based), x its local values [own|ghost]; forward = rows 1:n, backward = n:-1:1. */
+void orc_gs_sweep(double *x, const int32_t *rowptr, const int32_t *colval, const double *nzval,
+                  const double *diag, const double *b, int64_t n, int backward, int zero_guess) {
+  for (int64_t k = 0; k < n; ++k) {
+    const int64_t row = backward ? n - 1 - k : k;
+    double s = b[row];
+    for (int64_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
+      const int64_t col = colval[p - 1] - 1;
+      if (zero_guess) { if (col < row) s -= nzval[p - 1] * x[col]; }
+      else s -= nzval[p - 1] * x[col];
+    }
+    const double d = diag[row];
+    if (!zero_guess) s += d * x[row];
+    s = s / d;
+    x[row] = s;
+  }
+}

@@ -1081,6 +1081,130 @@ def laplacian_fem(nodes_per_dir, parts_per_dir):
     return Is, Js, Vs, node_partition, node_partition
 
 
+# --------------------------------------------------------------------------------------
+# HPCG multigrid preconditioner: HPCG/src/mg_preconditioner.jl + PartitionedSolvers GS smoother
+# --------------------------------------------------------------------------------------
+def restrict_operator(nx, ny, nz):
+    """HPCG/src/mg_preconditioner.jl:81-103: coarse row -> fine row (1-based), every second point per direction."""
+    nxc, nyc, nzc = nx // 2, ny // 2, nz // 2
+    f2c = np.zeros(nxc * nyc * nzc, dtype=I32)
+    for izc in range(1, nzc + 1):
+        for iyc in range(1, nyc + 1):
+            for ixc in range(1, nxc + 1):
+                cur = (izc - 1) * nxc * nyc + (iyc - 1) * nxc + (ixc - 1) + 1
+                f2c[cur - 1] = 2 * (izc - 1) * nx * ny + 2 * (iyc - 1) * nx + 2 * (ixc - 1) + 1
+    return f2c
+
+
+def dense_diag(A: PSparse):
+    """dense_diag!(d,A) (src/p_sparse_matrix.jl:2171-2189): diagonal of the own_own block of every part."""
+    out = []
+    for M, r in zip(A.matrix_partition, A.rows):
+        d = np.zeros(r.n_own)
+        for row in range(r.n_own):
+            for p in range(M.rowptr[row] - 1, M.rowptr[row + 1] - 1):
+                if M.colval[p] - 1 == row:
+                    d[row] = M.nzval[p]
+        out.append(d)
+    return out
+
+
+def gauss_seidel_step(x, A: PSparse, diag, b, zero_guess=False, cache=None):
+    """gauss_seidel(p;iterations=1,sweep=:symmetric) step (PartitionedSolvers/src/smoothers.jl:105-131):
+    consistent!(x) unless zero_guess; forward sweep (zero-guess variant if zero_guess); backward sweep."""
+    if not zero_guess:
+        consistent(x, A.cols, cache)
+    lib = oracle_c().lib
+    lib.orc_gs_sweep.restype = None
+    lib.orc_gs_sweep.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    for xi, M, d, bi, r in zip(x, A.matrix_partition, diag, b, A.rows):
+        bo = np.ascontiguousarray(bi[:r.n_own])
+        for backward, zero in ((0, 1 if zero_guess else 0), (1, 0)):
+            lib.orc_gs_sweep(xi.ctypes.data, M.rowptr.ctypes.data, M.colval.ctypes.data, M.nzval.ctypes.data,
+                             d.ctypes.data, bo.ctypes.data, r.n_own, backward, zero)
+    return x
+
+
+@dataclass
+class MgPreconditioner:
+    """Mg_preconditioner (HPCG/src/mg_preconditioner.jl:44-65), levels 1 (coarsest) .. l (finest), stored 0-based."""
+    f2c: list
+    A: list
+    diag: list
+    r: list
+    x: list
+    Axf: list
+    l: int
+
+
+def pc_setup(np3, l, nx, ny, nz):
+    """pc_setup (HPCG/src/mg_preconditioner.jl:142-187): level l is the problem itself, each coarser level halves nx,ny,nz."""
+    npx, npy, npz = np3
+    f2c, As, diags, rs, xs, Axfs = [None] * (l - 1), [None] * l, [None] * l, [None] * l, [None] * l, [None] * l
+    for lev in range(l, 0, -1):
+        A, b, _ = hpcg_build_p_matrix(nx, ny, nz, npx, npy, npz)
+        As[lev - 1], rs[lev - 1] = A, b
+        diags[lev - 1] = dense_diag(A)
+        xs[lev - 1] = [np.zeros(c.n_local) for c in A.cols]
+        Axfs[lev - 1] = [np.zeros(c.n_local) for c in A.cols]
+        if lev > 1:
+            f2c[lev - 2] = restrict_operator(nx, ny, nz)
+            nx, ny, nz = nx // 2, ny // 2, nz // 2
+    return MgPreconditioner(f2c, As, diags, rs, xs, Axfs, l)
+
+
+def pc_solve(x, s: MgPreconditioner, b, l, zero_guess=False):
+    """pc_solve! (HPCG/src/mg_preconditioner.jl:314-329)."""
+    A, d = s.A[l - 1], s.diag[l - 1]
+    if l == 1:
+        gauss_seidel_step(x, A, d, b, zero_guess)
+    else:
+        gauss_seidel_step(x, A, d, b, zero_guess)                       # presmoother
+        mul_no_lat(s.Axf[l - 1], A, x)
+        f2c = s.f2c[l - 2]
+        for rc, rf, axf in zip(s.r[l - 2], b, s.Axf[l - 1]):             # p_restrict! on local values
+            rc[:len(f2c)] = rf[f2c - 1] - axf[f2c - 1]
+        for xc in s.x[l - 2]:
+            xc[:] = 0.0
+        pc_solve(s.x[l - 2], s, s.r[l - 2], l - 1, zero_guess=True)
+        for xf, xc in zip(x, s.x[l - 2]):                                # p_prolongate!
+            xf[f2c - 1] += xc[:len(f2c)]
+        gauss_seidel_step(x, A, d, b)                                    # postsmoother (consistent!(x) first)
+    return x
+
+
+def ref_cg_mg(x, A: PSparse, b, S: MgPreconditioner, maxiter=50, tolerance=0.0, history=None):
+    """ref_cg!(x,A,b,...;Pl=S) (HPCG/src/ref_cg.jl:40-134): ldiv!(c,Pl,r) = fill!(c,0); pc_solve!(c,Pl,r,l;zero_guess=true)."""
+    ind = A.cols
+    u = [np.zeros_like(v) for v in x]
+    r = [v.copy() for v in b]
+    c = [np.zeros_like(v) for v in x]
+    mul(c, A, x)
+    for ri, ci, i in zip(r, c, ind):
+        ri[:i.n_own] -= ci[:i.n_own]
+    residual0 = residual = norm2(r, ind)
+    rho, iters = 1.0, 0
+    while not (iters >= maxiter or residual / residual0 <= tolerance):
+        for ci in c:
+            ci[:] = 0.0
+        pc_solve(c, S, r, S.l, zero_guess=True)
+        rho_prev = rho
+        rho = dot(c, r, ind)
+        beta = rho / rho_prev
+        for ui, ci, i in zip(u, c, ind):
+            ui[:i.n_own] = ci[:i.n_own] + beta * ui[:i.n_own]
+        mul_no_lat(c, A, u)
+        alpha = rho / dot(u, c, ind)
+        for xi, ui, ri, ci, i in zip(x, u, r, c, ind):
+            xi[:i.n_own] += alpha * ui[:i.n_own]
+            ri[:i.n_own] -= alpha * ci[:i.n_own]
+        residual = norm2(r, ind)
+        iters += 1
+        if history is not None:
+            history.append(residual)
+    return x, residual0, residual, iters
+
+
 def hash_x(gids):
     """x[gid] = ((gid*2654435761) mod 2^32)/2^32, stateless and partition independent."""
     g = np.asarray(gids, dtype=np.uint64)

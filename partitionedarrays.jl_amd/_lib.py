@@ -68,6 +68,14 @@ _SIGS = {
     "pa_csr_update_values": [P, P],
     "pa_csr_update_values_from": [P, P, i64],
     "pa_csr_destroy": [P],
+    "pa_gs_create": [P, i64, i64, i64, P, P, P, cint, PP],
+    "pa_gs_destroy": [P],
+    "pa_gs_info": [P, C.POINTER(i64), C.POINTER(i64)],
+    "pa_gs_sweep": [P, P, P, cint, cint],
+    "pa_transfer_create": [P, i64, P, cint, PP],
+    "pa_transfer_destroy": [P],
+    "pa_transfer_restrict": [P, P, P, P],
+    "pa_transfer_prolongate": [P, P, P],
     "pa_scatter_create": [P, i64, i64, P, cint, PP],
     "pa_scatter_destroy": [P],
     "pa_scatter_add": [P, P, P, cint],

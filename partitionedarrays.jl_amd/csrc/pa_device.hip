@@ -157,6 +157,35 @@ __global__ __launch_bounds__(256) void k_dot_final(const double *__restrict__ pa
   if (threadIdx.x == 0) *out = t;
 }
 
+// Gauss-Seidel, one dependency level: one lane per row of the level; the reference's per-row arithmetic
+// (PartitionedSolvers/src/smoothers.jl:144-160; zero-guess variant :236-259).
+__global__ void k_gs_level(double *__restrict__ x, const double *__restrict__ b, const int *__restrict__ rowptr,
+                           const int *__restrict__ col, const double *__restrict__ val, const double *__restrict__ diag,
+                           const int *__restrict__ rows, int n, int zero_guess) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int row = rows[k];
+  double s = b[row];
+  for (int p = rowptr[row]; p < rowptr[row + 1]; ++p) {
+    const int c = col[p];
+    if (!zero_guess || c < row) s = s - val[p] * x[c];
+  }
+  const double d = diag[row];
+  if (!zero_guess) s = s + d * x[row];
+  x[row] = s / d;
+}
+
+__global__ void k_restrict(double *__restrict__ rc, const double *__restrict__ rf, const double *__restrict__ axf,
+                           const int *__restrict__ f2c, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) rc[i] = rf[f2c[i]] - axf[f2c[i]];
+}
+
+__global__ void k_prolongate(double *__restrict__ xf, const double *__restrict__ xc, const int *__restrict__ f2c, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) xf[f2c[i]] = xf[f2c[i]] + xc[i];
+}
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -685,11 +714,149 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
   return PA_OK;
 }
 
+static int upload_i32(const std::vector<int32_t> &h, int32_t **d);
+
+// ------------------------------------------------------------------------------------------------
+// Gauss-Seidel smoother (level scheduled) and grid transfer: HPCG multigrid preconditioner
+// ------------------------------------------------------------------------------------------------
+extern "C" int pa_gs_create(pa_ctx *c, int64_t n_own, int64_t n_local, int64_t nnz, const int32_t *rowptr,
+                            const int32_t *colval, const double *nzval, int index_base, pa_gs **out) {
+  PA_REQUIRE(c && out && rowptr && (nnz == 0 || (colval && nzval)), "bad arguments");
+  PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  PA_REQUIRE(n_own >= 0 && n_local >= n_own && nnz < (int64_t)2147483000, "bad sizes");
+  std::vector<int32_t> rp(n_own + 1), col(nnz), level(n_own, 0);
+  std::vector<double> diag(n_own, 0.0);
+  for (int64_t r = 0; r <= n_own; ++r) rp[r] = rowptr[r] - index_base;
+  PA_REQUIRE(rp[0] == 0 && rp[n_own] == nnz, "rowptr does not span the stored entries");
+  int32_t n_levels = 0;
+  for (int64_t r = 0; r < n_own; ++r) {
+    int32_t lv = 0;
+    bool has_diag = false;
+    for (int64_t p = rp[r]; p < rp[r + 1]; ++p) {
+      const int64_t j = (int64_t)colval[p] - index_base;
+      PA_REQUIRE(j >= 0 && j < n_local, "column out of range at entry %lld", (long long)p);
+      col[p] = (int32_t)j;
+      if (j == r) { diag[r] = nzval[p]; has_diag = true; }
+      if (j < r) lv = std::max(lv, level[j] + 1);
+    }
+    PA_REQUIRE(has_diag && diag[r] != 0.0, "row %lld has no (non-zero) diagonal entry", (long long)r);
+    level[r] = lv;
+    n_levels = std::max(n_levels, lv + 1);
+  }
+  // the parallel schedule equals the sequential sweep only if every own column j > i of row i is swept later
+  for (int64_t r = 0; r < n_own; ++r)
+    for (int64_t p = rp[r]; p < rp[r + 1]; ++p)
+      PA_REQUIRE(!(col[p] > r && col[p] < n_own) || level[col[p]] > level[r],
+                 "own x own pattern is not structurally symmetric at (%lld,%d): level scheduling would change the sweep order",
+                 (long long)r, col[p]);
+  pa_gs *g = new pa_gs();
+  g->ctx = c; g->n_own = n_own; g->n_local = n_local; g->nnz = nnz;
+  g->lev_ptr.assign(n_levels + 1, 0);
+  for (int64_t r = 0; r < n_own; ++r) g->lev_ptr[level[r] + 1]++;
+  for (int l = 0; l < n_levels; ++l) {
+    g->max_level_rows = std::max<int64_t>(g->max_level_rows, g->lev_ptr[l + 1]);
+    g->lev_ptr[l + 1] += g->lev_ptr[l];
+  }
+  std::vector<int32_t> rows(n_own), fill(g->lev_ptr.begin(), g->lev_ptr.end() - (n_levels ? 1 : 0));
+  for (int64_t r = 0; r < n_own; ++r) rows[fill[level[r]]++] = (int32_t)r;  // ascending row inside a level
+  PA_HIP(hipSetDevice(c->device));
+  PA_TRY(upload_i32(rp, &g->d_rowptr));
+  PA_TRY(upload_i32(col, &g->d_col));
+  PA_TRY(upload_i32(rows, &g->d_rows));
+  PA_HIP(hipMalloc(&g->d_val, sizeof(double) * std::max<int64_t>(1, nnz)));
+  PA_HIP(hipMalloc(&g->d_diag, sizeof(double) * std::max<int64_t>(1, n_own)));
+  if (nnz) PA_HIP(hipMemcpy(g->d_val, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
+  if (n_own) PA_HIP(hipMemcpy(g->d_diag, diag.data(), sizeof(double) * n_own, hipMemcpyHostToDevice));
+  *out = g;
+  return PA_OK;
+}
+
+extern "C" int pa_gs_destroy(pa_gs *g) {
+  if (!g) return PA_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->s[0]);
+  (void)hipFree(g->d_rowptr); (void)hipFree(g->d_col); (void)hipFree(g->d_rows); (void)hipFree(g->d_val); (void)hipFree(g->d_diag);
+  delete g;
+  return PA_OK;
+}
+
+extern "C" int pa_gs_info(const pa_gs *g, int64_t *n_levels, int64_t *max_rows) {
+  PA_REQUIRE(g != nullptr, "gs is NULL");
+  if (n_levels) *n_levels = (int64_t)g->lev_ptr.size() - 1;
+  if (max_rows) *max_rows = g->max_level_rows;
+  return PA_OK;
+}
+
+extern "C" int pa_gs_sweep(pa_gs *g, pa_vec *x, const pa_vec *b, int backward, int zero_guess) {
+  PA_REQUIRE(g && x && b, "bad arguments");
+  PA_REQUIRE(x->n_own + x->n_ghost == g->n_local && x->n_own == g->n_own, "x does not match the matrix (%lld own, %lld local)",
+             (long long)g->n_own, (long long)g->n_local);
+  PA_REQUIRE(b->n_own == g->n_own, "b does not match the matrix");
+  PA_REQUIRE(x->d != b->d, "x and b alias");
+  pa_ctx *c = g->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  const int nl = (int)g->lev_ptr.size() - 1;
+  for (int k = 0; k < nl; ++k) {
+    const int l = backward ? nl - 1 - k : k;
+    const int n = g->lev_ptr[l + 1] - g->lev_ptr[l];
+    if (n == 0) continue;
+    hipLaunchKernelGGL(k_gs_level, dim3((n + 127) / 128), dim3(128), 0, c->s[0], x->d, b->d, g->d_rowptr, g->d_col, g->d_val,
+                       g->d_diag, g->d_rows + g->lev_ptr[l], n, zero_guess);
+  }
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_transfer_create(pa_ctx *c, int64_t n_coarse, const int32_t *f2c, int index_base, pa_transfer **out) {
+  PA_REQUIRE(c && out && n_coarse >= 0 && (n_coarse == 0 || f2c), "bad arguments");
+  PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  std::vector<int32_t> h(n_coarse);
+  for (int64_t i = 0; i < n_coarse; ++i) {
+    h[i] = f2c[i] - index_base;
+    PA_REQUIRE(h[i] >= 0, "negative fine index at %lld", (long long)i);
+  }
+  pa_transfer *t = new pa_transfer();
+  t->ctx = c; t->n_coarse = n_coarse;
+  PA_HIP(hipSetDevice(c->device));
+  PA_TRY(upload_i32(h, &t->d_f2c));
+  *out = t;
+  return PA_OK;
+}
+
+extern "C" int pa_transfer_destroy(pa_transfer *t) {
+  if (!t) return PA_OK;
+  (void)hipSetDevice(t->ctx->device);
+  (void)hipStreamSynchronize(t->ctx->s[0]);
+  (void)hipFree(t->d_f2c);
+  delete t;
+  return PA_OK;
+}
+
+extern "C" int pa_transfer_restrict(pa_transfer *t, pa_vec *rc, const pa_vec *rf, const pa_vec *axf) {
+  PA_REQUIRE(t && rc && rf && axf, "bad arguments");
+  PA_REQUIRE(rc->n_own + rc->n_ghost >= t->n_coarse && rf->n_own + rf->n_ghost == axf->n_own + axf->n_ghost, "vector sizes");
+  if (t->n_coarse == 0) return PA_OK;
+  PA_HIP(hipSetDevice(t->ctx->device));
+  hipLaunchKernelGGL(k_restrict, dim3((t->n_coarse + 255) / 256), dim3(256), 0, t->ctx->s[0], rc->d, rf->d, axf->d, t->d_f2c,
+                     (int)t->n_coarse);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_transfer_prolongate(pa_transfer *t, pa_vec *xf, const pa_vec *xc) {
+  PA_REQUIRE(t && xf && xc, "bad arguments");
+  PA_REQUIRE(xc->n_own + xc->n_ghost >= t->n_coarse, "coarse vector too short");
+  if (t->n_coarse == 0) return PA_OK;
+  PA_HIP(hipSetDevice(t->ctx->device));
+  hipLaunchKernelGGL(k_prolongate, dim3((t->n_coarse + 255) / 256), dim3(256), 0, t->ctx->s[0], xf->d, xc->d, t->d_f2c,
+                     (int)t->n_coarse);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // deterministic scatter-add maps (sparse_matrix!(A,V,K), src/sparse_utils.jl:454-466)
 // ------------------------------------------------------------------------------------------------
-static int upload_i32(const std::vector<int32_t> &h, int32_t **d);
-
 extern "C" int pa_scatter_create(pa_ctx *c, int64_t n_dst, int64_t n_src, const int32_t *dest, int index_base, pa_scatter **out) {
   PA_REQUIRE(c && out && n_dst >= 0 && n_src >= 0 && (n_src == 0 || dest), "bad arguments");
   PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");

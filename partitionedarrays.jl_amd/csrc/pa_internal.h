@@ -105,6 +105,20 @@ struct pa_scatter {
   int32_t *d_tgt = nullptr, *d_tptr = nullptr, *d_tp = nullptr;
 };
 
+struct pa_gs {
+  pa_ctx *ctx = nullptr;
+  int64_t n_own = 0, n_local = 0, nnz = 0, max_level_rows = 0;
+  int32_t *d_rowptr = nullptr, *d_col = nullptr, *d_rows = nullptr;  // 0-based CSR; rows sorted by level
+  double *d_val = nullptr, *d_diag = nullptr;
+  std::vector<int32_t> lev_ptr;  // host: level l owns d_rows[lev_ptr[l] .. lev_ptr[l+1])
+};
+
+struct pa_transfer {
+  pa_ctx *ctx = nullptr;
+  int64_t n_coarse = 0;
+  int32_t *d_f2c = nullptr;  // 0-based fine row of every coarse row
+};
+
 int pa_plan_mark_arrived(pa_plan *p);
 
 #endif

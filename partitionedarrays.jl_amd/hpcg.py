@@ -7,14 +7,136 @@ broadcasts, all on device-resident PVectors.
 """
 from __future__ import annotations
 
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib as L
+from .primitives import pmap, local_items
 from .p_sparse_matrix import mul_, mul_no_overlap_
-from .p_vector import axpby_, copy_, dot, norm, similar
+from .p_vector import axpby_, copy_, dot, norm, similar, pzeros, consistent_, context
 
 mul_no_lat_ = mul_no_overlap_     # HPCG/src/hpcg_utils.jl:6-17: blocking consistent!, then the local product
 
 
-def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None):
-    """ref_cg!(x,A,b,timing_data;tolerance,maxiter,Pl=Identity()) -> x, residual0, residual, iters.
+# ----------------------------------------------------------------------------------------------
+# multigrid preconditioner (HPCG/src/mg_preconditioner.jl) with the Gauss-Seidel smoother of PartitionedSolvers
+# ----------------------------------------------------------------------------------------------
+def restrict_operator(nx, ny, nz):
+    """restrict_operator(nx,ny,nz) (HPCG/src/mg_preconditioner.jl:81-103): fine row (1-based) of every coarse row."""
+    assert nx % 2 == 0 and ny % 2 == 0 and nz % 2 == 0
+    nxc, nyc, nzc = nx // 2, ny // 2, nz // 2
+    izc, iyc, ixc = np.meshgrid(np.arange(nzc), np.arange(nyc), np.arange(nxc), indexing="ij")
+    return (2 * izc * nx * ny + 2 * iyc * nx + 2 * ixc + 1).ravel().astype(np.int32)
+
+
+class GaussSeidel:
+    """gauss_seidel(p;iterations=1,sweep=:symmetric) of one PSparseMatrix (PartitionedSolvers/src/smoothers.jl:91-131)
+    on the device: pa_gs holds the unsplit local CSR of every part, its diagonal and the dependency levels."""
+
+    def __init__(self, A):
+        if A.host_blocks is None:
+            raise L.PAError("the Gauss-Seidel smoother needs the host blocks: build the matrix with keep_host=True")
+        self.A = A
+
+        def make(h, r, c):
+            oo, oh = h
+            # unsplit local CSR: own columns then ghost columns (+n_own), the storage HPCG uses (split_format=false)
+            cnt = np.diff(oo.rowptr.astype(np.int64)) + np.diff(oh.rowptr.astype(np.int64))
+            rowptr = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32)
+            n = r.n_own
+            ro = np.repeat(np.arange(n), np.diff(oo.rowptr.astype(np.int64)))
+            rh = np.repeat(np.arange(n), np.diff(oh.rowptr.astype(np.int64)))
+            rows = np.concatenate([ro, rh])
+            cols = np.concatenate([oo.colval.astype(np.int64), oh.colval.astype(np.int64) + c.n_own])
+            vals = np.concatenate([oo.nzval, oh.nzval])
+            order = np.lexsort((cols, rows))
+            g = C.c_void_p()
+            colv = np.ascontiguousarray(cols[order], np.int32)
+            val = np.ascontiguousarray(vals[order])
+            L.call("pa_gs_create", context().h, n, c.n_local, len(val), L.ptr(rowptr), L.ptr(colv), L.ptr(val), 1, C.byref(g))
+            return g
+
+        self.gs = pmap(make, A.host_blocks, A.row_partition, A.col_partition)
+
+    def info(self):
+        def f(g):
+            a, b = C.c_int64(), C.c_int64()
+            L.call("pa_gs_info", g, C.byref(a), C.byref(b))
+            return dict(levels=a.value, max_rows_per_level=b.value)
+        return pmap(f, self.gs)
+
+    def step_(self, x, b, zero_guess=False):
+        """gauss_seidel_step (smoothers.jl:105-131): consistent!(x) unless zero_guess; forward sweep (zero-guess
+        variant: only columns < row); backward sweep."""
+        if not zero_guess:
+            consistent_(x).wait()
+        pmap(lambda g, xv, bv: L.call("pa_gs_sweep", g, xv.h, bv.h, 0, 1 if zero_guess else 0), self.gs, x.vector_partition, b.vector_partition)
+        pmap(lambda g, xv, bv: L.call("pa_gs_sweep", g, xv.h, bv.h, 1, 0), self.gs, x.vector_partition, b.vector_partition)
+        return x
+
+
+@dataclass
+class MgPreconditioner:
+    """Mg_preconditioner (HPCG/src/mg_preconditioner.jl:44-65); index 0 is the coarsest level, l-1 the finest."""
+    f2c: list          # per coarse level: device transfer handles of every part
+    A_vec: list
+    gs_states: list
+    r: list
+    x: list
+    Axf: list
+    l: int
+
+
+def pc_setup(ranks, np_, l, nx, ny, nz):
+    """pc_setup(np,ranks,l,nx,ny,nz) (HPCG/src/mg_preconditioner.jl:142-187)."""
+    from .gallery import build_p_matrix, compute_optimal_shape_XYZ
+    npx, npy, npz = compute_optimal_shape_XYZ(np_)
+    f2c, As, gss, rs, xs, Axfs = [None] * (l - 1), [None] * l, [None] * l, [None] * l, [None] * l, [None] * l
+    for lev in range(l, 0, -1):
+        A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=True, fused=True)
+        As[lev - 1], rs[lev - 1] = A, b
+        gss[lev - 1] = GaussSeidel(A)
+        xs[lev - 1], Axfs[lev - 1] = pzeros(A.col_partition), pzeros(A.col_partition)
+        if lev > 1:
+            op = restrict_operator(nx, ny, nz)
+
+            def mk(_r):
+                t = C.c_void_p()
+                L.call("pa_transfer_create", context().h, len(op), L.ptr(op), 1, C.byref(t))
+                return t
+            f2c[lev - 2] = pmap(mk, A.row_partition)
+            nx, ny, nz = nx // 2, ny // 2, nz // 2
+    return MgPreconditioner(f2c, As, gss, rs, xs, Axfs, l)
+
+
+def pc_solve_(x, s: MgPreconditioner, b, l, zero_guess=False):
+    """pc_solve!(x,s,b,l;zero_guess) (HPCG/src/mg_preconditioner.jl:314-329): one V-cycle."""
+    gs, A = s.gs_states[l - 1], s.A_vec[l - 1]
+    if l == 1:
+        gs.step_(x, b, zero_guess)
+        return x
+    gs.step_(x, b, zero_guess)                                            # presmoother
+    mul_no_lat_(s.Axf[l - 1], A, x)
+    t = s.f2c[l - 2]
+    pmap(lambda th, rc, rf, ax: L.call("pa_transfer_restrict", th, rc.h, rf.h, ax.h),
+         t, s.r[l - 2].vector_partition, b.vector_partition, s.Axf[l - 1].vector_partition)
+    pmap(lambda v: v.fill(0.0), s.x[l - 2].vector_partition)
+    pc_solve_(s.x[l - 2], s, s.r[l - 2], l - 1, zero_guess=True)
+    pmap(lambda th, xf, xc: L.call("pa_transfer_prolongate", th, xf.h, xc.h), t, x.vector_partition, s.x[l - 2].vector_partition)
+    gs.step_(x, b)                                                         # postsmoother
+    return x
+
+
+def ldiv_(x, P: MgPreconditioner, b):
+    """ldiv!(x,P::Mg_preconditioner,b) (HPCG/src/mg_preconditioner.jl:204-208)."""
+    pmap(lambda v: v.fill(0.0), x.vector_partition)
+    return pc_solve_(x, P, b, P.l, zero_guess=True)
+
+
+def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None, Pl=None):
+    """ref_cg!(x,A,b,timing_data;tolerance,maxiter,Pl) -> x, residual0, residual, iters (Pl=None: Identity()).
     `overlap=True` uses mul! (latency hiding, src/p_sparse_matrix.jl:2090); False uses mul_no_lat! as HPCG does."""
     mv = mul_ if overlap else mul_no_lat_
     # cg_iterator! (ref_cg.jl:76-96).  Vectors that are multiplied by A live on the column partition (= row
@@ -29,7 +151,10 @@ def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None):
     rho = 1.0
     iters = 0
     while not (iters >= maxiter or residual / residual0 <= tolerance):      # done(it,iteration) (:23)
-        copy_(c, r)                      # ldiv!(c, Identity(), r)  (:48)
+        if Pl is None:
+            copy_(c, r)                  # ldiv!(c, Identity(), r)  (:48)
+        else:
+            ldiv_(c, Pl, r)              # MG V-cycle
         rho_prev = rho
         rho = dot(c, r)                  # (:52)
         beta = rho / rho_prev

@@ -92,6 +92,9 @@ G["hpcg"] = {"src": "HPCG/test/hpcg_benchmark_tests.jl:15-28", "seq_grid": [32, 
              "parts": [2, 2, 1], "n_per_part": [16, 16, 16],
              "property": "b of the sequential build == collect(pb) of the 2x2x1 partitioned build"}
 
+G["hpcg_known_answer"] = {"src": "HPCG/test/hpcg_benchmark_tests.jl:31-41", "np": 4, "parts": [2, 2, 1], "n": [32, 32, 32],
+                          "levels": 4, "maxiter": 50, "expected_ref_tol": 2.877476184683206e-13, "assert_below": 1.0e-12}
+
 G["ghost_first_seen"] = {"src": "SURVEY.md Appendix A (derived from HPCG/src/sparse_matrix.jl:41-57 + src/p_range.jl:226-239)",
                          "global": [8, 4, 4], "parts": [2, 1, 1], "part": 2, "ghost_gids_head": [4, 12, 36, 44, 20, 52]}
 

@@ -547,3 +547,39 @@ def test_config4_shape_cg_iteration_8_parts_96_cubed():
     assert it == 30 and all(h1 < h0 for h0, h1 in zip([r0] + hist[:-1], hist))
     assert r / r0 < 0.1                      # unpreconditioned CG on a 192^3 grid: slow but steady
     assert all(float(v.mean()) > 0.0 for v in x.own_values().items)   # x is moving from 0 towards the solution 1
+
+
+# ---------------------------------------------------------------- HPCG multigrid preconditioner
+def test_gauss_seidel_sweeps_bit_exact(orc):
+    """Level-scheduled Gauss-Seidel == the reference's sequential sweep, bit for bit (forward zero-guess, backward,
+    forward with a non-zero guess), on 4 parts of the 27-pt matrix."""
+    A, b = pa.build_p_matrix(ranks(4), 8, 6, 6, 16, 12, 6, 2, 2, 1, keep_host=True)
+    Ao, bo, _ = orc.hpcg_build_p_matrix(8, 6, 6, 2, 2, 1)
+    gs = pa.GaussSeidel(A)
+    assert all(i["levels"] > 1 for i in gs.info().items)
+    d = orc.dense_diag(Ao)
+    xo = [np.zeros(c.n_local) for c in Ao.cols]
+    x = pa.pzeros(A.col_partition)
+    for zero in (True, False, False):
+        gs.step_(x, b, zero_guess=zero)
+        orc.gauss_seidel_step(xo, Ao, d, bo, zero_guess=zero)
+        for got, exp in zip(x.local_values().items, xo):
+            assert np.array_equal(got, exp), zero
+
+
+def test_hpcg_mg_pcg_known_answer_on_device(orc, golden):
+    """HPCG/test/hpcg_benchmark_tests.jl:31-41 on the device path: 4 parts x 32^3, 4 MG levels, 50 PCG iterations.
+    normr/normr0 < 1e-12 and within 1e-9 relative of the recorded 2.877476184683206e-13; the residual history follows
+    the oracle's (dot products reassociate, everything else is bit-identical)."""
+    c = golden["hpcg_known_answer"]
+    S = pa.pc_setup(ranks(c["np"]), c["np"], c["levels"], *c["n"])
+    A, b = S.A_vec[-1], S.r[-1]
+    x = pa.pzeros(A.col_partition)
+    hist = []
+    x, r0, r, it = pa.ref_cg_(x, A, b, maxiter=c["maxiter"], overlap=False, history=hist, Pl=S)
+    assert it == c["maxiter"] and r / r0 < c["assert_below"]
+    assert abs(r / r0 - c["expected_ref_tol"]) <= 1e-9 * c["expected_ref_tol"]
+    So = orc.pc_setup(tuple(c["parts"]), c["levels"], *c["n"])
+    ho = []
+    orc.ref_cg_mg([np.zeros(col.n_local) for col in So.A[-1].cols], So.A[-1], So.r[-1], So, maxiter=c["maxiter"], history=ho)
+    assert np.allclose(hist, ho, rtol=1e-9, atol=0)
