@@ -166,9 +166,23 @@ __global__ void k_gs_level(double *__restrict__ x, const double *__restrict__ b,
   if (k >= n) return;
   const int row = rows[k];
   double s = b[row];
-  for (int p = rowptr[row]; p < rowptr[row + 1]; ++p) {
-    const int c = col[p];
-    if (!zero_guess || c < row) s = s - val[p] * x[c];
+  const int p0 = rowptr[row], p1 = rowptr[row + 1];
+  // groups of 9 entries: all index/value loads, then all x gathers, then the (ordered) subtract chain -- three
+  // memory round trips per group instead of three per entry (the kernel is latency-bound: a level is a few thousand rows)
+  for (int p = p0; p < p1; p += 9) {
+    int c[9];
+    double a[9], xv[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const int q = min(p + j, p1 - 1);
+      c[j] = col[q];
+      a[j] = val[q];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; ++j) xv[j] = x[c[j]];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+      if (p + j < p1 && (!zero_guess || c[j] < row)) s = s - a[j] * xv[j];
   }
   const double d = diag[row];
   if (!zero_guess) s = s + d * x[row];
