@@ -167,21 +167,23 @@ __global__ void k_gs_level(double *__restrict__ x, const double *__restrict__ b,
   const int row = rows[k];
   double s = b[row];
   const int p0 = rowptr[row], p1 = rowptr[row + 1];
-  // groups of 9 entries: all index/value loads, then all x gathers, then the (ordered) subtract chain -- three
-  // memory round trips per group instead of three per entry (the kernel is latency-bound: a level is a few thousand rows)
-  for (int p = p0; p < p1; p += 9) {
-    int c[9];
-    double a[9], xv[9];
+  // groups of GS_GROUP entries: all index/value loads, then all x gathers, then the (ordered) subtract chain -- three
+  // memory round trips per group instead of three per entry (the kernel is latency-bound: a level is a few thousand
+  // rows).  9 measured best on MI355X (27, a whole stencil row, needs 128 VGPRs and is slower).
+  constexpr int GS_GROUP = 9;
+  for (int p = p0; p < p1; p += GS_GROUP) {
+    int c[GS_GROUP];
+    double a[GS_GROUP], xv[GS_GROUP];
 #pragma unroll
-    for (int j = 0; j < 9; ++j) {
+    for (int j = 0; j < GS_GROUP; ++j) {
       const int q = min(p + j, p1 - 1);
       c[j] = col[q];
       a[j] = val[q];
     }
 #pragma unroll
-    for (int j = 0; j < 9; ++j) xv[j] = x[c[j]];
+    for (int j = 0; j < GS_GROUP; ++j) xv[j] = x[c[j]];
 #pragma unroll
-    for (int j = 0; j < 9; ++j)
+    for (int j = 0; j < GS_GROUP; ++j)
       if (p + j < p1 && (!zero_guess || c[j] < row)) s = s - a[j] * xv[j];
   }
   const double d = diag[row];
