@@ -111,6 +111,12 @@ struct pa_gs {
   int32_t *d_rowptr = nullptr, *d_col = nullptr, *d_rows = nullptr;  // 0-based CSR; rows sorted by level
   double *d_val = nullptr, *d_diag = nullptr;
   std::vector<int32_t> lev_ptr;  // host: level l owns d_rows[lev_ptr[l] .. lev_ptr[l+1])
+  struct graph_entry {             // one captured sweep (a chain of level kernels) per (x, b, direction, zero_guess)
+    const void *x, *b;
+    int backward, zero_guess;
+    hipGraphExec_t exec;
+  };
+  std::vector<graph_entry> graphs;
 };
 
 struct pa_transfer {
