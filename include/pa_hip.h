@@ -176,10 +176,17 @@ int pa_scatter_add(pa_scatter *s, pa_vec *dst, const pa_vec *src, int zero_first
  * the own columns j < i of row i) and one kernel per level runs its rows in parallel.  With a structurally symmetric
  * own x own pattern (checked at creation) every row still sees exactly the values the sequential sweep gives it, and
  * each row's arithmetic is the reference's (s = b; s -= a*x[col] in stored order; s += d*x[row]; s /= d), so the
- * sweep is bit-identical to the CPU loop.  backward != 0 walks the levels in reverse (rows n:-1:1). */
+ * sweep is bit-identical to the CPU loop.  backward != 0 walks the levels in reverse (rows n:-1:1).
+ *
+ * ordering = PA_GS_MULTICOLOR replaces the dependency levels by the colours of a greedy colouring of the own x own
+ * pattern (27-pt stencil: 8 colours instead of ~7n levels): a different -- much more parallel -- sweep order, NOT
+ * the reference's arithmetic.  It is the "optimised" variant HPCG's opt_cg! hook is for (HPCG/src/opt_cg.jl,
+ * HPCG/src/hpcg_benchmark.jl:60-78): it must reach the reference tolerance and is charged for its extra iterations. */
+#define PA_GS_SEQUENTIAL 0
+#define PA_GS_MULTICOLOR 1
 typedef struct pa_gs pa_gs;
 int pa_gs_create(pa_ctx *ctx, int64_t n_own, int64_t n_local, int64_t nnz, const int32_t *rowptr,
-                 const int32_t *colval, const double *nzval, int index_base, pa_gs **gs);
+                 const int32_t *colval, const double *nzval, int index_base, int ordering, pa_gs **gs);
 int pa_gs_destroy(pa_gs *gs);
 int pa_gs_info(const pa_gs *gs, int64_t *n_levels, int64_t *max_rows_per_level);
 int pa_gs_sweep(pa_gs *gs, pa_vec *x, const pa_vec *b, int backward, int zero_guess);

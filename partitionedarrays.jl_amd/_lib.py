@@ -68,7 +68,7 @@ _SIGS = {
     "pa_csr_update_values": [P, P],
     "pa_csr_update_values_from": [P, P, i64],
     "pa_csr_destroy": [P],
-    "pa_gs_create": [P, i64, i64, i64, P, P, P, cint, PP],
+    "pa_gs_create": [P, i64, i64, i64, P, P, P, cint, cint, PP],
     "pa_gs_destroy": [P],
     "pa_gs_info": [P, C.POINTER(i64), C.POINTER(i64)],
     "pa_gs_sweep": [P, P, P, cint, cint],

@@ -736,8 +736,9 @@ static int upload_i32(const std::vector<int32_t> &h, int32_t **d);
 // Gauss-Seidel smoother (level scheduled) and grid transfer: HPCG multigrid preconditioner
 // ------------------------------------------------------------------------------------------------
 extern "C" int pa_gs_create(pa_ctx *c, int64_t n_own, int64_t n_local, int64_t nnz, const int32_t *rowptr,
-                            const int32_t *colval, const double *nzval, int index_base, pa_gs **out) {
+                            const int32_t *colval, const double *nzval, int index_base, int ordering, pa_gs **out) {
   PA_REQUIRE(c && out && rowptr && (nnz == 0 || (colval && nzval)), "bad arguments");
+  PA_REQUIRE(ordering == PA_GS_SEQUENTIAL || ordering == PA_GS_MULTICOLOR, "unknown ordering %d", ordering);
   PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
   PA_REQUIRE(n_own >= 0 && n_local >= n_own && nnz < (int64_t)2147483000, "bad sizes");
   std::vector<int32_t> rp(n_own + 1), col(nnz), level(n_own, 0);
@@ -756,13 +757,23 @@ extern "C" int pa_gs_create(pa_ctx *c, int64_t n_own, int64_t n_local, int64_t n
       if (j < r) lv = std::max(lv, level[j] + 1);
     }
     PA_REQUIRE(has_diag && diag[r] != 0.0, "row %lld has no (non-zero) diagonal entry", (long long)r);
+    if (ordering == PA_GS_MULTICOLOR) {
+      // greedy colouring in natural order: smallest colour no already-coloured own neighbour uses (<= 64 colours)
+      uint64_t used = 0;
+      for (int64_t p = rp[r]; p < rp[r + 1]; ++p)
+        if (col[p] < r && level[col[p]] < 64) used |= 1ull << level[col[p]];
+      lv = 0;
+      while (lv < 63 && (used >> lv) & 1ull) ++lv;
+    }
     level[r] = lv;
     n_levels = std::max(n_levels, lv + 1);
   }
-  // the parallel schedule equals the sequential sweep only if every own column j > i of row i is swept later
+  // the parallel schedule equals the sequential sweep only if every own column j > i of row i is swept later;
+  // a colouring only needs neighbours to differ
   for (int64_t r = 0; r < n_own; ++r)
     for (int64_t p = rp[r]; p < rp[r + 1]; ++p)
-      PA_REQUIRE(!(col[p] > r && col[p] < n_own) || level[col[p]] > level[r],
+      PA_REQUIRE(!(col[p] > r && col[p] < n_own) ||
+                     (ordering == PA_GS_SEQUENTIAL ? level[col[p]] > level[r] : level[col[p]] != level[r]),
                  "own x own pattern is not structurally symmetric at (%lld,%d): level scheduling would change the sweep order",
                  (long long)r, col[p]);
   pa_gs *g = new pa_gs();

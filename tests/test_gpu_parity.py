@@ -583,3 +583,19 @@ def test_hpcg_mg_pcg_known_answer_on_device(orc, golden):
     ho = []
     orc.ref_cg_mg([np.zeros(col.n_local) for col in So.A[-1].cols], So.A[-1], So.r[-1], So, maxiter=c["maxiter"], history=ho)
     assert np.allclose(hist, ho, rtol=1e-9, atol=0)
+
+
+def test_multicolor_gauss_seidel_as_hpcg_optimised_variant(golden):
+    """The multicolour smoother is NOT the reference's arithmetic; it is validated the way HPCG validates an optimised
+    run (HPCG/src/hpcg_benchmark.jl:60-78): opt_cg! must reach the reference tolerance (here the recorded 2.877e-13 of
+    the 4 x 32^3 known answer) within 10x the reference iterations, and the extra iterations are reported."""
+    c = golden["hpcg_known_answer"]
+    S = pa.pc_setup(ranks(c["np"]), c["np"], c["levels"], *c["n"], ordering="multicolor")
+    assert all(i["levels"] == 8 for g in S.gs_states for i in g.info().items)        # 27-pt stencil: 8 colours
+    A, b = S.A_vec[-1], S.r[-1]
+    x = pa.pzeros(A.col_partition)
+    x, r0, r, it = pa.opt_cg_(x, A, b, maxiter=10 * c["maxiter"], tolerance=c["expected_ref_tol"], Pl=S)
+    assert r / r0 <= c["expected_ref_tol"] and it <= 10 * c["maxiter"]
+    assert it < 2 * c["maxiter"]                                                     # in practice a few iterations more
+    for vals in x.own_values().items:
+        assert np.allclose(vals, 1.0, atol=1e-9)                                     # b = A*1
