@@ -11,7 +11,7 @@ import numpy as np
 
 from . import _lib as L
 from .primitives import pmap, tuple_of_arrays
-from .p_range import uniform_partition, _cartesian
+from .p_range import uniform_partition
 from .p_sparse_matrix import psparse_from_coo
 from .p_vector import pvector
 

@@ -13,7 +13,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib as L
-from .primitives import pmap, local_items
+from .primitives import pmap
 from .p_sparse_matrix import mul_, mul_no_overlap_
 from .p_vector import axpby_, copy_, dot, norm, similar, pzeros, consistent_, context
 

@@ -13,7 +13,7 @@ import itertools
 import numpy as np
 
 from . import _lib as L
-from .primitives import (DebugArray, exchange, exchange_graph, linear_indices, pmap, tuple_of_arrays,
+from .primitives import (exchange, exchange_graph, linear_indices, pmap, tuple_of_arrays,
                          getany, gather)
 
 I32, I64 = np.int32, np.int64

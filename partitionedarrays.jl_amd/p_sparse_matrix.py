@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib as L
-from .primitives import pmap, local_items
+from .primitives import pmap
 from .p_range import PRange, find_owner, union_ghost
 from .p_vector import PVector, Task, consistent_, assemble_, context
 

@@ -1,8 +1,5 @@
 """The one-part-per-process device path on the 1-GPU box: P ranks share cuda:0, transport = host-staged gloo.
 (RCCL itself needs distinct GPUs; its call sequence is pinned by test_rccl_single_rank_loopback.)"""
-import os
-import sys
-
 import pytest
 
 from test_multiprocess_gloo import _run
