@@ -190,6 +190,16 @@ int pa_gs_create(pa_ctx *ctx, int64_t n_own, int64_t n_local, int64_t nnz, const
 int pa_gs_destroy(pa_gs *gs);
 int pa_gs_info(const pa_gs *gs, int64_t *n_levels, int64_t *max_rows_per_level);
 int pa_gs_sweep(pa_gs *gs, pa_vec *x, const pa_vec *b, int backward, int zero_guess);
+/* Colours of the greedy colouring pa_gs_create(PA_GS_MULTICOLOR) uses (natural order, smallest free colour). */
+int pa_host_greedy_coloring(int64_t n_own, const int32_t *rowptr, const int32_t *colval, int index_base,
+                            int32_t *color, int32_t *n_colors);
+/* One colour of a multicolour Gauss-Seidel sweep written as SpMV + update (the optimised HPCG variant):
+ *   x[row] = x[row] + (b[row] - t[row]) / diag[row];  t[row] = 0   for the listed rows, where t = A*x was accumulated
+ * for these rows by pa_spmv(beta = 1) on the colour's sub-matrix into a zeroed t.  rows are local ids in `index_base`. */
+typedef struct pa_rowset pa_rowset;
+int pa_rowset_create(pa_ctx *ctx, int64_t n, const int32_t *rows, int index_base, pa_rowset **rs);
+int pa_rowset_destroy(pa_rowset *rs);
+int pa_gs_color_update(pa_rowset *rs, pa_vec *x, const pa_vec *b, pa_vec *t, const pa_vec *diag);
 /* restrict! / prolongate! (HPCG/src/mg_preconditioner.jl:224-251): f2c[i] = fine row of coarse row i.
  *   restrict  : r_c[i] = r_f[f2c[i]] - Axf[f2c[i]]          prolongate: x_f[f2c[i]] += x_c[i] */
 typedef struct pa_transfer pa_transfer;

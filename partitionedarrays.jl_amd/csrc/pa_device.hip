@@ -191,6 +191,16 @@ __global__ void k_gs_level(double *__restrict__ x, const double *__restrict__ b,
   x[row] = s / d;
 }
 
+__global__ void k_gs_color_update(double *__restrict__ x, const double *__restrict__ b, double *__restrict__ t,
+                                  const double *__restrict__ diag, const int *__restrict__ rows, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) {
+    const int r = rows[k];
+    x[r] = x[r] + (b[r] - t[r]) / diag[r];
+    t[r] = 0.0;  // t is an accumulator for the next colour's A*x (pa_spmv with beta = 1 touches only its rows)
+  }
+}
+
 __global__ void k_restrict(double *__restrict__ rc, const double *__restrict__ rf, const double *__restrict__ axf,
                            const int *__restrict__ f2c, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -861,6 +871,59 @@ extern "C" int pa_gs_sweep(pa_gs *g, pa_vec *x, const pa_vec *b, int backward, i
   }
   g->graphs.push_back({x->d, b->d, backward != 0, zero_guess != 0, exec});
   PA_HIP(hipGraphLaunch(exec, c->s[0]));
+  return PA_OK;
+}
+
+extern "C" int pa_host_greedy_coloring(int64_t n_own, const int32_t *rowptr, const int32_t *colval, int index_base,
+                                       int32_t *color, int32_t *n_colors) {
+  PA_REQUIRE(rowptr && color && n_colors && (index_base == 0 || index_base == 1), "bad arguments");
+  int32_t nc = 0;
+  for (int64_t r = 0; r < n_own; ++r) {
+    uint64_t used = 0;
+    for (int64_t p = rowptr[r] - index_base; p < rowptr[r + 1] - index_base; ++p) {
+      const int64_t j = (int64_t)colval[p] - index_base;
+      if (j < r && color[j] < 64) used |= 1ull << color[j];
+    }
+    int32_t c = 0;
+    while (c < 63 && (used >> c) & 1ull) ++c;
+    color[r] = c;
+    nc = std::max(nc, c + 1);
+  }
+  *n_colors = nc;
+  return PA_OK;
+}
+
+extern "C" int pa_rowset_create(pa_ctx *c, int64_t n, const int32_t *rows, int index_base, pa_rowset **out) {
+  PA_REQUIRE(c && out && n >= 0 && (n == 0 || rows) && (index_base == 0 || index_base == 1), "bad arguments");
+  std::vector<int32_t> h(n);
+  for (int64_t i = 0; i < n; ++i) {
+    h[i] = rows[i] - index_base;
+    PA_REQUIRE(h[i] >= 0, "negative row id at %lld", (long long)i);
+  }
+  pa_rowset *r = new pa_rowset();
+  r->ctx = c; r->n = n;
+  PA_HIP(hipSetDevice(c->device));
+  PA_TRY(upload_i32(h, &r->d_rows));
+  *out = r;
+  return PA_OK;
+}
+
+extern "C" int pa_rowset_destroy(pa_rowset *r) {
+  if (!r) return PA_OK;
+  (void)hipSetDevice(r->ctx->device);
+  (void)hipStreamSynchronize(r->ctx->s[0]);
+  (void)hipFree(r->d_rows);
+  delete r;
+  return PA_OK;
+}
+
+extern "C" int pa_gs_color_update(pa_rowset *r, pa_vec *x, const pa_vec *b, pa_vec *t, const pa_vec *diag) {
+  PA_REQUIRE(r && x && b && t && diag, "bad arguments");
+  if (r->n == 0) return PA_OK;
+  PA_HIP(hipSetDevice(r->ctx->device));
+  hipLaunchKernelGGL(k_gs_color_update, dim3((r->n + 255) / 256), dim3(256), 0, r->ctx->s[0], x->d, b->d, t->d, diag->d, r->d_rows,
+                     (int)r->n);
+  PA_HIP(hipGetLastError());
   return PA_OK;
 }
 

@@ -119,6 +119,12 @@ struct pa_gs {
   std::vector<graph_entry> graphs;
 };
 
+struct pa_rowset {
+  pa_ctx *ctx = nullptr;
+  int64_t n = 0;
+  int32_t *d_rows = nullptr;
+};
+
 struct pa_transfer {
   pa_ctx *ctx = nullptr;
   int64_t n_coarse = 0;

@@ -2,7 +2,7 @@ import sys, time
 sys.path.insert(0, '.')
 from __graft_entry__ import load_package
 pa = load_package()
-for n, ordering in ((64, "sequential"), (128, "sequential"), (128, "multicolor"), (256, "multicolor")):
+for n, ordering in ((128, "sequential"), (128, "multicolor"), (128, "multicolor_spmv"), (256, "multicolor"), (256, "multicolor_spmv")):
     ranks = pa.DebugArray([1])
     S = pa.pc_setup(ranks, 1, 4, n, n, n, ordering)
     A, b = S.A_vec[-1], S.r[-1]

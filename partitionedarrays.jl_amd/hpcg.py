@@ -84,6 +84,76 @@ class GaussSeidel:
         return x
 
 
+def _unsplit_csr(h, r, c):
+    """(own_own, own_ghost) -> the unsplit local CSR HPCG stores (n_own x n_local, ghost columns shifted by n_own)."""
+    oo, oh = h
+    n = r.n_own
+    cnt = np.diff(oo.rowptr.astype(np.int64)) + np.diff(oh.rowptr.astype(np.int64))
+    rowptr = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32)
+    rows = np.concatenate([np.repeat(np.arange(n), np.diff(oo.rowptr.astype(np.int64))),
+                           np.repeat(np.arange(n), np.diff(oh.rowptr.astype(np.int64)))])
+    cols = np.concatenate([oo.colval.astype(np.int64), oh.colval.astype(np.int64) + c.n_own])
+    vals = np.concatenate([oo.nzval, oh.nzval])
+    order = np.lexsort((cols, rows))
+    return rowptr, np.ascontiguousarray(cols[order], np.int32), np.ascontiguousarray(vals[order]), rows[order]
+
+
+class ColoredGaussSeidelSpMV:
+    """Multicolour Gauss-Seidel written as SpMV + update, the fast form of the optimised variant: every colour's rows
+    are a (row-compacted) CSR block that runs through the row-split LDS kernel, then x[row] += (b - A*x)[row] / d.
+    Same sweep as GaussSeidel(ordering="multicolor") up to rounding (the residual is summed first, then subtracted)."""
+
+    def __init__(self, A):
+        from .p_sparse_matrix import HostCSR, DeviceCSR
+        from .p_vector import DeviceVector
+        if A.host_blocks is None:
+            raise L.PAError("the Gauss-Seidel smoother needs the host blocks: build the matrix with keep_host=True")
+        self.A = A
+        self.ordering = "multicolor_spmv"
+
+        def make(h, r, c):
+            rowptr, colv, val, rows = _unsplit_csr(h, r, c)
+            n = r.n_own
+            color = np.zeros(n, np.int32)
+            ncol = C.c_int32()
+            L.call("pa_host_greedy_coloring", n, L.ptr(rowptr), L.ptr(colv), 1, L.ptr(color), C.byref(ncol))
+            diag = np.zeros(n)
+            isd = colv.astype(np.int64) - 1 == rows
+            diag[rows[isd]] = val[isd]
+            blocks = []
+            ecolor = color[rows]
+            for k in range(ncol.value):
+                sel = ecolor == k
+                cnt = np.bincount(rows[sel], minlength=n)
+                rp = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32)
+                sub = HostCSR(n, c.n_local, rp, np.ascontiguousarray(colv[sel]), np.ascontiguousarray(val[sel]))
+                rs = C.c_void_p()
+                ids = np.ascontiguousarray(np.nonzero(color == k)[0] + 1, np.int32)
+                L.call("pa_rowset_create", context().h, len(ids), L.ptr(ids), 1, C.byref(rs))
+                blocks.append((DeviceCSR(sub), rs))
+            return blocks, DeviceVector(n, 0).upload(diag), DeviceVector(n, 0)
+
+        self.parts = pmap(make, A.host_blocks, A.row_partition, A.col_partition)
+
+    def info(self):
+        return pmap(lambda p: dict(levels=len(p[0]), max_rows_per_level=0), self.parts)
+
+    def step_(self, x, b, zero_guess=False):
+        if not zero_guess:
+            consistent_(x).wait()
+
+        def sweep(p, xv, bv, order):
+            blocks, diag, t = p
+            for k in order:
+                blk, rs = blocks[k]
+                L.call("pa_spmv", blk.h, xv.h, L.SEG_LOCAL, t.h, L.SEG_OWN, 1.0, 1.0)
+                L.call("pa_gs_color_update", rs, xv.h, bv.h, t.h, diag.h)
+
+        pmap(lambda p, xv, bv: sweep(p, xv, bv, range(len(p[0]))), self.parts, x.vector_partition, b.vector_partition)
+        pmap(lambda p, xv, bv: sweep(p, xv, bv, range(len(p[0]) - 1, -1, -1)), self.parts, x.vector_partition, b.vector_partition)
+        return x
+
+
 @dataclass
 class MgPreconditioner:
     """Mg_preconditioner (HPCG/src/mg_preconditioner.jl:44-65); index 0 is the coarsest level, l-1 the finest."""
@@ -104,7 +174,7 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential"):
     for lev in range(l, 0, -1):
         A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=True, fused=True)
         As[lev - 1], rs[lev - 1] = A, b
-        gss[lev - 1] = GaussSeidel(A, ordering)
+        gss[lev - 1] = ColoredGaussSeidelSpMV(A) if ordering == "multicolor_spmv" else GaussSeidel(A, ordering)
         xs[lev - 1], Axfs[lev - 1] = pzeros(A.col_partition), pzeros(A.col_partition)
         if lev > 1:
             op = restrict_operator(nx, ny, nz)

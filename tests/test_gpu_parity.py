@@ -585,12 +585,13 @@ def test_hpcg_mg_pcg_known_answer_on_device(orc, golden):
     assert np.allclose(hist, ho, rtol=1e-9, atol=0)
 
 
-def test_multicolor_gauss_seidel_as_hpcg_optimised_variant(golden):
+@pytest.mark.parametrize("ordering", ["multicolor", "multicolor_spmv"])
+def test_multicolor_gauss_seidel_as_hpcg_optimised_variant(golden, ordering):
     """The multicolour smoother is NOT the reference's arithmetic; it is validated the way HPCG validates an optimised
     run (HPCG/src/hpcg_benchmark.jl:60-78): opt_cg! must reach the reference tolerance (here the recorded 2.877e-13 of
     the 4 x 32^3 known answer) within 10x the reference iterations, and the extra iterations are reported."""
     c = golden["hpcg_known_answer"]
-    S = pa.pc_setup(ranks(c["np"]), c["np"], c["levels"], *c["n"], ordering="multicolor")
+    S = pa.pc_setup(ranks(c["np"]), c["np"], c["levels"], *c["n"], ordering=ordering)
     assert all(i["levels"] == 8 for g in S.gs_states for i in g.info().items)        # 27-pt stencil: 8 colours
     A, b = S.A_vec[-1], S.r[-1]
     x = pa.pzeros(A.col_partition)
