@@ -162,7 +162,7 @@ def test_device_path_fails_loudly_without_gpu():
 
 
 @pytest.mark.parametrize("shape,parts", [((4, 4, 4), (2, 2, 2)), ((5, 3, 6), (2, 2, 1)), ((6, 4, 2), (2, 1, 1)),
-                                         ((4, 4, 4), (1, 1, 1)), ((2, 2, 2), (3, 2, 2)), ((64, 64, 64), (1, 2, 1))])
+                                         ((4, 4, 4), (1, 1, 1)), ((2, 2, 2), (3, 2, 2)), ((40, 36, 32), (1, 2, 1))])
 def test_fused_hpcg_setup_equals_oracle(orc, shape, parts):
     """The fused generator used for 256^3 parts writes exactly the arrays of the step-by-step chain."""
     nx, ny, nz = shape
