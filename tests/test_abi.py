@@ -35,3 +35,62 @@ def test_errors_are_statuses_not_aborts():
     assert st == -2 and b"NULL" in L.lib.pa_last_error()
     n = ctypes.c_int(-1)
     assert L.lib.pa_device_count(ctypes.byref(n)) == 0 and n.value >= 0
+
+
+# ---- the Julia glue (not runnable here: no julia in the image) is checked statically against the header ---------------
+def _prototypes():
+    txt = open(os.path.join(ROOT, "include", "pa_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"([A-Za-z_][\w \*]*?)\b(pa_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt):
+        args = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
+        protos[name] = (ret.strip(), args)
+    return protos
+
+
+def _c_class(t):
+    t = t.replace("const", " ")
+    if "*" in t or "[" in t:
+        return "ptr"
+    t = t.split()
+    t = t[0] if len(t) == 1 else " ".join(t[:-1])        # drop the parameter name
+    return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "double": "f64", "size_t": "u64"}[t]
+
+
+def _jl_class(t):
+    t = t.strip()
+    if t.startswith(("Ptr{", "Ref{")) or t == "Cstring":
+        return "ptr"
+    return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Float64": "f64", "Csize_t": "u64"}[t]
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        depth += ch in "({"
+        depth -= ch in ")}"
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return [x.strip() for x in out]
+
+
+def test_julia_glue_ccalls_match_header():
+    """Every `ccall((:pa_x, libpa), Ret, (Args...), ...)` of the glue names a declared entry point with the
+    declared number and classes (pointer / 32-bit / 64-bit / double) of arguments."""
+    protos = _prototypes()
+    src = open(os.path.join(ROOT, "partitionedarrays.jl_amd", "julia", "PartitionedArraysHIP.jl")).read()
+    src = "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
+    calls = re.findall(r"ccall\(\(:(pa_[a-z0-9_]+),\s*libpa\),\s*(\w+),\s*\(((?:[^()]|\([^()]*\))*?)\)\s*[,)]", src)
+    assert len(calls) >= 20
+    for name, ret, argt in calls:
+        assert name in protos, f"glue calls {name}, which include/pa_hip.h does not declare"
+        cret, cargs = protos[name]
+        jl = [_jl_class(t) for t in _split_top(argt.rstrip(","))] if argt.strip() else []
+        cc = [_c_class(a) for a in cargs]
+        assert jl == cc, f"{name}: glue passes {jl}, header declares {cc}"
+        assert _jl_class(ret) == _c_class(cret + " x"), f"{name}: return type"
