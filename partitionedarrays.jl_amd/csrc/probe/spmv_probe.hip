@@ -116,8 +116,26 @@ __global__ __launch_bounds__(BLK) void k_spmv_abl(
     if (ABL & 8192) {      // burst emulation: only every SL-th dispatch wave of 2048 blocks stores, SL times as much
       if (((b >> 11) % SL) == SL - 1) {
         const long o = ((long)(r0 / 64) * 64 * SL) % 16000000l;
-        for (int g = 0; g < SL; ++g) y[o + (long)g * (r1 - r0) + (r - r0)] = acc;
+        if (ABL & 65536) { for (int g = 0; g < SL; ++g) y[(o + (long)g * 500009l * 8) % 16000000l + (r - r0)] = acc; }   // same bursts in time, scattered in space
+        else for (int g = 0; g < SL; ++g) y[o + (long)g * (r1 - r0) + (r - r0)] = acc;
       }
+    }
+    else if (ABL & 32768) {   // scalar stores: the row sums leave through the scalar data cache, not the TA/TCP path
+      const unsigned lo = (unsigned)__double_as_longlong(acc), hi = (unsigned)(__double_as_longlong(acc) >> 32);
+      const int wbase = __builtin_amdgcn_readfirstlane(r - (tid & 63));
+      const int n = min(64, __builtin_amdgcn_readfirstlane(r1) - wbase);
+      double *yb = y + wbase;
+      for (int i = 0; i < n; ++i) {
+        const unsigned long long v = ((unsigned long long)__builtin_amdgcn_readlane(hi, i) << 32) | __builtin_amdgcn_readlane(lo, i);
+        double *p = yb + i;
+        asm volatile("s_store_dwordx2 %0, %1, 0x0" ::"s"(v), "s"(p) : "memory");
+        if ((i & 7) == 7) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
+    }
+    else if (ABL & 16384) {   // time-gated store: every block stores at the next multiple of SL x 10 ns
+      while ((wall_clock64() % SL) > SL / 8) __builtin_amdgcn_s_sleep(2);
+      y[r] = acc;
     }
     else if (ABL & 1024) reinterpret_cast<float *>(y)[r] = (float)acc;                 // half the bytes
     else if (ABL & 2048) unsafeAtomicAdd(&y[r], acc);                            // L2 atomic instead of a store
@@ -276,6 +294,15 @@ int main(int argc, char **argv) {
                          d_y2, dc, nch, cpx); }, bytes_spmv, {}}); }
   ADD_ABLS(256, 8, 0, 0)
   ADD_ABLS(256, 8, 2, 0)
+  ADD_ABLS(256, 8, 32768, 0)
+  ADD_ABLS(256, 8, 73728, 8)
+  ADD_ABLS(256, 8, 73728, 16)
+  ADD_ABLS(256, 8, 73728, 32)
+  ADD_ABLS(256, 8, 16384, 50)
+  ADD_ABLS(256, 8, 16384, 100)
+  ADD_ABLS(256, 8, 16384, 200)
+  ADD_ABLS(256, 8, 16384, 400)
+  ADD_ABLS(256, 8, 16384, 1600)
   ADD_ABLS(256, 8, 8192, 2)
   ADD_ABLS(256, 8, 8192, 4)
   ADD_ABLS(256, 8, 8192, 8)
@@ -293,7 +320,7 @@ int main(int argc, char **argv) {
     unsigned long long *d_bad; CK(hipMalloc(&d_bad, 8));
     V[0].run(); CK(hipDeviceSynchronize());
     for (size_t i = 1; i < V.size(); ++i) {
-      if (V[i].name.find("c16=true") == std::string::npos) continue;
+      if (V[i].name.find("c16=true") == std::string::npos && V[i].name.find("abl=32768") == std::string::npos) continue;
       CK(hipMemset(d_y2, 0xff, sizeof(double) * nrows)); CK(hipMemset(d_bad, 0, 8));
       V[i].run();
       hipLaunchKernelGGL(k_cmp, dim3((nrows + 255) / 256), dim3(256), 0, 0, d_y, d_y2, nrows, d_bad);
