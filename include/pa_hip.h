@@ -98,6 +98,25 @@ int pa_vec_dot_result(pa_ctx *ctx, void **device_scalar);
  * all-reduce over the parts after pa_comm_allreduce_sum(comm, device_scalar, 1, PA_STREAM_COMPUTE). */
 int pa_ctx_read_scalar(pa_ctx *ctx, double *host_out);
 
+/* Solver scalars that never visit the host.  The reference's CG (HPCG/src/ref_cg.jl:52-67) reads rho, u'c and
+ * |r| back on every iteration, each a blocking reduction; here a context owns PA_N_SLOTS device doubles ("slots";
+ * slot 0 is also where pa_vec_dot leaves its result) and a coefficient is written (c, num, den) = c*slot[num]/slot[den]
+ * with PA_SLOT_ONE standing for 1.0, evaluated on the device in IEEE fp64 -- the same value the host would compute.
+ * accumulate != 0 adds to the slot instead of overwriting it (the in-order sum over several parts of one process,
+ * reduction(+,...) in src/debug_array.jl); across processes all-reduce pa_ctx_slot_ptr with pa_comm_allreduce_sum. */
+#define PA_N_SLOTS 16
+#define PA_SLOT_ONE (-1)
+int pa_vec_dot_slot(const pa_vec *x, const pa_vec *y, int slot, int accumulate);
+int pa_vec_axpby_slot(pa_vec *y, double ca, int a_num, int a_den, const pa_vec *x, double cb, int b_num, int b_den,
+                      int segment);                                   /* y = (ca*s[a_num]/s[a_den])*x + (cb*...)*y */
+/* x .+= alpha .* u ; r .-= alpha .* c ; slot[rr_slot] = dot(r,r), alpha = slot[num]/slot[den]: the three
+ * statements HPCG/src/ref_cg.jl:64-67 in one pass over the own values (bit-identical to the unfused calls). */
+int pa_cg_update(pa_vec *x, pa_vec *r, const pa_vec *u, const pa_vec *c, int num, int den, int rr_slot,
+                 int accumulate);
+int pa_ctx_slot_ptr(pa_ctx *ctx, int slot, void **device_ptr);
+int pa_ctx_write_slot(pa_ctx *ctx, int slot, double value);           /* asynchronous, compute stream */
+int pa_ctx_read_slots(pa_ctx *ctx, int first, int n, double *host_out); /* synchronises the compute stream */
+
 /* ---- CSR blocks: the local matrix type (src/sparse_utils.jl:609-669; SplitMatrix blocks
  *      src/p_sparse_matrix.jl:588-627,670-681) ------------------------------------------------- */
 /* rowptr has n_rows+1 entries, colval/nzval nnz entries, columns sorted inside a row (what

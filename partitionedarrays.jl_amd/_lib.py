@@ -63,6 +63,12 @@ _SIGS = {
     "pa_vec_dot": [P, P, C.POINTER(f64)],
     "pa_vec_dot_result": [P, PP],
     "pa_ctx_read_scalar": [P, C.POINTER(f64)],
+    "pa_vec_dot_slot": [P, P, cint, cint],
+    "pa_vec_axpby_slot": [P, f64, cint, cint, P, f64, cint, cint, cint],
+    "pa_cg_update": [P, P, P, P, cint, cint, cint, cint],
+    "pa_ctx_slot_ptr": [P, cint, PP],
+    "pa_ctx_write_slot": [P, cint, f64],
+    "pa_ctx_read_slots": [P, cint, cint, C.POINTER(f64)],
     "pa_csr_create": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_create_from_csc": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_update_values": [P, P],
@@ -120,6 +126,7 @@ for _name, _args in _SIGS.items():
 SEG_OWN, SEG_GHOST, SEG_LOCAL = 0, 1, 2
 CONSISTENT, ASSEMBLE = 0, 1
 STREAM_COMPUTE, STREAM_COMM = 0, 1
+N_SLOTS, SLOT_ONE = 16, -1
 UNIQUE_ID_BYTES = 128
 
 

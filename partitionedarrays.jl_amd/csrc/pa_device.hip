@@ -157,6 +157,52 @@ __global__ __launch_bounds__(256) void k_dot_final(const double *__restrict__ pa
   if (threadIdx.x == 0) *out = t;
 }
 
+// ---- solver scalars that stay on the device (slots): coefficient = c * slot[num] / slot[den], index < 0 => 1 ----
+__device__ __forceinline__ double slot_coef(const double *__restrict__ slots, double c, int num, int den) {
+  double v = c;
+  if (num >= 0) v = v * slots[num];
+  if (den >= 0) v = v / slots[den];
+  return v;
+}
+
+__global__ void k_axpby_slot(double *__restrict__ y, const double *__restrict__ x, int64_t n,
+                             const double *__restrict__ slots, double ca, int an, int ad, double cb, int bn, int bd) {
+  const double a = slot_coef(slots, ca, an, ad), b = slot_coef(slots, cb, bn, bd);
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] = a * x[i] + b * y[i];
+}
+
+// x .+= alpha .* u ; r .-= alpha .* c ; partial sums of dot(r,r) -- the tail of a CG iteration
+// (HPCG/src/ref_cg.jl:64-67) in one pass; same per-element arithmetic and the same reduction tree as
+// k_axpby + k_axpby + k_dot_partial, so the results are bit-identical to the unfused sequence.
+__global__ __launch_bounds__(256) void k_cg_update(double *__restrict__ x, double *__restrict__ r,
+                                                   const double *__restrict__ u, const double *__restrict__ c,
+                                                   int64_t n, const double *__restrict__ slots, int num, int den,
+                                                   double *__restrict__ partial) {
+  __shared__ double sh[4];
+  const double a = slot_coef(slots, 1.0, num, den), ma = slot_coef(slots, -1.0, num, den);
+  double s = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    x[i] = a * u[i] + 1.0 * x[i];
+    const double rn = ma * c[i] + 1.0 * r[i];
+    r[i] = rn;
+    s += rn * rn;
+  }
+  const double t = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_dot_final_slot(const double *__restrict__ partial, int n, double *out,
+                                                        int accumulate) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += partial[i];
+  const double t = block_sum_256(s, sh);
+  if (threadIdx.x == 0) *out = accumulate ? *out + t : t;
+}
+
 // Gauss-Seidel, one dependency level: one lane per row of the level; the reference's per-row arithmetic
 // (PartitionedSolvers/src/smoothers.jl:144-160; zero-guess variant :236-259).
 __global__ void k_gs_level(double *__restrict__ x, const double *__restrict__ b, const int *__restrict__ rowptr,
@@ -234,8 +280,8 @@ extern "C" int pa_ctx_create(int device, pa_ctx **out) {
   snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   c->n_partials = 1024;
   PA_HIP(hipMalloc(&c->d_partials, sizeof(double) * c->n_partials));
-  PA_HIP(hipMalloc(&c->d_scalar, sizeof(double) * 8));
-  PA_HIP(hipMemset(c->d_scalar, 0, sizeof(double) * 8));
+  PA_HIP(hipMalloc(&c->d_scalar, sizeof(double) * PA_N_SLOTS));
+  PA_HIP(hipMemset(c->d_scalar, 0, sizeof(double) * PA_N_SLOTS));
   PA_HIP(hipDeviceSynchronize());  // the context's streams are non-blocking: do not race with default-stream set-up
   *out = c;
   return PA_OK;
@@ -449,6 +495,79 @@ extern "C" int pa_ctx_read_scalar(pa_ctx *c, double *host_out) {
   PA_REQUIRE(c && host_out, "bad arguments");
   PA_HIP(hipSetDevice(c->device));
   PA_HIP(hipMemcpyAsync(host_out, c->d_scalar, sizeof(double), hipMemcpyDeviceToHost, c->s[0]));
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  return PA_OK;
+}
+
+// ---- device-resident solver scalars -------------------------------------------------------------
+#define PA_SLOT_OK(s) ((s) >= 0 && (s) < PA_N_SLOTS)
+#define PA_COEF_OK(s) ((s) >= -1 && (s) < PA_N_SLOTS)
+
+extern "C" int pa_vec_dot_slot(const pa_vec *x, const pa_vec *y, int slot, int accumulate) {
+  PA_REQUIRE(x && y, "bad arguments");
+  PA_REQUIRE(x->n_own == y->n_own, "own-size mismatch (%lld vs %lld)", (long long)x->n_own, (long long)y->n_own);
+  PA_REQUIRE(PA_SLOT_OK(slot), "slot %d out of range [0,%d)", slot, PA_N_SLOTS);
+  pa_ctx *c = x->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  const int nb = grid_for(x->n_own, 256 * 8, c->n_partials);
+  hipLaunchKernelGGL(k_dot_partial, dim3(nb), dim3(256), 0, c->s[0], x->d, y->d, x->n_own, c->d_partials);
+  hipLaunchKernelGGL(k_dot_final_slot, dim3(1), dim3(256), 0, c->s[0], c->d_partials, nb, c->d_scalar + slot, accumulate);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_vec_axpby_slot(pa_vec *y, double ca, int a_num, int a_den, const pa_vec *x, double cb, int b_num,
+                                 int b_den, int seg) {
+  PA_REQUIRE(y && x, "bad arguments");
+  PA_REQUIRE(y->n_own == x->n_own && y->n_ghost == x->n_ghost, "size mismatch");
+  PA_REQUIRE(PA_COEF_OK(a_num) && PA_COEF_OK(a_den) && PA_COEF_OK(b_num) && PA_COEF_OK(b_den), "slot out of range");
+  int64_t off, len;
+  PA_TRY(seg_range(y, seg, &off, &len));
+  if (len == 0) return PA_OK;
+  PA_HIP(hipSetDevice(y->ctx->device));
+  hipLaunchKernelGGL(k_axpby_slot, dim3(grid_for(len, 256)), dim3(256), 0, y->ctx->s[0], y->d + off, x->d + off, len,
+                     y->ctx->d_scalar, ca, a_num, a_den, cb, b_num, b_den);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_cg_update(pa_vec *x, pa_vec *r, const pa_vec *u, const pa_vec *cv, int num, int den, int rr_slot,
+                            int accumulate) {
+  PA_REQUIRE(x && r && u && cv, "bad arguments");
+  PA_REQUIRE(x->n_own == r->n_own && x->n_own == u->n_own && x->n_own == cv->n_own, "own-size mismatch");
+  PA_REQUIRE(PA_COEF_OK(num) && PA_COEF_OK(den) && PA_SLOT_OK(rr_slot), "slot out of range");
+  PA_REQUIRE(rr_slot != num && rr_slot != den, "the result slot must differ from the coefficient slots");
+  pa_ctx *c = x->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  const int nb = grid_for(x->n_own, 256 * 8, c->n_partials);
+  hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, c->s[0], x->d, r->d, u->d, cv->d, x->n_own, c->d_scalar, num,
+                     den, c->d_partials);
+  hipLaunchKernelGGL(k_dot_final_slot, dim3(1), dim3(256), 0, c->s[0], c->d_partials, nb, c->d_scalar + rr_slot, accumulate);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_ctx_slot_ptr(pa_ctx *c, int slot, void **p) {
+  PA_REQUIRE(c && p, "bad arguments");
+  PA_REQUIRE(PA_SLOT_OK(slot), "slot %d out of range [0,%d)", slot, PA_N_SLOTS);
+  *p = c->d_scalar + slot;
+  return PA_OK;
+}
+
+extern "C" int pa_ctx_write_slot(pa_ctx *c, int slot, double value) {
+  PA_REQUIRE(c != nullptr, "ctx is NULL");
+  PA_REQUIRE(PA_SLOT_OK(slot), "slot %d out of range [0,%d)", slot, PA_N_SLOTS);
+  PA_HIP(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, c->s[0], c->d_scalar + slot, (int64_t)1, value);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_ctx_read_slots(pa_ctx *c, int first, int n, double *host_out) {
+  PA_REQUIRE(c && host_out, "bad arguments");
+  PA_REQUIRE(first >= 0 && n >= 1 && first + n <= PA_N_SLOTS, "slots [%d,%d) out of range", first, first + n);
+  PA_HIP(hipSetDevice(c->device));
+  PA_HIP(hipMemcpyAsync(host_out, c->d_scalar + first, sizeof(double) * n, hipMemcpyDeviceToHost, c->s[0]));
   PA_HIP(hipStreamSynchronize(c->s[0]));
   return PA_OK;
 }

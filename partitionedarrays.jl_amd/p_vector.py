@@ -464,6 +464,70 @@ def axpby_(y: PVector, alpha, x: PVector, beta) -> PVector:
     return y
 
 
+# ---- solver scalars that stay on the device (include/pa_hip.h "slots") ---------------------------------------------
+def slots_supported(a: PVector) -> bool:
+    """Device-resident scalars need every part's context reachable without a host round trip: all parts in this
+    process (DebugArray), or one part per process with an RCCL communicator (or a single process)."""
+    vp = a.vector_partition
+    if isinstance(vp, DebugArray):
+        return True
+    if isinstance(vp, TorchDistArray):
+        import torch.distributed as dist
+        return dist.get_world_size(vp.group) == 1 or (TRANSPORT == "rccl" and context().comm is not None)
+    return False
+
+
+def _slot_allreduce(vp, slot):
+    import torch.distributed as dist
+    if dist.get_world_size(vp.group) > 1:
+        ctx = context()
+        ptr = C.c_void_p()
+        L.call("pa_ctx_slot_ptr", ctx.h, slot, C.byref(ptr))
+        ctx.comm.allreduce_sum(ptr, 1, L.STREAM_COMPUTE)
+
+
+def dot_slot(a: PVector, b: PVector, slot: int) -> None:
+    """slot <- dot(a,b) without a host read-back: per-part dots accumulate in part order (DebugArray) or are
+    all-reduced by RCCL on the compute stream (one part per process)."""
+    vp, vq = a.vector_partition, b.vector_partition
+    if isinstance(vp, TorchDistArray):
+        L.call("pa_vec_dot_slot", vp.item.h, vq.item.h, slot, 0)
+        _slot_allreduce(vp, slot)
+    else:
+        for k, (x, y) in enumerate(zip(vp.items, vq.items)):
+            L.call("pa_vec_dot_slot", x.h, y.h, slot, int(k > 0))
+
+
+def axpby_slot_(y: PVector, ca, a_num, a_den, x: PVector, cb, b_num, b_den) -> PVector:
+    """y .= (ca*s[a_num]/s[a_den]) .* x .+ (cb*s[b_num]/s[b_den]) .* y with the scalars read on the device."""
+    pmap(lambda yv, xv: L.call("pa_vec_axpby_slot", yv.h, float(ca), a_num, a_den, xv.h, float(cb), b_num, b_den,
+                               L.SEG_OWN), y.vector_partition, x.vector_partition)
+    return y
+
+
+def cg_update_(x: PVector, r: PVector, u: PVector, c: PVector, num: int, den: int, rr_slot: int) -> None:
+    """x .+= alpha .* u; r .-= alpha .* c; slot[rr_slot] = dot(r,r) with alpha = s[num]/s[den] (ref_cg.jl:64-67)."""
+    vx = x.vector_partition
+    if isinstance(vx, TorchDistArray):
+        L.call("pa_cg_update", vx.item.h, r.vector_partition.item.h, u.vector_partition.item.h,
+               c.vector_partition.item.h, num, den, rr_slot, 0)
+        _slot_allreduce(vx, rr_slot)
+    else:
+        for k, (a, b, d, e) in enumerate(zip(vx.items, r.vector_partition.items, u.vector_partition.items,
+                                             c.vector_partition.items)):
+            L.call("pa_cg_update", a.h, b.h, d.h, e.h, num, den, rr_slot, int(k > 0))
+
+
+def write_slot(slot: int, value: float) -> None:
+    L.call("pa_ctx_write_slot", context().h, slot, float(value))
+
+
+def read_slots(first: int, n: int = 1):
+    out = (C.c_double * n)()
+    L.call("pa_ctx_read_slots", context().h, first, n, out)
+    return list(out)
+
+
 def copy_(dst: PVector, src: PVector) -> PVector:
     pmap(lambda d, s: L.call("pa_vec_copy", d.h, s.h, L.SEG_LOCAL), dst.vector_partition, src.vector_partition)
     return dst

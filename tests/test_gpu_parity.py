@@ -338,6 +338,59 @@ def test_ref_cg_identity_preconditioner(orc):
             assert np.allclose(vals, 1.0, atol=1e-8)
 
 
+@pytest.mark.parametrize("P,np3,with_mg", [(1, (1, 1, 1), False), (8, (2, 2, 2), False), (4, (2, 2, 1), True)])
+def test_opt_cg_device_scalars_bit_identical_to_ref_cg(P, np3, with_mg):
+    """opt_cg_ keeps rho, u'c and |r|^2 in device slots and fuses ref_cg.jl:64-67 into one pass; the arithmetic and
+    the reduction trees are those of ref_cg_, so residual history and solution must be bit-identical."""
+    n = (16, 16, 16)
+    if with_mg:
+        S = pa.pc_setup(ranks(P), P, 3, *n, ordering="multicolor_spmv")
+        A, b = S.A_vec[-1], S.r[-1]
+    else:
+        S = None
+        A, b = pa.build_p_matrix(ranks(P), *n, *(a * q for a, q in zip(n, np3)), *np3)
+    out = []
+    for fn in (pa.ref_cg_, pa.opt_cg_):
+        x = pa.pzeros(A.col_partition)
+        hist = []
+        x, r0, r, it = fn(x, A, b, maxiter=12, history=hist, Pl=S)
+        out.append((r0, r, it, hist, [v.copy() for v in x.own_values().items]))
+    (r0a, ra, ita, ha, xa), (r0b, rb, itb, hb, xb) = out
+    assert (r0a, ra, ita) == (r0b, rb, itb) and ha == hb
+    for u, v in zip(xa, xb):
+        assert np.array_equal(u, v)
+    # without a history the host reads nothing inside the loop; the end state is the same
+    x = pa.pzeros(A.col_partition)
+    x, r0, r, it = pa.opt_cg_(x, A, b, maxiter=12, Pl=S)
+    assert (r0, r, it) == (r0a, ra, ita)
+    # tolerance > 0: stops at the same iteration as the reference loop
+    xa_, r0a_, ra_, ita_ = pa.ref_cg_(pa.pzeros(A.col_partition), A, b, maxiter=200, tolerance=1e-6, Pl=S)
+    xb_, r0b_, rb_, itb_ = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=200, tolerance=1e-6, Pl=S)
+    assert (ita_, ra_) == (itb_, rb_) and ita_ < 200
+
+
+def test_slot_api_errors_and_values():
+    ctx = pa.context()
+    pa.write_slot(5, 2.5)
+    pa.write_slot(6, -4.0)
+    assert pa.read_slots(5, 2) == [2.5, -4.0]
+    g = pa.uniform_partition(ranks(1), (1,), (1000,))
+    x = pa.pvector_from_function(lambda i: np.arange(1, i.n_local + 1, dtype=np.float64), g)
+    y = pa.pones(g)
+    pa.dot_slot(x, y, 7)
+    assert pa.read_slots(7)[0] == 500500.0
+    pa.axpby_slot_(y, 1.0, 5, 6, x, -2.0, pa._lib.SLOT_ONE, 5)            # y = (2.5/-4) x + (-2/2.5) y
+    want = (2.5 / -4.0) * np.arange(1, 1001) + (-2.0 / 2.5) * 1.0
+    assert np.array_equal(y.own_values().items[0], want)
+    with pytest.raises(pa._lib.PAError):
+        pa.write_slot(16, 1.0)
+    with pytest.raises(pa._lib.PAError):
+        pa.dot_slot(x, y, -1)
+    with pytest.raises(pa._lib.PAError):
+        pa._lib.call("pa_cg_update", x.vector_partition.items[0].h, y.vector_partition.items[0].h,
+                     x.vector_partition.items[0].h, y.vector_partition.items[0].h, 1, 2, 1, 0)
+
+
 # ---------------------------------------------------------------- BASELINE config 5 (FEM, ghost-heavy, irregular rows)
 @pytest.mark.parametrize("nodes,parts", [((63, 47), (4, 2)), ((11, 9, 10), (2, 2, 2))])
 def test_config5_fem_disassembled_assemble_mul(orc, nodes, parts):
