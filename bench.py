@@ -31,6 +31,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--grid", dest="n", type=int, default=256, help="grid points per direction per part")
+    ap.add_argument("--cg-iters", type=int, default=int(os.environ.get("PA_BENCH_CG", "20")),
+                    help="iterations of the CG loop timed after the headline measurement (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -222,6 +224,29 @@ def main():
     except Exception:
         pass
 
+    # ---- BASELINE config 4's loop, reported beside the headline (never part of `value`): one CG iteration of
+    # HPCG/src/ref_cg.jl (consistent!+mul!, 2 dots + norm, 3 axpys; Identity preconditioner), as the reference
+    # schedules it (ref_cg_: a blocking reduction per dot) and as opt_cg_ does (scalars stay on the device).
+    cg = None
+    if args.cg_iters > 0:
+        def cg_time(fn, k):
+            xx = pa.pzeros(A.col_partition)
+            barrier()
+            t = time.perf_counter()
+            fn(xx, A, b, maxiter=k)
+            ctx.sync()
+            barrier()
+            return time.perf_counter() - t
+        cg = {}
+        for name, fn in (("ref_cg", pa.ref_cg_), ("opt_cg", pa.opt_cg_)):
+            cg_time(fn, 2)
+            d = cg_time(fn, 4 + args.cg_iters) - cg_time(fn, 4)     # the difference cancels allocation + first residual
+            if N > 1:
+                tt = torch.tensor([d], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                d = float(tt.item())
+            cg[name] = d / args.cg_iters * 1e3
+
     if rank == 0:
         out = {
             "metric": "HPCG 27-pt SpMV GFLOP/s + achieved HBM GB/s per GPU",
@@ -242,6 +267,16 @@ def main():
             "parity_gate": "A*1==b bit-exact; ghosts==owners bit-exact",
             "setup_s": round(t_setup, 1),
         }
+        if cg:
+            n_rows_total = n_own * N
+            cg_flops = 2.0 * nnz_total + 12.0 * n_rows_total      # SpMV + 3 dots + 3 axpys (HPCG/src/report_results.jl)
+            out["cg_loop"] = {"what": "one CG iteration of HPCG ref_cg.jl on the same matrix (BASELINE config 4 loop, "
+                                      "Identity preconditioner): consistent!+mul!, 2 dots + norm, 3 axpys",
+                              "iterations_timed": args.cg_iters,
+                              "ms_per_iteration_ref_cg": round(cg["ref_cg"], 4),
+                              "ms_per_iteration_opt_cg": round(cg["opt_cg"], 4),
+                              "gflops_opt_cg": round(cg_flops / (cg["opt_cg"] * 1e-3) / 1e9, 1),
+                              "note": "opt_cg_ = same arithmetic (bit-identical iterates), scalars kept on the device"}
         if N == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.cpu_n)
             if cb:

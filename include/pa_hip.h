@@ -219,6 +219,14 @@ typedef struct pa_rowset pa_rowset;
 int pa_rowset_create(pa_ctx *ctx, int64_t n, const int32_t *rows, int index_base, pa_rowset **rs);
 int pa_rowset_destroy(pa_rowset *rs);
 int pa_gs_color_update(pa_rowset *rs, pa_vec *x, const pa_vec *b, pa_vec *t, const pa_vec *diag);
+/* The same sweep with the update fused into the SpMV kernel's epilogue and all colours queued by one call:
+ * blocks[k] holds every stored entry of colour k's own rows (n_own x n_local, e.g. from pa_csr_create on the rows of
+ * that colour; empty rows are compacted away); for k ascending (backward != 0: descending)
+ *   x[row] = x[row] + (b[row] - sum_p val[p]*x[col[p]]) / diag[row]      for the rows of colour k, in place.
+ * Bit-identical to pa_spmv(beta = 1) into a zeroed t followed by pa_gs_color_update; a proper colouring (no stored
+ * entry couples two rows of one colour, pa_host_greedy_coloring) makes the in-place update race-free. */
+int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_vec *b, const pa_vec *diag,
+                      int backward);
 /* restrict! / prolongate! (HPCG/src/mg_preconditioner.jl:224-251): f2c[i] = fine row of coarse row i.
  *   restrict  : r_c[i] = r_f[f2c[i]] - Axf[f2c[i]]          prolongate: x_f[f2c[i]] += x_c[i] */
 typedef struct pa_transfer pa_transfer;
@@ -226,6 +234,11 @@ int pa_transfer_create(pa_ctx *ctx, int64_t n_coarse, const int32_t *f2c, int in
 int pa_transfer_destroy(pa_transfer *t);
 int pa_transfer_restrict(pa_transfer *t, pa_vec *r_c, const pa_vec *r_f, const pa_vec *Axf);
 int pa_transfer_prolongate(pa_transfer *t, pa_vec *x_f, const pa_vec *x_c);
+/* Fused residual + restriction: r_c[i] = r_f[f2c[i]] - (A x_f)[f2c[i]] without forming A x_f on the other fine rows.
+ * `rows` is a block (n_own x n_local, pa_csr_create) holding the stored entries of exactly the fine rows f2c -- attach
+ * checks that -- and must outlive the transfer's use of it.  Same row sums as pa_spmv + pa_transfer_restrict. */
+int pa_transfer_attach_rows(pa_transfer *t, const pa_csr *rows);
+int pa_transfer_restrict_fused(pa_transfer *t, pa_vec *r_c, const pa_vec *r_f, const pa_vec *x_f);
 
 /* ---- RCCL communicator (MPI.Init / Comm_dup analogue, src/mpi_array.jl:42-53) ---------------- */
 #define PA_UNIQUE_ID_BYTES 128

@@ -82,8 +82,11 @@ _SIGS = {
     "pa_rowset_create": [P, i64, P, cint, PP],
     "pa_rowset_destroy": [P],
     "pa_gs_color_update": [P, P, P, P, P],
+    "pa_gs_color_sweep": [P, cint, P, P, P, cint],
     "pa_transfer_create": [P, i64, P, cint, PP],
     "pa_transfer_destroy": [P],
+    "pa_transfer_attach_rows": [P, P],
+    "pa_transfer_restrict_fused": [P, P, P, P],
     "pa_transfer_restrict": [P, P, P, P],
     "pa_transfer_prolongate": [P, P, P],
     "pa_scatter_create": [P, i64, i64, P, cint, PP],

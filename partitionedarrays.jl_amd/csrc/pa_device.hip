@@ -846,14 +846,50 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
   if (A->n_chunks > 0) {
     const int cpx = (int)((A->n_chunks + 7) / 8);
 #define PA_LAUNCH_SPMV(C16, PAT)                                                                                     \
-  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT>), dim3(cpx * 8), dim3(SPMV_BLK), 0, c->s[0], \
-                     A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val, x->d + xoff,       \
-                     y->d + yoff, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta)
+  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
+                     c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
+                     x->d + xoff, y->d + yoff, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta,    \
+                     (double *)nullptr, (const double *)nullptr, (const double *)nullptr)
     if (A->use_pattern && A->use_c16) PA_LAUNCH_SPMV(true, true);
     else if (A->use_pattern) PA_LAUNCH_SPMV(false, true);
     else if (A->use_c16) PA_LAUNCH_SPMV(true, false);
     else PA_LAUNCH_SPMV(false, false);
 #undef PA_LAUNCH_SPMV
+  }
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+// One multicolour Gauss-Seidel sweep written as SpMV with a fused update: colour k's rows are the (row-compacted)
+// block blocks[k] (n_own x n_local, every stored entry of those rows); its launch gathers from x and updates x's own
+// rows of that colour in place, x[row] += (b[row] - (A x)[row]) / diag[row].  Colours run in ascending order
+// (backward != 0: descending), one launch each on the compute stream.
+extern "C" int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_vec *b, const pa_vec *diag,
+                                 int backward) {
+  PA_REQUIRE(blocks && x && b && diag && n_colors >= 0, "bad arguments");
+  pa_ctx *c = x->ctx;
+  for (int k = 0; k < n_colors; ++k) {
+    const pa_csr *A = blocks[k];
+    PA_REQUIRE(A != nullptr, "colour block %d is NULL", k);
+    PA_REQUIRE(A->n_rows == x->n_own && A->n_cols == x->n_own + x->n_ghost, "colour block %d is %lld x %lld, x has %lld own + %lld ghost",
+               k, (long long)A->n_rows, (long long)A->n_cols, (long long)x->n_own, (long long)x->n_ghost);
+  }
+  PA_REQUIRE(b->n_own == x->n_own && diag->n_own == x->n_own, "b / diag own sizes differ from x");
+  PA_HIP(hipSetDevice(c->device));
+  for (int i = 0; i < n_colors; ++i) {
+    const pa_csr *A = blocks[backward ? n_colors - 1 - i : i];
+    if (A->n_chunks == 0) continue;
+    const int cpx = (int)((A->n_chunks + 7) / 8);
+#define PA_LAUNCH_GS(C16, PAT)                                                                                       \
+  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 1>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
+                     c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
+                     (const double *)nullptr, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, \
+                     1.0, 0.0, x->d, (const double *)b->d, (const double *)diag->d)
+    if (A->use_pattern && A->use_c16) PA_LAUNCH_GS(true, true);
+    else if (A->use_pattern) PA_LAUNCH_GS(false, true);
+    else if (A->use_c16) PA_LAUNCH_GS(true, false);
+    else PA_LAUNCH_GS(false, false);
+#undef PA_LAUNCH_GS
   }
   PA_HIP(hipGetLastError());
   return PA_OK;
@@ -1078,6 +1114,50 @@ extern "C" int pa_transfer_restrict(pa_transfer *t, pa_vec *rc, const pa_vec *rf
   PA_HIP(hipSetDevice(t->ctx->device));
   hipLaunchKernelGGL(k_restrict, dim3((t->n_coarse + 255) / 256), dim3(256), 0, t->ctx->s[0], rc->d, rf->d, axf->d, t->d_f2c,
                      (int)t->n_coarse);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+// Fused residual + restriction (the reference computes Axf = A*x on every fine row and then keeps one row in eight,
+// HPCG/src/mg_preconditioner.jl:320-321,224-237): `rows` holds the stored entries of the fine rows f2c only, and the
+// row-split kernel's epilogue writes r_c[i] = r_f[f2c[i]] - (A x_f)[f2c[i]] -- the same row sums, one eighth of the work.
+extern "C" int pa_transfer_attach_rows(pa_transfer *t, const pa_csr *rows) {
+  PA_REQUIRE(t && rows, "bad arguments");
+  PA_REQUIRE(rows->ctx == t->ctx, "transfer and block live in different contexts");
+  PA_REQUIRE(rows->compact && rows->n_crows == t->n_coarse,
+             "the block must store exactly the %lld fine rows of the coarse grid (it stores %lld%s)", (long long)t->n_coarse,
+             (long long)rows->n_crows, rows->compact ? "" : ", not compacted");
+  PA_HIP(hipSetDevice(t->ctx->device));
+  std::vector<int32_t> a(t->n_coarse), b(t->n_coarse);
+  PA_HIP(hipMemcpy(a.data(), t->d_f2c, sizeof(int32_t) * t->n_coarse, hipMemcpyDeviceToHost));
+  PA_HIP(hipMemcpy(b.data(), rows->d_row_ids, sizeof(int32_t) * t->n_coarse, hipMemcpyDeviceToHost));
+  for (int64_t i = 0; i < t->n_coarse; ++i)
+    PA_REQUIRE(a[i] == b[i], "stored row %lld of the block is fine row %d, the transfer expects %d", (long long)i, b[i], a[i]);
+  t->rows = rows;
+  return PA_OK;
+}
+
+extern "C" int pa_transfer_restrict_fused(pa_transfer *t, pa_vec *rc, const pa_vec *rf, const pa_vec *xf) {
+  PA_REQUIRE(t && rc && rf && xf, "bad arguments");
+  PA_REQUIRE(t->rows != nullptr, "no row block attached (pa_transfer_attach_rows)");
+  const pa_csr *A = t->rows;
+  PA_REQUIRE(rc->n_own + rc->n_ghost >= t->n_coarse, "coarse vector too short");
+  PA_REQUIRE(rf->n_own == A->n_rows && xf->n_own + xf->n_ghost == A->n_cols, "fine vector sizes do not match the block");
+  PA_REQUIRE(rc->d != xf->d && rc->d != rf->d, "r_c aliases a fine vector");
+  if (A->n_chunks == 0) return PA_OK;
+  pa_ctx *c = t->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  const int cpx = (int)((A->n_chunks + 7) / 8);
+#define PA_LAUNCH_RR(C16, PAT)                                                                                       \
+  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 2>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
+                     c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
+                     (const double *)xf->d, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx,  \
+                     1.0, 0.0, rc->d, (const double *)rf->d, (const double *)nullptr)
+  if (A->use_pattern && A->use_c16) PA_LAUNCH_RR(true, true);
+  else if (A->use_pattern) PA_LAUNCH_RR(false, true);
+  else if (A->use_c16) PA_LAUNCH_RR(true, false);
+  else PA_LAUNCH_RR(false, false);
+#undef PA_LAUNCH_RR
   PA_HIP(hipGetLastError());
   return PA_OK;
 }

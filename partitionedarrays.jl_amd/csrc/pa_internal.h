@@ -129,6 +129,7 @@ struct pa_transfer {
   pa_ctx *ctx = nullptr;
   int64_t n_coarse = 0;
   int32_t *d_f2c = nullptr;  // 0-based fine row of every coarse row
+  const pa_csr *rows = nullptr;  // optional: the stored entries of exactly those fine rows (fused residual + restrict)
 };
 
 int pa_plan_mark_arrived(pa_plan *p);

@@ -64,14 +64,22 @@ __device__ __forceinline__ int pa_pattern_col(int q, int nq, int q1, int q2, int
 //   BLK  threads per workgroup, NPT stored entries per lane (chunk capacity CAP = BLK*NPT products in LDS),
 //   NT   non-temporal matrix loads, C16 use the 16-bit column stream where the chunk has one,
 //   PAT  use row-pattern descriptors where the chunk has one (pdesc/pdelta may be NULL when PAT is false).
-template <int BLK, int NPT, bool NT, bool C16, bool PAT>
+//   EPI  0: y[row] = beta*y[row] + sum (x, y distinct).
+//        1: Gauss-Seidel colour update in place, gs_x[row] += (gs_b[row] - sum) / gs_diag[row] with the products
+//           gathered from gs_x itself (x, y unused).  Race-free when the block's rows form one colour of a proper
+//           colouring: no row of the launch reads another row of the launch, only itself.
+//        2: fused residual + restriction, gs_x[r] = gs_b[row] - sum for the r-th stored (compacted) row: the coarse
+//           residual r_c = (r_f - A x_f) at the fine rows a coarse grid keeps (gs_x = r_c, gs_b = r_f, x_in = x_f).
+template <int BLK, int NPT, bool NT, bool C16, bool PAT, int EPI = 0>
 __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
-    const double *__restrict__ val, const double *__restrict__ x,
+    const double *__restrict__ val, const double *__restrict__ x_in,
     double *__restrict__ y, const int *__restrict__ chunk_row, const int *__restrict__ row_ids, int n_chunks,
-    int chunks_per_xcd, double alpha, double beta) {
+    int chunks_per_xcd, double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
+    const double *__restrict__ gs_diag) {
   constexpr int CAP = BLK * NPT;
+  const double *x = EPI == 1 ? gs_x : x_in;   // EPI 1 reads and writes the same vector: no restrict promise on it
   static_assert(NPT % 2 == 0, "pairs");
   __shared__ __attribute__((aligned(16))) double prod[CAP];
   const int tid = threadIdx.x;
@@ -166,18 +174,20 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         re = crp[r + 1];
       }
       const int row = row_ids ? row_ids[r] : r;
-      double acc = (beta == 0.0) ? 0.0 : beta * y[row];
+      double acc = (EPI != 0 || beta == 0.0) ? 0.0 : beta * y[row];
       const int a = ra - base, e = re - base;
 #pragma unroll 4
       for (int p = a; p < e; ++p) acc = acc + prod[p];
-      y[row] = acc;
+      if (EPI == 1) gs_x[row] = gs_x[row] + (gs_b[row] - acc) / gs_diag[row];
+      else if (EPI == 2) gs_x[r] = gs_b[row] - acc;
+      else y[row] = acc;
     }
   } else {
     // one long row (more stored entries than a chunk holds): windows of CAP products, summed by
     // lane 0 in ascending p so that even this path keeps the reference's order.
     const int row = row_ids ? row_ids[r0] : r0;
     double acc = 0.0;
-    if (tid == 0) acc = (beta == 0.0) ? 0.0 : beta * y[row];
+    if (tid == 0) acc = (EPI != 0 || beta == 0.0) ? 0.0 : beta * y[row];
     for (int w = p0; w < p1; w += CAP) {
       const int wend = min(w + CAP, p1);
       for (int idx = w + tid; idx < wend; idx += BLK) {
@@ -190,7 +200,11 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         for (int p = 0; p < wend - w; ++p) acc = acc + prod[p];
       __syncthreads();
     }
-    if (tid == 0) y[row] = acc;
+    if (tid == 0) {
+      if (EPI == 1) gs_x[row] = gs_x[row] + (gs_b[row] - acc) / gs_diag[row];
+      else if (EPI == 2) gs_x[r0] = gs_b[row] - acc;
+      else y[row] = acc;
+    }
   }
 }
 

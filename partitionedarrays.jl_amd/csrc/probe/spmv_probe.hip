@@ -230,7 +230,7 @@ int main(int argc, char **argv) {
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"spmv<" #BLK "," #NPT "," #NT ",c16=" #C16 ">", [=]() {                                        \
       hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, C16, false>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d16, dwin, \
-                         (const int *)nullptr, (const int *)nullptr, d_val, d_x, (C16 ? d_y2 : d_y), dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
+                         (const int *)nullptr, (const int *)nullptr, d_val, d_x, (C16 ? d_y2 : d_y), dc, (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_SPMV4(256, 4, true, false)
   ADD_SPMV4(256, 6, true, true)
   ADD_SPMV4(256, 6, true, false)
@@ -257,7 +257,7 @@ int main(int argc, char **argv) {
 #define ADD_ATTR(NAME, VALP, C16P, YP, NT)                                                                   \
     V.push_back({NAME, [=]() {                                                                                 \
       hipLaunchKernelGGL((k_spmv_rowsplit<256, 6, NT, true, false>), dim3(cpx * 8), dim3(256), 0, 0, d_rp, d_col, C16P, dwin, \
-                         (const int *)nullptr, (const int *)nullptr, VALP, d_x, YP, dc, (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}});
+                         (const int *)nullptr, (const int *)nullptr, VALP, d_x, YP, dc, (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}});
     ADD_ATTR("c16 base (cached all, nt)", d_val, d16, d_y2, true)
     ADD_ATTR("c16 matrix uncached, nt", uval, u16, d_y2, true)
     ADD_ATTR("c16 matrix uncached, plain", uval, u16, d_y2, false)
@@ -279,7 +279,7 @@ int main(int argc, char **argv) {
     V.push_back({"pattern<" #BLK "," #NPT ",nt=" #NT ">c16=true", [=]() {                                                  \
       hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, false, true>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, \
                          (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
-                         (const int *)nullptr, nch, cpx, 1.0, 0.0); }, bytes_spmv, {}}); }
+                         (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_PAT(256, 8, true)
   ADD_PAT(256, 8, false)
   ADD_PAT(256, 12, true)

@@ -99,9 +99,39 @@ def _unsplit_csr(h, r, c):
     return rowptr, np.ascontiguousarray(cols[order], np.int32), np.ascontiguousarray(vals[order]), rows[order]
 
 
+def _rows_block(h, r, c, f):
+    """The stored entries of the own rows `f` (0-based, ascending) of one part as an n_own x n_local block in the
+    unsplit column order (own columns, then ghost columns shifted by n_own); every other row is empty."""
+    from .p_sparse_matrix import HostCSR
+    oo, oh = h
+    n = r.n_own
+
+    def take(blk):
+        rp = blk.rowptr.astype(np.int64) - 1
+        cnt = rp[f + 1] - rp[f]
+        first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
+        return cnt, first, np.repeat(rp[f] - first, cnt) + np.arange(int(cnt.sum()))
+
+    c1, f1, i1 = take(oo)
+    c2, f2, i2 = take(oh)
+    cnt = c1 + c2
+    start = np.concatenate([[0], np.cumsum(cnt)])
+    colv = np.empty(int(start[-1]), np.int32)
+    val = np.empty(int(start[-1]))
+    p1 = np.repeat(start[:-1] - f1, c1) + np.arange(int(c1.sum()))
+    p2 = np.repeat(start[:-1] + c1 - f2, c2) + np.arange(int(c2.sum()))
+    colv[p1], val[p1] = oo.colval[i1], oo.nzval[i1]
+    colv[p2], val[p2] = oh.colval[i2] + c.n_own, oh.nzval[i2]
+    full = np.zeros(n, np.int64)
+    full[f] = cnt
+    rp = np.concatenate([[1], 1 + np.cumsum(full)]).astype(np.int32)
+    return HostCSR(n, c.n_local, rp, colv, val)
+
+
 class ColoredGaussSeidelSpMV:
     """Multicolour Gauss-Seidel written as SpMV + update, the fast form of the optimised variant: every colour's rows
-    are a (row-compacted) CSR block that runs through the row-split LDS kernel, then x[row] += (b - A*x)[row] / d.
+    are a (row-compacted) CSR block that runs through the row-split LDS kernel, whose epilogue does
+    x[row] += (b - A*x)[row] / d in place (pa_gs_color_sweep: the 8 colour launches of a sweep are one call).
     Same sweep as GaussSeidel(ordering="multicolor") up to rounding (the residual is summed first, then subtracted)."""
 
     def __init__(self, A):
@@ -128,11 +158,9 @@ class ColoredGaussSeidelSpMV:
                 cnt = np.bincount(rows[sel], minlength=n)
                 rp = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32)
                 sub = HostCSR(n, c.n_local, rp, np.ascontiguousarray(colv[sel]), np.ascontiguousarray(val[sel]))
-                rs = C.c_void_p()
-                ids = np.ascontiguousarray(np.nonzero(color == k)[0] + 1, np.int32)
-                L.call("pa_rowset_create", context().h, len(ids), L.ptr(ids), 1, C.byref(rs))
-                blocks.append((DeviceCSR(sub), rs))
-            return blocks, DeviceVector(n, 0).upload(diag), DeviceVector(n, 0)
+                blocks.append(DeviceCSR(sub))
+            handles = (C.c_void_p * len(blocks))(*[blk.h for blk in blocks])
+            return blocks, DeviceVector(n, 0).upload(diag), handles, color
 
         self.parts = pmap(make, A.host_blocks, A.row_partition, A.col_partition)
 
@@ -142,16 +170,9 @@ class ColoredGaussSeidelSpMV:
     def step_(self, x, b, zero_guess=False):
         if not zero_guess:
             consistent_(x).wait()
-
-        def sweep(p, xv, bv, order):
-            blocks, diag, t = p
-            for k in order:
-                blk, rs = blocks[k]
-                L.call("pa_spmv", blk.h, xv.h, L.SEG_LOCAL, t.h, L.SEG_OWN, 1.0, 1.0)
-                L.call("pa_gs_color_update", rs, xv.h, bv.h, t.h, diag.h)
-
-        pmap(lambda p, xv, bv: sweep(p, xv, bv, range(len(p[0]))), self.parts, x.vector_partition, b.vector_partition)
-        pmap(lambda p, xv, bv: sweep(p, xv, bv, range(len(p[0]) - 1, -1, -1)), self.parts, x.vector_partition, b.vector_partition)
+        for backward in (0, 1):        # forward then backward sweep; one call queues the 8 colour launches
+            pmap(lambda p, xv, bv: L.call("pa_gs_color_sweep", p[2], len(p[0]), xv.h, bv.h, p[1].h, backward),
+                 self.parts, x.vector_partition, b.vector_partition)
         return x
 
 
@@ -165,10 +186,16 @@ class MgPreconditioner:
     x: list
     Axf: list
     l: int
+    row_blocks: list = None   # per coarse level: the fine rows the coarse grid keeps, as blocks (fused restriction)
 
 
-def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential"):
-    """pc_setup(np,ranks,l,nx,ny,nz) (HPCG/src/mg_preconditioner.jl:142-187).  ordering: see GaussSeidel."""
+def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=None):
+    """pc_setup(np,ranks,l,nx,ny,nz) (HPCG/src/mg_preconditioner.jl:142-187).  ordering: see GaussSeidel.
+    fuse_restriction (default: on for the multicolour orderings): the residual A*x is formed only on the fine rows the
+    coarse grid keeps (pa_transfer_restrict_fused) -- the same row sums, so r_c is bit-identical."""
+    if fuse_restriction is None:
+        fuse_restriction = ordering != "sequential"
+    rbs = [None] * (l - 1)
     from .gallery import build_p_matrix, compute_optimal_shape_XYZ
     npx, npy, npz = compute_optimal_shape_XYZ(np_)
     f2c, As, gss, rs, xs, Axfs = [None] * (l - 1), [None] * l, [None] * l, [None] * l, [None] * l, [None] * l
@@ -185,8 +212,14 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential"):
                 L.call("pa_transfer_create", context().h, len(op), L.ptr(op), 1, C.byref(t))
                 return t
             f2c[lev - 2] = pmap(mk, A.row_partition)
+            if fuse_restriction:
+                from .p_sparse_matrix import DeviceCSR
+                blk = pmap(lambda hb, r, c: DeviceCSR(_rows_block(hb, r, c, op.astype(np.int64) - 1)),
+                           A.host_blocks, A.row_partition, A.col_partition)
+                pmap(lambda t, bk: L.call("pa_transfer_attach_rows", t, bk.h), f2c[lev - 2], blk)
+                rbs[lev - 2] = blk
             nx, ny, nz = nx // 2, ny // 2, nz // 2
-    return MgPreconditioner(f2c, As, gss, rs, xs, Axfs, l)
+    return MgPreconditioner(f2c, As, gss, rs, xs, Axfs, l, rbs)
 
 
 def pc_solve_(x, s: MgPreconditioner, b, l, zero_guess=False):
@@ -196,10 +229,15 @@ def pc_solve_(x, s: MgPreconditioner, b, l, zero_guess=False):
         gs.step_(x, b, zero_guess)
         return x
     gs.step_(x, b, zero_guess)                                            # presmoother
-    mul_no_lat_(s.Axf[l - 1], A, x)
     t = s.f2c[l - 2]
-    pmap(lambda th, rc, rf, ax: L.call("pa_transfer_restrict", th, rc.h, rf.h, ax.h),
-         t, s.r[l - 2].vector_partition, b.vector_partition, s.Axf[l - 1].vector_partition)
+    if s.row_blocks is not None and s.row_blocks[l - 2] is not None:
+        consistent_(x).wait()
+        pmap(lambda th, rc, rf, xf: L.call("pa_transfer_restrict_fused", th, rc.h, rf.h, xf.h),
+             t, s.r[l - 2].vector_partition, b.vector_partition, x.vector_partition)
+    else:
+        mul_no_lat_(s.Axf[l - 1], A, x)
+        pmap(lambda th, rc, rf, ax: L.call("pa_transfer_restrict", th, rc.h, rf.h, ax.h),
+             t, s.r[l - 2].vector_partition, b.vector_partition, s.Axf[l - 1].vector_partition)
     pmap(lambda v: v.fill(0.0), s.x[l - 2].vector_partition)
     pc_solve_(s.x[l - 2], s, s.r[l - 2], l - 1, zero_guess=True)
     pmap(lambda th, xf, xc: L.call("pa_transfer_prolongate", th, xf.h, xc.h), t, x.vector_partition, s.x[l - 2].vector_partition)

@@ -638,6 +638,55 @@ def test_hpcg_mg_pcg_known_answer_on_device(orc, golden):
     assert np.allclose(hist, ho, rtol=1e-9, atol=0)
 
 
+def test_fused_colour_sweep_equals_spmv_plus_update():
+    """pa_gs_color_sweep (update fused into the row-split kernel's epilogue) == pa_spmv(beta=1) into a zeroed t followed
+    by pa_gs_color_update, colour by colour, bit for bit; 2 parts so that ghost columns take part."""
+    import pa_amd._lib as L
+    A, b = pa.build_p_matrix(ranks(2), 12, 10, 8, 24, 10, 8, 2, 1, 1, keep_host=True)
+    S = pa.ColoredGaussSeidelSpMV(A)
+    xf = lambda i: ((i.get_local_to_global() * 7919) % 13 - 6.0) / 8.0
+    x1 = pa.pvector_from_function(xf, A.col_partition)
+    x2 = pa.pvector_from_function(xf, A.col_partition)
+    S.step_(x1, b)
+    pa.consistent_(x2).wait()
+    for (blocks, diag, _, color), xv, bv in zip(S.parts.items, x2.vector_partition.items, b.vector_partition.items):
+        t = pa.DeviceVector(xv.n_own, 0)
+        sets = []
+        for k in range(len(blocks)):
+            ids = np.ascontiguousarray(np.nonzero(color == k)[0] + 1, np.int32)
+            rs = C.c_void_p()
+            L.call("pa_rowset_create", pa.context().h, len(ids), L.ptr(ids), 1, C.byref(rs))
+            sets.append(rs)
+        for order in (range(len(blocks)), range(len(blocks) - 1, -1, -1)):
+            for k in order:
+                L.call("pa_spmv", blocks[k].h, xv.h, L.SEG_LOCAL, t.h, L.SEG_OWN, 1.0, 1.0)
+                L.call("pa_gs_color_update", sets[k], xv.h, bv.h, t.h, diag.h)
+        for rs in sets:
+            L.call("pa_rowset_destroy", rs)
+    for u, v in zip(x1.own_values().items, x2.own_values().items):
+        assert np.array_equal(u, v) and np.all(np.isfinite(u))
+    assert len(S.parts.items[0][0]) == 8
+
+
+@pytest.mark.parametrize("ordering", ["sequential", "multicolor_spmv"])
+def test_fused_residual_restriction_is_bit_identical(ordering):
+    """pc_setup(fuse_restriction=True) forms A*x only on the fine rows the coarse grid keeps (row-split kernel with the
+    restriction as its epilogue); the V-cycle output must equal the unfused mul_no_lat! + restrict! bit for bit."""
+    outs = []
+    for fuse in (False, True):
+        S = pa.pc_setup(ranks(2), 2, 3, 16, 8, 8, ordering=ordering, fuse_restriction=fuse)
+        assert (S.row_blocks[0] is not None) == fuse
+        A, b = S.A_vec[-1], S.r[-1]
+        z = pa.pzeros(A.col_partition)
+        pa.ldiv_(z, S, b)
+        outs.append([v.copy() for v in z.own_values().items] + [v.copy() for v in S.r[0].own_values().items])
+    for u, v in zip(*outs):
+        assert np.array_equal(u, v) and np.all(np.isfinite(u)) and np.any(u != 0.0)
+    import pa_amd._lib as L
+    with pytest.raises(L.PAError):      # a block that does not hold exactly the coarse grid's fine rows is refused
+        L.call("pa_transfer_attach_rows", S.f2c[0].items[0], S.A_vec[-1].matrix_partition.items[0].own_own.h)
+
+
 @pytest.mark.parametrize("ordering", ["multicolor", "multicolor_spmv"])
 def test_multicolor_gauss_seidel_as_hpcg_optimised_variant(golden, ordering):
     """The multicolour smoother is NOT the reference's arithmetic; it is validated the way HPCG validates an optimised
