@@ -641,13 +641,15 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std
       if (!win.empty()) PA_HIP(hipMemcpy(A->d_win, win.data(), sizeof(int32_t) * win.size(), hipMemcpyHostToDevice));
     }
   }
-  // row-pattern descriptors (no column stream at all) for square, uncompacted blocks. PA_SPMV_PATTERN=0 disables.
+  // row-pattern descriptors (no column stream at all); compacted blocks describe runs of constant row-id stride.
+  // PA_SPMV_PATTERN=0 disables.
   {
     const char *e = getenv("PA_SPMV_PATTERN");
-    const bool want = !(e && atoi(e) == 0) && nnz > 0 && !compact && n_rows == n_cols;
+    const bool want = !(e && atoi(e) == 0) && nnz > 0;
     if (want) {
       std::vector<int32_t> pdesc, pdelta;
-      A->n_pattern_chunks = pa_encode_patterns(crp.data(), col0, nc, chunk_row, PA_SPMV_CHUNK_NNZ, pdesc, pdelta, host_threads(nnz));
+      A->n_pattern_chunks = pa_encode_patterns(crp.data(), col0, compact ? row_ids.data() : nullptr, nc, chunk_row,
+                                               PA_SPMV_CHUNK_NNZ, pdesc, pdelta, host_threads(nnz));
       // worth it only when it covers most of the matrix
       if (A->n_pattern_chunks * 2 >= A->n_chunks) {
         A->use_pattern = true;
@@ -774,9 +776,20 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
                                             const int32_t *colval, int index_base, int64_t *n_chunks, int64_t *n_pattern,
                                             int64_t *n_c16, int64_t *n_patterns) {
   PA_REQUIRE(rowptr && (nnz == 0 || colval) && (index_base == 0 || index_base == 1), "bad arguments");
-  std::vector<int32_t> crp(n_rows + 1), col(nnz);
+  std::vector<int32_t> crp(n_rows + 1), col(nnz), row_ids;
   for (int64_t r = 0; r <= n_rows; ++r) crp[r] = rowptr[r] - index_base;
   for (int64_t p = 0; p < nnz; ++p) col[p] = colval[p] - index_base;
+  {  // the compaction rule of csr_build
+    int64_t n_nonempty = 0;
+    for (int64_t r = 0; r < n_rows; ++r) n_nonempty += crp[r + 1] > crp[r];
+    if (n_rows > 0 && n_nonempty * 2 < n_rows) {
+      std::vector<int32_t> c2(1, 0);
+      for (int64_t r = 0; r < n_rows; ++r)
+        if (crp[r + 1] > crp[r]) { row_ids.push_back((int32_t)r); c2.push_back(crp[r + 1]); }
+      crp.swap(c2);
+      n_rows = (int64_t)row_ids.size();
+    }
+  }
   std::vector<int32_t> chunk_row;
   int64_t n_long = 0;
   pa_build_chunks(crp.data(), n_rows, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
@@ -784,7 +797,8 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
   std::vector<uint16_t> c16(nnz + 8, 0);
   std::vector<int32_t> win((size_t)nch * PA_C16_WINDOWS, 0), pdesc, pdelta;
   const int64_t nfall = pa_encode_col16(crp.data(), col.data(), chunk_row, PA_SPMV_CHUNK_NNZ, c16.data(), win.data(), 1);
-  const int64_t npat = pa_encode_patterns(crp.data(), col.data(), n_rows, chunk_row, PA_SPMV_CHUNK_NNZ, pdesc, pdelta, 1);
+  const int64_t npat = pa_encode_patterns(crp.data(), col.data(), row_ids.empty() ? nullptr : row_ids.data(), n_rows, chunk_row,
+                                          PA_SPMV_CHUNK_NNZ, pdesc, pdelta, 1);
   for (int64_t c = 0; c < nch; ++c) {
     const int64_t r0 = chunk_row[c], r1 = chunk_row[c + 1], p0 = crp[r0], p1 = crp[r1];
     PA_REQUIRE(r1 > r0, "empty chunk %lld", (long long)c);
@@ -799,9 +813,10 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
       for (int64_t p = p0; p < p1; ++p) {
         const int q = (int)(p - p0);
         const int s = (q >= d[1]) + (q >= d[2]) + (q >= d[3]);
-        const int t = q - (s ? d[s] : 0), L = d[8 + s];
+        const bool strided = !row_ids.empty();
+        const int t = q - (s ? d[s] : 0), L = strided ? (d[8 + s] & 255) : d[8 + s], stride = strided ? (d[8 + s] >> 8) : 1;
         const int rr = L == 1 ? t : (int)(((uint64_t)(uint32_t)t * (uint64_t)(0xFFFFFFFFu / (uint32_t)L + 1u)) >> 32);
-        const int32_t dec = d[4 + s] + rr + pdelta[(size_t)d[12 + s] * PA_PAT_MAXLEN + (t - rr * L)];
+        const int32_t dec = d[4 + s] + rr * stride + pdelta[(size_t)d[12 + s] * PA_PAT_MAXLEN + (t - rr * L)];
         PA_REQUIRE(dec == col[p], "pattern decode mismatch at entry %lld (chunk %lld)", (long long)p, (long long)c);
       }
   }
@@ -850,10 +865,12 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
                      x->d + xoff, y->d + yoff, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta,    \
                      (double *)nullptr, (const double *)nullptr, (const double *)nullptr)
-    if (A->use_pattern && A->use_c16) PA_LAUNCH_SPMV(true, true);
-    else if (A->use_pattern) PA_LAUNCH_SPMV(false, true);
-    else if (A->use_c16) PA_LAUNCH_SPMV(true, false);
-    else PA_LAUNCH_SPMV(false, false);
+    if (A->use_pattern && A->compact && A->use_c16) PA_LAUNCH_SPMV(true, 2);
+    else if (A->use_pattern && A->compact) PA_LAUNCH_SPMV(false, 2);
+    else if (A->use_pattern && A->use_c16) PA_LAUNCH_SPMV(true, 1);
+    else if (A->use_pattern) PA_LAUNCH_SPMV(false, 1);
+    else if (A->use_c16) PA_LAUNCH_SPMV(true, 0);
+    else PA_LAUNCH_SPMV(false, 0);
 #undef PA_LAUNCH_SPMV
   }
   PA_HIP(hipGetLastError());
@@ -885,10 +902,12 @@ extern "C" int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x,
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
                      (const double *)nullptr, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, \
                      1.0, 0.0, x->d, (const double *)b->d, (const double *)diag->d)
-    if (A->use_pattern && A->use_c16) PA_LAUNCH_GS(true, true);
-    else if (A->use_pattern) PA_LAUNCH_GS(false, true);
-    else if (A->use_c16) PA_LAUNCH_GS(true, false);
-    else PA_LAUNCH_GS(false, false);
+    if (A->use_pattern && A->compact && A->use_c16) PA_LAUNCH_GS(true, 2);
+    else if (A->use_pattern && A->compact) PA_LAUNCH_GS(false, 2);
+    else if (A->use_pattern && A->use_c16) PA_LAUNCH_GS(true, 1);
+    else if (A->use_pattern) PA_LAUNCH_GS(false, 1);
+    else if (A->use_c16) PA_LAUNCH_GS(true, 0);
+    else PA_LAUNCH_GS(false, 0);
 #undef PA_LAUNCH_GS
   }
   PA_HIP(hipGetLastError());
@@ -1153,10 +1172,12 @@ extern "C" int pa_transfer_restrict_fused(pa_transfer *t, pa_vec *rc, const pa_v
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
                      (const double *)xf->d, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx,  \
                      1.0, 0.0, rc->d, (const double *)rf->d, (const double *)nullptr)
-  if (A->use_pattern && A->use_c16) PA_LAUNCH_RR(true, true);
-  else if (A->use_pattern) PA_LAUNCH_RR(false, true);
-  else if (A->use_c16) PA_LAUNCH_RR(true, false);
-  else PA_LAUNCH_RR(false, false);
+  if (A->use_pattern && A->compact && A->use_c16) PA_LAUNCH_RR(true, 2);
+  else if (A->use_pattern && A->compact) PA_LAUNCH_RR(false, 2);
+  else if (A->use_pattern && A->use_c16) PA_LAUNCH_RR(true, 1);
+  else if (A->use_pattern) PA_LAUNCH_RR(false, 1);
+  else if (A->use_c16) PA_LAUNCH_RR(true, 0);
+  else PA_LAUNCH_RR(false, 0);
 #undef PA_LAUNCH_RR
   PA_HIP(hipGetLastError());
   return PA_OK;

@@ -35,21 +35,26 @@ typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 //   "row patterns": no per-entry column at all.  A row's pattern is its list of (col - row) deltas; stencil / FEM
 //            matrices on structured grids have a handful of distinct patterns (27-pt: 27).  A chunk made of at most
 //            PA_PAT_SEGMENTS runs of consecutive rows with one pattern each is described by 16 ints (pdesc) and its
-//            columns are recomputed: col = first_row(seg) + (t / L) + delta[pat(seg)][t % L], t = entry index inside
-//            the segment.  Chunks that do not fit (more runs, rows longer than PA_PAT_MAXLEN) use c16 / 32-bit columns.
+//            columns are recomputed: col = first_row(seg) + (t / L) * stride(seg) + delta[pat(seg)][t % L], t = entry
+//            index inside the segment (stride: row-id step of a run, 1 unless the block is row-compacted, e.g. 2 along
+//            a grid line for the rows of one Gauss-Seidel colour).  Chunks that do not fit (more runs, rows longer than
+//            PA_PAT_MAXLEN, rows whose pattern is rare) use c16 / 32-bit columns.
 #define PA_PAT_SEGMENTS 4
 #define PA_PAT_MAXLEN 32
 
 // column of entry q (relative to the chunk's first entry) from the chunk's pattern descriptor
+template <bool STRIDED>
 __device__ __forceinline__ int pa_pattern_col(int q, int nq, int q1, int q2, int q3, int L0, int L1, int L2, int L3,
                                               int s0r, int s1r, int s2r, int s3r, int dA, int dB) {
   q = max(0, min(q, nq));
   const bool g1 = q >= q1, g2 = q >= q2, g3 = q >= q3;  // chained selects (a runtime-indexed array would go to scratch)
-  int qs = g1 ? q1 : 0, L = g1 ? L1 : L0, rs = g1 ? s1r : s0r;
-  qs = g2 ? q2 : qs; L = g2 ? L2 : L; rs = g2 ? s2r : rs;
-  qs = g3 ? q3 : qs; L = g3 ? L3 : L; rs = g3 ? s3r : rs;
+  int qs = g1 ? q1 : 0, Ls = g1 ? L1 : L0, rs = g1 ? s1r : s0r;
+  qs = g2 ? q2 : qs; Ls = g2 ? L2 : Ls; rs = g2 ? s2r : rs;
+  qs = g3 ? q3 : qs; Ls = g3 ? L3 : Ls; rs = g3 ? s3r : rs;
   const int s = (int)g1 + (int)g2 + (int)g3;
   const int t = q - qs;
+  // descriptor word: row length | row-id stride << 8 (the stride bits are only set for row-compacted blocks)
+  const int L = STRIDED ? (Ls & 255) : Ls, stride = STRIDED ? (Ls >> 8) : 1;
   const int rr = L == 1 ? t : (int)__umulhi((unsigned)t, 0xFFFFFFFFu / (unsigned)L + 1u);  // t / L, exact for t < 2^32 / L
   const int kk = t - rr * L;
   // lanes 0-31 / 32-63 of dA hold the deltas of segment 0 / 1, of dB those of segment 2 / 3.  ds_bpermute reads the
@@ -57,20 +62,21 @@ __device__ __forceinline__ int pa_pattern_col(int q, int nq, int q1, int q2, int
   const int sel = (((s & 1) << 5) + kk) << 2;
   const int delA = __builtin_amdgcn_ds_bpermute(sel, dA);
   const int delB = __builtin_amdgcn_ds_bpermute(sel, dB);
-  return rs + rr + ((s & 2) ? delB : delA);
+  return rs + rr * stride + ((s & 2) ? delB : delA);
 }
 
 // y[row] = beta*y[row] + sum_p (val[p]*x[col[p]])*alpha, products summed in ascending p.
 //   BLK  threads per workgroup, NPT stored entries per lane (chunk capacity CAP = BLK*NPT products in LDS),
 //   NT   non-temporal matrix loads, C16 use the 16-bit column stream where the chunk has one,
-//   PAT  use row-pattern descriptors where the chunk has one (pdesc/pdelta may be NULL when PAT is false).
+//   PAT  0: no row patterns (pdesc/pdelta may be NULL); 1: use row-pattern descriptors where the chunk has one, rows
+//        of a run are consecutive; 2: the same for row-compacted blocks, a run has a row-id stride.
 //   EPI  0: y[row] = beta*y[row] + sum (x, y distinct).
 //        1: Gauss-Seidel colour update in place, gs_x[row] += (gs_b[row] - sum) / gs_diag[row] with the products
 //           gathered from gs_x itself (x, y unused).  Race-free when the block's rows form one colour of a proper
 //           colouring: no row of the launch reads another row of the launch, only itself.
 //        2: fused residual + restriction, gs_x[r] = gs_b[row] - sum for the r-th stored (compacted) row: the coarse
 //           residual r_c = (r_f - A x_f) at the fine rows a coarse grid keeps (gs_x = r_c, gs_b = r_f, x_in = x_f).
-template <int BLK, int NPT, bool NT, bool C16, bool PAT, int EPI = 0>
+template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0>
 __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
@@ -129,8 +135,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const int idx = min(base + (k * BLK + tid) * 2, last);
-        c0[k] = pa_pattern_col(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
-        c1[k] = pa_pattern_col(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
+        c0[k] = pa_pattern_col<PAT == 2>(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
+        c1[k] = pa_pattern_col<PAT == 2>(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
       }
     } else if (use16) {
       unsigned q[NPT / 2];
@@ -268,22 +274,27 @@ inline int64_t pa_encode_col16(const int32_t *crp, const int32_t *col, const std
   return nf;
 }
 
-// Host-side row-pattern analysis.  pdesc: n_chunks*16 ints ({nseg | 0, q1..q3, r0..r3, L0..L3, pat0..pat3});
-// pdelta: PA_PAT_MAXLEN ints per pattern.  Returns the number of chunks that got a descriptor (0: give up, e.g. an
-// unstructured matrix where every row is its own pattern).
-inline int64_t pa_encode_patterns(const int32_t *crp, const int32_t *col, int64_t n_rows,
+// Host-side row-pattern analysis.  pdesc: n_chunks*16 ints ({nseg | 0, q1..q3, r0..r3, (L | stride<<8)0..3, pat0..3});
+// pdelta: PA_PAT_MAXLEN ints per pattern.  row_ids (or NULL) maps a stored (compacted) row to its row id; deltas are
+// col - row id.  Only patterns shared by at least `min_rows` rows enter the table (an unstructured row is its own
+// pattern and keeps explicit columns).  Returns the number of chunks that got a
+// descriptor.
+inline int64_t pa_encode_patterns(const int32_t *crp, const int32_t *col, const int32_t *row_ids, int64_t n_rows,
                                   const std::vector<int32_t> &chunk_row, int cap, std::vector<int32_t> &pdesc,
-                                  std::vector<int32_t> &pdelta, int n_threads, int max_patterns = 4096) {
+                                  std::vector<int32_t> &pdelta, int n_threads, int max_patterns = 4096,
+                                  int min_rows = 2) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   pdesc.assign((size_t)n_chunks * 16, 0);
   pdelta.clear();
   if (n_threads < 1) n_threads = 1;
+  auto rid = [&](int64_t r) -> int32_t { return row_ids ? row_ids[r] : (int32_t)r; };
   // phase A (parallel): a 64-bit hash of every row's delta list
   std::vector<uint64_t> h(n_rows);
   auto hash_rows = [&](int t) {
     for (int64_t r = n_rows * t / n_threads; r < n_rows * (t + 1) / n_threads; ++r) {
       uint64_t x = 1469598103934665603ull ^ (uint64_t)(crp[r + 1] - crp[r]);
-      for (int64_t p = crp[r]; p < crp[r + 1]; ++p) { x ^= (uint64_t)(uint32_t)(col[p] - (int32_t)r); x *= 1099511628211ull; x ^= x >> 29; }
+      const int32_t id = rid(r);
+      for (int64_t p = crp[r]; p < crp[r + 1]; ++p) { x ^= (uint64_t)(uint32_t)(col[p] - id); x *= 1099511628211ull; x ^= x >> 29; }
       h[r] = x;
     }
   };
@@ -293,33 +304,47 @@ inline int64_t pa_encode_patterns(const int32_t *crp, const int32_t *col, int64_
     hash_rows(0);
     for (auto &x : th) x.join();
   }
-  // phase B (sequential, one map lookup per row): pattern ids, verified against the stored deltas
+  // phase B (sequential): how many rows share each hash, then pattern ids for the frequent ones, verified against the
+  // stored deltas
+  std::unordered_map<uint64_t, int32_t> freq;
+  freq.reserve(1 << 16);
+  for (int64_t r = 0; r < n_rows; ++r) {
+    const int len = crp[r + 1] - crp[r];
+    if (len < 1 || len > PA_PAT_MAXLEN) continue;
+    int32_t &f = freq[h[r]];
+    if (f < min_rows) ++f;
+    if ((int64_t)freq.size() > (int64_t)1 << 22 && n_rows > ((int64_t)1 << 23)) break;   // unstructured: stop counting
+  }
   std::vector<int32_t> rowpat(n_rows);
   std::vector<int32_t> plen;
   std::unordered_map<uint64_t, std::vector<int32_t>> ids;
   for (int64_t r = 0; r < n_rows; ++r) {
     const int len = crp[r + 1] - crp[r];
-    if (len > PA_PAT_MAXLEN) { rowpat[r] = -1; continue; }
+    rowpat[r] = -1;
+    if (len < 1 || len > PA_PAT_MAXLEN) continue;
+    auto fi = freq.find(h[r]);
+    if (fi == freq.end() || fi->second < min_rows) continue;
     auto &cand = ids[h[r]];
+    const int32_t id_r = rid(r);
     int32_t id = -1;
     for (int32_t c : cand) {
       if (plen[c] != len) continue;
       bool same = true;
-      for (int k = 0; k < len && same; ++k) same = pdelta[(size_t)c * PA_PAT_MAXLEN + k] == col[crp[r] + k] - (int32_t)r;
+      for (int k = 0; k < len && same; ++k) same = pdelta[(size_t)c * PA_PAT_MAXLEN + k] == col[crp[r] + k] - id_r;
       if (same) { id = c; break; }
     }
     if (id < 0) {
-      if ((int)plen.size() >= max_patterns) { pdesc.assign((size_t)n_chunks * 16, 0); pdelta.assign(PA_PAT_MAXLEN, 0); return 0; }
+      if ((int)plen.size() >= max_patterns) continue;   // table full: this row keeps explicit columns
       id = (int32_t)plen.size();
       plen.push_back(len);
       pdelta.resize((size_t)(id + 1) * PA_PAT_MAXLEN, 0);
-      for (int k = 0; k < len; ++k) pdelta[(size_t)id * PA_PAT_MAXLEN + k] = col[crp[r] + k] - (int32_t)r;
+      for (int k = 0; k < len; ++k) pdelta[(size_t)id * PA_PAT_MAXLEN + k] = col[crp[r] + k] - id_r;
       cand.push_back(id);
     }
     rowpat[r] = id;
   }
-  if (pdelta.empty()) pdelta.assign(PA_PAT_MAXLEN, 0);
-  // phase C (parallel): runs of equal patterns inside every chunk
+  if (pdelta.empty()) { pdelta.assign(PA_PAT_MAXLEN, 0); return 0; }
+  // phase C (parallel): runs of equal pattern and constant row-id stride inside every chunk
   std::vector<int64_t> good(n_threads, 0);
   auto segs = [&](int t) {
     for (int64_t c = n_chunks * t / n_threads; c < n_chunks * (t + 1) / n_threads; ++c) {
@@ -328,19 +353,36 @@ inline int64_t pa_encode_patterns(const int32_t *crp, const int32_t *col, int64_
       const int64_t p0 = crp[r0], p1 = crp[r1];
       bool ok = (p1 - (p0 & ~1)) <= cap && p1 > p0;
       int ns = 0;
+      int64_t run_rows = 0;
+      int32_t stride = 1;
       for (int64_t r = r0; ok && r < r1; ++r) {
         if (rowpat[r] < 0) { ok = false; break; }
-        if (ns == 0 || rowpat[r] != d[12 + ns - 1]) {
-          if (ns == PA_PAT_SEGMENTS) { ok = false; break; }
-          if (ns) d[ns] = (int32_t)(crp[r] - p0);
-          d[4 + ns] = (int32_t)r;
-          d[8 + ns] = crp[r + 1] - crp[r] > 0 ? crp[r + 1] - crp[r] : 1;
-          d[12 + ns] = rowpat[r];
-          ++ns;
+        bool extend = ns > 0 && rowpat[r] == d[12 + ns - 1];
+        if (extend) {
+          const int32_t step = rid(r) - rid(r - 1);
+          if (run_rows == 1) {
+            if (step < 1 || step >= (1 << 20)) extend = false;
+            else stride = step;
+          } else if (step != stride) {
+            extend = false;
+          }
         }
+        if (extend) {
+          ++run_rows;
+          if (row_ids) d[8 + ns - 1] = (d[8 + ns - 1] & 255) | (stride << 8);
+          continue;
+        }
+        if (ns == PA_PAT_SEGMENTS) { ok = false; break; }
+        if (ns) d[ns] = (int32_t)(crp[r] - p0);
+        d[4 + ns] = rid(r);
+        d[8 + ns] = (crp[r + 1] - crp[r]) | (row_ids ? 1 << 8 : 0);
+        d[12 + ns] = rowpat[r];
+        ++ns;
+        run_rows = 1;
+        stride = 1;
       }
       if (!ok) { for (int k = 0; k < 16; ++k) d[k] = 0; continue; }
-      for (int s = ns; s < PA_PAT_SEGMENTS; ++s) { if (s) d[s] = 1 << 30; d[4 + s] = 0; d[8 + s] = 1; d[12 + s] = 0; }
+      for (int s = ns; s < PA_PAT_SEGMENTS; ++s) { if (s) d[s] = 1 << 30; d[4 + s] = 0; d[8 + s] = 1 | (row_ids ? 1 << 8 : 0); d[12 + s] = 0; }
       d[0] = ns;
       ++good[t];
     }

@@ -8,11 +8,14 @@ ordering = sys.argv[2] if len(sys.argv) > 2 else "multicolor_spmv"
 ranks = pa.DebugArray([1])
 S = pa.pc_setup(ranks, 1, 4, n, n, n, ordering)
 A, b = S.A_vec[-1], S.r[-1]
-x = pa.pzeros(A.col_partition)
-pa.ref_cg_(x, A, b, maxiter=2, overlap=False, Pl=S)
-pa.context().sync()
-x = pa.pzeros(A.col_partition)
-t = time.perf_counter()
-x, r0, r, it = pa.ref_cg_(x, A, b, maxiter=10, overlap=False, Pl=S)
-pa.context().sync()
-print(n, ordering, 'ms per MG-PCG iteration', round((time.perf_counter() - t) / 10 * 1e3, 2), 'r/r0', r / r0, flush=True)
+def run(k):
+    x = pa.pzeros(A.col_partition)
+    pa.context().sync()
+    t = time.perf_counter()
+    out = pa.opt_cg_(x, A, b, maxiter=k, Pl=S)
+    pa.context().sync()
+    return time.perf_counter() - t, out
+run(2)
+t1, _ = run(3)
+t2, (x, r0, r, it) = run(13)
+print(n, ordering, 'ms per MG-PCG iteration', round((t2 - t1) / 10 * 1e3, 2), 'r/r0', r / r0, flush=True)

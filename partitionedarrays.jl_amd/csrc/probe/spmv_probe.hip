@@ -229,7 +229,7 @@ int main(int argc, char **argv) {
       CK(hipMemcpy(dwin, win.data(), 4 * win.size(), hipMemcpyHostToDevice)); }                                 \
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"spmv<" #BLK "," #NPT "," #NT ",c16=" #C16 ">", [=]() {                                        \
-      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, C16, false>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d16, dwin, \
+      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, C16, 0>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d16, dwin, \
                          (const int *)nullptr, (const int *)nullptr, d_val, d_x, (C16 ? d_y2 : d_y), dc, (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_SPMV4(256, 4, true, false)
   ADD_SPMV4(256, 6, true, true)
@@ -270,7 +270,7 @@ int main(int argc, char **argv) {
 #define ADD_PAT(BLK, NPT, NT)                                                                                     \
   { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, BLK * NPT, 4096, cr, &nl);           \
     const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
-    const int64_t ng = pa_encode_patterns(rp.data(), hcol.data(), nrows, cr, BLK * NPT, pdesc, pdelta, 32);     \
+    const int64_t ng = pa_encode_patterns(rp.data(), hcol.data(), nullptr, nrows, cr, BLK * NPT, pdesc, pdelta, 32);     \
     printf("pattern<%d,%d>: %d chunks, %lld with a descriptor, %zu patterns\n", BLK, NPT, nch, (long long)ng, pdelta.size() / 32); \
     int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
     CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
