@@ -318,6 +318,37 @@ def test_full_size_27pt_128_two_parts_properties():
         assert np.array_equal(4.0 * a_, b_)
 
 
+def test_config4_full_size_256_cubed_eight_parts_on_one_gpu():
+    """BASELINE config 4 at its full size -- 27-pt, 256^3 rows per part, 8 parts as (2,2,2), global 512^3 -- with all
+    eight parts resident on ONE GPU (46 GB of HBM; the exchange is device-to-device copies instead of RCCL).
+    Closed-form sizes of SURVEY 8 (C4), then size-independent properties: A*1 == b bit-exactly, ghosts == owners after
+    consistent!, and three CG iterations with device scalars == the reference schedule, bit for bit."""
+    n = 256
+    A, b = pa.build_p_matrix(ranks(8), n, n, n, 2 * n, 2 * n, 2 * n, 2, 2, 2)
+    sizes = pa.pmap(lambda m, c: (m.own_own.nnz, m.own_ghost.nnz, c.n_own, c.n_ghost), A.matrix_partition, A.col_partition)
+    assert sizes.items == [(449455096, 1762567, 16777216, 197377)] * 8      # 766^3/8, (767^3 - 766^3)/8, 256^3, ghosts
+    assert sum(s[0] + s[1] for s in sizes.items) == 8 * 451217663 == 1534 ** 3
+    enc = A.matrix_partition.items[0].own_own.encoding()
+    assert enc["pattern"] >= 0.999 * sum(enc.values())
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, pa.pones(A.col_partition))
+    for got, exp in zip(y.own_values().items, b.own_values().items):
+        assert np.array_equal(got, exp)
+    g = A.col_partition
+    x = pa.pvector_from_function(lambda i: ((i.get_local_to_global() % 7) - 3.0) * (i.get_local_to_owner() == i.part), g)
+    pa.mul_(y, A, x)
+    for vals, ind in zip(x.ghost_values().items, g.items):
+        assert np.array_equal(vals, (ind.get_local_to_global()[ind.n_own:] % 7) - 3.0)
+    del x, y
+    res = []
+    for fn in (pa.ref_cg_, pa.opt_cg_):
+        hist = []
+        z, r0, r, it = fn(pa.pzeros(g), A, b, maxiter=3, history=hist)
+        res.append((r0, r, hist, float(z.own_values().items[7][-1])))
+        del z
+    assert res[0] == res[1] and res[0][1] < res[0][0]
+
+
 # ---------------------------------------------------------------- CG loop (BASELINE config 4 shape, small)
 def test_ref_cg_identity_preconditioner(orc):
     """HPCG/src/ref_cg.jl with Pl = Identity(): consistent!+mul!, 2 dots + norm, 3 axpys per iteration, on 8 parts.
