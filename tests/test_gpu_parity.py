@@ -718,6 +718,21 @@ def test_fused_residual_restriction_is_bit_identical(ordering):
         L.call("pa_transfer_attach_rows", S.f2c[0].items[0], S.A_vec[-1].matrix_partition.items[0].own_own.h)
 
 
+def test_hpcg_benchmark_three_phases_small():
+    """hpcg_benchmark (HPCG/src/hpcg_benchmark.jl): reference phase with the level-scheduled smoother, optimised phase
+    to the reference tolerance (extra iterations charged), timed sets, and the report's rating; 4 parts x 16^3."""
+    rep = pa.hpcg_benchmark(ranks(4), 4, 16, 16, 16, total_runtime=3600.0, max_sets=2)
+    it = rep["iter_data"]
+    assert it["ref_iters_set"] == 50 and 50 <= it["opt_iters_set"] < 100 and it["opt_iters_total"] == 2 * it["opt_iters_set"]
+    assert rep["optimised_phase"]["iterations_to_ref_tol"] == it["opt_iters_set"]
+    assert 0.0 < rep["reproducibility_data"]["mean"] <= rep["reference_phase"]["ref_tol"] * 1.0000001
+    assert rep["reproducibility_data"]["var"] == 0.0                       # deterministic kernels: identical sets
+    assert rep["nr_equations"] == 4 * 16 ** 3 and rep["non_zeros"] == (3 * 32 - 2) ** 2 * (3 * 16 - 2)
+    t = rep["times"]
+    assert t["total"] > 0 and 0 < t["DDOT"] + t["WAXPBY"] + t["SPMV"] + t["MG"] <= t["total"] * 1.05
+    assert rep["GFLOP/s"]["Total_conv"] <= rep["GFLOP/s"]["Total"] and rep["Overview"]["GFLOP/s"] > 0
+
+
 @pytest.mark.parametrize("ordering", ["multicolor", "multicolor_spmv"])
 def test_multicolor_gauss_seidel_as_hpcg_optimised_variant(golden, ordering):
     """The multicolour smoother is NOT the reference's arithmetic; it is validated the way HPCG validates an optimised

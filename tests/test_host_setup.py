@@ -253,3 +253,25 @@ def test_spmv_row_split_and_column_encodings_decode_exactly(orc):
     A = pa.compresscoo(Irow, Jcol, np.ones(len(Irow)), m, n)
     e = _check_enc(A)
     assert e["pattern"] == 0 and e["c16"] < e["chunks"]
+
+
+def test_hpcg_geometry_and_report_models(orc):
+    """hpcg_geometry: closed-form rows / stored entries per level == what the generator builds (oracle, 4 parts);
+    hpcg_report: the flop and byte models of HPCG/src/report_results.jl:27-77 on hand-computable inputs."""
+    g = pa.hpcg_geometry(4, 2, 8, 8, 8)
+    assert (g["npx"], g["npy"], g["npz"]) == (2, 2, 1) and g["nrows"] == [8 * 8 * 4, 16 * 16 * 8]
+    for lev, n in ((1, 8), (0, 4)):
+        Ao, _, _ = orc.hpcg_build_p_matrix(n, n, n, 2, 2, 1)
+        assert sum(blk.own_own.nnz + blk.own_ghost.nnz for blk in Ao.blocks) == g["nnz"][lev]
+    geom = dict(nx=2, ny=2, nz=2, npx=1, npy=1, npz=1, nnz=[10, 100], nrows=[1, 8])
+    times = dict(total=2.0, DDOT=0.25, WAXPBY=0.25, SPMV=0.5, MG=1.0, setup=1.0, opt_time=0.5, ref_time=1.0)
+    rep = pa.hpcg_report(1, times, 2, 50, 100, 3, [1e-9, 3e-9, 2e-9], geom)
+    f = 3 * 100                                                                  # nr_cg_sets * opt_max_iters
+    fl = rep["flops"]
+    assert fl["DDOT"] == fl["WAXPBY"] == (3 * f + 3) * 2 * 8 and fl["SpMV"] == (f + 3) * 2 * 100
+    assert fl["MG"] == f * 10 * 100 + f * 4 * 10 and fl["Total_conv"] == fl["Total"] * 0.5
+    reads = (3 * f + 3) * 2 * 8 * 8 * 2 + (f + 3) * (100 * 16 + 8 * 8) + f * ((2 * 100 * 16 + 64) * 2 + 100 * 16 + 64) + f * (2 * 10 * 16 + 8)
+    writes = (3 * f + 3) * 8 + (3 * f + 3) * 64 + (f + 3) * 64 + f * 100 * 8 * 3 + f * 8
+    assert rep["GB/s"]["Read"] == reads / 2.0 / 1e9 and rep["GB/s"]["Write"] == writes / 2.0 / 1e9
+    assert rep["Overview"]["GFLOP/s"] == fl["Total_conv"] / (2.0 + 3 * (0.05 + 0.1)) / 1e9
+    assert rep["reproducibility_data"]["mean"] == 2e-9 and abs(rep["reproducibility_data"]["var"] - 1e-18) < 1e-30
