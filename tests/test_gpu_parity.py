@@ -76,6 +76,38 @@ def test_repeated_exchanges_and_periodic_partition(orc):
         assert np.array_equal(a, b)
 
 
+def test_jacobi_tutorial_equals_serial_jacobi_bit_for_bit():
+    """G14: docs/jacobi_tutorial.jl:239-263, jacobi_par(10,100,3) on uniform_partition(ranks,3,10,true) -- local ranges
+    1:4, 3:7, 6:10, local order = global order (ghosts at both ends) -- with consistent! on the device every sweep and
+    the tutorial's local update on the host.  The same operations as a serial Jacobi: own values equal bit for bit."""
+    n, niters, p = 10, 100, 3
+    parts = pa.uniform_partition(ranks(p), (p,), (n,), (True,))
+    assert [i.get_local_to_global().tolist() for i in parts.items] == [[1, 2, 3, 4], [3, 4, 5, 6, 7], [6, 7, 8, 9, 10]]
+
+    def init(ind):
+        a = np.zeros(ind.n_local)
+        a[0], a[-1] = 1.0, -1.0
+        return a
+    u, u_new = pa.pvector_from_function(init, parts), pa.pvector_from_function(init, parts)
+    for _ in range(niters):
+        pa.consistent_(u).wait()
+        for dv, dn in zip(u.vector_partition.items, u_new.vector_partition.items):
+            a, b = dv.download(0, len(dv)), dn.download(0, len(dn))
+            b[1:-1] = 0.5 * (a[:-2] + a[2:])
+            dn.upload(b)
+        u, u_new = u_new, u
+    s = np.zeros(n)
+    s[0], s[-1] = 1.0, -1.0
+    s_new = s.copy()
+    for _ in range(niters):
+        s_new[1:-1] = 0.5 * (s[:-2] + s[2:])
+        s, s_new = s_new, s
+    for dv, ind in zip(u.vector_partition.items, parts.items):
+        own = ind.get_local_to_owner() == ind.part
+        assert np.array_equal(dv.download(0, len(dv))[own], s[ind.get_local_to_global()[own] - 1])
+    assert abs(s[4]) < 0.5 and s[1] > s[8]                  # the profile relaxes from +1 towards -1
+
+
 # ---------------------------------------------------------------- mul!
 def _oracle_mul(orc, Ao, xo):
     yo = [np.zeros(r.n_local) for r in Ao.rows]
@@ -169,6 +201,53 @@ def test_config1_laplacian_64_cubed_4_parts(orc):
     yo = _oracle_mul(orc, Ao, [np.ones(c.n_local) for c in Ao.cols])
     for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
         assert np.array_equal(got, exp[:r.n_own])
+
+
+def test_fdm_example_end_to_end():
+    """G13: test/fdm_example.jl:11-128 -- 9^3 grid on (2,1,2) parts, 7-point stencil in the interior, identity rows on
+    the boundary (a non-symmetric matrix), exact solution u = x + y imposed through the initial guess; CG must reach
+    norm(x - x_hat) < 1e-5 on the own values, as the reference asserts (:128)."""
+    parts_per_dir, nodes = (2, 1, 2), (9, 9, 9)
+    h = 2.0 / (nodes[0] - 1)
+    coeffs = np.array([-6, 1, 1, 1, 1, 1, 1]) / h ** 2
+    points = [(0, 0, 0), (-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1)]
+    rows = pa.uniform_partition(ranks(4), parts_per_dir, nodes)
+
+    def cart(g):                                                   # CartesianIndices(nodes)[g], 0-based coordinates
+        g = np.asarray(g) - 1
+        return np.stack([g % nodes[0], (g // nodes[0]) % nodes[1], g // (nodes[0] * nodes[1])], axis=-1)
+
+    def coo(ind):
+        I, J, V = [], [], []
+        gl = ind.get_local_to_global()
+        b, xh = np.zeros(ind.n_local), np.zeros(ind.n_local)
+        for k, (g, c) in enumerate(zip(gl, cart(gl))):
+            xh[k] = c[0] * h + c[1] * h
+            if any(ci == 0 or ci == n - 1 for ci, n in zip(c, nodes)):
+                I.append(g), J.append(g), V.append(1.0)
+                b[k] = xh[k]
+            else:
+                for v, d in zip(coeffs, points):
+                    cc = c + np.array(d)
+                    I.append(g), J.append(1 + cc[0] + nodes[0] * (cc[1] + nodes[1] * cc[2])), V.append(-v)
+        return np.array(I), np.array(J), np.array(V), b, xh
+
+    out = pa.pmap(coo, rows)
+    I, J, V = (pa.pmap(lambda o, k=k: o[k], out) for k in range(3))
+    A = pa.psparse_from_coo(I, J, V, rows)
+    cols = A.col_partition
+
+    def x0(ind):
+        c = cart(ind.get_local_to_global())
+        bnd = np.any((c == 0) | (c == np.array(nodes) - 1), axis=1)
+        v = np.where(bnd, c[:, 0] * h + c[:, 1] * h, 0.0)
+        v[ind.n_own:] = 0.0                                        # only own values are set (:104-116)
+        return v
+    x = pa.pvector_from_function(x0, cols)
+    b = pa.pvector_from_function(lambda ind: np.concatenate([out.items[ind.part - 1][3], np.zeros(ind.n_ghost)]), cols)
+    x, r0, r, it = pa.ref_cg_(x, A, b, maxiter=729, tolerance=1.4901161193847656e-08)   # IterativeSolvers: sqrt(eps)
+    err = sum(float(np.sum((xv - o[4]) ** 2)) for xv, o in zip(x.own_values().items, out.items)) ** 0.5
+    assert err < 1.0e-5 and it < 729
 
 
 # ---------------------------------------------------------------- local SpMV on irregular matrices
