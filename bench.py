@@ -17,9 +17,27 @@ import os
 import sys
 import time
 
+# dmabuf IPC is the only mode the host driver supports (RCCL / cross-process GPU memory); harmless for one process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+PHASE = ["start"]
+
+
+def watchdog(seconds):
+    """A multi-process run that deadlocks (a neighbour exchange that never completes) would sit until the driver's
+    own limit; instead say where it hung and exit non-zero.  Generous: set-up + 4 x the default run fit many times."""
+    import threading
+
+    def fire():
+        print(f"[bench watchdog] no progress after {seconds} s, phase = {PHASE[0]!r}; aborting", file=sys.stderr, flush=True)
+        os._exit(4)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
@@ -81,6 +99,7 @@ def main():
     import torch.distributed as dist
     from __graft_entry__ import load_package
     if N > 1 or world > 1:
+        watchdog(float(os.environ.get("PA_BENCH_WATCHDOG_S", "1500")))
         assert world == N, f"--gpus {N} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {N}"
         local = int(os.environ.get("LOCAL_RANK", str(rank))) % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
@@ -100,6 +119,7 @@ def main():
         import pa_amd.p_vector as pv
         transport = os.environ.get("PA_TRANSPORT", "rccl")
         if transport == "rccl":
+            PHASE[0] = "RCCL communicator"
             try:                       # direct RCCL (ncclSend/ncclRecv issued by libpa_hip on its comm stream)
                 pa.init_comm()
                 good = 1
@@ -115,6 +135,7 @@ def main():
     else:
         ranks = pa.DebugArray([1])
 
+    PHASE[0] = "matrix set-up"
     t_setup = time.perf_counter()
     A, b = pa.build_p_matrix(ranks, n, n, n, *gn, npx, npy, npz)
     # x[gid] = ((gid*2654435761) mod 2^32)/2^32 on OWN entries only: mul! must bring the ghosts
@@ -144,6 +165,7 @@ def main():
             ok = bool(flag.item())
         return ok
 
+    PHASE[0] = f"parity gate (transport {transport})"
     ok = gate()
     if not ok and N > 1 and transport == "rccl":
         print(f"[rank {rank}] parity gate failed with the direct RCCL transport; retrying with torch.distributed p2p",
@@ -180,6 +202,7 @@ def main():
             dist.barrier()
             ctx.sync()
 
+    PHASE[0] = f"timed mul! loop (transport {transport})"
     for _ in range(args.warmup):
         step()
     barrier()
@@ -228,6 +251,7 @@ def main():
     # HPCG/src/ref_cg.jl (consistent!+mul!, 2 dots + norm, 3 axpys; Identity preconditioner), as the reference
     # schedules it (ref_cg_: a blocking reduction per dot) and as opt_cg_ does (scalars stay on the device).
     cg = None
+    PHASE[0] = "CG loop"
     if args.cg_iters > 0:
         def cg_time(fn, k):
             xx = pa.pzeros(A.col_partition)
