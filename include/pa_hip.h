@@ -171,6 +171,7 @@ int pa_plan_buffers(pa_plan *plan, int mode, void **snd, int64_t *snd_len, void 
  *                        bit-identical to the reference's loop) followed by ghost := 0 (:703-705). */
 int pa_exchange_pack(pa_plan *plan, const pa_vec *v, int mode);
 int pa_exchange_finish(pa_plan *plan, pa_vec *v, int mode);
+
 /* Transport A: every part lives in this process (DebugArray analogue, src/debug_array.jl:250-255,
  * src/primitives.jl:1020-1042): device-to-device slice copies between the plans' buffers.
  * plans[i] must be the plan of part (i + index_base). Call after pa_exchange_pack on ALL parts. */
@@ -178,6 +179,24 @@ int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mode);
 /* Transport B: one process per part over RCCL (MPIArray analogue, src/mpi_array.jl:575-614):
  * one ncclGroup of ncclSend/ncclRecv per neighbour on the comm stream; rank = part - index_base. */
 int pa_exchange_rccl(pa_plan *plan, pa_comm *comm, int mode);
+
+/* ---- operator level: the whole mul! of a part in one call ------------------------------------------------------------
+ * pa_matrix = the operands of mul! that do not change between products: the own_own / own_ghost blocks of an ASSEMBLED
+ * PSparseMatrix part (src/p_sparse_matrix.jl:588-627,1040-1092) and the exchange plan of its column partition (the
+ * cache of the PVector it multiplies).  Blocks and plan stay the caller's (pa_matrix_destroy frees only the handle).
+ *   pa_mul (c,a,b)            src/p_sparse_matrix.jl:2090-2103:  t = consistent!(b) [pack, neighbour exchange on the comm
+ *                             stream]; c_own = A_oo b_own on the compute stream, overlapping; wait(t) [unpack]; c_own += A_oh b_ghost
+ *   pa_mul5(c,a,b,alpha,beta) :2105-2142, assembled branch (a sub-assembled matrix needs its ghost-row blocks and
+ *                             assemble!(c): compose pa_spmv / pa_exchange_* as the host mirror's mul5_ does)
+ * One part per process: pass the RCCL communicator (NULL only for a single part without neighbours).
+ *   pa_mul_all                every part of one process (DebugArray, src/debug_array.jl:110-117,250): parts r = 0..n-1 in
+ *                             order, exchange by device-to-device copies; one call queues all the pipelines. */
+typedef struct pa_matrix pa_matrix;
+int pa_matrix_create(pa_ctx *ctx, const pa_csr *own_own, const pa_csr *own_ghost, pa_plan *col_plan, pa_matrix **m);
+int pa_matrix_destroy(pa_matrix *m);
+int pa_mul(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b);
+int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta);
+int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta);
 
 /* ---- deterministic scatter-add maps: sparse_matrix!(A,V,K) (src/sparse_utils.jl:454-466) -------------------- */
 /* dst[dest[p]] += src[p] for p ascending (entries with dest[p] < index_base are skipped, as `k < 1` is there);

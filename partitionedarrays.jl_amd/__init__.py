@@ -16,7 +16,7 @@ from .p_vector import (Context, Event, context, init_comm, DeviceVector, DeviceA
                        dot, norm, axpby_, copy_, slots_supported, dot_slot, axpby_slot_, cg_update_, write_slot,
                        read_slots)
 from .p_sparse_matrix import (HostCSR, DeviceCSR, SplitMatrixBlocks, PSparseMatrix, compresscoo, sparse_matrix,  # noqa: F401
-                              split_format_locally, spmv_, psparse, psparse_from_coo, mul_, mul5_, mul_no_overlap_,
+                              split_format_locally, spmv_, psparse, psparse_from_coo, mul_, mul_c_, mul5_, mul_no_overlap_,
                               psparse_disassembled, psparse_assemble_host, psparse_, MatrixReassemblyCache,
                               mul5_transpose_)
 from .gallery import laplacian_fem, laplacian_fdm, build_matrix, build_p_matrix, build_split_blocks_fused, compute_optimal_shape_XYZ  # noqa: F401

@@ -63,6 +63,11 @@ _SIGS = {
     "pa_vec_dot": [P, P, C.POINTER(f64)],
     "pa_vec_dot_result": [P, PP],
     "pa_ctx_read_scalar": [P, C.POINTER(f64)],
+    "pa_matrix_create": [P, P, P, P, PP],
+    "pa_matrix_destroy": [P],
+    "pa_mul": [P, P, P, P],
+    "pa_mul5": [P, P, P, P, f64, f64],
+    "pa_mul_all": [P, i32, P, P, f64, f64],
     "pa_vec_dot_slot": [P, P, cint, cint],
     "pa_vec_axpby_slot": [P, f64, cint, cint, P, f64, cint, cint, cint],
     "pa_cg_update": [P, P, P, P, cint, cint, cint, cint],

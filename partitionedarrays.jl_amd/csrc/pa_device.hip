@@ -1445,3 +1445,73 @@ extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
   p->phase = 0;
   return PA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// operator level: mul!(c,a,b) of one part (or of all parts of a process) in one call
+// ------------------------------------------------------------------------------------------------
+extern "C" int pa_matrix_create(pa_ctx *c, const pa_csr *own_own, const pa_csr *own_ghost, pa_plan *col_plan, pa_matrix **out) {
+  PA_REQUIRE(c && own_own && own_ghost && col_plan && out, "bad arguments");
+  PA_REQUIRE(own_own->ctx == c && own_ghost->ctx == c && col_plan->ctx == c, "operands live in different contexts");
+  PA_REQUIRE(own_own->n_rows == own_ghost->n_rows, "own_own has %lld rows, own_ghost %lld", (long long)own_own->n_rows,
+             (long long)own_ghost->n_rows);
+  PA_REQUIRE(own_own->n_cols + own_ghost->n_cols == col_plan->n_local,
+             "blocks have %lld own + %lld ghost columns, the column plan %lld local ids", (long long)own_own->n_cols,
+             (long long)own_ghost->n_cols, (long long)col_plan->n_local);
+  pa_matrix *m = new pa_matrix();
+  m->ctx = c; m->oo = own_own; m->oh = own_ghost; m->plan = col_plan;
+  *out = m;
+  return PA_OK;
+}
+
+extern "C" int pa_matrix_destroy(pa_matrix *m) {
+  delete m;
+  return PA_OK;
+}
+
+static int mul_check(const pa_matrix *m, const pa_vec *c, const pa_vec *b) {
+  PA_REQUIRE(m && c && b, "bad arguments");
+  // @boundscheck matching_own_indices / matching_ghost_indices (src/p_sparse_matrix.jl:2091-2093)
+  PA_REQUIRE(c->n_own == m->oo->n_rows, "matching_own_indices(axes(c,1),axes(a,1)) failed");
+  PA_REQUIRE(b->n_own == m->oo->n_cols && b->n_ghost == m->oh->n_cols, "matching_own/ghost_indices(axes(a,2),axes(b,1)) failed");
+  return PA_OK;
+}
+
+// src/p_sparse_matrix.jl:2105-2142 (assembled branch); alpha = 1, beta = 0 is :2090-2103
+extern "C" int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta) {
+  PA_TRY(mul_check(m, c, b));
+  PA_REQUIRE(c->d != b->d, "c and b alias");
+  if (!comm) {
+    PA_REQUIRE(m->plan->snd.nbr.empty() && m->plan->rcv.nbr.empty(), "the column plan has neighbours: pass the communicator");
+    PA_REQUIRE(m->plan->part == 0, "without a communicator the part must be the only one");
+  }
+  PA_TRY(pa_exchange_pack(m->plan, b, PA_CONSISTENT));                       // t = consistent!(b)
+  if (comm) PA_TRY(pa_exchange_rccl(m->plan, comm, PA_CONSISTENT));
+  else {
+    pa_plan *one[1] = {m->plan};
+    PA_TRY(pa_exchange_local(one, 1, PA_CONSISTENT));
+  }
+  PA_TRY(pa_spmv(m->oo, b, PA_SEG_OWN, c, PA_SEG_OWN, alpha, beta));        // own x own, overlaps the exchange
+  PA_TRY(pa_exchange_finish(m->plan, b, PA_CONSISTENT));                     // wait(t)
+  PA_TRY(pa_spmv(m->oh, b, PA_SEG_GHOST, c, PA_SEG_OWN, alpha, 1.0));       // own x ghost
+  return PA_OK;
+}
+
+extern "C" int pa_mul(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b) { return pa_mul5(m, comm, c, b, 1.0, 0.0); }
+
+extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta) {
+  PA_REQUIRE(m && c && b && n_parts > 0, "bad arguments");
+  std::vector<pa_plan *> plans(n_parts);
+  for (int r = 0; r < n_parts; ++r) {
+    PA_TRY(mul_check(m[r], c[r], b[r]));
+    PA_REQUIRE(c[r]->d != b[r]->d, "c and b alias (part %d)", r);
+    plans[r] = m[r]->plan;
+  }
+  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], b[r], PA_CONSISTENT));
+  PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_CONSISTENT));
+  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
+  for (int r = 0; r < n_parts; ++r) {
+    PA_TRY(pa_exchange_finish(plans[r], b[r], PA_CONSISTENT));
+    PA_TRY(pa_spmv(m[r]->oh, b[r], PA_SEG_GHOST, c[r], PA_SEG_OWN, alpha, 1.0));
+  }
+  return PA_OK;
+}

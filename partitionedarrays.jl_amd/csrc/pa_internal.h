@@ -132,6 +132,12 @@ struct pa_transfer {
   const pa_csr *rows = nullptr;  // optional: the stored entries of exactly those fine rows (fused residual + restrict)
 };
 
+struct pa_matrix {
+  pa_ctx *ctx = nullptr;
+  const pa_csr *oo = nullptr, *oh = nullptr;   // own_own, own_ghost (not owned)
+  pa_plan *plan = nullptr;                     // exchange plan of the column partition (not owned)
+};
+
 int pa_plan_mark_arrived(pa_plan *p);
 
 #endif

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib as L
 from .primitives import pmap
-from .p_sparse_matrix import mul_, mul_no_overlap_
+from .p_sparse_matrix import mul_, mul_c_, mul_no_overlap_
 from .p_vector import (axpby_, copy_, dot, norm, similar, pzeros, consistent_, context, slots_supported, dot_slot,
                        axpby_slot_, cg_update_, write_slot, read_slots)
 
@@ -288,7 +288,7 @@ def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_ev
         with tm.span("WAXPBY"):
             axpby_slot_(u, 1.0, ONE, ONE, z, 1.0, s_rho, s_prev)   # u .= z .+ (rho/rho_prev) .* u
         with tm.span("SPMV"):
-            mul_(c, A, u)
+            mul_c_(c, A, u)                                      # mul! queued by one library call
         with tm.span("DDOT"):
             dot_slot(u, c, s_uc)
         with tm.span("WAXPBY"):                                  # (carries the |r|^2 reduction of :67 as well)

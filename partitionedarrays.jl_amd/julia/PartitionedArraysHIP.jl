@@ -190,6 +190,31 @@ end
 # assemble!(o,a) zero-fills the ghosts after the task (src/p_vector.jl:703-705); pa_exchange_finish already did,
 # and fill!(::HIPSegment,0) above keeps that line of the reference valid.
 
+# ---------------------------------------------------------------- operator level (optional fast path)
+# The methods above already make the reference's mul! body run on the device.  `mul_fused!` queues the same
+# pipeline (src/p_sparse_matrix.jl:2090-2142, assembled branch) with ONE ccall per process instead of five:
+# pa_mul_all for DebugArray back-ends, pa_mul5 + the RCCL communicator for MPIArray back-ends.
+function _matrix_handle(a, plan)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pa_matrix_create, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                context().handle, a.blocks.own_own.handle, a.blocks.own_ghost.handle, plan, h))
+    h[]
+end
+function mul_fused!(c::PVector, A::PSparseMatrix, b::PVector, α::Real=1.0, β::Real=0.0)
+    @assert A.assembled
+    plans = b.cache.plans
+    ms = map(_matrix_handle, partition(A), plans)
+    _mul_fused!(ms, partition(c), partition(b), plans, Float64(α), Float64(β))
+    foreach(m -> ccall((:pa_matrix_destroy, libpa), Cint, (Ptr{Cvoid},), m), ms)
+    c
+end
+_mul_fused!(ms::DebugArray, cs, bs, plans, α, β) =
+    check(ccall((:pa_mul_all, libpa), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Float64, Float64),
+                ms.items, length(ms.items), [v.handle for v in cs.items], [v.handle for v in bs.items], α, β))
+_mul_fused!(ms::MPIArray, cs, bs, plans, α, β) =
+    check(ccall((:pa_mul5, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64),
+                ms.item, init_comm!(ms.comm), cs.item.handle, bs.item.handle, α, β))
+
 # ---------------------------------------------------------------- conversions
 "Device twin of a host PVector{Vector{Float64}} whose local ids are [own | ghost] (block partitions)."
 function to_hip(v::PVector)

@@ -216,6 +216,54 @@ def mul_(c: PVector, a: PSparseMatrix, b: PVector) -> PVector:
     return c
 
 
+def _operator_handles(a: PSparseMatrix, b: PVector):
+    """pa_matrix of every part for the pair (a, b): blocks of `a` + the exchange plan of b's cache; built once per pair."""
+    cache = b.__dict__.setdefault("_pa_matrices", {})
+    if id(a) not in cache:
+        def mk(blk, plan):
+            h = C.c_void_p()
+            L.call("pa_matrix_create", context().h, blk.own_own.h, blk.own_ghost.h, plan, C.byref(h))
+            return h
+        cache[id(a)] = _OperatorHandles(pmap(mk, a.matrix_partition, b.cache.plans), a)
+    return cache[id(a)].handles
+
+
+class _OperatorHandles:
+    def __init__(self, handles, a):
+        self.handles, self.a = handles, a        # `a` stays alive as long as its handles do
+
+    def __del__(self):
+        try:
+            from .primitives import local_items
+            for h in local_items(self.handles):
+                L.lib.pa_matrix_destroy(h)
+        except Exception:
+            pass
+
+
+def mul_c_(c: PVector, a: PSparseMatrix, b: PVector, alpha=1.0, beta=0.0) -> PVector:
+    """mul!(c,a,b[,alpha,beta]) queued by ONE library call per process (pa_mul5 / pa_mul_all, include/pa_hip.h
+    "operator level") instead of five: the same kernels in the same order as mul_ / mul5_, so the same bits.
+    Needs an assembled matrix and either all parts in this process or one part per process over RCCL."""
+    from .primitives import DebugArray, TorchDistArray
+    from . import p_vector as pv
+    _check_axes(c, a, b)
+    vp = b.vector_partition
+    if not a.assembled or not (isinstance(vp, DebugArray) or (isinstance(vp, TorchDistArray) and (
+            vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None)))):
+        return mul5_(c, a, b, alpha, beta)
+    hs = _operator_handles(a, b)
+    if isinstance(vp, DebugArray):
+        n = len(vp.items)
+        arr = lambda xs: (C.c_void_p * n)(*xs)
+        L.call("pa_mul_all", arr(hs.items), n, arr([v.h for v in c.vector_partition.items]), arr([v.h for v in vp.items]),
+               float(alpha), float(beta))
+    else:
+        comm = context().comm.h if (vp.size > 1) else None
+        L.call("pa_mul5", hs.item, comm, c.vector_partition.item.h, vp.item.h, float(alpha), float(beta))
+    return c
+
+
 def mul5_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PVector:
     """mul!(c,a,b,alpha,beta) (src/p_sparse_matrix.jl:2105-2142), assembled and sub-assembled."""
     _check_axes(c, a, b)

@@ -181,6 +181,46 @@ def test_mul5_alpha_beta(orc):
             assert np.array_equal(got, exp[:r.n_own]), (alpha, beta)
 
 
+def test_operator_level_mul_equals_composed_mul(orc):
+    """pa_mul_all / pa_mul5 (one library call per mul!) queue the kernels of mul_ / mul5_ in the same order: same bits.
+    8 parts in one process, and a single part through the one-part-per-process entry point."""
+    import pa_amd._lib as L
+    for P, shape in ((8, (2, 2, 2)), (1, (1, 1, 1))):
+        A, b = pa.build_p_matrix(ranks(P), 8, 6, 10, 8 * shape[0], 6 * shape[1], 10 * shape[2], *shape)
+        g = A.col_partition
+        xf = lambda i: orc.hash_x(i.get_local_to_global()) * (i.get_local_to_owner() == i.part)
+        x1, x2 = pa.pvector_from_function(xf, g), pa.pvector_from_function(xf, g)
+        y0 = lambda i: np.sin(i.get_local_to_global().astype(float))
+        for alpha, beta in ((1.0, 0.0), (-0.75, 2.5)):
+            y1, y2 = pa.pvector_from_function(y0, A.row_partition), pa.pvector_from_function(y0, A.row_partition)
+            pa.mul5_(y1, A, x1, alpha, beta)
+            pa.mul_c_(y2, A, x2, alpha, beta)
+            for u, v in zip(y1.own_values().items, y2.own_values().items):
+                assert np.array_equal(u, v)
+            for u, v in zip(x1.ghost_values().items, x2.ghost_values().items):
+                assert np.array_equal(u, v)
+        if P == 1:                                    # the per-process entry point, no communicator needed
+            blk, xv, yv = A.matrix_partition.items[0], x2.vector_partition.items[0], y2.vector_partition.items[0]
+            m = C.c_void_p()
+            L.call("pa_matrix_create", pa.context().h, blk.own_own.h, blk.own_ghost.h, x2.cache.plans.items[0], C.byref(m))
+            L.call("pa_mul", m, None, yv.h, xv.h)
+            pa.mul_(y1, A, x1)
+            assert np.array_equal(y1.own_values().items[0], yv.own())
+            with pytest.raises(L.PAError):            # matching_own_indices
+                L.call("pa_mul", m, None, pa.DeviceVector(3, 0).h, xv.h)
+            with pytest.raises(L.PAError):            # c and b alias
+                L.call("pa_mul", m, None, xv.h, xv.h)
+            L.call("pa_mul", m, None, yv.h, xv.h)     # the plan is still usable after the refused calls
+            L.call("pa_matrix_destroy", m)
+        else:
+            blk = A.matrix_partition.items[1]
+            m = C.c_void_p()
+            L.call("pa_matrix_create", pa.context().h, blk.own_own.h, blk.own_ghost.h, x2.cache.plans.items[1], C.byref(m))
+            with pytest.raises(L.PAError):            # a part with neighbours needs the communicator
+                L.call("pa_mul", m, None, y2.vector_partition.items[1].h, x2.vector_partition.items[1].h)
+            L.call("pa_matrix_destroy", m)
+
+
 def test_config1_laplacian_64_cubed_4_parts(orc):
     """BASELINE config 1: 7-pt 64^3 on (2,2,1) parts: the reference's CPU-runnable case, vs the oracle."""
     n, parts = (64, 64, 64), (2, 2, 1)
