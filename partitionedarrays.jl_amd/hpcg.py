@@ -45,20 +45,9 @@ class GaussSeidel:
         self.A = A
 
         def make(h, r, c):
-            oo, oh = h
-            # unsplit local CSR: own columns then ghost columns (+n_own), the storage HPCG uses (split_format=false)
-            cnt = np.diff(oo.rowptr.astype(np.int64)) + np.diff(oh.rowptr.astype(np.int64))
-            rowptr = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32)
+            rowptr, colv, val, _ = _unsplit_csr(h, r, c)   # the storage HPCG uses (split_format=false)
             n = r.n_own
-            ro = np.repeat(np.arange(n), np.diff(oo.rowptr.astype(np.int64)))
-            rh = np.repeat(np.arange(n), np.diff(oh.rowptr.astype(np.int64)))
-            rows = np.concatenate([ro, rh])
-            cols = np.concatenate([oo.colval.astype(np.int64), oh.colval.astype(np.int64) + c.n_own])
-            vals = np.concatenate([oo.nzval, oh.nzval])
-            order = np.lexsort((cols, rows))
             g = C.c_void_p()
-            colv = np.ascontiguousarray(cols[order], np.int32)
-            val = np.ascontiguousarray(vals[order])
             L.call("pa_gs_create", context().h, n, c.n_local, len(val), L.ptr(rowptr), L.ptr(colv), L.ptr(val), 1,
                    {"sequential": 0, "multicolor": 1}[ordering], C.byref(g))
             return g
@@ -86,17 +75,12 @@ class GaussSeidel:
 
 
 def _unsplit_csr(h, r, c):
-    """(own_own, own_ghost) -> the unsplit local CSR HPCG stores (n_own x n_local, ghost columns shifted by n_own)."""
-    oo, oh = h
-    n = r.n_own
-    cnt = np.diff(oo.rowptr.astype(np.int64)) + np.diff(oh.rowptr.astype(np.int64))
-    rowptr = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32)
-    rows = np.concatenate([np.repeat(np.arange(n), np.diff(oo.rowptr.astype(np.int64))),
-                           np.repeat(np.arange(n), np.diff(oh.rowptr.astype(np.int64)))])
-    cols = np.concatenate([oo.colval.astype(np.int64), oh.colval.astype(np.int64) + c.n_own])
-    vals = np.concatenate([oo.nzval, oh.nzval])
-    order = np.lexsort((cols, rows))
-    return rowptr, np.ascontiguousarray(cols[order], np.int32), np.ascontiguousarray(vals[order]), rows[order]
+    """(own_own, own_ghost) -> the unsplit local CSR HPCG stores (n_own x n_local, ghost columns shifted by n_own):
+    rowptr (1-based), colval (1-based), nzval, and the 0-based row of every entry.  Both blocks are row-sorted with
+    sorted columns and every ghost column is larger than every own column, so the merge is a placement, not a sort."""
+    blk = _rows_block(h, r, c, np.arange(r.n_own, dtype=np.int64))
+    rows = np.repeat(np.arange(r.n_own), np.diff(blk.rowptr.astype(np.int64)))
+    return blk.rowptr, blk.colval, blk.nzval, rows
 
 
 def _rows_block(h, r, c, f):
