@@ -247,6 +247,29 @@ def main():
     except Exception:
         pass
 
+    # ---- what this box's HBM delivers to the simplest kernels ("re-confirm on the box with a device triad"):
+    # a device-to-device copy and a two-stream read (dot) over vectors far larger than the 256 MiB Infinity Cache
+    box = None
+    if rank == 0 or N > 1:
+        PHASE[0] = "copy / read calibration"
+        m = 1 << 27                                              # 1 GiB per vector
+        va, vb = pa.DeviceVector(m, 0), pa.DeviceVector(m, 0)
+        va.fill(1.0), vb.fill(2.0)
+
+        def ev_time(f, reps=5):
+            f()
+            e0, e1 = ctx.event().record(L.STREAM_COMPUTE), None
+            for _ in range(reps):
+                f()
+            e1 = ctx.event().record(L.STREAM_COMPUTE)
+            ctx.sync()
+            return e0.elapsed_ms(e1) / reps
+        t_copy = ev_time(lambda: L.call("pa_vec_copy", vb.h, va.h, L.SEG_OWN))
+        t_read = ev_time(lambda: L.call("pa_vec_dot_slot", va.h, vb.h, 5, 0))
+        box = {"copy_gbps": round(2 * 8 * m / t_copy / 1e6, 1), "read_gbps": round(2 * 8 * m / t_read / 1e6, 1),
+               "what": "1 GiB vectors: hipMemcpyAsync device-to-device (read+write bytes) and k_dot_partial (two read streams)"}
+        del va, vb
+
     # ---- BASELINE config 4's loop, reported beside the headline (never part of `value`): one CG iteration of
     # HPCG/src/ref_cg.jl (consistent!+mul!, 2 dots + norm, 3 axpys; Identity preconditioner), as the reference
     # schedules it (ref_cg_: a blocking reduction per dot) and as opt_cg_ does (scalars stay on the device).
@@ -287,7 +310,8 @@ def main():
                                                       "column encoding of the chunks: " + json.dumps(blk.own_own.encoding()),
                          "achieved": round(ach, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": bytes_oo, "avg_launch_ms": round(kern_ms, 4)},
+                         "algorithmic_bytes_per_launch": bytes_oo, "avg_launch_ms": round(kern_ms, 4),
+                         "this_box": box},
             "parity_gate": "A*1==b bit-exact; ghosts==owners bit-exact",
             "setup_s": round(t_setup, 1),
         }
