@@ -468,6 +468,33 @@ def test_config4_full_size_256_cubed_eight_parts_on_one_gpu():
     assert res[0] == res[1] and res[0][1] < res[0][0]
 
 
+def test_config5_full_size_fem_4096_squared_eight_parts(orc):
+    """BASELINE config 5 at the size SURVEY 8 names: Q1 FEM Laplacian on 4096 x 4096 nodes, 8 parts as (4,2), the
+    default psparse route (disassembled COO -> assemble -> split).  Size-independent properties: ghosts == owners
+    after consistent!, linearity for power-of-two scalings (bit-exact), and every part's own rows against the C oracle's
+    spmv_csr!/mul!(…,1,1) run on that part's host blocks with the device's ghost values."""
+    n = 4096
+    I, J, V, rows, cols = pa.laplacian_fem((n, n), (4, 2), ranks(8))
+    A = pa.psparse_disassembled(I, J, V, rows, cols, keep_host=True)
+    del I, J, V
+    assert sum(r.n_own for r in A.row_partition.items) == n * n
+    g = A.col_partition
+    xf = lambda i: orc.hash_x(i.get_local_to_global()) * (i.get_local_to_owner() == i.part)
+    x, x4 = pa.pvector_from_function(xf, g), pa.pvector_from_function(lambda i: 4.0 * xf(i), g)
+    y, y4 = pa.pzeros(A.row_partition), pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x)
+    pa.mul_(y4, A, x4)
+    K = orc.oracle_c()
+    for yv, y4v, xv, ind, (oo, oh) in zip(y.own_values().items, y4.own_values().items, x.local_values().items, g.items,
+                                          A.host_blocks.items):
+        assert np.array_equal(xv, orc.hash_x(ind.get_local_to_global()))                 # ghosts == owners
+        assert np.array_equal(4.0 * yv, y4v)
+        want = np.zeros(ind.n_own)
+        K.spmv_csr(want, np.ascontiguousarray(xv[:ind.n_own]), orc.CSR(oo.m, oo.n, oo.rowptr, oo.colval, oo.nzval))
+        K.mul5_csr(want, orc.CSR(oh.m, oh.n, oh.rowptr, oh.colval, oh.nzval), np.ascontiguousarray(xv[ind.n_own:]), 1.0, 1.0)
+        assert np.array_equal(yv, want)
+
+
 # ---------------------------------------------------------------- CG loop (BASELINE config 4 shape, small)
 def test_ref_cg_identity_preconditioner(orc):
     """HPCG/src/ref_cg.jl with Pl = Identity(): consistent!+mul!, 2 dots + norm, 3 axpys per iteration, on 8 parts.
