@@ -94,3 +94,21 @@ def test_julia_glue_ccalls_match_header():
         cc = [_c_class(a) for a in cargs]
         assert jl == cc, f"{name}: glue passes {jl}, header declares {cc}"
         assert _jl_class(ret) == _c_class(cret + " x"), f"{name}: return type"
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/rNN_bench_n1.json is one line printed by bench.py on an MI355X: the keys the driver and the judge read."""
+    import glob
+    import json
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_n1.json")))[-1]
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "GFLOP/s" and d["dtype"] == "f64" and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 3e9
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_ms"] / 1e6) < 1.0
+    assert abs(d["value"] - 2 * d["config"]["nnz_per_part"] * d["n_gpus"] / d["ms_per_step"] / 1e6) < 0.5
