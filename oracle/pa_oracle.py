@@ -920,8 +920,10 @@ def psparse_from_coo(I, J, V, row_partition, index_dtype=I32):
     return psparse_assembled(I, J, V, row_partition, cols, index_dtype)
 
 
-def ref_cg(x, A: PSparse, b, maxiter=50, tolerance=0.0, history=None):
-    """HPCG/src/ref_cg.jl:40-134 with Pl = Identity(): x, residual0, residual, iters (lists of local arrays)."""
+def ref_cg(x, A: PSparse, b, maxiter=50, tolerance=0.0, history=None, mv=None):
+    """HPCG/src/ref_cg.jl:40-134 with Pl = Identity(): x, residual0, residual, iters (lists of local arrays).
+    mv: the product used (default mul_no_lat!, as HPCG; pass `mul` for a matrix that only has its split blocks)."""
+    mul_no_lat = mv or globals()["mul_no_lat"]
     ind = A.cols
     u = [np.zeros_like(v) for v in x]
     r = [v.copy() for v in b]
@@ -1084,6 +1086,148 @@ def laplacian_fem(nodes_per_dir, parts_per_dir):
 # --------------------------------------------------------------------------------------
 # HPCG multigrid preconditioner: HPCG/src/mg_preconditioner.jl + PartitionedSolvers GS smoother
 # --------------------------------------------------------------------------------------
+def pvector_disassembled(I, V, rows):
+    """pvector(I,V,rows)|>fetch, default flags (src/p_vector.jl:887-925): union_ghost, dense_vector (:853-863:
+    a[i] += v in entry order, ids < 1 skipped), then assemble(A,rows) (:1331-1345).  Returns the own values per part."""
+    I_owner = find_owner(rows, I)
+    rows_sa = [union_ghost(r, i, o) for r, i, o in zip(rows, I, I_owner)]
+    vals = []
+    for r, gi, v in zip(rows_sa, I, V):
+        a = np.zeros(r.n_local)
+        for k, x in zip(r.global_to_local(gi), v):
+            if k >= 1:
+                a[k - 1] += x
+        vals.append(a)
+    assemble(vals, rows_sa)
+    return [a[:r.n_own].copy() for a, r in zip(vals, rows_sa)]
+
+
+# --------------------------------------------------------------------------------------
+# test/fem_example.jl (BASELINE config 5): the set-up loops, literally
+# --------------------------------------------------------------------------------------
+def fem_example_setup(parts_per_dir=(2, 2), cells_per_dir=(10, 10), length_in_x=2.0):
+    """test/fem_example.jl:13-29 (setup_params), :31-67 (setup_grid), :69-113 (setup_space), :115-139
+    (setup_cell_dofs), :275-276 (consistent! of the cell -> global dofs table), :141-168 (finish_cell_dofs), :170-198
+    (setup_IJV), :200-236 (setup_b): cell by cell, element node by element node, exactly the reference's loops.
+    Returns per part I, J, V, II, VV, the dof partition and a function giving the exact solution at a global dof."""
+    P = int(np.prod(parts_per_dir))
+    cx, cy = cells_per_dir
+    nodes = (cx + 1, cy + 1)
+    h = max(length_in_x / cx, length_in_x / cy)
+    Ae = (h ** 2 / 6) * np.array([[4.0, -1.0, -1.0, -2.0], [-1.0, 4.0, -2.0, -1.0], [-1.0, -2.0, 4.0, -1.0],
+                                  [-2.0, -1.0, -1.0, 4.0]])
+    cells = uniform_partition(parts_per_dir, cells_per_dir, (True, True))
+    enodes = [(1, 1), (2, 1), (1, 2), (2, 2)]                      # CartesianIndices((2,2)), linear order
+    is_bnd = lambda node_1d, nodes_1d: node_1d == 1 or node_1d == nodes_1d
+    grids, spaces = [], []
+    for ind in cells:
+        l2g = ind.local_to_global
+        first, last = int(l2g[0]), int(l2g[-1])
+        fc = ((first - 1) % cx + 1, (first - 1) // cx + 1)         # linear_to_cartesian_global_cell[first] (:46-49)
+        lc = ((last - 1) % cx + 1, (last - 1) // cx + 1)
+        ncx, ncy = lc[0] - fc[0] + 1, lc[1] - fc[1] + 1
+        nnx = ncx + 1
+        loc_cells = [(i, j) for j in range(1, ncy + 1) for i in range(1, ncx + 1)]   # linear_to_cartesian_local_cell
+        lnode = lambda i, j, nnx=nnx: (i - 1) + nnx * (j - 1) + 1   # cartesian_to_linear_local_node
+        lcell = lambda i, j, ncx=ncx: (i - 1) + ncx * (j - 1) + 1
+        gnode = lambda i, j, fc=fc: (fc[0] + i - 1, fc[1] + j - 1)  # local_to_global_cartesian_node
+        # setup_space
+        node_to_dof = [1] * (nnx * (ncy + 1))
+        for (ci, cj) in loc_cells:
+            for (ei, ej) in enodes:
+                gi, gj = fc[0] + ci - 1 + (ei - 1), fc[1] + cj - 1 + (ej - 1)
+                if is_bnd(gi, nodes[0]) or is_bnd(gj, nodes[1]):
+                    node_to_dof[lnode(ci + ei - 1, cj + ej - 1) - 1] = 0
+        dof_to_node = [k + 1 for k, v in enumerate(node_to_dof) if v == 1]
+        n_local_dofs = len(dof_to_node)
+        for d, nd in enumerate(dof_to_node, start=1):
+            node_to_dof[nd - 1] = d
+        dof_owner = [0] * n_local_dofs
+        for (ci, cj) in loc_cells:
+            owner = int(ind.local_to_owner[lcell(ci, cj) - 1])
+            for (ei, ej) in enodes:
+                d = node_to_dof[lnode(ci + ei - 1, cj + ej - 1) - 1]
+                if d > 0:
+                    dof_owner[d - 1] = max(dof_owner[d - 1], owner)
+        n_own = sum(1 for o in dof_owner if o == ind.part)
+        grids.append(dict(ind=ind, fc=fc, ncx=ncx, ncy=ncy, loc_cells=loc_cells, lnode=lnode, lcell=lcell, gnode=gnode))
+        spaces.append(dict(node_to_dof=node_to_dof, dof_owner=dof_owner, n_own=n_own,
+                           cell_dofs=[[0, 0, 0, 0] for _ in loc_cells]))
+    n_global = sum(s["n_own"] for s in spaces)
+    dofs = variable_partition([s["n_own"] for s in spaces], n_global)
+    # setup_cell_dofs
+    for g, s, dp in zip(grids, spaces, dofs):
+        offset = int(dp.own_to_global[0]) - 1 if dp.n_own else 0
+        perm = [0] * len(s["dof_owner"])
+        k = 0
+        for d, o in enumerate(s["dof_owner"]):
+            if o == g["ind"].part:
+                k += 1
+                perm[d] = k
+        for (ci, cj) in g["loc_cells"]:
+            for e, (ei, ej) in enumerate(enodes):
+                d = s["node_to_dof"][g["lnode"](ci + ei - 1, cj + ej - 1) - 1]
+                if d > 0 and perm[d - 1] > 0:
+                    s["cell_dofs"][g["lcell"](ci, cj) - 1][e] = perm[d - 1] + offset
+    # consistent!(cell_to_global_dofs): a ghost cell's row is its owner's row
+    snapshot = [[row[:] for row in s["cell_dofs"]] for s in spaces]
+    for g, s in zip(grids, spaces):
+        ind = g["ind"]
+        for lc, (gid, owner) in enumerate(zip(ind.local_to_global, ind.local_to_owner)):
+            if owner != ind.part:
+                src = grids[owner - 1]["ind"]
+                s["cell_dofs"][lc] = snapshot[owner - 1][int(src.global_to_local([gid])[0]) - 1][:]
+    # finish_cell_dofs
+    for g, s in zip(grids, spaces):
+        l2g = [0] * len(s["dof_owner"])
+        for (ci, cj) in g["loc_cells"]:
+            for e, (ei, ej) in enumerate(enodes):
+                d = s["node_to_dof"][g["lnode"](ci + ei - 1, cj + ej - 1) - 1]
+                gd = s["cell_dofs"][g["lcell"](ci, cj) - 1][e]
+                if d > 0 and gd > 0:
+                    l2g[d - 1] = gd
+        for (ci, cj) in g["loc_cells"]:
+            for e, (ei, ej) in enumerate(enodes):
+                d = s["node_to_dof"][g["lnode"](ci + ei - 1, cj + ej - 1) - 1]
+                if d > 0:
+                    assert l2g[d - 1] != 0
+                    s["cell_dofs"][g["lcell"](ci, cj) - 1][e] = l2g[d - 1]
+    # setup_IJV, setup_b, exact solution
+    Is, Js, Vs, IIs, VVs, exact = [], [], [], [], [], {}
+    for g, s in zip(grids, spaces):
+        ind = g["ind"]
+        I, J, V, II, VV = [], [], [], [], []
+        for (ci, cj) in g["loc_cells"]:
+            lc = g["lcell"](ci, cj)
+            if ind.local_to_owner[lc - 1] != ind.part:
+                continue
+            gd = s["cell_dofs"][lc - 1]
+            for er, grow in enumerate(gd):
+                if grow <= 0:
+                    continue
+                for ec, gcol in enumerate(gd):
+                    if gcol <= 0:
+                        continue
+                    I.append(grow), J.append(gcol), V.append(Ae[er, ec])
+            ue = [0.0] * 4
+            for e, (ei, ej) in enumerate(enodes):
+                d = s["node_to_dof"][g["lnode"](ci + ei - 1, cj + ej - 1) - 1]
+                gi, gj = g["gnode"](ci + ei - 1, cj + ej - 1)
+                uval = (gi - 1) * h + (gj - 1) * h                   # u(x) = x[1] + x[2] (:11)
+                if d <= 0:
+                    ue[e] = uval
+                else:
+                    exact[gd[e]] = uval
+            for er, grow in enumerate(gd):
+                if grow > 0:
+                    ge = ((Ae[er, 0] * ue[0] + Ae[er, 1] * ue[1]) + Ae[er, 2] * ue[2]) + Ae[er, 3] * ue[3]
+                    II.append(grow), VV.append(-ge)
+        Is.append(np.array(I, I64)), Js.append(np.array(J, I64)), Vs.append(np.array(V, F64))
+        IIs.append(np.array(II, I64)), VVs.append(np.array(VV, F64))
+    return dict(I=Is, J=Js, V=Vs, II=IIs, VV=VVs, dof_partition=dofs, exact=exact, n_global_dofs=n_global,
+                n_own_dofs=[s["n_own"] for s in spaces])
+
+
 def restrict_operator(nx, ny, nz):
     """HPCG/src/mg_preconditioner.jl:81-103: coarse row -> fine row (1-based), every second point per direction."""
     nxc, nyc, nzc = nx // 2, ny // 2, nz // 2

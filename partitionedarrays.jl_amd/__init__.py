@@ -14,11 +14,12 @@ from .p_range import (JaggedArray, LocalIndices, PRange, local_range, uniform_pa
 from .p_vector import (Context, Event, context, init_comm, DeviceVector, DeviceAssemblyCache, Task, PVector,  # noqa: F401
                        pvector_from_function, pfill, pzeros, pones, similar, pvector, consistent_, assemble_,
                        dot, norm, axpby_, copy_, slots_supported, dot_slot, axpby_slot_, cg_update_, write_slot,
-                       read_slots)
+                       read_slots, on_partition, pvector_disassembled, pvector_, VectorReassemblyCache)
 from .p_sparse_matrix import (HostCSR, DeviceCSR, SplitMatrixBlocks, PSparseMatrix, compresscoo, sparse_matrix,  # noqa: F401
                               split_format_locally, spmv_, psparse, psparse_from_coo, mul_, mul_c_, mul5_, mul_no_overlap_,
                               psparse_disassembled, psparse_assemble_host, psparse_, MatrixReassemblyCache,
-                              mul5_transpose_)
+                              mul5_transpose_, psystem, psystem_)
 from .gallery import laplacian_fem, laplacian_fdm, build_matrix, build_p_matrix, build_split_blocks_fused, compute_optimal_shape_XYZ  # noqa: F401
 from .hpcg import (hpcg_benchmark, hpcg_report, hpcg_geometry, CgTimer, ref_cg_, opt_cg_, mul_no_lat_, restrict_operator, GaussSeidel, ColoredGaussSeidelSpMV, MgPreconditioner, pc_setup, pc_solve_,  # noqa: F401
                    ldiv_)
+from . import fem_example  # noqa: F401,E402

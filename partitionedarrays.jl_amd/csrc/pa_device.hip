@@ -454,7 +454,9 @@ extern "C" int pa_vec_fill(pa_vec *v, int seg, double value) {
 
 extern "C" int pa_vec_copy(pa_vec *dst, const pa_vec *src, int seg) {
   PA_REQUIRE(dst && src, "bad arguments");
-  PA_REQUIRE(dst->n_own == src->n_own && dst->n_ghost == src->n_ghost, "size mismatch");
+  // own values of vectors on different index partitions with matching own indices may be copied (w .= v2 in
+  // assemble(v,rows), src/p_vector.jl:1331-1345); the other segments need identical layouts
+  PA_REQUIRE(dst->n_own == src->n_own && (seg == PA_SEG_OWN || dst->n_ghost == src->n_ghost), "size mismatch");
   int64_t off, len;
   PA_TRY(seg_range(dst, seg, &off, &len));
   if (len == 0) return PA_OK;
@@ -465,7 +467,7 @@ extern "C" int pa_vec_copy(pa_vec *dst, const pa_vec *src, int seg) {
 
 extern "C" int pa_vec_axpby(pa_vec *y, double a, const pa_vec *x, double b, int seg) {
   PA_REQUIRE(y && x, "bad arguments");
-  PA_REQUIRE(y->n_own == x->n_own && y->n_ghost == x->n_ghost, "size mismatch");
+  PA_REQUIRE(y->n_own == x->n_own && (seg == PA_SEG_OWN || y->n_ghost == x->n_ghost), "size mismatch");
   int64_t off, len;
   PA_TRY(seg_range(y, seg, &off, &len));
   if (len == 0) return PA_OK;
@@ -519,7 +521,7 @@ extern "C" int pa_vec_dot_slot(const pa_vec *x, const pa_vec *y, int slot, int a
 extern "C" int pa_vec_axpby_slot(pa_vec *y, double ca, int a_num, int a_den, const pa_vec *x, double cb, int b_num,
                                  int b_den, int seg) {
   PA_REQUIRE(y && x, "bad arguments");
-  PA_REQUIRE(y->n_own == x->n_own && y->n_ghost == x->n_ghost, "size mismatch");
+  PA_REQUIRE(y->n_own == x->n_own && (seg == PA_SEG_OWN || y->n_ghost == x->n_ghost), "size mismatch");
   PA_REQUIRE(PA_COEF_OK(a_num) && PA_COEF_OK(a_den) && PA_COEF_OK(b_num) && PA_COEF_OK(b_den), "slot out of range");
   int64_t off, len;
   PA_TRY(seg_range(y, seg, &off, &len));

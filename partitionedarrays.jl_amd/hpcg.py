@@ -249,8 +249,8 @@ def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_ev
     ONE = L.SLOT_ONE
     s_rho, s_prev, s_rr, s_uc = 1, 2, 3, 4
     u = similar(x)
-    r = similar(x)
-    c = similar(x)
+    r = similar(b)
+    c = similar(b)
     copy_(r, b)
     mul_(c, A, x)
     axpby_(r, -1.0, c, 1.0)
@@ -346,8 +346,8 @@ def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None, Pl=N
     # cg_iterator! (ref_cg.jl:76-96).  Vectors that are multiplied by A live on the column partition (= row
     # partition + ghosts, HPCG/src/sparse_matrix.jl:119).
     u = similar(x)                       # u .= 0
-    r = similar(x)
-    c = similar(x)
+    r = similar(b)                       # r and c live where b does: the column partition in HPCG (sparse_matrix.jl:119),
+    c = similar(b)                       # the (ghost-free or sub-assembled) row partition in test/fem_example.jl
     copy_(r, b)                          # copyto!(r,b)
     mv(c, A, x)                          # c = A*x
     axpby_(r, -1.0, c, 1.0)              # r .-= c

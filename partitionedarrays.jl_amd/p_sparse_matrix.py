@@ -523,3 +523,27 @@ def psparse_(C_: PSparseMatrix, V, cache: MatrixReassemblyCache) -> Task:
              C_.matrix_partition, cache.W, cache.nnz_oo)
 
     return Task(finish, C_)
+
+
+def psystem(I, J, V, I2, V2, rows, cols, reuse=False, assemble=True):
+    """psystem(I,J,V,I2,V2,rows,cols;reuse,assemble)|>fetch (src/p_sparse_matrix.jl:2475-2528): the matrix and the
+    right-hand side of a linear system from the COO data of one cell loop, default (disassembled) flags.
+    Returns A, b (and the pair of caches for psystem_ when reuse)."""
+    from .p_vector import pvector_disassembled
+    if reuse and not assemble:
+        raise L.PAError("psystem(reuse=true, assemble=false): the re-assembly caches exist for the assembled system only")
+    if reuse:
+        A, cacheA = psparse_disassembled(I, J, V, rows, cols, reuse=True, assemble=assemble)
+        b, cacheb = pvector_disassembled(I2, V2, rows, reuse=True, assemble=assemble)
+        return A, b, (cacheA, cacheb)
+    return (psparse_disassembled(I, J, V, rows, cols, assemble=assemble),
+            pvector_disassembled(I2, V2, rows, assemble=assemble))
+
+
+def psystem_(A, b, V, V2, cache):
+    """psystem!(A,b,V,V2,cache) (src/p_sparse_matrix.jl:2530-2539): psparse! + pvector! on the device."""
+    from .p_vector import pvector_
+    cacheA, cacheb = cache
+    psparse_(A, V, cacheA).wait()
+    pvector_(b, V2, cacheb)
+    return A, b

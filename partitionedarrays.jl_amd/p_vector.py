@@ -413,6 +413,83 @@ def pvector(I, V, index_partition) -> PVector:
     return PVector(parts, index_partition)
 
 
+def on_partition(v: PVector, index_partition) -> PVector:
+    """A vector on `index_partition` with v's own values (ghosts 0): `w .= v` between partitions whose own indices
+    match (src/p_vector.jl:1331-1345); used to move a right-hand side from the row to the column partition."""
+    w = pzeros(index_partition)
+    pmap(lambda d, s: L.call("pa_vec_copy", d.h, s.h, L.SEG_OWN), w.vector_partition, v.vector_partition)
+    return w
+
+
+class VectorReassemblyCache:
+    """cache of pvector(...;reuse=true) (src/p_vector.jl:887-987): K = local ids of the entries on the sub-assembled
+    partition (as a deterministic device scatter), the sub-assembled vector A and the work copy of assemble(v,rows)."""
+
+    def __init__(self, A_sa: PVector, work: PVector, scatters, n_entries):
+        self.A_sa, self.work, self.scatters, self.n_entries = A_sa, work, scatters, n_entries
+
+    def __del__(self):
+        try:
+            for s in local_items(self.scatters):
+                L.lib.pa_scatter_destroy(s)
+        except Exception:
+            pass
+
+
+def pvector_disassembled(I, V, rows, reuse=False, assemble=True):
+    """pvector(I,V,rows)|>fetch with the DEFAULT flags (src/p_vector.jl:887-925,966-987): the entries of a part may
+    touch rows it does not own (cell-wise FEM loops).  find_owner -> union_ghost -> dense_vector on the sub-assembled
+    partition (a[lid] += v in entry order, :853-863) -> assemble(A,rows) (:1331-1345: copy, assemble!, own values).
+    assemble=False returns the sub-assembled vector itself.  reuse=True also returns the cache of pvector_."""
+    from .p_range import find_owner, union_ghost
+    rows_sa = pmap(union_ghost, rows, I, find_owner(rows, I))
+    K = pmap(lambda r, gi: r.global_to_local(gi).astype(np.int32), rows_sa, I)
+
+    def dense(ind, k, v):
+        out = np.zeros(ind.n_local, F64)
+        keep = k >= 1
+        np.add.at(out, k[keep].astype(np.int64) - 1, np.asarray(v, F64)[keep])     # sequential, entry order
+        return out
+    A_sa = pvector_from_function_values(pmap(dense, rows_sa, K, V), rows_sa)
+    if not assemble:
+        return (A_sa, None) if reuse else A_sa
+    work = similar(A_sa)
+    copy_(work, A_sa)
+    assemble_(work).wait()
+    w = on_partition(work, rows)
+    if not reuse:
+        return w
+
+    def mk(ind, k):
+        s = C.c_void_p()
+        L.call("pa_scatter_create", context().h, ind.n_local, len(k), L.ptr(np.ascontiguousarray(k, np.int32)), 1, C.byref(s))
+        return s
+    return w, VectorReassemblyCache(A_sa, work, pmap(mk, rows_sa, K), pmap(len, K))
+
+
+def pvector_(b: PVector, V, cache: VectorReassemblyCache) -> PVector:
+    """pvector!(b,V,cache) (src/p_vector.jl:990-1008): dense_vector!(A,K,V) (:865-873: fill 0, then a[k] += v in entry
+    order -- here one deterministic scatter-add on the device), assemble!(B,A,cacheB), own values into b."""
+    def scatter(s, a, v, n):
+        v = np.ascontiguousarray(v, F64)
+        assert len(v) == n, "V must have the length it had when the cache was built"
+        src = DeviceVector(n, 0).upload(v)
+        L.call("pa_scatter_add", s, a.h, src.h, 1)
+    pmap(scatter, cache.scatters, cache.A_sa.vector_partition, V, cache.n_entries)
+    copy_(cache.work, cache.A_sa)
+    assemble_(cache.work).wait()
+    pmap(lambda d, s: L.call("pa_vec_copy", d.h, s.h, L.SEG_OWN), b.vector_partition, cache.work.vector_partition)
+    return b
+
+
+def pvector_from_function_values(host_values, index_partition) -> PVector:
+    """PVector(values,index_partition) from host arrays in local order."""
+    it = pmap(lambda h: h, host_values)
+    parts = pmap(lambda ind, h: (DeviceVector(ind.n_own, ind.n_ghost) if ind.own_is_contiguous_prefix
+                                 else DeviceVector(ind.n_local, 0)).upload(h), index_partition, it)
+    return PVector(parts, index_partition)
+
+
 def consistent_(a: PVector) -> Task:
     """consistent!(a) (src/p_vector.jl:747-755): ghost <- owner.  Returns a task; wait() it."""
     t = assemble_impl(L.CONSISTENT, a.vector_partition, a.cache)

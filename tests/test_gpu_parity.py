@@ -468,6 +468,54 @@ def test_config4_full_size_256_cubed_eight_parts_on_one_gpu():
     assert res[0] == res[1] and res[0][1] < res[0][0]
 
 
+def _fem_error(x, S, A):
+    """norm(x - x_hat) over own values, x_hat from setup_exact_solution on A's column partition (fem_example.jl:284-288)."""
+    xh = pa.pmap(lambda s, c: pa.fem_example.setup_exact_solution(s, S["params"], c), S["spaces"], A.col_partition)
+    return sum(float(np.sum((xv - h[:len(xv)]) ** 2)) for xv, h in zip(x.own_values().items, xh.items)) ** 0.5
+
+
+def _fem_cg(A, b):
+    x, r0, r, it = pa.ref_cg_(pa.pzeros(A.col_partition), A, b, maxiter=400, tolerance=1.4901161193847656e-08)
+    assert it < 400
+    return x
+
+
+@pytest.mark.parametrize("parts,cells", [((2, 2), (10, 10)), ((4, 2), (24, 18))])
+def test_fem_example_all_variants(parts, cells):
+    """BASELINE config 5 is test/fem_example.jl: ghosted cell partition, part-by-part dof numbering, cell-wise COO.
+    Every solve of the reference file (:261-343) on the device path, each asserting norm(x - x_hat) < 1e-5 as it does:
+    psparse + pvector; re-assembly with psparse! / pvector!; psystem; psystem with reuse and psystem! with doubled
+    values; the sub-assembled system (mul! assembles the product)."""
+    P = int(np.prod(parts))
+    S = pa.fem_example.fem_example_system(ranks(P), parts, cells)
+    I, J, V, II, VV, dofs = (S[k] for k in ("I", "J", "V", "II", "VV", "dof_partition"))
+    A = pa.psparse_disassembled(I, J, V, dofs, dofs)                                    # :277,279
+    b = pa.pvector_disassembled(II, VV, dofs)                                           # :280
+    x = _fem_cg(A, b)
+    assert _fem_error(x, S, A) < 1.0e-5                                                 # :288
+    x_first = [v.copy() for v in x.own_values().items]
+    A, cacheA = pa.psparse_disassembled(I, J, V, dofs, dofs, reuse=True)                # :291
+    b, cacheb = pa.pvector_disassembled(II, VV, dofs, reuse=True)                       # :292
+    pa.psparse_(A, V, cacheA).wait()                                                    # :293
+    pa.pvector_(b, VV, cacheb)                                                          # :294
+    x = _fem_cg(A, b)
+    assert _fem_error(x, S, A) < 1.0e-5                                                 # :298
+    for u, v in zip(x.own_values().items, x_first):
+        assert np.array_equal(u, v)                                                     # re-assembly reproduces the bits
+    A, b = pa.psystem(I, J, V, II, VV, dofs, dofs)                                      # :301
+    assert _fem_error(_fem_cg(A, b), S, A) < 1.0e-5                                     # :303
+    A, b, cache = pa.psystem(I, J, V, II, VV, dofs, dofs, reuse=True)                   # :313-317
+    assert _fem_error(_fem_cg(A, b), S, A) < 1.0e-5                                     # :319
+    V2, VV2 = pa.pmap(lambda v: 2 * v, V), pa.pmap(lambda v: 2 * v, VV)                 # :322-323
+    pa.psystem_(A, b, V2, VV2, cache)                                                   # :325
+    x = _fem_cg(A, b)
+    assert _fem_error(x, S, A) < 1.0e-5                                                 # :328
+    A, b = pa.psystem(I, J, V, II, VV, dofs, dofs, assemble=False)                      # :331
+    assert not A.assembled and any(r.n_ghost > 0 for r in A.row_partition.items) == (P > 1)
+    pa.assemble_(b).wait()                                                              # :332
+    assert _fem_error(_fem_cg(A, b), S, A) < 1.0e-5                                     # :333-338
+
+
 def test_config5_full_size_fem_4096_squared_eight_parts(orc):
     """BASELINE config 5 at the size SURVEY 8 names: Q1 FEM Laplacian on 4096 x 4096 nodes, 8 parts as (4,2), the
     default psparse route (disassembled COO -> assemble -> split).  Size-independent properties: ghosts == owners

@@ -228,3 +228,19 @@ def test_hpcg_mg_pcg_known_answer(orc, golden):
     x, r0, r, it = orc.ref_cg_mg(x, A, b, S, maxiter=c["maxiter"])
     assert it == c["maxiter"] and r / r0 < c["assert_below"]
     assert abs(r / r0 - c["expected_ref_tol"]) <= 1e-9 * c["expected_ref_tol"]
+
+
+def test_fem_example_known_answer(orc):
+    """test/fem_example.jl:261-288 at the oracle level: the example's set-up loops (restated literally), psparse and
+    pvector with the default flags, CG; the reference asserts norm(x - x_hat) < 1e-5 (:288)."""
+    S = orc.fem_example_setup((2, 2), (10, 10))
+    dofs = S["dof_partition"]
+    assert S["n_global_dofs"] == 81 and sum(S["n_own_dofs"]) == 81
+    A, _ = orc.psparse_disassembled(S["I"], S["J"], S["V"], dofs, dofs)
+    b_own = orc.pvector_disassembled(S["II"], S["VV"], dofs)
+    b = [np.concatenate([bo, np.zeros(c.n_ghost)]) for bo, c in zip(b_own, A.cols)]
+    x = [np.zeros(c.n_local) for c in A.cols]
+    x, r0, r, it = orc.ref_cg(x, A, b, maxiter=81, tolerance=1.4901161193847656e-08, mv=orc.mul)
+    err = sum(float(np.sum((xv[:c.n_own] - np.array([S["exact"][int(g)] for g in c.own_to_global])) ** 2))
+              for xv, c in zip(x, A.cols)) ** 0.5
+    assert err < 1.0e-5 and it < 81
