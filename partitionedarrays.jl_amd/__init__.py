@@ -14,7 +14,8 @@ from .p_range import (JaggedArray, LocalIndices, PRange, local_range, uniform_pa
 from .p_vector import (Context, Event, context, init_comm, DeviceVector, DeviceAssemblyCache, Task, PVector,  # noqa: F401
                        pvector_from_function, pfill, pzeros, pones, similar, pvector, consistent_, assemble_,
                        dot, norm, axpby_, copy_, slots_supported, dot_slot, axpby_slot_, cg_update_, write_slot,
-                       read_slots, on_partition, pvector_disassembled, pvector_, VectorReassemblyCache)
+                       read_slots, on_partition, pvector_disassembled, pvector_, VectorReassemblyCache,
+                       pvector_from_function_values)
 from .p_sparse_matrix import (HostCSR, DeviceCSR, SplitMatrixBlocks, PSparseMatrix, compresscoo, sparse_matrix,  # noqa: F401
                               split_format_locally, spmv_, psparse, psparse_from_coo, mul_, mul_c_, mul5_, mul_no_overlap_,
                               psparse_disassembled, psparse_assemble_host, psparse_, MatrixReassemblyCache,

@@ -69,8 +69,10 @@ def setup_space(cell_indices, params) -> PartSpace:
     cell_nodes = np.stack([(ci + di) + nnx * (cj + dj) for di, dj in ELEMENT_NODES], axis=1)
     cell_dofs_local = node_to_dof[cell_nodes]
     dof_owner = np.zeros(len(dof_node), I64)                 # max over the touching local cells (:90-101)
-    m = cell_dofs_local > 0
-    np.maximum.at(dof_owner, cell_dofs_local[m] - 1, np.broadcast_to(owner[:, None], m.shape)[m])
+    for e in range(4):                                       # a node is the e-th node of at most one cell
+        d = cell_dofs_local[:, e]
+        m = d > 0
+        dof_owner[d[m] - 1] = np.maximum(dof_owner[d[m] - 1], owner[m])
     return PartSpace(cell_indices.part, (int(fx), int(fy), ncx, ncy), owner, cell_dofs_local, dof_owner, dof_node,
                      int(np.count_nonzero(dof_owner == cell_indices.part)))
 

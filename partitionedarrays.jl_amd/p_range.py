@@ -242,15 +242,26 @@ def uniform_partition(ranks, np_, n, ghost=None, periodic=None):
                 if i >= len(my):
                     break
             owners.append(my)
-        lens = [hi - lo + 1 for lo, hi in local_ranges]
-        l2g, l2o = [], []
-        for rev in itertools.product(*[range(k) for k in reversed(lens)]):      # column-major (:648)
-            ci = tuple(reversed(rev))
-            is_own = all(own_ranges[d][0] <= local_ranges[d][0] + ci[d] <= own_ranges[d][1] for d in range(len(n)))
-            gci = tuple(((local_ranges[d][0] + ci[d] - 1) % n[d]) + 1 for d in range(len(n)))   # CircularArray
-            l2g.append(_linear(gci, n))
-            l2o.append(rank if is_own else _linear(tuple(owners[d][ci[d]] for d in range(len(n))), np_))
-        return LocalIndices(n_global, rank, local_to_global=np.array(l2g, I64), local_to_owner=np.array(l2o, I32))
+        # column-major over the local box (:648): per dimension the global coordinate (CircularArray wrap) and the
+        # owner coordinate of every local coordinate, combined by broadcasting (dimension 0 fastest)
+        D = len(n)
+        l2g = np.zeros((), I64)
+        l2o = np.zeros((), I64)
+        is_own = np.ones((), bool)
+        gstride, ostride = 1, 1
+        for d in range(D):
+            lo, hi = local_ranges[d]
+            shape = [1] * D
+            shape[D - 1 - d] = hi - lo + 1                                     # axis 0 slowest ... last fastest
+            c = np.arange(lo, hi + 1, dtype=I64)
+            l2g = l2g + (((c - 1) % n[d]).reshape(shape)) * gstride
+            l2o = l2o + ((np.asarray(owners[d], I64) - 1).reshape(shape)) * ostride
+            is_own = is_own & ((c >= own_ranges[d][0]) & (c <= own_ranges[d][1])).reshape(shape)
+            gstride *= n[d]
+            ostride *= np_[d]
+        l2o = np.where(is_own, rank - 1, l2o)
+        return LocalIndices(n_global, rank, local_to_global=(l2g + 1).ravel().astype(I64),
+                            local_to_owner=(l2o + 1).ravel().astype(I32))
 
     indices = pmap(block, ranks)
     if ghost is not None:

@@ -543,6 +543,44 @@ def test_config5_full_size_fem_4096_squared_eight_parts(orc):
         assert np.array_equal(yv, want)
 
 
+def test_fem_example_full_size_4096_squared_cells(orc):
+    """test/fem_example.jl itself at BASELINE config 5's size: 4096 x 4096 cells on (4,2) parts (16.8 M free dofs, the
+    dof partition is 1-D by part while the geometry is 2-D blocks: every part has interface dofs owned by up to three
+    other parts).  psparse + pvector with the default flags, then the size-independent checks: ghosts == owners,
+    linearity (bit-exact), every part's own rows against the C oracle on that part's host blocks, and the right-hand
+    side against the oracle's pvector on a coarser copy of the same problem is covered by the small-size tests."""
+    n = 4096
+    S = pa.fem_example.fem_example_system(ranks(8), (4, 2), (n, n))
+    dofs = S["dof_partition"]
+    assert S["n_global_dofs"] == (n - 1) ** 2
+    A = pa.psparse_disassembled(S["I"], S["J"], S["V"], dofs, dofs, keep_host=True)
+    b = pa.pvector_disassembled(S["II"], S["VV"], dofs)
+    assert sum(bk.own_own.nnz + bk.own_ghost.nnz for bk in A.matrix_partition.items) == (3 * (n - 1) - 2) ** 2
+    g = A.col_partition
+    xf = lambda i: orc.hash_x(i.get_local_to_global()) * (i.get_local_to_owner() == i.part)
+    x, x4 = pa.pvector_from_function(xf, g), pa.pvector_from_function(lambda i: 4.0 * xf(i), g)
+    y, y4 = pa.pzeros(A.row_partition), pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x)
+    pa.mul_(y4, A, x4)
+    K = orc.oracle_c()
+    for yv, y4v, xv, ind, (oo, oh) in zip(y.own_values().items, y4.own_values().items, x.local_values().items, g.items,
+                                          A.host_blocks.items):
+        assert np.array_equal(xv, orc.hash_x(ind.get_local_to_global()))
+        assert np.array_equal(4.0 * yv, y4v)
+        want = np.zeros(ind.n_own)
+        K.spmv_csr(want, np.ascontiguousarray(xv[:ind.n_own]), orc.CSR(oo.m, oo.n, oo.rowptr, oo.colval, oo.nzval))
+        K.mul5_csr(want, orc.CSR(oh.m, oh.n, oh.rowptr, oh.colval, oh.nzval), np.ascontiguousarray(xv[ind.n_own:]), 1.0, 1.0)
+        assert np.array_equal(yv, want)
+    # the assembled right-hand side is non-zero only next to the Dirichlet boundary; A*x_hat reproduces it (the
+    # discrete solution of this problem IS u = x + y: bilinear elements represent it exactly)
+    xh = pa.pvector_from_function_values(pa.pmap(lambda s, c: pa.fem_example.setup_exact_solution(s, S["params"], c),
+                                                 S["spaces"], g), g)
+    pa.consistent_(xh).wait()
+    pa.mul_(y, A, xh)
+    for yv, bv in zip(y.own_values().items, b.own_values().items):
+        assert np.allclose(yv, bv, rtol=0, atol=1e-12) and np.count_nonzero(bv) < 4 * 4 * n
+
+
 # ---------------------------------------------------------------- CG loop (BASELINE config 4 shape, small)
 def test_ref_cg_identity_preconditioner(orc):
     """HPCG/src/ref_cg.jl with Pl = Identity(): consistent!+mul!, 2 dots + norm, 3 axpys per iteration, on 8 parts.
