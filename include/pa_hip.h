@@ -198,6 +198,17 @@ int pa_mul(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b);
 int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta);
 int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta);
 
+/* ---- hipGraph capture: a launch-bound loop body is queued once, captured, and replayed ------------------------------
+ * Between pa_graph_begin and pa_graph_end nothing runs: every asynchronous entry point (pa_spmv, pa_exchange_pack /
+ * _local / _finish, pa_vec_axpby*, pa_vec_dot_slot, pa_cg_update, pa_mul*, pa_gs_color_sweep, ...) is recorded from the
+ * compute stream (the comm stream joins through the exchange's events); calls that synchronise or allocate
+ * (pa_vec_download, pa_ctx_read_*, pa_*_create) are not allowed inside.  pa_graph_launch replays on the compute stream. */
+typedef struct pa_graph pa_graph;
+int pa_graph_begin(pa_ctx *ctx);
+int pa_graph_end(pa_ctx *ctx, pa_graph **g);
+int pa_graph_launch(pa_graph *g);
+int pa_graph_destroy(pa_graph *g);
+
 /* ---- deterministic scatter-add maps: sparse_matrix!(A,V,K) (src/sparse_utils.jl:454-466) -------------------- */
 /* dst[dest[p]] += src[p] for p ascending (entries with dest[p] < index_base are skipped, as `k < 1` is there);
  * one lane per distinct destination adds its sources in ascending p: the reference's order, no atomics.

@@ -11,7 +11,7 @@ from .primitives import (MAIN, DebugArray, TorchDistArray, ExchangeGraph, with_d
                          find_rcv_ids_gather_scatter, is_consistent)
 from .p_range import (JaggedArray, LocalIndices, PRange, local_range, uniform_partition, variable_partition,  # noqa: F401
                       find_owner, filter_ghost, union_ghost, assembly_neighbors, assembly_local_indices)
-from .p_vector import (Context, Event, context, init_comm, DeviceVector, DeviceAssemblyCache, Task, PVector,  # noqa: F401
+from .p_vector import (Context, Event, Graph, context, init_comm, DeviceVector, DeviceAssemblyCache, Task, PVector,  # noqa: F401
                        pvector_from_function, pfill, pzeros, pones, similar, pvector, consistent_, assemble_,
                        dot, norm, axpby_, copy_, slots_supported, dot_slot, axpby_slot_, cg_update_, write_slot,
                        read_slots, on_partition, pvector_disassembled, pvector_, VectorReassemblyCache,

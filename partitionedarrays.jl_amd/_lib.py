@@ -63,6 +63,10 @@ _SIGS = {
     "pa_vec_dot": [P, P, C.POINTER(f64)],
     "pa_vec_dot_result": [P, PP],
     "pa_ctx_read_scalar": [P, C.POINTER(f64)],
+    "pa_graph_begin": [P],
+    "pa_graph_end": [P, PP],
+    "pa_graph_launch": [P],
+    "pa_graph_destroy": [P],
     "pa_matrix_create": [P, P, P, P, PP],
     "pa_matrix_destroy": [P],
     "pa_mul": [P, P, P, P],

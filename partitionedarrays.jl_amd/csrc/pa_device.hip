@@ -1517,3 +1517,51 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
   }
   return PA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// hipGraph capture of whatever the entry points queue (launch-bound loops: a CG iteration of a small part is
+// ~10 kernels of a few microseconds each)
+// ------------------------------------------------------------------------------------------------
+extern "C" int pa_graph_begin(pa_ctx *c) {
+  PA_REQUIRE(c != nullptr, "ctx is NULL");
+  PA_REQUIRE(!c->capturing, "a capture is already open on this context");
+  PA_HIP(hipSetDevice(c->device));
+  PA_HIP(hipStreamBeginCapture(c->s[0], hipStreamCaptureModeThreadLocal));
+  c->capturing = true;
+  return PA_OK;
+}
+
+extern "C" int pa_graph_end(pa_ctx *c, pa_graph **out) {
+  PA_REQUIRE(c && out, "bad arguments");
+  PA_REQUIRE(c->capturing, "pa_graph_end without pa_graph_begin");
+  c->capturing = false;
+  hipGraph_t graph = nullptr;
+  PA_HIP(hipStreamEndCapture(c->s[0], &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    pa_set_err("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return PA_ERR_HIP;
+  }
+  pa_graph *g = new pa_graph();
+  g->ctx = c; g->exec = exec;
+  *out = g;
+  return PA_OK;
+}
+
+extern "C" int pa_graph_launch(pa_graph *g) {
+  PA_REQUIRE(g != nullptr, "graph is NULL");
+  PA_HIP(hipSetDevice(g->ctx->device));
+  PA_HIP(hipGraphLaunch(g->exec, g->ctx->s[0]));
+  return PA_OK;
+}
+
+extern "C" int pa_graph_destroy(pa_graph *g) {
+  if (!g) return PA_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->s[0]);
+  (void)hipGraphExecDestroy(g->exec);
+  delete g;
+  return PA_OK;
+}

@@ -45,6 +45,7 @@ struct pa_ctx {
   double *d_partials = nullptr;
   int n_partials = 0;
   double *d_scalar = nullptr;
+  bool capturing = false;                 // a pa_graph_begin is open on the compute stream
 };
 
 struct pa_event {
@@ -136,6 +137,11 @@ struct pa_matrix {
   pa_ctx *ctx = nullptr;
   const pa_csr *oo = nullptr, *oh = nullptr;   // own_own, own_ghost (not owned)
   pa_plan *plan = nullptr;                     // exchange plan of the column partition (not owned)
+};
+
+struct pa_graph {
+  pa_ctx *ctx = nullptr;
+  hipGraphExec_t exec = nullptr;
 };
 
 int pa_plan_mark_arrived(pa_plan *p);

@@ -51,6 +51,35 @@ class Context:
         return Event(self)
 
 
+class Graph:
+    """hipGraph of whatever is queued between `with Graph() as g:` and its end (pa_graph_begin/_end): nothing runs while
+    recording; g.launch() replays the recorded kernels and copies on the compute stream with one submission."""
+
+    def __init__(self, ctx=None):
+        self.ctx = ctx or context()
+        self.h = None
+
+    def __enter__(self):
+        L.call("pa_graph_begin", self.ctx.h)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = C.c_void_p()
+        L.call("pa_graph_end", self.ctx.h, C.byref(h))
+        self.h = h
+        return False
+
+    def launch(self):
+        L.call("pa_graph_launch", self.h)
+
+    def __del__(self):
+        try:
+            if self.h is not None:
+                L.lib.pa_graph_destroy(self.h)
+        except Exception:
+            pass
+
+
 class Event:
     """HIP event on one of the context's streams (PTimer replacement, src/p_timer.jl)."""
 

@@ -632,6 +632,28 @@ def test_opt_cg_device_scalars_bit_identical_to_ref_cg(P, np3, with_mg):
     assert (ita_, ra_) == (itb_, rb_) and ita_ < 200
 
 
+@pytest.mark.parametrize("P,np3", [(1, (1, 1, 1)), (4, (2, 2, 1))])      # 4 parts: graph mode declines, eager loop runs
+def test_opt_cg_replayed_from_a_hipgraph_is_bit_identical(P, np3):
+    """graph=True records three CG iterations (kernels of the exchange, both SpMV blocks, the slot BLAS-1) into a
+    hipGraph and replays it; 14 iterations = 4 replays + 2 eager iterations must give the bits of the eager loop."""
+    n = (16, 12, 8)
+    A, b = pa.build_p_matrix(ranks(P), *n, *(a * q for a, q in zip(n, np3)), *np3)
+    outs = []
+    for graph in (False, True):
+        x, r0, r, it = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=14, graph=graph)
+        outs.append((r0, r, it, [v.copy() for v in x.own_values().items]))
+    assert outs[0][:3] == outs[1][:3] and outs[0][2] == 14
+    for u, v in zip(outs[0][3], outs[1][3]):
+        assert np.array_equal(u, v)
+    import pa_amd._lib as L
+    with pytest.raises(L.PAError):                      # a second capture on the same context is refused
+        with pa.Graph():
+            L.call("pa_graph_begin", pa.context().h)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, pa.pones(A.col_partition))            # the context is usable after the refused capture
+    assert all(np.array_equal(g, e) for g, e in zip(y.own_values().items, b.own_values().items))
+
+
 def test_slot_api_errors_and_values():
     ctx = pa.context()
     pa.write_slot(5, 2.5)
