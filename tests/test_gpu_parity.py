@@ -654,6 +654,36 @@ def test_opt_cg_replayed_from_a_hipgraph_is_bit_identical(P, np3):
     assert all(np.array_equal(g, e) for g, e in zip(y.own_values().items, b.own_values().items))
 
 
+def test_empty_part_and_empty_blocks(orc):
+    """Edge cases of the containers: a part that owns nothing (variable_partition([5,0,7])), hence empty vectors, 0 x n
+    blocks and a plan without neighbours on that part; a matrix with empty rows; an all-zero own_ghost block."""
+    n_own = [5, 0, 7]
+    rows = pa.variable_partition(ranks(3).__class__(n_own), 12)
+    orows = orc.variable_partition(n_own, 12)
+    gi = [np.arange(1, 6), np.zeros(0, int), np.arange(6, 13)]
+    # tridiagonal, rows 3 and 9 left empty
+    I = [np.concatenate([[g] * 3 for g in part if g not in (3, 9)]).astype(np.int64) if len(part) else np.zeros(0, np.int64) for part in gi]
+    J = [np.clip(np.concatenate([[g - 1, g, g + 1] for g in part if g not in (3, 9)]), 1, 12).astype(np.int64) if len(part) else np.zeros(0, np.int64) for part in gi]
+    V = [np.tile([-1.0, 2.5, -0.75], len(i) // 3) for i in I]
+    A = pa.psparse_from_coo(pa.DebugArray(I), pa.DebugArray(J), pa.DebugArray(V), rows)
+    Ao = orc.psparse_from_coo(I, J, V, orows)
+    assert [(b.own_own.nnz, b.own_ghost.nnz) for b in A.matrix_partition.items] == \
+        [(bo.own_own.nnz, bo.own_ghost.nnz) for bo in Ao.blocks] and A.matrix_partition.items[1].own_own.nnz == 0
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = upload([v.copy() for v in xo], A.col_partition)
+    y = pa.pvector_from_function(lambda i: np.full(i.n_local, 7.0), A.row_partition)
+    pa.mul_(y, A, x)
+    yo = _oracle_mul(orc, Ao, xo)
+    for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+    assert y.own_values().items[0][2] == 0.0 and len(y.own_values().items[1]) == 0        # empty row -> 0, empty part
+    pa.mul5_(y, A, x, -2.0, 0.5)
+    assert abs(pa.norm(x) - orc.norm2(xo, Ao.cols)) <= 1e-13 * orc.norm2(xo, Ao.cols)
+    pa.assemble_(x).wait()
+    for vals, c in zip(x.ghost_values().items, Ao.cols):
+        assert not vals.any()
+
+
 def test_slot_api_errors_and_values():
     ctx = pa.context()
     pa.write_slot(5, 2.5)
