@@ -21,6 +21,24 @@ from .p_vector import (axpby_, copy_, dot, norm, similar, pzeros, consistent_, c
 mul_no_lat_ = mul_no_overlap_     # HPCG/src/hpcg_utils.jl:6-17: blocking consistent!, then the local product
 
 
+def mul_no_lat_unsplit_(c, A, b):
+    """mul_no_lat! literally (HPCG/src/hpcg_utils.jl:6-17): blocking consistent!(b), then ONE spmv! on the unsplit local
+    CSR (n_own x n_local, columns [own | ghost]) that HPCG stores with split_format=false (K9 of SURVEY 2c).  The unsplit
+    block is built once per matrix from the host blocks (keep_host=True) and cached; a row's entries are its own
+    columns then its ghost columns, the order the split path adds them in, so the result has the same bits."""
+    from .p_sparse_matrix import DeviceCSR, spmv_, _check_axes
+    _check_axes(c, A, b)
+    if A.host_blocks is None:
+        raise L.PAError("the unsplit product needs the host blocks: build the matrix with keep_host=True")
+    if getattr(A, "_unsplit", None) is None:
+        A._unsplit = pmap(lambda hb, r, cc: DeviceCSR(_rows_block(hb, r, cc, np.arange(r.n_own, dtype=np.int64))),
+                          A.host_blocks, A.row_partition, A.col_partition)
+    consistent_(b).wait()
+    pmap(lambda cv, blk, bv: spmv_(cv, blk, bv, L.SEG_LOCAL, L.SEG_OWN, 1.0, 0.0), c.vector_partition, A._unsplit,
+         b.vector_partition)
+    return c
+
+
 # ----------------------------------------------------------------------------------------------
 # multigrid preconditioner (HPCG/src/mg_preconditioner.jl) with the Gauss-Seidel smoother of PartitionedSolvers
 # ----------------------------------------------------------------------------------------------

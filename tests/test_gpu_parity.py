@@ -181,6 +181,23 @@ def test_mul5_alpha_beta(orc):
             assert np.array_equal(got, exp[:r.n_own]), (alpha, beta)
 
 
+def test_unsplit_local_product_equals_split_product(orc):
+    """K9: HPCG's mul_no_lat! on the unsplit local CSR (one kernel launch, columns [own | ghost]) == mul! on the split
+    blocks, bit for bit, 8 parts; and == the oracle's mul_no_lat!."""
+    A, b = pa.build_p_matrix(ranks(8), 9, 7, 8, 18, 14, 16, 2, 2, 2, keep_host=True)
+    Ao, _, _ = orc.hpcg_build_p_matrix(9, 7, 8, 2, 2, 2)
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    y1, y2 = pa.pzeros(A.row_partition), pa.pzeros(A.row_partition)
+    pa.mul_(y1, A, upload([v.copy() for v in xo], A.col_partition))
+    pa.mul_no_lat_unsplit_(y2, A, upload([v.copy() for v in xo], A.col_partition))
+    yo = [np.zeros(r.n_local) for r in Ao.rows]
+    orc.mul_no_lat(yo, Ao, [v.copy() for v in xo])
+    for u, v, w, r in zip(y1.own_values().items, y2.own_values().items, yo, Ao.rows):
+        assert np.array_equal(u, v) and np.array_equal(v, w[:r.n_own])
+    enc = A._unsplit.items[0].encoding()
+    assert sum(enc.values()) > 0 and A._unsplit.items[0].nnz == A.matrix_partition.items[0].own_own.nnz + A.matrix_partition.items[0].own_ghost.nnz
+
+
 def test_operator_level_mul_equals_composed_mul(orc):
     """pa_mul_all / pa_mul5 (one library call per mul!) queue the kernels of mul_ / mul5_ in the same order: same bits.
     8 parts in one process, and a single part through the one-part-per-process entry point."""
