@@ -123,6 +123,12 @@ int pa_ctx_read_slots(pa_ctx *ctx, int first, int n, double *host_out); /* synch
  * compresscoo / sparsecsr produce).  index_bytes in {4,8}, index_base in {0,1}. */
 int pa_csr_create(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr,
                   const void *colval, int index_bytes, int index_base, const double *nzval, pa_csr **A);
+/* The same with separate widths for the row pointers and the column indices.  Device offsets are Int32; a block with
+ * 2^31 stored entries or more (up to the 288 GB of the GPU: rows and columns still < 2^31) needs 64-bit row pointers
+ * and is stored as consecutive row slabs with Int32 offsets each -- pa_spmv, pa_csr_update_values* and pa_mul* see one
+ * block; the fused Gauss-Seidel / restriction epilogues need a single slab.  0-based Int32 colval is used in place. */
+int pa_csr_create_mixed(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr, int rowptr_bytes,
+                        const void *colval, int colval_bytes, int index_base, const double *nzval, pa_csr **A);
 /* CSC input (the reference's default SparseMatrixCSC storage); converted to CSR at upload:
  * spmv_csc! and spmv_csr! give bit-identical results (same per-row add order). */
 int pa_csr_create_from_csc(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr,
@@ -331,6 +337,12 @@ int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int6
                            int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost, int32_t *oo_rowptr,
                            int32_t *oo_colval, double *oo_nzval, int32_t *oh_rowptr, int32_t *oh_colval,
                            double *oh_nzval, double *b);
+
+/* The same with Int64 row pointers, for a part of 2^31 stored entries or more (columns stay Int32). */
+int pa_host_hpcg_split_csr64(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                             int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost, int64_t *oo_rowptr,
+                             int32_t *oo_colval, double *oo_nzval, int64_t *oh_rowptr, int32_t *oh_colval,
+                             double *oh_nzval, double *b);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,7 @@ _SIGS = {
     "pa_ctx_write_slot": [P, cint, f64],
     "pa_ctx_read_slots": [P, cint, cint, C.POINTER(f64)],
     "pa_csr_create": [P, i64, i64, i64, P, P, cint, cint, P, PP],
+    "pa_csr_create_mixed": [P, i64, i64, i64, P, cint, P, cint, cint, P, PP],
     "pa_csr_create_from_csc": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_update_values": [P, P],
     "pa_csr_update_values_from": [P, P, i64],
@@ -126,6 +127,7 @@ _SIGS = {
     "pa_host_check_spmv_encodings": [i64, i64, i64, P, P, cint] + [C.POINTER(i64)] * 4,
     "pa_host_hpcg_ghosts": [i64] * 9 + [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "pa_host_hpcg_split_csr": [i64] * 9 + [P, i64, P, P, P, P, P, P, P],
+    "pa_host_hpcg_split_csr64": [i64] * 9 + [P, i64, P, P, P, P, P, P, P],
 }
 # every symbol the header declares (tests/test_abi.py checks this list against include/pa_hip.h)
 EXPORTS = ["pa_version", "pa_last_error"] + list(_SIGS)

@@ -587,8 +587,8 @@ static inline int64_t read_index(const void *a, int bytes, int64_t i) {
   return bytes == 4 ? (int64_t)((const int32_t *)a)[i] : ((const int64_t *)a)[i];
 }
 
-static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
-                     const int32_t *col0 /*0-based, host*/, const double *nzval, pa_csr **out) {
+static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
+                          const int32_t *col0 /*0-based, host*/, const double *nzval, pa_csr **out) {
   // non-empty rows; compact when most rows are empty (the own_ghost block: only boundary rows)
   std::vector<int32_t> row_ids;
   int64_t n_nonempty = 0;
@@ -672,26 +672,87 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std
   return PA_OK;
 }
 
+// Stored entries per slab: Int32 offsets (plus the padding) must stay below 2^31.  PA_CSR_MAX_SLAB_NNZ lowers the
+// limit (tests force several slabs on small matrices).
+static int64_t slab_limit() {
+  const char *e = getenv("PA_CSR_MAX_SLAB_NNZ");
+  const int64_t hard = ((int64_t)1 << 31) - ((int64_t)1 << 16);
+  if (e && atoll(e) > 0 && atoll(e) < hard) return atoll(e);
+  return hard;
+}
+
+static void csr_free_chain(pa_csr *A);
+
+// rp: 0-based Int64 row pointers of the whole block.  One slab when the block fits Int32 offsets, else consecutive
+// row slabs (greedy, whole rows).
+static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const std::vector<int64_t> &rp,
+                     const int32_t *col0 /*0-based, host*/, const double *nzval, pa_csr **out) {
+  const int64_t limit = slab_limit();
+  pa_csr *head = nullptr, *tail = nullptr;
+  int64_t r0 = 0;
+  do {
+    int64_t r1 = r0;
+    if (nnz - rp[r0] <= limit) r1 = n_rows;
+    else {
+      // largest r1 with rp[r1] - rp[r0] <= limit
+      r1 = std::upper_bound(rp.begin() + r0, rp.end(), rp[r0] + limit) - rp.begin() - 1;
+      if (r1 <= r0) {
+        csr_free_chain(head);
+        pa_set_err("row %lld alone has more stored entries than a slab holds (%lld)", (long long)r0, (long long)limit);
+        return PA_ERR_ARG;
+      }
+    }
+    std::vector<int32_t> rp32(r1 - r0 + 1);
+    for (int64_t r = r0; r <= r1; ++r) rp32[r - r0] = (int32_t)(rp[r] - rp[r0]);
+    pa_csr *S = nullptr;
+    const int64_t snnz = rp[r1] - rp[r0];
+    const int st = csr_build_slab(c, r1 - r0, n_cols, snnz, rp32, col0 ? col0 + rp[r0] : nullptr, nzval ? nzval + rp[r0] : nullptr, &S);
+    if (st != PA_OK) { csr_free_chain(head); return st; }
+    S->row0 = r0; S->nnz0 = rp[r0];
+    if (tail) tail->next = S; else head = S;
+    tail = S;
+    r0 = r1;
+  } while (r0 < n_rows);
+  head->t_rows = n_rows;
+  head->t_nnz = nnz;
+  *out = head;
+  return PA_OK;
+}
+
 extern "C" int pa_csr_create(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr,
                              const void *colval, int index_bytes, int index_base, const double *nzval, pa_csr **out) {
+  return pa_csr_create_mixed(c, n_rows, n_cols, nnz, rowptr, index_bytes, colval, index_bytes, index_base, nzval, out);
+}
+
+extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr,
+                                   int rowptr_bytes, const void *colval, int colval_bytes, int index_base,
+                                   const double *nzval, pa_csr **out) {
   PA_REQUIRE(c && out && rowptr, "bad arguments");
-  PA_REQUIRE(index_bytes == 4 || index_bytes == 8, "index_bytes must be 4 or 8");
+  PA_REQUIRE((rowptr_bytes == 4 || rowptr_bytes == 8) && (colval_bytes == 4 || colval_bytes == 8), "index bytes must be 4 or 8");
   PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
   PA_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0, "negative size");
-  PA_REQUIRE(nnz < (int64_t)2147483000 && n_rows < (int64_t)2147483000 && n_cols < (int64_t)2147483000,
-             "block too large for Int32 device indices");
+  PA_REQUIRE(n_rows < (int64_t)2147483000 && n_cols < (int64_t)2147483000, "block too large for Int32 device indices");
+  PA_REQUIRE(rowptr_bytes == 8 || nnz < (int64_t)2147483000, "2^31 stored entries or more need 64-bit row pointers");
   PA_REQUIRE(nnz == 0 || (colval && nzval), "colval/nzval are NULL");
-  std::vector<int32_t> rp(n_rows + 1);
-  for (int64_t r = 0; r <= n_rows; ++r) rp[r] = (int32_t)(read_index(rowptr, index_bytes, r) - index_base);
+  std::vector<int64_t> rp(n_rows + 1);
+  for (int64_t r = 0; r <= n_rows; ++r) rp[r] = read_index(rowptr, rowptr_bytes, r) - index_base;
   PA_REQUIRE(rp[0] == 0 && rp[n_rows] == nnz, "rowptr does not span [base, base+nnz]");
   for (int64_t r = 0; r < n_rows; ++r) PA_REQUIRE(rp[r + 1] >= rp[r], "rowptr not monotone at row %lld", (long long)r);
-  std::vector<int32_t> col(nnz);
-  for (int64_t p = 0; p < nnz; ++p) {
-    const int64_t j = read_index(colval, index_bytes, p) - index_base;
-    PA_REQUIRE(j >= 0 && j < n_cols, "column index out of range at entry %lld", (long long)p);
-    col[p] = (int32_t)j;
+  std::vector<int32_t> colbuf;
+  const int32_t *col0 = nullptr;
+  if (colval_bytes == 4 && index_base == 0) {
+    col0 = (const int32_t *)colval;                      // already what the device wants: no copy of a multi-GB array
+    for (int64_t p = 0; p < nnz; ++p) PA_REQUIRE(col0[p] >= 0 && col0[p] < n_cols, "column index out of range at entry %lld", (long long)p);
+  } else {
+    colbuf.resize(nnz);
+    for (int64_t p = 0; p < nnz; ++p) {
+      const int64_t j = read_index(colval, colval_bytes, p) - index_base;
+      PA_REQUIRE(j >= 0 && j < n_cols, "column index out of range at entry %lld", (long long)p);
+      colbuf[p] = (int32_t)j;
+    }
+    col0 = colbuf.data();
   }
-  return csr_build(c, n_rows, n_cols, nnz, rp, col.data(), nzval, out);
+  return csr_build(c, n_rows, n_cols, nnz, rp, col0, nzval, out);
 }
 
 extern "C" int pa_csr_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr,
@@ -701,22 +762,24 @@ extern "C" int pa_csr_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols,
   PA_REQUIRE(index_bytes == 4 || index_bytes == 8, "index_bytes must be 4 or 8");
   PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
   PA_REQUIRE(nnz == 0 || (rowval && nzval), "rowval/nzval are NULL");
-  PA_REQUIRE(nnz < (int64_t)2147483000, "block too large for Int32 device indices");
+  PA_REQUIRE(n_rows < (int64_t)2147483000 && n_cols < (int64_t)2147483000, "block too large for Int32 device indices");
+  PA_REQUIRE(index_bytes == 8 || nnz < (int64_t)2147483000, "2^31 stored entries or more need 64-bit pointers");
   // counting transpose; columns end up ascending inside each row because we sweep columns in order
-  std::vector<int32_t> rp(n_rows + 1, 0);
+  std::vector<int64_t> rp(n_rows + 1, 0);
   for (int64_t p = 0; p < nnz; ++p) {
     const int64_t i = read_index(rowval, index_bytes, p) - index_base;
     PA_REQUIRE(i >= 0 && i < n_rows, "row index out of range at entry %lld", (long long)p);
     rp[i + 1]++;
   }
   for (int64_t r = 0; r < n_rows; ++r) rp[r + 1] += rp[r];
-  std::vector<int32_t> col(nnz), fill(rp.begin(), rp.end() - 1);
+  std::vector<int32_t> col(nnz);
+  std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
   std::vector<double> val(nnz);
   for (int64_t j = 0; j < n_cols; ++j) {
     const int64_t a = read_index(colptr, index_bytes, j) - index_base, e = read_index(colptr, index_bytes, j + 1) - index_base;
     for (int64_t p = a; p < e; ++p) {
       const int64_t i = read_index(rowval, index_bytes, p) - index_base;
-      const int32_t q = fill[i]++;
+      const int64_t q = fill[i]++;
       col[q] = (int32_t)j;
       val[q] = nzval[p];
     }
@@ -725,50 +788,63 @@ extern "C" int pa_csr_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols,
 }
 
 extern "C" int pa_csr_update_values(pa_csr *A, const double *nzval) {
-  PA_REQUIRE(A && (nzval || A->nnz == 0), "bad arguments");
-  if (A->nnz == 0) return PA_OK;
+  PA_REQUIRE(A && (nzval || A->t_nnz == 0), "bad arguments");
+  if (A->t_nnz == 0) return PA_OK;
   PA_HIP(hipSetDevice(A->ctx->device));
-  PA_HIP(hipMemcpyAsync(A->d_val, nzval, sizeof(double) * A->nnz, hipMemcpyHostToDevice, A->ctx->s[0]));
+  for (pa_csr *S = A; S; S = S->next)
+    if (S->nnz) PA_HIP(hipMemcpyAsync(S->d_val, nzval + S->nnz0, sizeof(double) * S->nnz, hipMemcpyHostToDevice, A->ctx->s[0]));
   PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
   return PA_OK;
 }
 
 extern "C" int pa_csr_update_values_from(pa_csr *A, const pa_vec *src, int64_t offset) {
   PA_REQUIRE(A && src && offset >= 0, "bad arguments");
-  PA_REQUIRE(offset + A->nnz <= src->n_own + src->n_ghost, "source vector too short for nnz=%lld at offset %lld",
-             (long long)A->nnz, (long long)offset);
-  if (A->nnz == 0) return PA_OK;
+  PA_REQUIRE(offset + A->t_nnz <= src->n_own + src->n_ghost, "source vector too short for nnz=%lld at offset %lld",
+             (long long)A->t_nnz, (long long)offset);
+  if (A->t_nnz == 0) return PA_OK;
   PA_HIP(hipSetDevice(A->ctx->device));
-  PA_HIP(hipMemcpyAsync(A->d_val, src->d + offset, sizeof(double) * A->nnz, hipMemcpyDeviceToDevice, A->ctx->s[0]));
+  for (pa_csr *S = A; S; S = S->next)
+    if (S->nnz)
+      PA_HIP(hipMemcpyAsync(S->d_val, src->d + offset + S->nnz0, sizeof(double) * S->nnz, hipMemcpyDeviceToDevice, A->ctx->s[0]));
   return PA_OK;
+}
+
+static void csr_free_chain(pa_csr *A) {
+  while (A) {
+    pa_csr *n = A->next;
+    (void)hipFree(A->d_crp);
+    (void)hipFree(A->d_col);
+    (void)hipFree(A->d_val);
+    (void)hipFree(A->d_chunk_row);
+    if (A->d_row_ids) (void)hipFree(A->d_row_ids);
+    if (A->d_col16) (void)hipFree(A->d_col16);
+    if (A->d_win) (void)hipFree(A->d_win);
+    if (A->d_pdesc) (void)hipFree(A->d_pdesc);
+    if (A->d_pdelta) (void)hipFree(A->d_pdelta);
+    delete A;
+    A = n;
+  }
 }
 
 extern "C" int pa_csr_destroy(pa_csr *A) {
   if (!A) return PA_OK;
   (void)hipSetDevice(A->ctx->device);
   (void)hipStreamSynchronize(A->ctx->s[0]);
-  (void)hipFree(A->d_crp);
-  (void)hipFree(A->d_col);
-  (void)hipFree(A->d_val);
-  (void)hipFree(A->d_chunk_row);
-  if (A->d_row_ids) (void)hipFree(A->d_row_ids);
-  if (A->d_col16) (void)hipFree(A->d_col16);
-  if (A->d_win) (void)hipFree(A->d_win);
-  if (A->d_pdesc) (void)hipFree(A->d_pdesc);
-  if (A->d_pdelta) (void)hipFree(A->d_pdelta);
-  delete A;
+  csr_free_chain(A);
   return PA_OK;
 }
 
 extern "C" int pa_csr_info(const pa_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz, int64_t *n_chunks,
                            int64_t *n_nonempty, int64_t *n_long) {
   PA_REQUIRE(A != nullptr, "csr is NULL");
-  if (n_rows) *n_rows = A->n_rows;
+  int64_t ch = 0, ne = 0, nl = 0;
+  for (const pa_csr *S = A; S; S = S->next) { ch += S->n_chunks; ne += S->n_nonempty; nl += S->n_long; }
+  if (n_rows) *n_rows = A->t_rows;
   if (n_cols) *n_cols = A->n_cols;
-  if (nnz) *nnz = A->nnz;
-  if (n_chunks) *n_chunks = A->n_chunks;
-  if (n_nonempty) *n_nonempty = A->n_nonempty;
-  if (n_long) *n_long = A->n_long;
+  if (nnz) *nnz = A->t_nnz;
+  if (n_chunks) *n_chunks = ch;
+  if (n_nonempty) *n_nonempty = ne;
+  if (n_long) *n_long = nl;
   return PA_OK;
 }
 
@@ -832,14 +908,18 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
 
 extern "C" int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern, int64_t *n_c16, int64_t *n_c32) {
   PA_REQUIRE(A != nullptr, "csr is NULL");
-  const int64_t pat = A->use_pattern ? A->n_pattern_chunks : 0;
-  // chunks without a pattern descriptor use the 16-bit stream when they encode, else 32-bit columns
-  int64_t c16 = 0;
-  if (A->use_c16) c16 = (A->n_chunks - A->n_c16_fallback) - pat;
-  if (c16 < 0) c16 = 0;
-  if (n_pattern) *n_pattern = pat;
-  if (n_c16) *n_c16 = c16;
-  if (n_c32) *n_c32 = A->n_chunks - pat - c16;
+  int64_t tp = 0, t16 = 0, t32 = 0;
+  for (const pa_csr *S = A; S; S = S->next) {
+    const int64_t pat = S->use_pattern ? S->n_pattern_chunks : 0;
+    // chunks without a pattern descriptor use the 16-bit stream when they encode, else 32-bit columns
+    int64_t c16 = 0;
+    if (S->use_c16) c16 = (S->n_chunks - S->n_c16_fallback) - pat;
+    if (c16 < 0) c16 = 0;
+    tp += pat; t16 += c16; t32 += S->n_chunks - pat - c16;
+  }
+  if (n_pattern) *n_pattern = tp;
+  if (n_c16) *n_c16 = t16;
+  if (n_c32) *n_c32 = t32;
   return PA_OK;
 }
 
@@ -849,31 +929,34 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
   PA_TRY(seg_range(x, xseg, &xoff, &xlen));
   PA_TRY(seg_range(y, yseg, &yoff, &ylen));
   // @boundscheck of spmv! (src/sparse_utils.jl:618-621)
-  PA_REQUIRE(ylen == A->n_rows, "length(b)=%lld != size(A,1)=%lld", (long long)ylen, (long long)A->n_rows);
+  PA_REQUIRE(ylen == A->t_rows, "length(b)=%lld != size(A,1)=%lld", (long long)ylen, (long long)A->t_rows);
   PA_REQUIRE(xlen == A->n_cols, "length(x)=%lld != size(A,2)=%lld", (long long)xlen, (long long)A->n_cols);
   PA_REQUIRE(x->d != y->d || xseg != yseg, "x and y alias");
   pa_ctx *c = A->ctx;
   PA_HIP(hipSetDevice(c->device));
-  double kbeta = beta;
-  if (A->compact && beta != 1.0) {
-    // rows without stored entries still get beta*y (rmul!/fill! of the reference); the kernel then accumulates
-    if (ylen) hipLaunchKernelGGL(k_scale, dim3(grid_for(ylen, 256)), dim3(256), 0, c->s[0], y->d + yoff, ylen, beta);
-    kbeta = 1.0;
-  }
-  if (A->n_chunks > 0) {
-    const int cpx = (int)((A->n_chunks + 7) / 8);
+  for (const pa_csr *S = A; S; S = S->next) {          // one slab unless the block has 2^31 stored entries or more
+    double *ys = y->d + yoff + S->row0;
+    double kbeta = beta;
+    if (S->compact && beta != 1.0) {
+      // rows without stored entries still get beta*y (rmul!/fill! of the reference); the kernel then accumulates
+      if (S->n_rows) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n_rows, 256)), dim3(256), 0, c->s[0], ys, S->n_rows, beta);
+      kbeta = 1.0;
+    }
+    if (S->n_chunks > 0) {
+      const int cpx = (int)((S->n_chunks + 7) / 8);
 #define PA_LAUNCH_SPMV(C16, PAT)                                                                                     \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
-                     c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
-                     x->d + xoff, y->d + yoff, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, alpha, kbeta,    \
+                     c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val,           \
+                     x->d + xoff, ys, S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta,             \
                      (double *)nullptr, (const double *)nullptr, (const double *)nullptr)
-    if (A->use_pattern && A->compact && A->use_c16) PA_LAUNCH_SPMV(true, 2);
-    else if (A->use_pattern && A->compact) PA_LAUNCH_SPMV(false, 2);
-    else if (A->use_pattern && A->use_c16) PA_LAUNCH_SPMV(true, 1);
-    else if (A->use_pattern) PA_LAUNCH_SPMV(false, 1);
-    else if (A->use_c16) PA_LAUNCH_SPMV(true, 0);
-    else PA_LAUNCH_SPMV(false, 0);
+      if (S->use_pattern && S->compact && S->use_c16) PA_LAUNCH_SPMV(true, 2);
+      else if (S->use_pattern && S->compact) PA_LAUNCH_SPMV(false, 2);
+      else if (S->use_pattern && S->use_c16) PA_LAUNCH_SPMV(true, 1);
+      else if (S->use_pattern) PA_LAUNCH_SPMV(false, 1);
+      else if (S->use_c16) PA_LAUNCH_SPMV(true, 0);
+      else PA_LAUNCH_SPMV(false, 0);
 #undef PA_LAUNCH_SPMV
+    }
   }
   PA_HIP(hipGetLastError());
   return PA_OK;
@@ -890,8 +973,9 @@ extern "C" int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x,
   for (int k = 0; k < n_colors; ++k) {
     const pa_csr *A = blocks[k];
     PA_REQUIRE(A != nullptr, "colour block %d is NULL", k);
-    PA_REQUIRE(A->n_rows == x->n_own && A->n_cols == x->n_own + x->n_ghost, "colour block %d is %lld x %lld, x has %lld own + %lld ghost",
-               k, (long long)A->n_rows, (long long)A->n_cols, (long long)x->n_own, (long long)x->n_ghost);
+    PA_REQUIRE(A->t_rows == x->n_own && A->n_cols == x->n_own + x->n_ghost, "colour block %d is %lld x %lld, x has %lld own + %lld ghost",
+               k, (long long)A->t_rows, (long long)A->n_cols, (long long)x->n_own, (long long)x->n_ghost);
+    PA_REQUIRE(A->next == nullptr, "colour block %d is stored in several slabs (>= 2^31 entries): not supported by the fused sweep", k);
   }
   PA_REQUIRE(b->n_own == x->n_own && diag->n_own == x->n_own, "b / diag own sizes differ from x");
   PA_HIP(hipSetDevice(c->device));
@@ -1145,6 +1229,7 @@ extern "C" int pa_transfer_restrict(pa_transfer *t, pa_vec *rc, const pa_vec *rf
 extern "C" int pa_transfer_attach_rows(pa_transfer *t, const pa_csr *rows) {
   PA_REQUIRE(t && rows, "bad arguments");
   PA_REQUIRE(rows->ctx == t->ctx, "transfer and block live in different contexts");
+  PA_REQUIRE(rows->next == nullptr, "a block stored in several slabs (>= 2^31 entries) is not supported by the fused restriction");
   PA_REQUIRE(rows->compact && rows->n_crows == t->n_coarse,
              "the block must store exactly the %lld fine rows of the coarse grid (it stores %lld%s)", (long long)t->n_coarse,
              (long long)rows->n_crows, rows->compact ? "" : ", not compacted");
@@ -1163,7 +1248,7 @@ extern "C" int pa_transfer_restrict_fused(pa_transfer *t, pa_vec *rc, const pa_v
   PA_REQUIRE(t->rows != nullptr, "no row block attached (pa_transfer_attach_rows)");
   const pa_csr *A = t->rows;
   PA_REQUIRE(rc->n_own + rc->n_ghost >= t->n_coarse, "coarse vector too short");
-  PA_REQUIRE(rf->n_own == A->n_rows && xf->n_own + xf->n_ghost == A->n_cols, "fine vector sizes do not match the block");
+  PA_REQUIRE(rf->n_own == A->t_rows && xf->n_own + xf->n_ghost == A->n_cols, "fine vector sizes do not match the block");
   PA_REQUIRE(rc->d != xf->d && rc->d != rf->d, "r_c aliases a fine vector");
   if (A->n_chunks == 0) return PA_OK;
   pa_ctx *c = t->ctx;
@@ -1454,8 +1539,8 @@ extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
 extern "C" int pa_matrix_create(pa_ctx *c, const pa_csr *own_own, const pa_csr *own_ghost, pa_plan *col_plan, pa_matrix **out) {
   PA_REQUIRE(c && own_own && own_ghost && col_plan && out, "bad arguments");
   PA_REQUIRE(own_own->ctx == c && own_ghost->ctx == c && col_plan->ctx == c, "operands live in different contexts");
-  PA_REQUIRE(own_own->n_rows == own_ghost->n_rows, "own_own has %lld rows, own_ghost %lld", (long long)own_own->n_rows,
-             (long long)own_ghost->n_rows);
+  PA_REQUIRE(own_own->t_rows == own_ghost->t_rows, "own_own has %lld rows, own_ghost %lld", (long long)own_own->t_rows,
+             (long long)own_ghost->t_rows);
   PA_REQUIRE(own_own->n_cols + own_ghost->n_cols == col_plan->n_local,
              "blocks have %lld own + %lld ghost columns, the column plan %lld local ids", (long long)own_own->n_cols,
              (long long)own_ghost->n_cols, (long long)col_plan->n_local);
@@ -1473,7 +1558,7 @@ extern "C" int pa_matrix_destroy(pa_matrix *m) {
 static int mul_check(const pa_matrix *m, const pa_vec *c, const pa_vec *b) {
   PA_REQUIRE(m && c && b, "bad arguments");
   // @boundscheck matching_own_indices / matching_ghost_indices (src/p_sparse_matrix.jl:2091-2093)
-  PA_REQUIRE(c->n_own == m->oo->n_rows, "matching_own_indices(axes(c,1),axes(a,1)) failed");
+  PA_REQUIRE(c->n_own == m->oo->t_rows, "matching_own_indices(axes(c,1),axes(a,1)) failed");
   PA_REQUIRE(b->n_own == m->oo->n_cols && b->n_ghost == m->oh->n_cols, "matching_own/ghost_indices(axes(a,2),axes(b,1)) failed");
   return PA_OK;
 }

@@ -323,11 +323,13 @@ extern "C" int pa_host_hpcg_ghosts(int64_t nx, int64_t ny, int64_t nz, int64_t g
   return PA_OK;
 }
 
-// Pass 2: own_own / own_ghost CSR (1-based Int32, sorted columns) and b, written row by row in parallel.
-extern "C" int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
-                                      int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost,
-                                      int32_t *oo_rowptr, int32_t *oo_colval, double *oo_nzval, int32_t *oh_rowptr,
-                                      int32_t *oh_colval, double *oh_nzval, double *b) {
+// Pass 2: own_own / own_ghost CSR (1-based, sorted columns) and b, written row by row in parallel.  RP = Int32 row
+// pointers (SparseMatrixCSR{1,Float64,Int32}) or Int64 for a part with 2^31 stored entries or more.
+template <typename RP>
+static int hpcg_split_csr_impl(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                               int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost,
+                               RP *oo_rowptr, int32_t *oo_colval, double *oo_nzval, RP *oh_rowptr,
+                               int32_t *oh_colval, double *oh_nzval, double *b) {
   PA_REQUIRE(nx > 0 && ny > 0 && nz > 0 && oo_rowptr && oh_rowptr && oo_colval && oo_nzval && b, "bad arguments");
   PA_REQUIRE(n_ghost == 0 || (ghost_gids && oh_colval && oh_nzval), "ghost arrays are NULL");
   const HpcgGeom G{nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0};
@@ -347,8 +349,8 @@ extern "C" int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_
           int ax, bx; dim_counts(gix0 + ix, gix0, nx, gnx, ax, bx);
           const int64_t tot = (int64_t)(ax + bx) * (ay + by) * (az + bz), own = (int64_t)ax * ay * az;
           a += own; c += tot - own; ++row;
-          PA_REQUIRE(a < 2147483647 && c < 2147483647, "block too large for Int32 row pointers");
-          oo_rowptr[row] = (int32_t)a; oh_rowptr[row] = (int32_t)c;
+          PA_REQUIRE(sizeof(RP) == 8 || (a < 2147483647 && c < 2147483647), "block too large for Int32 row pointers");
+          oo_rowptr[row] = (RP)a; oh_rowptr[row] = (RP)c;
           b[row - 1] = 27.0 - (double)tot;
         }
       }
@@ -391,4 +393,20 @@ extern "C" int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_
   }
   PA_REQUIRE(!bad, "a ghost column is missing from ghost_gids (call pa_host_hpcg_ghosts first)");
   return PA_OK;
+}
+
+extern "C" int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                                      int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost,
+                                      int32_t *oo_rowptr, int32_t *oo_colval, double *oo_nzval, int32_t *oh_rowptr,
+                                      int32_t *oh_colval, double *oh_nzval, double *b) {
+  return hpcg_split_csr_impl<int32_t>(nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0, ghost_gids, n_ghost, oo_rowptr, oo_colval,
+                                      oo_nzval, oh_rowptr, oh_colval, oh_nzval, b);
+}
+
+extern "C" int pa_host_hpcg_split_csr64(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                                        int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost,
+                                        int64_t *oo_rowptr, int32_t *oo_colval, double *oo_nzval, int64_t *oh_rowptr,
+                                        int32_t *oh_colval, double *oh_nzval, double *b) {
+  return hpcg_split_csr_impl<int64_t>(nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0, ghost_gids, n_ghost, oo_rowptr, oo_colval,
+                                      oo_nzval, oh_rowptr, oh_colval, oh_nzval, b);
 }

@@ -78,6 +78,12 @@ struct pa_csr {
   int64_t n_pattern_chunks = 0;    // chunks whose columns are recomputed from a pattern
   int32_t *d_pdesc = nullptr;      // n_chunks * 16 descriptor ints; [c*16] = #segments or 0
   int32_t *d_pdelta = nullptr;     // 32 deltas per pattern
+  // A block with 2^31 stored entries or more is a chain of row slabs, each a complete pa_csr with Int32 offsets of its
+  // own: this node holds rows [row0, row0 + n_rows) and the entries [nnz0, nnz0 + nnz) of the block.  The head also
+  // carries the block's totals.
+  pa_csr *next = nullptr;
+  int64_t row0 = 0, nnz0 = 0;
+  int64_t t_rows = 0, t_nnz = 0;
 };
 
 struct pa_plan {

@@ -92,10 +92,13 @@ def build_split_blocks_fused(my_rows, nx, ny, nz, gnx, gny, gnz):
     cols = LocalIndices(my_rows.n_global, my_rows.part, np_=my_rows.np_, n=my_rows.n, ranges=my_rows.ranges,
                         starts=my_rows.starts, ghost_to_global=ghosts, ghost_to_owner=owners)
     n = nx * ny * nz
-    oo = HostCSR(n, n, np.zeros(n + 1, np.int32), np.zeros(noo.value, np.int32), np.zeros(noo.value, F64))
-    oh = HostCSR(n, ng.value, np.zeros(n + 1, np.int32), np.zeros(noh.value, np.int32), np.zeros(noh.value, F64))
+    # Int32 row pointers as HPCG stores them (sparse_matrix.jl:115); Int64 ones for a part of 2^31 entries or more
+    big = max(noo.value, noh.value) >= 2 ** 31 - 2 ** 16
+    rp_t, fn = (np.int64, "pa_host_hpcg_split_csr64") if big else (np.int32, "pa_host_hpcg_split_csr")
+    oo = HostCSR(n, n, np.zeros(n + 1, rp_t), np.zeros(noo.value, np.int32), np.zeros(noo.value, F64))
+    oh = HostCSR(n, ng.value, np.zeros(n + 1, rp_t), np.zeros(noh.value, np.int32), np.zeros(noh.value, F64))
     b = np.zeros(n, F64)
-    L.call("pa_host_hpcg_split_csr", *args, L.ptr(ghosts), ng.value, L.ptr(oo.rowptr), L.ptr(oo.colval), L.ptr(oo.nzval),
+    L.call(fn, *args, L.ptr(ghosts), ng.value, L.ptr(oo.rowptr), L.ptr(oo.colval), L.ptr(oo.nzval),
            L.ptr(oh.rowptr), L.ptr(oh.colval), L.ptr(oh.nzval), L.ptr(b))
     return cols, oo, oh, b
 

@@ -82,9 +82,10 @@ class DeviceCSR:
         self.ctx = ctx or context()
         self.m, self.n, self.nnz = A.m, A.n, A.nnz
         self.h = C.c_void_p()
-        assert A.rowptr.dtype == I32 and A.colval.dtype == I32
-        L.call("pa_csr_create", self.ctx.h, A.m, A.n, A.nnz, L.ptr(A.rowptr), L.ptr(A.colval), 4, 1,
-               L.ptr(A.nzval), C.byref(self.h))
+        assert A.rowptr.dtype in (I32, I64) and A.colval.dtype == I32
+        # Int64 row pointers: a block of 2^31 stored entries or more (kept as row slabs on the device)
+        L.call("pa_csr_create_mixed", self.ctx.h, A.m, A.n, A.nnz, L.ptr(A.rowptr), A.rowptr.dtype.itemsize,
+               L.ptr(A.colval), 4, 1, L.ptr(A.nzval), C.byref(self.h))
 
     @staticmethod
     def transposed(A: HostCSR, ctx=None) -> "DeviceCSR":

@@ -454,6 +454,40 @@ def test_full_size_27pt_128_two_parts_properties():
         assert np.array_equal(4.0 * a_, b_)
 
 
+def test_block_with_more_than_2_to_31_entries_and_forced_slabs(monkeypatch, orc):
+    """Device offsets are Int32; a block of 2^31 stored entries or more is kept as consecutive row slabs (Int64 row
+    pointers at the boundary).  (1) forced on a small matrix (PA_CSR_MAX_SLAB_NNZ): 17 slabs give the bits of one;
+    values can be updated through the slabs.  (2) for real: one part of 432^3 rows, 2 166 720 184 entries > 2^31, built
+    by the native generator with Int64 row pointers: closed-form size, A*1 == b bit-exactly, patterns on both slabs."""
+    A1, b1 = pa.build_p_matrix(ranks(1), 20, 12, 9, 20, 12, 9, 1, 1, 1, keep_host=True)
+    monkeypatch.setenv("PA_CSR_MAX_SLAB_NNZ", "3000")
+    A9, _ = pa.build_p_matrix(ranks(1), 20, 12, 9, 20, 12, 9, 1, 1, 1, keep_host=True)
+    monkeypatch.delenv("PA_CSR_MAX_SLAB_NNZ")
+    i1, i9 = A1.matrix_partition.items[0].own_own.info(), A9.matrix_partition.items[0].own_own.info()
+    assert (i1["n_rows"], i1["nnz"]) == (i9["n_rows"], i9["nnz"]) and i9["n_chunks"] > i1["n_chunks"]
+    x = pa.pvector_from_function(lambda i: orc.hash_x(i.get_local_to_global()), A1.col_partition)
+    y1, y9 = pa.pzeros(A1.row_partition), pa.pzeros(A9.row_partition)
+    pa.mul5_(y1, A1, x, -1.5, 0.0)
+    pa.mul5_(y9, A9, x, -1.5, 0.0)
+    assert np.array_equal(y1.own_values().items[0], y9.own_values().items[0])
+    new_vals = np.cos(np.arange(i1["nnz"], dtype=np.float64))
+    for A in (A1, A9):
+        A.matrix_partition.items[0].own_own.update_values(new_vals)
+    pa.mul_(y1, A1, x)
+    pa.mul_(y9, A9, x)
+    assert np.array_equal(y1.own_values().items[0], y9.own_values().items[0]) and np.any(y1.own_values().items[0] != 0)
+    del A1, A9, y1, y9, x
+    n = 432
+    A, b = pa.build_p_matrix(ranks(1), n, n, n, n, n, n, 1, 1, 1)
+    blk = A.matrix_partition.items[0].own_own
+    info, enc = blk.info(), blk.encoding()
+    assert info["nnz"] == (3 * n - 2) ** 3 > 2 ** 31 and info["n_rows"] == n ** 3
+    assert enc["pattern"] >= 0.999 * info["n_chunks"]
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, pa.pones(A.col_partition))
+    assert np.array_equal(y.own_values().items[0], b.own_values().items[0])
+
+
 def test_config4_full_size_256_cubed_eight_parts_on_one_gpu():
     """BASELINE config 4 at its full size -- 27-pt, 256^3 rows per part, 8 parts as (2,2,2), global 512^3 -- with all
     eight parts resident on ONE GPU (46 GB of HBM; the exchange is device-to-device copies instead of RCCL).
