@@ -255,7 +255,9 @@ typedef struct pa_rowset pa_rowset;
 int pa_rowset_create(pa_ctx *ctx, int64_t n, const int32_t *rows, int index_base, pa_rowset **rs);
 int pa_rowset_destroy(pa_rowset *rs);
 int pa_gs_color_update(pa_rowset *rs, pa_vec *x, const pa_vec *b, pa_vec *t, const pa_vec *diag);
-/* The same sweep with the update fused into the SpMV kernel's epilogue and all colours queued by one call:
+/* The same sweep (gauss_seidel_sweep!, PartitionedSolvers/src/smoothers.jl:144-160, rows taken colour by colour instead
+ * of 1..n: HPCG's optimised variant, HPCG/src/opt_cg.jl) with the update fused into the SpMV kernel's epilogue and all
+ * colours queued by one call:
  * blocks[k] holds every stored entry of colour k's own rows (n_own x n_local, e.g. from pa_csr_create on the rows of
  * that colour; empty rows are compacted away); for k ascending (backward != 0: descending)
  *   x[row] = x[row] + (b[row] - sum_p val[p]*x[col[p]]) / diag[row]      for the rows of colour k, in place.
