@@ -306,7 +306,7 @@ def main():
                        "ghosts_per_part": n_ghost, "index_type": "Int32", "transport": {"rccl": "rccl-p2p (ncclSend/ncclRecv group on the comm stream)", "torch": "torch.distributed p2p (fallback)"}.get(transport, transport)},
             "gflops_per_gpu": round(value / N, 2),
             "hbm_gbps_per_gpu_algorithmic": round(bytes_mul / (ms_per_step * 1e-3) / 1e9, 1),
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_rowsplit<256,8,nt> (own x own): CSR row split, LDS-staged products; "
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_rowsplit<256,6,nt> (own x own): CSR row split, LDS-staged products; "
                                                       "column encoding of the chunks: " + json.dumps(blk.own_own.encoding()),
                          "achieved": round(ach, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,

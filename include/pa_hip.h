@@ -50,7 +50,7 @@ extern "C" {
 #define PA_STREAM_COMPUTE 0
 #define PA_STREAM_COMM 1
 
-#define PA_SPMV_CHUNK_NNZ 2048   /* LDS-staged products per workgroup (16 KiB of fp64) */
+#define PA_SPMV_CHUNK_NNZ 1536   /* LDS-staged products per workgroup (12 KiB of fp64) */
 
 typedef struct pa_ctx pa_ctx;     /* one device + its two streams                                  */
 typedef struct pa_vec pa_vec;     /* local values of one part of a PVector, layout [own | ghost]   */

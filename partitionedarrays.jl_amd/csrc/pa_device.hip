@@ -68,7 +68,7 @@ extern "C" int pa_device_count(int *count) {
 
 // shipped configuration of the row-split kernel (chosen with probe/spmv_probe.hip on MI355X)
 constexpr int SPMV_BLK = 256;
-constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (8)
+constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (6)
 constexpr bool SPMV_NT = true;
 
 static int host_threads(int64_t work) {

@@ -282,6 +282,12 @@ int main(int argc, char **argv) {
                          (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_PAT(256, 8, true)
   ADD_PAT(256, 8, false)
+  ADD_PAT(256, 4, true)
+  ADD_PAT(256, 6, true)
+  ADD_PAT(128, 8, true)
+  ADD_PAT(128, 4, true)
+  ADD_PAT(512, 4, true)
+  ADD_PAT(192, 8, true)
   ADD_PAT(256, 12, true)
   ADD_PAT(256, 16, true)
   ADD_PAT(128, 16, true)

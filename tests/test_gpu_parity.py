@@ -456,11 +456,11 @@ def test_full_size_27pt_128_two_parts_properties():
 
 def test_block_with_more_than_2_to_31_entries_and_forced_slabs(monkeypatch, orc):
     """Device offsets are Int32; a block of 2^31 stored entries or more is kept as consecutive row slabs (Int64 row
-    pointers at the boundary).  (1) forced on a small matrix (PA_CSR_MAX_SLAB_NNZ): 17 slabs give the bits of one;
+    pointers at the boundary).  (1) forced on a small matrix (PA_CSR_MAX_SLAB_NNZ = 1000, less than a chunk): ~50 slabs give the bits of one;
     values can be updated through the slabs.  (2) for real: one part of 432^3 rows, 2 166 720 184 entries > 2^31, built
     by the native generator with Int64 row pointers: closed-form size, A*1 == b bit-exactly, patterns on both slabs."""
     A1, b1 = pa.build_p_matrix(ranks(1), 20, 12, 9, 20, 12, 9, 1, 1, 1, keep_host=True)
-    monkeypatch.setenv("PA_CSR_MAX_SLAB_NNZ", "3000")
+    monkeypatch.setenv("PA_CSR_MAX_SLAB_NNZ", "1000")
     A9, _ = pa.build_p_matrix(ranks(1), 20, 12, 9, 20, 12, 9, 1, 1, 1, keep_host=True)
     monkeypatch.delenv("PA_CSR_MAX_SLAB_NNZ")
     i1, i9 = A1.matrix_partition.items[0].own_own.info(), A9.matrix_partition.items[0].own_own.info()
