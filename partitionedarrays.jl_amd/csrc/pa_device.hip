@@ -12,11 +12,11 @@
 // the reference's order, so SpMV is bit-identical to the CPU loop (no FMA contraction).
 //
 // SpMV design (bandwidth-bound; no MFMA on purpose):
-//   * host-side "row split": consecutive rows are grouped into chunks of <= 2048 stored entries
+//   * host-side "row split": consecutive rows are grouped into chunks of <= 1536 stored entries
 //     (PA_SPMV_CHUNK_NNZ); one 256-thread workgroup per chunk.
 //   * load phase: every lane streams 16-byte value pairs + 8-byte column pairs (fully coalesced,
 //     non-temporal: the matrix is read once and must not evict x from L2), gathers x through
-//     L1/L2, multiplies, and stages the products in LDS (16 KiB per workgroup).
+//     L1/L2, multiplies, and stages the products in LDS (12 KiB per workgroup).
 //   * reduce phase: one lane per row walks its products in LDS in ascending p -- the reference's
 //     left-to-right order -- and writes y.  64-wide wavefronts: lanes of a wave own consecutive rows,
 //     so their LDS reads are stride-(row length) apart: conflict-free for 27 (odd), 2-way for 18.
