@@ -112,3 +112,19 @@ def test_committed_bench_line_follows_the_contract():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 3e9
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_ms"] / 1e6) < 1.0
     assert abs(d["value"] - 2 * d["config"]["nnz_per_part"] * d["n_gpus"] / d["ms_per_step"] / 1e6) < 0.5
+
+
+def test_header_is_valid_c99_and_the_c_example_links():
+    """include/pa_hip.h is a C header (extern "C" guards, no C++ in the declarations): gcc -std=c99 -Werror accepts it,
+    and examples/c_abi_smoke.c -- the ABI used from plain C -- compiles and links against libpa_hip.so."""
+    import subprocess
+    load_package()
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c",
+                           os.path.join(inc, "pa_hip.h")])
+    out = os.path.join(ROOT, "examples", "c_abi_smoke")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", inc,
+                           os.path.join(ROOT, "examples", "c_abi_smoke.c"), "-L", os.path.join(ROOT, "partitionedarrays.jl_amd"),
+                           "-lpa_hip", "-Wl,-rpath," + os.path.join(ROOT, "partitionedarrays.jl_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", out])
+    assert os.path.exists(out)

@@ -5,6 +5,7 @@ the row-split kernel sums each row's products in the reference's order with unfu
 so every comparison below is np.array_equal; dot/norm: relative 1e-13 (tree reduction).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -733,6 +734,20 @@ def test_empty_part_and_empty_blocks(orc):
     pa.assemble_(x).wait()
     for vals, c in zip(x.ghost_values().items, Ao.cols):
         assert not vals.any()
+
+
+def test_c_example_runs_without_python_or_torch():
+    """examples/c_abi_smoke.c: two parts of a 1-D Laplacian handed over as the reference stores them, mul! through
+    pa_mul_all and a dot, from a plain C program (its own process: no Python, no PyTorch in it)."""
+    import subprocess
+    from __graft_entry__ import ROOT
+    exe = os.path.join(ROOT, "examples", "c_abi_smoke")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    env = dict(os.environ, LD_LIBRARY_PATH=os.path.join(ROOT, "partitionedarrays.jl_amd") + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "c_abi_smoke: OK" in r.stdout, r.stdout + r.stderr
 
 
 def test_slot_api_errors_and_values():
