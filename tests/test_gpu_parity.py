@@ -736,6 +736,30 @@ def test_empty_part_and_empty_blocks(orc):
         assert not vals.any()
 
 
+def test_device_memory_is_returned():
+    """Handles own their HBM: building and dropping matrices, vectors, plans, smoothers and graphs repeatedly leaves
+    the device's free memory where it was (hipMemGetInfo through torch, which is only the messenger here)."""
+    import gc
+    import torch
+
+    def cycle():
+        S = pa.pc_setup(ranks(2), 2, 3, 32, 16, 16, ordering="multicolor_spmv")
+        A, b = S.A_vec[-1], S.r[-1]
+        x, r0, r, it = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=3, Pl=S)
+        A1, b1 = pa.build_p_matrix(ranks(1), 48, 48, 48, 48, 48, 48, 1, 1, 1)
+        pa.opt_cg_(pa.pzeros(A1.col_partition), A1, b1, maxiter=6, graph=True)
+    cycle()
+    gc.collect()
+    pa.context().sync()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        cycle()
+    gc.collect()
+    pa.context().sync()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free1 - free0) < 64 << 20, f"device memory moved by {(free0 - free1) / 2**20:.1f} MiB over 3 cycles"
+
+
 def test_c_example_runs_without_python_or_torch():
     """examples/c_abi_smoke.c: two parts of a 1-D Laplacian handed over as the reference stores them, mul! through
     pa_mul_all and a dot, from a plain C program (its own process: no Python, no PyTorch in it)."""
