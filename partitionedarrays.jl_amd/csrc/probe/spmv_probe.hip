@@ -70,6 +70,81 @@ __global__ void k_readsum(const d2 *__restrict__ a, double *out, long n2) {
 //   ABL bit0: reduce reads one product per row instead of walking the row   bit1: no y store
 //       bit4: nontemporal y store   bit5: y store into a 2 MiB window   bit6: (unused)
 //       bit2: no LDS write / barrier                                         bit3: no x gather
+
+// ---- persistent variant with the row sums parked in LDS and written in bursts ----------------------------------------
+// grid = 8 XCDs x WPX workgroups; workgroup i of XCD k walks chunks k*cpx + i, + WPX, + 2*WPX, ... (so that at any moment
+// the workgroups of an XCD work on consecutive chunks, as in the one-workgroup-per-chunk kernel); the row sums of KF
+// consecutive iterations stay in LDS (ROWS_MAX rows per chunk) and are stored together.
+template <int NPT, int KF, int ROWS_MAX>
+__global__ __launch_bounds__(256) void k_spmv_persist(
+    const int *__restrict__ crp, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const int *__restrict__ chunk_row, int n_chunks, int cpx, int wpx) {
+  constexpr int BLK = 256, CAP = BLK * NPT;
+  __shared__ __attribute__((aligned(16))) double prod[CAP];
+  __shared__ double ybuf[KF * ROWS_MAX];
+  __shared__ int yrow0[KF], ynr[KF];
+  const int tid = threadIdx.x;
+  const int xcd = blockIdx.x & 7, wi = blockIdx.x >> 3;
+  int kslot = 0;
+  for (int j = wi; j < cpx; j += wpx) {
+    const int chunk = xcd * cpx + j;
+    const bool live = chunk < n_chunks;
+    if (live) {
+      const int r0 = chunk_row[chunk], r1 = chunk_row[chunk + 1];
+      const int p0 = crp[r0], p1 = crp[r1];
+      const int base = p0 & ~1;
+      int ra = 0, re = 0;
+      if (r0 + tid < r1) { ra = crp[r0 + tid]; re = crp[r0 + tid + 1]; }
+      const int last = max((p1 - 1) & ~1, 0);
+      const int *d = pdesc + chunk * 16;
+      const int q1 = d[1], q2 = d[2], q3 = d[3];
+      const int s0r = d[4], s1r = d[5], s2r = d[6], s3r = d[7];
+      const int L0 = d[8], L1 = d[9], L2 = d[10], L3 = d[11];
+      const int pt0 = d[12], pt1 = d[13], pt2 = d[14], pt3 = d[15];
+      const int lane = tid & 63;
+      const int dA = pdelta[((lane >> 5) ? pt1 : pt0) * PA_PAT_MAXLEN + (lane & 31)];
+      const int dB = pdelta[((lane >> 5) ? pt3 : pt2) * PA_PAT_MAXLEN + (lane & 31)];
+      d2 v[NPT / 2];
+#pragma unroll
+      for (int k = 0; k < NPT / 2; ++k) {
+        const int idx = min(base + (k * BLK + tid) * 2, last);
+        v[k] = pa_stream_load<true>(reinterpret_cast<const d2 *>(val + idx));
+      }
+      const int nq = p1 - p0 - 1;
+#pragma unroll
+      for (int k = 0; k < NPT / 2; ++k) {
+        const int idx = min(base + (k * BLK + tid) * 2, last);
+        const int c0 = pa_pattern_col<false>(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
+        const int c1 = pa_pattern_col<false>(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
+        d2 pr;
+        pr.x = v[k].x * x[c0];
+        pr.y = v[k].y * x[c1];
+        *reinterpret_cast<d2 *>(&prod[(k * BLK + tid) * 2]) = pr;
+      }
+      __syncthreads();
+      if (r0 + tid < r1) {
+        double acc = 0.0;
+        const int a = ra - base, e = re - base;
+#pragma unroll 4
+        for (int p = a; p < e; ++p) acc = acc + prod[p];
+        ybuf[kslot * ROWS_MAX + tid] = acc;
+      }
+      if (tid == 0) { yrow0[kslot] = r0; ynr[kslot] = r1 - r0; }
+      ++kslot;
+    }
+    __syncthreads();
+    if (kslot == KF || j + wpx >= cpx) {           // burst: KF chunks' row sums leave together
+      for (int s = 0; s < kslot; ++s) {
+        const int nr = ynr[s];
+        if (tid < nr) y[yrow0[s] + tid] = ybuf[s * ROWS_MAX + tid];
+      }
+      kslot = 0;
+      __syncthreads();
+    }
+  }
+}
+
 template <int BLK, int NPT, bool XCD, int ABL, int SL = 0>
 __global__ __launch_bounds__(BLK) void k_spmv_abl(
     const int *__restrict__ crp, const int *__restrict__ col, const double *__restrict__ val,
@@ -288,6 +363,26 @@ int main(int argc, char **argv) {
   ADD_PAT(128, 4, true)
   ADD_PAT(512, 4, true)
   ADD_PAT(192, 8, true)
+#define ADD_PERSIST(NPT, KF, WPX)                                                                                 \
+  { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, 256 * NPT, 96, cr, &nl);             \
+    const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
+    const int64_t ng = pa_encode_patterns(rp.data(), hcol.data(), nullptr, nrows, cr, 256 * NPT, pdesc, pdelta, 32, 4096, 1); \
+    if (ng != nch) printf("persist: %lld of %d chunks have a descriptor -- variant skipped\n", (long long)ng, nch);  \
+    else {                                                                                                        \
+    int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
+    const int cpx = (nch + 7) / 8;                                                                              \
+    V.push_back({"persist<" #NPT ",KF=" #KF ",wpx=" #WPX ">c16=true", [=]() {                                   \
+      hipLaunchKernelGGL((k_spmv_persist<NPT, KF, 96>), dim3(8 * WPX), dim3(256), 0, 0, d_rp, ddesc, ddel, d_val, d_x, d_y2, dc, \
+                         nch, cpx, WPX); }, bytes_spmv, {}}); } }
+  ADD_PERSIST(6, 1, 256)
+  ADD_PERSIST(6, 4, 256)
+  ADD_PERSIST(6, 8, 256)
+  ADD_PERSIST(6, 16, 256)
+  ADD_PERSIST(6, 8, 224)
+  ADD_PERSIST(8, 8, 256)
+  ADD_PERSIST(6, 32, 192)
   ADD_PAT(256, 12, true)
   ADD_PAT(256, 16, true)
   ADD_PAT(128, 16, true)
