@@ -706,6 +706,32 @@ def test_opt_cg_replayed_from_a_hipgraph_is_bit_identical(P, np3):
     assert all(np.array_equal(g, e) for g, e in zip(y.own_values().items, b.own_values().items))
 
 
+def test_27_parts_26_neighbours(orc):
+    """27-pt stencil on 3 x 3 x 3 parts: the middle part exchanges with all 26 neighbours (faces, edges, corners --
+    messages of n^2, n and 1 values).  mul!, consistent! and assemble! against the oracle, bit-exact."""
+    n = 5
+    A, b = pa.build_p_matrix(ranks(27), n, n, n, 3 * n, 3 * n, 3 * n, 3, 3, 3)
+    Ao, bo, _ = orc.hpcg_build_p_matrix(n, n, n, 3, 3, 3)
+    nb = pa.assembly_neighbors(A.col_partition)[0].items
+    assert len(nb[13]) == 26 and len(nb[0]) == 7                       # middle part / corner part
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = upload([v.copy() for v in xo], A.col_partition)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_c_(y, A, x)
+    yo = _oracle_mul(orc, Ao, xo)
+    for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+    pa.mul_(y, A, pa.pones(A.col_partition))
+    for got, exp in zip(y.own_values().items, b.own_values().items):
+        assert np.array_equal(got, exp)
+    host = [orc.hash_x(c.local_to_global + 7) for c in Ao.cols]          # ghosts carry their own values: assemble! adds them
+    v = upload([h.copy() for h in host], A.col_partition)
+    pa.assemble_(v).wait()
+    orc.assemble(host, Ao.cols)
+    for a_, b_ in zip(v.local_values().items, host):
+        assert np.array_equal(a_, b_)
+
+
 def test_empty_part_and_empty_blocks(orc):
     """Edge cases of the containers: a part that owns nothing (variable_partition([5,0,7])), hence empty vectors, 0 x n
     blocks and a plan without neighbours on that part; a matrix with empty rows; an all-zero own_ghost block."""
