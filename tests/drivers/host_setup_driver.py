@@ -102,6 +102,13 @@ def main():
             for mine, ref in zip(pa.getany(host), (Af.blocks[k].own_own, Af.blocks[k].own_ghost)):
                 assert np.array_equal(mine.rowptr, ref.rowptr) and np.array_equal(mine.colval, ref.colval)
                 assert np.array_equal(mine.nzval, ref.nzval)
+            # test/fem_example.jl's set-up: the cell -> dof table of the ghost cells crosses processes (jagged consistent!)
+            S = pa.fem_example.fem_example_system(ranks, fparts, (9, 6))
+            O = orc.fem_example_setup(fparts, (9, 6))
+            assert S["n_global_dofs"] == O["n_global_dofs"]
+            for key in ("I", "J", "V", "II", "VV"):
+                assert np.array_equal(pa.getany(S[key]), O[key][k]), key
+            assert np.array_equal(pa.getany(S["dof_partition"]).own_to_global, O["dof_partition"][k].own_to_global)
         return True
 
     ok = pa.with_torchdist(body)
