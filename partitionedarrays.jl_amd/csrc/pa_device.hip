@@ -539,6 +539,7 @@ extern "C" int pa_cg_update(pa_vec *x, pa_vec *r, const pa_vec *u, const pa_vec 
   PA_REQUIRE(x->n_own == r->n_own && x->n_own == u->n_own && x->n_own == cv->n_own, "own-size mismatch");
   PA_REQUIRE(PA_COEF_OK(num) && PA_COEF_OK(den) && PA_SLOT_OK(rr_slot), "slot out of range");
   PA_REQUIRE(rr_slot != num && rr_slot != den, "the result slot must differ from the coefficient slots");
+  PA_REQUIRE(x->d != r->d && x->d != u->d && x->d != cv->d && r->d != u->d && r->d != cv->d, "x, r, u, c must be distinct vectors");
   pa_ctx *c = x->ctx;
   PA_HIP(hipSetDevice(c->device));
   const int nb = grid_for(x->n_own, 256 * 8, c->n_partials);
@@ -978,6 +979,7 @@ extern "C" int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x,
     PA_REQUIRE(A->next == nullptr, "colour block %d is stored in several slabs (>= 2^31 entries): not supported by the fused sweep", k);
   }
   PA_REQUIRE(b->n_own == x->n_own && diag->n_own == x->n_own, "b / diag own sizes differ from x");
+  PA_REQUIRE(x->d != b->d && x->d != diag->d, "x aliases b or diag");
   PA_HIP(hipSetDevice(c->device));
   for (int i = 0; i < n_colors; ++i) {
     const pa_csr *A = blocks[backward ? n_colors - 1 - i : i];
