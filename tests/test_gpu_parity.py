@@ -370,6 +370,32 @@ def test_csc_upload_gives_same_bits(orc):
     L.call("pa_csr_destroy", h)
 
 
+def test_index_widths_and_bases_give_the_same_block(orc):
+    """pa_csr_create / pa_csr_create_mixed accept the reference's index types as stored: Int32 or Int64, 1-based (Julia)
+    or 0-based, and the mixed form (Int64 row pointers, Int32 columns).  Same device block, same product bits."""
+    import pa_amd._lib as L
+    rng = np.random.default_rng(11)
+    A = _random_csr(rng, 300, 500, rng.integers(0, 40, 300))
+    x = pa.DeviceVector(500, 0).upload(rng.standard_normal(500))
+    outs = []
+    for rb, cb, base in ((4, 4, 1), (8, 8, 1), (8, 4, 1), (4, 4, 0), (8, 4, 0), (4, 8, 0)):
+        rp = np.ascontiguousarray(A.rowptr.astype(np.int64) - 1 + base, np.int32 if rb == 4 else np.int64)
+        cv = np.ascontiguousarray(A.colval.astype(np.int64) - 1 + base, np.int32 if cb == 4 else np.int64)
+        h = C.c_void_p()
+        L.call("pa_csr_create_mixed", pa.context().h, A.m, A.n, A.nnz, L.ptr(rp), rb, L.ptr(cv), cb, base, L.ptr(A.nzval), C.byref(h))
+        y = pa.DeviceVector(300, 0)
+        L.call("pa_spmv", h, x.h, L.SEG_OWN, y.h, L.SEG_OWN, 1.0, 0.0)
+        outs.append(y.own())
+        L.call("pa_csr_destroy", h)
+    want = np.zeros(300)
+    orc.oracle_c().spmv_csr(want, x.own(), orc.CSR(A.m, A.n, A.rowptr, A.colval, A.nzval))
+    for o in outs:
+        assert np.array_equal(o, want)
+    with pytest.raises(L.PAError):                       # 2^31 entries or more need 64-bit row pointers
+        L.call("pa_csr_create_mixed", pa.context().h, 10, 10, 2 ** 31, L.ptr(np.zeros(11, np.int32)), 4,
+               L.ptr(np.zeros(1, np.int32)), 4, 0, L.ptr(np.zeros(1)), C.byref(C.c_void_p()))
+
+
 def test_argument_errors_are_reported():
     A = pa.DeviceCSR(pa.compresscoo([1, 2], [1, 2], [1.0, 1.0], 2, 2))
     x, y = pa.DeviceVector(3, 0), pa.DeviceVector(2, 0)
