@@ -144,6 +144,12 @@ int pa_csr_info(const pa_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
 /* How the row-split chunks of A get their column indices (library-internal index compression; the values, the
  * results and pa_csr_update_values are unaffected): recomputed from row patterns / 16-bit windowed stream / 32-bit. */
 int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern_chunks, int64_t *n_c16_chunks, int64_t *n_c32_chunks);
+/* Optional, lossless: with PA_SPMV_VALUE_DICT=1 in the environment at creation, a block whose stored values take at most
+ * 64 distinct bit patterns (27-point HPCG: 2; Q1 stiffness on a uniform grid: about a dozen) also keeps one byte per
+ * entry and the kernels stream that instead of the 8-byte values -- same values, same products, same order, same bits.
+ * pa_csr_update_values* drop the dictionary (the block continues on the fp64 stream).  n_values = distinct values in
+ * use, 0 when the block streams fp64 values.  Off by default: bench.py's headline never uses it. */
+int pa_csr_value_dict(const pa_csr *A, int *n_values);
 /* y_seg = beta*y_seg + alpha*A*x_seg.
  *   spmv!(b,A,x)            (src/sparse_utils.jl:617-623,649-669)  <=> alpha=1, beta=0
  *   muladd!(b,A,x)          (src/p_sparse_matrix.jl:2088)            <=> alpha=1, beta=1

@@ -665,6 +665,71 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
       }
     }
   }
+  // optional lossless value dictionary (PA_SPMV_VALUE_DICT=1): at most PA_VDICT_MAX distinct bit patterns
+  {
+    const char *e = getenv("PA_SPMV_VALUE_DICT");
+    if (e && atoi(e) != 0 && nnz > 0) {
+      const int T = host_threads(nnz);
+      std::vector<std::vector<uint64_t>> local(T);
+      std::vector<char> over(T, 0);
+      auto scan = [&](int t) {
+        std::vector<uint64_t> &d = local[t];
+        for (int64_t p = nnz * t / T; p < nnz * (t + 1) / T; ++p) {
+          uint64_t bits;
+          memcpy(&bits, &nzval[p], 8);
+          size_t k = 0;
+          while (k < d.size() && d[k] != bits) ++k;
+          if (k == d.size()) {
+            if (d.size() == PA_VDICT_MAX) { over[t] = 1; return; }
+            d.push_back(bits);
+          }
+        }
+      };
+      {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(scan, t);
+        scan(0);
+        for (auto &x : th) x.join();
+      }
+      std::vector<uint64_t> dict;
+      bool ok = true;
+      for (int t = 0; t < T && ok; ++t) {
+        if (over[t]) ok = false;
+        for (uint64_t b : local[t]) {
+          if (std::find(dict.begin(), dict.end(), b) == dict.end()) {
+            if (dict.size() == PA_VDICT_MAX) { ok = false; break; }
+            dict.push_back(b);
+          }
+        }
+      }
+      if (ok) {
+        std::vector<uint8_t> code(nnz + pad, 0);
+        auto enc = [&](int t) {
+          for (int64_t p = nnz * t / T; p < nnz * (t + 1) / T; ++p) {
+            uint64_t bits;
+            memcpy(&bits, &nzval[p], 8);
+            size_t k = 0;
+            while (dict[k] != bits) ++k;
+            code[p] = (uint8_t)k;
+          }
+        };
+        {
+          std::vector<std::thread> th;
+          for (int t = 1; t < T; ++t) th.emplace_back(enc, t);
+          enc(0);
+          for (auto &x : th) x.join();
+        }
+        std::vector<double> dv(PA_VDICT_MAX, 0.0);
+        memcpy(dv.data(), dict.data(), 8 * dict.size());
+        PA_HIP(hipMalloc(&A->d_code, nnz + pad));
+        PA_HIP(hipMalloc(&A->d_dict, sizeof(double) * PA_VDICT_MAX));
+        PA_HIP(hipMemcpy(A->d_code, code.data(), nnz + pad, hipMemcpyHostToDevice));
+        PA_HIP(hipMemcpy(A->d_dict, dv.data(), sizeof(double) * PA_VDICT_MAX, hipMemcpyHostToDevice));
+        A->use_vdict = true;
+        A->n_dict = (int)dict.size();
+      }
+    }
+  }
   if (compact) {
     PA_HIP(hipMalloc(&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc)));
     if (nc) PA_HIP(hipMemcpy(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice));
@@ -792,8 +857,10 @@ extern "C" int pa_csr_update_values(pa_csr *A, const double *nzval) {
   PA_REQUIRE(A && (nzval || A->t_nnz == 0), "bad arguments");
   if (A->t_nnz == 0) return PA_OK;
   PA_HIP(hipSetDevice(A->ctx->device));
-  for (pa_csr *S = A; S; S = S->next)
+  for (pa_csr *S = A; S; S = S->next) {
+    S->use_vdict = false;            // the codes describe the old values: back to the fp64 stream
     if (S->nnz) PA_HIP(hipMemcpyAsync(S->d_val, nzval + S->nnz0, sizeof(double) * S->nnz, hipMemcpyHostToDevice, A->ctx->s[0]));
+  }
   PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
   return PA_OK;
 }
@@ -804,9 +871,11 @@ extern "C" int pa_csr_update_values_from(pa_csr *A, const pa_vec *src, int64_t o
              (long long)A->t_nnz, (long long)offset);
   if (A->t_nnz == 0) return PA_OK;
   PA_HIP(hipSetDevice(A->ctx->device));
-  for (pa_csr *S = A; S; S = S->next)
+  for (pa_csr *S = A; S; S = S->next) {
+    S->use_vdict = false;
     if (S->nnz)
       PA_HIP(hipMemcpyAsync(S->d_val, src->d + offset + S->nnz0, sizeof(double) * S->nnz, hipMemcpyDeviceToDevice, A->ctx->s[0]));
+  }
   return PA_OK;
 }
 
@@ -822,6 +891,8 @@ static void csr_free_chain(pa_csr *A) {
     if (A->d_win) (void)hipFree(A->d_win);
     if (A->d_pdesc) (void)hipFree(A->d_pdesc);
     if (A->d_pdelta) (void)hipFree(A->d_pdelta);
+    if (A->d_code) (void)hipFree(A->d_code);
+    if (A->d_dict) (void)hipFree(A->d_dict);
     delete A;
     A = n;
   }
@@ -887,7 +958,7 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
         const int32_t dec = win[c * PA_C16_WINDOWS + (c16[p] >> 12)] + (c16[p] & 4095);
         PA_REQUIRE(dec == col[p], "c16 decode mismatch at entry %lld", (long long)p);
       }
-    const int32_t *d = &pdesc[(size_t)c * 16];
+    const int32_t *d = &pdesc[(size_t)c * PA_PDESC_INTS];
     if (npat > 0 && d[0] > 0)
       for (int64_t p = p0; p < p1; ++p) {
         const int q = (int)(p - p0);
@@ -924,6 +995,19 @@ extern "C" int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern, int64_t *n_c
   return PA_OK;
 }
 
+extern "C" int pa_csr_value_dict(const pa_csr *A, int *n_values) {
+  PA_REQUIRE(A && n_values, "bad arguments");
+  int n = 0;
+  bool all = true;
+  for (const pa_csr *S = A; S; S = S->next) {
+    if (S->nnz == 0) continue;
+    if (!S->use_vdict) all = false;
+    n = std::max(n, S->n_dict);
+  }
+  *n_values = all ? n : 0;
+  return PA_OK;
+}
+
 extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int yseg, double alpha, double beta) {
   PA_REQUIRE(A && x && y, "bad arguments");
   int64_t xoff, xlen, yoff, ylen;
@@ -945,17 +1029,31 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
     }
     if (S->n_chunks > 0) {
       const int cpx = (int)((S->n_chunks + 7) / 8);
-#define PA_LAUNCH_SPMV(C16, PAT)                                                                                     \
-  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
+#define PA_LAUNCH_SPMV(C16, PAT, VD)                                                                                     \
+  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
                      c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val,           \
                      x->d + xoff, ys, S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta,             \
-                     (double *)nullptr, (const double *)nullptr, (const double *)nullptr)
-      if (S->use_pattern && S->compact && S->use_c16) PA_LAUNCH_SPMV(true, 2);
-      else if (S->use_pattern && S->compact) PA_LAUNCH_SPMV(false, 2);
-      else if (S->use_pattern && S->use_c16) PA_LAUNCH_SPMV(true, 1);
-      else if (S->use_pattern) PA_LAUNCH_SPMV(false, 1);
-      else if (S->use_c16) PA_LAUNCH_SPMV(true, 0);
-      else PA_LAUNCH_SPMV(false, 0);
+                     (double *)nullptr, (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict)
+      const int sel_ = (S->use_pattern ? (S->compact ? 2 : 1) : 0) * 2 + (S->use_c16 ? 1 : 0);
+      if (S->use_vdict) {
+        switch (sel_) {
+          case 5: PA_LAUNCH_SPMV(true, 2, true); break;
+          case 4: PA_LAUNCH_SPMV(false, 2, true); break;
+          case 3: PA_LAUNCH_SPMV(true, 1, true); break;
+          case 2: PA_LAUNCH_SPMV(false, 1, true); break;
+          case 1: PA_LAUNCH_SPMV(true, 0, true); break;
+          default: PA_LAUNCH_SPMV(false, 0, true); break;
+        }
+      } else {
+        switch (sel_) {
+          case 5: PA_LAUNCH_SPMV(true, 2, false); break;
+          case 4: PA_LAUNCH_SPMV(false, 2, false); break;
+          case 3: PA_LAUNCH_SPMV(true, 1, false); break;
+          case 2: PA_LAUNCH_SPMV(false, 1, false); break;
+          case 1: PA_LAUNCH_SPMV(true, 0, false); break;
+          default: PA_LAUNCH_SPMV(false, 0, false); break;
+        }
+      }
 #undef PA_LAUNCH_SPMV
     }
   }
@@ -985,17 +1083,31 @@ extern "C" int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x,
     const pa_csr *A = blocks[backward ? n_colors - 1 - i : i];
     if (A->n_chunks == 0) continue;
     const int cpx = (int)((A->n_chunks + 7) / 8);
-#define PA_LAUNCH_GS(C16, PAT)                                                                                       \
-  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 1>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
+#define PA_LAUNCH_GS(C16, PAT, VD)                                                                                       \
+  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 1, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
                      (const double *)nullptr, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, \
-                     1.0, 0.0, x->d, (const double *)b->d, (const double *)diag->d)
-    if (A->use_pattern && A->compact && A->use_c16) PA_LAUNCH_GS(true, 2);
-    else if (A->use_pattern && A->compact) PA_LAUNCH_GS(false, 2);
-    else if (A->use_pattern && A->use_c16) PA_LAUNCH_GS(true, 1);
-    else if (A->use_pattern) PA_LAUNCH_GS(false, 1);
-    else if (A->use_c16) PA_LAUNCH_GS(true, 0);
-    else PA_LAUNCH_GS(false, 0);
+                     1.0, 0.0, x->d, (const double *)b->d, (const double *)diag->d, A->d_code, A->d_dict)
+    const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
+    if (A->use_vdict) {
+      switch (sel_) {
+        case 5: PA_LAUNCH_GS(true, 2, true); break;
+        case 4: PA_LAUNCH_GS(false, 2, true); break;
+        case 3: PA_LAUNCH_GS(true, 1, true); break;
+        case 2: PA_LAUNCH_GS(false, 1, true); break;
+        case 1: PA_LAUNCH_GS(true, 0, true); break;
+        default: PA_LAUNCH_GS(false, 0, true); break;
+      }
+    } else {
+      switch (sel_) {
+        case 5: PA_LAUNCH_GS(true, 2, false); break;
+        case 4: PA_LAUNCH_GS(false, 2, false); break;
+        case 3: PA_LAUNCH_GS(true, 1, false); break;
+        case 2: PA_LAUNCH_GS(false, 1, false); break;
+        case 1: PA_LAUNCH_GS(true, 0, false); break;
+        default: PA_LAUNCH_GS(false, 0, false); break;
+      }
+    }
 #undef PA_LAUNCH_GS
   }
   PA_HIP(hipGetLastError());
@@ -1256,17 +1368,31 @@ extern "C" int pa_transfer_restrict_fused(pa_transfer *t, pa_vec *rc, const pa_v
   pa_ctx *c = t->ctx;
   PA_HIP(hipSetDevice(c->device));
   const int cpx = (int)((A->n_chunks + 7) / 8);
-#define PA_LAUNCH_RR(C16, PAT)                                                                                       \
-  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 2>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
+#define PA_LAUNCH_RR(C16, PAT, VD)                                                                                       \
+  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 2, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
                      (const double *)xf->d, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx,  \
-                     1.0, 0.0, rc->d, (const double *)rf->d, (const double *)nullptr)
-  if (A->use_pattern && A->compact && A->use_c16) PA_LAUNCH_RR(true, 2);
-  else if (A->use_pattern && A->compact) PA_LAUNCH_RR(false, 2);
-  else if (A->use_pattern && A->use_c16) PA_LAUNCH_RR(true, 1);
-  else if (A->use_pattern) PA_LAUNCH_RR(false, 1);
-  else if (A->use_c16) PA_LAUNCH_RR(true, 0);
-  else PA_LAUNCH_RR(false, 0);
+                     1.0, 0.0, rc->d, (const double *)rf->d, (const double *)nullptr, A->d_code, A->d_dict)
+  const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
+  if (A->use_vdict) {
+    switch (sel_) {
+      case 5: PA_LAUNCH_RR(true, 2, true); break;
+      case 4: PA_LAUNCH_RR(false, 2, true); break;
+      case 3: PA_LAUNCH_RR(true, 1, true); break;
+      case 2: PA_LAUNCH_RR(false, 1, true); break;
+      case 1: PA_LAUNCH_RR(true, 0, true); break;
+      default: PA_LAUNCH_RR(false, 0, true); break;
+    }
+  } else {
+    switch (sel_) {
+      case 5: PA_LAUNCH_RR(true, 2, false); break;
+      case 4: PA_LAUNCH_RR(false, 2, false); break;
+      case 3: PA_LAUNCH_RR(true, 1, false); break;
+      case 2: PA_LAUNCH_RR(false, 1, false); break;
+      case 1: PA_LAUNCH_RR(true, 0, false); break;
+      default: PA_LAUNCH_RR(false, 0, false); break;
+    }
+  }
 #undef PA_LAUNCH_RR
   PA_HIP(hipGetLastError());
   return PA_OK;

@@ -78,6 +78,10 @@ struct pa_csr {
   int64_t n_pattern_chunks = 0;    // chunks whose columns are recomputed from a pattern
   int32_t *d_pdesc = nullptr;      // n_chunks * 16 descriptor ints; [c*16] = #segments or 0
   int32_t *d_pdelta = nullptr;     // 32 deltas per pattern
+  bool use_vdict = false;          // value dictionary present and current (dropped when the values are updated)
+  int n_dict = 0;
+  uint8_t *d_code = nullptr;       // one byte per stored entry (padded)
+  double *d_dict = nullptr;        // PA_VDICT_MAX values
   // A block with 2^31 stored entries or more is a chain of row slabs, each a complete pa_csr with Int32 offsets of its
   // own: this node holds rows [row0, row0 + n_rows) and the entries [nnz0, nnz0 + nnz) of the block.  The head also
   // carries the block's totals.

@@ -41,21 +41,24 @@ typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 //            PA_PAT_MAXLEN, rows whose pattern is rare) use c16 / 32-bit columns.
 #define PA_PAT_SEGMENTS 4
 #define PA_PAT_MAXLEN 32
+#define PA_PDESC_INTS 20   // {nseg, q1..q3, first row x4, (L | stride<<8) x4, pattern x4, magic x4 (2^32/L rounded up)}
 
 // column of entry q (relative to the chunk's first entry) from the chunk's pattern descriptor
 template <bool STRIDED>
 __device__ __forceinline__ int pa_pattern_col(int q, int nq, int q1, int q2, int q3, int L0, int L1, int L2, int L3,
-                                              int s0r, int s1r, int s2r, int s3r, int dA, int dB) {
+                                              int s0r, int s1r, int s2r, int s3r, unsigned M0, unsigned M1, unsigned M2,
+                                              unsigned M3, int dA, int dB) {
   q = max(0, min(q, nq));
   const bool g1 = q >= q1, g2 = q >= q2, g3 = q >= q3;  // chained selects (a runtime-indexed array would go to scratch)
   int qs = g1 ? q1 : 0, Ls = g1 ? L1 : L0, rs = g1 ? s1r : s0r;
-  qs = g2 ? q2 : qs; Ls = g2 ? L2 : Ls; rs = g2 ? s2r : rs;
-  qs = g3 ? q3 : qs; Ls = g3 ? L3 : Ls; rs = g3 ? s3r : rs;
+  unsigned M = g1 ? M1 : M0;                  // 2^32 / L rounded up, from the descriptor (a division per entry otherwise)
+  qs = g2 ? q2 : qs; Ls = g2 ? L2 : Ls; rs = g2 ? s2r : rs; M = g2 ? M2 : M;
+  qs = g3 ? q3 : qs; Ls = g3 ? L3 : Ls; rs = g3 ? s3r : rs; M = g3 ? M3 : M;
   const int s = (int)g1 + (int)g2 + (int)g3;
   const int t = q - qs;
   // descriptor word: row length | row-id stride << 8 (the stride bits are only set for row-compacted blocks)
   const int L = STRIDED ? (Ls & 255) : Ls, stride = STRIDED ? (Ls >> 8) : 1;
-  const int rr = L == 1 ? t : (int)__umulhi((unsigned)t, 0xFFFFFFFFu / (unsigned)L + 1u);  // t / L, exact for t < 2^32 / L
+  const int rr = L == 1 ? t : (int)__umulhi((unsigned)t, M);  // t / L, exact for t < 2^32 / L
   const int kk = t - rr * L;
   // lanes 0-31 / 32-63 of dA hold the deltas of segment 0 / 1, of dB those of segment 2 / 3.  ds_bpermute reads the
   // SOURCE lane's register, so both are fetched and the requesting lane selects.
@@ -63,6 +66,22 @@ __device__ __forceinline__ int pa_pattern_col(int q, int nq, int q1, int q2, int
   const int delA = __builtin_amdgcn_ds_bpermute(sel, dA);
   const int delB = __builtin_amdgcn_ds_bpermute(sel, dB);
   return rs + rr * stride + ((s & 2) ? delB : delA);
+}
+
+// The same when every entry a wavefront decodes in one step lies in ONE run of the chunk (the common case: a chunk has
+// at most 4 runs and a step covers 128 consecutive entries): the run's parameters are wave-uniform (scalar registers),
+// so the per-entry compare/select chains disappear -- 9 vector instructions and one ds_bpermute per entry instead of ~35
+// and two.  dsrc = the register (dA or dB) that holds the run's deltas, half = which 32-lane half of it.
+template <bool STRIDED>
+__device__ __forceinline__ int pa_pattern_col_uniform(int q, int nq, int qs, int Lw, int rs, unsigned M, int dsrc,
+                                                      int half) {
+  q = max(0, min(q, nq));
+  const int t = q - qs;
+  const int L = STRIDED ? (Lw & 255) : Lw, stride = STRIDED ? (Lw >> 8) : 1;
+  const int rr = L == 1 ? t : (int)__umulhi((unsigned)t, M);
+  const int kk = t - (int)__umul24((unsigned)rr, (unsigned)L);
+  const int del = __builtin_amdgcn_ds_bpermute(((half << 5) + kk) << 2, dsrc);
+  return rs + (STRIDED ? (int)__umul24((unsigned)rr, (unsigned)stride) : rr) + del;
 }
 
 // y[row] = beta*y[row] + sum_p (val[p]*x[col[p]])*alpha, products summed in ascending p.
@@ -76,14 +95,20 @@ __device__ __forceinline__ int pa_pattern_col(int q, int nq, int q1, int q2, int
 //           colouring: no row of the launch reads another row of the launch, only itself.
 //        2: fused residual + restriction, gs_x[r] = gs_b[row] - sum for the r-th stored (compacted) row: the coarse
 //           residual r_c = (r_f - A x_f) at the fine rows a coarse grid keeps (gs_x = r_c, gs_b = r_f, x_in = x_f).
-template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0>
+//   VD   value dictionary (optional, lossless): a block with at most PA_VDICT_MAX distinct stored values (bit patterns)
+//        keeps one byte per entry (`code`) and the values in `dict`; lane l holds dict[l] and an entry's value is fetched
+//        from the lane that holds it with ds_bpermute -- 1 byte of matrix stream per entry instead of 8.  The 27-point
+//        HPCG operator has 2 distinct values, a Q1 stiffness matrix on a uniform grid about a dozen.
+#define PA_VDICT_MAX 64
+template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, bool VD = false>
 __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
     const double *__restrict__ val, const double *__restrict__ x_in,
     double *__restrict__ y, const int *__restrict__ chunk_row, const int *__restrict__ row_ids, int n_chunks,
     int chunks_per_xcd, double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
-    const double *__restrict__ gs_diag) {
+    const double *__restrict__ gs_diag, const unsigned char *__restrict__ code = nullptr,
+    const double *__restrict__ dict = nullptr) {
   constexpr int CAP = BLK * NPT;
   const double *x = EPI == 1 ? gs_x : x_in;   // EPI 1 reads and writes the same vector: no restrict promise on it
   static_assert(NPT % 2 == 0, "pairs");
@@ -111,39 +136,65 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     // Every load instruction is contiguous across the 64 lanes (16 B, 8 B or 4 B per lane).
     const int last = max((p1 - 1) & ~1, 0);
     int nseg = 0;
-    if (PAT) nseg = pdesc[chunk * 16];
+    if (PAT) nseg = pdesc[chunk * PA_PDESC_INTS];
     int mywin = -1;
     if (C16 && nseg <= 0) mywin = win[chunk * PA_C16_WINDOWS + (tid & (PA_C16_WINDOWS - 1))];
     const bool use16 = C16 && nseg <= 0 && (__builtin_amdgcn_readfirstlane(mywin) >= 0);   // lane 0 holds window 0
     d2 v[NPT / 2];
+    unsigned cc[NPT / 2];
     int c0[NPT / 2], c1[NPT / 2];
+    int dict_lo = 0, dict_hi = 0;
+    if (VD) {
+      const double dv = dict[tid & 63];
+      dict_lo = __double2loint(dv);
+      dict_hi = __double2hiint(dv);
+    }
     if (PAT && nseg > 0) {
-      const int *d = pdesc + chunk * 16;
+      const int *d = pdesc + chunk * PA_PDESC_INTS;
       const int q1 = d[1], q2 = d[2], q3 = d[3];
       const int s0r = d[4], s1r = d[5], s2r = d[6], s3r = d[7];
       const int L0 = d[8], L1 = d[9], L2 = d[10], L3 = d[11];
       const int pt0 = d[12], pt1 = d[13], pt2 = d[14], pt3 = d[15];
+      const unsigned M0 = d[16], M1 = d[17], M2 = d[18], M3 = d[19];
       const int lane = tid & 63;
       const int dA = pdelta[((lane >> 5) ? pt1 : pt0) * PA_PAT_MAXLEN + (lane & 31)];
       const int dB = pdelta[((lane >> 5) ? pt3 : pt2) * PA_PAT_MAXLEN + (lane & 31)];
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const int idx = min(base + (k * BLK + tid) * 2, last);
-        v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+        if (VD) cc[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned short *>(code + idx));
+        else v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
       }
       const int nq = p1 - p0 - 1;
+      const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);   // first thread of this wavefront (uniform)
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const int idx = min(base + (k * BLK + tid) * 2, last);
-        c0[k] = pa_pattern_col<PAT == 2>(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
-        c1[k] = pa_pattern_col<PAT == 2>(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
+        // the entries this wavefront decodes in this step: [ulo, uhi] relative to the chunk's first entry
+        const int ulo = max(0, min(min(base + (k * BLK + wave0) * 2, last) - p0, nq));
+        const int uhi = max(0, min(min(base + (k * BLK + wave0 + 63) * 2, last) + 1 - p0, nq));
+        const int sa = (int)(ulo >= q1) + (int)(ulo >= q2) + (int)(ulo >= q3);
+        const int sb = (int)(uhi >= q1) + (int)(uhi >= q2) + (int)(uhi >= q3);
+        if (sa == sb) {                                               // wave-uniform branch
+          const int qs = sa == 0 ? 0 : sa == 1 ? q1 : sa == 2 ? q2 : q3;
+          const int Lw = sa == 0 ? L0 : sa == 1 ? L1 : sa == 2 ? L2 : L3;
+          const int rs = sa == 0 ? s0r : sa == 1 ? s1r : sa == 2 ? s2r : s3r;
+          const unsigned Mw = sa == 0 ? M0 : sa == 1 ? M1 : sa == 2 ? M2 : M3;
+          const int dsrc = (sa & 2) ? dB : dA;
+          c0[k] = pa_pattern_col_uniform<PAT == 2>(idx - p0, nq, qs, Lw, rs, Mw, dsrc, sa & 1);
+          c1[k] = pa_pattern_col_uniform<PAT == 2>(idx + 1 - p0, nq, qs, Lw, rs, Mw, dsrc, sa & 1);
+        } else {
+          c0[k] = pa_pattern_col<PAT == 2>(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
+          c1[k] = pa_pattern_col<PAT == 2>(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
+        }
       }
     } else if (use16) {
       unsigned q[NPT / 2];
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const int idx = min(base + (k * BLK + tid) * 2, last);
-        v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+        if (VD) cc[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned short *>(code + idx));
+        else v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
         q[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned *>(col16 + idx));
       }
 #pragma unroll
@@ -157,9 +208,18 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const int idx = min(base + (k * BLK + tid) * 2, last);
-        v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+        if (VD) cc[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned short *>(code + idx));
+        else v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
         const i2 c = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + idx));
         c0[k] = c.x; c1[k] = c.y;
+      }
+    }
+    if (VD) {
+#pragma unroll
+      for (int k = 0; k < NPT / 2; ++k) {
+        const int s0 = (cc[k] & 0xffu) << 2, s1 = (cc[k] >> 8) << 2;
+        v[k].x = __hiloint2double(__builtin_amdgcn_ds_bpermute(s0, dict_hi), __builtin_amdgcn_ds_bpermute(s0, dict_lo));
+        v[k].y = __hiloint2double(__builtin_amdgcn_ds_bpermute(s1, dict_hi), __builtin_amdgcn_ds_bpermute(s1, dict_lo));
       }
     }
 #pragma unroll
@@ -274,7 +334,8 @@ inline int64_t pa_encode_col16(const int32_t *crp, const int32_t *col, const std
   return nf;
 }
 
-// Host-side row-pattern analysis.  pdesc: n_chunks*16 ints ({nseg | 0, q1..q3, r0..r3, (L | stride<<8)0..3, pat0..3});
+// Host-side row-pattern analysis.  pdesc: n_chunks*PA_PDESC_INTS ints ({nseg | 0, q1..q3, r0..r3, (L | stride<<8)0..3,
+// pat0..3, magic0..3});
 // pdelta: PA_PAT_MAXLEN ints per pattern.  row_ids (or NULL) maps a stored (compacted) row to its row id; deltas are
 // col - row id.  Only patterns shared by at least `min_rows` rows enter the table (an unstructured row is its own
 // pattern and keeps explicit columns).  Returns the number of chunks that got a
@@ -284,7 +345,7 @@ inline int64_t pa_encode_patterns(const int32_t *crp, const int32_t *col, const 
                                   std::vector<int32_t> &pdelta, int n_threads, int max_patterns = 4096,
                                   int min_rows = 2) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
-  pdesc.assign((size_t)n_chunks * 16, 0);
+  pdesc.assign((size_t)n_chunks * PA_PDESC_INTS, 0);
   pdelta.clear();
   if (n_threads < 1) n_threads = 1;
   auto rid = [&](int64_t r) -> int32_t { return row_ids ? row_ids[r] : (int32_t)r; };
@@ -348,7 +409,7 @@ inline int64_t pa_encode_patterns(const int32_t *crp, const int32_t *col, const 
   std::vector<int64_t> good(n_threads, 0);
   auto segs = [&](int t) {
     for (int64_t c = n_chunks * t / n_threads; c < n_chunks * (t + 1) / n_threads; ++c) {
-      int32_t *d = &pdesc[(size_t)c * 16];
+      int32_t *d = &pdesc[(size_t)c * PA_PDESC_INTS];
       const int64_t r0 = chunk_row[c], r1 = chunk_row[c + 1];
       const int64_t p0 = crp[r0], p1 = crp[r1];
       bool ok = (p1 - (p0 & ~1)) <= cap && p1 > p0;
@@ -381,8 +442,12 @@ inline int64_t pa_encode_patterns(const int32_t *crp, const int32_t *col, const 
         run_rows = 1;
         stride = 1;
       }
-      if (!ok) { for (int k = 0; k < 16; ++k) d[k] = 0; continue; }
+      if (!ok) { for (int k = 0; k < PA_PDESC_INTS; ++k) d[k] = 0; continue; }
       for (int s = ns; s < PA_PAT_SEGMENTS; ++s) { if (s) d[s] = 1 << 30; d[4 + s] = 0; d[8 + s] = 1 | (row_ids ? 1 << 8 : 0); d[12 + s] = 0; }
+      for (int s = 0; s < PA_PAT_SEGMENTS; ++s) {
+        const uint32_t L = (uint32_t)(d[8 + s] & 255);
+        d[16 + s] = (int32_t)(L > 1 ? 0xFFFFFFFFu / L + 1u : 0u);
+      }
       d[0] = ns;
       ++good[t];
     }

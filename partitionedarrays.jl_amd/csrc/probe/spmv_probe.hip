@@ -97,11 +97,12 @@ __global__ __launch_bounds__(256) void k_spmv_persist(
       int ra = 0, re = 0;
       if (r0 + tid < r1) { ra = crp[r0 + tid]; re = crp[r0 + tid + 1]; }
       const int last = max((p1 - 1) & ~1, 0);
-      const int *d = pdesc + chunk * 16;
+      const int *d = pdesc + chunk * PA_PDESC_INTS;
       const int q1 = d[1], q2 = d[2], q3 = d[3];
       const int s0r = d[4], s1r = d[5], s2r = d[6], s3r = d[7];
       const int L0 = d[8], L1 = d[9], L2 = d[10], L3 = d[11];
       const int pt0 = d[12], pt1 = d[13], pt2 = d[14], pt3 = d[15];
+      const unsigned M0 = d[16], M1 = d[17], M2 = d[18], M3 = d[19];
       const int lane = tid & 63;
       const int dA = pdelta[((lane >> 5) ? pt1 : pt0) * PA_PAT_MAXLEN + (lane & 31)];
       const int dB = pdelta[((lane >> 5) ? pt3 : pt2) * PA_PAT_MAXLEN + (lane & 31)];
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(256) void k_spmv_persist(
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const int idx = min(base + (k * BLK + tid) * 2, last);
-        const int c0 = pa_pattern_col<false>(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
-        const int c1 = pa_pattern_col<false>(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, dA, dB);
+        const int c0 = pa_pattern_col<false>(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
+        const int c1 = pa_pattern_col<false>(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
         d2 pr;
         pr.x = v[k].x * x[c0];
         pr.y = v[k].y * x[c1];

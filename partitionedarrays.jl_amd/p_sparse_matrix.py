@@ -112,6 +112,12 @@ class DeviceCSR:
         L.call("pa_csr_encoding", self.h, *[C.byref(x) for x in v])
         return dict(zip(["pattern", "c16", "c32"], [x.value for x in v]))
 
+    def value_dict(self):
+        """Distinct values held in the optional value dictionary (PA_SPMV_VALUE_DICT=1 at creation), 0 when unused."""
+        n = C.c_int()
+        L.call("pa_csr_value_dict", self.h, C.byref(n))
+        return n.value
+
     def update_values(self, nzval):
         nzval = np.ascontiguousarray(nzval, F64)
         assert len(nzval) == self.nnz

@@ -370,6 +370,63 @@ def test_csc_upload_gives_same_bits(orc):
     L.call("pa_csr_destroy", h)
 
 
+def test_value_dictionary_mode_is_lossless(monkeypatch, orc):
+    """PA_SPMV_VALUE_DICT=1: blocks with at most 64 distinct stored values stream one byte per entry instead of eight.
+    Same bits as the fp64 stream on the 27-point operator (2 values; 2 parts, mul! and the multicolour MG-PCG), on a Q1
+    FEM matrix; a matrix with more distinct values keeps the fp64 stream; updating the values drops the dictionary."""
+    def hpcg(P, shape):
+        return pa.build_p_matrix(ranks(P), 16, 12, 10, 16 * shape[0], 12 * shape[1], 10 * shape[2], *shape, keep_host=True)
+    A0, b0 = hpcg(2, (2, 1, 1))
+    monkeypatch.setenv("PA_SPMV_VALUE_DICT", "1")
+    A1, b1 = hpcg(2, (2, 1, 1))
+    assert [bk.own_own.value_dict() for bk in A1.matrix_partition.items] == [2, 2]
+    assert [bk.own_own.value_dict() for bk in A0.matrix_partition.items] == [0, 0]
+    xf = lambda i: orc.hash_x(i.get_local_to_global()) * (i.get_local_to_owner() == i.part)
+    ys = []
+    for A in (A0, A1):
+        x = pa.pvector_from_function(xf, A.col_partition)
+        y = pa.pvector_from_function(lambda i: np.cos(i.get_local_to_global().astype(float)), A.row_partition)
+        pa.mul5_(y, A, x, -0.5, 1.25)
+        ys.append([v.copy() for v in y.own_values().items])
+    for u, v in zip(*ys):
+        assert np.array_equal(u, v)
+    # the multicolour smoother's colour blocks and the fused restriction go through the same kernels
+    S1 = pa.pc_setup(ranks(2), 2, 3, 16, 8, 8, ordering="multicolor_spmv")
+    monkeypatch.delenv("PA_SPMV_VALUE_DICT")
+    S0 = pa.pc_setup(ranks(2), 2, 3, 16, 8, 8, ordering="multicolor_spmv")
+    res = []
+    for S in (S0, S1):
+        A, b = S.A_vec[-1], S.r[-1]
+        h = []
+        x, r0, r, it = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=8, Pl=S, history=h)
+        res.append((r0, h, [v.copy() for v in x.own_values().items]))
+    assert res[0][:2] == res[1][:2] and all(np.array_equal(u, v) for u, v in zip(res[0][2], res[1][2]))
+    monkeypatch.setenv("PA_SPMV_VALUE_DICT", "1")
+    # FEM: a handful of distinct values; random values: too many -> fp64 stream
+    I, J, V, rows, cols = pa.laplacian_fem((40, 30), (1, 1), ranks(1))
+    F = pa.psparse_disassembled(I, J, V, rows, cols, keep_host=True)
+    assert 2 <= F.matrix_partition.items[0].own_own.value_dict() <= 64
+    rng = np.random.default_rng(5)
+    R = pa.DeviceCSR(_random_csr(rng, 200, 300, rng.integers(1, 30, 200)))
+    assert R.value_dict() == 0
+    monkeypatch.delenv("PA_SPMV_VALUE_DICT")
+    F0 = pa.psparse_disassembled(I, J, V, rows, cols, keep_host=True)
+    xF = pa.pvector_from_function(xf, F.col_partition)
+    yF, yF0 = pa.pzeros(F.row_partition), pa.pzeros(F0.row_partition)
+    pa.mul_(yF, F, xF)
+    pa.mul_(yF0, F0, xF)
+    assert np.array_equal(yF.own_values().items[0], yF0.own_values().items[0])
+    blk = A1.matrix_partition.items[0].own_own
+    blk.update_values(np.sin(np.arange(blk.nnz, dtype=np.float64)))
+    assert blk.value_dict() == 0
+    A0.matrix_partition.items[0].own_own.update_values(np.sin(np.arange(blk.nnz, dtype=np.float64)))
+    x = pa.pvector_from_function(xf, A1.col_partition)
+    y0, y1 = pa.pzeros(A0.row_partition), pa.pzeros(A1.row_partition)
+    pa.mul_(y0, A0, x)
+    pa.mul_(y1, A1, x)
+    assert all(np.array_equal(u, v) for u, v in zip(y0.own_values().items, y1.own_values().items))
+
+
 def test_index_widths_and_bases_give_the_same_block(orc):
     """pa_csr_create / pa_csr_create_mixed accept the reference's index types as stored: Int32 or Int64, 1-based (Julia)
     or 0-based, and the mixed form (Int64 row pointers, Int32 columns).  Same device block, same product bits."""
