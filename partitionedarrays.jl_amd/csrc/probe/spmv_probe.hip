@@ -364,6 +364,22 @@ int main(int argc, char **argv) {
   ADD_PAT(128, 4, true)
   ADD_PAT(512, 4, true)
   ADD_PAT(192, 8, true)
+#define ADD_PAT_EPI(BLK, NPT, EPI)                                                                                \
+  { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, BLK * NPT, 4096, cr, &nl);           \
+    const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
+    pa_encode_patterns(rp.data(), hcol.data(), nullptr, nrows, cr, BLK * NPT, pdesc, pdelta, 32);               \
+    int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
+    const int cpx = (nch + 7) / 8;                                                                              \
+    V.push_back({"pattern<" #BLK "," #NPT ",epi=" #EPI ">", [=]() {                                             \
+      hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, true, false, 1, EPI>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, \
+                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
+                         (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
+  ADD_PAT_EPI(256, 6, 0)
+  ADD_PAT_EPI(256, 6, 7)
+  ADD_PAT_EPI(256, 8, 7)
+  ADD_PAT_EPI(256, 6, 8)
 #define ADD_PERSIST(NPT, KF, WPX)                                                                                 \
   { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, 256 * NPT, 96, cr, &nl);             \
     const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
@@ -422,7 +438,7 @@ int main(int argc, char **argv) {
     unsigned long long *d_bad; CK(hipMalloc(&d_bad, 8));
     V[0].run(); CK(hipDeviceSynchronize());
     for (size_t i = 1; i < V.size(); ++i) {
-      if (V[i].name.find("c16=true") == std::string::npos && V[i].name.find("abl=32768") == std::string::npos) continue;
+      if (V[i].name.find("c16=true") == std::string::npos && V[i].name.find("abl=32768") == std::string::npos && (V[i].name.find("epi=") == std::string::npos || V[i].name.find("epi=7") != std::string::npos)) continue;
       CK(hipMemset(d_y2, 0xff, sizeof(double) * nrows)); CK(hipMemset(d_bad, 0, 8));
       V[i].run();
       hipLaunchKernelGGL(k_cmp, dim3((nrows + 255) / 256), dim3(256), 0, 0, d_y, d_y2, nrows, d_bad);
