@@ -76,7 +76,7 @@ struct pa_csr {
   int32_t *d_win = nullptr;        // n_chunks * 16 window bases; [c*16] < 0 => 32-bit chunk
   bool use_pattern = false;        // row-pattern descriptors present
   int64_t n_pattern_chunks = 0;    // chunks whose columns are recomputed from a pattern
-  int32_t *d_pdesc = nullptr;      // n_chunks * 16 descriptor ints; [c*16] = #segments or 0
+  int32_t *d_pdesc = nullptr;      // n_chunks * PA_PDESC_INTS descriptor ints; first of a chunk = #segments or 0
   int32_t *d_pdelta = nullptr;     // 32 deltas per pattern
   bool use_vdict = false;          // value dictionary present and current (dropped when the values are updated)
   int n_dict = 0;
