@@ -100,7 +100,7 @@ __device__ __forceinline__ int pa_pattern_col_uniform(int q, int nq, int qs, int
 //        from the lane that holds it with ds_bpermute -- 1 byte of matrix stream per entry instead of 8.  The 27-point
 //        HPCG operator has 2 distinct values, a Q1 stiffness matrix on a uniform grid about a dozen.
 #define PA_VDICT_MAX 64
-template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, bool VD = false>
+template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, bool VD = false, int UNR = 4>
 __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       const int row = row_ids ? row_ids[r] : r;
       double acc = (EPI != 0 || beta == 0.0) ? 0.0 : beta * y[row];
       const int a = ra - base, e = re - base;
-#pragma unroll 4
+#pragma unroll UNR
       for (int p = a; p < e; ++p) acc = acc + prod[p];
       if (EPI == 1) gs_x[row] = gs_x[row] + (gs_b[row] - acc) / gs_diag[row];
       else if (EPI == 2) gs_x[r] = gs_b[row] - acc;
