@@ -413,8 +413,21 @@ int main(int argc, char **argv) {
                          (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_PAT_ROWS(56)
   ADD_PAT_ROWS(48)
-  ADD_PAT_ROWS(32)
-  ADD_PAT_ROWS(64)
+#define ADD_PAT_ROWS8(MAXR)                                                                                        \
+  { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, 2048, MAXR, cr, &nl, 16);            \
+    const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
+    pa_encode_patterns(rp.data(), hcol.data(), nullptr, nrows, cr, 2048, pdesc, pdelta, 32);                    \
+    int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
+    const int cpx = (nch + 7) / 8;                                                                              \
+    V.push_back({"pattern<256,8,maxrows=" #MAXR ",align16>", [=]() {                                            \
+      hipLaunchKernelGGL((k_spmv_rowsplit<256, 8, true, false, 1, 0>), dim3(cpx * 8), dim3(256), 0, 0, d_rp, d_col, \
+                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
+                         (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
+  ADD_PAT_ROWS8(64)
+  ADD_PAT_ROWS8(72)
+  ADD_PAT_ROWS8(4096)
 #define ADD_PERSIST(NPT, KF, WPX)                                                                                 \
   { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, 256 * NPT, 96, cr, &nl);             \
     const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
