@@ -380,6 +380,8 @@ int main(int argc, char **argv) {
   ADD_PAT_EPI(256, 6, 7)
   ADD_PAT_EPI(256, 8, 7)
   ADD_PAT_EPI(256, 6, 8)
+  ADD_PAT_EPI(256, 6, 9)
+  ADD_PAT_EPI(256, 6, 10)
 #define ADD_PAT_UNR(UNR)                                                                                          \
   { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, 1536, 4096, cr, &nl);                \
     const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
