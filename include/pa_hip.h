@@ -346,6 +346,13 @@ int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int6
                            int32_t *oo_colval, double *oo_nzval, int32_t *oh_rowptr, int32_t *oh_colval,
                            double *oh_nzval, double *b);
 
+/* Set-up of the multicolour smoother: the rows of a part (split blocks, 1-based Int32) dealt by colour into n_colors
+ * blocks in the unsplit column order (own columns, then ghost columns + n_own_cols), plus the diagonal.  out_rowptr[k]
+ * (n_own+1 entries, 1-based) is prefilled by the caller: a row of another colour has length 0 in block k. */
+int pa_host_color_split(int64_t n_own, int64_t n_own_cols, const int32_t *oo_rowptr, const int32_t *oo_colval,
+                        const double *oo_nzval, const int32_t *oh_rowptr, const int32_t *oh_colval, const double *oh_nzval,
+                        const int32_t *color, int32_t n_colors, const int32_t *const *out_rowptr,
+                        int32_t *const *out_colval, double *const *out_nzval, double *diag);
 /* The same with Int64 row pointers, for a part of 2^31 stored entries or more (columns stay Int32). */
 int pa_host_hpcg_split_csr64(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
                              int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost, int64_t *oo_rowptr,

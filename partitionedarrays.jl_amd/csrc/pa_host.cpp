@@ -410,3 +410,49 @@ extern "C" int pa_host_hpcg_split_csr64(int64_t nx, int64_t ny, int64_t nz, int6
   return hpcg_split_csr_impl<int64_t>(nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0, ghost_gids, n_ghost, oo_rowptr, oo_colval,
                                       oo_nzval, oh_rowptr, oh_colval, oh_nzval, b);
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Multicolour smoother set-up: split the rows of a part by colour into n_colors blocks (n_own x n_local, unsplit
+// column order: own columns, then ghost columns shifted by n_own_cols) and extract the diagonal.  out_rowptr[k] is
+// colour k's 1-based row pointer (n_own+1 entries, prefilled by the caller from the row lengths: a row of another colour
+// has length 0); the entries are copied row by row in parallel.
+// ------------------------------------------------------------------------------------------------
+extern "C" int pa_host_color_split(int64_t n_own, int64_t n_own_cols, const int32_t *oo_rowptr, const int32_t *oo_colval,
+                                   const double *oo_nzval, const int32_t *oh_rowptr, const int32_t *oh_colval,
+                                   const double *oh_nzval, const int32_t *color, int32_t n_colors,
+                                   const int32_t *const *out_rowptr, int32_t *const *out_colval,
+                                   double *const *out_nzval, double *diag) {
+  PA_REQUIRE(n_own >= 0 && oo_rowptr && oh_rowptr && color && out_rowptr && out_colval && out_nzval && diag && n_colors > 0,
+             "bad arguments");
+  bool bad = false;
+  const int T = n_threads_for(n_own * 27);
+  auto work = [&](int t) {
+    for (int64_t r = n_own * t / T; r < n_own * (t + 1) / T; ++r) {
+      const int k = color[r];
+      if (k < 0 || k >= n_colors) { bad = true; continue; }
+      int64_t dst = out_rowptr[k][r] - 1;
+      const int64_t need = (oo_rowptr[r + 1] - oo_rowptr[r]) + (oh_rowptr[r + 1] - oh_rowptr[r]);
+      if (out_rowptr[k][r + 1] - out_rowptr[k][r] != need) { bad = true; continue; }
+      double d = 0.0;
+      for (int64_t p = oo_rowptr[r] - 1; p < oo_rowptr[r + 1] - 1; ++p, ++dst) {
+        out_colval[k][dst] = oo_colval[p];
+        out_nzval[k][dst] = oo_nzval[p];
+        if (oo_colval[p] - 1 == r) d = oo_nzval[p];
+      }
+      for (int64_t p = oh_rowptr[r] - 1; p < oh_rowptr[r + 1] - 1; ++p, ++dst) {
+        out_colval[k][dst] = oh_colval[p] + (int32_t)n_own_cols;
+        out_nzval[k][dst] = oh_nzval[p];
+      }
+      diag[r] = d;
+    }
+  };
+  if (T == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+  }
+  PA_REQUIRE(!bad, "colour out of range, or a colour's row pointer does not match the row lengths");
+  return PA_OK;
+}

@@ -145,22 +145,25 @@ class ColoredGaussSeidelSpMV:
         self.ordering = "multicolor_spmv"
 
         def make(h, r, c):
-            rowptr, colv, val, rows = _unsplit_csr(h, r, c)
+            oo, oh = h
             n = r.n_own
             color = np.zeros(n, np.int32)
             ncol = C.c_int32()
-            L.call("pa_host_greedy_coloring", n, L.ptr(rowptr), L.ptr(colv), 1, L.ptr(color), C.byref(ncol))
+            # rows of one colour must not be coupled: the own x own block holds every coupling between own rows
+            L.call("pa_host_greedy_coloring", n, L.ptr(oo.rowptr), L.ptr(oo.colval), 1, L.ptr(color), C.byref(ncol))
+            K = ncol.value
+            length = np.diff(oo.rowptr.astype(np.int64)) + np.diff(oh.rowptr.astype(np.int64))
+            subs = []
+            for k in range(K):
+                rp = np.concatenate([[1], 1 + np.cumsum(np.where(color == k, length, 0))]).astype(np.int32)
+                nz = int(rp[-1]) - 1
+                subs.append(HostCSR(n, c.n_local, rp, np.zeros(nz, np.int32), np.zeros(nz, np.float64)))
             diag = np.zeros(n)
-            isd = colv.astype(np.int64) - 1 == rows
-            diag[rows[isd]] = val[isd]
-            blocks = []
-            ecolor = color[rows]
-            for k in range(ncol.value):
-                sel = ecolor == k
-                cnt = np.bincount(rows[sel], minlength=n)
-                rp = np.concatenate([[1], 1 + np.cumsum(cnt)]).astype(np.int32)
-                sub = HostCSR(n, c.n_local, rp, np.ascontiguousarray(colv[sel]), np.ascontiguousarray(val[sel]))
-                blocks.append(DeviceCSR(sub))
+            arr = lambda xs: (C.c_void_p * K)(*[x.ctypes.data for x in xs])
+            L.call("pa_host_color_split", n, c.n_own, L.ptr(oo.rowptr), L.ptr(oo.colval), L.ptr(oo.nzval), L.ptr(oh.rowptr),
+                   L.ptr(oh.colval), L.ptr(oh.nzval), L.ptr(color), K, arr([s.rowptr for s in subs]),
+                   arr([s.colval for s in subs]), arr([s.nzval for s in subs]), L.ptr(diag))
+            blocks = [DeviceCSR(s) for s in subs]
             handles = (C.c_void_p * len(blocks))(*[blk.h for blk in blocks])
             return blocks, DeviceVector(n, 0).upload(diag), handles, color
 
