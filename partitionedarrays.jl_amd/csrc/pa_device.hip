@@ -811,11 +811,22 @@ extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, in
     for (int64_t p = 0; p < nnz; ++p) PA_REQUIRE(col0[p] >= 0 && col0[p] < n_cols, "column index out of range at entry %lld", (long long)p);
   } else {
     colbuf.resize(nnz);
-    for (int64_t p = 0; p < nnz; ++p) {
-      const int64_t j = read_index(colval, colval_bytes, p) - index_base;
-      PA_REQUIRE(j >= 0 && j < n_cols, "column index out of range at entry %lld", (long long)p);
-      colbuf[p] = (int32_t)j;
+    const int T = host_threads(nnz);
+    std::vector<int64_t> bad(T, -1);
+    auto conv = [&](int t) {
+      for (int64_t p = nnz * t / T; p < nnz * (t + 1) / T; ++p) {
+        const int64_t j = read_index(colval, colval_bytes, p) - index_base;
+        if (j < 0 || j >= n_cols) { if (bad[t] < 0) bad[t] = p; continue; }
+        colbuf[p] = (int32_t)j;
+      }
+    };
+    {
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; ++t) th.emplace_back(conv, t);
+      conv(0);
+      for (auto &x : th) x.join();
     }
+    for (int t = 0; t < T; ++t) PA_REQUIRE(bad[t] < 0, "column index out of range at entry %lld", (long long)bad[t]);
     col0 = colbuf.data();
   }
   return csr_build(c, n_rows, n_cols, nnz, rp, col0, nzval, out);
