@@ -94,11 +94,19 @@ class GaussSeidel:
 
 def _unsplit_csr(h, r, c):
     """(own_own, own_ghost) -> the unsplit local CSR HPCG stores (n_own x n_local, ghost columns shifted by n_own):
-    rowptr (1-based), colval (1-based), nzval, and the 0-based row of every entry.  Both blocks are row-sorted with
-    sorted columns and every ghost column is larger than every own column, so the merge is a placement, not a sort."""
-    blk = _rows_block(h, r, c, np.arange(r.n_own, dtype=np.int64))
-    rows = np.repeat(np.arange(r.n_own), np.diff(blk.rowptr.astype(np.int64)))
-    return blk.rowptr, blk.colval, blk.nzval, rows
+    rowptr (1-based), colval (1-based), nzval, diag.  Both blocks are row-sorted with sorted columns and every ghost
+    column is larger than every own column, so the merge is a placement (native, multi-threaded: the one-colour case of
+    pa_host_color_split)."""
+    oo, oh = h
+    n = r.n_own
+    length = np.diff(oo.rowptr.astype(np.int64)) + np.diff(oh.rowptr.astype(np.int64))
+    rowptr = np.concatenate([[1], 1 + np.cumsum(length)]).astype(np.int32)
+    nz = int(rowptr[-1]) - 1
+    colv, val, diag = np.zeros(nz, np.int32), np.zeros(nz, np.float64), np.zeros(n)
+    one = lambda a: (C.c_void_p * 1)(a.ctypes.data)
+    L.call("pa_host_color_split", n, c.n_own, L.ptr(oo.rowptr), L.ptr(oo.colval), L.ptr(oo.nzval), L.ptr(oh.rowptr),
+           L.ptr(oh.colval), L.ptr(oh.nzval), L.ptr(np.zeros(n, np.int32)), 1, one(rowptr), one(colv), one(val), L.ptr(diag))
+    return rowptr, colv, val, diag
 
 
 def _rows_block(h, r, c, f):
