@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <thread>
 #include <cstring>
 #include <numeric>
@@ -591,6 +592,14 @@ static inline int64_t read_index(const void *a, int bytes, int64_t i) {
 static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
                           const int32_t *col0 /*0-based, host*/, const double *nzval, pa_csr **out) {
   // non-empty rows; compact when most rows are empty (the own_ghost block: only boundary rows)
+  const bool tm_ = getenv("PA_SETUP_TIMING") != nullptr;   // stderr: seconds per phase of this function
+  auto t0_ = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!tm_) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[pa setup] %-10s %8.3f s  (nnz %lld)\n", what, std::chrono::duration<double>(t1 - t0_).count(), (long long)nnz);
+    t0_ = t1;
+  };
   std::vector<int32_t> row_ids;
   int64_t n_nonempty = 0;
   for (int64_t r = 0; r < n_rows; ++r) n_nonempty += rp[r + 1] > rp[r];
@@ -612,6 +621,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   std::vector<int32_t> chunk_row;
   int64_t n_long = 0;
   pa_build_chunks(crp.data(), nc, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
+  lap("chunks");
   pa_csr *A = new pa_csr();
   A->ctx = c; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
   A->n_crows = nc; A->n_chunks = (int64_t)chunk_row.size() - 1; A->n_nonempty = n_nonempty; A->n_long = n_long;
@@ -630,6 +640,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
     PA_HIP(hipMemcpy(A->d_val, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
   }
   PA_HIP(hipMemcpy(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size(), hipMemcpyHostToDevice));
+  lap("upload");
   // 16-bit windowed column stream (index compression; see pa_spmv_kernel.h). PA_SPMV_COL16=0 disables it.
   {
     const char *e = getenv("PA_SPMV_COL16");
@@ -638,10 +649,12 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
       std::vector<uint16_t> c16(nnz + pad, 0);
       std::vector<int32_t> win((size_t)A->n_chunks * PA_C16_WINDOWS, 0);
       A->n_c16_fallback = pa_encode_col16(crp.data(), col0, chunk_row, PA_SPMV_CHUNK_NNZ, c16.data(), win.data(), host_threads(nnz));
+      lap("col16");
       PA_HIP(hipMalloc(&A->d_col16, sizeof(uint16_t) * (nnz + pad)));
       PA_HIP(hipMalloc(&A->d_win, sizeof(int32_t) * std::max<size_t>(1, win.size())));
       PA_HIP(hipMemcpy(A->d_col16, c16.data(), sizeof(uint16_t) * (nnz + pad), hipMemcpyHostToDevice));
       if (!win.empty()) PA_HIP(hipMemcpy(A->d_win, win.data(), sizeof(int32_t) * win.size(), hipMemcpyHostToDevice));
+      lap("col16 up");
     }
   }
   // row-pattern descriptors (no column stream at all); compacted blocks describe runs of constant row-id stride.
@@ -653,6 +666,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
       std::vector<int32_t> pdesc, pdelta;
       A->n_pattern_chunks = pa_encode_patterns(crp.data(), col0, compact ? row_ids.data() : nullptr, nc, chunk_row,
                                                PA_SPMV_CHUNK_NNZ, pdesc, pdelta, host_threads(nnz));
+      lap("patterns");
       // worth it only when it covers most of the matrix
       if (A->n_pattern_chunks * 2 >= A->n_chunks) {
         A->use_pattern = true;
@@ -800,6 +814,7 @@ extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, in
   PA_REQUIRE(n_rows < (int64_t)2147483000 && n_cols < (int64_t)2147483000, "block too large for Int32 device indices");
   PA_REQUIRE(rowptr_bytes == 8 || nnz < (int64_t)2147483000, "2^31 stored entries or more need 64-bit row pointers");
   PA_REQUIRE(nnz == 0 || (colval && nzval), "colval/nzval are NULL");
+  const auto t0_ = std::chrono::steady_clock::now();
   std::vector<int64_t> rp(n_rows + 1);
   for (int64_t r = 0; r <= n_rows; ++r) rp[r] = read_index(rowptr, rowptr_bytes, r) - index_base;
   PA_REQUIRE(rp[0] == 0 && rp[n_rows] == nnz, "rowptr does not span [base, base+nnz]");
@@ -829,6 +844,8 @@ extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, in
     for (int t = 0; t < T; ++t) PA_REQUIRE(bad[t] < 0, "column index out of range at entry %lld", (long long)bad[t]);
     col0 = colbuf.data();
   }
+  if (getenv("PA_SETUP_TIMING"))
+    fprintf(stderr, "[pa setup] %-10s %8.3f s  (nnz %lld)\n", "validate", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(), (long long)nnz);
   return csr_build(c, n_rows, n_cols, nnz, rp, col0, nzval, out);
 }
 
