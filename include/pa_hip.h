@@ -144,6 +144,10 @@ int pa_csr_info(const pa_csr *A, int64_t *n_rows, int64_t *n_cols, int64_t *nnz,
 /* How the row-split chunks of A get their column indices (library-internal index compression; the values, the
  * results and pa_csr_update_values are unaffected): recomputed from row patterns / 16-bit windowed stream / 32-bit. */
 int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern_chunks, int64_t *n_c16_chunks, int64_t *n_c32_chunks);
+/* HBM bytes the block occupies (values, the column streams actually kept, row pointers, chunk table, descriptors).
+ * A block whose chunks are described by row patterns keeps no columns for them: a stencil operator costs ~8 bytes per
+ * stored entry, a block on the 16-bit stream ~14 (8 + 4 + 2). */
+int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes);
 /* Optional, lossless: with PA_SPMV_VALUE_DICT=1 in the environment at creation, a block whose stored values take at most
  * 64 distinct bit patterns (27-point HPCG: 2; Q1 stiffness on a uniform grid: about a dozen) also keeps one byte per
  * entry and the kernels stream that instead of the 8-byte values -- same values, same products, same order, same bits.

@@ -628,57 +628,48 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   A->compact = compact;
   PA_HIP(hipSetDevice(c->device));
   const size_t pad = 8;
+  // column streams first: they decide what has to live in HBM at all (see pa_encode_columns).  PA_SPMV_PATTERN=0 /
+  // PA_SPMV_COL16=0 disable the row-pattern descriptors / the 16-bit windowed stream.
+  pa_col_streams cs;
+  {
+    const char *ep = getenv("PA_SPMV_PATTERN"), *e16 = getenv("PA_SPMV_COL16"), *ec = getenv("PA_SPMV_COMPACT_STREAMS");
+    pa_encode_columns(crp.data(), col0, compact ? row_ids.data() : nullptr, nc, chunk_row, PA_SPMV_CHUNK_NNZ,
+                      !(ep && atoi(ep) == 0) && nnz > 0, !(e16 && atoi(e16) == 0) && nnz > 0, host_threads(nnz), cs,
+                      !(ec && atoi(ec) == 0));
+  }
+  lap("encode");
+  A->use_pattern = cs.use_pattern; A->use_c16 = cs.use_c16;
+  A->n_pattern_chunks = cs.n_pattern; A->n_c16_chunks = cs.n_c16; A->n_c32_chunks = cs.n_c32;
+  A->n_c16_fallback = cs.use_c16 ? A->n_chunks - cs.n_pattern - cs.n_c16 : 0;
+  A->n_col32 = cs.full ? nnz : (int64_t)cs.c32.size() - (int64_t)pad;
   PA_HIP(hipMalloc(&A->d_crp, sizeof(int32_t) * (nc + 1)));
-  PA_HIP(hipMalloc(&A->d_col, sizeof(int32_t) * (nnz + pad)));
+  PA_HIP(hipMalloc(&A->d_col, sizeof(int32_t) * (A->n_col32 + pad)));
   PA_HIP(hipMalloc(&A->d_val, sizeof(double) * (nnz + pad)));
   PA_HIP(hipMalloc(&A->d_chunk_row, sizeof(int32_t) * chunk_row.size()));
-  PA_HIP(hipMemset(A->d_col + nnz, 0, sizeof(int32_t) * pad));
+  PA_HIP(hipMemset(A->d_col + A->n_col32, 0, sizeof(int32_t) * pad));
   PA_HIP(hipMemset(A->d_val + nnz, 0, sizeof(double) * pad));
   PA_HIP(hipMemcpy(A->d_crp, crp.data(), sizeof(int32_t) * (nc + 1), hipMemcpyHostToDevice));
   if (nnz) {
-    PA_HIP(hipMemcpy(A->d_col, col0, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    if (cs.full) PA_HIP(hipMemcpy(A->d_col, col0, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    else if (A->n_col32) PA_HIP(hipMemcpy(A->d_col, cs.c32.data(), sizeof(int32_t) * A->n_col32, hipMemcpyHostToDevice));
     PA_HIP(hipMemcpy(A->d_val, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
   }
   PA_HIP(hipMemcpy(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size(), hipMemcpyHostToDevice));
+  if (cs.use_c16) {
+    A->n_col16 = (int64_t)cs.c16.size();
+    PA_HIP(hipMalloc(&A->d_col16, sizeof(uint16_t) * cs.c16.size()));
+    PA_HIP(hipMalloc(&A->d_win, sizeof(int32_t) * std::max<size_t>(1, cs.win.size())));
+    PA_HIP(hipMemcpy(A->d_col16, cs.c16.data(), sizeof(uint16_t) * cs.c16.size(), hipMemcpyHostToDevice));
+    if (!cs.win.empty()) PA_HIP(hipMemcpy(A->d_win, cs.win.data(), sizeof(int32_t) * cs.win.size(), hipMemcpyHostToDevice));
+  }
+  if (cs.use_pattern) {
+    PA_HIP(hipMalloc(&A->d_pdesc, sizeof(int32_t) * cs.pdesc.size()));
+    A->n_pdelta = (int64_t)cs.pdelta.size();
+    PA_HIP(hipMalloc(&A->d_pdelta, sizeof(int32_t) * cs.pdelta.size()));
+    PA_HIP(hipMemcpy(A->d_pdesc, cs.pdesc.data(), sizeof(int32_t) * cs.pdesc.size(), hipMemcpyHostToDevice));
+    PA_HIP(hipMemcpy(A->d_pdelta, cs.pdelta.data(), sizeof(int32_t) * cs.pdelta.size(), hipMemcpyHostToDevice));
+  }
   lap("upload");
-  // 16-bit windowed column stream (index compression; see pa_spmv_kernel.h). PA_SPMV_COL16=0 disables it.
-  {
-    const char *e = getenv("PA_SPMV_COL16");
-    A->use_c16 = !(e && atoi(e) == 0) && nnz > 0;
-    if (A->use_c16) {
-      std::vector<uint16_t> c16(nnz + pad, 0);
-      std::vector<int32_t> win((size_t)A->n_chunks * PA_C16_WINDOWS, 0);
-      A->n_c16_fallback = pa_encode_col16(crp.data(), col0, chunk_row, PA_SPMV_CHUNK_NNZ, c16.data(), win.data(), host_threads(nnz));
-      lap("col16");
-      PA_HIP(hipMalloc(&A->d_col16, sizeof(uint16_t) * (nnz + pad)));
-      PA_HIP(hipMalloc(&A->d_win, sizeof(int32_t) * std::max<size_t>(1, win.size())));
-      PA_HIP(hipMemcpy(A->d_col16, c16.data(), sizeof(uint16_t) * (nnz + pad), hipMemcpyHostToDevice));
-      if (!win.empty()) PA_HIP(hipMemcpy(A->d_win, win.data(), sizeof(int32_t) * win.size(), hipMemcpyHostToDevice));
-      lap("col16 up");
-    }
-  }
-  // row-pattern descriptors (no column stream at all); compacted blocks describe runs of constant row-id stride.
-  // PA_SPMV_PATTERN=0 disables.
-  {
-    const char *e = getenv("PA_SPMV_PATTERN");
-    const bool want = !(e && atoi(e) == 0) && nnz > 0;
-    if (want) {
-      std::vector<int32_t> pdesc, pdelta;
-      A->n_pattern_chunks = pa_encode_patterns(crp.data(), col0, compact ? row_ids.data() : nullptr, nc, chunk_row,
-                                               PA_SPMV_CHUNK_NNZ, pdesc, pdelta, host_threads(nnz));
-      lap("patterns");
-      // worth it only when it covers most of the matrix
-      if (A->n_pattern_chunks * 2 >= A->n_chunks) {
-        A->use_pattern = true;
-        PA_HIP(hipMalloc(&A->d_pdesc, sizeof(int32_t) * pdesc.size()));
-        PA_HIP(hipMalloc(&A->d_pdelta, sizeof(int32_t) * pdelta.size()));
-        PA_HIP(hipMemcpy(A->d_pdesc, pdesc.data(), sizeof(int32_t) * pdesc.size(), hipMemcpyHostToDevice));
-        PA_HIP(hipMemcpy(A->d_pdelta, pdelta.data(), sizeof(int32_t) * pdelta.size(), hipMemcpyHostToDevice));
-      } else {
-        A->n_pattern_chunks = 0;
-      }
-    }
-  }
   // optional lossless value dictionary (PA_SPMV_VALUE_DICT=1): at most PA_VDICT_MAX distinct bit patterns
   {
     const char *e = getenv("PA_SPMV_VALUE_DICT");
@@ -972,22 +963,28 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
   int64_t n_long = 0;
   pa_build_chunks(crp.data(), n_rows, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
   const int64_t nch = (int64_t)chunk_row.size() - 1;
-  std::vector<uint16_t> c16(nnz + 8, 0);
-  std::vector<int32_t> win((size_t)nch * PA_C16_WINDOWS, 0), pdesc, pdelta;
-  const int64_t nfall = pa_encode_col16(crp.data(), col.data(), chunk_row, PA_SPMV_CHUNK_NNZ, c16.data(), win.data(), 1);
-  const int64_t npat = pa_encode_patterns(crp.data(), col.data(), row_ids.empty() ? nullptr : row_ids.data(), n_rows, chunk_row,
-                                          PA_SPMV_CHUNK_NNZ, pdesc, pdelta, 1);
+  // both forms of the streams: full length (no descriptors) and compacted next to the row patterns
+  pa_col_streams full, cs;
+  pa_encode_columns(crp.data(), col.data(), nullptr, n_rows, chunk_row, PA_SPMV_CHUNK_NNZ, false, true, 1, full);
+  pa_encode_columns(crp.data(), col.data(), row_ids.empty() ? nullptr : row_ids.data(), n_rows, chunk_row, PA_SPMV_CHUNK_NNZ,
+                    true, true, 1, cs);
+  PA_REQUIRE(full.full && full.n_c16 + full.n_c32 == nch, "chunk counts of the full-length streams");
+  PA_REQUIRE(cs.n_pattern + cs.n_c16 + cs.n_c32 == nch, "chunk counts of the compacted streams");
+  const int64_t npat = cs.n_pattern;
+  const std::vector<int32_t> &pdesc = cs.pdesc, &pdelta = cs.pdelta;
   for (int64_t c = 0; c < nch; ++c) {
     const int64_t r0 = chunk_row[c], r1 = chunk_row[c + 1], p0 = crp[r0], p1 = crp[r1];
+    const bool is_long = (p1 - (p0 & ~1)) > PA_SPMV_CHUNK_NNZ;
     PA_REQUIRE(r1 > r0, "empty chunk %lld", (long long)c);
-    PA_REQUIRE((p1 - (p0 & ~1)) <= PA_SPMV_CHUNK_NNZ || r1 - r0 == 1, "chunk %lld overflows the LDS stage", (long long)c);
-    if (win[c * PA_C16_WINDOWS] >= 0 && (p1 - (p0 & ~1)) <= PA_SPMV_CHUNK_NNZ)
+    PA_REQUIRE(!is_long || r1 - r0 == 1, "chunk %lld overflows the LDS stage", (long long)c);
+    if (full.win[c * PA_C16_WINDOWS] >= 0 && !is_long)
       for (int64_t p = p0; p < p1; ++p) {
-        const int32_t dec = win[c * PA_C16_WINDOWS + (c16[p] >> 12)] + (c16[p] & 4095);
+        const int32_t dec = full.win[c * PA_C16_WINDOWS + (full.c16[p] >> 12)] + (full.c16[p] & 4095);
         PA_REQUIRE(dec == col[p], "c16 decode mismatch at entry %lld", (long long)p);
       }
+    if (!cs.use_pattern) continue;
     const int32_t *d = &pdesc[(size_t)c * PA_PDESC_INTS];
-    if (npat > 0 && d[0] > 0)
+    if (d[0] > 0) {
       for (int64_t p = p0; p < p1; ++p) {
         const int q = (int)(p - p0);
         const int s = (q >= d[1]) + (q >= d[2]) + (q >= d[3]);
@@ -997,7 +994,22 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
         const int32_t dec = d[4 + s] + rr * stride + pdelta[(size_t)d[12 + s] * PA_PAT_MAXLEN + (t - rr * L)];
         PA_REQUIRE(dec == col[p], "pattern decode mismatch at entry %lld (chunk %lld)", (long long)p, (long long)c);
       }
+    } else if (cs.win[c * PA_C16_WINDOWS] >= 0 && !is_long) {     // compacted 16-bit stream, the kernel's indexing
+      for (int64_t p = p0; p < p1; ++p) {
+        const int64_t k = p + d[1];
+        PA_REQUIRE(k >= 0 && k + 1 < (int64_t)cs.c16.size(), "compacted c16 slot out of range (chunk %lld)", (long long)c);
+        const int32_t dec = cs.win[c * PA_C16_WINDOWS + (cs.c16[k] >> 12)] + (cs.c16[k] & 4095);
+        PA_REQUIRE(dec == col[p], "compacted c16 decode mismatch at entry %lld", (long long)p);
+      }
+    } else {                                                       // compacted 32-bit stream
+      for (int64_t p = p0; p < p1; ++p) {
+        const int64_t k = p + d[2];
+        PA_REQUIRE(k >= 0 && k + 1 < (int64_t)cs.c32.size(), "compacted 32-bit slot out of range (chunk %lld)", (long long)c);
+        PA_REQUIRE(cs.c32[k] == col[p], "compacted 32-bit column mismatch at entry %lld", (long long)p);
+      }
+    }
   }
+  const int64_t nfall = full.n_c32;
   if (n_chunks) *n_chunks = nch;
   if (n_pattern) *n_pattern = npat;
   if (n_c16) *n_c16 = nch - nfall;
@@ -1010,16 +1022,26 @@ extern "C" int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern, int64_t *n_c
   PA_REQUIRE(A != nullptr, "csr is NULL");
   int64_t tp = 0, t16 = 0, t32 = 0;
   for (const pa_csr *S = A; S; S = S->next) {
-    const int64_t pat = S->use_pattern ? S->n_pattern_chunks : 0;
-    // chunks without a pattern descriptor use the 16-bit stream when they encode, else 32-bit columns
-    int64_t c16 = 0;
-    if (S->use_c16) c16 = (S->n_chunks - S->n_c16_fallback) - pat;
-    if (c16 < 0) c16 = 0;
-    tp += pat; t16 += c16; t32 += S->n_chunks - pat - c16;
+    tp += S->n_pattern_chunks; t16 += S->n_c16_chunks; t32 += S->n_c32_chunks;
   }
   if (n_pattern) *n_pattern = tp;
   if (n_c16) *n_c16 = t16;
   if (n_c32) *n_c32 = t32;
+  return PA_OK;
+}
+
+extern "C" int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes) {
+  PA_REQUIRE(A && bytes, "bad arguments");
+  int64_t t = 0;
+  for (const pa_csr *S = A; S; S = S->next) {
+    const int64_t pad = 8;
+    t += 4 * (S->n_crows + 1) + 4 * (S->n_col32 + pad) + 8 * (S->nnz + pad) + 4 * (S->n_chunks + 1);
+    if (S->use_c16) t += 2 * S->n_col16 + 4 * S->n_chunks * PA_C16_WINDOWS;
+    if (S->use_pattern) t += 4 * S->n_chunks * PA_PDESC_INTS + 4 * S->n_pdelta;
+    if (S->use_vdict) t += S->nnz + pad + 8 * PA_VDICT_MAX;
+    if (S->compact) t += 4 * S->n_crows;
+  }
+  *bytes = t;
   return PA_OK;
 }
 

@@ -26,7 +26,8 @@ __device__ __forceinline__ T pa_stream_load(const T *p) {
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 
 // Column encodings of a chunk
-//   32-bit : col[p]                                            (always present; fallback and long rows)
+//   32-bit : col[p]                                            (fallback and long rows; see pa_encode_columns for which
+//            chunks keep a column stream at all)
 //   "c16"  : col[p] = win[chunk][c16[p] >> 12] + (c16[p] & 4095)  -- up to PA_C16_WINDOWS 4096-aligned column
 //            windows per chunk (stencil / FEM / banded rows touch a handful of narrow column clusters), 2 bytes per
 //            stored entry instead of 4.  Pure index compression: values stay fp64, pa_csr_update_values is unaffected,
@@ -140,6 +141,13 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     int mywin = -1;
     if (C16 && nseg <= 0) mywin = win[chunk * PA_C16_WINDOWS + (tid & (PA_C16_WINDOWS - 1))];
     const bool use16 = C16 && nseg <= 0 && (__builtin_amdgcn_readfirstlane(mywin) >= 0);   // lane 0 holds window 0
+    // A block with row patterns keeps columns only for its chunks WITHOUT a descriptor (compacted streams): such a
+    // chunk's descriptor slot holds where its columns sit relative to its entry offsets (0: full-length streams).
+    int sh16 = 0, sh32 = 0;
+    if (PAT && nseg <= 0) {
+      sh16 = pdesc[chunk * PA_PDESC_INTS + 1];
+      sh32 = pdesc[chunk * PA_PDESC_INTS + 2];
+    }
     d2 v[NPT / 2];
     unsigned cc[NPT / 2];
     int c0[NPT / 2], c1[NPT / 2];
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         const int idx = min(base + (k * BLK + tid) * 2, last);
         if (VD) cc[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned short *>(code + idx));
         else v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
-        q[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned *>(col16 + idx));
+        q[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned *>(col16 + (idx + sh16)));
       }
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
@@ -210,7 +218,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         const int idx = min(base + (k * BLK + tid) * 2, last);
         if (VD) cc[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned short *>(code + idx));
         else v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
-        const i2 c = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + idx));
+        const i2 c = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + (idx + sh32)));
         c0[k] = c.x; c1[k] = c.y;
       }
     }
@@ -258,12 +266,13 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     // one long row (more stored entries than a chunk holds): windows of CAP products, summed by
     // lane 0 in ascending p so that even this path keeps the reference's order.
     const int row = row_ids ? row_ids[r0] : r0;
+    const int *lcol = col + (PAT ? pdesc[chunk * PA_PDESC_INTS + 2] : 0);   // compacted 32-bit stream, see above
     double acc = 0.0;
     if (tid == 0) acc = (EPI != 0 || beta == 0.0) ? 0.0 : beta * y[row];
     for (int w = p0; w < p1; w += CAP) {
       const int wend = min(w + CAP, p1);
       for (int idx = w + tid; idx < wend; idx += BLK) {
-        double pr = val[idx] * x[col[idx]];
+        double pr = val[idx] * x[lcol[idx]];
         if (alpha != 1.0) pr = pr * alpha;
         prod[idx - w] = pr;
       }
@@ -310,8 +319,10 @@ inline void pa_build_chunks(const int32_t *crp, int64_t nc, int cap, int max_row
 
 // Host-side c16 encoding of every chunk (multi-threaded over chunks). win has n_chunks*PA_C16_WINDOWS entries;
 // win[c*16] = -1 marks a chunk that keeps 32-bit columns (too many windows, or a long row).
+// pos (or NULL): where chunk c's entries go in c16, pos[c] = slot of the entry at its 2-aligned start, or -1 = this chunk
+// gets no 16-bit columns (not counted as a fallback).  NULL: entry p goes to c16[p].
 inline int64_t pa_encode_col16(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row, int cap,
-                               uint16_t *c16, int32_t *win, int n_threads) {
+                               uint16_t *c16, int32_t *win, int n_threads, const int64_t *pos = nullptr) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   std::vector<int64_t> fallback(n_threads > 0 ? n_threads : 1, 0);
   auto work = [&](int t, int T) {
@@ -319,6 +330,8 @@ inline int64_t pa_encode_col16(const int32_t *crp, const int32_t *col, const std
       int32_t *w = win + c * PA_C16_WINDOWS;
       for (int s = 0; s < PA_C16_WINDOWS; ++s) w[s] = 0;
       const int64_t p0 = crp[chunk_row[c]], p1 = crp[chunk_row[c + 1]];
+      if (pos && pos[c] < 0) { w[0] = -1; continue; }
+      const int64_t shift = pos ? pos[c] - (p0 & ~(int64_t)1) : 0;
       bool ok = (p1 - (p0 & ~1)) <= cap;
       int n = 0;
       int32_t tags[PA_C16_WINDOWS];
@@ -330,7 +343,7 @@ inline int64_t pa_encode_col16(const int32_t *crp, const int32_t *col, const std
           if (n == PA_C16_WINDOWS) { ok = false; break; }
           tags[n++] = tag;
         }
-        c16[p] = (uint16_t)((s << 12) | (col[p] & 4095));
+        c16[p + shift] = (uint16_t)((s << 12) | (col[p] & 4095));
       }
       if (ok) for (int s = 0; s < n; ++s) w[s] = tags[s] << 12;
       else { w[0] = -1; ++fallback[t]; }
@@ -474,6 +487,88 @@ inline int64_t pa_encode_patterns(const int32_t *crp, const int32_t *col, const 
   int64_t ng = 0;
   for (auto v : good) ng += v;
   return ng;
+}
+
+// Column streams of one block exactly as the kernel reads them.
+//   block without row patterns: `c16` (when wanted) is full length, entry p at c16[p], and the 32-bit columns are the
+//     caller's own array (`full`);
+//   block with row patterns (descriptors on at least half of its chunks): columns are kept ONLY for the chunks without
+//     a descriptor -- `c16` for those that encode in 16-bit windows, `c32` for the rest (too many windows, long rows) --
+//     and such a chunk's descriptor slot holds {0, shift16, shift32}: its entry p sits at c16[p + shift16] or
+//     c32[p + shift32].  A stencil operator then stores 8 bytes per entry (the value) instead of 14.
+struct pa_col_streams {
+  bool use_pattern = false, use_c16 = false, full = true;
+  std::vector<int32_t> pdesc, pdelta, win, c32;
+  std::vector<uint16_t> c16;
+  int64_t n_pattern = 0, n_c16 = 0, n_c32 = 0;   // chunks by column encoding
+};
+
+inline void pa_encode_columns(const int32_t *crp, const int32_t *col, const int32_t *row_ids, int64_t n_rows,
+                              const std::vector<int32_t> &chunk_row, int cap, bool want_pattern, bool want_c16,
+                              int n_threads, pa_col_streams &S, bool compact_streams = true) {
+  const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
+  const int64_t nnz = n_rows > 0 ? crp[n_rows] : 0;
+  const size_t pad = 8;
+  S = pa_col_streams();
+  if (nnz == 0 || n_chunks == 0) { S.n_c32 = n_chunks; return; }
+  if (want_pattern) {
+    S.n_pattern = pa_encode_patterns(crp, col, row_ids, n_rows, chunk_row, cap, S.pdesc, S.pdelta, n_threads);
+    S.use_pattern = S.n_pattern > 0 && S.n_pattern * 2 >= n_chunks;   // worth it only when it covers most of the block
+    if (!S.use_pattern) { S.n_pattern = 0; S.pdesc.clear(); S.pdelta.clear(); }
+  }
+  S.use_c16 = want_c16;
+  if (want_c16) S.win.assign((size_t)n_chunks * PA_C16_WINDOWS, 0);
+  if (!S.use_pattern || !compact_streams) {
+    // full-length streams (with descriptors only for measurements: their column slots stay 0 = no shift)
+    if (want_c16) {
+      S.c16.assign(nnz + pad, 0);
+      pa_encode_col16(crp, col, chunk_row, cap, S.c16.data(), S.win.data(), n_threads);
+    }
+    for (int64_t c = 0; c < n_chunks; ++c) {
+      if (S.use_pattern && S.pdesc[(size_t)c * PA_PDESC_INTS] > 0) continue;
+      if (want_c16 && S.win[(size_t)c * PA_C16_WINDOWS] >= 0) ++S.n_c16; else ++S.n_c32;
+    }
+    return;
+  }
+  S.full = false;
+  auto span = [&](int64_t c) {   // slots of chunk c counted from its 2-aligned start, plus the pair the clamped loads may touch
+    const int64_t p0 = crp[chunk_row[c]], p1 = crp[chunk_row[c + 1]];
+    return ((p1 - (p0 & ~(int64_t)1) + 1) & ~(int64_t)1) + 2;
+  };
+  auto start = [&](int64_t c) { return (int64_t)crp[chunk_row[c]] & ~(int64_t)1; };
+  if (want_c16) {
+    std::vector<int64_t> pos(n_chunks, -1);
+    int64_t n16 = 0;
+    for (int64_t c = 0; c < n_chunks; ++c) {
+      if (S.pdesc[(size_t)c * PA_PDESC_INTS] > 0) continue;
+      if (crp[chunk_row[c + 1]] - start(c) > cap) continue;           // a long row keeps 32-bit columns
+      pos[c] = n16;
+      n16 += span(c);
+    }
+    S.c16.assign(n16 + pad, 0);
+    pa_encode_col16(crp, col, chunk_row, cap, S.c16.data(), S.win.data(), n_threads, pos.data());
+    for (int64_t c = 0; c < n_chunks; ++c)
+      if (pos[c] >= 0 && S.win[(size_t)c * PA_C16_WINDOWS] >= 0) {
+        S.pdesc[(size_t)c * PA_PDESC_INTS + 1] = (int32_t)(pos[c] - start(c));
+        ++S.n_c16;
+      }
+  }
+  int64_t n32 = 0;
+  std::vector<int64_t> pos32(n_chunks, -1);
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    if (S.pdesc[(size_t)c * PA_PDESC_INTS] > 0) continue;
+    if (want_c16 && S.win[(size_t)c * PA_C16_WINDOWS] >= 0) continue;
+    pos32[c] = n32;
+    n32 += span(c);
+    ++S.n_c32;
+  }
+  S.c32.assign(n32 + pad, 0);
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    if (pos32[c] < 0) continue;
+    const int64_t b = start(c), p1 = crp[chunk_row[c + 1]];
+    std::memcpy(&S.c32[pos32[c]], col + b, sizeof(int32_t) * (size_t)(p1 - b));
+    S.pdesc[(size_t)c * PA_PDESC_INTS + 2] = (int32_t)(pos32[c] - b);
+  }
 }
 
 #endif

@@ -112,6 +112,12 @@ class DeviceCSR:
         L.call("pa_csr_encoding", self.h, *[C.byref(x) for x in v])
         return dict(zip(["pattern", "c16", "c32"], [x.value for x in v]))
 
+    def device_bytes(self):
+        """HBM bytes the block occupies (pa_csr_device_bytes)."""
+        n = C.c_int64()
+        L.call("pa_csr_device_bytes", self.h, C.byref(n))
+        return n.value
+
     def value_dict(self):
         """Distinct values held in the optional value dictionary (PA_SPMV_VALUE_DICT=1 at creation), 0 when unused."""
         n = C.c_int()

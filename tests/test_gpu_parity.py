@@ -984,6 +984,48 @@ def test_column_encodings_agree_bit_for_bit(orc, monkeypatch):
     assert e["pattern"] == 0 and e["c16"] > 0 and e["c32"] == 0
 
 
+def test_compacted_column_streams_in_a_mixed_block(orc, monkeypatch):
+    """A block whose chunks are mostly described by row patterns keeps columns ONLY for the other chunks (compacted
+    16-bit and 32-bit streams addressed through the chunk's descriptor slot): banded rows (patterns) + rows with
+    random columns near the diagonal (16-bit windows) + scattered rows (32-bit) + one row longer than a chunk, in ONE
+    block.  Same bits as the oracle and as the full-length streams; ~8 bytes of HBM per stored entry instead of 14."""
+    rng = np.random.default_rng(11)
+    n = 60000
+    rows = {r: [r + d for d in (-300, -1, 0, 1, 300) if 1 <= r + d <= n] for r in range(1, n + 1)}
+    for r in range(20000, 20400):
+        rows[r] = sorted(set(int(c) for c in np.clip(r + rng.integers(-3000, 3000, 24), 1, n)))
+    for r in range(40000, 40300):
+        rows[r] = sorted(int(c) + 1 for c in rng.choice(n, size=int(rng.integers(20, 60)), replace=False))
+    rows[50000] = sorted(int(c) + 1 for c in rng.choice(n, size=4000, replace=False))
+    I = np.concatenate([np.full(len(c), r) for r, c in rows.items()])
+    J = np.concatenate([np.asarray(c) for c in rows.values()])
+    V = rng.standard_normal(len(I))
+    A = pa.compresscoo(I, J, V, n, n)
+    oA = orc.CSR(A.m, A.n, A.rowptr, A.colval, A.nzval)
+    xh = rng.standard_normal(n)
+    exp = orc.oracle_c().mul5_csr(np.full(n, 0.25), oA, xh, 0.75, -2.0)
+    x = pa.DeviceVector(n, 0).upload(xh)
+    out = {}
+    for pat in ("1", "0"):
+        monkeypatch.setenv("PA_SPMV_PATTERN", pat)
+        dA = pa.DeviceCSR(A)
+        y = pa.DeviceVector(n, 0).upload(np.full(n, 0.25))
+        pa.spmv_(y, dA, x, alpha=0.75, beta=-2.0)
+        assert np.array_equal(y.download(), exp), pat
+        out[pat] = (dA.encoding(), dA.device_bytes(), dA.info())
+    enc, nbytes, info = out["1"]
+    assert enc["pattern"] > 0 and enc["c16"] > 0 and enc["c32"] > 0 and info["n_long_rows"] == 1
+    assert enc["pattern"] + enc["c16"] + enc["c32"] == info["n_chunks"]
+    assert out["0"][0]["pattern"] == 0 and out["0"][0]["c16"] > 0
+    assert nbytes < 10 * A.nnz + 8 * n and out["0"][1] > 14 * A.nnz      # values (+ few columns) vs values + both streams
+    # the same through the colour-update and restriction kernels' dispatch is covered by the MG tests (HPCG blocks
+    # are compacted the same way); the 27-point operator: 8 bytes per entry + row pointers
+    monkeypatch.delenv("PA_SPMV_PATTERN")
+    A27, _ = pa.build_p_matrix(ranks(1), 64, 64, 64, 64, 64, 64, 1, 1, 1)
+    blk = A27.matrix_partition.items[0].own_own
+    assert blk.device_bytes() < 9.0 * blk.nnz
+
+
 def test_config2_laplacian_256_cubed_single_part(orc):
     """BASELINE config 2: 7-point Laplacian 256^3, one part, fp64 CSR SpMV only (no exchange), through the
     step-by-step set-up chain.  Size-independent properties: A*1 == alpha*(2D - #neighbours) bit-exactly
