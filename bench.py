@@ -226,6 +226,12 @@ def main():
             dist.barrier()
             ctx.sync()
 
+    # optional, measured, result-neutral: keep the value stream in the allocation on which own x own runs fastest with
+    # THESE x and y (pa_csr_tune_placement).  PA_PLACEMENT_TRIES=0 turns it off.
+    tries = int(os.environ.get("PA_PLACEMENT_TRIES", "6"))
+    if tries > 1:
+        PHASE[0] = "value-stream placement"
+        blk.own_own.tune_placement(xv, yv, tries=tries)
     PHASE[0] = f"timed mul! loop (transport {transport})"
     for _ in range(args.warmup):
         step()
@@ -351,7 +357,10 @@ def main():
                          "achieved": round(ach, 1),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_oo, "avg_launch_ms": round(kern_ms, 4),
-                         "this_box": box},
+                         "this_box": box,
+                         "value_stream_placement": dict(blk.own_own.placement(), what="allocations of the value stream timed with the "
+                                                        "bench's own x and y before the warm-up, fastest kept "
+                                                        "(pa_csr_tune_placement, PA_PLACEMENT_TRIES; DESIGN.md 3)")},
             "parity_gate": "A*1==b bit-exact; ghosts==owners bit-exact",
             "setup_s": round(t_setup, 1),
         }

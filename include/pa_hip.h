@@ -148,6 +148,16 @@ int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern_chunks, int64_t *n_c16_c
  * A block whose chunks are described by row patterns keeps no columns for them: a stencil operator costs ~8 bytes per
  * stored entry, a block on the 16-bit stream ~14 (8 + 4 + 2). */
 int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes);
+/* Value-stream placement, chosen by measurement (optional; never changes a result).  On some MI355X boxes the product
+ * kernel's time depends on WHICH allocations hold the value stream and the vectors (0.67 ... 0.82 ms for the 27-point
+ * 256^3 operator: same kernel, same data; stable for given allocations).  pa_csr_tune_placement
+ * copies A's values into up to `tries` allocations, times y = A*x on each with the caller's own x and y (the vectors of
+ * the hot loop; y is overwritten with A*x) and keeps the fastest copy; the rest is freed (transient HBM: (tries-1) x the
+ * value stream, never more than half of what is free).  Slabs under 8 M stored entries are left alone.
+ * pa_csr_placement reports what happened: candidates timed (0: not tuned), ms per product on the first and on the
+ * kept allocation. */
+int pa_csr_tune_placement(pa_csr *A, const pa_vec *x, int x_segment, pa_vec *y, int y_segment, int tries);
+int pa_csr_placement(const pa_csr *A, int *candidates, double *first_ms, double *kept_ms);
 /* Optional, lossless: with PA_SPMV_VALUE_DICT=1 in the environment at creation, a block whose stored values take at most
  * 64 distinct bit patterns (27-point HPCG: 2; Q1 stiffness on a uniform grid: about a dozen) also keeps one byte per
  * entry and the kernels stream that instead of the 8-byte values -- same values, same products, same order, same bits.

@@ -81,6 +81,8 @@ _SIGS = {
     "pa_csr_create": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_value_dict": [P, C.POINTER(cint)],
     "pa_csr_device_bytes": [P, C.POINTER(i64)],
+    "pa_csr_placement": [P, C.POINTER(cint), C.POINTER(f64), C.POINTER(f64)],
+    "pa_csr_tune_placement": [P, P, cint, P, cint, cint],
     "pa_csr_create_mixed": [P, i64, i64, i64, P, cint, P, cint, cint, P, PP],
     "pa_csr_create_from_csc": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_update_values": [P, P],

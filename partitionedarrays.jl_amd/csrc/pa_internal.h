@@ -74,6 +74,8 @@ struct pa_csr {
   int64_t n_c16_fallback = 0;      // chunks that keep 32-bit columns
   int64_t n_c16_chunks = 0, n_c32_chunks = 0;   // chunks by column encoding (with n_pattern_chunks: all of them)
   int64_t n_pdelta = 0;
+  int placement_tries = 0;                      // value-stream placement chosen by measurement (tune_value_placement)
+  float placement_first_ms = 0, placement_best_ms = 0;
   int64_t n_col32 = 0, n_col16 = 0;             // entries held in d_col / d_col16 (compacted when the block has row patterns)
   uint16_t *d_col16 = nullptr;     // (slot << 12) | (col & 4095), padded
   int32_t *d_win = nullptr;        // n_chunks * 16 window bases; [c*16] < 0 => 32-bit chunk

@@ -116,8 +116,13 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
   __shared__ __attribute__((aligned(16))) double prod[CAP];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
+#ifdef PA_PROBE_IDENTITY_CHUNK_MAP   // probe builds only (csrc/probe/placement_probe.hip)
+  const int chunk = b;
+  if (chunk >= n_chunks) return;
+#else
   const int chunk = (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
   if (chunk >= n_chunks || (b >> 3) >= chunks_per_xcd) return;
+#endif
   const int r0 = chunk_row[chunk];
   const int r1 = chunk_row[chunk + 1];
   const int p0 = crp[r0];

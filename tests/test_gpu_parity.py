@@ -1026,6 +1026,36 @@ def test_compacted_column_streams_in_a_mixed_block(orc, monkeypatch):
     assert blk.device_bytes() < 9.0 * blk.nnz
 
 
+def test_placement_tuning_never_changes_a_result(orc):
+    """pa_csr_tune_placement moves the value stream between allocations by measurement: the product before, during and
+    after is bit-identical, value updates keep working on the kept allocation, small blocks are left alone."""
+    A, b = pa.build_p_matrix(ranks(1), 72, 72, 72, 72, 72, 72, 1, 1, 1, keep_host=True)
+    blk = A.matrix_partition.items[0].own_own
+    h = pa.local_items(A.host_blocks)[0][0]
+    n = blk.m
+    xh = orc.hash_x(np.arange(1, n + 1))
+    x = pa.DeviceVector(n, 0).upload(xh)
+    y = pa.DeviceVector(n, 0)
+    pa.spmv_(y, blk, x)
+    before = y.download()
+    assert blk.placement()["candidates"] == 0
+    rep = blk.tune_placement(x, y, tries=3)
+    assert rep["candidates"] == 3 and 0 < rep["kept_ms"] <= rep["first_ms"]
+    assert np.array_equal(y.download(), before)            # y holds A*x after tuning, as documented
+    y.fill(0.0)
+    pa.spmv_(y, blk, x)
+    assert np.array_equal(y.download(), before)
+    blk.update_values(2.0 * h.nzval)                       # the kept allocation is the block's value stream from now on
+    pa.spmv_(y, blk, x)
+    assert np.array_equal(y.download(), 2.0 * before)
+    small, _ = pa.build_p_matrix(ranks(1), 16, 16, 16, 16, 16, 16, 1, 1, 1)
+    sb = small.matrix_partition.items[0].own_own
+    xs, ys = pa.DeviceVector(sb.n, 0), pa.DeviceVector(sb.m, 0)
+    assert sb.tune_placement(xs, ys, tries=4)["candidates"] == 0
+    with pytest.raises(pa.PAError):
+        blk.tune_placement(x, x)                           # aliasing is refused like in spmv!
+
+
 def test_config2_laplacian_256_cubed_single_part(orc):
     """BASELINE config 2: 7-point Laplacian 256^3, one part, fp64 CSR SpMV only (no exchange), through the
     step-by-step set-up chain.  Size-independent properties: A*1 == alpha*(2D - #neighbours) bit-exactly
