@@ -18,6 +18,17 @@ if os.path.exists(ks):
         w.writerows(rows)
     out["kernel_stats"] = [{"name": r["Name"][:80], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                             "pct": float(r["Percentage"])} for r in rows[:6]]
+# the timed region only: the headline-only pass ends with exactly `steps` (50) launches of the product kernel
+kth = os.path.join(src, "prof_kth", "kth_kernel_trace.csv")
+if os.path.exists(kth):
+    d = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+         for r in csv.DictReader(open(kth)) if "k_spmv_rowsplit" in r["Kernel_Name"]]
+    d.sort()
+    last = [u for _, u in d[-50:]]
+    out["timed_region"] = {"what": "the last 50 launches of k_spmv_rowsplit in the headline-only pass = bench.py's timed steps "
+                                   "(earlier launches: parity gate, placement candidates, warm-up)",
+                           "launches_total": len(d), "avg_us_last_50": sum(last) / max(1, len(last)),
+                           "min_us": min(last), "max_us": max(last), "avg_us_all": sum(u for _, u in d) / max(1, len(d))}
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d, f in (("prof_fetch", "f"), ("prof_write", "w"), ("prof_tcc", "t")):
     p = os.path.join(src, d, f"{f}_counter_collection.csv")
