@@ -228,7 +228,7 @@ def main():
 
     # optional, measured, result-neutral: keep the value stream in the allocation on which own x own runs fastest with
     # THESE x and y (pa_csr_tune_placement).  PA_PLACEMENT_TRIES=0 turns it off.
-    tries = int(os.environ.get("PA_PLACEMENT_TRIES", "8"))
+    tries = int(os.environ.get("PA_PLACEMENT_TRIES", "16"))
     if tries > 1:
         PHASE[0] = "value-stream placement"
         blk.own_own.tune_placement(xv, yv, tries=tries)

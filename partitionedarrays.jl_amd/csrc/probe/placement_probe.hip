@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "pa_spmv_kernel.h"
@@ -106,11 +107,48 @@ int main(int argc, char **argv) {
   };
   for (int w = 0; w < 3; ++w) run(d_val, 20);     // clocks up
   printf("27-pt %d^3: nnz %ld, %d chunks; value stream %.2f GB\n", n, nnz, nch, vbytes / 1e9);
-  if (argc > 3) {   // counter mode (run under rocprofv3 --pmc): N copies, 2 launches each, event time per copy
+  if (argc > 3 && std::string(argv[3]) == "pmc") {   // counter mode (run under rocprofv3 --pmc): N copies, 2 launches each, event time per copy
     std::vector<double *> V(1, d_val);
     for (int k = 1; k < copies; ++k) { double *v; CK(hipMalloc(&v, vbytes)); CK(hipMemcpy(v, d_val, vbytes, hipMemcpyDeviceToDevice)); V.push_back(v); }
     for (int round = 0; round < 2; ++round)
       for (int k = 0; k < copies; ++k) printf("round %d copy %d: %.4f ms\n", round, k, run(V[k], 2));
+    return 0;
+  }
+  if (argc > 3 && copies == 1) {   // ballast mode: hold b GiB, then time exact-size copies allocated after it
+    const size_t G = (size_t)1 << 30;
+    const size_t b = (size_t)atol(argv[3]);
+    size_t fr = 0, tot = 0; CK(hipMemGetInfo(&fr, &tot));
+    char *ballast = nullptr; if (b) CK(hipMalloc(&ballast, b * G));
+    printf("free %.1f of %.1f GiB before; ballast %zu GiB:", fr / (double)G, tot / (double)G, b);
+    std::vector<double *> V;
+    for (int k = 0; k < 4; ++k) {
+      double *v; CK(hipMalloc(&v, vbytes)); CK(hipMemcpy(v, d_val, vbytes, hipMemcpyDeviceToDevice)); V.push_back(v);
+      printf(" %.4f", run(v, 20));
+    }
+    if (ballast) CK(hipFree(ballast));
+    printf(" | after freeing the ballast:");
+    for (int k = 0; k < 4; ++k) printf(" %.4f", run(V[k], 20));
+    double *xn, *yn; CK(hipMalloc(&xn, sizeof(double) * (nrows + 2))); CK(hipMalloc(&yn, sizeof(double) * nrows));
+    CK(hipMemcpy(xn, d_x, sizeof(double) * (nrows + 2), hipMemcpyDeviceToDevice));
+    d_x = xn; d_y = yn;
+    printf(" | with x,y allocated now:");
+    for (int k = 0; k < 4; ++k) printf(" %.4f", run(V[k], 20));
+    printf("\n");
+    return 0;
+  }
+  if (argc > 2 && copies == 0) {   // values carved out of arenas of different sizes vs separate allocations, interleaved
+    const size_t G = (size_t)1 << 30;
+    const size_t extra[] = {0, 0, 4 * G, 0, 12 * G, 0, 28 * G, 0, 60 * G, 0, 0, 4 * G, 12 * G};
+    for (size_t ex : extra) {
+      char *a; CK(hipMalloc(&a, vbytes + ex));
+      float t[3]; size_t offs[3] = {0, ex / 2 & ~((size_t)4095), ex};
+      for (int k = 0; k < 3; ++k) {
+        CK(hipMemcpy(a + offs[k], d_val, vbytes, hipMemcpyDeviceToDevice));
+        t[k] = run((double *)(a + offs[k]), 20);
+        if (ex == 0) { t[1] = t[2] = t[0]; break; }
+      }
+      printf("allocation of values + %2zu GiB at %p: values at the start %.4f, in the middle %.4f, at the end %.4f ms\n", ex / G, (void *)a, t[0], t[1], t[2]);
+    }
     return 0;
   }
   if (argc > 2 && copies < 0) {   // what changes a kept copy's speed: frees?  new vectors?
