@@ -30,6 +30,7 @@
 #include <chrono>
 #include <thread>
 #include <cstring>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -812,13 +813,13 @@ extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, in
   for (int64_t r = 0; r <= n_rows; ++r) rp[r] = read_index(rowptr, rowptr_bytes, r) - index_base;
   PA_REQUIRE(rp[0] == 0 && rp[n_rows] == nnz, "rowptr does not span [base, base+nnz]");
   for (int64_t r = 0; r < n_rows; ++r) PA_REQUIRE(rp[r + 1] >= rp[r], "rowptr not monotone at row %lld", (long long)r);
-  std::vector<int32_t> colbuf;
+  std::unique_ptr<int32_t[]> colbuf;                   // (not a vector: no single-threaded zero fill of a multi-GB array)
   const int32_t *col0 = nullptr;
   if (colval_bytes == 4 && index_base == 0) {
     col0 = (const int32_t *)colval;                      // already what the device wants: no copy of a multi-GB array
     for (int64_t p = 0; p < nnz; ++p) PA_REQUIRE(col0[p] >= 0 && col0[p] < n_cols, "column index out of range at entry %lld", (long long)p);
   } else {
-    colbuf.resize(nnz);
+    colbuf.reset(new int32_t[std::max<int64_t>(1, nnz)]);
     const int T = host_threads(nnz);
     std::vector<int64_t> bad(T, -1);
     auto conv = [&](int t) {
@@ -835,7 +836,7 @@ extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, in
       for (auto &x : th) x.join();
     }
     for (int t = 0; t < T; ++t) PA_REQUIRE(bad[t] < 0, "column index out of range at entry %lld", (long long)bad[t]);
-    col0 = colbuf.data();
+    col0 = colbuf.get();
   }
   if (getenv("PA_SETUP_TIMING"))
     fprintf(stderr, "[pa setup] %-10s %8.3f s  (nnz %lld)\n", "validate", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(), (long long)nnz);
