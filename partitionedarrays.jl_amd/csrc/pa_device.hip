@@ -1132,20 +1132,22 @@ static int tune_value_placement(pa_csr *S, const double *xs, double *ys, int tri
     return PA_OK;
   };
   for (int w = 0; w < 6; ++w) spmv_launch_slab(S, xs, ys, 1.0, 0.0);           // clocks up before anything is compared
-  float first = 0, now = 0, fastest_seen = 1e30f;
+  float first = 0, now = 0;
   PA_TRY(time_current(&first));
   now = first;
-  fastest_seen = first;
   int timed = 1;
+  const auto t_begin = std::chrono::steady_clock::now();
   // Rounds of up to 4 candidates.  Freeing the losers can itself change the time of the copy that is kept (measured:
-  // csrc/probe/placement_probe.hip, ballast mode), so the kept copy is timed again after the frees and another round
-  // starts while it is more than 3 % away from the fastest time any copy has shown.
+  // csrc/probe/placement_probe.hip, ballast mode), so the kept copy is timed again after the frees and competes again
+  // in the next round.
   while (timed < tries) {
     size_t free_b = 0, total_b = 0;
     PA_HIP(hipMemGetInfo(&free_b, &total_b));
     int k = std::min(4, tries - timed);
     while (k > 0 && (size_t)k * vbytes > free_b / 2) --k;                       // never more than half of what is free
     if (k < 1) break;
+    // (Pushing the candidates to other depths of the device memory with a transient ballast allocation of 40-120 GiB
+    // finds a fast placement more often, but allocating and freeing the ballast costs 5-11 s: not worth it.)
     std::vector<double *> cand(1, S->d_val);
     for (int t = 0; t < k; ++t) {
       double *v = nullptr;
@@ -1168,18 +1170,17 @@ static int tune_value_placement(pa_csr *S, const double *xs, double *ys, int tri
     for (size_t j = 0; j < cand.size(); ++j)
       if (j != win) (void)hipFree(cand[j]);
     PA_TRY(time_current(&now));
-    for (float t : best) fastest_seen = std::min(fastest_seen, t);
     if (verbose) {
       fprintf(stderr, "[pa setup] placement round:");
       for (float t : best) fprintf(stderr, " %.4f", t);
       fprintf(stderr, " ms -> kept #%zu, %.4f ms once the others are freed\n", win, now);
     }
-    if (now <= 1.03f * fastest_seen) break;
   }
   PA_HIP(hipGetLastError());
   S->placement_tries = timed;
   S->placement_first_ms = first;
   S->placement_best_ms = now;
+  if (verbose) fprintf(stderr, "[pa setup] placement took %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return PA_OK;
 }
