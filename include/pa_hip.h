@@ -148,14 +148,17 @@ int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern_chunks, int64_t *n_c16_c
  * A block whose chunks are described by row patterns keeps no columns for them: a stencil operator costs ~8 bytes per
  * stored entry, a block on the 16-bit stream ~14 (8 + 4 + 2). */
 int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes);
-/* Value-stream placement, chosen by measurement (optional; never changes a result).  On some MI355X boxes the product
- * kernel's time depends on WHICH allocations hold the value stream and the vectors (0.67 ... 0.82 ms for the 27-point
- * 256^3 operator: same kernel, same data; stable for given allocations).  pa_csr_tune_placement
- * copies A's values into up to `tries` allocations, times y = A*x on each with the caller's own x and y (the vectors of
- * the hot loop; y is overwritten with A*x) and keeps the fastest copy; the rest is freed (transient HBM: (tries-1) x the
- * value stream, never more than half of what is free).  Slabs under 8 M stored entries are left alone.
- * pa_csr_placement reports what happened: candidates timed (0: not tuned), ms per product on the first and on the
- * kept allocation. */
+/* Placement of the value stream and of the result vector, chosen by measurement (optional; never changes a result).
+ * On most MI355X boxes the product kernel's time depends on WHICH allocations hold the value stream and y (0.67 ... 0.82
+ * ms for the 27-point 256^3 operator: same kernel, same data; a pure (values, y) interaction, x plays no part; stable
+ * for given allocations).  pa_csr_tune_placement times y = A*x with the caller's x on up to `tries`
+ * copies of A's values, each against up to 6 allocations for y, in rounds of 4 copies, and keeps the fastest pair; the
+ * rest is freed (transient HBM: 4 x the value stream + 5 x y, never more than half of what is free).
+ *   - y is overwritten with A*x.  If the library owns y's storage (pa_vec_create) and A is one slab, the storage MAY MOVE
+ *     to another allocation (same content, same handle): device pointers obtained through pa_vec_data before the call,
+ *     and hipGraphs captured with y, are invalid afterwards.  PA_PLACEMENT_MOVE_Y=0 in the environment keeps y in place.
+ *   - x and y must be different vectors.  Slabs under 8 M stored entries are left alone.
+ * pa_csr_placement reports what happened: value copies timed (0: not tuned), ms per product before and after. */
 int pa_csr_tune_placement(pa_csr *A, const pa_vec *x, int x_segment, pa_vec *y, int y_segment, int tries);
 int pa_csr_placement(const pa_csr *A, int *candidates, double *first_ms, double *kept_ms);
 /* Optional, lossless: with PA_SPMV_VALUE_DICT=1 in the environment at creation, a block whose stored values take at most

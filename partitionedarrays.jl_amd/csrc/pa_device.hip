@@ -1106,76 +1106,96 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
   }
 }
 
-// Placement of the value stream, chosen by measurement.  On some MI355X boxes the SAME kernel on the SAME values
-// runs at 0.67 ... 0.82 ms (27-point 256^3) depending on which allocations hold the value stream and the vectors --
-// stable for a given set of allocations, unrelated to virtual addresses or their alignment, no difference in TLB misses,
-// L2 traffic or request counts (csrc/probe/placement_probe.hip); other boxes give 0.775 ms whatever
-// the placement.  Physical placement is not ours to choose, so pa_csr_tune_placement copies the values of a large slab
-// into a few more allocations, times the product kernel WITH THE CALLER'S x AND y on each (two interleaved rounds, best
-// of each) and keeps the fastest; the others are freed.
-static int tune_value_placement(pa_csr *S, const double *xs, double *ys, int tries) {
+// Placement of the value stream and of the result vector, chosen by measurement.  On most MI355X boxes the SAME kernel
+// on the SAME data runs at 0.67 ... 0.82 ms (27-point 256^3) depending on WHICH ALLOCATIONS hold the value stream and
+// y: the copies x (x,y)-pairs matrix of csrc/probe/placement_probe.hip shows a pure (values, y) interaction -- x plays
+// no part, y allocations fall into two classes, and a value allocation is fast with one class only (or with none).  It
+// is stable for given allocations, unrelated to virtual addresses or their alignment, invisible in TLB, L2 and request
+// counters, and the fast pairs run exactly as fast as the kernel without its y store: the read stream and the
+// 64-byte write stream interfere in the memory system, or do not, depending on physical placement.
+// Physical placement is not ours to choose, so it is chosen by measurement: rounds of up to 4 more copies of the
+// values and up to 5 more allocations for y, every pair timed with the caller's x; the fastest pair is kept, the rest
+// freed, and -- since freeing large allocations can itself shift the times -- the kept pair competes again in the next
+// round.  The result vector's storage moves only when the library owns it (pa_vec_create) and the block is one slab.
+static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, int tries) {
   pa_ctx *c = S->ctx;
   if (tries < 2 || S->nnz < ((int64_t)8 << 20) || S->n_chunks < 1 || c->capturing || S->use_vdict) return PA_OK;
   const size_t pad = 8, vbytes = sizeof(double) * (S->nnz + pad);
+  const size_t ybytes = sizeof(double) * (size_t)(y->n_own + y->n_ghost + 2);
+  const char *em = getenv("PA_PLACEMENT_MOVE_Y");
+  const bool move_y = y->owned && S->next == nullptr && S->row0 == 0 && !(em && atoi(em) == 0);
   hipEvent_t e0, e1;
   PA_HIP(hipEventCreate(&e0));
   PA_HIP(hipEventCreate(&e1));
   const bool verbose = getenv("PA_SETUP_TIMING") != nullptr;
-  auto time_current = [&](float *ms_out) -> int {            // average of 4 launches after one untimed launch
-    spmv_launch_slab(S, xs, ys, 1.0, 0.0);
+  const auto t_begin = std::chrono::steady_clock::now();
+  double *ycur = y->d;                                        // where the result goes at the moment (y->d itself until the end)
+  auto time_pair = [&](double *val, double *yb, float *ms_out) -> int {   // average of 3 launches after one untimed launch
+    S->d_val = val;
+    spmv_launch_slab(S, xs, yb + yoff, 1.0, 0.0);
     PA_HIP(hipEventRecord(e0, c->s[0]));
-    for (int r = 0; r < 4; ++r) spmv_launch_slab(S, xs, ys, 1.0, 0.0);
+    for (int r = 0; r < 3; ++r) spmv_launch_slab(S, xs, yb + yoff, 1.0, 0.0);
     PA_HIP(hipEventRecord(e1, c->s[0]));
     PA_HIP(hipEventSynchronize(e1));
     PA_HIP(hipEventElapsedTime(ms_out, e0, e1));
-    *ms_out /= 4;
+    *ms_out /= 3;
     return PA_OK;
   };
-  for (int w = 0; w < 6; ++w) spmv_launch_slab(S, xs, ys, 1.0, 0.0);           // clocks up before anything is compared
+  for (int w = 0; w < 6; ++w) spmv_launch_slab(S, xs, ycur + yoff, 1.0, 0.0);   // clocks up before anything is compared
   float first = 0, now = 0;
-  PA_TRY(time_current(&first));
+  PA_TRY(time_pair(S->d_val, ycur, &first));
   now = first;
   int timed = 1;
-  const auto t_begin = std::chrono::steady_clock::now();
-  // Rounds of up to 4 candidates.  Freeing the losers can itself change the time of the copy that is kept (measured:
-  // csrc/probe/placement_probe.hip, ballast mode), so the kept copy is timed again after the frees and competes again
-  // in the next round.
   while (timed < tries) {
     size_t free_b = 0, total_b = 0;
     PA_HIP(hipMemGetInfo(&free_b, &total_b));
     int k = std::min(4, tries - timed);
-    while (k > 0 && (size_t)k * vbytes > free_b / 2) --k;                       // never more than half of what is free
+    while (k > 0 && (size_t)k * vbytes + 5 * ybytes > free_b / 2) --k;          // never more than half of what is free
     if (k < 1) break;
-    // (Pushing the candidates to other depths of the device memory with a transient ballast allocation of 40-120 GiB
-    // finds a fast placement more often, but allocating and freeing the ballast costs 5-11 s: not worth it.)
-    std::vector<double *> cand(1, S->d_val);
+    std::vector<double *> vals(1, S->d_val), ys(1, ycur);
     for (int t = 0; t < k; ++t) {
       double *v = nullptr;
       if (hipMalloc(&v, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
-      PA_HIP(hipMemcpyAsync(v, S->d_val, vbytes, hipMemcpyDeviceToDevice, c->s[0]));
-      cand.push_back(v);
+      PA_HIP(hipMemcpyAsync(v, vals[0], vbytes, hipMemcpyDeviceToDevice, c->s[0]));
+      vals.push_back(v);
     }
-    if (cand.size() < 2) break;
-    std::vector<float> best(cand.size(), 1e30f);
-    for (int round = 0; round < 2; ++round)
-      for (size_t j = 0; j < cand.size(); ++j) {
-        S->d_val = cand[j];
+    for (int t = 0; move_y && t < 5; ++t) {
+      double *v = nullptr;
+      if (hipMalloc(&v, ybytes) != hipSuccess) { (void)hipGetLastError(); break; }
+      ys.push_back(v);
+    }
+    if (vals.size() * ys.size() < 2) break;
+    size_t bi = 0, bj = 0;
+    float best = 1e30f;
+    std::vector<float> row_best(vals.size(), 1e30f);
+    for (size_t i = 0; i < vals.size(); ++i)
+      for (size_t j = 0; j < ys.size(); ++j) {
         float ms = 0;
-        PA_TRY(time_current(&ms));
-        best[j] = std::min(best[j], ms);
+        PA_TRY(time_pair(vals[i], ys[j], &ms));
+        row_best[i] = std::min(row_best[i], ms);
+        if (ms < best) { best = ms; bi = i; bj = j; }
       }
-    timed += (int)cand.size() - 1;
-    const size_t win = (size_t)(std::min_element(best.begin(), best.end()) - best.begin());
-    S->d_val = cand[win];
-    for (size_t j = 0; j < cand.size(); ++j)
-      if (j != win) (void)hipFree(cand[j]);
-    PA_TRY(time_current(&now));
+    timed += (int)vals.size() - 1;
+    for (size_t i = 0; i < vals.size(); ++i)
+      if (i != bi) (void)hipFree(vals[i]);
+    for (size_t j = 0; j < ys.size(); ++j)
+      if (j != bj && ys[j] != y->d) (void)hipFree(ys[j]);      // (the vector's own storage goes only once its content is moved)
+    ycur = ys[bj];
+    PA_TRY(time_pair(vals[bi], ycur, &now));
     if (verbose) {
-      fprintf(stderr, "[pa setup] placement round:");
-      for (float t : best) fprintf(stderr, " %.4f", t);
-      fprintf(stderr, " ms -> kept #%zu, %.4f ms once the others are freed\n", win, now);
+      fprintf(stderr, "[pa setup] placement round (%zu value copies x %zu result allocations), best per value copy:", vals.size(), ys.size());
+      for (float t : row_best) fprintf(stderr, " %.4f", t);
+      fprintf(stderr, " ms -> kept (#%zu, y #%zu), %.4f ms once the others are freed\n", bi, bj, now);
     }
   }
+  if (ycur != y->d) {                                         // the vector moves: same content, new allocation
+    PA_HIP(hipMemsetAsync(ycur + (y->n_own + y->n_ghost), 0, 2 * sizeof(double), c->s[0]));
+    PA_HIP(hipMemcpyAsync(ycur, y->d, sizeof(double) * (size_t)(y->n_own + y->n_ghost), hipMemcpyDeviceToDevice, c->s[0]));
+    PA_HIP(hipStreamSynchronize(c->s[0]));
+    (void)hipFree(y->d);
+    y->d = ycur;
+  }
+  spmv_launch_slab(S, xs, y->d + yoff, 1.0, 0.0);             // y = A*x, as documented
   PA_HIP(hipGetLastError());
   S->placement_tries = timed;
   S->placement_first_ms = first;
@@ -1192,10 +1212,10 @@ extern "C" int pa_csr_tune_placement(pa_csr *A, const pa_vec *x, int xseg, pa_ve
   PA_TRY(seg_range(y, yseg, &yoff, &ylen));
   PA_REQUIRE(ylen == A->t_rows, "length(b)=%lld != size(A,1)=%lld", (long long)ylen, (long long)A->t_rows);
   PA_REQUIRE(xlen == A->n_cols, "length(x)=%lld != size(A,2)=%lld", (long long)xlen, (long long)A->n_cols);
-  PA_REQUIRE(x->d != y->d || xseg != yseg, "x and y alias");
+  PA_REQUIRE(x->d != y->d, "x and y are the same vector");
   PA_HIP(hipSetDevice(A->ctx->device));
   PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
-  for (pa_csr *S = A; S; S = S->next) PA_TRY(tune_value_placement(S, x->d + xoff, y->d + yoff + S->row0, tries));
+  for (pa_csr *S = A; S; S = S->next) PA_TRY(tune_placement(S, x->d + xoff, y, yoff + S->row0, tries));
   return PA_OK;
 }
 

@@ -119,8 +119,9 @@ class DeviceCSR:
         return n.value
 
     def tune_placement(self, x, y, x_segment=L.SEG_OWN, y_segment=L.SEG_OWN, tries=6):
-        """Keep the value stream in the allocation on which y = A*x runs fastest WITH these x and y (the vectors of
-        the hot loop; y is overwritten).  Optional, measured, never changes a result (pa_csr_tune_placement)."""
+        """Keep the value stream -- and y's storage, when the library owns it -- in the allocations on which y = A*x runs
+        fastest with this x (the vectors of the hot loop; y is overwritten with A*x; its device pointer may change).
+        Optional, measured, never changes a result (pa_csr_tune_placement)."""
         L.call("pa_csr_tune_placement", self.h, x.h, x_segment, y.h, y_segment, int(tries))
         return self.placement()
 
