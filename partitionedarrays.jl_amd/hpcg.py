@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib as L
 from .primitives import pmap
-from .p_sparse_matrix import mul_, mul_c_, mul_no_overlap_
+from .p_sparse_matrix import mul_, mul_c_, mul_no_overlap_, tune_placement_
 from .p_vector import (axpby_, copy_, dot, norm, similar, pzeros, consistent_, context, slots_supported, dot_slot,
                        axpby_slot_, cg_update_, write_slot, read_slots)
 
@@ -264,7 +264,7 @@ def ldiv_(x, P: MgPreconditioner, b):
     return pc_solve_(x, P, b, P.l, zero_guess=True)
 
 
-def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_every=1, timer=None, graph=False):
+def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_every=1, timer=None, graph=False, work=None):
     """opt_cg! (HPCG/src/opt_cg.jl): the hook for an optimised solve.  Same PCG as ref_cg_ -- the same kernels'
     arithmetic in the same order, so the iterates are bit-identical -- scheduled for the GPU: rho, u'c and |r|^2 stay
     in device slots (no blocking reduction per dot, ref_cg.jl:52,60,67), the three statements :64-67 are one pass
@@ -276,13 +276,15 @@ def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_ev
     period of the slot rotation -- are recorded into a hipGraph once and replayed; for small parts, where an iteration is
     ten kernels of a few microseconds, this removes the launch overhead.  Same kernels, same bits."""
     if not slots_supported(x):
-        return ref_cg_(x, A, b, maxiter=maxiter, tolerance=tolerance, overlap=True, history=history, Pl=Pl, timer=timer)
+        return ref_cg_(x, A, b, maxiter=maxiter, tolerance=tolerance, overlap=True, history=history, Pl=Pl, timer=timer, work=work)
     tm = timer or _NO_TIMER
     ONE = L.SLOT_ONE
     s_rho, s_prev, s_rr, s_uc = 1, 2, 3, 4
-    u = similar(x)
-    r = similar(b)
-    c = similar(b)
+    if work is None:
+        u, r, c = similar(x), similar(b), similar(b)
+    else:                                                    # (cg_work: the same vectors for every solve)
+        u, r, c = work
+        pmap(lambda v: v.fill(0.0), u.vector_partition)
     copy_(r, b)
     mul_(c, A, x)
     axpby_(r, -1.0, c, 1.0)
@@ -391,15 +393,30 @@ class _NoTimer:
 _NO_TIMER = _NoTimer()
 
 
-def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None, Pl=None, timer=None):
+def cg_work(x, b, A=None, tune_placement=0):
+    """The work vectors (u, r, c) of ref_cg_ / opt_cg_ for solves with x and b, to pass as `work=`.  With A and
+    tune_placement=k > 1 every part's own_own value stream and the storage of c are placed, by measurement, where the
+    loop's product c = A*u runs fastest (tune_placement_; result-neutral)."""
+    u, r, c = similar(x), similar(b), similar(b)
+    if A is not None and tune_placement > 1 and A.assembled:
+        tune_placement_(A, c, u, tune_placement)
+    return u, r, c
+
+
+def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None, Pl=None, timer=None, work=None):
     """ref_cg!(x,A,b,timing_data;tolerance,maxiter,Pl) -> x, residual0, residual, iters (Pl=None: Identity()).
-    `overlap=True` uses mul! (latency hiding, src/p_sparse_matrix.jl:2090); False uses mul_no_lat! as HPCG does."""
+    `overlap=True` uses mul! (latency hiding, src/p_sparse_matrix.jl:2090); False uses mul_no_lat! as HPCG does.
+    work=(u, r, c): reuse these work vectors (from cg_work) instead of allocating them; u is zeroed as `similar` would."""
     mv = mul_ if overlap else mul_no_lat_
     # cg_iterator! (ref_cg.jl:76-96).  Vectors that are multiplied by A live on the column partition (= row
     # partition + ghosts, HPCG/src/sparse_matrix.jl:119).
-    u = similar(x)                       # u .= 0
-    r = similar(b)                       # r and c live where b does: the column partition in HPCG (sparse_matrix.jl:119),
-    c = similar(b)                       # the (ghost-free or sub-assembled) row partition in test/fem_example.jl
+    if work is None:
+        u = similar(x)                   # u .= 0
+        r = similar(b)                   # r and c live where b does: the column partition in HPCG (sparse_matrix.jl:119),
+        c = similar(b)                   # the (ghost-free or sub-assembled) row partition in test/fem_example.jl
+    else:
+        u, r, c = work
+        pmap(lambda v: v.fill(0.0), u.vector_partition)
     copy_(r, b)                          # copyto!(r,b)
     mv(c, A, x)                          # c = A*x
     axpby_(r, -1.0, c, 1.0)              # r .-= c

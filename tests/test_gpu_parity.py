@@ -767,6 +767,22 @@ def test_opt_cg_device_scalars_bit_identical_to_ref_cg(P, np3, with_mg):
     assert (ita_, ra_) == (itb_, rb_) and ita_ < 200
 
 
+def test_cg_with_reused_and_placement_tuned_work_vectors_is_bit_identical():
+    """cg_work: the work vectors allocated once (and, with tune_placement, the value stream and c moved to the allocations
+    on which c = A*u runs fastest) -- ref_cg_ and opt_cg_ give the bits of the allocating loops, solve after solve."""
+    A, b = pa.build_p_matrix(ranks(2), 96, 96, 64, 192, 96, 64, 2, 1, 1)         # 2 x 590k rows, 15.7 M entries per part
+    x0, r00, r0, it0 = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=9)
+    want = [v.copy() for v in x0.own_values().items]
+    work = pa.cg_work(pa.pzeros(A.col_partition), b, A, tune_placement=3)
+    assert all(blk.own_own.placement()["candidates"] == 3 for blk in A.matrix_partition.items)
+    for fn in (pa.opt_cg_, pa.ref_cg_, pa.opt_cg_):
+        x, r0_, r_, it = fn(pa.pzeros(A.col_partition), A, b, maxiter=9, work=work)
+        assert it == it0 == 9
+        for g, e in zip(x.own_values().items, want):
+            assert np.array_equal(g, e)
+    assert (r0_, r_) == (r00, r0)
+
+
 @pytest.mark.parametrize("P,np3", [(1, (1, 1, 1)), (4, (2, 2, 1))])      # 4 parts: graph mode declines, eager loop runs
 def test_opt_cg_replayed_from_a_hipgraph_is_bit_identical(P, np3):
     """graph=True records three CG iterations (kernels of the exchange, both SpMV blocks, the slot BLAS-1) into a
