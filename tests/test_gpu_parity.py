@@ -1042,7 +1042,7 @@ def test_compacted_column_streams_in_a_mixed_block(orc, monkeypatch):
     assert blk.device_bytes() < 9.0 * blk.nnz
 
 
-def test_placement_tuning_never_changes_a_result(orc):
+def test_placement_tuning_never_changes_a_result(orc, monkeypatch):
     """pa_csr_tune_placement moves the value stream between allocations by measurement: the product before, during and
     after is bit-identical, value updates keep working on the kept allocation, small blocks are left alone."""
     A, b = pa.build_p_matrix(ranks(1), 72, 72, 72, 72, 72, 72, 1, 1, 1, keep_host=True)
@@ -1070,6 +1070,17 @@ def test_placement_tuning_never_changes_a_result(orc):
     assert sb.tune_placement(xs, ys, tries=4)["candidates"] == 0
     with pytest.raises(pa.PAError):
         blk.tune_placement(x, x)                           # aliasing is refused like in spmv!
+    # a block kept as row slabs: every slab's values are placed on their own, y stays where it is
+    monkeypatch.setenv("PA_CSR_MAX_SLAB_NNZ", "9000000")
+    hb = pa.local_items(pa.build_p_matrix(ranks(1), 96, 96, 96, 96, 96, 96, 1, 1, 1, keep_host=True)[0].host_blocks)[0][0]
+    dS = pa.DeviceCSR(hb)
+    monkeypatch.delenv("PA_CSR_MAX_SLAB_NNZ")
+    xs = pa.DeviceVector(hb.n, 0).upload(orc.hash_x(np.arange(1, hb.n + 1)))
+    ys = pa.DeviceVector(hb.m, 0)
+    pa.spmv_(ys, dS, xs)
+    want, where = ys.download(), ys.data_ptr()
+    assert dS.tune_placement(xs, ys, tries=3)["candidates"] == 3 and ys.data_ptr() == where
+    assert np.array_equal(ys.download(), want)
 
 
 def test_config2_laplacian_256_cubed_single_part(orc):
