@@ -114,6 +114,20 @@ int main(int argc, char **argv) {
       for (int k = 0; k < copies; ++k) printf("round %d copy %d: %.4f ms\n", round, k, run(V[k], 2));
     return 0;
   }
+  if (argc > 3 && copies == 2) {   // y map: result vectors allocated one after the other through the device memory
+    const int NY = atoi(argv[3]);
+    double *v1; CK(hipMalloc(&v1, vbytes)); CK(hipMemcpy(v1, d_val, vbytes, hipMemcpyDeviceToDevice));
+    printf("y index: GiB allocated so far | ms with the original values | ms with a second copy\n");
+    size_t total = 0;
+    for (int j = 0; j < NY; ++j) {
+      double *yn; if (hipMalloc(&yn, sizeof(double) * nrows) != hipSuccess) break;
+      total += sizeof(double) * nrows;
+      d_y = yn;
+      const float a = run(d_val, 2), b = run(v1, 2);
+      printf("%4d %7.2f %.4f %.4f %p\n", j, total / 1073741824.0, a, b, (void *)yn);
+    }
+    return 0;
+  }
   if (argc > 3 && copies == 1) {   // ballast mode: hold b GiB, then time exact-size copies allocated after it
     const size_t G = (size_t)1 << 30;
     const size_t b = (size_t)atol(argv[3]);
