@@ -1153,16 +1153,18 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
     while (k > 0 && (size_t)k * vbytes + 5 * ybytes > free_b / 2) --k;          // never more than half of what is free
     if (k < 1) break;
     std::vector<double *> vals(1, S->d_val), ys(1, ycur);
-    for (int t = 0; t < k; ++t) {
+    // result allocations and value copies alternate: the classes are ranges of device memory several GiB long
+    // (DESIGN.md section 3), so the y candidates should be spread, not adjacent
+    for (int t = 0; t <= k; ++t) {
       double *v = nullptr;
+      if (move_y && (int)ys.size() < 6) {
+        if (hipMalloc(&v, ybytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        ys.push_back(v);
+      }
+      if (t == k) break;
       if (hipMalloc(&v, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
       PA_HIP(hipMemcpyAsync(v, vals[0], vbytes, hipMemcpyDeviceToDevice, c->s[0]));
       vals.push_back(v);
-    }
-    for (int t = 0; move_y && t < 5; ++t) {
-      double *v = nullptr;
-      if (hipMalloc(&v, ybytes) != hipSuccess) { (void)hipGetLastError(); break; }
-      ys.push_back(v);
     }
     if (vals.size() * ys.size() < 2) break;
     size_t bi = 0, bj = 0;
