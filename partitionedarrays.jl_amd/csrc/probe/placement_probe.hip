@@ -114,6 +114,22 @@ int main(int argc, char **argv) {
       for (int k = 0; k < copies; ++k) printf("round %d copy %d: %.4f ms\n", round, k, run(V[k], 2));
     return 0;
   }
+  if (argc > 2 && copies == 3) {   // y carved out of the allocation that holds the values: before them, after them, or apart
+    const size_t ysz = ((sizeof(double) * nrows + ((size_t)2 << 20) - 1) >> 21) << 21;
+    double *y_orig = d_y;
+    printf("one allocation [y | values | y]: ms with y before the values, after them, and in the original separate allocation\n");
+    for (int k = 0; k < 10; ++k) {
+      char *a; CK(hipMalloc(&a, vbytes + 2 * ysz + ((size_t)4 << 20)));
+      double *yb = (double *)a, *v = (double *)(a + ysz), *ya = (double *)(a + ysz + ((vbytes + ((size_t)2 << 20) - 1) >> 21 << 21));
+      CK(hipMemcpy(v, d_val, vbytes, hipMemcpyDeviceToDevice));
+      d_y = yb; const float t0 = run(v, 10);
+      d_y = ya; const float t1 = run(v, 10);
+      d_y = y_orig; const float t2 = run(v, 10);
+      double *ys; CK(hipMalloc(&ys, sizeof(double) * nrows)); d_y = ys; const float t3 = run(v, 10);
+      printf("allocation %d at %p: %.4f %.4f %.4f | y allocated right after it: %.4f\n", k, (void *)a, t0, t1, t2, t3);
+    }
+    return 0;
+  }
   if (argc > 3 && copies == 2) {   // y map: result vectors allocated one after the other through the device memory
     const int NY = atoi(argv[3]);
     double *v1; CK(hipMalloc(&v1, vbytes)); CK(hipMemcpy(v1, d_val, vbytes, hipMemcpyDeviceToDevice));
