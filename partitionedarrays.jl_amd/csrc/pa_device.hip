@@ -1216,6 +1216,7 @@ extern "C" int pa_csr_tune_placement(pa_csr *A, const pa_vec *x, int xseg, pa_ve
   PA_REQUIRE(xlen == A->n_cols, "length(x)=%lld != size(A,2)=%lld", (long long)xlen, (long long)A->n_cols);
   PA_REQUIRE(x->d != y->d, "x and y are the same vector");
   PA_HIP(hipSetDevice(A->ctx->device));
+  PA_HIP(hipStreamSynchronize(A->ctx->s[1]));          // nothing in flight may still use y's storage: it can move
   PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
   for (pa_csr *S = A; S; S = S->next) PA_TRY(tune_placement(S, x->d + xoff, y, yoff + S->row0, tries));
   return PA_OK;
