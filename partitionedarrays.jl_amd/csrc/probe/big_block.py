@@ -11,7 +11,7 @@ A, b = pa.build_p_matrix(pa.DebugArray([1]), n, n, n, n, n, n, 1, 1, 1)
 pa.context().sync()
 print('set-up', round(time.perf_counter() - t, 1), 's', flush=True)
 blk = A.matrix_partition.items[0].own_own
-print('info', blk.info(), 'encoding', blk.encoding(), '2^31 =', 2 ** 31)
+print('info', blk.info(), 'encoding', blk.encoding(), '2^31 =', 2 ** 31, 'HBM bytes', blk.device_bytes(), '= %.2f per stored entry' % (blk.device_bytes() / blk.nnz))
 x = pa.pones(A.col_partition); y = pa.pzeros(A.row_partition)
 pa.mul_(y, A, x)
 print('A*1 == b:', all(np.array_equal(g, e) for g, e in zip(y.own_values().items, b.own_values().items)))
