@@ -112,6 +112,7 @@ struct pa_plan {
   int32_t *d_tgt = nullptr, *d_tptr = nullptr, *d_tp = nullptr;
   hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
   int phase = 0;     // 0 idle, 1 packed, 2 arrived
+  bool own_comm_stream = false;   // this exchange's transport ran on this part's comm stream alone (RCCL: one part per process)
   int mode = 0;
 };
 

@@ -155,5 +155,6 @@ extern "C" int pa_exchange_rccl(pa_plan *p, pa_comm *m, int mode) {
     if (len) PA_NCCL(g_api.Send(o.d_buf + o.ptrs[j], len, ncclDouble, o.nbr[j], m->comm, st));
   }
   PA_NCCL(g_api.GroupEnd());
+  p->own_comm_stream = true;
   return pa_plan_mark_arrived(p);
 }
