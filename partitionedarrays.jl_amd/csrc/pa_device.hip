@@ -1119,8 +1119,13 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
 // round.  The result vector's storage moves only when the library owns it (pa_vec_create) and the block is one slab.
 static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, int tries) {
   pa_ctx *c = S->ctx;
-  if (tries < 2 || S->nnz < ((int64_t)8 << 20) || S->n_chunks < 1 || c->capturing || S->use_vdict) return PA_OK;
-  const size_t pad = 8, vbytes = sizeof(double) * (S->nnz + pad);
+  if (tries < 2 || S->nnz < ((int64_t)8 << 20) || S->n_chunks < 1 || c->capturing) return PA_OK;
+  // the stream the kernel reads per stored entry: the fp64 values, or their one-byte codes when the block has a value
+  // dictionary (the values then stay where they are: only pa_csr_update_values touches them)
+  const bool vd = S->use_vdict;
+  const size_t pad = 8, vbytes = vd ? (size_t)(S->nnz + pad) : sizeof(double) * (S->nnz + pad);
+  auto stream = [&]() -> void * { return vd ? (void *)S->d_code : (void *)S->d_val; };
+  auto set_stream = [&](void *q) { if (vd) S->d_code = (uint8_t *)q; else S->d_val = (double *)q; };
   const size_t ybytes = sizeof(double) * (size_t)(y->n_own + y->n_ghost + 2);
   const char *em = getenv("PA_PLACEMENT_MOVE_Y");
   const bool move_y = y->owned && S->next == nullptr && S->row0 == 0 && !(em && atoi(em) == 0);
@@ -1130,8 +1135,8 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
   const bool verbose = getenv("PA_SETUP_TIMING") != nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
   double *ycur = y->d;                                        // where the result goes at the moment (y->d itself until the end)
-  auto time_pair = [&](double *val, double *yb, float *ms_out) -> int {   // average of 3 launches after one untimed launch
-    S->d_val = val;
+  auto time_pair = [&](void *val, double *yb, float *ms_out) -> int {   // average of 3 launches after one untimed launch
+    set_stream(val);
     spmv_launch_slab(S, xs, yb + yoff, 1.0, 0.0);
     PA_HIP(hipEventRecord(e0, c->s[0]));
     for (int r = 0; r < 3; ++r) spmv_launch_slab(S, xs, yb + yoff, 1.0, 0.0);
@@ -1143,7 +1148,7 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
   };
   for (int w = 0; w < 6; ++w) spmv_launch_slab(S, xs, ycur + yoff, 1.0, 0.0);   // clocks up before anything is compared
   float first = 0, now = 0;
-  PA_TRY(time_pair(S->d_val, ycur, &first));
+  PA_TRY(time_pair(stream(), ycur, &first));
   now = first;
   int timed = 1;
   while (timed < tries) {
@@ -1152,7 +1157,8 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
     int k = std::min(4, tries - timed);
     while (k > 0 && (size_t)k * vbytes + 5 * ybytes > free_b / 2) --k;          // never more than half of what is free
     if (k < 1) break;
-    std::vector<double *> vals(1, S->d_val), ys(1, ycur);
+    std::vector<void *> vals(1, stream());
+    std::vector<double *> ys(1, ycur);
     // result allocations and value copies alternate: the classes are ranges of device memory several GiB long
     // (DESIGN.md section 3), so the y candidates should be spread, not adjacent
     for (int t = 0; t <= k; ++t) {
@@ -1162,9 +1168,10 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
         ys.push_back(v);
       }
       if (t == k) break;
-      if (hipMalloc(&v, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
-      PA_HIP(hipMemcpyAsync(v, vals[0], vbytes, hipMemcpyDeviceToDevice, c->s[0]));
-      vals.push_back(v);
+      void *q = nullptr;
+      if (hipMalloc(&q, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
+      PA_HIP(hipMemcpyAsync(q, vals[0], vbytes, hipMemcpyDeviceToDevice, c->s[0]));
+      vals.push_back(q);
     }
     if (vals.size() * ys.size() < 2) break;
     size_t bi = 0, bj = 0;

@@ -1070,6 +1070,18 @@ def test_placement_tuning_never_changes_a_result(orc, monkeypatch):
     assert sb.tune_placement(xs, ys, tries=4)["candidates"] == 0
     with pytest.raises(pa.PAError):
         blk.tune_placement(x, x)                           # aliasing is refused like in spmv!
+    # a block with a value dictionary: the one-byte code stream is what gets placed; same bits, and a value update
+    # afterwards still finds the fp64 values where they were
+    monkeypatch.setenv("PA_SPMV_VALUE_DICT", "1")
+    dV = pa.DeviceCSR(h)
+    monkeypatch.delenv("PA_SPMV_VALUE_DICT")
+    assert dV.value_dict() == 2
+    yv = pa.DeviceVector(n, 0)
+    assert dV.tune_placement(x, yv, tries=3)["candidates"] == 3
+    assert np.array_equal(yv.download(), before)
+    dV.update_values(2.0 * h.nzval)
+    pa.spmv_(yv, dV, x)
+    assert dV.value_dict() == 0 and np.array_equal(yv.download(), 2.0 * before)
     # a block kept as row slabs: every slab's values are placed on their own, y stays where it is
     monkeypatch.setenv("PA_CSR_MAX_SLAB_NNZ", "9000000")
     hb = pa.local_items(pa.build_p_matrix(ranks(1), 96, 96, 96, 96, 96, 96, 1, 1, 1, keep_host=True)[0].host_blocks)[0][0]
