@@ -152,7 +152,7 @@ int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes);
  * On most MI355X boxes the product kernel's time depends on WHICH allocations hold the value stream and y (0.67 ... 0.82
  * ms for the 27-point 256^3 operator: same kernel, same data; a pure (values, y) interaction, x plays no part; stable
  * for given allocations).  pa_csr_tune_placement times y = A*x with the caller's x on up to `tries`
- * copies of A's values, each against up to 6 allocations for y, in rounds of 4 copies, and keeps the fastest pair; the
+ * copies of A's values (of their one-byte codes when the block has a value dictionary), each against up to 6 allocations for y, in rounds of 4 copies, and keeps the fastest pair; the
  * rest is freed (transient HBM: 4 x the value stream + 5 x y, never more than half of what is free).
  *   - y is overwritten with A*x.  If the library owns y's storage (pa_vec_create) and A is one slab, the storage MAY MOVE
  *     to another allocation (same content, same handle): device pointers obtained through pa_vec_data before the call,
