@@ -409,8 +409,15 @@ def pvector_from_function(f, index_partition, cache=None) -> PVector:
 
 
 def pfill(value, index_partition) -> PVector:
-    """pfill(v,index_partition) (src/p_vector.jl:1047)."""
-    return pvector_from_function(lambda ind: np.full(ind.n_local, value, F64), index_partition)
+    """pfill(v,index_partition) (src/p_vector.jl:1047): filled on the device (no host array, no upload)."""
+
+    def make(ind):
+        v = DeviceVector(ind.n_own, ind.n_ghost) if ind.own_is_contiguous_prefix else DeviceVector(ind.n_local, 0)
+        if value != 0.0:                     # (pa_vec_create hands out zeroed storage)
+            v.fill(float(value))
+        return v
+
+    return PVector(pmap(make, index_partition), index_partition, None)
 
 
 def pzeros(index_partition) -> PVector:
