@@ -29,6 +29,22 @@ if os.path.exists(kth):
                                    "(earlier launches: parity gate, placement candidates, warm-up)",
                            "launches_total": len(d), "avg_us_last_50": sum(last) / max(1, len(last)),
                            "min_us": min(last), "max_us": max(last), "avg_us_all": sum(u for _, u in d) / max(1, len(d))}
+# the default bench command's own timed region inside ITS trace: bench.py prints the CLOCK_MONOTONIC bounds
+kt = os.path.join(src, "prof_kt", "kt_kernel_trace.csv")
+bl = os.path.join(src, "bench_kt.log")
+if os.path.exists(kt) and os.path.exists(bl):
+    line = [l for l in open(bl) if l.startswith('{"metric"')]
+    if line:
+        bench = json.loads(line[-1])
+        lo, hi = bench["roofline"].get("timed_region_monotonic_ns", [0, 0])
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt))
+             if "k_spmv_rowsplit" in r["Kernel_Name"] and ", 0, false" in r["Kernel_Name"] and lo <= int(r["Start_Timestamp"]) <= hi]
+        # (own x ghost is the same kernel on an empty block at one part: no launch)
+        out["default_command_timed_region"] = {
+            "what": "launches of the headline kernel between the CLOCK_MONOTONIC bounds bench.py reports for its timed steps, "
+                    "in the trace of the default command (profiles/rNN_kernel_stats.csv averages ALL launches of the process: "
+                    "parity gate, placement search, warm-up, timed steps, CG loop)",
+            "launches": len(d), "avg_us": sum(d) / max(1, len(d)), "bench_avg_launch_ms": bench["roofline"]["avg_launch_ms"]}
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d, f in (("prof_fetch", "f"), ("prof_write", "w"), ("prof_tcc", "t")):
     p = os.path.join(src, d, f"{f}_counter_collection.csv")
