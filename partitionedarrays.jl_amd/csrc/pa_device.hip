@@ -1148,6 +1148,7 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
   };
   for (int w = 0; w < 6; ++w) spmv_launch_slab(S, xs, ycur + yoff, 1.0, 0.0);   // clocks up before anything is compared
   float first = 0, now = 0;
+  std::vector<float> all_ms;                                  // every pair's time: their median is what an ordinary pair costs
   PA_TRY(time_pair(stream(), ycur, &first));
   now = first;
   int timed = 1;
@@ -1182,6 +1183,7 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
         float ms = 0;
         PA_TRY(time_pair(vals[i], ys[j], &ms));
         row_best[i] = std::min(row_best[i], ms);
+        all_ms.push_back(ms);
         if (ms < best) { best = ms; bi = i; bj = j; }
       }
     timed += (int)vals.size() - 1;
@@ -1195,6 +1197,46 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
       fprintf(stderr, "[pa setup] placement round (%zu value copies x %zu result allocations), best per value copy:", vals.size(), ys.size());
       for (float t : row_best) fprintf(stderr, " %.4f", t);
       fprintf(stderr, " ms -> kept (#%zu, y #%zu), %.4f ms once the others are freed\n", bi, bj, now);
+    }
+  }
+  // No fast pair among the candidates (the kept one is within 6 % of the median)?  Then walk y alone down the device
+  // memory: up to 48 rungs of [spacer | y candidate] one GiB apart, each timed against the kept value copy -- the classes
+  // are ranges many GiB long and most value copies have a fast one somewhere (the range map).
+  if (move_y && all_ms.size() >= 4) {
+    std::vector<float> sorted(all_ms);
+    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
+    const float median = sorted[sorted.size() / 2];
+    if (now > 0.94f * median) {
+      const size_t rung = (size_t)1 << 30;
+      size_t free_b = 0, total_b = 0;
+      PA_HIP(hipMemGetInfo(&free_b, &total_b));
+      const int rungs = (int)std::min<size_t>(48, free_b / 2 / rung);
+      std::vector<void *> spacers;
+      std::vector<double *> ys;
+      double *ybest = nullptr;
+      float tbest = now;
+      for (int j = 0; j < rungs; ++j) {
+        void *sp = nullptr;
+        double *yc = nullptr;
+        if (rung > ybytes && hipMalloc(&sp, rung - ybytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (sp) spacers.push_back(sp);
+        if (hipMalloc(&yc, ybytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        ys.push_back(yc);
+        float ms = 0;
+        PA_TRY(time_pair(stream(), yc, &ms));
+        if (ms < tbest) { tbest = ms; ybest = yc; }
+        if (ms < 0.93f * median) break;                       // a fast range: stop here
+      }
+      for (void *q : spacers) (void)hipFree(q);
+      for (double *q : ys)
+        if (q != ybest) (void)hipFree(q);
+      if (ybest) {
+        if (ycur != y->d) (void)hipFree(ycur);
+        ycur = ybest;
+      }
+      PA_TRY(time_pair(stream(), ycur, &now));
+      if (verbose) fprintf(stderr, "[pa setup] placement ladder: %zu rungs, best %.4f ms (median of the pairs %.4f), %.4f ms once the rest is freed\n",
+                           ys.size(), tbest, median, now);
     }
   }
   if (ycur != y->d) {                                         // the vector moves: same content, new allocation
