@@ -1152,7 +1152,10 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
   PA_TRY(time_pair(stream(), ycur, &first));
   now = first;
   int timed = 1;
-  while (timed < tries) {
+  int budget = tries;
+  for (int pass = 0; pass < 2; ++pass) {                      // rounds, then the ladder; if the ladder moved y, one more round on it
+  bool ladder_moved = false;
+  while (timed < budget) {
     size_t free_b = 0, total_b = 0;
     PA_HIP(hipMemGetInfo(&free_b, &total_b));
     int k = std::min(4, tries - timed);
@@ -1233,11 +1236,15 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
       if (ybest) {
         if (ycur != y->d) (void)hipFree(ycur);
         ycur = ybest;
+        ladder_moved = true;
       }
       PA_TRY(time_pair(stream(), ycur, &now));
       if (verbose) fprintf(stderr, "[pa setup] placement ladder: %zu rungs, best %.4f ms (median of the pairs %.4f), %.4f ms once the rest is freed\n",
                            ys.size(), tbest, median, now);
     }
+  }
+  if (!ladder_moved) break;
+  budget = timed + 4;                                         // four more value copies against the y the ladder found
   }
   if (ycur != y->d) {                                         // the vector moves: same content, new allocation
     PA_HIP(hipMemsetAsync(ycur + (y->n_own + y->n_ghost), 0, 2 * sizeof(double), c->s[0]));
