@@ -1217,7 +1217,7 @@ static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, 
       std::vector<void *> spacers;
       std::vector<double *> ys;
       double *ybest = nullptr;
-      float tbest = now;
+      float tbest = 0.97f * now;                               // (a rung has to beat the kept pair by 3 % to count)
       for (int j = 0; j < rungs; ++j) {
         void *sp = nullptr;
         double *yc = nullptr;
