@@ -230,21 +230,26 @@ def main():
     # THESE x and y (pa_csr_tune_placement).  PA_PLACEMENT_TRIES=0 turns it off.
     tries = int(os.environ.get("PA_PLACEMENT_TRIES", "16"))
     placement_searches = 0
+    tries0 = tries                         # (the same on every rank: what the collective decisions below depend on)
     for attempt in range(3):
         if tries > 1:
             PHASE[0] = "value-stream placement"
-            kept = blk.own_own.tune_placement(xv, yv, tries=tries)["kept_ms"]
-            placement_searches += 1
+            try:                               # an optional, result-neutral step never costs the run its line
+                kept = blk.own_own.tune_placement(xv, yv, tries=tries)["kept_ms"]
+                placement_searches += 1
+            except Exception as e:             # noqa: BLE001
+                print(f"[rank {rank}] placement search skipped: {e}", file=sys.stderr)
+                tries = 0
         PHASE[0] = f"warm-up (transport {transport})"
         for _ in range(args.warmup):
             step()
-        if tries <= 1 or args.warmup < 1 or args.steps < 1:
+        if tries0 <= 1 or args.warmup < 1 or args.steps < 1:
             break
         # a placement can stop holding when other allocations come and go: one untimed step with the
         # kernel's events tells; search again (at most twice) if the product is 4 % slower than the search left it
         step(0)
         ctx.sync()
-        again = 1 if ev0[0].elapsed_ms(ev1[0]) > 1.04 * kept else 0
+        again = 1 if tries > 1 and ev0[0].elapsed_ms(ev1[0]) > 1.04 * kept else 0
         if N > 1:                          # (every rank decides the same: the search is a collective no-op otherwise)
             flag = torch.tensor([again])
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
