@@ -10,6 +10,10 @@ matrix, 256^3 rows per part (BASELINE.json: the size the metric is quoted on): c
 RCCL neighbour exchange -> unpack] overlapped with own x own, then own x ghost.  Weak scaling: part p of an
 (npx,npy,npz) = compute_optimal_shape_XYZ(N) grid lives on GPU p-1.  Inputs are resident in HBM before the
 timed region.  Rank 0 prints ONE JSON line.
+
+Order of the run: set-up, parity gate, warm-up, the K timed steps (wall clock between barriers, nothing else in the
+loop), then -- outside the headline's timed region -- a second pass of K steps with HIP events around the dominant
+kernel (roofline), the overlap-off comparison (N > 1), the CG loop, the other BASELINE configs (N = 1) and the CPU baseline.
 """
 import argparse
 import json
@@ -53,43 +57,167 @@ def parse():
                     help="iterations of the CG loop timed after the headline measurement (0: skip)")
     ap.add_argument("--no-value-dict", dest="value_dict", action="store_false",
                     help="skip the extra measurement of the optional value-dictionary mode (N=1 only)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="the timed step waits for the ghost exchange BEFORE own x own (HPCG's mul_no_lat! order): "
+                         "what the overlap is worth is `overlap.ms_per_step_off` vs `_on` of a default run")
+    ap.add_argument("--no-extra", dest="extra", action="store_false", help="skip BASELINE configs 2, 3, 5 (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=160, help="grid size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU work of the baseline sample (per rank)")
     return ap.parse_args()
 
 
-def cpu_baseline(n):
-    """The reference's spmv_csr! loop (src/sparse_utils.jl:649-669) restated in C (oracle/pa_oracle.c,
-    -O3 -ffp-contract=off), one core, on a bounded sample: the same 27-point matrix at n^3 rows."""
-    import ctypes as C
+def hash_x(gids):
+    """x[gid] = ((gid*2654435761) mod 2^32)/2^32: stateless, identical on any number of parts."""
+    g = np.asarray(gids).astype(np.uint64)
+    return ((g * np.uint64(2654435761)) % np.uint64(2 ** 32)).astype(np.float64) / float(2 ** 32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's mul! as its own processes would run it -- one part per process, one core per process
+# (mpiexec -n P with single-threaded ranks, src/mpi_array.jl:42-53), every loop the oracle's C restatement
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_mul_baseline(pa, A, N, rank, seconds):
+    """pack -> exchange -> spmv_csr!(own x own) -> unpack -> muladd!(own x ghost) of THIS rank's part at the bench's own
+    size, on one pinned core, with the oracle's C loops (oracle/pa_oracle.c; src/p_vector.jl:587-612,
+    src/sparse_utils.jl:649-669, src/p_sparse_matrix.jl:2088,2098-2101); the exchange between the ranks' buffers goes
+    through torch.distributed's CPU backend (gloo) the way the reference's goes through MPI.  All ranks run
+    concurrently; the reported time per mul! is the slowest rank's median."""
+    import torch
+    import torch.distributed as dist
     from __graft_entry__ import load_oracle
     orc = load_oracle()
     K = orc.oracle_c()
     if not hasattr(K, "lib"):
         return None
-    lib = K.lib
-    lib.orc_hpcg_csr_single.restype = C.c_int64
-    lib.orc_hpcg_csr_single.argtypes = [C.c_int32] * 3 + [C.c_void_p] * 3
-    rows = n ** 3
-    rowptr = np.zeros(rows + 1, np.int32)
-    nnz = lib.orc_hpcg_csr_single(n, n, n, rowptr.ctypes.data, None, None)
-    colval, nzval = np.zeros(nnz, np.int32), np.zeros(nnz, np.float64)
-    lib.orc_hpcg_csr_single(n, n, n, rowptr.ctypes.data, colval.ctypes.data, nzval.ctypes.data)
-    x = orc.hash_x(np.arange(1, rows + 1))
-    y = np.zeros(rows)
-    A = orc.CSR(rows, rows, rowptr, colval, nzval)
-    K.spmv_csr(y, x, A)                       # warm
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        K.spmv_csr(y, x, A)
-        reps += 1
-        dt = time.perf_counter() - t0
-        if dt > 12.0 or reps >= 200:
-            break
-    t = dt / reps
-    return {"value": round(2.0 * nnz / t / 1e9, 4), "unit": "GFLOP/s", "cores": 1, "kind": "port",
-            "sample": f"27-pt HPCG matrix {n}^3 rows ({nnz} nnz), {reps} x spmv_csr! (oracle/pa_oracle.c) in {dt:.1f} s",
-            "gbps_algorithmic": round((nnz * 12 + (rows + 1) * 4 + rows * 16) / t / 1e9, 3)}
+    oo, oh = pa.local_items(A.host_blocks)[0]
+    ind = pa.local_items(A.col_partition)[0]
+    cache = ind.cache
+    nbr_snd, nbr_rcv = np.asarray(cache["neighbors_snd"]), np.asarray(cache["neighbors_rcv"])
+    lsnd, lrcv = cache["local_indices_snd"], cache["local_indices_rcv"]
+    # consistent! uses the reversed cache (src/p_vector.jl:748): pack the own ids others ghost (rcv side), unpack into my ghosts
+    buf_out = np.zeros(len(lrcv.data))
+    buf_in = np.zeros(len(lsnd.data))
+    x = np.zeros(ind.n_local)
+    x[:ind.n_own] = hash_x(ind.own_to_global)
+    y = np.zeros(oo.m)
+    Aoo, Aoh = orc.CSR(oo.m, oo.n, oo.rowptr, oo.colval, oo.nzval), orc.CSR(oh.m, oh.n, oh.rowptr, oh.colval, oh.nzval)
+    t_out, t_in = torch.from_numpy(buf_out), torch.from_numpy(buf_in)
+    xg = x[ind.n_own:]                       # ghost values: a view (the device layout [own | ghost] is the host layout too)
+    glids = (np.asarray(lsnd.data, np.int64) - ind.n_own).astype(np.int32)
+
+    # one core per rank
+    cores = sorted(os.sched_getaffinity(0))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    mine = cores[(local * max(1, len(cores) // max(N, 1))) % len(cores)]
+    old = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, {mine})
+    torch_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+
+    def one():
+        K.pack(buf_out, x, np.asarray(lrcv.data, np.int32))
+        reqs = []
+        for k, q in enumerate(nbr_snd):     # my ghosts' owners send to me
+            a, e = int(lsnd.ptrs[k]) - 1, int(lsnd.ptrs[k + 1]) - 1
+            if e > a:
+                reqs.append(dist.irecv(t_in[a:e], int(q) - 1))
+        for k, q in enumerate(nbr_rcv):
+            a, e = int(lrcv.ptrs[k]) - 1, int(lrcv.ptrs[k + 1]) - 1
+            if e > a:
+                reqs.append(dist.isend(t_out[a:e], int(q) - 1))
+        K.spmv_csr(y, x[:ind.n_own], Aoo)                      # own x own while the messages travel
+        for r in reqs:
+            r.wait()
+        K.unpack_insert(xg, buf_in, glids)
+        K.mul5_csr(y, Aoh, xg, 1.0, 1.0)                       # muladd!
+    try:
+        one()
+        if N > 1:
+            dist.barrier()
+        times = []
+        t_begin = time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            one()
+            times.append(time.perf_counter() - t0)
+            stop = 1 if (time.perf_counter() - t_begin > seconds and len(times) >= 3) or len(times) >= 200 else 0
+            if N > 1:                        # every rank does the same number of products (they exchange messages)
+                flag = torch.tensor([stop])
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                stop = int(flag.item())
+            if stop:
+                break
+    finally:
+        os.sched_setaffinity(0, old)
+        torch.set_num_threads(torch_threads)
+    med = float(np.median(times))
+    nnz = oo.nnz + oh.nnz
+    if N > 1:
+        tt = torch.tensor([med, float(nnz)], dtype=torch.float64)
+        mx = tt.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        med, nnz_total = float(mx[0].item()), int(tt[1].item())
+    else:
+        nnz_total = nnz
+    bytes_part = nnz * 12 + (oo.m + 1) * 4 + ind.n_local * 8 + oo.m * 8
+    return {"value": round(2.0 * nnz_total / med / 1e9, 3), "unit": "GFLOP/s", "cores": N, "kind": "port",
+            "ms_per_mul": round(med * 1e3, 2), "gflops": round(2.0 * nnz_total / med / 1e9, 3),
+            "gbps_algorithmic_per_core": round(bytes_part / med / 1e9, 2),
+            "sample": f"the bench's own workload ({oo.m} rows, {nnz} stored entries per part, {N} part(s)): {len(times)} x mul! per "
+                      f"rank = pack / exchange (gloo p2p) / spmv_csr! / unpack / muladd!, oracle/pa_oracle.c loops (-O3 "
+                      f"-ffp-contract=off), one process pinned to one core per part (mpiexec -n {N} of the reference), median of "
+                      f"the slowest rank"}
+
+
+def cpu_c1_debugarray(seconds=3.0):
+    """BASELINE config 1 the way DebugArray runs it (src/debug_array.jl:110-117): gallery laplacian 7-point 64^3 on 4
+    parts (2,2,1), ONE core looping over the parts, mul! = consistent! + spmv! + muladd! with the oracle's loops."""
+    from __graft_entry__ import load_oracle
+    orc = load_oracle()
+    if not hasattr(orc.oracle_c(), "lib"):
+        return None
+    Io, Jo, Vo, rows, _ = orc.laplacian_fdm_fast((64, 64, 64), (2, 2, 1))        # src/gallery.jl:12-86, docs/examples.jl:223
+    A = orc.psparse_from_coo(Io, Jo, Vo, rows)
+    K = orc.oracle_c()
+    x = [np.ascontiguousarray(orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part)) for c in A.cols]
+    y = [np.zeros(r.n_own) for r in A.rows]
+    cache = orc.p_vector_cache(x, A.cols).reverse()             # consistent! = reversed cache + insert (src/p_vector.jl:748)
+    lsnd = [np.ascontiguousarray(l.data, np.int32) for l in cache.local_indices_snd]
+    lrcv = [np.ascontiguousarray(l.data, np.int32) for l in cache.local_indices_rcv]
+    copies = []                                                 # exchange_impl! of DebugArray: src/primitives.jl:1020-1042
+    for r, rids in enumerate(cache.neighbors_rcv):
+        for i, sp in enumerate(rids):
+            j = list(cache.neighbors_snd[sp - 1]).index(r + 1)
+            pr, ps = cache.buffer_rcv[r].ptrs, cache.buffer_snd[sp - 1].ptrs
+            copies.append((cache.buffer_rcv[r].data, int(pr[i]) - 1, int(pr[i + 1]) - 1, cache.buffer_snd[sp - 1].data, int(ps[j]) - 1, int(ps[j + 1]) - 1))
+    P = len(x)
+
+    def mul():                                                  # mul!(c,a,b), src/p_sparse_matrix.jl:2098-2101, parts in sequence
+        for p in range(P):
+            K.pack(cache.buffer_snd[p].data, x[p], lsnd[p])
+        for dst, a0, a1, src, b0, b1 in copies:
+            dst[a0:a1] = src[b0:b1]
+        for p in range(P):
+            K.spmv_csr(y[p], x[p][:A.cols[p].n_own], A.blocks[p].own_own)
+        for p in range(P):
+            K.unpack_insert(x[p], cache.buffer_rcv[p].data, lrcv[p])
+        for p in range(P):
+            K.mul5_csr(y[p], A.blocks[p].own_ghost, x[p][A.cols[p].n_own:], 1.0, 1.0)
+    mul()
+    want = [np.zeros(r.n_local) for r in A.rows]
+    orc.mul(want, A, [v.copy() for v in x])                     # the oracle's own mul! on the same input: same bits
+    assert all(np.array_equal(g, w[:len(g)]) for g, w in zip(y, want)), "the timed C1 loop differs from the oracle's mul!"
+    times, t_begin = [], time.perf_counter()
+    while time.perf_counter() - t_begin < seconds or len(times) < 3:
+        t0 = time.perf_counter()
+        mul()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    nnz = sum(b.own_own.nnz + b.own_ghost.nnz for b in A.blocks)
+    return {"what": "config 1: 7-pt 64^3, 4 parts (2,2,1), DebugArray order (parts one after the other), 1 core",
+            "cores": 1, "ms_per_mul": round(med * 1e3, 3), "gflops": round(2.0 * nnz / med / 1e9, 3), "nnz": int(nnz),
+            "reps": len(times)}
 
 
 def calibrate_box(pa, ctx, L):
@@ -114,6 +242,74 @@ def calibrate_box(pa, ctx, L):
             "what": "1 GiB vectors: hipMemcpyAsync device-to-device (read+write bytes) and k_dot_partial (two read streams)"}
 
 
+def time_block(pa, ctx, L, blk, n_rows, n_cols, reps=30):
+    """Events around `reps` products of one block with its own vectors: ms per product."""
+    x = pa.DeviceVector(n_cols, 0).upload(hash_x(np.arange(1, n_cols + 1)))
+    y = pa.DeviceVector(n_rows, 0)
+    for _ in range(5):
+        pa.spmv_(y, blk, x)
+    e0 = ctx.event().record(L.STREAM_COMPUTE)
+    for _ in range(reps):
+        pa.spmv_(y, blk, x)
+    e1 = ctx.event().record(L.STREAM_COMPUTE)
+    ctx.sync()
+    return e0.elapsed_ms(e1) / reps
+
+
+def extra_configs(pa, ctx, L):
+    """BASELINE configs 2, 3 (one part's size) and 5 (one part's rows) on this GPU, one entry each: ms per product,
+    GFLOP/s, algorithmic GB/s (12 B per entry + 20 B per row), moved GB/s (bytes the block's encoding makes the
+    kernel read + x once + y once), column encoding of the chunks."""
+    out = []
+    ranks1 = pa.DebugArray([1])
+
+    def entry(workload, blk, n_rows, n_cols, ms, t_setup):
+        nnz = blk.nnz
+        alg = nnz * 12 + (n_rows + 1) * 4 + n_cols * 8 + n_rows * 8
+        moved = blk.stream_bytes() + n_cols * 8 + n_rows * 8
+        return {"workload": workload, "rows": int(n_rows), "nnz": int(nnz), "ms": round(ms, 4),
+                "gflops": round(2.0 * nnz / ms / 1e6, 1), "algorithmic_gbps": round(alg / ms / 1e6, 1),
+                "moved_gbps": round(moved / ms / 1e6, 1), "encoding": blk.encoding(), "setup_s": round(t_setup, 1)}
+    # config 2: 7-point Laplacian 256^3, one part, SpMV only (gallery laplacian_fdm -> psparse, Int32 CSR)
+    PHASE[0] = "extra: config 2"
+    t = time.perf_counter()
+    I, J, V, rows, cols = pa.laplacian_fdm((256, 256, 256), (1, 1, 1), ranks1)
+    A2 = pa.psparse_from_coo(I, J, V, rows)
+    del I, J, V
+    b2 = A2.matrix_partition.items[0].own_own
+    ts = time.perf_counter() - t
+    out.append(entry("config 2: gallery 7-pt Laplacian 256^3, 1 part, pa_spmv only", b2, b2.m, b2.n,
+                     time_block(pa, ctx, L, b2, b2.m, b2.n), ts))
+    del A2, b2
+    # config 3's size: 27-point 128^3, one part, mul!
+    PHASE[0] = "extra: config 3 size"
+    t = time.perf_counter()
+    A3, _ = pa.build_p_matrix(ranks1, 128, 128, 128, 128, 128, 128, 1, 1, 1)
+    b3 = A3.matrix_partition.items[0].own_own
+    ts = time.perf_counter() - t
+    x3, y3 = pa.pvector_from_function(lambda ind: hash_x(ind.get_local_to_global()), A3.col_partition), pa.pzeros(A3.row_partition)
+    for _ in range(5):
+        pa.mul_(y3, A3, x3)
+    e0 = ctx.event().record(L.STREAM_COMPUTE)
+    for _ in range(50):
+        pa.mul_(y3, A3, x3)
+    e1 = ctx.event().record(L.STREAM_COMPUTE)
+    ctx.sync()
+    out.append(entry("config 3's size: HPCG 27-pt 128^3, 1 part, mul!", b3, b3.m, b3.n, e0.elapsed_ms(e1) / 50, ts))
+    del A3, b3, x3, y3
+    # config 5: the rows one part of the 4096^2-node Q1 FEM matrix on (4,2) parts holds: 1024 x 2048 nodes
+    PHASE[0] = "extra: config 5 part"
+    t = time.perf_counter()
+    I, J, V, rows, cols = pa.laplacian_fem((1024, 2048), (1, 1), ranks1)
+    A5 = pa.psparse_disassembled(I, J, V, rows, cols)
+    del I, J, V
+    b5 = A5.matrix_partition.items[0].own_own
+    ts = time.perf_counter() - t
+    out.append(entry("config 5: Q1 FEM Laplacian 2-D, 1024 x 2048 nodes (= one part's rows of the 4096^2 instance on (4,2) "
+                     "parts), disassembled psparse route, pa_spmv", b5, b5.m, b5.n, time_block(pa, ctx, L, b5, b5.m, b5.n), ts))
+    return out
+
+
 def main():
     args = parse()
     N = args.gpus
@@ -134,25 +330,41 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     pa = load_package()
     ctx = pa.context()
+    import pa_amd._lib as L
 
     n = args.n
     npx, npy, npz = pa.compute_optimal_shape_XYZ(N)
     gn = (npx * n, npy * n, npz * n)
     transport = "none(1 part)"
+    rccl_ranks_seen = None
     if N > 1:
         import pa_amd.p_vector as pv
         transport = os.environ.get("PA_TRANSPORT", "rccl")
+        allow_fallback = os.environ.get("PA_ALLOW_TRANSPORT_FALLBACK", "0") == "1"
         if transport == "rccl":
             PHASE[0] = "RCCL communicator"
+            err = ""
             try:                       # direct RCCL (ncclSend/ncclRecv issued by libpa_hip on its comm stream)
-                pa.init_comm()
-                good = 1
+                comm = pa.init_comm()
+                rccl_ranks_seen = comm.info()["nranks"]
+                good = 1 if rccl_ranks_seen == N else 0
+                if not good:
+                    err = f"the communicator reports {rccl_ranks_seen} ranks, expected {N}"
             except Exception as e:     # noqa: BLE001
-                print(f"[rank {rank}] direct RCCL communicator failed: {e}", file=sys.stderr)
-                good = 0
+                good, err = 0, str(e)
+            if not good:
+                print(f"[rank {rank}] direct RCCL communicator failed: {err}", file=sys.stderr, flush=True)
             flag = torch.tensor([good])
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if not flag.item():
+                # the RCCL neighbour exchange IS what an N > 1 line measures: a silent downgrade would report another
+                # path under the same name.  PA_ALLOW_TRANSPORT_FALLBACK=1 lets the run continue on torch.distributed p2p,
+                # labelled as such in config.transport.
+                if not allow_fallback:
+                    print("[bench] RCCL transport unavailable on at least one rank; refusing to downgrade "
+                          "(PA_ALLOW_TRANSPORT_FALLBACK=1 overrides)", file=sys.stderr, flush=True)
+                    dist.barrier()
+                    os._exit(3)
                 transport = "torch"
         pv.TRANSPORT = transport
         ranks = pa.with_torchdist(lambda distribute: distribute(range(1, N + 1)))
@@ -161,11 +373,12 @@ def main():
 
     PHASE[0] = "matrix set-up"
     t_setup = time.perf_counter()
-    A, b = pa.build_p_matrix(ranks, n, n, n, *gn, npx, npy, npz)
-    # x[gid] = ((gid*2654435761) mod 2^32)/2^32 on OWN entries only: mul! must bring the ghosts
+    want_cpu = not args.no_cpu_baseline
+    A, b = pa.build_p_matrix(ranks, n, n, n, *gn, npx, npy, npz, keep_host=want_cpu)
+
+    # x[gid] = hash on OWN entries only: mul! must bring the ghosts
     def xfun(ind):
-        g = ind.get_local_to_global().astype(np.uint64)
-        v = ((g * np.uint64(2654435761)) % np.uint64(2 ** 32)).astype(np.float64) / float(2 ** 32)
+        v = hash_x(ind.get_local_to_global())
         v[ind.n_own:] = 0.0
         return v
     x = pa.pvector_from_function(xfun, A.col_partition)
@@ -180,9 +393,7 @@ def main():
         x.vector_partition = pa.pmap(lambda v, ind: v.upload(xfun(ind)), x.vector_partition, A.col_partition)
         pa.mul_(y, A, x)
         for vals, ind in zip(pa.local_items(x.local_values()), pa.local_items(A.col_partition)):
-            g = ind.get_local_to_global().astype(np.uint64)
-            want = ((g * np.uint64(2654435761)) % np.uint64(2 ** 32)).astype(np.float64) / float(2 ** 32)
-            ok = ok and np.array_equal(vals, want)
+            ok = ok and np.array_equal(vals, hash_x(ind.get_local_to_global()))
         if N > 1:
             flag = torch.tensor([1 if ok else 0])
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -190,34 +401,30 @@ def main():
         return ok
 
     PHASE[0] = f"parity gate (transport {transport})"
-    ok = gate()
-    if not ok and N > 1 and transport == "rccl":
-        print(f"[rank {rank}] parity gate failed with the direct RCCL transport; retrying with torch.distributed p2p",
-              file=sys.stderr)
-        transport = pv.TRANSPORT = "torch"
-        ok = gate()
-    if not ok:
-        raise SystemExit("parity gate failed: A*1 != b or ghost values differ from their owners")
+    if not gate():
+        print(f"[bench] parity gate failed (transport {transport}): A*1 != b or ghost values differ from their owners",
+              file=sys.stderr, flush=True)
+        if N > 1:
+            dist.barrier()
+        os._exit(5)
 
     blk = pa.local_items(A.matrix_partition)[0]
     ind = pa.local_items(A.col_partition)[0]
     nnz_oo, nnz_oh, n_own, n_ghost = blk.own_own.nnz, blk.own_ghost.nnz, ind.n_own, ind.n_ghost
-
-    # ---- HIP events around the dominant kernel (own x own SpMV) inside the timed region, compute stream
-    import pa_amd._lib as L
     xv, yv = pa.local_items(x.vector_partition)[0], pa.local_items(y.vector_partition)[0]
-    ev0 = [ctx.event() for _ in range(args.steps)]
-    ev1 = [ctx.event() for _ in range(args.steps)]
 
-    def step(k=None):
+    def step(overlap=True, ev=None):
         # mul!(c,a,b): src/p_sparse_matrix.jl:2098-2101
         t = pa.consistent_(x)
-        if k is not None:
-            ev0[k].record(L.STREAM_COMPUTE)
+        if not overlap:
+            t.wait()                     # mul_no_lat! (HPCG/src/hpcg_utils.jl:6-17): exchange first, then the products
+        if ev:
+            ev[0].record(L.STREAM_COMPUTE)
         pa.spmv_(yv, blk.own_own, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
-        if k is not None:
-            ev1[k].record(L.STREAM_COMPUTE)
-        t.wait()
+        if ev:
+            ev[1].record(L.STREAM_COMPUTE)
+        if overlap:
+            t.wait()
         pa.spmv_(yv, blk.own_ghost, xv, L.SEG_GHOST, L.SEG_OWN, 1.0, 1.0)
 
     def barrier():
@@ -226,52 +433,55 @@ def main():
             dist.barrier()
             ctx.sync()
 
-    # optional, measured, result-neutral: keep the value stream in the allocation on which own x own runs fastest with
-    # THESE x and y (pa_csr_tune_placement).  PA_PLACEMENT_TRIES=0 turns it off.
-    tries = int(os.environ.get("PA_PLACEMENT_TRIES", "16"))
-    placement_searches = 0
-    tries0 = tries                         # (the same on every rank: what the collective decisions below depend on)
-    for attempt in range(3):
-        if tries > 1:
-            PHASE[0] = "value-stream placement"
-            try:                               # an optional, result-neutral step never costs the run its line
-                kept = blk.own_own.tune_placement(xv, yv, tries=tries)["kept_ms"]
-                placement_searches += 1
-            except Exception as e:             # noqa: BLE001
-                print(f"[rank {rank}] placement search skipped: {e}", file=sys.stderr)
-                tries = 0
-        PHASE[0] = f"warm-up (transport {transport})"
-        for _ in range(args.warmup):
-            step()
-        if tries0 <= 1 or args.warmup < 1 or args.steps < 1:
-            break
-        # a placement can stop holding when other allocations come and go: one untimed step with the
-        # kernel's events tells; search again (at most twice) if the product is 4 % slower than the search left it
-        step(0)
+    def timed(steps, overlap):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks."""
+        barrier()
+        m0 = time.clock_gettime_ns(time.CLOCK_MONOTONIC)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(overlap)
         ctx.sync()
-        again = 1 if tries > 1 and ev0[0].elapsed_ms(ev1[0]) > 1.04 * kept else 0
-        if N > 1:                          # (every rank decides the same: the search is a collective no-op otherwise)
-            flag = torch.tensor([again])
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            again = int(flag.item())
-        if not again:
-            break
+        barrier()
+        dt = time.perf_counter() - t0
+        m1 = time.clock_gettime_ns(time.CLOCK_MONOTONIC)
+        if N > 1:
+            tt = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, m0, m1
+
+    overlap_on = not args.no_overlap
+    PHASE[0] = f"warm-up (transport {transport})"
+    for _ in range(args.warmup):
+        step(overlap_on)
     PHASE[0] = f"timed mul! loop (transport {transport})"
+    dt, mono0, mono1 = timed(args.steps, overlap_on)
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- second pass, outside the headline's timed region: HIP events (compute stream) around own x own and around the
+    # whole step, every launch on its own; median and mean of max(50, steps) launches
+    PHASE[0] = "kernel-event pass"
+    K2 = max(50, args.steps)
+    evs = [[ctx.event() for _ in range(4)] for _ in range(K2)]
     barrier()
-    mono0 = time.clock_gettime_ns(time.CLOCK_MONOTONIC)       # (lets profiles/summarize.py find the timed launches in a trace)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(k)
+    for k in range(K2):
+        evs[k][2].record(L.STREAM_COMPUTE)
+        step(overlap_on, ev=evs[k][:2])
+        evs[k][3].record(L.STREAM_COMPUTE)
     ctx.sync()
     barrier()
-    dt = time.perf_counter() - t0
-    mono1 = time.clock_gettime_ns(time.CLOCK_MONOTONIC)
+    kern = np.array([e[0].elapsed_ms(e[1]) for e in evs])
+    whole = np.array([e[2].elapsed_ms(e[3]) for e in evs])
+    kern_ms, kern_med = float(kern.mean()), float(np.median(kern))
+
+    overlap = None
     if N > 1:
-        tt = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms_per_step = dt / args.steps * 1e3
-    kern_ms = float(np.mean([a.elapsed_ms(b_) for a, b_ in zip(ev0, ev1)]))
+        PHASE[0] = "overlap on/off comparison"
+        t_other, _, _ = timed(args.steps, not overlap_on)
+        on, off = (ms_per_step, t_other / args.steps * 1e3) if overlap_on else (t_other / args.steps * 1e3, ms_per_step)
+        overlap = {"ms_per_step_on": round(on, 4), "ms_per_step_off": round(off, 4), "headline_uses": "on" if overlap_on else "off",
+                   "what": "mul! with the ghost exchange under own x own (src/p_sparse_matrix.jl:2098-2100) vs exchange first "
+                           "(HPCG mul_no_lat!), same steps, same barriers"}
 
     nnz = nnz_oo + nnz_oh
     if N > 1:
@@ -283,10 +493,13 @@ def main():
     flops_total = 2.0 * nnz_total
     value = flops_total / (ms_per_step * 1e-3) / 1e9
 
-    # algorithmic bytes: whole mul! per part, and the dominant kernel's share
+    # algorithmic bytes: whole mul! per part, and the dominant kernel's share; moved bytes: what the
+    # block's encoding makes the kernel read (pa_csr_stream_bytes) + x once + y once
     bytes_mul = nnz * 12 + (n_own + 1) * 4 + (n_own + n_ghost) * 8 + n_own * 8
     bytes_oo = nnz_oo * 12 + (n_own + 1) * 4 + n_own * 8 + n_own * 8
+    moved_oo = blk.own_own.stream_bytes() + n_own * 8 + n_own * 8
     ach = bytes_oo / (kern_ms * 1e-3) / 1e9
+    ach_moved = moved_oo / (kern_ms * 1e-3) / 1e9
 
     # measured HBM traffic of the dominant kernel: PMC passes are separate rocprofv3 runs (never inside a timed
     # run); their per-launch summary is committed under profiles/ and quoted here (null when absent).
@@ -297,18 +510,19 @@ def main():
         if cands and n == 256:
             pm = json.load(open(cands[-1]))["pmc_per_launch"]["k_spmv_rowsplit"]
             traffic = round(pm["fetch_bytes_gfx950_corrected"] + pm["write_bytes"])
-            traffic_src = os.path.relpath(cands[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, 1-GPU 256^3 run)"
+            traffic_src = (os.path.relpath(cands[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of a separate 1-GPU 256^3 "
+                           "run of this command, not of this process)")
     except Exception:
         pass
 
-    # ---- what this box's HBM delivers to the simplest kernels ("re-confirm on the box with a device triad"):
-    # a device-to-device copy and a two-stream read (dot) over vectors far larger than the 256 MiB Infinity Cache
     box = None
-    try:
-        box = calibrate_box(pa, ctx, L) if (rank == 0 or N > 1) else None
-    except Exception as e:                                   # noqa: BLE001  (an extra; no collectives inside)
-        print(f"[bench] HBM calibration skipped: {e}", file=sys.stderr)
-    # ---- optional mode, reported beside the headline and never part of `value`: the same mul! with the lossless value
+    if rank == 0:
+        try:
+            box = calibrate_box(pa, ctx, L)
+        except Exception as e:                                   # noqa: BLE001  (an extra; no collectives inside)
+            print(f"[bench] HBM calibration skipped: {e}", file=sys.stderr)
+
+    # ---- optional mode, reported beside the headline and never part of `value`: the same product with the lossless value
     # dictionary (PA_SPMV_VALUE_DICT=1: one byte per stored entry instead of eight when a block has <= 64 distinct values)
     vdict = None
     if N == 1 and args.value_dict:
@@ -322,8 +536,6 @@ def main():
             pa.mul_(y2, A2, x)
             same = all(np.array_equal(a_, b_) for a_, b_ in zip(pa.local_items(y2.own_values()), pa.local_items(y.own_values())))
             y2v = pa.local_items(y2.vector_partition)[0]
-            if tries > 1:                                      # the code stream and y2 placed by measurement as well
-                blk2.own_own.tune_placement(xv, y2v, tries=tries)
             for _ in range(args.warmup):
                 pa.spmv_(y2v, blk2.own_own, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
             e0 = ctx.event().record(L.STREAM_COMPUTE)
@@ -348,8 +560,7 @@ def main():
     cg = None
     PHASE[0] = "CG loop"
     if args.cg_iters > 0:
-        # the loop's own work vectors, allocated once; the value stream and c placed for c = A*u (result-neutral)
-        work = pa.cg_work(pa.pzeros(A.col_partition), b, A, tune_placement=tries)
+        work = pa.cg_work(pa.pzeros(A.col_partition), b, A)     # the loop's own work vectors, allocated once
 
         def cg_time(fn, k):
             xx = pa.pzeros(A.col_partition)
@@ -369,31 +580,70 @@ def main():
                 d = float(tt.item())
             cg[name] = d / args.cg_iters * 1e3
 
+    extras = None
+    if N == 1 and args.extra and rank == 0:
+        try:
+            extras = extra_configs(pa, ctx, L)
+        except Exception as e:                                 # noqa: BLE001
+            print(f"[bench] extra configs skipped at {PHASE[0]!r}: {e}", file=sys.stderr)
+
+    cpu = None
+    if want_cpu:
+        PHASE[0] = "CPU baseline"
+        try:
+            cpu = cpu_mul_baseline(pa, A, N, rank, args.cpu_seconds)
+            if cpu is not None and rank == 0:
+                c1 = cpu_c1_debugarray()
+                if c1:
+                    cpu["c1_debugarray"] = c1
+        except Exception as e:                                 # noqa: BLE001
+            if N > 1:
+                raise                                           # (a rank that drops out of a collective would hang the others)
+            print(f"[bench] CPU baseline skipped: {e}", file=sys.stderr)
+
     if rank == 0:
+        prio = ctx.stream_priorities()
         out = {
             "metric": "HPCG 27-pt SpMV GFLOP/s + achieved HBM GB/s per GPU",
             "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"HPCG 27-pt stencil {n}^3 rows per part, {N} part(s) as ({npx},{npy},{npz}), "
-                                   "mul! = consistent!(pack+exchange+unpack) overlapped with own*own, then own*ghost",
+                                   "mul! = consistent!(pack+exchange+unpack) " + ("overlapped with own*own, then own*ghost" if overlap_on else
+                                                                                   "completed BEFORE own*own (--no-overlap), then own*ghost"),
                        "rows_per_part": n_own, "nnz_per_part": nnz, "nnz_own_own": nnz_oo, "nnz_own_ghost": nnz_oh,
-                       "ghosts_per_part": n_ghost, "index_type": "Int32", "transport": {"rccl": "rccl-p2p (ncclSend/ncclRecv group on the comm stream)", "torch": "torch.distributed p2p (fallback)"}.get(transport, transport)},
+                       "ghosts_per_part": n_ghost, "index_type": "Int32",
+                       "transport": {"rccl": "rccl-p2p (ncclSend/ncclRecv group on the comm stream)",
+                                     "torch": "torch.distributed p2p (FALLBACK, PA_ALLOW_TRANSPORT_FALLBACK=1: not the RCCL row)",
+                                     "host": "host-staged gloo (test transport: ranks may share a GPU)"}.get(transport, transport),
+                       "rccl_ranks_seen": rccl_ranks_seen, "overlap": overlap_on,
+                       "stream_priority": prio},
             "gflops_per_gpu": round(value / N, 2),
             "hbm_gbps_per_gpu_algorithmic": round(bytes_mul / (ms_per_step * 1e-3) / 1e9, 1),
+            "ms_per_step_median_events": round(float(np.median(whole)), 4),
             "roofline": {"bound": "hbm", "kernel": "k_spmv_rowsplit<256,6,nt> (own x own): CSR row split, LDS-staged products; "
                                                       "column encoding of the chunks: " + json.dumps(blk.own_own.encoding()),
-                         "achieved": round(ach, 1),
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": bytes_oo, "avg_launch_ms": round(kern_ms, 4),
+                         "median_launch_ms": round(kern_med, 4), "launches_timed": int(K2),
+                         "moved_bytes_per_launch": int(moved_oo), "achieved_moved": round(ach_moved, 1),
+                         "frac_moved": round(ach_moved / HBM_PEAK_GBPS, 4),
+                         "frac_moved_vs_this_box_read": (round(ach_moved / box["read_gbps"], 4) if box else None),
+                         "what": "`achieved`/`frac`: the reference's CSR bytes (12 B per stored entry + 20 B per row, SURVEY 8d) over "
+                                 "the kernel's average launch time; `achieved_moved`/`frac_moved`: the bytes this kernel must actually "
+                                 "move (row patterns leave no column stream: values + row pointers + descriptors + x once + y once)",
                          "timed_region_monotonic_ns": [mono0, mono1],
                          "this_box": box,
-                         "value_stream_placement": dict(blk.own_own.placement(), searches=placement_searches, what="allocations of the value stream timed with the "
-                                                        "bench's own x and y before the warm-up, fastest kept "
-                                                        "(pa_csr_tune_placement, PA_PLACEMENT_TRIES; DESIGN.md 3)")},
+                         "memory_classes": {"arena": ctx.arena(), "value_stream": blk.own_own.memory_class(),
+                                            "x": xv.memory_class(), "y": yv.memory_class(),
+                                            "what": "csrc/pa_arena.hip: matrix streams and vectors live in different memory classes "
+                                                    "of one contiguous arena (a write stream in its read stream's class costs 13-15 %)"}},
             "parity_gate": "A*1==b bit-exact; ghosts==owners bit-exact",
             "setup_s": round(t_setup, 1),
         }
+        if overlap:
+            out["overlap"] = overlap
         if vdict:
             out["value_dictionary_mode"] = vdict
         if cg:
@@ -405,11 +655,11 @@ def main():
                               "ms_per_iteration_ref_cg": round(cg["ref_cg"], 4),
                               "ms_per_iteration_opt_cg": round(cg["opt_cg"], 4),
                               "gflops_opt_cg": round(cg_flops / (cg["opt_cg"] * 1e-3) / 1e9, 1),
-                              "note": "opt_cg_ = same arithmetic (bit-identical iterates), scalars kept on the device"}
-        if N == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.cpu_n)
-            if cb:
-                out["cpu_baseline"] = cb
+                              "note": "opt_cg_ = scalars kept on the device, u'c accumulated inside the product kernel"}
+        if extras:
+            out["extra_configs"] = extras
+        if cpu:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if N > 1:
         dist.barrier()

@@ -70,6 +70,28 @@ int pa_ctx_destroy(pa_ctx *ctx);
 int pa_ctx_sync(pa_ctx *ctx);                        /* both streams */
 int pa_ctx_stream(pa_ctx *ctx, int which, void **hip_stream);
 int pa_ctx_device_info(pa_ctx *ctx, int *cus, int *xcds, size_t *hbm_bytes, char *name, size_t name_len);
+/* The comm stream is created with the device's greatest priority (numerically lowest), the compute stream with the
+ * least: the pack / RCCL send-recv / unpack kernels of t = consistent!(b) must get CUs while own x own (~300 k
+ * workgroups) is running, or the exchange of mul! (src/p_sparse_matrix.jl:2098-2100) is not hidden.  Any out-pointer
+ * may be NULL. */
+int pa_ctx_stream_priority(pa_ctx *ctx, int which, int *priority, int *least, int *greatest);
+
+/* ---- where the big arrays live: the context's HBM arena and its memory-class map (csrc/pa_arena.hip) ----------------
+ * Measured on MI355X: device memory falls into three classes (about a third each, physically contiguous regions of
+ * 2-96 GiB, boundaries differ from box to box); a product whose 64-byte write stream (y) sits in the class its read
+ * stream (the values) comes from runs 13-15 % slower than with y in either other class.  So a context keeps ONE
+ * physically contiguous arena (PA_ARENA_FRACTION of the free memory, default 0.70; PA_ARENA_GIB; PA_ARENA=0: none),
+ * maps its classes once with a stand-in kernel (~0.2 s, when the first allocation >= PA_ARENA_MIN_MIB = 256 arrives)
+ * and serves every buffer >= 1 MiB from it by rule: matrix streams (pa_csr_create*) from class 0, vectors
+ * (pa_vec_create) from classes 1 / 2.  Nothing is timed at the caller's expense and nothing ever moves.
+ * pa_ctx_arena_info: size, number of classes found (1: no structure seen), usable bytes per class, bytes in use, map time.
+ * pa_ctx_arena_map: class of every cell (-1: a boundary runs through it).  pa_ctx_arena_build forces the set-up now.
+ * pa_csr_memory_class / pa_vec_memory_class: class of a block's value stream / a vector's storage (-1: outside). */
+int pa_ctx_arena_build(pa_ctx *ctx);
+int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class_bytes[3], int64_t *used, double *map_ms);
+int pa_ctx_arena_map(pa_ctx *ctx, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells);
+int pa_csr_memory_class(const pa_csr *A, int *cls);
+int pa_vec_memory_class(const pa_vec *v, int *cls);
 
 /* ---- events / timing (replaces PTimer, src/p_timer.jl; HIP events on the launching stream) --- */
 int pa_event_create(pa_ctx *ctx, pa_event **ev);
@@ -148,19 +170,11 @@ int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern_chunks, int64_t *n_c16_c
  * A block whose chunks are described by row patterns keeps no columns for them: a stencil operator costs ~8 bytes per
  * stored entry, a block on the 16-bit stream ~14 (8 + 4 + 2). */
 int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes);
-/* Placement of the value stream and of the result vector, chosen by measurement (optional; never changes a result).
- * On most MI355X boxes the product kernel's time depends on WHICH allocations hold the value stream and y (0.67 ... 0.82
- * ms for the 27-point 256^3 operator: same kernel, same data; a pure (values, y) interaction, x plays no part; stable
- * for given allocations).  pa_csr_tune_placement times y = A*x with the caller's x on up to `tries`
- * copies of A's values (of their one-byte codes when the block has a value dictionary), each against up to 6 allocations for y, in rounds of 4 copies, and keeps the fastest pair; the
- * rest is freed (transient HBM: 4 x the value stream + 5 x y, never more than half of what is free).
- *   - y is overwritten with A*x.  If the library owns y's storage (pa_vec_create) and A is one slab, the storage MAY MOVE
- *     to another allocation (same content, same handle): device pointers obtained through pa_vec_data before the call,
- *     and hipGraphs captured with y, are invalid afterwards.  PA_PLACEMENT_MOVE_Y=0 in the environment keeps y in place.
- *   - x and y must be different vectors.  Slabs under 8 M stored entries are left alone.
- * pa_csr_placement reports what happened: value copies timed (0: not tuned), ms per product before and after. */
-int pa_csr_tune_placement(pa_csr *A, const pa_vec *x, int x_segment, pa_vec *y, int y_segment, int tries);
-int pa_csr_placement(const pa_csr *A, int *candidates, double *first_ms, double *kept_ms);
+/* Bytes one product must READ from the block (each once): values, row pointers, chunk table and, per chunk, whatever
+ * gives it its columns (pattern descriptor / window table + 16-bit stream / 32-bit columns).  Plus x once and y once
+ * this is the compulsory HBM traffic of pa_spmv -- bench.py's `roofline.moved_bytes_per_launch` -- as opposed to the
+ * reference's CSR bytes (12 per stored entry) `roofline.achieved` is quoted on. */
+int pa_csr_stream_bytes(const pa_csr *A, int64_t *bytes);
 /* Optional, lossless: with PA_SPMV_VALUE_DICT=1 in the environment at creation, a block whose stored values take at most
  * 64 distinct bit patterns (27-point HPCG: 2; Q1 stiffness on a uniform grid: about a dozen) also keeps one byte per
  * entry and the kernels stream that instead of the 8-byte values -- same values, same products, same order, same bits.
@@ -309,6 +323,9 @@ int pa_comm_destroy(pa_comm *comm);
 /* reduction(+,…;destination=:all) of device doubles (src/mpi_array.jl:494): in place, given stream */
 int pa_comm_allreduce_sum(pa_comm *comm, void *device_ptr, int64_t count, int which_stream);
 int pa_comm_barrier(pa_comm *comm);
+/* What the communicator itself reports (ncclCommUserRank / ncclCommCount): MPI.Comm_rank / Comm_size,
+ * src/mpi_array.jl:51-53.  bench.py prints nranks as `rccl_ranks_seen`. */
+int pa_comm_info(pa_comm *comm, int *rank, int *nranks);
 
 /* ---- host-side set-up helpers (native twins of the reference's set-up loops) ----------------- */
 /* All ids 1-based Int64/Int32 exactly as the reference stores them. */

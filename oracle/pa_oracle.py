@@ -98,7 +98,7 @@ def local_range(p, np_, n, ghost=False, periodic=False):
     if rem >= (np_ - p + 1):
         l += 1
         offset += p - (np_ - rem) - 1
-    g = 1 if ghost else 0
+    g = int(ghost)                       # a number of ghost layers: `start = 1+offset-ghost` (:813)
     start = 1 + offset - g
     stop = l + offset + g
     if periodic:
@@ -142,11 +142,12 @@ class Indices:
     ranges: tuple = ()                # own box ((lo,hi),...) inclusive, block partitions only
     starts: tuple = ()                # per-dim block starts (+ n+1), for find_owner
     cache: dict = field(default_factory=dict)   # AssemblyCache, src/p_range.jl:354-359
+    is_own: object = None             # own flags when the constructor decides them by the own box (src/p_range.jl:650-665)
 
     def __post_init__(self):
         self.local_to_global = np.asarray(self.local_to_global, dtype=I64)
         self.local_to_owner = np.asarray(self.local_to_owner, dtype=I32)
-        own = self.local_to_owner == self.part
+        own = self.local_to_owner == self.part if self.is_own is None else np.asarray(self.is_own, dtype=bool)
         # src/p_range.jl:1121-1128 (findall; perm)
         self.own_to_local = (np.nonzero(own)[0] + 1).astype(I32)
         self.ghost_to_local = (np.nonzero(~own)[0] + 1).astype(I32)
@@ -266,20 +267,21 @@ def uniform_partition(np_, n, ghost=None, periodic=None):
                     break
             owners.append(my)
         lens = [hi - lo + 1 for lo, hi in local_ranges]
-        l2g, l2o = [], []
+        l2g, l2o, own_flags = [], [], []
         for ci0 in itertools.product(*[range(L) for L in reversed(lens)]):
             ci = tuple(reversed(ci0))                         # column-major enumeration (:648)
             is_own = all(own_ranges[d][0] <= local_ranges[d][0] + ci[d] <= own_ranges[d][1]
                          for d in range(len(n)))
             gci = tuple(((local_ranges[d][0] + ci[d] - 1) % n[d]) + 1 for d in range(len(n)))  # CircularArray
             l2g.append(_linear(gci, n))
+            own_flags.append(is_own)     # a wrapped copy of an own id (periodic, one part in that direction) stays a ghost
             if is_own:
                 l2o.append(rank)
             else:
                 o = tuple(owners[d][ci[d]] for d in range(len(n)))
                 l2o.append(_linear(o, np_))
         ind = Indices(int(np.prod(n)), rank, np.array(l2g, I64), np.array(l2o, I32),
-                      "block-permuted", np_, n, own_ranges, starts)
+                      "block-permuted", np_, n, own_ranges, starts, is_own=np.array(own_flags, bool))
         parts.append(ind)
     if ghost is not None:
         assembly_neighbors(parts, symmetric=True)             # src/p_range.jl:596

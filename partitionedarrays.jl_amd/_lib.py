@@ -46,6 +46,7 @@ _SIGS = {
     "pa_ctx_sync": [P],
     "pa_ctx_stream": [P, cint, PP],
     "pa_ctx_device_info": [P, C.POINTER(cint), C.POINTER(cint), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t],
+    "pa_ctx_stream_priority": [P, cint, C.POINTER(cint), C.POINTER(cint), C.POINTER(cint)],
     "pa_event_create": [P, PP],
     "pa_event_destroy": [P],
     "pa_event_record": [P, cint],
@@ -81,8 +82,12 @@ _SIGS = {
     "pa_csr_create": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_value_dict": [P, C.POINTER(cint)],
     "pa_csr_device_bytes": [P, C.POINTER(i64)],
-    "pa_csr_placement": [P, C.POINTER(cint), C.POINTER(f64), C.POINTER(f64)],
-    "pa_csr_tune_placement": [P, P, cint, P, cint, cint],
+    "pa_csr_stream_bytes": [P, C.POINTER(i64)],
+    "pa_ctx_arena_build": [P],
+    "pa_ctx_arena_info": [P, C.POINTER(i64), C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(f64)],
+    "pa_ctx_arena_map": [P, C.POINTER(i64), P, i64, C.POINTER(i64)],
+    "pa_csr_memory_class": [P, C.POINTER(cint)],
+    "pa_vec_memory_class": [P, C.POINTER(cint)],
     "pa_csr_create_mixed": [P, i64, i64, i64, P, cint, P, cint, cint, P, PP],
     "pa_csr_create_from_csc": [P, i64, i64, i64, P, P, cint, cint, P, PP],
     "pa_csr_update_values": [P, P],
@@ -121,6 +126,7 @@ _SIGS = {
     "pa_comm_destroy": [P],
     "pa_comm_allreduce_sum": [P, P, i64, cint],
     "pa_comm_barrier": [P],
+    "pa_comm_info": [P, C.POINTER(cint), C.POINTER(cint)],
     "pa_host_hpcg_build_matrix": [i64] * 9 + [P, P, P, P, P, C.POINTER(i64)],
     "pa_host_laplacian_fdm": [i32, P, P, P, P, P, P, C.POINTER(i64)],
     "pa_host_find_owner_block": [i32, P, P, PP, P, i64, P],

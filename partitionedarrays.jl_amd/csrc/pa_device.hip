@@ -68,7 +68,7 @@ extern "C" int pa_device_count(int *count) {
 // ------------------------------------------------------------------------------------------------
 #include "pa_spmv_kernel.h"
 
-// shipped configuration of the row-split kernel (chosen with probe/spmv_probe.hip on MI355X)
+// shipped configuration of the row-split kernel (chosen with tools/probe/spmv_probe.hip on MI355X)
 constexpr int SPMV_BLK = 256;
 constexpr int SPMV_NPT = PA_SPMV_CHUNK_NNZ / SPMV_BLK;  // stored entries per lane (6)
 constexpr bool SPMV_NT = true;
@@ -271,8 +271,14 @@ extern "C" int pa_ctx_create(int device, pa_ctx **out) {
   PA_HIP(hipSetDevice(device));
   pa_ctx *c = new pa_ctx();
   c->device = device;
-  PA_HIP(hipStreamCreateWithFlags(&c->s[0], hipStreamNonBlocking));
-  PA_HIP(hipStreamCreateWithFlags(&c->s[1], hipStreamNonBlocking));
+  // The comm stream gets the highest priority the device offers: own x own puts ~300 k workgroups in front of the
+  // dispatcher, and the pack kernel, RCCL's send/recv kernels and the unpack have to get CUs while it runs or the
+  // exchange does not hide under it (mul!: src/p_sparse_matrix.jl:2098-2100).  Numerically lower = higher priority.
+  int prio_least = 0, prio_greatest = 0;
+  PA_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+  c->comm_priority = prio_greatest;
+  PA_HIP(hipStreamCreateWithPriority(&c->s[0], hipStreamNonBlocking, prio_least));
+  PA_HIP(hipStreamCreateWithPriority(&c->s[1], hipStreamNonBlocking, prio_greatest));
   PA_HIP(hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming));
   hipDeviceProp_t prop;
   PA_HIP(hipGetDeviceProperties(&prop, device));
@@ -296,6 +302,7 @@ extern "C" int pa_ctx_destroy(pa_ctx *c) {
   (void)hipStreamSynchronize(c->s[1]);
   (void)hipFree(c->d_partials);
   (void)hipFree(c->d_scalar);
+  pa_arena_destroy(c);
   (void)hipEventDestroy(c->ev_compute);
   (void)hipStreamDestroy(c->s[0]);
   (void)hipStreamDestroy(c->s[1]);
@@ -314,6 +321,18 @@ extern "C" int pa_ctx_sync(pa_ctx *c) {
 extern "C" int pa_ctx_stream(pa_ctx *c, int which, void **s) {
   PA_REQUIRE(c && s && (which == 0 || which == 1), "bad arguments");
   *s = (void *)c->s[which];
+  return PA_OK;
+}
+
+extern "C" int pa_ctx_stream_priority(pa_ctx *c, int which, int *priority, int *least, int *greatest) {
+  PA_REQUIRE(c && (which == 0 || which == 1), "bad arguments");
+  PA_HIP(hipSetDevice(c->device));
+  int lo = 0, hi = 0, pr = 0;
+  PA_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  PA_HIP(hipStreamGetPriority(c->s[which], &pr));
+  if (priority) *priority = pr;
+  if (least) *least = lo;
+  if (greatest) *greatest = hi;
   return PA_OK;
 }
 
@@ -376,7 +395,7 @@ extern "C" int pa_vec_create(pa_ctx *c, int64_t n_own, int64_t n_ghost, pa_vec *
   pa_vec *v = new pa_vec();
   v->ctx = c; v->n_own = n_own; v->n_ghost = n_ghost; v->owned = true;
   const size_t bytes = sizeof(double) * (size_t)(n_own + n_ghost + 2);
-  PA_HIP(hipMalloc(&v->d, bytes));
+  PA_TRY(pa_dev_alloc(c, (void **)&v->d, bytes, PA_MEM_VECTOR));   // a memory class no matrix stream lives in (pa_arena.hip)
   PA_HIP(hipMemsetAsync(v->d, 0, bytes, c->s[0]));
   *out = v;
   return PA_OK;
@@ -396,7 +415,7 @@ extern "C" int pa_vec_destroy(pa_vec *v) {
     (void)hipSetDevice(v->ctx->device);
     (void)hipStreamSynchronize(v->ctx->s[0]);
     (void)hipStreamSynchronize(v->ctx->s[1]);
-    (void)hipFree(v->d);
+    pa_dev_free(v->ctx, v->d);
   }
   delete v;
   return PA_OK;
@@ -643,10 +662,17 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   A->n_pattern_chunks = cs.n_pattern; A->n_c16_chunks = cs.n_c16; A->n_c32_chunks = cs.n_c32;
   A->n_c16_fallback = cs.use_c16 ? A->n_chunks - cs.n_pattern - cs.n_c16 : 0;
   A->n_col32 = cs.full ? nnz : (int64_t)cs.c32.size() - (int64_t)pad;
-  PA_HIP(hipMalloc(&A->d_crp, sizeof(int32_t) * (nc + 1)));
-  PA_HIP(hipMalloc(&A->d_col, sizeof(int32_t) * (A->n_col32 + pad)));
-  PA_HIP(hipMalloc(&A->d_val, sizeof(double) * (nnz + pad)));
-  PA_HIP(hipMalloc(&A->d_chunk_row, sizeof(int32_t) * chunk_row.size()));
+  for (int64_t ch = 0; ch < A->n_chunks; ++ch) {           // stored entries by the column encoding their chunk reads
+    const int64_t ne = (int64_t)crp[chunk_row[ch + 1]] - crp[chunk_row[ch]];
+    if (cs.use_pattern && cs.pdesc[(size_t)ch * PA_PDESC_INTS] > 0) continue;
+    if (cs.use_c16 && cs.win[(size_t)ch * PA_C16_WINDOWS] >= 0 && ne + (crp[chunk_row[ch]] & 1) <= PA_SPMV_CHUNK_NNZ) A->nnz_c16 += ne;
+    else A->nnz_c32 += ne;
+  }
+  // (the value stream first: it is the allocation that brings the context's arena into being, pa_arena.hip)
+  PA_TRY(pa_dev_alloc(c, (void **)&A->d_val, sizeof(double) * (nnz + pad), PA_MEM_MATRIX));
+  PA_TRY(pa_dev_alloc(c, (void **)&A->d_crp, sizeof(int32_t) * (nc + 1), PA_MEM_MATRIX));
+  PA_TRY(pa_dev_alloc(c, (void **)&A->d_col, sizeof(int32_t) * (A->n_col32 + pad), PA_MEM_MATRIX));
+  PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_row, sizeof(int32_t) * chunk_row.size(), PA_MEM_MATRIX));
   PA_HIP(hipMemset(A->d_col + A->n_col32, 0, sizeof(int32_t) * pad));
   PA_HIP(hipMemset(A->d_val + nnz, 0, sizeof(double) * pad));
   PA_HIP(hipMemcpy(A->d_crp, crp.data(), sizeof(int32_t) * (nc + 1), hipMemcpyHostToDevice));
@@ -658,21 +684,21 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   PA_HIP(hipMemcpy(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size(), hipMemcpyHostToDevice));
   if (cs.use_c16) {
     A->n_col16 = (int64_t)cs.c16.size();
-    PA_HIP(hipMalloc(&A->d_col16, sizeof(uint16_t) * cs.c16.size()));
-    PA_HIP(hipMalloc(&A->d_win, sizeof(int32_t) * std::max<size_t>(1, cs.win.size())));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_col16, sizeof(uint16_t) * cs.c16.size(), PA_MEM_MATRIX));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_win, sizeof(int32_t) * std::max<size_t>(1, cs.win.size()), PA_MEM_MATRIX));
     PA_HIP(hipMemcpy(A->d_col16, cs.c16.data(), sizeof(uint16_t) * cs.c16.size(), hipMemcpyHostToDevice));
     if (!cs.win.empty()) PA_HIP(hipMemcpy(A->d_win, cs.win.data(), sizeof(int32_t) * cs.win.size(), hipMemcpyHostToDevice));
   }
   if (cs.use_pattern) {
-    PA_HIP(hipMalloc(&A->d_pdesc, sizeof(int32_t) * cs.pdesc.size()));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_pdesc, sizeof(int32_t) * cs.pdesc.size(), PA_MEM_MATRIX));
     A->n_pdelta = (int64_t)cs.pdelta.size();
-    PA_HIP(hipMalloc(&A->d_pdelta, sizeof(int32_t) * cs.pdelta.size()));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_pdelta, sizeof(int32_t) * cs.pdelta.size(), PA_MEM_MATRIX));
     PA_HIP(hipMemcpy(A->d_pdesc, cs.pdesc.data(), sizeof(int32_t) * cs.pdesc.size(), hipMemcpyHostToDevice));
     PA_HIP(hipMemcpy(A->d_pdelta, cs.pdelta.data(), sizeof(int32_t) * cs.pdelta.size(), hipMemcpyHostToDevice));
   }
   lap("upload");
-  if (tm_) fprintf(stderr, "[pa setup] val %p (%lld B) col %p crp %p chunk_row %p pdesc %p\n", (void *)A->d_val, (long long)(8 * (nnz + pad)),
-                   (void *)A->d_col, (void *)A->d_crp, (void *)A->d_chunk_row, (void *)A->d_pdesc);
+  if (tm_) fprintf(stderr, "[pa setup] val %p (%lld B, memory class %d) col %p crp %p chunk_row %p pdesc %p\n", (void *)A->d_val,
+                   (long long)(8 * (nnz + pad)), pa_mem_class(c, A->d_val), (void *)A->d_col, (void *)A->d_crp, (void *)A->d_chunk_row, (void *)A->d_pdesc);
   // optional lossless value dictionary (PA_SPMV_VALUE_DICT=1): at most PA_VDICT_MAX distinct bit patterns
   {
     const char *e = getenv("PA_SPMV_VALUE_DICT");
@@ -729,8 +755,8 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
         }
         std::vector<double> dv(PA_VDICT_MAX, 0.0);
         memcpy(dv.data(), dict.data(), 8 * dict.size());
-        PA_HIP(hipMalloc(&A->d_code, nnz + pad));
-        PA_HIP(hipMalloc(&A->d_dict, sizeof(double) * PA_VDICT_MAX));
+        PA_TRY(pa_dev_alloc(c, (void **)&A->d_code, nnz + pad, PA_MEM_MATRIX));
+        PA_TRY(pa_dev_alloc(c, (void **)&A->d_dict, sizeof(double) * PA_VDICT_MAX, PA_MEM_MATRIX));
         PA_HIP(hipMemcpy(A->d_code, code.data(), nnz + pad, hipMemcpyHostToDevice));
         PA_HIP(hipMemcpy(A->d_dict, dv.data(), sizeof(double) * PA_VDICT_MAX, hipMemcpyHostToDevice));
         A->use_vdict = true;
@@ -739,7 +765,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
     }
   }
   if (compact) {
-    PA_HIP(hipMalloc(&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc)));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc), PA_MEM_MATRIX));
     if (nc) PA_HIP(hipMemcpy(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice));
   }
   *out = A;
@@ -904,17 +930,17 @@ extern "C" int pa_csr_update_values_from(pa_csr *A, const pa_vec *src, int64_t o
 static void csr_free_chain(pa_csr *A) {
   while (A) {
     pa_csr *n = A->next;
-    (void)hipFree(A->d_crp);
-    (void)hipFree(A->d_col);
-    (void)hipFree(A->d_val);
-    (void)hipFree(A->d_chunk_row);
-    if (A->d_row_ids) (void)hipFree(A->d_row_ids);
-    if (A->d_col16) (void)hipFree(A->d_col16);
-    if (A->d_win) (void)hipFree(A->d_win);
-    if (A->d_pdesc) (void)hipFree(A->d_pdesc);
-    if (A->d_pdelta) (void)hipFree(A->d_pdelta);
-    if (A->d_code) (void)hipFree(A->d_code);
-    if (A->d_dict) (void)hipFree(A->d_dict);
+    pa_dev_free(A->ctx, A->d_crp);
+    pa_dev_free(A->ctx, A->d_col);
+    pa_dev_free(A->ctx, A->d_val);
+    pa_dev_free(A->ctx, A->d_chunk_row);
+    if (A->d_row_ids) pa_dev_free(A->ctx, A->d_row_ids);
+    if (A->d_col16) pa_dev_free(A->ctx, A->d_col16);
+    if (A->d_win) pa_dev_free(A->ctx, A->d_win);
+    if (A->d_pdesc) pa_dev_free(A->ctx, A->d_pdesc);
+    if (A->d_pdelta) pa_dev_free(A->ctx, A->d_pdelta);
+    if (A->d_code) pa_dev_free(A->ctx, A->d_code);
+    if (A->d_dict) pa_dev_free(A->ctx, A->d_dict);
     delete A;
     A = n;
   }
@@ -1048,14 +1074,34 @@ extern "C" int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes) {
   return PA_OK;
 }
 
-extern "C" int pa_csr_placement(const pa_csr *A, int *candidates, double *first_ms, double *kept_ms) {
-  PA_REQUIRE(A && candidates && first_ms && kept_ms, "bad arguments");
-  *candidates = 0; *first_ms = 0; *kept_ms = 0;
-  for (const pa_csr *S = A; S; S = S->next) {          // slabs: candidates of the largest, times summed
-    *candidates = std::max(*candidates, S->placement_tries);
-    *first_ms += S->placement_first_ms;
-    *kept_ms += S->placement_best_ms;
+// Bytes one product MUST read from the block's own storage (each exactly once): values, the row pointers, the chunk
+// table, and per chunk whatever gives it its columns -- a pattern descriptor (no column stream), the window table + the
+// 16-bit stream, or 32-bit columns.  With x read once and y written once this is the compulsory HBM traffic of pa_spmv
+// ("moved bytes"), as opposed to the reference's CSR bytes (12 per stored entry) the SURVEY's roofline is quoted on.
+extern "C" int pa_csr_stream_bytes(const pa_csr *A, int64_t *bytes) {
+  PA_REQUIRE(A && bytes, "bad arguments");
+  int64_t t = 0;
+  for (const pa_csr *S = A; S; S = S->next) {
+    t += (S->use_vdict ? 1 : 8) * S->nnz + 4 * (S->n_crows + 1) + 4 * (S->n_chunks + 1);
+    if (S->use_vdict) t += 8 * PA_VDICT_MAX;
+    if (S->use_pattern) t += 4 * S->n_chunks * PA_PDESC_INTS + 4 * S->n_pdelta;
+    if (S->use_c16) t += 4 * (S->n_chunks - S->n_pattern_chunks) * PA_C16_WINDOWS;
+    t += 2 * S->nnz_c16 + 4 * S->nnz_c32;
+    if (S->compact) t += 4 * S->n_crows;
   }
+  *bytes = t;
+  return PA_OK;
+}
+
+extern "C" int pa_csr_memory_class(const pa_csr *A, int *cls) {
+  PA_REQUIRE(A && cls, "bad arguments");
+  *cls = pa_mem_class(A->ctx, A->d_val);
+  return PA_OK;
+}
+
+extern "C" int pa_vec_memory_class(const pa_vec *v, int *cls) {
+  PA_REQUIRE(v && cls, "bad arguments");
+  *cls = pa_mem_class(v->ctx, v->d);
   return PA_OK;
 }
 
@@ -1104,178 +1150,6 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
       }
 #undef PA_LAUNCH_SPMV
   }
-}
-
-// Placement of the value stream and of the result vector, chosen by measurement.  On most MI355X boxes the SAME kernel
-// on the SAME data runs at 0.67 ... 0.82 ms (27-point 256^3) depending on WHICH ALLOCATIONS hold the value stream and
-// y: the copies x (x,y)-pairs matrix of csrc/probe/placement_probe.hip shows a pure (values, y) interaction -- x plays
-// no part, y allocations fall into two classes, and a value allocation is fast with one class only (or with none).  It
-// is stable for given allocations, unrelated to virtual addresses or their alignment, invisible in TLB, L2 and request
-// counters, and the fast pairs run exactly as fast as the kernel without its y store: the read stream and the
-// 64-byte write stream interfere in the memory system, or do not, depending on physical placement.
-// Physical placement is not ours to choose, so it is chosen by measurement: rounds of up to 4 more copies of the
-// values and up to 5 more allocations for y, every pair timed with the caller's x; the fastest pair is kept, the rest
-// freed, and -- since freeing large allocations can itself shift the times -- the kept pair competes again in the next
-// round.  The result vector's storage moves only when the library owns it (pa_vec_create) and the block is one slab.
-static int tune_placement(pa_csr *S, const double *xs, pa_vec *y, int64_t yoff, int tries) {
-  pa_ctx *c = S->ctx;
-  if (tries < 2 || S->nnz < ((int64_t)8 << 20) || S->n_chunks < 1 || c->capturing) return PA_OK;
-  // the stream the kernel reads per stored entry: the fp64 values, or their one-byte codes when the block has a value
-  // dictionary (the values then stay where they are: only pa_csr_update_values touches them)
-  const bool vd = S->use_vdict;
-  const size_t pad = 8, vbytes = vd ? (size_t)(S->nnz + pad) : sizeof(double) * (S->nnz + pad);
-  auto stream = [&]() -> void * { return vd ? (void *)S->d_code : (void *)S->d_val; };
-  auto set_stream = [&](void *q) { if (vd) S->d_code = (uint8_t *)q; else S->d_val = (double *)q; };
-  const size_t ybytes = sizeof(double) * (size_t)(y->n_own + y->n_ghost + 2);
-  const char *em = getenv("PA_PLACEMENT_MOVE_Y");
-  const bool move_y = y->owned && S->next == nullptr && S->row0 == 0 && !(em && atoi(em) == 0);
-  hipEvent_t e0, e1;
-  PA_HIP(hipEventCreate(&e0));
-  PA_HIP(hipEventCreate(&e1));
-  const bool verbose = getenv("PA_SETUP_TIMING") != nullptr;
-  const auto t_begin = std::chrono::steady_clock::now();
-  double *ycur = y->d;                                        // where the result goes at the moment (y->d itself until the end)
-  auto time_pair = [&](void *val, double *yb, float *ms_out) -> int {   // average of 3 launches after one untimed launch
-    set_stream(val);
-    spmv_launch_slab(S, xs, yb + yoff, 1.0, 0.0);
-    PA_HIP(hipEventRecord(e0, c->s[0]));
-    for (int r = 0; r < 3; ++r) spmv_launch_slab(S, xs, yb + yoff, 1.0, 0.0);
-    PA_HIP(hipEventRecord(e1, c->s[0]));
-    PA_HIP(hipEventSynchronize(e1));
-    PA_HIP(hipEventElapsedTime(ms_out, e0, e1));
-    *ms_out /= 3;
-    return PA_OK;
-  };
-  for (int w = 0; w < 6; ++w) spmv_launch_slab(S, xs, ycur + yoff, 1.0, 0.0);   // clocks up before anything is compared
-  float first = 0, now = 0;
-  std::vector<float> all_ms;                                  // every pair's time: their median is what an ordinary pair costs
-  PA_TRY(time_pair(stream(), ycur, &first));
-  now = first;
-  int timed = 1;
-  int budget = tries;
-  for (int pass = 0; pass < 2; ++pass) {                      // rounds, then the ladder; if the ladder moved y, one more round on it
-  bool ladder_moved = false;
-  while (timed < budget) {
-    size_t free_b = 0, total_b = 0;
-    PA_HIP(hipMemGetInfo(&free_b, &total_b));
-    int k = std::min(4, tries - timed);
-    while (k > 0 && (size_t)k * vbytes + 5 * ybytes > free_b / 2) --k;          // never more than half of what is free
-    if (k < 1) break;
-    std::vector<void *> vals(1, stream());
-    std::vector<double *> ys(1, ycur);
-    // result allocations and value copies alternate: the classes are ranges of device memory several GiB long
-    // (DESIGN.md section 3), so the y candidates should be spread, not adjacent
-    for (int t = 0; t <= k; ++t) {
-      double *v = nullptr;
-      if (move_y && (int)ys.size() < 6) {
-        if (hipMalloc(&v, ybytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        ys.push_back(v);
-      }
-      if (t == k) break;
-      void *q = nullptr;
-      if (hipMalloc(&q, vbytes) != hipSuccess) { (void)hipGetLastError(); break; }
-      PA_HIP(hipMemcpyAsync(q, vals[0], vbytes, hipMemcpyDeviceToDevice, c->s[0]));
-      vals.push_back(q);
-    }
-    if (vals.size() * ys.size() < 2) break;
-    size_t bi = 0, bj = 0;
-    float best = 1e30f;
-    std::vector<float> row_best(vals.size(), 1e30f);
-    for (size_t i = 0; i < vals.size(); ++i)
-      for (size_t j = 0; j < ys.size(); ++j) {
-        float ms = 0;
-        PA_TRY(time_pair(vals[i], ys[j], &ms));
-        row_best[i] = std::min(row_best[i], ms);
-        all_ms.push_back(ms);
-        if (ms < best) { best = ms; bi = i; bj = j; }
-      }
-    timed += (int)vals.size() - 1;
-    for (size_t i = 0; i < vals.size(); ++i)
-      if (i != bi) (void)hipFree(vals[i]);
-    for (size_t j = 0; j < ys.size(); ++j)
-      if (j != bj && ys[j] != y->d) (void)hipFree(ys[j]);      // (the vector's own storage goes only once its content is moved)
-    ycur = ys[bj];
-    PA_TRY(time_pair(vals[bi], ycur, &now));
-    if (verbose) {
-      fprintf(stderr, "[pa setup] placement round (%zu value copies x %zu result allocations), best per value copy:", vals.size(), ys.size());
-      for (float t : row_best) fprintf(stderr, " %.4f", t);
-      fprintf(stderr, " ms -> kept (#%zu, y #%zu), %.4f ms once the others are freed\n", bi, bj, now);
-    }
-  }
-  // No fast pair among the candidates (the kept one is within 6 % of the median)?  Then walk y alone down the device
-  // memory: up to 48 rungs of [spacer | y candidate] one GiB apart, each timed against the kept value copy -- the classes
-  // are ranges many GiB long and most value copies have a fast one somewhere (the range map).
-  if (move_y && all_ms.size() >= 4) {
-    std::vector<float> sorted(all_ms);
-    std::nth_element(sorted.begin(), sorted.begin() + sorted.size() / 2, sorted.end());
-    const float median = sorted[sorted.size() / 2];
-    if (now > 0.94f * median) {
-      const size_t rung = (size_t)1 << 30;
-      size_t free_b = 0, total_b = 0;
-      PA_HIP(hipMemGetInfo(&free_b, &total_b));
-      const int rungs = (int)std::min<size_t>(48, free_b / 2 / rung);
-      std::vector<void *> spacers;
-      std::vector<double *> ys;
-      double *ybest = nullptr;
-      float tbest = 0.97f * now;                               // (a rung has to beat the kept pair by 3 % to count)
-      for (int j = 0; j < rungs; ++j) {
-        void *sp = nullptr;
-        double *yc = nullptr;
-        if (rung > ybytes && hipMalloc(&sp, rung - ybytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        if (sp) spacers.push_back(sp);
-        if (hipMalloc(&yc, ybytes) != hipSuccess) { (void)hipGetLastError(); break; }
-        ys.push_back(yc);
-        float ms = 0;
-        PA_TRY(time_pair(stream(), yc, &ms));
-        if (ms < tbest) { tbest = ms; ybest = yc; }
-        if (ms < 0.93f * median) break;                       // a fast range: stop here
-      }
-      for (void *q : spacers) (void)hipFree(q);
-      for (double *q : ys)
-        if (q != ybest) (void)hipFree(q);
-      if (ybest) {
-        if (ycur != y->d) (void)hipFree(ycur);
-        ycur = ybest;
-        ladder_moved = true;
-      }
-      PA_TRY(time_pair(stream(), ycur, &now));
-      if (verbose) fprintf(stderr, "[pa setup] placement ladder: %zu rungs, best %.4f ms (median of the pairs %.4f), %.4f ms once the rest is freed\n",
-                           ys.size(), tbest, median, now);
-    }
-  }
-  if (!ladder_moved) break;
-  budget = timed + 4;                                         // four more value copies against the y the ladder found
-  }
-  if (ycur != y->d) {                                         // the vector moves: same content, new allocation
-    PA_HIP(hipMemsetAsync(ycur + (y->n_own + y->n_ghost), 0, 2 * sizeof(double), c->s[0]));
-    PA_HIP(hipMemcpyAsync(ycur, y->d, sizeof(double) * (size_t)(y->n_own + y->n_ghost), hipMemcpyDeviceToDevice, c->s[0]));
-    PA_HIP(hipStreamSynchronize(c->s[0]));
-    (void)hipFree(y->d);
-    y->d = ycur;
-  }
-  spmv_launch_slab(S, xs, y->d + yoff, 1.0, 0.0);             // y = A*x, as documented
-  PA_HIP(hipGetLastError());
-  S->placement_tries = timed;
-  S->placement_first_ms = first;
-  S->placement_best_ms = now;
-  if (verbose) fprintf(stderr, "[pa setup] placement took %.2f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return PA_OK;
-}
-
-extern "C" int pa_csr_tune_placement(pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int yseg, int tries) {
-  PA_REQUIRE(A && x && y, "bad arguments");
-  int64_t xoff, xlen, yoff, ylen;
-  PA_TRY(seg_range(x, xseg, &xoff, &xlen));
-  PA_TRY(seg_range(y, yseg, &yoff, &ylen));
-  PA_REQUIRE(ylen == A->t_rows, "length(b)=%lld != size(A,1)=%lld", (long long)ylen, (long long)A->t_rows);
-  PA_REQUIRE(xlen == A->n_cols, "length(x)=%lld != size(A,2)=%lld", (long long)xlen, (long long)A->n_cols);
-  PA_REQUIRE(x->d != y->d, "x and y are the same vector");
-  PA_HIP(hipSetDevice(A->ctx->device));
-  PA_HIP(hipStreamSynchronize(A->ctx->s[1]));          // nothing in flight may still use y's storage: it can move
-  PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
-  for (pa_csr *S = A; S; S = S->next) PA_TRY(tune_placement(S, x->d + xoff, y, yoff + S->row0, tries));
-  return PA_OK;
 }
 
 extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int yseg, double alpha, double beta) {

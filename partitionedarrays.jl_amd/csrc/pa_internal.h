@@ -35,6 +35,8 @@ void pa_set_err(const char *fmt, ...);
     if (pa_s_ != PA_OK) return pa_s_; \
   } while (0)
 
+struct pa_arena;
+
 struct pa_ctx {
   int device = 0;
   hipStream_t s[2] = {nullptr, nullptr};  // [0] compute, [1] comm
@@ -46,7 +48,20 @@ struct pa_ctx {
   int n_partials = 0;
   double *d_scalar = nullptr;
   bool capturing = false;                 // a pa_graph_begin is open on the compute stream
+  int comm_priority = 0;                  // priority the comm stream was created with (the device's greatest)
+  pa_arena *arena = nullptr;              // contiguous HBM arena with its memory-class map (pa_arena.hip), built lazily
+  bool arena_tried = false;
 };
+
+// Device memory of a context (pa_arena.hip).  kind says what the buffer is FOR, which decides its memory class:
+// matrix streams and vectors never share one (a product's write stream must not sit in its read stream's class).
+#define PA_MEM_PLAIN 0    /* hipMalloc */
+#define PA_MEM_MATRIX 1   /* streamed by the product kernels: values, columns, row pointers, descriptors */
+#define PA_MEM_VECTOR 2   /* local values of a PVector */
+int pa_dev_alloc(pa_ctx *c, void **p, size_t bytes, int kind);
+void pa_dev_free(pa_ctx *c, void *p);
+int pa_mem_class(const pa_ctx *c, const void *p);    // 0..2, or -1 outside the arena
+void pa_arena_destroy(pa_ctx *c);
 
 struct pa_event {
   pa_ctx *ctx = nullptr;
@@ -74,8 +89,7 @@ struct pa_csr {
   int64_t n_c16_fallback = 0;      // chunks that keep 32-bit columns
   int64_t n_c16_chunks = 0, n_c32_chunks = 0;   // chunks by column encoding (with n_pattern_chunks: all of them)
   int64_t n_pdelta = 0;
-  int placement_tries = 0;                      // value-stream placement chosen by measurement (tune_value_placement)
-  float placement_first_ms = 0, placement_best_ms = 0;
+  int64_t nnz_c16 = 0, nnz_c32 = 0;             // stored entries whose chunk reads the 16-bit stream / 32-bit columns
   int64_t n_col32 = 0, n_col16 = 0;             // entries held in d_col / d_col16 (compacted when the block has row patterns)
   uint16_t *d_col16 = nullptr;     // (slot << 12) | (col & 4095), padded
   int32_t *d_win = nullptr;        // n_chunks * 16 window bases; [c*16] < 0 => 32-bit chunk

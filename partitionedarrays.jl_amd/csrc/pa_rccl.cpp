@@ -25,6 +25,8 @@ struct Api {
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   bool ok = false;
 };
 Api g_api;
@@ -47,9 +49,11 @@ void load_api() {
   PA_SYM(Recv, ncclRecv);
   PA_SYM(AllReduce, ncclAllReduce);
   PA_SYM(GetErrorString, ncclGetErrorString);
+  PA_SYM(CommCount, ncclCommCount);
+  PA_SYM(CommUserRank, ncclCommUserRank);
 #undef PA_SYM
   g_api.ok = g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.GroupStart && g_api.GroupEnd &&
-             g_api.Send && g_api.Recv && g_api.AllReduce && g_api.GetErrorString;
+             g_api.Send && g_api.Recv && g_api.AllReduce && g_api.GetErrorString && g_api.CommCount && g_api.CommUserRank;
 }
 
 int need_api() {
@@ -129,6 +133,17 @@ extern "C" int pa_comm_barrier(pa_comm *m) {
   PA_REQUIRE(m != nullptr, "comm is NULL");
   PA_TRY(pa_comm_allreduce_sum(m, m->d_token, 1, PA_STREAM_COMM));
   PA_HIP(hipStreamSynchronize(m->ctx->s[1]));
+  return PA_OK;
+}
+
+extern "C" int pa_comm_info(pa_comm *m, int *rank, int *nranks) {
+  PA_REQUIRE(m != nullptr, "comm is NULL");
+  PA_TRY(need_api());
+  int r = -1, n = -1;
+  PA_NCCL(g_api.CommUserRank(m->comm, &r));
+  PA_NCCL(g_api.CommCount(m->comm, &n));
+  if (rank) *rank = r;
+  if (nranks) *nranks = n;
   return PA_OK;
 }
 

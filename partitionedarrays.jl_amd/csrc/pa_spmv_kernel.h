@@ -1,5 +1,5 @@
 // pa_spmv_kernel.h -- the row-split CSR SpMV kernel (K1/K2) and its host-side row split.
-// Shared by pa_device.hip (the product) and probe/spmv_probe.hip (A/B tuning harness).
+// Shared by pa_device.hip (the product) and tools/probe/spmv_probe.hip (A/B tuning harness).
 //
 // Reference loops: spmv_csr! src/sparse_utils.jl:649-669; muladd! src/p_sparse_matrix.jl:2088.
 // Must be compiled with -ffp-contract=off (one rounding per multiply and per add).
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
   __shared__ __attribute__((aligned(16))) double prod[CAP];
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-#ifdef PA_PROBE_IDENTITY_CHUNK_MAP   // probe builds only (csrc/probe/placement_probe.hip)
+#ifdef PA_PROBE_IDENTITY_CHUNK_MAP   // probe builds only (tools/probe/placement_probe.hip)
   const int chunk = b;
   if (chunk >= n_chunks) return;
 #else
@@ -247,6 +247,27 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       *reinterpret_cast<d2 *>(&prod[(k * BLK + tid) * 2]) = pr;
     }
     __syncthreads();
+    if (EPI == 11) {   // probe only: a lane owns the two rows of a 16-byte slot of y and stores them with one dwordx4
+      for (int rb = (r0 & ~1) + 2 * tid; rb < r1; rb += 2 * BLK) {
+        double acc2[2] = {0.0, 0.0};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = rb + h;
+          if (r < r0 || r >= r1) continue;
+          const int a = crp[r] - base, e = crp[r + 1] - base;
+          double acc = 0.0;
+#pragma unroll UNR
+          for (int p = a; p < e; ++p) acc = acc + prod[p];
+          acc2[h] = acc;
+        }
+        if (rb >= r0 && rb + 1 < r1) {
+          d2 o; o.x = acc2[0]; o.y = acc2[1];
+          __builtin_nontemporal_store(o, reinterpret_cast<d2 *>(&y[rb]));
+        } else if (rb >= r0) __builtin_nontemporal_store(acc2[0], &y[rb]);
+        else __builtin_nontemporal_store(acc2[1], &y[rb + 1]);
+      }
+      return;
+    }
     for (int r = r0 + tid; r < r1; r += BLK) {
       if (r != r0 + tid) {
         ra = crp[r];

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _lib as L
 from .primitives import pmap
-from .p_sparse_matrix import mul_, mul_c_, mul_no_overlap_, tune_placement_
+from .p_sparse_matrix import mul_, mul_c_, mul_no_overlap_
 from .p_vector import (axpby_, copy_, dot, norm, similar, pzeros, consistent_, context, slots_supported, dot_slot,
                        axpby_slot_, cg_update_, write_slot, read_slots)
 
@@ -312,7 +312,7 @@ def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_ev
         while iters + 3 <= maxiter:
             g.launch()
             iters += 3
-    while not (iters >= maxiter or residual / residual0 <= tolerance):
+    while not (iters >= maxiter or _converged(residual, residual0, tolerance)):
         if Pl is None:
             s_prev, s_rho, s_rr = s_rho, s_rr, s_prev        # rho_prev = rho; rho = dot(r,r), already on the device
             z = r
@@ -393,14 +393,19 @@ class _NoTimer:
 _NO_TIMER = _NoTimer()
 
 
-def cg_work(x, b, A=None, tune_placement=0):
-    """The work vectors (u, r, c) of ref_cg_ / opt_cg_ for solves with x and b, to pass as `work=`.  With A and
-    tune_placement=k > 1 every part's own_own value stream and the storage of c are placed, by measurement, where the
-    loop's product c = A*u runs fastest (tune_placement_; result-neutral)."""
-    u, r, c = similar(x), similar(b), similar(b)
-    if A is not None and tune_placement > 1 and A.assembled:
-        tune_placement_(A, c, u, tune_placement)
-    return u, r, c
+def _converged(residual, residual0, tolerance):
+    """`residual/residual0 <= tolerance` (HPCG/src/ref_cg.jl:23) with Julia's floating-point semantics: 0/0 is NaN and
+    the comparison is false (a zero right-hand side iterates to maxiter), x/0 is Inf."""
+    if residual0 == 0.0:
+        return False if residual == 0.0 or residual != residual else float("inf") <= tolerance
+    return residual / residual0 <= tolerance
+
+
+def cg_work(x, b, A=None):
+    """The work vectors (u, r, c) of ref_cg_ / opt_cg_ for solves with x and b, to pass as `work=`: allocated once
+    instead of per solve.  (Where they live is the context arena's business: vectors never share a memory class with
+    the matrix streams, csrc/pa_arena.hip.)"""
+    return similar(x), similar(b), similar(b)
 
 
 def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None, Pl=None, timer=None, work=None):
@@ -424,7 +429,7 @@ def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None, Pl=N
     rho = 1.0
     iters = 0
     tm = timer or _NO_TIMER
-    while not (iters >= maxiter or residual / residual0 <= tolerance):      # done(it,iteration) (:23)
+    while not (iters >= maxiter or _converged(residual, residual0, tolerance)):      # done(it,iteration) (:23)
         with tm.span("MG"):
             if Pl is None:
                 copy_(c, r)                  # ldiv!(c, Identity(), r)  (:48)

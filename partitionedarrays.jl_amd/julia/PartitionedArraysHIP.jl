@@ -215,20 +215,6 @@ _mul_fused!(ms::MPIArray, cs, bs, plans, α, β) =
     check(ccall((:pa_mul5, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64),
                 ms.item, init_comm!(ms.comm), cs.item.handle, bs.item.handle, α, β))
 
-"""
-    tune_placement!(A, c, b; tries=8)
-
-Optional and result-neutral: every part keeps the value stream of its own_own block in the allocation on which
-`c_own = A_oo*b_own` runs fastest with THESE vectors (the pair a solver multiplies with in its loop); `c` is overwritten.
-"""
-function tune_placement!(A::PSparseMatrix, c::PVector, b::PVector; tries::Integer=8)
-    foreach(partition(A), partition(c), partition(b)) do a, cv, bv
-        check(ccall((:pa_csr_tune_placement, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Cint),
-                    a.blocks.own_own.handle, bv.handle, PA_SEG_OWN, cv.handle, PA_SEG_OWN, tries))
-    end
-    A
-end
-
 # ---------------------------------------------------------------- conversions
 "Device twin of a host PVector{Vector{Float64}} whose local ids are [own | ghost] (block partitions)."
 function to_hip(v::PVector)

@@ -63,7 +63,7 @@ def local_range(p, np_, n, ghost=False, periodic=False):
     if rem >= (np_ - p + 1):
         l += 1
         offset += p - (np_ - rem) - 1
-    g = 1 if ghost else 0
+    g = int(ghost)                      # a number of ghost layers (Bool or Integer in the reference: `1+offset-ghost`)
     start, stop = 1 + offset - g, l + offset + g
     if periodic:
         return start, stop
@@ -96,7 +96,7 @@ class LocalIndices:
     """
 
     def __init__(self, n_global, part, *, np_=None, n=None, ranges=None, starts=None,
-                 ghost_to_global=None, ghost_to_owner=None, local_to_global=None, local_to_owner=None):
+                 ghost_to_global=None, ghost_to_owner=None, local_to_global=None, local_to_owner=None, is_own=None):
         self.n_global = int(n_global)
         self.part = int(part)
         self.cache = {}                       # AssemblyCache (src/p_range.jl:354-359)
@@ -114,7 +114,10 @@ class LocalIndices:
             self.kind = "generic"
             self.local_to_global = np.ascontiguousarray(local_to_global, dtype=I64)
             self.local_to_owner = np.ascontiguousarray(local_to_owner, dtype=I32)
-            own = self.local_to_owner == self.part
+            # own = "inside the own box" when the constructor knows it (block_with_constant_size, src/p_range.jl:650-665:
+            # a periodic direction with ONE part wraps onto ids this part owns, and the reference keeps those copies as
+            # ghosts owned by self); otherwise own = owned by this part (LocalIndices, :1121)
+            own = self.local_to_owner == self.part if is_own is None else np.ascontiguousarray(is_own, dtype=bool)
             self._own_to_local = (np.nonzero(own)[0] + 1).astype(I32)      # src/p_range.jl:1121
             self._ghost_to_local = (np.nonzero(~own)[0] + 1).astype(I32)   # :1122
             self.n_own, self.n_ghost = len(self._own_to_local), len(self._ghost_to_local)
@@ -143,6 +146,18 @@ class LocalIndices:
     def own_is_contiguous_prefix(self):
         """True when local ids are [own | ghost]: the layout the SpMV kernels need."""
         return self.kind == "block" or bool(np.array_equal(self._own_to_local, np.arange(1, self.n_own + 1)))
+
+    @property
+    def local_to_device(self):
+        """0-based position of every local id in the DEVICE layout, which is always [own | ghost] (what the kernels and
+        the own-value reductions need); None when the local order already is that (block partitions)."""
+        if self.own_is_contiguous_prefix:
+            return None
+        if getattr(self, "_l2d", None) is None:
+            l2d = np.empty(self.n_local, dtype=np.int64)
+            l2d[np.concatenate([self._own_to_local, self._ghost_to_local]).astype(np.int64) - 1] = np.arange(self.n_local)
+            self._l2d = l2d
+        return self._l2d
 
     @property
     def own_to_global(self):
@@ -214,7 +229,7 @@ def uniform_partition(ranks, np_, n, ghost=None, periodic=None):
     """uniform_partition(ranks,np,n[,ghost[,periodic]]) (src/p_range.jl:585-671)."""
     if isinstance(np_, (int, np.integer)):
         np_, n = (int(np_),), (int(n),)
-        ghost = None if ghost is None else (bool(ghost),)
+        ghost = None if ghost is None else (int(ghost),)
         periodic = None if periodic is None else (bool(periodic),)
     np_, n = tuple(int(x) for x in np_), tuple(int(x) for x in n)
     assert int(np.prod(np_)) == len(ranks), "prod(np) == length(rank)"       # :586
@@ -261,7 +276,7 @@ def uniform_partition(ranks, np_, n, ghost=None, periodic=None):
             ostride *= np_[d]
         l2o = np.where(is_own, rank - 1, l2o)
         return LocalIndices(n_global, rank, local_to_global=(l2g + 1).ravel().astype(I64),
-                            local_to_owner=(l2o + 1).ravel().astype(I32))
+                            local_to_owner=(l2o + 1).ravel().astype(I32), is_own=np.broadcast_to(is_own, l2g.shape).ravel())
 
     indices = pmap(block, ranks)
     if ghost is not None:
@@ -352,13 +367,16 @@ def assembly_local_indices(indices, neighbors_snd=None, neighbors_rcv=None):
     if not getany(have):
         def snd_side(ind, parts_snd):
             # ghosts grouped by owner, in ascending local id inside a group (:506-513)
-            gl, go = ind.ghost_to_local, ind.ghost_to_owner
+            # (a ghost owned by this very part -- the wrapped copies of a periodic direction with one part -- is not sent:
+            # `if owner != rank`, :494,503)
+            keep = ind.ghost_to_owner != ind.part
+            gl, go = ind.ghost_to_local[keep], ind.ghost_to_owner[keep]
             slot = np.searchsorted(parts_snd, go)
             order = np.argsort(slot, kind="stable")
             ptrs = np.zeros(len(parts_snd) + 1, dtype=I32)
             np.add.at(ptrs, slot + 1, 1)
             length_to_ptrs(ptrs)
-            return (JaggedArray(gl[order].astype(I32), ptrs), JaggedArray(ind.ghost_to_global[order], ptrs.copy()))
+            return (JaggedArray(gl[order].astype(I32), ptrs), JaggedArray(ind.ghost_to_global[keep][order], ptrs.copy()))
 
         lids_snd, gids_snd = tuple_of_arrays(pmap(snd_side, indices, neighbors_snd))
         graph = exchange_graph(neighbors_snd, rcv=neighbors_rcv)

@@ -118,18 +118,18 @@ class DeviceCSR:
         L.call("pa_csr_device_bytes", self.h, C.byref(n))
         return n.value
 
-    def tune_placement(self, x, y, x_segment=L.SEG_OWN, y_segment=L.SEG_OWN, tries=6):
-        """Keep the value stream -- and y's storage, when the library owns it -- in the allocations on which y = A*x runs
-        fastest with this x (the vectors of the hot loop; y is overwritten with A*x; its device pointer may change).
-        Optional, measured, never changes a result (pa_csr_tune_placement)."""
-        L.call("pa_csr_tune_placement", self.h, x.h, x_segment, y.h, y_segment, int(tries))
-        return self.placement()
+    def stream_bytes(self):
+        """Bytes one product must read from the block, each once (pa_csr_stream_bytes): values, row pointers, chunk table
+        and whatever gives each chunk its columns."""
+        n = C.c_int64()
+        L.call("pa_csr_stream_bytes", self.h, C.byref(n))
+        return n.value
 
-    def placement(self):
-        """What the measured placement of the value stream did at creation (pa_csr_placement)."""
-        n, a, b = C.c_int(), C.c_double(), C.c_double()
-        L.call("pa_csr_placement", self.h, C.byref(n), C.byref(a), C.byref(b))
-        return {"candidates": n.value, "first_ms": round(a.value, 4), "kept_ms": round(b.value, 4)}
+    def memory_class(self):
+        """Memory class of the value stream inside the context's arena (pa_csr_memory_class; -1: outside)."""
+        n = C.c_int()
+        L.call("pa_csr_memory_class", self.h, C.byref(n))
+        return n.value
 
     def value_dict(self):
         """Distinct values held in the optional value dictionary (PA_SPMV_VALUE_DICT=1 at creation), 0 when unused."""
@@ -265,15 +265,6 @@ class _OperatorHandles:
                 L.lib.pa_matrix_destroy(h)
         except Exception:
             pass
-
-
-def tune_placement_(a: PSparseMatrix, c: PVector, b: PVector, tries=6):
-    """Optional, measured, result-neutral: for every part keep the own_own value stream in the allocation on which
-    c_own = A_oo*b_own runs fastest WITH these vectors -- the pair a solver multiplies with in its loop
-    (pa_csr_tune_placement).  c is overwritten.  Returns the per-part reports."""
-    _check_axes(c, a, b)
-    return pmap(lambda cv, blk, bv: blk.own_own.tune_placement(bv, cv, L.SEG_OWN, L.SEG_OWN, tries),
-                c.vector_partition, a.matrix_partition, b.vector_partition)
 
 
 def mul_c_(c: PVector, a: PSparseMatrix, b: PVector, alpha=1.0, beta=0.0) -> PVector:

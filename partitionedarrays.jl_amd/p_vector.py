@@ -50,6 +50,31 @@ class Context:
     def event(self):
         return Event(self)
 
+    def stream_priorities(self):
+        """(compute, comm, least, greatest) stream priorities: the comm stream holds the device's greatest
+        (pa_ctx_stream_priority)."""
+        a, b, lo, hi = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        L.call("pa_ctx_stream_priority", self.h, L.STREAM_COMPUTE, C.byref(a), C.byref(lo), C.byref(hi))
+        L.call("pa_ctx_stream_priority", self.h, L.STREAM_COMM, C.byref(b), None, None)
+        return dict(compute=a.value, comm=b.value, least=lo.value, greatest=hi.value)
+
+    def arena(self, build=False):
+        """The context's HBM arena and its memory-class map (csrc/pa_arena.hip): size, classes found, usable GiB per
+        class, GiB in use, map time, and the class of every 512 MiB cell as a string ('.' = a boundary cell)."""
+        if build:
+            L.call("pa_ctx_arena_build", self.h)
+        size, used, ncls, ms = C.c_int64(), C.c_int64(), C.c_int(), C.c_double()
+        per = (C.c_int64 * 3)()
+        L.call("pa_ctx_arena_info", self.h, C.byref(size), C.byref(ncls), per, C.byref(used), C.byref(ms))
+        n, cell = C.c_int64(), C.c_int64()
+        L.call("pa_ctx_arena_map", self.h, C.byref(cell), None, 0, C.byref(n))
+        cells = np.zeros(max(n.value, 1), np.int8)
+        L.call("pa_ctx_arena_map", self.h, C.byref(cell), L.ptr(cells), n.value, C.byref(n))
+        G = float(1 << 30)
+        return dict(gib=round(size.value / G, 1), classes=ncls.value, class_gib=[round(v / G, 1) for v in per],
+                    used_gib=round(used.value / G, 2), map_ms=round(ms.value, 1), cell_mib=cell.value >> 20,
+                    cells="".join("." if v < 0 else str(int(v)) for v in cells[:n.value]))
+
 
 class Graph:
     """hipGraph of whatever is queued between `with Graph() as g:` and its end (pa_graph_begin/_end): nothing runs while
@@ -135,6 +160,12 @@ class RcclComm:
     def barrier(self):
         L.call("pa_comm_barrier", self.h)
 
+    def info(self):
+        """Rank and size as the communicator itself reports them (ncclCommUserRank / ncclCommCount)."""
+        r, n = C.c_int(), C.c_int()
+        L.call("pa_comm_info", self.h, C.byref(r), C.byref(n))
+        return dict(rank=r.value, nranks=n.value)
+
 
 def init_comm(group=None):
     """Create (once) the RCCL communicator used by the device exchange of TorchDistArray back-ends."""
@@ -150,9 +181,13 @@ def init_comm(group=None):
 class DeviceVector:
     """Local values of one part in HBM (allocate_local_values, src/p_vector.jl:8-14)."""
 
-    def __init__(self, n_own, n_ghost, ctx=None):
+    def __init__(self, n_own, n_ghost, ctx=None, l2d=None):
         self.ctx = ctx or context()
         self.n_own, self.n_ghost = int(n_own), int(n_ghost)
+        # The device layout is always [own | ghost].  `l2d` (LocalIndices.local_to_device) maps a local id to its device
+        # position for partitions whose local order is something else (PermutedLocalIndices, src/p_range.jl:1372:
+        # uniform_partition with ghost layers); whole-vector upload/download then speak the LOCAL order.
+        self.l2d = l2d
         self.h = C.c_void_p()
         L.call("pa_vec_create", self.ctx.h, self.n_own, self.n_ghost, C.byref(self.h))
 
@@ -161,6 +196,11 @@ class DeviceVector:
 
     def upload(self, host, offset=0):
         host = np.ascontiguousarray(host, dtype=F64)
+        if self.l2d is not None:
+            assert offset == 0 and len(host) == len(self), "a permuted local vector is uploaded whole"
+            dev = np.empty(len(host), dtype=F64)
+            dev[self.l2d] = host
+            host = dev
         L.call("pa_vec_upload", self.h, L.ptr(host), offset, len(host))
         return self
 
@@ -168,13 +208,21 @@ class DeviceVector:
         length = len(self) - offset if length is None else length
         out = np.empty(length, dtype=F64)
         L.call("pa_vec_download", self.h, L.ptr(out), offset, length)
+        if self.l2d is not None:
+            assert offset == 0 and length == len(self), "a permuted local vector is downloaded whole"
+            out = out[self.l2d]
         return out
 
     def own(self):
-        return self.download(0, self.n_own)
+        return self._device_order(0, self.n_own)
 
     def ghost(self):
-        return self.download(self.n_own, self.n_ghost)
+        return self._device_order(self.n_own, self.n_ghost)
+
+    def _device_order(self, offset, length):
+        out = np.empty(length, dtype=F64)
+        L.call("pa_vec_download", self.h, L.ptr(out), offset, length)
+        return out
 
     def fill(self, value, segment=L.SEG_LOCAL):
         L.call("pa_vec_fill", self.h, segment, float(value))
@@ -184,6 +232,12 @@ class DeviceVector:
         p = C.c_void_p()
         L.call("pa_vec_data", self.h, C.byref(p))
         return p.value
+
+    def memory_class(self):
+        """Memory class of the storage inside the context's arena (pa_vec_memory_class; -1: outside)."""
+        n = C.c_int()
+        L.call("pa_vec_memory_class", self.h, C.byref(n))
+        return n.value
 
     def __del__(self):
         try:
@@ -208,9 +262,14 @@ class DeviceAssemblyCache:
         def make(ind, ns, nr, ls, lr):
             h = C.c_void_p()
             ns32, nr32 = np.ascontiguousarray(ns, np.int32), np.ascontiguousarray(nr, np.int32)
+            l2d = ind.local_to_device
+
+            def dev(lids):           # the cache's 1-based local ids as 1-based positions of the device layout [own | ghost]
+                lids = np.ascontiguousarray(lids, np.int32)
+                return lids if l2d is None else np.ascontiguousarray(l2d[lids.astype(np.int64) - 1] + 1, np.int32)
             L.call("pa_plan_create", context().h, ind.part, ind.n_local, len(ns32), L.ptr(ns32), L.ptr(ls.ptrs),
-                   L.ptr(np.ascontiguousarray(ls.data, np.int32)), len(nr32), L.ptr(nr32), L.ptr(lr.ptrs),
-                   L.ptr(np.ascontiguousarray(lr.data, np.int32)), 1, C.byref(h))
+                   L.ptr(dev(ls.data)), len(nr32), L.ptr(nr32), L.ptr(lr.ptrs),
+                   L.ptr(dev(lr.data)), 1, C.byref(h))
             plan_info[h.value] = dict(
                 snd=[(int(q), int(ls.ptrs[k]) - 1, int(ls.ptrs[k + 1]) - 1) for k, q in enumerate(ns32)],
                 rcv=[(int(q), int(lr.ptrs[k]) - 1, int(lr.ptrs[k + 1]) - 1) for k, q in enumerate(nr32)])
@@ -395,11 +454,18 @@ def partition(a):
     return a.vector_partition if isinstance(a, PVector) else a.partition
 
 
+def allocate_local_values(ind) -> DeviceVector:
+    """allocate_local_values(V, indices) (src/p_vector.jl:8-14) for V = DeviceVector: n_own + n_ghost zeroed doubles in
+    HBM, device layout [own | ghost] whatever the local order of `ind` is -- dot / norm / the own-value broadcasts then
+    reduce over own values only (src/p_vector.jl:1189-1206) on every kind of partition."""
+    return DeviceVector(ind.n_own, ind.n_ghost, l2d=ind.local_to_device)
+
+
 def pvector_from_function(f, index_partition, cache=None) -> PVector:
     """pvector(f,index_partition): f(indices) gives the host local values to upload (src/p_vector.jl:815)."""
 
     def make(ind):
-        v = DeviceVector(ind.n_own, ind.n_ghost) if ind.own_is_contiguous_prefix else DeviceVector(ind.n_local, 0)
+        v = allocate_local_values(ind)
         vals = np.ascontiguousarray(f(ind), dtype=F64)
         assert len(vals) == ind.n_local
         v.upload(vals)
@@ -412,7 +478,7 @@ def pfill(value, index_partition) -> PVector:
     """pfill(v,index_partition) (src/p_vector.jl:1047): filled on the device (no host array, no upload)."""
 
     def make(ind):
-        v = DeviceVector(ind.n_own, ind.n_ghost) if ind.own_is_contiguous_prefix else DeviceVector(ind.n_local, 0)
+        v = allocate_local_values(ind)
         if value != 0.0:                     # (pa_vec_create hands out zeroed storage)
             v.fill(float(value))
         return v
@@ -444,8 +510,7 @@ def pvector(I, V, index_partition) -> PVector:
         return out
 
     host = pmap(vals, index_partition, I, V)
-    parts = pmap(lambda ind, h: (DeviceVector(ind.n_own, ind.n_ghost) if ind.own_is_contiguous_prefix
-                                 else DeviceVector(ind.n_local, 0)).upload(h), index_partition, host)
+    parts = pmap(lambda ind, h: allocate_local_values(ind).upload(h), index_partition, host)
     return PVector(parts, index_partition)
 
 
@@ -521,8 +586,7 @@ def pvector_(b: PVector, V, cache: VectorReassemblyCache) -> PVector:
 def pvector_from_function_values(host_values, index_partition) -> PVector:
     """PVector(values,index_partition) from host arrays in local order."""
     it = pmap(lambda h: h, host_values)
-    parts = pmap(lambda ind, h: (DeviceVector(ind.n_own, ind.n_ghost) if ind.own_is_contiguous_prefix
-                                 else DeviceVector(ind.n_local, 0)).upload(h), index_partition, it)
+    parts = pmap(lambda ind, h: allocate_local_values(ind).upload(h), index_partition, it)
     return PVector(parts, index_partition)
 
 

@@ -12,6 +12,8 @@ src/primitives.jl:152; MPI rank = part - 1, src/mpi_array.jl:51).
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 
 import numpy as np
@@ -275,13 +277,58 @@ def is_consistent(graph: ExchangeGraph) -> bool:
     return True
 
 
+CHECK_EXCHANGE_GRAPHS = os.environ.get("PA_CHECK_EXCHANGE_GRAPHS", "0") == "1"
+
+
 def exchange(snd, graph: ExchangeGraph):
     """exchange(snd,graph)|>fetch for HOST data (src/primitives.jl:921-935,1005-1042).
 
     snd[i][j] (a scalar, or a sequence -> jagged exchange) goes to part graph.snd[i][j];
     the result rcv[i][j] is what part graph.rcv[i][j] sent to i.  Used at set-up (global ids of the
-    ghosts, slice lengths); the per-iteration exchange of values is the device path.
+    ghosts, slice lengths, the I/J/V triplets of a first-time matrix assembly); the per-iteration exchange of
+    values is the device path.
+
+    One part per process (TorchDistArray): point-to-point, one message per directed edge of the graph, as the MPI
+    back-end does (Irecv!/Isend per neighbour, src/mpi_array.jl:575-614) -- a rank's traffic is what ITS neighbours
+    send, independent of the number of parts.  The graph's consistency (src/primitives.jl:861-874, two all-gathers)
+    is only checked with PA_CHECK_EXCHANGE_GRAPHS=1 there; the in-process DebugArray always checks it.
     """
+    if isinstance(snd, TorchDistArray):
+        import torch.distributed as dist
+        if CHECK_EXCHANGE_GRAPHS:
+            assert is_consistent(graph)
+        group = snd.group
+        me = dist.get_rank(group) + 1
+        snd_ids, rcv_ids = [int(q) for q in graph.snd.item], [int(q) for q in graph.rcv.item]
+        data = list(snd.item)
+        assert len(data) == len(snd_ids), "one item per send neighbour"
+        out = [None] * len(rcv_ids)
+        world = dist.get_world_size(group)
+
+        def grank(part):
+            return part - 1 if group is None else dist.get_global_rank(group, part - 1)
+        # Deadlock-free pairing without non-blocking object sends: the directed edges are served in rounds of the
+        # classical pairwise schedule -- in round k rank r talks to partner (k - r) mod P; of a pair, the lower rank sends
+        # first.  Every edge (i -> j) is met in exactly one round by both of its ends.
+        for k in range(world):
+            partner0 = (k - (me - 1)) % world
+            partner = partner0 + 1
+            if partner == me:
+                if me in snd_ids and me in rcv_ids:                   # a part that lists itself (never on this path; kept exact)
+                    out[rcv_ids.index(me)] = data[snd_ids.index(me)]
+                continue
+            do_send, do_recv = partner in snd_ids, partner in rcv_ids
+            first_send = me < partner
+            for phase in (0, 1):
+                if (phase == 0) == first_send:
+                    if do_send:
+                        dist.send_object_list([data[snd_ids.index(partner)]], dst=grank(partner), group=group)
+                else:
+                    if do_recv:
+                        box = [None]
+                        dist.recv_object_list(box, src=grank(partner), group=group)
+                        out[rcv_ids.index(partner)] = box[0]
+        return TorchDistArray(out, group)
     assert is_consistent(graph)
     packed = pmap(lambda ids, data: ([int(x) for x in ids], list(data)), graph.snd, snd)
     everything = gather(packed, destination="all")

@@ -8,6 +8,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import pathlib
 import pytest
 
 from __graft_entry__ import load_package
@@ -767,14 +768,13 @@ def test_opt_cg_device_scalars_bit_identical_to_ref_cg(P, np3, with_mg):
     assert (ita_, ra_) == (itb_, rb_) and ita_ < 200
 
 
-def test_cg_with_reused_and_placement_tuned_work_vectors_is_bit_identical():
-    """cg_work: the work vectors allocated once (and, with tune_placement, the value stream and c moved to the allocations
-    on which c = A*u runs fastest) -- ref_cg_ and opt_cg_ give the bits of the allocating loops, solve after solve."""
+def test_cg_with_reused_work_vectors_is_bit_identical():
+    """cg_work: the work vectors allocated once -- ref_cg_ and opt_cg_ give the bits of the allocating loops, solve
+    after solve."""
     A, b = pa.build_p_matrix(ranks(2), 96, 96, 64, 192, 96, 64, 2, 1, 1)         # 2 x 590k rows, 15.7 M entries per part
     x0, r00, r0, it0 = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=9)
     want = [v.copy() for v in x0.own_values().items]
-    work = pa.cg_work(pa.pzeros(A.col_partition), b, A, tune_placement=3)
-    assert all(blk.own_own.placement()["candidates"] == 3 for blk in A.matrix_partition.items)
+    work = pa.cg_work(pa.pzeros(A.col_partition), b, A)
     for fn in (pa.opt_cg_, pa.ref_cg_, pa.opt_cg_):
         x, r0_, r_, it = fn(pa.pzeros(A.col_partition), A, b, maxiter=9, work=work)
         assert it == it0 == 9
@@ -1042,57 +1042,57 @@ def test_compacted_column_streams_in_a_mixed_block(orc, monkeypatch):
     assert blk.device_bytes() < 9.0 * blk.nnz
 
 
-def test_placement_tuning_never_changes_a_result(orc, monkeypatch):
-    """pa_csr_tune_placement moves the value stream between allocations by measurement: the product before, during and
-    after is bit-identical, value updates keep working on the kept allocation, small blocks are left alone."""
-    A, b = pa.build_p_matrix(ranks(1), 72, 72, 72, 72, 72, 72, 1, 1, 1, keep_host=True)
-    blk = A.matrix_partition.items[0].own_own
-    h = pa.local_items(A.host_blocks)[0][0]
-    n = blk.m
-    xh = orc.hash_x(np.arange(1, n + 1))
-    x = pa.DeviceVector(n, 0).upload(xh)
-    y = pa.DeviceVector(n, 0)
-    pa.spmv_(y, blk, x)
-    before = y.download()
-    assert blk.placement()["candidates"] == 0
-    rep = blk.tune_placement(x, y, tries=3)
-    assert rep["candidates"] == 3 and rep["kept_ms"] > 0 and rep["first_ms"] > 0
-    assert np.array_equal(y.download(), before)            # y holds A*x after tuning, as documented
-    y.fill(0.0)
-    pa.spmv_(y, blk, x)
-    assert np.array_equal(y.download(), before)
-    blk.update_values(2.0 * h.nzval)                       # the kept allocation is the block's value stream from now on
-    pa.spmv_(y, blk, x)
-    assert np.array_equal(y.download(), 2.0 * before)
-    small, _ = pa.build_p_matrix(ranks(1), 16, 16, 16, 16, 16, 16, 1, 1, 1)
-    sb = small.matrix_partition.items[0].own_own
-    xs, ys = pa.DeviceVector(sb.n, 0), pa.DeviceVector(sb.m, 0)
-    assert sb.tune_placement(xs, ys, tries=4)["candidates"] == 0
-    with pytest.raises(pa.PAError):
-        blk.tune_placement(x, x)                           # aliasing is refused like in spmv!
-    # a block with a value dictionary: the one-byte code stream is what gets placed; same bits, and a value update
-    # afterwards still finds the fp64 values where they were
-    monkeypatch.setenv("PA_SPMV_VALUE_DICT", "1")
-    dV = pa.DeviceCSR(h)
-    monkeypatch.delenv("PA_SPMV_VALUE_DICT")
-    assert dV.value_dict() == 2
-    yv = pa.DeviceVector(n, 0)
-    assert dV.tune_placement(x, yv, tries=3)["candidates"] == 3
-    assert np.array_equal(yv.download(), before)
-    dV.update_values(2.0 * h.nzval)
-    pa.spmv_(yv, dV, x)
-    assert dV.value_dict() == 0 and np.array_equal(yv.download(), 2.0 * before)
-    # a block kept as row slabs: every slab's values are placed on their own, y stays where it is
-    monkeypatch.setenv("PA_CSR_MAX_SLAB_NNZ", "9000000")
-    hb = pa.local_items(pa.build_p_matrix(ranks(1), 96, 96, 96, 96, 96, 96, 1, 1, 1, keep_host=True)[0].host_blocks)[0][0]
-    dS = pa.DeviceCSR(hb)
-    monkeypatch.delenv("PA_CSR_MAX_SLAB_NNZ")
-    xs = pa.DeviceVector(hb.n, 0).upload(orc.hash_x(np.arange(1, hb.n + 1)))
-    ys = pa.DeviceVector(hb.m, 0)
-    pa.spmv_(ys, dS, xs)
-    want, where = ys.download(), ys.data_ptr()
-    assert dS.tune_placement(xs, ys, tries=3)["candidates"] == 3 and ys.data_ptr() == where
-    assert np.array_equal(ys.download(), want)
+def test_arena_places_matrix_streams_and_vectors_in_different_memory_classes(orc, tmp_path):
+    """csrc/pa_arena.hip: the first allocation of PA_ARENA_MIN_MIB or more brings the context's contiguous arena into
+    being; its class map must show the structure measured on MI355X (at least two classes); the value stream of a big
+    block then sits in class 0 and vectors in another class, freed storage is handed out again, and the product on
+    arena-resident operands is bit-identical to the oracle's.  Runs in a child process so that the arena (70 % of the free
+    memory by default; 40 GiB here) does not stay with the test session's context."""
+    import subprocess, sys, json, textwrap
+    code = textwrap.dedent("""
+        import json, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from __graft_entry__ import load_package, load_oracle
+        pa, orc = load_package(), load_oracle()
+        ctx = pa.context()
+        out = {"before": ctx.arena()}
+        A, b = pa.build_p_matrix(pa.DebugArray([1]), 128, 128, 128, 128, 128, 128, 1, 1, 1, keep_host=True)   # 55.7 M entries: 446 MB of values
+        blk = A.matrix_partition.items[0].own_own
+        out["after"] = ctx.arena()
+        out["matrix_class"] = blk.memory_class()
+        n = blk.m
+        x = pa.DeviceVector(n, 0).upload(orc.hash_x(np.arange(1, n + 1)))
+        y = pa.DeviceVector(n, 0)
+        out["vector_classes"] = [x.memory_class(), y.memory_class()]
+        pa.spmv_(y, blk, x)
+        h = pa.local_items(A.host_blocks)[0][0]
+        want = np.zeros(n)
+        orc.oracle_c().spmv_csr(want, orc.hash_x(np.arange(1, n + 1)), orc.CSR(h.m, h.n, h.rowptr, h.colval, h.nzval))
+        out["bit_identical"] = bool(np.array_equal(y.download(), want))
+        used = ctx.arena()["used_gib"]
+        p0 = y.data_ptr()
+        del y
+        import gc; gc.collect()
+        y2 = pa.DeviceVector(n, 0)
+        out["reused"] = y2.data_ptr() == p0
+        small = pa.DeviceVector(1000, 0)
+        out["small_vector_class"] = small.memory_class()
+        print("RESULT " + json.dumps(out))
+    """ % str(pathlib.Path(__file__).resolve().parents[1]))
+    env = dict(os.environ, PA_ARENA_GIB="40", PA_ARENA_MIN_MIB="256")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["before"]["gib"] == 0                                   # lazily: nothing big had been allocated yet
+    assert out["after"]["gib"] >= 8 and out["bit_identical"]
+    assert out["small_vector_class"] == -1                             # below 1 MiB: plain hipMalloc
+    assert out["reused"]
+    if out["after"]["classes"] >= 2:                                   # the structure the rule exists for
+        assert out["matrix_class"] == 0
+        assert all(c in (1, 2) for c in out["vector_classes"]), out
+    else:                                                              # a 40 GiB arena inside one class region: nothing to place by
+        assert out["matrix_class"] == 0 and all(c == 0 for c in out["vector_classes"]), out
 
 
 def test_config2_laplacian_256_cubed_single_part(orc):

@@ -1,7 +1,7 @@
 // placement_probe.hip -- does the product kernel's time depend on WHERE hipMalloc put the value stream?
 // 27-point 256^3 operator, the shipped kernel configuration (256 threads, 6 per lane, row patterns), one x / y pair,
 // and the SAME values copied into (a) several separate allocations, (b) one arena at offsets of different alignment.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I.. -I../../../include placement_probe.hip -o placement_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../../partitionedarrays.jl_amd/csrc -I../../include placement_probe.hip -o placement_probe
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp
-P=/root/repo/partitionedarrays.jl_amd/csrc/probe/placement_probe
+P=/root/repo/tools/probe/placement_probe
 O=/root/repo/gpurun_out/pmcp
 rm -rf $O; mkdir -p $O
 i=0

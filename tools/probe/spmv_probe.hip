@@ -1,7 +1,7 @@
 // spmv_probe.hip -- A/B harness for the row-split SpMV kernel on the HPCG 27-point matrix (one part,
 // n^3 rows).  Development tool: builds the matrix on the device, runs interleaved rounds of kernel
 // variants / ablations, prints median and min time and the algorithmic GB/s.  Not part of libpa_hip.so.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I.. -I../../../include spmv_probe.hip -o spmv_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I../../partitionedarrays.jl_amd/csrc -I../../include spmv_probe.hip -o spmv_probe
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
