@@ -135,6 +135,13 @@ int pa_vec_axpby_slot(pa_vec *y, double ca, int a_num, int a_den, const pa_vec *
  * statements HPCG/src/ref_cg.jl:64-67 in one pass over the own values (bit-identical to the unfused calls). */
 int pa_cg_update(pa_vec *x, pa_vec *r, const pa_vec *u, const pa_vec *c, int num, int den, int rr_slot,
                  int accumulate);
+/* The same three statements split so that the loop needs two passes less: r .-= alpha .* c with slot[rr_slot] = dot(r,r)
+ * (pa_cg_r_update), and x .+= alpha .* u deferred to the moment u is about to change, fused with u .= z .+ beta .* u
+ * (pa_cg_xu_update, alpha = slot[a_num]/slot[a_den] of the iteration before, beta = slot[b_num]/slot[b_den];
+ * HPCG/src/ref_cg.jl:56,64-65).  x is not read inside the loop, so the iterates are the same numbers, bit for bit; the
+ * caller flushes the last x update with pa_vec_axpby_slot when the loop ends. */
+int pa_cg_r_update(pa_vec *r, const pa_vec *c, int num, int den, int rr_slot, int accumulate);
+int pa_cg_xu_update(pa_vec *x, pa_vec *u, const pa_vec *z, int a_num, int a_den, int b_num, int b_den);
 int pa_ctx_slot_ptr(pa_ctx *ctx, int slot, void **device_ptr);
 int pa_ctx_write_slot(pa_ctx *ctx, int slot, double value);           /* asynchronous, compute stream */
 int pa_ctx_read_slots(pa_ctx *ctx, int first, int n, double *host_out); /* synchronises the compute stream */
@@ -240,6 +247,14 @@ int pa_matrix_destroy(pa_matrix *m);
 int pa_mul(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b);
 int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta);
 int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta);
+/* mul!(c,a,b) that also leaves this part's share of dot(b,c) in a slot (accumulate != 0: added to it): the CG loop's
+ * c = A*u and u'c (HPCG/src/ref_cg.jl:59-60) without a pass over u and c for the dot -- every workgroup of the product
+ * kernels adds b_own[row] * (its rows' products) in a fixed order, two small launches reduce the per-chunk partial sums.
+ * Deterministic, but not the association of pa_vec_dot_slot: u'c agrees with the separate dot to rounding (~1e-15
+ * relative), not bit for bit.  c is bit-identical to pa_mul's.  Across processes all-reduce the slot as for pa_vec_dot_slot.
+ * pa_mul_all_dot: every part of one process, the slot = the sum over the parts in part order. */
+int pa_mul_dot(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, int slot, int accumulate);
+int pa_mul_all_dot(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, int slot);
 
 /* ---- hipGraph capture: a launch-bound loop body is queued once, captured, and replayed ------------------------------
  * Between pa_graph_begin and pa_graph_end nothing runs: every asynchronous entry point (pa_spmv, pa_exchange_pack /

@@ -73,9 +73,13 @@ _SIGS = {
     "pa_mul": [P, P, P, P],
     "pa_mul5": [P, P, P, P, f64, f64],
     "pa_mul_all": [P, i32, P, P, f64, f64],
+    "pa_mul_dot": [P, P, P, P, cint, cint],
+    "pa_mul_all_dot": [P, i32, P, P, cint],
     "pa_vec_dot_slot": [P, P, cint, cint],
     "pa_vec_axpby_slot": [P, f64, cint, cint, P, f64, cint, cint, cint],
     "pa_cg_update": [P, P, P, P, cint, cint, cint, cint],
+    "pa_cg_r_update": [P, P, cint, cint, cint, cint],
+    "pa_cg_xu_update": [P, P, P, cint, cint, cint, cint],
     "pa_ctx_slot_ptr": [P, cint, PP],
     "pa_ctx_write_slot": [P, cint, f64],
     "pa_ctx_read_slots": [P, cint, cint, C.POINTER(f64)],

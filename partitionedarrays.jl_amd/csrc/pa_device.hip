@@ -127,7 +127,8 @@ __global__ void k_zero_at(double *__restrict__ v, const int *__restrict__ idx, i
 __global__ void k_axpby(double *__restrict__ y, const double *__restrict__ x, int64_t n, double a, double b) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) y[i] = a * x[i] + b * y[i];
+  // x only streams through (non-temporal: see k_cg_r_update); y is the vector that is wanted next (u before a product)
+  for (; i < n; i += stride) y[i] = a * __builtin_nontemporal_load(&x[i]) + b * y[i];
 }
 
 __device__ inline double block_sum_256(double s, double *sh) {
@@ -146,7 +147,8 @@ __global__ __launch_bounds__(256) void k_dot_partial(const double *__restrict__ 
   __shared__ double sh[4];
   double s = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += x[i] * y[i];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    s += __builtin_nontemporal_load(&x[i]) * __builtin_nontemporal_load(&y[i]);
   const double t = block_sum_256(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
@@ -172,7 +174,7 @@ __global__ void k_axpby_slot(double *__restrict__ y, const double *__restrict__ 
   const double a = slot_coef(slots, ca, an, ad), b = slot_coef(slots, cb, bn, bd);
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) y[i] = a * x[i] + b * y[i];
+  for (; i < n; i += stride) y[i] = a * __builtin_nontemporal_load(&x[i]) + b * y[i];
 }
 
 // x .+= alpha .* u ; r .-= alpha .* c ; partial sums of dot(r,r) -- the tail of a CG iteration
@@ -187,11 +189,56 @@ __global__ __launch_bounds__(256) void k_cg_update(double *__restrict__ x, doubl
   double s = 0.0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    x[i] = a * u[i] + 1.0 * x[i];
-    const double rn = ma * c[i] + 1.0 * r[i];
-    r[i] = rn;
+    __builtin_nontemporal_store(a * u[i] + 1.0 * __builtin_nontemporal_load(&x[i]), &x[i]);
+    const double rn = ma * __builtin_nontemporal_load(&c[i]) + 1.0 * __builtin_nontemporal_load(&r[i]);
+    __builtin_nontemporal_store(rn, &r[i]);
     s += rn * rn;
   }
+  const double t = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// r .-= alpha .* c ; partial sums of dot(r,r): the second and third statement of HPCG/src/ref_cg.jl:64-67 (per element
+// and per reduction step the arithmetic of k_cg_update, so |r|^2 keeps its bits)
+__global__ __launch_bounds__(256) void k_cg_r_update(double *__restrict__ r, const double *__restrict__ c, int64_t n,
+                                                     const double *__restrict__ slots, int num, int den,
+                                                     double *__restrict__ partial) {
+  __shared__ double sh[4];
+  const double ma = slot_coef(slots, -1.0, num, den);
+  double s = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // non-temporal: these streams are not wanted again before the next product, whose row pointers, descriptors and
+  // gathered vector are (a product right behind another product finds ~225 MB of them in the Infinity Cache and runs
+  // 7 % faster than one behind a kernel that streamed its operands through that cache: tools/probe/spmv_context.py)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double rn = ma * __builtin_nontemporal_load(&c[i]) + 1.0 * __builtin_nontemporal_load(&r[i]);
+    __builtin_nontemporal_store(rn, &r[i]);
+    s += rn * rn;
+  }
+  const double t = block_sum_256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// x .+= alpha .* u (the first statement of ref_cg.jl:64-67, left over from the iteration before) and then
+// u .= z .+ beta .* u (:56) in one pass: x is not read inside the loop, so its update may wait until u is about to change.
+// Per element the arithmetic of k_cg_update's x line and of k_axpby_slot: same bits.
+__global__ void k_cg_xu_update(double *__restrict__ x, double *__restrict__ u, const double *__restrict__ z, int64_t n,
+                               const double *__restrict__ slots, int a_num, int a_den, int b_num, int b_den) {
+  const double a = slot_coef(slots, 1.0, a_num, a_den), b = slot_coef(slots, 1.0, b_num, b_den);
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {       // (x and z stream past the caches; u is what the next product gathers: it stays)
+    const double ui = u[i];
+    __builtin_nontemporal_store(a * ui + 1.0 * __builtin_nontemporal_load(&x[i]), &x[i]);
+    u[i] = 1.0 * __builtin_nontemporal_load(&z[i]) + b * ui;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sum_partial(const double *__restrict__ p, int64_t n, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += p[i];
   const double t = block_sum_256(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
@@ -302,6 +349,7 @@ extern "C" int pa_ctx_destroy(pa_ctx *c) {
   (void)hipStreamSynchronize(c->s[1]);
   (void)hipFree(c->d_partials);
   (void)hipFree(c->d_scalar);
+  if (c->d_dotpart) pa_dev_free(c, c->d_dotpart);
   pa_arena_destroy(c);
   (void)hipEventDestroy(c->ev_compute);
   (void)hipStreamDestroy(c->s[0]);
@@ -567,6 +615,35 @@ extern "C" int pa_cg_update(pa_vec *x, pa_vec *r, const pa_vec *u, const pa_vec 
   hipLaunchKernelGGL(k_cg_update, dim3(nb), dim3(256), 0, c->s[0], x->d, r->d, u->d, cv->d, x->n_own, c->d_scalar, num,
                      den, c->d_partials);
   hipLaunchKernelGGL(k_dot_final_slot, dim3(1), dim3(256), 0, c->s[0], c->d_partials, nb, c->d_scalar + rr_slot, accumulate);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_cg_r_update(pa_vec *r, const pa_vec *cv, int num, int den, int rr_slot, int accumulate) {
+  PA_REQUIRE(r && cv, "bad arguments");
+  PA_REQUIRE(r->n_own == cv->n_own, "own-size mismatch");
+  PA_REQUIRE(PA_COEF_OK(num) && PA_COEF_OK(den) && PA_SLOT_OK(rr_slot), "slot out of range");
+  PA_REQUIRE(rr_slot != num && rr_slot != den, "the result slot must differ from the coefficient slots");
+  PA_REQUIRE(r->d != cv->d, "r and c must be distinct vectors");
+  pa_ctx *c = r->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  const int nb = grid_for(r->n_own, 256 * 8, c->n_partials);
+  hipLaunchKernelGGL(k_cg_r_update, dim3(nb), dim3(256), 0, c->s[0], r->d, cv->d, r->n_own, c->d_scalar, num, den, c->d_partials);
+  hipLaunchKernelGGL(k_dot_final_slot, dim3(1), dim3(256), 0, c->s[0], c->d_partials, nb, c->d_scalar + rr_slot, accumulate);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+extern "C" int pa_cg_xu_update(pa_vec *x, pa_vec *u, const pa_vec *z, int a_num, int a_den, int b_num, int b_den) {
+  PA_REQUIRE(x && u && z, "bad arguments");
+  PA_REQUIRE(x->n_own == u->n_own && x->n_own == z->n_own, "own-size mismatch");
+  PA_REQUIRE(PA_COEF_OK(a_num) && PA_COEF_OK(a_den) && PA_COEF_OK(b_num) && PA_COEF_OK(b_den), "slot out of range");
+  PA_REQUIRE(x->d != u->d && x->d != z->d && u->d != z->d, "x, u, z must be distinct vectors");
+  if (x->n_own == 0) return PA_OK;
+  pa_ctx *c = x->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_cg_xu_update, dim3(grid_for(x->n_own, 256)), dim3(256), 0, c->s[0], x->d, u->d, z->d, x->n_own, c->d_scalar,
+                     a_num, a_den, b_num, b_den);
   PA_HIP(hipGetLastError());
   return PA_OK;
 }
@@ -1857,6 +1934,150 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
   for (int r = 0; r < n_parts; ++r) {
     PA_TRY(pa_exchange_finish(plans[r], b[r], PA_CONSISTENT));
     PA_TRY(pa_spmv(m[r]->oh, b[r], PA_SEG_GHOST, c[r], PA_SEG_OWN, alpha, 1.0));
+  }
+  return PA_OK;
+}
+
+// ---- mul!(c,a,b) that also leaves dot(b,c) in a slot: the CG loop's c = A*u and u'c (HPCG/src/ref_cg.jl:59-60) with no pass
+// over u and c for the dot.  Every chunk of the product kernels (EPI 3) writes its partial sum of b_own[row] * (row's
+// products); own x own and own x ghost each contribute their own products, so the total is b_own'(A_oo b_own + A_oh b_ghost).
+static int dot_scratch(pa_ctx *c, int64_t n) {
+  if (n <= c->n_dotpart) return PA_OK;
+  if (c->capturing) { pa_set_err("the fused product + dot needs its scratch before a capture opens (run it once eagerly)"); return PA_ERR_STATE; }
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  if (c->d_dotpart) pa_dev_free(c, c->d_dotpart);
+  c->d_dotpart = nullptr;
+  c->n_dotpart = 0;
+  // a write stream of the product kernels like y: it must not sit in the matrix streams' memory class either
+  const int64_t cap = std::max<int64_t>(n + n / 4 + 64, (int64_t)1 << 17);
+  PA_TRY(pa_dev_alloc(c, (void **)&c->d_dotpart, sizeof(double) * (size_t)cap, PA_MEM_VECTOR));
+  c->n_dotpart = cap;
+  return PA_OK;
+}
+
+// one block (all of its slabs): y_seg = beta*y_seg + A*x_seg, partial[off + chunk] = that chunk's share of u'(A x)
+static int spmv_dot_block(const pa_csr *A, const double *x, double *y, double beta, const double *u, double *partial) {
+  pa_ctx *c = A->ctx;
+  int64_t off = 0;
+  for (const pa_csr *S = A; S; S = S->next) {
+    double *ys = y + S->row0;
+    const double *us = u + S->row0;
+    double kbeta = beta;
+    if (S->compact && beta != 1.0) {
+      if (S->n_rows) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n_rows, 256)), dim3(256), 0, c->s[0], ys, S->n_rows, beta);
+      kbeta = 1.0;
+    }
+    if (S->n_chunks > 0) {
+      const int cpx = (int)((S->n_chunks + 7) / 8);
+#define PA_LAUNCH_DOT(C16, PAT)                                                                                           \
+  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0, \
+                     c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, x, ys,     \
+                     S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, 1.0, kbeta, partial + off, us,              \
+                     (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr)
+      switch ((S->use_pattern ? (S->compact ? 2 : 1) : 0) * 2 + (S->use_c16 ? 1 : 0)) {
+        case 5: PA_LAUNCH_DOT(true, 2); break;
+        case 4: PA_LAUNCH_DOT(false, 2); break;
+        case 3: PA_LAUNCH_DOT(true, 1); break;
+        case 2: PA_LAUNCH_DOT(false, 1); break;
+        case 1: PA_LAUNCH_DOT(true, 0); break;
+        default: PA_LAUNCH_DOT(false, 0); break;
+      }
+#undef PA_LAUNCH_DOT
+    }
+    off += S->n_chunks;
+  }
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+static int64_t chunks_of(const pa_csr *A) {
+  int64_t n = 0;
+  for (const pa_csr *S = A; S; S = S->next) n += S->n_chunks;
+  return n;
+}
+static bool has_vdict(const pa_csr *A) {
+  for (const pa_csr *S = A; S; S = S->next) if (S->use_vdict) return true;
+  return false;
+}
+
+// the part's share of dot(b,c), reduced into the slot (two small launches)
+static int dot_finish(pa_ctx *c, int64_t n_partials, int slot, int accumulate) {
+  if (n_partials == 0) {
+    if (!accumulate) hipLaunchKernelGGL(k_fill, dim3(1), dim3(64), 0, c->s[0], c->d_scalar + slot, (int64_t)1, 0.0);
+  } else {
+    const int nb = grid_for(n_partials, 256 * 8, c->n_partials);
+    hipLaunchKernelGGL(k_sum_partial, dim3(nb), dim3(256), 0, c->s[0], c->d_dotpart, n_partials, c->d_partials);
+    hipLaunchKernelGGL(k_dot_final_slot, dim3(1), dim3(256), 0, c->s[0], c->d_partials, nb, c->d_scalar + slot, accumulate);
+  }
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+static int mul_dot_part(pa_matrix *m, pa_vec *cv, pa_vec *b, int slot, int accumulate, bool first_half, bool second_half) {
+  pa_ctx *c = m->ctx;
+  const int64_t noo = chunks_of(m->oo), noh = chunks_of(m->oh);
+  if (has_vdict(m->oo) || has_vdict(m->oh)) {       // (value-dictionary blocks: the plain product, then the dot as its own pass)
+    if (first_half) PA_TRY(pa_spmv(m->oo, b, PA_SEG_OWN, cv, PA_SEG_OWN, 1.0, 0.0));
+    if (second_half) {
+      PA_TRY(pa_spmv(m->oh, b, PA_SEG_GHOST, cv, PA_SEG_OWN, 1.0, 1.0));
+      PA_TRY(pa_vec_dot_slot(b, cv, slot, accumulate));
+    }
+    return PA_OK;
+  }
+  if (first_half) {
+    PA_TRY(dot_scratch(c, noo + noh));
+    PA_TRY(spmv_dot_block(m->oo, b->d, cv->d, 0.0, b->d, c->d_dotpart));
+  }
+  if (second_half) {
+    PA_TRY(spmv_dot_block(m->oh, b->d + b->n_own, cv->d, 1.0, b->d, c->d_dotpart + noo));
+    PA_TRY(dot_finish(c, noo + noh, slot, accumulate));
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_mul_dot(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, int slot, int accumulate) {
+  PA_TRY(mul_check(m, c, b));
+  PA_REQUIRE(c->d != b->d, "c and b alias");
+  PA_REQUIRE(PA_SLOT_OK(slot), "slot %d out of range [0,%d)", slot, PA_N_SLOTS);
+  PA_REQUIRE(b->n_own == c->n_own, "dot(b,c) needs a square operator: %lld columns, %lld rows", (long long)b->n_own, (long long)c->n_own);
+  if (!comm) {
+    PA_REQUIRE(m->plan->snd.nbr.empty() && m->plan->rcv.nbr.empty(), "the column plan has neighbours: pass the communicator");
+    PA_REQUIRE(m->plan->part == 0, "without a communicator the part must be the only one");
+  }
+  PA_HIP(hipSetDevice(m->ctx->device));
+  PA_TRY(pa_exchange_pack(m->plan, b, PA_CONSISTENT));
+  if (comm) PA_TRY(pa_exchange_rccl(m->plan, comm, PA_CONSISTENT));
+  else {
+    pa_plan *one[1] = {m->plan};
+    PA_TRY(pa_exchange_local(one, 1, PA_CONSISTENT));
+  }
+  PA_TRY(mul_dot_part(m, c, b, slot, accumulate, true, false));
+  PA_TRY(pa_exchange_finish(m->plan, b, PA_CONSISTENT));
+  PA_TRY(mul_dot_part(m, c, b, slot, accumulate, false, true));
+  return PA_OK;
+}
+
+// every part of one process: the slot ends up holding the sum over the parts, added in part order
+extern "C" int pa_mul_all_dot(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, int slot) {
+  PA_REQUIRE(m && c && b && n_parts > 0, "bad arguments");
+  PA_REQUIRE(PA_SLOT_OK(slot), "slot %d out of range [0,%d)", slot, PA_N_SLOTS);
+  std::vector<pa_plan *> plans(n_parts);
+  for (int r = 0; r < n_parts; ++r) {
+    PA_TRY(mul_check(m[r], c[r], b[r]));
+    PA_REQUIRE(c[r]->d != b[r]->d, "c and b alias (part %d)", r);
+    PA_REQUIRE(b[r]->n_own == c[r]->n_own, "dot(b,c) needs a square operator (part %d)", r);
+    PA_REQUIRE(m[r]->ctx == m[0]->ctx, "the parts of one call share a context");
+    plans[r] = m[r]->plan;
+  }
+  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], b[r], PA_CONSISTENT));
+  PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_CONSISTENT));
+  // the parts share the context's partial-sum scratch: part r's product + reduction run before part r+1's first half
+  // overwrites it (one stream: in order), so own x own of part r cannot wait for ALL exchanges as pa_mul_all's does --
+  // one part (the benchmark's case) loses nothing
+  for (int r = 0; r < n_parts; ++r) {
+    PA_TRY(mul_dot_part(m[r], c[r], b[r], slot, r > 0, true, false));
+    PA_TRY(pa_exchange_finish(plans[r], b[r], PA_CONSISTENT));
+    PA_TRY(mul_dot_part(m[r], c[r], b[r], slot, r > 0, false, true));
   }
   return PA_OK;
 }

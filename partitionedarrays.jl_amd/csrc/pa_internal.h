@@ -47,6 +47,8 @@ struct pa_ctx {
   double *d_partials = nullptr;
   int n_partials = 0;
   double *d_scalar = nullptr;
+  double *d_dotpart = nullptr;            // per-chunk partial sums of a fused product + dot (pa_mul_dot)
+  int64_t n_dotpart = 0;
   bool capturing = false;                 // a pa_graph_begin is open on the compute stream
   int comm_priority = 0;                  // priority the comm stream was created with (the device's greatest)
   pa_arena *arena = nullptr;              // contiguous HBM arena with its memory-class map (pa_arena.hip), built lazily

@@ -85,6 +85,29 @@ __device__ __forceinline__ int pa_pattern_col_uniform(int q, int nq, int qs, int
   return rs + (STRIDED ? (int)__umul24((unsigned)rr, (unsigned)stride) : rr) + del;
 }
 
+// Sum of a double over the 64 lanes of a wavefront, the same value returned in every lane, in a fixed order: four DPP
+// row_shr steps inside each row of 16 lanes (a few cycles each; __shfl_down goes through the LDS crossbar, ~100 cycles a
+// step -- on the one wavefront whose exit frees a workgroup's LDS that is 8 % of the product kernel), then the four
+// row totals read with v_readlane and added left to right.
+template <int CTRL>
+__device__ __forceinline__ double pa_dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double pa_wave_sum(double v) {
+  v = v + pa_dpp_move<0x111>(v);   // row_shr:1 (lanes without a source get 0)
+  v = v + pa_dpp_move<0x112>(v);   // row_shr:2
+  v = v + pa_dpp_move<0x114>(v);   // row_shr:4
+  v = v + pa_dpp_move<0x118>(v);   // row_shr:8 -> lane 15 of every row holds the row's sum
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double a = __hiloint2double(__builtin_amdgcn_readlane(hi, 15), __builtin_amdgcn_readlane(lo, 15));
+  const double b = __hiloint2double(__builtin_amdgcn_readlane(hi, 31), __builtin_amdgcn_readlane(lo, 31));
+  const double c = __hiloint2double(__builtin_amdgcn_readlane(hi, 47), __builtin_amdgcn_readlane(lo, 47));
+  const double d = __hiloint2double(__builtin_amdgcn_readlane(hi, 63), __builtin_amdgcn_readlane(lo, 63));
+  return ((a + b) + c) + d;
+}
+
 // y[row] = beta*y[row] + sum_p (val[p]*x[col[p]])*alpha, products summed in ascending p.
 //   BLK  threads per workgroup, NPT stored entries per lane (chunk capacity CAP = BLK*NPT products in LDS),
 //   NT   non-temporal matrix loads, C16 use the 16-bit column stream where the chunk has one,
@@ -96,6 +119,10 @@ __device__ __forceinline__ int pa_pattern_col_uniform(int q, int nq, int qs, int
 //           colouring: no row of the launch reads another row of the launch, only itself.
 //        2: fused residual + restriction, gs_x[r] = gs_b[row] - sum for the r-th stored (compacted) row: the coarse
 //           residual r_c = (r_f - A x_f) at the fine rows a coarse grid keeps (gs_x = r_c, gs_b = r_f, x_in = x_f).
+//        3: the product plus one term of a dot product: y as for EPI 0 (alpha = 1), and gs_x[chunk] = sum over the chunk's
+//           rows of gs_b[row] * (sum of the row's products) -- the per-chunk partial sums of u'(A x), u = gs_b, summed in a
+//           fixed order (row order per lane, shuffle tree, wave sums): deterministic.  The CG loop's u'c = dot(u, A u)
+//           (HPCG/src/ref_cg.jl:60) costs no pass over u and c this way.
 //   VD   value dictionary (optional, lossless): a block with at most PA_VDICT_MAX distinct stored values (bit patterns)
 //        keeps one byte per entry (`code`) and the values in `dict`; lane l holds dict[l] and an entry's value is fetched
 //        from the lane that holds it with ds_bpermute -- 1 byte of matrix stream per entry instead of 8.  The 27-point
@@ -132,9 +159,11 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
   if (p1 - base <= CAP) {
     // my first row's extent, fetched early so the latency hides under the matrix stream
     int ra = 0, re = 0;
+    double urow = 0.0;                       // EPI 3: u[my first row], fetched now so that the reduce phase does not wait for it
     if (r0 + tid < r1) {
       ra = crp[r0 + tid];
       re = crp[r0 + tid + 1];
+      if (EPI == 3) urow = gs_b[row_ids ? row_ids[r0 + tid] : r0 + tid];
     }
     // Unconditional loads: lanes past the chunk's end re-read its last pair (same address => no extra
     // traffic) and their products are never summed.  A guarded load would make the compiler wait for
@@ -268,16 +297,26 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       }
       return;
     }
+    double dacc = 0.0;                       // EPI 3: this lane's share of the dot product
     for (int r = r0 + tid; r < r1; r += BLK) {
       if (r != r0 + tid) {
         ra = crp[r];
         re = crp[r + 1];
       }
       const int row = row_ids ? row_ids[r] : r;
-      double acc = (EPI != 0 || beta == 0.0) ? 0.0 : beta * y[row];
+      double acc = ((EPI != 0 && EPI != 3) || beta == 0.0) ? 0.0 : beta * y[row];
       const int a = ra - base, e = re - base;
 #pragma unroll UNR
       for (int p = a; p < e; ++p) acc = acc + prod[p];
+      if (EPI == 3) {
+        double pr = acc;                     // the row's products alone (beta = 0: that is acc itself)
+        if (beta != 0.0) {
+          pr = 0.0;
+          for (int p = a; p < e; ++p) pr = pr + prod[p];
+        }
+        dacc = dacc + (r == r0 + tid ? urow : gs_b[row]) * pr;
+        __builtin_nontemporal_store(acc, &y[row]);
+      } else
       if (EPI == 1) gs_x[row] = gs_x[row] + (gs_b[row] - acc) / gs_diag[row];
       else if (EPI == 2) gs_x[r] = gs_b[row] - acc;
       else if (EPI == 7) { if (acc == 123.456) y[row] = acc; }   // probe only: the kernel without its y store
@@ -288,13 +327,28 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       // store (0.791 vs 0.820 ms; sc1 0.797, sc0 sc1 0.807, sc0 sc1 nt 0.842, no store at all 0.681)
       else __builtin_nontemporal_store(acc, &y[row]);
     }
+    if (EPI == 3) {
+      dacc = pa_wave_sum(dacc);
+      if (r1 - r0 <= 64) {                   // (block-uniform) every row sat in wavefront 0: the other three just leave
+        if (tid == 0) gs_x[chunk] = dacc;
+      } else {
+        __shared__ double wsum[BLK / 64];
+        if ((tid & 63) == 0) wsum[tid >> 6] = dacc;
+        __syncthreads();
+        if (tid == 0) {
+          double t = 0.0;
+          for (int w = 0; w < BLK / 64; ++w) t = t + wsum[w];
+          gs_x[chunk] = t;
+        }
+      }
+    }
   } else {
     // one long row (more stored entries than a chunk holds): windows of CAP products, summed by
     // lane 0 in ascending p so that even this path keeps the reference's order.
     const int row = row_ids ? row_ids[r0] : r0;
     const int *lcol = col + (PAT ? pdesc[chunk * PA_PDESC_INTS + 2] : 0);   // compacted 32-bit stream, see above
-    double acc = 0.0;
-    if (tid == 0) acc = (EPI != 0 || beta == 0.0) ? 0.0 : beta * y[row];
+    double acc = 0.0, accp = 0.0;
+    if (tid == 0) acc = ((EPI != 0 && EPI != 3) || beta == 0.0) ? 0.0 : beta * y[row];
     for (int w = p0; w < p1; w += CAP) {
       const int wend = min(w + CAP, p1);
       for (int idx = w + tid; idx < wend; idx += BLK) {
@@ -304,13 +358,19 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       }
       __syncthreads();
       if (tid == 0)
-        for (int p = 0; p < wend - w; ++p) acc = acc + prod[p];
+        for (int p = 0; p < wend - w; ++p) {
+          acc = acc + prod[p];
+          if (EPI == 3) accp = accp + prod[p];
+        }
       __syncthreads();
     }
     if (tid == 0) {
       if (EPI == 1) gs_x[row] = gs_x[row] + (gs_b[row] - acc) / gs_diag[row];
       else if (EPI == 2) gs_x[r0] = gs_b[row] - acc;
-      else y[row] = acc;
+      else {
+        y[row] = acc;
+        if (EPI == 3) gs_x[chunk] = gs_b[row] * accp;
+      }
     }
   }
 }

@@ -14,9 +14,9 @@ import numpy as np
 
 from . import _lib as L
 from .primitives import pmap
-from .p_sparse_matrix import mul_, mul_c_, mul_no_overlap_
+from .p_sparse_matrix import mul_, mul_c_, mul_dot_, mul_no_overlap_
 from .p_vector import (axpby_, copy_, dot, norm, similar, pzeros, consistent_, context, slots_supported, dot_slot,
-                       axpby_slot_, cg_update_, write_slot, read_slots)
+                       axpby_slot_, cg_update_, cg_r_update_, cg_xu_update_, write_slot, read_slots)
 
 mul_no_lat_ = mul_no_overlap_     # HPCG/src/hpcg_utils.jl:6-17: blocking consistent!, then the local product
 
@@ -264,13 +264,22 @@ def ldiv_(x, P: MgPreconditioner, b):
     return pc_solve_(x, P, b, P.l, zero_guess=True)
 
 
-def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_every=1, timer=None, graph=False, work=None):
-    """opt_cg! (HPCG/src/opt_cg.jl): the hook for an optimised solve.  Same PCG as ref_cg_ -- the same kernels'
-    arithmetic in the same order, so the iterates are bit-identical -- scheduled for the GPU: rho, u'c and |r|^2 stay
-    in device slots (no blocking reduction per dot, ref_cg.jl:52,60,67), the three statements :64-67 are one pass
-    (pa_cg_update), mul! hides the exchange behind own*own, and with the identity preconditioner the copy c = r and
-    rho = dot(c,r) are not repeated (rho is the |r|^2 the update just produced).  The host reads the residual only
-    when it needs it: every `check_every` iterations if tolerance > 0 or a history is kept, else once at the end.
+def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_every=1, timer=None, graph=False, work=None,
+            fuse=True):
+    """opt_cg! (HPCG/src/opt_cg.jl): the hook for an optimised solve.  Same PCG as ref_cg_, scheduled for the GPU: rho,
+    u'c and |r|^2 stay in device slots (no blocking reduction per dot, ref_cg.jl:52,60,67), mul! hides the exchange behind
+    own*own, and with the identity preconditioner the copy c = r and rho = dot(c,r) are not repeated (rho is the |r|^2
+    the update just produced).  The host reads the residual only when it needs it: every `check_every` iterations if
+    tolerance > 0 or a history is kept, else once at the end.
+
+    fuse=True (default) takes three passes over the vectors out of every iteration:
+      * u'c is accumulated inside the product kernels (mul_dot_: every workgroup adds u[row] * its rows' sums) -- no
+        dot pass.  Deterministic, but another summation order than dot(u,c): alpha, hence the iterates, agree with
+        ref_cg_'s to rounding (scalars ~1e-15 relative per iteration; tests/…opt_cg_fused… bounds the drift), not bit for bit;
+      * x .+= alpha .* u waits until u is about to change and shares a pass with u .= z .+ beta .* u (cg_xu_update_; x is
+        not read inside the loop, so this alone keeps every bit); r .-= alpha .* c with |r|^2 is the other pass.
+    fuse=False keeps the dot as its own kernel and the three statements ref_cg.jl:64-67 in one pass (pa_cg_update): the
+    same kernels' arithmetic in ref_cg_'s order -- iterates bit-identical to ref_cg_ (tested).
     HPCG runs this to the reference tolerance and charges extra iterations (HPCG/src/hpcg_benchmark.jl:60-78).
     graph=True (fixed iteration count, identity preconditioner, a single part): three iterations -- one
     period of the slot rotation -- are recorded into a hipGraph once and replayed; for small parts, where an iteration is
@@ -292,26 +301,62 @@ def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_ev
     residual0 = residual = read_slots(s_rr)[0] ** 0.5
     write_slot(s_rho, 1.0)
     iters = 0
+    pending = [None]                                         # (num, den) slots of the alpha whose x .+= alpha .* u is still due
+
+    def product(s_uc_):
+        """c = A*u and s_uc = u'c"""
+        if not (fuse and mul_dot_(c, A, u, s_uc_)):
+            mul_c_(c, A, u)                                      # mul! queued by one library call
+            dot_slot(u, c, s_uc_)
+
+    def iteration(s_rho_, s_prev_, s_rr_, z):
+        """ref_cg.jl:56-67 given rho in s_rho_, the previous rho in s_prev_; leaves |r|^2 in s_rr_"""
+        if fuse:
+            with tm.span("WAXPBY"):
+                if pending[0] is None:
+                    axpby_slot_(u, 1.0, ONE, ONE, z, 1.0, s_rho_, s_prev_)   # u .= z .+ (rho/rho_prev) .* u
+                else:
+                    cg_xu_update_(x, u, z, pending[0][0], pending[0][1], s_rho_, s_prev_)
+            with tm.span("SPMV"):
+                product(s_uc)
+            with tm.span("WAXPBY"):
+                cg_r_update_(r, c, s_rho_, s_uc, s_rr_)              # alpha = rho/u'c
+            pending[0] = (s_rho_, s_uc)
+        else:
+            with tm.span("WAXPBY"):
+                axpby_slot_(u, 1.0, ONE, ONE, z, 1.0, s_rho_, s_prev_)
+            with tm.span("SPMV"):
+                mul_c_(c, A, u)
+            with tm.span("DDOT"):
+                dot_slot(u, c, s_uc)
+            with tm.span("WAXPBY"):                                  # (carries the |r|^2 reduction of :67 as well)
+                cg_update_(x, r, u, c, s_rho_, s_uc, s_rr_)
+
+    def flush():
+        if pending[0] is not None:                           # the last x .+= alpha .* u
+            axpby_slot_(x, 1.0, pending[0][0], pending[0][1], u, 1.0, ONE, ONE)
+            pending[0] = None
+
     from .primitives import DebugArray
-    if graph and Pl is None and tolerance == 0.0 and history is None and timer is None and maxiter >= 6 \
+    if graph and Pl is None and tolerance == 0.0 and history is None and timer is None and maxiter >= 7 \
             and isinstance(x.vector_partition, DebugArray) and len(x.vector_partition.items) == 1:
         # (one part only: capturing the inter-part copies of several parts made hipStreamEndCapture of ROCm 7.0 crash)
         from .p_vector import Graph
-        mul_c_(c, A, u)                                      # (creates the operator handles outside the capture)
+        s = [s_rho, s_prev, s_rr]
+        s[1], s[0], s[2] = s[0], s[2], s[1]                  # one eager iteration: creates the operator handles and the
+        iteration(s[0], s[1], s[2], r)                       # fused dot's scratch outside the capture, and leaves an
+        iters += 1                                           # x update pending like every iteration after it
 
         def three():                                         # slots after 3 iterations are where they started
-            s = [s_rho, s_prev, s_rr]
             for _ in range(3):
                 s[1], s[0], s[2] = s[0], s[2], s[1]
-                axpby_slot_(u, 1.0, ONE, ONE, r, 1.0, s[0], s[1])
-                mul_c_(c, A, u)
-                dot_slot(u, c, s_uc)
-                cg_update_(x, r, u, c, s[0], s_uc, s[2])
+                iteration(s[0], s[1], s[2], r)
         with Graph() as g:
             three()
         while iters + 3 <= maxiter:
             g.launch()
             iters += 3
+        s_rho, s_prev, s_rr = s
     while not (iters >= maxiter or _converged(residual, residual0, tolerance)):
         if Pl is None:
             s_prev, s_rho, s_rr = s_rho, s_rr, s_prev        # rho_prev = rho; rho = dot(r,r), already on the device
@@ -323,19 +368,13 @@ def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_ev
             with tm.span("DDOT"):
                 dot_slot(c, r, s_rho)
             z = c
-        with tm.span("WAXPBY"):
-            axpby_slot_(u, 1.0, ONE, ONE, z, 1.0, s_rho, s_prev)   # u .= z .+ (rho/rho_prev) .* u
-        with tm.span("SPMV"):
-            mul_c_(c, A, u)                                      # mul! queued by one library call
-        with tm.span("DDOT"):
-            dot_slot(u, c, s_uc)
-        with tm.span("WAXPBY"):                                  # (carries the |r|^2 reduction of :67 as well)
-            cg_update_(x, r, u, c, s_rho, s_uc, s_rr)            # alpha = rho/u'c
+        iteration(s_rho, s_prev, s_rr, z)
         iters += 1
         if history is not None or (tolerance > 0.0 and iters % check_every == 0):
             residual = read_slots(s_rr)[0] ** 0.5
             if history is not None:
                 history.append(residual)
+    flush()
     residual = read_slots(s_rr)[0] ** 0.5
     return x, residual0, residual, iters
 

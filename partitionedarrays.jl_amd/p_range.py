@@ -225,8 +225,11 @@ def _block_starts(np_, n):
                  for npd, nd in zip(np_, n))
 
 
-def uniform_partition(ranks, np_, n, ghost=None, periodic=None):
-    """uniform_partition(ranks,np,n[,ghost[,periodic]]) (src/p_range.jl:585-671)."""
+def uniform_partition(ranks, np_, n=None, ghost=None, periodic=None):
+    """uniform_partition(ranks,np,n[,ghost[,periodic]]) (src/p_range.jl:585-671); uniform_partition(ranks,n) is
+    uniform_partition(ranks,length(ranks),n) (:601-603)."""
+    if n is None:
+        np_, n = len(ranks), np_
     if isinstance(np_, (int, np.integer)):
         np_, n = (int(np_),), (int(n),)
         ghost = None if ghost is None else (int(ghost),)

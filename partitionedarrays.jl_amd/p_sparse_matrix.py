@@ -290,6 +290,34 @@ def mul_c_(c: PVector, a: PSparseMatrix, b: PVector, alpha=1.0, beta=0.0) -> PVe
     return c
 
 
+def mul_dot_(c: PVector, a: PSparseMatrix, b: PVector, slot: int) -> bool:
+    """c = a*b as mul! does it AND slot <- dot(b,c), the dot accumulated inside the product kernels (pa_mul_dot /
+    pa_mul_all_dot): the c = A*u, u'c pair of a CG iteration (HPCG/src/ref_cg.jl:59-60) without the dot's pass over u
+    and c.  c is bit-identical to mul!'s; the dot agrees with dot(b,c) to rounding (another summation order).  Returns
+    False -- having done nothing -- when the operator-level call does not apply (sub-assembled matrix, host-staged
+    transport, rectangular operator): the caller then uses mul_c_ and dot_slot."""
+    from .primitives import DebugArray, TorchDistArray
+    from . import p_vector as pv
+    _check_axes(c, a, b)
+    vp = b.vector_partition
+    if not a.assembled or not (isinstance(vp, DebugArray) or (isinstance(vp, TorchDistArray) and (
+            vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None)))):
+        return False
+    from .primitives import local_items
+    if any(bv.n_own != cv.n_own for bv, cv in zip(local_items(vp), local_items(c.vector_partition))):
+        return False
+    hs = _operator_handles(a, b)
+    if isinstance(vp, DebugArray):
+        n = len(vp.items)
+        arr = lambda xs: (C.c_void_p * n)(*xs)
+        L.call("pa_mul_all_dot", arr(hs.items), n, arr([v.h for v in c.vector_partition.items]), arr([v.h for v in vp.items]), slot)
+    else:
+        comm = context().comm.h if (vp.size > 1) else None
+        L.call("pa_mul_dot", hs.item, comm, c.vector_partition.item.h, vp.item.h, slot, 0)
+        pv._slot_allreduce(vp, slot)
+    return True
+
+
 def mul5_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PVector:
     """mul!(c,a,b,alpha,beta) (src/p_sparse_matrix.jl:2105-2142), assembled and sub-assembled."""
     _check_axes(c, a, b)

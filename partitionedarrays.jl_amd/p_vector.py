@@ -695,6 +695,23 @@ def cg_update_(x: PVector, r: PVector, u: PVector, c: PVector, num: int, den: in
             L.call("pa_cg_update", a.h, b.h, d.h, e.h, num, den, rr_slot, int(k > 0))
 
 
+def cg_r_update_(r: PVector, c: PVector, num: int, den: int, rr_slot: int) -> None:
+    """r .-= alpha .* c; slot[rr_slot] = dot(r,r), alpha = s[num]/s[den] (ref_cg.jl:65-67; pa_cg_r_update)."""
+    vr = r.vector_partition
+    if isinstance(vr, TorchDistArray):
+        L.call("pa_cg_r_update", vr.item.h, c.vector_partition.item.h, num, den, rr_slot, 0)
+        _slot_allreduce(vr, rr_slot)
+    else:
+        for k, (a, b) in enumerate(zip(vr.items, c.vector_partition.items)):
+            L.call("pa_cg_r_update", a.h, b.h, num, den, rr_slot, int(k > 0))
+
+
+def cg_xu_update_(x: PVector, u: PVector, z: PVector, a_num: int, a_den: int, b_num: int, b_den: int) -> None:
+    """x .+= (s[a_num]/s[a_den]) .* u, then u .= z .+ (s[b_num]/s[b_den]) .* u, one pass (pa_cg_xu_update)."""
+    pmap(lambda xv, uv, zv: L.call("pa_cg_xu_update", xv.h, uv.h, zv.h, a_num, a_den, b_num, b_den),
+         x.vector_partition, u.vector_partition, z.vector_partition)
+
+
 def write_slot(slot: int, value: float) -> None:
     L.call("pa_ctx_write_slot", context().h, slot, float(value))
 
