@@ -494,144 +494,3 @@ def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None, Pl=N
         if history is not None:
             history.append(residual)
     return x, residual0, residual, iters
-
-
-# ----------------------------------------------------------------------------------------------
-# the benchmark driver and its report (HPCG/src/hpcg_benchmark.jl, HPCG/src/report_results.jl)
-# ----------------------------------------------------------------------------------------------
-def hpcg_geometry(np_, l, nx, ny, nz):
-    """Geometry (HPCG/src/mg_preconditioner.jl:17-26): per level (index 0 = coarsest) global rows and stored entries
-    of the 27-point operator, closed form: prod(g_d) rows, prod(3 g_d - 2) entries."""
-    from .gallery import compute_optimal_shape_XYZ
-    npx, npy, npz = compute_optimal_shape_XYZ(np_)
-    nrows, nnz = [], []
-    for lev in range(l):
-        f = 2 ** (l - 1 - lev)
-        g = (npx * nx // f, npy * ny // f, npz * nz // f)
-        nrows.append(g[0] * g[1] * g[2])
-        nnz.append((3 * g[0] - 2) * (3 * g[1] - 2) * (3 * g[2] - 2))
-    return dict(nx=nx, ny=ny, nz=nz, npx=npx, npy=npy, npz=npz, nnz=nnz, nrows=nrows)
-
-
-def hpcg_report(np_, times, levels, ref_max_iters, opt_max_iters, nr_cg_sets, norm_data, geom):
-    """report_results (HPCG/src/report_results.jl:21-144): the flop and byte models of the official benchmark and its
-    GFLOP/s rating.  `times`: dict total/DDOT/WAXPBY/SPMV/MG/setup/opt_time/ref_time in seconds (timing_data[1..10])."""
-    fniters = nr_cg_sets * opt_max_iters
-    fnrow, fnnz = float(geom["nrows"][levels - 1]), float(geom["nnz"][levels - 1])
-    ops_ddot = (3.0 * fniters + nr_cg_sets) * 2.0 * fnrow
-    ops_waxpby = (3.0 * fniters + nr_cg_sets) * 2.0 * fnrow
-    ops_spmv = (fniters + nr_cg_sets) * 2.0 * fnnz
-    ops_mg = 0.0
-    for i in range(1, levels):                               # levels 2..l of the reference
-        ops_mg += fniters * (4.0 + 2.0 + 4.0) * geom["nnz"][i]
-    ops_mg += fniters * 4.0 * geom["nnz"][0]
-    ops = ops_ddot + ops_waxpby + ops_spmv + ops_mg
-    ref_ops = ops * (ref_max_iters / opt_max_iters)
-    f8, i8 = 8.0, 8.0                                        # sizeof(Float64), sizeof(Int64): the model's, not ours
-    reads = (3.0 * fniters + nr_cg_sets) * 2.0 * fnrow * f8 * 2 + (fniters + nr_cg_sets) * (fnnz * (f8 + i8) + fnrow * f8)
-    writes = (3.0 * fniters + nr_cg_sets) * f8 + (3.0 * fniters + nr_cg_sets) * fnrow * f8 + (fniters + nr_cg_sets) * fnrow * f8
-    for i in range(1, levels):
-        nz, nr = float(geom["nnz"][i]), float(geom["nrows"][i])
-        reads += fniters * (2.0 * nz * (f8 + i8) + nr * f8) * 2 + fniters * (nz * (f8 + i8) + nr * f8)
-        writes += fniters * nz * f8 * 3
-    reads += fniters * (2.0 * geom["nnz"][0] * (f8 + i8) + geom["nrows"][0] * f8)
-    writes += fniters * geom["nrows"][0] * f8
-    ref_rw = (reads + writes) * ref_max_iters / opt_max_iters
-    overhead = times["total"] + nr_cg_sets * (times["opt_time"] / 10.0 + times["setup"] / 10.0)
-    norm_data = np.asarray(norm_data, dtype=np.float64)
-    gf = lambda o, t: (o / t / 1e9) if t > 0 else float("nan")
-    return {
-        "procs": np_, "times": dict(times), "nr_equations": int(fnrow), "non_zeros": int(fnnz),
-        "multigrid_data": {f"level_{i + 1}": {"non_zeros": geom["nnz"][i], "nr_equations": geom["nrows"][i]} for i in range(levels)},
-        "geometry": {k: geom[k] for k in ("npx", "npy", "npz", "nx", "ny", "nz")},
-        "iter_data": {"ref_iters_set": ref_max_iters, "opt_iters_set": opt_max_iters,
-                      "ref_iters_total": ref_max_iters * nr_cg_sets, "opt_iters_total": opt_max_iters * nr_cg_sets},
-        "reproducibility_data": {"mean": float(norm_data.mean()), "var": float(norm_data.var(ddof=1)) if len(norm_data) > 1 else 0.0},
-        "flops": {"DDOT": ops_ddot, "WAXPBY": ops_waxpby, "SpMV": ops_spmv, "MG": ops_mg, "Total": ops, "Total_conv": ref_ops},
-        "GB/s": {"Read": reads / times["total"] / 1e9, "Write": writes / times["total"] / 1e9,
-                 "Total": (reads + writes) / times["total"] / 1e9, "Total_conv_opt": ref_rw / overhead / 1e9},
-        "GFLOP/s": {"DDOT": gf(ops_ddot, times["DDOT"]), "WAXPBY": gf(ops_waxpby, times["WAXPBY"]),
-                    "SpMV": gf(ops_spmv, times["SPMV"]), "MG": gf(ops_mg, times["MG"]),
-                    "Total": ops / times["total"] / 1e9, "Total_conv": ref_ops / times["total"] / 1e9,
-                    "Total_conv_opt": ref_ops / overhead / 1e9},
-        "Overview": {"GFLOP/s": ref_ops / overhead / 1e9, "time": times["total"]},
-    }
-
-
-def hpcg_benchmark(ranks, np_, nx, ny, nz, total_runtime=60.0, levels=4, ref_max_iters=50, ref_ordering="sequential",
-                   opt_ordering="multicolor_spmv", max_sets=None, output_type="none", output_folder="results"):
-    """hpcg_benchmark(distribute,np,nx,ny,nz;total_runtime) (HPCG/src/hpcg_benchmark.jl:28-116), three phases:
-      reference   : two sets of `ref_max_iters` MG-PCG iterations with the reference's smoother -> ref_tol = |r|/|r0|;
-      optimisation: the optimised solver (multicolour smoother, opt_cg_) runs to ref_tol; the iterations it needs
-                    (>= ref_max_iters) are what every timed set must perform -- extra iterations are charged;
-      timing      : ceil(total_runtime / worst set time) sets of that many iterations.
-    Returns the report dictionary of hpcg_report (and writes it when output_type is "json" or "txt")."""
-    import time
-    from .primitives import getany, reduction
-    ctx = context()
-
-    def elapsed(f):
-        ctx.sync()
-        t = time.perf_counter()
-        out = f()
-        ctx.sync()
-        return time.perf_counter() - t, out
-
-    pmax = lambda v: float(getany(reduction(max, pmap(lambda _r: v, ranks), destination="all")))
-    t_setup, S_ref = elapsed(lambda: pc_setup(ranks, np_, levels, nx, ny, nz, ordering=ref_ordering))
-    geom = hpcg_geometry(np_, levels, nx, ny, nz)
-    A, b = S_ref.A_vec[-1], S_ref.r[-1]
-    ref_timer = CgTimer()
-    t_ref = 0.0
-    for _ in range(2):
-        dt, (x, normr0, normr, iters) = elapsed(lambda: ref_cg_(pzeros(A.col_partition), A, b, maxiter=ref_max_iters,
-                                                                 tolerance=0.0, overlap=False, Pl=S_ref, timer=ref_timer))
-        t_ref += dt
-    ref_ms = ref_timer.resolve()
-    ref_tol = normr / normr0
-    del S_ref, x
-
-    t_opt_setup, S = elapsed(lambda: pc_setup(ranks, np_, levels, nx, ny, nz, ordering=opt_ordering))
-    A, b = S.A_vec[-1], S.r[-1]
-    opt_n_iters, worst = ref_max_iters, 0.0
-    for _ in range(2):
-        dt, (x, normr0, normr, iters) = elapsed(lambda: opt_cg_(pzeros(A.col_partition), A, b, maxiter=10 * ref_max_iters,
-                                                                 tolerance=ref_tol, Pl=S))
-        if normr / normr0 > ref_tol:
-            raise L.PAError(f"the optimised solver did not reach the reference tolerance {ref_tol:.3e} in {iters} iterations")
-        opt_n_iters, worst = max(opt_n_iters, iters), max(worst, dt)
-    worst = pmax(worst)
-    nr_sets = max(1, int(np.ceil(total_runtime / worst)))
-    if max_sets is not None:
-        nr_sets = min(nr_sets, max_sets)
-    timer = CgTimer()
-    norm_data, total = [], 0.0
-    for _ in range(nr_sets):
-        dt, (x, normr0, normr, iters) = elapsed(lambda: opt_cg_(pzeros(A.col_partition), A, b, maxiter=opt_n_iters,
-                                                                 tolerance=0.0, Pl=S, timer=timer))
-        norm_data.append(normr / normr0)
-        total += dt
-    ms = timer.resolve()
-    times = {"total": pmax(total), "DDOT": ms["DDOT"] / 1e3, "WAXPBY": ms["WAXPBY"] / 1e3, "SPMV": ms["SPMV"] / 1e3,
-             "MG": ms["MG"] / 1e3, "setup": pmax(t_setup), "opt_time": pmax(t_opt_setup),
-             "ref_time": (ref_ms["SPMV"] + ref_ms["MG"]) / 1e3 / 2}
-    rep = hpcg_report(np_, times, levels, ref_max_iters, opt_n_iters, nr_sets, norm_data, geom)
-    rep["reference_phase"] = {"ref_tol": ref_tol, "seconds_per_set": t_ref / 2, "ordering": ref_ordering}
-    rep["optimised_phase"] = {"ordering": opt_ordering, "iterations_to_ref_tol": opt_n_iters, "worst_set_seconds": worst}
-    if output_type != "none" and getany(pmap(lambda r: r, ranks)) == 1:
-        import json
-        import os
-        os.makedirs(output_folder, exist_ok=True)
-        stamp = time.strftime("%Y-%m-%d_%H-%M-%S")
-        path = os.path.join(output_folder, f"hpcg-benchmark_results{stamp}.{output_type}")
-        with open(path, "w") as f:
-            if output_type == "json":
-                json.dump(rep, f, indent=1)
-            else:
-                f.write("########## Problem Summary  ##########\n")
-                for k in ("procs", "nr_equations", "non_zeros", "geometry", "iter_data", "reproducibility_data", "times",
-                          "flops", "GB/s", "GFLOP/s"):
-                    f.write(f"{k}: {rep[k]}\n")
-                f.write(f"HPCG result is VALID with a GFLOP/s rating of: {rep['Overview']['GFLOP/s']}\n")
-        rep["file"] = path
-    return rep

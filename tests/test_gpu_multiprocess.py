@@ -10,3 +10,49 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("nproc", [2, 4, 8])
 def test_device_path_one_part_per_process(nproc):
     _run("device_path_driver.py", nproc, {"PA_TRANSPORT": "host"})
+
+
+def _bench(nproc, env, args=()):
+    import json
+    import os
+    import subprocess
+    import sys
+    from test_multiprocess_gloo import ROOT, _free_port
+    e = dict(os.environ, OMP_NUM_THREADS="1", PA_HOST_THREADS="1")
+    e.update(env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "5", "--warmup", "1",
+           "--grid", "32", "--cg-iters", "3", "--cpu-seconds", "0.5", *args]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_line_of_a_multi_rank_run_carries_every_field():
+    """`bench.py --gpus 2` with both ranks on this box's one GPU (host-staged transport): the line carries
+    the transport, the overlap on/off comparison, the stream priorities, the moved-bytes roofline and a CPU baseline on 2
+    cores (one pinned process per part, exchanging over gloo)."""
+    r, d = _bench(2, {"PA_TRANSPORT": "host", "PA_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["transport"].startswith("host-staged")
+    assert d["config"]["overlap"] is True and set(d["overlap"]) >= {"ms_per_step_on", "ms_per_step_off"}
+    pr = d["config"]["stream_priority"]
+    assert pr["comm"] == pr["greatest"] and pr["compute"] == pr["least"]
+    rf = d["roofline"]
+    assert rf["moved_bytes_per_launch"] < rf["algorithmic_bytes_per_launch"] and 0 < rf["frac_moved"] and rf["median_launch_ms"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == 2 and cb["kind"] == "port" and cb["ms_per_mul"] > 0 and cb["c1_debugarray"]["cores"] == 1
+    assert d["cg_loop"]["ms_per_iteration_opt_cg"] > 0
+    r2, d2 = _bench(2, {"PA_TRANSPORT": "host", "PA_BENCH_BACKEND": "gloo"}, ("--no-overlap", "--no-cpu-baseline"))
+    assert r2.returncode == 0 and d2["config"]["overlap"] is False and d2["overlap"]["headline_uses"] == "off"
+
+
+def test_bench_refuses_to_downgrade_the_rccl_transport_silently():
+    """Two ranks on ONE GPU cannot form an RCCL communicator: the run must end with a non-zero status and no line --
+    never a line that measured another transport under the RCCL row's name.  With PA_ALLOW_TRANSPORT_FALLBACK=1 it
+    continues on torch.distributed p2p and says so (that, too, needs distinct GPUs: only the refusal is checked here)."""
+    # (torch's own process group on gloo, so that the first RCCL communicator of the run is libpa_hip's: ncclCommInitRank
+    # with two ranks on one device fails, which is the situation the refusal exists for)
+    r, d = _bench(2, {"PA_TRANSPORT": "rccl", "PA_BENCH_BACKEND": "gloo", "PA_BENCH_WATCHDOG_S": "240"}, ("--no-cpu-baseline",))
+    assert r.returncode != 0 and d is None, r.stdout[-2000:]
+    assert "refusing to downgrade" in r.stderr, r.stderr[-3000:]
