@@ -82,13 +82,15 @@ int pa_ctx_stream_priority(pa_ctx *ctx, int which, int *priority, int *least, in
  * stream (the values) comes from runs 13-15 % slower than with y in either other class.  So a context keeps ONE
  * physically contiguous arena (PA_ARENA_FRACTION of the free memory, default 0.70; PA_ARENA_GIB; PA_ARENA=0: none),
  * maps its classes once with a stand-in kernel (~0.2 s, when the first allocation >= PA_ARENA_MIN_MIB = 256 arrives)
- * and serves every buffer >= 1 MiB from it by rule: matrix streams (pa_csr_create*) from class 0, vectors
- * (pa_vec_create) from classes 1 / 2.  Nothing is timed at the caller's expense and nothing ever moves.
- * pa_ctx_arena_info: size, number of classes found (1: no structure seen), usable bytes per class, bytes in use, map time.
+ * and serves every buffer >= 1 MiB from it by rule: matrix streams (pa_csr_create*) from the class with the most
+ * room, vectors (pa_vec_create) from the two others.  Nothing is timed at the caller's expense and nothing ever moves.
+ * pa_ctx_arena_info: size, number of classes found (1: no structure seen), usable bytes per class, bytes in use, map time,
+ * the class matrix streams go to.
  * pa_ctx_arena_map: class of every cell (-1: a boundary runs through it).  pa_ctx_arena_build forces the set-up now.
  * pa_csr_memory_class / pa_vec_memory_class: class of a block's value stream / a vector's storage (-1: outside). */
 int pa_ctx_arena_build(pa_ctx *ctx);
-int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class_bytes[3], int64_t *used, double *map_ms);
+int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class_bytes[3], int64_t *used, double *map_ms,
+                      int *matrix_class);
 int pa_ctx_arena_map(pa_ctx *ctx, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells);
 int pa_csr_memory_class(const pa_csr *A, int *cls);
 int pa_vec_memory_class(const pa_vec *v, int *cls);

@@ -10,9 +10,10 @@
 // class.  Neither virtual addresses nor allocation order predict the class; a 40 us stand-in kernel does (a 1 : 27
 // write : read stream pair, the product's ratio) -- so the context maps its arena once (~0.2 s, at the first allocation
 // of 256 MiB or more) and then places by rule, with no timing of the caller's kernels and no moving of vectors:
-//     matrix streams (values, columns, row pointers, descriptors)  -> class 0 (the class of the arena's first cell)
-//     vectors                                                        -> classes 1 and 2, alternating
-// A request that no run of its preferred classes holds takes the other classes, then plain hipMalloc.
+//     matrix streams (values, columns, row pointers, descriptors)  -> the class with the most room in the arena
+//     vectors                                                        -> the two other classes, alternating
+// A request that no run of its preferred classes holds takes another class (matrix streams the one with fewer vectors,
+// vectors the one with fewer matrix streams), then plain hipMalloc.  Classes are numbered in the order the map meets them.
 // Replaces round 1's pa_csr_tune_placement (a search over hipMalloc'ed copies that found a fast pair on two boxes of three).
 #include <hip/hip_runtime.h>
 
@@ -54,8 +55,11 @@ struct pa_arena {
   struct blk { size_t len; int cls; };
   std::map<size_t, blk> free_;             // offset -> free block (never spans a class change)
   std::map<size_t, blk> live_;             // offset -> allocated block
+  std::map<size_t, int> live_kind_;        // offset -> PA_MEM_MATRIX / PA_MEM_VECTOR
   size_t used = 0, peak = 0;
-  int next_vec_class = 1;
+  int matrix_class = 0;                    // the class with the most room: where matrix streams go
+  size_t mat_bytes[3] = {0, 0, 0}, vec_bytes[3] = {0, 0, 0};   // what lives where (by kind)
+  unsigned vec_turn = 0;                   // vectors alternate between the two other classes while both are free of matrix streams
 };
 
 static constexpr size_t ARENA_ALIGN = (size_t)256 << 10;
@@ -180,6 +184,8 @@ static int arena_build(pa_ctx *c) {
     }
     i = j;
   }
+  for (int k = 1; k < 3; ++k)
+    if (a->class_bytes[k] > a->class_bytes[a->matrix_class]) a->matrix_class = k;
   a->map_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   c->arena = a;
   if (getenv("PA_SETUP_TIMING")) {
@@ -215,14 +221,26 @@ int pa_dev_alloc(pa_ctx *c, void **p, size_t bytes, int kind) {
   if (kind != PA_MEM_PLAIN && bytes >= small) {
     if (!c->arena && !c->arena_tried && bytes >= first_big) PA_TRY(arena_build(c));
     if (pa_arena *a = c->arena) {
-      int order[3] = {0, 2, 1};                                           // matrix streams: class 0, then 2, then 1
-      if (kind == PA_MEM_VECTOR) {
-        if (a->n_classes >= 3) { order[0] = a->next_vec_class; order[1] = 3 - a->next_vec_class; order[2] = 0; }
-        else { order[0] = 1; order[1] = 2; order[2] = 0; }
+      // The rule: a vector never shares a class with a matrix stream.  Matrix streams fill the roomiest class first and
+      // spill into the class that holds fewer vectors; vectors take the other classes -- alternating while both are
+      // free of matrix streams (BLAS-1 kernels, too, run 3-6 % faster when what they write is not where they read) --
+      // and end up next to matrix streams only when nothing else is left.
+      const int M = a->matrix_class, o1 = (M + 1) % 3, o2 = (M + 2) % 3;
+      int order[3];
+      if (kind == PA_MEM_MATRIX) {
+        order[0] = M;
+        order[1] = a->vec_bytes[o1] <= a->vec_bytes[o2] ? o1 : o2;
+        order[2] = order[1] == o1 ? o2 : o1;
+      } else {
+        int first = a->mat_bytes[o1] < a->mat_bytes[o2] ? o1 : a->mat_bytes[o2] < a->mat_bytes[o1] ? o2 : ((a->vec_turn++ & 1) ? o2 : o1);
+        order[0] = first;
+        order[1] = first == o1 ? o2 : o1;
+        order[2] = M;
       }
       for (int k = 0; k < 3; ++k)
         if ((*p = arena_take(a, bytes, order[k])) != nullptr) {
-          if (kind == PA_MEM_VECTOR && a->n_classes >= 3 && k == 0) a->next_vec_class = 3 - a->next_vec_class;
+          (kind == PA_MEM_MATRIX ? a->mat_bytes : a->vec_bytes)[order[k]] += (bytes + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
+          a->live_kind_[(size_t)((char *)*p - a->base)] = kind;
           return PA_OK;
         }
     }
@@ -242,6 +260,12 @@ void pa_dev_free(pa_ctx *c, void *p) {
     const int cls = it->second.cls;
     a->live_.erase(it);
     a->used -= len;
+    auto kd = a->live_kind_.find(off);
+    if (kd != a->live_kind_.end()) {
+      size_t *acct = kd->second == PA_MEM_MATRIX ? a->mat_bytes : a->vec_bytes;
+      acct[cls] -= std::min(acct[cls], len);
+      a->live_kind_.erase(kd);
+    }
     size_t start = off;
     auto nx = a->free_.find(off + len);           // merge with free neighbours of the same class (never across a boundary cell)
     if (nx != a->free_.end() && nx->second.cls == cls && a->cls[(off + len) / a->cell] == cls && a->cls[(off + len - 1) / a->cell] == cls) {
@@ -277,7 +301,7 @@ void pa_arena_destroy(pa_ctx *c) {
 }
 
 extern "C" int pa_ctx_arena_info(pa_ctx *c, int64_t *bytes, int *n_classes, int64_t class_bytes[3], int64_t *used,
-                                 double *map_ms) {
+                                 double *map_ms, int *matrix_class) {
   PA_REQUIRE(c != nullptr, "ctx is NULL");
   const pa_arena *a = c->arena;
   if (bytes) *bytes = a ? (int64_t)a->size : 0;
@@ -285,6 +309,7 @@ extern "C" int pa_ctx_arena_info(pa_ctx *c, int64_t *bytes, int *n_classes, int6
   if (class_bytes) for (int k = 0; k < 3; ++k) class_bytes[k] = a ? (int64_t)a->class_bytes[k] : 0;
   if (used) *used = a ? (int64_t)a->used : 0;
   if (map_ms) *map_ms = a ? a->map_ms : 0.0;
+  if (matrix_class) *matrix_class = a ? a->matrix_class : -1;
   return PA_OK;
 }
 

@@ -63,15 +63,15 @@ class Context:
         class, GiB in use, map time, and the class of every 512 MiB cell as a string ('.' = a boundary cell)."""
         if build:
             L.call("pa_ctx_arena_build", self.h)
-        size, used, ncls, ms = C.c_int64(), C.c_int64(), C.c_int(), C.c_double()
+        size, used, ncls, ms, mcls = C.c_int64(), C.c_int64(), C.c_int(), C.c_double(), C.c_int()
         per = (C.c_int64 * 3)()
-        L.call("pa_ctx_arena_info", self.h, C.byref(size), C.byref(ncls), per, C.byref(used), C.byref(ms))
+        L.call("pa_ctx_arena_info", self.h, C.byref(size), C.byref(ncls), per, C.byref(used), C.byref(ms), C.byref(mcls))
         n, cell = C.c_int64(), C.c_int64()
         L.call("pa_ctx_arena_map", self.h, C.byref(cell), None, 0, C.byref(n))
         cells = np.zeros(max(n.value, 1), np.int8)
         L.call("pa_ctx_arena_map", self.h, C.byref(cell), L.ptr(cells), n.value, C.byref(n))
         G = float(1 << 30)
-        return dict(gib=round(size.value / G, 1), classes=ncls.value, class_gib=[round(v / G, 1) for v in per],
+        return dict(gib=round(size.value / G, 1), classes=ncls.value, matrix_class=mcls.value, class_gib=[round(v / G, 1) for v in per],
                     used_gib=round(used.value / G, 2), map_ms=round(ms.value, 1), cell_mib=cell.value >> 20,
                     cells="".join("." if v < 0 else str(int(v)) for v in cells[:n.value]))
 

@@ -6,7 +6,7 @@ import json
 import os
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
 out = {}
 ks = os.path.join(src, "prof_kt", "kt_kernel_stats.csv")
@@ -26,7 +26,7 @@ if os.path.exists(kth):
     d.sort()
     last = [u for _, u in d[-50:]]
     out["timed_region"] = {"what": "the last 50 launches of k_spmv_rowsplit in the headline-only pass = bench.py's timed steps "
-                                   "(earlier launches: parity gate, placement candidates, warm-up)",
+                                   "(earlier launches: parity gate, warm-up)",
                            "launches_total": len(d), "avg_us_last_50": sum(last) / max(1, len(last)),
                            "min_us": min(last), "max_us": max(last), "avg_us_all": sum(u for _, u in d) / max(1, len(d))}
 # the default bench command's own timed region inside ITS trace: bench.py prints the CLOCK_MONOTONIC bounds
@@ -43,8 +43,10 @@ if os.path.exists(kt) and os.path.exists(bl):
         out["default_command_timed_region"] = {
             "what": "launches of the headline kernel between the CLOCK_MONOTONIC bounds bench.py reports for its timed steps, "
                     "in the trace of the default command (profiles/rNN_kernel_stats.csv averages ALL launches of the process: "
-                    "parity gate, placement search, warm-up, timed steps, CG loop)",
-            "launches": len(d), "avg_us": sum(d) / max(1, len(d)), "bench_avg_launch_ms": bench["roofline"]["avg_launch_ms"]}
+                    "parity gate, warm-up, timed steps, the event pass, CG loop, value-dictionary mode, extra configs)",
+            "launches": len(d), "avg_us": sum(d) / max(1, len(d)), "bench_ms_per_step": bench["ms_per_step"],
+            "bench_avg_launch_ms_event_pass": bench["roofline"]["avg_launch_ms"]}
+        json.dump(bench, open(os.path.join(os.path.dirname(__file__), f"{tag}_bench_n1.json"), "w"))
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d, f in (("prof_fetch", "f"), ("prof_write", "w"), ("prof_tcc", "t")):
     p = os.path.join(src, d, f"{f}_counter_collection.csv")

@@ -128,3 +128,197 @@ def test_header_is_valid_c99_and_the_c_example_links():
                            "-lpa_hip", "-Wl,-rpath," + os.path.join(ROOT, "partitionedarrays.jl_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", out])
     assert os.path.exists(out)
+
+
+# ---- the glue's METHODS against the reference's generic functions -----------------------------------
+def _glue_src():
+    src = open(os.path.join(ROOT, "partitionedarrays.jl_amd", "julia", "PartitionedArraysHIP.jl")).read()
+    return "\n".join(l for l in src.splitlines() if not l.lstrip().startswith("#"))
+
+
+def _signatures():
+    import json
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")))["signatures"]
+
+
+def _glue_methods(src):
+    """(qualified name, [(arg name, arg type)]) of every method the glue adds to a function of another module."""
+    out = []
+    for m in re.finditer(r"(?:^|\n)\s*(?:function\s+)?((?:PartitionedArrays|LinearAlgebra|Base)\.[A-Za-z_!]+)\(((?:[^()]|\([^()]*\))*)\)\s*(?:=|\n)", src):
+        args = []
+        for a in _split_top(m.group(2).split(";")[0]):
+            nm, _, ty = a.partition("::")
+            args.append((nm.strip(), ty.strip()))
+        out.append((m.group(1), args))
+    return out
+
+
+def test_julia_glue_methods_match_the_reference_generic_functions():
+    """The glue overloads allocate_local_values / own_values / ghost_values (src/p_vector.jl:8-26), p_vector_cache_impl
+    (:451), assemble_impl! (:587) and spmv! (src/sparse_utils.jl:617): each method must have the arity and the argument
+    ORDER of the reference's generic function (tests/golden/reference_signatures.json, extracted by make_signatures.py) --
+    a `::Type{...}` slot where the reference has one, and the reference's own names for the named slots."""
+    sigs = _signatures()
+    by_name = {}
+    for s in sigs:
+        by_name.setdefault(s["function"], []).append(s)
+    methods = _glue_methods(_glue_src())
+    seen = set()
+    for qname, args in methods:
+        mod, fn = qname.split(".")
+        if mod != "PartitionedArrays" or fn not in by_name:
+            continue
+        cands = [s for s in by_name[fn] if len(s["positional"]) == len(args)]
+        assert cands, f"{qname}: the glue defines {len(args)} positional arguments, the reference has {[len(s['positional']) for s in by_name[fn]]}"
+        ok = False
+        for s in cands:
+            good = True
+            for (gn, gt), ref in zip(args, s["positional"]):
+                ref_is_type = ref["type"].startswith("Type")
+                if ref_is_type != gt.startswith("Type"):
+                    good = False
+                if ref["name"] in ("indices", "f", "vector_partition", "index_partition", "cache") and gn and gn != ref["name"]:
+                    good = False
+            ok = ok or good
+        assert ok, f"{qname}{args} does not line up with any reference method {[s['positional'] for s in cands]}"
+        seen.add(fn)
+    assert seen >= {"allocate_local_values", "own_values", "ghost_values", "p_vector_cache_impl", "assemble_impl!", "spmv!"}, seen
+    # calls INTO the reference: arity of what the glue calls
+    src = _glue_src()
+    for fn, n in (("assembly_neighbors", 1), ("assembly_local_indices", 3), ("split_matrix_blocks", 4), ("split_matrix", 3)):
+        m = re.search(r"(?<![\w.!])(?:PartitionedArrays\.)?" + re.escape(fn) + r"\(((?:[^()]|\([^()]*\))*)\)", src)
+        assert m, fn
+        assert len(_split_top(m.group(1))) == n, (fn, m.group(1))
+        assert any(len(s["positional"]) == n for s in by_name[fn]), fn
+    # insert is compared by identity in assemble_impl!: it must be the reference's two-argument insert(a,b) = b
+    assert [len(s["positional"]) for s in by_name["insert"]] == [2]
+
+
+def test_reference_signature_fixture_is_current():
+    """Only where the reference tree exists (the build container): the committed fixture equals a fresh extraction."""
+    import importlib.util
+    import json
+    import pytest
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("no reference tree on this box")
+    spec = importlib.util.spec_from_file_location("make_signatures", os.path.join(ROOT, "tests", "golden", "make_signatures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(mod.OUT))
+    old = mod.OUT
+    try:
+        mod.OUT = os.path.join("/tmp", "reference_signatures_check.json")
+        mod.main()
+        assert json.load(open(mod.OUT)) == want
+    finally:
+        mod.OUT = old
+
+
+# ---- the glue's ccall sequence of mul!, replayed through ctypes with the glue's own type tuples -------------------------
+_JL2C = {"Cint": ctypes.c_int, "Int32": ctypes.c_int32, "Int64": ctypes.c_int64, "Float64": ctypes.c_double}
+
+
+def _glue_ccalls(func_pattern):
+    """[(entry point, [ctypes types])] of the ccalls inside the glue function whose header matches `func_pattern`, in
+    source order; pointer-like Julia types (Ptr{...}, Ref{...}) become c_void_p."""
+    src = _glue_src()
+    m = re.search(func_pattern, src)
+    assert m, func_pattern
+    body = src[m.start():]
+    end = re.search(r"\n(?:end|function |[A-Za-z_.!]+\([^\n]*\) =)", body[1:])
+    body = body[:end.start() + 1 + (3 if body[end.start() + 1:].startswith("\nend") else 0)] if end else body
+    out = []
+    for name, ret, argt in re.findall(r"ccall\(\(:(pa_[a-z0-9_]+),\s*libpa\),\s*(\w+),\s*\(((?:[^()]|\([^()]*\))*?)\)\s*[,)]", body):
+        types = [(_JL2C.get(t.strip(), ctypes.c_void_p)) for t in _split_top(argt.rstrip(","))]
+        out.append((name, types))
+    return out
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_glue_ccall_sequence_of_mul_replayed_through_ctypes(orc):
+    """What the reference's mul!(c,a,b) (src/p_sparse_matrix.jl:2090-2103) executes once the glue's methods exist,
+    replayed call by call with the argument type tuples WRITTEN IN THE GLUE (parsed from its ccalls, not from the header
+    or from the Python binding): p_vector_cache_impl -> pa_plan_create; consistent!(b) -> assemble_impl!(insert, ...,
+    reverse(cache)) -> pa_exchange_pack per part, pa_exchange_local, [own x own: spmv! -> pa_spmv], wait(t) ->
+    pa_exchange_finish per part, [own x ghost: mul!(b,A,x,1,1) -> pa_spmv].  4 parts of an 8 x 8 x 4 HPCG grid, bit-exact
+    against the oracle.  The glue itself cannot run here (no Julia); this pins its call sequence and its type tuples."""
+    import numpy as np
+    pa = load_package()
+    lib = ctypes.CDLL(pa.LIB_PATH)
+    seq = {
+        "ctx": _glue_ccalls(r"function context\("),
+        "vec": _glue_ccalls(r"function HIPVector\(n_own::Integer, n_ghost::Integer\)"),
+        "upload": _glue_ccalls(r"function HIPVector\(host::Vector\{Float64\}"),
+        "download": _glue_ccalls(r"function Base\.Array\(v::HIPVector\)"),
+        "csr": _glue_ccalls(r"function HIPCSR\(A::SparseMatrixCSR"),
+        "cache": _glue_ccalls(r"function PartitionedArrays\.p_vector_cache_impl"),
+        "local": _glue_ccalls(r"_transport!\(plans::DebugArray"),
+        "impl": _glue_ccalls(r"function PartitionedArrays\.assemble_impl!"),
+        "spmv": _glue_ccalls(r"function PartitionedArrays\.spmv!"),
+        "mul5": _glue_ccalls(r"function LinearAlgebra\.mul!"),
+    }
+    assert [n for n, _ in seq["impl"]] == ["pa_exchange_pack", "pa_exchange_finish"]
+    assert [n for n, _ in seq["cache"]] == ["pa_plan_create"] and [n for n, _ in seq["local"]] == ["pa_exchange_local"]
+
+    def call(key, k, *vals):
+        name, types = seq[key][k]
+        assert len(types) == len(vals), (name, len(types), len(vals))
+        f = getattr(lib, name)
+        f.restype, f.argtypes = ctypes.c_int, types
+        st = f(*vals)
+        assert st == 0, (name, lib.pa_last_error())
+
+    P = ctypes.c_void_p
+    vp = lambda a: a.ctypes.data_as(P)
+    # the host data the reference would hold (the oracle builds it the reference's way, 1-based)
+    A, _b, _ = orc.hpcg_build_p_matrix(4, 4, 4, 2, 2, 1)
+    cache = orc.p_vector_cache([np.zeros(c.n_local) for c in A.cols], A.cols)
+    ctx = P()
+    call("ctx", 0, 0, ctypes.byref(ctx))
+    nparts = len(A.cols)
+    xs, ys, oo, oh, plans, keep = [], [], [], [], [], []
+    xh = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in A.cols]
+    for p in range(nparts):
+        c, r = A.cols[p], A.rows[p]
+        for lst, n_own, n_ghost, host in ((xs, c.n_own, c.n_ghost, xh[p]), (ys, r.n_own, 0, None)):
+            h = P()
+            call("vec", 0, ctx, n_own, n_ghost, ctypes.byref(h))
+            if host is not None:
+                hb = np.ascontiguousarray(host)
+                call("upload", 0, h, vp(hb), 0, len(hb))
+            lst.append(h)
+        for lst, M in ((oo, A.blocks[p].own_own), (oh, A.blocks[p].own_ghost)):
+            h = P()
+            rp, cv, nz = (np.ascontiguousarray(M.rowptr, np.int32), np.ascontiguousarray(M.colval, np.int32), np.ascontiguousarray(M.nzval))
+            keep += [rp, cv, nz]
+            call("csr", 0, ctx, M.m, M.n, len(nz), vp(rp), vp(cv), 4, 1, vp(nz), ctypes.byref(h))
+            lst.append(h)
+        ns, nr = np.ascontiguousarray(cache.neighbors_snd[p], np.int32), np.ascontiguousarray(cache.neighbors_rcv[p], np.int32)
+        ls, lr = cache.local_indices_snd[p], cache.local_indices_rcv[p]
+        arrs = [ns, np.ascontiguousarray(ls.ptrs, np.int32), np.ascontiguousarray(ls.data, np.int32), nr,
+                np.ascontiguousarray(lr.ptrs, np.int32), np.ascontiguousarray(lr.data, np.int32)]
+        keep += arrs
+        h = P()
+        call("cache", 0, ctx, p + 1, c.n_local, len(ns), vp(arrs[0]), vp(arrs[1]), vp(arrs[2]), len(nr), vp(arrs[3]), vp(arrs[4]),
+             vp(arrs[5]), 1, ctypes.byref(h))
+        plans.append(h)
+    CONSISTENT, OWN, GHOST = 0, 0, 1
+    for p in range(nparts):                                   # t = consistent!(b): pack ...
+        call("impl", 0, plans[p], xs[p], CONSISTENT)
+    arr = (ctypes.c_void_p * nparts)(*[h.value for h in plans])
+    call("local", 0, arr, nparts, CONSISTENT)                 # ... exchange!
+    for p in range(nparts):                                   # foreach(spmv!, own_values(c), own_own, own_values(b))
+        call("spmv", 0, oo[p], xs[p], OWN, ys[p], OWN, 1.0, 0.0)
+    for p in range(nparts):                                   # wait(t)
+        call("impl", 1, plans[p], xs[p], CONSISTENT)
+    for p in range(nparts):                                   # foreach(muladd!, own_values(c), own_ghost, ghost_values(b))
+        call("mul5", 0, oh[p], xs[p], GHOST, ys[p], OWN, 1.0, 1.0)
+    want = [np.zeros(r.n_local) for r in A.rows]
+    orc.mul(want, A, [v.copy() for v in xh])
+    for p in range(nparts):
+        got = np.zeros(A.rows[p].n_own)
+        call("download", 0, ys[p], vp(got), 0, len(got))
+        assert np.array_equal(got, want[p][:len(got)]), f"part {p + 1}"
