@@ -1229,6 +1229,36 @@ def test_fem_matrix_on_a_randomly_permuted_mesh(orc):
     assert np.allclose(y0.download(), want[perm - 1], rtol=0, atol=1e-11)
 
 
+def test_norm_on_a_ghosted_uniform_partition_counts_own_values_only(orc):
+    """uniform_partition(ranks,(2,2),(6,6),(true,true)) gives PermutedLocalIndices -- the local order is the
+    extended box, own ids are not a prefix.  The device stores [own | ghost] whatever the local order is, so after a
+    consistent! (every ghost holds its owner's value) dot / norm still reduce over own values only
+    (src/p_vector.jl:1189-1206), the ghost exchange is bit-exact in LOCAL order, and axpby touches own values only."""
+    for np_, n, ghost, per in (((2, 2), (6, 6), (True, True), None), ((2, 2), (10, 10), (2, 2), (True, True)), ((1, 2), (4, 4), (True, True), (True, True))):
+        P = int(np.prod(np_))
+        parts = pa.uniform_partition(ranks(P), np_, n, ghost, per)
+        oparts = orc.uniform_partition(np_, n, ghost, per)
+        assert [(i.n_own, i.n_ghost) for i in parts.items] == [(o.n_own, o.n_ghost) for o in oparts]
+        assert not parts.items[0].own_is_contiguous_prefix
+        f = lambda g: np.sin(g.astype(float)) + 2.0
+        v = pa.pvector_from_function(lambda i: f(i.get_local_to_global()) * (i.get_local_to_owner() == i.part), parts)
+        vo = [f(o.local_to_global) * (o.local_to_owner == o.part) for o in oparts]
+        pa.consistent_(v).wait()
+        orc.consistent(vo, oparts)
+        for got, want in zip(v.local_values().items, vo):
+            assert np.array_equal(got, want)                                # local order, ghosts included
+        want = orc.norm2(vo, oparts)
+        assert abs(pa.norm(v) - want) <= 1e-13 * want
+        assert abs(pa.dot(v, v) - orc.dot(vo, vo, oparts)) <= 1e-13 * want * want
+        w = pa.pzeros(parts)
+        pa.axpby_(w, 2.0, v, 0.0)                                            # own values only: w's ghosts stay 0
+        for got, o, src in zip(w.local_values().items, oparts, vo):
+            exp = np.zeros(o.n_local)
+            exp[o.own_to_local - 1] = 2.0 * src[o.own_to_local - 1]
+            assert np.array_equal(got, exp)
+        assert all(np.array_equal(g, src[o.own_to_local - 1]) for g, o, src in zip(v.own_values().items, oparts, vo))
+
+
 def test_config2_laplacian_256_cubed_single_part(orc):
     """BASELINE config 2: 7-point Laplacian 256^3, one part, fp64 CSR SpMV only (no exchange), through the
     step-by-step set-up chain.  Size-independent properties: A*1 == alpha*(2D - #neighbours) bit-exactly

@@ -304,3 +304,34 @@ def test_fem_example_vectorised_setup_equals_the_literal_loops(orc, parts, cells
     for s, d in zip(S["spaces"].items, S["dof_partition"].items):
         xh = pa.fem_example.setup_exact_solution(s, S["params"], d)
         assert np.array_equal(xh[:d.n_own], np.array([O["exact"][int(g)] for g in d.own_to_global]))
+
+
+def test_ghost_layers_and_self_owned_ghosts_match_the_reference_constructor(orc):
+    """ADVICE r01.  local_range's `ghost` is a number of layers (src/p_range.jl:813: 1+offset-ghost): the reference's own
+    tests build uniform_partition(rank,(2,2),(10,10),(2,2)) (test/p_vector_tests.jl); block_with_constant_size sizes the
+    part as prod(length(local_ranges)) local / prod(length(own_ranges)) own ids (:640-642).  A periodic direction with one
+    part wraps onto ids this part owns: those copies are ghosts owned by self (:650-665) and are never exchanged (:494)."""
+    assert pa.local_range(1, 2, 10, 2) == (1, 7) and orc.local_range(1, 2, 10, 2) == (1, 7)
+    assert pa.local_range(2, 2, 10, 2) == (4, 10) and pa.local_range(1, 2, 10, 2, True) == (-1, 7)
+    cases = [(((2, 2), (10, 10), (2, 2), None), (25, 24)), (((2, 2), (10, 10), (2, 2), (True, True)), (25, 56)),
+             (((1, 2), (4, 4), (True, True), (True, True)), (8, 16)), ((3, 10, 2, None), None)]
+    for (np_, n, ghost, per), sizes in cases:
+        P = int(np.prod(np_))
+        mine = pa.uniform_partition(pa.DebugArray(range(1, P + 1)), np_, n, ghost, per)
+        theirs = orc.uniform_partition(np_, n, ghost, per)
+        for a, b in zip(mine.items, theirs):
+            assert np.array_equal(a.get_local_to_global(), b.local_to_global) and np.array_equal(a.get_local_to_owner(), b.local_to_owner)
+            assert np.array_equal(a.own_to_local, b.own_to_local) and np.array_equal(a.ghost_to_local, b.ghost_to_local)
+            if sizes:
+                assert (a.n_own, a.n_ghost) == sizes
+            ns, nr = a.cache["neighbors_snd"], a.cache["neighbors_rcv"]
+            assert a.part not in list(ns) and a.part not in list(nr)
+        ls, lr = pa.assembly_local_indices(mine)
+        ols, olr = orc.assembly_local_indices(theirs)
+        for x, y in zip(ls.items, ols):
+            assert np.array_equal(x.data, y.data) and np.array_equal(x.ptrs, y.ptrs)
+        for x, y in zip(lr.items, olr):
+            assert np.array_equal(x.data, y.data) and np.array_equal(x.ptrs, y.ptrs)
+    # the 1-D form with two layers: parts of 3,3,4 ids plus up to two ghosts on each side
+    one = pa.uniform_partition(pa.DebugArray(range(1, 4)), 3, 10, 2)
+    assert [list(i.get_local_to_global()) for i in one.items] == [[1, 2, 3, 4, 5], [2, 3, 4, 5, 6, 7, 8], [5, 6, 7, 8, 9, 10]]
