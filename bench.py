@@ -44,6 +44,50 @@ def watchdog(seconds):
     return t
 sys.path.insert(0, ROOT)
 
+LINE = [None]            # rank 0: the JSON line as far as it is known (the headline first, optional sections add to it)
+
+
+class optional_section:
+    """Nothing after the headline measurement may cost the run its line.  With one process an exception is enough to skip
+    a section; with N processes a rank that fails or hangs inside a section leaves the others waiting in a collective,
+    so every rank arms the same timer: when it fires (or the section raises), rank 0 prints the line it has -- headline
+    complete, the section listed under `optional_sections_unfinished` -- and every rank leaves with status 0."""
+
+    def __init__(self, name, seconds, N, rank):
+        seconds = float(os.environ.get("PA_BENCH_SECTION_TIMEOUT_S", seconds))
+        self.name, self.seconds, self.N, self.rank, self.timer = name, seconds, N, rank, None
+
+    def _bail(self, why):
+        print(f"[bench rank {self.rank}] optional section {self.name!r} {why}; the line goes out without it", file=sys.stderr, flush=True)
+        if self.rank == 0 and LINE[0] is not None:
+            LINE[0].setdefault("optional_sections_unfinished", []).append(self.name)
+            print(json.dumps(LINE[0]), flush=True)
+        os._exit(0)
+
+    def __enter__(self):
+        PHASE[0] = self.name
+        if self.N > 1:
+            import threading
+            self.timer = threading.Timer(self.seconds, self._bail, args=(f"did not finish within {self.seconds:.0f} s",))
+            self.timer.daemon = True
+            self.timer.start()
+            if os.environ.get("PA_BENCH_FAULT") == f"{self.name}:hang:{self.rank}":     # (tests: a rank that never comes back)
+                time.sleep(1e6)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if self.timer is not None:
+            self.timer.cancel()
+        if et is None or not issubclass(et, Exception):
+            return False
+        if self.N > 1:
+            import traceback
+            traceback.print_exception(et, ev, tb)
+            self._bail(f"raised {et.__name__}: {ev}")
+        print(f"[bench] optional section {self.name!r} skipped: {ev}", file=sys.stderr, flush=True)
+        return True
+
+
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
 
 
@@ -474,15 +518,6 @@ def main():
     whole = np.array([e[2].elapsed_ms(e[3]) for e in evs])
     kern_ms, kern_med = float(kern.mean()), float(np.median(kern))
 
-    overlap = None
-    if N > 1:
-        PHASE[0] = "overlap on/off comparison"
-        t_other, _, _ = timed(args.steps, not overlap_on)
-        on, off = (ms_per_step, t_other / args.steps * 1e3) if overlap_on else (t_other / args.steps * 1e3, ms_per_step)
-        overlap = {"ms_per_step_on": round(on, 4), "ms_per_step_off": round(off, 4), "headline_uses": "on" if overlap_on else "off",
-                   "what": "mul! with the ghost exchange under own x own (src/p_sparse_matrix.jl:2098-2100) vs exchange first "
-                           "(HPCG mul_no_lat!), same steps, same barriers"}
-
     nnz = nnz_oo + nnz_oh
     if N > 1:
         tot = torch.tensor([nnz], dtype=torch.int64)
@@ -521,85 +556,6 @@ def main():
             box = calibrate_box(pa, ctx, L)
         except Exception as e:                                   # noqa: BLE001  (an extra; no collectives inside)
             print(f"[bench] HBM calibration skipped: {e}", file=sys.stderr)
-
-    # ---- optional mode, reported beside the headline and never part of `value`: the same product with the lossless value
-    # dictionary (PA_SPMV_VALUE_DICT=1: one byte per stored entry instead of eight when a block has <= 64 distinct values)
-    vdict = None
-    if N == 1 and args.value_dict:
-        try:                                                   # an optional extra never costs the headline its line
-            PHASE[0] = "value-dictionary mode"
-            os.environ["PA_SPMV_VALUE_DICT"] = "1"
-            A2, _b2 = pa.build_p_matrix(ranks, n, n, n, *gn, npx, npy, npz)
-            os.environ.pop("PA_SPMV_VALUE_DICT")
-            blk2 = pa.local_items(A2.matrix_partition)[0]
-            y2 = pa.pzeros(A2.row_partition)
-            pa.mul_(y2, A2, x)
-            same = all(np.array_equal(a_, b_) for a_, b_ in zip(pa.local_items(y2.own_values()), pa.local_items(y.own_values())))
-            y2v = pa.local_items(y2.vector_partition)[0]
-            for _ in range(args.warmup):
-                pa.spmv_(y2v, blk2.own_own, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
-            e0 = ctx.event().record(L.STREAM_COMPUTE)
-            for _ in range(args.steps):
-                pa.spmv_(y2v, blk2.own_own, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
-            e1 = ctx.event().record(L.STREAM_COMPUTE)
-            ctx.sync()
-            ms2 = e0.elapsed_ms(e1) / args.steps
-            vdict = {"what": "own x own SpMV with PA_SPMV_VALUE_DICT=1 (optional, lossless; NOT used for `value`)",
-                     "distinct_values": blk2.own_own.value_dict(), "bit_identical_to_headline_product": bool(same),
-                     "avg_launch_ms": round(ms2, 4), "gflops": round(2.0 * nnz_oo / (ms2 * 1e-3) / 1e9, 1),
-                     "algorithmic_gbps": round(bytes_oo / (ms2 * 1e-3) / 1e9, 1)}
-            del A2, _b2, y2, blk2
-        except Exception as e:                                 # noqa: BLE001
-            os.environ.pop("PA_SPMV_VALUE_DICT", None)
-            print(f"[bench] value-dictionary extra skipped: {e}", file=sys.stderr)
-            vdict = None
-
-    # ---- BASELINE config 4's loop, reported beside the headline (never part of `value`): one CG iteration of
-    # HPCG/src/ref_cg.jl (consistent!+mul!, 2 dots + norm, 3 axpys; Identity preconditioner), as the reference
-    # schedules it (ref_cg_: a blocking reduction per dot) and as opt_cg_ does (scalars stay on the device).
-    cg = None
-    PHASE[0] = "CG loop"
-    if args.cg_iters > 0:
-        work = pa.cg_work(pa.pzeros(A.col_partition), b, A)     # the loop's own work vectors, allocated once
-
-        def cg_time(fn, k):
-            xx = pa.pzeros(A.col_partition)
-            barrier()
-            t = time.perf_counter()
-            fn(xx, A, b, maxiter=k, work=work)
-            ctx.sync()
-            barrier()
-            return time.perf_counter() - t
-        cg = {}
-        for name, fn in (("ref_cg", pa.ref_cg_), ("opt_cg", pa.opt_cg_)):
-            cg_time(fn, 2)
-            d = cg_time(fn, 4 + args.cg_iters) - cg_time(fn, 4)     # the difference cancels allocation + first residual
-            if N > 1:
-                tt = torch.tensor([d], dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                d = float(tt.item())
-            cg[name] = d / args.cg_iters * 1e3
-
-    extras = None
-    if N == 1 and args.extra and rank == 0:
-        try:
-            extras = extra_configs(pa, ctx, L)
-        except Exception as e:                                 # noqa: BLE001
-            print(f"[bench] extra configs skipped at {PHASE[0]!r}: {e}", file=sys.stderr)
-
-    cpu = None
-    if want_cpu:
-        PHASE[0] = "CPU baseline"
-        try:
-            cpu = cpu_mul_baseline(pa, A, N, rank, args.cpu_seconds)
-            if cpu is not None and rank == 0:
-                c1 = cpu_c1_debugarray()
-                if c1:
-                    cpu["c1_debugarray"] = c1
-        except Exception as e:                                 # noqa: BLE001
-            if N > 1:
-                raise                                           # (a rank that drops out of a collective would hang the others)
-            print(f"[bench] CPU baseline skipped: {e}", file=sys.stderr)
 
     if rank == 0:
         prio = ctx.stream_priorities()
@@ -642,24 +598,112 @@ def main():
             "parity_gate": "A*1==b bit-exact; ghosts==owners bit-exact",
             "setup_s": round(t_setup, 1),
         }
-        if overlap:
-            out["overlap"] = overlap
+        LINE[0] = out
+
+    # ---------------- everything below is optional: it adds to the line, it can never take the line away ----------------
+    overlap = None
+    if N > 1:
+        with optional_section("overlap on/off comparison", 120, N, rank):
+            t_other, _, _ = timed(args.steps, not overlap_on)
+            on, off = (ms_per_step, t_other / args.steps * 1e3) if overlap_on else (t_other / args.steps * 1e3, ms_per_step)
+            overlap = {"ms_per_step_on": round(on, 4), "ms_per_step_off": round(off, 4), "headline_uses": "on" if overlap_on else "off",
+                       "what": "mul! with the ghost exchange under own x own (src/p_sparse_matrix.jl:2098-2100) vs exchange first "
+                               "(HPCG mul_no_lat!), same steps, same barriers"}
+            if rank == 0:
+                LINE[0]["overlap"] = overlap
+
+    # ---- optional mode, reported beside the headline and never part of `value`: the same product with the lossless value
+    # dictionary (PA_SPMV_VALUE_DICT=1: one byte per stored entry instead of eight when a block has <= 64 distinct values)
+    vdict = None
+    if N == 1 and args.value_dict:
+        try:                                                   # an optional extra never costs the headline its line
+            PHASE[0] = "value-dictionary mode"
+            os.environ["PA_SPMV_VALUE_DICT"] = "1"
+            A2, _b2 = pa.build_p_matrix(ranks, n, n, n, *gn, npx, npy, npz)
+            os.environ.pop("PA_SPMV_VALUE_DICT")
+            blk2 = pa.local_items(A2.matrix_partition)[0]
+            y2 = pa.pzeros(A2.row_partition)
+            pa.mul_(y2, A2, x)
+            same = all(np.array_equal(a_, b_) for a_, b_ in zip(pa.local_items(y2.own_values()), pa.local_items(y.own_values())))
+            y2v = pa.local_items(y2.vector_partition)[0]
+            for _ in range(args.warmup):
+                pa.spmv_(y2v, blk2.own_own, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
+            e0 = ctx.event().record(L.STREAM_COMPUTE)
+            for _ in range(args.steps):
+                pa.spmv_(y2v, blk2.own_own, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
+            e1 = ctx.event().record(L.STREAM_COMPUTE)
+            ctx.sync()
+            ms2 = e0.elapsed_ms(e1) / args.steps
+            vdict = {"what": "own x own SpMV with PA_SPMV_VALUE_DICT=1 (optional, lossless; NOT used for `value`)",
+                     "distinct_values": blk2.own_own.value_dict(), "bit_identical_to_headline_product": bool(same),
+                     "avg_launch_ms": round(ms2, 4), "gflops": round(2.0 * nnz_oo / (ms2 * 1e-3) / 1e9, 1),
+                     "algorithmic_gbps": round(bytes_oo / (ms2 * 1e-3) / 1e9, 1)}
+            del A2, _b2, y2, blk2
+        except Exception as e:                                 # noqa: BLE001
+            os.environ.pop("PA_SPMV_VALUE_DICT", None)
+            print(f"[bench] value-dictionary extra skipped: {e}", file=sys.stderr)
+            vdict = None
+
+    # ---- BASELINE config 4's loop, reported beside the headline (never part of `value`): one CG iteration of
+    # HPCG/src/ref_cg.jl (consistent!+mul!, 2 dots + norm, 3 axpys; Identity preconditioner), as the reference
+    # schedules it (ref_cg_: a blocking reduction per dot) and as opt_cg_ does (scalars stay on the device).
+    cg = None
+    if args.cg_iters > 0:
+        with optional_section("CG loop", 240, N, rank):
+            work = pa.cg_work(pa.pzeros(A.col_partition), b, A)     # the loop's own work vectors, allocated once
+
+            def cg_time(fn, k):
+                xx = pa.pzeros(A.col_partition)
+                barrier()
+                t = time.perf_counter()
+                fn(xx, A, b, maxiter=k, work=work)
+                ctx.sync()
+                barrier()
+                return time.perf_counter() - t
+            res = {}
+            for name, fn in (("ref_cg", pa.ref_cg_), ("opt_cg", pa.opt_cg_)):
+                cg_time(fn, 2)
+                d = cg_time(fn, 4 + args.cg_iters) - cg_time(fn, 4)     # the difference cancels allocation + first residual
+                if N > 1:
+                    tt = torch.tensor([d], dtype=torch.float64)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    d = float(tt.item())
+                res[name] = d / args.cg_iters * 1e3
+            cg = res
+            if rank == 0:
+                n_rows_total = n_own * N
+                cg_flops = 2.0 * nnz_total + 12.0 * n_rows_total      # SpMV + 3 dots + 3 axpys (HPCG/src/report_results.jl)
+                LINE[0]["cg_loop"] = {"what": "one CG iteration of HPCG ref_cg.jl on the same matrix (BASELINE config 4 loop, "
+                                              "Identity preconditioner): consistent!+mul!, 2 dots + norm, 3 axpys",
+                                      "iterations_timed": args.cg_iters,
+                                      "ms_per_iteration_ref_cg": round(cg["ref_cg"], 4),
+                                      "ms_per_iteration_opt_cg": round(cg["opt_cg"], 4),
+                                      "gflops_opt_cg": round(cg_flops / (cg["opt_cg"] * 1e-3) / 1e9, 1),
+                                      "note": "opt_cg_ = scalars kept on the device, u'c accumulated inside the product "
+                                              "kernels, x's update fused into u's pass"}
+
+    extras = None
+    if N == 1 and args.extra and rank == 0:
+        try:
+            extras = extra_configs(pa, ctx, L)
+        except Exception as e:                                 # noqa: BLE001
+            print(f"[bench] extra configs skipped at {PHASE[0]!r}: {e}", file=sys.stderr)
+
+    if want_cpu:
+        with optional_section("CPU baseline", 3 * args.cpu_seconds + 240, N, rank):
+            cpu = cpu_mul_baseline(pa, A, N, rank, args.cpu_seconds)
+            if cpu is not None and rank == 0:
+                c1 = cpu_c1_debugarray()
+                if c1:
+                    cpu["c1_debugarray"] = c1
+                LINE[0]["cpu_baseline"] = cpu
+
+    if rank == 0:
+        out = LINE[0]
         if vdict:
             out["value_dictionary_mode"] = vdict
-        if cg:
-            n_rows_total = n_own * N
-            cg_flops = 2.0 * nnz_total + 12.0 * n_rows_total      # SpMV + 3 dots + 3 axpys (HPCG/src/report_results.jl)
-            out["cg_loop"] = {"what": "one CG iteration of HPCG ref_cg.jl on the same matrix (BASELINE config 4 loop, "
-                                      "Identity preconditioner): consistent!+mul!, 2 dots + norm, 3 axpys",
-                              "iterations_timed": args.cg_iters,
-                              "ms_per_iteration_ref_cg": round(cg["ref_cg"], 4),
-                              "ms_per_iteration_opt_cg": round(cg["opt_cg"], 4),
-                              "gflops_opt_cg": round(cg_flops / (cg["opt_cg"] * 1e-3) / 1e9, 1),
-                              "note": "opt_cg_ = scalars kept on the device, u'c accumulated inside the product kernel"}
         if extras:
             out["extra_configs"] = extras
-        if cpu:
-            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     if N > 1:
         dist.barrier()

@@ -56,3 +56,14 @@ def test_bench_refuses_to_downgrade_the_rccl_transport_silently():
     r, d = _bench(2, {"PA_TRANSPORT": "rccl", "PA_BENCH_BACKEND": "gloo", "PA_BENCH_WATCHDOG_S": "240"}, ("--no-cpu-baseline",))
     assert r.returncode != 0 and d is None, r.stdout[-2000:]
     assert "refusing to downgrade" in r.stderr, r.stderr[-3000:]
+
+
+def test_a_rank_lost_in_an_optional_section_does_not_cost_the_line():
+    """Everything after the headline measurement is optional: rank 1 never returns from the CG section (injected), every
+    rank's section timer fires, rank 0 prints the line it has -- headline complete, `cg_loop` absent, the section named --
+    and the job ends with status 0."""
+    r, d = _bench(2, {"PA_TRANSPORT": "host", "PA_BENCH_BACKEND": "gloo", "PA_BENCH_FAULT": "CG loop:hang:1",
+                      "PA_BENCH_SECTION_TIMEOUT_S": "20"}, ("--no-cpu-baseline",))
+    assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert d["value"] > 0 and "cg_loop" not in d and d["optional_sections_unfinished"] == ["CG loop"]
+    assert "overlap" in d and d["roofline"]["frac_moved"] > 0
