@@ -198,6 +198,20 @@ int pa_csr_value_dict(const pa_csr *A, int *n_values);
 int pa_spmv(const pa_csr *A, const pa_vec *x, int x_segment, pa_vec *y, int y_segment, double alpha,
             double beta);
 
+/* ---- SELL-C-sigma storage with one lane per row (csrc/pa_sell.hip): a second, structurally different bit-exact SpMV ----
+ * A wavefront owns a slab of 64 rows (sorted by length inside windows of `sigma` rows; sigma = 1: as they come) and every
+ * lane walks ITS row's stored entries in the reference's order (spmv_csr! src/sparse_utils.jl:649-669;
+ * SparseMatricesCSR.mul!(y,A,x,alpha,beta)) with the accumulator in a register: no LDS stage, no cross-lane sum, so the
+ * result equals the reference's -- and pa_spmv's -- bit for bit.  Streams 12 bytes per stored entry plus the padding of
+ * each slab (pa_sell_info), against 8 for a stencil block on row patterns: a parity / debugging mode and a format for short
+ * irregular rows, not the product path.  Arguments as pa_csr_create / pa_spmv. */
+typedef struct pa_sell pa_sell;
+int pa_sell_create(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr, const void *colval,
+                   int index_bytes, int index_base, const double *nzval, int sigma, pa_sell **A);
+int pa_sell_destroy(pa_sell *A);
+int pa_sell_info(const pa_sell *A, int64_t *n_slabs, int64_t *padded_entries, int64_t *nnz);
+int pa_sell_spmv(const pa_sell *A, const pa_vec *x, int x_segment, pa_vec *y, int y_segment, double alpha, double beta);
+
 /* ---- exchange plans: p_vector_cache_impl / VectorAssemblyCache (src/p_vector.jl:418-468) ------ */
 /* The arrays are the cache fields in ASSEMBLY orientation, as the reference builds them
  * (src/p_range.jl:417-531):

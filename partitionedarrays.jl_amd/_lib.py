@@ -118,6 +118,10 @@ _SIGS = {
     "pa_csr_info": [P] + [C.POINTER(i64)] * 6,
     "pa_csr_encoding": [P] + [C.POINTER(i64)] * 3,
     "pa_spmv": [P, P, cint, P, cint, f64, f64],
+    "pa_sell_create": [P, i64, i64, i64, P, P, cint, cint, P, cint, PP],
+    "pa_sell_destroy": [P],
+    "pa_sell_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
+    "pa_sell_spmv": [P, P, cint, P, cint, f64, f64],
     "pa_plan_create": [P, i32, i64, i32, P, P, P, i32, P, P, P, cint, PP],
     "pa_plan_destroy": [P],
     "pa_plan_buffers": [P, cint, PP, C.POINTER(i64), PP, C.POINTER(i64)],

@@ -149,9 +149,31 @@ class DeviceCSR:
             pass
 
 
-def spmv_(b, A: DeviceCSR, x, x_segment=L.SEG_OWN, b_segment=L.SEG_OWN, alpha=1.0, beta=0.0):
-    """spmv!(b,A,x) / mul!(b,A,x,alpha,beta) on device vectors (src/sparse_utils.jl:609-669)."""
-    L.call("pa_spmv", A.h, x.h, x_segment, b.h, b_segment, float(alpha), float(beta))
+class DeviceSELL:
+    """The same block in SELL-C-sigma storage, one lane per row (pa_sell, csrc/pa_sell.hip): a second bit-exact SpMV."""
+
+    def __init__(self, A: HostCSR, sigma=1, ctx=None):
+        self.ctx = ctx or context()
+        self.m, self.n, self.nnz = A.m, A.n, A.nnz
+        self.h = C.c_void_p()
+        L.call("pa_sell_create", self.ctx.h, A.m, A.n, A.nnz, L.ptr(A.rowptr), L.ptr(A.colval), A.colval.dtype.itemsize, 1,
+               L.ptr(A.nzval), int(sigma), C.byref(self.h))
+
+    def info(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        L.call("pa_sell_info", self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(n_slabs=a.value, padded_entries=b.value, nnz=c.value)
+
+    def __del__(self):
+        try:
+            L.lib.pa_sell_destroy(self.h)
+        except Exception:
+            pass
+
+
+def spmv_(b, A, x, x_segment=L.SEG_OWN, b_segment=L.SEG_OWN, alpha=1.0, beta=0.0):
+    """spmv!(b,A,x) / mul!(b,A,x,alpha,beta) on device vectors (src/sparse_utils.jl:609-669); A: DeviceCSR or DeviceSELL."""
+    L.call("pa_sell_spmv" if isinstance(A, DeviceSELL) else "pa_spmv", A.h, x.h, x_segment, b.h, b_segment, float(alpha), float(beta))
     return b
 
 

@@ -1259,6 +1259,51 @@ def test_norm_on_a_ghosted_uniform_partition_counts_own_values_only(orc):
         assert all(np.array_equal(g, src[o.own_to_local - 1]) for g, o, src in zip(v.own_values().items, oparts, vo))
 
 
+@pytest.mark.parametrize("sigma", [1, 256])
+def test_sell_c_sigma_one_lane_per_row_is_bit_identical(orc, sigma):
+    """SELL-C-sigma storage, one lane walks one row in the reference's order with its sum in a register.
+    Against the oracle's spmv_csr! / mul!(y,A,x,alpha,beta) AND against the row-split kernel, bit for bit, on a 27-point
+    block, ragged rows with empty ones, rows of thousands of entries, a row count that is no multiple of 64, and values
+    whose row sums are -0.0 (padding must not touch them)."""
+    rng = np.random.default_rng(7)
+    A27, _ = pa.build_p_matrix(ranks(1), 20, 17, 13, 20, 17, 13, 1, 1, 1, keep_host=True)
+    cases = [pa.local_items(A27.host_blocks)[0][0],
+             _random_csr(rng, 1003, 700, rng.integers(0, 30, 1003) * (rng.random(1003) < 0.7)),
+             _random_csr(rng, 130, 6000, np.concatenate([[4000, 0, 2500], rng.integers(0, 9, 127)]))]
+    for H in cases:
+        xh = rng.standard_normal(H.n)
+        Ho = orc.CSR(H.m, H.n, H.rowptr, H.colval, H.nzval)
+        want = np.zeros(H.m)
+        orc.oracle_c().spmv_csr(want, xh, Ho)
+        S, D = pa.DeviceSELL(H, sigma=sigma), pa.DeviceCSR(H)
+        info = S.info()
+        assert info["nnz"] == H.nnz and info["padded_entries"] >= H.nnz and info["n_slabs"] == (H.m + 63) // 64
+        x = pa.DeviceVector(H.n, 0).upload(xh)
+        ys, yd = pa.DeviceVector(H.m, 0), pa.DeviceVector(H.m, 0)
+        pa.spmv_(ys, S, x)
+        pa.spmv_(yd, D, x)
+        assert np.array_equal(ys.download(), want) and np.array_equal(yd.download(), want)
+        y0 = rng.standard_normal(H.m)
+        ys.upload(y0)
+        pa.spmv_(ys, S, x, alpha=-0.75, beta=2.5)
+        w5 = y0.copy()
+        orc.oracle_c().mul5_csr(w5, Ho, xh, -0.75, 2.5)
+        assert np.array_equal(ys.download(), w5)
+    if sigma > 1:                                        # sorting by length is what keeps the padding of ragged rows small
+        H = cases[1]
+        assert pa.DeviceSELL(H, sigma=sigma).info()["padded_entries"] < pa.DeviceSELL(H, sigma=1).info()["padded_entries"]
+    # signed zeros: beta*y = -0.0 on an empty row and products that are all -0.0 must come out as the reference's loop leaves them
+    H = pa.HostCSR(3, 2, np.array([1, 1, 3, 4], np.int32), np.array([1, 2, 1], np.int32), np.array([-0.0, 0.0, -1.0]))
+    S = pa.DeviceSELL(H, sigma=sigma)
+    x = pa.DeviceVector(2, 0).upload(np.array([1.0, 1.0]))
+    y = pa.DeviceVector(3, 0).upload(np.array([0.0, 0.0, 0.0]))
+    pa.spmv_(y, S, x, alpha=1.0, beta=-1.0)
+    w = np.zeros(3)
+    orc.oracle_c().mul5_csr(w, orc.CSR(3, 2, H.rowptr, H.colval, H.nzval), np.array([1.0, 1.0]), 1.0, -1.0)
+    got = y.download()
+    assert np.array_equal(got, w) and np.array_equal(np.signbit(got), np.signbit(w))
+
+
 def test_config2_laplacian_256_cubed_single_part(orc):
     """BASELINE config 2: 7-point Laplacian 256^3, one part, fp64 CSR SpMV only (no exchange), through the
     step-by-step set-up chain.  Size-independent properties: A*1 == alpha*(2D - #neighbours) bit-exactly
