@@ -586,9 +586,13 @@ def main():
                          "moved_bytes_per_launch": int(moved_oo), "achieved_moved": round(ach_moved, 1),
                          "frac_moved": round(ach_moved / HBM_PEAK_GBPS, 4),
                          "frac_moved_vs_this_box_read": (round(ach_moved / box["read_gbps"], 4) if box else None),
+                         "frac_moved_back_to_back": (round(moved_oo / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if N == 1 else None),
                          "what": "`achieved`/`frac`: the reference's CSR bytes (12 B per stored entry + 20 B per row, SURVEY 8d) over "
                                  "the kernel's average launch time; `achieved_moved`/`frac_moved`: the bytes this kernel must actually "
-                                 "move (row patterns leave no column stream: values + row pointers + descriptors + x once + y once)",
+                                 "move (row patterns leave no column stream: values + row pointers + descriptors + x once + y once); "
+                                 "`avg_launch_ms` is the kernel alone (event pass: ~19 us of event records before every launch), "
+                                 "`frac_moved_back_to_back` uses ms_per_step, the period of launches queued back to back (one part: a "
+                                 "step IS one launch), which also pays for the predecessor's dirty lines draining",
                          "timed_region_monotonic_ns": [mono0, mono1],
                          "this_box": box,
                          "memory_classes": {"arena": ctx.arena(), "value_stream": blk.own_own.memory_class(),

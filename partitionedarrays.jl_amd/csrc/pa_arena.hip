@@ -103,10 +103,10 @@ static int class_pass(pa_ctx *c, pa_arena *a, hipEvent_t e0, hipEvent_t e1, cons
 }
 
 static int arena_build(pa_ctx *c) {
+  if (c->capturing) return PA_OK;             // (not now: mapping the classes launches and synchronises; the next request tries again)
   c->arena_tried = true;
   const char *on = getenv("PA_ARENA");
   if (on && atoi(on) == 0) return PA_OK;
-  if (c->capturing) return PA_OK;
   PA_HIP(hipSetDevice(c->device));
   const size_t G = (size_t)1 << 30;
   size_t fr = 0, tot = 0;

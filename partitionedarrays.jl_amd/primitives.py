@@ -304,6 +304,14 @@ def exchange(snd, graph: ExchangeGraph):
         assert len(data) == len(snd_ids), "one item per send neighbour"
         out = [None] * len(rcv_ids)
         world = dist.get_world_size(group)
+        # host data travels over the host back-end when the group has one ("cpu:gloo,cuda:nccl"): set-up does not depend
+        # on the GPU transport, and no device memory is touched for pickled index lists
+        try:
+            import torch
+            dev = torch.device("cpu") if "gloo" in str(dist.get_backend_config(group)) else None
+        except Exception:                                    # noqa: BLE001
+            dev = None
+        kw = {} if dev is None else {"device": dev}
 
         def grank(part):
             return part - 1 if group is None else dist.get_global_rank(group, part - 1)
@@ -322,11 +330,11 @@ def exchange(snd, graph: ExchangeGraph):
             for phase in (0, 1):
                 if (phase == 0) == first_send:
                     if do_send:
-                        dist.send_object_list([data[snd_ids.index(partner)]], dst=grank(partner), group=group)
+                        dist.send_object_list([data[snd_ids.index(partner)]], dst=grank(partner), group=group, **kw)
                 else:
                     if do_recv:
                         box = [None]
-                        dist.recv_object_list(box, src=grank(partner), group=group)
+                        dist.recv_object_list(box, src=grank(partner), group=group, **kw)
                         out[rcv_ids.index(partner)] = box[0]
         return TorchDistArray(out, group)
     assert is_consistent(graph)

@@ -18,17 +18,32 @@ if os.path.exists(ks):
         w.writerows(rows)
     out["kernel_stats"] = [{"name": r["Name"][:80], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                             "pct": float(r["Percentage"])} for r in rows[:6]]
-# the timed region only: the headline-only pass ends with exactly `steps` (50) launches of the product kernel
+# the headline-only pass: its timed steps (between the CLOCK_MONOTONIC bounds bench.py prints) run back to back; the event
+# pass that follows brackets every launch with two event records, which leaves ~19 us between launches
 kth = os.path.join(src, "prof_kth", "kth_kernel_trace.csv")
-if os.path.exists(kth):
-    d = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-         for r in csv.DictReader(open(kth)) if "k_spmv_rowsplit" in r["Kernel_Name"]]
-    d.sort()
-    last = [u for _, u in d[-50:]]
-    out["timed_region"] = {"what": "the last 50 launches of k_spmv_rowsplit in the headline-only pass = bench.py's timed steps "
-                                   "(earlier launches: parity gate, warm-up)",
-                           "launches_total": len(d), "avg_us_last_50": sum(last) / max(1, len(last)),
-                           "min_us": min(last), "max_us": max(last), "avg_us_all": sum(u for _, u in d) / max(1, len(d))}
+blh = os.path.join(src, "bench_kth.log")
+if os.path.exists(kth) and os.path.exists(blh):
+    line = [l for l in open(blh) if l.startswith('{"metric"')]
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(kth)) if "k_spmv_rowsplit" in r["Kernel_Name"])
+    if line and d:
+        bench = json.loads(line[-1])
+        lo, hi = bench["roofline"].get("timed_region_monotonic_ns", [0, 0])
+        timed = [(a, b) for a, b in d if lo <= a <= hi]
+        after = [(a, b) for a, b in d if a > hi][:bench["roofline"].get("launches_timed", 50)]
+
+        def stats(seg):
+            if not seg:
+                return None
+            dur = [(b - a) / 1e3 for a, b in seg]
+            gap = [(seg[i + 1][0] - seg[i][1]) / 1e3 for i in range(len(seg) - 1)]
+            return {"launches": len(seg), "avg_us": sum(dur) / len(dur), "min_us": min(dur), "max_us": max(dur),
+                    "avg_gap_to_next_us": sum(gap) / max(1, len(gap)), "period_us": (seg[-1][1] - seg[0][0]) / 1e3 / len(seg)}
+        out["headline_only_pass"] = {
+            "what": "k_spmv_rowsplit launches of `bench.py --no-cpu-baseline --no-value-dict --no-extra --cg-iters 0`: the timed steps "
+                    "run back to back (a launch's duration then includes waiting for its predecessor's dirty lines to drain: the "
+                    "period is what ms_per_step measures), the event pass leaves a gap before every launch (the kernel alone)",
+            "timed_steps": stats(timed), "event_pass": stats(after), "bench_ms_per_step": bench["ms_per_step"],
+            "bench_avg_launch_ms_event_pass": bench["roofline"]["avg_launch_ms"], "launches_total": len(d)}
 # the default bench command's own timed region inside ITS trace: bench.py prints the CLOCK_MONOTONIC bounds
 kt = os.path.join(src, "prof_kt", "kt_kernel_trace.csv")
 bl = os.path.join(src, "bench_kt.log")
