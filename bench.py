@@ -495,6 +495,19 @@ def main():
         return dt, m0, m1
 
     overlap_on = not args.no_overlap
+    # ---- clock ramp, before the W warm-up steps and outside every timed region: after the host-side parity gate the GPU has
+    # been idle for seconds and needs ~40 launches (30 ms) of this kernel to be back at its working clocks -- the first
+    # launch after the idle takes 0.83 ms, the 40th 0.68 (rocprofv3 trace of round 2, profiles/r02_summary.json).  W = 5
+    # warm-up steps do not cover that; a fixed 150 steps do, the same number on every rank.
+    PHASE[0] = "clock ramp"
+    ramp = []
+    for _ in range(15):
+        e0 = ctx.event().record(L.STREAM_COMPUTE)
+        for _ in range(10):
+            step(overlap_on)
+        e1 = ctx.event().record(L.STREAM_COMPUTE)
+        ctx.sync()
+        ramp.append(e0.elapsed_ms(e1) / 10)
     PHASE[0] = f"warm-up (transport {transport})"
     for _ in range(args.warmup):
         step(overlap_on)
@@ -600,6 +613,9 @@ def main():
                                             "what": "csrc/pa_arena.hip: matrix streams and vectors live in different memory classes "
                                                     "of one contiguous arena (a write stream in its read stream's class costs 13-15 %)"}},
             "parity_gate": "A*1==b bit-exact; ghosts==owners bit-exact",
+            "clock_ramp": {"steps": 10 * len(ramp), "first_10_ms_per_step": round(ramp[0], 4), "last_10_ms_per_step": round(ramp[-1], 4),
+                           "what": "untimed steps run before the W warm-up steps: the GPU idles during the host-side parity gate and "
+                                   "needs ~40 launches to be back at its working clocks"},
             "setup_s": round(t_setup, 1),
         }
         LINE[0] = out

@@ -324,7 +324,9 @@ extern "C" int pa_ctx_create(int device, pa_ctx **out) {
   int prio_least = 0, prio_greatest = 0;
   PA_HIP(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
   c->comm_priority = prio_greatest;
-  PA_HIP(hipStreamCreateWithPriority(&c->s[0], hipStreamNonBlocking, prio_least));
+  int prio_compute = prio_least;
+  if (const char *e = getenv("PA_COMPUTE_PRIORITY")) prio_compute = atoi(e);     // (measurements)
+  PA_HIP(hipStreamCreateWithPriority(&c->s[0], hipStreamNonBlocking, prio_compute));
   PA_HIP(hipStreamCreateWithPriority(&c->s[1], hipStreamNonBlocking, prio_greatest));
   PA_HIP(hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming));
   hipDeviceProp_t prop;
@@ -1100,7 +1102,7 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
         const int32_t dec = d[4 + s] + rr * stride + pdelta[(size_t)d[12 + s] * PA_PAT_MAXLEN + (t - rr * L)];
         PA_REQUIRE(dec == col[p], "pattern decode mismatch at entry %lld (chunk %lld)", (long long)p, (long long)c);
       }
-    } else if (cs.win[c * PA_C16_WINDOWS] >= 0 && !is_long) {     // compacted 16-bit stream, the kernel's indexing
+    } else if (cs.use_c16 && cs.win[c * PA_C16_WINDOWS] >= 0 && !is_long) {     // compacted 16-bit stream, the kernel's indexing
       for (int64_t p = p0; p < p1; ++p) {
         const int64_t k = p + d[1];
         PA_REQUIRE(k >= 0 && k + 1 < (int64_t)cs.c16.size(), "compacted c16 slot out of range (chunk %lld)", (long long)c);
@@ -1118,7 +1120,7 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
   const int64_t nfall = full.n_c32;
   if (n_chunks) *n_chunks = nch;
   if (n_pattern) *n_pattern = npat;
-  if (n_c16) *n_c16 = nch - nfall;
+  if (n_c16) *n_c16 = nch - nfall;             // (of the full-length encoding: what the 16-bit windows COULD carry)
   if (n_patterns) *n_patterns = (int64_t)pdelta.size() / PA_PAT_MAXLEN;
   (void)n_cols;
   return PA_OK;
