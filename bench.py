@@ -138,28 +138,42 @@ def cpu_mul_baseline(pa, A, N, rank, seconds):
     cache = ind.cache
     nbr_snd, nbr_rcv = np.asarray(cache["neighbors_snd"]), np.asarray(cache["neighbors_rcv"])
     lsnd, lrcv = cache["local_indices_snd"], cache["local_indices_rcv"]
+
+    # one PHYSICAL core per rank: of every set of hyper-thread siblings only the first logical CPU counts (Linux numbers
+    # the siblings of core i as i and i + n/2, so "every (n/N)-th logical CPU" would pin two ranks to one core)
+    allowed = sorted(os.sched_getaffinity(0))
+    cores, seen = [], set()
+    for cpu in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(cpu)
+        if sib not in seen:
+            seen.add(sib)
+            cores.append(cpu)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    mine = cores[(local * len(cores)) // max(N, 1) % len(cores)]     # spread over the sockets / CCDs, as `--map-by` would
+    old = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, {mine})
+    torch_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    # the operands are (re)created by the pinned thread: first touch puts them on this core's NUMA node, where an MPI rank
+    # of the reference would have allocated them
     # consistent! uses the reversed cache (src/p_vector.jl:748): pack the own ids others ghost (rcv side), unpack into my ghosts
     buf_out = np.zeros(len(lrcv.data))
     buf_in = np.zeros(len(lsnd.data))
     x = np.zeros(ind.n_local)
     x[:ind.n_own] = hash_x(ind.own_to_global)
     y = np.zeros(oo.m)
-    Aoo, Aoh = orc.CSR(oo.m, oo.n, oo.rowptr, oo.colval, oo.nzval), orc.CSR(oh.m, oh.n, oh.rowptr, oh.colval, oh.nzval)
+    Aoo = orc.CSR(oo.m, oo.n, oo.rowptr.copy(), oo.colval.copy(), oo.nzval.copy())
+    Aoh = orc.CSR(oh.m, oh.n, oh.rowptr.copy(), oh.colval.copy(), oh.nzval.copy())
     t_out, t_in = torch.from_numpy(buf_out), torch.from_numpy(buf_in)
     xg = x[ind.n_own:]                       # ghost values: a view (the device layout [own | ghost] is the host layout too)
     glids = (np.asarray(lsnd.data, np.int64) - ind.n_own).astype(np.int32)
-
-    # one core per rank
-    cores = sorted(os.sched_getaffinity(0))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    mine = cores[(local * max(1, len(cores) // max(N, 1))) % len(cores)]
-    old = os.sched_getaffinity(0)
-    os.sched_setaffinity(0, {mine})
-    torch_threads = torch.get_num_threads()
-    torch.set_num_threads(1)
+    plids = np.ascontiguousarray(lrcv.data, np.int32)
 
     def one():
-        K.pack(buf_out, x, np.asarray(lrcv.data, np.int32))
+        K.pack(buf_out, x, plids)
         reqs = []
         for k, q in enumerate(nbr_snd):     # my ghosts' owners send to me
             a, e = int(lsnd.ptrs[k]) - 1, int(lsnd.ptrs[k + 1]) - 1
@@ -208,6 +222,7 @@ def cpu_mul_baseline(pa, A, N, rank, seconds):
     return {"value": round(2.0 * nnz_total / med / 1e9, 3), "unit": "GFLOP/s", "cores": N, "kind": "port",
             "ms_per_mul": round(med * 1e3, 2), "gflops": round(2.0 * nnz_total / med / 1e9, 3),
             "gbps_algorithmic_per_core": round(bytes_part / med / 1e9, 2),
+            "pinned_to_cpu": int(mine), "physical_cores_available": len(cores),
             "sample": f"the bench's own workload ({oo.m} rows, {nnz} stored entries per part, {N} part(s)): {len(times)} x mul! per "
                       f"rank = pack / exchange (gloo p2p) / spmv_csr! / unpack / muladd!, oracle/pa_oracle.c loops (-O3 "
                       f"-ffp-contract=off), one process pinned to one core per part (mpiexec -n {N} of the reference), median of "
