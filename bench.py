@@ -628,9 +628,9 @@ def main():
                          "what": "`achieved`/`frac`: the reference's CSR bytes (12 B per stored entry + 20 B per row, SURVEY 8d) over "
                                  "the kernel's average launch time; `achieved_moved`/`frac_moved`: the bytes this kernel must actually "
                                  "move (row patterns leave no column stream: values + row pointers + descriptors + x once + y once); "
-                                 "`avg_launch_ms` is the kernel alone (event pass: ~19 us of event records before every launch), "
-                                 "`frac_moved_back_to_back` uses ms_per_step, the period of launches queued back to back (one part: a "
-                                 "step IS one launch), which also pays for the predecessor's dirty lines draining",
+                                 "`avg_launch_ms` comes from the event pass (~19 us of event records between launches), "
+                                 "`frac_moved_back_to_back` from ms_per_step, the period of launches queued back to back (one part: a "
+                                 "step IS one launch)",
                          "timed_region_monotonic_ns": [mono0, mono1],
                          "this_box": box,
                          "memory_classes": {"arena": ctx.arena(), "value_stream": blk.own_own.memory_class(),

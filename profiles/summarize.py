@@ -19,7 +19,9 @@ if os.path.exists(ks):
     out["kernel_stats"] = [{"name": r["Name"][:80], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                             "pct": float(r["Percentage"])} for r in rows[:6]]
 # the headline-only pass: its timed steps (between the CLOCK_MONOTONIC bounds bench.py prints) run back to back; the event
-# pass that follows brackets every launch with two event records, which leaves ~19 us between launches
+# pass that follows brackets every launch with two event records, which leaves ~19 us between launches.  (Before bench.py
+# ran its clock-ramp steps the first timed launches took up to 0.83 ms: the GPU was still coming back from the idle of the
+# host-side parity gate.)
 kth = os.path.join(src, "prof_kth", "kth_kernel_trace.csv")
 blh = os.path.join(src, "bench_kth.log")
 if os.path.exists(kth) and os.path.exists(blh):
