@@ -483,7 +483,16 @@ def main():
     xv, yv = pa.local_items(x.vector_partition)[0], pa.local_items(y.vector_partition)[0]
 
     def step(overlap=True, ev=None):
-        # mul!(c,a,b): src/p_sparse_matrix.jl:2098-2101
+        # mul!(c,a,b): src/p_sparse_matrix.jl:2098-2101.  The timed loops queue it with ONE library call per step (pa_mul5 /
+        # pa_mul_all; overlap off: pa_mul_no_lat), so that the host's share of a step -- seven neighbours' worth of
+        # send/recv bookkeeping on an 8-GPU run -- is C, not Python; the event pass composes the same calls itself to put
+        # its events around own x own.  Same kernels, same order, same bits.
+        if ev is None:
+            if overlap:
+                pa.mul_c_(y, A, x)
+            else:
+                pa.mul_no_lat_c_(y, A, x)
+            return
         t = pa.consistent_(x)
         if not overlap:
             t.wait()                     # mul_no_lat! (HPCG/src/hpcg_utils.jl:6-17): exchange first, then the products

@@ -262,6 +262,9 @@ int pa_matrix_create(pa_ctx *ctx, const pa_csr *own_own, const pa_csr *own_ghost
 int pa_matrix_destroy(pa_matrix *m);
 int pa_mul(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b);
 int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta);
+/* mul_no_lat!(c,a,b) (HPCG/src/hpcg_utils.jl:6-17): the exchange is completed BEFORE own x own -- HPCG's reference order and the
+ * "overlap off" side of bench.py's on/off comparison.  Same kernels and bits as pa_mul. */
+int pa_mul_no_lat(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b);
 int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta);
 /* mul!(c,a,b) that also leaves this part's share of dot(b,c) in a slot (accumulate != 0: added to it): the CG loop's
  * c = A*u and u'c (HPCG/src/ref_cg.jl:59-60) without a pass over u and c for the dot -- every workgroup of the product

@@ -72,6 +72,7 @@ _SIGS = {
     "pa_matrix_destroy": [P],
     "pa_mul": [P, P, P, P],
     "pa_mul5": [P, P, P, P, f64, f64],
+    "pa_mul_no_lat": [P, P, P, P],
     "pa_mul_all": [P, i32, P, P, f64, f64],
     "pa_mul_dot": [P, P, P, P, cint, cint],
     "pa_mul_all_dot": [P, i32, P, P, cint],

@@ -1922,6 +1922,27 @@ extern "C" int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double
 
 extern "C" int pa_mul(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b) { return pa_mul5(m, comm, c, b, 1.0, 0.0); }
 
+// mul_no_lat!(c,a,b) (HPCG/src/hpcg_utils.jl:6-17): consistent!(b) |> wait FIRST, then the two local products -- the order
+// HPCG's reference solver uses, and the "overlap off" side of bench.py's comparison.  Same kernels, same bits as pa_mul.
+extern "C" int pa_mul_no_lat(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b) {
+  PA_TRY(mul_check(m, c, b));
+  PA_REQUIRE(c->d != b->d, "c and b alias");
+  if (!comm) {
+    PA_REQUIRE(m->plan->snd.nbr.empty() && m->plan->rcv.nbr.empty(), "the column plan has neighbours: pass the communicator");
+    PA_REQUIRE(m->plan->part == 0, "without a communicator the part must be the only one");
+  }
+  PA_TRY(pa_exchange_pack(m->plan, b, PA_CONSISTENT));
+  if (comm) PA_TRY(pa_exchange_rccl(m->plan, comm, PA_CONSISTENT));
+  else {
+    pa_plan *one[1] = {m->plan};
+    PA_TRY(pa_exchange_local(one, 1, PA_CONSISTENT));
+  }
+  PA_TRY(pa_exchange_finish(m->plan, b, PA_CONSISTENT));
+  PA_TRY(pa_spmv(m->oo, b, PA_SEG_OWN, c, PA_SEG_OWN, 1.0, 0.0));
+  PA_TRY(pa_spmv(m->oh, b, PA_SEG_GHOST, c, PA_SEG_OWN, 1.0, 1.0));
+  return PA_OK;
+}
+
 extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta) {
   PA_REQUIRE(m && c && b && n_parts > 0, "bad arguments");
   std::vector<pa_plan *> plans(n_parts);

@@ -323,6 +323,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       else if (EPI == 8) y[row] = acc;                            // probe only: plain (cached) y store
       else if (EPI == 9) y[row & 0x3ffff] = acc;                  // probe only: plain store into a 2 MiB window
       else if (EPI == 10) __builtin_nontemporal_store(acc, &y[row & 0x3ffff]);   // probe only: nt store into the window
+      else if (EPI == 12) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(&y[row]), "v"(acc) : "memory");   // probe only
+      else if (EPI == 13) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(&y[row]), "v"(acc) : "memory");   // probe only
       // non-temporal: y is written once and not read again by this kernel; measured 3.6 % faster than the plain
       // store (0.791 vs 0.820 ms; sc1 0.797, sc0 sc1 0.807, sc0 sc1 nt 0.842, no store at all 0.681)
       else __builtin_nontemporal_store(acc, &y[row]);

@@ -312,6 +312,23 @@ def mul_c_(c: PVector, a: PSparseMatrix, b: PVector, alpha=1.0, beta=0.0) -> PVe
     return c
 
 
+def mul_no_lat_c_(c: PVector, a: PSparseMatrix, b: PVector) -> PVector:
+    """HPCG's mul_no_lat!(c,a,b) (HPCG/src/hpcg_utils.jl:6-17) queued by one library call per part (pa_mul_no_lat): the
+    exchange completes before own x own.  Falls back to mul_no_overlap_ where the operator-level call does not apply."""
+    from .primitives import DebugArray, TorchDistArray, local_items
+    from . import p_vector as pv
+    _check_axes(c, a, b)
+    vp = b.vector_partition
+    one_per_process = isinstance(vp, TorchDistArray) and (vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None))
+    single = isinstance(vp, DebugArray) and len(vp.items) == 1
+    if not a.assembled or not (one_per_process or single):
+        return mul_no_overlap_(c, a, b)
+    h = local_items(_operator_handles(a, b))[0]
+    comm = context().comm.h if (one_per_process and vp.size > 1) else None
+    L.call("pa_mul_no_lat", h, comm, local_items(c.vector_partition)[0].h, local_items(vp)[0].h)
+    return c
+
+
 def mul_dot_(c: PVector, a: PSparseMatrix, b: PVector, slot: int) -> bool:
     """c = a*b as mul! does it AND slot <- dot(b,c), the dot accumulated inside the product kernels (pa_mul_dot /
     pa_mul_all_dot): the c = A*u, u'c pair of a CG iteration (HPCG/src/ref_cg.jl:59-60) without the dot's pass over u

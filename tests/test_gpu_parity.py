@@ -1304,6 +1304,25 @@ def test_sell_c_sigma_one_lane_per_row_is_bit_identical(orc, sigma):
     assert np.array_equal(got, w) and np.array_equal(np.signbit(got), np.signbit(w))
 
 
+def test_one_call_products_give_the_bits_of_the_composed_mul(orc):
+    """mul_c_ (pa_mul_all / pa_mul5) and mul_no_lat_c_ (pa_mul_no_lat; several parts in one process: the composed
+    mul_no_overlap_) against mul_ on 1 and 8 parts: same kernels in the same order, so the same bits -- and the ghosts of b
+    are those of the owners afterwards in every variant."""
+    for P, np3, n in ((1, (1, 1, 1), (20, 16, 12)), (8, (2, 2, 2), (10, 8, 6))):
+        A, _b = pa.build_p_matrix(ranks(P), *n, *(a * q for a, q in zip(n, np3)), *np3)
+        mk = lambda: pa.pvector_from_function(lambda i: orc.hash_x(i.get_local_to_global()) * (i.get_local_to_owner() == i.part), A.col_partition)
+        outs = []
+        for f in (pa.mul_, pa.mul_c_, pa.mul_no_lat_c_, pa.mul_no_overlap_):
+            x, y = mk(), pa.pzeros(A.row_partition)
+            f(y, A, x)
+            outs.append(([v.copy() for v in y.own_values().items], [v.copy() for v in x.local_values().items]))
+        for ys, xs in outs[1:]:
+            assert all(np.array_equal(a, b) for a, b in zip(ys, outs[0][0]))
+            assert all(np.array_equal(a, b) for a, b in zip(xs, outs[0][1]))
+        for xs, ind in zip(outs[0][1], A.col_partition.items):
+            assert np.array_equal(xs, orc.hash_x(ind.get_local_to_global()))
+
+
 def test_config2_laplacian_256_cubed_single_part(orc):
     """BASELINE config 2: 7-point Laplacian 256^3, one part, fp64 CSR SpMV only (no exchange), through the
     step-by-step set-up chain.  Size-independent properties: A*1 == alpha*(2D - #neighbours) bit-exactly

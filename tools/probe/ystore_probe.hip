@@ -115,9 +115,11 @@ int main(int argc, char **argv) {
                      (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, val_, d_x, y_, dc, (const int *)nullptr, nch, \
                      cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr)
   auto run = [&](const double *val, double *y, int epi = 0, int reps = 10) {
-    for (int w = 0; w < 2; ++w) { if (epi == 11) LAUNCH(11, val, y); else if (epi == 7) LAUNCH(7, val, y); else LAUNCH(0, val, y); }
+    auto go = [&]() { if (epi == 11) LAUNCH(11, val, y); else if (epi == 7) LAUNCH(7, val, y); else if (epi == 8) LAUNCH(8, val, y);
+                      else if (epi == 12) LAUNCH(12, val, y); else if (epi == 13) LAUNCH(13, val, y); else LAUNCH(0, val, y); };
+    for (int w = 0; w < 2; ++w) go();
     CK(hipEventRecord(e0, 0));
-    for (int w = 0; w < reps; ++w) { if (epi == 11) LAUNCH(11, val, y); else if (epi == 7) LAUNCH(7, val, y); else LAUNCH(0, val, y); }
+    for (int w = 0; w < reps; ++w) go();
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); CK(hipGetLastError());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return ms / reps;
@@ -254,6 +256,9 @@ int main(int argc, char **argv) {
         printf("  product, y in class 2, x in class 1:            %.4f\n", run(v, y2));
       }
       d_x = xs;
+      for (int round = 0; round < 3; ++round)
+        printf("  store flavours, y in class 1 (round %d): nt %.4f | plain %.4f | sc1 %.4f | sc0 sc1 %.4f | no store %.4f\n", round,
+               run(v, y1, 0, 20), run(v, y1, 8, 20), run(v, y1, 12, 20), run(v, y1, 13, 20), run(v, y1, 7, 20));
       printf("  product, y in class 0 (next to the values):     %.4f\n", run(v, (double *)(a + cv * cell + ((vbytes + 2 * M - 1) / (2 * M)) * 2 * M)));
       // BLAS-1 across classes: y = a*x + b*y (read 2, write 1) and w = x + y (read 2, write 1, distinct)
       auto tb = [&](auto f) { f(); CK(hipEventRecord(e0, 0)); for (int w = 0; w < 5; ++w) f(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / 5; };
