@@ -7,7 +7,7 @@ Host-side mirror (Python over the C ABI of libpa_hip.so) of the reference's inte
 from ._lib import PAError, LIB_PATH, SEG_OWN, SEG_GHOST, SEG_LOCAL, CONSISTENT, ASSEMBLE  # noqa: F401
 from .primitives import (MAIN, DebugArray, TorchDistArray, ExchangeGraph, with_debug, with_torchdist,  # noqa: F401
                          linear_indices, pmap, pforeach, tuple_of_arrays, getany, local_items, map_main,
-                         gather, scatter, reduction, preduce, scan, exchange, exchange_graph,
+                         gather, scatter, multicast, reduction, preduce, scan, exchange, exchange_graph,
                          find_rcv_ids_gather_scatter, is_consistent)
 from .p_range import (JaggedArray, LocalIndices, PRange, local_range, uniform_partition, variable_partition,  # noqa: F401
                       find_owner, filter_ghost, union_ghost, assembly_neighbors, assembly_local_indices)

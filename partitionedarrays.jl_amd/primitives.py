@@ -179,6 +179,16 @@ def scatter(snd, source=MAIN):
     return TorchDistArray(out[0], snd.group)
 
 
+def multicast(snd, source=MAIN):
+    """multicast(snd;source) (src/primitives.jl:486-561): every part receives the item part `source` holds."""
+    if isinstance(snd, DebugArray):
+        return DebugArray([snd.items[source - 1] for _ in snd.items])
+    import torch.distributed as dist
+    box = [snd.item if snd.rank + 1 == source else None]
+    dist.broadcast_object_list(box, src=_global_rank(snd.group, source - 1), group=snd.group)
+    return TorchDistArray(box[0], snd.group)
+
+
 def _global_rank(group, group_rank):
     import torch.distributed as dist
     if group is None:

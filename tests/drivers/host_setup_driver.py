@@ -33,6 +33,19 @@ def main():
         assert pa.getany(pa.scan(lambda a, b: a + b, ranks, type="inclusive", init=0)) == me * (me + 1) // 2
         assert pa.getany(pa.scan(lambda a, b: a + b, ranks, type="exclusive", init=1)) == 1 + me * (me - 1) // 2
         if P == 4:
+            c6 = golden["collectives"]                       # the literal expectations, one part per process
+            b10 = pa.pmap(lambda r: 10 * r, ranks)
+            assert pa.getany(pa.gather(b10, destination="all")) == c6["gather_10rank"]["rcv"]
+            snd = pa.pmap(lambda r: list(range(1, r + 1)), ranks)
+            assert pa.getany(pa.gather(snd, destination="all")) == c6["gather_ragged"]["rcv_all"]
+            assert pa.getany(pa.scatter(pa.gather(snd))) == list(range(1, me + 1))
+            assert pa.getany(pa.multicast(ranks, source=2)) == c6["multicast_rank_source2"]
+            assert pa.getany(pa.multicast(snd, source=2)) == c6["multicast_ragged_source2"]
+            a3 = pa.pmap(lambda r: 3 * (r % 3), ranks)
+            plus = lambda x, y: x + y
+            assert pa.getany(pa.scan(plus, a3, type="inclusive", init=0)) == c6["scan"]["inclusive_init0"][me - 1]
+            assert pa.getany(pa.scan(plus, a3, type="exclusive", init=1)) == c6["scan"]["exclusive_init1"][me - 1]
+            assert pa.getany(pa.reduction(plus, ranks, init=10, destination="all")) == c6["reduction"]["sum_init10_all"]
             for c in golden["exchange"]:
                 snd_ids = distribute(c["snd_ids"])
                 graph = pa.exchange_graph(snd_ids, None if c["rcv_ids"] is None else distribute(c["rcv_ids"]))

@@ -98,6 +98,15 @@ G["hpcg_known_answer"] = {"src": "HPCG/test/hpcg_benchmark_tests.jl:31-41", "np"
 G["ghost_first_seen"] = {"src": "SURVEY.md Appendix A (derived from HPCG/src/sparse_matrix.jl:41-57 + src/p_range.jl:226-239)",
                          "global": [8, 4, 4], "parts": [2, 1, 1], "part": 2, "ghost_gids_head": [4, 12, 36, 44, 20, 52]}
 
+# G6 collectives on 4 parts (rank = 1..4): literal expectations of test/primitives_tests.jl
+G["collectives"] = {"src": "test/primitives_tests.jl:40-150", "np": 4,
+                    "gather_10rank": {"snd": [10, 20, 30, 40], "rcv": [10, 20, 30, 40], "destination": 2, "lines": "40-49,58-62"},
+                    "gather_ragged": {"snd": [[1], [1, 2], [1, 2, 3], [1, 2, 3, 4]], "rcv_all": [[1], [1, 2], [1, 2, 3], [1, 2, 3, 4]], "lines": "64-78"},
+                    "scatter_roundtrip": "scatter(gather(snd)) == snd (lines 51-55, 67-72)",
+                    "multicast_rank_source2": 2, "multicast_ragged_source2": [1, 2], "multicast_lines": "103-112",
+                    "scan": {"a": "3*mod(rank,3)", "a_values": [3, 6, 0, 3], "inclusive_init0": [3, 9, 9, 12], "exclusive_init1": [1, 4, 10, 10], "lines": "114-126"},
+                    "reduction": {"sum_init0": 10, "sum_init10_all": 20, "reduce": 10, "reduce_init2": 12, "lines": "140-150"}}
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_literals.json")
 with open(out, "w") as f:
     json.dump(G, f, indent=1)

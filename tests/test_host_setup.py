@@ -335,3 +335,29 @@ def test_ghost_layers_and_self_owned_ghosts_match_the_reference_constructor(orc)
     # the 1-D form with two layers: parts of 3,3,4 ids plus up to two ghosts on each side
     one = pa.uniform_partition(pa.DebugArray(range(1, 4)), 3, 10, 2)
     assert [list(i.get_local_to_global()) for i in one.items] == [[1, 2, 3, 4, 5], [2, 3, 4, 5, 6, 7, 8], [5, 6, 7, 8, 9, 10]]
+
+
+def test_collectives_goldens(golden):
+    """G6: gather / scatter / multicast / scan / reduction on 4 parts against the literal expectations of
+    test/primitives_tests.jl:40-150 (DebugArray back-end; the one-part-per-process back-end runs the same checks in
+    tests/drivers/host_setup_driver.py)."""
+    c = golden["collectives"]
+    rank = pa.DebugArray(range(1, c["np"] + 1))
+    b = pa.pmap(lambda r: 10 * r, rank)
+    rcv = pa.gather(b, destination=c["gather_10rank"]["destination"])
+    assert rcv.items[c["gather_10rank"]["destination"] - 1] == c["gather_10rank"]["rcv"]
+    assert pa.scatter(rcv, source=c["gather_10rank"]["destination"]).items == b.items
+    assert all(v == c["gather_10rank"]["rcv"] for v in pa.gather(b, destination="all").items)
+    snd = pa.pmap(lambda r: list(range(1, r + 1)), rank)
+    assert pa.scatter(pa.gather(snd)).items == snd.items
+    assert all(v == c["gather_ragged"]["rcv_all"] for v in pa.gather(snd, destination="all").items)
+    assert all(v == c["multicast_rank_source2"] for v in pa.multicast(rank, source=2).items)
+    assert all(v == c["multicast_ragged_source2"] for v in pa.multicast(snd, source=2).items)
+    a = pa.pmap(lambda r: 3 * (r % 3), rank)
+    assert a.items == c["scan"]["a_values"]
+    plus = lambda x, y: x + y
+    assert pa.gather(pa.scan(plus, a, type="inclusive", init=0)).items[0] == c["scan"]["inclusive_init0"]
+    assert pa.gather(pa.scan(plus, a, type="exclusive", init=1)).items[0] == c["scan"]["exclusive_init1"]
+    assert pa.reduction(plus, rank, init=0).items[0] == c["reduction"]["sum_init0"]
+    assert all(v == c["reduction"]["sum_init10_all"] for v in pa.reduction(plus, rank, init=10, destination="all").items)
+    assert pa.preduce(plus, rank) == c["reduction"]["reduce"] and pa.preduce(plus, rank, init=2) == c["reduction"]["reduce_init2"]
