@@ -107,6 +107,11 @@ G["collectives"] = {"src": "test/primitives_tests.jl:40-150", "np": 4,
                     "scan": {"a": "3*mod(rank,3)", "a_values": [3, 6, 0, 3], "inclusive_init0": [3, 9, 9, 12], "exclusive_init1": [1, 4, 10, 10], "lines": "114-126"},
                     "reduction": {"sum_init0": 10, "sum_init10_all": 20, "reduce": 10, "reduce_init2": 12, "lines": "140-150"}}
 
+# G10 JaggedArray construction / equality
+G["jagged_array"] = {"src": "test/jagged_array_tests.jl:6-22", "a": [[1, 2], [3, 4, 5], [], [3, 4]],
+                     "data": [1, 2, 3, 4, 5, 3, 4], "ptrs": [1, 3, 6, 6, 8],
+                     "note": "data/ptrs follow from length_to_ptrs! (src/jagged_array.jl:11-18): ptrs[1] = 1, ptrs[i+1] = ptrs[i] + length(a[i])"}
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_literals.json")
 with open(out, "w") as f:
     json.dump(G, f, indent=1)

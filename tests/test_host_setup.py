@@ -361,3 +361,13 @@ def test_collectives_goldens(golden):
     assert pa.reduction(plus, rank, init=0).items[0] == c["reduction"]["sum_init0"]
     assert all(v == c["reduction"]["sum_init10_all"] for v in pa.reduction(plus, rank, init=10, destination="all").items)
     assert pa.preduce(plus, rank) == c["reduction"]["reduce"] and pa.preduce(plus, rank, init=2) == c["reduction"]["reduce_init2"]
+
+
+def test_jagged_array_golden(orc, golden):
+    """G10 (test/jagged_array_tests.jl:6-22): JaggedArray(a) == a, rebuilt from (data, ptrs) == itself; 1-based ptrs."""
+    c = golden["jagged_array"]
+    for J in (pa.JaggedArray.from_lists(c["a"], np.int64), orc.Jagged.from_lists(c["a"], dtype=np.int64)):
+        assert list(J.data) == c["data"] and list(J.ptrs) == c["ptrs"] and len(J) == len(c["a"])
+        assert [list(J[i]) for i in range(len(J))] == c["a"]
+    b = pa.JaggedArray.from_lists(c["a"], np.int64)
+    assert pa.JaggedArray(b.data, b.ptrs) == b and b.tolists() == c["a"]
