@@ -922,6 +922,24 @@ def psparse_from_coo(I, J, V, row_partition, index_dtype=I32):
     return psparse_assembled(I, J, V, row_partition, cols, index_dtype)
 
 
+def _fdiv(a, b):
+    """a / b as Julia's Float64 division gives it: 0/0 = NaN, x/0 = +-Inf (python raises ZeroDivisionError)."""
+    if b != 0.0:
+        return a / b
+    if a == 0.0 or a != a:
+        return float("nan")
+    import math
+    return math.copysign(float("inf"), a) * math.copysign(1.0, b)
+
+
+def _converged(residual, residual0, tolerance):
+    """residual/residual0 <= tolerance (HPCG/src/ref_cg.jl:23) with Julia's semantics: 0/0 is NaN (comparison false: a zero
+    right-hand side iterates to maxiter), x/0 is Inf."""
+    if residual0 == 0.0:
+        return False if (residual == 0.0 or residual != residual) else float("inf") <= tolerance
+    return residual / residual0 <= tolerance
+
+
 def ref_cg(x, A: PSparse, b, maxiter=50, tolerance=0.0, history=None, mv=None):
     """HPCG/src/ref_cg.jl:40-134 with Pl = Identity(): x, residual0, residual, iters (lists of local arrays).
     mv: the product used (default mul_no_lat!, as HPCG; pass `mul` for a matrix that only has its split blocks)."""
@@ -935,16 +953,16 @@ def ref_cg(x, A: PSparse, b, maxiter=50, tolerance=0.0, history=None, mv=None):
         ri[:i.n_own] -= ci[:i.n_own]
     residual0 = residual = norm2(r, ind)
     rho, iters = 1.0, 0
-    while not (iters >= maxiter or residual / residual0 <= tolerance):
+    while not (iters >= maxiter or _converged(residual, residual0, tolerance)):
         for ci, ri in zip(c, r):
             ci[:] = ri
         rho_prev = rho
         rho = dot(c, r, ind)
-        beta = rho / rho_prev
+        beta = _fdiv(rho, rho_prev)
         for ui, ci, i in zip(u, c, ind):
             ui[:i.n_own] = ci[:i.n_own] + beta * ui[:i.n_own]
         mul_no_lat(c, A, u)
-        alpha = rho / dot(u, c, ind)
+        alpha = _fdiv(rho, dot(u, c, ind))
         for xi, ui, ri, ci, i in zip(x, u, r, c, ind):
             xi[:i.n_own] += alpha * ui[:i.n_own]
             ri[:i.n_own] -= alpha * ci[:i.n_own]
@@ -1330,17 +1348,17 @@ def ref_cg_mg(x, A: PSparse, b, S: MgPreconditioner, maxiter=50, tolerance=0.0, 
         ri[:i.n_own] -= ci[:i.n_own]
     residual0 = residual = norm2(r, ind)
     rho, iters = 1.0, 0
-    while not (iters >= maxiter or residual / residual0 <= tolerance):
+    while not (iters >= maxiter or _converged(residual, residual0, tolerance)):
         for ci in c:
             ci[:] = 0.0
         pc_solve(c, S, r, S.l, zero_guess=True)
         rho_prev = rho
         rho = dot(c, r, ind)
-        beta = rho / rho_prev
+        beta = _fdiv(rho, rho_prev)
         for ui, ci, i in zip(u, c, ind):
             ui[:i.n_own] = ci[:i.n_own] + beta * ui[:i.n_own]
         mul_no_lat(c, A, u)
-        alpha = rho / dot(u, c, ind)
+        alpha = _fdiv(rho, dot(u, c, ind))
         for xi, ui, ri, ci, i in zip(x, u, r, c, ind):
             xi[:i.n_own] += alpha * ui[:i.n_own]
             ri[:i.n_own] -= alpha * ci[:i.n_own]

@@ -432,6 +432,16 @@ class _NoTimer:
 _NO_TIMER = _NoTimer()
 
 
+def _fdiv(a, b):
+    """a / b as Julia's Float64 division gives it: 0/0 = NaN, x/0 = +-Inf (python raises ZeroDivisionError)."""
+    if b != 0.0:
+        return a / b
+    if a == 0.0 or a != a:
+        return float("nan")
+    import math
+    return math.copysign(float("inf"), a) * math.copysign(1.0, b)
+
+
 def _converged(residual, residual0, tolerance):
     """`residual/residual0 <= tolerance` (HPCG/src/ref_cg.jl:23) with Julia's floating-point semantics: 0/0 is NaN and
     the comparison is false (a zero right-hand side iterates to maxiter), x/0 is Inf."""
@@ -477,14 +487,14 @@ def ref_cg_(x, A, b, maxiter=50, tolerance=0.0, overlap=True, history=None, Pl=N
         rho_prev = rho
         with tm.span("DDOT"):
             rho = dot(c, r)                  # (:52)
-        beta = rho / rho_prev
+        beta = _fdiv(rho, rho_prev)
         with tm.span("WAXPBY"):
             axpby_(u, 1.0, c, beta)          # u .= c .+ beta .* u     (:56)
         with tm.span("SPMV"):
             mv(c, A, u)                      # c = A*u                 (:59)
         with tm.span("DDOT"):
             uc = dot(u, c)                   # (:60)
-        alpha = rho / uc
+        alpha = _fdiv(rho, uc)
         with tm.span("WAXPBY"):
             axpby_(x, alpha, u, 1.0)         # x .+= alpha .* u        (:64)
             axpby_(r, -alpha, c, 1.0)        # r .-= alpha .* c        (:65)

@@ -1323,6 +1323,19 @@ def test_one_call_products_give_the_bits_of_the_composed_mul(orc):
             assert np.array_equal(xs, orc.hash_x(ind.get_local_to_global()))
 
 
+def test_cg_with_a_zero_right_hand_side_behaves_like_julia(orc):
+    """`residual/residual0 <= tolerance` with residual0 == 0 is 0/0 = NaN in Julia -- false, so the loop runs to
+    maxiter on NaNs -- where python raised ZeroDivisionError (and took the job down under with_torchdist)."""
+    A, b = pa.build_p_matrix(ranks(1), 8, 8, 8, 8, 8, 8, 1, 1, 1)
+    zero = pa.pzeros(A.col_partition)
+    for fn in (pa.ref_cg_, pa.opt_cg_):
+        x, r0, r, it = fn(pa.pzeros(A.col_partition), A, zero, maxiter=4, tolerance=1e-6)
+        assert it == 4 and r0 == 0.0 and r != r                       # NaN residual, all iterations done
+    Ao, bo, _ = orc.hpcg_build_p_matrix(8, 8, 8, 1, 1, 1)
+    xo, r0o, ro, ito = orc.ref_cg([np.zeros(c.n_local) for c in Ao.cols], Ao, [np.zeros_like(v) for v in bo], maxiter=4, tolerance=1e-6)
+    assert ito == 4 and r0o == 0.0 and ro != ro
+
+
 def test_config2_laplacian_256_cubed_single_part(orc):
     """BASELINE config 2: 7-point Laplacian 256^3, one part, fp64 CSR SpMV only (no exchange), through the
     step-by-step set-up chain.  Size-independent properties: A*1 == alpha*(2D - #neighbours) bit-exactly
