@@ -1336,6 +1336,40 @@ def test_cg_with_a_zero_right_hand_side_behaves_like_julia(orc):
     assert ito == 4 and r0o == 0.0 and ro != ro
 
 
+def test_new_entry_points_return_statuses_on_bad_arguments():
+    """The round-2 entry points keep the ABI's convention: a bad call is a status + message, never an abort."""
+    import pa_amd._lib as L
+    import ctypes as C
+    A, b = pa.build_p_matrix(ranks(1), 6, 6, 6, 6, 6, 6, 1, 1, 1, keep_host=True)
+    H = pa.local_items(A.host_blocks)[0][0]
+    x, y = pa.pzeros(A.col_partition), pa.pzeros(A.row_partition)
+    xv, yv = x.vector_partition.items[0], y.vector_partition.items[0]
+    import pa_amd.p_sparse_matrix as psm
+    h = psm._operator_handles(A, x).items[0]
+    for args, what in (((h, None, yv.h, xv.h, 99, 0), "slot"), ((h, None, xv.h, xv.h, 3, 0), "alias")):
+        with pytest.raises(L.PAError, match=what):
+            L.call("pa_mul_dot", *args)
+    with pytest.raises(L.PAError, match="distinct"):
+        L.call("pa_cg_r_update", xv.h, xv.h, 1, 2, 3, 0)
+    with pytest.raises(L.PAError, match="result slot"):
+        L.call("pa_cg_r_update", xv.h, yv.h, 3, 2, 3, 0)
+    with pytest.raises(L.PAError, match="distinct"):
+        L.call("pa_cg_xu_update", xv.h, xv.h, yv.h, 1, 2, 1, 2)
+    with pytest.raises(L.PAError, match="alias"):
+        L.call("pa_mul_no_lat", h, None, xv.h, xv.h)
+    out = C.c_void_p()
+    with pytest.raises(L.PAError, match="sigma"):
+        L.call("pa_sell_create", pa.context().h, H.m, H.n, H.nnz, L.ptr(H.rowptr), L.ptr(H.colval), 4, 1, L.ptr(H.nzval), 0, C.byref(out))
+    bad = H.colval.copy()
+    bad[3] = H.n + 5
+    with pytest.raises(L.PAError, match="column index out of range"):
+        L.call("pa_sell_create", pa.context().h, H.m, H.n, H.nnz, L.ptr(H.rowptr), L.ptr(bad), 4, 1, L.ptr(H.nzval), 1, C.byref(out))
+    S = pa.DeviceSELL(H)
+    with pytest.raises(L.PAError, match="size"):
+        pa.spmv_(pa.DeviceVector(H.m + 1, 0), S, pa.DeviceVector(H.n, 0))
+    assert L.lib.pa_ctx_arena_info(None, None, None, None, None, None, None) == -2
+
+
 def test_config2_laplacian_256_cubed_single_part(orc):
     """BASELINE config 2: 7-point Laplacian 256^3, one part, fp64 CSR SpMV only (no exchange), through the
     step-by-step set-up chain.  Size-independent properties: A*1 == alpha*(2D - #neighbours) bit-exactly
