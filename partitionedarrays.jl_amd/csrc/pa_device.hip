@@ -403,7 +403,9 @@ extern "C" int pa_event_create(pa_ctx *c, pa_event **ev) {
   PA_HIP(hipSetDevice(c->device));
   pa_event *e = new pa_event();
   e->ctx = c;
-  PA_HIP(hipEventCreate(&e->ev));
+  // timing events: no system-scope fence when they complete (the default one writes back / invalidates the caches between
+  // two launches: a product bracketed by default events ran 3 % slower than the same product queued back to back)
+  PA_HIP(hipEventCreateWithFlags(&e->ev, hipEventDisableSystemFence));
   *ev = e;
   return PA_OK;
 }
