@@ -45,7 +45,8 @@ if os.path.exists(kth) and os.path.exists(blh):
                     "run back to back (a launch's duration then includes waiting for its predecessor's dirty lines to drain: the "
                     "period is what ms_per_step measures), the event pass leaves a gap before every launch (the kernel alone)",
             "timed_steps": stats(timed), "event_pass": stats(after), "bench_ms_per_step": bench["ms_per_step"],
-            "bench_avg_launch_ms_event_pass": bench["roofline"]["avg_launch_ms"], "launches_total": len(d)}
+            "bench_avg_launch_ms": bench["roofline"]["avg_launch_ms"],
+            "bench_event_pass": bench["roofline"].get("event_pass"), "launches_total": len(d)}
 # the default bench command's own timed region inside ITS trace: bench.py prints the CLOCK_MONOTONIC bounds
 kt = os.path.join(src, "prof_kt", "kt_kernel_trace.csv")
 bl = os.path.join(src, "bench_kt.log")
@@ -62,7 +63,7 @@ if os.path.exists(kt) and os.path.exists(bl):
                     "in the trace of the default command (profiles/rNN_kernel_stats.csv averages ALL launches of the process: "
                     "parity gate, warm-up, timed steps, the event pass, CG loop, value-dictionary mode, extra configs)",
             "launches": len(d), "avg_us": sum(d) / max(1, len(d)), "bench_ms_per_step": bench["ms_per_step"],
-            "bench_avg_launch_ms_event_pass": bench["roofline"]["avg_launch_ms"]}
+            "bench_avg_launch_ms": bench["roofline"]["avg_launch_ms"], "bench_event_pass": bench["roofline"].get("event_pass")}
         json.dump(bench, open(os.path.join(os.path.dirname(__file__), f"{tag}_bench_n1.json"), "w"))
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d, f in (("prof_fetch", "f"), ("prof_write", "w"), ("prof_tcc", "t")):
