@@ -10,6 +10,7 @@
 #   vector cache       p_vector_cache_impl    src/p_vector.jl:451-468
 #   ghost exchange     assemble_impl!         src/p_vector.jl:587-612   (used by assemble! :695 and consistent! :747)
 #   local SpMV         spmv!, mul!(…,α,β)     src/sparse_utils.jl:609-669, src/p_sparse_matrix.jl:2088
+#   BLAS-1             dot, norm, broadcast   src/p_vector.jl:1189-1277 (the local arrays' broadcast is what PVector's calls)
 # With these methods defined, the reference's own `mul!(c::PVector,a::PSparseMatrix,b::PVector)`
 # (src/p_sparse_matrix.jl:2090-2103) runs unchanged: pack/exchange on the comm stream, own*own on the compute
 # stream, wait(t), own*ghost.
@@ -104,6 +105,85 @@ function LinearAlgebra.dot(a::HIPSegment, b::HIPSegment)
     out = Ref{Float64}(0.0)
     check(ccall((:pa_vec_dot, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), a.parent.handle, b.parent.handle, out))
     out[]
+end
+
+# ---------------------------------------------------------------- BLAS-1 on segments: what a solver loop does to a PVector
+# The reference's PVector broadcast (src/p_vector.jl:1216-1277) hands the expression to the LOCAL arrays: `x .+= alpha .* u`
+# becomes, per part, materialize!(own_values(x), broadcasted(+, own_values(x), broadcasted(*, alpha, own_values(u)))).
+# For HIPSegments that expression is flattened into a linear combination  dest = sum_i coef_i * v_i + constant  and run by
+# pa_vec_axpby (y = a*x + b*y, unfused multiply and add: the same roundings as the reference's loop for the statements of a CG
+# iteration, HPCG/src/ref_cg.jl:56,64-65: c .+ beta .* u, x .+ alpha .* u, r .- alpha .* c).  Anything that is not a linear
+# combination of at most two vectors is refused (no scalar fallback: scalar indexing of device memory is an error).
+struct HIPStyle <: Base.Broadcast.AbstractArrayStyle{1} end
+HIPStyle(::Val{1}) = HIPStyle()
+HIPStyle(::Val{N}) where N = Base.Broadcast.DefaultArrayStyle{N}()
+Base.BroadcastStyle(::Type{HIPSegment}) = HIPStyle()
+
+"dest-independent linear form of a broadcast tree: (constant, [(segment, coefficient), ...])"
+_lin(x::Number) = (Float64(x), Tuple{HIPSegment,Float64}[])
+_lin(x::Base.RefValue{<:Number}) = _lin(x[])
+_lin(x::HIPSegment) = (0.0, [(x, 1.0)])
+function _lin(bc::Base.Broadcast.Broadcasted)
+    f, a = bc.f, map(_lin, bc.args)
+    if f === (+) && length(a) == 2
+        return (a[1][1] + a[2][1], vcat(a[1][2], a[2][2]))
+    elseif f === (-) && length(a) == 2
+        return (a[1][1] - a[2][1], vcat(a[1][2], [(v, -c) for (v, c) in a[2][2]]))
+    elseif f === (-) && length(a) == 1
+        return (-a[1][1], [(v, -c) for (v, c) in a[1][2]])
+    elseif f === (*) && length(a) == 2 && (isempty(a[1][2]) || isempty(a[2][2]))
+        k, t = isempty(a[1][2]) ? (a[1][1], a[2]) : (a[2][1], a[1])
+        return (k * t[1], [(v, k * c) for (v, c) in t[2]])
+    elseif f === (/) && length(a) == 2 && isempty(a[2][2])
+        return (a[1][1] / a[2][1], [(v, c / a[2][1]) for (v, c) in a[1][2]])
+    elseif f === identity && length(a) == 1
+        return a[1]
+    end
+    error("PartitionedArraysHIP: only linear combinations of device vectors are broadcast on the device (got $(f))")
+end
+_axpby!(y::HIPSegment, a, x::HIPSegment, b) =
+    check(ccall((:pa_vec_axpby, libpa), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Cint),
+                y.parent.handle, Float64(a), x.parent.handle, Float64(b), y.seg))
+function Base.copyto!(dest::HIPSegment, bc::Base.Broadcast.Broadcasted{HIPStyle})
+    k, terms = _lin(bc)
+    all(t -> t[1].seg == dest.seg, terms) || error("PartitionedArraysHIP: a broadcast mixes own and ghost segments")
+    k == 0.0 || isempty(terms) || error("PartitionedArraysHIP: vector + constant is not broadcast on the device")
+    merged = Tuple{HIPSegment,Float64}[]                        # equal vectors merge: x .+ x is 2x
+    for (v, c) in terms
+        i = findfirst(t -> t[1].parent === v.parent, merged)
+        i === nothing ? push!(merged, (v, c)) : (merged[i] = (v, merged[i][2] + c))
+    end
+    mine = findfirst(t -> t[1].parent === dest.parent, merged)
+    b = mine === nothing ? 0.0 : merged[mine][2]
+    rest = [t for t in merged if t[1].parent !== dest.parent]
+    if isempty(rest)
+        isempty(merged) ? fill!(dest, k) : _axpby!(dest, 0.0, dest, b)
+    elseif length(rest) == 1
+        _axpby!(dest, rest[1][2], rest[1][1], b)                 # dest = a*v + b*dest
+    elseif length(rest) == 2 && mine === nothing
+        _axpby!(dest, rest[1][2], rest[1][1], 0.0)               # dest = a*v, then += c*w
+        _axpby!(dest, rest[2][2], rest[2][1], 1.0)
+    else
+        error("PartitionedArraysHIP: a broadcast of more than two device vectors is not supported")
+    end
+    dest
+end
+Base.copyto!(dest::HIPSegment, bc::Base.Broadcast.Broadcasted{<:Base.Broadcast.AbstractArrayStyle{0}}) =
+    fill!(dest, _lin(bc)[1])                                     # u .= zero(T)  (HPCG/src/ref_cg.jl:71)
+Base.copyto!(dest::HIPSegment, src::HIPSegment) =
+    (dest.parent === src.parent || check(ccall((:pa_vec_copy, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint),
+                                               dest.parent.handle, src.parent.handle, dest.seg)); dest)
+Base.copy!(dest::HIPVector, src::HIPVector) =
+    (check(ccall((:pa_vec_copy, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), dest.handle, src.handle, PA_SEG_LOCAL)); dest)
+Base.copyto!(dest::HIPVector, src::HIPVector) = copy!(dest, src)
+Base.similar(v::HIPVector) = HIPVector(v.n_own, v.n_ghost)
+Base.similar(v::HIPVector, ::Type{Float64}) = HIPVector(v.n_own, v.n_ghost)
+Base.fill!(v::HIPVector, x) =
+    (check(ccall((:pa_vec_fill, libpa), Cint, (Ptr{Cvoid}, Cint, Float64), v.handle, PA_SEG_LOCAL, x)); v)
+"norm(own_values(a),p) of LinearAlgebra.norm(a::PVector,p) (src/p_vector.jl:1201-1206); p = 2 on the device."
+function LinearAlgebra.norm(s::HIPSegment, p::Real=2)
+    p == 2 || error("PartitionedArraysHIP: only the 2-norm is computed on the device")
+    sqrt(dot(s, s))
 end
 
 # ---------------------------------------------------------------- local matrix type
