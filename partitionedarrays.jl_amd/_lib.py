@@ -16,7 +16,7 @@ import numpy as np
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpa_hip.so")
+LIB_PATH = os.environ.get("PA_HIP_LIBRARY") or os.path.join(_HERE, "libpa_hip.so")   # the override: probe builds of the library
 
 
 class PAError(RuntimeError):
@@ -118,6 +118,7 @@ _SIGS = {
     "pa_scatter_add": [P, P, P, cint],
     "pa_csr_info": [P] + [C.POINTER(i64)] * 6,
     "pa_csr_encoding": [P] + [C.POINTER(i64)] * 3,
+    "pa_csr_xwin_info": [P] + [C.POINTER(i64)] * 3,
     "pa_spmv": [P, P, cint, P, cint, f64, f64],
     "pa_sell_create": [P, i64, i64, i64, P, P, cint, cint, P, cint, PP],
     "pa_sell_destroy": [P],

@@ -67,6 +67,7 @@ extern "C" int pa_device_count(int *count) {
 // kernels
 // ------------------------------------------------------------------------------------------------
 #include "pa_spmv_kernel.h"
+#include "pa_spmv_xwin.h"
 
 // shipped configuration of the row-split kernel (chosen with tools/probe/spmv_probe.hip on MI355X)
 constexpr int SPMV_BLK = 256;
@@ -770,6 +771,35 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
     PA_HIP(hipMemcpy(A->d_col16, cs.c16.data(), sizeof(uint16_t) * cs.c16.size(), hipMemcpyHostToDevice));
     if (!cs.win.empty()) PA_HIP(hipMemcpy(A->d_win, cs.win.data(), sizeof(int32_t) * cs.win.size(), hipMemcpyHostToDevice));
   }
+  // Rows without a pattern whose columns stay within a band: groups of chunks read x from an LDS copy of their span
+  // (pa_spmv_xwin.h).  Taken when most of the block's chunks fall into groups and the staged x is a fraction of the matrix
+  // bytes the groups stream; PA_SPMV_XWIN=0 keeps every chunk on k_spmv_rowsplit.
+  {
+    const char *ex = getenv("PA_SPMV_XWIN");
+    if (cs.use_c16 && !cs.use_pattern && !compact && !(ex && atoi(ex) == 0) && A->n_chunks >= 64) {
+      std::vector<pa_xw_group> groups;
+      std::vector<int32_t> rest;
+      int64_t grouped = 0;
+      const int64_t staged = pa_build_xw_groups(crp.data(), col0, chunk_row, cs.win.data(), groups, rest, &grouped);
+      const bool forced = ex && atoi(ex) == 2;
+      if (!groups.empty() && (forced || (grouped * 2 >= nnz && staged * 8 * 2 <= grouped * 10))) {
+        std::vector<int32_t> chunk_p(chunk_row.size());
+        for (size_t k = 0; k < chunk_row.size(); ++k) chunk_p[k] = crp[chunk_row[k]];
+        A->n_xw_groups = (int64_t)groups.size(); A->n_xw_rest = (int64_t)rest.size();
+        A->n_xw_chunks = A->n_chunks - A->n_xw_rest; A->xw_staged = staged;
+        PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_p, sizeof(int32_t) * chunk_p.size(), PA_MEM_MATRIX));
+        PA_TRY(pa_dev_alloc(c, (void **)&A->d_xw_grp, sizeof(pa_xw_group) * groups.size(), PA_MEM_MATRIX));
+        PA_HIP(hipMemcpy(A->d_chunk_p, chunk_p.data(), sizeof(int32_t) * chunk_p.size(), hipMemcpyHostToDevice));
+        PA_HIP(hipMemcpy(A->d_xw_grp, groups.data(), sizeof(pa_xw_group) * groups.size(), hipMemcpyHostToDevice));
+        if (!rest.empty()) {
+          PA_TRY(pa_dev_alloc(c, (void **)&A->d_xw_rest, sizeof(int32_t) * rest.size(), PA_MEM_MATRIX));
+          PA_HIP(hipMemcpy(A->d_xw_rest, rest.data(), sizeof(int32_t) * rest.size(), hipMemcpyHostToDevice));
+        }
+      }
+      if (tm_) fprintf(stderr, "[pa setup] x windows: %lld groups, %lld of %lld entries, %lld staged x entries, %s\n",
+                       (long long)groups.size(), (long long)grouped, (long long)nnz, (long long)staged, A->n_xw_groups ? "used" : "not used");
+    }
+  }
   if (cs.use_pattern) {
     PA_TRY(pa_dev_alloc(c, (void **)&A->d_pdesc, sizeof(int32_t) * cs.pdesc.size(), PA_MEM_MATRIX));
     A->n_pdelta = (int64_t)cs.pdelta.size();
@@ -1018,6 +1048,9 @@ static void csr_free_chain(pa_csr *A) {
     if (A->d_row_ids) pa_dev_free(A->ctx, A->d_row_ids);
     if (A->d_col16) pa_dev_free(A->ctx, A->d_col16);
     if (A->d_win) pa_dev_free(A->ctx, A->d_win);
+    if (A->d_chunk_p) pa_dev_free(A->ctx, A->d_chunk_p);
+    if (A->d_xw_grp) pa_dev_free(A->ctx, A->d_xw_grp);
+    if (A->d_xw_rest) pa_dev_free(A->ctx, A->d_xw_rest);
     if (A->d_pdesc) pa_dev_free(A->ctx, A->d_pdesc);
     if (A->d_pdelta) pa_dev_free(A->ctx, A->d_pdelta);
     if (A->d_code) pa_dev_free(A->ctx, A->d_code);
@@ -1140,6 +1173,18 @@ extern "C" int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern, int64_t *n_c
   return PA_OK;
 }
 
+extern "C" int pa_csr_xwin_info(const pa_csr *A, int64_t *n_groups, int64_t *n_chunks, int64_t *staged_x_entries) {
+  PA_REQUIRE(A != nullptr, "csr is NULL");
+  int64_t g = 0, k = 0, st = 0;
+  for (const pa_csr *S = A; S; S = S->next) {
+    g += S->n_xw_groups; k += S->n_xw_chunks; st += S->xw_staged;
+  }
+  if (n_groups) *n_groups = g;
+  if (n_chunks) *n_chunks = k;
+  if (staged_x_entries) *staged_x_entries = st;
+  return PA_OK;
+}
+
 extern "C" int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes) {
   PA_REQUIRE(A && bytes, "bad arguments");
   int64_t t = 0;
@@ -1147,6 +1192,7 @@ extern "C" int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes) {
     const int64_t pad = 8;
     t += 4 * (S->n_crows + 1) + 4 * (S->n_col32 + pad) + 8 * (S->nnz + pad) + 4 * (S->n_chunks + 1);
     if (S->use_c16) t += 2 * S->n_col16 + 4 * S->n_chunks * PA_C16_WINDOWS;
+    if (S->n_xw_groups) t += 4 * (S->n_chunks + 1) + 16 * S->n_xw_groups + 4 * S->n_xw_rest;
     if (S->use_pattern) t += 4 * S->n_chunks * PA_PDESC_INTS + 4 * S->n_pdelta;
     if (S->use_vdict) t += S->nnz + pad + 8 * PA_VDICT_MAX;
     if (S->compact) t += 4 * S->n_crows;
@@ -1167,6 +1213,7 @@ extern "C" int pa_csr_stream_bytes(const pa_csr *A, int64_t *bytes) {
     if (S->use_vdict) t += 8 * PA_VDICT_MAX;
     if (S->use_pattern) t += 4 * S->n_chunks * PA_PDESC_INTS + 4 * S->n_pdelta;
     if (S->use_c16) t += 4 * (S->n_chunks - S->n_pattern_chunks) * PA_C16_WINDOWS;
+    if (S->n_xw_groups) t += 4 * (S->n_chunks + 1) + 16 * S->n_xw_groups + 4 * S->n_xw_rest;
     t += 2 * S->nnz_c16 + 4 * S->nnz_c32;
     if (S->compact) t += 4 * S->n_crows;
   }
@@ -1202,6 +1249,21 @@ extern "C" int pa_csr_value_dict(const pa_csr *A, int *n_values) {
 // the product kernel on one slab, raw pointers (x: the block's column segment, ys: this slab's rows)
 static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta) {
   pa_ctx *c = S->ctx;
+  if (S->n_xw_groups > 0 && !S->use_vdict) {
+    const int gpx = (int)((S->n_xw_groups + 7) / 8);
+    hipLaunchKernelGGL((k_spmv_xwin<PA_XW_SUB, SPMV_NPT, SPMV_NT>), dim3(gpx * 8), dim3(256 * PA_XW_SUB), 0, c->s[0], S->d_crp,
+                       S->d_col16, S->d_win, S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, (const pa_xw_group *)S->d_xw_grp,
+                       (int)S->n_xw_groups, gpx, (int)S->n_cols, alpha, kbeta);
+    if (S->n_xw_rest > 0) {                              // what fits no group: the general kernel over a chunk list
+      const int cpx = (int)((S->n_xw_rest + 7) / 8);
+      hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
+                         c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
+                         S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, alpha, kbeta, (double *)nullptr,
+                         (const double *)nullptr, (const double *)nullptr, (const unsigned char *)nullptr,
+                         (const double *)nullptr, S->d_xw_rest);
+    }
+    return;
+  }
   if (S->n_chunks > 0) {
       const int cpx = (int)((S->n_chunks + 7) / 8);
 #define PA_LAUNCH_SPMV(C16, PAT, VD)                                                                                     \

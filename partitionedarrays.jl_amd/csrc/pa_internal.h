@@ -103,6 +103,12 @@ struct pa_csr {
   int n_dict = 0;
   uint8_t *d_code = nullptr;       // one byte per stored entry (padded)
   double *d_dict = nullptr;        // PA_VDICT_MAX values
+  // x-window launch (pa_spmv_xwin.h): groups of consecutive 16-bit chunks whose x span is staged in LDS; the other chunks
+  // of the block stay on k_spmv_rowsplit through d_xw_rest.  n_xw_groups = 0: the block does not use it.
+  int64_t n_xw_groups = 0, n_xw_rest = 0, n_xw_chunks = 0, xw_staged = 0;
+  int32_t *d_chunk_p = nullptr;    // n_chunks+1: crp[chunk_row[c]]
+  void *d_xw_grp = nullptr;        // n_xw_groups x {first chunk, chunks, first column, columns}
+  int32_t *d_xw_rest = nullptr;
   // A block with 2^31 stored entries or more is a chain of row slabs, each a complete pa_csr with Int32 offsets of its
   // own: this node holds rows [row0, row0 + n_rows) and the entries [nnz0, nnz0 + nnz) of the block.  The head also
   // carries the block's totals.

@@ -123,6 +123,7 @@ __device__ __forceinline__ double pa_wave_sum(double v) {
 //           rows of gs_b[row] * (sum of the row's products) -- the per-chunk partial sums of u'(A x), u = gs_b, summed in a
 //           fixed order (row order per lane, shuffle tree, wave sums): deterministic.  The CG loop's u'c = dot(u, A u)
 //           (HPCG/src/ref_cg.jl:60) costs no pass over u and c this way.
+//   chunk_list (or NULL): the launch covers these chunks only -- what k_spmv_xwin (pa_spmv_xwin.h) leaves over.
 //   VD   value dictionary (optional, lossless): a block with at most PA_VDICT_MAX distinct stored values (bit patterns)
 //        keeps one byte per entry (`code`) and the values in `dict`; lane l holds dict[l] and an entry's value is fetched
 //        from the lane that holds it with ds_bpermute -- 1 byte of matrix stream per entry instead of 8.  The 27-point
@@ -136,19 +137,26 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     double *__restrict__ y, const int *__restrict__ chunk_row, const int *__restrict__ row_ids, int n_chunks,
     int chunks_per_xcd, double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
     const double *__restrict__ gs_diag, const unsigned char *__restrict__ code = nullptr,
-    const double *__restrict__ dict = nullptr) {
+    const double *__restrict__ dict = nullptr, const int *__restrict__ chunk_list = nullptr) {
   constexpr int CAP = BLK * NPT;
   const double *x = EPI == 1 ? gs_x : x_in;   // EPI 1 reads and writes the same vector: no restrict promise on it
   static_assert(NPT % 2 == 0, "pairs");
+#ifdef PA_PROBE_LDS_PAD               // probe builds only: one pad slot per 32 products (row strides of 2^k then miss each other's banks)
+#define PA_PSLOT(p) ((p) + ((p) >> 5))
+  __shared__ __attribute__((aligned(16))) double prod[CAP + CAP / 32 + 2];
+#else
+#define PA_PSLOT(p) (p)
   __shared__ __attribute__((aligned(16))) double prod[CAP];
+#endif
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
 #ifdef PA_PROBE_IDENTITY_CHUNK_MAP   // probe builds only (tools/probe/placement_probe.hip)
   const int chunk = b;
   if (chunk >= n_chunks) return;
 #else
-  const int chunk = (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
+  int chunk = (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
   if (chunk >= n_chunks || (b >> 3) >= chunks_per_xcd) return;
+  if (chunk_list) chunk = chunk_list[chunk];       // a launch over some of the block's chunks (n_chunks = length of the list)
 #endif
   const int r0 = chunk_row[chunk];
   const int r1 = chunk_row[chunk + 1];
@@ -245,6 +253,10 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         const unsigned lo = q[k] & 0xffffu, hi = q[k] >> 16;
         c0[k] = __builtin_amdgcn_ds_bpermute((lo >> 12) << 2, mywin) + (lo & 4095);
         c1[k] = __builtin_amdgcn_ds_bpermute((hi >> 12) << 2, mywin) + (hi & 4095);
+#ifdef PA_PROBE_NO_GATHER             // probe builds only: the 16-bit path with lane-contiguous x reads (wrong results)
+        c0[k] = min(r0 + (tid & 63) + (int)(lo & 1), r1 - 1);
+        c1[k] = min(r0 + (tid & 63) + (int)(hi & 1), r1 - 1);
+#endif
       }
     } else {
 #pragma unroll
@@ -273,7 +285,12 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         pr.x = pr.x * alpha;
         pr.y = pr.y * alpha;
       }
+#ifdef PA_PROBE_LDS_PAD
+      prod[PA_PSLOT((k * BLK + tid) * 2)] = pr.x;
+      prod[PA_PSLOT((k * BLK + tid) * 2) + 1] = pr.y;
+#else
       *reinterpret_cast<d2 *>(&prod[(k * BLK + tid) * 2]) = pr;
+#endif
     }
     __syncthreads();
     if (EPI == 11) {   // probe only: a lane owns the two rows of a 16-byte slot of y and stores them with one dwordx4
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       double acc = ((EPI != 0 && EPI != 3) || beta == 0.0) ? 0.0 : beta * y[row];
       const int a = ra - base, e = re - base;
 #pragma unroll UNR
-      for (int p = a; p < e; ++p) acc = acc + prod[p];
+      for (int p = a; p < e; ++p) acc = acc + prod[PA_PSLOT(p)];
       if (EPI == 3) {
         double pr = acc;                     // the row's products alone (beta = 0: that is acc itself)
         if (beta != 0.0) {

@@ -1,0 +1,189 @@
+// Row-split CSR SpMV for banded but unstructured rows: the same chunks, the same streams and the same arithmetic as
+// k_spmv_rowsplit (pa_spmv_kernel.h), with the gathers served from LDS.
+//
+// Why: a block whose rows follow no pattern reads x through one gather per stored entry.  With columns spread over a
+// band of a few thousand (an unstructured mesh in a bandwidth-reducing numbering), the 64 lanes of one gather touch ~60
+// different cache lines, and the ~32 KiB of x one chunk needs does not survive in a 32 KiB L1 shared by 4-5 resident
+// workgroups: most gathers become L2 requests of a whole line for 8 useful bytes (measured: 0.216 ms for 64 M entries,
+// 0.131 ms with the same kernel reading x lane-contiguously).  Here a workgroup owns a GROUP of consecutive chunks whose
+// columns span at most PA_XW_CAP entries of x; it copies that span into LDS once, with full-width coalesced loads, and
+// every gather of the group's chunks is a ds_read_b64.  x then costs (span / entries of the group) * 8 bytes per entry of
+// coalesced L2 traffic instead of a line per gather.
+//
+// Bit-exactness: unchanged.  Products val[p] * x[col[p]] are formed one by one (no FMA), land in their own LDS slot and
+// are summed by the row's lane in ascending p (src/sparse_utils.jl:649-669, spmv_csr!).
+//
+// A workgroup is SUB sub-groups of 256 lanes; sub-group s works on chunks first+s, first+s+SUB, ... of the group, all
+// share the x window.  Chunks that do not fit a group (a span wider than the cap, 32-bit columns, a row longer than a
+// chunk) stay on k_spmv_rowsplit through its chunk list.
+#pragma once
+#include "pa_spmv_kernel.h"
+
+#define PA_XW_CAP 5120      // doubles of x a workgroup stages (40 KiB)
+#ifndef PA_XW_MAXG
+#define PA_XW_MAXG 16       // chunks per group at most
+#endif
+#ifndef PA_XW_SUB
+#define PA_XW_SUB 2         // sub-groups of 256 lanes per workgroup (chunks of a group in flight at a time)
+#endif
+#define PA_XW_PSLOT(p) ((p) + ((p) >> 5))
+#define PA_XW_MING 4        // a shorter group would move more x than matrix: its chunks go to k_spmv_rowsplit
+
+struct pa_xw_group { int first, cnt, wlo, wlen; };
+
+template <int SUB, int NPT, bool NT>
+__global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
+    const int *__restrict__ crp, const unsigned short *__restrict__ col16, const int *__restrict__ win,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const int *__restrict__ chunk_row, const int *__restrict__ chunk_p, const pa_xw_group *__restrict__ grp,
+    int n_groups, int groups_per_xcd, int n_cols, double alpha, double beta) {
+  constexpr int BLK = 256, CAP = BLK * NPT, NTHR = BLK * SUB;
+  constexpr int PCAP = CAP + CAP / 32 + 2;            // one pad slot per 32 products: rows of 2^k entries miss each other's banks
+  __shared__ __attribute__((aligned(16))) double xs[PA_XW_CAP + 4];
+  __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
+  const int tid = threadIdx.x;
+  const int t = tid & (BLK - 1);
+  const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);
+  double *prod = prod_all + sub * PCAP;
+  const int b = blockIdx.x;
+  const int g = (b & 7) * groups_per_xcd + (b >> 3);  // XCD-aware: workgroup b sits on XCD b%8, neighbours in g share an L2
+  if (g >= n_groups || (b >> 3) >= groups_per_xcd) return;
+  const pa_xw_group G = grp[g];
+  const int ch_end = G.first + G.cnt;
+
+  d2 v[NPT / 2];
+  unsigned q[NPT / 2];
+  int mywin = 0, ra = 0, re = 0;
+  int r0 = 0, r1 = 0, p0 = 0, p1 = 0;                 // the chunk whose loads are in flight
+  int nr0 = 0, nr1 = 0, np0 = 0, np1 = 0;             // the one after it (row and entry bounds only)
+  auto meta = [&](int ch, int &a0, int &a1, int &b0, int &b1) {
+    a0 = chunk_row[ch]; a1 = chunk_row[ch + 1]; b0 = chunk_p[ch]; b1 = chunk_p[ch + 1];
+  };
+  auto issue = [&](int ch) {                          // every load of chunk ch this lane needs; none is waited for here
+    const int base = p0 & ~1, last = max((p1 - 1) & ~1, 0);
+#pragma unroll
+    for (int k = 0; k < NPT / 2; ++k) {
+      const int idx = min(base + (k * BLK + t) * 2, last);
+      v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+      q[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned *>(col16 + idx));
+    }
+    mywin = win[ch * PA_C16_WINDOWS + (t & (PA_C16_WINDOWS - 1))];
+    if (r0 + t < r1) {
+      ra = crp[r0 + t];
+      re = crp[r0 + t + 1];
+    }
+  };
+  int ch = G.first + sub;
+  if (ch < ch_end) {
+    meta(ch, r0, r1, p0, p1);
+    issue(ch);
+    if (ch + SUB < ch_end) meta(ch + SUB, nr0, nr1, np0, np1);
+  }
+  // the x window: element wl of x sits at xs[0]; wl <= wlo is chosen so that x + wl is 16-byte aligned
+  const int wl = G.wlo - (int)(((reinterpret_cast<uintptr_t>(x) >> 3) + (uintptr_t)G.wlo) & 1);
+  {
+    const int npair = (G.wlo + G.wlen - wl + 1) >> 1;
+    if (wl >= 0 && wl + 2 * npair <= n_cols) {        // (block-uniform) every pair lies inside x: 16-byte loads
+      constexpr int KX = (PA_XW_CAP / 2 + 2 + NTHR - 1) / NTHR;
+      d2 xv[KX];
+#pragma unroll
+      for (int k = 0; k < KX; ++k) xv[k] = *reinterpret_cast<const d2 *>(x + wl + 2 * min(tid + k * NTHR, npair - 1));
+#pragma unroll
+      for (int k = 0; k < KX; ++k)
+        if (tid + k * NTHR < npair) *reinterpret_cast<d2 *>(&xs[2 * (tid + k * NTHR)]) = xv[k];
+    } else {                                          // the first / last window of the vector
+      for (int i = tid; i < 2 * npair; i += NTHR) {
+        const int e = wl + i;
+        xs[i] = (e >= 0 && e < n_cols) ? x[e] : 0.0;
+      }
+    }
+  }
+  __syncthreads();
+  for (; __builtin_amdgcn_readfirstlane(ch - sub) < ch_end; ch += SUB) {   // every sub-group runs the same number of rounds
+    const bool act = ch < ch_end;                                           // wave-uniform
+    const int cr0 = r0, cr1 = r1, cbase = p0 & ~1, cra = ra, cre = re;
+    if (act) {
+      const int wrel = mywin - wl;
+#pragma unroll
+      for (int k = 0; k < NPT / 2; ++k) {
+        const unsigned lo = q[k] & 0xffffu, hi = q[k] >> 16;
+        const int c0 = __builtin_amdgcn_ds_bpermute((lo >> 12) << 2, wrel) + (lo & 4095);
+        const int c1 = __builtin_amdgcn_ds_bpermute((hi >> 12) << 2, wrel) + (hi & 4095);
+        double a = v[k].x * xs[c0];
+        double c = v[k].y * xs[c1];
+        if (alpha != 1.0) {
+          a = a * alpha;
+          c = c * alpha;
+        }
+        const int s = PA_XW_PSLOT((k * BLK + t) * 2);
+        prod[s] = a;
+        prod[s + 1] = c;
+      }
+      // the next chunk's loads go out before this one's row sums: they fly during the barrier and the reduce phase
+      if (ch + SUB < ch_end) {
+        r0 = nr0; r1 = nr1; p0 = np0; p1 = np1;
+        issue(ch + SUB);
+        if (ch + 2 * SUB < ch_end) meta(ch + 2 * SUB, nr0, nr1, np0, np1);
+      }
+    }
+    __syncthreads();
+    if (act) {
+      int a = cra - cbase, e = cre - cbase;
+      for (int r = cr0 + t; r < cr1; r += BLK) {
+        if (r != cr0 + t) {
+          a = crp[r] - cbase;
+          e = crp[r + 1] - cbase;
+        }
+        double acc = beta == 0.0 ? 0.0 : beta * y[r];
+#pragma unroll 4
+        for (int p = a; p < e; ++p) acc = acc + prod[PA_XW_PSLOT(p)];
+        __builtin_nontemporal_store(acc, &y[r]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Host side: groups of consecutive 16-bit chunks whose columns span at most PA_XW_CAP - 2 entries; `rest` gets every
+// other chunk.  Returns the entries of x the groups stage in total (the extra traffic the window path pays).
+inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row,
+                                  const int32_t *win, std::vector<pa_xw_group> &groups, std::vector<int32_t> &rest,
+                                  int64_t *grouped_entries) {
+  const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
+  std::vector<int32_t> cmin(n_chunks), cmax(n_chunks);
+  for (int64_t c = 0; c < n_chunks; ++c) {
+    int32_t lo = INT32_MAX, hi = -1;
+    if (win[c * PA_C16_WINDOWS] >= 0)
+      for (int64_t p = crp[chunk_row[c]]; p < crp[chunk_row[c + 1]]; ++p) {
+        lo = std::min(lo, col[p]);
+        hi = std::max(hi, col[p]);
+      }
+    cmin[c] = lo;
+    cmax[c] = hi;
+  }
+  groups.clear();
+  rest.clear();
+  int64_t staged = 0;
+  *grouped_entries = 0;
+  int64_t c = 0;
+  while (c < n_chunks) {
+    if (cmax[c] < 0) { rest.push_back((int32_t)c++); continue; }
+    int32_t lo = cmin[c], hi = cmax[c];
+    int64_t e = c + 1;
+    if (hi - lo + 2 <= PA_XW_CAP - 2)
+      while (e < n_chunks && e - c < PA_XW_MAXG && cmax[e] >= 0) {
+        const int32_t l2 = std::min(lo, cmin[e]), h2 = std::max(hi, cmax[e]);
+        if (h2 - l2 + 2 > PA_XW_CAP - 2) break;
+        lo = l2; hi = h2; ++e;
+      }
+    if (hi - lo + 2 > PA_XW_CAP - 2 || e - c < PA_XW_MING) {
+      for (int64_t k = c; k < e; ++k) rest.push_back((int32_t)k);
+    } else {
+      groups.push_back(pa_xw_group{(int)c, (int)(e - c), lo, hi - lo + 1});
+      staged += hi - lo + 1;
+      *grouped_entries += (int64_t)crp[chunk_row[e]] - crp[chunk_row[c]];
+    }
+    c = e;
+  }
+  return staged;
+}

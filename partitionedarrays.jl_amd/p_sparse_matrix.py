@@ -112,6 +112,12 @@ class DeviceCSR:
         L.call("pa_csr_encoding", self.h, *[C.byref(x) for x in v])
         return dict(zip(["pattern", "c16", "c32"], [x.value for x in v]))
 
+    def xwin(self):
+        """x-window launch of banded rows without a pattern (pa_csr_xwin_info): groups, chunks in groups, staged x entries."""
+        v = [C.c_int64() for _ in range(3)]
+        L.call("pa_csr_xwin_info", self.h, *[C.byref(x) for x in v])
+        return dict(zip(["groups", "chunks", "staged_x"], [x.value for x in v]))
+
     def device_bytes(self):
         """HBM bytes the block occupies (pa_csr_device_bytes)."""
         n = C.c_int64()

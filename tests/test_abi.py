@@ -322,3 +322,74 @@ def test_glue_ccall_sequence_of_mul_replayed_through_ctypes(orc):
         got = np.zeros(A.rows[p].n_own)
         call("download", 0, ys[p], vp(got), 0, len(got))
         assert np.array_equal(got, want[p][:len(got)]), f"part {p + 1}"
+
+
+@pytest.mark.gpu
+def test_glue_blas1_ccalls_replay_the_reference_cg_statements():
+    """The statements of the reference CG loop on vectors (HPCG/src/ref_cg.jl:56-71: u .= c .+ beta .* u, x .+= alpha .* u,
+    r .-= alpha .* c, u .= 0, copyto!(r,b), norm(r)) as the glue lowers them -- `_lin` flattens the broadcast tree into
+    (coefficient, vector) pairs and `copyto!` issues pa_vec_axpby(dest, a, v, b) -- replayed with the type tuples written in
+    the glue, bit for bit against the same statements in numpy (unfused multiply, then add)."""
+    import numpy as np
+    pa = load_package()
+    lib = ctypes.CDLL(pa.LIB_PATH)
+    seq = {
+        "ctx": _glue_ccalls(r"function context\("),
+        "vec": _glue_ccalls(r"function HIPVector\(n_own::Integer, n_ghost::Integer\)"),
+        "upload": _glue_ccalls(r"function HIPVector\(host::Vector\{Float64\}"),
+        "download": _glue_ccalls(r"function Base\.Array\(v::HIPVector\)"),
+        "axpby": _glue_ccalls(r"_axpby!\(y::HIPSegment"),
+        "fill": _glue_ccalls(r"Base\.fill!\(s::HIPSegment"),
+        "copy": _glue_ccalls(r"Base\.copyto!\(dest::HIPSegment, src::HIPSegment\)"),
+        "dot": _glue_ccalls(r"function LinearAlgebra\.dot\(a::HIPSegment"),
+    }
+    assert [n for n, _ in seq["axpby"]] == ["pa_vec_axpby"] and [n for n, _ in seq["copy"]] == ["pa_vec_copy"]
+    assert [n for n, _ in seq["fill"]] == ["pa_vec_fill"] and [n for n, _ in seq["dot"]] == ["pa_vec_dot"]
+
+    def call(key, *vals):
+        name, types = seq[key][0]
+        assert len(types) == len(vals), (name, len(types), len(vals))
+        f = getattr(lib, name)
+        f.restype, f.argtypes = ctypes.c_int, types
+        assert f(*vals) == 0, (name, lib.pa_last_error())
+
+    P = ctypes.c_void_p
+    vp = lambda a: a.ctypes.data_as(P)
+    ctx = P()
+    call("ctx", 0, ctypes.byref(ctx))
+    n_own, n_ghost, OWN = 70001, 13, 0
+    rng = np.random.default_rng(5)
+    host = {k: rng.standard_normal(n_own + n_ghost) * 10.0 ** rng.integers(-3, 4, n_own + n_ghost) for k in "xucrb"}
+    dev = {}
+    for k, h in host.items():
+        dev[k] = P()
+        call("vec", ctx, n_own, n_ghost, ctypes.byref(dev[k]))
+        call("upload", dev[k], vp(h), 0, len(h))
+    alpha, beta = 0.7310585786300049, 1.0 / 3.0
+    o = slice(0, n_own)
+    # u .= c .+ beta .* u      ->  terms [(c,1),(u,beta)], dest u:  axpby(u, 1, c, beta)
+    call("axpby", dev["u"], 1.0, dev["c"], beta, OWN)
+    host["u"][o] = host["c"][o] + beta * host["u"][o]
+    # x .+= alpha .* u         ->  [(x,1),(u,alpha)], dest x:       axpby(x, alpha, u, 1)
+    call("axpby", dev["x"], alpha, dev["u"], 1.0, OWN)
+    host["x"][o] = host["x"][o] + alpha * host["u"][o]
+    # r .-= alpha .* c         ->  [(r,1),(c,-alpha)], dest r:      axpby(r, -alpha, c, 1)
+    call("axpby", dev["r"], -alpha, dev["c"], 1.0, OWN)
+    host["r"][o] = host["r"][o] - alpha * host["c"][o]
+    # c .= x .- u  (neither is dest)  ->  axpby(c, 1, x, 0); axpby(c, -1, u, 1)
+    call("axpby", dev["c"], 1.0, dev["x"], 0.0, OWN)
+    call("axpby", dev["c"], -1.0, dev["u"], 1.0, OWN)
+    host["c"][o] = host["x"][o] - host["u"][o]
+    # norm(r): sqrt(dot(r,r)) over the own values -- pairwise order is the library's, so compare to the documented tolerance
+    out = ctypes.c_double(0.0)
+    call("dot", dev["r"], dev["r"], ctypes.byref(out))
+    assert abs(out.value - float(host["r"][o] @ host["r"][o])) <= 1e-12 * out.value
+    # copyto!(own_values(b), own_values(r)); fill!(own_values(u), 0): ghosts untouched
+    call("copy", dev["b"], dev["r"], OWN)
+    host["b"][o] = host["r"][o]
+    call("fill", dev["u"], OWN, 0.0)
+    host["u"][o] = 0.0
+    for k in "xucrb":
+        got = np.empty(n_own + n_ghost)
+        call("download", dev[k], vp(got), 0, len(got))
+        assert np.array_equal(got, host[k]), k

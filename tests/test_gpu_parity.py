@@ -1200,6 +1200,57 @@ def test_unstructured_rows_in_a_band_keep_their_bits(orc):
     assert np.array_equal(y.download(), y0)
 
 
+def test_x_window_launch_of_banded_rows_is_bit_identical(orc, monkeypatch):
+    """Banded rows without a pattern go through k_spmv_xwin (groups of chunks gather x from an LDS copy of their span) and
+    what fits no group through k_spmv_rowsplit's chunk list: ragged rows (0..39 entries, empty ones included), a band of
+    +-1500, rows that reach anywhere (their chunks leave the groups), a stretch of rows too wide for any window, signed
+    zeros.  spmv! and the alpha/beta form equal the oracle's spmv_csr! / mul! loops bit for bit, with the window launch on
+    and off, and on a vector segment that is only 8-byte aligned (the ghost segment of a vector with an odd own length)."""
+    import pa_amd._lib as L
+    rng = np.random.default_rng(11)
+    m = 200_001
+    lens = rng.integers(0, 40, m)
+    lens[rng.choice(m, 500, replace=False)] = 0
+    rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(m), lens)
+    col = np.clip(rows + rng.integers(-1500, 1500, size=len(rows)), 0, m - 1)
+    far = rng.choice(len(rows), size=60, replace=False)
+    col[far] = rng.integers(0, m, size=60)
+    wide = (rows >= 90_000) & (rows < 93_000)                       # spans of 20000 columns: no window holds them
+    col[wide] = np.clip(rows[wide] + rng.integers(-10000, 10000, size=int(wide.sum())), 0, m - 1)
+    order = np.lexsort((col, rows))
+    val = rng.standard_normal(len(rows))
+    val[rng.choice(len(rows), 2000, replace=False)] = -0.0
+    H = pa.HostCSR(m, m, rp, (col[order] + 1).astype(np.int32), val)
+    Ho = orc.CSR(m, m, H.rowptr, H.colval, H.nzval)
+    xh = rng.standard_normal(m)
+    xh[rng.choice(m, 300, replace=False)] = 0.0
+    want = np.zeros(m)
+    orc.oracle_c().spmv_csr(want, xh, Ho)
+    want5 = np.full(m, 0.25)
+    orc.oracle_c().mul5_csr(want5, Ho, xh, -2.0, 3.0)
+    for switch in ("1", "0"):
+        monkeypatch.setenv("PA_SPMV_XWIN", switch)
+        A = pa.DeviceCSR(H)
+        xw = A.xwin()
+        if switch == "1":
+            assert xw["groups"] > 0 and 0 < xw["chunks"] < A.info()["n_chunks"], xw       # both launches run
+        else:
+            assert xw["groups"] == 0
+        x = pa.DeviceVector(m, 0).upload(xh)
+        y = pa.DeviceVector(m, 0)
+        pa.spmv_(y, A, x)
+        assert np.array_equal(y.download(), want), switch
+        y.upload(np.full(m, 0.25))
+        pa.spmv_(y, A, x, alpha=-2.0, beta=3.0)
+        assert np.array_equal(y.download(), want5), switch
+        # x in the ghost segment of a vector with 3 own entries: the segment starts 24 bytes into the allocation
+        xg = pa.DeviceVector(3, m).upload(np.concatenate([np.zeros(3), xh]))
+        y2 = pa.DeviceVector(m, 0)
+        pa.spmv_(y2, A, xg, x_segment=L.SEG_GHOST)
+        assert np.array_equal(y2.download(), want), switch
+
+
 def test_fem_matrix_on_a_randomly_permuted_mesh(orc):
     """The same Q1 stiffness matrix with its nodes renumbered at random: no row pattern, no band -- every chunk falls to the
     16-bit-window / 32-bit column streams and the plain gather.  Bit-identical to the oracle's spmv_csr!."""

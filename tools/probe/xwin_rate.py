@@ -1,0 +1,54 @@
+"""Banded rows without a pattern: the x-window launch (pa_spmv_xwin.h) against k_spmv_rowsplit on the same block."""
+import os, sys
+sys.path.insert(0, '.')
+import numpy as np
+from __graft_entry__ import load_package
+pa = load_package()
+import pa_amd._lib as L
+ctx = pa.context()
+tag = sys.argv[1] if len(sys.argv) > 1 else "product"
+
+def rate(name, H):
+    x = pa.DeviceVector(H.n, 0).upload(np.random.default_rng(1).standard_normal(H.n))
+    out = []
+    for sw in ("0", "2"):
+        os.environ["PA_SPMV_XWIN"] = sw
+        blk = pa.DeviceCSR(H)
+        y = pa.DeviceVector(H.m, 0)
+        for _ in range(60): pa.spmv_(y, blk, x)
+        e0 = ctx.event().record(L.STREAM_COMPUTE)
+        for _ in range(50): pa.spmv_(y, blk, x)
+        e1 = ctx.event().record(L.STREAM_COMPUTE); ctx.sync()
+        ms = e0.elapsed_ms(e1) / 50
+        out.append((ms, y.download(), blk.xwin()))
+        del blk, y
+    same = np.array_equal(out[0][1], out[1][1])
+    alg = (H.nnz * 12 + H.m * 20) / 1e6
+    print(f"[{tag:10s}] {name:44s} row split {out[0][0]:7.4f} ms {alg/out[0][0]:7.1f} GB/s | x windows {out[1][0]:7.4f} ms {alg/out[1][0]:7.1f} GB/s"
+          f"  same bits {same}  {out[1][2]}", flush=True)
+    os.environ.pop("PA_SPMV_XWIN")
+    auto = pa.DeviceCSR(H).xwin()["groups"] > 0
+    print(f"[{tag:10s}]    default choice: {'x windows' if auto else 'row split'}", flush=True)
+
+rng = np.random.default_rng(0)
+m = 4_000_000
+for band in (8000, 2000, 500, 100):
+    base = np.repeat(np.arange(m), 16)
+    col = np.sort(np.clip(base + rng.integers(-band, band, size=m * 16), 0, m - 1).reshape(m, 16), axis=1).ravel().astype(np.int32) + 1
+    H = pa.HostCSR(m, m, (1 + 16 * np.arange(m + 1)).astype(np.int32), col, rng.standard_normal(m * 16))
+    rate(f"4M rows x 16 within +-{band}", H)
+    del H, col, base
+m = 2_000_000
+lens = rng.integers(1, 40, m)
+rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
+rows = np.repeat(np.arange(m), lens)
+colr = np.clip(rows + rng.integers(-2000, 2000, size=len(rows)), 0, m - 1)
+order = np.lexsort((colr, rows))
+rate("2M ragged rows (1..39) within +-2000", pa.HostCSR(m, m, rp, (colr[order] + 1).astype(np.int32), rng.standard_normal(len(rows))))
+m = 2_000_000
+lens = rng.integers(3, 9, m)
+rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
+rows = np.repeat(np.arange(m), lens)
+colr = np.clip(rows + rng.integers(-1000, 1000, size=len(rows)), 0, m - 1)
+order = np.lexsort((colr, rows))
+rate("2M short rows (3..8) within +-1000", pa.HostCSR(m, m, rp, (colr[order] + 1).astype(np.int32), rng.standard_normal(len(rows))))
