@@ -326,11 +326,11 @@ def time_block(pa, ctx, L, blk, n_rows, n_cols, reps=30):
     return e0.elapsed_ms(e1) / reps
 
 
-def extra_configs(pa, ctx, L):
+def extra_configs(pa, ctx, L, out):
     """BASELINE configs 2, 3 (one part's size) and 5 (one part's rows) on this GPU, one entry each: ms per product,
     GFLOP/s, algorithmic GB/s (12 B per entry + 20 B per row), moved GB/s (bytes the block's encoding makes the
-    kernel read + x once + y once), column encoding of the chunks."""
-    out = []
+    kernel read + x once + y once), column encoding of the chunks -- plus rows without a pattern inside a band.  Entries
+    are appended to `out` as they are measured (a failure keeps what came before it)."""
     ranks1 = pa.DebugArray([1])
 
     def entry(workload, blk, n_rows, n_cols, ms, t_setup):
@@ -376,6 +376,26 @@ def extra_configs(pa, ctx, L):
     ts = time.perf_counter() - t
     out.append(entry("config 5: Q1 FEM Laplacian 2-D, 1024 x 2048 nodes (= one part's rows of the 4096^2 instance on (4,2) "
                      "parts), disassembled psparse route, pa_spmv", b5, b5.m, b5.n, time_block(pa, ctx, L, b5, b5.m, b5.n), ts))
+    del A5, b5
+    # rows without any pattern inside a band (an unstructured mesh in a bandwidth-reducing numbering):
+    # 2 M rows of 16 entries, columns drawn at random within +-2000 of the diagonal
+    PHASE[0] = "extra: banded unstructured rows"
+    t = time.perf_counter()
+    rng = np.random.default_rng(0)
+    m = 2_000_000
+    col = np.repeat(np.arange(m, dtype=np.int32), 16).reshape(m, 16)
+    col += rng.integers(-2000, 2000, size=(m, 16), dtype=np.int32)
+    np.clip(col, 0, m - 1, out=col)
+    col.sort(axis=1)
+    col += 1
+    Hb = pa.HostCSR(m, m, (1 + 16 * np.arange(m + 1)).astype(np.int32), col.ravel(), rng.standard_normal(m * 16))
+    bb = pa.DeviceCSR(Hb)
+    del Hb, col
+    ts = time.perf_counter() - t
+    e = entry("unstructured rows in a band: 2 M rows x 16 entries, random columns within +-2000 of the diagonal, pa_spmv",
+              bb, m, m, time_block(pa, ctx, L, bb, m, m), ts)
+    e["x_window_launch"] = bb.xwin()
+    out.append(e)
     return out
 
 
@@ -750,10 +770,12 @@ def main():
 
     extras = None
     if N == 1 and args.extra and rank == 0:
+        extras = []
         try:
-            extras = extra_configs(pa, ctx, L)
+            extra_configs(pa, ctx, L, extras)
         except Exception as e:                                 # noqa: BLE001
-            print(f"[bench] extra configs skipped at {PHASE[0]!r}: {e}", file=sys.stderr)
+            print(f"[bench] extra configs stopped at {PHASE[0]!r}: {e}", file=sys.stderr)
+        extras = extras or None
 
     if want_cpu:
         with optional_section("CPU baseline", 3 * args.cpu_seconds + 240, N, rank):

@@ -2054,7 +2054,19 @@ static int spmv_dot_block(const pa_csr *A, const double *x, double *y, double be
       if (S->n_rows) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n_rows, 256)), dim3(256), 0, c->s[0], ys, S->n_rows, beta);
       kbeta = 1.0;
     }
-    if (S->n_chunks > 0) {
+    if (S->n_xw_groups > 0) {
+      const int gpx = (int)((S->n_xw_groups + 7) / 8);
+      hipLaunchKernelGGL((k_spmv_xwin<PA_XW_SUB, SPMV_NPT, SPMV_NT, true>), dim3(gpx * 8), dim3(256 * PA_XW_SUB), 0, c->s[0],
+                         S->d_crp, S->d_col16, S->d_win, S->d_val, x, ys, S->d_chunk_row, S->d_chunk_p,
+                         (const pa_xw_group *)S->d_xw_grp, (int)S->n_xw_groups, gpx, (int)S->n_cols, 1.0, kbeta, us, partial + off);
+      if (S->n_xw_rest > 0) {
+        const int cpx = (int)((S->n_xw_rest + 7) / 8);
+        hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
+                           c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, x, ys,
+                           S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, 1.0, kbeta, partial + off, us,
+                           (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr, S->d_xw_rest);
+      }
+    } else if (S->n_chunks > 0) {
       const int cpx = (int)((S->n_chunks + 7) / 8);
 #define PA_LAUNCH_DOT(C16, PAT)                                                                                           \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0, \

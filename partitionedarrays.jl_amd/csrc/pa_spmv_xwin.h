@@ -21,8 +21,9 @@
 
 #define PA_XW_CAP 5120      // doubles of x a workgroup stages (40 KiB)
 #ifndef PA_XW_MAXG
-#define PA_XW_MAXG 16       // chunks per group at most
+#define PA_XW_MAXG 16       // chunks per group at most (fewer on a small block: see pa_build_xw_groups)
 #endif
+#define PA_XW_WANT_GROUPS 2048   // 256 CUs x 2 resident workgroups x 4 rounds: below that the tail of the launch shows
 #ifndef PA_XW_SUB
 #define PA_XW_SUB 2         // sub-groups of 256 lanes per workgroup (chunks of a group in flight at a time)
 #endif
@@ -31,16 +32,21 @@
 
 struct pa_xw_group { int first, cnt, wlo, wlen; };
 
-template <int SUB, int NPT, bool NT>
+// DOT: also partial[chunk] = sum over the chunk's rows of u[row] * (sum of the row's products), in the order of
+// k_spmv_rowsplit's EPI 3 (per lane in row order, pa_wave_sum, the four wave sums left to right): the same bits whichever
+// kernel a chunk runs on.
+template <int SUB, int NPT, bool NT, bool DOT = false>
 __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
     const int *__restrict__ crp, const unsigned short *__restrict__ col16, const int *__restrict__ win,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const int *__restrict__ chunk_row, const int *__restrict__ chunk_p, const pa_xw_group *__restrict__ grp,
-    int n_groups, int groups_per_xcd, int n_cols, double alpha, double beta) {
+    int n_groups, int groups_per_xcd, int n_cols, double alpha, double beta, const double *__restrict__ u = nullptr,
+    double *__restrict__ partial = nullptr) {
   constexpr int BLK = 256, CAP = BLK * NPT, NTHR = BLK * SUB;
   constexpr int PCAP = CAP + CAP / 32 + 2;            // one pad slot per 32 products: rows of 2^k entries miss each other's banks
   __shared__ __attribute__((aligned(16))) double xs[PA_XW_CAP + 4];
   __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
+  __shared__ double wsum[SUB * (BLK / 64)];
   const int tid = threadIdx.x;
   const int t = tid & (BLK - 1);
   const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);
@@ -54,6 +60,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
   d2 v[NPT / 2];
   unsigned q[NPT / 2];
   int mywin = 0, ra = 0, re = 0;
+  double ur = 0.0;                                    // DOT: u of this lane's first row
   int r0 = 0, r1 = 0, p0 = 0, p1 = 0;                 // the chunk whose loads are in flight
   int nr0 = 0, nr1 = 0, np0 = 0, np1 = 0;             // the one after it (row and entry bounds only)
   auto meta = [&](int ch, int &a0, int &a1, int &b0, int &b1) {
@@ -71,6 +78,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
     if (r0 + t < r1) {
       ra = crp[r0 + t];
       re = crp[r0 + t + 1];
+      if (DOT) ur = u[r0 + t];
     }
   };
   int ch = G.first + sub;
@@ -102,6 +110,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
   for (; __builtin_amdgcn_readfirstlane(ch - sub) < ch_end; ch += SUB) {   // every sub-group runs the same number of rounds
     const bool act = ch < ch_end;                                           // wave-uniform
     const int cr0 = r0, cr1 = r1, cbase = p0 & ~1, cra = ra, cre = re;
+    const double cur = ur;
     if (act) {
       const int wrel = mywin - wl;
 #pragma unroll
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
     __syncthreads();
     if (act) {
       int a = cra - cbase, e = cre - cbase;
+      double dacc = 0.0;
       for (int r = cr0 + t; r < cr1; r += BLK) {
         if (r != cr0 + t) {
           a = crp[r] - cbase;
@@ -137,10 +147,29 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
         double acc = beta == 0.0 ? 0.0 : beta * y[r];
 #pragma unroll 4
         for (int p = a; p < e; ++p) acc = acc + prod[PA_XW_PSLOT(p)];
+        if (DOT) {
+          double pr = acc;                            // the row's products alone
+          if (beta != 0.0) {
+            pr = 0.0;
+            for (int p = a; p < e; ++p) pr = pr + prod[PA_XW_PSLOT(p)];
+          }
+          dacc = dacc + (r == cr0 + t ? cur : u[r]) * pr;
+        }
         __builtin_nontemporal_store(acc, &y[r]);
+      }
+      if (DOT) {
+        dacc = pa_wave_sum(dacc);
+        if (cr1 - cr0 <= 64) {
+          if (t == 0) partial[ch] = dacc;
+        } else if ((t & 63) == 0) wsum[sub * (BLK / 64) + (t >> 6)] = dacc;
       }
     }
     __syncthreads();
+    if (DOT && act && cr1 - cr0 > 64 && t == 0) {
+      double sum = 0.0;
+      for (int w = 0; w < BLK / 64; ++w) sum = sum + wsum[sub * (BLK / 64) + w];
+      partial[ch] = sum;
+    }
   }
 }
 
@@ -161,6 +190,9 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const 
     cmin[c] = lo;
     cmax[c] = hi;
   }
+  // a small block gets shorter groups, so that the launch still has a few rounds of workgroups per CU (2 M short rows,
+  // 7268 chunks: 0.0335 ms with groups of 8, 0.0381 with groups of 16)
+  const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XW_MAXG, n_chunks / PA_XW_WANT_GROUPS));
   groups.clear();
   rest.clear();
   int64_t staged = 0;
@@ -171,7 +203,7 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const 
     int32_t lo = cmin[c], hi = cmax[c];
     int64_t e = c + 1;
     if (hi - lo + 2 <= PA_XW_CAP - 2)
-      while (e < n_chunks && e - c < PA_XW_MAXG && cmax[e] >= 0) {
+      while (e < n_chunks && e - c < maxg && cmax[e] >= 0) {
         const int32_t l2 = std::min(lo, cmin[e]), h2 = std::max(hi, cmax[e]);
         if (h2 - l2 + 2 > PA_XW_CAP - 2) break;
         lo = l2; hi = h2; ++e;

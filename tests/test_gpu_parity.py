@@ -856,6 +856,40 @@ def test_fused_product_and_dot_matches_the_separate_calls(orc):
     assert abs(pa.read_slots(7)[0] - want) <= 1e-12 * max(1.0, abs(want))
 
 
+def test_fused_product_and_dot_on_banded_rows_is_the_same_on_both_launches(monkeypatch):
+    """Banded rows without a pattern: pa_mul_dot through k_spmv_xwin (+ the chunk list) and through k_spmv_rowsplit alone
+    give the same c AND the same dot, bit for bit (the per-chunk partial sums are formed in one order on both), with
+    chunks of more than 64 rows (short rows) and of fewer."""
+    import pa_amd.p_sparse_matrix as psm
+    rng = np.random.default_rng(23)
+    m = 150_000
+    lens = np.where(np.arange(m) < 60_000, rng.integers(1, 6, m), rng.integers(10, 40, m))
+    rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(m), lens)
+    col = np.clip(rows + rng.integers(-1200, 1200, size=len(rows)), 0, m - 1)
+    col[rng.choice(len(rows), 30, replace=False)] = rng.integers(0, m, 30)
+    order = np.lexsort((col, rows))
+    H = pa.HostCSR(m, m, rp, (col[order] + 1).astype(np.int32), rng.standard_normal(len(rows)))
+    ind = pa.uniform_partition(ranks(1), m)
+    uh = rng.standard_normal(m)
+    outs = []
+    for switch in ("1", "0"):
+        monkeypatch.setenv("PA_SPMV_XWIN", switch)
+        blk = pa.DeviceCSR(H)
+        assert (blk.xwin()["groups"] > 0) == (switch == "1")
+        empty = pa.DeviceCSR(pa.HostCSR(m, 0, np.ones(m + 1, np.int32), np.zeros(0, np.int32), np.zeros(0)))
+        Ah = pa.PSparseMatrix(pa.DebugArray([psm.SplitMatrixBlocks(blk, empty)]), ind, ind, True)
+        u = pa.pvector_from_function(lambda i: uh, ind)
+        c1, c2 = pa.pzeros(ind), pa.pzeros(ind)
+        pa.mul_c_(c1, Ah, u)
+        assert psm.mul_dot_(c2, Ah, u, 7)
+        assert np.array_equal(c2.own_values().items[0], c1.own_values().items[0])
+        outs.append((c2.own_values().items[0].copy(), pa.read_slots(7)[0]))
+        want = float(uh @ outs[-1][0])
+        assert abs(outs[-1][1] - want) <= 1e-12 * max(1.0, abs(want))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+
+
 @pytest.mark.parametrize("P,np3", [(1, (1, 1, 1)), (4, (2, 2, 1))])      # 4 parts: graph mode declines, eager loop runs
 def test_opt_cg_replayed_from_a_hipgraph_is_bit_identical(P, np3):
     """graph=True records three CG iterations (kernels of the exchange, both SpMV blocks, the slot BLAS-1) into a
