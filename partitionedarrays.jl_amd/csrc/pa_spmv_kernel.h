@@ -237,6 +237,10 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
           c0[k] = pa_pattern_col<PAT == 2>(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
           c1[k] = pa_pattern_col<PAT == 2>(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
         }
+#ifdef PA_PROBE_NO_GATHER             // probe builds only: lane-contiguous x reads in place of the pattern's columns (wrong results)
+        c0[k] = min(max(c0[k], 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);
+        c1[k] = min(max(c1[k], 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);
+#endif
       }
     } else if (use16) {
       unsigned q[NPT / 2];
@@ -276,11 +280,22 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         v[k].y = __hiloint2double(__builtin_amdgcn_ds_bpermute(s1, dict_hi), __builtin_amdgcn_ds_bpermute(s1, dict_lo));
       }
     }
+#ifdef PA_PROBE_LDS_X                  // probe builds only: three coalesced loads of x per lane into LDS, gathers from there (wrong results)
+    __shared__ double xprobe[3 * BLK];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xprobe[tid + k * BLK] = x[min(max(r0 - BLK + tid + k * BLK, 0), r1 - 1)];
+    __syncthreads();
+#endif
 #pragma unroll
     for (int k = 0; k < NPT / 2; ++k) {
       d2 pr;
+#ifdef PA_PROBE_LDS_X
+      pr.x = v[k].x * xprobe[(c0[k] - r0) & 511];
+      pr.y = v[k].y * xprobe[(c1[k] - r0) & 511];
+#else
       pr.x = v[k].x * x[c0[k]];
       pr.y = v[k].y * x[c1[k]];
+#endif
       if (alpha != 1.0) {
         pr.x = pr.x * alpha;
         pr.y = pr.y * alpha;

@@ -23,7 +23,7 @@
 #ifndef PA_XW_MAXG
 #define PA_XW_MAXG 16       // chunks per group at most (fewer on a small block: see pa_build_xw_groups)
 #endif
-#define PA_XW_WANT_GROUPS 2048   // 256 CUs x 2 resident workgroups x 4 rounds: below that the tail of the launch shows
+#define PA_XW_WANT_GROUPS 900    // a launch of fewer workgroups than about two rounds of the 512 resident ones shows its tail
 #ifndef PA_XW_SUB
 #define PA_XW_SUB 2         // sub-groups of 256 lanes per workgroup (chunks of a group in flight at a time)
 #endif
@@ -190,8 +190,8 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const 
     cmin[c] = lo;
     cmax[c] = hi;
   }
-  // a small block gets shorter groups, so that the launch still has a few rounds of workgroups per CU (2 M short rows,
-  // 7268 chunks: 0.0335 ms with groups of 8, 0.0381 with groups of 16)
+  // a small block gets shorter groups, so that the launch still has about two rounds of workgroups per CU (2 M short rows,
+  // 7268 chunks: 0.0402 ms with groups of 4, 0.0335 with groups of 8, 0.0381 with groups of 16)
   const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XW_MAXG, n_chunks / PA_XW_WANT_GROUPS));
   groups.clear();
   rest.clear();

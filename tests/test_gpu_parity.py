@@ -1285,6 +1285,34 @@ def test_x_window_launch_of_banded_rows_is_bit_identical(orc, monkeypatch):
         assert np.array_equal(y2.download(), want), switch
 
 
+def test_fem_matrix_renumbered_by_reverse_cuthill_mckee(orc):
+    """What an unstructured-mesh code does before it assembles: the Q1 mesh numbered at random, then renumbered by reverse
+    Cuthill-McKee (scipy).  No row pattern comes back, but the columns do fall into a band: the block takes the x-window
+    launch, bit-identical to the oracle's spmv_csr! and to k_spmv_rowsplit alone."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    I, J, V, rows, cols = pa.laplacian_fem((400, 300), (1, 1), ranks(1))
+    n = 400 * 300
+    perm = np.random.default_rng(29).permutation(n)                  # random id of node g (0-based)
+    Ip, Jp = perm[I.items[0] - 1], perm[J.items[0] - 1]
+    G = sp.csr_matrix((np.ones(len(Ip)), (Ip, Jp)), shape=(n, n))
+    order = reverse_cuthill_mckee(G, symmetric_mode=True)            # order[k] = old id of the node that becomes k
+    new_id = np.empty(n, np.int64)
+    new_id[order] = np.arange(n)
+    Hc = pa.compresscoo(new_id[Ip] + 1, new_id[Jp] + 1, V.items[0], n, n)
+    band = int(np.max(np.abs(np.repeat(np.arange(n), np.diff(Hc.rowptr)) - (Hc.colval - 1))))
+    assert band < 2400, band
+    A = pa.DeviceCSR(Hc)
+    assert A.encoding()["pattern"] == 0 and A.xwin()["groups"] > 0, (A.encoding(), A.xwin())
+    xh = orc.hash_x(np.arange(1, n + 1)) - 0.5
+    want = np.zeros(n)
+    orc.oracle_c().spmv_csr(want, xh, orc.CSR(n, n, Hc.rowptr, Hc.colval, Hc.nzval))
+    x = pa.DeviceVector(n, 0).upload(xh)
+    y = pa.DeviceVector(n, 0)
+    pa.spmv_(y, A, x)
+    assert np.array_equal(y.download(), want)
+
+
 def test_fem_matrix_on_a_randomly_permuted_mesh(orc):
     """The same Q1 stiffness matrix with its nodes renumbered at random: no row pattern, no band -- every chunk falls to the
     16-bit-window / 32-bit column streams and the plain gather.  Bit-identical to the oracle's spmv_csr!."""

@@ -52,3 +52,19 @@ rows = np.repeat(np.arange(m), lens)
 colr = np.clip(rows + rng.integers(-1000, 1000, size=len(rows)), 0, m - 1)
 order = np.lexsort((colr, rows))
 rate("2M short rows (3..8) within +-1000", pa.HostCSR(m, m, rp, (colr[order] + 1).astype(np.int32), rng.standard_normal(len(rows))))
+
+# a Q1 mesh numbered at random, then renumbered by reverse Cuthill-McKee: what an unstructured-mesh code hands over
+import scipy.sparse as sp
+from scipy.sparse.csgraph import reverse_cuthill_mckee
+for dims in ((600, 4000), (1000, 4000)):
+    I, J, V, rows_, cols_ = pa.laplacian_fem(dims, (1, 1), pa.DebugArray([1]))
+    n = dims[0] * dims[1]
+    perm = np.random.default_rng(29).permutation(n)
+    Ip, Jp = perm[I.items[0] - 1], perm[J.items[0] - 1]
+    G = sp.csr_matrix((np.ones(len(Ip), np.int8), (Ip, Jp)), shape=(n, n))
+    order = reverse_cuthill_mckee(G, symmetric_mode=True)
+    new_id = np.empty(n, np.int64); new_id[order] = np.arange(n)
+    Hc = pa.compresscoo(new_id[Ip] + 1, new_id[Jp] + 1, V.items[0], n, n)
+    band = int(np.max(np.abs(np.repeat(np.arange(n), np.diff(Hc.rowptr)) - (Hc.colval - 1))))
+    rate(f"Q1 FEM {dims[0]}x{dims[1]} nodes, random then RCM (band {band})", Hc)
+    del I, J, V, G, Hc
