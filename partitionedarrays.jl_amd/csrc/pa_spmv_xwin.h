@@ -116,8 +116,10 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const unsigned lo = q[k] & 0xffffu, hi = q[k] >> 16;
-        const int c0 = __builtin_amdgcn_ds_bpermute((lo >> 12) << 2, wrel) + (lo & 4095);
-        const int c1 = __builtin_amdgcn_ds_bpermute((hi >> 12) << 2, wrel) + (hi & 4095);
+        // (the entry before an odd first entry and the one after an odd last entry belong to the neighbouring chunks: decoded
+        // with this chunk's windows they give any index; their products are never summed, but the reads stay inside xs)
+        const int c0 = min(max(__builtin_amdgcn_ds_bpermute((lo >> 12) << 2, wrel) + (int)(lo & 4095), 0), PA_XW_CAP + 3);
+        const int c1 = min(max(__builtin_amdgcn_ds_bpermute((hi >> 12) << 2, wrel) + (int)(hi & 4095), 0), PA_XW_CAP + 3);
         double a = v[k].x * xs[c0];
         double c = v[k].y * xs[c1];
         if (alpha != 1.0) {

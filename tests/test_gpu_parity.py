@@ -1285,6 +1285,41 @@ def test_x_window_launch_of_banded_rows_is_bit_identical(orc, monkeypatch):
         assert np.array_equal(y2.download(), want), switch
 
 
+def test_unstructured_banded_psparse_on_four_parts(orc):
+    """mul! on a PSparseMatrix with no structure at all: 4 parts of a 1-D block partition, 5..24 entries per row at random
+    columns within +-1500 of the diagonal (so every part has up to 1500 ghosts on each side, referenced irregularly).
+    psparse builds the blocks, the own x own blocks take the x-window launch, own x ghost the compacted row split; the
+    product equals the oracle's mul! bit for bit."""
+    P, n = 4, 320_000
+    rows = pa.uniform_partition(ranks(P), n)
+    orows = orc.uniform_partition(P, n)
+    rng = np.random.default_rng(41)
+    Is, Js, Vs = [], [], []
+    for ind in orows:
+        g = ind.own_to_global
+        lens = rng.integers(5, 25, len(g))
+        I = np.repeat(g, lens)
+        J = np.clip(I + rng.integers(-1500, 1500, len(I)), 1, n)
+        Is.append(I.astype(np.int64)); Js.append(J.astype(np.int64)); Vs.append(rng.standard_normal(len(I)))
+    A = pa.psparse_from_coo(pa.DebugArray([a.copy() for a in Is]), pa.DebugArray([a.copy() for a in Js]),
+                            pa.DebugArray([a.copy() for a in Vs]), rows)
+    Ao = orc.psparse_from_coo([a.copy() for a in Is], [a.copy() for a in Js], [a.copy() for a in Vs], orows)
+    for blk in A.matrix_partition.items:
+        assert blk.own_own.encoding()["pattern"] == 0 and blk.own_own.xwin()["groups"] > 0, blk.own_own.xwin()
+        assert blk.own_ghost.nnz > 0
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) - 0.25 * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = upload([v.copy() for v in xo], A.col_partition)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x)
+    yo = _oracle_mul(orc, Ao, xo)
+    for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+    c2 = pa.pzeros(A.row_partition)
+    pa.mul_c_(c2, A, x)                                         # the one-call product takes the same launches
+    for got, exp, r in zip(c2.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+
+
 def test_fem_matrix_renumbered_by_reverse_cuthill_mckee(orc):
     """What an unstructured-mesh code does before it assembles: the Q1 mesh numbered at random, then renumbered by reverse
     Cuthill-McKee (scipy).  No row pattern comes back, but the columns do fall into a band: the block takes the x-window
