@@ -405,6 +405,11 @@ int pa_host_split_csr(int64_t n_own_rows, int64_t n_own_cols, int64_t n_ghost_co
 int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr,
                                  const int32_t *colval, int index_base, int64_t *n_chunks, int64_t *n_pattern_chunks,
                                  int64_t *n_c16_chunks, int64_t *n_patterns);
+/* Host-only self-check of the x-window groups of pa_csr_xwin_info (no GPU): every chunk in exactly one group or left to
+ * the general kernel, every column of a group inside its window, windows within the kernel's LDS stage. */
+int pa_host_check_xw_groups(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr, const int32_t *colval,
+                            int index_base, int64_t *n_groups, int64_t *n_grouped_chunks, int64_t *staged_x_entries,
+                            int64_t *grouped_entries);
 
 /* Fused HPCG set-up for large parts: the same arrays as the chain above (build_matrix -> find_owner ->
  * union_ghost -> map_global_to_local! -> compresscoo -> split_format_locally, HPCG/src/sparse_matrix.jl:105-122)

@@ -1221,6 +1221,59 @@ extern "C" int pa_csr_stream_bytes(const pa_csr *A, int64_t *bytes) {
   return PA_OK;
 }
 
+// Host-only self-check of the x-window groups (pa_spmv_xwin.h): built as csr_build_slab builds them; every chunk is in
+// exactly one group or in the rest list, a group's chunks all read the 16-bit stream, every column of a group lies in its
+// window, and the window fits the kernel's LDS stage.
+extern "C" int pa_host_check_xw_groups(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr, const int32_t *colval,
+                                       int index_base, int64_t *n_groups, int64_t *n_grouped_chunks, int64_t *staged_x_entries,
+                                       int64_t *grouped_entries) {
+  PA_REQUIRE(rowptr && (nnz == 0 || colval) && (index_base == 0 || index_base == 1), "bad arguments");
+  std::vector<int32_t> crp(n_rows + 1), col(nnz);
+  for (int64_t r = 0; r <= n_rows; ++r) crp[r] = rowptr[r] - index_base;
+  for (int64_t p = 0; p < nnz; ++p) col[p] = colval[p] - index_base;
+  std::vector<int32_t> chunk_row;
+  int64_t n_long = 0;
+  pa_build_chunks(crp.data(), n_rows, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
+  const int64_t nch = (int64_t)chunk_row.size() - 1;
+  pa_col_streams full;
+  pa_encode_columns(crp.data(), col.data(), nullptr, n_rows, chunk_row, PA_SPMV_CHUNK_NNZ, false, true, 1, full);
+  std::vector<pa_xw_group> groups;
+  std::vector<int32_t> rest;
+  int64_t grouped = 0, staged = 0, in_groups = 0;
+  if (full.use_c16) staged = pa_build_xw_groups(crp.data(), col.data(), chunk_row, full.win.data(), groups, rest, &grouped);
+  else for (int64_t c = 0; c < nch; ++c) rest.push_back((int32_t)c);
+  std::vector<char> seen(nch, 0);
+  int64_t check_staged = 0, check_grouped = 0;
+  for (const pa_xw_group &g : groups) {
+    PA_REQUIRE(g.cnt >= PA_XW_MING && g.cnt <= PA_XW_MAXG, "group of %d chunks", g.cnt);
+    PA_REQUIRE(g.first >= 0 && g.first + g.cnt <= nch, "group outside the block");
+    PA_REQUIRE(g.wlo >= 0 && g.wlen >= 1 && g.wlo + g.wlen <= n_cols && g.wlen + 2 <= PA_XW_CAP, "window [%d,+%d) does not fit", g.wlo, g.wlen);
+    for (int c = g.first; c < g.first + g.cnt; ++c) {
+      PA_REQUIRE(!seen[c], "chunk %d in two groups", c);
+      seen[c] = 1;
+      const int64_t p0 = crp[chunk_row[c]], p1 = crp[chunk_row[c + 1]];
+      PA_REQUIRE(full.win[(size_t)c * PA_C16_WINDOWS] >= 0 && p1 - (p0 & ~1) <= PA_SPMV_CHUNK_NNZ, "chunk %d has no 16-bit columns", c);
+      for (int64_t p = p0; p < p1; ++p)
+        PA_REQUIRE(col[p] >= g.wlo && col[p] < g.wlo + g.wlen, "column %d of chunk %d outside its window", col[p], c);
+      check_grouped += p1 - p0;
+    }
+    check_staged += g.wlen;
+    in_groups += g.cnt;
+  }
+  for (int32_t c : rest) {
+    PA_REQUIRE(c >= 0 && c < nch && !seen[c], "chunk %d listed twice", c);
+    seen[c] = 1;
+  }
+  for (int64_t c = 0; c < nch; ++c) PA_REQUIRE(seen[c], "chunk %lld in no launch", (long long)c);
+  for (size_t k = 1; k < rest.size(); ++k) PA_REQUIRE(rest[k] > rest[k - 1], "rest list not ascending");
+  PA_REQUIRE(check_staged == staged && check_grouped == grouped, "group totals");
+  if (n_groups) *n_groups = (int64_t)groups.size();
+  if (n_grouped_chunks) *n_grouped_chunks = in_groups;
+  if (staged_x_entries) *staged_x_entries = staged;
+  if (grouped_entries) *grouped_entries = grouped;
+  return PA_OK;
+}
+
 extern "C" int pa_csr_memory_class(const pa_csr *A, int *cls) {
   PA_REQUIRE(A && cls, "bad arguments");
   *cls = pa_mem_class(A->ctx, A->d_val);

@@ -1285,6 +1285,42 @@ def test_x_window_launch_of_banded_rows_is_bit_identical(orc, monkeypatch):
         assert np.array_equal(y2.download(), want), switch
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_x_window_launch_on_random_banded_blocks(orc, seed):
+    """Random banded blocks (size, band, row-length law, rectangular shapes, alpha/beta all drawn from the seed): the
+    product through the library's default choice of launches equals the oracle's loop bit for bit."""
+    rng = np.random.default_rng(1000 + seed)
+    m = int(rng.integers(100_000, 260_000))
+    n = m + int(rng.integers(0, 5000)) * int(seed % 2)                # odd seeds: more columns than rows
+    band = int(rng.choice([40, 700, 1800, 2300]))
+    law = seed % 3
+    lens = (np.full(m, int(rng.integers(2, 30))) if law == 0 else
+            rng.integers(0, int(rng.integers(5, 60)), m) if law == 1 else
+            np.where(rng.random(m) < 0.02, rng.integers(200, 1600, m), rng.integers(1, 12, m)))
+    rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(m), lens)
+    col = np.clip(rows + rng.integers(-band, band + 1, size=len(rows)), 0, n - 1)
+    order = np.lexsort((col, rows))
+    H = pa.HostCSR(m, n, rp, (col[order] + 1).astype(np.int32), rng.standard_normal(len(rows)))
+    Ho = orc.CSR(m, n, H.rowptr, H.colval, H.nzval)
+    xh = rng.standard_normal(n)
+    A = pa.DeviceCSR(H)
+    if band <= 700:                     # (a wide band with short rows fits no group of four chunks: the block stays on the row split)
+        assert A.xwin()["groups"] > 0, (seed, band, law, A.xwin(), A.encoding())
+    x = pa.DeviceVector(n, 0).upload(xh)
+    y = pa.DeviceVector(m, 0)
+    want = np.zeros(m)
+    orc.oracle_c().spmv_csr(want, xh, Ho)
+    pa.spmv_(y, A, x)
+    assert np.array_equal(y.download(), want), (seed, band, law)
+    alpha, beta = float(rng.standard_normal()), float(rng.standard_normal())
+    y0 = rng.standard_normal(m)
+    y.upload(y0.copy())
+    pa.spmv_(y, A, x, alpha=alpha, beta=beta)
+    orc.oracle_c().mul5_csr(y0, Ho, xh, alpha, beta)
+    assert np.array_equal(y.download(), y0), (seed, band, law)
+
+
 def test_unstructured_banded_psparse_on_four_parts(orc):
     """mul! on a PSparseMatrix with no structure at all: 4 parts of a 1-D block partition, 5..24 entries per row at random
     columns within +-1500 of the diagonal (so every part has up to 1500 ghosts on each side, referenced irregularly).

@@ -226,6 +226,43 @@ def _check_enc(A):
     return dict(zip(["chunks", "pattern", "c16", "patterns"], [x.value for x in v]))
 
 
+def _check_xw(A):
+    import ctypes as C
+    import pa_amd._lib as L
+    v = [C.c_int64() for _ in range(4)]
+    L.call("pa_host_check_xw_groups", A.m, A.n, A.nnz, L.ptr(A.rowptr), L.ptr(A.colval), 1, *[C.byref(x) for x in v])
+    return dict(zip(["groups", "chunks", "staged_x", "entries"], [x.value for x in v]))
+
+
+def test_x_window_groups_cover_every_chunk_once():
+    """Host logic of the x-window launch (csrc/pa_spmv_xwin.h): on banded rows without a pattern the groups hold most
+    chunks, each chunk sits in exactly one group or in the list left to the general kernel, every column of a group lies
+    inside its window and the window fits the LDS stage -- checked entry by entry by the library's own self-check; rows that
+    reach anywhere or a band wider than the window leave their chunks to the general kernel."""
+    rng = np.random.default_rng(2)
+
+    def banded(m, band, lens, far=0):
+        rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
+        rows = np.repeat(np.arange(m), lens)
+        col = np.clip(rows + rng.integers(-band, band + 1, size=len(rows)), 0, m - 1)
+        if far:
+            col[rng.choice(len(rows), far, replace=False)] = rng.integers(0, m, far)
+        order = np.lexsort((col, rows))
+        return pa.HostCSR(m, m, rp, (col[order] + 1).astype(np.int32), np.ones(len(rows)))
+
+    m = 150_000
+    e = _check_xw(banded(m, 1500, np.full(m, 16)))
+    n_chunks = -(-m * 16 // 1536)
+    assert e["groups"] > 0 and e["chunks"] >= 0.95 * n_chunks and e["entries"] >= 0.95 * m * 16
+    assert e["staged_x"] * 8 < 0.6 * e["entries"] * 10                      # staged x against the matrix bytes of the groups
+    e2 = _check_xw(banded(m, 1500, rng.integers(0, 40, m), far=50))          # ragged, empty rows, rows that reach anywhere
+    assert e2["groups"] > 0 and 0 < e2["chunks"]
+    e3 = _check_xw(banded(m, 9000, np.full(m, 16)))                           # a span of 18000 columns fits no window
+    assert e3["groups"] == 0 and e3["chunks"] == 0
+    e4 = _check_xw(banded(3000, 100, np.full(3000, 4)))                       # fewer chunks than one group's minimum
+    assert e4["groups"] in (0, 1, 2)
+
+
 def test_spmv_row_split_and_column_encodings_decode_exactly(orc):
     """Host logic of the device SpMV: the row split covers every row once, and both column encodings (row patterns,
     16-bit windows) decode to the original columns, on stencil, FEM, ragged and scattered matrices."""
