@@ -237,6 +237,19 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
           c0[k] = pa_pattern_col<PAT == 2>(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
           c1[k] = pa_pattern_col<PAT == 2>(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
         }
+#ifdef PA_PROBE_TILE_X                // probe builds only, 27-point 256^3: the x footprint a chunk WOULD have if its rows were a tile of
+        {                             // 4 grid lines x 14 nodes instead of 57 consecutive nodes of one line (wrong results)
+          auto tile = [&](int c) {
+            const int off = c - r0;
+            const int dz = (off + 32768) >> 16, rem = off - (dz << 16);
+            const int dy = (rem + 64) >> 8, qdx = rem - (dy << 8) + 14;                 // q + dx + 14 in [13, 71]
+            const int ly = (qdx * 4682) >> 16;                                          // qdx / 14
+            return max(r0 + (qdx - ly * 14) + ((ly - 1 + dy) << 8) + (dz << 16), 0);
+          };
+          c0[k] = tile(c0[k]);
+          c1[k] = tile(c1[k]);
+        }
+#endif
 #ifdef PA_PROBE_NO_GATHER             // probe builds only: lane-contiguous x reads in place of the pattern's columns (wrong results)
         c0[k] = min(max(c0[k], 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);
         c1[k] = min(max(c1[k], 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);
