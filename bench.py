@@ -615,12 +615,14 @@ def main():
     traffic, traffic_src = None, None
     try:
         import glob
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
-        if cands and n == 256:
-            pm = json.load(open(cands[-1]))["pmc_per_launch"]["k_spmv_rowsplit"]
-            traffic = round(pm["fetch_bytes_gfx950_corrected"] + pm["write_bytes"])
-            traffic_src = (os.path.relpath(cands[-1], ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of a separate 1-GPU 256^3 "
-                           "run of this command, not of this process)")
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_summary.json")))
+        for cand in reversed(cands if n == 256 else []):          # the newest round's summary that holds the counters
+            pm = json.load(open(cand)).get("pmc_per_launch", {}).get("k_spmv_rowsplit")
+            if pm and "fetch_bytes_gfx950_corrected" in pm and "write_bytes" in pm:
+                traffic = round(pm["fetch_bytes_gfx950_corrected"] + pm["write_bytes"])
+                traffic_src = (os.path.relpath(cand, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of a separate 1-GPU 256^3 "
+                               "run of this command, not of this process)")
+                break
     except Exception:
         pass
 
