@@ -178,7 +178,8 @@ int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern_chunks, int64_t *n_c16_c
 /* Banded rows without a pattern: groups of consecutive chunks whose span of x is copied into LDS once and gathered from
  * there (csrc/pa_spmv_xwin.h; same products, same order -- spmv_csr!, src/sparse_utils.jl:649-669).  n_groups = 0: the
  * block does not use it (PA_SPMV_XWIN=0 turns it off, =2 forces it for every block that has groups). */
-int pa_csr_xwin_info(const pa_csr *A, int64_t *n_groups, int64_t *n_chunks, int64_t *staged_x_entries);
+int pa_csr_xwin_info(const pa_csr *A, int64_t *n_groups, int64_t *n_chunks, int64_t *staged_x_entries,
+                     int64_t *n_big_groups /* of n_groups: those on the 128 KiB window (one workgroup per CU) */);
 /* HBM bytes the block occupies (values, the column streams actually kept, row pointers, chunk table, descriptors).
  * A block whose chunks are described by row patterns keeps no columns for them: a stencil operator costs ~8 bytes per
  * stored entry, a block on the 16-bit stream ~14 (8 + 4 + 2). */
@@ -409,7 +410,7 @@ int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int64_t nnz, co
  * the general kernel, every column of a group inside its window, windows within the kernel's LDS stage. */
 int pa_host_check_xw_groups(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr, const int32_t *colval,
                             int index_base, int64_t *n_groups, int64_t *n_grouped_chunks, int64_t *staged_x_entries,
-                            int64_t *grouped_entries);
+                            int64_t *grouped_entries, int64_t *n_big_groups);
 
 /* Fused HPCG set-up for large parts: the same arrays as the chain above (build_matrix -> find_owner ->
  * union_ghost -> map_global_to_local! -> compresscoo -> split_format_locally, HPCG/src/sparse_matrix.jl:105-122)

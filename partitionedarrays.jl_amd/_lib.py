@@ -118,7 +118,7 @@ _SIGS = {
     "pa_scatter_add": [P, P, P, cint],
     "pa_csr_info": [P] + [C.POINTER(i64)] * 6,
     "pa_csr_encoding": [P] + [C.POINTER(i64)] * 3,
-    "pa_csr_xwin_info": [P] + [C.POINTER(i64)] * 3,
+    "pa_csr_xwin_info": [P] + [C.POINTER(i64)] * 4,
     "pa_spmv": [P, P, cint, P, cint, f64, f64],
     "pa_sell_create": [P, i64, i64, i64, P, P, cint, cint, P, cint, PP],
     "pa_sell_destroy": [P],
@@ -145,7 +145,7 @@ _SIGS = {
     "pa_host_compresscoo_csr": [P, P, P, i64, i64, i64, cint, P, P, P, C.POINTER(i64)],
     "pa_host_split_csr": [i64, i64, i64, P, P, P, P, P, P, P, P, P, C.POINTER(i64), C.POINTER(i64)],
     "pa_host_check_spmv_encodings": [i64, i64, i64, P, P, cint] + [C.POINTER(i64)] * 4,
-    "pa_host_check_xw_groups": [i64, i64, i64, P, P, cint] + [C.POINTER(i64)] * 4,
+    "pa_host_check_xw_groups": [i64, i64, i64, P, P, cint] + [C.POINTER(i64)] * 5,
     "pa_host_hpcg_ghosts": [i64] * 9 + [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "pa_host_hpcg_split_csr": [i64] * 9 + [P, i64, P, P, P, P, P, P, P],
     "pa_host_color_split": [i64, i64, P, P, P, P, P, P, P, i32, P, P, P, P],

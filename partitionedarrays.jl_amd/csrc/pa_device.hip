@@ -777,15 +777,17 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   {
     const char *ex = getenv("PA_SPMV_XWIN");
     if (cs.use_c16 && !cs.use_pattern && !compact && !(ex && atoi(ex) == 0) && A->n_chunks >= 64) {
-      std::vector<pa_xw_group> groups;
-      std::vector<int32_t> rest;
-      int64_t grouped = 0;
-      const int64_t staged = pa_build_xw_groups(crp.data(), col0, chunk_row, cs.win.data(), groups, rest, &grouped);
       const bool forced = ex && atoi(ex) == 2;
-      if (!groups.empty() && (forced || (grouped * 2 >= nnz && staged * 8 * 2 <= grouped * 10))) {
+      pa_xw_plan P;
+      pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P);
+      const std::vector<pa_xw_group> &groups = P.groups;
+      const std::vector<int32_t> &rest = P.rest;
+      const int64_t grouped = P.grouped, staged = P.staged;
+      if (!groups.empty() && (forced || grouped * 2 >= nnz)) {
         std::vector<int32_t> chunk_p(chunk_row.size());
         for (size_t k = 0; k < chunk_row.size(); ++k) chunk_p[k] = crp[chunk_row[k]];
         A->n_xw_groups = (int64_t)groups.size(); A->n_xw_rest = (int64_t)rest.size();
+        A->n_xw_small = P.n_small; A->n_xw_big = P.n_big;
         A->n_xw_chunks = A->n_chunks - A->n_xw_rest; A->xw_staged = staged;
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_p, sizeof(int32_t) * chunk_p.size(), PA_MEM_MATRIX));
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_xw_grp, sizeof(pa_xw_group) * groups.size(), PA_MEM_MATRIX));
@@ -796,8 +798,9 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
           PA_HIP(hipMemcpy(A->d_xw_rest, rest.data(), sizeof(int32_t) * rest.size(), hipMemcpyHostToDevice));
         }
       }
-      if (tm_) fprintf(stderr, "[pa setup] x windows: %lld groups, %lld of %lld entries, %lld staged x entries, %s\n",
-                       (long long)groups.size(), (long long)grouped, (long long)nnz, (long long)staged, A->n_xw_groups ? "used" : "not used");
+      if (tm_) fprintf(stderr, "[pa setup] x windows: %lld + %lld groups (40 / 128 KiB), %lld of %lld entries, %lld staged x entries, %s\n",
+                       (long long)P.n_small, (long long)P.n_big, (long long)grouped, (long long)nnz, (long long)staged,
+                       A->n_xw_groups ? "used" : "not used");
     }
   }
   if (cs.use_pattern) {
@@ -1173,15 +1176,17 @@ extern "C" int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern, int64_t *n_c
   return PA_OK;
 }
 
-extern "C" int pa_csr_xwin_info(const pa_csr *A, int64_t *n_groups, int64_t *n_chunks, int64_t *staged_x_entries) {
+extern "C" int pa_csr_xwin_info(const pa_csr *A, int64_t *n_groups, int64_t *n_chunks, int64_t *staged_x_entries,
+                                int64_t *n_big_groups) {
   PA_REQUIRE(A != nullptr, "csr is NULL");
-  int64_t g = 0, k = 0, st = 0;
+  int64_t g = 0, k = 0, st = 0, big = 0;
   for (const pa_csr *S = A; S; S = S->next) {
-    g += S->n_xw_groups; k += S->n_xw_chunks; st += S->xw_staged;
+    g += S->n_xw_groups; k += S->n_xw_chunks; st += S->xw_staged; big += S->n_xw_big;
   }
   if (n_groups) *n_groups = g;
   if (n_chunks) *n_chunks = k;
   if (staged_x_entries) *staged_x_entries = st;
+  if (n_big_groups) *n_big_groups = big;
   return PA_OK;
 }
 
@@ -1226,7 +1231,7 @@ extern "C" int pa_csr_stream_bytes(const pa_csr *A, int64_t *bytes) {
 // window, and the window fits the kernel's LDS stage.
 extern "C" int pa_host_check_xw_groups(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *rowptr, const int32_t *colval,
                                        int index_base, int64_t *n_groups, int64_t *n_grouped_chunks, int64_t *staged_x_entries,
-                                       int64_t *grouped_entries) {
+                                       int64_t *grouped_entries, int64_t *n_big_groups) {
   PA_REQUIRE(rowptr && (nnz == 0 || colval) && (index_base == 0 || index_base == 1), "bad arguments");
   std::vector<int32_t> crp(n_rows + 1), col(nnz);
   for (int64_t r = 0; r <= n_rows; ++r) crp[r] = rowptr[r] - index_base;
@@ -1237,17 +1242,22 @@ extern "C" int pa_host_check_xw_groups(int64_t n_rows, int64_t n_cols, int64_t n
   const int64_t nch = (int64_t)chunk_row.size() - 1;
   pa_col_streams full;
   pa_encode_columns(crp.data(), col.data(), nullptr, n_rows, chunk_row, PA_SPMV_CHUNK_NNZ, false, true, 1, full);
-  std::vector<pa_xw_group> groups;
-  std::vector<int32_t> rest;
-  int64_t grouped = 0, staged = 0, in_groups = 0;
-  if (full.use_c16) staged = pa_build_xw_groups(crp.data(), col.data(), chunk_row, full.win.data(), groups, rest, &grouped);
-  else for (int64_t c = 0; c < nch; ++c) rest.push_back((int32_t)c);
+  pa_xw_plan P;
+  if (full.use_c16) pa_plan_xw(crp.data(), col.data(), chunk_row, full.win.data(), false, P);
+  else for (int64_t c = 0; c < nch; ++c) P.rest.push_back((int32_t)c);
+  const std::vector<pa_xw_group> &groups = P.groups;
+  const std::vector<int32_t> &rest = P.rest;
+  const int64_t grouped = P.grouped, staged = P.staged;
+  int64_t in_groups = 0;
+  PA_REQUIRE(P.n_small + P.n_big == (int64_t)groups.size(), "tier counts");
   std::vector<char> seen(nch, 0);
   int64_t check_staged = 0, check_grouped = 0;
-  for (const pa_xw_group &g : groups) {
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    const pa_xw_group &g = groups[gi];
+    const int cap = (int64_t)gi < P.n_small ? PA_XW_CAP : PA_XW_CAP_BIG;
     PA_REQUIRE(g.cnt >= PA_XW_MING && g.cnt <= PA_XW_MAXG, "group of %d chunks", g.cnt);
     PA_REQUIRE(g.first >= 0 && g.first + g.cnt <= nch, "group outside the block");
-    PA_REQUIRE(g.wlo >= 0 && g.wlen >= 1 && g.wlo + g.wlen <= n_cols && g.wlen + 2 <= PA_XW_CAP, "window [%d,+%d) does not fit", g.wlo, g.wlen);
+    PA_REQUIRE(g.wlo >= 0 && g.wlen >= 1 && g.wlo + g.wlen <= n_cols && g.wlen + 2 <= cap, "window [%d,+%d) does not fit", g.wlo, g.wlen);
     for (int c = g.first; c < g.first + g.cnt; ++c) {
       PA_REQUIRE(!seen[c], "chunk %d in two groups", c);
       seen[c] = 1;
@@ -1268,6 +1278,7 @@ extern "C" int pa_host_check_xw_groups(int64_t n_rows, int64_t n_cols, int64_t n
   for (size_t k = 1; k < rest.size(); ++k) PA_REQUIRE(rest[k] > rest[k - 1], "rest list not ascending");
   PA_REQUIRE(check_staged == staged && check_grouped == grouped, "group totals");
   if (n_groups) *n_groups = (int64_t)groups.size();
+  if (n_big_groups) *n_big_groups = P.n_big;
   if (n_grouped_chunks) *n_grouped_chunks = in_groups;
   if (staged_x_entries) *staged_x_entries = staged;
   if (grouped_entries) *grouped_entries = grouped;
@@ -1299,22 +1310,45 @@ extern "C" int pa_csr_value_dict(const pa_csr *A, int *n_values) {
   return PA_OK;
 }
 
-// the product kernel on one slab, raw pointers (x: the block's column segment, ys: this slab's rows)
-static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta) {
+// the x-window launches of a slab (pa_spmv_xwin.h): small-window groups, big-window groups, and k_spmv_rowsplit over the
+// chunks that are in no group; u != NULL: the fused dot (partial[chunk] as k_spmv_rowsplit's EPI 3 writes it)
+static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta, const double *u, double *partial) {
   pa_ctx *c = S->ctx;
-  if (S->n_xw_groups > 0 && !S->use_vdict) {
-    const int gpx = (int)((S->n_xw_groups + 7) / 8);
-    hipLaunchKernelGGL((k_spmv_xwin<PA_XW_SUB, SPMV_NPT, SPMV_NT>), dim3(gpx * 8), dim3(256 * PA_XW_SUB), 0, c->s[0], S->d_crp,
-                       S->d_col16, S->d_win, S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, (const pa_xw_group *)S->d_xw_grp,
-                       (int)S->n_xw_groups, gpx, (int)S->n_cols, alpha, kbeta);
-    if (S->n_xw_rest > 0) {                              // what fits no group: the general kernel over a chunk list
-      const int cpx = (int)((S->n_xw_rest + 7) / 8);
+  const pa_xw_group *grp = (const pa_xw_group *)S->d_xw_grp;
+#define PA_LAUNCH_XW(DOT, XCAP, G, NG)                                                                                              \
+  hipLaunchKernelGGL((k_spmv_xwin<PA_XW_SUB, SPMV_NPT, SPMV_NT, DOT, XCAP>), dim3((((NG) + 7) / 8) * 8), dim3(256 * PA_XW_SUB), 0,  \
+                     c->s[0], S->d_crp, S->d_col16, S->d_win, S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, (G), (int)(NG),        \
+                     (int)(((NG) + 7) / 8), (int)S->n_cols, alpha, kbeta, u, partial)
+  if (S->n_xw_small > 0) {
+    if (u) PA_LAUNCH_XW(true, PA_XW_CAP, grp, S->n_xw_small);
+    else PA_LAUNCH_XW(false, PA_XW_CAP, grp, S->n_xw_small);
+  }
+  if (S->n_xw_big > 0) {
+    if (u) PA_LAUNCH_XW(true, PA_XW_CAP_BIG, grp + S->n_xw_small, S->n_xw_big);
+    else PA_LAUNCH_XW(false, PA_XW_CAP_BIG, grp + S->n_xw_small, S->n_xw_big);
+  }
+#undef PA_LAUNCH_XW
+  if (S->n_xw_rest > 0) {                              // what fits no group: the general kernel over a chunk list
+    const int cpx = (int)((S->n_xw_rest + 7) / 8);
+    if (u)
+      hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
+                         c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
+                         S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, 1.0, kbeta, partial, u,
+                         (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr, S->d_xw_rest);
+    else
       hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
                          c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                          S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, alpha, kbeta, (double *)nullptr,
                          (const double *)nullptr, (const double *)nullptr, (const unsigned char *)nullptr,
                          (const double *)nullptr, S->d_xw_rest);
-    }
+  }
+}
+
+// the product kernel on one slab, raw pointers (x: the block's column segment, ys: this slab's rows)
+static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta) {
+  pa_ctx *c = S->ctx;
+  if (S->n_xw_groups > 0 && !S->use_vdict) {
+    launch_xwin(S, xs, ys, alpha, kbeta, nullptr, nullptr);
     return;
   }
   if (S->n_chunks > 0) {
@@ -2108,17 +2142,7 @@ static int spmv_dot_block(const pa_csr *A, const double *x, double *y, double be
       kbeta = 1.0;
     }
     if (S->n_xw_groups > 0) {
-      const int gpx = (int)((S->n_xw_groups + 7) / 8);
-      hipLaunchKernelGGL((k_spmv_xwin<PA_XW_SUB, SPMV_NPT, SPMV_NT, true>), dim3(gpx * 8), dim3(256 * PA_XW_SUB), 0, c->s[0],
-                         S->d_crp, S->d_col16, S->d_win, S->d_val, x, ys, S->d_chunk_row, S->d_chunk_p,
-                         (const pa_xw_group *)S->d_xw_grp, (int)S->n_xw_groups, gpx, (int)S->n_cols, 1.0, kbeta, us, partial + off);
-      if (S->n_xw_rest > 0) {
-        const int cpx = (int)((S->n_xw_rest + 7) / 8);
-        hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
-                           c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, x, ys,
-                           S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, 1.0, kbeta, partial + off, us,
-                           (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr, S->d_xw_rest);
-      }
+      launch_xwin(S, x, ys, 1.0, kbeta, us, partial + off);
     } else if (S->n_chunks > 0) {
       const int cpx = (int)((S->n_chunks + 7) / 8);
 #define PA_LAUNCH_DOT(C16, PAT)                                                                                           \

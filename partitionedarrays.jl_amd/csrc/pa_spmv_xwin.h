@@ -19,7 +19,13 @@
 #pragma once
 #include "pa_spmv_kernel.h"
 
+// Two window sizes: 40 KiB (two workgroups = 16 waves per CU) and, for the chunks whose span does not fit that, 128 KiB
+// (one workgroup per CU: 4 M rows x 16 within +-4000 / +-6000 0.158 / 0.164 ms against 0.245 / 0.263 on the row split;
+// within +-2000 the small window is the faster one, 0.126 against 0.158).
+#ifndef PA_XW_CAP
 #define PA_XW_CAP 5120      // doubles of x a workgroup stages (40 KiB)
+#endif
+#define PA_XW_CAP_BIG 16380 // ... and in the one-workgroup-per-CU instantiation (128 KiB)
 #ifndef PA_XW_MAXG
 #define PA_XW_MAXG 16       // chunks per group at most (fewer on a small block: see pa_build_xw_groups)
 #endif
@@ -35,7 +41,7 @@ struct pa_xw_group { int first, cnt, wlo, wlen; };
 // DOT: also partial[chunk] = sum over the chunk's rows of u[row] * (sum of the row's products), in the order of
 // k_spmv_rowsplit's EPI 3 (per lane in row order, pa_wave_sum, the four wave sums left to right): the same bits whichever
 // kernel a chunk runs on.
-template <int SUB, int NPT, bool NT, bool DOT = false>
+template <int SUB, int NPT, bool NT, bool DOT = false, int XCAP = PA_XW_CAP>
 __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
     const int *__restrict__ crp, const unsigned short *__restrict__ col16, const int *__restrict__ win,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
@@ -44,7 +50,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
     double *__restrict__ partial = nullptr) {
   constexpr int BLK = 256, CAP = BLK * NPT, NTHR = BLK * SUB;
   constexpr int PCAP = CAP + CAP / 32 + 2;            // one pad slot per 32 products: rows of 2^k entries miss each other's banks
-  __shared__ __attribute__((aligned(16))) double xs[PA_XW_CAP + 4];
+  __shared__ __attribute__((aligned(16))) double xs[XCAP + 4];
   __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
   __shared__ double wsum[SUB * (BLK / 64)];
   const int tid = threadIdx.x;
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
   {
     const int npair = (G.wlo + G.wlen - wl + 1) >> 1;
     if (wl >= 0 && wl + 2 * npair <= n_cols) {        // (block-uniform) every pair lies inside x: 16-byte loads
-      constexpr int KX = (PA_XW_CAP / 2 + 2 + NTHR - 1) / NTHR;
+      constexpr int KX = (XCAP / 2 + 2 + NTHR - 1) / NTHR;
       d2 xv[KX];
 #pragma unroll
       for (int k = 0; k < KX; ++k) xv[k] = *reinterpret_cast<const d2 *>(x + wl + 2 * min(tid + k * NTHR, npair - 1));
@@ -118,8 +124,8 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
         const unsigned lo = q[k] & 0xffffu, hi = q[k] >> 16;
         // (the entry before an odd first entry and the one after an odd last entry belong to the neighbouring chunks: decoded
         // with this chunk's windows they give any index; their products are never summed, but the reads stay inside xs)
-        const int c0 = min(max(__builtin_amdgcn_ds_bpermute((lo >> 12) << 2, wrel) + (int)(lo & 4095), 0), PA_XW_CAP + 3);
-        const int c1 = min(max(__builtin_amdgcn_ds_bpermute((hi >> 12) << 2, wrel) + (int)(hi & 4095), 0), PA_XW_CAP + 3);
+        const int c0 = min(max(__builtin_amdgcn_ds_bpermute((lo >> 12) << 2, wrel) + (int)(lo & 4095), 0), XCAP + 3);
+        const int c1 = min(max(__builtin_amdgcn_ds_bpermute((hi >> 12) << 2, wrel) + (int)(hi & 4095), 0), XCAP + 3);
         double a = v[k].x * xs[c0];
         double c = v[k].y * xs[c1];
         if (alpha != 1.0) {
@@ -175,16 +181,17 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
   }
 }
 
-// Host side: groups of consecutive 16-bit chunks whose columns span at most PA_XW_CAP - 2 entries; `rest` gets every
-// other chunk.  Returns the entries of x the groups stage in total (the extra traffic the window path pays).
+// Host side: groups of consecutive 16-bit chunks, not yet `taken`, whose columns span at most cap - 2 entries; the chunks
+// of every group are marked taken.  Appends to `groups`; returns the entries of x these groups stage in total (the extra
+// L2 traffic the window path pays) and, in *grouped_entries, the stored entries they hold.
 inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row,
-                                  const int32_t *win, std::vector<pa_xw_group> &groups, std::vector<int32_t> &rest,
+                                  const int32_t *win, int cap, std::vector<char> &taken, std::vector<pa_xw_group> &groups,
                                   int64_t *grouped_entries) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   std::vector<int32_t> cmin(n_chunks), cmax(n_chunks);
   for (int64_t c = 0; c < n_chunks; ++c) {
     int32_t lo = INT32_MAX, hi = -1;
-    if (win[c * PA_C16_WINDOWS] >= 0)
+    if (!taken[c] && win[c * PA_C16_WINDOWS] >= 0)
       for (int64_t p = crp[chunk_row[c]]; p < crp[chunk_row[c + 1]]; ++p) {
         lo = std::min(lo, col[p]);
         hi = std::max(hi, col[p]);
@@ -195,29 +202,55 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const 
   // a small block gets shorter groups, so that the launch still has about two rounds of workgroups per CU (2 M short rows,
   // 7268 chunks: 0.0402 ms with groups of 4, 0.0335 with groups of 8, 0.0381 with groups of 16)
   const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XW_MAXG, n_chunks / PA_XW_WANT_GROUPS));
-  groups.clear();
-  rest.clear();
   int64_t staged = 0;
   *grouped_entries = 0;
   int64_t c = 0;
   while (c < n_chunks) {
-    if (cmax[c] < 0) { rest.push_back((int32_t)c++); continue; }
+    if (cmax[c] < 0) { ++c; continue; }
     int32_t lo = cmin[c], hi = cmax[c];
     int64_t e = c + 1;
-    if (hi - lo + 2 <= PA_XW_CAP - 2)
+    if (hi - lo + 2 <= cap - 2)
       while (e < n_chunks && e - c < maxg && cmax[e] >= 0) {
         const int32_t l2 = std::min(lo, cmin[e]), h2 = std::max(hi, cmax[e]);
-        if (h2 - l2 + 2 > PA_XW_CAP - 2) break;
+        if (h2 - l2 + 2 > cap - 2) break;
         lo = l2; hi = h2; ++e;
       }
-    if (hi - lo + 2 > PA_XW_CAP - 2 || e - c < PA_XW_MING) {
-      for (int64_t k = c; k < e; ++k) rest.push_back((int32_t)k);
-    } else {
+    if (hi - lo + 2 <= cap - 2 && e - c >= PA_XW_MING) {
       groups.push_back(pa_xw_group{(int)c, (int)(e - c), lo, hi - lo + 1});
+      for (int64_t k = c; k < e; ++k) taken[k] = 1;
       staged += hi - lo + 1;
       *grouped_entries += (int64_t)crp[chunk_row[e]] - crp[chunk_row[c]];
     }
     c = e;
   }
   return staged;
+}
+
+// Both tiers for one block: small-window groups first, big-window groups over what they left, each tier kept only when
+// the x it stages is at most 0.625 x the matrix bytes (10 per entry) its groups stream.  groups = [small..., big...].
+struct pa_xw_plan {
+  std::vector<pa_xw_group> groups;
+  std::vector<int32_t> rest;
+  int64_t n_small = 0, n_big = 0, staged = 0, grouped = 0;
+};
+inline void pa_plan_xw(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row, const int32_t *win,
+                       bool forced, pa_xw_plan &P) {
+  const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
+  P = pa_xw_plan();
+  std::vector<char> taken(n_chunks, 0);
+  const int caps[2] = {PA_XW_CAP, PA_XW_CAP_BIG};
+  for (int tier = 0; tier < 2; ++tier) {
+    std::vector<char> t2 = taken;
+    std::vector<pa_xw_group> g;
+    int64_t grouped = 0;
+    const int64_t staged = pa_build_xw_groups(crp, col, chunk_row, win, caps[tier], t2, g, &grouped);
+    if (g.empty() || !(forced || staged * 8 * 2 <= grouped * 10)) continue;
+    taken.swap(t2);
+    P.groups.insert(P.groups.end(), g.begin(), g.end());
+    (tier == 0 ? P.n_small : P.n_big) = (int64_t)g.size();
+    P.staged += staged;
+    P.grouped += grouped;
+  }
+  for (int64_t c = 0; c < n_chunks; ++c)
+    if (!taken[c]) P.rest.push_back((int32_t)c);
 }

@@ -1283,6 +1283,10 @@ def test_x_window_launch_of_banded_rows_is_bit_identical(orc, monkeypatch):
         y2 = pa.DeviceVector(m, 0)
         pa.spmv_(y2, A, xg, x_segment=L.SEG_GHOST)
         assert np.array_equal(y2.download(), want), switch
+        # new nonzeros on the same pattern (psparse!-style refresh): both launches read the block's one value stream
+        A.update_values(np.ascontiguousarray(-0.5 * H.nzval))
+        pa.spmv_(y, A, x)
+        assert np.array_equal(y.download(), -0.5 * want), switch
 
 
 @pytest.mark.parametrize("seed", range(6))

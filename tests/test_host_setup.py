@@ -229,9 +229,9 @@ def _check_enc(A):
 def _check_xw(A):
     import ctypes as C
     import pa_amd._lib as L
-    v = [C.c_int64() for _ in range(4)]
+    v = [C.c_int64() for _ in range(5)]
     L.call("pa_host_check_xw_groups", A.m, A.n, A.nnz, L.ptr(A.rowptr), L.ptr(A.colval), 1, *[C.byref(x) for x in v])
-    return dict(zip(["groups", "chunks", "staged_x", "entries"], [x.value for x in v]))
+    return dict(zip(["groups", "chunks", "staged_x", "entries", "big_groups"], [x.value for x in v]))
 
 
 def test_x_window_groups_cover_every_chunk_once():
@@ -257,6 +257,14 @@ def test_x_window_groups_cover_every_chunk_once():
     assert e["staged_x"] * 8 < 0.6 * e["entries"] * 10                      # staged x against the matrix bytes of the groups
     e2 = _check_xw(banded(m, 1500, rng.integers(0, 40, m), far=50))          # ragged, empty rows, rows that reach anywhere
     assert e2["groups"] > 0 and 0 < e2["chunks"]
+    assert e["big_groups"] == 0
+    e5 = _check_xw(banded(m, 5000, np.full(m, 16)))     # a span of 10000 columns, but a block this small gets groups of 4
+    assert e5["groups"] == 0                             # chunks: 83 KB of x for 61 KB of matrix -- declined
+    m2 = 1_000_000                                       # the same band on a block with groups of 11: the 128 KiB window
+    e6 = _check_xw(banded(m2, 4000, np.full(m2, 16)))
+    assert e6["groups"] >= e6["big_groups"] >= e6["groups"] - 4 > 0, e6       # (the clipped ends of the band fit the small window)
+    assert e6["chunks"] >= 0.95 * (m2 * 16 // 1536), e6
+    assert e6["staged_x"] * 8 <= 0.625 * e6["entries"] * 10
     e3 = _check_xw(banded(m, 9000, np.full(m, 16)))                           # a span of 18000 columns fits no window
     assert e3["groups"] == 0 and e3["chunks"] == 0
     e4 = _check_xw(banded(3000, 100, np.full(3000, 4)))                       # fewer chunks than one group's minimum

@@ -32,12 +32,14 @@ def rate(name, H):
 
 rng = np.random.default_rng(0)
 m = 4_000_000
-for band in (8000, 2000, 500, 100):
+bands = tuple(int(b) for b in sys.argv[2].split(",")) if len(sys.argv) > 2 else (8000, 2000, 500, 100)
+for band in bands:
     base = np.repeat(np.arange(m), 16)
     col = np.sort(np.clip(base + rng.integers(-band, band, size=m * 16), 0, m - 1).reshape(m, 16), axis=1).ravel().astype(np.int32) + 1
     H = pa.HostCSR(m, m, (1 + 16 * np.arange(m + 1)).astype(np.int32), col, rng.standard_normal(m * 16))
     rate(f"4M rows x 16 within +-{band}", H)
     del H, col, base
+if len(sys.argv) > 2: sys.exit(0)
 m = 2_000_000
 lens = rng.integers(1, 40, m)
 rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
