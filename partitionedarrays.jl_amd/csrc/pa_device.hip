@@ -787,7 +787,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
         std::vector<int32_t> chunk_p(chunk_row.size());
         for (size_t k = 0; k < chunk_row.size(); ++k) chunk_p[k] = crp[chunk_row[k]];
         A->n_xw_groups = (int64_t)groups.size(); A->n_xw_rest = (int64_t)rest.size();
-        A->n_xw_small = P.n_small; A->n_xw_big = P.n_big;
+        for (int t = 0; t < PA_XW_TIERS; ++t) A->n_xw_tier[t] = P.n_tier[t];
         A->n_xw_chunks = A->n_chunks - A->n_xw_rest; A->xw_staged = staged;
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_p, sizeof(int32_t) * chunk_p.size(), PA_MEM_MATRIX));
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_xw_grp, sizeof(pa_xw_group) * groups.size(), PA_MEM_MATRIX));
@@ -798,8 +798,8 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
           PA_HIP(hipMemcpy(A->d_xw_rest, rest.data(), sizeof(int32_t) * rest.size(), hipMemcpyHostToDevice));
         }
       }
-      if (tm_) fprintf(stderr, "[pa setup] x windows: %lld + %lld groups (40 / 128 KiB), %lld of %lld entries, %lld staged x entries, %s\n",
-                       (long long)P.n_small, (long long)P.n_big, (long long)grouped, (long long)nnz, (long long)staged,
+      if (tm_) fprintf(stderr, "[pa setup] x windows: %lld + %lld + %lld groups (40 / 96 / 128 KiB), %lld of %lld entries, %lld staged x entries, %s\n",
+                       (long long)P.n_tier[0], (long long)P.n_tier[1], (long long)P.n_tier[2], (long long)grouped, (long long)nnz, (long long)staged,
                        A->n_xw_groups ? "used" : "not used");
     }
   }
@@ -1181,7 +1181,7 @@ extern "C" int pa_csr_xwin_info(const pa_csr *A, int64_t *n_groups, int64_t *n_c
   PA_REQUIRE(A != nullptr, "csr is NULL");
   int64_t g = 0, k = 0, st = 0, big = 0;
   for (const pa_csr *S = A; S; S = S->next) {
-    g += S->n_xw_groups; k += S->n_xw_chunks; st += S->xw_staged; big += S->n_xw_big;
+    g += S->n_xw_groups; k += S->n_xw_chunks; st += S->xw_staged; big += S->n_xw_tier[1] + S->n_xw_tier[2];
   }
   if (n_groups) *n_groups = g;
   if (n_chunks) *n_chunks = k;
@@ -1249,12 +1249,12 @@ extern "C" int pa_host_check_xw_groups(int64_t n_rows, int64_t n_cols, int64_t n
   const std::vector<int32_t> &rest = P.rest;
   const int64_t grouped = P.grouped, staged = P.staged;
   int64_t in_groups = 0;
-  PA_REQUIRE(P.n_small + P.n_big == (int64_t)groups.size(), "tier counts");
+  PA_REQUIRE(P.n_tier[0] + P.n_tier[1] + P.n_tier[2] == (int64_t)groups.size(), "tier counts");
   std::vector<char> seen(nch, 0);
   int64_t check_staged = 0, check_grouped = 0;
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const pa_xw_group &g = groups[gi];
-    const int cap = (int64_t)gi < P.n_small ? PA_XW_CAP : PA_XW_CAP_BIG;
+    const int cap = (int64_t)gi < P.n_tier[0] ? PA_XW_CAP : (int64_t)gi < P.n_tier[0] + P.n_tier[1] ? PA_XW_CAP_MID : PA_XW_CAP_BIG;
     PA_REQUIRE(g.cnt >= PA_XW_MING && g.cnt <= PA_XW_MAXG, "group of %d chunks", g.cnt);
     PA_REQUIRE(g.first >= 0 && g.first + g.cnt <= nch, "group outside the block");
     PA_REQUIRE(g.wlo >= 0 && g.wlen >= 1 && g.wlo + g.wlen <= n_cols && g.wlen + 2 <= cap, "window [%d,+%d) does not fit", g.wlo, g.wlen);
@@ -1278,7 +1278,7 @@ extern "C" int pa_host_check_xw_groups(int64_t n_rows, int64_t n_cols, int64_t n
   for (size_t k = 1; k < rest.size(); ++k) PA_REQUIRE(rest[k] > rest[k - 1], "rest list not ascending");
   PA_REQUIRE(check_staged == staged && check_grouped == grouped, "group totals");
   if (n_groups) *n_groups = (int64_t)groups.size();
-  if (n_big_groups) *n_big_groups = P.n_big;
+  if (n_big_groups) *n_big_groups = P.n_tier[1] + P.n_tier[2];
   if (n_grouped_chunks) *n_grouped_chunks = in_groups;
   if (staged_x_entries) *staged_x_entries = staged;
   if (grouped_entries) *grouped_entries = grouped;
@@ -1315,17 +1315,22 @@ extern "C" int pa_csr_value_dict(const pa_csr *A, int *n_values) {
 static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta, const double *u, double *partial) {
   pa_ctx *c = S->ctx;
   const pa_xw_group *grp = (const pa_xw_group *)S->d_xw_grp;
-#define PA_LAUNCH_XW(DOT, XCAP, G, NG)                                                                                              \
-  hipLaunchKernelGGL((k_spmv_xwin<PA_XW_SUB, SPMV_NPT, SPMV_NT, DOT, XCAP>), dim3((((NG) + 7) / 8) * 8), dim3(256 * PA_XW_SUB), 0,  \
-                     c->s[0], S->d_crp, S->d_col16, S->d_win, S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, (G), (int)(NG),        \
+#define PA_LAUNCH_XW(SUB, DOT, XCAP, G, NG)                                                                                \
+  hipLaunchKernelGGL((k_spmv_xwin<SUB, SPMV_NPT, SPMV_NT, DOT, XCAP>), dim3((((NG) + 7) / 8) * 8), dim3(256 * SUB), 0, c->s[0],  \
+                     S->d_crp, S->d_col16, S->d_win, S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, (G), (int)(NG),           \
                      (int)(((NG) + 7) / 8), (int)S->n_cols, alpha, kbeta, u, partial)
-  if (S->n_xw_small > 0) {
-    if (u) PA_LAUNCH_XW(true, PA_XW_CAP, grp, S->n_xw_small);
-    else PA_LAUNCH_XW(false, PA_XW_CAP, grp, S->n_xw_small);
+  const int64_t n0 = S->n_xw_tier[0], n1 = S->n_xw_tier[1], n2 = S->n_xw_tier[2];
+  if (n0 > 0) {
+    if (u) PA_LAUNCH_XW(PA_XW_SUB, true, PA_XW_CAP, grp, n0);
+    else PA_LAUNCH_XW(PA_XW_SUB, false, PA_XW_CAP, grp, n0);
   }
-  if (S->n_xw_big > 0) {
-    if (u) PA_LAUNCH_XW(true, PA_XW_CAP_BIG, grp + S->n_xw_small, S->n_xw_big);
-    else PA_LAUNCH_XW(false, PA_XW_CAP_BIG, grp + S->n_xw_small, S->n_xw_big);
+  if (n1 > 0) {
+    if (u) PA_LAUNCH_XW(4, true, PA_XW_CAP_MID, grp + n0, n1);
+    else PA_LAUNCH_XW(4, false, PA_XW_CAP_MID, grp + n0, n1);
+  }
+  if (n2 > 0) {
+    if (u) PA_LAUNCH_XW(2, true, PA_XW_CAP_BIG, grp + n0 + n1, n2);
+    else PA_LAUNCH_XW(2, false, PA_XW_CAP_BIG, grp + n0 + n1, n2);
   }
 #undef PA_LAUNCH_XW
   if (S->n_xw_rest > 0) {                              // what fits no group: the general kernel over a chunk list

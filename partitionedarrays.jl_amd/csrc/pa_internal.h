@@ -106,7 +106,7 @@ struct pa_csr {
   // x-window launch (pa_spmv_xwin.h): groups of consecutive 16-bit chunks whose x span is staged in LDS; the other chunks
   // of the block stay on k_spmv_rowsplit through d_xw_rest.  n_xw_groups = 0: the block does not use it.
   int64_t n_xw_groups = 0, n_xw_rest = 0, n_xw_chunks = 0, xw_staged = 0;   // n_xw_groups: both tiers
-  int64_t n_xw_small = 0, n_xw_big = 0;   // d_xw_grp = [small-window groups..., big-window groups...]
+  int64_t n_xw_tier[3] = {0, 0, 0};       // d_xw_grp = [40 KiB-window groups..., 96 KiB..., 128 KiB...]
   int32_t *d_chunk_p = nullptr;    // n_chunks+1: crp[chunk_row[c]]
   void *d_xw_grp = nullptr;        // n_xw_groups x {first chunk, chunks, first column, columns}
   int32_t *d_xw_rest = nullptr;

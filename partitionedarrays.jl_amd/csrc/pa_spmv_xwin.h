@@ -19,13 +19,15 @@
 #pragma once
 #include "pa_spmv_kernel.h"
 
-// Two window sizes: 40 KiB (two workgroups = 16 waves per CU) and, for the chunks whose span does not fit that, 128 KiB
-// (one workgroup per CU: 4 M rows x 16 within +-4000 / +-6000 0.158 / 0.164 ms against 0.245 / 0.263 on the row split;
+// Three window sizes: 40 KiB (two workgroups = 16 waves per CU) and, for the chunks whose span does not fit that, 96 KiB
+// with four sub-groups and 128 KiB with two (one workgroup per CU: 4 M rows x 16 within +-4000 / +-6000 0.158 / 0.164 ms against 0.245 / 0.263 on the row split;
 // within +-2000 the small window is the faster one, 0.126 against 0.158).
 #ifndef PA_XW_CAP
 #define PA_XW_CAP 5120      // doubles of x a workgroup stages (40 KiB)
 #endif
-#define PA_XW_CAP_BIG 16380 // ... and in the one-workgroup-per-CU instantiation (128 KiB)
+#define PA_XW_CAP_MID 12284 // ... 96 KiB, four sub-groups: one workgroup of 16 waves per CU
+#define PA_XW_CAP_BIG 16380 // ... 128 KiB, two sub-groups: one workgroup of 8 waves per CU
+#define PA_XW_TIERS 3
 #ifndef PA_XW_MAXG
 #define PA_XW_MAXG 16       // chunks per group at most (fewer on a small block: see pa_build_xw_groups)
 #endif
@@ -185,8 +187,8 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
 // of every group are marked taken.  Appends to `groups`; returns the entries of x these groups stage in total (the extra
 // L2 traffic the window path pays) and, in *grouped_entries, the stored entries they hold.
 inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row,
-                                  const int32_t *win, int cap, std::vector<char> &taken, std::vector<pa_xw_group> &groups,
-                                  int64_t *grouped_entries) {
+                                  const int32_t *win, int cap, int max_ratio_16ths, std::vector<char> &taken,
+                                  std::vector<pa_xw_group> &groups, int64_t *grouped_entries) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   std::vector<int32_t> cmin(n_chunks), cmax(n_chunks);
   for (int64_t c = 0; c < n_chunks; ++c) {
@@ -215,7 +217,10 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const 
         if (h2 - l2 + 2 > cap - 2) break;
         lo = l2; hi = h2; ++e;
       }
-    if (hi - lo + 2 <= cap - 2 && e - c >= PA_XW_MING) {
+    // a group pays when the x it stages (8 B per column of the span) is at most max_ratio x the matrix bytes it streams
+    // (10 B per stored entry); a shorter group over the same span would only be worse, so a failed group's chunks are all left
+    const int64_t ent = (int64_t)crp[chunk_row[e]] - crp[chunk_row[c]];
+    if (hi - lo + 2 <= cap - 2 && e - c >= PA_XW_MING && (int64_t)(hi - lo + 1) * 8 * 16 <= ent * 10 * max_ratio_16ths) {
       groups.push_back(pa_xw_group{(int)c, (int)(e - c), lo, hi - lo + 1});
       for (int64_t k = c; k < e; ++k) taken[k] = 1;
       staged += hi - lo + 1;
@@ -226,28 +231,33 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const 
   return staged;
 }
 
-// Both tiers for one block: small-window groups first, big-window groups over what they left, each tier kept only when
-// the x it stages is at most 0.625 x the matrix bytes (10 per entry) its groups stream.  groups = [small..., big...].
+// The tiers of one block: 40 KiB groups first, then 96 KiB and 128 KiB groups over what the smaller windows left (every
+// group passes the staged-x test of pa_build_xw_groups unless `forced`).
+// groups = [tier 0..., tier 1..., tier 2...].
 struct pa_xw_plan {
   std::vector<pa_xw_group> groups;
   std::vector<int32_t> rest;
-  int64_t n_small = 0, n_big = 0, staged = 0, grouped = 0;
+  int64_t n_tier[PA_XW_TIERS] = {0, 0, 0}, staged = 0, grouped = 0;
 };
 inline void pa_plan_xw(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row, const int32_t *win,
                        bool forced, pa_xw_plan &P) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   P = pa_xw_plan();
   std::vector<char> taken(n_chunks, 0);
-  const int caps[2] = {PA_XW_CAP, PA_XW_CAP_BIG};
-  for (int tier = 0; tier < 2; ++tier) {
+  const int caps[PA_XW_TIERS] = {PA_XW_CAP, PA_XW_CAP_MID, PA_XW_CAP_BIG};
+  for (int tier = 0; tier < PA_XW_TIERS; ++tier) {
     std::vector<char> t2 = taken;
     std::vector<pa_xw_group> g;
     int64_t grouped = 0;
-    const int64_t staged = pa_build_xw_groups(crp, col, chunk_row, win, caps[tier], t2, g, &grouped);
-    if (g.empty() || !(forced || staged * 8 * 2 <= grouped * 10)) continue;
+    // 40 KiB windows compete with a row split that is not bad on such spans (5.9 TB/s within +-500): staged x <= 0.625 x
+    // the matrix bytes.  Spans beyond that are where the row split's gathers go to L2 (3.1-3.6 TB/s): there even as much x
+    // as matrix pays (+-7000, ratio 0.63: 0.172 ms against 0.269; +-8000 forced, ratio 2.1: 0.259 against 0.274).
+    const int ratio16 = forced ? 1 << 20 : tier == 0 ? 10 : 16;
+    const int64_t staged = pa_build_xw_groups(crp, col, chunk_row, win, caps[tier], ratio16, t2, g, &grouped);
+    if (g.empty()) continue;
     taken.swap(t2);
     P.groups.insert(P.groups.end(), g.begin(), g.end());
-    (tier == 0 ? P.n_small : P.n_big) = (int64_t)g.size();
+    P.n_tier[tier] = (int64_t)g.size();
     P.staged += staged;
     P.grouped += grouped;
   }

@@ -11,8 +11,9 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "product"
 def rate(name, H):
     x = pa.DeviceVector(H.n, 0).upload(np.random.default_rng(1).standard_normal(H.n))
     out = []
-    for sw in ("0", "2"):
-        os.environ["PA_SPMV_XWIN"] = sw
+    for sw in ("0", None, "2"):                       # row split only / the library's choice / x windows wherever groups exist
+        if sw is None: os.environ.pop("PA_SPMV_XWIN", None)
+        else: os.environ["PA_SPMV_XWIN"] = sw
         blk = pa.DeviceCSR(H)
         y = pa.DeviceVector(H.m, 0)
         for _ in range(60): pa.spmv_(y, blk, x)
@@ -22,13 +23,11 @@ def rate(name, H):
         ms = e0.elapsed_ms(e1) / 50
         out.append((ms, y.download(), blk.xwin()))
         del blk, y
-    same = np.array_equal(out[0][1], out[1][1])
+    os.environ.pop("PA_SPMV_XWIN", None)
+    same = np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][1], out[2][1])
     alg = (H.nnz * 12 + H.m * 20) / 1e6
-    print(f"[{tag:10s}] {name:44s} row split {out[0][0]:7.4f} ms {alg/out[0][0]:7.1f} GB/s | x windows {out[1][0]:7.4f} ms {alg/out[1][0]:7.1f} GB/s"
-          f"  same bits {same}  {out[1][2]}", flush=True)
-    os.environ.pop("PA_SPMV_XWIN")
-    auto = pa.DeviceCSR(H).xwin()["groups"] > 0
-    print(f"[{tag:10s}]    default choice: {'x windows' if auto else 'row split'}", flush=True)
+    print(f"[{tag:10s}] {name:40s} row split {out[0][0]:7.4f} ms {alg/out[0][0]:6.0f} GB/s | default {out[1][0]:7.4f} ms {alg/out[1][0]:6.0f} GB/s "
+          f"| forced {out[2][0]:7.4f} ms {alg/out[2][0]:6.0f} GB/s  same bits {same}  default {out[1][2]}", flush=True)
 
 rng = np.random.default_rng(0)
 m = 4_000_000
