@@ -856,17 +856,17 @@ def test_fused_product_and_dot_matches_the_separate_calls(orc):
     assert abs(pa.read_slots(7)[0] - want) <= 1e-12 * max(1.0, abs(want))
 
 
-def test_fused_product_and_dot_on_banded_rows_is_the_same_on_both_launches(monkeypatch):
+@pytest.mark.parametrize("m,band,tier", [(150_000, 1200, "40 KiB"), (150_000, 3000, "96 KiB"), (800_000, 6500, "128 KiB")])
+def test_fused_product_and_dot_on_banded_rows_is_the_same_on_both_launches(monkeypatch, m, band, tier):
     """Banded rows without a pattern: pa_mul_dot through k_spmv_xwin (+ the chunk list) and through k_spmv_rowsplit alone
     give the same c AND the same dot, bit for bit (the per-chunk partial sums are formed in one order on both), with
-    chunks of more than 64 rows (short rows) and of fewer."""
+    chunks of more than 64 rows (short rows) and of fewer -- on each of the three window sizes."""
     import pa_amd.p_sparse_matrix as psm
     rng = np.random.default_rng(23)
-    m = 150_000
-    lens = np.where(np.arange(m) < 60_000, rng.integers(1, 6, m), rng.integers(10, 40, m))
+    lens = np.where(np.arange(m) < m // 3, rng.integers(1, 6, m), rng.integers(10, 40, m))
     rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
     rows = np.repeat(np.arange(m), lens)
-    col = np.clip(rows + rng.integers(-1200, 1200, size=len(rows)), 0, m - 1)
+    col = np.clip(rows + rng.integers(-band, band, size=len(rows)), 0, m - 1)
     col[rng.choice(len(rows), 30, replace=False)] = rng.integers(0, m, 30)
     order = np.lexsort((col, rows))
     H = pa.HostCSR(m, m, rp, (col[order] + 1).astype(np.int32), rng.standard_normal(len(rows)))
@@ -876,7 +876,10 @@ def test_fused_product_and_dot_on_banded_rows_is_the_same_on_both_launches(monke
     for switch in ("1", "0"):
         monkeypatch.setenv("PA_SPMV_XWIN", switch)
         blk = pa.DeviceCSR(H)
-        assert (blk.xwin()["groups"] > 0) == (switch == "1")
+        xw = blk.xwin()
+        assert (xw["groups"] > 0) == (switch == "1"), xw
+        if switch == "1":
+            assert (xw["big_groups"] > 0.5 * xw["groups"]) == (tier != "40 KiB"), (tier, xw)
         empty = pa.DeviceCSR(pa.HostCSR(m, 0, np.ones(m + 1, np.int32), np.zeros(0, np.int32), np.zeros(0)))
         Ah = pa.PSparseMatrix(pa.DebugArray([psm.SplitMatrixBlocks(blk, empty)]), ind, ind, True)
         u = pa.pvector_from_function(lambda i: uh, ind)
