@@ -795,6 +795,70 @@ def test_opt_cg_device_scalars_bit_identical_to_ref_cg(P, np3, with_mg):
     assert itc_ == ita_ and abs(rc_ - ra_) <= 1e-9 * ra_
 
 
+def test_cg_on_an_unstructured_banded_spd_matrix_four_parts(orc):
+    """The CG loops on a PSparseMatrix without any structure: a symmetric, diagonally dominant matrix with 6..20 random
+    couplings per row inside a band of +-1500, on 4 parts (irregular ghosts on both sides of every part boundary).  The own
+    x own blocks run on the x-window launches, the fused loop on their dot variant.  ref_cg_ on the device equals the
+    oracle's ref_cg (the reference loop on the host) to rounding of the reductions; opt_cg_(fuse=False) equals ref_cg_ bit
+    for bit; opt_cg_ (fused) to 1e-9 on the residual history; all three converge to the solution the matrix was built for."""
+    P, n = 4, 240_000
+    rows = pa.uniform_partition(ranks(P), n)
+    orows = orc.uniform_partition(P, n)
+    rng = np.random.default_rng(53)
+    k = rng.integers(3, 11, n)                                      # couplings (i, j > i) generated from the lower index
+    i0 = np.repeat(np.arange(1, n + 1), k)
+    j0 = i0 + rng.integers(1, 1500, len(i0))
+    keep = j0 <= n                                                  # (clipping to n would give row n thousands of entries)
+    i0, j0 = i0[keep], j0[keep]
+    v0 = -rng.random(len(i0)) - 0.1
+    diag = np.zeros(n + 1)
+    np.add.at(diag, i0, -v0)
+    np.add.at(diag, j0, -v0)
+    I = np.concatenate([i0, j0, np.arange(1, n + 1)])
+    J = np.concatenate([j0, i0, np.arange(1, n + 1)])
+    V = np.concatenate([v0, v0, 2.0 * diag[1:] + 1.0])            # strictly dominant diagonal: the residual falls steadily
+    order = np.lexsort((J, I))
+    I, J, V = I[order], J[order], V[order]
+    Is, Js, Vs = [], [], []
+    for ind in orows:
+        lo, hi = ind.own_to_global[0], ind.own_to_global[-1]
+        sel = (I >= lo) & (I <= hi)
+        Is.append(I[sel].astype(np.int64)); Js.append(J[sel].astype(np.int64)); Vs.append(V[sel].copy())
+    A = pa.psparse_from_coo(pa.DebugArray([a.copy() for a in Is]), pa.DebugArray([a.copy() for a in Js]),
+                            pa.DebugArray([a.copy() for a in Vs]), rows)
+    for blk in A.matrix_partition.items:
+        assert blk.own_own.xwin()["groups"] > 0 and blk.own_ghost.nnz > 0
+    xs = pa.pvector_from_function(lambda ind: np.cos(0.001 * ind.get_local_to_global()) * (ind.get_local_to_owner() == ind.part),
+                                  A.col_partition)
+    b = pa.pzeros(A.col_partition)
+    pa.mul_(b, A, xs)
+    out = []
+    for fn in (pa.ref_cg_, functools.partial(pa.opt_cg_, fuse=False), pa.opt_cg_):
+        hist = []
+        x, r0, r, it = fn(pa.pzeros(A.col_partition), A, b, maxiter=60, tolerance=1e-8, history=hist)
+        assert r / r0 <= 1e-8 and it < 60
+        for got, want in zip(x.own_values().items, xs.own_values().items):
+            assert np.abs(got - want).max() <= 1e-5
+        out.append((r0, r, it, hist, [v.copy() for v in x.own_values().items]))
+    (r0a, ra, ita, ha, xa), (r0b, rb, itb, hb, xb), (r0c, rc, itc, hc, xc) = out
+    assert (r0a, ra, ita) == (r0b, rb, itb) and ha == hb
+    for u, v in zip(xa, xb):
+        assert np.array_equal(u, v)
+    assert itc == ita and np.allclose(hc, ha, rtol=1e-9, atol=0)
+    # (on a matrix where CG's residual norm peaks -- the same construction with V = diag + 1 and the couplings clipped into
+    # row n -- a peak amplifies the rounding difference of the fused u'c to percents for an iteration or two, in any pair of loops that
+    # round differently; the histories meet again to 1e-14 after each peak.  tools/probe/cg_unstructured_debug.py)
+    # the oracle's loop on the host: same iteration count, history to the rounding of the (differently ordered) reductions
+    Ao = orc.psparse_from_coo([a.copy() for a in Is], [a.copy() for a in Js], [a.copy() for a in Vs], orows)
+    bo = [np.zeros(c.n_local) for c in Ao.cols]
+    for dst, src, c in zip(bo, b.own_values().items, Ao.cols):
+        dst[:c.n_own] = src
+    ho = []
+    xo, r0o, ro, ito = orc.ref_cg([np.zeros(c.n_local) for c in Ao.cols], Ao, bo, maxiter=60, tolerance=1e-8, history=ho,
+                                  mv=orc.mul)
+    assert ito == ita and np.allclose(ho, ha, rtol=1e-8, atol=0)
+
+
 def test_cg_with_reused_work_vectors_is_bit_identical():
     """cg_work: the work vectors allocated once -- ref_cg_ and opt_cg_ give the bits of the allocating loops, solve
     after solve."""
