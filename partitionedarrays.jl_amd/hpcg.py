@@ -275,7 +275,9 @@ def opt_cg_(x, A, b, maxiter=500, tolerance=0.0, history=None, Pl=None, check_ev
     fuse=True (default) takes three passes over the vectors out of every iteration:
       * u'c is accumulated inside the product kernels (mul_dot_: every workgroup adds u[row] * its rows' sums) -- no
         dot pass.  Deterministic, but another summation order than dot(u,c): alpha, hence the iterates, agree with
-        ref_cg_'s to rounding (scalars ~1e-15 relative per iteration; tests/…opt_cg_fused… bounds the drift), not bit for bit;
+        ref_cg_'s to rounding (scalars ~1e-15 relative per iteration; tests/…opt_cg_fused… bounds the drift), not bit for bit
+        (where CG's residual norm peaks -- a plateau of the underlying minimal residual -- that rounding difference shows
+        in percents for an iteration or two and the histories meet again afterwards, as for any two loops that round differently);
       * x .+= alpha .* u waits until u is about to change and shares a pass with u .= z .+ beta .* u (cg_xu_update_; x is
         not read inside the loop, so this alone keeps every bit); r .-= alpha .* c with |r|^2 is the other pass.
     fuse=False keeps the dot as its own kernel and the three statements ref_cg.jl:64-67 in one pass (pa_cg_update): the
