@@ -50,7 +50,9 @@ extern "C" {
 #define PA_STREAM_COMPUTE 0
 #define PA_STREAM_COMM 1
 
+#ifndef PA_SPMV_CHUNK_NNZ        /* (probe builds of the library override it) */
 #define PA_SPMV_CHUNK_NNZ 1536   /* LDS-staged products per workgroup (12 KiB of fp64) */
+#endif
 
 typedef struct pa_ctx pa_ctx;     /* one device + its two streams                                  */
 typedef struct pa_vec pa_vec;     /* local values of one part of a PVector, layout [own | ghost]   */

@@ -25,8 +25,15 @@
 #ifndef PA_XW_CAP
 #define PA_XW_CAP 5120      // doubles of x a workgroup stages (40 KiB)
 #endif
-#define PA_XW_CAP_MID 12284 // ... 96 KiB, four sub-groups: one workgroup of 16 waves per CU
-#define PA_XW_CAP_BIG 16380 // ... 128 KiB, two sub-groups: one workgroup of 8 waves per CU
+// ... 96 KiB with four sub-groups (one workgroup of 16 waves per CU) and 128 KiB with two (8 waves): what the 160 KiB of
+// LDS leave next to the sub-groups' product slots (12284 / 16380 entries with the shipped 1536 products per chunk)
+constexpr int pa_xw_cap_for(int sub, int want) {
+  const int pcap = PA_SPMV_CHUNK_NNZ + PA_SPMV_CHUNK_NNZ / 32 + 2;
+  const int room = ((163840 - 256 - sub * pcap * 8 - sub * 32) / 8 - 4) & ~3;
+  return room < want ? room : want;
+}
+#define PA_XW_CAP_MID pa_xw_cap_for(4, 12284)
+#define PA_XW_CAP_BIG pa_xw_cap_for(2, 16380)
 #define PA_XW_TIERS 3
 #ifndef PA_XW_MAXG
 #define PA_XW_MAXG 16       // chunks per group at most (fewer on a small block: see pa_build_xw_groups)
