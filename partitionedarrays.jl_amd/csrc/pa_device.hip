@@ -741,6 +741,15 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   }
   lap("encode");
   A->use_pattern = cs.use_pattern; A->use_c16 = cs.use_c16;
+  if (!cs.use_pattern && nc > 0) {                         // (see PADP in pa_spmv_kernel.h)
+    int64_t mult8 = 0, nonempty = 0;
+    for (int64_t r = 0; r < nc; ++r) {
+      const int32_t len = crp[r + 1] - crp[r];
+      nonempty += len > 0;
+      mult8 += len > 0 && (len & 7) == 0;
+    }
+    A->pad_products = mult8 * 2 > nonempty;
+  }
   A->n_pattern_chunks = cs.n_pattern; A->n_c16_chunks = cs.n_c16; A->n_c32_chunks = cs.n_c32;
   A->n_c16_fallback = cs.use_c16 ? A->n_chunks - cs.n_pattern - cs.n_c16 : 0;
   A->n_col32 = cs.full ? nnz : (int64_t)cs.c32.size() - (int64_t)pad;
@@ -1364,7 +1373,18 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
                      xs, ys, S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta,             \
                      (double *)nullptr, (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict)
       const int sel_ = (S->use_pattern ? (S->compact ? 2 : 1) : 0) * 2 + (S->use_c16 ? 1 : 0);
-      if (S->use_vdict) {
+      if (S->pad_products && !S->use_vdict && sel_ < 2) {
+        if (sel_ == 1)
+          hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false, 4, true>), dim3(cpx * 8), dim3(SPMV_BLK),
+                             0, c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
+                             S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
+                             (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict);
+        else
+          hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, false, 0, 0, false, 4, true>), dim3(cpx * 8), dim3(SPMV_BLK),
+                             0, c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
+                             S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
+                             (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict);
+      } else if (S->use_vdict) {
         switch (sel_) {
           case 5: PA_LAUNCH_SPMV(true, 2, true); break;
           case 4: PA_LAUNCH_SPMV(false, 2, true); break;

@@ -87,6 +87,7 @@ struct pa_csr {
   double *d_val = nullptr;         // padded
   int32_t *d_chunk_row = nullptr;  // n_chunks+1 row boundaries of the row split
   int32_t *d_row_ids = nullptr;    // compacted row -> row, or NULL
+  bool pad_products = false;       // no row patterns and most rows hold a multiple of 8 entries: padded product slots (PADP)
   bool use_c16 = false;            // 16-bit windowed column stream present
   int64_t n_c16_fallback = 0;      // chunks that keep 32-bit columns
   int64_t n_c16_chunks = 0, n_c32_chunks = 0;   // chunks by column encoding (with n_pattern_chunks: all of them)

@@ -129,7 +129,7 @@ __device__ __forceinline__ double pa_wave_sum(double v) {
 //        from the lane that holds it with ds_bpermute -- 1 byte of matrix stream per entry instead of 8.  The 27-point
 //        HPCG operator has 2 distinct values, a Q1 stiffness matrix on a uniform grid about a dozen.
 #define PA_VDICT_MAX 64
-template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, bool VD = false, int UNR = 4>
+template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, bool VD = false, int UNR = 4, bool PADP = false>
 __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
@@ -141,13 +141,14 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
   constexpr int CAP = BLK * NPT;
   const double *x = EPI == 1 ? gs_x : x_in;   // EPI 1 reads and writes the same vector: no restrict promise on it
   static_assert(NPT % 2 == 0, "pairs");
-#ifdef PA_PROBE_LDS_PAD               // probe builds only: one pad slot per 32 products (row strides of 2^k then miss each other's banks)
-#define PA_PSLOT(p) ((p) + ((p) >> 5))
-  __shared__ __attribute__((aligned(16))) double prod[CAP + CAP / 32 + 2];
-#else
-#define PA_PSLOT(p) (p)
-  __shared__ __attribute__((aligned(16))) double prod[CAP];
-#endif
+  // PADP: two pad slots per 32 products, for blocks whose rows mostly hold a multiple of 8 stored entries: the lanes of the
+  // reduce phase otherwise sit on the same banks (rows of 16: two banks, 16-way; with the pad 2-way; 4 M x 16 within +-500:
+  // 0.145 -> 0.136 ms).  Two slots, not one, so that a lane's pair of products stays 16-byte aligned and goes out as one
+  // ds_write_b128.  Other row lengths (18, 27, 81, ragged) lose 2-3 % to the slot arithmetic: the library picks the variant
+  // per block (pa_csr::pad_products).
+  constexpr bool PAD = PADP;
+  __shared__ __attribute__((aligned(16))) double prod[PAD ? CAP + CAP / 16 + 2 : CAP];
+#define PA_PSLOT(p) (PAD ? (p) + 2 * ((p) >> 5) : (p))
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
 #ifdef PA_PROBE_IDENTITY_CHUNK_MAP   // probe builds only (tools/probe/placement_probe.hip)
@@ -313,12 +314,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         pr.x = pr.x * alpha;
         pr.y = pr.y * alpha;
       }
-#ifdef PA_PROBE_LDS_PAD
-      prod[PA_PSLOT((k * BLK + tid) * 2)] = pr.x;
-      prod[PA_PSLOT((k * BLK + tid) * 2) + 1] = pr.y;
-#else
-      *reinterpret_cast<d2 *>(&prod[(k * BLK + tid) * 2]) = pr;
-#endif
+      *reinterpret_cast<d2 *>(&prod[PA_PSLOT((k * BLK + tid) * 2)]) = pr;
     }
     __syncthreads();
     if (EPI == 11) {   // probe only: a lane owns the two rows of a 16-byte slot of y and stores them with one dwordx4
@@ -331,7 +327,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
           const int a = crp[r] - base, e = crp[r + 1] - base;
           double acc = 0.0;
 #pragma unroll UNR
-          for (int p = a; p < e; ++p) acc = acc + prod[p];
+          for (int p = a; p < e; ++p) acc = acc + prod[PA_PSLOT(p)];
           acc2[h] = acc;
         }
         if (rb >= r0 && rb + 1 < r1) {
@@ -357,7 +353,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         double pr = acc;                     // the row's products alone (beta = 0: that is acc itself)
         if (beta != 0.0) {
           pr = 0.0;
-          for (int p = a; p < e; ++p) pr = pr + prod[p];
+          for (int p = a; p < e; ++p) pr = pr + prod[PA_PSLOT(p)];
         }
         dacc = dacc + (r == r0 + tid ? urow : gs_b[row]) * pr;
         __builtin_nontemporal_store(acc, &y[row]);

@@ -28,7 +28,7 @@
 // ... 96 KiB with four sub-groups (one workgroup of 16 waves per CU) and 128 KiB with two (8 waves): what the 160 KiB of
 // LDS leave next to the sub-groups' product slots (12284 / 16380 entries with the shipped 1536 products per chunk)
 constexpr int pa_xw_cap_for(int sub, int want) {
-  const int pcap = PA_SPMV_CHUNK_NNZ + PA_SPMV_CHUNK_NNZ / 32 + 2;
+  const int pcap = PA_SPMV_CHUNK_NNZ + PA_SPMV_CHUNK_NNZ / 16 + 2;
   const int room = ((163840 - 256 - sub * pcap * 8 - sub * 32) / 8 - 4) & ~3;
   return room < want ? room : want;
 }
@@ -42,7 +42,10 @@ constexpr int pa_xw_cap_for(int sub, int want) {
 #ifndef PA_XW_SUB
 #define PA_XW_SUB 2         // sub-groups of 256 lanes per workgroup (chunks of a group in flight at a time)
 #endif
-#define PA_XW_PSLOT(p) ((p) + ((p) >> 5))
+#define PA_XW_PSLOT(p) ((p) + 2 * ((p) >> 5))   // two pad slots per 32 products: pairs stay 16-byte aligned (see pa_spmv_kernel.h)
+#define PA_XW_MIN_LINES 96  // a group's chunks must touch, on average, this many 128-byte lines of x each (12 KiB): below that
+                            // the lines stay in L1 between the gathers of a chunk and k_spmv_rowsplit is the faster kernel
+                            // (a grid with 2 interleaved unknowns per node: ~20 lines per chunk, 0.077 ms against 0.083 here)
 #define PA_XW_MING 4        // a shorter group would move more x than matrix: its chunks go to k_spmv_rowsplit
 
 struct pa_xw_group { int first, cnt, wlo, wlen; };
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
     int n_groups, int groups_per_xcd, int n_cols, double alpha, double beta, const double *__restrict__ u = nullptr,
     double *__restrict__ partial = nullptr) {
   constexpr int BLK = 256, CAP = BLK * NPT, NTHR = BLK * SUB;
-  constexpr int PCAP = CAP + CAP / 32 + 2;            // one pad slot per 32 products: rows of 2^k entries miss each other's banks
+  constexpr int PCAP = CAP + CAP / 16 + 2;            // padded product slots: rows of 2^k entries miss each other's banks
   __shared__ __attribute__((aligned(16))) double xs[XCAP + 4];
   __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
   __shared__ double wsum[SUB * (BLK / 64)];
@@ -141,9 +144,10 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
           a = a * alpha;
           c = c * alpha;
         }
-        const int s = PA_XW_PSLOT((k * BLK + t) * 2);
-        prod[s] = a;
-        prod[s + 1] = c;
+        d2 pr;
+        pr.x = a;
+        pr.y = c;
+        *reinterpret_cast<d2 *>(&prod[PA_XW_PSLOT((k * BLK + t) * 2)]) = pr;
       }
       // the next chunk's loads go out before this one's row sums: they fly during the barrier and the reduce phase
       if (ch + SUB < ch_end) {
@@ -197,14 +201,27 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const 
                                   const int32_t *win, int cap, int max_ratio_16ths, std::vector<char> &taken,
                                   std::vector<pa_xw_group> &groups, int64_t *grouped_entries) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
-  std::vector<int32_t> cmin(n_chunks), cmax(n_chunks);
+  std::vector<int32_t> cmin(n_chunks), cmax(n_chunks), lines(n_chunks, 0);
+  std::vector<uint64_t> bits;
   for (int64_t c = 0; c < n_chunks; ++c) {
     int32_t lo = INT32_MAX, hi = -1;
-    if (!taken[c] && win[c * PA_C16_WINDOWS] >= 0)
+    if (!taken[c] && win[c * PA_C16_WINDOWS] >= 0) {
       for (int64_t p = crp[chunk_row[c]]; p < crp[chunk_row[c + 1]]; ++p) {
         lo = std::min(lo, col[p]);
         hi = std::max(hi, col[p]);
       }
+      if (hi >= 0 && hi - lo + 2 <= cap - 2) {          // distinct 128-byte lines of x (16 entries) the chunk's gathers touch
+        const int32_t l0 = lo >> 4;
+        bits.assign((size_t)(((hi >> 4) - l0) >> 6) + 1, 0);
+        for (int64_t p = crp[chunk_row[c]]; p < crp[chunk_row[c + 1]]; ++p) {
+          const int32_t l = (col[p] >> 4) - l0;
+          bits[l >> 6] |= 1ull << (l & 63);
+        }
+        int n = 0;
+        for (uint64_t w : bits) n += __builtin_popcountll(w);
+        lines[c] = n;
+      }
+    }
     cmin[c] = lo;
     cmax[c] = hi;
   }
@@ -227,7 +244,10 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const 
     // a group pays when the x it stages (8 B per column of the span) is at most max_ratio x the matrix bytes it streams
     // (10 B per stored entry); a shorter group over the same span would only be worse, so a failed group's chunks are all left
     const int64_t ent = (int64_t)crp[chunk_row[e]] - crp[chunk_row[c]];
-    if (hi - lo + 2 <= cap - 2 && e - c >= PA_XW_MING && (int64_t)(hi - lo + 1) * 8 * 16 <= ent * 10 * max_ratio_16ths) {
+    int64_t touched = 0;
+    for (int64_t k = c; k < e; ++k) touched += lines[k];
+    const bool scattered = max_ratio_16ths >= (1 << 20) || touched >= (int64_t)PA_XW_MIN_LINES * (e - c);
+    if (hi - lo + 2 <= cap - 2 && e - c >= PA_XW_MING && scattered && (int64_t)(hi - lo + 1) * 8 * 16 <= ent * 10 * max_ratio_16ths) {
       groups.push_back(pa_xw_group{(int)c, (int)(e - c), lo, hi - lo + 1});
       for (int64_t k = c; k < e; ++k) taken[k] = 1;
       staged += hi - lo + 1;

@@ -1357,9 +1357,10 @@ def test_x_window_launch_of_banded_rows_is_bit_identical(orc, monkeypatch):
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_x_window_launch_on_random_banded_blocks(orc, seed):
+def test_x_window_launch_on_random_banded_blocks(orc, seed, monkeypatch):
     """Random banded blocks (size, band, row-length law, rectangular shapes, alpha/beta all drawn from the seed): the
-    product through the library's default choice of launches equals the oracle's loop bit for bit."""
+    product through the library's default choice of launches (x windows where the chunks' gathers are scattered enough and the
+    span fits one, the row split otherwise) AND through the forced window launches equals the oracle's loop bit for bit."""
     rng = np.random.default_rng(1000 + seed)
     m = int(rng.integers(100_000, 260_000))
     n = m + int(rng.integers(0, 5000)) * int(seed % 2)                # odd seeds: more columns than rows
@@ -1375,21 +1376,23 @@ def test_x_window_launch_on_random_banded_blocks(orc, seed):
     H = pa.HostCSR(m, n, rp, (col[order] + 1).astype(np.int32), rng.standard_normal(len(rows)))
     Ho = orc.CSR(m, n, H.rowptr, H.colval, H.nzval)
     xh = rng.standard_normal(n)
-    A = pa.DeviceCSR(H)
-    if band <= 700:                     # (a wide band with short rows fits no group of four chunks: the block stays on the row split)
-        assert A.xwin()["groups"] > 0, (seed, band, law, A.xwin(), A.encoding())
-    x = pa.DeviceVector(n, 0).upload(xh)
-    y = pa.DeviceVector(m, 0)
     want = np.zeros(m)
     orc.oracle_c().spmv_csr(want, xh, Ho)
-    pa.spmv_(y, A, x)
-    assert np.array_equal(y.download(), want), (seed, band, law)
     alpha, beta = float(rng.standard_normal()), float(rng.standard_normal())
     y0 = rng.standard_normal(m)
-    y.upload(y0.copy())
-    pa.spmv_(y, A, x, alpha=alpha, beta=beta)
-    orc.oracle_c().mul5_csr(y0, Ho, xh, alpha, beta)
-    assert np.array_equal(y.download(), y0), (seed, band, law)
+    want5 = y0.copy()
+    orc.oracle_c().mul5_csr(want5, Ho, xh, alpha, beta)
+    x = pa.DeviceVector(n, 0).upload(xh)
+    for switch in (None, "2"):
+        if switch is not None:
+            monkeypatch.setenv("PA_SPMV_XWIN", switch)
+        A = pa.DeviceCSR(H)
+        y = pa.DeviceVector(m, 0)
+        pa.spmv_(y, A, x)
+        assert np.array_equal(y.download(), want), (seed, band, law, switch, A.xwin())
+        y.upload(y0.copy())
+        pa.spmv_(y, A, x, alpha=alpha, beta=beta)
+        assert np.array_equal(y.download(), want5), (seed, band, law, switch, A.xwin())
 
 
 def test_unstructured_banded_psparse_on_four_parts(orc):
@@ -1427,10 +1430,11 @@ def test_unstructured_banded_psparse_on_four_parts(orc):
         assert np.array_equal(got, exp[:r.n_own])
 
 
-def test_fem_matrix_renumbered_by_reverse_cuthill_mckee(orc):
+def test_fem_matrix_renumbered_by_reverse_cuthill_mckee(orc, monkeypatch):
     """What an unstructured-mesh code does before it assembles: the Q1 mesh numbered at random, then renumbered by reverse
-    Cuthill-McKee (scipy).  No row pattern comes back, but the columns do fall into a band: the block takes the x-window
-    launch, bit-identical to the oracle's spmv_csr! and to k_spmv_rowsplit alone."""
+    Cuthill-McKee (scipy).  No row pattern comes back, but the columns do fall into a band, in a few clusters per row (the
+    neighbouring level sets): few lines of x per chunk, so the library keeps the block on the row split; forced onto the
+    x-window launches it gives the same bits.  Both equal the oracle's spmv_csr!."""
     import scipy.sparse as sp
     from scipy.sparse.csgraph import reverse_cuthill_mckee
     I, J, V, rows, cols = pa.laplacian_fem((400, 300), (1, 1), ranks(1))
@@ -1444,15 +1448,18 @@ def test_fem_matrix_renumbered_by_reverse_cuthill_mckee(orc):
     Hc = pa.compresscoo(new_id[Ip] + 1, new_id[Jp] + 1, V.items[0], n, n)
     band = int(np.max(np.abs(np.repeat(np.arange(n), np.diff(Hc.rowptr)) - (Hc.colval - 1))))
     assert band < 2400, band
-    A = pa.DeviceCSR(Hc)
-    assert A.encoding()["pattern"] == 0 and A.xwin()["groups"] > 0, (A.encoding(), A.xwin())
     xh = orc.hash_x(np.arange(1, n + 1)) - 0.5
     want = np.zeros(n)
     orc.oracle_c().spmv_csr(want, xh, orc.CSR(n, n, Hc.rowptr, Hc.colval, Hc.nzval))
     x = pa.DeviceVector(n, 0).upload(xh)
-    y = pa.DeviceVector(n, 0)
-    pa.spmv_(y, A, x)
-    assert np.array_equal(y.download(), want)
+    for switch in (None, "2"):
+        if switch is not None:
+            monkeypatch.setenv("PA_SPMV_XWIN", switch)
+        A = pa.DeviceCSR(Hc)
+        assert A.encoding()["pattern"] == 0 and (A.xwin()["groups"] > 0) == (switch == "2"), (A.encoding(), A.xwin())
+        y = pa.DeviceVector(n, 0)
+        pa.spmv_(y, A, x)
+        assert np.array_equal(y.download(), want), switch
 
 
 def test_fem_matrix_on_a_randomly_permuted_mesh(orc):

@@ -38,7 +38,7 @@ for band in bands:
     H = pa.HostCSR(m, m, (1 + 16 * np.arange(m + 1)).astype(np.int32), col, rng.standard_normal(m * 16))
     rate(f"4M rows x 16 within +-{band}", H)
     del H, col, base
-if len(sys.argv) > 2: sys.exit(0)
+if len(sys.argv) > 3: sys.exit(0)
 m = 2_000_000
 lens = rng.integers(1, 40, m)
 rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
