@@ -111,12 +111,23 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
     const int npair = (G.wlo + G.wlen - wl + 1) >> 1;
     if (wl >= 0 && wl + 2 * npair <= n_cols) {        // (block-uniform) every pair lies inside x: 16-byte loads
       constexpr int KX = (XCAP / 2 + 2 + NTHR - 1) / NTHR;
+#ifndef PA_XW_NO_GLDS
+      // global_load_lds_dwordx4: 16 bytes per lane straight into LDS at (wave-uniform base) + lane * 16 -- the window is
+      // lane-linear, so no register round trip and no ds_write pass (the hardware masks the lanes past the window's end)
+      const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+#pragma unroll
+      for (int k = 0; k < KX; ++k)
+        if (tid + k * NTHR < npair)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(x + wl + 2 * (tid + k * NTHR)),
+                                           (__attribute__((address_space(3))) void *)(xs + 2 * (k * NTHR + wave0)), 16, 0, 0);
+#else
       d2 xv[KX];
 #pragma unroll
       for (int k = 0; k < KX; ++k) xv[k] = *reinterpret_cast<const d2 *>(x + wl + 2 * min(tid + k * NTHR, npair - 1));
 #pragma unroll
       for (int k = 0; k < KX; ++k)
         if (tid + k * NTHR < npair) *reinterpret_cast<d2 *>(&xs[2 * (tid + k * NTHR)]) = xv[k];
+#endif
     } else {                                          // the first / last window of the vector
       for (int i = tid; i < 2 * npair; i += NTHR) {
         const int e = wl + i;
