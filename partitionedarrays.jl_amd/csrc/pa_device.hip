@@ -788,7 +788,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
     if (cs.use_c16 && !cs.use_pattern && !compact && !(ex && atoi(ex) == 0) && A->n_chunks >= 64) {
       const bool forced = ex && atoi(ex) == 2;
       pa_xw_plan P;
-      pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P);
+      pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz));
       const std::vector<pa_xw_group> &groups = P.groups;
       const std::vector<int32_t> &rest = P.rest;
       const int64_t grouped = P.grouped, staged = P.staged;
@@ -807,6 +807,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
           PA_HIP(hipMemcpy(A->d_xw_rest, rest.data(), sizeof(int32_t) * rest.size(), hipMemcpyHostToDevice));
         }
       }
+      lap("x windows");
       if (tm_) fprintf(stderr, "[pa setup] x windows: %lld + %lld + %lld groups (40 / 96 / 128 KiB), %lld of %lld entries, %lld staged x entries, %s\n",
                        (long long)P.n_tier[0], (long long)P.n_tier[1], (long long)P.n_tier[2], (long long)grouped, (long long)nnz, (long long)staged,
                        A->n_xw_groups ? "used" : "not used");

@@ -205,37 +205,55 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
   }
 }
 
-// Host side: groups of consecutive 16-bit chunks, not yet `taken`, whose columns span at most cap - 2 entries; the chunks
-// of every group are marked taken.  Appends to `groups`; returns the entries of x these groups stage in total (the extra
-// L2 traffic the window path pays) and, in *grouped_entries, the stored entries they hold.
-inline int64_t pa_build_xw_groups(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row,
-                                  const int32_t *win, int cap, int max_ratio_16ths, std::vector<char> &taken,
-                                  std::vector<pa_xw_group> &groups, int64_t *grouped_entries) {
+// Host side, per chunk (multi-threaded over chunks): first and last column, and how many distinct 128-byte lines of x (16
+// entries) its gathers touch -- only for chunks on the 16-bit stream whose span fits the largest window.
+struct pa_xw_chunk_stats { std::vector<int32_t> cmin, cmax, lines; };
+inline void pa_xw_scan_chunks(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row, const int32_t *win,
+                              int max_cap, int n_threads, pa_xw_chunk_stats &S) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
-  std::vector<int32_t> cmin(n_chunks), cmax(n_chunks), lines(n_chunks, 0);
-  std::vector<uint64_t> bits;
-  for (int64_t c = 0; c < n_chunks; ++c) {
-    int32_t lo = INT32_MAX, hi = -1;
-    if (!taken[c] && win[c * PA_C16_WINDOWS] >= 0) {
+  S.cmin.assign(n_chunks, INT32_MAX); S.cmax.assign(n_chunks, -1); S.lines.assign(n_chunks, 0);
+  auto work = [&](int t, int T) {
+    std::vector<uint64_t> bits;
+    for (int64_t c = n_chunks * t / T; c < n_chunks * (t + 1) / T; ++c) {
+      if (win[c * PA_C16_WINDOWS] < 0) continue;
+      int32_t lo = INT32_MAX, hi = -1;
       for (int64_t p = crp[chunk_row[c]]; p < crp[chunk_row[c + 1]]; ++p) {
         lo = std::min(lo, col[p]);
         hi = std::max(hi, col[p]);
       }
-      if (hi >= 0 && hi - lo + 2 <= cap - 2) {          // distinct 128-byte lines of x (16 entries) the chunk's gathers touch
-        const int32_t l0 = lo >> 4;
-        bits.assign((size_t)(((hi >> 4) - l0) >> 6) + 1, 0);
-        for (int64_t p = crp[chunk_row[c]]; p < crp[chunk_row[c + 1]]; ++p) {
-          const int32_t l = (col[p] >> 4) - l0;
-          bits[l >> 6] |= 1ull << (l & 63);
-        }
-        int n = 0;
-        for (uint64_t w : bits) n += __builtin_popcountll(w);
-        lines[c] = n;
+      S.cmin[c] = lo; S.cmax[c] = hi;
+      if (hi < 0 || hi - lo + 2 > max_cap - 2) continue;
+      const int32_t l0 = lo >> 4;
+      bits.assign((size_t)(((hi >> 4) - l0) >> 6) + 1, 0);
+      for (int64_t p = crp[chunk_row[c]]; p < crp[chunk_row[c + 1]]; ++p) {
+        const int32_t l = (col[p] >> 4) - l0;
+        bits[l >> 6] |= 1ull << (l & 63);
       }
+      int n = 0;
+      for (uint64_t w : bits) n += __builtin_popcountll(w);
+      S.lines[c] = n;
     }
-    cmin[c] = lo;
-    cmax[c] = hi;
+  };
+  if (n_threads <= 1) work(0, 1);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 1; t < n_threads; ++t) th.emplace_back(work, t, n_threads);
+    work(0, n_threads);
+    for (auto &x : th) x.join();
   }
+}
+
+// Groups of consecutive 16-bit chunks, not yet `taken`, whose columns span at most cap - 2 entries; the chunks
+// of every group are marked taken.  Appends to `groups`; returns the entries of x these groups stage in total (the extra
+// L2 traffic the window path pays) and, in *grouped_entries, the stored entries they hold.
+inline int64_t pa_build_xw_groups(const int32_t *crp, const std::vector<int32_t> &chunk_row, const pa_xw_chunk_stats &S,
+                                  int cap, int max_ratio_16ths, std::vector<char> &taken,
+                                  std::vector<pa_xw_group> &groups, int64_t *grouped_entries) {
+  const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
+  const std::vector<int32_t> &cmin = S.cmin, &lines = S.lines;
+  std::vector<int32_t> cmax = S.cmax;
+  for (int64_t c = 0; c < n_chunks; ++c)
+    if (taken[c]) cmax[c] = -1;
   // a small block gets shorter groups, so that the launch still has about two rounds of workgroups per CU (2 M short rows,
   // 7268 chunks: 0.0402 ms with groups of 4, 0.0335 with groups of 8, 0.0381 with groups of 16)
   const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XW_MAXG, n_chunks / PA_XW_WANT_GROUPS));
@@ -278,11 +296,13 @@ struct pa_xw_plan {
   int64_t n_tier[PA_XW_TIERS] = {0, 0, 0}, staged = 0, grouped = 0;
 };
 inline void pa_plan_xw(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row, const int32_t *win,
-                       bool forced, pa_xw_plan &P) {
+                       bool forced, pa_xw_plan &P, int n_threads = 1) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   P = pa_xw_plan();
   std::vector<char> taken(n_chunks, 0);
   const int caps[PA_XW_TIERS] = {PA_XW_CAP, PA_XW_CAP_MID, PA_XW_CAP_BIG};
+  pa_xw_chunk_stats S;
+  pa_xw_scan_chunks(crp, col, chunk_row, win, PA_XW_CAP_BIG, n_threads, S);
   for (int tier = 0; tier < PA_XW_TIERS; ++tier) {
     std::vector<char> t2 = taken;
     std::vector<pa_xw_group> g;
@@ -291,7 +311,7 @@ inline void pa_plan_xw(const int32_t *crp, const int32_t *col, const std::vector
     // the matrix bytes.  Spans beyond that are where the row split's gathers go to L2 (3.1-3.6 TB/s): there even as much x
     // as matrix pays (+-7000, ratio 0.63: 0.172 ms against 0.269; +-8000 forced, ratio 2.1: 0.259 against 0.274).
     const int ratio16 = forced ? 1 << 20 : tier == 0 ? 10 : 16;
-    const int64_t staged = pa_build_xw_groups(crp, col, chunk_row, win, caps[tier], ratio16, t2, g, &grouped);
+    const int64_t staged = pa_build_xw_groups(crp, chunk_row, S, caps[tier], ratio16, t2, g, &grouped);
     if (g.empty()) continue;
     taken.swap(t2);
     P.groups.insert(P.groups.end(), g.begin(), g.end());
