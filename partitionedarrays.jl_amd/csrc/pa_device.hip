@@ -783,6 +783,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   // Rows without a pattern whose columns stay within a band: groups of chunks read x from an LDS copy of their span
   // (pa_spmv_xwin.h).  Taken when most of the block's chunks fall into groups and the staged x is a fraction of the matrix
   // bytes the groups stream; PA_SPMV_XWIN=0 keeps every chunk on k_spmv_rowsplit.
+  lap("upload");
   {
     const char *ex = getenv("PA_SPMV_XWIN");
     if (cs.use_c16 && !cs.use_pattern && !compact && !(ex && atoi(ex) == 0) && A->n_chunks >= 64) {
@@ -820,7 +821,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
     PA_HIP(hipMemcpy(A->d_pdesc, cs.pdesc.data(), sizeof(int32_t) * cs.pdesc.size(), hipMemcpyHostToDevice));
     PA_HIP(hipMemcpy(A->d_pdelta, cs.pdelta.data(), sizeof(int32_t) * cs.pdelta.size(), hipMemcpyHostToDevice));
   }
-  lap("upload");
+  lap("descriptors");
   if (tm_) fprintf(stderr, "[pa setup] val %p (%lld B, memory class %d) col %p crp %p chunk_row %p pdesc %p\n", (void *)A->d_val,
                    (long long)(8 * (nnz + pad)), pa_mem_class(c, A->d_val), (void *)A->d_col, (void *)A->d_crp, (void *)A->d_chunk_row, (void *)A->d_pdesc);
   // optional lossless value dictionary (PA_SPMV_VALUE_DICT=1): at most PA_VDICT_MAX distinct bit patterns
