@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
       constexpr int KX = (XCAP / 2 + 2 + NTHR - 1) / NTHR;
 #ifndef PA_XW_NO_GLDS
       // global_load_lds_dwordx4: 16 bytes per lane straight into LDS at (wave-uniform base) + lane * 16 -- the window is
-      // lane-linear, so no register round trip and no ds_write pass (the hardware masks the lanes past the window's end)
+      // lane-linear, so no register round trip and no ds_write pass; lanes past the window's end are switched off by the
+      // guard (a masked lane neither loads nor writes).  The compiler drains these loads (vmcnt) before the barrier below.
       const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);
 #pragma unroll
       for (int k = 0; k < KX; ++k)
