@@ -39,11 +39,14 @@ constexpr int pa_xw_cap_for(int sub, int want) {
 #define PA_XW_MAXG 16       // chunks per group at most (fewer on a small block: see pa_build_xw_groups)
 #endif
 #define PA_XW_WANT_GROUPS 900    // a launch of fewer workgroups than about two rounds of the 512 resident ones shows its tail
+#ifndef PA_XW_UNROLL
+#define PA_XW_UNROLL 4      // products a lane fetches ahead of its running sum in the reduce phase
+#endif
 #ifndef PA_XW_SUB
 #define PA_XW_SUB 2         // sub-groups of 256 lanes per workgroup (chunks of a group in flight at a time)
 #endif
 #define PA_XW_PSLOT(p) ((p) + 2 * ((p) >> 5))   // two pad slots per 32 products: pairs stay 16-byte aligned (see pa_spmv_kernel.h)
-#define PA_XW_MIN_LINES 96  // a group's chunks must touch, on average, this many 128-byte lines of x each (12 KiB): below that
+#define PA_XW_MIN_LINES 48  // a group's chunks must touch, on average, this many 128-byte lines of x each (6 KiB): below that
                             // the lines stay in L1 between the gathers of a chunk and k_spmv_rowsplit is the faster kernel
                             // (a grid with 2 interleaved unknowns per node: ~20 lines per chunk, 0.077 ms against 0.083 here)
 #define PA_XW_MING 4        // a shorter group would move more x than matrix: its chunks go to k_spmv_rowsplit
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
           e = crp[r + 1] - cbase;
         }
         double acc = beta == 0.0 ? 0.0 : beta * y[r];
-#pragma unroll 4
+#pragma unroll PA_XW_UNROLL
         for (int p = a; p < e; ++p) acc = acc + prod[PA_XW_PSLOT(p)];
         if (DOT) {
           double pr = acc;                            // the row's products alone
