@@ -301,9 +301,11 @@ def calibrate_box(pa, ctx, L):
             "what": "1 GiB vectors: hipMemcpyAsync device-to-device (read+write bytes) and k_dot_partial (two read streams)"}
 
 
-def spin_up(ctx, f, busy_ms=45.0):
+def spin_up(ctx, f, busy_ms=200.0):
     """Bring the GPU back to its working clocks after host-side work left it idle: repeat f until the device has been busy
-    for `busy_ms` (the product needs ~40 launches = 30 ms at 256^3; see the clock ramp in main())."""
+    for `busy_ms` (the product needs ~40 launches = 30 ms at 256^3 after the short idle of the parity gate, see the clock
+    ramp in main(); after the seconds of idle while the host builds another matrix 45 ms were not enough -- a 0.115 ms kernel
+    measured 0.125 ms, tools/probe/xwin_rate.py)."""
     t0 = time.perf_counter()
     while (time.perf_counter() - t0) * 1e3 < busy_ms:
         for _ in range(10):
@@ -378,11 +380,11 @@ def extra_configs(pa, ctx, L, out):
                      "parts), disassembled psparse route, pa_spmv", b5, b5.m, b5.n, time_block(pa, ctx, L, b5, b5.m, b5.n), ts))
     del A5, b5
     # rows without any pattern inside a band (an unstructured mesh in a bandwidth-reducing numbering):
-    # 2 M rows of 16 entries, columns drawn at random within +-2000 of the diagonal
+    # 4 M rows of 16 entries, columns drawn at random within +-2000 of the diagonal
     PHASE[0] = "extra: banded unstructured rows"
     t = time.perf_counter()
     rng = np.random.default_rng(0)
-    m = 2_000_000
+    m = 4_000_000
     col = np.repeat(np.arange(m, dtype=np.int32), 16).reshape(m, 16)
     col += rng.integers(-2000, 2000, size=(m, 16), dtype=np.int32)
     np.clip(col, 0, m - 1, out=col)
@@ -392,7 +394,7 @@ def extra_configs(pa, ctx, L, out):
     bb = pa.DeviceCSR(Hb)
     del Hb, col
     ts = time.perf_counter() - t
-    e = entry("unstructured rows in a band: 2 M rows x 16 entries, random columns within +-2000 of the diagonal, pa_spmv",
+    e = entry("unstructured rows in a band: 4 M rows x 16 entries, random columns within +-2000 of the diagonal, pa_spmv",
               bb, m, m, time_block(pa, ctx, L, bb, m, m), ts)
     e["x_window_launch"] = bb.xwin()
     out.append(e)
