@@ -1,4 +1,5 @@
-"""One part per process (torch.distributed), every rank on the SAME GPU, host-staged transport (PA_TRANSPORT=host):
+"""One part per process (torch.distributed); by default every rank on the SAME GPU, host-staged transport (PA_TRANSPORT=host);
+with PA_TRANSPORT=rccl one GPU per rank and the RCCL neighbour exchange of csrc/pa_rccl.cpp (needs as many GPUs as ranks):
 the full N>1 device path -- pack kernel, exchange, unpack kernel, own*own / own*ghost SpMV, dot -- against the
 sequential oracle, bit-exact.  Run by tests/test_gpu_multiprocess.py on the 1-GPU box."""
 import os
@@ -9,7 +10,7 @@ import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-os.environ["PA_TRANSPORT"] = "host"
+os.environ.setdefault("PA_TRANSPORT", "host")       # "rccl": one GPU per rank (LOCAL_RANK), ncclSend/ncclRecv between them
 from __graft_entry__ import load_package, load_oracle  # noqa: E402
 
 pa = load_package()
@@ -63,6 +64,10 @@ def body(distribute):
 
 if __name__ == "__main__":
     dist.init_process_group("gloo")
+    if os.environ["PA_TRANSPORT"] == "rccl":
+        from pa_amd.p_vector import init_comm
+        comm = init_comm()
+        assert comm.info() == {"rank": dist.get_rank(), "nranks": dist.get_world_size()}
     pa.with_torchdist(body)
     dist.barrier()
     dist.destroy_process_group()
