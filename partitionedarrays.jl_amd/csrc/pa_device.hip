@@ -1350,13 +1350,14 @@ static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double al
       hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
                          c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                          S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, 1.0, kbeta, partial, u,
-                         (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr, S->d_xw_rest);
+                         (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr, S->d_xw_rest,
+                         (int)S->n_cols - 1);
     else
       hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
                          c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                          S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, alpha, kbeta, (double *)nullptr,
                          (const double *)nullptr, (const double *)nullptr, (const unsigned char *)nullptr,
-                         (const double *)nullptr, S->d_xw_rest);
+                         (const double *)nullptr, S->d_xw_rest, (int)S->n_cols - 1);
   }
 }
 
@@ -1373,19 +1374,22 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
                      c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val,           \
                      xs, ys, S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta,             \
-                     (double *)nullptr, (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict)
+                     (double *)nullptr, (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict,         \
+                     (const int *)nullptr, (int)S->n_cols - 1)
       const int sel_ = (S->use_pattern ? (S->compact ? 2 : 1) : 0) * 2 + (S->use_c16 ? 1 : 0);
       if (S->pad_products && !S->use_vdict && sel_ < 2) {
         if (sel_ == 1)
           hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false, 4, true>), dim3(cpx * 8), dim3(SPMV_BLK),
                              0, c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                              S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
-                             (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict);
+                             (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict, (const int *)nullptr,
+                             (int)S->n_cols - 1);
         else
           hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, false, 0, 0, false, 4, true>), dim3(cpx * 8), dim3(SPMV_BLK),
                              0, c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                              S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
-                             (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict);
+                             (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict, (const int *)nullptr,
+                             (int)S->n_cols - 1);
       } else if (S->use_vdict) {
         switch (sel_) {
           case 5: PA_LAUNCH_SPMV(true, 2, true); break;
@@ -1460,7 +1464,8 @@ extern "C" int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x,
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 1, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
                      (const double *)nullptr, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, \
-                     1.0, 0.0, x->d, (const double *)b->d, (const double *)diag->d, A->d_code, A->d_dict)
+                     1.0, 0.0, x->d, (const double *)b->d, (const double *)diag->d, A->d_code, A->d_dict,                  \
+                     (const int *)nullptr, (int)A->n_cols - 1)
     const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
     if (A->use_vdict) {
       switch (sel_) {
@@ -1745,7 +1750,8 @@ extern "C" int pa_transfer_restrict_fused(pa_transfer *t, pa_vec *rc, const pa_v
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 2, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
                      (const double *)xf->d, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx,  \
-                     1.0, 0.0, rc->d, (const double *)rf->d, (const double *)nullptr, A->d_code, A->d_dict)
+                     1.0, 0.0, rc->d, (const double *)rf->d, (const double *)nullptr, A->d_code, A->d_dict,                \
+                     (const int *)nullptr, (int)A->n_cols - 1)
   const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
   if (A->use_vdict) {
     switch (sel_) {
@@ -2176,7 +2182,8 @@ static int spmv_dot_block(const pa_csr *A, const double *x, double *y, double be
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0, \
                      c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, x, ys,     \
                      S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, 1.0, kbeta, partial + off, us,              \
-                     (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr)
+                     (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr,                 \
+                     (const int *)nullptr, (int)S->n_cols - 1)
       switch ((S->use_pattern ? (S->compact ? 2 : 1) : 0) * 2 + (S->use_c16 ? 1 : 0)) {
         case 5: PA_LAUNCH_DOT(true, 2); break;
         case 4: PA_LAUNCH_DOT(false, 2); break;

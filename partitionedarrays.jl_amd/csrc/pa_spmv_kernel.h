@@ -124,6 +124,7 @@ __device__ __forceinline__ double pa_wave_sum(double v) {
 //           fixed order (row order per lane, shuffle tree, wave sums): deterministic.  The CG loop's u'c = dot(u, A u)
 //           (HPCG/src/ref_cg.jl:60) costs no pass over u and c this way.
 //   chunk_list (or NULL): the launch covers these chunks only -- what k_spmv_xwin (pa_spmv_xwin.h) leaves over.
+//   max_col: n_cols - 1 of the block (bounds the columns lanes outside the chunk decode on the 16-bit path).
 //   VD   value dictionary (optional, lossless): a block with at most PA_VDICT_MAX distinct stored values (bit patterns)
 //        keeps one byte per entry (`code`) and the values in `dict`; lane l holds dict[l] and an entry's value is fetched
 //        from the lane that holds it with ds_bpermute -- 1 byte of matrix stream per entry instead of 8.  The 27-point
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     double *__restrict__ y, const int *__restrict__ chunk_row, const int *__restrict__ row_ids, int n_chunks,
     int chunks_per_xcd, double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
     const double *__restrict__ gs_diag, const unsigned char *__restrict__ code = nullptr,
-    const double *__restrict__ dict = nullptr, const int *__restrict__ chunk_list = nullptr) {
+    const double *__restrict__ dict = nullptr, const int *__restrict__ chunk_list = nullptr, int max_col = 0x7fffffff) {
   constexpr int CAP = BLK * NPT;
   const double *x = EPI == 1 ? gs_x : x_in;   // EPI 1 reads and writes the same vector: no restrict promise on it
   static_assert(NPT % 2 == 0, "pairs");
@@ -269,8 +270,11 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       for (int k = 0; k < NPT / 2; ++k) {
         // window base of slot s lives in lane s of `mywin` (any 16-lane group): fetch it with ds_bpermute
         const unsigned lo = q[k] & 0xffffu, hi = q[k] >> 16;
-        c0[k] = __builtin_amdgcn_ds_bpermute((lo >> 12) << 2, mywin) + (lo & 4095);
-        c1[k] = __builtin_amdgcn_ds_bpermute((hi >> 12) << 2, mywin) + (hi & 4095);
+        // max_col = n_cols - 1: the entry before an odd first entry and the one after an odd last entry belong to the
+        // neighbouring chunks; decoded with THIS chunk's windows their codes can point up to 4095 columns past the end of x
+        // (their products are never summed, but the load must stay inside the vector)
+        c0[k] = min(__builtin_amdgcn_ds_bpermute((lo >> 12) << 2, mywin) + (int)(lo & 4095), max_col);
+        c1[k] = min(__builtin_amdgcn_ds_bpermute((hi >> 12) << 2, mywin) + (int)(hi & 4095), max_col);
 #ifdef PA_PROBE_NO_GATHER             // probe builds only: the 16-bit path with lane-contiguous x reads (wrong results)
         c0[k] = min(r0 + (tid & 63) + (int)(lo & 1), r1 - 1);
         c1[k] = min(r0 + (tid & 63) + (int)(hi & 1), r1 - 1);
