@@ -5,7 +5,7 @@
 //   K3     k_pack            src/p_vector.jl:595-599
 //   K4     k_unpack_insert   src/p_vector.jl:605-609 with f = insert (:755)
 //   K5     k_unpack_add      same loop with f = + (:695-697), deterministic (ascending p per target)
-//   K6     k_zero_at         src/p_vector.jl:703-705
+//   K6     k_fill (ghosts)   src/p_vector.jl:703-705
 //   K8     k_axpby / k_dot_* src/p_vector.jl:1189-1277
 //
 // This file is compiled with -ffp-contract=off: every product and every sum is rounded once, in
@@ -120,10 +120,6 @@ __global__ void k_unpack_add(double *__restrict__ v, const double *__restrict__ 
   }
 }
 
-__global__ void k_zero_at(double *__restrict__ v, const int *__restrict__ idx, int n) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n) v[idx[p]] = 0.0;
-}
 
 __global__ void k_axpby(double *__restrict__ y, const double *__restrict__ x, int64_t n, double a, double b) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2013,7 +2009,12 @@ extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
   PA_REQUIRE(p->phase >= 1 && p->mode == mode, "pa_exchange_finish without a matching pa_exchange_pack");
   PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector/plan size mismatch");
   pa_ctx *c = p->ctx;
-  if (p->snd.n == 0 && p->rcv.n == 0) {
+  if (p->snd.n == 0 && p->rcv.n == 0) {                     // nothing travels; assemble! still zeroes the ghosts (below)
+    if (mode == PA_ASSEMBLE && v->n_ghost > 0) {
+      PA_HIP(hipSetDevice(c->device));
+      hipLaunchKernelGGL(k_fill, dim3(grid_for(v->n_ghost, 256)), dim3(256), 0, c->s[0], v->d + v->n_own, (int64_t)v->n_ghost, 0.0);
+      PA_HIP(hipGetLastError());
+    }
     p->phase = 0;
     return PA_OK;
   }
@@ -2043,8 +2044,12 @@ extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
     if (p->n_tgt)
       hipLaunchKernelGGL(k_unpack_add, dim3((p->n_tgt + 255) / 256), dim3(256), 0, c->s[0], v->d, in.d_buf, p->d_tgt, p->d_tptr,
                          p->d_tp, (int)p->n_tgt);
-    // fill!(ghost_values(a),0): the snd side lists every ghost local id exactly once
-    if (p->snd.n) hipLaunchKernelGGL(k_zero_at, dim3((p->snd.n + 255) / 256), dim3(256), 0, c->s[0], v->d, p->snd.d_idx, (int)p->snd.n);
+    // fill!(ghost_values(a),0) (src/p_vector.jl:703-705): EVERY ghost value, also the ones no message carries -- a periodic
+    // direction with a single part makes wrap-around copies whose owner is the part itself; they are ghosts, are not
+    // exchanged (compute_assembly_neighbors skips owner == rank, src/p_range.jl:441-445) and are zeroed all the same.  The
+    // device layout is [own | ghost], so that is the tail of the vector.
+    if (v->n_ghost > 0)
+      hipLaunchKernelGGL(k_fill, dim3(grid_for(v->n_ghost, 256)), dim3(256), 0, c->s[0], v->d + v->n_own, (int64_t)v->n_ghost, 0.0);
   }
   PA_HIP(hipGetLastError());
   // the next pack (on the comm stream) must not overwrite buffers this unpack still reads

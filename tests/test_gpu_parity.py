@@ -1521,6 +1521,35 @@ def test_norm_on_a_ghosted_uniform_partition_counts_own_values_only(orc):
         assert all(np.array_equal(g, src[o.own_to_local - 1]) for g, o, src in zip(v.own_values().items, oparts, vo))
 
 
+@pytest.mark.parametrize("np_,n,ghost,per", [((1,), (6,), (1,), (True,)), ((2, 1), (14, 16), (1, 2), (True, True)),
+                                            ((2, 1, 1), (10, 14, 14), (0, 0, 2), (True, True, True)),
+                                            ((1, 3), (6, 4), (1, 0), (True, False)), ((4, 2, 1), (18, 9, 7), (2, 2, 1), (False, True, True))])
+def test_assemble_zeroes_every_ghost_also_the_self_owned_ones(orc, np_, n, ghost, per):
+    """assemble!(a) ends with fill!(ghost_values(a),0) (src/p_vector.jl:703-705).  A periodic direction with ONE part makes
+    wrap-around copies owned by the part itself: ghosts that no message carries (compute_assembly_neighbors skips owner ==
+    rank, src/p_range.jl:441-445) -- they are zeroed like the others, also on a part that exchanges nothing at all.
+    (Found by tools/probe/fuzz_exchange.py in round 2: the device zeroed the ids of its send side only.)"""
+    P = int(np.prod(np_))
+    parts = pa.uniform_partition(ranks(P), np_, n, ghost, per)
+    oparts = orc.uniform_partition(np_, n, ghost, per)
+    assert any((o.local_to_owner[o.ghost_to_local - 1] == o.part).any() for o in oparts)      # self-owned ghosts exist
+    rng = np.random.default_rng(3)
+    wo = [rng.standard_normal(o.n_local) for o in oparts]
+    it = iter([w.copy() for w in wo])
+    w = pa.pvector_from_function(lambda ind: next(it), parts)
+    pa.assemble_(w).wait()
+    orc.assemble(wo, oparts)
+    for got, want in zip(w.local_values().items, wo):
+        assert np.array_equal(got, want)
+    vo = [rng.standard_normal(o.n_local) for o in oparts]
+    it = iter([v.copy() for v in vo])
+    v = pa.pvector_from_function(lambda ind: next(it), parts)
+    pa.consistent_(v).wait()
+    orc.consistent(vo, oparts)
+    for got, want in zip(v.local_values().items, vo):
+        assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("sigma", [1, 256])
 def test_sell_c_sigma_one_lane_per_row_is_bit_identical(orc, sigma):
     """SELL-C-sigma storage, one lane walks one row in the reference's order with its sum in a register.

@@ -66,6 +66,24 @@ for case in range(n_cases):
             bad += 1
             print(f"MISMATCH case {seed0 + case} XWIN={sw}: m {m} n {n} law {law} band {band} nnz {H.nnz} ghost {ghost} spmv {ok1} mul5 {ok2} {A.encoding()} {A.xwin()}", flush=True)
         del A, y
+    os.environ.pop("PA_SPMV_XWIN", None)
+    # the same block in SELL-C-sigma storage, and its transpose uploaded through the CSC entry point (A' stored by rows =
+    # A stored by columns: the product with the transposed block is A' * z, the oracle's mul5_csr_t)
+    S = pa.DeviceSELL(H, sigma=int(rng.choice([1, 64, 1024])))
+    y = pa.DeviceVector(m, 0)
+    pa.spmv_(y, S, x, x_segment=seg)
+    if not np.array_equal(y.download(), want):
+        bad += 1
+        print(f"MISMATCH case {seed0 + case} SELL: m {m} n {n} law {law} band {band}", flush=True)
+    zt = rng.standard_normal(m)
+    wt = np.zeros(n); orc.oracle_c().mul5_csr_t(wt, Ho, zt, 1.0, 0.0)
+    T = pa.DeviceCSR.transposed(H)
+    yt = pa.DeviceVector(n, 0)
+    pa.spmv_(yt, T, pa.DeviceVector(m, 0).upload(zt))
+    if not np.array_equal(yt.download(), wt):
+        bad += 1
+        print(f"MISMATCH case {seed0 + case} transposed (CSC upload): m {m} n {n} law {law} band {band}", flush=True)
+    del S, T, y, yt
     if case % 10 == 9:
         print(f"{case + 1} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
 print(f"done: {n_cases} cases, {bad} mismatches; blocks by what ran: {cover}")
