@@ -1862,6 +1862,9 @@ extern "C" int pa_plan_create(pa_ctx *c, int32_t part, int64_t n_local, int32_t 
   auto side = [&](pa_plan::side &s, int32_t n, const int32_t *nbr, const int32_t *ptrs, const int32_t *idx) -> int {
     s.nbr.assign(nbr, nbr + n);
     for (auto &q : s.nbr) q -= index_base;
+    for (int i = 0; i < n; ++i) {
+      PA_REQUIRE(s.nbr[i] >= 0, "neighbour %d is not a part id (%d with index base %d)", i + 1, s.nbr[i] + index_base, index_base);
+    }
     s.ptrs.resize(n + 1);
     for (int i = 0; i <= n; ++i) s.ptrs[i] = ptrs[i] - index_base;
     PA_REQUIRE(s.ptrs[0] == 0, "ptrs[1] must be the index base");
