@@ -7,8 +7,9 @@ from __graft_entry__ import load_package, load_oracle
 pa = load_package()
 orc = load_oracle()
 import pa_amd._lib as L
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_cases = int(args[0]) if len(args) > 0 else 100
+seed0 = int(args[1]) if len(args) > 1 else 0
 t0 = time.time()
 bad = 0
 cover = {"default_windows": 0, "default_big_windows": 0, "forced_windows": 0, "rest_chunks": 0, "padded_slots_rows_of_8k": 0, "c32_chunks": 0}
@@ -33,6 +34,9 @@ for case in range(n_cases):
     else: col = np.clip(centre + rng.integers(-band, band + 1, len(rows)), 0, n - 1)
     order = np.lexsort((col, rows))
     val = rng.standard_normal(len(rows))
+    if "--few-values" in sys.argv:                    # with PA_SPMV_VALUE_DICT=1: the lossless value dictionary (<= 64 values)
+        nv = int(rng.integers(1, 80))
+        val = rng.standard_normal(nv)[rng.integers(0, nv, len(rows))]
     val[rng.random(len(rows)) < 0.01] = -0.0
     H = pa.HostCSR(m, n, rp.astype(np.int32), (col[order] + 1).astype(np.int32), val)
     Ho = orc.CSR(m, n, H.rowptr, H.colval, H.nzval)
