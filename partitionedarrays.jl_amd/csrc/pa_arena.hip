@@ -22,6 +22,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <map>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "pa_internal.h"
@@ -219,9 +221,75 @@ static void *arena_take(pa_arena *a, size_t bytes, int cls) {
   return nullptr;
 }
 
+// ---- PA_DEBUG_GUARD: one mapping per buffer, the buffer flush with its end, nothing mapped behind it ----
+static int guard_level() {                                  // 0 off, 1 guarded mappings, 2 + every new buffer filled with 0xFF bytes
+  static int g = -1;
+  if (g < 0) { const char *e = getenv("PA_DEBUG_GUARD"); g = e ? atoi(e) : 0; }
+  return g;
+}
+static bool guard_mode() { return guard_level() >= 1; }
+struct guard_rec { void *va; size_t total, mapped; hipMemGenericAllocationHandle_t h; };
+static std::mutex g_guard_mu;
+static std::unordered_map<void *, guard_rec> g_guard_live;
+
+hipError_t pa_raw_malloc_impl(void **p, size_t bytes) {
+  if (!guard_mode()) return hipMalloc(p, bytes);
+  int dev = 0;
+  hipError_t st = hipGetDevice(&dev);
+  if (st != hipSuccess) return st;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = dev;
+  size_t gran = 0;
+  if ((st = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum)) != hipSuccess) return st;
+  if (bytes == 0) bytes = 8;
+  guard_rec r;
+  r.mapped = (bytes + gran - 1) / gran * gran;
+  r.total = r.mapped + gran;                               // the granule behind the mapping stays unmapped
+  if ((st = hipMemAddressReserve(&r.va, r.total, gran, nullptr, 0)) != hipSuccess) return st;
+  if ((st = hipMemCreate(&r.h, r.mapped, &prop, 0)) != hipSuccess) { (void)hipMemAddressFree(r.va, r.total); return st; }
+  if ((st = hipMemMap(r.va, r.mapped, 0, r.h, 0)) != hipSuccess) { (void)hipMemRelease(r.h); (void)hipMemAddressFree(r.va, r.total); return st; }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if ((st = hipMemSetAccess(r.va, r.mapped, &acc, 1)) != hipSuccess) return st;
+  if (guard_level() >= 2) {                                  // (a buffer the library forgets to initialise then reads as NaNs)
+    (void)hipMemset(r.va, 0xFF, r.mapped);
+    (void)hipDeviceSynchronize();
+  }
+  *p = (char *)r.va + (r.mapped - (bytes + 15) / 16 * 16);    // 16-byte aligned, ends within 16 bytes of the mapping's end
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  g_guard_live[*p] = r;
+  return hipSuccess;
+}
+
+hipError_t pa_raw_free(void *p) {
+  if (!p) return hipSuccess;
+  if (guard_mode()) {
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    auto it = g_guard_live.find(p);
+    if (it != g_guard_live.end()) {
+      const guard_rec r = it->second;
+      g_guard_live.erase(it);
+      (void)hipDeviceSynchronize();
+      // The mapping is NOT handed back: unmapping and re-using the physical pages gave wrong products and faults that
+      // disappear when nothing is ever unmapped (stale lines of the old owner written back over the new one's data, as far as
+      // could be told) -- an artefact of this debugging allocator, not of the library.  Guarded runs are short; they leak.
+      (void)r;
+      return hipSuccess;
+    }
+  }
+  return hipFree(p);
+}
+
 int pa_dev_alloc(pa_ctx *c, void **p, size_t bytes, int kind) {
   *p = nullptr;
   if (bytes == 0) bytes = 8;
+  if (guard_mode()) {                                      // no arena: every buffer gets its own guarded mapping
+    PA_HIP(pa_raw_malloc_impl(p, bytes));
+    return PA_OK;
+  }
   const size_t small = (size_t)1 << 20;          // below 1 MiB the class of a buffer does not matter
   size_t first_big = (size_t)256 << 20;          // the arena is built when the first allocation this large arrives
   if (const char *e = getenv("PA_ARENA_MIN_MIB")) first_big = (size_t)atol(e) << 20;
@@ -258,6 +326,7 @@ int pa_dev_alloc(pa_ctx *c, void **p, size_t bytes, int kind) {
 
 void pa_dev_free(pa_ctx *c, void *p) {
   if (!p) return;
+  if (guard_mode()) { (void)pa_raw_free(p); return; }
   pa_arena *a = c ? c->arena : nullptr;
   if (a && (char *)p >= a->base && (char *)p < a->base + a->size) {
     const size_t off = (size_t)((char *)p - a->base);

@@ -333,9 +333,10 @@ extern "C" int pa_ctx_create(int device, pa_ctx **out) {
   c->hbm = prop.totalGlobalMem;
   snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
   c->n_partials = 1024;
-  PA_HIP(hipMalloc(&c->d_partials, sizeof(double) * c->n_partials));
-  PA_HIP(hipMalloc(&c->d_scalar, sizeof(double) * PA_N_SLOTS));
-  PA_HIP(hipMemset(c->d_scalar, 0, sizeof(double) * PA_N_SLOTS));
+  PA_HIP(pa_raw_malloc(&c->d_partials, sizeof(double) * c->n_partials));
+  PA_HIP(pa_raw_malloc(&c->d_scalar, sizeof(double) * PA_N_SLOTS));
+  PA_HIP(hipMemsetAsync(c->d_scalar, 0, sizeof(double) * PA_N_SLOTS, c->s[0]));   // (on the stream the slot kernels run on: the
+  PA_HIP(hipStreamSynchronize(c->s[0]));                                            // null stream does not order with it)
   PA_HIP(hipDeviceSynchronize());  // the context's streams are non-blocking: do not race with default-stream set-up
   *out = c;
   return PA_OK;
@@ -346,8 +347,8 @@ extern "C" int pa_ctx_destroy(pa_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->s[0]);
   (void)hipStreamSynchronize(c->s[1]);
-  (void)hipFree(c->d_partials);
-  (void)hipFree(c->d_scalar);
+  (void)pa_raw_free(c->d_partials);
+  (void)pa_raw_free(c->d_scalar);
   if (c->d_dotpart) pa_dev_free(c, c->d_dotpart);
   pa_arena_destroy(c);
   (void)hipEventDestroy(c->ev_compute);
@@ -760,21 +761,22 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_crp, sizeof(int32_t) * (nc + 1), PA_MEM_MATRIX));
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_col, sizeof(int32_t) * (A->n_col32 + pad), PA_MEM_MATRIX));
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_row, sizeof(int32_t) * chunk_row.size(), PA_MEM_MATRIX));
-  PA_HIP(hipMemset(A->d_col + A->n_col32, 0, sizeof(int32_t) * pad));
-  PA_HIP(hipMemset(A->d_val + nnz, 0, sizeof(double) * pad));
-  PA_HIP(hipMemcpy(A->d_crp, crp.data(), sizeof(int32_t) * (nc + 1), hipMemcpyHostToDevice));
+  PA_HIP(hipMemsetAsync(A->d_col + A->n_col32, 0, sizeof(int32_t) * pad, c->s[0]));   // (the streams are non-blocking: a
+  PA_HIP(hipMemsetAsync(A->d_val + nnz, 0, sizeof(double) * pad, c->s[0]));            // null-stream memset would not be ordered
+  PA_HIP(hipStreamSynchronize(c->s[0]));                                               // with the kernels that read the padding)
+  PA_HIP(pa_h2d(A->d_crp, crp.data(), sizeof(int32_t) * (nc + 1)));
   if (nnz) {
-    if (cs.full) PA_HIP(hipMemcpy(A->d_col, col0, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
-    else if (A->n_col32) PA_HIP(hipMemcpy(A->d_col, cs.c32.data(), sizeof(int32_t) * A->n_col32, hipMemcpyHostToDevice));
-    PA_HIP(hipMemcpy(A->d_val, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
+    if (cs.full) PA_HIP(pa_h2d(A->d_col, col0, sizeof(int32_t) * nnz));
+    else if (A->n_col32) PA_HIP(pa_h2d(A->d_col, cs.c32.data(), sizeof(int32_t) * A->n_col32));
+    PA_HIP(pa_h2d(A->d_val, nzval, sizeof(double) * nnz));
   }
-  PA_HIP(hipMemcpy(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size(), hipMemcpyHostToDevice));
+  PA_HIP(pa_h2d(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size()));
   if (cs.use_c16) {
     A->n_col16 = (int64_t)cs.c16.size();
     PA_TRY(pa_dev_alloc(c, (void **)&A->d_col16, sizeof(uint16_t) * cs.c16.size(), PA_MEM_MATRIX));
     PA_TRY(pa_dev_alloc(c, (void **)&A->d_win, sizeof(int32_t) * std::max<size_t>(1, cs.win.size()), PA_MEM_MATRIX));
-    PA_HIP(hipMemcpy(A->d_col16, cs.c16.data(), sizeof(uint16_t) * cs.c16.size(), hipMemcpyHostToDevice));
-    if (!cs.win.empty()) PA_HIP(hipMemcpy(A->d_win, cs.win.data(), sizeof(int32_t) * cs.win.size(), hipMemcpyHostToDevice));
+    PA_HIP(pa_h2d(A->d_col16, cs.c16.data(), sizeof(uint16_t) * cs.c16.size()));
+    if (!cs.win.empty()) PA_HIP(pa_h2d(A->d_win, cs.win.data(), sizeof(int32_t) * cs.win.size()));
   }
   // Rows without a pattern whose columns stay within a band: groups of chunks read x from an LDS copy of their span
   // (pa_spmv_xwin.h).  Taken when most of the block's chunks fall into groups and the staged x is a fraction of the matrix
@@ -797,11 +799,11 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
         A->n_xw_chunks = A->n_chunks - A->n_xw_rest; A->xw_staged = staged;
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_p, sizeof(int32_t) * chunk_p.size(), PA_MEM_MATRIX));
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_xw_grp, sizeof(pa_xw_group) * groups.size(), PA_MEM_MATRIX));
-        PA_HIP(hipMemcpy(A->d_chunk_p, chunk_p.data(), sizeof(int32_t) * chunk_p.size(), hipMemcpyHostToDevice));
-        PA_HIP(hipMemcpy(A->d_xw_grp, groups.data(), sizeof(pa_xw_group) * groups.size(), hipMemcpyHostToDevice));
+        PA_HIP(pa_h2d(A->d_chunk_p, chunk_p.data(), sizeof(int32_t) * chunk_p.size()));
+        PA_HIP(pa_h2d(A->d_xw_grp, groups.data(), sizeof(pa_xw_group) * groups.size()));
         if (!rest.empty()) {
           PA_TRY(pa_dev_alloc(c, (void **)&A->d_xw_rest, sizeof(int32_t) * rest.size(), PA_MEM_MATRIX));
-          PA_HIP(hipMemcpy(A->d_xw_rest, rest.data(), sizeof(int32_t) * rest.size(), hipMemcpyHostToDevice));
+          PA_HIP(pa_h2d(A->d_xw_rest, rest.data(), sizeof(int32_t) * rest.size()));
         }
       }
       lap("x windows");
@@ -814,8 +816,8 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
     PA_TRY(pa_dev_alloc(c, (void **)&A->d_pdesc, sizeof(int32_t) * cs.pdesc.size(), PA_MEM_MATRIX));
     A->n_pdelta = (int64_t)cs.pdelta.size();
     PA_TRY(pa_dev_alloc(c, (void **)&A->d_pdelta, sizeof(int32_t) * cs.pdelta.size(), PA_MEM_MATRIX));
-    PA_HIP(hipMemcpy(A->d_pdesc, cs.pdesc.data(), sizeof(int32_t) * cs.pdesc.size(), hipMemcpyHostToDevice));
-    PA_HIP(hipMemcpy(A->d_pdelta, cs.pdelta.data(), sizeof(int32_t) * cs.pdelta.size(), hipMemcpyHostToDevice));
+    PA_HIP(pa_h2d(A->d_pdesc, cs.pdesc.data(), sizeof(int32_t) * cs.pdesc.size()));
+    PA_HIP(pa_h2d(A->d_pdelta, cs.pdelta.data(), sizeof(int32_t) * cs.pdelta.size()));
   }
   lap("descriptors");
   if (tm_) fprintf(stderr, "[pa setup] val %p (%lld B, memory class %d) col %p crp %p chunk_row %p pdesc %p\n", (void *)A->d_val,
@@ -878,8 +880,8 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
         memcpy(dv.data(), dict.data(), 8 * dict.size());
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_code, nnz + pad, PA_MEM_MATRIX));
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_dict, sizeof(double) * PA_VDICT_MAX, PA_MEM_MATRIX));
-        PA_HIP(hipMemcpy(A->d_code, code.data(), nnz + pad, hipMemcpyHostToDevice));
-        PA_HIP(hipMemcpy(A->d_dict, dv.data(), sizeof(double) * PA_VDICT_MAX, hipMemcpyHostToDevice));
+        PA_HIP(pa_h2d(A->d_code, code.data(), nnz + pad));
+        PA_HIP(pa_h2d(A->d_dict, dv.data(), sizeof(double) * PA_VDICT_MAX));
         A->use_vdict = true;
         A->n_dict = (int)dict.size();
       }
@@ -887,7 +889,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   }
   if (compact) {
     PA_TRY(pa_dev_alloc(c, (void **)&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc), PA_MEM_MATRIX));
-    if (nc) PA_HIP(hipMemcpy(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc, hipMemcpyHostToDevice));
+    if (nc) PA_HIP(pa_h2d(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc));
   }
   *out = A;
   return PA_OK;
@@ -1548,10 +1550,10 @@ extern "C" int pa_gs_create(pa_ctx *c, int64_t n_own, int64_t n_local, int64_t n
   PA_TRY(upload_i32(rp, &g->d_rowptr));
   PA_TRY(upload_i32(col, &g->d_col));
   PA_TRY(upload_i32(rows, &g->d_rows));
-  PA_HIP(hipMalloc(&g->d_val, sizeof(double) * std::max<int64_t>(1, nnz)));
-  PA_HIP(hipMalloc(&g->d_diag, sizeof(double) * std::max<int64_t>(1, n_own)));
-  if (nnz) PA_HIP(hipMemcpy(g->d_val, nzval, sizeof(double) * nnz, hipMemcpyHostToDevice));
-  if (n_own) PA_HIP(hipMemcpy(g->d_diag, diag.data(), sizeof(double) * n_own, hipMemcpyHostToDevice));
+  PA_HIP(pa_raw_malloc(&g->d_val, sizeof(double) * std::max<int64_t>(1, nnz)));
+  PA_HIP(pa_raw_malloc(&g->d_diag, sizeof(double) * std::max<int64_t>(1, n_own)));
+  if (nnz) PA_HIP(pa_h2d(g->d_val, nzval, sizeof(double) * nnz));
+  if (n_own) PA_HIP(pa_h2d(g->d_diag, diag.data(), sizeof(double) * n_own));
   *out = g;
   return PA_OK;
 }
@@ -1561,7 +1563,7 @@ extern "C" int pa_gs_destroy(pa_gs *g) {
   (void)hipSetDevice(g->ctx->device);
   (void)hipStreamSynchronize(g->ctx->s[0]);
   for (auto &e : g->graphs) (void)hipGraphExecDestroy(e.exec);
-  (void)hipFree(g->d_rowptr); (void)hipFree(g->d_col); (void)hipFree(g->d_rows); (void)hipFree(g->d_val); (void)hipFree(g->d_diag);
+  (void)pa_raw_free(g->d_rowptr); (void)pa_raw_free(g->d_col); (void)pa_raw_free(g->d_rows); (void)pa_raw_free(g->d_val); (void)pa_raw_free(g->d_diag);
   delete g;
   return PA_OK;
 }
@@ -1660,7 +1662,7 @@ extern "C" int pa_rowset_destroy(pa_rowset *r) {
   if (!r) return PA_OK;
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->s[0]);
-  (void)hipFree(r->d_rows);
+  (void)pa_raw_free(r->d_rows);
   delete r;
   return PA_OK;
 }
@@ -1695,7 +1697,7 @@ extern "C" int pa_transfer_destroy(pa_transfer *t) {
   if (!t) return PA_OK;
   (void)hipSetDevice(t->ctx->device);
   (void)hipStreamSynchronize(t->ctx->s[0]);
-  (void)hipFree(t->d_f2c);
+  (void)pa_raw_free(t->d_f2c);
   delete t;
   return PA_OK;
 }
@@ -1821,9 +1823,9 @@ extern "C" int pa_scatter_destroy(pa_scatter *s) {
   if (!s) return PA_OK;
   (void)hipSetDevice(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->s[0]);
-  (void)hipFree(s->d_tgt);
-  (void)hipFree(s->d_tptr);
-  (void)hipFree(s->d_tp);
+  (void)pa_raw_free(s->d_tgt);
+  (void)pa_raw_free(s->d_tptr);
+  (void)pa_raw_free(s->d_tp);
   delete s;
   return PA_OK;
 }
@@ -1845,8 +1847,8 @@ extern "C" int pa_scatter_add(pa_scatter *s, pa_vec *dst, const pa_vec *src, int
 // exchange plans
 // ------------------------------------------------------------------------------------------------
 static int upload_i32(const std::vector<int32_t> &h, int32_t **d) {
-  PA_HIP(hipMalloc(d, sizeof(int32_t) * std::max<size_t>(1, h.size())));
-  if (!h.empty()) PA_HIP(hipMemcpy(*d, h.data(), sizeof(int32_t) * h.size(), hipMemcpyHostToDevice));
+  PA_HIP(pa_raw_malloc(d, sizeof(int32_t) * std::max<size_t>(1, h.size())));
+  if (!h.empty()) PA_HIP(pa_h2d(*d, h.data(), sizeof(int32_t) * h.size()));
   return PA_OK;
 }
 
@@ -1883,8 +1885,9 @@ extern "C" int pa_plan_create(pa_ctx *c, int32_t part, int64_t n_local, int32_t 
   PA_HIP(hipSetDevice(c->device));
   for (pa_plan::side *s : {&p->snd, &p->rcv}) {
     PA_TRY(upload_i32(s->idx, &s->d_idx));
-    PA_HIP(hipMalloc(&s->d_buf, sizeof(double) * std::max<int64_t>(1, s->n)));
-    PA_HIP(hipMemset(s->d_buf, 0, sizeof(double) * std::max<int64_t>(1, s->n)));
+    PA_HIP(pa_raw_malloc(&s->d_buf, sizeof(double) * std::max<int64_t>(1, s->n)));
+    PA_HIP(hipMemsetAsync(s->d_buf, 0, sizeof(double) * std::max<int64_t>(1, s->n), c->s[1]));   // (the stream the pack kernel writes it on)
+    PA_HIP(hipStreamSynchronize(c->s[1]));
   }
   // inverse map of the rcv side for the deterministic assemble!(+): target lid -> its p's, ascending
   {
@@ -1918,12 +1921,12 @@ extern "C" int pa_plan_destroy(pa_plan *p) {
   (void)hipStreamSynchronize(p->ctx->s[0]);
   (void)hipStreamSynchronize(p->ctx->s[1]);
   for (pa_plan::side *s : {&p->snd, &p->rcv}) {
-    (void)hipFree(s->d_idx);
-    (void)hipFree(s->d_buf);
+    (void)pa_raw_free(s->d_idx);
+    (void)pa_raw_free(s->d_buf);
   }
-  (void)hipFree(p->d_tgt);
-  (void)hipFree(p->d_tptr);
-  (void)hipFree(p->d_tp);
+  (void)pa_raw_free(p->d_tgt);
+  (void)pa_raw_free(p->d_tptr);
+  (void)pa_raw_free(p->d_tp);
   (void)hipEventDestroy(p->ev_packed);
   (void)hipEventDestroy(p->ev_arrived);
   delete p;

@@ -62,6 +62,23 @@ struct pa_ctx {
 #define PA_MEM_VECTOR 2   /* local values of a PVector */
 int pa_dev_alloc(pa_ctx *c, void **p, size_t bytes, int kind);
 void pa_dev_free(pa_ctx *c, void *p);
+// hipMalloc / hipFree of the library's small buffers.  PA_DEBUG_GUARD=1 (a debugging aid, pa_arena.hip): EVERY device buffer
+// then ends (within 16 bytes) at the end of its own mapping with unmapped address space behind it, so that a load or store
+// past the end of a buffer faults instead of landing in a neighbour; =2 also fills every new buffer with 0xFF bytes, so that
+// a buffer the library forgets to initialise reads as NaNs.  Nothing is freed in this mode.  The fuzzers of tools/probe run
+// under it.
+hipError_t pa_raw_malloc_impl(void **p, size_t bytes);
+hipError_t pa_raw_free(void *p);
+template <class T>
+inline hipError_t pa_raw_malloc(T **p, size_t bytes) { return pa_raw_malloc_impl((void **)p, bytes); }
+// Host-to-device copy of set-up data, complete ON THE DEVICE when it returns.  The library's streams are non-blocking: nothing
+// orders a kernel on them behind a null-stream copy, and a synchronous hipMemcpy from pageable memory may return once the
+// data sits in the staging buffer -- with every new buffer poisoned (PA_DEBUG_GUARD=2) the first product after a block's
+// creation then read the poison in the tail of the value stream or in the chunk table.
+inline hipError_t pa_h2d(void *dst, const void *src, size_t bytes) {
+  hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+  return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
 int pa_mem_class(const pa_ctx *c, const void *p);    // 0..2, or -1 outside the arena
 void pa_arena_destroy(pa_ctx *c);
 

@@ -103,8 +103,9 @@ extern "C" int pa_comm_create(pa_ctx *c, const char id[PA_UNIQUE_ID_BYTES], int 
   pa_comm *m = new pa_comm();
   m->ctx = c; m->rank = rank; m->nranks = nranks;
   PA_NCCL(g_api.CommInitRank(&m->comm, nranks, u, rank));
-  PA_HIP(hipMalloc(&m->d_token, sizeof(double)));
-  PA_HIP(hipMemset(m->d_token, 0, sizeof(double)));
+  PA_HIP(pa_raw_malloc(&m->d_token, sizeof(double)));
+  PA_HIP(hipMemsetAsync(m->d_token, 0, sizeof(double), c->s[1]));
+  PA_HIP(hipStreamSynchronize(c->s[1]));
   *out = m;
   return PA_OK;
 }
@@ -115,7 +116,7 @@ extern "C" int pa_comm_destroy(pa_comm *m) {
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->s[0]);
   (void)hipStreamSynchronize(m->ctx->s[1]);
-  (void)hipFree(m->d_token);
+  (void)pa_raw_free(m->d_token);
   g_api.CommDestroy(m->comm);
   delete m;
   return PA_OK;

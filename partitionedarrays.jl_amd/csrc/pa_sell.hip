@@ -126,12 +126,12 @@ extern "C" int pa_sell_create(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_slab_ptr, sizeof(int64_t) * slab_ptr.size(), PA_MEM_MATRIX));
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_len, sizeof(int32_t) * std::max<size_t>(1, len.size()), PA_MEM_MATRIX));
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_row, sizeof(int32_t) * std::max<size_t>(1, row.size()), PA_MEM_MATRIX));
-  PA_HIP(hipMemcpy(A->d_val, val.data(), sizeof(double) * val.size(), hipMemcpyHostToDevice));
-  PA_HIP(hipMemcpy(A->d_col, col.data(), sizeof(int32_t) * col.size(), hipMemcpyHostToDevice));
-  PA_HIP(hipMemcpy(A->d_slab_ptr, slab_ptr.data(), sizeof(int64_t) * slab_ptr.size(), hipMemcpyHostToDevice));
+  PA_HIP(pa_h2d(A->d_val, val.data(), sizeof(double) * val.size()));
+  PA_HIP(pa_h2d(A->d_col, col.data(), sizeof(int32_t) * col.size()));
+  PA_HIP(pa_h2d(A->d_slab_ptr, slab_ptr.data(), sizeof(int64_t) * slab_ptr.size()));
   if (!len.empty()) {
-    PA_HIP(hipMemcpy(A->d_len, len.data(), sizeof(int32_t) * len.size(), hipMemcpyHostToDevice));
-    PA_HIP(hipMemcpy(A->d_row, row.data(), sizeof(int32_t) * row.size(), hipMemcpyHostToDevice));
+    PA_HIP(pa_h2d(A->d_len, len.data(), sizeof(int32_t) * len.size()));
+    PA_HIP(pa_h2d(A->d_row, row.data(), sizeof(int32_t) * row.size()));
   }
   *out = A;
   return PA_OK;
