@@ -65,7 +65,7 @@ void pa_dev_free(pa_ctx *c, void *p);
 // hipMalloc / hipFree of the library's small buffers.  PA_DEBUG_GUARD=1 (a debugging aid, pa_arena.hip): EVERY device buffer
 // then ends (within 16 bytes) at the end of its own mapping with unmapped address space behind it, so that a load or store
 // past the end of a buffer faults instead of landing in a neighbour; =2 also fills every new buffer with 0xFF bytes, so that
-// a buffer the library forgets to initialise reads as NaNs.  Nothing is freed in this mode.  The fuzzers of tools/probe run
+// a buffer the library forgets to initialise reads as NaNs.  Nothing is freed in this mode.  The fuzzers of tests/fuzz run
 // under it.
 hipError_t pa_raw_malloc_impl(void **p, size_t bytes);
 hipError_t pa_raw_free(void *p);

@@ -1,7 +1,7 @@
 """Corrupted inputs at the C ABI: a valid CSR block / exchange plan with ONE thing broken at random (a column out of range,
 a row pointer that decreases or overshoots, a wrong entry count, a local id outside the vector, a neighbour id that is no
 part, ptrs that do not start at 1, ...).  Every call must come back with a status < 0 and a message -- never a fault, never
-a silently accepted object whose product then reads out of bounds.  python tools/probe/fuzz_bad_inputs.py [cases] [seed0]"""
+a silently accepted object whose product then reads out of bounds.  python tests/fuzz/fuzz_bad_inputs.py [cases] [seed0]"""
 import sys, ctypes as C
 sys.path.insert(0, '.')
 import numpy as np

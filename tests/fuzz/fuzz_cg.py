@@ -1,7 +1,7 @@
 """The CG loops on random symmetric, strictly diagonally dominant PSparseMatrices (random parts, sizes, bands, row lengths):
 opt_cg_(fuse=False) must equal ref_cg_ bit for bit (history and solution), opt_cg_ (fused) within 1e-9 on the history, the
 hipGraph replay (one part) must equal the eager fused loop bit for bit, and ref_cg_ must follow the oracle's loop.
-python tools/probe/fuzz_cg.py [cases] [seed0]"""
+python tests/fuzz/fuzz_cg.py [cases] [seed0]"""
 import sys, time, functools
 sys.path.insert(0, '.')
 import numpy as np

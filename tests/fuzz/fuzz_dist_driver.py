@@ -2,7 +2,7 @@
 PSparseMatrices as in fuzz_mul.py, every rank building its own part and checking it against the sequential oracle run
 redundantly on every rank -- mul!, mul!(...,alpha,beta), the one-call product, consistent!, assemble!, dot, a few iterations of
 the CG loops.  Run:  python -m torch.distributed.run --nproc-per-node P --master-addr 127.0.0.1 --master-port N
-tools/probe/fuzz_dist_driver.py [cases] [seed0]"""
+tests/fuzz/fuzz_dist_driver.py [cases] [seed0]"""
 import os, sys, time, functools
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tools/probe/ -> repo
 sys.path.insert(0, ROOT)

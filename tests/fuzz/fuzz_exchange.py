@@ -1,6 +1,6 @@
 """Random Cartesian partitions (1-3 dimensions, random part grids, integer ghost layers, periodic directions): the index
 sets against the oracle's, then consistent!, assemble!, dot and norm on random vectors, bit for bit in LOCAL order.
-python tools/probe/fuzz_exchange.py [cases] [seed0]"""
+python tests/fuzz/fuzz_exchange.py [cases] [seed0]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np

@@ -1,6 +1,6 @@
 """The FEM route at random: laplacian_fem on random 2-D / 3-D node counts and part grids -> psparse (disassembled -> assemble),
 mul!; the same matrix kept sub-assembled, mul!(...,alpha,beta) (own and ghost rows, then assemble!(c)); psparse! with new
-values through the device re-assembly -- each against the oracle, bit for bit.  python tools/probe/fuzz_fem.py [cases] [seed0]"""
+values through the device re-assembly -- each against the oracle, bit for bit.  python tests/fuzz/fuzz_fem.py [cases] [seed0]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np

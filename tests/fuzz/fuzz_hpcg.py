@@ -1,7 +1,7 @@
 """The HPCG route at random: build_p_matrix on random local grids and part grids -> mul!, mul_no_lat!, the level-scheduled
 Gauss-Seidel sweeps (forward / backward, zero and non-zero guess) against the oracle, bit for bit; a few iterations of the
 reference CG loop against the oracle's loop; the fused residual + restriction against the separate kernels.
-python tools/probe/fuzz_hpcg.py [cases] [seed0]"""
+python tests/fuzz/fuzz_hpcg.py [cases] [seed0]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np

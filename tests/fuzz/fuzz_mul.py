@@ -1,6 +1,6 @@
 """Random PSparseMatrices on random numbers of parts (1-D block partitions, rows of random length, columns at random inside a
 band or anywhere: irregular ghost sets on every part) through mul!, mul!(...,alpha,beta), the one-call product, the transpose
-product, consistent!, assemble! and dot against the oracle, bit for bit.  python tools/probe/fuzz_mul.py [cases] [seed0]"""
+product, consistent!, assemble! and dot against the oracle, bit for bit.  python tests/fuzz/fuzz_mul.py [cases] [seed0]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np

@@ -1,7 +1,7 @@
 """Block partitions with arbitrary ghosts: variable_partition (random own sizes, EMPTY parts included) or a uniform Cartesian
 partition, each part then given random ghost ids through find_owner + union_ghost (duplicates, own ids and repeats in the
 request, as an assembly would produce them).  Index sets, assembly neighbours and local indices against the oracle, then
-consistent!, assemble!, dot on random vectors, bit for bit.  python tools/probe/fuzz_partitions.py [cases] [seed0]"""
+consistent!, assemble!, dot on random vectors, bit for bit.  python tests/fuzz/fuzz_partitions.py [cases] [seed0]"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np

@@ -1,5 +1,5 @@
 """Random blocks through every launch the library can choose (default, x windows forced, row split only, SELL) against the
-oracle's spmv_csr! / mul! loops, bit for bit.  python tools/probe/fuzz_spmv.py [cases] [seed0]"""
+oracle's spmv_csr! / mul! loops, bit for bit.  python tests/fuzz/fuzz_spmv.py [cases] [seed0]"""
 import os, sys, time
 sys.path.insert(0, '.')
 import numpy as np

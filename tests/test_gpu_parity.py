@@ -1528,7 +1528,7 @@ def test_assemble_zeroes_every_ghost_also_the_self_owned_ones(orc, np_, n, ghost
     """assemble!(a) ends with fill!(ghost_values(a),0) (src/p_vector.jl:703-705).  A periodic direction with ONE part makes
     wrap-around copies owned by the part itself: ghosts that no message carries (compute_assembly_neighbors skips owner ==
     rank, src/p_range.jl:441-445) -- they are zeroed like the others, also on a part that exchanges nothing at all.
-    (Found by tools/probe/fuzz_exchange.py in round 2: the device zeroed the ids of its send side only.)"""
+    (Found by tests/fuzz/fuzz_exchange.py in round 2: the device zeroed the ids of its send side only.)"""
     P = int(np.prod(np_))
     parts = pa.uniform_partition(ranks(P), np_, n, ghost, per)
     oparts = orc.uniform_partition(np_, n, ghost, per)
