@@ -37,6 +37,11 @@ def test_fuzzers_under_guarded_poisoned_buffers():
         assert " 0 mismatches" in out or " 0 with mismatches" in out, out[-500:]
 
 
+def test_random_call_orders_on_exchange_plans_are_refused_or_right():
+    out = _fuzz("fuzz_call_order.py", 150, 425300)
+    assert " 0 with mismatches" in out, out[-500:]
+
+
 def test_corrupted_inputs_are_rejected_with_a_status():
     out = _fuzz("fuzz_bad_inputs.py", 300, 425200)
     assert ", 0 accepted" in out, out[-800:]

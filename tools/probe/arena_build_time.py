@@ -1,6 +1,6 @@
 """What the context's arena costs to build, by size (PA_ARENA_GIB)."""
 import os, sys, time, subprocess
-if len(sys.argv) > 1:
+if len(sys.argv) == 2:
     sys.path.insert(0, '.')
     from __graft_entry__ import load_package
     pa = load_package()
@@ -10,8 +10,9 @@ if len(sys.argv) > 1:
     ctx.sync()
     print(f"PA_ARENA_GIB={os.environ.get('PA_ARENA_GIB', 'default')}: build {time.perf_counter() - t:.2f} s  -> {info['gib']:.0f} GiB, map {info['map_ms']:.0f} ms, classes {info['class_gib']}", flush=True)
 else:
-    for g in ("8", "32", "96", ""):
+    for g in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("8", "32", "96", "")):
         e = dict(os.environ)
         if g: e["PA_ARENA_GIB"] = g
         else: e.pop("PA_ARENA_GIB", None)
         subprocess.run([sys.executable, __file__, "child"], env=e)
+
