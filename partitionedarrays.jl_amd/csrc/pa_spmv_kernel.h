@@ -252,6 +252,17 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
           c1[k] = tile(c1[k]);
         }
 #endif
+#ifdef PA_PROBE_ONE_PLANE             // probe builds only, 27-point 256^3: every gather redirected into the row's own grid plane (the
+        {                             // dz = -1 / +1 entries read where the dz = 0 entries do): the same instruction count and the
+          auto flat = [&](int c) {    // same lines per plane, a third of the pages / L2 footprint per gather (wrong results)
+            const int off = c - r0;
+            const int dz = (off + 32768) >> 16;
+            return max(c - (dz << 16), 0);
+          };
+          c0[k] = flat(c0[k]);
+          c1[k] = flat(c1[k]);
+        }
+#endif
 #ifdef PA_PROBE_NO_GATHER             // probe builds only: lane-contiguous x reads in place of the pattern's columns (wrong results)
         c0[k] = min(max(c0[k], 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);
         c1[k] = min(max(c1[k], 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);
