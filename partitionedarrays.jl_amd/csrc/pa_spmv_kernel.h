@@ -3,6 +3,11 @@
 //
 // Reference loops: spmv_csr! src/sparse_utils.jl:649-669; muladd! src/p_sparse_matrix.jl:2088.
 // Must be compiled with -ffp-contract=off (one rounding per multiply and per add).
+//
+// Probe-only code, never compiled into libpa_hip.so: the EPI values 7-13 (variants of the y store) and the macros
+// PA_PROBE_IDENTITY_CHUNK_MAP, PA_PROBE_NO_GATHER, PA_PROBE_ONE_PLANE, PA_PROBE_TILE_X, PA_PROBE_LDS_X exist for the what-if
+// builds of tools/probe/Makefile (each gives WRONG results on purpose and answers one question about where the time goes;
+// the answers are in DESIGN.md sections 3, 6 and 8 and profiles/r02_*whatif*.log).
 #ifndef PA_SPMV_KERNEL_H
 #define PA_SPMV_KERNEL_H
 
