@@ -1,4 +1,5 @@
-"""One part per PROCESS (torch.distributed, the ranks share this box's GPU, exchange staged through the host): random
+"""One part per PROCESS (torch.distributed; by default the ranks share this box's GPU and the exchange is staged through the
+host, with PA_TRANSPORT=rccl every rank takes its own GPU and the exchange is csrc/pa_rccl.cpp's): random
 PSparseMatrices as in fuzz_mul.py, every rank building its own part and checking it against the sequential oracle run
 redundantly on every rank -- mul!, mul!(...,alpha,beta), the one-call product, consistent!, assemble!, dot, a few iterations of
 the CG loops.  Run:  python -m torch.distributed.run --nproc-per-node P --master-addr 127.0.0.1 --master-port N
@@ -108,6 +109,9 @@ def body(distribute):
 
 if __name__ == "__main__":
     dist.init_process_group("gloo")
+    if os.environ["PA_TRANSPORT"] == "rccl":               # one GPU per rank (LOCAL_RANK): the RCCL neighbour exchange itself
+        from pa_amd.p_vector import init_comm
+        init_comm()
     ok = pa.with_torchdist(body)
     dist.barrier()
     dist.destroy_process_group()

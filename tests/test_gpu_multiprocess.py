@@ -29,6 +29,23 @@ def test_rccl_exchange_between_distinct_gpus(nproc):
     _run("device_path_driver.py", nproc, {"PA_TRANSPORT": "rccl"})
 
 
+@pytest.mark.parametrize("nproc", [2, 4, 8])
+def test_random_matrices_over_rccl_between_distinct_gpus(nproc):
+    """tests/fuzz/fuzz_dist_driver.py with the RCCL transport: 60 random PSparseMatrices, every rank on its own GPU checking its
+    part of mul!, the alpha/beta form, consistent!, assemble!, dot and the CG loops against the sequential oracle."""
+    if _gpus() < nproc:
+        pytest.skip(f"{_gpus()} GPU(s) visible, {nproc} needed")
+    import os
+    import subprocess
+    import sys
+    from test_multiprocess_gloo import ROOT, _free_port
+    e = dict(os.environ, OMP_NUM_THREADS="1", PA_HOST_THREADS="1", PA_TRANSPORT="rccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "fuzz", "fuzz_dist_driver.py"), "60", "31000"]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 with mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def test_bench_two_gpus_over_rccl():
     """`bench.py --gpus 2` the way the driver launches it, on two GPUs: the line says RCCL and two ranks."""
     if _gpus() < 2:
