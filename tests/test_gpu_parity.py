@@ -1829,6 +1829,21 @@ def test_hpcg_mg_pcg_known_answer_on_device(orc, golden):
     assert np.allclose(hist, ho, rtol=1e-9, atol=0)
 
 
+def test_v_cycle_replayed_from_a_hipgraph_is_bit_identical():
+    """pc_setup(..., graph=True) (one part, multicolour smoother): ldiv_ records the V-cycle into a hipGraph per (x, b) pair
+    and replays it -- the same kernels in the same order, so the MG-PCG history and the solution keep every bit."""
+    outs = []
+    for graph in (False, True):
+        S = pa.pc_setup(ranks(1), 1, 3, 16, 16, 16, "multicolor_spmv", graph=graph)
+        assert S.graph == graph
+        A, b = S.A_vec[-1], S.r[-1]
+        h = []
+        x, r0, r, it = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=9, Pl=S, history=h)
+        outs.append((h, r0, r, x.own_values().items[0].copy(), len(S._graphs)))
+    assert outs[0][:3] == outs[1][:3] and np.array_equal(outs[0][3], outs[1][3])
+    assert outs[0][4] == 0 and outs[1][4] == 1
+
+
 def test_fused_colour_sweep_equals_spmv_plus_update():
     """pa_gs_color_sweep (update fused into the row-split kernel's epilogue) == pa_spmv(beta=1) into a zeroed t followed
     by pa_gs_color_update, colour by colour, bit for bit; 2 parts so that ghost columns take part."""
