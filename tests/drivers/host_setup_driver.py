@@ -122,6 +122,31 @@ def main():
             for key in ("I", "J", "V", "II", "VV"):
                 assert np.array_equal(pa.getany(S[key]), O[key][k]), key
             assert np.array_equal(pa.getany(S["dof_partition"]).own_to_global, O["dof_partition"][k].own_to_global)
+        # random block partitions with arbitrary ghosts, one part per process: find_owner / union_ghost are local, the assembly
+        # neighbours and local indices come out of point-to-point exchanges over random graphs (every rank draws the same
+        # numbers and checks its own part against the sequential oracle)
+        for seed in range(40):
+            rng = np.random.default_rng(77000 + seed)
+            n_own = [int(rng.integers(0, 25)) if rng.random() < 0.85 else 0 for _ in range(P)]
+            if sum(n_own) == 0:
+                n_own[0] = 4
+            n = sum(n_own)
+            parts = pa.variable_partition(distribute(list(n_own)), n)
+            oparts = orc.variable_partition(list(n_own), n)
+            req = [rng.integers(1, n + 1, int(rng.integers(0, 20))).astype(np.int64) for _ in range(P)]
+            owners = pa.find_owner(parts, distribute([r.copy() for r in req]))
+            oowners = orc.find_owner(oparts, [r.copy() for r in req])
+            assert np.array_equal(pa.getany(owners), oowners[k]), seed
+            parts = pa.pmap(pa.union_ghost, parts, distribute([r.copy() for r in req]), owners)
+            oparts = [orc.union_ghost(o, r, w) for o, r, w in zip(oparts, req, oowners)]
+            assert np.array_equal(pa.getany(parts).get_local_to_global(), oparts[k].local_to_global), seed
+            snd, rcv = pa.assembly_neighbors(parts)
+            osnd, orcv = orc.assembly_neighbors(oparts)
+            assert np.array_equal(pa.getany(snd), osnd[k]) and np.array_equal(pa.getany(rcv), orcv[k]), seed
+            ls, lr = pa.assembly_local_indices(parts)
+            ols, olr = orc.assembly_local_indices(oparts)
+            for mine, ref in ((pa.getany(ls), ols[k]), (pa.getany(lr), olr[k])):
+                assert np.array_equal(mine.data, ref.data) and np.array_equal(mine.ptrs, ref.ptrs), seed
         return True
 
     ok = pa.with_torchdist(body)
