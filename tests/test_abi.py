@@ -110,7 +110,13 @@ def test_committed_bench_line_follows_the_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 3e9
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_ms"] / 1e6) < 1.0
+    if "frac_algorithmic_csr" in r:      # round 3 on: `frac` is the physical (moved-bytes) fraction, never above 1
+        assert 0 < r["frac"] <= 1.0 and d["warmup_effective"] >= d["warmup"] and "cold" in d
+        assert abs(r["achieved"] - r["moved_bytes_per_launch"] / r["avg_launch_ms"] / 1e6) < 1.0
+        assert abs(r["achieved_algorithmic_csr"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_ms"] / 1e6) < 1.0
+        assert len(d["general_csr"]) == 2 and all(e["bit_identical_to_headline_product"] for e in d["general_csr"])
+    else:                                 # rounds 1-2 quoted `frac` on the reference's CSR bytes
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_ms"] / 1e6) < 1.0
     assert abs(d["value"] - 2 * d["config"]["nnz_per_part"] * d["n_gpus"] / d["ms_per_step"] / 1e6) < 0.5
 
 

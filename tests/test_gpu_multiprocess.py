@@ -82,7 +82,7 @@ def test_bench_line_of_a_multi_rank_run_carries_every_field():
     pr = d["config"]["stream_priority"]
     assert pr["comm"] == pr["greatest"] and pr["compute"] == pr["least"]
     rf = d["roofline"]
-    assert rf["moved_bytes_per_launch"] < rf["algorithmic_bytes_per_launch"] and 0 < rf["frac_moved"] and rf["median_launch_ms"] > 0
+    assert rf["moved_bytes_per_launch"] < rf["algorithmic_bytes_per_launch"] and 0 < rf["frac"] <= 1.0 and rf["median_launch_ms"] > 0
     cb = d["cpu_baseline"]
     assert cb["cores"] == 2 and cb["kind"] == "port" and cb["ms_per_mul"] > 0 and cb["c1_debugarray"]["cores"] == 1
     assert d["cg_loop"]["ms_per_iteration_opt_cg"] > 0
@@ -109,4 +109,4 @@ def test_a_rank_lost_in_an_optional_section_does_not_cost_the_line():
                       "PA_BENCH_SECTION_TIMEOUT_S": "20"}, ("--no-cpu-baseline",))
     assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
     assert d["value"] > 0 and "cg_loop" not in d and d["optional_sections_unfinished"] == ["CG loop"]
-    assert "overlap" in d and d["roofline"]["frac_moved"] > 0
+    assert "overlap" in d and 0 < d["roofline"]["frac"] <= 1.0
