@@ -78,22 +78,28 @@ int pa_ctx_device_info(pa_ctx *ctx, int *cus, int *xcds, size_t *hbm_bytes, char
  * may be NULL. */
 int pa_ctx_stream_priority(pa_ctx *ctx, int which, int *priority, int *least, int *greatest);
 
-/* ---- where the big arrays live: the context's HBM arena and its memory-class map (csrc/pa_arena.hip) ----------------
- * Measured on MI355X: device memory falls into three classes (about a third each, physically contiguous regions of
- * 2-96 GiB, boundaries differ from box to box); a product whose 64-byte write stream (y) sits in the class its read
- * stream (the values) comes from runs 13-15 % slower than with y in either other class.  So a context keeps ONE
- * physically contiguous arena (PA_ARENA_FRACTION of the free memory, default 0.70; PA_ARENA_GIB; PA_ARENA=0: none),
- * maps its classes once with a stand-in kernel (~0.2 s, when the first allocation >= PA_ARENA_MIN_MIB = 256 arrives)
- * and serves every buffer >= 1 MiB from it by rule: matrix streams (pa_csr_create*) from the class with the most
- * room, vectors (pa_vec_create) from the two others.  Nothing is timed at the caller's expense and nothing ever moves.
- * pa_ctx_arena_info: size, number of classes found (1: no structure seen), usable bytes per class, bytes in use, map time,
- * the class matrix streams go to.
- * pa_ctx_arena_map: class of every cell (-1: a boundary runs through it).  pa_ctx_arena_build forces the set-up now.
+/* ---- where the big arrays live: the context's HBM extents and their memory-class maps (csrc/pa_arena.hip) -----------
+ * Measured on MI355X: device memory falls into three classes (about a third each, physically contiguous regions of tens
+ * of GiB); a product whose 64-byte write stream (y) sits in the class its read stream (the values) comes from runs
+ * 13-15 % slower than with y in either other class.  A context therefore serves every buffer >= 1 MiB from physically
+ * contiguous EXTENTS acquired on demand (16 GiB each, PA_ARENA_EXTENT_GIB; the first when an allocation >=
+ * PA_ARENA_MIN_MIB = 256 arrives; together at most PA_ARENA_FRACTION = 0.70 of the free memory or PA_ARENA_GIB;
+ * PA_ARENA=0: none) and classified with a stand-in kernel when acquired (~20-50 ms each): matrix streams
+ * (pa_csr_create*) go to the class the first one landed in, vectors (pa_vec_create) to a class without matrix streams --
+ * found, when none is at hand, by walking over further extents that are handed back at once.  An extent nothing lives
+ * in is released.  Nothing is timed at the caller's expense, nothing ever moves, any failure falls back to hipMalloc.
+ * pa_ctx_arena_info: bytes held, classes met (<= 3), bytes per class in the held extents, bytes in use, time spent
+ * acquiring + classifying, the class matrix streams go to (-1: none yet).
+ * pa_ctx_arena_map: class of every 512 MiB cell, extent after extent (-1: a boundary runs through it, -2: between two
+ * extents).  pa_ctx_arena_stats: extents held, bytes acquired / released so far, peak bytes in use, vectors whose
+ * (matrix stream, vector) pair passed / failed the self-check, the budget.  pa_ctx_arena_build acquires a first extent now.
  * pa_csr_memory_class / pa_vec_memory_class: class of a block's value stream / a vector's storage (-1: outside). */
 int pa_ctx_arena_build(pa_ctx *ctx);
 int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class_bytes[3], int64_t *used, double *map_ms,
                       int *matrix_class);
 int pa_ctx_arena_map(pa_ctx *ctx, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells);
+int pa_ctx_arena_stats(pa_ctx *ctx, int64_t *n_extents, int64_t *bytes_acquired, int64_t *bytes_released, int64_t *peak_used,
+                       int64_t *pairs_ok, int64_t *pairs_failed, int64_t *budget);
 int pa_csr_memory_class(const pa_csr *A, int *cls);
 int pa_vec_memory_class(const pa_vec *v, int *cls);
 
@@ -113,7 +119,8 @@ int pa_vec_upload(pa_vec *v, const double *host, int64_t offset, int64_t len);  
 int pa_vec_download(const pa_vec *v, double *host, int64_t offset, int64_t len);
 int pa_vec_fill(pa_vec *v, int segment, double value);                  /* fill!(…_values(v), value) */
 int pa_vec_copy(pa_vec *dst, const pa_vec *src, int segment);           /* copy!  */
-/* own-values BLAS-1 (src/p_vector.jl:1189-1206, broadcast :1216-1277): y = a*x + b*y on a segment */
+/* own-values BLAS-1 (src/p_vector.jl:1189-1206, broadcast :1216-1277): y = a*x + b*y on a segment, the multiply and the
+ * add rounded separately.  b == 0 is the assignment y = a*x: y is not read (what `dest .= a .* v` does); x may be y. */
 int pa_vec_axpby(pa_vec *y, double a, const pa_vec *x, double b, int segment);
 /* local dot over OWN values (the per-part term of dot(a,b), src/p_vector.jl:1190); deterministic
  * two-pass reduction; result left in a device scalar (pa_vec_dot_result) and, if host_out != NULL,

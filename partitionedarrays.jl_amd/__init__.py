@@ -21,6 +21,6 @@ from .p_sparse_matrix import (HostCSR, DeviceCSR, DeviceSELL, SplitMatrixBlocks,
                               psparse_disassembled, psparse_assemble_host, psparse_, MatrixReassemblyCache,
                               mul5_transpose_, psystem, psystem_)
 from .gallery import laplacian_fem, laplacian_fdm, build_matrix, build_p_matrix, build_split_blocks_fused, compute_optimal_shape_XYZ  # noqa: F401
-from .hpcg import (CgTimer, ref_cg_, opt_cg_, cg_work, mul_no_lat_, mul_no_lat_unsplit_, restrict_operator, GaussSeidel, ColoredGaussSeidelSpMV, MgPreconditioner, pc_setup, pc_solve_,  # noqa: F401
+from .hpcg import (CgTimer, ref_cg_, opt_cg_, hpcg_benchmark, cg_work, mul_no_lat_, mul_no_lat_unsplit_, restrict_operator, GaussSeidel, ColoredGaussSeidelSpMV, MgPreconditioner, pc_setup, pc_solve_,  # noqa: F401
                    ldiv_)
 from . import fem_example  # noqa: F401,E402

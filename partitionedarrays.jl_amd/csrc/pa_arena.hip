@@ -1,20 +1,28 @@
-// pa_arena.hip -- where the big arrays of a context live in the 288 GB of HBM3E: one physically contiguous arena with a
-// measured map of its memory classes, and the rule "a product's write stream never shares a class with its read stream".
+// pa_arena.hip -- where the big arrays of a context live in the 288 GB of HBM3E: physically contiguous extents acquired ON
+// DEMAND, each with a measured map of its memory classes, and the rule "a product's write stream never shares a class
+// with its read stream".
 //
-// What was measured on MI355X (tools/probe/ystore_probe.hip, gpurun_out of round 2): device memory
-// falls into THREE classes of about a third each, laid out in physically contiguous regions of 2 ... 96 GiB whose
-// boundaries differ from box to box.  A kernel that streams reads from one class while it writes 64-byte lines into the
-// SAME class loses 13-15 % (27-point 256^3 product: 0.765 ms against 0.670 ms; the kernel without its store: 0.63 ms);
-// with the write stream in either of the other two classes the penalty is gone, wherever x lives.  A plain hipMalloc
-// of a few GB may straddle classes (then no place for y is fast), so the value stream must be ONE contiguous piece of one
+// What was measured on MI355X (tools/probe/ystore_probe.hip, extent_probe.hip): device memory falls into THREE
+// classes of about a third each, laid out in physically contiguous regions of tens of GiB.  A kernel that streams reads
+// from one class while it writes 64-byte lines into the SAME class loses 13-15 % (27-point 256^3 product: 0.765 ms
+// against 0.670 ms; without its store 0.63 ms); with the write stream in either other class the penalty is gone, wherever
+// x lives.  A plain hipMalloc of a few GB may straddle classes, so the value stream must be ONE contiguous piece of one
 // class.  Neither virtual addresses nor allocation order predict the class; a 40 us stand-in kernel does (a 1 : 27
-// write : read stream pair, the product's ratio) -- so the context maps its arena once (~0.2 s, at the first allocation
-// of 256 MiB or more) and then places by rule, with no timing of the caller's kernels and no moving of vectors:
-//     matrix streams (values, columns, row pointers, descriptors)  -> the class with the most room in the arena
-//     vectors                                                        -> the two other classes, alternating
-// A request that no run of its preferred classes holds takes another class (matrix streams the one with fewer vectors,
-// vectors the one with fewer matrix streams), then plain hipMalloc.  Classes are numbered in the order the map meets them.
-// Replaces round 1's pa_csr_tune_placement (a search over hipMalloc'ed copies that found a fast pair on two boxes of three).
+// write : read stream pair, the product's ratio).
+//
+// Round 3: the single grab of 70 % of the free memory (7 s, hostile to anything else on the
+// device) is gone.  The arena is a list of EXTENTS (16 GiB by default, PA_ARENA_EXTENT_GIB; a bigger request gets an extent
+// of its own), each acquired when a class runs out of room and classified at once against the reference cell of every
+// class met so far.  Placement by rule, no timing of the caller's kernels, nothing ever moves:
+//     matrix streams (values, columns, row pointers, descriptors) -> the class the first one landed in
+//     vectors                                                      -> a class that holds no matrix stream
+// When no such class is at hand the arena WALKS: it acquires extents one after the other until one shows another class,
+// keeps that one and hands the ones it walked over back to the driver at once (transient; bounded by PA_ARENA_WALK_GIB =
+// 160 and by the budget PA_ARENA_FRACTION = 0.70 of the free memory / PA_ARENA_GIB).  An extent nothing lives in any more
+// is released.  Every big vector handed out is checked once against the newest matrix stream with the same stand-in
+// kernel (~1.5 ms, PA_ARENA_SELFCHECK=0 disables): a pair that times as "same class" although the map says otherwise is
+// moved to the other clean class or reported.  All of it under the context's mutex; any failure (no contiguous memory, a
+// probe error) freezes growth and falls back to hipMalloc -- never an error of the caller's allocation.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -47,24 +55,44 @@ __global__ __launch_bounds__(256) void k_class_probe(const pa_d2 *__restrict__ r
   else if (s == 123.456) wr[(size_t)blk * 56] = s;       // keeps every lane's loads alive
 }
 
-struct pa_arena {
+// One physically contiguous piece of the arena, acquired on demand and classified when acquired.
+struct pa_extent {
   char *base = nullptr;
-  size_t size = 0, cell = 0;
-  std::vector<int8_t> cls;                 // per cell: 0, 1, 2, or -1 (a class boundary runs through it: not handed out)
-  int n_classes = 1;
-  double map_ms = 0;
-  size_t class_bytes[3] = {0, 0, 0};       // usable bytes by class
-  struct blk { size_t len; int cls; };
-  std::map<size_t, blk> free_;             // offset -> free block (never spans a class change)
-  std::map<size_t, blk> live_;             // offset -> allocated block
-  std::map<size_t, int> live_kind_;        // offset -> PA_MEM_MATRIX / PA_MEM_VECTOR
+  size_t size = 0;
+  std::vector<int8_t> cls;                 // per cell: global class 0..2, or -1 (a boundary runs through it / not told: not handed out)
+  size_t live = 0;                         // bytes handed out from it (a class's scratch counts)
+};
+
+struct pa_arena {
+  size_t cell = (size_t)512 << 20;
+  std::vector<pa_extent *> ext;
+  int n_classes = 0;                       // global classes met so far (<= 3), numbered in the order they were met
+  const char *ref[3] = {nullptr, nullptr, nullptr};   // a cell wholly inside class k: the read stream of a classification pass
+  char *scr[3] = {nullptr, nullptr, nullptr};         // the tail of that cell, never handed out: a write stream KNOWN to be in class k
+  double map_ms = 0;                       // time spent acquiring and classifying, so far
+  size_t budget = 0;                       // bytes the extents together may hold
+  size_t held = 0, acquired = 0, released = 0;
+  int n_acquired = 0, n_released = 0;
+  bool frozen = false;                     // an acquisition or a classification failed: no more growth (what exists keeps serving)
+  struct blk { size_t len; int cls; int kind; pa_extent *e; };
+  std::map<uintptr_t, blk> free_;          // address -> free block (never spans a class change or two extents)
+  std::map<uintptr_t, blk> live_;          // address -> allocated block
   size_t used = 0, peak = 0;
-  int matrix_class = 0;                    // the class with the most room: where matrix streams go
+  int matrix_class = -1;                   // where matrix streams go: the class the first one landed in
   size_t mat_bytes[3] = {0, 0, 0}, vec_bytes[3] = {0, 0, 0};   // what lives where (by kind)
-  unsigned vec_turn = 0;                   // vectors alternate between the two other classes while both are free of matrix streams
+  unsigned vec_turn = 0;
+  const char *last_matrix = nullptr;       // the newest big matrix stream: the read stream of the pair self-check
+  size_t last_matrix_len = 0;
+  int last_matrix_cls = -1;
+  long check_ok = 0, check_failed = 0;     // vectors whose (matrix stream, vector) pair timed as "different classes" / "same class"
+  bool warned = false;
 };
 
 static constexpr size_t ARENA_ALIGN = (size_t)256 << 10;
+static constexpr size_t GIB = (size_t)1 << 30;
+
+static int probe_nb(size_t rd_bytes) { return (int)(rd_bytes / 12288); }
+static size_t probe_wr_bytes(int nb) { return ((size_t)nb * 56 * 8 + 4095) / 4096 * 4096; }
 
 static int probe_ms(pa_ctx *c, hipEvent_t e0, hipEvent_t e1, const char *rd, char *wr, int nb, float *ms) {
   const int per_xcd = (nb + 7) / 8;
@@ -80,145 +108,368 @@ static int probe_ms(pa_ctx *c, hipEvent_t e0, hipEvent_t e1, const char *rd, cha
   return PA_OK;
 }
 
-// One pass: the read stream sits at `rd`, the write stream at the END of every cell listed in `cells`.  slow[c] = the end
-// of cell c is in the read stream's class.  Returns false when the times do not separate (one class, or no signal).
-static int class_pass(pa_ctx *c, pa_arena *a, hipEvent_t e0, hipEvent_t e1, const char *rd, int nb, size_t wr_bytes,
-                      const std::vector<int> &cells, std::vector<char> &slow, bool *separated) {
+struct probe_events {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int make() {
+    PA_HIP(hipEventCreate(&e0));
+    PA_HIP(hipEventCreate(&e1));
+    return PA_OK;
+  }
+  ~probe_events() {
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+  }
+};
+
+// One pass over the cell ENDS listed in `cells` of extent X: the read stream sits at `rd`; `slow_ctl` is a write position
+// known to lie in rd's class, `fast_ctl` (or NULL) one known to lie in another.  same[c] = the end of cell c is in rd's
+// class.  The two clusters are ~11 % apart (0.182 / 0.164 ms); the controls, measured before and after the pass, fix the
+// threshold -- a pass over cells that are ALL in one class (nothing separates) is decided by them too.
+static int class_pass(pa_ctx *c, pa_arena *a, probe_events &ev, const pa_extent *X, const char *rd, char *slow_ctl, char *fast_ctl,
+                      const std::vector<int> &cells, std::vector<char> &same) {
+  const int nb = probe_nb(a->cell);
+  const size_t wr_bytes = probe_wr_bytes(nb);
+  auto wr_of = [&](int cell) { return X->base + (size_t)(cell + 1) * a->cell - wr_bytes; };
+  float s0 = 0, s1 = 0, f0 = 0, f1 = 0, warm = 0;
+  for (int k = 0; k < 4; ++k) PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, slow_ctl, nb, &warm));     // (working clocks)
+  PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, slow_ctl, nb, &s0));
+  if (fast_ctl) PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, fast_ctl, nb, &f0));
   std::vector<float> t(cells.size());
-  for (size_t i = 0; i < cells.size(); ++i)
-    PA_TRY(probe_ms(c, e0, e1, rd, a->base + (size_t)(cells[i] + 1) * a->cell - wr_bytes, nb, &t[i]));
-  // Two clusters about 11 % apart (other class / same class) are what the hardware gives; anything far above that is the
-  // same-class case plus interference from whoever else uses the device, so the slow end is capped at 1.3 x the fastest.
-  float mn = 1e30f, mx = 0;
-  for (float v : t) { mn = std::min(mn, v); mx = std::max(mx, v); }
-  mx = std::min(mx, 1.3f * mn);
-  *separated = !cells.empty() && mx > 1.06f * mn;
-  if (!*separated) return PA_OK;
-  const float thr = 0.5f * (mn + mx);
+  for (size_t i = 0; i < cells.size(); ++i) PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, wr_of(cells[i]), nb, &t[i]));
+  PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, slow_ctl, nb, &s1));
+  if (fast_ctl) PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, fast_ctl, nb, &f1));
+  const float slow = 0.5f * (s0 + s1);
+  float fast = fast_ctl ? 0.5f * (f0 + f1) : 0.9f * slow;
+  if (fast > 0.96f * slow) fast = 0.9f * slow;          // (the "fast" control did not separate: fall back on the known ratio)
+  const float thr = 0.5f * (slow + fast);
   for (size_t i = 0; i < cells.size(); ++i) {
     float v = t[i];
-    for (int again = 0; again < 2 && v > 0.97f * thr && v < 1.03f * thr; ++again) {     // too close to call: measure again
+    for (int again = 0; again < 2 && v > 0.98f * thr && v < 1.02f * thr; ++again) {       // too close to call: measure again
       float w = 0;
-      PA_TRY(probe_ms(c, e0, e1, rd, a->base + (size_t)(cells[i] + 1) * a->cell - wr_bytes, nb, &w));
+      PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, wr_of(cells[i]), nb, &w));
       v = 0.5f * (v + w);
     }
-    slow[cells[i]] = v > thr;
+    same[cells[i]] = v > thr;
   }
   return PA_OK;
 }
 
-static int arena_build(pa_ctx *c) {
-  if (c->capturing) return PA_OK;             // (not now: mapping the classes launches and synchronises; the next request tries again)
+static void arena_add_free(pa_arena *a, pa_extent *X, size_t off, size_t len, int cls) {
+  if (len) a->free_[(uintptr_t)(X->base + off)] = {len, cls, 0, X};
+}
+
+// Classes of a freshly acquired extent (nothing of it is handed out yet, so the passes may write into it): first against
+// the reference cell of every class met so far; what matches none is a class not met before -- a cell of it becomes that
+// class's reference, its tail the class's scratch.  A cell whose two ends disagree is not handed out.
+static int classify_extent(pa_ctx *c, pa_arena *a, pa_extent *X) {
+  probe_events ev;
+  PA_TRY(ev.make());
+  const int ncell = (int)(X->size / a->cell);
+  const int nb = probe_nb(a->cell);
+  const size_t wr_bytes = probe_wr_bytes(nb);
+  const size_t scr_bytes = (wr_bytes + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
+  std::vector<int> endc(ncell, -2);                     // class at the END of each cell; -2: not told yet
+  auto unknown = [&]() {
+    std::vector<int> u;
+    for (int i = 0; i < ncell; ++i) if (endc[i] == -2) u.push_back(i);
+    return u;
+  };
+  for (int k = 0; k < a->n_classes; ++k) {
+    std::vector<int> u = unknown();
+    if (u.empty()) break;
+    std::vector<char> same(ncell, 0);
+    char *fast_ctl = nullptr;
+    for (int j = 0; j < a->n_classes; ++j) if (j != k) { fast_ctl = a->scr[j]; break; }
+    PA_TRY(class_pass(c, a, ev, X, a->ref[k], a->scr[k], fast_ctl, u, same));
+    for (int i : u) if (same[i]) endc[i] = k;
+  }
+  int ref_cell[3] = {-1, -1, -1};
+  for (int from = 1; a->n_classes < 3;) {
+    // a cell whose both ends are still untold lies wholly in a class not met yet (one boundary per cell at most)
+    int r = -1;
+    for (int i = from; i < ncell; ++i) if (endc[i - 1] == -2 && endc[i] == -2) { r = i; break; }
+    if (r < 0) break;
+    std::vector<int> u = unknown();
+    std::vector<char> same(ncell, 0);
+    char *own_tail = X->base + (size_t)(r + 1) * a->cell - wr_bytes;
+    PA_TRY(class_pass(c, a, ev, X, X->base + (size_t)r * a->cell, own_tail, a->n_classes ? a->scr[0] : nullptr, u, same));
+    if (!(same[r - 1] && same[r])) { from = r + 1; continue; }     // (the cell straddles something after all: try the next one)
+    const int k = a->n_classes++;
+    for (int i : u) if (same[i]) endc[i] = k;
+    a->ref[k] = X->base + (size_t)r * a->cell;
+    a->scr[k] = X->base + (size_t)(r + 1) * a->cell - scr_bytes;
+    ref_cell[k] = r;
+    from = 1;
+  }
+  X->cls.assign(ncell, -1);
+  for (int i = 0; i < ncell; ++i) {
+    const int e = endc[i] < 0 ? -1 : endc[i];
+    X->cls[i] = (int8_t)((i == 0 || endc[i - 1] == endc[i]) ? e : -1);
+  }
+  // free runs of one class; the scratch at the tail of a reference cell stays out (it counts as live: the extent is kept)
+  for (int i = 0; i < ncell;) {
+    int j = i;
+    while (j < ncell && X->cls[j] == X->cls[i]) ++j;
+    if (X->cls[i] >= 0) {
+      size_t lo = (size_t)i * a->cell;
+      const size_t hi = (size_t)j * a->cell;
+      for (int k = 0; k < 3; ++k)
+        if (ref_cell[k] >= i && ref_cell[k] < j) {
+          const size_t s0 = (size_t)(ref_cell[k] + 1) * a->cell - scr_bytes;
+          arena_add_free(a, X, lo, s0 - lo, X->cls[i]);
+          lo = s0 + scr_bytes;
+          X->live += scr_bytes;
+        }
+      arena_add_free(a, X, lo, hi - lo, X->cls[i]);
+    }
+    i = j;
+  }
+  return PA_OK;
+}
+
+static void arena_log_extent(const pa_arena *a, const pa_extent *X, const char *why, double ms) {
+  if (!getenv("PA_SETUP_TIMING")) return;
+  fprintf(stderr, "[pa arena] +%.1f GiB contiguous at %p (%s), %.1f ms, %d classes known, holding %.1f GiB in %zu extents: ", X->size / (double)GIB,
+          (void *)X->base, why, ms, a->n_classes, a->held / (double)GIB, a->ext.size());
+  for (int8_t v : X->cls) fputc(v < 0 ? '.' : (char)('0' + v), stderr);
+  fputc('\n', stderr);
+}
+
+// Acquire and classify one extent of `bytes` (a multiple of the cell).  NULL (and the arena frozen) when the driver has no
+// contiguous memory left or a probe failed: the callers fall back to hipMalloc.
+static pa_extent *arena_acquire(pa_ctx *c, pa_arena *a, size_t bytes, const char *why) {
+  if (a->frozen || c->capturing) return nullptr;       // (classifying launches and synchronises: not inside a capture)
+  bytes = (bytes + a->cell - 1) / a->cell * a->cell;
+  if (a->held + bytes > a->budget) return nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  char *base = nullptr;
+  if (hipExtMallocWithFlags((void **)&base, bytes, hipDeviceMallocContiguous) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  pa_extent *X = new pa_extent();
+  X->base = base; X->size = bytes;
+  const int nc0 = a->n_classes;
+  const char *ref0[3] = {a->ref[0], a->ref[1], a->ref[2]};
+  char *scr0[3] = {a->scr[0], a->scr[1], a->scr[2]};
+  if (classify_extent(c, a, X) != PA_OK) {             // leave the arena as it was and stop growing
+    for (auto it = a->free_.begin(); it != a->free_.end();) it = it->second.e == X ? a->free_.erase(it) : std::next(it);
+    a->n_classes = nc0;
+    for (int k = 0; k < 3; ++k) { a->ref[k] = ref0[k]; a->scr[k] = scr0[k]; }
+    (void)hipGetLastError();
+    (void)hipFree(base);
+    delete X;
+    a->frozen = true;
+    if (getenv("PA_SETUP_TIMING")) fprintf(stderr, "[pa arena] classification failed (%s): no more growth, hipMalloc from here on\n", pa_last_error());
+    return nullptr;
+  }
+  a->ext.push_back(X);
+  a->held += bytes; a->acquired += bytes; a->n_acquired++;
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  a->map_ms += ms;
+  arena_log_extent(a, X, why, ms);
+  return X;
+}
+
+static void arena_release(pa_arena *a, pa_extent *X) {
+  for (auto it = a->free_.begin(); it != a->free_.end();) it = it->second.e == X ? a->free_.erase(it) : std::next(it);
+  a->ext.erase(std::find(a->ext.begin(), a->ext.end(), X));
+  a->held -= X->size; a->released += X->size; a->n_released++;
+  (void)hipFree(X->base);
+  if (getenv("PA_SETUP_TIMING")) fprintf(stderr, "[pa arena] -%.1f GiB at %p released, holding %.1f GiB\n", X->size / (double)GIB, (void *)X->base, a->held / (double)GIB);
+  delete X;
+}
+
+static int arena_init(pa_ctx *c) {
   c->arena_tried = true;
   const char *on = getenv("PA_ARENA");
   if (on && atoi(on) == 0) return PA_OK;
   PA_HIP(hipSetDevice(c->device));
-  const size_t G = (size_t)1 << 30;
   size_t fr = 0, tot = 0;
   PA_HIP(hipMemGetInfo(&fr, &tot));
   double frac = 0.70;
   if (const char *e = getenv("PA_ARENA_FRACTION")) frac = std::min(0.95, std::max(0.05, atof(e)));
-  size_t want = (size_t)(frac * (double)fr);
-  if (const char *e = getenv("PA_ARENA_GIB")) want = std::min<size_t>((size_t)atol(e) * G, (size_t)(0.95 * (double)fr));
-  const size_t cell = (size_t)512 << 20;
-  want = want / cell * cell;
-  hipEvent_t e0, e1;
-  PA_HIP(hipEventCreate(&e0));
-  PA_HIP(hipEventCreate(&e1));
-  char *base = nullptr;
-  while (want >= 8 * G) {       // physically contiguous: positions inside it are physical offsets, classes are regions
-    if (hipExtMallocWithFlags((void **)&base, want, hipDeviceMallocContiguous) == hipSuccess) break;
-    (void)hipGetLastError();
-    base = nullptr;
-    want = (want * 3 / 4) / cell * cell;
-  }
-  if (!base) {                  // no arena: every request falls through to hipMalloc
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return PA_OK;
-  }
   pa_arena *a = new pa_arena();
-  a->base = base; a->size = want; a->cell = cell;
-  const int ncell = (int)(want / cell);
-  a->cls.assign(ncell, 0);
-  const auto t0 = std::chrono::steady_clock::now();
-  const size_t rd_bytes = cell;                               // (twice the Infinity Cache: the stream comes from HBM)
-  const int nb = (int)(rd_bytes / 12288);
-  const size_t wr_bytes = ((size_t)nb * 56 * 8 + 4095) / 4096 * 4096;
-  // end[c] = class at the end of cell c.  Pass 0: read stream in cell 0.
-  std::vector<int> endc(ncell, 0), all(ncell);
-  for (int i = 0; i < ncell; ++i) all[i] = i;
-  std::vector<char> slow0(ncell, 1), slow1(ncell, 0);
-  bool sep0 = false, sep1 = false;
-  int st = class_pass(c, a, e0, e1, base, nb, wr_bytes, all, slow0, &sep0);
-  if (st == PA_OK && sep0) {
-    // Pass 1: read stream in the first cell whose both ends are outside class 0; splits the rest into classes 1 and 2
-    std::vector<int> rest;
-    for (int i = 0; i < ncell; ++i) if (!slow0[i]) rest.push_back(i);
-    for (int tries = 0, from = 1; tries < 3 && st == PA_OK && !sep1; ++tries) {
-      int ref = -1;
-      for (int i = from; i < ncell; ++i) if (!slow0[i - 1] && !slow0[i]) { ref = i; break; }
-      if (ref < 0) break;
-      std::fill(slow1.begin(), slow1.end(), 0);
-      bool sep = false;
-      st = class_pass(c, a, e0, e1, base + (size_t)ref * cell, nb, wr_bytes, rest, slow1, &sep);
-      if (st != PA_OK) break;
-      if (!sep) {                                     // nothing stands out against the reference: the rest is ONE class
-        for (int i : rest) slow1[i] = 1;
-        sep1 = true;
-      } else if (slow1[ref - 1] && slow1[ref]) {      // (the reference cell itself must come out as "same class")
-        sep1 = true;
-      } else {
-        from = ref + 1;
-      }
-    }
-    if (!sep1) for (int i : rest) slow1[i] = 1;
-    sep1 = true;
-    for (int i = 0; i < ncell; ++i) endc[i] = slow0[i] ? 0 : (sep1 ? (slow1[i] ? 1 : 2) : 1);
-    a->n_classes = 1 + (rest.empty() ? 0 : 1);
-    for (int i : rest) if (endc[i] == 2) { a->n_classes = 3; break; }
-  }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  if (st != PA_OK) { (void)hipFree(base); delete a; return st; }
-  // a cell is handed out when both of its ends are in one class
-  for (int i = 0; i < ncell; ++i) a->cls[i] = (int8_t)((i == 0 ? endc[0] : endc[i - 1]) == endc[i] ? endc[i] : -1);
-  if (endc[0] != 0) a->cls[0] = -1;
-  for (int i = 0; i < ncell;) {
-    int j = i;
-    while (j < ncell && a->cls[j] == a->cls[i]) ++j;
-    if (a->cls[i] >= 0) {
-      a->free_[(size_t)i * cell] = {(size_t)(j - i) * cell, a->cls[i]};
-      a->class_bytes[a->cls[i]] += (size_t)(j - i) * cell;
-    }
-    i = j;
-  }
-  for (int k = 1; k < 3; ++k)
-    if (a->class_bytes[k] > a->class_bytes[a->matrix_class]) a->matrix_class = k;
-  a->map_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  a->budget = (size_t)(frac * (double)fr);
+  if (const char *e = getenv("PA_ARENA_GIB")) a->budget = std::min<size_t>((size_t)atol(e) * GIB, (size_t)(0.95 * (double)fr));
   c->arena = a;
-  if (getenv("PA_SETUP_TIMING")) {
-    fprintf(stderr, "[pa arena] %.1f GiB contiguous at %p, %d classes (%.1f / %.1f / %.1f GiB usable), mapped in %.1f ms:", want / (double)G,
-            (void *)base, a->n_classes, a->class_bytes[0] / (double)G, a->class_bytes[1] / (double)G, a->class_bytes[2] / (double)G, a->map_ms);
-    for (int i = 0; i < ncell; ++i) fputc(a->cls[i] < 0 ? '.' : (char)('0' + a->cls[i]), stderr);
-    fputc('\n', stderr);
-  }
   return PA_OK;
 }
 
-static void *arena_take(pa_arena *a, size_t bytes, int cls) {
+static size_t extent_bytes(const pa_arena *a, size_t request) {
+  size_t e = (size_t)16 * GIB;
+  if (const char *s = getenv("PA_ARENA_EXTENT_GIB")) e = std::max<size_t>(1, (size_t)atol(s)) * GIB;
+  // a request that does not fit an extent of the usual size gets one of its own: the buffer + a cell at either end (a
+  // boundary cell is not handed out)
+  const size_t need = (request + a->cell - 1) / a->cell * a->cell + 2 * a->cell;
+  return std::max(e, need);
+}
+
+static void *arena_take(pa_arena *a, size_t bytes, int cls, int kind) {
   bytes = (bytes + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
   for (auto it = a->free_.begin(); it != a->free_.end(); ++it) {
     if (it->second.cls != cls || it->second.len < bytes) continue;
-    const size_t off = it->first, len = it->second.len;
+    const uintptr_t at = it->first;
+    const pa_arena::blk b = it->second;
     a->free_.erase(it);
-    if (len > bytes) a->free_[off + bytes] = {len - bytes, cls};
-    a->live_[off] = {bytes, cls};
+    if (b.len > bytes) a->free_[at + bytes] = {b.len - bytes, cls, 0, b.e};
+    a->live_[at] = {bytes, cls, kind, b.e};
+    b.e->live += bytes;
     a->used += bytes;
     a->peak = std::max(a->peak, a->used);
-    return a->base + off;
+    (kind == PA_MEM_MATRIX ? a->mat_bytes : a->vec_bytes)[cls] += bytes;
+    return (void *)at;
   }
   return nullptr;
+}
+
+static bool class_has_room(const pa_arena *a, size_t bytes, int cls) {
+  bytes = (bytes + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
+  for (auto &kv : a->free_) if (kv.second.cls == cls && kv.second.len >= bytes) return true;
+  return false;
+}
+
+static void arena_give_back(pa_arena *a, void *p);
+
+// Does the pair (newest big matrix stream, this vector) time as "different classes"?  One control (the matrix stream against
+// its own class's scratch) before and after, the pair in between: ~1.5 ms.  The map was measured cell by cell when the
+// extents were acquired; this checks the one thing it is FOR, on the buffers actually handed out.
+static int pair_check(pa_ctx *c, pa_arena *a, char *vec, size_t vec_bytes, bool *same) {
+  probe_events ev;
+  PA_TRY(ev.make());
+  const int nb = std::min(probe_nb(std::min(a->last_matrix_len, a->cell)), (int)(vec_bytes / 448));
+  float s0 = 0, s1 = 0, t = 0;
+  char *ctl = a->scr[a->last_matrix_cls];
+  PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, ctl, nb, &s0));
+  PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, ctl, nb, &s0));
+  PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, vec, nb, &t));
+  PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, ctl, nb, &s1));
+  *same = t > 0.96f * 0.5f * (s0 + s1);
+  return PA_OK;
+}
+
+static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
+  void *p = nullptr;
+  if (kind == PA_MEM_MATRIX) {
+    // Matrix streams stay in ONE class (the one the first landed in) as long as the device has memory of that class; a
+    // new extent comes before a spill into a class that holds vectors.
+    if (a->matrix_class >= 0 && (p = arena_take(a, bytes, a->matrix_class, kind))) return p;
+    if (a->matrix_class < 0)
+      for (int k = 0; k < a->n_classes && !p; ++k) if (a->vec_bytes[k] == 0) p = arena_take(a, bytes, k, kind);
+    if (!p) {
+      if (pa_extent *X = arena_acquire(c, a, extent_bytes(a, bytes), "matrix streams")) {
+        (void)X;
+        if (a->matrix_class >= 0) p = arena_take(a, bytes, a->matrix_class, kind);
+        for (int k = 0; k < a->n_classes && !p; ++k) if (a->vec_bytes[k] == 0) p = arena_take(a, bytes, k, kind);
+      }
+    }
+    if (!p) {                                           // spill: the class with the fewest vector bytes first
+      int order[3] = {0, 1, 2};
+      std::sort(order, order + 3, [&](int x, int y) { return a->vec_bytes[x] < a->vec_bytes[y]; });
+      for (int k = 0; k < 3 && !p; ++k) if (order[k] < a->n_classes) p = arena_take(a, bytes, order[k], kind);
+    }
+    if (p) {
+      const int cls = a->live_[(uintptr_t)p].cls;
+      if (a->matrix_class < 0) a->matrix_class = cls;
+      if (bytes >= a->last_matrix_len || bytes >= a->cell) { a->last_matrix = (const char *)p; a->last_matrix_len = bytes; a->last_matrix_cls = cls; }
+    }
+    return p;
+  }
+  // Vectors: a class that holds no matrix stream -- alternating while there are two of those (BLAS-1 kernels, too, run
+  // 3-6 % faster when what they write is not where they read).  When there is none, the arena WALKS: extents are acquired
+  // one after the other (the driver hands out physical memory in order, and a class is a region of tens of GiB) until one
+  // shows a class without matrix streams; the extents walked over are handed back at once.
+  auto try_clean = [&]() -> void * {
+    int cand[3], n = 0;
+    for (int k = 0; k < a->n_classes; ++k) if (a->mat_bytes[k] == 0 && k != a->matrix_class && class_has_room(a, bytes, k)) cand[n++] = k;
+    if (n == 0) return nullptr;
+    return arena_take(a, bytes, cand[(a->vec_turn++) % (unsigned)n], kind);
+  };
+  p = try_clean();
+  if (!p && !a->frozen && !c->capturing) {
+    std::vector<pa_extent *> walked;
+    size_t walk_budget = (size_t)160 * GIB;
+    if (const char *s = getenv("PA_ARENA_WALK_GIB")) walk_budget = (size_t)atol(s) * GIB;
+    size_t walked_bytes = 0;
+    while (!p && walked_bytes < walk_budget) {
+      pa_extent *X = arena_acquire(c, a, extent_bytes(a, bytes), "vectors: looking for a class without matrix streams");
+      if (!X) break;
+      walked.push_back(X);
+      walked_bytes += X->size;
+      p = try_clean();
+    }
+    for (pa_extent *X : walked) if (X->live == 0) arena_release(a, X);
+  }
+  if (!p) {                                             // nothing clean anywhere: next to the fewest matrix bytes
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int x, int y) { return a->mat_bytes[x] < a->mat_bytes[y]; });
+    for (int k = 0; k < 3 && !p; ++k) if (order[k] < a->n_classes) p = arena_take(a, bytes, order[k], kind);
+    return p;                                           // (knowingly next to matrix streams: nothing to check)
+  }
+  // self-check of the pair actually handed out (big vectors only: what a product writes)
+  static const int check_mode = getenv("PA_ARENA_SELFCHECK") ? atoi(getenv("PA_ARENA_SELFCHECK")) : 1;
+  if (check_mode && a->last_matrix && bytes >= ((size_t)32 << 20) && !c->capturing) {
+    const int cls = a->live_[(uintptr_t)p].cls;
+    bool same = false;
+    if (cls != a->last_matrix_cls && pair_check(c, a, (char *)p, bytes, &same) == PA_OK) {
+      if (!same) a->check_ok++;
+      else {
+        a->check_failed++;
+        // the map says "different classes", the pair says "same": try the other clean class once, else keep it and say so
+        void *q = nullptr;
+        for (int k = 0; k < a->n_classes && !q; ++k)
+          if (k != cls && k != a->last_matrix_cls && a->mat_bytes[k] == 0) q = arena_take(a, bytes, k, kind);
+        bool same2 = true;
+        if (q && pair_check(c, a, (char *)q, bytes, &same2) == PA_OK && !same2) {
+          arena_give_back(a, p);
+          p = q;
+        } else {
+          if (q) arena_give_back(a, q);
+          if (!a->warned) {
+            a->warned = true;
+            fprintf(stderr, "[pa arena] warning: a vector placed in memory class %d times as if it shared the matrix streams' class %d "
+                            "(products writing it may run ~13 %% slower); PA_ARENA_SELFCHECK=0 silences the check\n", cls, a->last_matrix_cls);
+          }
+        }
+      }
+    } else (void)hipGetLastError();
+  }
+  return p;
+}
+
+static void arena_give_back(pa_arena *a, void *p) {
+  auto it = a->live_.find((uintptr_t)p);
+  if (it == a->live_.end()) return;
+  pa_arena::blk b = it->second;
+  a->live_.erase(it);
+  a->used -= b.len;
+  b.e->live -= b.len;
+  size_t *acct = b.kind == PA_MEM_MATRIX ? a->mat_bytes : a->vec_bytes;
+  acct[b.cls] -= std::min(acct[b.cls], b.len);
+  if ((const char *)p == a->last_matrix) { a->last_matrix = nullptr; a->last_matrix_len = 0; a->last_matrix_cls = -1; }
+  if (b.e->live == 0) {                                 // nothing of the extent is in use any more (and it holds no class's scratch)
+    arena_release(a, b.e);
+    if (a->mat_bytes[0] + a->mat_bytes[1] + a->mat_bytes[2] == 0) a->matrix_class = -1;
+    return;
+  }
+  uintptr_t start = (uintptr_t)p;
+  size_t len = b.len;
+  auto nx = a->free_.find(start + len);                 // merge with free neighbours of the same extent and class
+  if (nx != a->free_.end() && nx->second.e == b.e && nx->second.cls == b.cls) {
+    len += nx->second.len;
+    a->free_.erase(nx);
+  }
+  auto pv = a->free_.lower_bound(start);
+  if (pv != a->free_.begin()) {
+    --pv;
+    if (pv->first + pv->second.len == start && pv->second.e == b.e && pv->second.cls == b.cls) {
+      start = pv->first;
+      len += pv->second.len;
+      a->free_.erase(pv);
+    }
+  }
+  a->free_[start] = {len, b.cls, 0, b.e};
+  if (a->mat_bytes[0] + a->mat_bytes[1] + a->mat_bytes[2] == 0) a->matrix_class = -1;
 }
 
 // ---- PA_DEBUG_GUARD: one mapping per buffer, the buffer flush with its end, nothing mapped behind it ----
@@ -291,33 +542,17 @@ int pa_dev_alloc(pa_ctx *c, void **p, size_t bytes, int kind) {
     return PA_OK;
   }
   const size_t small = (size_t)1 << 20;          // below 1 MiB the class of a buffer does not matter
-  size_t first_big = (size_t)256 << 20;          // the arena is built when the first allocation this large arrives
+  size_t first_big = (size_t)256 << 20;          // the arena comes into being when the first allocation this large arrives
   if (const char *e = getenv("PA_ARENA_MIN_MIB")) first_big = (size_t)atol(e) << 20;
   if (kind != PA_MEM_PLAIN && bytes >= small) {
-    if (!c->arena && !c->arena_tried && bytes >= first_big) PA_TRY(arena_build(c));
+    // (pa_*_create / pa_*_destroy may be reached from any host thread -- finalizers of a managed host language)
+    std::lock_guard<std::mutex> lk(c->mem_mu);
+    if (!c->arena && !c->arena_tried && bytes >= first_big && !c->capturing) {
+      if (arena_init(c) != PA_OK) (void)hipGetLastError();    // no arena: plain hipMalloc below
+    }
     if (pa_arena *a = c->arena) {
-      // The rule: a vector never shares a class with a matrix stream.  Matrix streams fill the roomiest class first and
-      // spill into the class that holds fewer vectors; vectors take the other classes -- alternating while both are
-      // free of matrix streams (BLAS-1 kernels, too, run 3-6 % faster when what they write is not where they read) --
-      // and end up next to matrix streams only when nothing else is left.
-      const int M = a->matrix_class, o1 = (M + 1) % 3, o2 = (M + 2) % 3;
-      int order[3];
-      if (kind == PA_MEM_MATRIX) {
-        order[0] = M;
-        order[1] = a->vec_bytes[o1] <= a->vec_bytes[o2] ? o1 : o2;
-        order[2] = order[1] == o1 ? o2 : o1;
-      } else {
-        int first = a->mat_bytes[o1] < a->mat_bytes[o2] ? o1 : a->mat_bytes[o2] < a->mat_bytes[o1] ? o2 : ((a->vec_turn++ & 1) ? o2 : o1);
-        order[0] = first;
-        order[1] = first == o1 ? o2 : o1;
-        order[2] = M;
-      }
-      for (int k = 0; k < 3; ++k)
-        if ((*p = arena_take(a, bytes, order[k])) != nullptr) {
-          (kind == PA_MEM_MATRIX ? a->mat_bytes : a->vec_bytes)[order[k]] += (bytes + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
-          a->live_kind_[(size_t)((char *)*p - a->base)] = kind;
-          return PA_OK;
-        }
+      PA_HIP(hipSetDevice(c->device));
+      if ((*p = arena_alloc(c, a, bytes, kind)) != nullptr) return PA_OK;
     }
   }
   PA_HIP(hipMalloc(p, bytes));
@@ -327,51 +562,33 @@ int pa_dev_alloc(pa_ctx *c, void **p, size_t bytes, int kind) {
 void pa_dev_free(pa_ctx *c, void *p) {
   if (!p) return;
   if (guard_mode()) { (void)pa_raw_free(p); return; }
-  pa_arena *a = c ? c->arena : nullptr;
-  if (a && (char *)p >= a->base && (char *)p < a->base + a->size) {
-    const size_t off = (size_t)((char *)p - a->base);
-    auto it = a->live_.find(off);
-    if (it == a->live_.end()) return;            // not ours (cannot happen for pointers pa_dev_alloc handed out)
-    size_t len = it->second.len;
-    const int cls = it->second.cls;
-    a->live_.erase(it);
-    a->used -= len;
-    auto kd = a->live_kind_.find(off);
-    if (kd != a->live_kind_.end()) {
-      size_t *acct = kd->second == PA_MEM_MATRIX ? a->mat_bytes : a->vec_bytes;
-      acct[cls] -= std::min(acct[cls], len);
-      a->live_kind_.erase(kd);
+  if (c) {
+    std::lock_guard<std::mutex> lk(c->mem_mu);
+    pa_arena *a = c->arena;
+    if (a && a->live_.count((uintptr_t)p)) {
+      arena_give_back(a, p);
+      return;
     }
-    size_t start = off;
-    auto nx = a->free_.find(off + len);           // merge with free neighbours of the same class (never across a boundary cell)
-    if (nx != a->free_.end() && nx->second.cls == cls && a->cls[(off + len) / a->cell] == cls && a->cls[(off + len - 1) / a->cell] == cls) {
-      len += nx->second.len;
-      a->free_.erase(nx);
-    }
-    auto pv = a->free_.lower_bound(off);
-    if (pv != a->free_.begin()) {
-      --pv;
-      if (pv->first + pv->second.len == off && pv->second.cls == cls && a->cls[(off - 1) / a->cell] == cls) {
-        start = pv->first;
-        len += pv->second.len;
-        a->free_.erase(pv);
-      }
-    }
-    a->free_[start] = {len, cls};
-    return;
   }
   (void)hipFree(p);
 }
 
 int pa_mem_class(const pa_ctx *c, const void *p) {
-  const pa_arena *a = c ? c->arena : nullptr;
-  if (!a || !p || (const char *)p < a->base || (const char *)p >= a->base + a->size) return -1;
-  return a->cls[(size_t)((const char *)p - a->base) / a->cell];
+  if (!c || !p) return -1;
+  std::lock_guard<std::mutex> lk(const_cast<pa_ctx *>(c)->mem_mu);
+  const pa_arena *a = c->arena;
+  if (!a) return -1;
+  for (const pa_extent *X : a->ext)
+    if ((const char *)p >= X->base && (const char *)p < X->base + X->size) return X->cls[(size_t)((const char *)p - X->base) / a->cell];
+  return -1;
 }
 
 void pa_arena_destroy(pa_ctx *c) {
   if (!c || !c->arena) return;
-  (void)hipFree(c->arena->base);
+  for (pa_extent *X : c->arena->ext) {
+    (void)hipFree(X->base);
+    delete X;
+  }
   delete c->arena;
   c->arena = nullptr;
 }
@@ -379,10 +596,14 @@ void pa_arena_destroy(pa_ctx *c) {
 extern "C" int pa_ctx_arena_info(pa_ctx *c, int64_t *bytes, int *n_classes, int64_t class_bytes[3], int64_t *used,
                                  double *map_ms, int *matrix_class) {
   PA_REQUIRE(c != nullptr, "ctx is NULL");
+  std::lock_guard<std::mutex> lk(c->mem_mu);
   const pa_arena *a = c->arena;
-  if (bytes) *bytes = a ? (int64_t)a->size : 0;
+  if (bytes) *bytes = a ? (int64_t)a->held : 0;
   if (n_classes) *n_classes = a ? a->n_classes : 0;
-  if (class_bytes) for (int k = 0; k < 3; ++k) class_bytes[k] = a ? (int64_t)a->class_bytes[k] : 0;
+  if (class_bytes) {
+    for (int k = 0; k < 3; ++k) class_bytes[k] = 0;
+    if (a) for (const pa_extent *X : a->ext) for (int8_t v : X->cls) if (v >= 0) class_bytes[v] += (int64_t)a->cell;
+  }
   if (used) *used = a ? (int64_t)a->used : 0;
   if (map_ms) *map_ms = a ? a->map_ms : 0.0;
   if (matrix_class) *matrix_class = a ? a->matrix_class : -1;
@@ -391,15 +612,40 @@ extern "C" int pa_ctx_arena_info(pa_ctx *c, int64_t *bytes, int *n_classes, int6
 
 extern "C" int pa_ctx_arena_map(pa_ctx *c, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells) {
   PA_REQUIRE(c && n_cells, "bad arguments");
+  std::lock_guard<std::mutex> lk(c->mem_mu);
   const pa_arena *a = c->arena;
-  *n_cells = a ? (int64_t)a->cls.size() : 0;
+  int64_t n = 0;
+  if (a) for (const pa_extent *X : a->ext) {             // extent after extent, -2 between two of them
+    if (n && classes && n < capacity) classes[n] = -2;
+    if (n) ++n;
+    for (int8_t v : X->cls) { if (classes && n < capacity) classes[n] = v; ++n; }
+  }
+  *n_cells = n;
   if (cell_bytes) *cell_bytes = a ? (int64_t)a->cell : 0;
-  if (a && classes) for (int64_t i = 0; i < std::min<int64_t>(capacity, *n_cells); ++i) classes[i] = a->cls[i];
   return PA_OK;
 }
 
+extern "C" int pa_ctx_arena_stats(pa_ctx *c, int64_t *n_extents, int64_t *bytes_acquired, int64_t *bytes_released,
+                                  int64_t *peak_used, int64_t *pairs_ok, int64_t *pairs_failed, int64_t *budget) {
+  PA_REQUIRE(c != nullptr, "ctx is NULL");
+  std::lock_guard<std::mutex> lk(c->mem_mu);
+  const pa_arena *a = c->arena;
+  if (n_extents) *n_extents = a ? (int64_t)a->ext.size() : 0;
+  if (bytes_acquired) *bytes_acquired = a ? (int64_t)a->acquired : 0;
+  if (bytes_released) *bytes_released = a ? (int64_t)a->released : 0;
+  if (peak_used) *peak_used = a ? (int64_t)a->peak : 0;
+  if (pairs_ok) *pairs_ok = a ? a->check_ok : 0;
+  if (pairs_failed) *pairs_failed = a ? a->check_failed : 0;
+  if (budget) *budget = a ? (int64_t)a->budget : 0;
+  return PA_OK;
+}
+
+// (kept for callers that want the first extent before their first big allocation: it acquires one extent of the usual size)
 extern "C" int pa_ctx_arena_build(pa_ctx *c) {
   PA_REQUIRE(c != nullptr, "ctx is NULL");
+  std::lock_guard<std::mutex> lk(c->mem_mu);
   if (c->arena || c->arena_tried) return PA_OK;
-  return arena_build(c);
+  PA_TRY(arena_init(c));
+  if (c->arena) (void)arena_acquire(c, c->arena, extent_bytes(c->arena, 0), "pa_ctx_arena_build");
+  return PA_OK;
 }

@@ -121,11 +121,18 @@ __global__ void k_unpack_add(double *__restrict__ v, const double *__restrict__ 
 }
 
 
-__global__ void k_axpby(double *__restrict__ y, const double *__restrict__ x, int64_t n, double a, double b) {
+// y = a*x + b*y, one rounding per multiply and per add.  b == 0 is a pure assignment y = a*x: y is NOT read (NaN / Inf
+// left in y do not survive as 0*NaN, and -0.0 products keep their sign: what `dest .= a .* v` gives in the reference's
+// broadcast, src/p_vector.jl:1216-1277).  x may be y itself (a scaling in place): no restrict promise on the pair.
+__global__ void k_axpby(double *y, const double *x, int64_t n, double a, double b) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   // x only streams through (non-temporal: see k_cg_r_update); y is the vector that is wanted next (u before a product)
-  for (; i < n; i += stride) y[i] = a * __builtin_nontemporal_load(&x[i]) + b * y[i];
+  if (b == 0.0) {
+    for (; i < n; i += stride) y[i] = a * __builtin_nontemporal_load(&x[i]);
+  } else {
+    for (; i < n; i += stride) y[i] = a * __builtin_nontemporal_load(&x[i]) + b * y[i];
+  }
 }
 
 __device__ inline double block_sum_256(double s, double *sh) {
@@ -445,8 +452,13 @@ extern "C" int pa_vec_create(pa_ctx *c, int64_t n_own, int64_t n_ghost, pa_vec *
   pa_vec *v = new pa_vec();
   v->ctx = c; v->n_own = n_own; v->n_ghost = n_ghost; v->owned = true;
   const size_t bytes = sizeof(double) * (size_t)(n_own + n_ghost + 2);
-  PA_TRY(pa_dev_alloc(c, (void **)&v->d, bytes, PA_MEM_VECTOR));   // a memory class no matrix stream lives in (pa_arena.hip)
-  PA_HIP(hipMemsetAsync(v->d, 0, bytes, c->s[0]));
+  if (const int st = pa_dev_alloc(c, (void **)&v->d, bytes, PA_MEM_VECTOR)) { delete v; return st; }   // a memory class no matrix stream lives in (pa_arena.hip)
+  if (hipMemsetAsync(v->d, 0, bytes, c->s[0]) != hipSuccess) {
+    pa_set_err("hipMemsetAsync failed on a new vector of %lld values", (long long)(n_own + n_ghost));
+    pa_dev_free(c, v->d);
+    delete v;
+    return PA_ERR_HIP;
+  }
   *out = v;
   return PA_OK;
 }
@@ -688,8 +700,11 @@ static inline int64_t read_index(const void *a, int bytes, int64_t i) {
   return bytes == 4 ? (int64_t)((const int32_t *)a)[i] : ((const int64_t *)a)[i];
 }
 
-static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
-                          const int32_t *col0 /*0-based, host*/, const double *nzval, pa_csr **out) {
+static void csr_free_chain(pa_csr *A);
+
+// fills the freshly created slab A; on any failure the caller (csr_build_slab) hands back whatever A holds by then
+static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
+                         const int32_t *col0 /*0-based, host*/, const double *nzval) {
   // non-empty rows; compact when most rows are empty (the own_ghost block: only boundary rows)
   const bool tm_ = getenv("PA_SETUP_TIMING") != nullptr;   // stderr: seconds per phase of this function
   auto t0_ = std::chrono::steady_clock::now();
@@ -721,8 +736,7 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
   int64_t n_long = 0;
   pa_build_chunks(crp.data(), nc, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
   lap("chunks");
-  pa_csr *A = new pa_csr();
-  A->ctx = c; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
+  A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
   A->n_crows = nc; A->n_chunks = (int64_t)chunk_row.size() - 1; A->n_nonempty = n_nonempty; A->n_long = n_long;
   A->compact = compact;
   PA_HIP(hipSetDevice(c->device));
@@ -891,6 +905,19 @@ static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz
     PA_TRY(pa_dev_alloc(c, (void **)&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc), PA_MEM_MATRIX));
     if (nc) PA_HIP(pa_h2d(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc));
   }
+  return PA_OK;
+}
+
+static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
+                          const int32_t *col0 /*0-based, host*/, const double *nzval, pa_csr **out) {
+  pa_csr *A = new pa_csr();
+  A->ctx = c;
+  const int st = csr_fill_slab(c, A, n_rows, n_cols, nnz, rp, col0, nzval);
+  if (st != PA_OK) {                 // a failed allocation or upload half-way: nothing stays behind (device buffers, arena blocks)
+    (void)hipGetLastError();
+    csr_free_chain(A);
+    return st;
+  }
   *out = A;
   return PA_OK;
 }
@@ -903,8 +930,6 @@ static int64_t slab_limit() {
   if (e && atoll(e) > 0 && atoll(e) < hard) return atoll(e);
   return hard;
 }
-
-static void csr_free_chain(pa_csr *A);
 
 // rp: 0-based Int64 row pointers of the whole block.  One slab when the block fits Int32 offsets, else consecutive
 // row slabs (greedy, whole rows).
@@ -1075,7 +1100,8 @@ static void csr_free_chain(pa_csr *A) {
 extern "C" int pa_csr_destroy(pa_csr *A) {
   if (!A) return PA_OK;
   (void)hipSetDevice(A->ctx->device);
-  (void)hipStreamSynchronize(A->ctx->s[0]);
+  (void)hipStreamSynchronize(A->ctx->s[0]);      // (both: the arena hands these blocks to the next caller at once, whereas
+  (void)hipStreamSynchronize(A->ctx->s[1]);      // hipFree used to synchronise the whole device)
   csr_free_chain(A);
   return PA_OK;
 }

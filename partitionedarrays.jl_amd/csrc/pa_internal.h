@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdint>
+#include <mutex>
 #include <vector>
 
 #include "pa_hip.h"
@@ -51,8 +52,9 @@ struct pa_ctx {
   int64_t n_dotpart = 0;
   bool capturing = false;                 // a pa_graph_begin is open on the compute stream
   int comm_priority = 0;                  // priority the comm stream was created with (the device's greatest)
-  pa_arena *arena = nullptr;              // contiguous HBM arena with its memory-class map (pa_arena.hip), built lazily
+  pa_arena *arena = nullptr;              // contiguous HBM extents with their memory-class maps (pa_arena.hip), on demand
   bool arena_tried = false;
+  std::mutex mem_mu;                      // guards the arena's maps: create / destroy may come from any host thread
 };
 
 // Device memory of a context (pa_arena.hip).  kind says what the buffer is FOR, which decides its memory class:

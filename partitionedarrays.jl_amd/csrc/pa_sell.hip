@@ -120,18 +120,26 @@ extern "C" int pa_sell_create(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t
     }
   pa_sell *A = new pa_sell();
   A->ctx = c; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->n_slabs = n_slabs; A->padded = padded; A->sigma = sigma;
-  PA_HIP(hipSetDevice(c->device));
-  PA_TRY(pa_dev_alloc(c, (void **)&A->d_val, sizeof(double) * val.size(), PA_MEM_MATRIX));
-  PA_TRY(pa_dev_alloc(c, (void **)&A->d_col, sizeof(int32_t) * col.size(), PA_MEM_MATRIX));
-  PA_TRY(pa_dev_alloc(c, (void **)&A->d_slab_ptr, sizeof(int64_t) * slab_ptr.size(), PA_MEM_MATRIX));
-  PA_TRY(pa_dev_alloc(c, (void **)&A->d_len, sizeof(int32_t) * std::max<size_t>(1, len.size()), PA_MEM_MATRIX));
-  PA_TRY(pa_dev_alloc(c, (void **)&A->d_row, sizeof(int32_t) * std::max<size_t>(1, row.size()), PA_MEM_MATRIX));
-  PA_HIP(pa_h2d(A->d_val, val.data(), sizeof(double) * val.size()));
-  PA_HIP(pa_h2d(A->d_col, col.data(), sizeof(int32_t) * col.size()));
-  PA_HIP(pa_h2d(A->d_slab_ptr, slab_ptr.data(), sizeof(int64_t) * slab_ptr.size()));
-  if (!len.empty()) {
-    PA_HIP(pa_h2d(A->d_len, len.data(), sizeof(int32_t) * len.size()));
-    PA_HIP(pa_h2d(A->d_row, row.data(), sizeof(int32_t) * row.size()));
+  auto fill = [&]() -> int {
+    PA_HIP(hipSetDevice(c->device));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_val, sizeof(double) * val.size(), PA_MEM_MATRIX));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_col, sizeof(int32_t) * col.size(), PA_MEM_MATRIX));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_slab_ptr, sizeof(int64_t) * slab_ptr.size(), PA_MEM_MATRIX));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_len, sizeof(int32_t) * std::max<size_t>(1, len.size()), PA_MEM_MATRIX));
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_row, sizeof(int32_t) * std::max<size_t>(1, row.size()), PA_MEM_MATRIX));
+    PA_HIP(pa_h2d(A->d_val, val.data(), sizeof(double) * val.size()));
+    PA_HIP(pa_h2d(A->d_col, col.data(), sizeof(int32_t) * col.size()));
+    PA_HIP(pa_h2d(A->d_slab_ptr, slab_ptr.data(), sizeof(int64_t) * slab_ptr.size()));
+    if (!len.empty()) {
+      PA_HIP(pa_h2d(A->d_len, len.data(), sizeof(int32_t) * len.size()));
+      PA_HIP(pa_h2d(A->d_row, row.data(), sizeof(int32_t) * row.size()));
+    }
+    return PA_OK;
+  };
+  if (const int st = fill()) {               // half-built: hand back what was taken (pa_dev_free ignores NULL)
+    (void)hipGetLastError();
+    (void)pa_sell_destroy(A);
+    return st;
   }
   *out = A;
   return PA_OK;
@@ -141,6 +149,7 @@ extern "C" int pa_sell_destroy(pa_sell *A) {
   if (!A) return PA_OK;
   (void)hipSetDevice(A->ctx->device);
   (void)hipStreamSynchronize(A->ctx->s[0]);
+  (void)hipStreamSynchronize(A->ctx->s[1]);
   pa_dev_free(A->ctx, A->d_val);
   pa_dev_free(A->ctx, A->d_col);
   pa_dev_free(A->ctx, A->d_slab_ptr);

@@ -62,29 +62,56 @@ function init_comm!(comm::MPI.Comm=MPI.COMM_WORLD)
 end
 
 # ---------------------------------------------------------------- local vector type
+# The device layout is ALWAYS [own | ghost] (what the kernels and the own-value reductions need).  Index partitions whose
+# local order is something else -- PermutedLocalIndices (src/p_range.jl:1372: uniform_partition with ghost layers, the
+# partitions of test/p_vector_tests.jl:93-124) and hand-made LocalIndices -- carry `l2d`: the 1-based device position of
+# every local id.  Whole-vector upload / download then speak the LOCAL order and the exchange plan is built from device
+# positions; `nothing` when the local order already is [own | ghost] (block partitions: no copy, no indirection).
 mutable struct HIPVector <: AbstractVector{Float64}
     handle::Ptr{Cvoid}
     n_own::Int
     n_ghost::Int
-    function HIPVector(n_own::Integer, n_ghost::Integer)
+    l2d::Union{Nothing,Vector{Int32}}
+    function HIPVector(n_own::Integer, n_ghost::Integer, l2d::Union{Nothing,Vector{Int32}}=nothing)
         h = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:pa_vec_create, libpa), Cint, (Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}),
                     context().handle, n_own, n_ghost, h))
-        v = new(h[], n_own, n_ghost)
+        v = new(h[], n_own, n_ghost, l2d)
         finalizer(x -> ccall((:pa_vec_destroy, libpa), Cint, (Ptr{Cvoid},), x.handle), v)
     end
 end
+"1-based device position of every local id of `indices`, or `nothing` when local ids already are [own | ghost]."
+function local_to_device(indices)
+    o2l, g2l = own_to_local(indices), ghost_to_local(indices)
+    no, ng = length(o2l), length(g2l)
+    (o2l == 1:no && g2l == (no + 1):(no + ng)) && return nothing
+    l2d = Vector{Int32}(undef, no + ng)
+    for (k, l) in enumerate(o2l); l2d[l] = k; end
+    for (k, l) in enumerate(g2l); l2d[l] = no + k; end
+    l2d
+end
 Base.size(v::HIPVector) = (v.n_own + v.n_ghost,)
 Base.getindex(::HIPVector, ::Int) = error("scalar indexing of a HIPVector is not allowed; use Array(v)")
-function HIPVector(host::Vector{Float64}, n_own::Integer)
-    v = HIPVector(n_own, length(host) - n_own)
-    check(ccall((:pa_vec_upload, libpa), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), v.handle, host, 0, length(host)))
+"Upload local values given in LOCAL order (permuted into the device layout when the partition needs it)."
+function upload!(v::HIPVector, host::AbstractVector{<:Real})
+    length(host) == length(v) || error("PartitionedArraysHIP: $(length(host)) values for a local vector of $(length(v))")
+    dev = Vector{Float64}(undef, length(host))
+    if v.l2d === nothing
+        copyto!(dev, host)
+    else
+        for l in eachindex(host); dev[v.l2d[l]] = host[l]; end
+    end
+    check(ccall((:pa_vec_upload, libpa), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), v.handle, dev, 0, length(dev)))
     v
 end
+function HIPVector(host::Vector{Float64}, n_own::Integer, l2d::Union{Nothing,Vector{Int32}}=nothing)
+    upload!(HIPVector(n_own, length(host) - n_own, l2d), host)
+end
+"Local values in LOCAL order."
 function Base.Array(v::HIPVector)
-    host = Vector{Float64}(undef, length(v))
-    check(ccall((:pa_vec_download, libpa), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), v.handle, host, 0, length(host)))
-    host
+    dev = Vector{Float64}(undef, length(v))
+    check(ccall((:pa_vec_download, libpa), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), v.handle, dev, 0, length(dev)))
+    v.l2d === nothing ? dev : dev[v.l2d]
 end
 
 "own_values / ghost_values of a HIPVector: a segment tag instead of a SubArray (src/p_vector.jl:20-26)."
@@ -94,14 +121,19 @@ struct HIPSegment <: AbstractVector{Float64}
 end
 Base.size(s::HIPSegment) = (s.seg == PA_SEG_OWN ? s.parent.n_own : s.parent.n_ghost,)
 PartitionedArrays.allocate_local_values(::Type{HIPVector}, indices) =
-    HIPVector(own_length(indices), ghost_length(indices))
+    HIPVector(own_length(indices), ghost_length(indices), local_to_device(indices))
 PartitionedArrays.allocate_local_values(v::HIPVector, ::Type{Float64}, indices) =
-    HIPVector(own_length(indices), ghost_length(indices))
+    HIPVector(own_length(indices), ghost_length(indices), local_to_device(indices))
 PartitionedArrays.own_values(v::HIPVector, indices) = HIPSegment(v, PA_SEG_OWN)
 PartitionedArrays.ghost_values(v::HIPVector, indices) = HIPSegment(v, PA_SEG_GHOST)
 Base.fill!(s::HIPSegment, x) =
     (check(ccall((:pa_vec_fill, libpa), Cint, (Ptr{Cvoid}, Cint, Float64), s.parent.handle, s.seg, x)); s)
+# dot(a::PVector,b::PVector) reduces dot(own_values(a),own_values(b)) over the parts (src/p_vector.jl:1189-1199): the device
+# reduction IS over own values (pa_vec_dot), so any other segment is refused rather than silently answered with the own
+# segment's result.
 function LinearAlgebra.dot(a::HIPSegment, b::HIPSegment)
+    (a.seg == PA_SEG_OWN && b.seg == PA_SEG_OWN) ||
+        error("PartitionedArraysHIP: dot / norm are computed on own values only (got a ghost segment)")
     out = Ref{Float64}(0.0)
     check(ccall((:pa_vec_dot, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}), a.parent.handle, b.parent.handle, out))
     out[]
@@ -110,36 +142,43 @@ end
 # ---------------------------------------------------------------- BLAS-1 on segments: what a solver loop does to a PVector
 # The reference's PVector broadcast (src/p_vector.jl:1216-1277) hands the expression to the LOCAL arrays: `x .+= alpha .* u`
 # becomes, per part, materialize!(own_values(x), broadcasted(+, own_values(x), broadcasted(*, alpha, own_values(u)))).
-# For HIPSegments that expression is flattened into a linear combination  dest = sum_i coef_i * v_i + constant  and run by
-# pa_vec_axpby (y = a*x + b*y, unfused multiply and add: the same roundings as the reference's loop for the statements of a CG
-# iteration, HPCG/src/ref_cg.jl:56,64-65: c .+ beta .* u, x .+ alpha .* u, r .- alpha .* c).  Anything that is not a linear
-# combination of at most two vectors is refused (no scalar fallback: scalar indexing of device memory is an error).
+# For HIPSegments that expression is flattened into  dest = a * v (+ b * w)  and run by pa_vec_axpby (y = a*x + b*y, unfused
+# multiply and add; b == 0 does not read y).  ONLY forms whose roundings are provably the element-wise loop's are accepted:
+#     k .* v   v .* k   -v   v .+ w   v .- w   v .+ k .* w   v .- k .* w   k .* v .+ l .* w        (k, l scalars)
+# i.e. every vector is multiplied by ONE scalar at most (k*(l*v), k .* (v .+ w), a .* v .+ b .* v would each round
+# differently when flattened) and nothing is divided (v ./ k is not v .* (1/k)).  These are the statements of a CG
+# iteration (HPCG/src/ref_cg.jl:56,64-65: c .+ beta .* u, x .+ alpha .* u, r .- alpha .* c).  Everything else is refused
+# (no scalar fallback: scalar indexing of device memory is an error).
 struct HIPStyle <: Base.Broadcast.AbstractArrayStyle{1} end
 HIPStyle(::Val{1}) = HIPStyle()
 HIPStyle(::Val{N}) where N = Base.Broadcast.DefaultArrayStyle{N}()
 Base.BroadcastStyle(::Type{HIPSegment}) = HIPStyle()
 
-"dest-independent linear form of a broadcast tree: (constant, [(segment, coefficient), ...])"
-_lin(x::Number) = (Float64(x), Tuple{HIPSegment,Float64}[])
+"linear form of a broadcast tree: (constant, [(segment, coefficient, scaled::Bool), ...]); scaled = a scalar was applied"
+_lin(x::Number) = (Float64(x), Tuple{HIPSegment,Float64,Bool}[])
 _lin(x::Base.RefValue{<:Number}) = _lin(x[])
-_lin(x::HIPSegment) = (0.0, [(x, 1.0)])
+_lin(x::HIPSegment) = (0.0, [(x, 1.0, false)])
 function _lin(bc::Base.Broadcast.Broadcasted)
     f, a = bc.f, map(_lin, bc.args)
     if f === (+) && length(a) == 2
         return (a[1][1] + a[2][1], vcat(a[1][2], a[2][2]))
-    elseif f === (-) && length(a) == 2
-        return (a[1][1] - a[2][1], vcat(a[1][2], [(v, -c) for (v, c) in a[2][2]]))
+    elseif f === (-) && length(a) == 2                       # negation is exact: (-k)*w + v == v - k*w bit for bit
+        return (a[1][1] - a[2][1], vcat(a[1][2], [(v, -c, sc) for (v, c, sc) in a[2][2]]))
     elseif f === (-) && length(a) == 1
-        return (-a[1][1], [(v, -c) for (v, c) in a[1][2]])
+        return (-a[1][1], [(v, -c, sc) for (v, c, sc) in a[1][2]])
     elseif f === (*) && length(a) == 2 && (isempty(a[1][2]) || isempty(a[2][2]))
         k, t = isempty(a[1][2]) ? (a[1][1], a[2]) : (a[2][1], a[1])
-        return (k * t[1], [(v, k * c) for (v, c) in t[2]])
-    elseif f === (/) && length(a) == 2 && isempty(a[2][2])
-        return (a[1][1] / a[2][1], [(v, c / a[2][1]) for (v, c) in a[1][2]])
+        isempty(t[2]) && return (k * t[1], t[2])             # scalar * scalar
+        (length(t[2]) == 1 && !t[2][1][3] && t[1] == 0.0) ||
+            error("PartitionedArraysHIP: a scalar applied to a sum or to an already scaled vector would round differently " *
+                  "from the element-wise loop; write it as k .* v .+ l .* w")
+        v, c, _ = t[2][1]
+        return (0.0, [(v, k * c, true)])                     # c is +-1 here: k*c is exact
     elseif f === identity && length(a) == 1
         return a[1]
     end
-    error("PartitionedArraysHIP: only linear combinations of device vectors are broadcast on the device (got $(f))")
+    error("PartitionedArraysHIP: only k .* v, v .+- w and v .+- k .* w are broadcast on the device (got $(f)); " *
+          "division is not (v ./ k is not v .* (1/k))")
 end
 _axpby!(y::HIPSegment, a, x::HIPSegment, b) =
     check(ccall((:pa_vec_axpby, libpa), Cint, (Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, Cint),
@@ -148,23 +187,26 @@ function Base.copyto!(dest::HIPSegment, bc::Base.Broadcast.Broadcasted{HIPStyle}
     k, terms = _lin(bc)
     all(t -> t[1].seg == dest.seg, terms) || error("PartitionedArraysHIP: a broadcast mixes own and ghost segments")
     k == 0.0 || isempty(terms) || error("PartitionedArraysHIP: vector + constant is not broadcast on the device")
-    merged = Tuple{HIPSegment,Float64}[]                        # equal vectors merge: x .+ x is 2x
-    for (v, c) in terms
-        i = findfirst(t -> t[1].parent === v.parent, merged)
-        i === nothing ? push!(merged, (v, c)) : (merged[i] = (v, merged[i][2] + c))
+    isempty(terms) && return fill!(dest, k)
+    length(terms) <= 2 || error("PartitionedArraysHIP: a broadcast of more than two device vectors is not supported")
+    if length(terms) == 2 && terms[1][1].parent === terms[2][1].parent
+        # the same vector twice: v .+ v and v .- v are exact as 2v and 0v; a .* v .+ b .* v is not (a+b) .* v
+        (abs(terms[1][2]) == 1.0 && abs(terms[2][2]) == 1.0) ||
+            error("PartitionedArraysHIP: a .* v .+ b .* v would round differently as (a+b) .* v")
+        terms[1][2] + terms[2][2] == 0.0 &&
+            error("PartitionedArraysHIP: v .- v is not broadcast on the device (0 .* v has the sign of v's zeros wrong); use fill!")
+        terms = [(terms[1][1], terms[1][2] + terms[2][2], true)]
     end
-    mine = findfirst(t -> t[1].parent === dest.parent, merged)
-    b = mine === nothing ? 0.0 : merged[mine][2]
-    rest = [t for t in merged if t[1].parent !== dest.parent]
-    if isempty(rest)
-        isempty(merged) ? fill!(dest, k) : _axpby!(dest, 0.0, dest, b)
-    elseif length(rest) == 1
-        _axpby!(dest, rest[1][2], rest[1][1], b)                 # dest = a*v + b*dest
-    elseif length(rest) == 2 && mine === nothing
-        _axpby!(dest, rest[1][2], rest[1][1], 0.0)               # dest = a*v, then += c*w
-        _axpby!(dest, rest[2][2], rest[2][1], 1.0)
+    mine = findfirst(t -> t[1].parent === dest.parent, terms)
+    if length(terms) == 1
+        v, a, _ = terms[1]
+        _axpby!(dest, a, v, 0.0)                                 # dest = a*v (b == 0: dest is not read; v may be dest itself)
+    elseif mine !== nothing
+        other = terms[3 - mine]
+        _axpby!(dest, other[2], other[1], terms[mine][2])        # dest = a*v + b*dest
     else
-        error("PartitionedArraysHIP: a broadcast of more than two device vectors is not supported")
+        _axpby!(dest, terms[1][2], terms[1][1], 0.0)             # dest = a*v, then dest = c*w + 1*dest
+        _axpby!(dest, terms[2][2], terms[2][1], 1.0)
     end
     dest
 end
@@ -176,8 +218,8 @@ Base.copyto!(dest::HIPSegment, src::HIPSegment) =
 Base.copy!(dest::HIPVector, src::HIPVector) =
     (check(ccall((:pa_vec_copy, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), dest.handle, src.handle, PA_SEG_LOCAL)); dest)
 Base.copyto!(dest::HIPVector, src::HIPVector) = copy!(dest, src)
-Base.similar(v::HIPVector) = HIPVector(v.n_own, v.n_ghost)
-Base.similar(v::HIPVector, ::Type{Float64}) = HIPVector(v.n_own, v.n_ghost)
+Base.similar(v::HIPVector) = HIPVector(v.n_own, v.n_ghost, v.l2d)
+Base.similar(v::HIPVector, ::Type{Float64}) = HIPVector(v.n_own, v.n_ghost, v.l2d)
 Base.fill!(v::HIPVector, x) =
     (check(ccall((:pa_vec_fill, libpa), Cint, (Ptr{Cvoid}, Cint, Float64), v.handle, PA_SEG_LOCAL, x)); v)
 "norm(own_values(a),p) of LinearAlgebra.norm(a::PVector,p) (src/p_vector.jl:1201-1206); p = 2 on the device."
@@ -238,11 +280,13 @@ function PartitionedArrays.p_vector_cache_impl(::Type{HIPVector}, vector_partiti
     indices_snd, indices_rcv = assembly_local_indices(index_partition, neighbors_snd, neighbors_rcv)
     plans = map(index_partition, neighbors_snd, neighbors_rcv, indices_snd, indices_rcv) do ids, ns, nr, is, ir
         h = Ref{Ptr{Cvoid}}(C_NULL)
+        l2d = local_to_device(ids)               # the cache's local ids as positions of the device layout [own | ghost]
+        dev(lids) = l2d === nothing ? convert(Vector{Int32}, lids) : Int32[l2d[l] for l in lids]
         check(ccall((:pa_plan_create, libpa), Cint,
                     (Ptr{Cvoid}, Int32, Int64, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32},
                      Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
                     context().handle, part_id(ids), local_length(ids),
-                    length(ns), ns, is.ptrs, is.data, length(nr), nr, ir.ptrs, ir.data, 1, h))
+                    length(ns), ns, is.ptrs, dev(is.data), length(nr), nr, ir.ptrs, dev(ir.data), 1, h))
         h[]
     end
     HIPAssemblyCache(plans, false)
@@ -296,10 +340,10 @@ _mul_fused!(ms::MPIArray, cs, bs, plans, α, β) =
                 ms.item, init_comm!(ms.comm), cs.item.handle, bs.item.handle, α, β))
 
 # ---------------------------------------------------------------- conversions
-"Device twin of a host PVector{Vector{Float64}} whose local ids are [own | ghost] (block partitions)."
+"Device twin of a host PVector{Vector{Float64}} on any kind of index partition (block, permuted, hand-made LocalIndices)."
 function to_hip(v::PVector)
     vals = map(partition(v), partition(axes(v, 1))) do x, ids
-        HIPVector(collect(Float64, x), own_length(ids))
+        HIPVector(collect(Float64, x), own_length(ids), local_to_device(ids))
     end
     PVector(vals, partition(axes(v, 1)))
 end

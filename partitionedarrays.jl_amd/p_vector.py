@@ -59,8 +59,10 @@ class Context:
         return dict(compute=a.value, comm=b.value, least=lo.value, greatest=hi.value)
 
     def arena(self, build=False):
-        """The context's HBM arena and its memory-class map (csrc/pa_arena.hip): size, classes found, usable GiB per
-        class, GiB in use, map time, and the class of every 512 MiB cell as a string ('.' = a boundary cell)."""
+        """The context's HBM extents and their memory-class maps (csrc/pa_arena.hip): GiB held, classes met, GiB per class
+        in the held extents, GiB in use, time spent acquiring + classifying, the class of every 512 MiB cell as a string
+        ('.' = a boundary cell, '|' between two extents), and what the arena did so far (extents, GiB acquired / released,
+        self-checked pairs)."""
         if build:
             L.call("pa_ctx_arena_build", self.h)
         size, used, ncls, ms, mcls = C.c_int64(), C.c_int64(), C.c_int(), C.c_double(), C.c_int()
@@ -70,10 +72,15 @@ class Context:
         L.call("pa_ctx_arena_map", self.h, C.byref(cell), None, 0, C.byref(n))
         cells = np.zeros(max(n.value, 1), np.int8)
         L.call("pa_ctx_arena_map", self.h, C.byref(cell), L.ptr(cells), n.value, C.byref(n))
+        st = [C.c_int64() for _ in range(7)]
+        L.call("pa_ctx_arena_stats", self.h, *[C.byref(v) for v in st])
         G = float(1 << 30)
         return dict(gib=round(size.value / G, 1), classes=ncls.value, matrix_class=mcls.value, class_gib=[round(v / G, 1) for v in per],
                     used_gib=round(used.value / G, 2), map_ms=round(ms.value, 1), cell_mib=cell.value >> 20,
-                    cells="".join("." if v < 0 else str(int(v)) for v in cells[:n.value]))
+                    cells="".join("|" if v == -2 else "." if v < 0 else str(int(v)) for v in cells[:n.value]),
+                    extents=st[0].value, acquired_gib=round(st[1].value / G, 1), released_gib=round(st[2].value / G, 1),
+                    peak_used_gib=round(st[3].value / G, 2), pairs_checked_ok=st[4].value, pairs_checked_same_class=st[5].value,
+                    budget_gib=round(st[6].value / G, 1))
 
 
 class Graph:

@@ -287,7 +287,27 @@ def is_consistent(graph: ExchangeGraph) -> bool:
     return True
 
 
-CHECK_EXCHANGE_GRAPHS = os.environ.get("PA_CHECK_EXCHANGE_GRAPHS", "0") == "1"
+# one part per process: 0 = trust the graph, 1 (default) = every rank checks that its receive list is exactly the set of
+# ranks that list it as a destination (one all-gather of a P-byte mask + one all-reduce of the verdict: an edge only one
+# end knows would otherwise leave that end waiting forever in a blocking receive), 2 = the reference's full is_consistent
+CHECK_EXCHANGE_GRAPHS = int(os.environ.get("PA_CHECK_EXCHANGE_GRAPHS", "1"))
+
+
+def _edges_match(dist, group, me, world, snd_ids, rcv_ids, kw):
+    """True on every rank iff, on every rank, rcv_ids == {i : rank i sends to me} (and no neighbour is listed twice)."""
+    import torch
+    mask = torch.zeros(world, dtype=torch.uint8, **kw)
+    for q in snd_ids:
+        if 1 <= q <= world:
+            mask[q - 1] = 1
+    rows = [torch.zeros(world, dtype=torch.uint8, **kw) for _ in range(world)]
+    dist.all_gather(rows, mask, group=group)
+    senders = sorted(i + 1 for i in range(world) if int(rows[i][me - 1]))
+    ok = (senders == sorted(rcv_ids) and len(set(snd_ids)) == len(snd_ids) and len(set(rcv_ids)) == len(rcv_ids)
+          and all(1 <= q <= world for q in snd_ids))
+    flag = torch.tensor([1 if ok else 0], **kw)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item()), senders
 
 
 def exchange(snd, graph: ExchangeGraph):
@@ -300,12 +320,14 @@ def exchange(snd, graph: ExchangeGraph):
 
     One part per process (TorchDistArray): point-to-point, one message per directed edge of the graph, as the MPI
     back-end does (Irecv!/Isend per neighbour, src/mpi_array.jl:575-614) -- a rank's traffic is what ITS neighbours
-    send, independent of the number of parts.  The graph's consistency (src/primitives.jl:861-874, two all-gathers)
-    is only checked with PA_CHECK_EXCHANGE_GRAPHS=1 there; the in-process DebugArray always checks it.
+    send, independent of the number of parts.  The graph's consistency (src/primitives.jl:861-874) is checked there in its
+    cheap form by default -- every rank's receive list must be exactly the ranks that send to it, or the call asserts on
+    EVERY rank instead of leaving one end in a blocking receive (PA_CHECK_EXCHANGE_GRAPHS=0 trusts the graph, =2 runs the
+    reference's full check); the in-process DebugArray always runs the full check.
     """
     if isinstance(snd, TorchDistArray):
         import torch.distributed as dist
-        if CHECK_EXCHANGE_GRAPHS:
+        if CHECK_EXCHANGE_GRAPHS >= 2:
             assert is_consistent(graph)
         group = snd.group
         me = dist.get_rank(group) + 1
@@ -322,30 +344,37 @@ def exchange(snd, graph: ExchangeGraph):
         except Exception:                                    # noqa: BLE001
             dev = None
         kw = {} if dev is None else {"device": dev}
+        if CHECK_EXCHANGE_GRAPHS == 1:
+            ok, senders = _edges_match(dist, group, me, world, snd_ids, rcv_ids, kw)
+            assert ok, (f"inconsistent ExchangeGraph (src/primitives.jl:861-874) seen from part {me}: it expects messages from "
+                        f"{sorted(rcv_ids)}, the parts that send to it are {senders}")
+        snd_at = {q: j for j, q in enumerate(snd_ids)}                 # partner -> position (a dict, not a scan per round)
+        rcv_at = {q: j for j, q in enumerate(rcv_ids)}
 
         def grank(part):
             return part - 1 if group is None else dist.get_global_rank(group, part - 1)
         # Deadlock-free pairing without non-blocking object sends: the directed edges are served in rounds of the
         # classical pairwise schedule -- in round k rank r talks to partner (k - r) mod P; of a pair, the lower rank sends
         # first.  Every edge (i -> j) is met in exactly one round by both of its ends.
-        for k in range(world):
-            partner0 = (k - (me - 1)) % world
-            partner = partner0 + 1
+        # Only the rounds of REAL neighbours are walked (in round order, which both ends of an edge compute alike): a rank
+        # with 6 neighbours among 512 parts does 6 rounds, not 512.
+        partners = sorted(set(snd_ids) | set(rcv_ids), key=lambda q: ((q - 1) + (me - 1)) % world)
+        for partner in partners:
             if partner == me:
-                if me in snd_ids and me in rcv_ids:                   # a part that lists itself (never on this path; kept exact)
-                    out[rcv_ids.index(me)] = data[snd_ids.index(me)]
+                if me in snd_at and me in rcv_at:                     # a part that lists itself (never on this path; kept exact)
+                    out[rcv_at[me]] = data[snd_at[me]]
                 continue
-            do_send, do_recv = partner in snd_ids, partner in rcv_ids
+            do_send, do_recv = partner in snd_at, partner in rcv_at
             first_send = me < partner
             for phase in (0, 1):
                 if (phase == 0) == first_send:
                     if do_send:
-                        dist.send_object_list([data[snd_ids.index(partner)]], dst=grank(partner), group=group, **kw)
+                        dist.send_object_list([data[snd_at[partner]]], dst=grank(partner), group=group, **kw)
                 else:
                     if do_recv:
                         box = [None]
                         dist.recv_object_list(box, src=grank(partner), group=group, **kw)
-                        out[rcv_ids.index(partner)] = box[0]
+                        out[rcv_at[partner]] = box[0]
         return TorchDistArray(out, group)
     assert is_consistent(graph)
     packed = pmap(lambda ids, data: ([int(x) for x in ids], list(data)), graph.snd, snd)

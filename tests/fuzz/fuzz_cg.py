@@ -44,7 +44,7 @@ for case in range(n_cases):
     pa.mul_(b, A, xs)
     fails, out = [], []
     its = 14
-    for fn in (pa.ref_cg_, functools.partial(pa.opt_cg_, fuse=False), pa.opt_cg_):
+    for fn in (pa.ref_cg_, pa.opt_cg_, functools.partial(pa.opt_cg_, fuse=True)):
         h = []
         x, r0, r, it = fn(pa.pzeros(A.col_partition), A, b, maxiter=its, history=h)
         out.append((r0, r, it, h, [v.copy() for v in x.own_values().items]))
@@ -52,8 +52,8 @@ for case in range(n_cases):
     if not ((r0a, ra, ita) == (r0b, rb, itb) and ha == hb and all(np.array_equal(u, v) for u, v in zip(xa, xb))): fails.append("unfused != ref_cg")
     if not np.allclose(hc, ha, rtol=1e-9, atol=1e-300): fails.append("fused history")
     if P == 1:
-        g1 = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=its, graph=True)
-        g0 = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=its)
+        g1 = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=its, graph=True, fuse=True)
+        g0 = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=its, fuse=True)
         if not (g1[1:] == g0[1:] and all(np.array_equal(u, v) for u, v in zip(g1[0].own_values().items, g0[0].own_values().items))): fails.append("graph replay")
     Ao = orc.psparse_from_coo([a.copy() for a in Is], [a.copy() for a in Js], [a.copy() for a in Vs], orows)
     bo = [np.zeros(c.n_local) for c in Ao.cols]

@@ -40,3 +40,14 @@ def test_exception_on_one_rank_fails_the_job():
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "drivers", "exception_driver.py")]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0
+
+
+def test_inconsistent_exchange_graph_asserts_on_every_rank_instead_of_hanging():
+    """an edge only one end knows (a send nobody receives) used to leave the sender in a blocking call for the
+    group's timeout; the cheap consistency check that is now on by default makes every rank raise together."""
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("PA_CHECK_EXCHANGE_GRAPHS", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "drivers", "bad_graph_driver.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "exitcode: 7" in (r.stdout + r.stderr).replace("exitcode  : 7", "exitcode: 7"), (r.stdout + r.stderr)[-3000:]

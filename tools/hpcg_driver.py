@@ -120,7 +120,7 @@ def hpcg_benchmark(ranks, np_, nx, ny, nz, total_runtime=60.0, levels=4, ref_max
     opt_n_iters, worst = ref_max_iters, 0.0
     for _ in range(2):
         dt, (x, normr0, normr, iters) = elapsed(lambda: opt_cg_(pzeros(A.col_partition), A, b, maxiter=10 * ref_max_iters,
-                                                                 tolerance=ref_tol, Pl=S))
+                                                                 tolerance=ref_tol, Pl=S, fuse=True))
         if normr / normr0 > ref_tol:
             raise pa.PAError(f"the optimised solver did not reach the reference tolerance {ref_tol:.3e} in {iters} iterations")
         opt_n_iters, worst = max(opt_n_iters, iters), max(worst, dt)
@@ -132,7 +132,7 @@ def hpcg_benchmark(ranks, np_, nx, ny, nz, total_runtime=60.0, levels=4, ref_max
     norm_data, total = [], 0.0
     for _ in range(nr_sets):
         dt, (x, normr0, normr, iters) = elapsed(lambda: opt_cg_(pzeros(A.col_partition), A, b, maxiter=opt_n_iters,
-                                                                 tolerance=0.0, Pl=S, timer=timer))
+                                                                 tolerance=0.0, Pl=S, timer=timer, fuse=True))
         norm_data.append(normr / normr0)
         total += dt
     ms = timer.resolve()
