@@ -4,10 +4,10 @@
 // Reference loops: spmv_csr! src/sparse_utils.jl:649-669; muladd! src/p_sparse_matrix.jl:2088.
 // Must be compiled with -ffp-contract=off (one rounding per multiply and per add).
 //
-// Probe-only code, never compiled into libpa_hip.so: the EPI values 7-13 (variants of the y store) and the macros
-// PA_PROBE_IDENTITY_CHUNK_MAP, PA_PROBE_NO_GATHER, PA_PROBE_ONE_PLANE, PA_PROBE_TILE_X, PA_PROBE_LDS_X exist for the what-if
-// builds of tools/probe/Makefile (each gives WRONG results on purpose and answers one question about where the time goes;
-// the answers are in DESIGN.md sections 3, 6 and 8 and profiles/r02_*whatif*.log).
+// This header holds the PRODUCT kernel only.  The what-if experiments of rounds 1-2 (kernels that give wrong results on
+// purpose to answer one question about where the time goes: no gather, one plane, tile footprint, x through LDS, variants
+// of the y store) live in tools/probe/pa_spmv_probe_hooks.h, which includes this file after defining the PA_HOOK_* macros
+// below; here every hook is empty, so nothing of the lab can reach libpa_hip.so.
 #ifndef PA_SPMV_KERNEL_H
 #define PA_SPMV_KERNEL_H
 
@@ -135,6 +135,27 @@ __device__ __forceinline__ double pa_wave_sum(double v) {
 //        from the lane that holds it with ds_bpermute -- 1 byte of matrix stream per entry instead of 8.  The 27-point
 //        HPCG operator has 2 distinct values, a Q1 stiffness matrix on a uniform grid about a dozen.
 #define PA_VDICT_MAX 64
+
+// ---- hook points (empty in the product; see the comment at the top) ------------------------------------------------------
+#ifndef PA_HOOK_CHUNK_MAP            /* blockIdx -> chunk: the product's XCD-aware map */
+#define PA_HOOK_CHUNK_MAP 0
+#endif
+#ifndef PA_HOOK_PATTERN_COLS         /* after a pair of pattern columns has been decoded */
+#define PA_HOOK_PATTERN_COLS(c0, c1, r0, r1, tid)
+#endif
+#ifndef PA_HOOK_C16_COLS             /* after a pair of 16-bit columns has been decoded */
+#define PA_HOOK_C16_COLS(c0, c1, lo, hi, r0, r1, tid)
+#endif
+#ifndef PA_HOOK_X_STAGE              /* before the products: a chance to stage x somewhere */
+#define PA_HOOK_X_STAGE(x, r0, r1, tid)
+#define PA_HOOK_X_AT(x, c, r0) (x)[c]
+#endif
+#ifndef PA_HOOK_ALT_REDUCE           /* a whole other reduce phase for some EPI values (returns from the kernel) */
+#define PA_HOOK_ALT_REDUCE()
+#endif
+#ifndef PA_HOOK_STORE_Y              /* the y store of EPI values the product does not know */
+#define PA_HOOK_STORE_Y(EPI, y, row, acc) __builtin_nontemporal_store(acc, &(y)[row])
+#endif
 template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, bool VD = false, int UNR = 4, bool PADP = false>
 __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
@@ -157,14 +178,9 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
 #define PA_PSLOT(p) (PAD ? (p) + 2 * ((p) >> 5) : (p))
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-#ifdef PA_PROBE_IDENTITY_CHUNK_MAP   // probe builds only (tools/probe/placement_probe.hip)
-  const int chunk = b;
-  if (chunk >= n_chunks) return;
-#else
-  int chunk = (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
-  if (chunk >= n_chunks || (b >> 3) >= chunks_per_xcd) return;
+  int chunk = PA_HOOK_CHUNK_MAP ? b : (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
+  if (chunk >= n_chunks || (!PA_HOOK_CHUNK_MAP && (b >> 3) >= chunks_per_xcd)) return;
   if (chunk_list) chunk = chunk_list[chunk];       // a launch over some of the block's chunks (n_chunks = length of the list)
-#endif
   const int r0 = chunk_row[chunk];
   const int r1 = chunk_row[chunk + 1];
   const int p0 = crp[r0];
@@ -244,34 +260,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
           c0[k] = pa_pattern_col<PAT == 2>(idx - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
           c1[k] = pa_pattern_col<PAT == 2>(idx + 1 - p0, nq, q1, q2, q3, L0, L1, L2, L3, s0r, s1r, s2r, s3r, M0, M1, M2, M3, dA, dB);
         }
-#ifdef PA_PROBE_TILE_X                // probe builds only, 27-point 256^3: the x footprint a chunk WOULD have if its rows were a tile of
-        {                             // 4 grid lines x 14 nodes instead of 57 consecutive nodes of one line (wrong results)
-          auto tile = [&](int c) {
-            const int off = c - r0;
-            const int dz = (off + 32768) >> 16, rem = off - (dz << 16);
-            const int dy = (rem + 64) >> 8, qdx = rem - (dy << 8) + 14;                 // q + dx + 14 in [13, 71]
-            const int ly = (qdx * 4682) >> 16;                                          // qdx / 14
-            return max(r0 + (qdx - ly * 14) + ((ly - 1 + dy) << 8) + (dz << 16), 0);
-          };
-          c0[k] = tile(c0[k]);
-          c1[k] = tile(c1[k]);
-        }
-#endif
-#ifdef PA_PROBE_ONE_PLANE             // probe builds only, 27-point 256^3: every gather redirected into the row's own grid plane (the
-        {                             // dz = -1 / +1 entries read where the dz = 0 entries do): the same instruction count and the
-          auto flat = [&](int c) {    // same lines per plane, a third of the pages / L2 footprint per gather (wrong results)
-            const int off = c - r0;
-            const int dz = (off + 32768) >> 16;
-            return max(c - (dz << 16), 0);
-          };
-          c0[k] = flat(c0[k]);
-          c1[k] = flat(c1[k]);
-        }
-#endif
-#ifdef PA_PROBE_NO_GATHER             // probe builds only: lane-contiguous x reads in place of the pattern's columns (wrong results)
-        c0[k] = min(max(c0[k], 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);
-        c1[k] = min(max(c1[k], 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);
-#endif
+        PA_HOOK_PATTERN_COLS(c0[k], c1[k], r0, r1, tid);
       }
     } else if (use16) {
       unsigned q[NPT / 2];
@@ -291,10 +280,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         // (their products are never summed, but the load must stay inside the vector)
         c0[k] = min(__builtin_amdgcn_ds_bpermute((lo >> 12) << 2, mywin) + (int)(lo & 4095), max_col);
         c1[k] = min(__builtin_amdgcn_ds_bpermute((hi >> 12) << 2, mywin) + (int)(hi & 4095), max_col);
-#ifdef PA_PROBE_NO_GATHER             // probe builds only: the 16-bit path with lane-contiguous x reads (wrong results)
-        c0[k] = min(r0 + (tid & 63) + (int)(lo & 1), r1 - 1);
-        c1[k] = min(r0 + (tid & 63) + (int)(hi & 1), r1 - 1);
-#endif
+        PA_HOOK_C16_COLS(c0[k], c1[k], lo, hi, r0, r1, tid);
       }
     } else {
 #pragma unroll
@@ -314,22 +300,12 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         v[k].y = __hiloint2double(__builtin_amdgcn_ds_bpermute(s1, dict_hi), __builtin_amdgcn_ds_bpermute(s1, dict_lo));
       }
     }
-#ifdef PA_PROBE_LDS_X                  // probe builds only: three coalesced loads of x per lane into LDS, gathers from there (wrong results)
-    __shared__ double xprobe[3 * BLK];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) xprobe[tid + k * BLK] = x[min(max(r0 - BLK + tid + k * BLK, 0), r1 - 1)];
-    __syncthreads();
-#endif
+    PA_HOOK_X_STAGE(x, r0, r1, tid);
 #pragma unroll
     for (int k = 0; k < NPT / 2; ++k) {
       d2 pr;
-#ifdef PA_PROBE_LDS_X
-      pr.x = v[k].x * xprobe[(c0[k] - r0) & 511];
-      pr.y = v[k].y * xprobe[(c1[k] - r0) & 511];
-#else
-      pr.x = v[k].x * x[c0[k]];
-      pr.y = v[k].y * x[c1[k]];
-#endif
+      pr.x = v[k].x * PA_HOOK_X_AT(x, c0[k], r0);
+      pr.y = v[k].y * PA_HOOK_X_AT(x, c1[k], r0);
       if (alpha != 1.0) {
         pr.x = pr.x * alpha;
         pr.y = pr.y * alpha;
@@ -337,27 +313,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       *reinterpret_cast<d2 *>(&prod[PA_PSLOT((k * BLK + tid) * 2)]) = pr;
     }
     __syncthreads();
-    if (EPI == 11) {   // probe only: a lane owns the two rows of a 16-byte slot of y and stores them with one dwordx4
-      for (int rb = (r0 & ~1) + 2 * tid; rb < r1; rb += 2 * BLK) {
-        double acc2[2] = {0.0, 0.0};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = rb + h;
-          if (r < r0 || r >= r1) continue;
-          const int a = crp[r] - base, e = crp[r + 1] - base;
-          double acc = 0.0;
-#pragma unroll UNR
-          for (int p = a; p < e; ++p) acc = acc + prod[PA_PSLOT(p)];
-          acc2[h] = acc;
-        }
-        if (rb >= r0 && rb + 1 < r1) {
-          d2 o; o.x = acc2[0]; o.y = acc2[1];
-          __builtin_nontemporal_store(o, reinterpret_cast<d2 *>(&y[rb]));
-        } else if (rb >= r0) __builtin_nontemporal_store(acc2[0], &y[rb]);
-        else __builtin_nontemporal_store(acc2[1], &y[rb + 1]);
-      }
-      return;
-    }
+    PA_HOOK_ALT_REDUCE();
     double dacc = 0.0;                       // EPI 3: this lane's share of the dot product
     for (int r = r0 + tid; r < r1; r += BLK) {
       if (r != r0 + tid) {
@@ -380,15 +336,10 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       } else
       if (EPI == 1) gs_x[row] = gs_x[row] + (gs_b[row] - acc) / gs_diag[row];
       else if (EPI == 2) gs_x[r] = gs_b[row] - acc;
-      else if (EPI == 7) { if (acc == 123.456) y[row] = acc; }   // probe only: the kernel without its y store
-      else if (EPI == 8) y[row] = acc;                            // probe only: plain (cached) y store
-      else if (EPI == 9) y[row & 0x3ffff] = acc;                  // probe only: plain store into a 2 MiB window
-      else if (EPI == 10) __builtin_nontemporal_store(acc, &y[row & 0x3ffff]);   // probe only: nt store into the window
-      else if (EPI == 12) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(&y[row]), "v"(acc) : "memory");   // probe only
-      else if (EPI == 13) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(&y[row]), "v"(acc) : "memory");   // probe only
       // non-temporal: y is written once and not read again by this kernel; measured 3.6 % faster than the plain
       // store (0.791 vs 0.820 ms; sc1 0.797, sc0 sc1 0.807, sc0 sc1 nt 0.842, no store at all 0.681)
-      else __builtin_nontemporal_store(acc, &y[row]);
+      else if (EPI == 0) __builtin_nontemporal_store(acc, &y[row]);
+      else { PA_HOOK_STORE_Y(EPI, y, row, acc); }
     }
     if (EPI == 3) {
       dacc = pa_wave_sum(dacc);

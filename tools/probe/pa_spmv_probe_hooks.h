@@ -1,0 +1,96 @@
+// pa_spmv_probe_hooks.h -- the what-if experiments of rounds 1-2 on the product kernel, OUTSIDE the product.
+//
+// csrc/pa_spmv_kernel.h has a handful of hook points (PA_HOOK_*) that are empty in libpa_hip.so.  This header defines them
+// and then includes the product kernel, so that tools/probe/*.hip and the variant libraries of tools/probe/Makefile get the
+// same kernel with ONE thing changed.  Every experiment gives WRONG results on purpose and answers one question about
+// where the time goes; the answers are in docs/LAB_NOTEBOOK.md and profiles/r02_*whatif*.log.
+//
+//   -DPA_PROBE_IDENTITY_CHUNK_MAP  workgroup b runs chunk b (no XCD-aware dealing)          placement_probe.hip
+//   -DPA_PROBE_NO_GATHER           lane-contiguous x reads in place of the decoded columns
+//   -DPA_PROBE_ONE_PLANE           every gather folded into the row's own grid plane (27-point 256^3)
+//   -DPA_PROBE_TILE_X              the x footprint of a 4 x 14 tile instead of 57 consecutive nodes
+//   -DPA_PROBE_LDS_X               three coalesced x loads per lane into LDS, gathers from there
+//   EPI 7..13 (template argument)  variants of the y store: none / plain / 2 MiB window / nt window / 16-byte pairs / sc1 / sc0 sc1
+#ifndef PA_SPMV_PROBE_HOOKS_H
+#define PA_SPMV_PROBE_HOOKS_H
+
+#ifdef PA_PROBE_IDENTITY_CHUNK_MAP
+#define PA_HOOK_CHUNK_MAP 1
+#endif
+
+#if defined(PA_PROBE_TILE_X)
+// 27-point 256^3: the x footprint a chunk WOULD have if its rows were a tile of 4 grid lines x 14 nodes
+#define PA_HOOK_PATTERN_COLS(c0, c1, r0, r1, tid)                                                       \
+  {                                                                                                     \
+    auto tile = [&](int c) {                                                                            \
+      const int off = c - r0;                                                                           \
+      const int dz = (off + 32768) >> 16, rem = off - (dz << 16);                                       \
+      const int dy = (rem + 64) >> 8, qdx = rem - (dy << 8) + 14;                                       \
+      const int ly = (qdx * 4682) >> 16;                                                                \
+      return max(r0 + (qdx - ly * 14) + ((ly - 1 + dy) << 8) + (dz << 16), 0);                          \
+    };                                                                                                  \
+    c0 = tile(c0);                                                                                      \
+    c1 = tile(c1);                                                                                      \
+  }
+#elif defined(PA_PROBE_ONE_PLANE)
+// the dz = -1 / +1 entries read where the dz = 0 entries do: same instruction count, a third of the pages per gather
+#define PA_HOOK_PATTERN_COLS(c0, c1, r0, r1, tid)                                                       \
+  {                                                                                                     \
+    auto flat = [&](int c) { const int dz = ((c - r0) + 32768) >> 16; return max(c - (dz << 16), 0); }; \
+    c0 = flat(c0);                                                                                      \
+    c1 = flat(c1);                                                                                      \
+  }
+#elif defined(PA_PROBE_NO_GATHER)
+#define PA_HOOK_PATTERN_COLS(c0, c1, r0, r1, tid)                                                       \
+  {                                                                                                     \
+    c0 = min(max(c0, 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);                                         \
+    c1 = min(max(c1, 0) & 1, 1) + min(r0 + (tid & 63), r1 - 1);                                         \
+  }
+#define PA_HOOK_C16_COLS(c0, c1, lo, hi, r0, r1, tid)                                                   \
+  {                                                                                                     \
+    c0 = min(r0 + (tid & 63) + (int)(lo & 1), r1 - 1);                                                  \
+    c1 = min(r0 + (tid & 63) + (int)(hi & 1), r1 - 1);                                                  \
+  }
+#endif
+
+#ifdef PA_PROBE_LDS_X
+#define PA_HOOK_X_STAGE(x, r0, r1, tid)                                                                 \
+  __shared__ double xprobe[3 * BLK];                                                                    \
+  _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) xprobe[tid + k_ * BLK] = x[min(max(r0 - BLK + tid + k_ * BLK, 0), r1 - 1)]; \
+  __syncthreads();
+#define PA_HOOK_X_AT(x, c, r0) xprobe[((c) - (r0)) & 511]
+#endif
+
+// EPI 11: a lane owns the two rows of a 16-byte slot of y and stores them with one dwordx4
+#define PA_HOOK_ALT_REDUCE()                                                                            \
+  if (EPI == 11) {                                                                                      \
+    for (int rb = (r0 & ~1) + 2 * tid; rb < r1; rb += 2 * BLK) {                                        \
+      double acc2[2] = {0.0, 0.0};                                                                      \
+      _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                   \
+        const int r = rb + h;                                                                           \
+        if (r < r0 || r >= r1) continue;                                                                \
+        const int a = crp[r] - base, e = crp[r + 1] - base;                                             \
+        double acc = 0.0;                                                                               \
+        for (int p = a; p < e; ++p) acc = acc + prod[PA_PSLOT(p)];                                      \
+        acc2[h] = acc;                                                                                  \
+      }                                                                                                 \
+      if (rb >= r0 && rb + 1 < r1) {                                                                    \
+        d2 o; o.x = acc2[0]; o.y = acc2[1];                                                             \
+        __builtin_nontemporal_store(o, reinterpret_cast<d2 *>(&y[rb]));                                 \
+      } else if (rb >= r0) __builtin_nontemporal_store(acc2[0], &y[rb]);                                \
+      else __builtin_nontemporal_store(acc2[1], &y[rb + 1]);                                            \
+    }                                                                                                   \
+    return;                                                                                             \
+  }
+
+#define PA_HOOK_STORE_Y(EPI, y, row, acc)                                                                                     \
+  if (EPI == 7) { if (acc == 123.456) (y)[row] = acc; }                     /* the kernel without its y store */              \
+  else if (EPI == 8) (y)[row] = acc;                                        /* plain (cached) store */                        \
+  else if (EPI == 9) (y)[(row) & 0x3ffff] = acc;                            /* plain store into a 2 MiB window */             \
+  else if (EPI == 10) __builtin_nontemporal_store(acc, &(y)[(row) & 0x3ffff]);                                               \
+  else if (EPI == 12) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(&(y)[row]), "v"(acc) : "memory");            \
+  else if (EPI == 13) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(&(y)[row]), "v"(acc) : "memory");        \
+  else __builtin_nontemporal_store(acc, &(y)[row])
+
+#include "pa_spmv_kernel.h"
+#endif
