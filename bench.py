@@ -591,6 +591,7 @@ def main():
         dt = time.perf_counter() - t0
         m1 = time.clock_gettime_ns(time.CLOCK_MONOTONIC)
         timed.device_ms = ea.elapsed_ms(eb)
+        timed.local_s = dt                              # this rank's own wall clock (the line's per_rank section)
         if N > 1:
             tt = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -616,6 +617,7 @@ def main():
         step(overlap_on)
     PHASE[0] = f"timed mul! loop (transport {transport})"
     dt, mono0, mono1 = timed(args.steps, overlap_on)
+    local_ms_headline = timed.local_s / args.steps * 1e3
     ms_per_step = dt / args.steps * 1e3
     device_ms_per_step = timed.device_ms / args.steps       # HIP events around the whole timed region, compute stream
 
@@ -755,6 +757,23 @@ def main():
                                "(HPCG mul_no_lat!), same steps, same barriers"}
             if rank == 0:
                 LINE[0]["overlap"] = overlap
+            local_ms_other = timed.local_s / args.steps * 1e3
+            # every rank's own view, so that the first real multi-GPU record diagnoses itself: device,
+            # communicator size seen, neighbours, what its arena holds, its own ms per step with the exchange under own x own
+            # and with the exchange first, its own x own launch time
+            ar = ctx.arena()
+            cache = ind.cache or {}
+            mine = torch.tensor([rank, torch.cuda.current_device(), -1 if rccl_ranks_seen is None else rccl_ranks_seen,
+                                 len(cache.get("neighbors_snd", ())), len(cache.get("neighbors_rcv", ())), n_ghost, ar["gib"], ar["used_gib"],
+                                 local_ms_headline if overlap_on else local_ms_other, local_ms_other if overlap_on else local_ms_headline,
+                                 kern_ms_events], dtype=torch.float64)
+            rows = [torch.zeros_like(mine) for _ in range(N)]
+            dist.all_gather(rows, mine)
+            if rank == 0:
+                keys = ("rank", "cuda_device", "rccl_ranks_seen", "neighbors_snd", "neighbors_rcv", "ghosts", "arena_held_gib", "arena_used_gib",
+                        "ms_per_step_overlap_on", "ms_per_step_overlap_off", "own_own_launch_ms")
+                LINE[0]["per_rank"] = [{k: (int(v) if k in keys[:6] else round(float(v), 4)) for k, v in zip(keys, r.tolist())} for r in rows]
+                LINE[0]["per_rank_transport"] = transport
 
     # ---- optional mode, reported beside the headline and never part of `value`: the same product with the lossless value
     # dictionary (PA_SPMV_VALUE_DICT=1: one byte per stored entry instead of eight when a block has <= 64 distinct values)

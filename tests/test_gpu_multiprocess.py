@@ -110,3 +110,23 @@ def test_a_rank_lost_in_an_optional_section_does_not_cost_the_line():
     assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
     assert d["value"] > 0 and "cg_loop" not in d and d["optional_sections_unfinished"] == ["CG loop"]
     assert "overlap" in d and 0 < d["roofline"]["frac"] <= 1.0
+
+
+def test_bench_eight_ranks_sharing_the_gpu_print_a_self_diagnosing_line():
+    """VERDICT r02 #9 (first-contact insurance for the 8-GPU record): `bench.py --gpus 8 --grid 32` the way the driver
+    launches it, all eight ranks on this box's one GPU over the host-staged transport: part grid (2,2,2), every part has
+    its 7 neighbours, the line carries one `per_rank` entry per rank (device, communicator size seen, neighbours, ghosts,
+    what its arena holds, its own ms per step with the exchange under own x own and with the exchange first), and no
+    rank's context holds HBM it does not use (eight ranks next to each other on one device: the on-demand arena)."""
+    r, d = _bench(8, {"PA_TRANSPORT": "host", "PA_BENCH_BACKEND": "gloo"}, ("--no-cpu-baseline",))
+    assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert d["n_gpus"] == 8 and "(2,2,2)" in d["config"]["workload"] and d["config"]["transport"].startswith("host-staged")
+    assert d["parity_gate"].startswith("A*1==b")
+    pr = d["per_rank"]
+    assert [e["rank"] for e in pr] == list(range(8)) and d["per_rank_transport"] == "host"
+    for e in pr:
+        assert e["neighbors_snd"] == 7 and e["neighbors_rcv"] == 7 and e["ghosts"] == 3 * 32 * 32 + 3 * 32 + 1, e
+        assert e["arena_held_gib"] <= 1.0, e                         # (32^3 rows per part: nothing big enough to start an arena)
+        assert e["ms_per_step_overlap_on"] > 0 and e["ms_per_step_overlap_off"] > 0 and e["own_own_launch_ms"] > 0, e
+    assert set(d["overlap"]) >= {"ms_per_step_on", "ms_per_step_off"}
+    assert abs(d["value"] - 2 * d["config"]["nnz_per_part"] * 8 / d["ms_per_step"] / 1e6) / d["value"] < 0.05   # (parts differ by their ghosts)
