@@ -100,6 +100,11 @@ int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class
 int pa_ctx_arena_map(pa_ctx *ctx, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells);
 int pa_ctx_arena_stats(pa_ctx *ctx, int64_t *n_extents, int64_t *bytes_acquired, int64_t *bytes_released, int64_t *peak_used,
                        int64_t *pairs_ok, int64_t *pairs_failed, int64_t *budget);
+/* testing aid: a host copy of one of the arrays the product kernel reads (first slab of the block) -- 0 row pointers,
+ * 1 32-bit columns, 2 16-bit codes, 3 windows, 4 pattern descriptors, 5 pattern table, 6 chunk table, 7 compacted row ids;
+ * *bytes = the array's size, copied when capacity allows.  The set-up runs on the device (csrc/pa_setup.hip; PA_SETUP_DEVICE=0:
+ * the host encoder): the tests compare the two builds of every array with this. */
+int pa_csr_debug_array(const pa_csr *A, int which, void *host, int64_t capacity, int64_t *bytes);
 int pa_csr_memory_class(const pa_csr *A, int *cls);
 int pa_vec_memory_class(const pa_vec *v, int *cls);
 

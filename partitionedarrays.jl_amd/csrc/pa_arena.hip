@@ -296,7 +296,8 @@ static void arena_trim(pa_arena *a) {
   static const int spare = getenv("PA_ARENA_SPARE") ? std::max(0, atoi(getenv("PA_ARENA_SPARE"))) : 1;
   std::vector<pa_extent *> empty;
   for (pa_extent *X : a->ext) if (X->live == 0) empty.push_back(X);
-  for (size_t i = 0; i + spare < empty.size(); ++i) arena_release(a, empty[i]);     // (ext is in order of acquisition: the oldest go)
+  const size_t keep = a->used > 0 ? (size_t)spare : 0;   // (a context that holds nothing any more holds no spare either)
+  for (size_t i = 0; i + keep < empty.size(); ++i) arena_release(a, empty[i]);      // (ext is in order of acquisition: the oldest go)
 }
 
 static int arena_init(pa_ctx *c) {

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "pa_internal.h"
+#include "pa_setup.h"
 
 thread_local std::string g_pa_err;
 
@@ -741,65 +742,114 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   A->compact = compact;
   PA_HIP(hipSetDevice(c->device));
   const size_t pad = 8;
-  // column streams first: they decide what has to live in HBM at all (see pa_encode_columns).  PA_SPMV_PATTERN=0 /
+  // Column streams: they decide what has to live in HBM at all (see pa_encode_columns).  PA_SPMV_PATTERN=0 /
   // PA_SPMV_COL16=0 disable the row-pattern descriptors / the 16-bit windowed stream.
-  pa_col_streams cs;
-  {
-    const char *ep = getenv("PA_SPMV_PATTERN"), *e16 = getenv("PA_SPMV_COL16"), *ec = getenv("PA_SPMV_COMPACT_STREAMS");
-    pa_encode_columns(crp.data(), col0, compact ? row_ids.data() : nullptr, nc, chunk_row, PA_SPMV_CHUNK_NNZ,
-                      !(ep && atoi(ep) == 0) && nnz > 0, !(e16 && atoi(e16) == 0) && nnz > 0, host_threads(nnz), cs,
-                      !(ec && atoi(ec) == 0));
-  }
-  lap("encode");
-  A->use_pattern = cs.use_pattern; A->use_c16 = cs.use_c16;
-  if (!cs.use_pattern && nc > 0) {                         // (see PADP in pa_spmv_kernel.h)
-    int64_t mult8 = 0, nonempty = 0;
-    for (int64_t r = 0; r < nc; ++r) {
-      const int32_t len = crp[r + 1] - crp[r];
-      nonempty += len > 0;
-      mult8 += len > 0 && (len & 7) == 0;
-    }
-    A->pad_products = mult8 * 2 > nonempty;
-  }
-  A->n_pattern_chunks = cs.n_pattern; A->n_c16_chunks = cs.n_c16; A->n_c32_chunks = cs.n_c32;
-  A->n_c16_fallback = cs.use_c16 ? A->n_chunks - cs.n_pattern - cs.n_c16 : 0;
-  A->n_col32 = cs.full ? nnz : (int64_t)cs.c32.size() - (int64_t)pad;
-  for (int64_t ch = 0; ch < A->n_chunks; ++ch) {           // stored entries by the column encoding their chunk reads
-    const int64_t ne = (int64_t)crp[chunk_row[ch + 1]] - crp[chunk_row[ch]];
-    if (cs.use_pattern && cs.pdesc[(size_t)ch * PA_PDESC_INTS] > 0) continue;
-    if (cs.use_c16 && cs.win[(size_t)ch * PA_C16_WINDOWS] >= 0 && ne + (crp[chunk_row[ch]] & 1) <= PA_SPMV_CHUNK_NNZ) A->nnz_c16 += ne;
-    else A->nnz_c32 += ne;
-  }
+  // Round 3: the encoding runs ON THE DEVICE (pa_setup.hip) over the raw CSR uploaded first -- row hashes, a radix sort,
+  // per-chunk descriptors, window tags and codes as kernels; PA_SETUP_DEVICE=0 keeps the host encoder below, whose arrays
+  // the device's equal byte for byte (tests/...test_device_side_encoding_equals_the_host_s).
+  const char *ep = getenv("PA_SPMV_PATTERN"), *e16 = getenv("PA_SPMV_COL16"), *ec = getenv("PA_SPMV_COMPACT_STREAMS"), *ed = getenv("PA_SETUP_DEVICE");
+  const bool want_pattern = !(ep && atoi(ep) == 0) && nnz > 0, want_c16 = !(e16 && atoi(e16) == 0) && nnz > 0;
+  const bool compact_streams = !(ec && atoi(ec) == 0), on_device = !(ed && atoi(ed) == 0) && nnz > 0;
   // (the value stream first: it is the allocation that brings the context's arena into being, pa_arena.hip)
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_val, sizeof(double) * (nnz + pad), PA_MEM_MATRIX));
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_crp, sizeof(int32_t) * (nc + 1), PA_MEM_MATRIX));
-  PA_TRY(pa_dev_alloc(c, (void **)&A->d_col, sizeof(int32_t) * (A->n_col32 + pad), PA_MEM_MATRIX));
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_row, sizeof(int32_t) * chunk_row.size(), PA_MEM_MATRIX));
-  PA_HIP(hipMemsetAsync(A->d_col + A->n_col32, 0, sizeof(int32_t) * pad, c->s[0]));   // (the streams are non-blocking: a
-  PA_HIP(hipMemsetAsync(A->d_val + nnz, 0, sizeof(double) * pad, c->s[0]));            // null-stream memset would not be ordered
-  PA_HIP(hipStreamSynchronize(c->s[0]));                                               // with the kernels that read the padding)
+  PA_HIP(hipMemsetAsync(A->d_val + nnz, 0, sizeof(double) * pad, c->s[0]));            // (the streams are non-blocking: a null-stream
+  PA_HIP(hipStreamSynchronize(c->s[0]));                                               // memset would not be ordered with the kernels)
   PA_HIP(pa_h2d(A->d_crp, crp.data(), sizeof(int32_t) * (nc + 1)));
-  if (nnz) {
-    if (cs.full) PA_HIP(pa_h2d(A->d_col, col0, sizeof(int32_t) * nnz));
-    else if (A->n_col32) PA_HIP(pa_h2d(A->d_col, cs.c32.data(), sizeof(int32_t) * A->n_col32));
-    PA_HIP(pa_h2d(A->d_val, nzval, sizeof(double) * nnz));
-  }
+  if (nnz) PA_HIP(pa_h2d(A->d_val, nzval, sizeof(double) * nnz));
   PA_HIP(pa_h2d(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size()));
-  if (cs.use_c16) {
-    A->n_col16 = (int64_t)cs.c16.size();
-    PA_TRY(pa_dev_alloc(c, (void **)&A->d_col16, sizeof(uint16_t) * cs.c16.size(), PA_MEM_MATRIX));
-    PA_TRY(pa_dev_alloc(c, (void **)&A->d_win, sizeof(int32_t) * std::max<size_t>(1, cs.win.size()), PA_MEM_MATRIX));
-    PA_HIP(pa_h2d(A->d_col16, cs.c16.data(), sizeof(uint16_t) * cs.c16.size()));
-    if (!cs.win.empty()) PA_HIP(pa_h2d(A->d_win, cs.win.data(), sizeof(int32_t) * cs.win.size()));
+  if (compact) {
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc), PA_MEM_MATRIX));
+    if (nc) PA_HIP(pa_h2d(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc));
+  }
+  lap("upload");
+  pa_col_streams cs;                       // host encoder's arrays (PA_SETUP_DEVICE=0); `win` also when the x windows are planned
+  if (on_device) {
+    // the raw columns go up whole; a block with row patterns keeps only the compacted streams made from them
+    int32_t *d_colfull = nullptr;
+    PA_TRY(pa_dev_alloc(c, (void **)&d_colfull, sizeof(int32_t) * (nnz + pad), PA_MEM_MATRIX));
+    A->d_col = d_colfull;                  // (owned by A from here on: a failure below frees it with the block)
+    PA_HIP(hipMemsetAsync(d_colfull + nnz, 0, sizeof(int32_t) * pad, c->s[0]));
+    PA_HIP(hipStreamSynchronize(c->s[0]));
+    PA_HIP(pa_h2d(d_colfull, col0, sizeof(int32_t) * nnz));
+    lap("columns up");
+    pa_dev_streams ds;
+    PA_TRY(pa_dev_encode_columns(c, A->d_crp, d_colfull, A->d_row_ids, nc, nnz, A->d_chunk_row, A->n_chunks, PA_SPMV_CHUNK_NNZ,
+                                 want_pattern, want_c16, compact_streams, ds));
+    A->use_pattern = ds.use_pattern; A->use_c16 = ds.use_c16; A->pad_products = ds.pad_products;
+    A->n_pattern_chunks = ds.n_pattern; A->n_c16_chunks = ds.n_c16; A->n_c32_chunks = ds.n_c32;
+    A->n_c16_fallback = ds.use_c16 ? A->n_chunks - ds.n_pattern - ds.n_c16 : 0;
+    A->nnz_c16 = ds.nnz_c16; A->nnz_c32 = ds.nnz_c32;
+    A->d_pdesc = ds.d_pdesc; A->d_pdelta = ds.d_pdelta; A->n_pdelta = ds.n_pdelta;
+    A->d_win = ds.d_win; A->d_col16 = ds.d_c16; A->n_col16 = ds.n_c16_slots;
+    if (ds.full) A->n_col32 = nnz;
+    else {
+      A->d_col = ds.d_c32; A->n_col32 = ds.n_c32_slots;
+      PA_HIP(hipStreamSynchronize(c->s[0]));
+      pa_dev_free(c, d_colfull);
+    }
+    cs.use_pattern = ds.use_pattern; cs.use_c16 = ds.use_c16; cs.full = ds.full;
+    if (tm_) fprintf(stderr, "[pa setup] device encode %.3f ms: %lld pattern / %lld c16 / %lld c32 chunks\n", ds.ms, (long long)ds.n_pattern,
+                     (long long)ds.n_c16, (long long)ds.n_c32);
+    lap("encode");
+  } else {
+    pa_encode_columns(crp.data(), col0, compact ? row_ids.data() : nullptr, nc, chunk_row, PA_SPMV_CHUNK_NNZ, want_pattern, want_c16,
+                      host_threads(nnz), cs, compact_streams);
+    lap("encode");
+    A->use_pattern = cs.use_pattern; A->use_c16 = cs.use_c16;
+    if (!cs.use_pattern && nc > 0) {                         // (see PADP in pa_spmv_kernel.h)
+      int64_t mult8 = 0, nonempty = 0;
+      for (int64_t r = 0; r < nc; ++r) {
+        const int32_t len = crp[r + 1] - crp[r];
+        nonempty += len > 0;
+        mult8 += len > 0 && (len & 7) == 0;
+      }
+      A->pad_products = mult8 * 2 > nonempty;
+    }
+    A->n_pattern_chunks = cs.n_pattern; A->n_c16_chunks = cs.n_c16; A->n_c32_chunks = cs.n_c32;
+    A->n_c16_fallback = cs.use_c16 ? A->n_chunks - cs.n_pattern - cs.n_c16 : 0;
+    A->n_col32 = cs.full ? nnz : (int64_t)cs.c32.size() - (int64_t)pad;
+    for (int64_t ch = 0; ch < A->n_chunks; ++ch) {           // stored entries by the column encoding their chunk reads
+      const int64_t ne = (int64_t)crp[chunk_row[ch + 1]] - crp[chunk_row[ch]];
+      if (cs.use_pattern && cs.pdesc[(size_t)ch * PA_PDESC_INTS] > 0) continue;
+      if (cs.use_c16 && cs.win[(size_t)ch * PA_C16_WINDOWS] >= 0 && ne + (crp[chunk_row[ch]] & 1) <= PA_SPMV_CHUNK_NNZ) A->nnz_c16 += ne;
+      else A->nnz_c32 += ne;
+    }
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_col, sizeof(int32_t) * (A->n_col32 + pad), PA_MEM_MATRIX));
+    PA_HIP(hipMemsetAsync(A->d_col + A->n_col32, 0, sizeof(int32_t) * pad, c->s[0]));
+    PA_HIP(hipStreamSynchronize(c->s[0]));
+    if (nnz) {
+      if (cs.full) PA_HIP(pa_h2d(A->d_col, col0, sizeof(int32_t) * nnz));
+      else if (A->n_col32) PA_HIP(pa_h2d(A->d_col, cs.c32.data(), sizeof(int32_t) * A->n_col32));
+    }
+    if (cs.use_c16) {
+      A->n_col16 = (int64_t)cs.c16.size();
+      PA_TRY(pa_dev_alloc(c, (void **)&A->d_col16, sizeof(uint16_t) * cs.c16.size(), PA_MEM_MATRIX));
+      PA_TRY(pa_dev_alloc(c, (void **)&A->d_win, sizeof(int32_t) * std::max<size_t>(1, cs.win.size()), PA_MEM_MATRIX));
+      PA_HIP(pa_h2d(A->d_col16, cs.c16.data(), sizeof(uint16_t) * cs.c16.size()));
+      if (!cs.win.empty()) PA_HIP(pa_h2d(A->d_win, cs.win.data(), sizeof(int32_t) * cs.win.size()));
+    }
+    if (cs.use_pattern) {
+      PA_TRY(pa_dev_alloc(c, (void **)&A->d_pdesc, sizeof(int32_t) * cs.pdesc.size(), PA_MEM_MATRIX));
+      A->n_pdelta = (int64_t)cs.pdelta.size();
+      PA_TRY(pa_dev_alloc(c, (void **)&A->d_pdelta, sizeof(int32_t) * cs.pdelta.size(), PA_MEM_MATRIX));
+      PA_HIP(pa_h2d(A->d_pdesc, cs.pdesc.data(), sizeof(int32_t) * cs.pdesc.size()));
+      PA_HIP(pa_h2d(A->d_pdelta, cs.pdelta.data(), sizeof(int32_t) * cs.pdelta.size()));
+    }
+    lap("streams up");
   }
   // Rows without a pattern whose columns stay within a band: groups of chunks read x from an LDS copy of their span
   // (pa_spmv_xwin.h).  Taken when most of the block's chunks fall into groups and the staged x is a fraction of the matrix
   // bytes the groups stream; PA_SPMV_XWIN=0 keeps every chunk on k_spmv_rowsplit.
-  lap("upload");
   {
     const char *ex = getenv("PA_SPMV_XWIN");
     if (cs.use_c16 && !cs.use_pattern && !compact && !(ex && atoi(ex) == 0) && A->n_chunks >= 64) {
       const bool forced = ex && atoi(ex) == 2;
+      if (on_device) {                     // the windows were made on the device: the (host-side) grouping reads them
+        cs.win.resize((size_t)A->n_chunks * PA_C16_WINDOWS);
+        PA_HIP(hipMemcpy(cs.win.data(), A->d_win, sizeof(int32_t) * cs.win.size(), hipMemcpyDeviceToHost));
+      }
       pa_xw_plan P;
       pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz));
       const std::vector<pa_xw_group> &groups = P.groups;
@@ -826,14 +876,7 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
                        A->n_xw_groups ? "used" : "not used");
     }
   }
-  if (cs.use_pattern) {
-    PA_TRY(pa_dev_alloc(c, (void **)&A->d_pdesc, sizeof(int32_t) * cs.pdesc.size(), PA_MEM_MATRIX));
-    A->n_pdelta = (int64_t)cs.pdelta.size();
-    PA_TRY(pa_dev_alloc(c, (void **)&A->d_pdelta, sizeof(int32_t) * cs.pdelta.size(), PA_MEM_MATRIX));
-    PA_HIP(pa_h2d(A->d_pdesc, cs.pdesc.data(), sizeof(int32_t) * cs.pdesc.size()));
-    PA_HIP(pa_h2d(A->d_pdelta, cs.pdelta.data(), sizeof(int32_t) * cs.pdelta.size()));
-  }
-  lap("descriptors");
+  lap("x windows");
   if (tm_) fprintf(stderr, "[pa setup] val %p (%lld B, memory class %d) col %p crp %p chunk_row %p pdesc %p\n", (void *)A->d_val,
                    (long long)(8 * (nnz + pad)), pa_mem_class(c, A->d_val), (void *)A->d_col, (void *)A->d_crp, (void *)A->d_chunk_row, (void *)A->d_pdesc);
   // optional lossless value dictionary (PA_SPMV_VALUE_DICT=1): at most PA_VDICT_MAX distinct bit patterns
@@ -900,10 +943,6 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
         A->n_dict = (int)dict.size();
       }
     }
-  }
-  if (compact) {
-    PA_TRY(pa_dev_alloc(c, (void **)&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc), PA_MEM_MATRIX));
-    if (nc) PA_HIP(pa_h2d(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc));
   }
   return PA_OK;
 }
@@ -991,7 +1030,19 @@ extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, in
   const int32_t *col0 = nullptr;
   if (colval_bytes == 4 && index_base == 0) {
     col0 = (const int32_t *)colval;                      // already what the device wants: no copy of a multi-GB array
-    for (int64_t p = 0; p < nnz; ++p) PA_REQUIRE(col0[p] >= 0 && col0[p] < n_cols, "column index out of range at entry %lld", (long long)p);
+    const int T = host_threads(nnz);
+    std::vector<int64_t> bad(T, -1);
+    auto chk = [&](int t) {
+      for (int64_t p = nnz * t / T; p < nnz * (t + 1) / T; ++p)
+        if (col0[p] < 0 || col0[p] >= n_cols) { bad[t] = p; return; }
+    };
+    {
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; ++t) th.emplace_back(chk, t);
+      chk(0);
+      for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < T; ++t) PA_REQUIRE(bad[t] < 0, "column index out of range at entry %lld", (long long)bad[t]);
   } else {
     colbuf.reset(new int32_t[std::max<int64_t>(1, nnz)]);
     const int T = host_threads(nnz);
@@ -1196,6 +1247,34 @@ extern "C" int pa_host_check_spmv_encodings(int64_t n_rows, int64_t n_cols, int6
   if (n_c16) *n_c16 = nch - nfall;             // (of the full-length encoding: what the 16-bit windows COULD carry)
   if (n_patterns) *n_patterns = (int64_t)pdelta.size() / PA_PAT_MAXLEN;
   (void)n_cols;
+  return PA_OK;
+}
+
+// Debugging / testing: a copy of one of the arrays the product kernel reads (first slab), so that two ways of building
+// them can be compared byte for byte.  which: 0 row pointers, 1 32-bit columns, 2 16-bit codes, 3 windows, 4 pattern
+// descriptors, 5 pattern table, 6 chunk table, 7 compacted row ids.  *bytes = size of the array; copied when it fits.
+extern "C" int pa_csr_debug_array(const pa_csr *A, int which, void *host, int64_t capacity, int64_t *bytes) {
+  PA_REQUIRE(A && bytes, "bad arguments");
+  const int64_t pad = 8;
+  const void *d = nullptr;
+  int64_t n = 0;
+  switch (which) {
+    case 0: d = A->d_crp; n = 4 * (A->n_crows + 1); break;
+    case 1: d = A->d_col; n = 4 * (A->n_col32 + pad); break;
+    case 2: d = A->d_col16; n = A->d_col16 ? 2 * A->n_col16 : 0; break;
+    case 3: d = A->d_win; n = A->d_win ? 4 * A->n_chunks * PA_C16_WINDOWS : 0; break;
+    case 4: d = A->d_pdesc; n = A->d_pdesc ? 4 * A->n_chunks * PA_PDESC_INTS : 0; break;
+    case 5: d = A->d_pdelta; n = A->d_pdelta ? 4 * A->n_pdelta : 0; break;
+    case 6: d = A->d_chunk_row; n = 4 * (A->n_chunks + 1); break;
+    case 7: d = A->d_row_ids; n = A->d_row_ids ? 4 * A->n_crows : 0; break;
+    default: pa_set_err("unknown array %d", which); return PA_ERR_ARG;
+  }
+  *bytes = n;
+  if (host && n > 0 && n <= capacity) {
+    PA_HIP(hipSetDevice(A->ctx->device));
+    PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
+    PA_HIP(hipMemcpy(host, d, (size_t)n, hipMemcpyDeviceToHost));
+  }
   return PA_OK;
 }
 

@@ -1,0 +1,36 @@
+// pa_setup.h -- device-side set-up of a CSR block's column encodings (pa_setup.hip); private to libpa_hip.so.
+#ifndef PA_SETUP_H
+#define PA_SETUP_H
+
+#include <cstdint>
+
+#include "pa_internal.h"
+
+// The column streams of one block exactly as k_spmv_rowsplit reads them, built ON THE DEVICE from the block's raw CSR
+// arrays (0-based Int32 row pointers and columns already in HBM): the device twin of pa_encode_columns
+// (pa_spmv_kernel.h), array for array and byte for byte (tests/test_gpu_parity.py::test_device_side_encoding_equals_the_host_s).
+struct pa_dev_streams {
+  bool use_pattern = false, use_c16 = false, full = true;
+  int32_t *d_pdesc = nullptr;    // n_chunks * PA_PDESC_INTS (only when use_pattern)
+  int32_t *d_pdelta = nullptr;   // n_pdelta ints
+  int32_t *d_win = nullptr;      // n_chunks * PA_C16_WINDOWS (only when use_c16)
+  uint16_t *d_c16 = nullptr;     // n_c16_slots entries (padding included)
+  int32_t *d_c32 = nullptr;      // compacted 32-bit columns, n_c32_slots entries + padding (only when !full)
+  int64_t n_pdelta = 0, n_c16_slots = 0, n_c32_slots = 0;
+  int64_t n_pattern = 0, n_c16 = 0, n_c32 = 0;   // chunks by column encoding
+  int64_t nnz_c16 = 0, nnz_c32 = 0;              // stored entries whose chunk reads the 16-bit stream / 32-bit columns
+  bool pad_products = false;
+  double ms = 0;                                 // device time of the encoding (events)
+};
+
+// d_crp[nc + 1], d_col[nnz (+ padding)], d_row_ids[nc] or NULL, d_chunk_row[n_chunks + 1]: device arrays, 0-based.
+// Output buffers are taken with pa_dev_alloc(..., PA_MEM_MATRIX); on failure everything taken so far is handed back.
+int pa_dev_encode_columns(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int32_t *d_row_ids, int64_t nc,
+                          int64_t nnz, const int32_t *d_chunk_row, int64_t n_chunks, int cap, bool want_pattern,
+                          bool want_c16, bool compact_streams, pa_dev_streams &S);
+void pa_dev_streams_free(pa_ctx *c, pa_dev_streams &S);
+
+// min / max of a device Int32 array (column range check of an uploaded block)
+int pa_dev_minmax_i32(pa_ctx *c, const int32_t *d, int64_t n, int32_t *mn, int32_t *mx);
+
+#endif

@@ -143,6 +143,19 @@ class DeviceCSR:
         L.call("pa_csr_value_dict", self.h, C.byref(n))
         return n.value
 
+    def debug_arrays(self):
+        """Host copies of the arrays the product kernel reads (pa_csr_debug_array; first slab): a testing aid."""
+        out = {}
+        for which, (name, dt) in enumerate((("crp", np.int32), ("col", np.int32), ("col16", np.uint16), ("win", np.int32),
+                                            ("pdesc", np.int32), ("pdelta", np.int32), ("chunk_row", np.int32), ("row_ids", np.int32))):
+            n = C.c_int64()
+            L.call("pa_csr_debug_array", self.h, which, None, 0, C.byref(n))
+            a = np.zeros(n.value // np.dtype(dt).itemsize, dt)
+            if n.value:
+                L.call("pa_csr_debug_array", self.h, which, L.ptr(a), n.value, C.byref(n))
+            out[name] = a
+        return out
+
     def update_values(self, nzval):
         nzval = np.ascontiguousarray(nzval, F64)
         assert len(nzval) == self.nnz

@@ -1936,3 +1936,73 @@ def test_multicolor_gauss_seidel_as_hpcg_optimised_variant(golden, ordering):
     assert it < 2 * c["maxiter"]                                                     # in practice a few iterations more
     for vals in x.own_values().items:
         assert np.allclose(vals, 1.0, atol=1e-9)                                     # b = A*1
+
+
+def _encoding_cases(orc):
+    """Blocks that exercise every branch of the column encoders: stencils (row patterns), a 7-point Laplacian (patterns + a few
+    explicit chunks), ragged and empty rows, rows longer than a chunk and longer than a pattern, columns all over (32-bit
+    chunks), banded random rows (16-bit windows, x-window groups), a block that is mostly empty rows (row-compacted, patterns
+    with a row-id stride: one Gauss-Seidel colour) and a mixed block (half stencil, half random)."""
+    rng = np.random.default_rng(11)
+
+    def csr(m, n, rows):
+        rp = np.zeros(m + 1, np.int64)
+        for i, r in enumerate(rows):
+            rp[i + 1] = rp[i] + len(r)
+        cols = np.concatenate([np.asarray(r, np.int64) for r in rows]) if rp[-1] else np.zeros(0, np.int64)
+        return pa.HostCSR(m, n, (rp + 1).astype(np.int32), (cols + 1).astype(np.int32), rng.standard_normal(int(rp[-1])))
+    Ao, _, _ = orc.hpcg_build_p_matrix(24, 24, 24, 1, 1, 1)
+    oo = Ao.blocks[0].own_own
+    yield "27-point 24^3", pa.HostCSR(oo.m, oo.n, oo.rowptr, oo.colval, oo.nzval)
+    Io, Jo, Vo, rows, _ = orc.laplacian_fdm_fast((40, 40, 40), (1, 1, 1))
+    B = orc.psparse_from_coo(Io, Jo, Vo, rows).blocks[0].own_own
+    yield "7-point 40^3", pa.HostCSR(B.m, B.n, B.rowptr, B.colval, B.nzval)
+    m = 60000
+    yield "ragged rows", csr(m, m, [np.sort(rng.choice(m, size=int(k), replace=False)) for k in rng.integers(0, 40, size=m)])
+    rows = [np.sort(np.clip(i + rng.integers(-1500, 1500, size=16), 0, m - 1)) for i in range(m)]
+    rows = [np.unique(r) for r in rows]
+    yield "banded random rows", csr(m, m, rows)
+    rows = [np.arange(max(0, i - 1), min(m, i + 2)) for i in range(m)]
+    rows[100] = np.sort(rng.choice(m, size=5000, replace=False))           # a row longer than a chunk
+    rows[2000] = np.sort(rng.choice(m, size=40, replace=False))            # longer than a pattern
+    rows[3000] = np.zeros(0, np.int64)
+    yield "tridiagonal with long rows", csr(m, m, rows)
+    oo_rows = [oo.colval[oo.rowptr[r] - 1:oo.rowptr[r + 1] - 1] - 1 if (r % 2 == 0 and (r // 24) % 2 == 0 and (r // 576) % 2 == 0) else np.zeros(0, np.int64)
+               for r in range(oo.m)]
+    yield "one colour of the 27-point operator (row-compacted, strided patterns)", csr(oo.m, oo.n, oo_rows)
+    half = [oo.colval[oo.rowptr[r] - 1:oo.rowptr[r + 1] - 1] - 1 if r < oo.m // 2 else np.sort(rng.choice(oo.n, size=20, replace=False))
+            for r in range(oo.m)]
+    yield "half stencil, half scattered rows", csr(oo.m, oo.n, half)
+    yield "scattered rows", csr(20000, 300000, [np.sort(rng.choice(300000, size=12, replace=False)) for _ in range(20000)])
+
+
+def test_device_side_encoding_equals_the_host_s(orc, monkeypatch):
+    """the column encodings of a block are built by kernels over the uploaded CSR (csrc/pa_setup.hip: row
+    hashes, radix sort, per-chunk descriptors, window tags, compacted streams).  Every array the product kernel reads --
+    pattern descriptors and table, windows, 16-bit codes, compacted 32-bit columns -- must equal, byte for byte, what the
+    host encoder (PA_SETUP_DEVICE=0; pa_encode_columns, itself pinned by pa_host_check_spmv_encodings) builds, in every
+    mode (patterns on / off, 16-bit stream on / off, compacted streams on / off), and the product must keep its bits."""
+    modes = [{}, {"PA_SPMV_PATTERN": "0"}, {"PA_SPMV_PATTERN": "0", "PA_SPMV_COL16": "0"}, {"PA_SPMV_COMPACT_STREAMS": "0"}, {"PA_SPMV_COL16": "0"}]
+    for name, H in _encoding_cases(orc):
+        xh = np.random.default_rng(3).standard_normal(H.n)
+        want = np.zeros(H.m)
+        orc.oracle_c().spmv_csr(want, xh, orc.CSR(H.m, H.n, H.rowptr, H.colval, H.nzval))
+        x = pa.DeviceVector(H.n, 0).upload(xh)
+        for mode in modes:
+            for k in ("PA_SPMV_PATTERN", "PA_SPMV_COL16", "PA_SPMV_COMPACT_STREAMS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in mode.items():
+                monkeypatch.setenv(k, v)
+            built = {}
+            for dev in ("0", "1"):
+                monkeypatch.setenv("PA_SETUP_DEVICE", dev)
+                blk = pa.DeviceCSR(H)
+                y = pa.DeviceVector(H.m, 0)
+                pa.spmv_(y, blk, x)
+                built[dev] = (blk.debug_arrays(), blk.encoding(), blk.stream_bytes(), blk.device_bytes(), blk.xwin(), y.download())
+            h, d = built["0"], built["1"]
+            assert h[1] == d[1] and h[2] == d[2] and h[3] == d[3] and h[4] == d[4], (name, mode, h[1:5], d[1:5])
+            for key in h[0]:
+                assert h[0][key].shape == d[0][key].shape and np.array_equal(h[0][key], d[0][key]), (name, mode, key)
+            assert np.array_equal(h[5], want) and np.array_equal(d[5], want), (name, mode)
+    monkeypatch.delenv("PA_SETUP_DEVICE")

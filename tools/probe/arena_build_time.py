@@ -1,7 +1,7 @@
 """What the context's arena costs to build, by size (PA_ARENA_GIB)."""
 import os, sys, time, subprocess
 if len(sys.argv) == 2:
-    sys.path.insert(0, '.')
+    import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
     from __graft_entry__ import load_package
     pa = load_package()
     ctx = pa.context()

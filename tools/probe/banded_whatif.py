@@ -1,6 +1,6 @@
 """Banded-unstructured rows through the library named by PA_HIP_LIBRARY (probe builds: LDS pad, lane-contiguous x reads)."""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,6 +1,6 @@
 """A part with more than 2^31 stored entries (27-pt, 432^3 rows): set-up time, slabs, SpMV rate, A*1 == b."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,6 +1,6 @@
 """One large part (n^3 rows of the 27-point operator) on one GPU with the arena: where things land and how fast mul! runs."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

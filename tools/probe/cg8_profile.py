@@ -1,6 +1,6 @@
 """BASELINE config 4 on ONE GPU (8 parts x 256^3 resident): CG iterations for a per-kernel rocprofv3 profile."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256

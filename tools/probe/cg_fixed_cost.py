@@ -1,6 +1,6 @@
 """Fixed cost of one opt_cg_ solve with the multigrid preconditioner (what a CG set pays besides its iterations)."""
 import sys, time, cProfile, pstats
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256

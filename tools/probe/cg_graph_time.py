@@ -1,6 +1,6 @@
 """CG iteration time, eager launches vs hipGraph replay, for small parts (launch-bound) up to 256^3."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 for n in (16, 32, 64, 128, 256):

@@ -1,7 +1,7 @@
 """One part, 27-pt n^3: `iters` iterations of opt_cg_ (fused and unfused) for a kernel trace.
    rocprofv3 --kernel-trace --stats -d gpurun_out/prof_cg -- python tools/probe/cg_profile.py 256 30"""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -1,6 +1,6 @@
 """Time per CG iteration (BASELINE config 4's loop on one part): ref_cg_ with Identity preconditioner."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -1,7 +1,7 @@
 """One CG iteration (identity preconditioner) on a symmetric, diagonally dominant matrix without any structure: 4 M rows,
 ~17 entries per row inside a band of +-2000, one part.  ms per iteration of ref_cg_, opt_cg_(fuse=False) and opt_cg_."""
 import sys, time, functools
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,7 +1,7 @@
 """Is the product kernel's fast/slow mode a clock / power state?  Long K1 loops on several block re-creations while a
 thread samples the sysfs clock levels and the socket power."""
 import glob, sys, threading, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,6 +1,6 @@
 """BASELINE config 2: 7-point Laplacian 256^3, one part, SpMV only."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

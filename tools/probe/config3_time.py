@@ -1,6 +1,6 @@
 """BASELINE config 3 (27-pt 128^3 per part, 2 parts) on one GPU: per-step cost of mul! composed from Python vs one call."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 for n, P, shape in ((128, 2, (2, 1, 1)), (128, 8, (2, 2, 2)), (64, 8, (2, 2, 2))):

@@ -1,6 +1,6 @@
 """BASELINE config 5 at size: gallery laplacian_fem on n x n nodes, 8 parts (4,2): set-up and mul! timings on one GPU."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

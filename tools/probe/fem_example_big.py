@@ -1,6 +1,6 @@
 """test/fem_example.jl at benchmark size: set-up, assembly and mul! timings on one GPU (8 parts as (4,2))."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,6 +1,6 @@
 """The headline product (27-pt 256^3) through the library named by PA_HIP_LIBRARY (probe builds)."""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,7 +1,7 @@
 """A vector-valued problem with interleaved unknowns (2 per node of a Q1 grid: the sparsity of 2-D elasticity): rows alternate
 between two patterns, which the row-pattern encoder (runs of consecutive rows with ONE pattern) does not describe."""
 import os, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import scipy.sparse as sp
 from __graft_entry__ import load_package

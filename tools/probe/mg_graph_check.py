@@ -1,6 +1,6 @@
 """MG-PCG with the V-cycle replayed from a hipGraph against the eager V-cycle: same bits, time per iteration."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,7 +1,7 @@
 """Does the multicolour V-cycle's time depend on where its blocks and vectors were allocated?  The same set-up four
 times in one process (earlier ones kept alive, so every repetition lands elsewhere), MG-PCG iteration time of each."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -1,6 +1,6 @@
 """20 MG-PCG iterations at 256^3 (multicolour SpMV smoother): the command rocprofv3 --kernel-trace --stats wraps."""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 for n, ordering in ((128, "sequential"), (128, "multicolor"), (128, "multicolor_spmv"), (256, "multicolor"), (256, "multicolor_spmv")):

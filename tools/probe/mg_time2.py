@@ -1,6 +1,6 @@
 """MG-PCG iteration time (opt_cg_ with the multicolour SpMV smoother), one part, 128^3 and 256^3."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 for n in (128, 256):

@@ -1,6 +1,6 @@
 """mul! over P parts resident on ONE GPU (DebugArray): per-part cost of pack/unpack/own*ghost next to own*own."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 import pa_amd._lib as L

@@ -1,6 +1,6 @@
 """mul! over 2 and 8 parts of n^3 resident on ONE GPU, after a spin-up: per-part time of mul_c_ (one library call) vs own*own alone."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -1,6 +1,6 @@
 """SpMV rates of K1 on matrices other than the HPCG operator (one part, one GPU)."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,7 +1,7 @@
 """Does K1's time depend on where hipMalloc puts the arrays?  One process, the same host matrix, T trials: a dummy
 allocation of varying size, then block + x + y created anew and timed (HIP events, 30 launches)."""
 import sys, ctypes as C
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,6 +1,6 @@
 """K1 time vs where x and y sit (sub-ranges of one arena wrapped with pa_vec_wrap), the block fixed."""
 import sys, ctypes as C
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

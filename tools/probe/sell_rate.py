@@ -1,6 +1,6 @@
 """SELL-C-sigma (one lane per row) against the row-split kernel: 27-point 128^3 and banded-unstructured rows."""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,6 +1,6 @@
 """Where pc_setup's time goes (multicolour smoother, one part)."""
 import sys, cProfile, pstats
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -3,7 +3,7 @@
 consecutive sorted entries) and fed to the existing kernel -- the row sums are wrong, the memory behaviour is the candidate's
 minus its scattered LDS writes."""
 import sys, os
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

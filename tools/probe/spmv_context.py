@@ -1,6 +1,6 @@
 """Why is own x own slower inside the CG loop than back to back?  Event-timed product in different surroundings."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,6 +1,6 @@
 """Two-stream read rate (the dot kernel) by footprint: does streaming slow down when the operands span tens of GB?"""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

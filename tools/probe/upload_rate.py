@@ -1,6 +1,6 @@
 """How fast do set-up uploads go?  512 MB of float64 from a numpy array into a device vector: first and later copies."""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,6 +1,6 @@
 """SpMV / CG / MG-PCG with the optional value dictionary (PA_SPMV_VALUE_DICT=1) next to the fp64 stream."""
 import os, sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from __graft_entry__ import load_package
 pa = load_package()
 import pa_amd._lib as L

@@ -1,6 +1,6 @@
 """A large banded-unstructured block (20 M rows x 16 = 320 M entries): x-window launches against the row split, same bits."""
 import os, sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

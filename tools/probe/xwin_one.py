@@ -1,7 +1,7 @@
 """One banded-unstructured block (4 M rows x 16 within +-2000), 40 products: the command the rocprofv3 passes of
 profiles/r02_xwin_* wrap."""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()

@@ -1,6 +1,6 @@
 """Banded rows without a pattern: the x-window launch (pa_spmv_xwin.h) against k_spmv_rowsplit on the same block."""
 import os, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from __graft_entry__ import load_package
 pa = load_package()
