@@ -82,11 +82,13 @@ int pa_ctx_stream_priority(pa_ctx *ctx, int which, int *priority, int *least, in
  * Measured on MI355X: device memory falls into three classes (about a third each, physically contiguous regions of tens
  * of GiB); a product whose 64-byte write stream (y) sits in the class its read stream (the values) comes from runs
  * 13-15 % slower than with y in either other class.  A context therefore serves every buffer >= 1 MiB from physically
- * contiguous EXTENTS acquired on demand (16 GiB each, PA_ARENA_EXTENT_GIB; the first when an allocation >=
+ * contiguous EXTENTS acquired on demand (8 GiB each, PA_ARENA_EXTENT_GIB; the first when an allocation >=
  * PA_ARENA_MIN_MIB = 256 arrives; together at most PA_ARENA_FRACTION = 0.70 of the free memory or PA_ARENA_GIB;
  * PA_ARENA=0: none) and classified with a stand-in kernel when acquired (~20-50 ms each): matrix streams
- * (pa_csr_create*) go to the class the first one landed in, vectors (pa_vec_create) to a class without matrix streams --
- * found, when none is at hand, by walking over further extents that are handed back at once.  An extent nothing lives
+ * (pa_csr_create*) go to the class the first one landed in, vectors (pa_vec_create) anywhere else: a plain allocation
+ * that the pair check (the stand-in kernel on the newest matrix stream and windows of the vector) finds clear of the
+ * matrix streams' class -- class code 9 -- or, failing that, a class without matrix streams found by walking over
+ * further extents that are handed back at once.  An extent nothing lives
  * in is released.  Nothing is timed at the caller's expense, nothing ever moves, any failure falls back to hipMalloc.
  * pa_ctx_arena_info: bytes held, classes met (<= 3), bytes per class in the held extents, bytes in use, time spent
  * acquiring + classifying, the class matrix streams go to (-1: none yet).
@@ -99,7 +101,7 @@ int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class
                       int *matrix_class);
 int pa_ctx_arena_map(pa_ctx *ctx, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells);
 int pa_ctx_arena_stats(pa_ctx *ctx, int64_t *n_extents, int64_t *bytes_acquired, int64_t *bytes_released, int64_t *peak_used,
-                       int64_t *pairs_ok, int64_t *pairs_failed, int64_t *budget);
+                       int64_t *pairs_ok, int64_t *pairs_failed, int64_t *budget, int64_t *plain_vector_bytes);
 /* testing aid: a host copy of one of the arrays the product kernel reads (first slab of the block) -- 0 row pointers,
  * 1 32-bit columns, 2 16-bit codes, 3 windows, 4 pattern descriptors, 5 pattern table, 6 chunk table, 7 compacted row ids;
  * *bytes = the array's size, copied when capacity allows.  The set-up runs on the device (csrc/pa_setup.hip; PA_SETUP_DEVICE=0:

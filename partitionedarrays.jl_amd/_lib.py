@@ -91,7 +91,7 @@ _SIGS = {
     "pa_ctx_arena_build": [P],
     "pa_ctx_arena_info": [P, C.POINTER(i64), C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(f64), C.POINTER(cint)],
     "pa_ctx_arena_map": [P, C.POINTER(i64), P, i64, C.POINTER(i64)],
-    "pa_ctx_arena_stats": [P] + [C.POINTER(i64)] * 7,
+    "pa_ctx_arena_stats": [P] + [C.POINTER(i64)] * 8,
     "pa_csr_debug_array": [P, cint, P, i64, C.POINTER(i64)],
     "pa_csr_memory_class": [P, C.POINTER(cint)],
     "pa_vec_memory_class": [P, C.POINTER(cint)],

@@ -11,12 +11,15 @@
 // write : read stream pair, the product's ratio).
 //
 // Round 3: the single grab of 70 % of the free memory (7 s, hostile to anything else on the
-// device) is gone.  The arena is a list of EXTENTS (16 GiB by default, PA_ARENA_EXTENT_GIB; a bigger request gets an extent
+// device) is gone.  The arena is a list of EXTENTS (8 GiB by default, PA_ARENA_EXTENT_GIB; a bigger request gets an extent
 // of its own), each acquired when a class runs out of room and classified at once against the reference cell of every
 // class met so far.  Placement by rule, no timing of the caller's kernels, nothing ever moves:
 //     matrix streams (values, columns, row pointers, descriptors) -> the class the first one landed in
-//     vectors                                                      -> a class that holds no matrix stream
-// When no such class is at hand the arena WALKS: it acquires extents one after the other until one shows another class,
+//     vectors                                                      -> anywhere else: a plain allocation the pair check
+//                                                                     finds clear of that class (the driver serves plain
+//                                                                     and contiguous requests from different ends of the
+//                                                                     memory), else a class that holds no matrix stream
+// When neither is at hand the arena WALKS: it acquires extents one after the other until one shows another class,
 // keeps that one and hands the ones it walked over back to the driver at once (transient; bounded by PA_ARENA_WALK_GIB =
 // 160 and by the budget PA_ARENA_FRACTION = 0.70 of the free memory / PA_ARENA_GIB).  An extent nothing lives in any more
 // is released, except the newest such one (PA_ARENA_SPARE = 1: re-allocating memory this process freed costs a driver-side
@@ -86,6 +89,9 @@ struct pa_arena {
   size_t last_matrix_len = 0;
   int last_matrix_cls = -1;
   long check_ok = 0, check_failed = 0;     // vectors whose (matrix stream, vector) pair timed as "different classes" / "same class"
+  std::map<uintptr_t, size_t> foreign_;    // plain hipMalloc'ed vectors the pair check found clear of the matrix streams' class
+  size_t foreign_bytes = 0;
+  long plain_rejected = 0;
   bool warned = false;
 };
 
@@ -296,8 +302,17 @@ static void arena_trim(pa_arena *a) {
   static const int spare = getenv("PA_ARENA_SPARE") ? std::max(0, atoi(getenv("PA_ARENA_SPARE"))) : 1;
   std::vector<pa_extent *> empty;
   for (pa_extent *X : a->ext) if (X->live == 0) empty.push_back(X);
-  const size_t keep = a->used > 0 ? (size_t)spare : 0;   // (a context that holds nothing any more holds no spare either)
-  for (size_t i = 0; i + keep < empty.size(); ++i) arena_release(a, empty[i]);      // (ext is in order of acquisition: the oldest go)
+  for (size_t i = 0; i + spare < empty.size(); ++i) arena_release(a, empty[i]);     // (ext is in order of acquisition: the oldest go)
+  if (a->used == 0) {
+    // Nothing of the context lives in the arena any more: everything goes back, the extents that hold the classes'
+    // reference cells included (a later allocation starts over: classes are only ever compared inside one context's
+    // lifetime of live buffers, and there are none).
+    while (!a->ext.empty()) arena_release(a, a->ext.back());
+    a->n_classes = 0;
+    for (int k = 0; k < 3; ++k) { a->ref[k] = nullptr; a->scr[k] = nullptr; a->mat_bytes[k] = a->vec_bytes[k] = 0; }
+    a->matrix_class = -1;
+    a->last_matrix = nullptr; a->last_matrix_len = 0; a->last_matrix_cls = -1;
+  }
 }
 
 static int arena_init(pa_ctx *c) {
@@ -317,7 +332,10 @@ static int arena_init(pa_ctx *c) {
 }
 
 static size_t extent_bytes(const pa_arena *a, size_t request) {
-  size_t e = (size_t)16 * GIB;
+  // 8 GiB: room for a 256^3 part's streams (3.6 GB of values, the columns while they are encoded, row pointers,
+  // descriptors).  Not more: memory another process (or this one) has used before is wiped by the driver when it is
+  // allocated again, 30-75 ms per GiB -- a 16 GiB extent cost 0.5 s on a box whose memory had been used.
+  size_t e = (size_t)8 * GIB;
   if (const char *s = getenv("PA_ARENA_EXTENT_GIB")) e = std::max<size_t>(1, (size_t)atol(s)) * GIB;
   // a request that does not fit an extent of the usual size gets one of its own: the buffer + a cell at either end (a
   // boundary cell is not handed out)
@@ -351,20 +369,39 @@ static bool class_has_room(const pa_arena *a, size_t bytes, int cls) {
 
 static void arena_give_back(pa_arena *a, void *p);
 
-// Does the pair (newest big matrix stream, this vector) time as "different classes"?  One control (the matrix stream against
-// its own class's scratch) before and after, the pair in between: ~1.5 ms.  The map was measured cell by cell when the
-// extents were acquired; this checks the one thing it is FOR, on the buffers actually handed out.
+// Does the pair (newest big matrix stream, this vector) time as "different classes"?  The stand-in kernel streams the
+// matrix buffer and writes into windows of the vector (up to 8, evenly spread, each what the kernel writes for the bytes it
+// reads: ~20 MB); a control -- the same read stream against the scratch of the matrix streams' own class -- is taken before
+// and after.  *same = some window times like the control (the clusters are ~15 % apart; a window that is half in the class
+// sits half-way).  ~0.5 ms per window.  The map was measured cell by cell when the extents were acquired; this checks the
+// one thing it is FOR, on the buffers actually handed out -- and it is what lets a plain hipMalloc'ed vector be used at all.
 static int pair_check(pa_ctx *c, pa_arena *a, char *vec, size_t vec_bytes, bool *same) {
   probe_events ev;
   PA_TRY(ev.make());
   const int nb = std::min(probe_nb(std::min(a->last_matrix_len, a->cell)), (int)(vec_bytes / 448));
-  float s0 = 0, s1 = 0, t = 0;
+  const size_t wr = (size_t)nb * 448;
+  const int n_win = (int)std::min<size_t>(8, (vec_bytes + wr - 1) / wr);
+  float s0 = 0, s1 = 0, worst = 0;
   char *ctl = a->scr[a->last_matrix_cls];
   PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, ctl, nb, &s0));
   PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, ctl, nb, &s0));
-  PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, vec, nb, &t));
+  std::vector<float> t(n_win);
+  for (int w = 0; w < n_win; ++w) {
+    const size_t off = n_win == 1 ? 0 : ((vec_bytes - wr) * (size_t)w / (size_t)(n_win - 1)) & ~(size_t)4095;
+    PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, vec + off, nb, &t[w]));
+  }
   PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, ctl, nb, &s1));
-  *same = t > 0.96f * 0.5f * (s0 + s1);
+  const float thr = 0.93f * 0.5f * (s0 + s1);
+  for (int w = 0; w < n_win; ++w) {
+    if (t[w] > thr) {                                   // (interference only ever slows a probe down: confirm)
+      const size_t off = n_win == 1 ? 0 : ((vec_bytes - wr) * (size_t)w / (size_t)(n_win - 1)) & ~(size_t)4095;
+      float again = 0;
+      PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, vec + off, nb, &again));
+      t[w] = std::min(t[w], again);
+    }
+    worst = std::max(worst, t[w]);
+  }
+  *same = worst > thr;
   return PA_OK;
 }
 
@@ -405,7 +442,29 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
     if (n == 0) return nullptr;
     return arena_take(a, bytes, cand[(a->vec_turn++) % (unsigned)n], kind);
   };
+  static const int check_mode = getenv("PA_ARENA_SELFCHECK") ? atoi(getenv("PA_ARENA_SELFCHECK")) : 1;
+  static const int plain_first = getenv("PA_ARENA_PLAIN_VECTORS") ? atoi(getenv("PA_ARENA_PLAIN_VECTORS")) : 1;
+  if (!a->last_matrix) return nullptr;                  // no matrix stream to stay away from (yet): a plain allocation
   p = try_clean();
+  if (!p && plain_first && check_mode && bytes >= ((size_t)32 << 20) && !c->capturing) {
+    // Before walking (which acquires -- and makes the driver wipe -- tens of GiB): the driver serves plain allocations
+    // from another end of the memory than the contiguous extents (tools/probe/extent_probe.hip (d): 128 MiB ... 4 GiB
+    // buffers never shared the first extent's class), so a plain buffer that the pair check finds clear of the matrix
+    // streams' class, window by window, is as good a home for a vector as a mapped extent -- and costs nothing to hold.
+    void *q = nullptr;
+    if (hipMalloc(&q, bytes) == hipSuccess) {
+      bool same = true;
+      if (pair_check(c, a, (char *)q, bytes, &same) == PA_OK && !same) {
+        a->foreign_[(uintptr_t)q] = bytes;
+        a->foreign_bytes += bytes;
+        a->check_ok++;
+        return q;
+      }
+      (void)hipGetLastError();
+      (void)hipFree(q);
+      a->plain_rejected++;
+    } else (void)hipGetLastError();
+  }
   if (!p && !a->frozen && !c->capturing) {
     std::vector<pa_extent *> walked;
     size_t walk_budget = (size_t)160 * GIB;
@@ -428,7 +487,6 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
     return p;                                           // (knowingly next to matrix streams: nothing to check)
   }
   // self-check of the pair actually handed out (big vectors only: what a product writes)
-  static const int check_mode = getenv("PA_ARENA_SELFCHECK") ? atoi(getenv("PA_ARENA_SELFCHECK")) : 1;
   if (check_mode && a->last_matrix && bytes >= ((size_t)32 << 20) && !c->capturing) {
     const int cls = a->live_[(uintptr_t)p].cls;
     bool same = false;
@@ -486,7 +544,7 @@ static void arena_give_back(pa_arena *a, void *p) {
   }
   a->free_[start] = {len, b.cls, 0, b.e};
   if (a->mat_bytes[0] + a->mat_bytes[1] + a->mat_bytes[2] == 0) a->matrix_class = -1;
-  if (b.e->live == 0) arena_trim(a);                    // nothing of the extent is in use any more (and it holds no class's scratch)
+  if (b.e->live == 0 || a->used == 0) arena_trim(a);    // nothing of the extent (or of the context) is in use any more
 }
 
 // ---- PA_DEBUG_GUARD: one mapping per buffer, the buffer flush with its end, nothing mapped behind it ----
@@ -586,6 +644,10 @@ void pa_dev_free(pa_ctx *c, void *p) {
       arena_give_back(a, p);
       return;
     }
+    if (a) {
+      auto f = a->foreign_.find((uintptr_t)p);
+      if (f != a->foreign_.end()) { a->foreign_bytes -= f->second; a->foreign_.erase(f); }
+    }
   }
   (void)hipFree(p);
 }
@@ -597,6 +659,7 @@ int pa_mem_class(const pa_ctx *c, const void *p) {
   if (!a) return -1;
   for (const pa_extent *X : a->ext)
     if ((const char *)p >= X->base && (const char *)p < X->base + X->size) return X->cls[(size_t)((const char *)p - X->base) / a->cell];
+  if (a->foreign_.count((uintptr_t)p)) return PA_MEM_CLASS_PLAIN_VERIFIED;
   return -1;
 }
 
@@ -643,7 +706,8 @@ extern "C" int pa_ctx_arena_map(pa_ctx *c, int64_t *cell_bytes, int8_t *classes,
 }
 
 extern "C" int pa_ctx_arena_stats(pa_ctx *c, int64_t *n_extents, int64_t *bytes_acquired, int64_t *bytes_released,
-                                  int64_t *peak_used, int64_t *pairs_ok, int64_t *pairs_failed, int64_t *budget) {
+                                  int64_t *peak_used, int64_t *pairs_ok, int64_t *pairs_failed, int64_t *budget,
+                                  int64_t *plain_vector_bytes) {
   PA_REQUIRE(c != nullptr, "ctx is NULL");
   std::lock_guard<std::mutex> lk(c->mem_mu);
   const pa_arena *a = c->arena;
@@ -652,6 +716,7 @@ extern "C" int pa_ctx_arena_stats(pa_ctx *c, int64_t *n_extents, int64_t *bytes_
   if (bytes_released) *bytes_released = a ? (int64_t)a->released : 0;
   if (peak_used) *peak_used = a ? (int64_t)a->peak : 0;
   if (pairs_ok) *pairs_ok = a ? a->check_ok : 0;
+  if (plain_vector_bytes) *plain_vector_bytes = a ? (int64_t)a->foreign_bytes : 0;
   if (pairs_failed) *pairs_failed = a ? a->check_failed : 0;
   if (budget) *budget = a ? (int64_t)a->budget : 0;
   return PA_OK;

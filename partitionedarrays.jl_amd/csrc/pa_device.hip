@@ -703,9 +703,35 @@ static inline int64_t read_index(const void *a, int bytes, int64_t i) {
 
 static void csr_free_chain(pa_csr *A);
 
+// Where a block's stored entries come from: host arrays (an upload) or device arrays (a block assembled on the device,
+// pa_setup.hip); 0-based columns either way.
+struct csr_src {
+  const int32_t *col0 = nullptr;
+  const double *nzval = nullptr;
+  const int32_t *d_col = nullptr;
+  const double *d_val = nullptr;
+  bool on_device() const { return d_col != nullptr || d_val != nullptr; }
+  csr_src at(int64_t off) const {
+    csr_src o;
+    o.col0 = col0 ? col0 + off : nullptr; o.nzval = nzval ? nzval + off : nullptr;
+    o.d_col = d_col ? d_col + off : nullptr; o.d_val = d_val ? d_val + off : nullptr;
+    return o;
+  }
+};
+
 // fills the freshly created slab A; on any failure the caller (csr_build_slab) hands back whatever A holds by then
 static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
-                         const int32_t *col0 /*0-based, host*/, const double *nzval) {
+                         const csr_src &src) {
+  const int32_t *col0 = src.col0;          // 0-based, host (NULL when the entries are already on the device)
+  const double *nzval = src.nzval;
+  std::vector<int32_t> col_host;           // a host copy of device-resident columns, made only when a host-side step wants one
+  auto host_columns = [&]() -> int {
+    if (col0 || nnz == 0) return PA_OK;
+    col_host.resize(nnz);
+    PA_HIP(hipMemcpy(col_host.data(), src.d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
+    col0 = col_host.data();
+    return PA_OK;
+  };
   // non-empty rows; compact when most rows are empty (the own_ghost block: only boundary rows)
   const bool tm_ = getenv("PA_SETUP_TIMING") != nullptr;   // stderr: seconds per phase of this function
   auto t0_ = std::chrono::steady_clock::now();
@@ -749,7 +775,7 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   // the device's equal byte for byte (tests/...test_device_side_encoding_equals_the_host_s).
   const char *ep = getenv("PA_SPMV_PATTERN"), *e16 = getenv("PA_SPMV_COL16"), *ec = getenv("PA_SPMV_COMPACT_STREAMS"), *ed = getenv("PA_SETUP_DEVICE");
   const bool want_pattern = !(ep && atoi(ep) == 0) && nnz > 0, want_c16 = !(e16 && atoi(e16) == 0) && nnz > 0;
-  const bool compact_streams = !(ec && atoi(ec) == 0), on_device = !(ed && atoi(ed) == 0) && nnz > 0;
+  const bool compact_streams = !(ec && atoi(ec) == 0), on_device = (!(ed && atoi(ed) == 0) || src.on_device()) && nnz > 0;
   // (the value stream first: it is the allocation that brings the context's arena into being, pa_arena.hip)
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_val, sizeof(double) * (nnz + pad), PA_MEM_MATRIX));
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_crp, sizeof(int32_t) * (nc + 1), PA_MEM_MATRIX));
@@ -757,7 +783,10 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   PA_HIP(hipMemsetAsync(A->d_val + nnz, 0, sizeof(double) * pad, c->s[0]));            // (the streams are non-blocking: a null-stream
   PA_HIP(hipStreamSynchronize(c->s[0]));                                               // memset would not be ordered with the kernels)
   PA_HIP(pa_h2d(A->d_crp, crp.data(), sizeof(int32_t) * (nc + 1)));
-  if (nnz) PA_HIP(pa_h2d(A->d_val, nzval, sizeof(double) * nnz));
+  if (nnz && src.on_device()) {
+    PA_HIP(hipMemcpyAsync(A->d_val, src.d_val, sizeof(double) * nnz, hipMemcpyDeviceToDevice, c->s[0]));
+    PA_HIP(hipStreamSynchronize(c->s[0]));
+  } else if (nnz) PA_HIP(pa_h2d(A->d_val, nzval, sizeof(double) * nnz));
   PA_HIP(pa_h2d(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size()));
   if (compact) {
     PA_TRY(pa_dev_alloc(c, (void **)&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc), PA_MEM_MATRIX));
@@ -772,7 +801,10 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
     A->d_col = d_colfull;                  // (owned by A from here on: a failure below frees it with the block)
     PA_HIP(hipMemsetAsync(d_colfull + nnz, 0, sizeof(int32_t) * pad, c->s[0]));
     PA_HIP(hipStreamSynchronize(c->s[0]));
-    PA_HIP(pa_h2d(d_colfull, col0, sizeof(int32_t) * nnz));
+    if (src.on_device()) {
+      PA_HIP(hipMemcpyAsync(d_colfull, src.d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToDevice, c->s[0]));
+      PA_HIP(hipStreamSynchronize(c->s[0]));
+    } else PA_HIP(pa_h2d(d_colfull, col0, sizeof(int32_t) * nnz));
     lap("columns up");
     pa_dev_streams ds;
     PA_TRY(pa_dev_encode_columns(c, A->d_crp, d_colfull, A->d_row_ids, nc, nnz, A->d_chunk_row, A->n_chunks, PA_SPMV_CHUNK_NNZ,
@@ -850,6 +882,7 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
         cs.win.resize((size_t)A->n_chunks * PA_C16_WINDOWS);
         PA_HIP(hipMemcpy(cs.win.data(), A->d_win, sizeof(int32_t) * cs.win.size(), hipMemcpyDeviceToHost));
       }
+      PA_TRY(host_columns());
       pa_xw_plan P;
       pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz));
       const std::vector<pa_xw_group> &groups = P.groups;
@@ -882,7 +915,7 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   // optional lossless value dictionary (PA_SPMV_VALUE_DICT=1): at most PA_VDICT_MAX distinct bit patterns
   {
     const char *e = getenv("PA_SPMV_VALUE_DICT");
-    if (e && atoi(e) != 0 && nnz > 0) {
+    if (e && atoi(e) != 0 && nnz > 0 && nzval) {
       const int T = host_threads(nnz);
       std::vector<std::vector<uint64_t>> local(T);
       std::vector<char> over(T, 0);
@@ -948,10 +981,10 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
 }
 
 static int csr_build_slab(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
-                          const int32_t *col0 /*0-based, host*/, const double *nzval, pa_csr **out) {
+                          const csr_src &src, pa_csr **out) {
   pa_csr *A = new pa_csr();
   A->ctx = c;
-  const int st = csr_fill_slab(c, A, n_rows, n_cols, nnz, rp, col0, nzval);
+  const int st = csr_fill_slab(c, A, n_rows, n_cols, nnz, rp, src);
   if (st != PA_OK) {                 // a failed allocation or upload half-way: nothing stays behind (device buffers, arena blocks)
     (void)hipGetLastError();
     csr_free_chain(A);
@@ -973,7 +1006,7 @@ static int64_t slab_limit() {
 // rp: 0-based Int64 row pointers of the whole block.  One slab when the block fits Int32 offsets, else consecutive
 // row slabs (greedy, whole rows).
 static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const std::vector<int64_t> &rp,
-                     const int32_t *col0 /*0-based, host*/, const double *nzval, pa_csr **out) {
+                     const csr_src &src, pa_csr **out) {
   const int64_t limit = slab_limit();
   pa_csr *head = nullptr, *tail = nullptr;
   int64_t r0 = 0;
@@ -993,7 +1026,7 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, con
     for (int64_t r = r0; r <= r1; ++r) rp32[r - r0] = (int32_t)(rp[r] - rp[r0]);
     pa_csr *S = nullptr;
     const int64_t snnz = rp[r1] - rp[r0];
-    const int st = csr_build_slab(c, r1 - r0, n_cols, snnz, rp32, col0 ? col0 + rp[r0] : nullptr, nzval ? nzval + rp[r0] : nullptr, &S);
+    const int st = csr_build_slab(c, r1 - r0, n_cols, snnz, rp32, src.at(rp[r0]), &S);
     if (st != PA_OK) { csr_free_chain(head); return st; }
     S->row0 = r0; S->nnz0 = rp[r0];
     if (tail) tail->next = S; else head = S;
@@ -1065,7 +1098,24 @@ extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, in
   }
   if (getenv("PA_SETUP_TIMING"))
     fprintf(stderr, "[pa setup] %-10s %8.3f s  (nnz %lld)\n", "validate", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(), (long long)nnz);
-  return csr_build(c, n_rows, n_cols, nnz, rp, col0, nzval, out);
+  csr_src src;
+  src.col0 = col0; src.nzval = nzval;
+  return csr_build(c, n_rows, n_cols, nnz, rp, src, out);
+}
+
+// A block whose stored entries are already in HBM (0-based Int32 row pointers and columns, made by the device-side
+// assembly of pa_setup.hip): the row split needs the row pointers on the host (one small download), everything per entry
+// stays on the device.
+int pa_csr_from_device(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_col,
+                       const double *d_val, pa_csr **out) {
+  std::vector<int32_t> rp32(n_rows + 1);
+  PA_HIP(hipSetDevice(c->device));
+  PA_HIP(hipMemcpy(rp32.data(), d_rowptr, sizeof(int32_t) * (n_rows + 1), hipMemcpyDeviceToHost));
+  std::vector<int64_t> rp(rp32.begin(), rp32.end());
+  PA_REQUIRE(rp[0] == 0 && rp[n_rows] == nnz, "device row pointers do not span the stored entries");
+  csr_src src;
+  src.d_col = d_col; src.d_val = d_val;
+  return csr_build(c, n_rows, n_cols, nnz, rp, src, out);
 }
 
 extern "C" int pa_csr_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr,
@@ -1097,7 +1147,9 @@ extern "C" int pa_csr_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols,
       val[q] = nzval[p];
     }
   }
-  return csr_build(c, n_rows, n_cols, nnz, rp, col.data(), val.data(), out);
+  csr_src src;
+  src.col0 = col.data(); src.nzval = val.data();
+  return csr_build(c, n_rows, n_cols, nnz, rp, src, out);
 }
 
 extern "C" int pa_csr_update_values(pa_csr *A, const double *nzval) {

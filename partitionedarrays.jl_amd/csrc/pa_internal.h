@@ -81,7 +81,8 @@ inline hipError_t pa_h2d(void *dst, const void *src, size_t bytes) {
   hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
   return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
 }
-int pa_mem_class(const pa_ctx *c, const void *p);    // 0..2, or -1 outside the arena
+#define PA_MEM_CLASS_PLAIN_VERIFIED 9   /* a plain allocation the pair check found clear of the matrix streams' class */
+int pa_mem_class(const pa_ctx *c, const void *p);    // 0..2, PA_MEM_CLASS_PLAIN_VERIFIED, or -1 (outside, unknown)
 void pa_arena_destroy(pa_ctx *c);
 
 struct pa_event {

@@ -30,6 +30,10 @@ int pa_dev_encode_columns(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col,
                           bool want_c16, bool compact_streams, pa_dev_streams &S);
 void pa_dev_streams_free(pa_ctx *c, pa_dev_streams &S);
 
+// pa_device.hip: a pa_csr from entries that are already in HBM (0-based; the arrays are copied, the caller keeps its own)
+int pa_csr_from_device(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_col,
+                       const double *d_val, pa_csr **out);
+
 // min / max of a device Int32 array (column range check of an uploaded block)
 int pa_dev_minmax_i32(pa_ctx *c, const int32_t *d, int64_t n, int32_t *mn, int32_t *mx);
 

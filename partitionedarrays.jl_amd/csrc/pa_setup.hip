@@ -15,13 +15,7 @@
 //   chunks without a descriptor -> window tags in first-seen order, 16-bit codes, or a copy of their 32-bit columns
 //                                                                               one lane (codes) / one wavefront (copy) per chunk
 // Reference loops these arrays serve: spmv_csr! src/sparse_utils.jl:649-669.
-#include <hip/hip_runtime.h>
-
-#include <cstring>   // (rocprim's texture iterator calls memset from host code)
-#include <rocprim/rocprim.hpp>
-
-#include <algorithm>
-#include <vector>
+#include "pa_dev_util.h"   // hip_runtime, rocprim, the scratch / scan / sort helpers
 
 #include "pa_setup.h"
 #include "pa_spmv_kernel.h"
@@ -295,56 +289,7 @@ __global__ void ks_minmax(const int *__restrict__ p, int64_t n, int *__restrict_
 
 // ---- host side -----------------------------------------------------------------------------------------------------------
 namespace {
-
-struct scratch {                                   // plain hipMalloc'ed temporaries, freed when the encoding returns
-  std::vector<void *> p;
-  template <class T> int get(T **out, size_t n) {
-    void *q = nullptr;
-    PA_HIP(hipMalloc(&q, std::max<size_t>(sizeof(T) * n, 16)));
-    p.push_back(q);
-    *out = (T *)q;
-    return PA_OK;
-  }
-  ~scratch() { for (void *q : p) (void)hipFree(q); }
-};
-
-inline dim3 grid1(int64_t n, int t = 256) { return dim3((unsigned)std::max<int64_t>(1, (n + t - 1) / t)); }
-
-template <class T>
-int scan_exclusive(scratch &sc, hipStream_t s, const T *in, T *out, size_t n) {
-  size_t tb = 0;
-  PA_HIP(rocprim::exclusive_scan((void *)nullptr, tb, in, out, (T)0, n, rocprim::plus<T>(), s));
-  char *tmp = nullptr;
-  PA_TRY(sc.get(&tmp, tb));
-  PA_HIP(rocprim::exclusive_scan((void *)tmp, tb, in, out, (T)0, n, rocprim::plus<T>(), s));
-  return PA_OK;
-}
-
-int scan_inclusive(scratch &sc, hipStream_t s, const int *in, int *out, size_t n) {
-  size_t tb = 0;
-  PA_HIP(rocprim::inclusive_scan((void *)nullptr, tb, in, out, n, rocprim::plus<int>(), s));
-  char *tmp = nullptr;
-  PA_TRY(sc.get(&tmp, tb));
-  PA_HIP(rocprim::inclusive_scan((void *)tmp, tb, in, out, n, rocprim::plus<int>(), s));
-  return PA_OK;
-}
-
-template <class K>
-int sort_pairs(scratch &sc, hipStream_t s, const K *ki, K *ko, const int *vi, int *vo, size_t n) {
-  size_t tb = 0;
-  PA_HIP(rocprim::radix_sort_pairs((void *)nullptr, tb, ki, ko, vi, vo, n, 0, (unsigned)(8 * sizeof(K)), s));
-  char *tmp = nullptr;
-  PA_TRY(sc.get(&tmp, tb));
-  PA_HIP(rocprim::radix_sort_pairs((void *)tmp, tb, ki, ko, vi, vo, n, 0, (unsigned)(8 * sizeof(K)), s));
-  return PA_OK;
-}
-
-template <class T>
-int d2h(hipStream_t s, T *host, const T *dev, size_t n) {
-  PA_HIP(hipMemcpyAsync(host, dev, sizeof(T) * n, hipMemcpyDeviceToHost, s));
-  PA_HIP(hipStreamSynchronize(s));
-  return PA_OK;
-}
+using namespace pa_util;
 
 // Row patterns of the block: pdesc (n_chunks x PA_PDESC_INTS, zeroed for chunks without a descriptor) and pdelta in S;
 // returns in *n_good the number of chunks that got a descriptor (0: no table worth having; S holds a one-pattern dummy

@@ -72,7 +72,7 @@ class Context:
         L.call("pa_ctx_arena_map", self.h, C.byref(cell), None, 0, C.byref(n))
         cells = np.zeros(max(n.value, 1), np.int8)
         L.call("pa_ctx_arena_map", self.h, C.byref(cell), L.ptr(cells), n.value, C.byref(n))
-        st = [C.c_int64() for _ in range(7)]
+        st = [C.c_int64() for _ in range(8)]
         L.call("pa_ctx_arena_stats", self.h, *[C.byref(v) for v in st])
         G = float(1 << 30)
         return dict(gib=round(size.value / G, 1), classes=ncls.value, matrix_class=mcls.value, class_gib=[round(v / G, 1) for v in per],
@@ -80,7 +80,7 @@ class Context:
                     cells="".join("|" if v == -2 else "." if v < 0 else str(int(v)) for v in cells[:n.value]),
                     extents=st[0].value, acquired_gib=round(st[1].value / G, 1), released_gib=round(st[2].value / G, 1),
                     peak_used_gib=round(st[3].value / G, 2), pairs_checked_ok=st[4].value, pairs_checked_same_class=st[5].value,
-                    budget_gib=round(st[6].value / G, 1))
+                    budget_gib=round(st[6].value / G, 1), plain_vectors_gib=round(st[7].value / G, 2))
 
 
 class Graph:

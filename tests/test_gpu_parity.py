@@ -1268,13 +1268,14 @@ def test_arena_places_matrix_streams_and_vectors_in_different_memory_classes(orc
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert out["before"]["gib"] == 0                                   # lazily: nothing big had been allocated yet
-    assert 8 <= out["after_matrix"]["gib"] <= 49, out["after_matrix"]  # the matrix streams' extent, the extent of b (a vector) and at most a spare
+    assert 4 <= out["after_matrix"]["gib"] <= 33, out["after_matrix"]  # the matrix streams' extent (+ what b, a vector, may have made it walk over)
     assert out["bit_identical"]
     assert out["small_vector_class"] == -1                             # below 1 MiB: plain hipMalloc
     assert out["reused"]
     M = out["after"]["matrix_class"]
     assert out["matrix_class"] == M
-    assert out["after"]["gib"] <= 65 and out["free_taken_gib"] <= 68, out   # held: the matrix extent, the vectors' extent(s), one spare -- not the device
+    assert out["after"]["gib"] <= 33 and out["free_taken_gib"] <= 36, out   # held: the matrix streams' extent (the vectors are plain allocations
+                                                                             # or one more extent, plus a spare) -- not the device
     if out["after"]["classes"] >= 2:                                   # the structure the rule exists for
         assert all(c >= 0 and c != M for c in out["vector_classes"]), (out, r.stderr[-3000:])
         assert out["after"]["pairs_checked_ok"] >= 1 and out["after"]["pairs_checked_same_class"] == 0, (out, r.stderr[-3000:])
