@@ -398,6 +398,65 @@ def extra_configs(pa, ctx, L, out):
               bb, m, m, time_block(pa, ctx, L, bb, m, m), ts)
     e["x_window_launch"] = bb.xwin()
     out.append(e)
+    del bb
+    # a non-pattern FEM matrix (VERDICT r02 #6b): the Q1 mesh numbered at random, then renumbered by reverse Cuthill-McKee --
+    # what an unstructured-mesh code hands over.  No row pattern survives; the columns fall into a band in a few clusters.
+    PHASE[0] = "extra: FEM mesh after RCM"
+    try:
+        import scipy.sparse as sp
+        from scipy.sparse.csgraph import reverse_cuthill_mckee
+        t = time.perf_counter()
+        nxm, nym = 1000, 800
+        I, J, V, rows, cols = pa.laplacian_fem((nxm, nym), (1, 1), ranks1)
+        nn = nxm * nym
+        perm = np.random.default_rng(29).permutation(nn)
+        Ip, Jp = perm[I.items[0] - 1], perm[J.items[0] - 1]
+        G = sp.csr_matrix((np.ones(len(Ip), np.float32), (Ip, Jp)), shape=(nn, nn))
+        order = reverse_cuthill_mckee(G, symmetric_mode=True)
+        new_id = np.empty(nn, np.int64)
+        new_id[order] = np.arange(nn)
+        Hc = pa.compresscoo(new_id[Ip] + 1, new_id[Jp] + 1, V.items[0], nn, nn)
+        band = int(np.max(np.abs(np.repeat(np.arange(nn), np.diff(Hc.rowptr)) - (Hc.colval - 1))))
+        del I, J, V, G
+        br = pa.DeviceCSR(Hc)
+        ts = time.perf_counter() - t
+        e = entry(f"Q1 FEM Laplacian on a {nxm} x {nym} mesh numbered at random, then reverse Cuthill-McKee (band {band}): no row "
+                  "patterns, pa_spmv", br, nn, nn, time_block(pa, ctx, L, br, nn, nn), ts)
+        e["x_window_launch"] = br.xwin()
+        out.append(e)
+        del br, Hc
+    except ImportError:
+        pass
+    # BASELINE config 5 as a whole: Q1 FEM Laplacian, 8 parts as (4,2) resident on this ONE GPU, the disassembled psparse
+    # route, full mul! = pack / device-to-device exchange / own x own / unpack / own x ghost of all 8 parts in one call
+    PHASE[0] = "extra: config 5 on 8 parts"
+    t = time.perf_counter()
+    n5 = int(os.environ.get("PA_BENCH_C5_NODES", "4096"))
+    ranks8 = pa.DebugArray(range(1, 9))
+    I, J, V, rows, cols = pa.laplacian_fem((n5, n5), (4, 2), ranks8)
+    A5 = pa.psparse_disassembled(I, J, V, rows, cols)
+    del I, J, V
+    ts = time.perf_counter() - t
+    x5 = pa.pvector_from_function(lambda ind: hash_x(ind.get_local_to_global()) * (ind.get_local_to_owner() == ind.part), A5.col_partition)
+    y5 = pa.pzeros(A5.row_partition)
+    spin_up(ctx, lambda: pa.mul_c_(y5, A5, x5))
+    reps = 30
+    e0 = ctx.event().record(L.STREAM_COMPUTE)
+    for _ in range(reps):
+        pa.mul_c_(y5, A5, x5)
+    e1 = ctx.event().record(L.STREAM_COMPUTE)
+    ctx.sync()
+    ms = e0.elapsed_ms(e1) / reps
+    blocks = pa.local_items(A5.matrix_partition)
+    nnz5 = sum(b.own_own.nnz + b.own_ghost.nnz for b in blocks)
+    ghosts = [c.n_ghost for c in pa.local_items(A5.col_partition)]
+    rows5 = sum(r.n_own for r in pa.local_items(A5.row_partition))
+    moved = sum(b.own_own.stream_bytes() + b.own_ghost.stream_bytes() for b in blocks) + 16 * rows5 + 3 * 8 * sum(ghosts)
+    out.append({"workload": f"config 5 whole: Q1 FEM Laplacian {n5} x {n5} nodes, 8 parts (4,2) ALL on this one GPU, disassembled psparse "
+                            "route, mul! = pack + device-to-device exchange + own x own + unpack + own x ghost (pa_mul_all)",
+                "parts": 8, "rows": int(rows5), "nnz": int(nnz5), "ghosts_per_part": ghosts, "ms_all_parts": round(ms, 4),
+                "ms_per_part": round(ms / 8, 4), "gflops": round(2.0 * nnz5 / ms / 1e6, 1), "moved_gbps": round(moved / ms / 1e6, 1),
+                "encoding_own_own": blocks[0].own_own.encoding(), "encoding_own_ghost": blocks[0].own_ghost.encoding(), "setup_s": round(ts, 1)})
     return out
 
 

@@ -82,13 +82,13 @@ int pa_ctx_stream_priority(pa_ctx *ctx, int which, int *priority, int *least, in
  * Measured on MI355X: device memory falls into three classes (about a third each, physically contiguous regions of tens
  * of GiB); a product whose 64-byte write stream (y) sits in the class its read stream (the values) comes from runs
  * 13-15 % slower than with y in either other class.  A context therefore serves every buffer >= 1 MiB from physically
- * contiguous EXTENTS acquired on demand (8 GiB each, PA_ARENA_EXTENT_GIB; the first when an allocation >=
+ * contiguous EXTENTS acquired on demand (16 GiB each, PA_ARENA_EXTENT_GIB; the first when an allocation >=
  * PA_ARENA_MIN_MIB = 256 arrives; together at most PA_ARENA_FRACTION = 0.70 of the free memory or PA_ARENA_GIB;
  * PA_ARENA=0: none) and classified with a stand-in kernel when acquired (~20-50 ms each): matrix streams
- * (pa_csr_create*) go to the class the first one landed in, vectors (pa_vec_create) anywhere else: a plain allocation
- * that the pair check (the stand-in kernel on the newest matrix stream and windows of the vector) finds clear of the
- * matrix streams' class -- class code 9 -- or, failing that, a class without matrix streams found by walking over
- * further extents that are handed back at once.  An extent nothing lives
+ * (pa_csr_create*) go to the class the first one landed in, vectors (pa_vec_create) to a class without matrix streams --
+ * found, when none is at hand, by walking over further extents that are handed back at once (PA_ARENA_PLAIN_VECTORS=1,
+ * experimental: first a plain allocation that the pair check finds clear of the matrix streams' class, class code 9).
+ * Every big vector handed out is pair-checked once against the matrix streams' class (~3 ms).  An extent nothing lives
  * in is released.  Nothing is timed at the caller's expense, nothing ever moves, any failure falls back to hipMalloc.
  * pa_ctx_arena_info: bytes held, classes met (<= 3), bytes per class in the held extents, bytes in use, time spent
  * acquiring + classifying, the class matrix streams go to (-1: none yet).
@@ -102,6 +102,28 @@ int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class
 int pa_ctx_arena_map(pa_ctx *ctx, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells);
 int pa_ctx_arena_stats(pa_ctx *ctx, int64_t *n_extents, int64_t *bytes_acquired, int64_t *bytes_released, int64_t *peak_used,
                        int64_t *pairs_ok, int64_t *pairs_failed, int64_t *budget, int64_t *plain_vector_bytes);
+/* ---- psparse(I,J,V,rows,cols;assembled=true) of one part ON THE DEVICE (csrc/pa_assemble.hip) ------------------------
+ * The reference's route for COO triplets in global ids -- union_ghost(rows, J, find_owner(rows, J)) (src/p_range.jl:205-259),
+ * map_global_to_local! (src/p_sparse_matrix.jl:1253-1254), compresscoo(...; combine = +, skip) (src/sparse_utils.jl:313-350),
+ * split_format_locally (src/p_sparse_matrix.jl:823-899) -- as kernels, scans and radix sorts over the uploaded triplets.
+ * rows / columns: block partitions (own ids = the box [lo, hi] of an n_global grid, 1-based inclusive, column-major; the row
+ * partition has no ghosts).  known_ghosts: ghost gids the column partition already has, in its order; discover_ghosts != 0
+ * appends the new ones in first-seen order (union_ghost), 0 treats unknown columns as not local (id 0: the CSR skip rule turns
+ * such entries into (1,1,0.0)).  Duplicates are added in input order.  Results: the ghost gids (known, then new), the two
+ * blocks as pa_csr objects (created on the device: no host CSR exists unless pa_coo_assembly_download is called), sizes. */
+typedef struct pa_coo_assembly pa_coo_assembly;
+int pa_coo_assemble(pa_ctx *ctx, int64_t count, const int64_t *I, const int64_t *J, const double *V, int32_t D,
+                    const int64_t *n_rows_global, const int64_t *row_lo, const int64_t *row_hi, const int64_t *n_cols_global,
+                    const int64_t *col_lo, const int64_t *col_hi, int64_t n_known_ghosts, const int64_t *known_ghosts,
+                    int discover_ghosts, pa_coo_assembly **out);
+int pa_coo_assembly_info(const pa_coo_assembly *h, int64_t *n_own_rows, int64_t *n_own_cols, int64_t *n_ghost,
+                         int64_t *nnz_own_own, int64_t *nnz_own_ghost, double *device_ms);
+int pa_coo_assembly_ghosts(const pa_coo_assembly *h, int64_t *ghost_gids);
+int pa_coo_assembly_blocks(pa_coo_assembly *h, pa_csr **own_own, pa_csr **own_ghost);
+/* 1-based host copies of a block (which: 0 own_own, 1 own_ghost): rowptr[n_own_rows + 1], colval / nzval[nnz] */
+int pa_coo_assembly_download(const pa_coo_assembly *h, int which, int32_t *rowptr, int32_t *colval, double *nzval);
+int pa_coo_assembly_destroy(pa_coo_assembly *h);
+
 /* testing aid: a host copy of one of the arrays the product kernel reads (first slab of the block) -- 0 row pointers,
  * 1 32-bit columns, 2 16-bit codes, 3 windows, 4 pattern descriptors, 5 pattern table, 6 chunk table, 7 compacted row ids;
  * *bytes = the array's size, copied when capacity allows.  The set-up runs on the device (csrc/pa_setup.hip; PA_SETUP_DEVICE=0:

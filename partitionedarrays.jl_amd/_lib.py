@@ -93,6 +93,12 @@ _SIGS = {
     "pa_ctx_arena_map": [P, C.POINTER(i64), P, i64, C.POINTER(i64)],
     "pa_ctx_arena_stats": [P] + [C.POINTER(i64)] * 8,
     "pa_csr_debug_array": [P, cint, P, i64, C.POINTER(i64)],
+    "pa_coo_assemble": [P, i64, P, P, P, C.c_int32, P, P, P, P, P, P, i64, P, cint, C.POINTER(P)],
+    "pa_coo_assembly_info": [P] + [C.POINTER(i64)] * 5 + [C.POINTER(f64)],
+    "pa_coo_assembly_ghosts": [P, P],
+    "pa_coo_assembly_blocks": [P, C.POINTER(P), C.POINTER(P)],
+    "pa_coo_assembly_download": [P, cint, P, P, P],
+    "pa_coo_assembly_destroy": [P],
     "pa_csr_memory_class": [P, C.POINTER(cint)],
     "pa_vec_memory_class": [P, C.POINTER(cint)],
     "pa_csr_create_mixed": [P, i64, i64, i64, P, cint, P, cint, cint, P, PP],

@@ -11,7 +11,7 @@
 // write : read stream pair, the product's ratio).
 //
 // Round 3: the single grab of 70 % of the free memory (7 s, hostile to anything else on the
-// device) is gone.  The arena is a list of EXTENTS (8 GiB by default, PA_ARENA_EXTENT_GIB; a bigger request gets an extent
+// device) is gone.  The arena is a list of EXTENTS (16 GiB by default, PA_ARENA_EXTENT_GIB; a bigger request gets an extent
 // of its own), each acquired when a class runs out of room and classified at once against the reference cell of every
 // class met so far.  Placement by rule, no timing of the caller's kernels, nothing ever moves:
 //     matrix streams (values, columns, row pointers, descriptors) -> the class the first one landed in
@@ -332,10 +332,11 @@ static int arena_init(pa_ctx *c) {
 }
 
 static size_t extent_bytes(const pa_arena *a, size_t request) {
-  // 8 GiB: room for a 256^3 part's streams (3.6 GB of values, the columns while they are encoded, row pointers,
-  // descriptors).  Not more: memory another process (or this one) has used before is wiped by the driver when it is
-  // allocated again, 30-75 ms per GiB -- a 16 GiB extent cost 0.5 s on a box whose memory had been used.
-  size_t e = (size_t)8 * GIB;
+  // 16 GiB: room for a 256^3 part's streams (3.6 GB of values, the columns while they are encoded, row pointers,
+  // descriptors) and for the next block or two -- a block that does not fit makes the arena walk.  Not more: memory that
+  // has been used before is wiped by the driver when it is allocated again, 30-75 ms per GiB (a 16 GiB extent: 15 ms
+  // on clean memory, 0.5 s after other processes had used the device).
+  size_t e = (size_t)16 * GIB;
   if (const char *s = getenv("PA_ARENA_EXTENT_GIB")) e = std::max<size_t>(1, (size_t)atol(s)) * GIB;
   // a request that does not fit an extent of the usual size gets one of its own: the buffer + a cell at either end (a
   // boundary cell is not handed out)
@@ -378,30 +379,44 @@ static void arena_give_back(pa_arena *a, void *p);
 static int pair_check(pa_ctx *c, pa_arena *a, char *vec, size_t vec_bytes, bool *same) {
   probe_events ev;
   PA_TRY(ev.make());
-  const int nb = std::min(probe_nb(std::min(a->last_matrix_len, a->cell)), (int)(vec_bytes / 448));
+  // The read stream: the reference cell of the matrix streams' class (512 MiB from HBM; a smaller matrix buffer would be
+  // served by the 256 MiB Infinity Cache and show no class at all) -- "is this vector in the matrix streams' class" is the
+  // question a classification pass asks of a cell.
+  const int cls = a->last_matrix_cls;
+  const char *rd = a->ref[cls];
+  const int nb = std::min(probe_nb(a->cell), (int)(vec_bytes / 448));
   const size_t wr = (size_t)nb * 448;
   const int n_win = (int)std::min<size_t>(8, (vec_bytes + wr - 1) / wr);
-  float s0 = 0, s1 = 0, worst = 0;
-  char *ctl = a->scr[a->last_matrix_cls];
-  PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, ctl, nb, &s0));
-  PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, ctl, nb, &s0));
+  auto off_of = [&](int w) { return n_win == 1 ? (size_t)0 : ((vec_bytes - wr) * (size_t)w / (size_t)(n_win - 1)) & ~(size_t)4095; };
+  char *slow_ctl = a->scr[cls], *fast_ctl = nullptr;
+  for (int j = 0; j < a->n_classes; ++j) if (j != cls) { fast_ctl = a->scr[j]; break; }
+  float s0 = 0, s1 = 0, f0 = 0, f1 = 0, worst = 0;
+  PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, slow_ctl, nb, &s0));
+  PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, slow_ctl, nb, &s0));
+  if (fast_ctl) PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, fast_ctl, nb, &f0));
   std::vector<float> t(n_win);
-  for (int w = 0; w < n_win; ++w) {
-    const size_t off = n_win == 1 ? 0 : ((vec_bytes - wr) * (size_t)w / (size_t)(n_win - 1)) & ~(size_t)4095;
-    PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, vec + off, nb, &t[w]));
-  }
-  PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, ctl, nb, &s1));
-  const float thr = 0.93f * 0.5f * (s0 + s1);
+  for (int w = 0; w < n_win; ++w) PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, vec + off_of(w), nb, &t[w]));
+  PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, slow_ctl, nb, &s1));
+  if (fast_ctl) PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, fast_ctl, nb, &f1));
+  const float slow = 0.5f * (s0 + s1);
+  float fast = fast_ctl ? 0.5f * (f0 + f1) : 0.87f * slow;
+  if (fast > 0.95f * slow) fast = 0.87f * slow;
+  const float thr = 0.5f * (slow + fast);
   for (int w = 0; w < n_win; ++w) {
     if (t[w] > thr) {                                   // (interference only ever slows a probe down: confirm)
-      const size_t off = n_win == 1 ? 0 : ((vec_bytes - wr) * (size_t)w / (size_t)(n_win - 1)) & ~(size_t)4095;
       float again = 0;
-      PA_TRY(probe_ms(c, ev.e0, ev.e1, a->last_matrix, vec + off, nb, &again));
+      PA_TRY(probe_ms(c, ev.e0, ev.e1, rd, vec + off_of(w), nb, &again));
       t[w] = std::min(t[w], again);
     }
     worst = std::max(worst, t[w]);
   }
   *same = worst > thr;
+  if (getenv("PA_SETUP_TIMING")) {
+    fprintf(stderr, "[pa arena] pair check of a %.0f MiB vector at %p against class %d: same-class control %.4f ms, other-class %.4f ms, windows",
+            vec_bytes / 1048576.0, (void *)vec, cls, slow, fast);
+    for (float v : t) fprintf(stderr, " %.4f", v);
+    fprintf(stderr, " -> %s\n", *same ? "SAME class" : "clear of it");
+  }
   return PA_OK;
 }
 
@@ -414,11 +429,24 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
     if (a->matrix_class < 0)
       for (int k = 0; k < a->n_classes && !p; ++k) if (a->vec_bytes[k] == 0) p = arena_take(a, bytes, k, kind);
     if (!p) {
-      if (pa_extent *X = arena_acquire(c, a, extent_bytes(a, bytes), "matrix streams")) {
-        (void)X;
-        if (a->matrix_class >= 0) p = arena_take(a, bytes, a->matrix_class, kind);
-        for (int k = 0; k < a->n_classes && !p; ++k) if (a->vec_bytes[k] == 0) p = arena_take(a, bytes, k, kind);
+      // the class is full: further extents, one after the other, until one offers the matrix streams' class again or a
+      // class no vector lives in (a vector must never find a matrix stream moving into its class: a product writing it
+      // would lose 13-16 % -- measured when 8 GiB extents made the second block of bench.py land next to the vectors:
+      // 0.95 instead of 0.81 ms); what the walk went over is handed back
+      size_t walk_budget = (size_t)64 * GIB, walked_bytes = 0;
+      if (const char *sw = getenv("PA_ARENA_WALK_GIB")) walk_budget = (size_t)atol(sw) * GIB;
+      auto take_clean = [&]() -> void * {
+        void *q = a->matrix_class >= 0 ? arena_take(a, bytes, a->matrix_class, kind) : nullptr;
+        for (int k = 0; k < a->n_classes && !q; ++k) if (a->vec_bytes[k] == 0) q = arena_take(a, bytes, k, kind);
+        return q;
+      };
+      while (!p && walked_bytes < walk_budget) {
+        pa_extent *X = arena_acquire(c, a, extent_bytes(a, bytes), "matrix streams");
+        if (!X) break;
+        walked_bytes += X->size;
+        p = take_clean();
       }
+      arena_trim(a);
     }
     if (!p) {                                           // spill: the class with the fewest vector bytes first
       int order[3] = {0, 1, 2};
@@ -443,11 +471,13 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
     return arena_take(a, bytes, cand[(a->vec_turn++) % (unsigned)n], kind);
   };
   static const int check_mode = getenv("PA_ARENA_SELFCHECK") ? atoi(getenv("PA_ARENA_SELFCHECK")) : 1;
-  static const int plain_first = getenv("PA_ARENA_PLAIN_VECTORS") ? atoi(getenv("PA_ARENA_PLAIN_VECTORS")) : 1;
+  static const int plain_first = getenv("PA_ARENA_PLAIN_VECTORS") ? atoi(getenv("PA_ARENA_PLAIN_VECTORS")) : 0;   // (experimental, below)
   if (!a->last_matrix) return nullptr;                  // no matrix stream to stay away from (yet): a plain allocation
   p = try_clean();
   if (!p && plain_first && check_mode && bytes >= ((size_t)32 << 20) && !c->capturing) {
-    // Before walking (which acquires -- and makes the driver wipe -- tens of GiB): the driver serves plain allocations
+    // PA_ARENA_PLAIN_VECTORS=1 (off by default: a vector verified against the matrix streams' class today is not verified
+    // against the class a LATER block may have to take).  Before walking (which acquires -- and makes the driver wipe --
+    // tens of GiB): the driver serves plain allocations
     // from another end of the memory than the contiguous extents (tools/probe/extent_probe.hip (d): 128 MiB ... 4 GiB
     // buffers never shared the first extent's class), so a plain buffer that the pair check finds clear of the matrix
     // streams' class, window by window, is as good a home for a vector as a mapped extent -- and costs nothing to hold.

@@ -1,0 +1,417 @@
+// pa_assemble.hip -- psparse(I,J,V,rows,cols;assembled=true) of ONE part on the device ("device-side
+// first-time set-up").
+//
+// The reference's route for a matrix given as COO triplets in global ids (src/p_sparse_matrix.jl:1249-1270, the route of
+// HPCG.build_p_matrix and test/gallery_tests.jl:33):
+//     cols = union_ghost(rows, J, find_owner(rows, J))        src/p_range.jl:205-259,346-348   new ghosts in first-seen order
+//     map_global_to_local!(I, rows); map_global_to_local!(J, cols)                              :1253-1254
+//     compresscoo(SparseMatrixCSR{1,Float64,Int32}, I, J, V, m, n; combine = +, skip)           src/sparse_utils.jl:313-350
+//     split_format_locally(A, rows, cols)                                                        src/p_sparse_matrix.jl:823-899
+// restated in pa_host.cpp as single-threaded loops (4 s for the 7-point 256^3 part of BASELINE config 2).  Here the triplets
+// are uploaded once and everything per entry is a kernel, a scan or a radix sort (rocPRIM):
+//     own-box arithmetic for rows and columns (block partitions: the own ids are a box of the global grid)
+//     ghosts: the non-own column gids with their positions, sorted by gid (stable) -> first occurrence of each -> sorted by
+//             that position = the first-seen order of filter_ghost; every occurrence then knows its ghost number
+//     key = (local row, local column), stable radix sort -> runs of equal key are summed left to right IN INPUT ORDER
+//             (compresscoo's combine = +; an entry with a row or column id < 1 becomes (1,1,0.0): the CSR skip rule)
+//     own | ghost split by column, row pointers by binary search in the sorted rows
+// The blocks go straight into pa_csr objects (row split on the host from the row pointers, column encodings on the device,
+// pa_setup.hip); the host gets the ghost gids (a few thousand) and, when it asks, copies of the CSR arrays.
+// Bit-identical to the host route: tests/test_gpu_parity.py::test_device_side_psparse_equals_the_host_route.
+#include "pa_dev_util.h"
+
+#include "pa_setup.h"
+
+using namespace pa_util;
+
+struct pa_box {                     // own ids of a block partition: a box of the global grid, column-major (src/p_range.jl:1471-1500)
+  int D;
+  long long n[8], lo[8], hi[8];
+};
+
+// 0-based own-local id of global id g (1-based), or -1 outside the box, -2 when g is no id at all (< 1 or > prod n)
+__device__ __forceinline__ long long own_local(const pa_box &b, long long g) {
+  if (g < 1) return -2;
+  long long r = g - 1, own = 0, stride = 1;
+  bool inside = true;
+#pragma unroll 1
+  for (int d = 0; d < b.D; ++d) {
+    const long long c = r % b.n[d] + 1;
+    r /= b.n[d];
+    if (c < b.lo[d] || c > b.hi[d]) inside = false;
+    own += (c - b.lo[d]) * stride;
+    stride *= (b.hi[d] - b.lo[d] + 1);
+  }
+  if (r != 0) return -2;            // beyond the global grid
+  return inside ? own : -1;
+}
+
+// li[e] = local row (0-based) or -1; lj[e] = own local column, -1 (no id), or -2 (a valid id outside the own box: a ghost)
+__global__ void ka_classify(const long long *__restrict__ I, const long long *__restrict__ J, int n, pa_box rows, pa_box cols,
+                            int *__restrict__ li, int *__restrict__ lj, int *__restrict__ is_ghost) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const long long a = own_local(rows, I[e]);
+  li[e] = a >= 0 ? (int)a : -1;     // rows that are not own are not local at all (the row partition has no ghosts here)
+  const long long b = own_local(cols, J[e]);
+  lj[e] = b >= 0 ? (int)b : (b == -1 ? -2 : -1);
+  is_ghost[e] = b == -1 ? 1 : 0;
+}
+
+// occurrences of ghost columns: (gid, position).  The n_known ghosts the column partition already has come first, as if
+// they had been seen before every entry (union_ghost appends to them).
+__global__ void ka_ghost_occ(const long long *__restrict__ J, const int *__restrict__ is_ghost, const int *__restrict__ gscan, int n,
+                             int n_known, unsigned long long *__restrict__ gid, int *__restrict__ pos) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n || !is_ghost[e]) return;
+  const int k = n_known + gscan[e];               // exclusive scan
+  gid[k] = (unsigned long long)J[e];
+  pos[k] = k;
+}
+__global__ void ka_known_occ(const long long *__restrict__ known, int n_known, unsigned long long *__restrict__ gid, int *__restrict__ pos) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_known) { gid[k] = (unsigned long long)known[k]; pos[k] = k; }
+}
+
+__global__ void ka_heads_u64(const unsigned long long *__restrict__ key, int n, int *__restrict__ head) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+}
+
+// unique ghost u (in gid order): first position it was seen at, and its gid
+__global__ void ka_unique(const unsigned long long *__restrict__ sgid, const int *__restrict__ spos, const int *__restrict__ head,
+                          const int *__restrict__ uscan, int n, int *__restrict__ first_pos, int *__restrict__ uid,
+                          long long *__restrict__ ugid) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const int u = uscan[i] - 1;
+  first_pos[u] = spos[i];           // stable sort: the smallest position of the run
+  uid[u] = u;
+  ugid[u] = (long long)sgid[i];
+}
+
+// after sorting the uniques by first position: rank[u] = ghost number (0-based), ghost_gid[rank] = gid
+__global__ void ka_rank(const int *__restrict__ uid_sorted, const long long *__restrict__ ugid, int n_unique, int *__restrict__ rank,
+                        long long *__restrict__ ghost_gid) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_unique) return;
+  rank[uid_sorted[k]] = k;
+  ghost_gid[k] = ugid[uid_sorted[k]];
+}
+
+// every occurrence learns its ghost number; occ_rank[position] (positions < n_known are the known ghosts themselves)
+__global__ void ka_occ_rank(const int *__restrict__ spos, const int *__restrict__ uscan, const int *__restrict__ rank, int n,
+                            int *__restrict__ occ_rank) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) occ_rank[spos[i]] = rank[uscan[i] - 1];
+}
+
+// key = (row << 32 | column) of the local matrix [own | ghost]; bad entries (a row or column that is not local) become
+// (0, 0) with value 0.0 -- compresscoo's skip rule for CSR (src/sparse_utils.jl:330-342,370-390)
+__global__ void ka_keys(const int *__restrict__ li, const int *__restrict__ lj, const int *__restrict__ is_ghost,
+                        const int *__restrict__ gscan, const int *__restrict__ occ_rank, int n, int n_known, int n_own_cols,
+                        int n_ghost_max, int discover, unsigned long long *__restrict__ key, int *__restrict__ idx,
+                        unsigned char *__restrict__ bad) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  int r = li[e], c = lj[e];
+  if (is_ghost[e]) {
+    const int k = occ_rank[n_known + gscan[e]];
+    c = (discover || k < n_known) ? n_own_cols + k : -1;       // (a column the given partition does not know: not local)
+  }
+  (void)n_ghost_max;
+  const bool b = r < 0 || c < 0;
+  bad[e] = b ? 1 : 0;
+  key[e] = b ? 0ull : ((unsigned long long)(unsigned)r << 32) | (unsigned)c;
+  idx[e] = e;
+}
+
+// one lane per run of equal key: the run's values added left to right in input order (stable sort)
+__global__ void ka_combine(const unsigned long long *__restrict__ skey, const int *__restrict__ sidx, const int *__restrict__ head,
+                           const int *__restrict__ hscan, const double *__restrict__ V, const unsigned char *__restrict__ bad, int n,
+                           int *__restrict__ orow, int *__restrict__ ocol, double *__restrict__ oval) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !head[i]) return;
+  const int o = hscan[i] - 1;
+  const unsigned long long k = skey[i];
+  double acc = bad[sidx[i]] ? 0.0 : V[sidx[i]];
+  for (int j = i + 1; j < n && skey[j] == k; ++j) acc = acc + (bad[sidx[j]] ? 0.0 : V[sidx[j]]);
+  orow[o] = (int)(k >> 32);
+  ocol[o] = (int)(k & 0xffffffffu);
+  oval[o] = acc;
+}
+
+__global__ void ka_is_own_col(const int *__restrict__ ocol, int n, int n_own_cols, int *__restrict__ f) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) f[i] = ocol[i] < n_own_cols ? 1 : 0;
+}
+
+__global__ void ka_split(const int *__restrict__ ocol, const double *__restrict__ oval, const int *__restrict__ f,
+                         const int *__restrict__ fscan, int n, int n_own_cols, int *__restrict__ oo_col, double *__restrict__ oo_val,
+                         int *__restrict__ oh_col, double *__restrict__ oh_val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int a = fscan[i];                          // exclusive: own-column entries before i
+  if (f[i]) { oo_col[a] = ocol[i]; oo_val[a] = oval[i]; }
+  else { oh_col[i - a] = ocol[i] - n_own_cols; oh_val[i - a] = oval[i]; }
+}
+
+// row pointers of both blocks: first output entry of row r by binary search in the sorted rows
+__global__ void ka_rowptr(const int *__restrict__ orow, const int *__restrict__ fscan, int n, int n_rows, int n_oo,
+                          int *__restrict__ oo_rp, int *__restrict__ oh_rp) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n_rows) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (orow[mid] < r) lo = mid + 1; else hi = mid;
+  }
+  const int a = lo < n ? fscan[lo] : n_oo;
+  oo_rp[r] = a;
+  oh_rp[r] = lo - a;
+}
+
+struct pa_coo_assembly {
+  pa_ctx *ctx = nullptr;
+  int64_t n_rows = 0, n_own_cols = 0, n_ghost = 0, n_known = 0, nnz_oo = 0, nnz_oh = 0;
+  std::vector<int64_t> ghost_gids;                 // all ghosts of the column partition: the known ones, then the new ones
+  int *oo_rp = nullptr, *oo_col = nullptr, *oh_rp = nullptr, *oh_col = nullptr;
+  double *oo_val = nullptr, *oh_val = nullptr;
+  double ms = 0;
+};
+
+static void assembly_free(pa_coo_assembly *h) {
+  if (!h) return;
+  for (void *p : {(void *)h->oo_rp, (void *)h->oo_col, (void *)h->oh_rp, (void *)h->oh_col, (void *)h->oo_val, (void *)h->oh_val}) (void)hipFree(p);
+  delete h;
+}
+
+static int assemble_impl(pa_ctx *c, pa_coo_assembly *h, int64_t count, const int64_t *I, const int64_t *J, const double *V,
+                         const pa_box &rows, const pa_box &cols, int64_t n_known, const int64_t *known, int discover) {
+  hipStream_t s = c->s[0];
+  scratch sc;
+  const int n = (int)count;
+  long long *dI = nullptr, *dJ = nullptr;
+  double *dV = nullptr;
+  PA_TRY(sc.get(&dI, count));
+  PA_TRY(sc.get(&dJ, count));
+  PA_TRY(sc.get(&dV, count));
+  PA_HIP(hipMemcpyAsync(dI, I, 8 * (size_t)count, hipMemcpyHostToDevice, s));
+  PA_HIP(hipMemcpyAsync(dJ, J, 8 * (size_t)count, hipMemcpyHostToDevice, s));
+  PA_HIP(hipMemcpyAsync(dV, V, 8 * (size_t)count, hipMemcpyHostToDevice, s));
+  int *li = nullptr, *lj = nullptr, *isg = nullptr, *gscan = nullptr;
+  PA_TRY(sc.get(&li, count));
+  PA_TRY(sc.get(&lj, count));
+  PA_TRY(sc.get(&isg, count + 1));
+  PA_TRY(sc.get(&gscan, count + 1));
+  PA_HIP(hipMemsetAsync(isg + count, 0, sizeof(int), s));
+  hipLaunchKernelGGL(ka_classify, grid1(count), dim3(256), 0, s, dI, dJ, n, rows, cols, li, lj, isg);
+  PA_TRY(scan_exclusive<int>(sc, s, isg, gscan, (size_t)count + 1));
+  int n_occ = 0;
+  PA_TRY(d2h(s, &n_occ, gscan + count, 1));
+  sc.release(dI);
+  // ---- ghosts in first-seen order
+  const int n_all = (int)n_known + n_occ;
+  int *occ_rank = nullptr;
+  PA_TRY(sc.get(&occ_rank, (size_t)n_all + 1));
+  h->n_known = n_known;
+  h->ghost_gids.assign(known, known + n_known);
+  if (n_all > 0) {
+    unsigned long long *gid = nullptr, *sgid = nullptr;
+    int *pos = nullptr, *spos = nullptr, *head = nullptr, *uscan = nullptr;
+    long long *dknown = nullptr;
+    PA_TRY(sc.get(&gid, n_all));
+    PA_TRY(sc.get(&sgid, n_all));
+    PA_TRY(sc.get(&pos, n_all));
+    PA_TRY(sc.get(&spos, n_all));
+    PA_TRY(sc.get(&head, n_all));
+    PA_TRY(sc.get(&uscan, n_all));
+    if (n_known) {
+      PA_TRY(sc.get(&dknown, n_known));
+      PA_HIP(hipMemcpyAsync(dknown, known, 8 * (size_t)n_known, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(ka_known_occ, grid1(n_known), dim3(256), 0, s, dknown, (int)n_known, gid, pos);
+    }
+    hipLaunchKernelGGL(ka_ghost_occ, grid1(count), dim3(256), 0, s, dJ, isg, gscan, n, (int)n_known, gid, pos);
+    PA_TRY(sort_pairs<unsigned long long>(sc, s, gid, sgid, pos, spos, (size_t)n_all));
+    hipLaunchKernelGGL(ka_heads_u64, grid1(n_all), dim3(256), 0, s, sgid, n_all, head);
+    PA_TRY(scan_inclusive(sc, s, head, uscan, (size_t)n_all));
+    int n_unique = 0;
+    PA_TRY(d2h(s, &n_unique, uscan + (n_all - 1), 1));
+    int *first_pos = nullptr, *uid = nullptr, *first_pos_s = nullptr, *uid_s = nullptr, *rank = nullptr;
+    long long *ugid = nullptr, *ghost_gid = nullptr;
+    PA_TRY(sc.get(&first_pos, n_unique));
+    PA_TRY(sc.get(&uid, n_unique));
+    PA_TRY(sc.get(&first_pos_s, n_unique));
+    PA_TRY(sc.get(&uid_s, n_unique));
+    PA_TRY(sc.get(&rank, n_unique));
+    PA_TRY(sc.get(&ugid, n_unique));
+    PA_TRY(sc.get(&ghost_gid, n_unique));
+    hipLaunchKernelGGL(ka_unique, grid1(n_all), dim3(256), 0, s, sgid, spos, head, uscan, n_all, first_pos, uid, ugid);
+    PA_TRY(sort_pairs<int>(sc, s, first_pos, first_pos_s, uid, uid_s, (size_t)n_unique));
+    hipLaunchKernelGGL(ka_rank, grid1(n_unique), dim3(256), 0, s, uid_s, ugid, n_unique, rank, ghost_gid);
+    hipLaunchKernelGGL(ka_occ_rank, grid1(n_all), dim3(256), 0, s, spos, uscan, rank, n_all, occ_rank);
+    PA_HIP(hipGetLastError());
+    // (the known ghosts must be distinct gids: then they keep the numbers 0 .. n_known-1 they came with)
+    PA_REQUIRE(n_unique >= n_known, "the column partition lists a ghost twice");
+    if (discover) {
+      h->ghost_gids.resize(n_unique);
+      PA_TRY(d2h(s, (long long *)h->ghost_gids.data(), ghost_gid, (size_t)n_unique));
+      for (int64_t k = 0; k < n_known; ++k) PA_REQUIRE(h->ghost_gids[k] == known[k], "the column partition lists a ghost twice (or an own id as a ghost)");
+    }
+  }
+  h->n_ghost = (int64_t)h->ghost_gids.size();
+  // ---- sort by (row, column), combine
+  unsigned long long *key = nullptr, *skey = nullptr;
+  int *idx = nullptr, *sidx = nullptr;
+  unsigned char *bad = nullptr;
+  PA_TRY(sc.get(&key, count));
+  PA_TRY(sc.get(&skey, count));
+  PA_TRY(sc.get(&idx, count));
+  PA_TRY(sc.get(&sidx, count));
+  PA_TRY(sc.get(&bad, count));
+  hipLaunchKernelGGL(ka_keys, grid1(count), dim3(256), 0, s, li, lj, isg, gscan, occ_rank, n, (int)n_known, (int)h->n_own_cols,
+                     (int)h->n_ghost, discover, key, idx, bad);
+  unsigned bits_r = 1, bits = 0;
+  while (((int64_t)1 << bits_r) < std::max<int64_t>(h->n_rows, 2)) ++bits_r;
+  bits = 32 + bits_r;
+  PA_TRY(sort_pairs<unsigned long long>(sc, s, key, skey, idx, sidx, (size_t)count, bits));
+  sc.release(key); sc.release(idx); sc.release(dJ); sc.release(li); sc.release(lj);
+  int *head = nullptr, *hscan = nullptr;
+  PA_TRY(sc.get(&head, count));
+  PA_TRY(sc.get(&hscan, count));
+  hipLaunchKernelGGL(ka_heads_u64, grid1(count), dim3(256), 0, s, skey, n, head);
+  PA_TRY(scan_inclusive(sc, s, head, hscan, (size_t)count));
+  int nnz = 0;
+  PA_TRY(d2h(s, &nnz, hscan + (count - 1), 1));
+  int *orow = nullptr, *ocol = nullptr, *f = nullptr, *fscan = nullptr;
+  double *oval = nullptr;
+  PA_TRY(sc.get(&orow, nnz));
+  PA_TRY(sc.get(&ocol, nnz));
+  PA_TRY(sc.get(&oval, nnz));
+  PA_TRY(sc.get(&f, (size_t)nnz + 1));
+  PA_TRY(sc.get(&fscan, (size_t)nnz + 1));
+  hipLaunchKernelGGL(ka_combine, grid1(count), dim3(256), 0, s, skey, sidx, head, hscan, dV, bad, n, orow, ocol, oval);
+  PA_HIP(hipMemsetAsync(f + nnz, 0, sizeof(int), s));
+  hipLaunchKernelGGL(ka_is_own_col, grid1(nnz), dim3(256), 0, s, ocol, nnz, (int)h->n_own_cols, f);
+  PA_TRY(scan_exclusive<int>(sc, s, f, fscan, (size_t)nnz + 1));
+  int n_oo = 0;
+  PA_TRY(d2h(s, &n_oo, fscan + nnz, 1));
+  h->nnz_oo = n_oo; h->nnz_oh = nnz - n_oo;
+  const size_t pad = 8;
+  PA_HIP(hipMalloc((void **)&h->oo_rp, sizeof(int) * (size_t)(h->n_rows + 1)));
+  PA_HIP(hipMalloc((void **)&h->oh_rp, sizeof(int) * (size_t)(h->n_rows + 1)));
+  PA_HIP(hipMalloc((void **)&h->oo_col, sizeof(int) * ((size_t)h->nnz_oo + pad)));
+  PA_HIP(hipMalloc((void **)&h->oh_col, sizeof(int) * ((size_t)h->nnz_oh + pad)));
+  PA_HIP(hipMalloc((void **)&h->oo_val, sizeof(double) * ((size_t)h->nnz_oo + pad)));
+  PA_HIP(hipMalloc((void **)&h->oh_val, sizeof(double) * ((size_t)h->nnz_oh + pad)));
+  hipLaunchKernelGGL(ka_split, grid1(nnz), dim3(256), 0, s, ocol, oval, f, fscan, nnz, (int)h->n_own_cols, h->oo_col, h->oo_val, h->oh_col, h->oh_val);
+  hipLaunchKernelGGL(ka_rowptr, grid1(h->n_rows + 1), dim3(256), 0, s, orow, fscan, nnz, (int)h->n_rows, n_oo, h->oo_rp, h->oh_rp);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(s));
+  return PA_OK;
+}
+
+static int make_box(pa_box &b, int32_t D, const int64_t *n, const int64_t *lo, const int64_t *hi, int64_t *n_own) {
+  PA_REQUIRE(D >= 1 && D <= 8 && n && lo && hi, "bad box");
+  b.D = D;
+  *n_own = 1;
+  for (int d = 0; d < D; ++d) {
+    PA_REQUIRE(n[d] >= 1 && lo[d] >= 1 && hi[d] <= n[d] && hi[d] >= lo[d] - 1, "own range [%lld,%lld] outside 1:%lld in direction %d", (long long)lo[d], (long long)hi[d], (long long)n[d], d + 1);
+    b.n[d] = n[d]; b.lo[d] = lo[d]; b.hi[d] = hi[d];
+    *n_own *= (hi[d] - lo[d] + 1);
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_coo_assemble(pa_ctx *c, int64_t count, const int64_t *I, const int64_t *J, const double *V, int32_t D,
+                               const int64_t *n_rows_global, const int64_t *row_lo, const int64_t *row_hi,
+                               const int64_t *n_cols_global, const int64_t *col_lo, const int64_t *col_hi, int64_t n_known_ghosts,
+                               const int64_t *known_ghosts, int discover_ghosts, pa_coo_assembly **out) {
+  PA_REQUIRE(c && out && count >= 0 && (count == 0 || (I && J && V)), "bad arguments");
+  PA_REQUIRE(n_known_ghosts >= 0 && (n_known_ghosts == 0 || known_ghosts), "bad ghost list");
+  PA_REQUIRE(count < (int64_t)2147480000 && n_known_ghosts < (int64_t)1 << 30, "more triplets than the device-side assembly indexes (2^31)");
+  pa_box rows, cols;
+  int64_t n_own_rows = 0, n_own_cols = 0;
+  PA_TRY(make_box(rows, D, n_rows_global, row_lo, row_hi, &n_own_rows));
+  PA_TRY(make_box(cols, D, n_cols_global, col_lo, col_hi, &n_own_cols));
+  PA_REQUIRE(n_own_rows < (int64_t)2147480000 && n_own_cols + n_known_ghosts + count < (int64_t)2147480000, "part too large for Int32 local ids");
+  PA_REQUIRE(count > 0 && n_own_rows > 0 && n_own_cols > 0, "the device-side assembly needs at least one triplet and one own row (the host route handles empty parts)");
+  PA_HIP(hipSetDevice(c->device));
+  pa_coo_assembly *h = new pa_coo_assembly();
+  h->ctx = c; h->n_rows = n_own_rows; h->n_own_cols = n_own_cols;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, c->s[0]);
+  const int st = assemble_impl(c, h, count, I, J, V, rows, cols, n_known_ghosts, known_ghosts, discover_ghosts);
+  (void)hipEventRecord(e1, c->s[0]);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (st != PA_OK) { (void)hipGetLastError(); assembly_free(h); return st; }
+  h->ms = ms;
+  *out = h;
+  return PA_OK;
+}
+
+extern "C" int pa_coo_assembly_info(const pa_coo_assembly *h, int64_t *n_own_rows, int64_t *n_own_cols, int64_t *n_ghost,
+                                    int64_t *nnz_own_own, int64_t *nnz_own_ghost, double *device_ms) {
+  PA_REQUIRE(h != nullptr, "assembly is NULL");
+  if (n_own_rows) *n_own_rows = h->n_rows;
+  if (n_own_cols) *n_own_cols = h->n_own_cols;
+  if (n_ghost) *n_ghost = h->n_ghost;
+  if (nnz_own_own) *nnz_own_own = h->nnz_oo;
+  if (nnz_own_ghost) *nnz_own_ghost = h->nnz_oh;
+  if (device_ms) *device_ms = h->ms;
+  return PA_OK;
+}
+
+extern "C" int pa_coo_assembly_ghosts(const pa_coo_assembly *h, int64_t *ghost_gids) {
+  PA_REQUIRE(h && (ghost_gids || h->n_ghost == 0), "bad arguments");
+  for (int64_t k = 0; k < h->n_ghost; ++k) ghost_gids[k] = h->ghost_gids[k];
+  return PA_OK;
+}
+
+extern "C" int pa_coo_assembly_blocks(pa_coo_assembly *h, pa_csr **own_own, pa_csr **own_ghost) {
+  PA_REQUIRE(h && own_own && own_ghost, "bad arguments");
+  pa_csr *a = nullptr, *b = nullptr;
+  PA_TRY(pa_csr_from_device(h->ctx, h->n_rows, h->n_own_cols, h->nnz_oo, h->oo_rp, h->oo_col, h->oo_val, &a));
+  const int st = pa_csr_from_device(h->ctx, h->n_rows, h->n_ghost, h->nnz_oh, h->oh_rp, h->oh_col, h->oh_val, &b);
+  if (st != PA_OK) { (void)pa_csr_destroy(a); return st; }
+  *own_own = a;
+  *own_ghost = b;
+  return PA_OK;
+}
+
+// 1-based host copies of one block (which: 0 own_own, 1 own_ghost), as SparseMatrixCSR{1,Float64,Int32} stores them
+__global__ void ka_plus_one(const int *__restrict__ in, int64_t n, int *__restrict__ out) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = in[i] + 1;
+}
+extern "C" int pa_coo_assembly_download(const pa_coo_assembly *h, int which, int32_t *rowptr, int32_t *colval, double *nzval) {
+  PA_REQUIRE(h && rowptr && (which == 0 || which == 1), "bad arguments");
+  pa_ctx *c = h->ctx;
+  const int64_t nnz = which ? h->nnz_oh : h->nnz_oo;
+  PA_REQUIRE(nnz == 0 || (colval && nzval), "colval / nzval are NULL");
+  PA_HIP(hipSetDevice(c->device));
+  scratch sc;
+  int *t = nullptr;
+  PA_TRY(sc.get(&t, (size_t)std::max<int64_t>(nnz, h->n_rows + 1)));
+  hipLaunchKernelGGL(ka_plus_one, dim3(1024), dim3(256), 0, c->s[0], which ? h->oh_rp : h->oo_rp, h->n_rows + 1, t);
+  PA_TRY(d2h(c->s[0], rowptr, t, (size_t)h->n_rows + 1));
+  if (nnz) {
+    hipLaunchKernelGGL(ka_plus_one, dim3(4096), dim3(256), 0, c->s[0], which ? h->oh_col : h->oo_col, nnz, t);
+    PA_TRY(d2h(c->s[0], colval, t, (size_t)nnz));
+    PA_TRY(d2h(c->s[0], nzval, which ? h->oh_val : h->oo_val, (size_t)nnz));
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_coo_assembly_destroy(pa_coo_assembly *h) {
+  if (!h) return PA_OK;
+  (void)hipSetDevice(h->ctx->device);
+  (void)hipStreamSynchronize(h->ctx->s[0]);
+  assembly_free(h);
+  return PA_OK;
+}

@@ -57,6 +57,21 @@ extern "C" int pa_host_hpcg_build_matrix(int64_t nx, int64_t ny, int64_t nz, int
 }
 
 // src/gallery.jl:40-84 `setup`: diag first (alpha*2D), then d = 1..D, i in (-1,+1): -alpha
+// The triplets are written by host threads over slabs of the outermost direction; a slab's first slot is a closed form
+// (rows + per direction the nodes that have a left / a right neighbour), so the stream is the sequential loop's.
+#include <thread>
+static int64_t fdm_count(int D, const int64_t *l, const int64_t *h, const int64_t *nn) {
+  int64_t rows = 1;
+  for (int d = 0; d < D; ++d) rows *= std::max<int64_t>(0, h[d] - l[d] + 1);
+  if (rows == 0) return 0;
+  int64_t t = rows;
+  for (int d = 0; d < D; ++d) {
+    const int64_t len = h[d] - l[d] + 1, others = rows / len;
+    const int64_t with_left = len - (l[d] <= 1 ? 1 : 0), with_right = len - (h[d] >= nn[d] ? 1 : 0);
+    t += others * (std::max<int64_t>(0, with_left) + std::max<int64_t>(0, with_right));
+  }
+  return t;
+}
 extern "C" int pa_host_laplacian_fdm(int32_t D, const int64_t *n, const int64_t *lo, const int64_t *hi, int64_t *I,
                                      int64_t *J, double *V, int64_t *nnz_out) {
   PA_REQUIRE(D >= 1 && D <= 3 && n && lo && hi && nnz_out, "bad arguments");
@@ -66,23 +81,41 @@ extern "C" int pa_host_laplacian_fdm(int32_t D, const int64_t *n, const int64_t 
   for (int d = 0; d < D; ++d) { l[d] = lo[d]; h[d] = hi[d]; nn[d] = n[d]; }
   for (int d = 1; d < D; ++d) stride[d] = stride[d - 1] * n[d - 1];
   const bool fill = I && J && V;
-  int64_t t = 0;
-  int64_t c[3];
-  for (c[2] = l[2]; c[2] <= h[2]; ++c[2])
-    for (c[1] = l[1]; c[1] <= h[1]; ++c[1])
-      for (c[0] = l[0]; c[0] <= h[0]; ++c[0]) {  // CartesianIndices(ranges): first index fastest
-        const int64_t node_i = (c[0] - 1) + (c[1] - 1) * (D > 1 ? stride[1] : 0) + (c[2] - 1) * (D > 2 ? stride[2] : 0) + 1;
-        if (fill) { I[t] = node_i; J[t] = node_i; V[t] = alpha * 2 * D; }
-        ++t;
-        for (int d = 0; d < D; ++d)
-          for (int i = -1; i <= 1; i += 2) {
-            const int64_t cj = c[d] + i;
-            if (cj < 1 || cj > nn[d]) continue;
-            if (fill) { I[t] = node_i; J[t] = node_i + i * stride[d]; V[t] = -alpha; }
-            ++t;
-          }
-      }
-  *nnz_out = t;
+  *nnz_out = fdm_count(D, l, h, nn);
+  if (!fill || *nnz_out == 0) return PA_OK;
+  const int od = D - 1;                                  // slabs of the outermost direction
+  const int64_t olen = h[od] - l[od] + 1;
+  unsigned hw = std::thread::hardware_concurrency();
+  int T = hw ? (int)std::min<unsigned>(hw, 32) : 4;
+  if (const char *e = getenv("PA_HOST_THREADS")) T = std::max(1, atoi(e));
+  if (*nnz_out < ((int64_t)1 << 20)) T = 1;
+  T = (int)std::min<int64_t>(T, olen);
+  auto work = [&](int th) {
+    int64_t sl[3] = {l[0], l[1], l[2]}, sh[3] = {h[0], h[1], h[2]}, before_h[3] = {h[0], h[1], h[2]};
+    sl[od] = l[od] + olen * th / T;
+    sh[od] = l[od] + olen * (th + 1) / T - 1;
+    before_h[od] = sl[od] - 1;
+    int64_t t = fdm_count(D, l, before_h, nn);          // slots of the slabs before this one
+    int64_t c[3];
+    for (c[2] = sl[2]; c[2] <= sh[2]; ++c[2])
+      for (c[1] = sl[1]; c[1] <= sh[1]; ++c[1])
+        for (c[0] = sl[0]; c[0] <= sh[0]; ++c[0]) {      // CartesianIndices(ranges): first index fastest
+          const int64_t node_i = (c[0] - 1) + (c[1] - 1) * (D > 1 ? stride[1] : 0) + (c[2] - 1) * (D > 2 ? stride[2] : 0) + 1;
+          I[t] = node_i; J[t] = node_i; V[t] = alpha * 2 * D;
+          ++t;
+          for (int d = 0; d < D; ++d)
+            for (int i = -1; i <= 1; i += 2) {
+              const int64_t cj = c[d] + i;
+              if (cj < 1 || cj > nn[d]) continue;
+              I[t] = node_i; J[t] = node_i + i * stride[d]; V[t] = -alpha;
+              ++t;
+            }
+        }
+  };
+  std::vector<std::thread> pool;
+  for (int th = 1; th < T; ++th) pool.emplace_back(work, th);
+  work(0);
+  for (auto &x : pool) x.join();
   return PA_OK;
 }
 

@@ -100,6 +100,15 @@ class DeviceCSR:
                L.ptr(A.nzval), C.byref(self.h))
         return self
 
+    @staticmethod
+    def from_handle(h, m, n, nnz, ctx=None) -> "DeviceCSR":
+        """Adopt a pa_csr the library built itself (a block assembled on the device, pa_coo_assembly_blocks)."""
+        self = DeviceCSR.__new__(DeviceCSR)
+        self.ctx = ctx or context()
+        self.m, self.n, self.nnz = int(m), int(n), int(nnz)
+        self.h = h
+        return self
+
     def info(self):
         v = [C.c_int64() for _ in range(6)]
         L.call("pa_csr_info", self.h, *[C.byref(x) for x in v])
@@ -245,8 +254,73 @@ def psparse(I, J, V, rows, cols, assembled=True, keep_host=False) -> PSparseMatr
     return PSparseMatrix(blocks, rows, cols, True, host)
 
 
+def _device_assembly_applies(row_partition, I):
+    """The device-side assembly (csrc/pa_assemble.hip) covers block row partitions without ghosts, parts with at least one
+    triplet, on a box with a GPU; PA_SETUP_DEVICE=0 keeps the host route (the two are compared bit for bit in the tests)."""
+    import os
+    if os.environ.get("PA_SETUP_DEVICE", "1") == "0":
+        return False
+    try:
+        context()
+    except Exception:                                          # noqa: BLE001  (no GPU: the host route still builds host blocks)
+        return False
+    from .primitives import local_items
+    return all(r.kind == "block" and r.n_ghost == 0 and r.n_own > 0 and len(i) > 0 and len(i) < 2 ** 31 - 10 ** 4
+               for r, i in zip(local_items(row_partition), local_items(I)))
+
+
+def psparse_from_coo_device(I, J, V, row_partition, keep_host=False) -> PSparseMatrix:
+    """psparse_from_coo with everything per triplet on the device: one upload of (I, J, V), then kernels, scans and radix
+    sorts (pa_coo_assemble); the host gets the new ghost gids and computes their owners (find_owner on a few thousand ids).
+    The blocks never exist on the host unless keep_host asks for copies."""
+    def build(Ii, Ji, Vi, r):
+        Ii, Ji = np.ascontiguousarray(Ii, I64), np.ascontiguousarray(Ji, I64)
+        Vi = np.ascontiguousarray(Vi, F64)
+        D = len(r.n)
+        n = np.array(r.n, I64)
+        lo = np.array([a for a, _ in r.ranges], I64)
+        hi = np.array([b for _, b in r.ranges], I64)
+        h = C.c_void_p()
+        L.call("pa_coo_assemble", context().h, len(Ii), L.ptr(Ii), L.ptr(Ji), L.ptr(Vi), D, L.ptr(n), L.ptr(lo), L.ptr(hi),
+               L.ptr(n), L.ptr(lo), L.ptr(hi), 0, None, 1, C.byref(h))
+        try:
+            v = [C.c_int64() for _ in range(5)]
+            ms = C.c_double()
+            L.call("pa_coo_assembly_info", h, *[C.byref(x) for x in v], C.byref(ms))
+            n_rows, n_own_cols, n_ghost, nnz_oo, nnz_oh = [x.value for x in v]
+            ghosts = np.zeros(n_ghost, I64)
+            L.call("pa_coo_assembly_ghosts", h, L.ptr(ghosts))
+            from .primitives import DebugArray
+            owners = find_owner(DebugArray([r]), DebugArray([ghosts])).items[0]
+            from .p_range import LocalIndices
+            c = LocalIndices(r.n_global, r.part, np_=r.np_, n=r.n, ranges=r.ranges, starts=r.starts,
+                             ghost_to_global=ghosts, ghost_to_owner=owners)
+            a, b = C.c_void_p(), C.c_void_p()
+            L.call("pa_coo_assembly_blocks", h, C.byref(a), C.byref(b))
+            blk = SplitMatrixBlocks(DeviceCSR.from_handle(a, n_rows, n_own_cols, nnz_oo), DeviceCSR.from_handle(b, n_rows, n_ghost, nnz_oh))
+            host = None
+            if keep_host:
+                host = []
+                for which, (ncol, nnz) in enumerate(((n_own_cols, nnz_oo), (n_ghost, nnz_oh))):
+                    H = HostCSR(n_rows, ncol, np.zeros(n_rows + 1, I32), np.zeros(nnz, I32), np.zeros(nnz, F64))
+                    L.call("pa_coo_assembly_download", h, which, L.ptr(H.rowptr), L.ptr(H.colval), L.ptr(H.nzval))
+                    host.append(H)
+                host = tuple(host)
+        finally:
+            L.lib.pa_coo_assembly_destroy(h)
+        return blk, c, host
+
+    out = pmap(build, I, J, V, row_partition)
+    blocks = pmap(lambda t: t[0], out)
+    cols = pmap(lambda t: t[1], out)
+    host = pmap(lambda t: t[2], out) if keep_host else None
+    return PSparseMatrix(blocks, row_partition, cols, True, host)
+
+
 def psparse_from_coo(I, J, V, row_partition, keep_host=False) -> PSparseMatrix:
     """The route of HPCG.build_p_matrix / test/gallery_tests.jl:33: find_owner -> union_ghost -> psparse."""
+    if _device_assembly_applies(row_partition, I):
+        return psparse_from_coo_device(I, J, V, row_partition, keep_host=keep_host)
     J_owner = find_owner(row_partition, J)
     cols = pmap(union_ghost, row_partition, J, J_owner)
     return psparse(I, J, V, row_partition, cols, assembled=True, keep_host=keep_host)
