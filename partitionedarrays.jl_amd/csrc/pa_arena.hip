@@ -22,8 +22,8 @@
 // When neither is at hand the arena WALKS: it acquires extents one after the other until one shows another class,
 // keeps that one and hands the ones it walked over back to the driver at once (transient; bounded by PA_ARENA_WALK_GIB =
 // 160 and by the budget PA_ARENA_FRACTION = 0.70 of the free memory / PA_ARENA_GIB).  An extent nothing lives in any more
-// is released, except the newest such one (PA_ARENA_SPARE = 1: re-allocating memory this process freed costs a driver-side
-// wipe of ~75 ms per GiB).  Every big vector handed out is checked once against the newest matrix stream with the same stand-in
+// is released (PA_ARENA_SPARE = n keeps the newest n: re-allocating memory that has been used costs a driver-side wipe of
+// 30-75 ms per GiB).  The extent the vectors' walk ends in is replaced by a right-sized one (4 GiB or 8 x the request).  Every big vector handed out is checked once against the newest matrix stream with the same stand-in
 // kernel (~1.5 ms, PA_ARENA_SELFCHECK=0 disables): a pair that times as "same class" although the map says otherwise is
 // moved to the other clean class or reported.  All of it under the context's mutex; any failure (no contiguous memory, a
 // probe error) freezes growth and falls back to hipMalloc -- never an error of the caller's allocation.
@@ -295,11 +295,12 @@ static void arena_release(pa_arena *a, pa_extent *X) {
   delete X;
 }
 
-// Extents nothing lives in are handed back to the driver -- all but the newest `spare` of them (PA_ARENA_SPARE, default 1):
-// memory this process has freed is wiped by the driver when it is allocated again, ~75 ms per GiB (extent_probe (a): 16 GiB
-// 0.84 s, 96 GiB 4.8 s), so a block that is created, destroyed and created again should find its extent still there.
+// Extents nothing lives in are handed back to the driver -- all but the newest PA_ARENA_SPARE of them (default 0: what a
+// context holds is what it uses; memory this process has freed is wiped by the driver when it is allocated again, 30-75 ms
+// per GiB -- extent_probe (a): 16 GiB 0.84 s, 96 GiB 4.8 s -- so a caller that creates, destroys and re-creates big blocks
+// in a loop may want a spare).
 static void arena_trim(pa_arena *a) {
-  static const int spare = getenv("PA_ARENA_SPARE") ? std::max(0, atoi(getenv("PA_ARENA_SPARE"))) : 1;
+  static const int spare = getenv("PA_ARENA_SPARE") ? std::max(0, atoi(getenv("PA_ARENA_SPARE"))) : 0;
   std::vector<pa_extent *> empty;
   for (pa_extent *X : a->ext) if (X->live == 0) empty.push_back(X);
   for (size_t i = 0; i + spare < empty.size(); ++i) arena_release(a, empty[i]);     // (ext is in order of acquisition: the oldest go)
@@ -496,19 +497,34 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
     } else (void)hipGetLastError();
   }
   if (!p && !a->frozen && !c->capturing) {
-    std::vector<pa_extent *> walked;
     size_t walk_budget = (size_t)160 * GIB;
     if (const char *s = getenv("PA_ARENA_WALK_GIB")) walk_budget = (size_t)atol(s) * GIB;
     size_t walked_bytes = 0;
+    pa_extent *found = nullptr;
     while (!p && walked_bytes < walk_budget) {
       pa_extent *X = arena_acquire(c, a, extent_bytes(a, bytes), "vectors: looking for a class without matrix streams");
       if (!X) break;
-      walked.push_back(X);
       walked_bytes += X->size;
-      p = try_clean();
+      if ((p = try_clean()) != nullptr) found = X;
     }
-    (void)walked;
-    arena_trim(a);                                      // what the walk went over goes back at once (but for the spare)
+    // Right-size what the walk found: the steps are big (to cross a class region of tens of GiB in a few of them), the
+    // vectors of a part are not -- the extent is handed back and a smaller one taken in its place (the driver gives the
+    // lowest free memory: the same place, hence the same class; checked, and the walk's own extent kept when it is not).
+    const size_t want = std::max<size_t>((size_t)4 * GIB, (8 * bytes + a->cell - 1) / a->cell * a->cell + 2 * a->cell);
+    if (p && found && found->size > want && found->live == a->live_[(uintptr_t)p].len) {
+      const int cls_found = a->live_[(uintptr_t)p].cls;
+      arena_give_back(a, p);                            // (found is empty now; the trim below keeps no spare by default)
+      p = nullptr;
+      if (std::find(a->ext.begin(), a->ext.end(), found) != a->ext.end()) arena_release(a, found);
+      pa_extent *Y = arena_acquire(c, a, want, "vectors: right-sized");
+      if (Y) p = try_clean();
+      if (!p) {                                         // it came from somewhere else after all: take a full step again
+        pa_extent *X = arena_acquire(c, a, extent_bytes(a, bytes), "vectors: looking for a class without matrix streams (again)");
+        if (X) p = try_clean();
+      }
+      (void)cls_found;
+    }
+    arena_trim(a);                                      // what the walk went over goes back at once
   }
   if (!p) {                                             // nothing clean anywhere: next to the fewest matrix bytes
     int order[3] = {0, 1, 2};

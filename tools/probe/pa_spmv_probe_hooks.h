@@ -10,9 +10,13 @@
 //   -DPA_PROBE_ONE_PLANE           every gather folded into the row's own grid plane (27-point 256^3)
 //   -DPA_PROBE_TILE_X              the x footprint of a 4 x 14 tile instead of 57 consecutive nodes
 //   -DPA_PROBE_LDS_X               three coalesced x loads per lane into LDS, gathers from there
+//   -DPA_PROBE_TILE_LDS            round 3, VERDICT r02 #5 "tile + LDS together": the x footprint of a 4 x 14 tile (3 planes x 6
+//                                  lines x 16 nodes = 288 doubles, 2.3 KB instead of the 4.2 KB of 57 consecutive nodes) staged
+//                                  ONCE per chunk with coalesced 128-byte runs, every gather a ds_read_b64
 //   EPI 7..13 (template argument)  variants of the y store: none / plain / 2 MiB window / nt window / 16-byte pairs / sc1 / sc0 sc1
 #ifndef PA_SPMV_PROBE_HOOKS_H
 #define PA_SPMV_PROBE_HOOKS_H
+#include <hip/hip_runtime.h>
 
 #ifdef PA_PROBE_IDENTITY_CHUNK_MAP
 #define PA_HOOK_CHUNK_MAP 1
@@ -51,6 +55,26 @@
     c0 = min(r0 + (tid & 63) + (int)(lo & 1), r1 - 1);                                                  \
     c1 = min(r0 + (tid & 63) + (int)(hi & 1), r1 - 1);                                                  \
   }
+#endif
+
+#ifdef PA_PROBE_TILE_LDS
+// lanes 0..287 fetch run = lane / 16 (plane = run / 6, line = run % 6), node = lane % 16 of the tile's footprint: 18 runs of
+// 128 bytes; a gather's true offset (dz, dy, q + dx) is folded into the tile (line = q / 14 + dy, node = q % 14 + dx).
+#define PA_HOOK_X_STAGE(x, r0, r1, tid)                                                                 \
+  __shared__ double xtile[3 * 6 * 16];                                                                  \
+  if (tid < 288) {                                                                                      \
+    const int run_ = tid >> 4, k_ = tid & 15, pl_ = run_ / 6, ln_ = run_ - pl_ * 6;                     \
+    xtile[tid] = x[min(max(r0 + k_ - 1 + (ln_ - 1) * 256 + (pl_ - 1) * 65536, 0), max_col)];            \
+  }                                                                                                     \
+  __syncthreads();
+__device__ __forceinline__ int pa_probe_tile_slot(int off) {
+  const int dz = (off + 32768) >> 16, rem = off - (dz << 16);
+  const int dy = (rem + 64) >> 8, qdx = rem - (dy << 8) + 14;                 // q + dx + 14 in [13, 71]
+  const int ly = (qdx * 4682) >> 16;                                          // qdx / 14
+  const int line = min(max(ly - 1 + dy + 1, 0), 5), node = qdx - ly * 14 + 1; // node in [1, 14]
+  return (dz + 1) * 96 + line * 16 + node;
+}
+#define PA_HOOK_X_AT(x, c, r0) xtile[min(max(pa_probe_tile_slot((c) - (r0)), 0), 287)]
 #endif
 
 #ifdef PA_PROBE_LDS_X
