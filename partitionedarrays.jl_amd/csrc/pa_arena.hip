@@ -511,11 +511,18 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
     // vectors of a part are not -- the extent is handed back and a smaller one taken in its place (the driver gives the
     // lowest free memory: the same place, hence the same class; checked, and the walk's own extent kept when it is not).
     const size_t want = std::max<size_t>((size_t)4 * GIB, (8 * bytes + a->cell - 1) / a->cell * a->cell + 2 * a->cell);
-    if (p && found && found->size > want && found->live == a->live_[(uintptr_t)p].len) {
+    // (an extent that showed a class for the first time also holds that class's reference cell and scratch: the class is
+    // forgotten with it -- it has the highest id, nothing else can carry it yet -- and met again in the smaller extent)
+    const size_t scr_len = (probe_wr_bytes(probe_nb(a->cell)) + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
+    const int top = a->n_classes - 1;
+    const bool introduced = p && found && top >= 0 && a->ref[top] >= found->base && a->ref[top] < found->base + found->size;
+    if (p && found && found->size > want && found->live == a->live_[(uintptr_t)p].len + (introduced ? scr_len : 0)) {
       const int cls_found = a->live_[(uintptr_t)p].cls;
-      arena_give_back(a, p);                            // (found is empty now; the trim below keeps no spare by default)
+      if (introduced) found->live -= scr_len;           // (the scratch goes with the extent)
+      arena_give_back(a, p);                            // (found is empty now: the trim inside hands it back)
       p = nullptr;
       if (std::find(a->ext.begin(), a->ext.end(), found) != a->ext.end()) arena_release(a, found);
+      if (introduced) { a->n_classes = top; a->ref[top] = nullptr; a->scr[top] = nullptr; a->mat_bytes[top] = a->vec_bytes[top] = 0; }
       pa_extent *Y = arena_acquire(c, a, want, "vectors: right-sized");
       if (Y) p = try_clean();
       if (!p) {                                         // it came from somewhere else after all: take a full step again

@@ -878,13 +878,18 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
     const char *ex = getenv("PA_SPMV_XWIN");
     if (cs.use_c16 && !cs.use_pattern && !compact && !(ex && atoi(ex) == 0) && A->n_chunks >= 64) {
       const bool forced = ex && atoi(ex) == 2;
-      if (on_device) {                     // the windows were made on the device: the (host-side) grouping reads them
-        cs.win.resize((size_t)A->n_chunks * PA_C16_WINDOWS);
-        PA_HIP(hipMemcpy(cs.win.data(), A->d_win, sizeof(int32_t) * cs.win.size(), hipMemcpyDeviceToHost));
-      }
-      PA_TRY(host_columns());
       pa_xw_plan P;
-      pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz));
+      if (on_device) {
+        // the windows and the raw columns are on the device: the per-entry part of the planning (first / last column and
+        // distinct lines of x per chunk) is a kernel, the greedy grouping over the chunks stays here
+        pa_xw_chunk_stats S;
+        S.cmin.resize(A->n_chunks); S.cmax.resize(A->n_chunks); S.lines.resize(A->n_chunks);
+        PA_TRY(pa_dev_xw_chunk_stats(c, A->d_crp, A->d_col, A->d_chunk_row, A->d_win, A->n_chunks, PA_XW_CAP_BIG, S.cmin.data(),
+                                     S.cmax.data(), S.lines.data()));
+        pa_plan_xw_from_stats(crp.data(), chunk_row, S, forced, P);
+      } else {
+        pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz));
+      }
       const std::vector<pa_xw_group> &groups = P.groups;
       const std::vector<int32_t> &rest = P.rest;
       const int64_t grouped = P.grouped, staged = P.staged;
@@ -915,6 +920,12 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   // optional lossless value dictionary (PA_SPMV_VALUE_DICT=1): at most PA_VDICT_MAX distinct bit patterns
   {
     const char *e = getenv("PA_SPMV_VALUE_DICT");
+    std::vector<double> val_host;            // (a block assembled on the device: the optional dictionary is built from a host copy)
+    if (e && atoi(e) != 0 && nnz > 0 && !nzval && src.d_val) {
+      val_host.resize(nnz);
+      PA_HIP(hipMemcpy(val_host.data(), src.d_val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
+      nzval = val_host.data();
+    }
     if (e && atoi(e) != 0 && nnz > 0 && nzval) {
       const int T = host_threads(nnz);
       std::vector<std::vector<uint64_t>> local(T);

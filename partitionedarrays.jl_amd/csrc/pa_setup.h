@@ -30,6 +30,11 @@ int pa_dev_encode_columns(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col,
                           bool want_c16, bool compact_streams, pa_dev_streams &S);
 void pa_dev_streams_free(pa_ctx *c, pa_dev_streams &S);
 
+// per-chunk statistics of the x-window planning (pa_xw_scan_chunks of pa_spmv_xwin.h) computed on the device; host arrays of
+// n_chunks entries each
+int pa_dev_xw_chunk_stats(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int32_t *d_chunk_row, const int32_t *d_win,
+                          int64_t n_chunks, int max_cap, int32_t *cmin, int32_t *cmax, int32_t *lines);
+
 // pa_device.hip: a pa_csr from entries that are already in HBM (0-based; the arrays are copied, the caller keeps its own)
 int pa_csr_from_device(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_col,
                        const double *d_val, pa_csr **out);

@@ -278,6 +278,37 @@ __global__ void ks_mult8(const int *__restrict__ crp, int n, unsigned long long 
   }
 }
 
+// Per chunk on the 16-bit stream: first and last column and the number of distinct 128-byte lines of x (16 entries) its
+// gathers touch -- pa_xw_scan_chunks (pa_spmv_xwin.h) on the device; the line set is a bitmap in registers (a chunk whose
+// span exceeds the largest window is not counted: it cannot join a group anyway).
+__global__ void ks_xw_stats(const int *__restrict__ crp, const int *__restrict__ col, const int *__restrict__ chunk_row,
+                            const int *__restrict__ win, int n_chunks, int max_cap, int *__restrict__ cmin, int *__restrict__ cmax,
+                            int *__restrict__ lines) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_chunks) return;
+  int lo = 0x7fffffff, hi = -1, n = 0;
+  if (win[(size_t)c * PA_C16_WINDOWS] >= 0) {
+    const int p0 = crp[chunk_row[c]], p1 = crp[chunk_row[c + 1]];
+    for (int p = p0; p < p1; ++p) { const int j = col[p]; lo = min(lo, j); hi = max(hi, j); }
+    if (hi >= 0 && hi - lo + 2 <= max_cap - 2) {
+      constexpr int W = 17;                                    // 17 x 64 lines x 16 entries >= the largest window + one line
+      unsigned long long bits[W];
+#pragma unroll
+      for (int k = 0; k < W; ++k) bits[k] = 0ull;
+      const int l0 = lo >> 4;
+      for (int p = p0; p < p1; ++p) {
+        const int l = (col[p] >> 4) - l0, w = l >> 6;
+        const unsigned long long m = 1ull << (l & 63);
+#pragma unroll
+        for (int k = 0; k < W; ++k) if (k == w) bits[k] |= m;
+      }
+#pragma unroll
+      for (int k = 0; k < W; ++k) n += __popcll(bits[k]);
+    }
+  }
+  cmin[c] = lo; cmax[c] = hi; lines[c] = n;
+}
+
 __global__ void ks_minmax(const int *__restrict__ p, int64_t n, int *__restrict__ out) {
   int mn = 0x7fffffff, mx = (int)0x80000000;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -452,6 +483,22 @@ int encode_impl(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int
 }
 
 }  // namespace
+
+int pa_dev_xw_chunk_stats(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int32_t *d_chunk_row, const int32_t *d_win,
+                          int64_t n_chunks, int max_cap, int32_t *cmin, int32_t *cmax, int32_t *lines) {
+  using namespace pa_util;
+  scratch sc;
+  int *a = nullptr, *b = nullptr, *l = nullptr;
+  PA_TRY(sc.get(&a, n_chunks));
+  PA_TRY(sc.get(&b, n_chunks));
+  PA_TRY(sc.get(&l, n_chunks));
+  hipLaunchKernelGGL(ks_xw_stats, grid1(n_chunks, 64), dim3(64), 0, c->s[0], d_crp, d_col, d_chunk_row, d_win, (int)n_chunks, max_cap, a, b, l);
+  PA_HIP(hipGetLastError());
+  PA_TRY(d2h(c->s[0], cmin, a, (size_t)n_chunks));
+  PA_TRY(d2h(c->s[0], cmax, b, (size_t)n_chunks));
+  PA_TRY(d2h(c->s[0], lines, l, (size_t)n_chunks));
+  return PA_OK;
+}
 
 void pa_dev_streams_free(pa_ctx *c, pa_dev_streams &S) {
   pa_dev_free(c, S.d_pdesc); pa_dev_free(c, S.d_pdelta); pa_dev_free(c, S.d_win); pa_dev_free(c, S.d_c16); pa_dev_free(c, S.d_c32);

@@ -299,14 +299,13 @@ struct pa_xw_plan {
   std::vector<int32_t> rest;
   int64_t n_tier[PA_XW_TIERS] = {0, 0, 0}, staged = 0, grouped = 0;
 };
-inline void pa_plan_xw(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row, const int32_t *win,
-                       bool forced, pa_xw_plan &P, int n_threads = 1) {
+// (the per-chunk statistics S come from pa_xw_scan_chunks on the host or from the device kernel of pa_setup.hip: the same numbers)
+inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t> &chunk_row, const pa_xw_chunk_stats &S, bool forced,
+                                  pa_xw_plan &P) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   P = pa_xw_plan();
   std::vector<char> taken(n_chunks, 0);
   const int caps[PA_XW_TIERS] = {PA_XW_CAP, PA_XW_CAP_MID, PA_XW_CAP_BIG};
-  pa_xw_chunk_stats S;
-  pa_xw_scan_chunks(crp, col, chunk_row, win, PA_XW_CAP_BIG, n_threads, S);
   for (int tier = 0; tier < PA_XW_TIERS; ++tier) {
     std::vector<char> t2 = taken;
     std::vector<pa_xw_group> g;
@@ -325,4 +324,10 @@ inline void pa_plan_xw(const int32_t *crp, const int32_t *col, const std::vector
   }
   for (int64_t c = 0; c < n_chunks; ++c)
     if (!taken[c]) P.rest.push_back((int32_t)c);
+}
+inline void pa_plan_xw(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row, const int32_t *win,
+                       bool forced, pa_xw_plan &P, int n_threads = 1) {
+  pa_xw_chunk_stats S;
+  pa_xw_scan_chunks(crp, col, chunk_row, win, PA_XW_CAP_BIG, n_threads, S);
+  pa_plan_xw_from_stats(crp, chunk_row, S, forced, P);
 }
