@@ -465,6 +465,9 @@ int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int6
 /* Set-up of the multicolour smoother: the rows of a part (split blocks, 1-based Int32) dealt by colour into n_colors
  * blocks in the unsplit column order (own columns, then ghost columns + n_own_cols), plus the diagonal.  out_rowptr[k]
  * (n_own+1 entries, 1-based) is prefilled by the caller: a row of another colour has length 0 in block k. */
+/* row pointers (1-based, n_own + 1 entries each) of the n_colors blocks pa_host_color_split fills; color[r] == -1: no block */
+int pa_host_color_rowptrs(int64_t n_own, const int32_t *oo_rowptr, const int32_t *oh_rowptr, const int32_t *color,
+                          int32_t n_colors, int32_t *const *out_rowptr);
 int pa_host_color_split(int64_t n_own, int64_t n_own_cols, const int32_t *oo_rowptr, const int32_t *oo_colval,
                         const double *oo_nzval, const int32_t *oh_rowptr, const int32_t *oh_colval, const double *oh_nzval,
                         const int32_t *color, int32_t n_colors, const int32_t *const *out_rowptr,

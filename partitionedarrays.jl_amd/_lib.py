@@ -156,6 +156,7 @@ _SIGS = {
     "pa_host_check_xw_groups": [i64, i64, i64, P, P, cint] + [C.POINTER(i64)] * 5,
     "pa_host_hpcg_ghosts": [i64] * 9 + [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "pa_host_hpcg_split_csr": [i64] * 9 + [P, i64, P, P, P, P, P, P, P],
+    "pa_host_color_rowptrs": [i64, P, P, P, C.c_int32, P],
     "pa_host_color_split": [i64, i64, P, P, P, P, P, P, P, i32, P, P, P, P],
     "pa_host_hpcg_split_csr64": [i64] * 9 + [P, i64, P, P, P, P, P, P, P],
 }

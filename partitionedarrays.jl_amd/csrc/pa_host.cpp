@@ -449,8 +449,57 @@ extern "C" int pa_host_hpcg_split_csr64(int64_t nx, int64_t ny, int64_t nz, int6
 // Multicolour smoother set-up: split the rows of a part by colour into n_colors blocks (n_own x n_local, unsplit
 // column order: own columns, then ghost columns shifted by n_own_cols) and extract the diagonal.  out_rowptr[k] is
 // colour k's 1-based row pointer (n_own+1 entries, prefilled by the caller from the row lengths: a row of another colour
-// has length 0); the entries are copied row by row in parallel.
+// has length 0); the entries are copied row by row in parallel.  color[r] == -1: row r goes to no block.
 // ------------------------------------------------------------------------------------------------
+// 1-based row pointers of the n_colors blocks pa_host_color_split fills: out_rowptr[k][r + 1] - out_rowptr[k][r] = the stored
+// entries of row r (own + ghost columns) when color[r] == k, else 0.  Threads take row ranges; a first pass gives every
+// range its first slot per colour.
+extern "C" int pa_host_color_rowptrs(int64_t n_own, const int32_t *oo_rowptr, const int32_t *oh_rowptr, const int32_t *color,
+                                     int32_t n_colors, int32_t *const *out_rowptr) {
+  PA_REQUIRE(n_own >= 0 && oo_rowptr && oh_rowptr && color && out_rowptr && n_colors > 0 && n_colors <= 64, "bad arguments");
+  const int T = n_threads_for(n_own * 8);
+  std::vector<int64_t> sums((size_t)T * n_colors, 0);
+  auto len = [&](int64_t r) { return (int64_t)(oo_rowptr[r + 1] - oo_rowptr[r]) + (oh_rowptr[r + 1] - oh_rowptr[r]); };
+  bool bad = false;
+  auto count = [&](int t) {
+    for (int64_t r = n_own * t / T; r < n_own * (t + 1) / T; ++r) {
+      const int k = color[r];
+      if (k == -1) continue;
+      if (k < 0 || k >= n_colors) { bad = true; continue; }
+      sums[(size_t)t * n_colors + k] += len(r);
+    }
+  };
+  auto fill = [&](int t) {
+    std::vector<int64_t> at(n_colors);
+    for (int k = 0; k < n_colors; ++k) {
+      int64_t a = 1;
+      for (int u = 0; u < t; ++u) a += sums[(size_t)u * n_colors + k];
+      at[k] = a;
+    }
+    for (int64_t r = n_own * t / T; r < n_own * (t + 1) / T; ++r) {
+      const int k = color[r];
+      for (int j = 0; j < n_colors; ++j) out_rowptr[j][r] = (int32_t)at[j];
+      if (k >= 0 && k < n_colors) at[k] += len(r);
+    }
+    if (t == T - 1) for (int j = 0; j < n_colors; ++j) out_rowptr[j][n_own] = (int32_t)at[j];
+  };
+  auto run = [&](auto &f) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(f, t);
+    f(0);
+    for (auto &x : th) x.join();
+  };
+  run(count);
+  PA_REQUIRE(!bad, "a colour outside 0..n_colors-1");
+  for (int k = 0; k < n_colors; ++k) {
+    int64_t tot = 0;
+    for (int t = 0; t < T; ++t) tot += sums[(size_t)t * n_colors + k];
+    PA_REQUIRE(tot < (int64_t)2147483000, "colour %d holds more entries than Int32 row pointers address", k);
+  }
+  run(fill);
+  return PA_OK;
+}
+
 extern "C" int pa_host_color_split(int64_t n_own, int64_t n_own_cols, const int32_t *oo_rowptr, const int32_t *oo_colval,
                                    const double *oo_nzval, const int32_t *oh_rowptr, const int32_t *oh_colval,
                                    const double *oh_nzval, const int32_t *color, int32_t n_colors,
@@ -463,6 +512,7 @@ extern "C" int pa_host_color_split(int64_t n_own, int64_t n_own_cols, const int3
   auto work = [&](int t) {
     for (int64_t r = n_own * t / T; r < n_own * (t + 1) / T; ++r) {
       const int k = color[r];
+      if (k == -1) continue;                         // a row no block takes (the caller wants some of the rows only)
       if (k < 0 || k >= n_colors) { bad = true; continue; }
       int64_t dst = out_rowptr[k][r] - 1;
       const int64_t need = (oo_rowptr[r + 1] - oo_rowptr[r]) + (oh_rowptr[r + 1] - oh_rowptr[r]);

@@ -111,30 +111,20 @@ def _unsplit_csr(h, r, c):
 
 def _rows_block(h, r, c, f):
     """The stored entries of the own rows `f` (0-based, ascending) of one part as an n_own x n_local block in the
-    unsplit column order (own columns, then ghost columns shifted by n_own); every other row is empty."""
+    unsplit column order (own columns, then ghost columns shifted by n_own); every other row is empty.  The copy is the
+    native, multi-threaded one of the colour split with one "colour" = the rows wanted (pa_host_color_split, -1 = no block)."""
     from .p_sparse_matrix import HostCSR
     oo, oh = h
     n = r.n_own
-
-    def take(blk):
-        rp = blk.rowptr.astype(np.int64) - 1
-        cnt = rp[f + 1] - rp[f]
-        first = np.concatenate([[0], np.cumsum(cnt)[:-1]])
-        return cnt, first, np.repeat(rp[f] - first, cnt) + np.arange(int(cnt.sum()))
-
-    c1, f1, i1 = take(oo)
-    c2, f2, i2 = take(oh)
-    cnt = c1 + c2
-    start = np.concatenate([[0], np.cumsum(cnt)])
-    colv = np.empty(int(start[-1]), np.int32)
-    val = np.empty(int(start[-1]))
-    p1 = np.repeat(start[:-1] - f1, c1) + np.arange(int(c1.sum()))
-    p2 = np.repeat(start[:-1] + c1 - f2, c2) + np.arange(int(c2.sum()))
-    colv[p1], val[p1] = oo.colval[i1], oo.nzval[i1]
-    colv[p2], val[p2] = oh.colval[i2] + c.n_own, oh.nzval[i2]
-    full = np.zeros(n, np.int64)
-    full[f] = cnt
-    rp = np.concatenate([[1], 1 + np.cumsum(full)]).astype(np.int32)
+    color = np.full(n, -1, np.int32)
+    color[f] = 0
+    one = lambda a: (C.c_void_p * 1)(a.ctypes.data)
+    rp = np.empty(n + 1, np.int32)
+    L.call("pa_host_color_rowptrs", n, L.ptr(oo.rowptr), L.ptr(oh.rowptr), L.ptr(color), 1, one(rp))
+    nz = int(rp[-1]) - 1
+    colv, val, diag = np.empty(nz, np.int32), np.empty(nz, np.float64), np.zeros(n)
+    L.call("pa_host_color_split", n, c.n_own, L.ptr(oo.rowptr), L.ptr(oo.colval), L.ptr(oo.nzval), L.ptr(oh.rowptr),
+           L.ptr(oh.colval), L.ptr(oh.nzval), L.ptr(color), 1, one(rp), one(colv), one(val), L.ptr(diag))
     return HostCSR(n, c.n_local, rp, colv, val)
 
 
@@ -160,14 +150,14 @@ class ColoredGaussSeidelSpMV:
             # rows of one colour must not be coupled: the own x own block holds every coupling between own rows
             L.call("pa_host_greedy_coloring", n, L.ptr(oo.rowptr), L.ptr(oo.colval), 1, L.ptr(color), C.byref(ncol))
             K = ncol.value
-            length = np.diff(oo.rowptr.astype(np.int64)) + np.diff(oh.rowptr.astype(np.int64))
-            subs = []
-            for k in range(K):
-                rp = np.concatenate([[1], 1 + np.cumsum(np.where(color == k, length, 0))]).astype(np.int32)
-                nz = int(rp[-1]) - 1
-                subs.append(HostCSR(n, c.n_local, rp, np.zeros(nz, np.int32), np.zeros(nz, np.float64)))
-            diag = np.zeros(n)
             arr = lambda xs: (C.c_void_p * K)(*[x.ctypes.data for x in xs])
+            rps = [np.empty(n + 1, np.int32) for _ in range(K)]                  # (one native, threaded pass for all colours)
+            L.call("pa_host_color_rowptrs", n, L.ptr(oo.rowptr), L.ptr(oh.rowptr), L.ptr(color), K, arr(rps))
+            subs = []
+            for rp in rps:
+                nz = int(rp[-1]) - 1
+                subs.append(HostCSR(n, c.n_local, rp, np.empty(nz, np.int32), np.empty(nz, np.float64)))
+            diag = np.zeros(n)
             L.call("pa_host_color_split", n, c.n_own, L.ptr(oo.rowptr), L.ptr(oo.colval), L.ptr(oo.nzval), L.ptr(oh.rowptr),
                    L.ptr(oh.colval), L.ptr(oh.nzval), L.ptr(color), K, arr([s.rowptr for s in subs]),
                    arr([s.colval for s in subs]), arr([s.nzval for s in subs]), L.ptr(diag))
