@@ -761,10 +761,8 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   const int64_t nc = (int64_t)crp.size() - 1;
   std::vector<int32_t> chunk_row;
   int64_t n_long = 0;
-  pa_build_chunks(crp.data(), nc, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
-  lap("chunks");
   A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz;
-  A->n_crows = nc; A->n_chunks = (int64_t)chunk_row.size() - 1; A->n_nonempty = n_nonempty; A->n_long = n_long;
+  A->n_crows = nc; A->n_nonempty = n_nonempty;
   A->compact = compact;
   PA_HIP(hipSetDevice(c->device));
   const size_t pad = 8;
@@ -779,10 +777,15 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   // (the value stream first: it is the allocation that brings the context's arena into being, pa_arena.hip)
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_val, sizeof(double) * (nnz + pad), PA_MEM_MATRIX));
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_crp, sizeof(int32_t) * (nc + 1), PA_MEM_MATRIX));
-  PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_row, sizeof(int32_t) * chunk_row.size(), PA_MEM_MATRIX));
   PA_HIP(hipMemsetAsync(A->d_val + nnz, 0, sizeof(double) * pad, c->s[0]));            // (the streams are non-blocking: a null-stream
   PA_HIP(hipStreamSynchronize(c->s[0]));                                               // memset would not be ordered with the kernels)
   PA_HIP(pa_h2d(A->d_crp, crp.data(), sizeof(int32_t) * (nc + 1)));
+  // the row split: on the device from the row pointers just uploaded (pointer doubling, pa_setup.hip) or the host's greedy loop
+  if (on_device) PA_TRY(pa_dev_row_split(c, A->d_crp, nc, PA_SPMV_CHUNK_NNZ, 4096, 8, chunk_row, &n_long));
+  else pa_build_chunks(crp.data(), nc, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
+  lap("chunks");
+  A->n_chunks = (int64_t)chunk_row.size() - 1; A->n_long = n_long;
+  PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_row, sizeof(int32_t) * chunk_row.size(), PA_MEM_MATRIX));
   if (nnz && src.on_device()) {
     PA_HIP(hipMemcpyAsync(A->d_val, src.d_val, sizeof(double) * nnz, hipMemcpyDeviceToDevice, c->s[0]));
     PA_HIP(hipStreamSynchronize(c->s[0]));

@@ -3,6 +3,7 @@
 #define PA_SETUP_H
 
 #include <cstdint>
+#include <vector>
 
 #include "pa_internal.h"
 
@@ -29,6 +30,11 @@ int pa_dev_encode_columns(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col,
                           int64_t nnz, const int32_t *d_chunk_row, int64_t n_chunks, int cap, bool want_pattern,
                           bool want_c16, bool compact_streams, pa_dev_streams &S);
 void pa_dev_streams_free(pa_ctx *c, pa_dev_streams &S);
+
+// the row split of pa_build_chunks (pa_spmv_kernel.h) on the device: chunk_row (host) = the chunk boundaries, the host
+// loop's array exactly
+int pa_dev_row_split(pa_ctx *c, const int32_t *d_crp, int64_t nc, int cap, int max_rows, int align_rows,
+                     std::vector<int32_t> &chunk_row, int64_t *n_long);
 
 // per-chunk statistics of the x-window planning (pa_xw_scan_chunks of pa_spmv_xwin.h) computed on the device; host arrays of
 // n_chunks entries each

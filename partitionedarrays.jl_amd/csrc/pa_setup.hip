@@ -278,6 +278,48 @@ __global__ void ks_mult8(const int *__restrict__ crp, int n, unsigned long long 
   }
 }
 
+// ---- the row split on the device (pa_build_chunks, pa_spmv_kernel.h) -------------------------------------------------------
+// The host loop is greedy and sequential: a chunk starts where the previous one ended.  In parallel: nxt[r] = the end of the
+// chunk that WOULD start at row r (independent per row: a binary search in the row pointers, the max-rows cap, the 64-byte
+// alignment rule), and the chunk starts are the orbit of row 0 under nxt.  The orbit is marked by pointer doubling: with
+// jump = nxt^(2^k), "every marked row marks jump[row]", then jump := jump o jump; after ceil(log2(rows)) + 1 rounds every
+// element of the orbit is marked (each index of the orbit is a sum of distinct powers of two) and nothing else is.
+__global__ void ks_chunk_next(const int *__restrict__ crp, int nc, int cap, int max_rows, int align_rows, int *__restrict__ nxt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nc) return;
+  if (r == nc) { nxt[r] = nc; return; }
+  const long long base = crp[r] & ~1;
+  int e = r + 1;
+  if ((long long)crp[e] - base <= cap) {
+    int lo = r + 1, hi = min(nc, r + max_rows);               // largest e in [lo, hi] with crp[e] - base <= cap
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if ((long long)crp[mid] - base <= cap) lo = mid; else hi = mid - 1;
+    }
+    e = lo;
+    if (align_rows > 1 && e < nc) {
+      const int ea = e - (e % align_rows);
+      if (ea > r && (long long)(ea - r) * 4 >= (long long)(e - r) * 3) e = ea;
+    }
+  }
+  nxt[r] = e;
+}
+__global__ void ks_orbit_mark(const int *__restrict__ jump, int n, int *__restrict__ mark) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && mark[r]) mark[jump[r]] = 1;                    // (in place: a row marked in this very round is on the orbit too)
+}
+__global__ void ks_jump_square(const int *__restrict__ in, int n, int *__restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) out[r] = in[in[r]];
+}
+__global__ void ks_chunk_rows(const int *__restrict__ mark, const int *__restrict__ mscan, const int *__restrict__ crp, int n, int nc,
+                              int cap, int *__restrict__ chunk_row, unsigned long long *__restrict__ n_long) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n || !mark[r]) return;
+  chunk_row[mscan[r]] = r;                                     // exclusive scan
+  if (r < nc && (long long)crp[r + 1] - (crp[r] & ~1) > cap) atomicAdd(n_long, 1ull);
+}
+
 // Per chunk on the 16-bit stream: first and last column and the number of distinct 128-byte lines of x (16 entries) its
 // gathers touch -- pa_xw_scan_chunks (pa_spmv_xwin.h) on the device; the line set is a bitmap in registers (a chunk whose
 // span exceeds the largest window is not counted: it cannot join a group anyway).
@@ -483,6 +525,48 @@ int encode_impl(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int
 }
 
 }  // namespace
+
+int pa_dev_row_split(pa_ctx *c, const int32_t *d_crp, int64_t nc, int cap, int max_rows, int align_rows,
+                     std::vector<int32_t> &chunk_row, int64_t *n_long) {
+  using namespace pa_util;
+  hipStream_t s = c->s[0];
+  scratch sc;
+  const int n = (int)nc + 1;
+  int *jump = nullptr, *jump2 = nullptr, *mark = nullptr, *mscan = nullptr, *out = nullptr;
+  unsigned long long *nl = nullptr;
+  PA_TRY(sc.get(&jump, n));
+  PA_TRY(sc.get(&jump2, n));
+  PA_TRY(sc.get(&mark, (size_t)n + 1));
+  PA_TRY(sc.get(&mscan, (size_t)n + 1));
+  PA_TRY(sc.get(&nl, 1));
+  PA_HIP(hipMemsetAsync(mark, 0, sizeof(int) * ((size_t)n + 1), s));
+  PA_HIP(hipMemsetAsync(nl, 0, sizeof(unsigned long long), s));
+  const int one = 1;
+  PA_HIP(hipMemcpyAsync(mark, &one, sizeof(int), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(ks_chunk_next, grid1(n), dim3(256), 0, s, d_crp, (int)nc, cap, max_rows, align_rows, jump);
+  int rounds = 1;
+  while (((int64_t)1 << rounds) < (int64_t)n) ++rounds;
+  for (int k = 0; k <= rounds; ++k) {
+    hipLaunchKernelGGL(ks_orbit_mark, grid1(n), dim3(256), 0, s, jump, n, mark);
+    hipLaunchKernelGGL(ks_jump_square, grid1(n), dim3(256), 0, s, jump, n, jump2);
+    std::swap(jump, jump2);
+  }
+  PA_HIP(hipGetLastError());
+  PA_TRY(scan_exclusive<int>(sc, s, mark, mscan, (size_t)n + 1));
+  int count = 0;
+  PA_TRY(d2h(s, &count, mscan + n, 1));
+  PA_REQUIRE(count >= 1, "the device row split lost its first row");
+  PA_TRY(sc.get(&out, count));
+  hipLaunchKernelGGL(ks_chunk_rows, grid1(n), dim3(256), 0, s, mark, mscan, d_crp, n, (int)nc, cap, out, nl);
+  PA_HIP(hipGetLastError());
+  chunk_row.resize(count);
+  PA_TRY(d2h(s, chunk_row.data(), out, (size_t)count));
+  unsigned long long h = 0;
+  PA_TRY(d2h(s, &h, nl, 1));
+  *n_long = (int64_t)h;
+  PA_REQUIRE(chunk_row.front() == 0 && chunk_row.back() == (int32_t)nc, "the device row split does not span the rows");
+  return PA_OK;
+}
 
 int pa_dev_xw_chunk_stats(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int32_t *d_chunk_row, const int32_t *d_win,
                           int64_t n_chunks, int max_cap, int32_t *cmin, int32_t *cmax, int32_t *lines) {

@@ -416,3 +416,60 @@ def test_jagged_array_golden(orc, golden):
         assert [list(J[i]) for i in range(len(J))] == c["a"]
     b = pa.JaggedArray.from_lists(c["a"], np.int64)
     assert pa.JaggedArray(b.data, b.ptrs) == b and b.tolists() == c["a"]
+
+
+def test_threaded_fdm_generator_writes_the_sequential_stream(orc, monkeypatch):
+    """pa_host_laplacian_fdm fills the triplets with host threads over slabs of the outermost direction, each slab's first
+    slot from a closed form: the stream must be the sequential loop's (src/gallery.jl:40-84) whatever the thread count, also
+    for parts that touch the grid's faces on either side, in 1, 2 and 3 dimensions.  (Large enough for the threads to start.)"""
+    for shape, parts in (((130, 120, 80), (1, 1, 1)), ((90, 100, 120), (2, 1, 2)), ((1500, 900), (2, 3)), ((1300000,), (3,))):
+        want = None
+        for threads in ("1", "3", "7"):
+            monkeypatch.setenv("PA_HOST_THREADS", threads)
+            I, J, V, _, _ = pa.laplacian_fdm(shape, parts, ranks(int(np.prod(parts))))
+            got = [(a.copy(), b.copy(), c.copy()) for a, b, c in zip(I.items, J.items, V.items)]
+            if want is None:
+                want = got
+                if int(np.prod(shape)) <= 1300000:          # the oracle's own (pure numpy) generator on the small ones
+                    Io, Jo, Vo, _, _ = orc.laplacian_fdm_fast(shape, parts) if len(shape) == 3 else orc.laplacian_fdm(shape, parts)
+                    for (a, b, c), io, jo, vo in zip(got, Io, Jo, Vo):
+                        assert np.array_equal(a, io) and np.array_equal(b, jo) and np.array_equal(c, vo), (shape, parts)
+            else:
+                for (a, b, c), (a0, b0, c0) in zip(got, want):
+                    assert np.array_equal(a, a0) and np.array_equal(b, b0) and np.array_equal(c, c0), (shape, parts, threads)
+
+
+def test_colour_block_row_pointers_and_row_subsets(orc, monkeypatch):
+    """pa_host_color_rowptrs (one threaded pass for all colours; -1 = a row no block takes) against the numpy statement it
+    replaces, and hpcg._rows_block (the restriction rows as a block) against a literal row-by-row copy."""
+    import ctypes as C
+    import pa_amd._lib as L
+    import pa_amd.hpcg as H
+    from pa_amd.gallery import build_split_blocks_fused
+    rows = pa.uniform_partition(ranks(4), (2, 2, 1), (64, 64, 32))
+    for threads in ("1", "5"):
+        monkeypatch.setenv("PA_HOST_THREADS", threads)
+        for my in rows.items:
+            cols, oo, oh, _ = build_split_blocks_fused(my, 32, 32, 32, 64, 64, 32)
+            n = my.n_own
+            color, ncol = np.zeros(n, np.int32), C.c_int32()
+            L.call("pa_host_greedy_coloring", n, L.ptr(oo.rowptr), L.ptr(oo.colval), 1, L.ptr(color), C.byref(ncol))
+            K = ncol.value
+            assert K == 8
+            color[::37] = -1                                              # rows no block takes
+            length = np.diff(oo.rowptr.astype(np.int64)) + np.diff(oh.rowptr.astype(np.int64))
+            rps = [np.empty(n + 1, np.int32) for _ in range(K)]
+            L.call("pa_host_color_rowptrs", n, L.ptr(oo.rowptr), L.ptr(oh.rowptr), L.ptr(color), K, (C.c_void_p * K)(*[x.ctypes.data for x in rps]))
+            for k in range(K):
+                assert np.array_equal(rps[k], np.concatenate([[1], 1 + np.cumsum(np.where(color == k, length, 0))]).astype(np.int32)), k
+            f = H.restrict_operator(32, 32, 32).astype(np.int64) - 1
+            B = H._rows_block((oo, oh), my, cols, f)
+            rp, cv, vv, keep = [1], [], [], set(f.tolist())
+            for r in range(n):
+                if r in keep:
+                    a, e = oo.rowptr[r] - 1, oo.rowptr[r + 1] - 1
+                    cv += list(oo.colval[a:e]); vv += list(oo.nzval[a:e])
+                    a, e = oh.rowptr[r] - 1, oh.rowptr[r + 1] - 1
+                    cv += list(oh.colval[a:e] + cols.n_own); vv += list(oh.nzval[a:e])
+                rp.append(len(cv) + 1)
+            assert np.array_equal(B.rowptr, np.array(rp)) and np.array_equal(B.colval, np.array(cv)) and np.array_equal(B.nzval, np.array(vv))
