@@ -85,6 +85,17 @@ static int host_threads(int64_t work) {
   return t;
 }
 
+// f(t, lo, hi) on T host threads over [0, n) split into T consecutive ranges (T = host_threads(work): 1 for small inputs)
+template <class F>
+static void host_parallel(int64_t n, int64_t work, F f) {
+  const int T = (int)std::min<int64_t>(host_threads(work), std::max<int64_t>(1, n));
+  if (T <= 1) { f(0, (int64_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(f, t, n * t / T, n * (t + 1) / T);
+  f(0, (int64_t)0, n / T);
+  for (auto &x : th) x.join();
+}
+
 __global__ void k_scale(double *__restrict__ y, int64_t n, double beta) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -743,18 +754,30 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   };
   std::vector<int32_t> row_ids;
   int64_t n_nonempty = 0;
-  for (int64_t r = 0; r < n_rows; ++r) n_nonempty += rp[r + 1] > rp[r];
+  std::vector<int64_t> part_cnt(33, 0);          // (host threads over row ranges: a colour block of the 256^3 operator has 16.8 M
+  host_parallel(n_rows, n_rows * 4, [&](int t, int64_t lo, int64_t hi) {      // rows, one in eight non-empty)
+    int64_t k = 0;
+    for (int64_t r = lo; r < hi; ++r) k += rp[r + 1] > rp[r];
+    part_cnt[t] = k;
+  });
+  for (int t = 0; t < 33; ++t) n_nonempty += part_cnt[t];
   const bool compact = n_rows > 0 && n_nonempty * 2 < n_rows;
   std::vector<int32_t> crp;
   if (compact) {
-    row_ids.reserve(n_nonempty);
-    crp.reserve(n_nonempty + 1);
-    crp.push_back(0);
-    for (int64_t r = 0; r < n_rows; ++r)
-      if (rp[r + 1] > rp[r]) {
-        row_ids.push_back((int32_t)r);
-        crp.push_back(rp[r + 1]);
-      }
+    row_ids.resize(n_nonempty);
+    crp.resize(n_nonempty + 1);
+    crp[0] = 0;
+    std::vector<int64_t> first(34, 0);
+    for (int t = 0; t < 33; ++t) first[t + 1] = first[t] + part_cnt[t];
+    host_parallel(n_rows, n_rows * 4, [&](int t, int64_t lo, int64_t hi) {
+      int64_t k = first[t];
+      for (int64_t r = lo; r < hi; ++r)
+        if (rp[r + 1] > rp[r]) {
+          row_ids[k] = (int32_t)r;
+          crp[k + 1] = rp[r + 1];
+          ++k;
+        }
+    });
   } else {
     crp.swap(rp);
   }
@@ -1037,7 +1060,9 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, con
       }
     }
     std::vector<int32_t> rp32(r1 - r0 + 1);
-    for (int64_t r = r0; r <= r1; ++r) rp32[r - r0] = (int32_t)(rp[r] - rp[r0]);
+    host_parallel(r1 - r0 + 1, (r1 - r0 + 1) * 4, [&](int, int64_t lo, int64_t hi) {
+      for (int64_t k = lo; k < hi; ++k) rp32[k] = (int32_t)(rp[r0 + k] - rp[r0]);
+    });
     pa_csr *S = nullptr;
     const int64_t snnz = rp[r1] - rp[r0];
     const int st = csr_build_slab(c, r1 - r0, n_cols, snnz, rp32, src.at(rp[r0]), &S);
@@ -1070,9 +1095,17 @@ extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, in
   PA_REQUIRE(nnz == 0 || (colval && nzval), "colval/nzval are NULL");
   const auto t0_ = std::chrono::steady_clock::now();
   std::vector<int64_t> rp(n_rows + 1);
-  for (int64_t r = 0; r <= n_rows; ++r) rp[r] = read_index(rowptr, rowptr_bytes, r) - index_base;
+  host_parallel(n_rows + 1, (n_rows + 1) * 4, [&](int, int64_t lo, int64_t hi) {
+    for (int64_t r = lo; r < hi; ++r) rp[r] = read_index(rowptr, rowptr_bytes, r) - index_base;
+  });
   PA_REQUIRE(rp[0] == 0 && rp[n_rows] == nnz, "rowptr does not span [base, base+nnz]");
-  for (int64_t r = 0; r < n_rows; ++r) PA_REQUIRE(rp[r + 1] >= rp[r], "rowptr not monotone at row %lld", (long long)r);
+  {
+    std::vector<int64_t> bad_row(33, -1);
+    host_parallel(n_rows, n_rows * 4, [&](int t, int64_t lo, int64_t hi) {
+      for (int64_t r = lo; r < hi; ++r) if (rp[r + 1] < rp[r]) { bad_row[t] = r; return; }
+    });
+    for (int t = 0; t < 33; ++t) PA_REQUIRE(bad_row[t] < 0, "rowptr not monotone at row %lld", (long long)bad_row[t]);
+  }
   std::unique_ptr<int32_t[]> colbuf;                   // (not a vector: no single-threaded zero fill of a multi-GB array)
   const int32_t *col0 = nullptr;
   if (colval_bytes == 4 && index_base == 0) {
