@@ -218,6 +218,8 @@ int pa_csr_encoding(const pa_csr *A, int64_t *n_pattern_chunks, int64_t *n_c16_c
  * block does not use it (PA_SPMV_XWIN=0 turns it off, =2 forces it for every block that has groups). */
 int pa_csr_xwin_info(const pa_csr *A, int64_t *n_groups, int64_t *n_chunks, int64_t *staged_x_entries,
                      int64_t *n_big_groups /* of n_groups: those on the 96 / 128 KiB windows (one workgroup per CU) */);
+/* groups of the sliding x window (csrc/pa_spmv_xwin.h, k_spmv_xring; counted in pa_csr_xwin_info's groups too) */
+int pa_csr_xring_info(const pa_csr *A, int64_t *n_ring_groups);
 /* HBM bytes the block occupies (values, the column streams actually kept, row pointers, chunk table, descriptors).
  * A block whose chunks are described by row patterns keeps no columns for them: a stencil operator costs ~8 bytes per
  * stored entry, a block on the 16-bit stream ~14 (8 + 4 + 2). */

@@ -127,6 +127,7 @@ _SIGS = {
     "pa_csr_info": [P] + [C.POINTER(i64)] * 6,
     "pa_csr_encoding": [P] + [C.POINTER(i64)] * 3,
     "pa_csr_xwin_info": [P] + [C.POINTER(i64)] * 4,
+    "pa_csr_xring_info": [P, C.POINTER(i64)],
     "pa_spmv": [P, P, cint, P, cint, f64, f64],
     "pa_sell_create": [P, i64, i64, i64, P, P, cint, cint, P, cint, PP],
     "pa_sell_destroy": [P],

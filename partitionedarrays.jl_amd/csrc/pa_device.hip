@@ -904,17 +904,21 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
     const char *ex = getenv("PA_SPMV_XWIN");
     if (cs.use_c16 && !cs.use_pattern && !compact && !(ex && atoi(ex) == 0) && A->n_chunks >= 64) {
       const bool forced = ex && atoi(ex) == 2;
+      const char *er = getenv("PA_SPMV_XRING");              // 0: windows only, 1 (default): 40 KiB windows, then the ring, 2: ring only
+      const int ring = er ? atoi(er) : 1;
+      std::vector<int32_t> cmax_host;
       pa_xw_plan P;
       if (on_device) {
         // the windows and the raw columns are on the device: the per-entry part of the planning (first / last column and
         // distinct lines of x per chunk) is a kernel, the greedy grouping over the chunks stays here
         pa_xw_chunk_stats S;
         S.cmin.resize(A->n_chunks); S.cmax.resize(A->n_chunks); S.lines.resize(A->n_chunks);
-        PA_TRY(pa_dev_xw_chunk_stats(c, A->d_crp, A->d_col, A->d_chunk_row, A->d_win, A->n_chunks, PA_XW_CAP_BIG, S.cmin.data(),
+        PA_TRY(pa_dev_xw_chunk_stats(c, A->d_crp, A->d_col, A->d_chunk_row, A->d_win, A->n_chunks, PA_XR_CAP, S.cmin.data(),
                                      S.cmax.data(), S.lines.data()));
-        pa_plan_xw_from_stats(crp.data(), chunk_row, S, forced, P);
+        pa_plan_xw_from_stats(crp.data(), chunk_row, S, forced, P, ring);
+        cmax_host.swap(S.cmax);
       } else {
-        pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz));
+        pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz), ring, &cmax_host);
       }
       const std::vector<pa_xw_group> &groups = P.groups;
       const std::vector<int32_t> &rest = P.rest;
@@ -924,6 +928,11 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
         for (size_t k = 0; k < chunk_row.size(); ++k) chunk_p[k] = crp[chunk_row[k]];
         A->n_xw_groups = (int64_t)groups.size(); A->n_xw_rest = (int64_t)rest.size();
         for (int t = 0; t < PA_XW_TIERS; ++t) A->n_xw_tier[t] = P.n_tier[t];
+        A->n_xw_ring = P.n_ring;
+        if (P.n_ring > 0) {
+          PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_cmax, sizeof(int32_t) * cmax_host.size(), PA_MEM_MATRIX));
+          PA_HIP(pa_h2d(A->d_chunk_cmax, cmax_host.data(), sizeof(int32_t) * cmax_host.size()));
+        }
         A->n_xw_chunks = A->n_chunks - A->n_xw_rest; A->xw_staged = staged;
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_p, sizeof(int32_t) * chunk_p.size(), PA_MEM_MATRIX));
         PA_TRY(pa_dev_alloc(c, (void **)&A->d_xw_grp, sizeof(pa_xw_group) * groups.size(), PA_MEM_MATRIX));
@@ -935,9 +944,9 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
         }
       }
       lap("x windows");
-      if (tm_) fprintf(stderr, "[pa setup] x windows: %lld + %lld + %lld groups (40 / 96 / 128 KiB), %lld of %lld entries, %lld staged x entries, %s\n",
-                       (long long)P.n_tier[0], (long long)P.n_tier[1], (long long)P.n_tier[2], (long long)grouped, (long long)nnz, (long long)staged,
-                       A->n_xw_groups ? "used" : "not used");
+      if (tm_) fprintf(stderr, "[pa setup] x windows: %lld + %lld + %lld groups (40 / 96 / 128 KiB) + %lld ring groups, %lld of %lld entries, %lld staged x entries, %s\n",
+                       (long long)P.n_tier[0], (long long)P.n_tier[1], (long long)P.n_tier[2], (long long)P.n_ring, (long long)grouped, (long long)nnz,
+                       (long long)staged, A->n_xw_groups ? "used" : "not used");
     }
   }
   lap("x windows");
@@ -1236,6 +1245,7 @@ static void csr_free_chain(pa_csr *A) {
     if (A->d_col16) pa_dev_free(A->ctx, A->d_col16);
     if (A->d_win) pa_dev_free(A->ctx, A->d_win);
     if (A->d_chunk_p) pa_dev_free(A->ctx, A->d_chunk_p);
+    if (A->d_chunk_cmax) pa_dev_free(A->ctx, A->d_chunk_cmax);
     if (A->d_xw_grp) pa_dev_free(A->ctx, A->d_xw_grp);
     if (A->d_xw_rest) pa_dev_free(A->ctx, A->d_xw_rest);
     if (A->d_pdesc) pa_dev_free(A->ctx, A->d_pdesc);
@@ -1403,6 +1413,14 @@ extern "C" int pa_csr_xwin_info(const pa_csr *A, int64_t *n_groups, int64_t *n_c
   return PA_OK;
 }
 
+extern "C" int pa_csr_xring_info(const pa_csr *A, int64_t *n_ring_groups) {
+  PA_REQUIRE(A && n_ring_groups, "bad arguments");
+  int64_t n = 0;
+  for (const pa_csr *S = A; S; S = S->next) n += S->n_xw_ring;
+  *n_ring_groups = n;
+  return PA_OK;
+}
+
 extern "C" int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes) {
   PA_REQUIRE(A && bytes, "bad arguments");
   int64_t t = 0;
@@ -1410,7 +1428,7 @@ extern "C" int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes) {
     const int64_t pad = 8;
     t += 4 * (S->n_crows + 1) + 4 * (S->n_col32 + pad) + 8 * (S->nnz + pad) + 4 * (S->n_chunks + 1);
     if (S->use_c16) t += 2 * S->n_col16 + 4 * S->n_chunks * PA_C16_WINDOWS;
-    if (S->n_xw_groups) t += 4 * (S->n_chunks + 1) + 16 * S->n_xw_groups + 4 * S->n_xw_rest;
+    if (S->n_xw_groups) t += 4 * (S->n_chunks + 1) + 16 * S->n_xw_groups + 4 * S->n_xw_rest + (S->n_xw_ring ? 4 * S->n_chunks : 0);
     if (S->use_pattern) t += 4 * S->n_chunks * PA_PDESC_INTS + 4 * S->n_pdelta;
     if (S->use_vdict) t += S->nnz + pad + 8 * PA_VDICT_MAX;
     if (S->compact) t += 4 * S->n_crows;
@@ -1431,7 +1449,7 @@ extern "C" int pa_csr_stream_bytes(const pa_csr *A, int64_t *bytes) {
     if (S->use_vdict) t += 8 * PA_VDICT_MAX;
     if (S->use_pattern) t += 4 * S->n_chunks * PA_PDESC_INTS + 4 * S->n_pdelta;
     if (S->use_c16) t += 4 * (S->n_chunks - S->n_pattern_chunks) * PA_C16_WINDOWS;
-    if (S->n_xw_groups) t += 4 * (S->n_chunks + 1) + 16 * S->n_xw_groups + 4 * S->n_xw_rest;
+    if (S->n_xw_groups) t += 4 * (S->n_chunks + 1) + 16 * S->n_xw_groups + 4 * S->n_xw_rest + (S->n_xw_ring ? 4 * S->n_chunks : 0);
     t += 2 * S->nnz_c16 + 4 * S->nnz_c32;
     if (S->compact) t += 4 * S->n_crows;
   }
@@ -1456,17 +1474,43 @@ extern "C" int pa_host_check_xw_groups(int64_t n_rows, int64_t n_cols, int64_t n
   pa_col_streams full;
   pa_encode_columns(crp.data(), col.data(), nullptr, n_rows, chunk_row, PA_SPMV_CHUNK_NNZ, false, true, 1, full);
   pa_xw_plan P;
-  if (full.use_c16) pa_plan_xw(crp.data(), col.data(), chunk_row, full.win.data(), false, P);
+  const char *er = getenv("PA_SPMV_XRING");
+  std::vector<int32_t> cmaxv;
+  if (full.use_c16) pa_plan_xw(crp.data(), col.data(), chunk_row, full.win.data(), false, P, 1, er ? atoi(er) : 1, &cmaxv);
   else for (int64_t c = 0; c < nch; ++c) P.rest.push_back((int32_t)c);
   const std::vector<pa_xw_group> &groups = P.groups;
   const std::vector<int32_t> &rest = P.rest;
   const int64_t grouped = P.grouped, staged = P.staged;
   int64_t in_groups = 0;
-  PA_REQUIRE(P.n_tier[0] + P.n_tier[1] + P.n_tier[2] == (int64_t)groups.size(), "tier counts");
+  const int64_t n_windows = P.n_tier[0] + P.n_tier[1] + P.n_tier[2];
+  PA_REQUIRE(n_windows + P.n_ring == (int64_t)groups.size(), "tier counts");
   std::vector<char> seen(nch, 0);
   int64_t check_staged = 0, check_grouped = 0;
   for (size_t gi = 0; gi < groups.size(); ++gi) {
     const pa_xw_group &g = groups[gi];
+    if ((int64_t)gi >= n_windows) {
+      // a ring group: replay k_spmv_xring's rounds (2 chunks each) -- every column a chunk gathers must have been loaded
+      // (>= the group's first column, <= the highest column loaded by its round) and not yet overwritten (within one ring
+      // capacity below that highest column)
+      PA_REQUIRE(g.cnt >= PA_XW_MING && g.cnt <= PA_XR_MAXG && g.first >= 0 && g.first + g.cnt <= nch, "ring group of %d chunks at %d", g.cnt, g.first);
+      int hcur = -1;
+      for (int c0 = g.first; c0 < g.first + g.cnt; c0 += 2) {
+        for (int c = c0; c < std::min(c0 + 2, g.first + g.cnt); ++c) hcur = std::max(hcur, cmaxv[c]);
+        for (int c = c0; c < std::min(c0 + 2, g.first + g.cnt); ++c) {
+          PA_REQUIRE(!seen[c], "chunk %d in two groups", c);
+          seen[c] = 1;
+          const int64_t p0 = crp[chunk_row[c]], p1 = crp[chunk_row[c + 1]];
+          PA_REQUIRE(full.win[(size_t)c * PA_C16_WINDOWS] >= 0 && p1 - (p0 & ~1) <= PA_SPMV_CHUNK_NNZ, "chunk %d has no 16-bit columns", c);
+          for (int64_t p = p0; p < p1; ++p)
+            PA_REQUIRE(col[p] >= g.wlo && col[p] <= hcur && col[p] > hcur - PA_XR_CAP, "column %d of chunk %d is not in the ring (loaded up to %d)", col[p], c, hcur);
+          check_grouped += p1 - p0;
+        }
+      }
+      PA_REQUIRE(g.wlen == hcur - g.wlo + 1, "ring group span");
+      check_staged += g.wlen;
+      in_groups += g.cnt;
+      continue;
+    }
     const int cap = (int64_t)gi < P.n_tier[0] ? PA_XW_CAP : (int64_t)gi < P.n_tier[0] + P.n_tier[1] ? PA_XW_CAP_MID : PA_XW_CAP_BIG;
     PA_REQUIRE(g.cnt >= PA_XW_MING && g.cnt <= PA_XW_MAXG, "group of %d chunks", g.cnt);
     PA_REQUIRE(g.first >= 0 && g.first + g.cnt <= nch, "group outside the block");
@@ -1546,6 +1590,17 @@ static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double al
     else PA_LAUNCH_XW(2, false, PA_XW_CAP_BIG, grp + n0 + n1, n2);
   }
 #undef PA_LAUNCH_XW
+  if (S->n_xw_ring > 0) {                              // runs of chunks served from the sliding x window
+    const int ng = (int)S->n_xw_ring, gpx = (ng + 7) / 8;
+    const pa_xw_group *rg = grp + n0 + n1 + n2;
+    if (u)
+      hipLaunchKernelGGL((k_spmv_xring<2, SPMV_NPT, SPMV_NT, true>), dim3(gpx * 8), dim3(512), 0, c->s[0], S->d_crp, S->d_col16, S->d_win,
+                         S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, S->d_chunk_cmax, rg, ng, gpx, (int)S->n_cols, alpha, kbeta, u, partial);
+    else
+      hipLaunchKernelGGL((k_spmv_xring<2, SPMV_NPT, SPMV_NT, false>), dim3(gpx * 8), dim3(512), 0, c->s[0], S->d_crp, S->d_col16, S->d_win,
+                         S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, S->d_chunk_cmax, rg, ng, gpx, (int)S->n_cols, alpha, kbeta,
+                         (const double *)nullptr, (double *)nullptr);
+  }
   if (S->n_xw_rest > 0) {                              // what fits no group: the general kernel over a chunk list
     const int cpx = (int)((S->n_xw_rest + 7) / 8);
     if (u)

@@ -209,6 +209,158 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
   }
 }
 
+// ---- the sliding x window ("ring") -------------------------------------------------------------------------------------------
+// Round 3 (VERDICT r02 #6a).  The windows above copy the span of a group of <= 16 chunks: a band of +-B costs 2B + rows of x
+// per group, and beyond +-7000 no group fits the LDS.  But consecutive chunks of a banded block need ALMOST THE SAME x: the
+// span moves by the chunk's rows (~100 entries) while it is 2B wide.  Here a workgroup owns a long run of consecutive chunks
+// and keeps x in a RING of PA_XR_CAP entries (128 KiB): entry e of x lives in slot e mod PA_XR_CAP, every round (SUB chunks)
+// appends the few new entries above the highest one loaded so far -- fetched at the top of the round, written behind the
+// round's first barrier, when nobody gathers any more -- and overwrites the oldest ones, which no later chunk reads (the host
+// checks: a chunk's smallest column is less than PA_XR_CAP below the highest column of its round and of all before it).  x
+// is then read from L2 once per run of chunks plus once per entry, whatever the band (up to +-8000), and a gather's slot is
+// the column itself masked -- no window base to subtract.  Same streams, same products, same order as k_spmv_rowsplit: same bits.
+#define PA_XR_CAP 16384
+#define PA_XR_MAXG 256      // chunks per ring group at most (fewer on a small block)
+#define PA_XR_WANT_GROUPS 768
+
+template <int SUB, int NPT, bool NT, bool DOT = false>
+__global__ __launch_bounds__(256 * SUB) void k_spmv_xring(
+    const int *__restrict__ crp, const unsigned short *__restrict__ col16, const int *__restrict__ win,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const int *__restrict__ chunk_row, const int *__restrict__ chunk_p, const int *__restrict__ chunk_cmax,
+    const pa_xw_group *__restrict__ grp, int n_groups, int groups_per_xcd, int n_cols, double alpha, double beta,
+    const double *__restrict__ u = nullptr, double *__restrict__ partial = nullptr) {
+  constexpr int BLK = 256, CAP = BLK * NPT, NTHR = BLK * SUB, C = PA_XR_CAP;
+  constexpr int PCAP = CAP + CAP / 16 + 2;
+  __shared__ __attribute__((aligned(16))) double xs[C];
+  __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
+  __shared__ double wsum[SUB * (BLK / 64)];
+  const int tid = threadIdx.x;
+  const int t = tid & (BLK - 1);
+  const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);
+  double *prod = prod_all + sub * PCAP;
+  const int b = blockIdx.x;
+  const int g = (b & 7) * groups_per_xcd + (b >> 3);
+  if (g >= n_groups || (b >> 3) >= groups_per_xcd) return;
+  const pa_xw_group G = grp[g];
+  const int ch_end = G.first + G.cnt;
+
+  d2 v[NPT / 2];
+  unsigned q[NPT / 2];
+  int mywin = 0, ra = 0, re = 0;
+  double ur = 0.0;
+  int r0 = 0, r1 = 0, p0 = 0, p1 = 0;
+  int nr0 = 0, nr1 = 0, np0 = 0, np1 = 0;
+  auto meta = [&](int ch, int &a0, int &a1, int &b0, int &b1) {
+    a0 = chunk_row[ch]; a1 = chunk_row[ch + 1]; b0 = chunk_p[ch]; b1 = chunk_p[ch + 1];
+  };
+  auto issue = [&](int ch) {
+    const int base = p0 & ~1, last = max((p1 - 1) & ~1, 0);
+#pragma unroll
+    for (int k = 0; k < NPT / 2; ++k) {
+      const int idx = min(base + (k * BLK + t) * 2, last);
+      v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+      q[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned *>(col16 + idx));
+    }
+    mywin = win[ch * PA_C16_WINDOWS + (t & (PA_C16_WINDOWS - 1))];
+    if (r0 + t < r1) {
+      ra = crp[r0 + t];
+      re = crp[r0 + t + 1];
+      if (DOT) ur = u[r0 + t];
+    }
+  };
+  // highest column of the chunks of the round that starts at chunk c0 (block-uniform)
+  auto round_hi = [&](int c0) {
+    int h = -1;
+#pragma unroll
+    for (int s = 0; s < SUB; ++s) if (c0 + s < ch_end) h = max(h, chunk_cmax[c0 + s]);
+    return h;
+  };
+  int ch = G.first + sub;
+  if (ch < ch_end) {
+    meta(ch, r0, r1, p0, p1);
+    issue(ch);
+    if (ch + SUB < ch_end) meta(ch + SUB, nr0, nr1, np0, np1);
+  }
+  // first fill: [wlo, highest column of the first round]
+  int hcur = min(round_hi(G.first), n_cols - 1);
+  for (int e = G.wlo + tid; e <= hcur; e += NTHR) xs[e & (C - 1)] = x[e];
+  __syncthreads();
+  for (int c0 = G.first; c0 < ch_end; c0 += SUB, ch += SUB) {                 // every sub-group runs the same rounds
+    const bool act = ch < ch_end;                                              // wave-uniform
+    const int cr0 = r0, cr1 = r1, cbase = p0 & ~1, cra = ra, cre = re;
+    const double cur = ur;
+    // the ring's new entries for the NEXT round: fetched now, they fly while this round's products are formed
+    const int hnext = c0 + SUB < ch_end ? min(max(round_hi(c0 + SUB), hcur), n_cols - 1) : hcur;
+    const int e_new = hcur + 1 + tid;
+    double xnew = 0.0;
+    if (e_new <= hnext) xnew = x[e_new];
+    if (act) {
+#pragma unroll
+      for (int k = 0; k < NPT / 2; ++k) {
+        const unsigned lo = q[k] & 0xffffu, hi = q[k] >> 16;
+        // (lanes outside the chunk decode a neighbour's code with this chunk's windows: any column, masked into the ring;
+        // their products are never summed)
+        const int c0_ = (__builtin_amdgcn_ds_bpermute((lo >> 12) << 2, mywin) + (int)(lo & 4095)) & (C - 1);
+        const int c1_ = (__builtin_amdgcn_ds_bpermute((hi >> 12) << 2, mywin) + (int)(hi & 4095)) & (C - 1);
+        double a = v[k].x * xs[c0_];
+        double c = v[k].y * xs[c1_];
+        if (alpha != 1.0) {
+          a = a * alpha;
+          c = c * alpha;
+        }
+        d2 pr;
+        pr.x = a;
+        pr.y = c;
+        *reinterpret_cast<d2 *>(&prod[PA_XW_PSLOT((k * BLK + t) * 2)]) = pr;
+      }
+      if (ch + SUB < ch_end) {
+        r0 = nr0; r1 = nr1; p0 = np0; p1 = np1;
+        issue(ch + SUB);
+        if (ch + 2 * SUB < ch_end) meta(ch + 2 * SUB, nr0, nr1, np0, np1);
+      }
+    }
+    __syncthreads();                                                           // nobody gathers any more: the ring may move
+    if (e_new <= hnext) xs[e_new & (C - 1)] = xnew;
+    for (int e = e_new + NTHR; e <= hnext; e += NTHR) xs[e & (C - 1)] = x[e];    // (a jump of more than 512 columns: rare)
+    hcur = hnext;
+    if (act) {
+      int a = cra - cbase, e = cre - cbase;
+      double dacc = 0.0;
+      for (int r = cr0 + t; r < cr1; r += BLK) {
+        if (r != cr0 + t) {
+          a = crp[r] - cbase;
+          e = crp[r + 1] - cbase;
+        }
+        double acc = beta == 0.0 ? 0.0 : beta * y[r];
+#pragma unroll PA_XW_UNROLL
+        for (int p = a; p < e; ++p) acc = acc + prod[PA_XW_PSLOT(p)];
+        if (DOT) {
+          double pr = acc;
+          if (beta != 0.0) {
+            pr = 0.0;
+            for (int p = a; p < e; ++p) pr = pr + prod[PA_XW_PSLOT(p)];
+          }
+          dacc = dacc + (r == cr0 + t ? cur : u[r]) * pr;
+        }
+        __builtin_nontemporal_store(acc, &y[r]);
+      }
+      if (DOT) {
+        dacc = pa_wave_sum(dacc);
+        if (cr1 - cr0 <= 64) {
+          if (t == 0) partial[ch] = dacc;
+        } else if ((t & 63) == 0) wsum[sub * (BLK / 64) + (t >> 6)] = dacc;
+      }
+    }
+    __syncthreads();
+    if (DOT && act && cr1 - cr0 > 64 && t == 0) {
+      double sum = 0.0;
+      for (int w = 0; w < BLK / 64; ++w) sum = sum + wsum[sub * (BLK / 64) + w];
+      partial[ch] = sum;
+    }
+  }
+}
+
 // Host side, per chunk (multi-threaded over chunks): first and last column, and how many distinct 128-byte lines of x (16
 // entries) its gathers touch -- only for chunks on the 16-bit stream whose span fits the largest window.
 struct pa_xw_chunk_stats { std::vector<int32_t> cmin, cmax, lines; };
@@ -291,22 +443,76 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const std::vector<int32_t>
   return staged;
 }
 
+// Ring groups (k_spmv_xring): maximal runs of consecutive 16-bit chunks, not yet taken, in which every chunk's smallest
+// column is less than PA_XR_CAP (minus a margin) below the highest column of its round and of all rounds before it -- a
+// round being `sub` consecutive chunks counted from the run's first; conservatively, of the sub - 1 chunks after it too.
+inline int64_t pa_build_xring_groups(const int32_t *crp, const std::vector<int32_t> &chunk_row, const pa_xw_chunk_stats &S, int sub,
+                                     std::vector<char> &taken, std::vector<pa_xw_group> &groups, int64_t *grouped_entries,
+                                     bool forced = false) {
+  const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
+  const int C = PA_XR_CAP - 64;
+  const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XR_MAXG, n_chunks / PA_XR_WANT_GROUPS));
+  int64_t staged = 0;
+  *grouped_entries = 0;
+  int64_t c = 0;
+  while (c < n_chunks) {
+    if (taken[c] || S.cmax[c] < 0) { ++c; continue; }
+    int64_t e = c;
+    int32_t runmax = -1, wlo = INT32_MAX;
+    int64_t touched = 0;
+    while (e < n_chunks && e - c < maxg && !taken[e] && S.cmax[e] >= 0) {
+      const int32_t rm = std::max(runmax, S.cmax[e]);
+      bool ok = true;
+      for (int64_t j = std::max(c, e - (sub - 1)); j <= e && ok; ++j) ok = (int64_t)rm - S.cmin[j] < C;
+      if (!ok) break;
+      runmax = rm;
+      wlo = std::min(wlo, S.cmin[e]);
+      touched += S.lines[e];
+      ++e;
+    }
+    // worth it when the chunks' gathers are scattered (as for the windows) and the run is long enough to pay its first fill
+    if (e - c >= PA_XW_MING && (forced || touched >= (int64_t)PA_XW_MIN_LINES * (e - c))) {
+      groups.push_back(pa_xw_group{(int)c, (int)(e - c), wlo, runmax - wlo + 1});
+      for (int64_t k = c; k < e; ++k) taken[k] = 1;
+      staged += runmax - wlo + 1;
+      *grouped_entries += (int64_t)crp[chunk_row[e]] - crp[chunk_row[c]];
+      c = e;
+    } else {
+      c = std::max(e, c + 1);
+    }
+  }
+  return staged;
+}
+
 // The tiers of one block: 40 KiB groups first, then 96 KiB and 128 KiB groups over what the smaller windows left (every
 // group passes the staged-x test of pa_build_xw_groups unless `forced`).
 // groups = [tier 0..., tier 1..., tier 2...].
 struct pa_xw_plan {
-  std::vector<pa_xw_group> groups;
+  std::vector<pa_xw_group> groups;      // [40 KiB windows..., 96 KiB..., 128 KiB..., ring groups...]
   std::vector<int32_t> rest;
-  int64_t n_tier[PA_XW_TIERS] = {0, 0, 0}, staged = 0, grouped = 0;
+  int64_t n_tier[PA_XW_TIERS] = {0, 0, 0}, n_ring = 0, staged = 0, grouped = 0;
 };
 // (the per-chunk statistics S come from pa_xw_scan_chunks on the host or from the device kernel of pa_setup.hip: the same numbers)
+// ring: 0 = windows only (the three tiers), 1 = 40 KiB windows first, then ring groups over what is left (then nothing: the
+// ring reaches further than the 96 / 128 KiB windows and stages less), 2 = ring groups only
 inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t> &chunk_row, const pa_xw_chunk_stats &S, bool forced,
-                                  pa_xw_plan &P) {
+                                  pa_xw_plan &P, int ring = 1) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   P = pa_xw_plan();
   std::vector<char> taken(n_chunks, 0);
   const int caps[PA_XW_TIERS] = {PA_XW_CAP, PA_XW_CAP_MID, PA_XW_CAP_BIG};
+  std::vector<pa_xw_group> ring_groups;
   for (int tier = 0; tier < PA_XW_TIERS; ++tier) {
+    if (ring == 2 || (ring == 1 && tier >= 1)) {
+      if (tier == (ring == 2 ? 0 : 1)) {
+        int64_t grouped = 0;
+        const int64_t staged = pa_build_xring_groups(crp, chunk_row, S, 2, taken, ring_groups, &grouped, forced);
+        P.n_ring = (int64_t)ring_groups.size();
+        P.staged += staged;
+        P.grouped += grouped;
+      }
+      continue;
+    }
     std::vector<char> t2 = taken;
     std::vector<pa_xw_group> g;
     int64_t grouped = 0;
@@ -322,12 +528,14 @@ inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t>
     P.staged += staged;
     P.grouped += grouped;
   }
+  P.groups.insert(P.groups.end(), ring_groups.begin(), ring_groups.end());
   for (int64_t c = 0; c < n_chunks; ++c)
     if (!taken[c]) P.rest.push_back((int32_t)c);
 }
 inline void pa_plan_xw(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row, const int32_t *win,
-                       bool forced, pa_xw_plan &P, int n_threads = 1) {
+                       bool forced, pa_xw_plan &P, int n_threads = 1, int ring = 1, std::vector<int32_t> *cmax_out = nullptr) {
   pa_xw_chunk_stats S;
-  pa_xw_scan_chunks(crp, col, chunk_row, win, PA_XW_CAP_BIG, n_threads, S);
-  pa_plan_xw_from_stats(crp, chunk_row, S, forced, P);
+  pa_xw_scan_chunks(crp, col, chunk_row, win, PA_XR_CAP, n_threads, S);       // (spans up to the ring's capacity are counted)
+  pa_plan_xw_from_stats(crp, chunk_row, S, forced, P, ring);
+  if (cmax_out) *cmax_out = S.cmax;
 }

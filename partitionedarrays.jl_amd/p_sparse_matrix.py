@@ -125,7 +125,9 @@ class DeviceCSR:
         """x-window launch of banded rows without a pattern (pa_csr_xwin_info): groups, chunks in groups, staged x entries."""
         v = [C.c_int64() for _ in range(4)]
         L.call("pa_csr_xwin_info", self.h, *[C.byref(x) for x in v])
-        return dict(zip(["groups", "chunks", "staged_x", "big_groups"], [x.value for x in v]))
+        r = C.c_int64()
+        L.call("pa_csr_xring_info", self.h, C.byref(r))
+        return dict(zip(["groups", "chunks", "staged_x", "big_groups", "ring_groups"], [x.value for x in v] + [r.value]))
 
     def device_bytes(self):
         """HBM bytes the block occupies (pa_csr_device_bytes)."""

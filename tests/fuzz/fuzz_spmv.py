@@ -55,6 +55,7 @@ for case in range(n_cases):
         if sw is None:
             cover["default_windows"] += xw["groups"] > 0
             cover["default_big_windows"] += xw["big_groups"] > 0
+            cover["default_ring"] = cover.get("default_ring", 0) + (xw.get("ring_groups", 0) > 0)
             cover["c32_chunks"] += enc["c32"] > 0
             cover["padded_slots_rows_of_8k"] += bool(law == 0 and lens[0] % 8 == 0)
         if sw == "2":

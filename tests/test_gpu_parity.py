@@ -920,11 +920,14 @@ def test_fused_product_and_dot_matches_the_separate_calls(orc):
     assert abs(pa.read_slots(7)[0] - want) <= 1e-12 * max(1.0, abs(want))
 
 
-@pytest.mark.parametrize("m,band,tier", [(150_000, 1200, "40 KiB"), (150_000, 3000, "96 KiB"), (800_000, 6500, "128 KiB")])
+@pytest.mark.parametrize("m,band,tier", [(150_000, 1200, "40 KiB"), (150_000, 3000, "96 KiB"), (800_000, 6500, "128 KiB"),
+                                         (150_000, 3000, "ring"), (800_000, 7800, "ring")])
 def test_fused_product_and_dot_on_banded_rows_is_the_same_on_both_launches(monkeypatch, m, band, tier):
-    """Banded rows without a pattern: pa_mul_dot through k_spmv_xwin (+ the chunk list) and through k_spmv_rowsplit alone
-    give the same c AND the same dot, bit for bit (the per-chunk partial sums are formed in one order on both), with
-    chunks of more than 64 rows (short rows) and of fewer -- on each of the three window sizes."""
+    """Banded rows without a pattern: pa_mul_dot through k_spmv_xwin / k_spmv_xring (+ the chunk list) and through
+    k_spmv_rowsplit alone give the same c AND the same dot, bit for bit (the per-chunk partial sums are formed in one order
+    on all of them), with chunks of more than 64 rows (short rows) and of fewer -- on each of the three window sizes and on
+    the sliding window."""
+    monkeypatch.setenv("PA_SPMV_XRING", "1" if tier == "ring" else "0")
     import pa_amd.p_sparse_matrix as psm
     rng = np.random.default_rng(23)
     lens = np.where(np.arange(m) < m // 3, rng.integers(1, 6, m), rng.integers(10, 40, m))
@@ -942,8 +945,10 @@ def test_fused_product_and_dot_on_banded_rows_is_the_same_on_both_launches(monke
         blk = pa.DeviceCSR(H)
         xw = blk.xwin()
         assert (xw["groups"] > 0) == (switch == "1"), xw
-        if switch == "1":
-            assert (xw["big_groups"] > 0.5 * xw["groups"]) == (tier != "40 KiB"), (tier, xw)
+        if switch == "1" and tier == "ring":
+            assert xw["ring_groups"] > 0.5 * xw["groups"], (tier, xw)
+        elif switch == "1":
+            assert (xw["big_groups"] > 0.5 * xw["groups"]) == (tier != "40 KiB") and xw["ring_groups"] == 0, (tier, xw)
         empty = pa.DeviceCSR(pa.HostCSR(m, 0, np.ones(m + 1, np.int32), np.zeros(0, np.int32), np.zeros(0)))
         Ah = pa.PSparseMatrix(pa.DebugArray([psm.SplitMatrixBlocks(blk, empty)]), ind, ind, True)
         u = pa.pvector_from_function(lambda i: uh, ind)
@@ -2058,3 +2063,62 @@ def test_device_side_psparse_equals_the_host_route(orc, monkeypatch):
         for p, (u, v) in enumerate(zip(yh, yd)):
             assert np.array_equal(u, v), (name, p)
     monkeypatch.delenv("PA_SETUP_DEVICE")
+
+
+@pytest.mark.parametrize("ring", ["1", "2"])
+def test_sliding_x_window_launch_is_bit_identical(orc, monkeypatch, ring):
+    """k_spmv_xring (csrc/pa_spmv_xwin.h): runs of consecutive chunks gather x from a ring of 16384 entries that every round
+    tops up with the columns above the highest one loaded so far.  Bands of +-2500 / +-6000 / +-7900, ragged and empty rows,
+    a stretch where the band JUMPS by 3000 columns (more new entries than one lane each can fetch), rows that reach anywhere
+    and a stretch too wide for the ring (both leave the runs for the chunk list), signed zeros; spmv!, the alpha/beta form,
+    x in an 8-byte-aligned ghost segment and new values on the same pattern -- bit for bit against the oracle's loops, with
+    the ring behind the 40 KiB windows (1) and alone (2)."""
+    import pa_amd._lib as L
+    monkeypatch.setenv("PA_SPMV_XRING", ring)
+    rng = np.random.default_rng(31)
+    m = 400_003
+    lens = rng.integers(0, 36, m)
+    lens[rng.choice(m, 800, replace=False)] = 0
+    rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
+    rows = np.repeat(np.arange(m), lens)
+    band = np.where(rows < 120_000, 2500, np.where(rows < 260_000, 6000, 7900))
+    centre = rows + np.where(rows >= 200_000, 3000, 0)                     # the band jumps at row 200000
+    col = np.clip(centre + (rng.random(len(rows)) * 2 - 1) * band, 0, m - 1).astype(np.int64)
+    far = rng.choice(len(rows), size=80, replace=False)
+    col[far] = rng.integers(0, m, size=80)
+    wide = (rows >= 300_000) & (rows < 304_000)                            # spans of 24000 columns: no ring holds them
+    col[wide] = np.clip(rows[wide] + rng.integers(-12000, 12000, size=int(wide.sum())), 0, m - 1)
+    order = np.lexsort((col, rows))
+    val = rng.standard_normal(len(rows))
+    val[rng.choice(len(rows), 3000, replace=False)] = -0.0
+    H = pa.HostCSR(m, m, rp, (col[order] + 1).astype(np.int32), val)
+    Ho = orc.CSR(m, m, H.rowptr, H.colval, H.nzval)
+    xh = rng.standard_normal(m)
+    want = np.zeros(m)
+    orc.oracle_c().spmv_csr(want, xh, Ho)
+    want5 = np.full(m, 0.25)
+    orc.oracle_c().mul5_csr(want5, Ho, xh, -2.0, 3.0)
+    A = pa.DeviceCSR(H)
+    xw = A.xwin()
+    assert xw["ring_groups"] > 0 and 0 < xw["chunks"] < A.info()["n_chunks"] and xw["big_groups"] == 0, xw
+    if ring == "2":
+        assert xw["ring_groups"] == xw["groups"], xw
+    x = pa.DeviceVector(m, 0).upload(xh)
+    y = pa.DeviceVector(m, 0)
+    pa.spmv_(y, A, x)
+    assert np.array_equal(y.download(), want)
+    y.upload(np.full(m, 0.25))
+    pa.spmv_(y, A, x, alpha=-2.0, beta=3.0)
+    assert np.array_equal(y.download(), want5)
+    xg = pa.DeviceVector(3, m).upload(np.concatenate([np.zeros(3), xh]))
+    y2 = pa.DeviceVector(m, 0)
+    pa.spmv_(y2, A, xg, x_segment=L.SEG_GHOST)
+    assert np.array_equal(y2.download(), want)
+    A.update_values(np.ascontiguousarray(-0.5 * H.nzval))
+    pa.spmv_(y, A, x)
+    assert np.array_equal(y.download(), -0.5 * want)
+    monkeypatch.setenv("PA_SPMV_XWIN", "0")                               # the row split alone on the same block: same bits
+    B = pa.DeviceCSR(H)
+    assert B.xwin()["groups"] == 0
+    pa.spmv_(y2, B, x)
+    assert np.array_equal(y2.download(), want)

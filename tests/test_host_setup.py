@@ -234,12 +234,13 @@ def _check_xw(A):
     return dict(zip(["groups", "chunks", "staged_x", "entries", "big_groups"], [x.value for x in v]))
 
 
-def test_x_window_groups_cover_every_chunk_once():
+def test_x_window_groups_cover_every_chunk_once(monkeypatch):
     """Host logic of the x-window launch (csrc/pa_spmv_xwin.h): on banded rows without a pattern the groups hold most
     chunks, each chunk sits in exactly one group or in the list left to the general kernel, every column of a group lies
     inside its window and the window fits the LDS stage -- checked entry by entry by the library's own self-check; rows that
     reach anywhere or a band wider than the window leave their chunks to the general kernel."""
     rng = np.random.default_rng(2)
+    monkeypatch.setenv("PA_SPMV_XRING", "0")             # the three window tiers alone (the ring groups: the next test)
 
     def banded(m, band, lens, far=0):
         rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
@@ -269,6 +270,40 @@ def test_x_window_groups_cover_every_chunk_once():
     assert e3["groups"] == 0 and e3["chunks"] == 0
     e4 = _check_xw(banded(3000, 100, np.full(3000, 4)))                       # fewer chunks than one group's minimum
     assert e4["groups"] in (0, 1, 2)
+
+
+def test_ring_groups_keep_every_gathered_column_resident(monkeypatch):
+    """Host logic of the sliding x window (k_spmv_xring): runs of consecutive chunks whose gathers stay within one ring
+    capacity (16384 entries) below the highest column loaded so far.  pa_host_check_xw_groups replays the kernel's rounds
+    and checks every stored column: loaded already, not overwritten yet.  Bands up to +-8000 are covered (the 128 KiB
+    windows ended at +-7000), the staged x is a few per cent of the matrix bytes, +-9000 fits nothing."""
+    rng = np.random.default_rng(4)
+
+    def banded(m, band, lens, far=0):
+        rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int32)
+        rows = np.repeat(np.arange(m), lens)
+        col = np.clip(rows + rng.integers(-band, band + 1, size=len(rows)), 0, m - 1)
+        if far:
+            col[rng.choice(len(rows), far, replace=False)] = rng.integers(0, m, far)
+        order = np.lexsort((col, rows))
+        return pa.HostCSR(m, m, rp, (col[order] + 1).astype(np.int32), np.ones(len(rows)))
+    m = 600_000
+    n_chunks = m * 16 // 1536
+    for band in (3000, 5000, 7900):
+        monkeypatch.setenv("PA_SPMV_XRING", "1")
+        e = _check_xw(banded(m, band, np.full(m, 16)))
+        assert e["chunks"] >= 0.97 * n_chunks and e["big_groups"] == 0, (band, e)
+        # the first fill of every run only: a fraction of the matrix bytes even on this small block (runs of 8 chunks; a
+        # 4 M-row block gets runs of 54 and a ratio of 0.1), where a 128 KiB window of 4 chunks staged 2 x the matrix bytes
+        assert e["staged_x"] * 8 <= (0.5 if band <= 3000 else 1.2) * e["entries"] * 10 and e["chunks"] >= 6 * e["groups"], (band, e)
+        monkeypatch.setenv("PA_SPMV_XRING", "2")                              # ring groups only (no 40 KiB windows first)
+        e2 = _check_xw(banded(m, band, np.full(m, 16)))
+        assert e2["chunks"] >= 0.97 * n_chunks, (band, e2)
+    monkeypatch.setenv("PA_SPMV_XRING", "1")
+    e9 = _check_xw(banded(m, 9000, np.full(m, 16)))
+    assert e9["chunks"] <= 0.04 * n_chunks, e9                                # (nothing but the clipped ends of the band)
+    er = _check_xw(banded(m, 4000, rng.integers(0, 40, m), far=200))          # ragged rows, empty rows, rows that reach anywhere
+    assert er["groups"] > 0 and er["chunks"] > 0
 
 
 def test_spmv_row_split_and_column_encodings_decode_exactly(orc):
