@@ -904,7 +904,7 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
     const char *ex = getenv("PA_SPMV_XWIN");
     if (cs.use_c16 && !cs.use_pattern && !compact && !(ex && atoi(ex) == 0) && A->n_chunks >= 64) {
       const bool forced = ex && atoi(ex) == 2;
-      const char *er = getenv("PA_SPMV_XRING");              // 0: windows only, 1 (default): 40 KiB windows, then the ring, 2: ring only
+      const char *er = getenv("PA_SPMV_XRING");              // 0: windows only, 1 (default): the window tiers, then the ring, 2: ring only
       const int ring = er ? atoi(er) : 1;
       std::vector<int32_t> cmax_host;
       pa_xw_plan P;

@@ -284,14 +284,16 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xring(
   }
   // first fill: [wlo, highest column of the first round]
   int hcur = min(round_hi(G.first), n_cols - 1);
-  for (int e = G.wlo + tid; e <= hcur; e += NTHR) xs[e & (C - 1)] = x[e];
-  __syncthreads();
+  int hi1 = G.first + SUB < ch_end ? round_hi(G.first + SUB) : -1;           // highest column of the round after this one,
+  for (int e = G.wlo + tid; e <= hcur; e += NTHR) xs[e & (C - 1)] = x[e];      // fetched a round ahead (its load must not
+  __syncthreads();                                                             // sit in front of the ring's own)
   for (int c0 = G.first; c0 < ch_end; c0 += SUB, ch += SUB) {                 // every sub-group runs the same rounds
     const bool act = ch < ch_end;                                              // wave-uniform
     const int cr0 = r0, cr1 = r1, cbase = p0 & ~1, cra = ra, cre = re;
     const double cur = ur;
     // the ring's new entries for the NEXT round: fetched now, they fly while this round's products are formed
-    const int hnext = c0 + SUB < ch_end ? min(max(round_hi(c0 + SUB), hcur), n_cols - 1) : hcur;
+    const int hnext = c0 + SUB < ch_end ? min(max(hi1, hcur), n_cols - 1) : hcur;
+    hi1 = c0 + 2 * SUB < ch_end ? round_hi(c0 + 2 * SUB) : -1;
     const int e_new = hcur + 1 + tid;
     double xnew = 0.0;
     if (e_new <= hnext) xnew = x[e_new];
@@ -493,8 +495,10 @@ struct pa_xw_plan {
   int64_t n_tier[PA_XW_TIERS] = {0, 0, 0}, n_ring = 0, staged = 0, grouped = 0;
 };
 // (the per-chunk statistics S come from pa_xw_scan_chunks on the host or from the device kernel of pa_setup.hip: the same numbers)
-// ring: 0 = windows only (the three tiers), 1 = 40 KiB windows first, then ring groups over what is left (then nothing: the
-// ring reaches further than the 96 / 128 KiB windows and stages less), 2 = ring groups only
+// ring: 0 = windows only (the three tiers), 1 = the three tiers first, then ring groups over what they left (measured, 4 M rows
+// x 16: the ring runs at 4.1-4.2 TB/s algorithmic whatever the band -- one workgroup of 8 waves per CU, two barriers per
+// round -- against 5.1-5.9 on the 96 / 128 KiB windows and 7.4 on the 40 KiB ones where those fit, and against 3.05 on the
+// row split at +-7900, where nothing else fits), 2 = ring groups only
 inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t> &chunk_row, const pa_xw_chunk_stats &S, bool forced,
                                   pa_xw_plan &P, int ring = 1) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
@@ -503,16 +507,7 @@ inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t>
   const int caps[PA_XW_TIERS] = {PA_XW_CAP, PA_XW_CAP_MID, PA_XW_CAP_BIG};
   std::vector<pa_xw_group> ring_groups;
   for (int tier = 0; tier < PA_XW_TIERS; ++tier) {
-    if (ring == 2 || (ring == 1 && tier >= 1)) {
-      if (tier == (ring == 2 ? 0 : 1)) {
-        int64_t grouped = 0;
-        const int64_t staged = pa_build_xring_groups(crp, chunk_row, S, 2, taken, ring_groups, &grouped, forced);
-        P.n_ring = (int64_t)ring_groups.size();
-        P.staged += staged;
-        P.grouped += grouped;
-      }
-      continue;
-    }
+    if (ring == 2) break;
     std::vector<char> t2 = taken;
     std::vector<pa_xw_group> g;
     int64_t grouped = 0;
@@ -525,6 +520,13 @@ inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t>
     taken.swap(t2);
     P.groups.insert(P.groups.end(), g.begin(), g.end());
     P.n_tier[tier] = (int64_t)g.size();
+    P.staged += staged;
+    P.grouped += grouped;
+  }
+  if (ring >= 1) {
+    int64_t grouped = 0;
+    const int64_t staged = pa_build_xring_groups(crp, chunk_row, S, 2, taken, ring_groups, &grouped, forced);
+    P.n_ring = (int64_t)ring_groups.size();
     P.staged += staged;
     P.grouped += grouped;
   }
