@@ -221,7 +221,8 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
 // the column itself masked -- no window base to subtract.  Same streams, same products, same order as k_spmv_rowsplit: same bits.
 #define PA_XR_CAP 16384
 #define PA_XR_MAXG 256      // chunks per ring group at most (fewer on a small block)
-#define PA_XR_WANT_GROUPS 768
+#define PA_XR_WANT_GROUPS 1024   // one workgroup per CU is resident (157 KB of LDS): the runs are cut so that there are at most
+                                 // 4 x 256 of them -- 772 runs (3 per CU and 4 left over) ran a quarter longer than 768 would
 
 template <int SUB, int NPT, bool NT, bool DOT = false>
 __global__ __launch_bounds__(256 * SUB) void k_spmv_xring(
@@ -453,7 +454,7 @@ inline int64_t pa_build_xring_groups(const int32_t *crp, const std::vector<int32
                                      bool forced = false) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   const int C = PA_XR_CAP - 64;
-  const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XR_MAXG, n_chunks / PA_XR_WANT_GROUPS));
+  const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XR_MAXG, (n_chunks + PA_XR_WANT_GROUPS - 1) / PA_XR_WANT_GROUPS));
   int64_t staged = 0;
   *grouped_entries = 0;
   int64_t c = 0;
