@@ -399,6 +399,24 @@ def extra_configs(pa, ctx, L, out):
     e["x_window_launch"] = bb.xwin()
     out.append(e)
     del bb
+    # the same beyond every LDS window (VERDICT r02 #6a): columns within +-7900 -- a span of 15 900 entries of x per chunk; runs
+    # of chunks gather from the sliding 128 KiB ring (k_spmv_xring), nothing else but the plain row split holds such a band
+    PHASE[0] = "extra: wide band"
+    t = time.perf_counter()
+    col = np.repeat(np.arange(m, dtype=np.int32), 16).reshape(m, 16)
+    col += rng.integers(-7900, 7900, size=(m, 16), dtype=np.int32)
+    np.clip(col, 0, m - 1, out=col)
+    col.sort(axis=1)
+    col += 1
+    Hw = pa.HostCSR(m, m, (1 + 16 * np.arange(m + 1)).astype(np.int32), col.ravel(), rng.standard_normal(m * 16))
+    bw = pa.DeviceCSR(Hw)
+    del Hw, col
+    ts = time.perf_counter() - t
+    e = entry("unstructured rows in a WIDE band: 4 M rows x 16 entries, random columns within +-7900 of the diagonal (beyond every LDS "
+              "window), pa_spmv", bw, m, m, time_block(pa, ctx, L, bw, m, m), ts)
+    e["x_window_launch"] = bw.xwin()
+    out.append(e)
+    del bw
     # a non-pattern FEM matrix (VERDICT r02 #6b): the Q1 mesh numbered at random, then renumbered by reverse Cuthill-McKee --
     # what an unstructured-mesh code hands over.  No row pattern survives; the columns fall into a band in a few clusters.
     PHASE[0] = "extra: FEM mesh after RCM"

@@ -473,8 +473,10 @@ inline int64_t pa_build_xring_groups(const int32_t *crp, const std::vector<int32
       touched += S.lines[e];
       ++e;
     }
-    // worth it when the chunks' gathers are scattered (as for the windows) and the run is long enough to pay its first fill
-    if (e - c >= PA_XW_MING && (forced || touched >= (int64_t)PA_XW_MIN_LINES * (e - c))) {
+    // worth it when the chunks' gathers are scattered (as for the windows) and the run is long enough to pay its first fill:
+    // the x it loads in all (8 B per column of its span) at most the matrix bytes it streams (10 B per stored entry)
+    const int64_t ent = e > c ? (int64_t)crp[chunk_row[e]] - crp[chunk_row[c]] : 0;
+    if (e - c >= PA_XW_MING && (forced || (touched >= (int64_t)PA_XW_MIN_LINES * (e - c) && (int64_t)(runmax - wlo + 1) * 8 <= ent * 10))) {
       groups.push_back(pa_xw_group{(int)c, (int)(e - c), wlo, runmax - wlo + 1});
       for (int64_t k = c; k < e; ++k) taken[k] = 1;
       staged += runmax - wlo + 1;
@@ -518,6 +520,9 @@ inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t>
     const int ratio16 = forced ? 1 << 20 : tier == 0 ? 10 : 16;
     const int64_t staged = pa_build_xw_groups(crp, chunk_row, S, caps[tier], ratio16, t2, g, &grouped);
     if (g.empty()) continue;
+    // (a tier that would launch a handful of workgroups -- the clipped ends of a band the ring takes -- is not worth its
+    // launch: 12 groups of the 128 KiB tier next to 1012 ring groups cost 0.212 ms instead of 0.189)
+    if (ring >= 1 && !forced && tier >= 1 && (int64_t)g.size() < 64) continue;
     taken.swap(t2);
     P.groups.insert(P.groups.end(), g.begin(), g.end());
     P.n_tier[tier] = (int64_t)g.size();

@@ -287,19 +287,19 @@ def test_ring_groups_keep_every_gathered_column_resident(monkeypatch):
             col[rng.choice(len(rows), far, replace=False)] = rng.integers(0, m, far)
         order = np.lexsort((col, rows))
         return pa.HostCSR(m, m, rp, (col[order] + 1).astype(np.int32), np.ones(len(rows)))
-    m = 600_000
+    m = 1_200_000
     n_chunks = m * 16 // 1536
     for band in (3000, 5000, 7900):
         monkeypatch.setenv("PA_SPMV_XRING", "1")                              # the window tiers first, the ring over what they left
         e = _check_xw(banded(m, band, np.full(m, 16)))
         assert e["chunks"] >= 0.97 * n_chunks, (band, e)
-        assert e["big_groups"] > (0.5 if band < 7900 else 0.0) * e["groups"] and (band < 7900 or e["big_groups"] <= 16), (band, e)   # +-7900 fits no window (but at the clipped ends): ring groups take it
+        assert (e["big_groups"] > 0.5 * e["groups"]) if band < 7900 else e["big_groups"] == 0, (band, e)   # +-7900 fits no window (the handful at the clipped ends is not launched): ring groups take it
         monkeypatch.setenv("PA_SPMV_XRING", "2")                              # ring groups only
         e2 = _check_xw(banded(m, band, np.full(m, 16)))
         assert e2["chunks"] >= 0.97 * n_chunks and e2["big_groups"] == 0, (band, e2)
         # the first fill of every run only: a fraction of the matrix bytes even on this small block (runs of 8 chunks; a
         # 4 M-row block gets runs of 54 and a ratio of 0.1), where a 128 KiB window of 4 chunks staged 2 x the matrix bytes
-        assert e2["staged_x"] * 8 <= (0.5 if band <= 3000 else 1.2) * e2["entries"] * 10 and e2["chunks"] >= 6 * e2["groups"], (band, e2)
+        assert e2["staged_x"] * 8 <= (0.5 if band <= 3000 else 1.0) * e2["entries"] * 10 and e2["chunks"] >= 6 * e2["groups"], (band, e2)
     monkeypatch.setenv("PA_SPMV_XRING", "1")
     e9 = _check_xw(banded(m, 9000, np.full(m, 16)))
     assert e9["chunks"] <= 0.04 * n_chunks, e9                                # (nothing but the clipped ends of the band)
