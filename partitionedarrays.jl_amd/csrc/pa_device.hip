@@ -1593,13 +1593,18 @@ static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double al
   if (S->n_xw_ring > 0) {                              // runs of chunks served from the sliding x window
     const int ng = (int)S->n_xw_ring, gpx = (ng + 7) / 8;
     const pa_xw_group *rg = grp + n0 + n1 + n2;
-    if (u)
-      hipLaunchKernelGGL((k_spmv_xring<2, SPMV_NPT, SPMV_NT, true>), dim3(gpx * 8), dim3(512), 0, c->s[0], S->d_crp, S->d_col16, S->d_win,
-                         S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, S->d_chunk_cmax, rg, ng, gpx, (int)S->n_cols, alpha, kbeta, u, partial);
-    else
-      hipLaunchKernelGGL((k_spmv_xring<2, SPMV_NPT, SPMV_NT, false>), dim3(gpx * 8), dim3(512), 0, c->s[0], S->d_crp, S->d_col16, S->d_win,
-                         S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, S->d_chunk_cmax, rg, ng, gpx, (int)S->n_cols, alpha, kbeta,
-                         (const double *)nullptr, (double *)nullptr);
+    static const int wide = getenv("PA_SPMV_XRING_LANES") ? atoi(getenv("PA_SPMV_XRING_LANES")) : 512;   // lanes per chunk: 256 or 512
+#define PA_LAUNCH_XR(DOT, BLKX, NPTX, UU, PP)                                                                                          \
+  hipLaunchKernelGGL((k_spmv_xring<2, NPTX, SPMV_NT, DOT, BLKX>), dim3(gpx * 8), dim3(2 * BLKX), 0, c->s[0], S->d_crp, S->d_col16, S->d_win, \
+                     S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, S->d_chunk_cmax, rg, ng, gpx, (int)S->n_cols, alpha, kbeta, UU, PP)
+    if (wide == 512) {
+      if (u) PA_LAUNCH_XR(true, 512, 4, u, partial);
+      else PA_LAUNCH_XR(false, 512, 4, (const double *)nullptr, (double *)nullptr);
+    } else {
+      if (u) PA_LAUNCH_XR(true, 256, SPMV_NPT, u, partial);
+      else PA_LAUNCH_XR(false, 256, SPMV_NPT, (const double *)nullptr, (double *)nullptr);
+    }
+#undef PA_LAUNCH_XR
   }
   if (S->n_xw_rest > 0) {                              // what fits no group: the general kernel over a chunk list
     const int cpx = (int)((S->n_xw_rest + 7) / 8);

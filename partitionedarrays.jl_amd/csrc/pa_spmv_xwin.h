@@ -224,21 +224,24 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
 #define PA_XR_WANT_GROUPS 1024   // one workgroup per CU is resident (157 KB of LDS): the runs are cut so that there are at most
                                  // 4 x 256 of them -- 772 runs (3 per CU and 4 left over) ran a quarter longer than 768 would
 
-template <int SUB, int NPT, bool NT, bool DOT = false>
-__global__ __launch_bounds__(256 * SUB) void k_spmv_xring(
+// BLK lanes work on one chunk (256 x 6 entries each as everywhere else, or 512 x 4 with the lanes past the chunk's 1536
+// entries idle: twice the waves on the CU for the same LDS)
+template <int SUB, int NPT, bool NT, bool DOT = false, int BLK = 256>
+__global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
     const int *__restrict__ crp, const unsigned short *__restrict__ col16, const int *__restrict__ win,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const int *__restrict__ chunk_row, const int *__restrict__ chunk_p, const int *__restrict__ chunk_cmax,
     const pa_xw_group *__restrict__ grp, int n_groups, int groups_per_xcd, int n_cols, double alpha, double beta,
     const double *__restrict__ u = nullptr, double *__restrict__ partial = nullptr) {
-  constexpr int BLK = 256, CAP = BLK * NPT, NTHR = BLK * SUB, C = PA_XR_CAP;
+  constexpr int CAP = PA_SPMV_CHUNK_NNZ, NTHR = BLK * SUB, C = PA_XR_CAP;
   constexpr int PCAP = CAP + CAP / 16 + 2;
+  static_assert(BLK * NPT >= CAP, "the lanes of a sub-group cover a chunk");
   __shared__ __attribute__((aligned(16))) double xs[C];
   __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
   __shared__ double wsum[SUB * (BLK / 64)];
   const int tid = threadIdx.x;
   const int t = tid & (BLK - 1);
-  const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int sub = __builtin_amdgcn_readfirstlane(tid / BLK);
   double *prod = prod_all + sub * PCAP;
   const int b = blockIdx.x;
   const int g = (b & 7) * groups_per_xcd + (b >> 3);
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xring(
         d2 pr;
         pr.x = a;
         pr.y = c;
-        *reinterpret_cast<d2 *>(&prod[PA_XW_PSLOT((k * BLK + t) * 2)]) = pr;
+        if (BLK * NPT == CAP || (k * BLK + t) * 2 < CAP) *reinterpret_cast<d2 *>(&prod[PA_XW_PSLOT((k * BLK + t) * 2)]) = pr;
       }
       if (ch + SUB < ch_end) {
         r0 = nr0; r1 = nr1; p0 = np0; p1 = np1;
