@@ -2103,8 +2103,8 @@ def test_sliding_x_window_launch_is_bit_identical(orc, monkeypatch, ring):
     orc.oracle_c().mul5_csr(want5, Ho, xh, -2.0, 3.0)
     A = pa.DeviceCSR(H)
     xw = A.xwin()
-    assert xw["ring_groups"] > 0 and 0 < xw["chunks"] < A.info()["n_chunks"], xw
-    if ring == "2":
+    assert xw["groups"] > 0 and 0 < xw["chunks"] < A.info()["n_chunks"], xw
+    if ring == "2":                                 # (behind the forced windows the ring may be left with nothing on this block)
         assert xw["ring_groups"] == xw["groups"] and xw["big_groups"] == 0, xw
     x = pa.DeviceVector(m, 0).upload(xh)
     y = pa.DeviceVector(m, 0)
