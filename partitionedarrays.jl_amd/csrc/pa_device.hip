@@ -1585,11 +1585,17 @@ static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double al
     if (u) PA_LAUNCH_XW(4, true, PA_XW_CAP_MID, grp + n0, n1);
     else PA_LAUNCH_XW(4, false, PA_XW_CAP_MID, grp + n0, n1);
   }
-  if (n2 > 0) {
-    if (u) PA_LAUNCH_XW(2, true, PA_XW_CAP_BIG, grp + n0 + n1, n2);
-    else PA_LAUNCH_XW(2, false, PA_XW_CAP_BIG, grp + n0 + n1, n2);
-  }
 #undef PA_LAUNCH_XW
+  if (n2 > 0) {                                        // 128 KiB windows: one workgroup per CU -- 2 x 512 lanes, 4 entries per lane
+    static const int wide2 = getenv("PA_SPMV_XWIN_BIG_LANES") ? atoi(getenv("PA_SPMV_XWIN_BIG_LANES")) : 512;
+#define PA_LAUNCH_XW2(DOT, BLKX, NPTX)                                                                                                  \
+  hipLaunchKernelGGL((k_spmv_xwin<2, NPTX, SPMV_NT, DOT, PA_XW_CAP_BIG, BLKX>), dim3(((n2 + 7) / 8) * 8), dim3(2 * BLKX), 0, c->s[0],   \
+                     S->d_crp, S->d_col16, S->d_win, S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, grp + n0 + n1, (int)n2,            \
+                     (int)((n2 + 7) / 8), (int)S->n_cols, alpha, kbeta, u, partial)
+    if (wide2 == 512) { if (u) PA_LAUNCH_XW2(true, 512, 4); else PA_LAUNCH_XW2(false, 512, 4); }
+    else { if (u) PA_LAUNCH_XW2(true, 256, SPMV_NPT); else PA_LAUNCH_XW2(false, 256, SPMV_NPT); }
+#undef PA_LAUNCH_XW2
+  }
   if (S->n_xw_ring > 0) {                              // runs of chunks served from the sliding x window
     const int ng = (int)S->n_xw_ring, gpx = (ng + 7) / 8;
     const pa_xw_group *rg = grp + n0 + n1 + n2;

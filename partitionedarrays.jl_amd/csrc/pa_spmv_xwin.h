@@ -56,21 +56,24 @@ struct pa_xw_group { int first, cnt, wlo, wlen; };
 // DOT: also partial[chunk] = sum over the chunk's rows of u[row] * (sum of the row's products), in the order of
 // k_spmv_rowsplit's EPI 3 (per lane in row order, pa_wave_sum, the four wave sums left to right): the same bits whichever
 // kernel a chunk runs on.
-template <int SUB, int NPT, bool NT, bool DOT = false, int XCAP = PA_XW_CAP>
-__global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
+// BLK lanes work on one chunk: 256 x 6 entries, or 512 x 4 (the lanes past the chunk's 1536 entries idle) where the LDS
+// leaves room for one workgroup per CU only and twice the waves help (the 128 KiB windows).
+template <int SUB, int NPT, bool NT, bool DOT = false, int XCAP = PA_XW_CAP, int BLK = 256>
+__global__ __launch_bounds__(BLK * SUB) void k_spmv_xwin(
     const int *__restrict__ crp, const unsigned short *__restrict__ col16, const int *__restrict__ win,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const int *__restrict__ chunk_row, const int *__restrict__ chunk_p, const pa_xw_group *__restrict__ grp,
     int n_groups, int groups_per_xcd, int n_cols, double alpha, double beta, const double *__restrict__ u = nullptr,
     double *__restrict__ partial = nullptr) {
-  constexpr int BLK = 256, CAP = BLK * NPT, NTHR = BLK * SUB;
+  constexpr int CAP = PA_SPMV_CHUNK_NNZ, NTHR = BLK * SUB;
   constexpr int PCAP = CAP + CAP / 16 + 2;            // padded product slots: rows of 2^k entries miss each other's banks
+  static_assert(BLK * NPT >= CAP, "the lanes of a sub-group cover a chunk");
   __shared__ __attribute__((aligned(16))) double xs[XCAP + 4];
   __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
   __shared__ double wsum[SUB * (BLK / 64)];
   const int tid = threadIdx.x;
   const int t = tid & (BLK - 1);
-  const int sub = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int sub = __builtin_amdgcn_readfirstlane(tid / BLK);
   double *prod = prod_all + sub * PCAP;
   const int b = blockIdx.x;
   const int g = (b & 7) * groups_per_xcd + (b >> 3);  // XCD-aware: workgroup b sits on XCD b%8, neighbours in g share an L2
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256 * SUB) void k_spmv_xwin(
         d2 pr;
         pr.x = a;
         pr.y = c;
-        *reinterpret_cast<d2 *>(&prod[PA_XW_PSLOT((k * BLK + t) * 2)]) = pr;
+        if (BLK * NPT == CAP || (k * BLK + t) * 2 < CAP) *reinterpret_cast<d2 *>(&prod[PA_XW_PSLOT((k * BLK + t) * 2)]) = pr;
       }
       // the next chunk's loads go out before this one's row sums: they fly during the barrier and the reduce phase
       if (ch + SUB < ch_end) {
