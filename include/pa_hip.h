@@ -97,6 +97,9 @@ int pa_ctx_stream_priority(pa_ctx *ctx, int which, int *priority, int *least, in
  * (matrix stream, vector) pair passed / failed the self-check, the budget.  pa_ctx_arena_build acquires a first extent now.
  * pa_csr_memory_class / pa_vec_memory_class: class of a block's value stream / a vector's storage (-1: outside). */
 int pa_ctx_arena_build(pa_ctx *ctx);
+/* vector_classes = 2: a solver's vectors (a multigrid hierarchy) alternate between two memory classes of their own -- kernels
+ * that read vectors and write one run 3-6 % faster; costs one more walk, once.  1 = the default. */
+int pa_ctx_arena_hint(pa_ctx *ctx, int vector_classes);
 int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class_bytes[3], int64_t *used, double *map_ms,
                       int *matrix_class);
 int pa_ctx_arena_map(pa_ctx *ctx, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells);

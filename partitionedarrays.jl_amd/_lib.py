@@ -89,6 +89,7 @@ _SIGS = {
     "pa_csr_device_bytes": [P, C.POINTER(i64)],
     "pa_csr_stream_bytes": [P, C.POINTER(i64)],
     "pa_ctx_arena_build": [P],
+    "pa_ctx_arena_hint": [P, cint],
     "pa_ctx_arena_info": [P, C.POINTER(i64), C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(f64), C.POINTER(cint)],
     "pa_ctx_arena_map": [P, C.POINTER(i64), P, i64, C.POINTER(i64)],
     "pa_ctx_arena_stats": [P] + [C.POINTER(i64)] * 8,

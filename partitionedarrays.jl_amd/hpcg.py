@@ -203,6 +203,11 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
     if graph is None:                                  # (off by default: 0.555 -> 0.488 ms per MG-PCG iteration at 32^3, nothing at
         graph = False                                  # 128^3 / 256^3 -- the launches already run ahead of the device there)
     rbs = [None] * (l - 1)
+    if ordering != "sequential":                      # (the colour updates read b, d, x and write x: two vector classes, csrc/pa_arena.hip)
+        try:
+            context().arena_hint(2)
+        except Exception:                             # noqa: BLE001  (no GPU: the host-side pieces still build)
+            pass
     from .gallery import build_p_matrix, compute_optimal_shape_XYZ
     npx, npy, npz = compute_optimal_shape_XYZ(np_)
     f2c, As, gss, rs, xs, Axfs = [None] * (l - 1), [None] * l, [None] * l, [None] * l, [None] * l, [None] * l

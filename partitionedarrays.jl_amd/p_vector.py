@@ -58,6 +58,10 @@ class Context:
         L.call("pa_ctx_stream_priority", self.h, L.STREAM_COMM, C.byref(b), None, None)
         return dict(compute=a.value, comm=b.value, least=lo.value, greatest=hi.value)
 
+    def arena_hint(self, vector_classes=2):
+        """Announce a solver's worth of vectors (pa_ctx_arena_hint): they alternate between two memory classes of their own."""
+        L.call("pa_ctx_arena_hint", self.h, int(vector_classes))
+
     def arena(self, build=False):
         """The context's HBM extents and their memory-class maps (csrc/pa_arena.hip): GiB held, classes met, GiB per class
         in the held extents, GiB in use, time spent acquiring + classifying, the class of every 512 MiB cell as a string
