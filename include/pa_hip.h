@@ -56,6 +56,7 @@ extern "C" {
 
 typedef struct pa_ctx pa_ctx;     /* one device + its two streams                                  */
 typedef struct pa_vec pa_vec;     /* local values of one part of a PVector, layout [own | ghost]   */
+typedef struct pa_gs pa_gs;       /* the level-scheduled Gauss-Seidel smoother of one part (below)  */
 typedef struct pa_csr pa_csr;     /* one CSR block of a SplitMatrix (own_own, own_ghost, ...)       */
 typedef struct pa_plan pa_plan;   /* VectorAssemblyCache of one part (src/p_vector.jl:418-426)      */
 typedef struct pa_comm pa_comm;   /* RCCL communicator: one rank per part (MPIArray analogue)       */
@@ -100,6 +101,9 @@ int pa_ctx_arena_build(pa_ctx *ctx);
 /* vector_classes = 2: a solver's vectors (a multigrid hierarchy) alternate between two memory classes of their own -- kernels
  * that read vectors and write one run 3-6 % faster; costs one more walk, once.  1 = the default. */
 int pa_ctx_arena_hint(pa_ctx *ctx, int vector_classes);
+/* An arena nothing lives in keeps up to PA_ARENA_SPARE_GIB (24) of extents for what the caller builds next (memory that
+ * has been used is wiped by the driver when allocated again: 0.9 s per 16 GiB); this hands them back now. */
+int pa_ctx_arena_release(pa_ctx *ctx);
 int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class_bytes[3], int64_t *used, double *map_ms,
                       int *matrix_class);
 int pa_ctx_arena_map(pa_ctx *ctx, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells);
@@ -126,6 +130,27 @@ int pa_coo_assembly_blocks(pa_coo_assembly *h, pa_csr **own_own, pa_csr **own_gh
 /* 1-based host copies of a block (which: 0 own_own, 1 own_ghost): rowptr[n_own_rows + 1], colval / nzval[nnz] */
 int pa_coo_assembly_download(const pa_coo_assembly *h, int which, int32_t *rowptr, int32_t *colval, double *nzval);
 int pa_coo_assembly_destroy(pa_coo_assembly *h);
+
+/* ---- blocks made of some rows of a part's matrix, built on the device (csrc/pa_rowsel.hip) ----------------------------
+ * What the multigrid set-up of the HPCG driver takes from a level's matrix: the colours of the multicolour Gauss-Seidel
+ * smoother (PartitionedSolvers/src/smoothers.jl:98-176 as SpMV + update) and the fine rows the coarse grid keeps
+ * (HPCG/src/mg_preconditioner.jl:224-251,314-329).  pa_ctx_keep_raw_columns(ctx, 1): blocks created from now on keep their
+ * Int32 columns in HBM next to the compacted streams the product reads (4 B per stored entry, until
+ * pa_csr_drop_raw_columns).  pa_csr_select_rows: out[k] = the n_rows x (own + ghost columns) block holding the rows r with
+ * mask[r] == k (host array of n_rows entries in -1..n_sel-1; -1: in no block) of own_own | own_ghost (own_ghost may be NULL;
+ * its columns are shifted by own_own's column count: the unsplit order HPCG stores), entries in stored order -- the blocks
+ * pa_host_color_split + pa_csr_create give, without the host copy and the second trip over PCIe.  pa_csr_diagonal:
+ * d[r] = the stored (r,r) entry of the block, 0.0 when there is none. */
+int pa_ctx_keep_raw_columns(pa_ctx *ctx, int on);
+int pa_csr_has_raw_columns(const pa_csr *A, int *yes);
+int pa_csr_drop_raw_columns(pa_csr *A);
+int pa_csr_select_rows(const pa_csr *own_own, const pa_csr *own_ghost, const int32_t *mask, int32_t n_sel, pa_csr **out);
+int pa_csr_diagonal(const pa_csr *own_own, pa_vec *d);
+/* pa_gs_create (below) for the sequential ordering from the part's blocks in HBM: the unsplit CSR, the diagonal and the
+ * dependency levels of the sweep (PartitionedSolvers/src/smoothers.jl:144-160) computed on the device, verified against
+ * their definition entry by entry.  PA_ERR_ARG when the own|own pattern is not structurally symmetric or a diagonal
+ * entry is missing (pa_gs_create's own conditions). */
+int pa_gs_create_from_blocks(const pa_csr *own_own, const pa_csr *own_ghost, int ordering, pa_gs **out);
 
 /* testing aid: a host copy of one of the arrays the product kernel reads (first slab of the block) -- 0 row pointers,
  * 1 32-bit columns, 2 16-bit codes, 3 windows, 4 pattern descriptors, 5 pattern table, 6 chunk table, 7 compacted row ids;
@@ -358,7 +383,6 @@ int pa_scatter_add(pa_scatter *s, pa_vec *dst, const pa_vec *src, int zero_first
  * HPCG/src/hpcg_benchmark.jl:60-78): it must reach the reference tolerance and is charged for its extra iterations. */
 #define PA_GS_SEQUENTIAL 0
 #define PA_GS_MULTICOLOR 1
-typedef struct pa_gs pa_gs;
 int pa_gs_create(pa_ctx *ctx, int64_t n_own, int64_t n_local, int64_t nnz, const int32_t *rowptr,
                  const int32_t *colval, const double *nzval, int index_base, int ordering, pa_gs **gs);
 int pa_gs_destroy(pa_gs *gs);

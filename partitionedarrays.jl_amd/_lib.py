@@ -90,10 +90,17 @@ _SIGS = {
     "pa_csr_stream_bytes": [P, C.POINTER(i64)],
     "pa_ctx_arena_build": [P],
     "pa_ctx_arena_hint": [P, cint],
+    "pa_ctx_arena_release": [P],
     "pa_ctx_arena_info": [P, C.POINTER(i64), C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(f64), C.POINTER(cint)],
     "pa_ctx_arena_map": [P, C.POINTER(i64), P, i64, C.POINTER(i64)],
     "pa_ctx_arena_stats": [P] + [C.POINTER(i64)] * 8,
     "pa_csr_debug_array": [P, cint, P, i64, C.POINTER(i64)],
+    "pa_ctx_keep_raw_columns": [P, cint],
+    "pa_csr_has_raw_columns": [P, C.POINTER(cint)],
+    "pa_csr_drop_raw_columns": [P],
+    "pa_csr_select_rows": [P, P, P, C.c_int32, P],
+    "pa_csr_diagonal": [P, P],
+    "pa_gs_create_from_blocks": [P, P, cint, C.POINTER(P)],
     "pa_coo_assemble": [P, i64, P, P, P, C.c_int32, P, P, P, P, P, P, i64, P, cint, C.POINTER(P)],
     "pa_coo_assembly_info": [P] + [C.POINTER(i64)] * 5 + [C.POINTER(f64)],
     "pa_coo_assembly_ghosts": [P, P],

@@ -23,9 +23,11 @@
 // keeps that one and hands the ones it walked over back to the driver at once (transient; bounded by PA_ARENA_WALK_GIB =
 // 160 and by the budget PA_ARENA_FRACTION = 0.70 of the free memory / PA_ARENA_GIB).  An extent nothing lives in any more
 // is released (PA_ARENA_SPARE = n keeps the newest n: re-allocating memory that has been used costs a driver-side wipe of
-// 30-75 ms per GiB).  The extent the vectors' walk ends in is replaced by a right-sized one (4 GiB or 8 x the request).  Every big vector handed out is checked once against the newest matrix stream with the same stand-in
-// kernel (~1.5 ms, PA_ARENA_SELFCHECK=0 disables): a pair that times as "same class" although the map says otherwise is
-// moved to the other clean class or reported.  All of it under the context's mutex; any failure (no contiguous memory, a
+// 30-75 ms per GiB).  The vectors' extents, and the steps of their walk, are 4 GiB (or 8 x the request): the extent the walk
+// ends in stays.  A big vector handed out is checked against the matrix streams' class with the same stand-in kernel
+// (~3 ms; once per cell it touches -- a solver that allocates its work vectors on every call pays nothing after the first;
+// PA_ARENA_SELFCHECK=0 disables): a pair that times as "same class" although the map says otherwise is moved to the other
+// clean class or reported.  All of it under the context's mutex; any failure (no contiguous memory, a
 // probe error) freezes growth and falls back to hipMalloc -- never an error of the caller's allocation.
 #include <hip/hip_runtime.h>
 
@@ -65,6 +67,7 @@ struct pa_extent {
   size_t size = 0;
   std::vector<int8_t> cls;                 // per cell: global class 0..2, or -1 (a boundary runs through it / not told: not handed out)
   size_t live = 0;                         // bytes handed out from it (a class's scratch counts)
+  std::vector<uint8_t> clear_of;           // per cell: bit m set = a vector here passed the pair check against matrix class m
 };
 
 struct pa_arena {
@@ -88,6 +91,8 @@ struct pa_arena {
   const char *last_matrix = nullptr;       // the newest big matrix stream: the read stream of the pair self-check
   size_t last_matrix_len = 0;
   int last_matrix_cls = -1;
+  bool release_idle = false;               // pa_ctx_arena_release: an idle arena hands everything back, spare or not
+  bool walking = false;                    // a walk is under way: what it went over is held until it has ended (arena_trim waits)
   int want_vec_classes = 1;                // pa_ctx_arena_hint: 2 = a solver's vectors alternate between two classes of their own
   bool second_walk_done = false;
   long check_ok = 0, check_failed = 0;     // vectors whose (matrix stream, vector) pair timed as "different classes" / "same class"
@@ -302,14 +307,18 @@ static void arena_release(pa_arena *a, pa_extent *X) {
 // per GiB -- extent_probe (a): 16 GiB 0.84 s, 96 GiB 4.8 s -- so a caller that creates, destroys and re-creates big blocks
 // in a loop may want a spare).
 static void arena_trim(pa_arena *a) {
+  if (a->walking) return;                  // (the extents a walk went over keep the driver from handing their memory out again)
   static const int spare = getenv("PA_ARENA_SPARE") ? std::max(0, atoi(getenv("PA_ARENA_SPARE"))) : 0;
   std::vector<pa_extent *> empty;
   for (pa_extent *X : a->ext) if (X->live == 0) empty.push_back(X);
   for (size_t i = 0; i + spare < empty.size(); ++i) arena_release(a, empty[i]);     // (ext is in order of acquisition: the oldest go)
-  if (a->used == 0) {
-    // Nothing of the context lives in the arena any more: everything goes back, the extents that hold the classes'
-    // reference cells included (a later allocation starts over: classes are only ever compared inside one context's
-    // lifetime of live buffers, and there are none).
+  // Nothing of the context lives in the arena any more: up to PA_ARENA_SPARE_GIB (24) stay as they are, classes and all, for
+  // whatever the caller builds next (a solver set up again, the next matrix of a parameter sweep: the driver wipes memory that
+  // has been used when it is allocated again, 0.9 s for a 16 GiB extent -- a third of the multigrid set-up at 256^3);
+  // beyond that, or on pa_ctx_arena_release, everything goes back, the extents that hold the classes' reference cells
+  // included (a later allocation starts over: classes are only ever compared inside one context's lifetime of live buffers).
+  static const size_t spare_bytes = (size_t)(getenv("PA_ARENA_SPARE_GIB") ? std::max(0, atoi(getenv("PA_ARENA_SPARE_GIB"))) : 24) * GIB;
+  if (a->used == 0 && (a->held > spare_bytes || a->release_idle)) {
     while (!a->ext.empty()) arena_release(a, a->ext.back());
     a->n_classes = 0;
     for (int k = 0; k < 3; ++k) { a->ref[k] = nullptr; a->scr[k] = nullptr; a->mat_bytes[k] = a->vec_bytes[k] = 0; }
@@ -444,12 +453,14 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
         for (int k = 0; k < a->n_classes && !q; ++k) if (a->vec_bytes[k] == 0) q = arena_take(a, bytes, k, kind);
         return q;
       };
+      a->walking = true;
       while (!p && walked_bytes < walk_budget) {
         pa_extent *X = arena_acquire(c, a, extent_bytes(a, bytes), "matrix streams");
         if (!X) break;
         walked_bytes += X->size;
         p = take_clean();
       }
+      a->walking = false;
       arena_trim(a);
     }
     if (!p) {                                           // spill: the class with the fewest vector bytes first
@@ -520,38 +531,23 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
   if (!p && !a->frozen && !c->capturing) {
     size_t walk_budget = (size_t)160 * GIB;
     if (const char *s = getenv("PA_ARENA_WALK_GIB")) walk_budget = (size_t)atol(s) * GIB;
+    if (second) walk_budget = std::min(walk_budget, (size_t)16 * GIB);   // (a second class is worth 1 % to a solver, not a long walk)
     size_t walked_bytes = 0;
     pa_extent *found = nullptr;
+    // The vectors' extents are small (4 GiB, or 8 x the request: the vectors of a part are a fraction of its matrix
+    // streams), and the walk steps in that size: the extent it ends in is the one that stays.  (Handing a big step back
+    // and taking a smaller extent "in its place" does not work: the driver serves the next request from elsewhere --
+    // measured, profiles/r03_mg_ab.md -- and wipes what was handed back before it is used again, 1 s per 16 GiB.)
+    const size_t step = std::max<size_t>((size_t)4 * GIB, (8 * bytes + a->cell - 1) / a->cell * a->cell + 2 * a->cell);
+    a->walking = true;
     while (!p && walked_bytes < walk_budget) {
-      pa_extent *X = arena_acquire(c, a, extent_bytes(a, bytes), second ? "vectors: looking for a second class of their own" : "vectors: looking for a class without matrix streams");
+      pa_extent *X = arena_acquire(c, a, step, second ? "vectors: looking for a second class of their own" : "vectors: looking for a class without matrix streams");
       if (!X) break;
       walked_bytes += X->size;
       if ((p = accept()) != nullptr) found = X;
     }
-    // Right-size what the walk found: the steps are big (to cross a class region of tens of GiB in a few of them), the
-    // vectors of a part are not -- the extent is handed back and a smaller one taken in its place (the driver gives the
-    // lowest free memory: the same place, hence the same class; checked, and the walk's own extent kept when it is not).
-    const size_t want = std::max<size_t>((size_t)4 * GIB, (8 * bytes + a->cell - 1) / a->cell * a->cell + 2 * a->cell);
-    // (an extent that showed a class for the first time also holds that class's reference cell and scratch: the class is
-    // forgotten with it -- it has the highest id, nothing else can carry it yet -- and met again in the smaller extent)
-    const size_t scr_len = (probe_wr_bytes(probe_nb(a->cell)) + ARENA_ALIGN - 1) / ARENA_ALIGN * ARENA_ALIGN;
-    const int top = a->n_classes - 1;
-    const bool introduced = p && found && top >= 0 && a->ref[top] >= found->base && a->ref[top] < found->base + found->size;
-    if (p && found && found->size > want && found->live == a->live_[(uintptr_t)p].len + (introduced ? scr_len : 0)) {
-      const int cls_found = a->live_[(uintptr_t)p].cls;
-      if (introduced) found->live -= scr_len;           // (the scratch goes with the extent)
-      arena_give_back(a, p);                            // (found is empty now: the trim inside hands it back)
-      p = nullptr;
-      if (std::find(a->ext.begin(), a->ext.end(), found) != a->ext.end()) arena_release(a, found);
-      if (introduced) { a->n_classes = top; a->ref[top] = nullptr; a->scr[top] = nullptr; a->mat_bytes[top] = a->vec_bytes[top] = 0; }
-      pa_extent *Y = arena_acquire(c, a, want, "vectors: right-sized");
-      if (Y) p = accept();
-      if (!p) {                                         // it came from somewhere else after all: take a full step again
-        pa_extent *X = arena_acquire(c, a, extent_bytes(a, bytes), "vectors: looking for a class without matrix streams (again)");
-        if (X) p = accept();
-      }
-      (void)cls_found;
-    }
+    (void)found;
+    a->walking = false;
     arena_trim(a);                                      // what the walk went over goes back at once
   }
   if (!p && second) p = try_clean();                    // (no second class within reach: the first one serves)
@@ -562,12 +558,24 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
     return p;                                           // (knowingly next to matrix streams: nothing to check)
   }
   // self-check of the pair actually handed out (big vectors only: what a product writes)
+  // (once per cell and matrix class: a solver that allocates its work vectors on every call must not pay a dozen probe
+  // launches per vector each time -- 0.57 ms per MG-PCG iteration of a 30-iteration solve at 256^3 when it did)
   if (check_mode && a->last_matrix && bytes >= ((size_t)32 << 20) && !c->capturing) {
-    const int cls = a->live_[(uintptr_t)p].cls;
+    const pa_arena::blk &bk = a->live_[(uintptr_t)p];
+    const int cls = bk.cls;
     bool same = false;
-    if (cls != a->last_matrix_cls && pair_check(c, a, (char *)p, bytes, &same) == PA_OK) {
-      if (!same) a->check_ok++;
-      else {
+    const uint8_t bit = (uint8_t)(1u << a->last_matrix_cls);
+    const size_t c0 = (size_t)((char *)p - bk.e->base) / a->cell, c1 = (size_t)((char *)p + bytes - 1 - bk.e->base) / a->cell;
+    bool known = cls != a->last_matrix_cls;
+    for (size_t k = c0; k <= c1 && known; ++k) known = k < bk.e->clear_of.size() && (bk.e->clear_of[k] & bit);
+    if (known) {
+      // every cell under this vector has been checked against the matrix streams' class before
+    } else if (cls != a->last_matrix_cls && pair_check(c, a, (char *)p, bytes, &same) == PA_OK) {
+      if (!same) {
+        a->check_ok++;
+        if (bk.e->clear_of.size() < bk.e->cls.size()) bk.e->clear_of.resize(bk.e->cls.size(), 0);
+        for (size_t k = c0; k <= c1 && k < bk.e->clear_of.size(); ++k) bk.e->clear_of[k] |= bit;
+      } else {
         a->check_failed++;
         // the map says "different classes", the pair says "same": try the other clean class once, else keep it and say so
         void *q = nullptr;
@@ -618,7 +626,7 @@ static void arena_give_back(pa_arena *a, void *p) {
     }
   }
   a->free_[start] = {len, b.cls, 0, b.e};
-  if (a->mat_bytes[0] + a->mat_bytes[1] + a->mat_bytes[2] == 0) a->matrix_class = -1;
+  // (the matrix streams' class stays what it is while extents are held: the next block goes where the room for it is)
   if (b.e->live == 0 || a->used == 0) arena_trim(a);    // nothing of the extent (or of the context) is in use any more
 }
 
@@ -799,6 +807,18 @@ extern "C" int pa_ctx_arena_stats(pa_ctx *c, int64_t *n_extents, int64_t *bytes_
 
 // A caller about to allocate a solver's worth of vectors (a multigrid hierarchy) asks for `vector_classes` = 2: the vectors
 // then alternate between two memory classes of their own (see arena_alloc); 1 = the default.
+extern "C" int pa_ctx_arena_release(pa_ctx *c) {
+  PA_REQUIRE(c != nullptr, "ctx is NULL");
+  std::lock_guard<std::mutex> lk(c->mem_mu);
+  if (pa_arena *a = c->arena) {
+    PA_HIP(hipSetDevice(c->device));
+    a->release_idle = true;
+    arena_trim(a);
+    a->release_idle = false;
+  }
+  return PA_OK;
+}
+
 extern "C" int pa_ctx_arena_hint(pa_ctx *c, int vector_classes) {
   PA_REQUIRE(c && (vector_classes == 1 || vector_classes == 2), "bad arguments");
   std::lock_guard<std::mutex> lk(c->mem_mu);

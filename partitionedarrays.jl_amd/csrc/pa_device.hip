@@ -721,9 +721,14 @@ struct csr_src {
   const double *nzval = nullptr;
   const int32_t *d_col = nullptr;
   const double *d_val = nullptr;
+  // rows counted (and, when most are empty, compacted) on the device already (pa_rowsel.hip): the row pointer handed to
+  // csr_fill_slab is the final one (n_nonempty + 1 entries with d_row_ids, n_rows + 1 without) and the host passes are skipped
+  int64_t pre_nonempty = -1;
+  const int32_t *d_pre_row_ids = nullptr;
   bool on_device() const { return d_col != nullptr || d_val != nullptr; }
   csr_src at(int64_t off) const {
     csr_src o;
+    o.pre_nonempty = pre_nonempty; o.d_pre_row_ids = d_pre_row_ids;
     o.col0 = col0 ? col0 + off : nullptr; o.nzval = nzval ? nzval + off : nullptr;
     o.d_col = d_col ? d_col + off : nullptr; o.d_val = d_val ? d_val + off : nullptr;
     return o;
@@ -754,32 +759,39 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   };
   std::vector<int32_t> row_ids;
   int64_t n_nonempty = 0;
-  std::vector<int64_t> part_cnt(33, 0);          // (host threads over row ranges: a colour block of the 256^3 operator has 16.8 M
-  host_parallel(n_rows, n_rows * 4, [&](int t, int64_t lo, int64_t hi) {      // rows, one in eight non-empty)
-    int64_t k = 0;
-    for (int64_t r = lo; r < hi; ++r) k += rp[r + 1] > rp[r];
-    part_cnt[t] = k;
-  });
-  for (int t = 0; t < 33; ++t) n_nonempty += part_cnt[t];
-  const bool compact = n_rows > 0 && n_nonempty * 2 < n_rows;
+  bool compact = false;
   std::vector<int32_t> crp;
-  if (compact) {
-    row_ids.resize(n_nonempty);
-    crp.resize(n_nonempty + 1);
-    crp[0] = 0;
-    std::vector<int64_t> first(34, 0);
-    for (int t = 0; t < 33; ++t) first[t + 1] = first[t] + part_cnt[t];
-    host_parallel(n_rows, n_rows * 4, [&](int t, int64_t lo, int64_t hi) {
-      int64_t k = first[t];
-      for (int64_t r = lo; r < hi; ++r)
-        if (rp[r + 1] > rp[r]) {
-          row_ids[k] = (int32_t)r;
-          crp[k + 1] = rp[r + 1];
-          ++k;
-        }
-    });
-  } else {
+  if (src.pre_nonempty >= 0) {
+    n_nonempty = src.pre_nonempty;
+    compact = src.d_pre_row_ids != nullptr;
     crp.swap(rp);
+  } else {
+    std::vector<int64_t> part_cnt(33, 0);          // (host threads over row ranges: a colour block of the 256^3 operator has 16.8 M
+    host_parallel(n_rows, n_rows * 4, [&](int t, int64_t lo, int64_t hi) {      // rows, one in eight non-empty)
+      int64_t k = 0;
+      for (int64_t r = lo; r < hi; ++r) k += rp[r + 1] > rp[r];
+      part_cnt[t] = k;
+    });
+    for (int t = 0; t < 33; ++t) n_nonempty += part_cnt[t];
+    compact = n_rows > 0 && n_nonempty * 2 < n_rows;
+    if (compact) {
+      row_ids.resize(n_nonempty);
+      crp.resize(n_nonempty + 1);
+      crp[0] = 0;
+      std::vector<int64_t> first(34, 0);
+      for (int t = 0; t < 33; ++t) first[t + 1] = first[t] + part_cnt[t];
+      host_parallel(n_rows, n_rows * 4, [&](int t, int64_t lo, int64_t hi) {
+        int64_t k = first[t];
+        for (int64_t r = lo; r < hi; ++r)
+          if (rp[r + 1] > rp[r]) {
+            row_ids[k] = (int32_t)r;
+            crp[k + 1] = rp[r + 1];
+            ++k;
+          }
+      });
+    } else {
+      crp.swap(rp);
+    }
   }
   const int64_t nc = (int64_t)crp.size() - 1;
   std::vector<int32_t> chunk_row;
@@ -816,7 +828,10 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   PA_HIP(pa_h2d(A->d_chunk_row, chunk_row.data(), sizeof(int32_t) * chunk_row.size()));
   if (compact) {
     PA_TRY(pa_dev_alloc(c, (void **)&A->d_row_ids, sizeof(int32_t) * std::max<int64_t>(1, nc), PA_MEM_MATRIX));
-    if (nc) PA_HIP(pa_h2d(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc));
+    if (nc && src.d_pre_row_ids) {
+      PA_HIP(hipMemcpyAsync(A->d_row_ids, src.d_pre_row_ids, sizeof(int32_t) * nc, hipMemcpyDeviceToDevice, c->s[0]));
+      PA_HIP(hipStreamSynchronize(c->s[0]));
+    } else if (nc) PA_HIP(pa_h2d(A->d_row_ids, row_ids.data(), sizeof(int32_t) * nc));
   }
   lap("upload");
   pa_col_streams cs;                       // host encoder's arrays (PA_SETUP_DEVICE=0); `win` also when the x windows are planned
@@ -845,7 +860,8 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
     else {
       A->d_col = ds.d_c32; A->n_col32 = ds.n_c32_slots;
       PA_HIP(hipStreamSynchronize(c->s[0]));
-      pa_dev_free(c, d_colfull);
+      if (c->keep_raw_columns) A->d_raw_col = d_colfull;
+      else pa_dev_free(c, d_colfull);
     }
     cs.use_pattern = ds.use_pattern; cs.use_c16 = ds.use_c16; cs.full = ds.full;
     if (tm_) fprintf(stderr, "[pa setup] device encode %.3f ms: %lld pattern / %lld c16 / %lld c32 chunks\n", ds.ms, (long long)ds.n_pattern,
@@ -1174,6 +1190,22 @@ int pa_csr_from_device(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, c
   return csr_build(c, n_rows, n_cols, nnz, rp, src, out);
 }
 
+// the same from rows the caller has counted and compacted on the device: crp = the final row pointer on the host (moved from)
+int pa_csr_from_device_rows(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t n_nonempty, std::vector<int32_t> &crp,
+                            const int32_t *d_row_ids, const int32_t *d_col, const double *d_val, pa_csr **out) {
+  PA_REQUIRE(nnz < slab_limit(), "a block of this size is a chain of slabs: the general constructor builds those");
+  PA_REQUIRE((int64_t)crp.size() == (d_row_ids ? n_nonempty : n_rows) + 1 && crp.front() == 0 && crp.back() == nnz,
+             "row pointers do not span the stored entries");
+  csr_src src;
+  src.d_col = d_col; src.d_val = d_val;
+  src.pre_nonempty = n_nonempty; src.d_pre_row_ids = d_row_ids;
+  pa_csr *S = nullptr;
+  PA_TRY(csr_build_slab(c, n_rows, n_cols, nnz, crp, src, &S));
+  S->t_rows = n_rows; S->t_nnz = nnz;
+  *out = S;
+  return PA_OK;
+}
+
 extern "C" int pa_csr_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr,
                                       const void *rowval, int index_bytes, int index_base, const double *nzval,
                                       pa_csr **out) {
@@ -1239,6 +1271,7 @@ static void csr_free_chain(pa_csr *A) {
     pa_csr *n = A->next;
     pa_dev_free(A->ctx, A->d_crp);
     pa_dev_free(A->ctx, A->d_col);
+    if (A->d_raw_col) pa_dev_free(A->ctx, A->d_raw_col);
     pa_dev_free(A->ctx, A->d_val);
     pa_dev_free(A->ctx, A->d_chunk_row);
     if (A->d_row_ids) pa_dev_free(A->ctx, A->d_row_ids);

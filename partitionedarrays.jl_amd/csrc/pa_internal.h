@@ -51,6 +51,7 @@ struct pa_ctx {
   double *d_dotpart = nullptr;            // per-chunk partial sums of a fused product + dot (pa_mul_dot)
   int64_t n_dotpart = 0;
   bool capturing = false;                 // a pa_graph_begin is open on the compute stream
+  bool keep_raw_columns = false;          // pa_ctx_keep_raw_columns: blocks created now keep their Int32 columns in HBM (pa_rowsel.hip)
   int comm_priority = 0;                  // priority the comm stream was created with (the device's greatest)
   pa_arena *arena = nullptr;              // contiguous HBM extents with their memory-class maps (pa_arena.hip), on demand
   bool arena_tried = false;
@@ -104,6 +105,8 @@ struct pa_csr {
   bool compact = false;
   int32_t *d_crp = nullptr;        // (compacted) row pointer, 0-based
   int32_t *d_col = nullptr;        // 0-based columns, padded
+  int32_t *d_raw_col = nullptr;    // every stored entry's column (kept on request while d_col holds a compacted stream:
+                                   // pa_ctx_keep_raw_columns; what pa_csr_select_rows reads), or NULL
   double *d_val = nullptr;         // padded
   int32_t *d_chunk_row = nullptr;  // n_chunks+1 row boundaries of the row split
   int32_t *d_row_ids = nullptr;    // compacted row -> row, or NULL

@@ -1,0 +1,415 @@
+// pa_rowsel.hip -- blocks made of SOME ROWS of a part's split matrix, built on the device from the blocks already in HBM
+// ("the colour split as kernels over the uploaded CSR").
+//
+// The multigrid set-up of the HPCG driver needs, per level, nine row subsets of the level's matrix: the eight colours of
+// the multicolour Gauss-Seidel smoother (the sweep of PartitionedSolvers/src/smoothers.jl:98-176 written as SpMV + update)
+// and the fine rows the coarse grid keeps (the residual that restrict! reads, HPCG/src/mg_preconditioner.jl:224-251,314-329).
+// Each is an n_own x n_local block in the UNSPLIT column order HPCG stores (own columns, then ghost columns shifted by the
+// number of own columns) whose other rows are empty.  Until round 3 the host copied the rows (pa_host_color_split) and every
+// subset went over PCIe again: 6 GB for a 256^3 part, 1.7 of the 3.4 s of pc_setup.  Here the part's own|own and own|ghost
+// blocks keep their raw Int32 columns in HBM while the set-up lasts (pa_ctx_keep_raw_columns), and a subset is
+//     lengths of the selected rows -> exclusive scan -> one lane per row copies its entries (own block first, then ghost)
+// handed to the same block constructor as an uploaded matrix (pa_csr_from_device: row split and column encodings on the
+// device).  Entry order inside a row = the host route's, so the blocks are the host route's, array for array
+// (tests/test_gpu_parity.py::test_device_side_row_subsets_equal_the_host_route).
+#include "pa_dev_util.h"
+
+#include <chrono>
+
+#include "pa_setup.h"
+
+using namespace pa_util;
+
+// per row of the (possibly row-compacted) block: where its entries start and how many there are
+__global__ void kr_spans(const int32_t *__restrict__ crp, const int32_t *__restrict__ row_ids, int nc, int32_t *__restrict__ start,
+                         int32_t *__restrict__ len) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const int r = row_ids ? row_ids[c] : c;
+  start[r] = crp[c];
+  len[r] = crp[c + 1] - crp[c];
+}
+
+// stored entries of every subset (64-bit: the sum over a subset must be checked against Int32 row pointers, not wrap)
+__global__ void kr_totals(const int32_t *__restrict__ mask, const int32_t *__restrict__ len_a, const int32_t *__restrict__ len_b, int n,
+                          int n_sel, unsigned long long *__restrict__ tot) {
+  __shared__ unsigned long long h[64];
+  if (threadIdx.x < 64) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) {
+    const int k = mask[r];
+    if (k >= 0 && k < n_sel) atomicAdd(&h[k], (unsigned long long)(len_a[r] + (len_b ? len_b[r] : 0)));
+  }
+  __syncthreads();
+  if (threadIdx.x < n_sel && h[threadIdx.x]) atomicAdd(&tot[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void kr_bad_mask(const int32_t *__restrict__ mask, int n, int n_sel, int *__restrict__ bad) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && (mask[r] < -1 || mask[r] >= n_sel)) *bad = 1;
+}
+
+__global__ void kr_len(const int32_t *__restrict__ mask, int k, const int32_t *__restrict__ len_a, const int32_t *__restrict__ len_b,
+                       int n, int32_t *__restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  out[r] = (r < n && mask[r] == k) ? len_a[r] + (len_b ? len_b[r] : 0) : 0;
+}
+
+// 8 lanes per selected row: lane j copies entries j, j + 8, ... (the own block's, then the ghost block's shifted)
+__global__ void kr_fill(const int32_t *__restrict__ mask, int k, int n, const int32_t *__restrict__ rp_out,
+                        const int32_t *__restrict__ start_a, const int32_t *__restrict__ len_a, const int32_t *__restrict__ col_a,
+                        const double *__restrict__ val_a, const int32_t *__restrict__ start_b, const int32_t *__restrict__ len_b,
+                        const int32_t *__restrict__ col_b, const double *__restrict__ val_b, int shift_b, int32_t *__restrict__ col_out,
+                        double *__restrict__ val_out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = (int)(t >> 3), j = (int)(t & 7);
+  if (r >= n || mask[r] != k) return;
+  const int dst = rp_out[r], la = len_a[r], sa = start_a[r];
+  for (int e = j; e < la; e += 8) {
+    col_out[dst + e] = col_a[sa + e];
+    val_out[dst + e] = val_a[sa + e];
+  }
+  if (len_b) {
+    const int lb = len_b[r], sb = start_b[r];
+    for (int e = j; e < lb; e += 8) {
+      col_out[dst + la + e] = col_b[sb + e] + shift_b;
+      val_out[dst + la + e] = val_b[sb + e];
+    }
+  }
+}
+
+__global__ void kr_flag(const int32_t *__restrict__ len, int n, int32_t *__restrict__ flag) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r <= n) flag[r] = r < n && len[r] > 0;
+}
+
+// the non-empty rows of a subset, in order: their ids and their row pointer (csr_fill_slab's compaction, on the device)
+__global__ void kr_compact(const int32_t *__restrict__ len, const int32_t *__restrict__ pos, const int32_t *__restrict__ rp, int n,
+                           int32_t *__restrict__ row_ids, int32_t *__restrict__ crp) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  if (r == n) { crp[pos[n]] = rp[n]; return; }
+  if (len[r] > 0) {
+    row_ids[pos[r]] = r;
+    crp[pos[r]] = rp[r];
+  }
+}
+
+__global__ void kr_diag(const int32_t *__restrict__ start, const int32_t *__restrict__ len, const int32_t *__restrict__ col,
+                        const double *__restrict__ val, int n, double *__restrict__ d) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double v = 0.0;
+  for (int p = start[r], e = p + len[r]; p < e; ++p)
+    if (col[p] == r) v = val[p];                       // (pa_host_color_split: the last stored (r,r) entry)
+  d[r] = v;
+}
+
+static const int32_t *raw_columns(const pa_csr *A) {
+  if (A->d_raw_col) return A->d_raw_col;
+  return A->n_col32 == A->nnz ? A->d_col : nullptr;    // (a block without compacted streams holds them all anyway)
+}
+
+extern "C" int pa_ctx_keep_raw_columns(pa_ctx *c, int on) {
+  PA_REQUIRE(c != nullptr, "ctx is NULL");
+  c->keep_raw_columns = on != 0;
+  return PA_OK;
+}
+
+extern "C" int pa_csr_has_raw_columns(const pa_csr *A, int *yes) {
+  PA_REQUIRE(A && yes, "bad arguments");
+  *yes = !A->next && (A->nnz == 0 || raw_columns(A) != nullptr);
+  return PA_OK;
+}
+
+extern "C" int pa_csr_drop_raw_columns(pa_csr *A) {
+  PA_REQUIRE(A != nullptr, "block is NULL");
+  for (pa_csr *S = A; S; S = S->next)
+    if (S->d_raw_col) {
+      PA_HIP(hipSetDevice(S->ctx->device));
+      PA_HIP(hipStreamSynchronize(S->ctx->s[0]));
+      pa_dev_free(S->ctx, S->d_raw_col);
+      S->d_raw_col = nullptr;
+    }
+  return PA_OK;
+}
+
+struct row_spans {
+  int32_t *start = nullptr, *len = nullptr;
+};
+
+static int spans_of(pa_ctx *c, scratch &sc, const pa_csr *A, int64_t n, row_spans &S) {
+  PA_TRY(sc.get(&S.start, (size_t)n + 1));
+  PA_TRY(sc.get(&S.len, (size_t)n + 1));
+  PA_HIP(hipMemsetAsync(S.start, 0, sizeof(int32_t) * (n + 1), c->s[0]));
+  PA_HIP(hipMemsetAsync(S.len, 0, sizeof(int32_t) * (n + 1), c->s[0]));
+  if (A->n_crows > 0)
+    hipLaunchKernelGGL(kr_spans, grid1(A->n_crows), dim3(256), 0, c->s[0], A->d_crp, A->d_row_ids, (int)A->n_crows, S.start, S.len);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+// out[k] (k = 0..n_sel-1) = the rows r of the part with mask[r] == k (mask: n_rows host entries in -1..n_sel-1; -1 = in no
+// block), columns: oo's, then oh's shifted by oo's column count.  oh may be NULL (a part without ghost columns).
+extern "C" int pa_csr_select_rows(const pa_csr *oo, const pa_csr *oh, const int32_t *mask, int32_t n_sel, pa_csr **out) {
+  PA_REQUIRE(oo && mask && out && n_sel > 0 && n_sel <= 64, "bad arguments");
+  PA_REQUIRE(!oo->next && !(oh && oh->next), "a block of 2^31 stored entries or more (a chain of slabs) takes the host route");
+  PA_REQUIRE(!oh || (oh->n_rows == oo->n_rows && oh->ctx == oo->ctx), "the own|ghost block does not match the own|own block");
+  pa_ctx *c = oo->ctx;
+  if (oh && oh->nnz == 0) oh = nullptr;
+  const int32_t *col_a = raw_columns(oo), *col_b = oh ? raw_columns(oh) : nullptr;
+  PA_REQUIRE(oo->nnz == 0 || col_a, "the own|own block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
+  PA_REQUIRE(!oh || col_b, "the own|ghost block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
+  const int64_t n = oo->n_rows, n_cols = oo->n_cols + (oh ? oh->n_cols : 0);
+  PA_REQUIRE(oo->nnz + (oh ? oh->nnz : 0) < (int64_t)2147483000 && n_cols < (int64_t)2147483000, "too large for Int32 offsets");
+  for (int k = 0; k < n_sel; ++k) out[k] = nullptr;
+  const auto t_begin = std::chrono::steady_clock::now();
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  scratch sc;
+  row_spans A, B;
+  PA_TRY(spans_of(c, sc, oo, n, A));
+  if (oh) PA_TRY(spans_of(c, sc, oh, n, B));
+  int32_t *d_mask = nullptr, *d_len = nullptr, *d_rp = nullptr, *d_flag = nullptr, *d_pos = nullptr, *d_ids = nullptr, *d_crp = nullptr;
+  int *d_bad = nullptr;
+  unsigned long long *d_tot = nullptr;
+  PA_TRY(sc.get(&d_mask, (size_t)n + 1));
+  PA_TRY(sc.get(&d_len, (size_t)n + 1));
+  PA_TRY(sc.get(&d_rp, (size_t)n + 1));
+  PA_TRY(sc.get(&d_flag, (size_t)n + 1));
+  PA_TRY(sc.get(&d_pos, (size_t)n + 1));
+  PA_TRY(sc.get(&d_ids, (size_t)n + 1));
+  PA_TRY(sc.get(&d_crp, (size_t)n + 1));
+  PA_TRY(sc.get(&d_bad, 1));
+  PA_TRY(sc.get(&d_tot, 64));
+  PA_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+  PA_HIP(hipMemsetAsync(d_tot, 0, sizeof(unsigned long long) * 64, s));
+  if (n) PA_HIP(hipMemcpyAsync(d_mask, mask, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+  if (n) {
+    hipLaunchKernelGGL(kr_bad_mask, grid1(n), dim3(256), 0, s, d_mask, (int)n, (int)n_sel, d_bad);
+    hipLaunchKernelGGL(kr_totals, grid1(n), dim3(256), 0, s, d_mask, A.len, oh ? B.len : nullptr, (int)n, (int)n_sel, d_tot);
+  }
+  int bad = 0;
+  unsigned long long tot[64];
+  PA_TRY(d2h(s, &bad, d_bad, 1));
+  PA_TRY(d2h(s, tot, d_tot, 64));
+  PA_REQUIRE(!bad, "a mask entry outside -1..n_sel-1");
+  unsigned long long most = 0;
+  for (int k = 0; k < n_sel; ++k) most = std::max(most, tot[k]);
+  PA_REQUIRE(most < 2147483000ull, "a row subset holds more entries than Int32 row pointers address");
+  // one pair of output buffers for all subsets (from the arena: no driver-side wipe per subset)
+  int32_t *d_col = nullptr;
+  double *d_val = nullptr;
+  PA_TRY(pa_dev_alloc(c, (void **)&d_col, sizeof(int32_t) * (most + 8), PA_MEM_MATRIX));
+  int st = pa_dev_alloc(c, (void **)&d_val, sizeof(double) * (most + 8), PA_MEM_MATRIX);
+  for (int k = 0; k < n_sel && st == PA_OK; ++k) {
+    hipLaunchKernelGGL(kr_len, grid1(n + 1), dim3(256), 0, s, d_mask, k, A.len, oh ? B.len : nullptr, (int)n, d_len);
+    st = scan_exclusive(sc, s, d_len, d_rp, (size_t)n + 1);
+    if (st != PA_OK) break;
+    if (tot[k])
+      hipLaunchKernelGGL(kr_fill, grid1(n * 8), dim3(256), 0, s, d_mask, k, (int)n, d_rp, A.start, A.len, col_a, oo->d_val,
+                         oh ? B.start : nullptr, oh ? B.len : nullptr, col_b, oh ? oh->d_val : nullptr, (int)oo->n_cols, d_col, d_val);
+    // non-empty rows counted, and compacted when most rows are empty (csr_fill_slab's rule), here: the host gets the final
+    // row pointer only (a colour of the 256^3 operator: 8 MB instead of 67, and no passes over 16.8 M rows)
+    hipLaunchKernelGGL(kr_flag, grid1(n + 1), dim3(256), 0, s, d_len, (int)n, d_flag);
+    st = scan_exclusive(sc, s, d_flag, d_pos, (size_t)n + 1);
+    if (st != PA_OK) break;
+    int32_t n_nonempty = 0;
+    st = d2h(s, &n_nonempty, d_pos + n, 1);
+    if (st != PA_OK) break;
+    const bool compact = n > 0 && (int64_t)n_nonempty * 2 < n;
+    std::vector<int32_t> crp((size_t)(compact ? n_nonempty : n) + 1);
+    if (compact) {
+      hipLaunchKernelGGL(kr_compact, grid1(n + 1), dim3(256), 0, s, d_len, d_pos, d_rp, (int)n, d_ids, d_crp);
+      st = d2h(s, crp.data(), d_crp, crp.size());
+    } else st = d2h(s, crp.data(), d_rp, crp.size());
+    if (st != PA_OK || hipGetLastError() != hipSuccess) { st = PA_ERR_HIP; break; }
+    st = pa_csr_from_device_rows(c, n, n_cols, (int64_t)tot[k], n_nonempty, crp, compact ? d_ids : nullptr, d_col, d_val, &out[k]);
+  }
+  (void)hipStreamSynchronize(s);
+  if (getenv("PA_SETUP_TIMING"))
+    fprintf(stderr, "[pa setup] %d row subset(s) of a %lld-row part on the device: %.3f s\n", (int)n_sel, (long long)n,
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count());
+  pa_dev_free(c, d_col);
+  if (d_val) pa_dev_free(c, d_val);
+  if (st != PA_OK)
+    for (int k = 0; k < n_sel; ++k)
+      if (out[k]) { pa_csr_destroy(out[k]); out[k] = nullptr; }
+  return st;
+}
+
+// d[r] = the stored (r,r) entry of the own|own block (0.0 when the row holds none): the smoother's diagonal
+extern "C" int pa_csr_diagonal(const pa_csr *oo, pa_vec *d) {
+  PA_REQUIRE(oo && d && !oo->next, "bad arguments");
+  PA_REQUIRE(d->n_own + d->n_ghost >= oo->n_rows, "the vector is shorter than the block has rows");
+  const int32_t *col = raw_columns(oo);
+  PA_REQUIRE(oo->nnz == 0 || col, "the block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
+  pa_ctx *c = oo->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  scratch sc;
+  row_spans A;
+  PA_TRY(spans_of(c, sc, oo, oo->n_rows, A));
+  if (oo->n_rows) hipLaunchKernelGGL(kr_diag, grid1(oo->n_rows), dim3(256), 0, c->s[0], A.start, A.len, col, oo->d_val, (int)oo->n_rows, d->d);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The level-scheduled Gauss-Seidel smoother (pa_gs, pa_device.hip) from the blocks already in HBM: the unsplit local CSR by
+// the kernels above (one subset: every row), the diagonal, and the dependency levels of the sequential sweep
+// (PartitionedSolvers/src/smoothers.jl:144-160: row i needs every own column j < i) by rounds over the rows whose lower
+// neighbours are all done -- level(i) = 1 + max level(j), the same numbers as pa_gs_create's loop over the rows in order.
+// A round finds the rows it frees through the UPPER entries of the rows it finishes, which is right when the own|own pattern
+// is structurally symmetric (what pa_gs_create demands anyway); the result is verified entry by entry against the definition
+// and the caller takes the host route when it does not hold.
+// ------------------------------------------------------------------------------------------------
+__global__ void kg_lower_count(const int32_t *__restrict__ start, const int32_t *__restrict__ len, const int32_t *__restrict__ col, int n,
+                               int32_t *__restrict__ cnt) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int k = 0;
+  for (int p = start[r], e = p + len[r]; p < e; ++p) k += col[p] < r;
+  cnt[r] = k;
+}
+
+__global__ void kg_first(const int32_t *__restrict__ cnt, int n, int32_t *__restrict__ frontier, int *__restrict__ count) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n && cnt[r] == 0) frontier[atomicAdd(count, 1)] = r;
+}
+
+__global__ void kg_round(const int32_t *__restrict__ frontier, int size, int lv, const int32_t *__restrict__ start,
+                         const int32_t *__restrict__ len, const int32_t *__restrict__ col, int n, int32_t *__restrict__ level,
+                         int32_t *__restrict__ cnt, int32_t *__restrict__ next, int *__restrict__ next_count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, lane = t & 7;
+  if (i >= size) return;
+  const int r = frontier[i];
+  if (lane == 0) level[r] = lv;
+  for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += 8) {
+    const int j = col[p];
+    if (j > r && j < n && atomicSub(&cnt[j], 1) == 1) next[atomicAdd(next_count, 1)] = j;
+  }
+}
+
+// level(r) == 1 + max level(own j < r) (0 without such an entry), every own j > r is swept later, the diagonal is there
+__global__ void kg_verify(const int32_t *__restrict__ start, const int32_t *__restrict__ len, const int32_t *__restrict__ col,
+                          const double *__restrict__ diag, const int32_t *__restrict__ level, int n, int *__restrict__ bad) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  int want = 0;
+  bool has_diag = false, ok = true;
+  for (int p = start[r], e = p + len[r]; p < e; ++p) {
+    const int j = col[p];
+    if (j == r) has_diag = true;
+    if (j < r) want = max(want, level[j] + 1);
+    if (j > r && j < n && level[j] <= level[r]) ok = false;
+  }
+  if (!ok || want != level[r]) atomicOr(bad, 1);
+  if (!has_diag || diag[r] == 0.0) atomicOr(bad, 2);
+}
+
+__global__ void kg_iota(int32_t *__restrict__ v, int n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) v[r] = r;
+}
+
+extern "C" int pa_gs_create_from_blocks(const pa_csr *oo, const pa_csr *oh, int ordering, pa_gs **out) {
+  PA_REQUIRE(oo && out, "bad arguments");
+  PA_REQUIRE(ordering == PA_GS_SEQUENTIAL, "the device route builds the sequential ordering only");
+  PA_REQUIRE(!oo->next && !(oh && oh->next), "a block of 2^31 stored entries or more (a chain of slabs) takes the host route");
+  PA_REQUIRE(!oh || (oh->n_rows == oo->n_rows && oh->ctx == oo->ctx), "the own|ghost block does not match the own|own block");
+  PA_REQUIRE(oo->n_rows == oo->n_cols, "the own|own block is not square");
+  pa_ctx *c = oo->ctx;
+  if (oh && oh->nnz == 0) oh = nullptr;
+  const int32_t *col_a = raw_columns(oo), *col_b = oh ? raw_columns(oh) : nullptr;
+  PA_REQUIRE(oo->nnz == 0 || col_a, "the own|own block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
+  PA_REQUIRE(!oh || col_b, "the own|ghost block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
+  const int64_t n = oo->n_rows, n_local = oo->n_cols + (oh ? oh->n_cols : 0), nnz = oo->nnz + (oh ? oh->nnz : 0);
+  PA_REQUIRE(nnz < (int64_t)2147483000 && n_local < (int64_t)2147483000, "too large for Int32 offsets");
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  scratch sc;
+  row_spans A, B;
+  PA_TRY(spans_of(c, sc, oo, n, A));
+  if (oh) PA_TRY(spans_of(c, sc, oh, n, B));
+  int32_t *d_mask = nullptr, *d_len = nullptr, *d_cnt = nullptr, *d_level = nullptr, *d_f0 = nullptr, *d_f1 = nullptr, *d_iota = nullptr,
+          *d_lsorted = nullptr;
+  int *d_count = nullptr;
+  PA_TRY(sc.get(&d_mask, (size_t)n + 1));
+  PA_TRY(sc.get(&d_len, (size_t)n + 1));
+  PA_TRY(sc.get(&d_cnt, (size_t)n + 1));
+  PA_TRY(sc.get(&d_level, (size_t)n + 1));
+  PA_TRY(sc.get(&d_f0, (size_t)n + 1));
+  PA_TRY(sc.get(&d_f1, (size_t)n + 1));
+  PA_TRY(sc.get(&d_iota, (size_t)n + 1));
+  PA_TRY(sc.get(&d_lsorted, (size_t)n + 1));
+  PA_TRY(sc.get(&d_count, 4));
+  pa_gs *g = new pa_gs();
+  g->ctx = c; g->n_own = n; g->n_local = n_local; g->nnz = nnz;
+  auto fail = [&](int st) { pa_gs_destroy(g); return st; };
+#define PA_G(call) do { if ((call) != hipSuccess) { pa_set_err("HIP error in %s: %s", #call, hipGetErrorString(hipGetLastError())); return fail(PA_ERR_HIP); } } while (0)
+#define PA_GT(call) do { const int st_ = (call); if (st_ != PA_OK) return fail(st_); } while (0)
+  PA_G(pa_raw_malloc(&g->d_rowptr, sizeof(int32_t) * (n + 1)));
+  PA_G(pa_raw_malloc(&g->d_col, sizeof(int32_t) * std::max<int64_t>(1, nnz)));
+  PA_G(pa_raw_malloc(&g->d_val, sizeof(double) * std::max<int64_t>(1, nnz)));
+  PA_G(pa_raw_malloc(&g->d_diag, sizeof(double) * std::max<int64_t>(1, n)));
+  PA_G(pa_raw_malloc(&g->d_rows, sizeof(int32_t) * std::max<int64_t>(1, n)));
+  // the unsplit CSR: every row, own entries then ghost entries shifted
+  PA_G(hipMemsetAsync(d_mask, 0, sizeof(int32_t) * (n + 1), s));
+  hipLaunchKernelGGL(kr_len, grid1(n + 1), dim3(256), 0, s, d_mask, 0, A.len, oh ? B.len : nullptr, (int)n, d_len);
+  PA_GT(scan_exclusive(sc, s, d_len, g->d_rowptr, (size_t)n + 1));
+  if (nnz)
+    hipLaunchKernelGGL(kr_fill, grid1(n * 8), dim3(256), 0, s, d_mask, 0, (int)n, g->d_rowptr, A.start, A.len, col_a, oo->d_val,
+                       oh ? B.start : nullptr, oh ? B.len : nullptr, col_b, oh ? oh->d_val : nullptr, (int)oo->n_cols, g->d_col, g->d_val);
+  if (n) hipLaunchKernelGGL(kr_diag, grid1(n), dim3(256), 0, s, A.start, A.len, col_a, oo->d_val, (int)n, g->d_diag);
+  // dependency levels by rounds
+  if (n) hipLaunchKernelGGL(kg_lower_count, grid1(n), dim3(256), 0, s, A.start, A.len, col_a, (int)n, d_cnt);
+  PA_G(hipMemsetAsync(d_count, 0, sizeof(int) * 4, s));
+  PA_G(hipMemsetAsync(d_level, 0xFF, sizeof(int32_t) * (n + 1), s));                        // -1: not reached
+  if (n) hipLaunchKernelGGL(kg_first, grid1(n), dim3(256), 0, s, d_cnt, (int)n, d_f0, d_count);
+  g->lev_ptr.assign(1, 0);
+  int64_t done = 0;
+  int size = 0, which = 0;
+  PA_GT(d2h(s, &size, d_count, 1));
+  while (size > 0) {
+    int32_t *cur = which ? d_f1 : d_f0, *nxt = which ? d_f0 : d_f1;
+    int *cnt_next = d_count + 1 + (which ^ 1) % 2;            // (two counters, used in turn)
+    PA_G(hipMemsetAsync(cnt_next, 0, sizeof(int), s));
+    hipLaunchKernelGGL(kg_round, grid1((int64_t)size * 8), dim3(256), 0, s, cur, size, (int)g->lev_ptr.size() - 1, A.start, A.len, col_a,
+                       (int)n, d_level, d_cnt, nxt, cnt_next);
+    done += size;
+    g->max_level_rows = std::max<int64_t>(g->max_level_rows, size);
+    g->lev_ptr.push_back((int32_t)done);
+    PA_GT(d2h(s, &size, cnt_next, 1));
+    which ^= 1;
+    if (done + size > n) break;                               // (more rows freed than there are: the pattern is not what the rounds assume)
+  }
+  int bad = done == n ? 0 : 1;
+  if (!bad && n) {
+    int *d_bad = d_count + 3;
+    PA_G(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+    hipLaunchKernelGGL(kg_verify, grid1(n), dim3(256), 0, s, A.start, A.len, col_a, g->d_diag, d_level, (int)n, d_bad);
+    PA_GT(d2h(s, &bad, d_bad, 1));
+  }
+  if (bad) {
+    pa_set_err(bad & 2 ? "a row has no (non-zero) diagonal entry"
+                       : "own x own pattern is not structurally symmetric: the rounds do not reproduce the sequential sweep's levels");
+    return fail(PA_ERR_ARG);
+  }
+  // rows by level, ascending inside a level (stable sort of the row ids by level)
+  if (n) {
+    hipLaunchKernelGGL(kg_iota, grid1(n), dim3(256), 0, s, d_iota, (int)n);
+    unsigned bits = 1;
+    while (((int64_t)1 << bits) < (int64_t)g->lev_ptr.size()) ++bits;
+    PA_GT(sort_pairs(sc, s, d_level, d_lsorted, d_iota, g->d_rows, (size_t)n, bits));
+  }
+  PA_G(hipGetLastError());
+  PA_G(hipStreamSynchronize(s));
+#undef PA_G
+#undef PA_GT
+  *out = g;
+  return PA_OK;
+}

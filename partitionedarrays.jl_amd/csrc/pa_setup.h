@@ -45,6 +45,11 @@ int pa_dev_xw_chunk_stats(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col,
 int pa_csr_from_device(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_col,
                        const double *d_val, pa_csr **out);
 
+// the same from rows the caller counted (and, when most are empty, compacted: d_row_ids) on the device; crp = the final row
+// pointer on the host (n_nonempty + 1 entries with d_row_ids, n_rows + 1 without; moved from).  One slab only.
+int pa_csr_from_device_rows(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t n_nonempty, std::vector<int32_t> &crp,
+                            const int32_t *d_row_ids, const int32_t *d_col, const double *d_val, pa_csr **out);
+
 // min / max of a device Int32 array (column range check of an uploaded block)
 int pa_dev_minmax_i32(pa_ctx *c, const int32_t *d, int64_t n, int32_t *mn, int32_t *mx);
 

@@ -103,12 +103,14 @@ def build_split_blocks_fused(my_rows, nx, ny, nz, gnx, gny, gnz):
     return cols, oo, oh, b
 
 
-def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=False, fused=None):
+def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=False, fused=None, keep_raw=False):
     """HPCG build_p_matrix (HPCG/src/sparse_matrix.jl:105-122) -> A (device PSparseMatrix), b (PVector).
 
     fused=False: the reference's chain, step by step (build_matrix -> find_owner -> union_ghost -> psparse).
     fused=True : the same arrays produced by the fused native generator (no COO triplets in host memory);
-                 default for parts of >= 2^18 rows.  tests/test_host_setup.py pins fused == chain == oracle."""
+                 default for parts of >= 2^18 rows.  tests/test_host_setup.py pins fused == chain == oracle.
+    keep_raw=True: the blocks keep their raw Int32 columns in HBM (pa_ctx_keep_raw_columns) so that row subsets can be cut
+                 from them on the device (the multigrid set-up, hpcg.pc_setup); drop them with DeviceCSR.drop_raw_columns()."""
     from .p_sparse_matrix import PSparseMatrix, SplitMatrixBlocks, DeviceCSR
     from .p_vector import PVector, DeviceVector
     row_partition = uniform_partition(ranks, (npx, npy, npz), (gnx, gny, gnz))
@@ -117,7 +119,14 @@ def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=Fa
     if fused:
         def one(my_rows):
             cols, oo, oh, b = build_split_blocks_fused(my_rows, nx, ny, nz, gnx, gny, gnz)
-            blk = SplitMatrixBlocks(DeviceCSR(oo), DeviceCSR(oh))
+            if keep_raw:
+                from .p_vector import context
+                L.call("pa_ctx_keep_raw_columns", context().h, 1)
+            try:
+                blk = SplitMatrixBlocks(DeviceCSR(oo), DeviceCSR(oh))
+            finally:
+                if keep_raw:
+                    L.call("pa_ctx_keep_raw_columns", context().h, 0)
             v = DeviceVector(cols.n_own, cols.n_ghost)
             v.upload(b, 0)
             return cols, blk, v, ((oo, oh) if keep_host else None)

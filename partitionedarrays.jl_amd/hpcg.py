@@ -8,6 +8,7 @@ broadcasts, all on device-resident PVectors.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -62,15 +63,22 @@ class GaussSeidel:
             raise L.PAError("the Gauss-Seidel smoother needs the host blocks: build the matrix with keep_host=True")
         self.A = A
 
-        def make(h, r, c):
+        def make(h, r, c, dev):
+            g = C.c_void_p()
+            if ordering == "sequential" and dev.own_own.has_raw_columns() and dev.own_ghost.has_raw_columns():
+                # the unsplit CSR, the diagonal and the dependency levels from the blocks already in HBM (csrc/pa_rowsel.hip)
+                try:
+                    L.call("pa_gs_create_from_blocks", dev.own_own.h, dev.own_ghost.h, 0, C.byref(g))
+                    return g
+                except L.PAError:
+                    g = C.c_void_p()                       # (the host loop below states what is wrong with the pattern)
             rowptr, colv, val, _ = _unsplit_csr(h, r, c)   # the storage HPCG uses (split_format=false)
             n = r.n_own
-            g = C.c_void_p()
             L.call("pa_gs_create", context().h, n, c.n_local, len(val), L.ptr(rowptr), L.ptr(colv), L.ptr(val), 1,
                    {"sequential": 0, "multicolor": 1}[ordering], C.byref(g))
             return g
 
-        self.gs = pmap(make, A.host_blocks, A.row_partition, A.col_partition)
+        self.gs = pmap(make, A.host_blocks, A.row_partition, A.col_partition, A.matrix_partition)
 
     def info(self):
         def f(g):
@@ -142,7 +150,7 @@ class ColoredGaussSeidelSpMV:
         self.A = A
         self.ordering = "multicolor_spmv"
 
-        def make(h, r, c):
+        def make(h, r, c, dev):
             oo, oh = h
             n = r.n_own
             color = np.zeros(n, np.int32)
@@ -150,6 +158,14 @@ class ColoredGaussSeidelSpMV:
             # rows of one colour must not be coupled: the own x own block holds every coupling between own rows
             L.call("pa_host_greedy_coloring", n, L.ptr(oo.rowptr), L.ptr(oo.colval), 1, L.ptr(color), C.byref(ncol))
             K = ncol.value
+            if dev.own_own.has_raw_columns() and dev.own_ghost.has_raw_columns():
+                # the colours' rows are cut from the blocks already in HBM (csrc/pa_rowsel.hip): no host copy of the entries,
+                # no second trip over PCIe
+                blocks = DeviceCSR.select_rows(dev.own_own, dev.own_ghost, color, K)
+                d = DeviceVector(n, 0)
+                L.call("pa_csr_diagonal", dev.own_own.h, d.h)
+                handles = (C.c_void_p * len(blocks))(*[blk.h for blk in blocks])
+                return blocks, d, handles, color
             arr = lambda xs: (C.c_void_p * K)(*[x.ctypes.data for x in xs])
             rps = [np.empty(n + 1, np.int32) for _ in range(K)]                  # (one native, threaded pass for all colours)
             L.call("pa_host_color_rowptrs", n, L.ptr(oo.rowptr), L.ptr(oh.rowptr), L.ptr(color), K, arr(rps))
@@ -165,7 +181,7 @@ class ColoredGaussSeidelSpMV:
             handles = (C.c_void_p * len(blocks))(*[blk.h for blk in blocks])
             return blocks, DeviceVector(n, 0).upload(diag), handles, color
 
-        self.parts = pmap(make, A.host_blocks, A.row_partition, A.col_partition)
+        self.parts = pmap(make, A.host_blocks, A.row_partition, A.col_partition, A.matrix_partition)
 
     def info(self):
         return pmap(lambda p: dict(levels=len(p[0]), max_rows_per_level=0), self.parts)
@@ -205,14 +221,19 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
     rbs = [None] * (l - 1)
     if ordering != "sequential":                      # (the colour updates read b, d, x and write x: two vector classes, csrc/pa_arena.hip)
         try:
-            context().arena_hint(2)
+            context().arena_hint(int(os.environ.get("PA_MG_VECTOR_CLASSES", "2")))
         except Exception:                             # noqa: BLE001  (no GPU: the host-side pieces still build)
             pass
     from .gallery import build_p_matrix, compute_optimal_shape_XYZ
     npx, npy, npz = compute_optimal_shape_XYZ(np_)
     f2c, As, gss, rs, xs, Axfs = [None] * (l - 1), [None] * l, [None] * l, [None] * l, [None] * l, [None] * l
     for lev in range(l, 0, -1):
-        A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=True, fused=True)
+        # (the level's blocks keep their raw columns in HBM while the smoother -- the colours' rows, or the unsplit CSR and
+        #  the dependency levels of the sequential sweep -- and the restriction's rows are made from them on the device,
+        #  csrc/pa_rowsel.hip; PA_SETUP_ROWSEL=0: the host copies them)
+        keep_raw = ordering in ("multicolor_spmv", "sequential") and os.environ.get("PA_SETUP_ROWSEL", "1") != "0"
+        A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=True, fused=True,
+                              keep_raw=keep_raw)
         As[lev - 1], rs[lev - 1] = A, b
         gss[lev - 1] = ColoredGaussSeidelSpMV(A) if ordering == "multicolor_spmv" else GaussSeidel(A, ordering)
         xs[lev - 1], Axfs[lev - 1] = pzeros(A.col_partition), pzeros(A.col_partition)
@@ -226,11 +247,18 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
             f2c[lev - 2] = pmap(mk, A.row_partition)
             if fuse_restriction:
                 from .p_sparse_matrix import DeviceCSR
-                blk = pmap(lambda hb, r, c: DeviceCSR(_rows_block(hb, r, c, op.astype(np.int64) - 1)),
-                           A.host_blocks, A.row_partition, A.col_partition)
+                def rows_block(hb, r, c, dev):
+                    if dev.own_own.has_raw_columns() and dev.own_ghost.has_raw_columns():
+                        mask = np.full(r.n_own, -1, np.int32)
+                        mask[op.astype(np.int64) - 1] = 0
+                        return DeviceCSR.select_rows(dev.own_own, dev.own_ghost, mask, 1)[0]
+                    return DeviceCSR(_rows_block(hb, r, c, op.astype(np.int64) - 1))
+                blk = pmap(rows_block, A.host_blocks, A.row_partition, A.col_partition, A.matrix_partition)
                 pmap(lambda t, bk: L.call("pa_transfer_attach_rows", t, bk.h), f2c[lev - 2], blk)
                 rbs[lev - 2] = blk
             nx, ny, nz = nx // 2, ny // 2, nz // 2
+        if keep_raw:
+            pmap(lambda dev: (dev.own_own.drop_raw_columns(), dev.own_ghost.drop_raw_columns()), A.matrix_partition)
     from .primitives import DebugArray
     one_part = isinstance(ranks, DebugArray) and len(ranks.items) == 1
     return MgPreconditioner(f2c, As, gss, rs, xs, Axfs, l, rbs, bool(graph) and one_part and ordering == "multicolor_spmv", {})

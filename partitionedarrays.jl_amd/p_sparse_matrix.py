@@ -142,6 +142,33 @@ class DeviceCSR:
         L.call("pa_csr_stream_bytes", self.h, C.byref(n))
         return n.value
 
+    def has_raw_columns(self):
+        """True when row subsets can be cut from this block on the device (pa_csr_select_rows): it kept its raw Int32
+        columns (created under pa_ctx_keep_raw_columns) or never compacted them."""
+        n = C.c_int()
+        L.call("pa_csr_has_raw_columns", self.h, C.byref(n))
+        return bool(n.value)
+
+    def drop_raw_columns(self):
+        L.call("pa_csr_drop_raw_columns", self.h)
+
+    @staticmethod
+    def select_rows(own_own, own_ghost, mask, n_sel):
+        """pa_csr_select_rows: the n_sel blocks made of the rows r with mask[r] == k of own_own | own_ghost (unsplit column
+        order), built on the device."""
+        mask = np.ascontiguousarray(mask, np.int32)
+        if mask.shape[0] != own_own.m:
+            raise L.PAError("one mask entry per row")
+        out = (C.c_void_p * n_sel)()
+        L.call("pa_csr_select_rows", own_own.h, own_ghost.h if own_ghost is not None else None, L.ptr(mask), n_sel, out)
+        blocks = []
+        for k in range(n_sel):
+            v = [C.c_int64() for _ in range(6)]
+            h = C.c_void_p(out[k])
+            L.call("pa_csr_info", h, *[C.byref(x) for x in v])
+            blocks.append(DeviceCSR.from_handle(h, v[0].value, v[1].value, v[2].value, own_own.ctx))
+        return blocks
+
     def memory_class(self):
         """Memory class of the value stream inside the context's arena (pa_csr_memory_class; -1: outside)."""
         n = C.c_int()

@@ -62,6 +62,10 @@ class Context:
         """Announce a solver's worth of vectors (pa_ctx_arena_hint): they alternate between two memory classes of their own."""
         L.call("pa_ctx_arena_hint", self.h, int(vector_classes))
 
+    def arena_release(self):
+        """Hand the extents of an idle arena back to the driver now (pa_ctx_arena_release; it keeps up to 24 GiB otherwise)."""
+        L.call("pa_ctx_arena_release", self.h)
+
     def arena(self, build=False):
         """The context's HBM extents and their memory-class maps (csrc/pa_arena.hip): GiB held, classes met, GiB per class
         in the held extents, GiB in use, time spent acquiring + classifying, the class of every 512 MiB cell as a string

@@ -2067,6 +2067,85 @@ def test_device_side_psparse_equals_the_host_route(orc, monkeypatch):
     monkeypatch.delenv("PA_SETUP_DEVICE")
 
 
+def test_device_side_row_subsets_equal_the_host_route(orc, monkeypatch):
+    """csrc/pa_rowsel.hip: the blocks the multigrid set-up cuts out of a level's matrix -- the colours of the multicolour
+    smoother and the fine rows the coarse grid keeps (HPCG/src/mg_preconditioner.jl:224-251,314-329) -- built on the device
+    from the part's own|own and own|ghost blocks (raw columns kept in HBM) against the host route (pa_host_color_split + an
+    upload, PA_SETUP_ROWSEL=0): every array the product kernel reads, the encodings, the diagonal, and the whole hierarchy
+    through an MG-PCG solve, bit for bit; on 2 parts (ghost columns, row-compacted own|ghost blocks) and on one."""
+    import pa_amd._lib as L
+    for P, n in ((2, (16, 8, 8)), (1, (16, 16, 16))):
+        built = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PA_SETUP_ROWSEL", mode)
+            S = pa.pc_setup(ranks(P), P, 3, *n, ordering="multicolor_spmv")
+            A, b = S.A_vec[-1], S.r[-1]
+            x, r0, r, it = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=12, Pl=S, fuse=True)
+            arrays = []
+            for lev in range(S.l):
+                for part in S.gs_states[lev].parts.items:
+                    arrays.append([(blk.debug_arrays(), blk.info(), blk.encoding(), blk.stream_bytes()) for blk in part[0]]
+                                  + [part[1].download(), part[3]])
+                if lev >= 1:
+                    arrays.append([(q.debug_arrays(), q.info(), q.encoding(), q.stream_bytes()) for q in S.row_blocks[lev - 1].items])
+            built[mode] = (arrays, [v.download() for v in x.vector_partition.items], r0, r, it)
+        d, h = built["1"], built["0"]
+        assert d[2:] == h[2:], (P, d[2:], h[2:])
+        for a, b_ in zip(d[1], h[1]):
+            assert np.array_equal(a, b_)
+        assert len(d[0]) == len(h[0])
+        for ea, eb in zip(d[0], h[0]):
+            assert len(ea) == len(eb)
+            for ia, ib in zip(ea, eb):
+                if isinstance(ia, tuple):
+                    assert ia[1:] == ib[1:], (P, ia[1:], ib[1:])
+                    assert ia[0].keys() == ib[0].keys()
+                    for key in ia[0]:
+                        assert ia[0][key].shape == ib[0][key].shape and np.array_equal(ia[0][key], ib[0][key]), (P, key)
+                else:
+                    assert np.array_equal(ia, ib), P
+    # the reference's smoother (sequential sweep, level-scheduled): unsplit CSR, diagonal and dependency levels made on the
+    # device (pa_gs_create_from_blocks: rounds over the rows whose lower neighbours are done) against pa_gs_create's loop
+    for P, n in ((2, (16, 8, 8)), (1, (16, 16, 16)), (4, (8, 8, 8))):
+        built = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PA_SETUP_ROWSEL", mode)
+            S = pa.pc_setup(ranks(P), P, 3, *n, ordering="sequential")
+            A, b = S.A_vec[-1], S.r[-1]
+            x, r0, r, it = pa.ref_cg_(pa.pzeros(A.col_partition), A, b, maxiter=8, overlap=False, Pl=S)
+            built[mode] = ([g.info().items for g in S.gs_states], [v.download() for v in x.vector_partition.items], r0, r, it)
+        d, h = built["1"], built["0"]
+        assert d[0] == h[0] and d[2:] == h[2:], (P, d[0], h[0], d[2:], h[2:])
+        for a, b_ in zip(d[1], h[1]):
+            assert np.array_equal(a, b_)
+    # the entry points on their own: a block that kept no raw columns, a mask outside -1..n_sel-1, a mask with holes
+    monkeypatch.delenv("PA_SETUP_ROWSEL")
+    Hc = next(iter(_encoding_cases(orc)))[1]
+    blk = pa.DeviceCSR(Hc)
+    if not blk.has_raw_columns():
+        with pytest.raises(pa.PAError, match="raw columns"):
+            pa.DeviceCSR.select_rows(blk, None, np.zeros(Hc.m, np.int32), 1)
+    L.call("pa_ctx_keep_raw_columns", pa.context().h, 1)
+    try:
+        blk = pa.DeviceCSR(Hc)
+    finally:
+        L.call("pa_ctx_keep_raw_columns", pa.context().h, 0)
+    assert blk.has_raw_columns()
+    with pytest.raises(pa.PAError, match="mask entry"):
+        pa.DeviceCSR.select_rows(blk, None, np.full(Hc.m, 3, np.int32), 2)
+    mask = (np.arange(Hc.m) % 3 - 1).astype(np.int32)              # -1, 0, 1, -1, ...
+    subs = pa.DeviceCSR.select_rows(blk, None, mask, 2)
+    xh = np.random.default_rng(5).standard_normal(Hc.n)
+    x = pa.DeviceVector(Hc.n, 0).upload(xh)
+    full = np.zeros(Hc.m)
+    orc.oracle_c().spmv_csr(full, xh, orc.CSR(Hc.m, Hc.n, Hc.rowptr, Hc.colval, Hc.nzval))
+    for k, sub in enumerate(subs):
+        y = pa.DeviceVector(Hc.m, 0)
+        pa.spmv_(y, sub, x)
+        assert np.array_equal(y.download(), np.where(mask == k, full, 0.0)), k
+    blk.drop_raw_columns()
+
+
 @pytest.mark.parametrize("ring", ["1", "2"])
 def test_sliding_x_window_launch_is_bit_identical(orc, monkeypatch, ring):
     """k_spmv_xring (csrc/pa_spmv_xwin.h): runs of consecutive chunks gather x from a ring of 16384 entries that every round
