@@ -151,6 +151,15 @@ int pa_csr_diagonal(const pa_csr *own_own, pa_vec *d);
  * their definition entry by entry.  PA_ERR_ARG when the own|own pattern is not structurally symmetric or a diagonal
  * entry is missing (pa_gs_create's own conditions). */
 int pa_gs_create_from_blocks(const pa_csr *own_own, const pa_csr *own_ghost, int ordering, pa_gs **out);
+/* pa_host_greedy_coloring (below) of the own_own block in HBM: color[r] (host, n_rows entries) = the smallest colour no own
+ * neighbour j < r has, computed by rounds on the device and verified against that definition; PA_ERR_ARG when the pattern
+ * is not structurally symmetric (colour on the host then). */
+int pa_csr_greedy_coloring(const pa_csr *own_own, int32_t *color, int32_t *n_colors);
+/* HPCG's 27-point operator of one part (HPCG/src/sparse_matrix.jl:28-122), own_own block and right-hand side, generated
+ * in HBM: the arrays pa_host_hpcg_split_csr writes (oo_*, b), no host copy, no upload.  nx,ny,nz: the part's box; gnx,gny,gnz:
+ * the global grid; gix0,giy0,giz0: global coordinates (1-based) of the part's first node.  b may be NULL. */
+int pa_hpcg_own_block_create(pa_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz,
+                             int64_t gix0, int64_t giy0, int64_t giz0, pa_csr **own_own, pa_vec *b);
 
 /* testing aid: a host copy of one of the arrays the product kernel reads (first slab of the block) -- 0 row pointers,
  * 1 32-bit columns, 2 16-bit codes, 3 windows, 4 pattern descriptors, 5 pattern table, 6 chunk table, 7 compacted row ids;
@@ -490,6 +499,12 @@ int pa_host_hpcg_split_csr(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int6
                            int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost, int32_t *oo_rowptr,
                            int32_t *oo_colval, double *oo_nzval, int32_t *oh_rowptr, int32_t *oh_colval,
                            double *oh_nzval, double *b);
+
+/* the own_ghost block alone (the same oh_* arrays): for a part whose own_own block and b are generated in HBM
+ * (pa_hpcg_own_block_create); only the rows on the part's surface are visited past the closed-form count */
+int pa_host_hpcg_ghost_block(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                             int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost, int32_t *oh_rowptr,
+                             int32_t *oh_colval, double *oh_nzval);
 
 /* Set-up of the multicolour smoother: the rows of a part (split blocks, 1-based Int32) dealt by colour into n_colors
  * blocks in the unsplit column order (own columns, then ghost columns + n_own_cols), plus the diagonal.  out_rowptr[k]

@@ -101,6 +101,8 @@ _SIGS = {
     "pa_csr_select_rows": [P, P, P, C.c_int32, P],
     "pa_csr_diagonal": [P, P],
     "pa_gs_create_from_blocks": [P, P, cint, C.POINTER(P)],
+    "pa_csr_greedy_coloring": [P, P, C.POINTER(C.c_int32)],
+    "pa_hpcg_own_block_create": [P] + [i64] * 9 + [C.POINTER(P), P],
     "pa_coo_assemble": [P, i64, P, P, P, C.c_int32, P, P, P, P, P, P, i64, P, cint, C.POINTER(P)],
     "pa_coo_assembly_info": [P] + [C.POINTER(i64)] * 5 + [C.POINTER(f64)],
     "pa_coo_assembly_ghosts": [P, P],
@@ -165,6 +167,7 @@ _SIGS = {
     "pa_host_check_xw_groups": [i64, i64, i64, P, P, cint] + [C.POINTER(i64)] * 5,
     "pa_host_hpcg_ghosts": [i64] * 9 + [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "pa_host_hpcg_split_csr": [i64] * 9 + [P, i64, P, P, P, P, P, P, P],
+    "pa_host_hpcg_ghost_block": [i64] * 9 + [P, i64, P, P, P],
     "pa_host_color_rowptrs": [i64, P, P, P, C.c_int32, P],
     "pa_host_color_split": [i64, i64, P, P, P, P, P, P, P, i32, P, P, P, P],
     "pa_host_hpcg_split_csr64": [i64] * 9 + [P, i64, P, P, P, P, P, P, P],

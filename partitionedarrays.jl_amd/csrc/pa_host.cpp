@@ -445,6 +445,70 @@ extern "C" int pa_host_hpcg_split_csr64(int64_t nx, int64_t ny, int64_t nz, int6
 }
 
 
+// The own|ghost block alone (1-based, sorted columns), for a part whose own|own block and right-hand side are generated in
+// HBM (pa_rowsel.hip, pa_hpcg_own_block_create): only the rows on the part's surface hold entries, the interior is skipped
+// after the closed-form count.  Same arrays as hpcg_split_csr_impl's oh_* outputs.
+extern "C" int pa_host_hpcg_ghost_block(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                                        int64_t giy0, int64_t giz0, const int64_t *ghost_gids, int64_t n_ghost,
+                                        int32_t *oh_rowptr, int32_t *oh_colval, double *oh_nzval) {
+  PA_REQUIRE(nx > 0 && ny > 0 && nz > 0 && oh_rowptr, "bad arguments");
+  PA_REQUIRE(n_ghost == 0 || (ghost_gids && oh_colval && oh_nzval), "ghost arrays are NULL");
+  const HpcgGeom G{nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0};
+  std::unordered_map<int64_t, int32_t> g2g;
+  g2g.reserve((size_t)n_ghost * 2 + 1);
+  for (int64_t k = 0; k < n_ghost; ++k) g2g.emplace(ghost_gids[k], (int32_t)(k + 1));
+  const int T = std::max(1, std::min<int>((int)nz, n_threads_for(nx * ny * nz * 4)));
+  std::vector<int64_t> first(T + 1, 0);
+  bool bad = false;
+  auto ghost_entries = [&](int64_t ix, int64_t iy, int64_t iz) {
+    int ax, bx, ay, by, az, bz;
+    dim_counts(gix0 + ix, gix0, nx, gnx, ax, bx);
+    dim_counts(giy0 + iy, giy0, ny, gny, ay, by);
+    dim_counts(giz0 + iz, giz0, nz, gnz, az, bz);
+    return (int64_t)(ax + bx) * (ay + by) * (az + bz) - (int64_t)ax * ay * az;
+  };
+  auto count = [&](int t) {
+    int64_t k = 0;
+    for (int64_t iz = nz * t / T; iz < nz * (t + 1) / T; ++iz)
+      for (int64_t iy = 0; iy < ny; ++iy)
+        for (int64_t ix = 0; ix < nx; ++ix) k += ghost_entries(ix, iy, iz);
+    first[t + 1] = k;
+  };
+  auto fill = [&](int t) {
+    int64_t q = first[t];
+    for (int64_t iz = nz * t / T; iz < nz * (t + 1) / T; ++iz)
+      for (int64_t iy = 0; iy < ny; ++iy)
+        for (int64_t ix = 0; ix < nx; ++ix) {
+          const int64_t row = iz * nx * ny + iy * nx + ix;
+          oh_rowptr[row] = (int32_t)(q + 1);
+          if (ghost_entries(ix, iy, iz) == 0) continue;
+          const int64_t gx = gix0 + ix, gy = giy0 + iy, gz = giz0 + iz, q0 = q;
+          for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
+            const int64_t cx = gx + sx, cy = gy + sy, cz = gz + sz;
+            if (!G.in_grid(cx, cy, cz) || G.in_own(cx, cy, cz)) continue;
+            auto it = g2g.find(G.gid(cx, cy, cz));
+            if (it == g2g.end()) { bad = true; continue; }
+            int64_t k = q;                               // insertion sort by ghost id inside the row (compresscoo sorts columns)
+            while (k > q0 && oh_colval[k - 1] > it->second) { oh_colval[k] = oh_colval[k - 1]; oh_nzval[k] = oh_nzval[k - 1]; --k; }
+            oh_colval[k] = it->second; oh_nzval[k] = -1.0; ++q;
+          }
+        }
+    if (t == T - 1) oh_rowptr[nx * ny * nz] = (int32_t)(q + 1);
+  };
+  auto run = [&](auto &f) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(f, t);
+    f(0);
+    for (auto &x : th) x.join();
+  };
+  run(count);
+  for (int t = 0; t < T; ++t) first[t + 1] += first[t];
+  PA_REQUIRE(first[T] < (int64_t)2147483000, "block too large for Int32 row pointers");
+  run(fill);
+  PA_REQUIRE(!bad, "a ghost column is missing from ghost_gids (call pa_host_hpcg_ghosts first)");
+  return PA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Multicolour smoother set-up: split the rows of a part by colour into n_colors blocks (n_own x n_local, unsplit
 // column order: own columns, then ghost columns shifted by n_own_cols) and extract the diagonal.  out_rowptr[k] is

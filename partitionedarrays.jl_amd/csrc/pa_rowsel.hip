@@ -413,3 +413,180 @@ extern "C" int pa_gs_create_from_blocks(const pa_csr *oo, const pa_csr *oh, int 
   *out = g;
   return PA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Greedy colouring in natural order (pa_host_greedy_coloring: row r takes the smallest colour no own neighbour j < r has)
+// by the same rounds: a row is coloured in the round after its last lower neighbour, from colours that are final by then.
+// Verified against the definition row by row (which has one solution); PA_ERR_ARG when the rounds do not get there (a
+// pattern that is not structurally symmetric): the caller colours on the host.
+// ------------------------------------------------------------------------------------------------
+__global__ void kg_round_color(const int32_t *__restrict__ frontier, int size, const int32_t *__restrict__ start,
+                               const int32_t *__restrict__ len, const int32_t *__restrict__ col, int n, int32_t *__restrict__ color,
+                               int32_t *__restrict__ cnt, int32_t *__restrict__ next, int *__restrict__ next_count) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = t >> 3, lane = t & 7;
+  if (i >= size) return;
+  const int r = frontier[i];
+  if (lane == 0) {
+    unsigned long long used = 0;
+    for (int p = start[r], e = p + len[r]; p < e; ++p) {
+      const int j = col[p];
+      if (j < r && color[j] < 64) used |= 1ull << color[j];
+    }
+    int c = 0;
+    while (c < 63 && (used >> c) & 1ull) ++c;
+    color[r] = c;
+  }
+  for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += 8) {
+    const int j = col[p];
+    if (j > r && j < n && atomicSub(&cnt[j], 1) == 1) next[atomicAdd(next_count, 1)] = j;
+  }
+}
+
+__global__ void kg_verify_color(const int32_t *__restrict__ start, const int32_t *__restrict__ len, const int32_t *__restrict__ col,
+                                const int32_t *__restrict__ color, int n, int *__restrict__ bad, int *__restrict__ n_colors) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  unsigned long long used = 0;
+  for (int p = start[r], e = p + len[r]; p < e; ++p) {
+    const int j = col[p];
+    if (j < r && color[j] >= 0 && color[j] < 64) used |= 1ull << color[j];
+    if (j < r && color[j] < 0) atomicOr(bad, 1);
+  }
+  int c = 0;
+  while (c < 63 && (used >> c) & 1ull) ++c;
+  if (c != color[r]) atomicOr(bad, 1);
+  atomicMax(n_colors, color[r] + 1);
+}
+
+extern "C" int pa_csr_greedy_coloring(const pa_csr *oo, int32_t *color, int32_t *n_colors) {
+  PA_REQUIRE(oo && color && n_colors && !oo->next, "bad arguments");
+  const int32_t *col = raw_columns(oo);
+  PA_REQUIRE(oo->nnz == 0 || col, "the block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
+  pa_ctx *c = oo->ctx;
+  const int64_t n = oo->n_rows;
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  scratch sc;
+  row_spans A;
+  PA_TRY(spans_of(c, sc, oo, n, A));
+  int32_t *d_cnt = nullptr, *d_color = nullptr, *d_f0 = nullptr, *d_f1 = nullptr;
+  int *d_count = nullptr;
+  PA_TRY(sc.get(&d_cnt, (size_t)n + 1));
+  PA_TRY(sc.get(&d_color, (size_t)n + 1));
+  PA_TRY(sc.get(&d_f0, (size_t)n + 1));
+  PA_TRY(sc.get(&d_f1, (size_t)n + 1));
+  PA_TRY(sc.get(&d_count, 8));
+  if (n) hipLaunchKernelGGL(kg_lower_count, grid1(n), dim3(256), 0, s, A.start, A.len, col, (int)n, d_cnt);
+  PA_HIP(hipMemsetAsync(d_count, 0, sizeof(int) * 8, s));
+  PA_HIP(hipMemsetAsync(d_color, 0xFF, sizeof(int32_t) * (n + 1), s));
+  if (n) hipLaunchKernelGGL(kg_first, grid1(n), dim3(256), 0, s, d_cnt, (int)n, d_f0, d_count);
+  int64_t done = 0;
+  int size = 0, which = 0;
+  PA_TRY(d2h(s, &size, d_count, 1));
+  while (size > 0) {
+    int32_t *cur = which ? d_f1 : d_f0, *nxt = which ? d_f0 : d_f1;
+    int *cnt_next = d_count + 1 + (which ^ 1);
+    PA_HIP(hipMemsetAsync(cnt_next, 0, sizeof(int), s));
+    hipLaunchKernelGGL(kg_round_color, grid1((int64_t)size * 8), dim3(256), 0, s, cur, size, A.start, A.len, col, (int)n, d_color, d_cnt, nxt,
+                       cnt_next);
+    done += size;
+    PA_TRY(d2h(s, &size, cnt_next, 1));
+    which ^= 1;
+    if (done + size > n) break;
+  }
+  int res[2] = {done == n ? 0 : 1, 0};
+  if (!res[0] && n) {
+    hipLaunchKernelGGL(kg_verify_color, grid1(n), dim3(256), 0, s, A.start, A.len, col, d_color, (int)n, d_count + 3, d_count + 4);
+    PA_TRY(d2h(s, res, d_count + 3, 2));
+  }
+  PA_HIP(hipGetLastError());
+  PA_REQUIRE(!res[0], "the rounds do not reproduce the greedy colouring in natural order (own x own pattern not structurally symmetric)");
+  if (n) PA_TRY(d2h(s, color, d_color, (size_t)n));
+  *n_colors = res[1];
+  return PA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HPCG's 27-point operator of one part, own|own block and right-hand side, generated in HBM
+// (HPCG/src/sparse_matrix.jl:28-122: build_matrix loops over the part's cells and their 27 neighbours in (sz, sy, sx)
+// order, 26.0 on the diagonal, -1.0 elsewhere, b = 27 - #neighbours inside the global grid; psparse then keeps the own
+// columns in own|own, in ascending local id -- which IS the (sz, sy, sx) order).  The host's fused generator
+// (pa_host.cpp, hpcg_split_csr_impl) writes the same arrays; the surface-only own|ghost block stays with it.
+// ------------------------------------------------------------------------------------------------
+struct hpcg_box { int nx, ny, nz; long long gnx, gny, gnz, gx0, gy0, gz0; };
+
+__device__ inline void dim_cnt(long long g, int i, int n, long long gn, int &own, int &grid) {
+  grid = 1 + (g > 0) + (g < gn - 1);
+  own = 1 + (i > 0) + (i < n - 1);
+}
+
+__global__ void kh_count(hpcg_box B, int n, int32_t *__restrict__ len, double *__restrict__ b) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  if (r == n) { len[r] = 0; return; }
+  const int ix = r % B.nx, iy = (r / B.nx) % B.ny, iz = r / (B.nx * B.ny);
+  int ax, bx, ay, by, az, bz;
+  dim_cnt(B.gx0 + ix, ix, B.nx, B.gnx, ax, bx);
+  dim_cnt(B.gy0 + iy, iy, B.ny, B.gny, ay, by);
+  dim_cnt(B.gz0 + iz, iz, B.nz, B.gnz, az, bz);
+  len[r] = ax * ay * az;
+  if (b) b[r] = 27.0 - (double)(bx * by * bz);
+}
+
+__global__ void kh_fill(hpcg_box B, int n, const int32_t *__restrict__ rp, int32_t *__restrict__ col, double *__restrict__ val) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int ix = r % B.nx, iy = (r / B.nx) % B.ny, iz = r / (B.nx * B.ny);
+  int p = rp[r];
+  for (int sz = -1; sz <= 1; ++sz) {
+    const int cz = iz + sz;
+    if (cz < 0 || cz >= B.nz) continue;
+    for (int sy = -1; sy <= 1; ++sy) {
+      const int cy = iy + sy;
+      if (cy < 0 || cy >= B.ny) continue;
+      for (int sx = -1; sx <= 1; ++sx) {
+        const int cx = ix + sx;
+        if (cx < 0 || cx >= B.nx) continue;
+        col[p] = (cz * B.ny + cy) * B.nx + cx;
+        val[p] = (sx == 0 && sy == 0 && sz == 0) ? 26.0 : -1.0;
+        ++p;
+      }
+    }
+  }
+}
+
+extern "C" int pa_hpcg_own_block_create(pa_ctx *c, int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz,
+                                        int64_t gix0, int64_t giy0, int64_t giz0, pa_csr **own_own, pa_vec *b) {
+  PA_REQUIRE(c && own_own && nx > 0 && ny > 0 && nz > 0, "bad arguments");
+  // (gix0, giy0, giz0: global coordinates of the part's first node, 1-based like pa_host_hpcg_split_csr's)
+  PA_REQUIRE(gix0 >= 1 && giy0 >= 1 && giz0 >= 1 && gix0 - 1 + nx <= gnx && giy0 - 1 + ny <= gny && giz0 - 1 + nz <= gnz, "the part's box is not inside the grid");
+  const int64_t n = nx * ny * nz;
+  PA_REQUIRE(n < (int64_t)2147483000 / 27, "a part of this size takes the host generator (Int64 row pointers, slabs)");
+  PA_REQUIRE(!b || b->n_own + b->n_ghost >= n, "b is shorter than the part has rows");
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  scratch sc;
+  int32_t *d_len = nullptr, *d_rp = nullptr;
+  PA_TRY(sc.get(&d_len, (size_t)n + 1));
+  PA_TRY(sc.get(&d_rp, (size_t)n + 1));
+  const hpcg_box B{(int)nx, (int)ny, (int)nz, (long long)gnx, (long long)gny, (long long)gnz, (long long)gix0 - 1, (long long)giy0 - 1, (long long)giz0 - 1};
+  hipLaunchKernelGGL(kh_count, grid1(n + 1), dim3(256), 0, s, B, (int)n, d_len, b ? b->d : nullptr);
+  PA_TRY(scan_exclusive(sc, s, d_len, d_rp, (size_t)n + 1));
+  std::vector<int32_t> crp((size_t)n + 1);
+  PA_TRY(d2h(s, crp.data(), d_rp, crp.size()));
+  const int64_t nnz = crp.back();
+  int32_t *d_col = nullptr;
+  double *d_val = nullptr;
+  PA_TRY(pa_dev_alloc(c, (void **)&d_col, sizeof(int32_t) * (nnz + 8), PA_MEM_MATRIX));
+  int st = pa_dev_alloc(c, (void **)&d_val, sizeof(double) * (nnz + 8), PA_MEM_MATRIX);
+  if (st == PA_OK) {
+    hipLaunchKernelGGL(kh_fill, grid1(n), dim3(256), 0, s, B, (int)n, d_rp, d_col, d_val);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = PA_ERR_HIP;
+  }
+  if (st == PA_OK) st = pa_csr_from_device_rows(c, n, n, nnz, n, crp, nullptr, d_col, d_val, own_own);
+  (void)hipStreamSynchronize(s);
+  pa_dev_free(c, d_col);
+  if (d_val) pa_dev_free(c, d_val);
+  return st;
+}

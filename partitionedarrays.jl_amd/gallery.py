@@ -103,6 +103,33 @@ def build_split_blocks_fused(my_rows, nx, ny, nz, gnx, gny, gnz):
     return cols, oo, oh, b
 
 
+def build_split_blocks_device(my_rows, nx, ny, nz, gnx, gny, gnz):
+    """One part of build_p_matrix with the own|own block and b generated in HBM (csrc/pa_rowsel.hip,
+    pa_hpcg_own_block_create) and only the surface -- ghost ids in first-seen order, the own|ghost block -- made by the host:
+    returns (col LocalIndices, SplitMatrixBlocks, DeviceVector b).  Same arrays as build_split_blocks_fused + upload
+    (tests/test_gpu_parity.py::test_hpcg_blocks_generated_on_the_device_equal_the_host_s)."""
+    from .p_range import LocalIndices, find_owner
+    from .p_sparse_matrix import HostCSR, DeviceCSR, SplitMatrixBlocks
+    from .p_vector import DeviceVector, context
+    from .primitives import DebugArray
+    g0 = [int(my_rows.ranges[d][0]) for d in range(3)]
+    args = [int(v) for v in (nx, ny, nz, gnx, gny, gnz, *g0)]
+    ng, noo, noh = C.c_int64(), C.c_int64(), C.c_int64()
+    L.call("pa_host_hpcg_ghosts", *args, None, C.byref(ng), C.byref(noo), C.byref(noh))
+    ghosts = np.zeros(ng.value, I64)
+    L.call("pa_host_hpcg_ghosts", *args, L.ptr(ghosts), C.byref(ng), C.byref(noo), C.byref(noh))
+    owners = find_owner(DebugArray([my_rows]), DebugArray([ghosts])).items[0]
+    cols = LocalIndices(my_rows.n_global, my_rows.part, np_=my_rows.np_, n=my_rows.n, ranges=my_rows.ranges,
+                        starts=my_rows.starts, ghost_to_global=ghosts, ghost_to_owner=owners)
+    n = nx * ny * nz
+    oh = HostCSR(n, ng.value, np.empty(n + 1, np.int32), np.empty(noh.value, np.int32), np.empty(noh.value, F64))
+    L.call("pa_host_hpcg_ghost_block", *args, L.ptr(ghosts), ng.value, L.ptr(oh.rowptr), L.ptr(oh.colval), L.ptr(oh.nzval))
+    v = DeviceVector(cols.n_own, cols.n_ghost)
+    h = C.c_void_p()
+    L.call("pa_hpcg_own_block_create", context().h, *args, C.byref(h), v.h)
+    return cols, SplitMatrixBlocks(DeviceCSR.from_handle(h, n, n, noo.value), DeviceCSR(oh)), v
+
+
 def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=False, fused=None, keep_raw=False):
     """HPCG build_p_matrix (HPCG/src/sparse_matrix.jl:105-122) -> A (device PSparseMatrix), b (PVector).
 
@@ -116,6 +143,22 @@ def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=Fa
     row_partition = uniform_partition(ranks, (npx, npy, npz), (gnx, gny, gnz))
     if fused is None:
         fused = nx * ny * nz >= (1 << 18)
+    import os
+    if fused and not keep_host and nx * ny * nz * 27 < 2 ** 31 - 2 ** 16 and os.environ.get("PA_SETUP_DEVICE", "1") != "0":
+        # nobody wants the host copy: the own|own block and b are generated in HBM (no 5.4 GB over PCIe for a 256^3 part)
+        from .p_vector import context
+
+        def one_dev(my_rows):
+            if keep_raw:
+                L.call("pa_ctx_keep_raw_columns", context().h, 1)
+            try:
+                return build_split_blocks_device(my_rows, nx, ny, nz, gnx, gny, gnz)
+            finally:
+                if keep_raw:
+                    L.call("pa_ctx_keep_raw_columns", context().h, 0)
+
+        cols, blocks, bvals = tuple_of_arrays(pmap(one_dev, row_partition))
+        return PSparseMatrix(blocks, row_partition, cols, True, None), PVector(bvals, cols)
     if fused:
         def one(my_rows):
             cols, oo, oh, b = build_split_blocks_fused(my_rows, nx, ny, nz, gnx, gny, gnz)

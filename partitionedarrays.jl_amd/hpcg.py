@@ -59,9 +59,8 @@ class GaussSeidel:
         """ordering="sequential": the reference's sweep order (dependency levels, bit-identical);
         ordering="multicolor": greedy colouring (27-pt: 8 colours), the fast `opt` variant (different arithmetic)."""
         self.ordering = ordering
-        if A.host_blocks is None:
-            raise L.PAError("the Gauss-Seidel smoother needs the host blocks: build the matrix with keep_host=True")
         self.A = A
+        no_host = "the Gauss-Seidel smoother needs the host blocks (build the matrix with keep_host=True) or blocks that kept their raw columns"
 
         def make(h, r, c, dev):
             g = C.c_void_p()
@@ -71,14 +70,19 @@ class GaussSeidel:
                     L.call("pa_gs_create_from_blocks", dev.own_own.h, dev.own_ghost.h, 0, C.byref(g))
                     return g
                 except L.PAError:
+                    if h is None:
+                        raise
                     g = C.c_void_p()                       # (the host loop below states what is wrong with the pattern)
+            if h is None:
+                raise L.PAError(no_host)
             rowptr, colv, val, _ = _unsplit_csr(h, r, c)   # the storage HPCG uses (split_format=false)
             n = r.n_own
             L.call("pa_gs_create", context().h, n, c.n_local, len(val), L.ptr(rowptr), L.ptr(colv), L.ptr(val), 1,
                    {"sequential": 0, "multicolor": 1}[ordering], C.byref(g))
             return g
 
-        self.gs = pmap(make, A.host_blocks, A.row_partition, A.col_partition, A.matrix_partition)
+        hb = A.host_blocks if A.host_blocks is not None else pmap(lambda _r: None, A.row_partition)
+        self.gs = pmap(make, hb, A.row_partition, A.col_partition, A.matrix_partition)
 
     def info(self):
         def f(g):
@@ -145,20 +149,29 @@ class ColoredGaussSeidelSpMV:
     def __init__(self, A):
         from .p_sparse_matrix import HostCSR, DeviceCSR
         from .p_vector import DeviceVector
-        if A.host_blocks is None:
-            raise L.PAError("the Gauss-Seidel smoother needs the host blocks: build the matrix with keep_host=True")
         self.A = A
         self.ordering = "multicolor_spmv"
 
         def make(h, r, c, dev):
-            oo, oh = h
             n = r.n_own
             color = np.zeros(n, np.int32)
             ncol = C.c_int32()
-            # rows of one colour must not be coupled: the own x own block holds every coupling between own rows
-            L.call("pa_host_greedy_coloring", n, L.ptr(oo.rowptr), L.ptr(oo.colval), 1, L.ptr(color), C.byref(ncol))
+            on_device = dev.own_own.has_raw_columns() and dev.own_ghost.has_raw_columns()
+            colored = False
+            if on_device:                                  # greedy colouring in natural order by rounds on the device
+                try:
+                    L.call("pa_csr_greedy_coloring", dev.own_own.h, L.ptr(color), C.byref(ncol))
+                    colored = True
+                except L.PAError:
+                    if h is None:
+                        raise
+            if not colored:
+                if h is None:
+                    raise L.PAError("the Gauss-Seidel smoother needs the host blocks (build the matrix with keep_host=True) or blocks that kept their raw columns")
+                # rows of one colour must not be coupled: the own x own block holds every coupling between own rows
+                L.call("pa_host_greedy_coloring", n, L.ptr(h[0].rowptr), L.ptr(h[0].colval), 1, L.ptr(color), C.byref(ncol))
             K = ncol.value
-            if dev.own_own.has_raw_columns() and dev.own_ghost.has_raw_columns():
+            if on_device:
                 # the colours' rows are cut from the blocks already in HBM (csrc/pa_rowsel.hip): no host copy of the entries,
                 # no second trip over PCIe
                 blocks = DeviceCSR.select_rows(dev.own_own, dev.own_ghost, color, K)
@@ -166,6 +179,7 @@ class ColoredGaussSeidelSpMV:
                 L.call("pa_csr_diagonal", dev.own_own.h, d.h)
                 handles = (C.c_void_p * len(blocks))(*[blk.h for blk in blocks])
                 return blocks, d, handles, color
+            oo, oh = h
             arr = lambda xs: (C.c_void_p * K)(*[x.ctypes.data for x in xs])
             rps = [np.empty(n + 1, np.int32) for _ in range(K)]                  # (one native, threaded pass for all colours)
             L.call("pa_host_color_rowptrs", n, L.ptr(oo.rowptr), L.ptr(oh.rowptr), L.ptr(color), K, arr(rps))
@@ -181,7 +195,8 @@ class ColoredGaussSeidelSpMV:
             handles = (C.c_void_p * len(blocks))(*[blk.h for blk in blocks])
             return blocks, DeviceVector(n, 0).upload(diag), handles, color
 
-        self.parts = pmap(make, A.host_blocks, A.row_partition, A.col_partition, A.matrix_partition)
+        hb = A.host_blocks if A.host_blocks is not None else pmap(lambda _r: None, A.row_partition)
+        self.parts = pmap(make, hb, A.row_partition, A.col_partition, A.matrix_partition)
 
     def info(self):
         return pmap(lambda p: dict(levels=len(p[0]), max_rows_per_level=0), self.parts)
@@ -231,8 +246,10 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
         # (the level's blocks keep their raw columns in HBM while the smoother -- the colours' rows, or the unsplit CSR and
         #  the dependency levels of the sequential sweep -- and the restriction's rows are made from them on the device,
         #  csrc/pa_rowsel.hip; PA_SETUP_ROWSEL=0: the host copies them)
-        keep_raw = ordering in ("multicolor_spmv", "sequential") and os.environ.get("PA_SETUP_ROWSEL", "1") != "0"
-        A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=True, fused=True,
+        keep_raw = (ordering in ("multicolor_spmv", "sequential") and os.environ.get("PA_SETUP_ROWSEL", "1") != "0"
+                    and os.environ.get("PA_SETUP_DEVICE", "1") != "0")
+        # (nothing of the set-up reads a host copy of the blocks then: they are generated in HBM, gallery.build_split_blocks_device)
+        A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=not keep_raw, fused=True,
                               keep_raw=keep_raw)
         As[lev - 1], rs[lev - 1] = A, b
         gss[lev - 1] = ColoredGaussSeidelSpMV(A) if ordering == "multicolor_spmv" else GaussSeidel(A, ordering)
@@ -253,7 +270,8 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
                         mask[op.astype(np.int64) - 1] = 0
                         return DeviceCSR.select_rows(dev.own_own, dev.own_ghost, mask, 1)[0]
                     return DeviceCSR(_rows_block(hb, r, c, op.astype(np.int64) - 1))
-                blk = pmap(rows_block, A.host_blocks, A.row_partition, A.col_partition, A.matrix_partition)
+                hb = A.host_blocks if A.host_blocks is not None else pmap(lambda _r: None, A.row_partition)
+                blk = pmap(rows_block, hb, A.row_partition, A.col_partition, A.matrix_partition)
                 pmap(lambda t, bk: L.call("pa_transfer_attach_rows", t, bk.h), f2c[lev - 2], blk)
                 rbs[lev - 2] = blk
             nx, ny, nz = nx // 2, ny // 2, nz // 2

@@ -2067,6 +2067,43 @@ def test_device_side_psparse_equals_the_host_route(orc, monkeypatch):
     monkeypatch.delenv("PA_SETUP_DEVICE")
 
 
+def test_hpcg_blocks_generated_on_the_device_equal_the_host_s(orc):
+    """csrc/pa_rowsel.hip, pa_hpcg_own_block_create + pa_host_hpcg_ghost_block: HPCG's 27-point operator of a part with the
+    own|own block and b generated in HBM (HPCG/src/sparse_matrix.jl:28-122) against the fused host generator + upload (itself
+    pinned to the reference's chain and the oracle by tests/test_host_setup.py): every array the product kernel reads, both
+    blocks, b, the ghost ids and their order -- on one part, on (2,2,2) parts of a non-cubic box, on (4,1,1); and the greedy
+    colouring in natural order computed by rounds on the device against pa_host_greedy_coloring."""
+    import pa_amd._lib as L
+    for P, shape, n in ((1, (1, 1, 1), (24, 24, 24)), (8, (2, 2, 2), (8, 6, 10)), (4, (4, 1, 1), (5, 9, 7)), (2, (2, 1, 1), (64, 64, 64))):
+        g = [s * k for s, k in zip(shape, n)]
+        Ad, bd = pa.build_p_matrix(ranks(P), *n, *g, *shape, keep_host=False, fused=True, keep_raw=True)
+        Ah, bh = pa.build_p_matrix(ranks(P), *n, *g, *shape, keep_host=True, fused=True)
+        assert Ad.host_blocks is None
+        for p in range(P):
+            cd, ch = Ad.col_partition.items[p], Ah.col_partition.items[p]
+            assert np.array_equal(cd.ghost_to_global, ch.ghost_to_global) and np.array_equal(cd.ghost_to_owner, ch.ghost_to_owner)
+            assert np.array_equal(bd.vector_partition.items[p].download(), bh.vector_partition.items[p].download())
+            for which in ("own_own", "own_ghost"):
+                d, h = getattr(Ad.matrix_partition.items[p], which), getattr(Ah.matrix_partition.items[p], which)
+                assert d.info() == h.info() and d.encoding() == h.encoding() and d.stream_bytes() == h.stream_bytes(), (P, p, which)
+                da, ha = d.debug_arrays(), h.debug_arrays()
+                assert da.keys() == ha.keys()
+                for key in da:
+                    assert da[key].shape == ha[key].shape and np.array_equal(da[key], ha[key]), (P, p, which, key)
+            oo = Ah.host_blocks.items[p][0]
+            want, k_want = np.zeros(oo.m, np.int32), C.c_int32()
+            L.call("pa_host_greedy_coloring", oo.m, L.ptr(oo.rowptr), L.ptr(oo.colval), 1, L.ptr(want), C.byref(k_want))
+            got, k_got = np.zeros(oo.m, np.int32), C.c_int32()
+            L.call("pa_csr_greedy_coloring", Ad.matrix_partition.items[p].own_own.h, L.ptr(got), C.byref(k_got))
+            assert k_got.value == k_want.value and np.array_equal(got, want), (P, p)
+        x = pa.pones(Ad.col_partition)
+        yd, yh = pa.pzeros(Ad.row_partition), pa.pzeros(Ah.row_partition)
+        pa.mul_(yd, Ad, x)
+        pa.mul_(yh, Ah, pa.pones(Ah.col_partition))
+        for u, v in zip(yd.vector_partition.items, yh.vector_partition.items):
+            assert np.array_equal(u.download(), v.download())
+
+
 def test_device_side_row_subsets_equal_the_host_route(orc, monkeypatch):
     """csrc/pa_rowsel.hip: the blocks the multigrid set-up cuts out of a level's matrix -- the colours of the multicolour
     smoother and the fine rows the coarse grid keeps (HPCG/src/mg_preconditioner.jl:224-251,314-329) -- built on the device
