@@ -190,6 +190,15 @@ def test_fused_hpcg_setup_equals_oracle(orc, shape, parts):
             assert np.array_equal(mine.rowptr, ref.rowptr) and np.array_equal(mine.colval, ref.colval)
             assert np.array_equal(mine.nzval, ref.nzval)
         assert np.array_equal(b, bo[k][:r.n_own])
+        # the surface-only generator of the own|ghost block (the own|own block is generated in HBM then, csrc/pa_rowsel.hip)
+        import ctypes as C
+        import pa_amd._lib as L
+        g0 = [int(r.ranges[d][0]) for d in range(3)]
+        ghosts = np.ascontiguousarray(cols.ghost_to_global, np.int64)
+        rp, cv, vv = np.full(r.n_own + 1, -7, np.int32), np.full(oh.nnz, -7, np.int32), np.full(oh.nnz, np.nan)
+        L.call("pa_host_hpcg_ghost_block", nx, ny, nz, px * nx, py * ny, pz * nz, *g0, L.ptr(ghosts), len(ghosts),
+               L.ptr(rp), L.ptr(cv), L.ptr(vv))
+        assert np.array_equal(rp, oh.rowptr) and np.array_equal(cv, oh.colval) and np.array_equal(vv, oh.nzval)
 
 
 @pytest.mark.parametrize("nodes,parts", [((6, 5), (2, 2)), ((4, 3, 3), (2, 1, 2)), ((7,), (3,)), ((9, 8), (4, 2))])
