@@ -103,6 +103,7 @@ _SIGS = {
     "pa_gs_create_from_blocks": [P, P, cint, C.POINTER(P)],
     "pa_csr_greedy_coloring": [P, P, C.POINTER(C.c_int32)],
     "pa_hpcg_own_block_create": [P] + [i64] * 9 + [C.POINTER(P), P],
+    "pa_hpcg_rhs": [P] + [i64] * 9 + [P],
     "pa_coo_assemble": [P, i64, P, P, P, C.c_int32, P, P, P, P, P, P, i64, P, cint, C.POINTER(P)],
     "pa_coo_assembly_info": [P] + [C.POINTER(i64)] * 5 + [C.POINTER(f64)],
     "pa_coo_assembly_ghosts": [P, P],

@@ -88,9 +88,8 @@ struct pa_arena {
   int matrix_class = -1;                   // where matrix streams go: the class the first one landed in
   size_t mat_bytes[3] = {0, 0, 0}, vec_bytes[3] = {0, 0, 0};   // what lives where (by kind)
   unsigned vec_turn = 0;
-  const char *last_matrix = nullptr;       // the newest big matrix stream: the read stream of the pair self-check
-  size_t last_matrix_len = 0;
-  int last_matrix_cls = -1;
+  int last_matrix_cls = -1;                // class of the newest big matrix stream handed out (what vectors stay away from; it
+                                           // outlives the stream: a block's set-up frees temporaries bigger than anything it keeps)
   bool release_idle = false;               // pa_ctx_arena_release: an idle arena hands everything back, spare or not
   bool walking = false;                    // a walk is under way: what it went over is held until it has ended (arena_trim waits)
   int want_vec_classes = 1;                // pa_ctx_arena_hint: 2 = a solver's vectors alternate between two classes of their own
@@ -323,7 +322,7 @@ static void arena_trim(pa_arena *a) {
     a->n_classes = 0;
     for (int k = 0; k < 3; ++k) { a->ref[k] = nullptr; a->scr[k] = nullptr; a->mat_bytes[k] = a->vec_bytes[k] = 0; }
     a->matrix_class = -1;
-    a->last_matrix = nullptr; a->last_matrix_len = 0; a->last_matrix_cls = -1;
+    a->last_matrix_cls = -1;
     a->second_walk_done = false;
   }
 }
@@ -471,7 +470,7 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
     if (p) {
       const int cls = a->live_[(uintptr_t)p].cls;
       if (a->matrix_class < 0) a->matrix_class = cls;
-      if (bytes >= a->last_matrix_len || bytes >= a->cell) { a->last_matrix = (const char *)p; a->last_matrix_len = bytes; a->last_matrix_cls = cls; }
+      if (bytes >= ((size_t)32 << 20)) a->last_matrix_cls = cls;
     }
     return p;
   }
@@ -487,7 +486,7 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
   };
   static const int check_mode = getenv("PA_ARENA_SELFCHECK") ? atoi(getenv("PA_ARENA_SELFCHECK")) : 1;
   static const int plain_first = getenv("PA_ARENA_PLAIN_VECTORS") ? atoi(getenv("PA_ARENA_PLAIN_VECTORS")) : 0;   // (experimental, below)
-  if (!a->last_matrix) return nullptr;                  // no matrix stream to stay away from (yet): a plain allocation
+  if (a->last_matrix_cls < 0) return nullptr;           // no matrix stream to stay away from (yet): a plain allocation
   // A caller that announced a solver's worth of vectors (pa_ctx_arena_hint: the multigrid hierarchy) gets TWO vector classes:
   // kernels that read vectors and write one (the Gauss-Seidel colour updates, BLAS-1) run 3-6 % faster when what they write
   // is not where they read (MG-PCG iteration at 256^3: 5.78 ms with the vectors alternating between two classes, 6.16 ms
@@ -560,7 +559,7 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
   // self-check of the pair actually handed out (big vectors only: what a product writes)
   // (once per cell and matrix class: a solver that allocates its work vectors on every call must not pay a dozen probe
   // launches per vector each time -- 0.57 ms per MG-PCG iteration of a 30-iteration solve at 256^3 when it did)
-  if (check_mode && a->last_matrix && bytes >= ((size_t)32 << 20) && !c->capturing) {
+  if (check_mode && a->last_matrix_cls >= 0 && bytes >= ((size_t)32 << 20) && !c->capturing) {
     const pa_arena::blk &bk = a->live_[(uintptr_t)p];
     const int cls = bk.cls;
     bool same = false;
@@ -608,7 +607,6 @@ static void arena_give_back(pa_arena *a, void *p) {
   b.e->live -= b.len;
   size_t *acct = b.kind == PA_MEM_MATRIX ? a->mat_bytes : a->vec_bytes;
   acct[b.cls] -= std::min(acct[b.cls], b.len);
-  if ((const char *)p == a->last_matrix) { a->last_matrix = nullptr; a->last_matrix_len = 0; a->last_matrix_cls = -1; }
   uintptr_t start = (uintptr_t)p;
   size_t len = b.len;
   auto nx = a->free_.find(start + len);                 // merge with free neighbours of the same extent and class

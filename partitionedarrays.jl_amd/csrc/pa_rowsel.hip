@@ -524,13 +524,13 @@ __device__ inline void dim_cnt(long long g, int i, int n, long long gn, int &own
 __global__ void kh_count(hpcg_box B, int n, int32_t *__restrict__ len, double *__restrict__ b) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r > n) return;
-  if (r == n) { len[r] = 0; return; }
+  if (r == n) { if (len) len[r] = 0; return; }
   const int ix = r % B.nx, iy = (r / B.nx) % B.ny, iz = r / (B.nx * B.ny);
   int ax, bx, ay, by, az, bz;
   dim_cnt(B.gx0 + ix, ix, B.nx, B.gnx, ax, bx);
   dim_cnt(B.gy0 + iy, iy, B.ny, B.gny, ay, by);
   dim_cnt(B.gz0 + iz, iz, B.nz, B.gnz, az, bz);
-  len[r] = ax * ay * az;
+  if (len) len[r] = ax * ay * az;
   if (b) b[r] = 27.0 - (double)(bx * by * bz);
 }
 
@@ -589,4 +589,20 @@ extern "C" int pa_hpcg_own_block_create(pa_ctx *c, int64_t nx, int64_t ny, int64
   pa_dev_free(c, d_col);
   if (d_val) pa_dev_free(c, d_val);
   return st;
+}
+
+// b alone (27 - the number of neighbours inside the global grid): for a vector created after the block, so that the arena
+// knows the matrix streams' class by the time it places it
+extern "C" int pa_hpcg_rhs(pa_ctx *c, int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                           int64_t giy0, int64_t giz0, pa_vec *b) {
+  PA_REQUIRE(c && b && nx > 0 && ny > 0 && nz > 0, "bad arguments");
+  PA_REQUIRE(gix0 >= 1 && giy0 >= 1 && giz0 >= 1 && gix0 - 1 + nx <= gnx && giy0 - 1 + ny <= gny && giz0 - 1 + nz <= gnz, "the part's box is not inside the grid");
+  const int64_t n = nx * ny * nz;
+  PA_REQUIRE(n < (int64_t)2147483000 && b->n_own + b->n_ghost >= n, "b is shorter than the part has rows");
+  PA_HIP(hipSetDevice(c->device));
+  const hpcg_box B{(int)nx, (int)ny, (int)nz, (long long)gnx, (long long)gny, (long long)gnz, (long long)gix0 - 1, (long long)giy0 - 1, (long long)giz0 - 1};
+  hipLaunchKernelGGL(kh_count, grid1(n + 1), dim3(256), 0, c->s[0], B, (int)n, (int32_t *)nullptr, b->d);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  return PA_OK;
 }

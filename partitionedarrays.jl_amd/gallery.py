@@ -124,9 +124,10 @@ def build_split_blocks_device(my_rows, nx, ny, nz, gnx, gny, gnz):
     n = nx * ny * nz
     oh = HostCSR(n, ng.value, np.empty(n + 1, np.int32), np.empty(noh.value, np.int32), np.empty(noh.value, F64))
     L.call("pa_host_hpcg_ghost_block", *args, L.ptr(ghosts), ng.value, L.ptr(oh.rowptr), L.ptr(oh.colval), L.ptr(oh.nzval))
-    v = DeviceVector(cols.n_own, cols.n_ghost)
     h = C.c_void_p()
-    L.call("pa_hpcg_own_block_create", context().h, *args, C.byref(h), v.h)
+    L.call("pa_hpcg_own_block_create", context().h, *args, C.byref(h), None)
+    v = DeviceVector(cols.n_own, cols.n_ghost)        # (after the block: the arena places it away from the matrix streams' class)
+    L.call("pa_hpcg_rhs", context().h, *args, v.h)
     return cols, SplitMatrixBlocks(DeviceCSR.from_handle(h, n, n, noo.value), DeviceCSR(oh)), v
 
 

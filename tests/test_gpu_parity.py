@@ -1267,6 +1267,10 @@ def test_arena_places_matrix_streams_and_vectors_in_different_memory_classes(orc
         out["reused"] = p0 in (y2.data_ptr(), y3.data_ptr())
         small = pa.DeviceVector(1000, 0)
         out["small_vector_class"] = small.memory_class()
+        # a block generated in HBM frees temporaries bigger than anything it keeps: the vectors made after it must still be placed
+        A2, b2 = pa.build_p_matrix(pa.DebugArray([1]), 128, 128, 128, 128, 128, 128, 1, 1, 1)
+        z = pa.DeviceVector(n, 0)
+        out["generated"] = [A2.matrix_partition.items[0].own_own.memory_class(), b2.vector_partition.items[0].memory_class(), z.memory_class()]
         print("RESULT " + json.dumps(out))
     """ % str(pathlib.Path(__file__).resolve().parents[1]))
     env = dict(os.environ, PA_ARENA_MIN_MIB="256", PA_SETUP_TIMING="1")
@@ -1286,6 +1290,7 @@ def test_arena_places_matrix_streams_and_vectors_in_different_memory_classes(orc
     if out["after"]["classes"] >= 2:                                   # the structure the rule exists for
         assert all(c >= 0 and c != M for c in out["vector_classes"]), (out, r.stderr[-3000:])
         assert out["after"]["pairs_checked_ok"] >= 1 and out["after"]["pairs_checked_same_class"] == 0, (out, r.stderr[-3000:])
+        assert out["generated"][0] == M and all(c >= 0 and c != M for c in out["generated"][1:]), out
         assert out["first_vector_s"] < 3.0, out                        # the walk is a fraction of a second, not the 7 s of round 2
     else:                                                              # the whole walk stayed inside one class region: nothing to place by
         assert all(c == M for c in out["vector_classes"]), out
