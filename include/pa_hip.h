@@ -420,6 +420,12 @@ int pa_gs_color_update(pa_rowset *rs, pa_vec *x, const pa_vec *b, pa_vec *t, con
  * entry couples two rows of one colour, pa_host_greedy_coloring) makes the in-place update race-free. */
 int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_vec *b, const pa_vec *diag,
                       int backward);
+/* The symmetric sweep (forward, then backward: gauss_seidel_step, smoothers.jl:105-131) as colours 0..K-1, K-2..0: the
+ * backward half does not relax colour K-1 a second time (nothing it couples to has changed; the update would add 0 up to
+ * rounding).  zero_guess != 0: the caller guarantees x == 0 (own and ghost); colour 0 is then x = b / diag, the colour
+ * launch's own expression with a zero row sum, without reading the block. */
+int pa_gs_color_symmetric_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_vec *b, const pa_vec *diag,
+                                int zero_guess);
 /* restrict! / prolongate! (HPCG/src/mg_preconditioner.jl:224-251): f2c[i] = fine row of coarse row i.
  *   restrict  : r_c[i] = r_f[f2c[i]] - Axf[f2c[i]]          prolongate: x_f[f2c[i]] += x_c[i] */
 typedef struct pa_transfer pa_transfer;

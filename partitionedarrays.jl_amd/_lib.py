@@ -126,6 +126,7 @@ _SIGS = {
     "pa_rowset_destroy": [P],
     "pa_gs_color_update": [P, P, P, P, P],
     "pa_gs_color_sweep": [P, cint, P, P, P, cint],
+    "pa_gs_color_symmetric_sweep": [P, cint, P, P, P, cint],
     "pa_transfer_create": [P, i64, P, cint, PP],
     "pa_transfer_destroy": [P],
     "pa_transfer_attach_rows": [P, P],

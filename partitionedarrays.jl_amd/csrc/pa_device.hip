@@ -1746,10 +1746,8 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
 // block blocks[k] (n_own x n_local, every stored entry of those rows); its launch gathers from x and updates x's own
 // rows of that colour in place, x[row] += (b[row] - (A x)[row]) / diag[row].  Colours run in ascending order
 // (backward != 0: descending), one launch each on the compute stream.
-extern "C" int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_vec *b, const pa_vec *diag,
-                                 int backward) {
+static int gs_color_check(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_vec *b, const pa_vec *diag) {
   PA_REQUIRE(blocks && x && b && diag && n_colors >= 0, "bad arguments");
-  pa_ctx *c = x->ctx;
   for (int k = 0; k < n_colors; ++k) {
     const pa_csr *A = blocks[k];
     PA_REQUIRE(A != nullptr, "colour block %d is NULL", k);
@@ -1759,39 +1757,80 @@ extern "C" int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x,
   }
   PA_REQUIRE(b->n_own == x->n_own && diag->n_own == x->n_own, "b / diag own sizes differ from x");
   PA_REQUIRE(x->d != b->d && x->d != diag->d, "x aliases b or diag");
-  PA_HIP(hipSetDevice(c->device));
-  for (int i = 0; i < n_colors; ++i) {
-    const pa_csr *A = blocks[backward ? n_colors - 1 - i : i];
-    if (A->n_chunks == 0) continue;
-    const int cpx = (int)((A->n_chunks + 7) / 8);
+  return PA_OK;
+}
+
+// one colour: x[row] += (b[row] - (A x)[row]) / diag[row] on the rows of the block, in place
+static void gs_color_launch(pa_ctx *c, const pa_csr *A, pa_vec *x, const pa_vec *b, const pa_vec *diag) {
+  if (A->n_chunks == 0) return;
+  const int cpx = (int)((A->n_chunks + 7) / 8);
 #define PA_LAUNCH_GS(C16, PAT, VD)                                                                                       \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 1, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
                      (const double *)nullptr, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, \
                      1.0, 0.0, x->d, (const double *)b->d, (const double *)diag->d, A->d_code, A->d_dict,                  \
                      (const int *)nullptr, (int)A->n_cols - 1)
-    const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
-    if (A->use_vdict) {
-      switch (sel_) {
-        case 5: PA_LAUNCH_GS(true, 2, true); break;
-        case 4: PA_LAUNCH_GS(false, 2, true); break;
-        case 3: PA_LAUNCH_GS(true, 1, true); break;
-        case 2: PA_LAUNCH_GS(false, 1, true); break;
-        case 1: PA_LAUNCH_GS(true, 0, true); break;
-        default: PA_LAUNCH_GS(false, 0, true); break;
-      }
-    } else {
-      switch (sel_) {
-        case 5: PA_LAUNCH_GS(true, 2, false); break;
-        case 4: PA_LAUNCH_GS(false, 2, false); break;
-        case 3: PA_LAUNCH_GS(true, 1, false); break;
-        case 2: PA_LAUNCH_GS(false, 1, false); break;
-        case 1: PA_LAUNCH_GS(true, 0, false); break;
-        default: PA_LAUNCH_GS(false, 0, false); break;
-      }
+  const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
+  if (A->use_vdict) {
+    switch (sel_) {
+      case 5: PA_LAUNCH_GS(true, 2, true); break;
+      case 4: PA_LAUNCH_GS(false, 2, true); break;
+      case 3: PA_LAUNCH_GS(true, 1, true); break;
+      case 2: PA_LAUNCH_GS(false, 1, true); break;
+      case 1: PA_LAUNCH_GS(true, 0, true); break;
+      default: PA_LAUNCH_GS(false, 0, true); break;
     }
-#undef PA_LAUNCH_GS
+  } else {
+    switch (sel_) {
+      case 5: PA_LAUNCH_GS(true, 2, false); break;
+      case 4: PA_LAUNCH_GS(false, 2, false); break;
+      case 3: PA_LAUNCH_GS(true, 1, false); break;
+      case 2: PA_LAUNCH_GS(false, 1, false); break;
+      case 1: PA_LAUNCH_GS(true, 0, false); break;
+      default: PA_LAUNCH_GS(false, 0, false); break;
+    }
   }
+#undef PA_LAUNCH_GS
+}
+
+extern "C" int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_vec *b, const pa_vec *diag,
+                                 int backward) {
+  PA_TRY(gs_color_check(blocks, n_colors, x, b, diag));
+  pa_ctx *c = x->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  for (int i = 0; i < n_colors; ++i) gs_color_launch(c, blocks[backward ? n_colors - 1 - i : i], x, b, diag);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+// the first colour of a sweep over x == 0: its rows see (A x)[row] == 0, so the update is b / diag -- the colour launch's own
+// expression with a zero row sum, without reading the block's entries (same bits: x[row] is +0.0, b - (+-0.0) is b)
+__global__ void k_gs_first_color_zero(double *x, const double *__restrict__ b, const double *__restrict__ diag,
+                                      const int32_t *__restrict__ crp, const int32_t *__restrict__ row_ids, int nc) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc || crp[c + 1] == crp[c]) return;
+  const int row = row_ids ? row_ids[c] : c;
+  x[row] = x[row] + (b[row] - 0.0) / diag[row];
+}
+
+// The symmetric sweep of the multicolour smoother in one call: colours 0 .. K-1, then K-2 .. 0.  The backward half starts
+// at K-2: colour K-1 has just been relaxed and nothing it couples to has changed since, so relaxing it again adds
+// (b - A x)[row] / diag[row] == 0 up to the rounding of the first update (rows of one colour are not coupled).
+// zero_guess != 0: the caller guarantees x == 0 (own and ghost entries); colour 0 then takes the shortcut above.
+extern "C" int pa_gs_color_symmetric_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_vec *b, const pa_vec *diag,
+                                           int zero_guess) {
+  PA_TRY(gs_color_check(blocks, n_colors, x, b, diag));
+  pa_ctx *c = x->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  for (int k = 0; k < n_colors; ++k) {
+    const pa_csr *A = blocks[k];
+    if (k == 0 && zero_guess) {
+      if (A->n_crows > 0)
+        hipLaunchKernelGGL(k_gs_first_color_zero, dim3((unsigned)((A->n_crows + 255) / 256)), dim3(256), 0, c->s[0], x->d,
+                           (const double *)b->d, (const double *)diag->d, A->d_crp, A->d_row_ids, (int)A->n_crows);
+    } else gs_color_launch(c, A, x, b, diag);
+  }
+  for (int k = n_colors - 2; k >= 0; --k) gs_color_launch(c, blocks[k], x, b, diag);
   PA_HIP(hipGetLastError());
   return PA_OK;
 }

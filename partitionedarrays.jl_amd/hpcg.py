@@ -204,9 +204,15 @@ class ColoredGaussSeidelSpMV:
     def step_(self, x, b, zero_guess=False):
         if not zero_guess:
             consistent_(x).wait()
-        for backward in (0, 1):        # forward then backward sweep; one call queues the 8 colour launches
-            pmap(lambda p, xv, bv: L.call("pa_gs_color_sweep", p[2], len(p[0]), xv.h, bv.h, p[1].h, backward),
-                 self.parts, x.vector_partition, b.vector_partition)
+        if os.environ.get("PA_GS_SYMMETRIC", "1") == "0":      # (the two halves as separate calls, every colour twice)
+            for backward in (0, 1):
+                pmap(lambda p, xv, bv: L.call("pa_gs_color_sweep", p[2], len(p[0]), xv.h, bv.h, p[1].h, backward),
+                     self.parts, x.vector_partition, b.vector_partition)
+            return x
+        # one call queues the 15 colour launches of the symmetric sweep: 0..7, then 6..0 (the last colour is not relaxed twice
+        # in a row); on a zero guess (the callers zero x first) colour 0 is b / d without reading its block
+        pmap(lambda p, xv, bv: L.call("pa_gs_color_symmetric_sweep", p[2], len(p[0]), xv.h, bv.h, p[1].h, 1 if zero_guess else 0),
+             self.parts, x.vector_partition, b.vector_partition)
         return x
 
 

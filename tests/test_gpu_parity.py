@@ -1870,33 +1870,51 @@ def test_v_cycle_replayed_from_a_hipgraph_is_bit_identical():
     assert outs[0][4] == 0 and outs[1][4] == 1
 
 
-def test_fused_colour_sweep_equals_spmv_plus_update():
-    """pa_gs_color_sweep (update fused into the row-split kernel's epilogue) == pa_spmv(beta=1) into a zeroed t followed
-    by pa_gs_color_update, colour by colour, bit for bit; 2 parts so that ghost columns take part."""
+def test_fused_colour_sweep_equals_spmv_plus_update(monkeypatch):
+    """The multicolour smoother's sweeps (update fused into the row-split kernel's epilogue) == pa_spmv(beta=1) into a zeroed
+    t followed by pa_gs_color_update, colour by colour, bit for bit; 2 parts so that ghost columns take part.  Both forms of
+    the symmetric sweep: pa_gs_color_symmetric_sweep (colours 0..7, 6..0: the last colour is not relaxed twice in a row) and
+    the two pa_gs_color_sweep halves (PA_GS_SYMMETRIC=0: 0..7, 7..0); the two differ by the rounding of one update; on a
+    zero guess the first colour's shortcut (b / d without reading the block) leaves every bit where the launch puts it."""
     import pa_amd._lib as L
     A, b = pa.build_p_matrix(ranks(2), 12, 10, 8, 24, 10, 8, 2, 1, 1, keep_host=True)
     S = pa.ColoredGaussSeidelSpMV(A)
     xf = lambda i: ((i.get_local_to_global() * 7919) % 13 - 6.0) / 8.0
-    x1 = pa.pvector_from_function(xf, A.col_partition)
-    x2 = pa.pvector_from_function(xf, A.col_partition)
-    S.step_(x1, b)
-    pa.consistent_(x2).wait()
-    for (blocks, diag, _, color), xv, bv in zip(S.parts.items, x2.vector_partition.items, b.vector_partition.items):
-        t = pa.DeviceVector(xv.n_own, 0)
-        sets = []
-        for k in range(len(blocks)):
-            ids = np.ascontiguousarray(np.nonzero(color == k)[0] + 1, np.int32)
-            rs = C.c_void_p()
-            L.call("pa_rowset_create", pa.context().h, len(ids), L.ptr(ids), 1, C.byref(rs))
-            sets.append(rs)
-        for order in (range(len(blocks)), range(len(blocks) - 1, -1, -1)):
-            for k in order:
-                L.call("pa_spmv", blocks[k].h, xv.h, L.SEG_LOCAL, t.h, L.SEG_OWN, 1.0, 1.0)
-                L.call("pa_gs_color_update", sets[k], xv.h, bv.h, t.h, diag.h)
-        for rs in sets:
-            L.call("pa_rowset_destroy", rs)
-    for u, v in zip(x1.own_values().items, x2.own_values().items):
-        assert np.array_equal(u, v) and np.all(np.isfinite(u))
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PA_GS_SYMMETRIC", mode)
+        x1 = pa.pvector_from_function(xf, A.col_partition)
+        x2 = pa.pvector_from_function(xf, A.col_partition)
+        S.step_(x1, b)
+        pa.consistent_(x2).wait()
+        for (blocks, diag, _, color), xv, bv in zip(S.parts.items, x2.vector_partition.items, b.vector_partition.items):
+            t = pa.DeviceVector(xv.n_own, 0)
+            sets = []
+            for k in range(len(blocks)):
+                ids = np.ascontiguousarray(np.nonzero(color == k)[0] + 1, np.int32)
+                rs = C.c_void_p()
+                L.call("pa_rowset_create", pa.context().h, len(ids), L.ptr(ids), 1, C.byref(rs))
+                sets.append(rs)
+            K = len(blocks)
+            back = range(K - 2, -1, -1) if mode == "1" else range(K - 1, -1, -1)
+            for order in (range(K), back):
+                for k in order:
+                    L.call("pa_spmv", blocks[k].h, xv.h, L.SEG_LOCAL, t.h, L.SEG_OWN, 1.0, 1.0)
+                    L.call("pa_gs_color_update", sets[k], xv.h, bv.h, t.h, diag.h)
+            for rs in sets:
+                L.call("pa_rowset_destroy", rs)
+        for u, v in zip(x1.own_values().items, x2.own_values().items):
+            assert np.array_equal(u, v) and np.all(np.isfinite(u))
+        results[mode] = [u.copy() for u in x1.own_values().items]
+    for u, v in zip(results["1"], results["0"]):
+        assert np.allclose(u, v, rtol=1e-13, atol=1e-15) and np.any(u != 0.0)
+    monkeypatch.setenv("PA_GS_SYMMETRIC", "1")
+    z1, z2 = pa.pzeros(A.col_partition), pa.pzeros(A.col_partition)
+    S.step_(z1, b, zero_guess=True)                                  # colour 0: x = b / d
+    for p, xv, bv in zip(S.parts.items, z2.vector_partition.items, b.vector_partition.items):
+        L.call("pa_gs_color_symmetric_sweep", p[2], len(p[0]), xv.h, bv.h, p[1].h, 0)      # colour 0 through its block
+    for u, v in zip(z1.own_values().items, z2.own_values().items):
+        assert np.array_equal(u, v) and np.any(u != 0.0)
     assert len(S.parts.items[0][0]) == 8
 
 
