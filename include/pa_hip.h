@@ -145,6 +145,9 @@ int pa_ctx_keep_raw_columns(pa_ctx *ctx, int on);
 int pa_csr_has_raw_columns(const pa_csr *A, int *yes);
 int pa_csr_drop_raw_columns(pa_csr *A);
 int pa_csr_select_rows(const pa_csr *own_own, const pa_csr *own_ghost, const int32_t *mask, int32_t n_sel, pa_csr **out);
+/* out[k] = the rows with mask == k restricted to their entries in own columns j with 0 <= mask[j] < k (NULL when there are
+ * none: k = 0 always); n_cols = the column count the blocks get (the part's own + ghost columns) */
+int pa_csr_select_rows_lower(const pa_csr *own_own, int64_t n_cols, const int32_t *mask, int32_t n_sel, pa_csr **out);
 int pa_csr_diagonal(const pa_csr *own_own, pa_vec *d);
 /* pa_gs_create (below) for the sequential ordering from the part's blocks in HBM: the unsplit CSR, the diagonal and the
  * dependency levels of the sweep (PartitionedSolvers/src/smoothers.jl:144-160) computed on the device, verified against
@@ -426,6 +429,11 @@ int pa_gs_color_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_v
  * launch's own expression with a zero row sum, without reading the block. */
 int pa_gs_color_symmetric_sweep(pa_csr *const *blocks, int n_colors, pa_vec *x, const pa_vec *b, const pa_vec *diag,
                                 int zero_guess);
+/* The zero-guess sweep with lower[k] = colour k's rows restricted to their entries in columns of a colour < k
+ * (pa_csr_select_rows_lower; NULL: the full block is used): the forward half reads only those -- every other entry meets
+ * an x that is still zero, and +-0.0 products change no bit of a row sum.  Same bits as zero_guess = 1 above. */
+int pa_gs_color_symmetric_sweep_zero(pa_csr *const *blocks, pa_csr *const *lower, int n_colors, pa_vec *x, const pa_vec *b,
+                                     const pa_vec *diag);
 /* restrict! / prolongate! (HPCG/src/mg_preconditioner.jl:224-251): f2c[i] = fine row of coarse row i.
  *   restrict  : r_c[i] = r_f[f2c[i]] - Axf[f2c[i]]          prolongate: x_f[f2c[i]] += x_c[i] */
 typedef struct pa_transfer pa_transfer;

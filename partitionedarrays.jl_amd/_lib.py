@@ -99,6 +99,7 @@ _SIGS = {
     "pa_csr_has_raw_columns": [P, C.POINTER(cint)],
     "pa_csr_drop_raw_columns": [P],
     "pa_csr_select_rows": [P, P, P, C.c_int32, P],
+    "pa_csr_select_rows_lower": [P, i64, P, C.c_int32, P],
     "pa_csr_diagonal": [P, P],
     "pa_gs_create_from_blocks": [P, P, cint, C.POINTER(P)],
     "pa_csr_greedy_coloring": [P, P, C.POINTER(C.c_int32)],
@@ -127,6 +128,7 @@ _SIGS = {
     "pa_gs_color_update": [P, P, P, P, P],
     "pa_gs_color_sweep": [P, cint, P, P, P, cint],
     "pa_gs_color_symmetric_sweep": [P, cint, P, P, P, cint],
+    "pa_gs_color_symmetric_sweep_zero": [P, P, cint, P, P, P],
     "pa_transfer_create": [P, i64, P, cint, PP],
     "pa_transfer_destroy": [P],
     "pa_transfer_attach_rows": [P, P],

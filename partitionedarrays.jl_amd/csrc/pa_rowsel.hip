@@ -80,6 +80,37 @@ __global__ void kr_fill(const int32_t *__restrict__ mask, int k, int n, const in
   }
 }
 
+// the same for the entries of a selected row whose (own) column has a LOWER mask value than the row (mask in 0..k-1): what a
+// forward sweep over x == 0 can see when it reaches colour k.  One lane per row: the entries keep their order.
+__global__ void kr_len_lower(const int32_t *__restrict__ mask, int k, const int32_t *__restrict__ start, const int32_t *__restrict__ len,
+                             const int32_t *__restrict__ col, int n, int32_t *__restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > n) return;
+  int cnt = 0;
+  if (r < n && mask[r] == k)
+    for (int p = start[r], e = p + len[r]; p < e; ++p) {
+      const int m = mask[col[p]];
+      cnt += m >= 0 && m < k;
+    }
+  out[r] = cnt;
+}
+
+__global__ void kr_fill_lower(const int32_t *__restrict__ mask, int k, int n, const int32_t *__restrict__ rp_out,
+                              const int32_t *__restrict__ start, const int32_t *__restrict__ len, const int32_t *__restrict__ col,
+                              const double *__restrict__ val, int32_t *__restrict__ col_out, double *__restrict__ val_out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n || mask[r] != k) return;
+  int dst = rp_out[r];
+  for (int p = start[r], e = p + len[r]; p < e; ++p) {
+    const int m = mask[col[p]];
+    if (m >= 0 && m < k) {
+      col_out[dst] = col[p];
+      val_out[dst] = val[p];
+      ++dst;
+    }
+  }
+}
+
 __global__ void kr_flag(const int32_t *__restrict__ len, int n, int32_t *__restrict__ flag) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r <= n) flag[r] = r < n && len[r] > 0;
@@ -153,8 +184,10 @@ static int spans_of(pa_ctx *c, scratch &sc, const pa_csr *A, int64_t n, row_span
 
 // out[k] (k = 0..n_sel-1) = the rows r of the part with mask[r] == k (mask: n_rows host entries in -1..n_sel-1; -1 = in no
 // block), columns: oo's, then oh's shifted by oo's column count.  oh may be NULL (a part without ghost columns).
-extern "C" int pa_csr_select_rows(const pa_csr *oo, const pa_csr *oh, const int32_t *mask, int32_t n_sel, pa_csr **out) {
+static int select_rows_impl(const pa_csr *oo, const pa_csr *oh, const int32_t *mask, int32_t n_sel, pa_csr **out, bool lower,
+                            int64_t n_cols_total) {
   PA_REQUIRE(oo && mask && out && n_sel > 0 && n_sel <= 64, "bad arguments");
+  PA_REQUIRE(!lower || oo->n_rows == oo->n_cols, "the own|own block is not square");
   PA_REQUIRE(!oo->next && !(oh && oh->next), "a block of 2^31 stored entries or more (a chain of slabs) takes the host route");
   PA_REQUIRE(!oh || (oh->n_rows == oo->n_rows && oh->ctx == oo->ctx), "the own|ghost block does not match the own|own block");
   pa_ctx *c = oo->ctx;
@@ -162,7 +195,8 @@ extern "C" int pa_csr_select_rows(const pa_csr *oo, const pa_csr *oh, const int3
   const int32_t *col_a = raw_columns(oo), *col_b = oh ? raw_columns(oh) : nullptr;
   PA_REQUIRE(oo->nnz == 0 || col_a, "the own|own block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
   PA_REQUIRE(!oh || col_b, "the own|ghost block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
-  const int64_t n = oo->n_rows, n_cols = oo->n_cols + (oh ? oh->n_cols : 0);
+  const int64_t n = oo->n_rows, n_cols = n_cols_total >= 0 ? n_cols_total : oo->n_cols + (oh ? oh->n_cols : 0);
+  PA_REQUIRE(n_cols >= oo->n_cols, "fewer columns than the own|own block has");
   PA_REQUIRE(oo->nnz + (oh ? oh->nnz : 0) < (int64_t)2147483000 && n_cols < (int64_t)2147483000, "too large for Int32 offsets");
   for (int k = 0; k < n_sel; ++k) out[k] = nullptr;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -205,10 +239,18 @@ extern "C" int pa_csr_select_rows(const pa_csr *oo, const pa_csr *oh, const int3
   PA_TRY(pa_dev_alloc(c, (void **)&d_col, sizeof(int32_t) * (most + 8), PA_MEM_MATRIX));
   int st = pa_dev_alloc(c, (void **)&d_val, sizeof(double) * (most + 8), PA_MEM_MATRIX);
   for (int k = 0; k < n_sel && st == PA_OK; ++k) {
-    hipLaunchKernelGGL(kr_len, grid1(n + 1), dim3(256), 0, s, d_mask, k, A.len, oh ? B.len : nullptr, (int)n, d_len);
+    if (lower) hipLaunchKernelGGL(kr_len_lower, grid1(n + 1), dim3(256), 0, s, d_mask, k, A.start, A.len, col_a, (int)n, d_len);
+    else hipLaunchKernelGGL(kr_len, grid1(n + 1), dim3(256), 0, s, d_mask, k, A.len, oh ? B.len : nullptr, (int)n, d_len);
     st = scan_exclusive(sc, s, d_len, d_rp, (size_t)n + 1);
     if (st != PA_OK) break;
-    if (tot[k])
+    if (lower) {                                        // (the subset's size is known only now)
+      int32_t t = 0;
+      st = d2h(s, &t, d_rp + n, 1);
+      if (st != PA_OK) break;
+      tot[k] = (unsigned long long)t;
+      if (t == 0) continue;                             // no block: out[k] stays NULL
+      hipLaunchKernelGGL(kr_fill_lower, grid1(n), dim3(256), 0, s, d_mask, k, (int)n, d_rp, A.start, A.len, col_a, oo->d_val, d_col, d_val);
+    } else if (tot[k])
       hipLaunchKernelGGL(kr_fill, grid1(n * 8), dim3(256), 0, s, d_mask, k, (int)n, d_rp, A.start, A.len, col_a, oo->d_val,
                          oh ? B.start : nullptr, oh ? B.len : nullptr, col_b, oh ? oh->d_val : nullptr, (int)oo->n_cols, d_col, d_val);
     // non-empty rows counted, and compacted when most rows are empty (csr_fill_slab's rule), here: the host gets the final
@@ -238,6 +280,17 @@ extern "C" int pa_csr_select_rows(const pa_csr *oo, const pa_csr *oh, const int3
     for (int k = 0; k < n_sel; ++k)
       if (out[k]) { pa_csr_destroy(out[k]); out[k] = nullptr; }
   return st;
+}
+
+extern "C" int pa_csr_select_rows(const pa_csr *oo, const pa_csr *oh, const int32_t *mask, int32_t n_sel, pa_csr **out) {
+  return select_rows_impl(oo, oh, mask, n_sel, out, false, -1);
+}
+
+// out[k] = the rows with mask == k again, but only their entries in own columns j with 0 <= mask[j] < k (no ghost columns):
+// all a forward multicolour sweep over x == 0 reads when it reaches colour k.  out[k] is NULL when there is no such entry
+// (k == 0 always).  n_cols: the column count the blocks get (own + ghost columns of the part, so that they take the same x).
+extern "C" int pa_csr_select_rows_lower(const pa_csr *oo, int64_t n_cols, const int32_t *mask, int32_t n_sel, pa_csr **out) {
+  return select_rows_impl(oo, nullptr, mask, n_sel, out, true, n_cols);
 }
 
 // d[r] = the stored (r,r) entry of the own|own block (0.0 when the row holds none): the smoother's diagonal

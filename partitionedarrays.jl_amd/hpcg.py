@@ -178,7 +178,12 @@ class ColoredGaussSeidelSpMV:
                 d = DeviceVector(n, 0)
                 L.call("pa_csr_diagonal", dev.own_own.h, d.h)
                 handles = (C.c_void_p * len(blocks))(*[blk.h for blk in blocks])
-                return blocks, d, handles, color
+                lower = lower_handles = None
+                if os.environ.get("PA_GS_LOWER", "1") != "0":
+                    # what the forward half of a zero-guess sweep reads: colour k's rows x columns of a lower colour
+                    lower = DeviceCSR.select_rows(dev.own_own, None, color, K, lower_cols=c.n_local)
+                    lower_handles = (C.c_void_p * K)(*[blk.h if blk is not None else None for blk in lower])
+                return blocks, d, handles, color, lower, lower_handles
             oo, oh = h
             arr = lambda xs: (C.c_void_p * K)(*[x.ctypes.data for x in xs])
             rps = [np.empty(n + 1, np.int32) for _ in range(K)]                  # (one native, threaded pass for all colours)
@@ -193,7 +198,7 @@ class ColoredGaussSeidelSpMV:
                    arr([s.colval for s in subs]), arr([s.nzval for s in subs]), L.ptr(diag))
             blocks = [DeviceCSR(s) for s in subs]
             handles = (C.c_void_p * len(blocks))(*[blk.h for blk in blocks])
-            return blocks, DeviceVector(n, 0).upload(diag), handles, color
+            return blocks, DeviceVector(n, 0).upload(diag), handles, color, None, None
 
         hb = A.host_blocks if A.host_blocks is not None else pmap(lambda _r: None, A.row_partition)
         self.parts = pmap(make, hb, A.row_partition, A.col_partition, A.matrix_partition)
@@ -211,8 +216,12 @@ class ColoredGaussSeidelSpMV:
             return x
         # one call queues the 15 colour launches of the symmetric sweep: 0..7, then 6..0 (the last colour is not relaxed twice
         # in a row); on a zero guess (the callers zero x first) colour 0 is b / d without reading its block
-        pmap(lambda p, xv, bv: L.call("pa_gs_color_symmetric_sweep", p[2], len(p[0]), xv.h, bv.h, p[1].h, 1 if zero_guess else 0),
-             self.parts, x.vector_partition, b.vector_partition)
+        def sweep(p, xv, bv):
+            if zero_guess and p[5] is not None:        # (the forward half reads the lower-colour blocks only)
+                L.call("pa_gs_color_symmetric_sweep_zero", p[2], p[5], len(p[0]), xv.h, bv.h, p[1].h)
+            else:
+                L.call("pa_gs_color_symmetric_sweep", p[2], len(p[0]), xv.h, bv.h, p[1].h, 1 if zero_guess else 0)
+        pmap(sweep, self.parts, x.vector_partition, b.vector_partition)
         return x
 
 

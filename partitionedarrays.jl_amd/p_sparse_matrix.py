@@ -153,16 +153,23 @@ class DeviceCSR:
         L.call("pa_csr_drop_raw_columns", self.h)
 
     @staticmethod
-    def select_rows(own_own, own_ghost, mask, n_sel):
+    def select_rows(own_own, own_ghost, mask, n_sel, lower_cols=None):
         """pa_csr_select_rows: the n_sel blocks made of the rows r with mask[r] == k of own_own | own_ghost (unsplit column
-        order), built on the device."""
+        order), built on the device.  lower_cols = n: pa_csr_select_rows_lower instead -- only the entries in own columns of
+        a lower mask value, blocks of n columns, None where there is no such entry."""
         mask = np.ascontiguousarray(mask, np.int32)
         if mask.shape[0] != own_own.m:
             raise L.PAError("one mask entry per row")
         out = (C.c_void_p * n_sel)()
-        L.call("pa_csr_select_rows", own_own.h, own_ghost.h if own_ghost is not None else None, L.ptr(mask), n_sel, out)
+        if lower_cols is not None:
+            L.call("pa_csr_select_rows_lower", own_own.h, int(lower_cols), L.ptr(mask), n_sel, out)
+        else:
+            L.call("pa_csr_select_rows", own_own.h, own_ghost.h if own_ghost is not None else None, L.ptr(mask), n_sel, out)
         blocks = []
         for k in range(n_sel):
+            if not out[k]:
+                blocks.append(None)
+                continue
             v = [C.c_int64() for _ in range(6)]
             h = C.c_void_p(out[k])
             L.call("pa_csr_info", h, *[C.byref(x) for x in v])

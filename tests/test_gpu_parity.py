@@ -1877,8 +1877,9 @@ def test_fused_colour_sweep_equals_spmv_plus_update(monkeypatch):
     the two pa_gs_color_sweep halves (PA_GS_SYMMETRIC=0: 0..7, 7..0); the two differ by the rounding of one update; on a
     zero guess the first colour's shortcut (b / d without reading the block) leaves every bit where the launch puts it."""
     import pa_amd._lib as L
-    A, b = pa.build_p_matrix(ranks(2), 12, 10, 8, 24, 10, 8, 2, 1, 1, keep_host=True)
+    A, b = pa.build_p_matrix(ranks(2), 12, 10, 8, 24, 10, 8, 2, 1, 1, keep_host=True, keep_raw=True)
     S = pa.ColoredGaussSeidelSpMV(A)
+    assert all(p[5] is not None and p[4][0] is None and all(q is not None for q in p[4][1:]) for p in S.parts.items)
     xf = lambda i: ((i.get_local_to_global() * 7919) % 13 - 6.0) / 8.0
     results = {}
     for mode in ("1", "0"):
@@ -1887,7 +1888,7 @@ def test_fused_colour_sweep_equals_spmv_plus_update(monkeypatch):
         x2 = pa.pvector_from_function(xf, A.col_partition)
         S.step_(x1, b)
         pa.consistent_(x2).wait()
-        for (blocks, diag, _, color), xv, bv in zip(S.parts.items, x2.vector_partition.items, b.vector_partition.items):
+        for (blocks, diag, _, color, *_lower), xv, bv in zip(S.parts.items, x2.vector_partition.items, b.vector_partition.items):
             t = pa.DeviceVector(xv.n_own, 0)
             sets = []
             for k in range(len(blocks)):
@@ -1910,7 +1911,7 @@ def test_fused_colour_sweep_equals_spmv_plus_update(monkeypatch):
         assert np.allclose(u, v, rtol=1e-13, atol=1e-15) and np.any(u != 0.0)
     monkeypatch.setenv("PA_GS_SYMMETRIC", "1")
     z1, z2 = pa.pzeros(A.col_partition), pa.pzeros(A.col_partition)
-    S.step_(z1, b, zero_guess=True)                                  # colour 0: x = b / d
+    S.step_(z1, b, zero_guess=True)                                  # colour 0: x = b / d; colours 1..7 forward: their lower-colour entries only
     for p, xv, bv in zip(S.parts.items, z2.vector_partition.items, b.vector_partition.items):
         L.call("pa_gs_color_symmetric_sweep", p[2], len(p[0]), xv.h, bv.h, p[1].h, 0)      # colour 0 through its block
     for u, v in zip(z1.own_values().items, z2.own_values().items):
