@@ -158,6 +158,12 @@ int pa_gs_create_from_blocks(const pa_csr *own_own, const pa_csr *own_ghost, int
  * neighbour j < r has, computed by rounds on the device and verified against that definition; PA_ERR_ARG when the pattern
  * is not structurally symmetric (colour on the host then). */
 int pa_csr_greedy_coloring(const pa_csr *own_own, int32_t *color, int32_t *n_colors);
+/* affinity[k] = the mean number of stored entries of a colour-k row whose column is one of kept_rows (0-based own rows: the
+ * fine rows a coarse grid keeps).  A multicolour smoother inside a multigrid cycle sweeps its colours in order of decreasing
+ * affinity, so that the kept rows' own colour sits at the turn of the symmetric sweep, not at its end (where the residual
+ * the restriction injects would be zero up to rounding). */
+int pa_csr_color_affinity(const pa_csr *own_own, const int32_t *color, int32_t n_colors, const int32_t *kept_rows, int64_t n_kept,
+                          double *affinity);
 /* HPCG's 27-point operator of one part (HPCG/src/sparse_matrix.jl:28-122), own_own block and right-hand side, generated
  * in HBM: the arrays pa_host_hpcg_split_csr writes (oo_*, b), no host copy, no upload.  nx,ny,nz: the part's box; gnx,gny,gnz:
  * the global grid; gix0,giy0,giz0: global coordinates (1-based) of the part's first node.  b may be NULL. */

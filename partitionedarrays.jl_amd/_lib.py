@@ -103,6 +103,7 @@ _SIGS = {
     "pa_csr_diagonal": [P, P],
     "pa_gs_create_from_blocks": [P, P, cint, C.POINTER(P)],
     "pa_csr_greedy_coloring": [P, P, C.POINTER(C.c_int32)],
+    "pa_csr_color_affinity": [P, P, C.c_int32, P, i64, P],
     "pa_hpcg_own_block_create": [P] + [i64] * 9 + [C.POINTER(P), P],
     "pa_hpcg_rhs": [P] + [i64] * 9 + [P],
     "pa_coo_assemble": [P, i64, P, P, P, C.c_int32, P, P, P, P, P, P, i64, P, cint, C.POINTER(P)],

@@ -659,3 +659,70 @@ extern "C" int pa_hpcg_rhs(pa_ctx *c, int64_t nx, int64_t ny, int64_t nz, int64_
   PA_HIP(hipStreamSynchronize(c->s[0]));
   return PA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// In which order to sweep the colours of a multicolour smoother inside a multigrid cycle: affinity[k] = the mean number of
+// stored entries of a colour-k row whose column is a row the coarse grid keeps.  Sweeping in order of decreasing affinity
+// puts the kept rows' own colour at the turn of the symmetric sweep instead of at its end, where their residual -- all the
+// restriction injects -- would be zero up to rounding (hpcg.py, ColoredGaussSeidelSpMV).
+// ------------------------------------------------------------------------------------------------
+__global__ void ka_mark(const int32_t *__restrict__ rows, int n_rows, int n, int32_t *__restrict__ mark) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_rows && rows[i] >= 0 && rows[i] < n) mark[rows[i]] = 1;
+}
+
+__global__ void ka_affinity(const int32_t *__restrict__ color, const int32_t *__restrict__ mark, const int32_t *__restrict__ start,
+                            const int32_t *__restrict__ len, const int32_t *__restrict__ col, int n, int n_colors,
+                            unsigned long long *__restrict__ sums, unsigned long long *__restrict__ rows) {
+  __shared__ unsigned long long hs[64], hr[64];
+  if (threadIdx.x < 64) { hs[threadIdx.x] = 0; hr[threadIdx.x] = 0; }
+  __syncthreads();
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) {
+    const int k = color[r];
+    if (k >= 0 && k < n_colors) {
+      unsigned cnt = 0;
+      for (int p = start[r], e = p + len[r]; p < e; ++p) cnt += col[p] < n && mark[col[p]] != 0;
+      atomicAdd(&hs[k], (unsigned long long)cnt);
+      atomicAdd(&hr[k], 1ull);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < n_colors) {
+    if (hs[threadIdx.x]) atomicAdd(&sums[threadIdx.x], hs[threadIdx.x]);
+    if (hr[threadIdx.x]) atomicAdd(&rows[threadIdx.x], hr[threadIdx.x]);
+  }
+}
+
+extern "C" int pa_csr_color_affinity(const pa_csr *oo, const int32_t *color, int32_t n_colors, const int32_t *kept_rows, int64_t n_kept,
+                                     double *affinity) {
+  PA_REQUIRE(oo && color && affinity && n_colors > 0 && n_colors <= 64 && n_kept >= 0 && (n_kept == 0 || kept_rows) && !oo->next, "bad arguments");
+  const int32_t *col = raw_columns(oo);
+  PA_REQUIRE(oo->nnz == 0 || col, "the block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
+  pa_ctx *c = oo->ctx;
+  const int64_t n = oo->n_rows;
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  scratch sc;
+  row_spans A;
+  PA_TRY(spans_of(c, sc, oo, n, A));
+  int32_t *d_color = nullptr, *d_mark = nullptr, *d_rows = nullptr;
+  unsigned long long *d_acc = nullptr;
+  PA_TRY(sc.get(&d_color, (size_t)n + 1));
+  PA_TRY(sc.get(&d_mark, (size_t)n + 1));
+  PA_TRY(sc.get(&d_rows, (size_t)n_kept + 1));
+  PA_TRY(sc.get(&d_acc, 128));
+  PA_HIP(hipMemsetAsync(d_mark, 0, sizeof(int32_t) * (n + 1), s));
+  PA_HIP(hipMemsetAsync(d_acc, 0, sizeof(unsigned long long) * 128, s));
+  if (n) PA_HIP(hipMemcpyAsync(d_color, color, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+  if (n_kept) {
+    PA_HIP(hipMemcpyAsync(d_rows, kept_rows, sizeof(int32_t) * n_kept, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(ka_mark, grid1(n_kept), dim3(256), 0, s, d_rows, (int)n_kept, (int)n, d_mark);
+  }
+  if (n) hipLaunchKernelGGL(ka_affinity, grid1(n), dim3(256), 0, s, d_color, d_mark, A.start, A.len, col, (int)n, (int)n_colors, d_acc, d_acc + 64);
+  unsigned long long acc[128];
+  PA_TRY(d2h(s, acc, d_acc, 128));
+  PA_HIP(hipGetLastError());
+  for (int k = 0; k < n_colors; ++k) affinity[k] = acc[64 + k] ? (double)acc[k] / (double)acc[64 + k] : 0.0;
+  return PA_OK;
+}

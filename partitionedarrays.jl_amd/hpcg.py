@@ -146,7 +146,9 @@ class ColoredGaussSeidelSpMV:
     x[row] += (b - A*x)[row] / d in place (pa_gs_color_sweep: the 8 colour launches of a sweep are one call).
     Same sweep as GaussSeidel(ordering="multicolor") up to rounding (the residual is summed first, then subtracted)."""
 
-    def __init__(self, A):
+    def __init__(self, A, kept_rows=None):
+        """kept_rows(row_indices) -> 0-based own rows of a part that the next coarser grid keeps (or None): decides the order
+        the colours are swept in (see make)."""
         from .p_sparse_matrix import HostCSR, DeviceCSR
         from .p_vector import DeviceVector
         self.A = A
@@ -171,6 +173,32 @@ class ColoredGaussSeidelSpMV:
                 # rows of one colour must not be coupled: the own x own block holds every coupling between own rows
                 L.call("pa_host_greedy_coloring", n, L.ptr(h[0].rowptr), L.ptr(h[0].colval), 1, L.ptr(color), C.byref(ncol))
             K = ncol.value
+            # In which order to sweep the colours.  Greedy colouring finds, for the 27-point operator, colour 0 = the nodes with
+            # all-even coordinates -- exactly the fine nodes the coarse grid keeps -- and a symmetric sweep 0..K-1..0 relaxes
+            # them LAST: the residual the restriction injects is then zero up to rounding and the coarse levels correct
+            # nothing (67 MG-PCG iterations at 256^3 where the reference ordering needs 50).  Rule: colours in order of
+            # decreasing affinity to the kept rows (mean number of a row's entries in kept columns, pa_csr_color_affinity: 8, 4,
+            # 2, 0 for rows with 3, 2, 1, 0 odd coordinates), ties in greedy order -- the kept rows' colour comes at the turn of
+            # the sweep (51 iterations at 128^3, 54 with the plainly reversed order, which serves where no coarse grid is known).
+            mode = os.environ.get("PA_GS_COLOR_ORDER", "affinity")
+            kept = kept_rows(r) if kept_rows is not None else None
+            if mode == "greedy" or K < 2:
+                pass
+            elif mode == "affinity" and on_device and kept is not None and len(kept):
+                aff = np.zeros(K)
+                kr = np.ascontiguousarray(kept, np.int32)
+                L.call("pa_csr_color_affinity", dev.own_own.h, L.ptr(color), K, L.ptr(kr), len(kr), L.ptr(aff))
+                order = np.lexsort((np.arange(K), -aff))              # greedy colours in sweep order
+                pos = np.empty(K, np.int32)
+                pos[order] = np.arange(K, dtype=np.int32)
+                color = pos[color].astype(np.int32)
+            elif mode not in ("affinity", "reverse") and len(mode.split(",")) == K:      # experiments: explicit sweep order
+                order = np.array([int(v) for v in mode.split(",")], np.int32)
+                pos = np.empty(K, np.int32)
+                pos[order] = np.arange(K, dtype=np.int32)
+                color = pos[color].astype(np.int32)
+            else:
+                color = (K - 1 - color).astype(np.int32)
             if on_device:
                 # the colours' rows are cut from the blocks already in HBM (csrc/pa_rowsel.hip): no host copy of the entries,
                 # no second trip over PCIe
@@ -182,6 +210,11 @@ class ColoredGaussSeidelSpMV:
                 if os.environ.get("PA_GS_LOWER", "1") != "0":
                     # what the forward half of a zero-guess sweep reads: colour k's rows x columns of a lower colour
                     lower = DeviceCSR.select_rows(dev.own_own, None, color, K, lower_cols=c.n_local)
+                    # (a lower block must hold an entry for every row of its colour -- a row without one would be skipped by the
+                    #  launch; where it does not, the sweep reads the colour's full block: same bits)
+                    for k in range(K):
+                        if lower[k] is not None and lower[k].info()["n_nonempty_rows"] != blocks[k].info()["n_nonempty_rows"]:
+                            lower[k] = None
                     lower_handles = (C.c_void_p * K)(*[blk.h if blk is not None else None for blk in lower])
                 return blocks, d, handles, color, lower, lower_handles
             oo, oh = h
@@ -267,10 +300,13 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
         A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=not keep_raw, fused=True,
                               keep_raw=keep_raw)
         As[lev - 1], rs[lev - 1] = A, b
-        gss[lev - 1] = ColoredGaussSeidelSpMV(A) if ordering == "multicolor_spmv" else GaussSeidel(A, ordering)
+        op = restrict_operator(nx, ny, nz) if lev > 1 else None
+        if ordering == "multicolor_spmv":
+            gss[lev - 1] = ColoredGaussSeidelSpMV(A, (lambda _r, op=op: op.astype(np.int64) - 1) if op is not None else None)
+        else:
+            gss[lev - 1] = GaussSeidel(A, ordering)
         xs[lev - 1], Axfs[lev - 1] = pzeros(A.col_partition), pzeros(A.col_partition)
         if lev > 1:
-            op = restrict_operator(nx, ny, nz)
 
             def mk(_r):
                 t = C.c_void_p()
