@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_gpu_parity.py -q -x -k "colour or color or multicolor or mg_ or hpcg or gauss or smoother or graph or row_subsets or fused_residual" > gpurun_out/r03z_pytest.log 2>&1
-tail -8 gpurun_out/r03z_pytest.log | cut -c1-300
-timeout 900 python tools/probe/color_order.py 128 2>/dev/null | head -5 | tee gpurun_out/r03z_color_order2.log
-timeout 900 python tools/hpcg_driver.py 1 256 30 > gpurun_out/r03z_hpcg256a.log 2>&1
-tail -1 gpurun_out/r03z_hpcg256a.log | cut -c1-600
-timeout 300 python tools/probe/mg_ab.py child $GRAFT_REPO_ROOT "affinity order" 256 2>/dev/null | grep "^\["
+for f in "fuzz_hpcg.py 200 953000" "fuzz_mul.py 300 950000" "fuzz_spmv.py 150 951000" "fuzz_fem.py 200 952000" "fuzz_cg.py 40 954000" "fuzz_partitions.py 1000 955000"; do
+  set -- $f
+  timeout 900 python tests/fuzz/$1 $2 $3 2>&1 | tail -2 > gpurun_out/r03late_$1.log
+  tail -1 gpurun_out/r03late_$1.log | cut -c1-300
+done
