@@ -740,14 +740,6 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
                          const csr_src &src) {
   const int32_t *col0 = src.col0;          // 0-based, host (NULL when the entries are already on the device)
   const double *nzval = src.nzval;
-  std::vector<int32_t> col_host;           // a host copy of device-resident columns, made only when a host-side step wants one
-  auto host_columns = [&]() -> int {
-    if (col0 || nnz == 0) return PA_OK;
-    col_host.resize(nnz);
-    PA_HIP(hipMemcpy(col_host.data(), src.d_col, sizeof(int32_t) * nnz, hipMemcpyDeviceToHost));
-    col0 = col_host.data();
-    return PA_OK;
-  };
   // non-empty rows; compact when most rows are empty (the own_ghost block: only boundary rows)
   const bool tm_ = getenv("PA_SETUP_TIMING") != nullptr;   // stderr: seconds per phase of this function
   auto t0_ = std::chrono::steady_clock::now();
