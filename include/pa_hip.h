@@ -130,6 +130,22 @@ int pa_coo_assembly_blocks(pa_coo_assembly *h, pa_csr **own_own, pa_csr **own_gh
 /* 1-based host copies of a block (which: 0 own_own, 1 own_ghost): rowptr[n_own_rows + 1], colval / nzval[nnz] */
 int pa_coo_assembly_download(const pa_coo_assembly *h, int which, int32_t *rowptr, int32_t *colval, double *nzval);
 int pa_coo_assembly_destroy(pa_coo_assembly *h);
+/* The disassembled route -- psparse(I,J,V,rows,cols) with the default flags, then assemble (src/p_sparse_matrix.jl:1150-1219,
+ * 1590-1756): a part's triplets may name rows other parts own.  pa_coo_subassemble: the sub-assembled local matrix (ghost rows
+ * and ghost columns numbered in first-seen order, duplicates added in input order); the own rows stay in HBM, the ghost rows
+ * -- gids, and entries sorted by (0-based ghost row, 0-based local column [own | ghost]) -- come back through
+ * pa_coo_subassembly_ghost_rows (ghost columns: pa_coo_assembly_ghosts) for the caller to send to their owners.
+ * pa_coo_assemble_finish: the own rows' entries in CSR order followed by the n_rcv triplets (global ids) that arrived, through
+ * the assembled route: the blocks and final ghost columns of setup_own_triplets + union_ghost + finalize_values (:1656-1723),
+ * read with pa_coo_assembly_info/_ghosts/_blocks/_download. */
+int pa_coo_subassemble(pa_ctx *ctx, int64_t count, const int64_t *I, const int64_t *J, const double *V, int32_t D,
+                       const int64_t *n_rows_global, const int64_t *row_lo, const int64_t *row_hi, const int64_t *n_cols_global,
+                       const int64_t *col_lo, const int64_t *col_hi, pa_coo_assembly **out);
+int pa_coo_subassembly_info(const pa_coo_assembly *h, int64_t *n_ghost_rows, int64_t *n_ghost_cols, int64_t *n_own_entries,
+                            int64_t *n_ghost_row_entries);
+int pa_coo_subassembly_ghost_rows(const pa_coo_assembly *h, int64_t *row_gids, int32_t *g_row, int32_t *g_col, double *g_val);
+int pa_coo_assemble_finish(const pa_coo_assembly *sub, int64_t n_rcv, const int64_t *I, const int64_t *J, const double *V,
+                           pa_coo_assembly **out);
 
 /* ---- blocks made of some rows of a part's matrix, built on the device (csrc/pa_rowsel.hip) ----------------------------
  * What the multigrid set-up of the HPCG driver takes from a level's matrix: the colours of the multicolour Gauss-Seidel

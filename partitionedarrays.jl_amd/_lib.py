@@ -108,6 +108,10 @@ _SIGS = {
     "pa_hpcg_rhs": [P] + [i64] * 9 + [P],
     "pa_coo_assemble": [P, i64, P, P, P, C.c_int32, P, P, P, P, P, P, i64, P, cint, C.POINTER(P)],
     "pa_coo_assembly_info": [P] + [C.POINTER(i64)] * 5 + [C.POINTER(f64)],
+    "pa_coo_subassemble": [P, i64, P, P, P, C.c_int32, P, P, P, P, P, P, C.POINTER(P)],
+    "pa_coo_subassembly_info": [P] + [C.POINTER(i64)] * 4,
+    "pa_coo_subassembly_ghost_rows": [P, P, P, P, P],
+    "pa_coo_assemble_finish": [P, i64, P, P, P, C.POINTER(P)],
     "pa_coo_assembly_ghosts": [P, P],
     "pa_coo_assembly_blocks": [P, C.POINTER(P), C.POINTER(P)],
     "pa_coo_assembly_download": [P, cint, P, P, P],

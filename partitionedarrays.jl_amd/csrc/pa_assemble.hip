@@ -20,6 +20,8 @@
 // Bit-identical to the host route: tests/test_gpu_parity.py::test_device_side_psparse_equals_the_host_route.
 #include "pa_dev_util.h"
 
+#include <chrono>
+
 #include "pa_setup.h"
 
 using namespace pa_util;
@@ -48,11 +50,14 @@ __device__ __forceinline__ long long own_local(const pa_box &b, long long g) {
 
 // li[e] = local row (0-based) or -1; lj[e] = own local column, -1 (no id), or -2 (a valid id outside the own box: a ghost)
 __global__ void ka_classify(const long long *__restrict__ I, const long long *__restrict__ J, int n, pa_box rows, pa_box cols,
-                            int *__restrict__ li, int *__restrict__ lj, int *__restrict__ is_ghost) {
+                            int *__restrict__ li, int *__restrict__ lj, int *__restrict__ is_ghost, int *__restrict__ is_rghost) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   const long long a = own_local(rows, I[e]);
-  li[e] = a >= 0 ? (int)a : -1;     // rows that are not own are not local at all (the row partition has no ghosts here)
+  // rows that are not own are not local at all when the row partition has no ghosts (assembled = true); the sub-assembled
+  // route (is_rghost != NULL) keeps them as ghost rows, numbered in first-seen order like the ghost columns
+  li[e] = a >= 0 ? (int)a : (a == -1 && is_rghost ? -2 : -1);
+  if (is_rghost) is_rghost[e] = a == -1 ? 1 : 0;
   const long long b = own_local(cols, J[e]);
   lj[e] = b >= 0 ? (int)b : (b == -1 ? -2 : -1);
   is_ghost[e] = b == -1 ? 1 : 0;
@@ -111,10 +116,12 @@ __global__ void ka_occ_rank(const int *__restrict__ spos, const int *__restrict_
 __global__ void ka_keys(const int *__restrict__ li, const int *__restrict__ lj, const int *__restrict__ is_ghost,
                         const int *__restrict__ gscan, const int *__restrict__ occ_rank, int n, int n_known, int n_own_cols,
                         int n_ghost_max, int discover, unsigned long long *__restrict__ key, int *__restrict__ idx,
-                        unsigned char *__restrict__ bad) {
+                        unsigned char *__restrict__ bad, const int *__restrict__ is_rghost, const int *__restrict__ rgscan,
+                        const int *__restrict__ rocc_rank, int n_own_rows) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
   int r = li[e], c = lj[e];
+  if (is_rghost && is_rghost[e]) r = n_own_rows + rocc_rank[rgscan[e]];
   if (is_ghost[e]) {
     const int k = occ_rank[n_known + gscan[e]];
     c = (discover || k < n_known) ? n_own_cols + k : -1;       // (a column the given partition does not know: not local)
@@ -178,87 +185,116 @@ struct pa_coo_assembly {
   int *oo_rp = nullptr, *oo_col = nullptr, *oh_rp = nullptr, *oh_col = nullptr;
   double *oo_val = nullptr, *oh_val = nullptr;
   double ms = 0;
+  // the sub-assembled route (pa_coo_subassemble): ghost rows in first-seen order; the compressed local matrix as sorted
+  // (row, column, value) entries -- the own rows' prefix stays in HBM for pa_coo_assemble_finish, the ghost rows' suffix (the
+  // part's surface) is on the host for the exchange with the rows' owners
+  bool sub = false;
+  pa_box rows_box{}, cols_box{};
+  std::vector<int64_t> row_ghost_gids;
+  int *s_row = nullptr, *s_col = nullptr;
+  double *s_val = nullptr;
+  int64_t n_prefix = 0;
+  std::vector<int32_t> g_row, g_col;               // suffix: 0-based ghost row, 0-based local column (own, then ghosts)
+  std::vector<double> g_val;
 };
 
 static void assembly_free(pa_coo_assembly *h) {
   if (!h) return;
-  for (void *p : {(void *)h->oo_rp, (void *)h->oo_col, (void *)h->oh_rp, (void *)h->oh_col, (void *)h->oo_val, (void *)h->oh_val}) (void)hipFree(p);
+  for (void *p : {(void *)h->oo_rp, (void *)h->oo_col, (void *)h->oh_rp, (void *)h->oh_col, (void *)h->oo_val, (void *)h->oh_val,
+                  (void *)h->s_row, (void *)h->s_col, (void *)h->s_val}) (void)hipFree(p);
   delete h;
 }
 
-static int assemble_impl(pa_ctx *c, pa_coo_assembly *h, int64_t count, const int64_t *I, const int64_t *J, const double *V,
-                         const pa_box &rows, const pa_box &cols, int64_t n_known, const int64_t *known, int discover) {
+// ids (gids of the entries flagged in isg, in input order, after n_known known ones) -> every occurrence's number in
+// first-seen order (occ_rank[n_known + running index]) and, when wanted, the list of distinct gids in that order
+static int number_first_seen(scratch &sc, hipStream_t s, const long long *dIDs, const int *isg, const int *gscan, int count, int n_occ,
+                             int64_t n_known, const int64_t *known, bool want_list, int **occ_rank_out, std::vector<int64_t> &gids,
+                             int *n_unique_out) {
+  const int n_all = (int)n_known + n_occ;
+  int *occ_rank = nullptr;
+  PA_TRY(sc.get(&occ_rank, (size_t)n_all + 1));
+  *occ_rank_out = occ_rank;
+  *n_unique_out = (int)n_known;
+  if (n_all == 0) return PA_OK;
+  unsigned long long *gid = nullptr, *sgid = nullptr;
+  int *pos = nullptr, *spos = nullptr, *head = nullptr, *uscan = nullptr;
+  long long *dknown = nullptr;
+  PA_TRY(sc.get(&gid, n_all));
+  PA_TRY(sc.get(&sgid, n_all));
+  PA_TRY(sc.get(&pos, n_all));
+  PA_TRY(sc.get(&spos, n_all));
+  PA_TRY(sc.get(&head, n_all));
+  PA_TRY(sc.get(&uscan, n_all));
+  if (n_known) {
+    PA_TRY(sc.get(&dknown, n_known));
+    PA_HIP(hipMemcpyAsync(dknown, known, 8 * (size_t)n_known, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(ka_known_occ, grid1(n_known), dim3(256), 0, s, dknown, (int)n_known, gid, pos);
+  }
+  if (count) hipLaunchKernelGGL(ka_ghost_occ, grid1(count), dim3(256), 0, s, dIDs, isg, gscan, count, (int)n_known, gid, pos);
+  PA_TRY(sort_pairs<unsigned long long>(sc, s, gid, sgid, pos, spos, (size_t)n_all));
+  hipLaunchKernelGGL(ka_heads_u64, grid1(n_all), dim3(256), 0, s, sgid, n_all, head);
+  PA_TRY(scan_inclusive(sc, s, head, uscan, (size_t)n_all));
+  int n_unique = 0;
+  PA_TRY(d2h(s, &n_unique, uscan + (n_all - 1), 1));
+  int *first_pos = nullptr, *uid = nullptr, *first_pos_s = nullptr, *uid_s = nullptr, *rank = nullptr;
+  long long *ugid = nullptr, *ghost_gid = nullptr;
+  PA_TRY(sc.get(&first_pos, n_unique));
+  PA_TRY(sc.get(&uid, n_unique));
+  PA_TRY(sc.get(&first_pos_s, n_unique));
+  PA_TRY(sc.get(&uid_s, n_unique));
+  PA_TRY(sc.get(&rank, n_unique));
+  PA_TRY(sc.get(&ugid, n_unique));
+  PA_TRY(sc.get(&ghost_gid, n_unique));
+  hipLaunchKernelGGL(ka_unique, grid1(n_all), dim3(256), 0, s, sgid, spos, head, uscan, n_all, first_pos, uid, ugid);
+  PA_TRY(sort_pairs<int>(sc, s, first_pos, first_pos_s, uid, uid_s, (size_t)n_unique));
+  hipLaunchKernelGGL(ka_rank, grid1(n_unique), dim3(256), 0, s, uid_s, ugid, n_unique, rank, ghost_gid);
+  hipLaunchKernelGGL(ka_occ_rank, grid1(n_all), dim3(256), 0, s, spos, uscan, rank, n_all, occ_rank);
+  PA_HIP(hipGetLastError());
+  // (the known ghosts must be distinct gids: then they keep the numbers 0 .. n_known-1 they came with)
+  PA_REQUIRE(n_unique >= n_known, "the column partition lists a ghost twice");
+  *n_unique_out = n_unique;
+  if (want_list) {
+    gids.resize(n_unique);
+    PA_TRY(d2h(s, (long long *)gids.data(), ghost_gid, (size_t)n_unique));
+    for (int64_t k = 0; k < n_known; ++k) PA_REQUIRE(gids[k] == known[k], "the column partition lists a ghost twice (or an own id as a ghost)");
+  }
+  for (void *q : {(void *)gid, (void *)sgid, (void *)pos, (void *)spos, (void *)head, (void *)uscan, (void *)first_pos, (void *)uid,
+                  (void *)first_pos_s, (void *)uid_s, (void *)rank, (void *)ugid, (void *)ghost_gid}) sc.release(q);
+  return PA_OK;
+}
+
+// the triplets are on the device (dI, dJ, dV: `count` entries, owned by sc); sub: keep rows outside the own box as ghost rows
+static int assemble_core(pa_ctx *c, pa_coo_assembly *h, scratch &sc, int64_t count, long long *dI, long long *dJ, double *dV,
+                         const pa_box &rows, const pa_box &cols, int64_t n_known, const int64_t *known, int discover, bool sub) {
   hipStream_t s = c->s[0];
-  scratch sc;
   const int n = (int)count;
-  long long *dI = nullptr, *dJ = nullptr;
-  double *dV = nullptr;
-  PA_TRY(sc.get(&dI, count));
-  PA_TRY(sc.get(&dJ, count));
-  PA_TRY(sc.get(&dV, count));
-  PA_HIP(hipMemcpyAsync(dI, I, 8 * (size_t)count, hipMemcpyHostToDevice, s));
-  PA_HIP(hipMemcpyAsync(dJ, J, 8 * (size_t)count, hipMemcpyHostToDevice, s));
-  PA_HIP(hipMemcpyAsync(dV, V, 8 * (size_t)count, hipMemcpyHostToDevice, s));
-  int *li = nullptr, *lj = nullptr, *isg = nullptr, *gscan = nullptr;
+  int *li = nullptr, *lj = nullptr, *isg = nullptr, *gscan = nullptr, *isr = nullptr, *rgscan = nullptr;
   PA_TRY(sc.get(&li, count));
   PA_TRY(sc.get(&lj, count));
   PA_TRY(sc.get(&isg, count + 1));
   PA_TRY(sc.get(&gscan, count + 1));
   PA_HIP(hipMemsetAsync(isg + count, 0, sizeof(int), s));
-  hipLaunchKernelGGL(ka_classify, grid1(count), dim3(256), 0, s, dI, dJ, n, rows, cols, li, lj, isg);
+  if (sub) {
+    PA_TRY(sc.get(&isr, count + 1));
+    PA_TRY(sc.get(&rgscan, count + 1));
+    PA_HIP(hipMemsetAsync(isr + count, 0, sizeof(int), s));
+  }
+  hipLaunchKernelGGL(ka_classify, grid1(count), dim3(256), 0, s, dI, dJ, n, rows, cols, li, lj, isg, isr);
   PA_TRY(scan_exclusive<int>(sc, s, isg, gscan, (size_t)count + 1));
-  int n_occ = 0;
+  int n_occ = 0, n_rocc = 0;
   PA_TRY(d2h(s, &n_occ, gscan + count, 1));
+  // ---- ghost rows (sub-assembled route) and ghost columns in first-seen order
+  int *rocc_rank = nullptr, *occ_rank = nullptr;
+  int n_ghost_rows = 0, n_unique = 0;
+  if (sub) {
+    PA_TRY(scan_exclusive<int>(sc, s, isr, rgscan, (size_t)count + 1));
+    PA_TRY(d2h(s, &n_rocc, rgscan + count, 1));
+    PA_TRY(number_first_seen(sc, s, dI, isr, rgscan, n, n_rocc, 0, nullptr, true, &rocc_rank, h->row_ghost_gids, &n_ghost_rows));
+  }
   sc.release(dI);
-  // ---- ghosts in first-seen order
-  const int n_all = (int)n_known + n_occ;
-  int *occ_rank = nullptr;
-  PA_TRY(sc.get(&occ_rank, (size_t)n_all + 1));
   h->n_known = n_known;
   h->ghost_gids.assign(known, known + n_known);
-  if (n_all > 0) {
-    unsigned long long *gid = nullptr, *sgid = nullptr;
-    int *pos = nullptr, *spos = nullptr, *head = nullptr, *uscan = nullptr;
-    long long *dknown = nullptr;
-    PA_TRY(sc.get(&gid, n_all));
-    PA_TRY(sc.get(&sgid, n_all));
-    PA_TRY(sc.get(&pos, n_all));
-    PA_TRY(sc.get(&spos, n_all));
-    PA_TRY(sc.get(&head, n_all));
-    PA_TRY(sc.get(&uscan, n_all));
-    if (n_known) {
-      PA_TRY(sc.get(&dknown, n_known));
-      PA_HIP(hipMemcpyAsync(dknown, known, 8 * (size_t)n_known, hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(ka_known_occ, grid1(n_known), dim3(256), 0, s, dknown, (int)n_known, gid, pos);
-    }
-    hipLaunchKernelGGL(ka_ghost_occ, grid1(count), dim3(256), 0, s, dJ, isg, gscan, n, (int)n_known, gid, pos);
-    PA_TRY(sort_pairs<unsigned long long>(sc, s, gid, sgid, pos, spos, (size_t)n_all));
-    hipLaunchKernelGGL(ka_heads_u64, grid1(n_all), dim3(256), 0, s, sgid, n_all, head);
-    PA_TRY(scan_inclusive(sc, s, head, uscan, (size_t)n_all));
-    int n_unique = 0;
-    PA_TRY(d2h(s, &n_unique, uscan + (n_all - 1), 1));
-    int *first_pos = nullptr, *uid = nullptr, *first_pos_s = nullptr, *uid_s = nullptr, *rank = nullptr;
-    long long *ugid = nullptr, *ghost_gid = nullptr;
-    PA_TRY(sc.get(&first_pos, n_unique));
-    PA_TRY(sc.get(&uid, n_unique));
-    PA_TRY(sc.get(&first_pos_s, n_unique));
-    PA_TRY(sc.get(&uid_s, n_unique));
-    PA_TRY(sc.get(&rank, n_unique));
-    PA_TRY(sc.get(&ugid, n_unique));
-    PA_TRY(sc.get(&ghost_gid, n_unique));
-    hipLaunchKernelGGL(ka_unique, grid1(n_all), dim3(256), 0, s, sgid, spos, head, uscan, n_all, first_pos, uid, ugid);
-    PA_TRY(sort_pairs<int>(sc, s, first_pos, first_pos_s, uid, uid_s, (size_t)n_unique));
-    hipLaunchKernelGGL(ka_rank, grid1(n_unique), dim3(256), 0, s, uid_s, ugid, n_unique, rank, ghost_gid);
-    hipLaunchKernelGGL(ka_occ_rank, grid1(n_all), dim3(256), 0, s, spos, uscan, rank, n_all, occ_rank);
-    PA_HIP(hipGetLastError());
-    // (the known ghosts must be distinct gids: then they keep the numbers 0 .. n_known-1 they came with)
-    PA_REQUIRE(n_unique >= n_known, "the column partition lists a ghost twice");
-    if (discover) {
-      h->ghost_gids.resize(n_unique);
-      PA_TRY(d2h(s, (long long *)h->ghost_gids.data(), ghost_gid, (size_t)n_unique));
-      for (int64_t k = 0; k < n_known; ++k) PA_REQUIRE(h->ghost_gids[k] == known[k], "the column partition lists a ghost twice (or an own id as a ghost)");
-    }
-  }
+  PA_TRY(number_first_seen(sc, s, dJ, isg, gscan, n, n_occ, n_known, known, discover != 0, &occ_rank, h->ghost_gids, &n_unique));
   h->n_ghost = (int64_t)h->ghost_gids.size();
   // ---- sort by (row, column), combine
   unsigned long long *key = nullptr, *skey = nullptr;
@@ -270,9 +306,9 @@ static int assemble_impl(pa_ctx *c, pa_coo_assembly *h, int64_t count, const int
   PA_TRY(sc.get(&sidx, count));
   PA_TRY(sc.get(&bad, count));
   hipLaunchKernelGGL(ka_keys, grid1(count), dim3(256), 0, s, li, lj, isg, gscan, occ_rank, n, (int)n_known, (int)h->n_own_cols,
-                     (int)h->n_ghost, discover, key, idx, bad);
+                     (int)h->n_ghost, discover, key, idx, bad, isr, rgscan, rocc_rank, (int)h->n_rows);
   unsigned bits_r = 1, bits = 0;
-  while (((int64_t)1 << bits_r) < std::max<int64_t>(h->n_rows, 2)) ++bits_r;
+  while (((int64_t)1 << bits_r) < std::max<int64_t>(h->n_rows + n_ghost_rows, 2)) ++bits_r;
   bits = 32 + bits_r;
   PA_TRY(sort_pairs<unsigned long long>(sc, s, key, skey, idx, sidx, (size_t)count, bits));
   sc.release(key); sc.release(idx); sc.release(dJ); sc.release(li); sc.release(lj);
@@ -285,30 +321,72 @@ static int assemble_impl(pa_ctx *c, pa_coo_assembly *h, int64_t count, const int
   PA_TRY(d2h(s, &nnz, hscan + (count - 1), 1));
   int *orow = nullptr, *ocol = nullptr, *f = nullptr, *fscan = nullptr;
   double *oval = nullptr;
-  PA_TRY(sc.get(&orow, nnz));
-  PA_TRY(sc.get(&ocol, nnz));
-  PA_TRY(sc.get(&oval, nnz));
+  const size_t pad = 8;
+  if (sub) {                                       // (kept with the handle)
+    PA_HIP(hipMalloc((void **)&h->s_row, sizeof(int) * ((size_t)nnz + pad)));
+    PA_HIP(hipMalloc((void **)&h->s_col, sizeof(int) * ((size_t)nnz + pad)));
+    PA_HIP(hipMalloc((void **)&h->s_val, sizeof(double) * ((size_t)nnz + pad)));
+    orow = h->s_row; ocol = h->s_col; oval = h->s_val;
+  } else {
+    PA_TRY(sc.get(&orow, nnz));
+    PA_TRY(sc.get(&ocol, nnz));
+    PA_TRY(sc.get(&oval, nnz));
+  }
   PA_TRY(sc.get(&f, (size_t)nnz + 1));
   PA_TRY(sc.get(&fscan, (size_t)nnz + 1));
   hipLaunchKernelGGL(ka_combine, grid1(count), dim3(256), 0, s, skey, sidx, head, hscan, dV, bad, n, orow, ocol, oval);
   PA_HIP(hipMemsetAsync(f + nnz, 0, sizeof(int), s));
   hipLaunchKernelGGL(ka_is_own_col, grid1(nnz), dim3(256), 0, s, ocol, nnz, (int)h->n_own_cols, f);
   PA_TRY(scan_exclusive<int>(sc, s, f, fscan, (size_t)nnz + 1));
-  int n_oo = 0;
-  PA_TRY(d2h(s, &n_oo, fscan + nnz, 1));
-  h->nnz_oo = n_oo; h->nnz_oh = nnz - n_oo;
-  const size_t pad = 8;
   PA_HIP(hipMalloc((void **)&h->oo_rp, sizeof(int) * (size_t)(h->n_rows + 1)));
   PA_HIP(hipMalloc((void **)&h->oh_rp, sizeof(int) * (size_t)(h->n_rows + 1)));
+  // row pointers of the own rows first: with ghost rows behind them, the blocks end where the own rows do
+  int n_oo_all = 0;
+  PA_TRY(d2h(s, &n_oo_all, fscan + nnz, 1));
+  hipLaunchKernelGGL(ka_rowptr, grid1(h->n_rows + 1), dim3(256), 0, s, orow, fscan, nnz, (int)h->n_rows, n_oo_all, h->oo_rp, h->oh_rp);
+  int end_oo = 0, end_oh = 0;
+  PA_TRY(d2h(s, &end_oo, h->oo_rp + h->n_rows, 1));
+  PA_TRY(d2h(s, &end_oh, h->oh_rp + h->n_rows, 1));
+  h->nnz_oo = end_oo; h->nnz_oh = end_oh;
+  h->n_prefix = (int64_t)end_oo + end_oh;
+  PA_REQUIRE(sub || h->n_prefix == nnz, "entries beyond the own rows in an assembled matrix");
+  if (sub) {
+    // the ghost rows' entries (the surface of the part) go to the host; the own rows' stay where they are
+    const int64_t ng = (int64_t)nnz - h->n_prefix;
+    h->g_row.resize(ng); h->g_col.resize(ng); h->g_val.resize(ng);
+    if (ng) {
+      PA_TRY(d2h(s, h->g_row.data(), orow + h->n_prefix, (size_t)ng));
+      PA_TRY(d2h(s, h->g_col.data(), ocol + h->n_prefix, (size_t)ng));
+      PA_TRY(d2h(s, h->g_val.data(), oval + h->n_prefix, (size_t)ng));
+      for (int64_t k = 0; k < ng; ++k) h->g_row[k] -= (int32_t)h->n_rows;
+    }
+    PA_HIP(hipGetLastError());
+    PA_HIP(hipStreamSynchronize(s));
+    return PA_OK;
+  }
   PA_HIP(hipMalloc((void **)&h->oo_col, sizeof(int) * ((size_t)h->nnz_oo + pad)));
   PA_HIP(hipMalloc((void **)&h->oh_col, sizeof(int) * ((size_t)h->nnz_oh + pad)));
   PA_HIP(hipMalloc((void **)&h->oo_val, sizeof(double) * ((size_t)h->nnz_oo + pad)));
   PA_HIP(hipMalloc((void **)&h->oh_val, sizeof(double) * ((size_t)h->nnz_oh + pad)));
   hipLaunchKernelGGL(ka_split, grid1(nnz), dim3(256), 0, s, ocol, oval, f, fscan, nnz, (int)h->n_own_cols, h->oo_col, h->oo_val, h->oh_col, h->oh_val);
-  hipLaunchKernelGGL(ka_rowptr, grid1(h->n_rows + 1), dim3(256), 0, s, orow, fscan, nnz, (int)h->n_rows, n_oo, h->oo_rp, h->oh_rp);
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(s));
   return PA_OK;
+}
+
+static int assemble_impl(pa_ctx *c, pa_coo_assembly *h, int64_t count, const int64_t *I, const int64_t *J, const double *V,
+                         const pa_box &rows, const pa_box &cols, int64_t n_known, const int64_t *known, int discover, bool sub) {
+  hipStream_t s = c->s[0];
+  scratch sc;
+  long long *dI = nullptr, *dJ = nullptr;
+  double *dV = nullptr;
+  PA_TRY(sc.get(&dI, count));
+  PA_TRY(sc.get(&dJ, count));
+  PA_TRY(sc.get(&dV, count));
+  PA_HIP(hipMemcpyAsync(dI, I, 8 * (size_t)count, hipMemcpyHostToDevice, s));
+  PA_HIP(hipMemcpyAsync(dJ, J, 8 * (size_t)count, hipMemcpyHostToDevice, s));
+  PA_HIP(hipMemcpyAsync(dV, V, 8 * (size_t)count, hipMemcpyHostToDevice, s));
+  return assemble_core(c, h, sc, count, dI, dJ, dV, rows, cols, n_known, known, discover, sub);
 }
 
 static int make_box(pa_box &b, int32_t D, const int64_t *n, const int64_t *lo, const int64_t *hi, int64_t *n_own) {
@@ -342,7 +420,7 @@ extern "C" int pa_coo_assemble(pa_ctx *c, int64_t count, const int64_t *I, const
   hipEvent_t e0 = nullptr, e1 = nullptr;
   (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0, c->s[0]);
-  const int st = assemble_impl(c, h, count, I, J, V, rows, cols, n_known_ghosts, known_ghosts, discover_ghosts);
+  const int st = assemble_impl(c, h, count, I, J, V, rows, cols, n_known_ghosts, known_ghosts, discover_ghosts, false);
   (void)hipEventRecord(e1, c->s[0]);
   (void)hipEventSynchronize(e1);
   float ms = 0;
@@ -350,6 +428,122 @@ extern "C" int pa_coo_assemble(pa_ctx *c, int64_t count, const int64_t *I, const
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (st != PA_OK) { (void)hipGetLastError(); assembly_free(h); return st; }
   h->ms = ms;
+  *out = h;
+  return PA_OK;
+}
+
+// ---- the disassembled route: psparse(I,J,V,rows,cols) with the default flags + assemble (src/p_sparse_matrix.jl:1150-1219,
+// 1590-1756).  A part's triplets may name rows other parts own (FEM assembly loops).  Step 1 (pa_coo_subassemble): the local
+// sub-assembled matrix -- ghost rows AND ghost columns numbered in first-seen order, one stable (row, column) sort, duplicates
+// added in input order -- whose own rows stay in HBM while the ghost rows (the part's surface) go to the host, which sends them
+// to their owners (the reference's setup_cache_snd + exchange).  Step 2 (pa_coo_assemble_finish): the own rows' entries, in
+// the order the reference walks them (own|own and own|ghost in CSR order), followed by what the neighbours sent, through the
+// assembled route above: the same left-to-right sums, the same first-seen order of the final ghost columns as
+// setup_own_triplets + union_ghost + finalize_values (:1656-1723).
+__device__ __forceinline__ long long own_global(const pa_box &b, long long id) {      // 0-based own id -> 1-based global id
+  long long g = 0, stride = 1;
+#pragma unroll 1
+  for (int d = 0; d < b.D; ++d) {
+    const long long ext = b.hi[d] - b.lo[d] + 1;
+    const long long c = b.lo[d] + id % ext;
+    id /= ext;
+    g += (c - 1) * stride;
+    stride *= b.n[d];
+  }
+  return g + 1;
+}
+
+__global__ void ka_expand(const int *__restrict__ srow, const int *__restrict__ scol, const double *__restrict__ sval, int n, pa_box rows,
+                          pa_box cols, int n_own_cols, const long long *__restrict__ ghost_gid, long long *__restrict__ I,
+                          long long *__restrict__ J, double *__restrict__ V) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  I[e] = own_global(rows, srow[e]);
+  J[e] = scol[e] < n_own_cols ? own_global(cols, scol[e]) : ghost_gid[scol[e] - n_own_cols];
+  V[e] = sval[e];
+}
+
+extern "C" int pa_coo_subassemble(pa_ctx *c, int64_t count, const int64_t *I, const int64_t *J, const double *V, int32_t D,
+                                  const int64_t *n_rows_global, const int64_t *row_lo, const int64_t *row_hi,
+                                  const int64_t *n_cols_global, const int64_t *col_lo, const int64_t *col_hi, pa_coo_assembly **out) {
+  PA_REQUIRE(c && out && count > 0 && I && J && V, "bad arguments");
+  PA_REQUIRE(count < (int64_t)2147480000, "more triplets than the device-side assembly indexes (2^31)");
+  pa_box rows, cols;
+  int64_t n_own_rows = 0, n_own_cols = 0;
+  PA_TRY(make_box(rows, D, n_rows_global, row_lo, row_hi, &n_own_rows));
+  PA_TRY(make_box(cols, D, n_cols_global, col_lo, col_hi, &n_own_cols));
+  PA_REQUIRE(n_own_rows > 0 && n_own_cols > 0 && n_own_rows + count < (int64_t)2147480000 && n_own_cols + count < (int64_t)2147480000,
+             "part empty or too large for Int32 local ids");
+  PA_HIP(hipSetDevice(c->device));
+  pa_coo_assembly *h = new pa_coo_assembly();
+  h->ctx = c; h->n_rows = n_own_rows; h->n_own_cols = n_own_cols; h->sub = true; h->rows_box = rows; h->cols_box = cols;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int st = assemble_impl(c, h, count, I, J, V, rows, cols, 0, nullptr, 1, true);
+  if (st != PA_OK) { (void)hipGetLastError(); assembly_free(h); return st; }
+  h->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *out = h;
+  return PA_OK;
+}
+
+extern "C" int pa_coo_subassembly_info(const pa_coo_assembly *h, int64_t *n_ghost_rows, int64_t *n_ghost_cols, int64_t *n_own_entries,
+                                       int64_t *n_ghost_row_entries) {
+  PA_REQUIRE(h && h->sub, "not a sub-assembly");
+  if (n_ghost_rows) *n_ghost_rows = (int64_t)h->row_ghost_gids.size();
+  if (n_ghost_cols) *n_ghost_cols = h->n_ghost;
+  if (n_own_entries) *n_own_entries = h->n_prefix;
+  if (n_ghost_row_entries) *n_ghost_row_entries = (int64_t)h->g_val.size();
+  return PA_OK;
+}
+
+// the ghost rows: their gids in first-seen order, and their entries sorted by (row, column): 0-based ghost row, 0-based local
+// column (own columns, then the ghost columns pa_coo_assembly_ghosts lists), value
+extern "C" int pa_coo_subassembly_ghost_rows(const pa_coo_assembly *h, int64_t *row_gids, int32_t *g_row, int32_t *g_col, double *g_val) {
+  PA_REQUIRE(h && h->sub, "not a sub-assembly");
+  for (size_t k = 0; k < h->row_ghost_gids.size(); ++k) row_gids[k] = h->row_ghost_gids[k];
+  for (size_t k = 0; k < h->g_val.size(); ++k) { g_row[k] = h->g_row[k]; g_col[k] = h->g_col[k]; g_val[k] = h->g_val[k]; }
+  return PA_OK;
+}
+
+extern "C" int pa_coo_assemble_finish(const pa_coo_assembly *sub, int64_t n_rcv, const int64_t *I, const int64_t *J, const double *V,
+                                      pa_coo_assembly **out) {
+  PA_REQUIRE(sub && sub->sub && out && n_rcv >= 0 && (n_rcv == 0 || (I && J && V)), "bad arguments");
+  pa_ctx *c = sub->ctx;
+  const int64_t count = sub->n_prefix + n_rcv;
+  PA_REQUIRE(count > 0 && count < (int64_t)2147480000, "no entries, or more than the device-side assembly indexes (2^31)");
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  pa_coo_assembly *h = new pa_coo_assembly();
+  h->ctx = c; h->n_rows = sub->n_rows; h->n_own_cols = sub->n_own_cols;
+  const auto t0 = std::chrono::steady_clock::now();
+  int st = PA_OK;
+  {
+    scratch sc;
+    long long *dI = nullptr, *dJ = nullptr, *dG = nullptr;
+    double *dV = nullptr;
+    auto run = [&]() -> int {
+      PA_TRY(sc.get(&dI, count));
+      PA_TRY(sc.get(&dJ, count));
+      PA_TRY(sc.get(&dV, count));
+      PA_TRY(sc.get(&dG, sub->ghost_gids.size() + 1));
+      if (!sub->ghost_gids.empty())
+        PA_HIP(hipMemcpyAsync(dG, sub->ghost_gids.data(), 8 * sub->ghost_gids.size(), hipMemcpyHostToDevice, s));
+      if (sub->n_prefix)
+        hipLaunchKernelGGL(ka_expand, grid1(sub->n_prefix), dim3(256), 0, s, sub->s_row, sub->s_col, sub->s_val, (int)sub->n_prefix,
+                           sub->rows_box, sub->cols_box, (int)sub->n_own_cols, dG, dI, dJ, dV);
+      if (n_rcv) {
+        PA_HIP(hipMemcpyAsync(dI + sub->n_prefix, I, 8 * (size_t)n_rcv, hipMemcpyHostToDevice, s));
+        PA_HIP(hipMemcpyAsync(dJ + sub->n_prefix, J, 8 * (size_t)n_rcv, hipMemcpyHostToDevice, s));
+        PA_HIP(hipMemcpyAsync(dV + sub->n_prefix, V, 8 * (size_t)n_rcv, hipMemcpyHostToDevice, s));
+      }
+      PA_HIP(hipGetLastError());
+      PA_HIP(hipStreamSynchronize(s));
+      sc.release(dG);
+      return assemble_core(c, h, sc, count, dI, dJ, dV, sub->rows_box, sub->cols_box, 0, nullptr, 1, false);
+    };
+    st = run();
+  }
+  if (st != PA_OK) { (void)hipGetLastError(); assembly_free(h); return st; }
+  h->ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   *out = h;
   return PA_OK;
 }

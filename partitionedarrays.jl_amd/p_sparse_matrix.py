@@ -574,6 +574,117 @@ def _nzindex(A: HostCSR, i, j):
     return np.where(keys[pos] == q, pos + 1, 0)
 
 
+def _assembly_snd(ghost_own, ghost_ghost, ps, r, c):
+    """setup_cache_snd (src/p_sparse_matrix.jl:1598-1650): the ghost rows' stored entries -- ghost_own's, then ghost_ghost's, each
+    in CSR order -- as global triplets grouped by the owner of their row (stable inside a group)."""
+    gi, gj, gv = _coo(ghost_own)
+    hi, hj, hv = _coo(ghost_ghost)
+    ii = np.concatenate([gi, hi])
+    gI = r.ghost_to_global[ii - 1]
+    gJ = np.concatenate([c.own_to_global[gj - 1], c.ghost_to_global[hj - 1]])
+    gV = np.concatenate([gv, hv])
+    (a, b, v), order, cuts = _group_by_owner(r.ghost_to_owner[ii - 1], np.asarray(ps), [gI, gJ, gV], with_order=True)
+    return a, b, v, (order + 1, cuts + 1)            # k_snd (1-based position in [ghost_own|ghost_ghost] nz), ptrs
+
+
+def _disassembled_device_applies(rows, cols, I, J):
+    """The device route of psparse + assemble (csrc/pa_assemble.hip, pa_coo_subassemble / pa_coo_assemble_finish): block
+    partitions without ghosts for rows and columns, every part with triplets, ids >= 1, a GPU; PA_SETUP_DEVICE=0: host route."""
+    if not _device_assembly_applies(rows, I):
+        return False
+    from .primitives import local_items
+    return (all(c.kind == "block" and c.n_ghost == 0 and c.n_own > 0 for c in local_items(cols))
+            and all(len(i) and int(np.min(i)) >= 1 and int(np.min(j)) >= 1 for i, j in zip(local_items(I), local_items(J))))
+
+
+def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False):
+    """psparse(I,J,V,rows,cols) with the default flags, then assemble (src/p_sparse_matrix.jl:1150-1219,1590-1756), with
+    everything per triplet on the device.  Per part: the sub-assembled local matrix by one sort (ghost rows and ghost columns in
+    first-seen order); its ghost rows -- the part's surface -- come to the host and travel to their owners exactly as
+    psparse_assemble_host sends them; the own rows, still in HBM, and what arrived go through the assembled route.  Same
+    blocks, same ghost order as the host route, bit for bit (tests/test_gpu_parity.py)."""
+    from .primitives import exchange, ExchangeGraph, DebugArray, tuple_of_arrays
+    from .p_range import assembly_neighbors, LocalIndices
+
+    def box(ind):
+        return (len(ind.n), np.array(ind.n, I64), np.array([a for a, _ in ind.ranges], I64), np.array([b for _, b in ind.ranges], I64))
+
+    def with_ghosts(ind, gids):
+        owners = find_owner(DebugArray([ind]), DebugArray([gids])).items[0]
+        return LocalIndices(ind.n_global, ind.part, np_=ind.np_, n=ind.n, ranges=ind.ranges, starts=ind.starts,
+                            ghost_to_global=gids, ghost_to_owner=owners)
+
+    def sub(Ii, Ji, Vi, r, c):
+        Ii, Ji, Vi = np.ascontiguousarray(Ii, I64), np.ascontiguousarray(Ji, I64), np.ascontiguousarray(Vi, F64)
+        D, nr, lor, hir = box(r)
+        Dc, ncg, loc, hic = box(c)
+        if D != Dc:
+            raise L.PAError("row and column partitions of different dimension")
+        h = C.c_void_p()
+        L.call("pa_coo_subassemble", context().h, len(Ii), L.ptr(Ii), L.ptr(Ji), L.ptr(Vi), D, L.ptr(nr), L.ptr(lor), L.ptr(hir),
+               L.ptr(ncg), L.ptr(loc), L.ptr(hic), C.byref(h))
+        try:
+            v = [C.c_int64() for _ in range(4)]
+            L.call("pa_coo_subassembly_info", h, *[C.byref(x) for x in v])
+            ngr, ngc, _n_own_entries, nge = [x.value for x in v]
+            cg = np.zeros(ngc, I64)
+            L.call("pa_coo_assembly_ghosts", h, L.ptr(cg))
+            rg, gr, gc, gv = np.zeros(ngr, I64), np.zeros(nge, I32), np.zeros(nge, I32), np.zeros(nge, F64)
+            L.call("pa_coo_subassembly_ghost_rows", h, L.ptr(rg), L.ptr(gr), L.ptr(gc), L.ptr(gv))
+        except Exception:
+            L.lib.pa_coo_assembly_destroy(h)
+            raise
+        r_sa, c_sa = with_ghosts(r, rg), with_ghosts(c, cg)
+        own = gc < c.n_own                                            # (sorted by (row, column): both halves stay in CSR order)
+
+        def csr(rows_, cols_, vals_, n_cols):
+            rp = np.zeros(ngr + 1, np.int64)
+            np.add.at(rp, rows_.astype(np.int64) + 1, 1)
+            return HostCSR(ngr, n_cols, (np.cumsum(rp) + 1).astype(I32), (cols_ + 1).astype(I32), vals_.copy())
+        return h, r_sa, c_sa, csr(gr[own], gc[own], gv[own], c.n_own), csr(gr[~own], gc[~own] - c.n_own, gv[~own], ngc)
+
+    hs, rows_sa, cols_sa, g_own, g_ghost = tuple_of_arrays(pmap(sub, I, J, V, rows, cols))
+    try:
+        parts_snd, parts_rcv = assembly_neighbors(rows_sa)
+        I_snd, J_snd, V_snd, _k = tuple_of_arrays(pmap(_assembly_snd, g_own, g_ghost, parts_snd, rows_sa, cols_sa))
+        graph = ExchangeGraph(parts_snd, parts_rcv)
+        I_rcv, J_rcv, V_rcv = exchange(I_snd, graph), exchange(J_snd, graph), exchange(V_snd, graph)
+
+        def finish(h, Ir, Jr, Vr, r, c):
+            cat = lambda xs, dt: np.ascontiguousarray(np.concatenate([np.asarray(x, dt) for x in xs]) if len(xs) else np.zeros(0, dt))  # noqa: E731
+            Ir, Jr, Vr = cat(Ir, I64), cat(Jr, I64), cat(Vr, F64)
+            f = C.c_void_p()
+            L.call("pa_coo_assemble_finish", h, len(Ir), L.ptr(Ir) if len(Ir) else None, L.ptr(Jr) if len(Ir) else None,
+                   L.ptr(Vr) if len(Ir) else None, C.byref(f))
+            try:
+                v = [C.c_int64() for _ in range(5)]
+                L.call("pa_coo_assembly_info", f, *[C.byref(x) for x in v], None)
+                n_rows, n_own_cols, n_ghost, nnz_oo, nnz_oh = [x.value for x in v]
+                ghosts = np.zeros(n_ghost, I64)
+                L.call("pa_coo_assembly_ghosts", f, L.ptr(ghosts))
+                c_fa = with_ghosts(c, ghosts)
+                a, b = C.c_void_p(), C.c_void_p()
+                L.call("pa_coo_assembly_blocks", f, C.byref(a), C.byref(b))
+                blk = SplitMatrixBlocks(DeviceCSR.from_handle(a, n_rows, n_own_cols, nnz_oo), DeviceCSR.from_handle(b, n_rows, n_ghost, nnz_oh))
+                host = None
+                if keep_host:
+                    host = []
+                    for which, (ncol, nnz) in enumerate(((n_own_cols, nnz_oo), (n_ghost, nnz_oh))):
+                        H = HostCSR(n_rows, ncol, np.zeros(n_rows + 1, I32), np.zeros(nnz, I32), np.zeros(nnz, F64))
+                        L.call("pa_coo_assembly_download", f, which, L.ptr(H.rowptr), L.ptr(H.colval), L.ptr(H.nzval))
+                        host.append(H)
+                    host = tuple(host)
+            finally:
+                L.lib.pa_coo_assembly_destroy(f)
+            return blk, c_fa, host
+
+        out = pmap(finish, hs, I_rcv, J_rcv, V_rcv, rows, cols)
+    finally:
+        pmap(lambda h: L.lib.pa_coo_assembly_destroy(h), hs)
+    blocks, cols_fa, host = tuple_of_arrays(out)
+    return PSparseMatrix(blocks, rows, cols_fa, True, host if keep_host else None)
+
+
 def psparse_assemble_host(blocks4, rows_sa, cols_sa, rows, reuse=False):
     """assemble(B,rows) for a split-format sub-assembled matrix, first time (psparse_assemble_impl,
     src/p_sparse_matrix.jl:1590-1756): ghost-row triplets travel to the owners of their rows, are appended to the
@@ -583,15 +694,8 @@ def psparse_assemble_host(blocks4, rows_sa, cols_sa, rows, reuse=False):
     from .p_range import assembly_neighbors, LocalIndices
     parts_snd, parts_rcv = assembly_neighbors(rows_sa)
 
-    def setup_snd(blk, ps, r, c):                                   # setup_cache_snd :1598-1650
-        gi, gj, gv = _coo(blk[2])
-        hi, hj, hv = _coo(blk[3])
-        ii = np.concatenate([gi, hi])
-        gI = r.ghost_to_global[ii - 1]
-        gJ = np.concatenate([c.own_to_global[gj - 1], c.ghost_to_global[hj - 1]])
-        gV = np.concatenate([gv, hv])
-        (a, b, v), order, cuts = _group_by_owner(r.ghost_to_owner[ii - 1], np.asarray(ps), [gI, gJ, gV], with_order=True)
-        return a, b, v, (order + 1, cuts + 1)            # k_snd (1-based position in [ghost_own|ghost_ghost] nz), ptrs
+    def setup_snd(blk, ps, r, c):
+        return _assembly_snd(blk[2], blk[3], ps, r, c)
 
     from .primitives import tuple_of_arrays
     I_snd, J_snd, V_snd, ksnd = tuple_of_arrays(pmap(setup_snd, blocks4, parts_snd, rows_sa, cols_sa))
@@ -648,6 +752,8 @@ def psparse_disassembled(I, J, V, rows, cols, keep_host=False, reuse=False, asse
     """psparse(SparseMatrixCSR{1,Float64,Int32},I,J,V,rows,cols)|>fetch with the DEFAULT flags
     (src/p_sparse_matrix.jl:1150-1219): every part may hold entries of rows it does not own (FEM assembly loops);
     find_owner/union_ghost for rows and columns, local compress + split, then assemble onto `rows`."""
+    if assemble and not reuse and _disassembled_device_applies(rows, cols, I, J):
+        return psparse_disassembled_device(I, J, V, rows, cols, keep_host=keep_host)
     I_owner = find_owner(rows, I)
     J_owner = find_owner(cols, J)
     rows_sa = pmap(union_ghost, rows, I, I_owner)

@@ -2091,6 +2091,57 @@ def test_device_side_psparse_equals_the_host_route(orc, monkeypatch):
     monkeypatch.delenv("PA_SETUP_DEVICE")
 
 
+def test_device_side_disassembled_psparse_equals_the_host_route(orc, monkeypatch):
+    """csrc/pa_assemble.hip, pa_coo_subassemble + pa_coo_assemble_finish: psparse(I,J,V,rows,cols) with the default flags and
+    assemble (src/p_sparse_matrix.jl:1150-1219,1590-1756) -- triplets of rows other parts own travel to their owners -- with the
+    sub-assembled matrix, the ghost numbering and the final compress on the device, against the host route (PA_SETUP_DEVICE=0,
+    itself pinned to the oracle): the same final ghost columns in the same order, the same CSR arrays bit for bit, the same
+    product.  Q1 FEM Laplacians in 2-D on (4,2) and 3-D on (2,2,1) parts (test/fem_example.jl's assembly loops), and random
+    triplets on 3 parts whose rows and columns lie anywhere, with duplicates on both sides of the exchange."""
+    rng = np.random.default_rng(33)
+    cases = []
+    for nodes, parts in (((40, 24), (4, 2)), ((9, 8, 7), (2, 2, 1)), ((30,), (3,))):
+        r = ranks(int(np.prod(parts)))
+        I, J, V, rows, cols = pa.laplacian_fem(nodes, parts, r)
+        cases.append((f"laplacian_fem {nodes} on {parts}", I, J, V, rows, cols))
+    r3 = ranks(3)
+    n = 5000
+    rows3 = pa.uniform_partition(r3, (3,), (n,))
+
+    def rand(ind):
+        m = 30000
+        Ii = rng.integers(1, n + 1, size=m).astype(np.int64)           # rows anywhere: two thirds belong to other parts
+        Ji = rng.integers(1, n + 1, size=m).astype(np.int64)
+        dup = rng.integers(0, m, size=m // 3)
+        Ii[dup], Ji[dup] = Ii[(dup * 11) % m], Ji[(dup * 11) % m]
+        return Ii, Ji, rng.standard_normal(m)
+    trip = pa.pmap(rand, rows3)
+    cases.append(("random triplets", pa.pmap(lambda t: t[0], trip), pa.pmap(lambda t: t[1], trip), pa.pmap(lambda t: t[2], trip), rows3, rows3))
+    from pa_amd import p_sparse_matrix as psm
+    for name, I, J, V, rows, cols in cases:
+        built = {}
+        for dev in ("0", "1"):
+            monkeypatch.setenv("PA_SETUP_DEVICE", dev)
+            cp = lambda a: pa.pmap(lambda v: np.array(v, copy=True), a)
+            assert psm._disassembled_device_applies(rows, cols, I, J) == (dev == "1"), name
+            A = pa.psparse_disassembled(cp(I), cp(J), cp(V), rows, cols, keep_host=True)
+            x = pa.pvector_from_function(lambda ind: orc.hash_x(ind.get_local_to_global()) * (ind.get_local_to_owner() == ind.part), A.col_partition)
+            y = pa.pzeros(A.row_partition)
+            pa.mul_(y, A, x)
+            built[dev] = (A, [v.copy() for v in pa.local_items(y.own_values())])
+        (Ah, yh), (Ad, yd) = built["0"], built["1"]
+        for p, (ch, cd) in enumerate(zip(pa.local_items(Ah.col_partition), pa.local_items(Ad.col_partition))):
+            assert np.array_equal(ch.ghost_to_global, cd.ghost_to_global) and np.array_equal(ch.ghost_to_owner, cd.ghost_to_owner), (name, p)
+        for p, (hh, hd) in enumerate(zip(pa.local_items(Ah.host_blocks), pa.local_items(Ad.host_blocks))):
+            for which in (0, 1):
+                a, b = hh[which], hd[which]
+                assert (a.m, a.n) == (b.m, b.n) and np.array_equal(a.rowptr, b.rowptr) and np.array_equal(a.colval, b.colval), (name, p, which)
+                assert np.array_equal(a.nzval.view(np.int64), b.nzval.view(np.int64)), (name, p, which)
+        for p, (u, v) in enumerate(zip(yh, yd)):
+            assert np.array_equal(u, v), (name, p)
+    monkeypatch.delenv("PA_SETUP_DEVICE")
+
+
 def test_hpcg_blocks_generated_on_the_device_equal_the_host_s(orc):
     """csrc/pa_rowsel.hip, pa_hpcg_own_block_create + pa_host_hpcg_ghost_block: HPCG's 27-point operator of a part with the
     own|own block and b generated in HBM (HPCG/src/sparse_matrix.jl:28-122) against the fused host generator + upload (itself
