@@ -358,4 +358,104 @@ function to_hip(A::PSparseMatrix)
     PSparseMatrix(mats, partition(axes(A, 1)), partition(axes(A, 2)), true)
 end
 
+# ---------------------------------------------------------------- psparse on the device (optional route)
+const BlockIndices = Union{PartitionedArrays.LocalIndicesWithConstantBlockSize,PartitionedArrays.LocalIndicesWithVariableBlockSize}
+_box(r::BlockIndices) = (length(r.n), collect(Int64, r.n), Int64[first(x) for x in r.ranges], Int64[last(x) for x in r.ranges])
+_empty_csr(n) = HIPCSR(SparseMatrixCSR{1}(0, n, Int32[1], Int32[], Float64[]))
+function _assembly_blocks(h::Ptr{Cvoid}, rows, cols)
+    a, b = Ref{Ptr{Cvoid}}(C_NULL), Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pa_coo_assembly_blocks, libpa), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}), h, a, b))
+    check(ccall((:pa_coo_assembly_destroy, libpa), Cint, (Ptr{Cvoid},), h))
+    no, nc, ng = own_length(rows), own_length(cols), ghost_length(cols)
+    blocks = PartitionedArrays.split_matrix_blocks(_adopt(a[], no, nc), _adopt(b[], no, ng), _empty_csr(nc), _empty_csr(ng))
+    PartitionedArrays.split_matrix(blocks, PartitionedArrays.local_permutation(rows), PartitionedArrays.local_permutation(cols))
+end
+function _assembly_ghosts(h::Ptr{Cvoid})
+    v = [Ref{Int64}(0) for _ in 1:5]
+    check(ccall((:pa_coo_assembly_info, libpa), Cint,
+                (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ptr{Float64}), h, v[1], v[2], v[3], v[4], v[5], C_NULL))
+    g = zeros(Int64, v[3][])
+    check(ccall((:pa_coo_assembly_ghosts, libpa), Cint, (Ptr{Cvoid}, Ptr{Int64}), h, g))
+    g
+end
+"""
+    psparse_hip(I,J,V,rows) -> PSparseMatrix whose blocks are HIPCSR
+
+`psparse(I,J,V,rows,cols;assembled=true)` with `cols = union_ghost(rows,J,find_owner(rows,J))` (src/p_sparse_matrix.jl:1249-1270;
+the route of HPCG.build_p_matrix, HPCG/src/sparse_matrix.jl:105-122, and test/gallery_tests.jl:33) with everything per triplet
+on the device (csrc/pa_assemble.hip): one upload of (I,J,V) per part, ghost columns in first-seen order, a stable (row, column)
+sort with duplicates added in input order, the own | ghost split.  Block row partitions without ghosts.
+"""
+function psparse_hip(I, J, V, rows)
+    asm = map(I, J, V, rows) do i, j, v, r
+        r isa BlockIndices && ghost_length(r) == 0 || error("psparse_hip: block row partition without ghosts expected")
+        D, n, lo, hi = _box(r)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pa_coo_assemble, libpa), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
+                     Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Cint, Ref{Ptr{Cvoid}}),
+                    context().handle, length(i), convert(Vector{Int64}, i), convert(Vector{Int64}, j), convert(Vector{Float64}, v),
+                    D, n, lo, hi, n, lo, hi, 0, C_NULL, 1, h))
+        h[]
+    end
+    ghosts = map(_assembly_ghosts, asm)
+    cols = map(union_ghost, rows, ghosts, find_owner(rows, ghosts))     # (already distinct and in first-seen order)
+    mats = map(_assembly_blocks, asm, rows, cols)
+    PSparseMatrix(mats, rows, cols, true)
+end
+"""
+    psparse_disassembled_hip(I,J,V,rows,cols) -> assembled PSparseMatrix whose blocks are HIPCSR
+
+`psparse(I,J,V,rows,cols) |> fetch` with the default flags, then `assemble` (src/p_sparse_matrix.jl:1150-1219,1590-1756; the
+route of test/fem_example.jl): per part the sub-assembled matrix on the device (ghost rows and columns in first-seen order), its
+ghost rows sent to their owners with the reference's own `exchange`, the own rows and what arrived through the assembled route.
+"""
+function psparse_disassembled_hip(I, J, V, rows, cols)
+    subs = map(I, J, V, rows, cols) do i, j, v, r, c
+        D, nr, lor, hir = _box(r)
+        _, nc, loc, hic = _box(c)
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pa_coo_subassemble, libpa), Cint,
+                    (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
+                     Ptr{Int64}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
+                    context().handle, length(i), convert(Vector{Int64}, i), convert(Vector{Int64}, j), convert(Vector{Float64}, v),
+                    D, nr, lor, hir, nc, loc, hic, h))
+        h[]
+    end
+    surf = map(subs) do h                       # ghost rows: gids (first-seen order) and entries sorted by (row, column)
+        v = [Ref{Int64}(0) for _ in 1:4]
+        check(ccall((:pa_coo_subassembly_info, libpa), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}), h, v[1], v[2], v[3], v[4]))
+        gids, gr, gc, gv = zeros(Int64, v[1][]), zeros(Int32, v[4][]), zeros(Int32, v[4][]), zeros(Float64, v[4][])
+        check(ccall((:pa_coo_subassembly_ghost_rows, libpa), Cint, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}), h, gids, gr, gc, gv))
+        (gids, gr, gc, gv, _assembly_ghosts(h))
+    end
+    row_ghosts = map(s -> s[1], surf)
+    rows_sa = map(union_ghost, rows, row_ghosts, find_owner(rows, row_ghosts))
+    parts_snd, parts_rcv = assembly_neighbors(rows_sa)
+    # setup_cache_snd (:1598-1650): the ghost rows' entries as global triplets, grouped by the owner of their row
+    snd = map(surf, rows_sa, cols, parts_snd) do s, r, c, ps
+        gids, gr, gc, gv, cg = s
+        gI = gids[gr .+ 1]
+        gJ = [k < own_length(c) ? own_to_global(c)[k+1] : cg[k-own_length(c)+1] for k in gc]
+        owner = ghost_to_owner(r)[gr .+ 1]
+        halves = vcat(findall(k -> k < own_length(c), gc), findall(k -> k >= own_length(c), gc))    # ghost_own's entries, then ghost_ghost's
+        sel = [[e for e in halves if owner[e] == p] for p in ps]
+        (JaggedArray([gI[x] for x in sel]), JaggedArray([gJ[x] for x in sel]), JaggedArray([gv[x] for x in sel]))
+    end
+    graph = ExchangeGraph(parts_snd, parts_rcv)
+    Ircv = exchange(map(x -> x[1], snd), graph) |> fetch
+    Jrcv = exchange(map(x -> x[2], snd), graph) |> fetch
+    Vrcv = exchange(map(x -> x[3], snd), graph) |> fetch
+    fin = map(subs, Ircv, Jrcv, Vrcv) do h, i, j, v
+        f = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pa_coo_assemble_finish, libpa), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                    h, length(i.data), convert(Vector{Int64}, i.data), convert(Vector{Int64}, j.data), convert(Vector{Float64}, v.data), f))
+        check(ccall((:pa_coo_assembly_destroy, libpa), Cint, (Ptr{Cvoid},), h))
+        f[]
+    end
+    ghosts = map(_assembly_ghosts, fin)
+    cols_fa = map(union_ghost, cols, ghosts, find_owner(cols, ghosts))
+    PSparseMatrix(map(_assembly_blocks, fin, rows, cols_fa), rows, cols_fa, true)
+end
+
 end # module
