@@ -724,11 +724,12 @@ struct csr_src {
   // rows counted (and, when most are empty, compacted) on the device already (pa_rowsel.hip): the row pointer handed to
   // csr_fill_slab is the final one (n_nonempty + 1 entries with d_row_ids, n_rows + 1 without) and the host passes are skipped
   int64_t pre_nonempty = -1;
+  bool pre_compact = false;
   const int32_t *d_pre_row_ids = nullptr;
   bool on_device() const { return d_col != nullptr || d_val != nullptr; }
   csr_src at(int64_t off) const {
     csr_src o;
-    o.pre_nonempty = pre_nonempty; o.d_pre_row_ids = d_pre_row_ids;
+    o.pre_nonempty = pre_nonempty; o.pre_compact = pre_compact; o.d_pre_row_ids = d_pre_row_ids;
     o.col0 = col0 ? col0 + off : nullptr; o.nzval = nzval ? nzval + off : nullptr;
     o.d_col = d_col ? d_col + off : nullptr; o.d_val = d_val ? d_val + off : nullptr;
     return o;
@@ -755,7 +756,7 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   std::vector<int32_t> crp;
   if (src.pre_nonempty >= 0) {
     n_nonempty = src.pre_nonempty;
-    compact = src.d_pre_row_ids != nullptr;
+    compact = src.pre_compact;
     crp.swap(rp);
   } else {
     std::vector<int64_t> part_cnt(33, 0);          // (host threads over row ranges: a colour block of the 256^3 operator has 16.8 M
@@ -1111,6 +1112,23 @@ extern "C" int pa_csr_create_mixed(pa_ctx *c, int64_t n_rows, int64_t n_cols, in
   PA_REQUIRE(rowptr_bytes == 8 || nnz < (int64_t)2147483000, "2^31 stored entries or more need 64-bit row pointers");
   PA_REQUIRE(nnz == 0 || (colval && nzval), "colval/nzval are NULL");
   const auto t0_ = std::chrono::steady_clock::now();
+  if (nnz == 0) {
+    // a block without stored entries (the own|ghost block of a part without ghost columns: 16.8 M rows at 256^3): every row
+    // pointer must equal the base; nothing else to look at, no Int64 copy of them
+    std::vector<int64_t> bad_row(33, -1);
+    host_parallel(n_rows + 1, (n_rows + 1) * 2, [&](int t, int64_t lo, int64_t hi) {
+      for (int64_t r = lo; r < hi; ++r) if (read_index(rowptr, rowptr_bytes, r) != index_base) { bad_row[t] = r; return; }
+    });
+    for (int t = 0; t < 33; ++t) PA_REQUIRE(bad_row[t] < 0, "rowptr does not span [base, base+nnz] (row %lld)", (long long)bad_row[t]);
+    std::vector<int32_t> crp(1, 0);
+    csr_src src;
+    src.pre_nonempty = 0; src.pre_compact = n_rows > 0;
+    pa_csr *S = nullptr;
+    PA_TRY(csr_build_slab(c, n_rows, n_cols, 0, crp, src, &S));
+    S->t_rows = n_rows; S->t_nnz = 0;
+    *out = S;
+    return PA_OK;
+  }
   std::vector<int64_t> rp(n_rows + 1);
   host_parallel(n_rows + 1, (n_rows + 1) * 4, [&](int, int64_t lo, int64_t hi) {
     for (int64_t r = lo; r < hi; ++r) rp[r] = read_index(rowptr, rowptr_bytes, r) - index_base;
@@ -1190,7 +1208,7 @@ int pa_csr_from_device_rows(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t n
              "row pointers do not span the stored entries");
   csr_src src;
   src.d_col = d_col; src.d_val = d_val;
-  src.pre_nonempty = n_nonempty; src.d_pre_row_ids = d_row_ids;
+  src.pre_nonempty = n_nonempty; src.pre_compact = d_row_ids != nullptr; src.d_pre_row_ids = d_row_ids;
   pa_csr *S = nullptr;
   PA_TRY(csr_build_slab(c, n_rows, n_cols, nnz, crp, src, &S));
   S->t_rows = n_rows; S->t_nnz = nnz;

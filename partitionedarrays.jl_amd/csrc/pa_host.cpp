@@ -333,22 +333,37 @@ extern "C" int pa_host_hpcg_ghosts(int64_t nx, int64_t ny, int64_t nz, int64_t g
   PA_REQUIRE(nx > 0 && ny > 0 && nz > 0 && n_ghost && nnz_oo && nnz_oh, "bad arguments");
   const HpcgGeom G{nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0};
   std::unordered_set<int64_t> seen;
-  int64_t m = 0, oo = 0, oh = 0;
+  int64_t m = 0;
+  // block sizes in closed form: the counts factor per direction
+  auto sums = [&](int64_t g0, int64_t n_own, int64_t gn, int64_t &own, int64_t &tot) {
+    own = tot = 0;
+    for (int64_t i = 0; i < n_own; ++i) { int a, b; dim_counts(g0 + i, g0, n_own, gn, a, b); own += a; tot += a + b; }
+  };
+  int64_t ox, tx, oy, ty, oz, tz;
+  sums(gix0, nx, gnx, ox, tx); sums(giy0, ny, gny, oy, ty); sums(giz0, nz, gnz, oz, tz);
+  const int64_t oo = ox * oy * oz, oh = tx * ty * tz - oo;
+  // the ghosts: only rows on the part's surface have any; they are visited in the order of the full sweep (iz, iy, ix), the
+  // interior of every line skipped (a line whose y or z neighbours leave the box is surface from end to end)
+  auto visit = [&](int64_t ix, int64_t iy, int64_t iz) {
+    const int64_t gx = gix0 + ix, gy = giy0 + iy, gz = giz0 + iz;
+    for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
+      if (!G.in_grid(gx + sx, gy + sy, gz + sz) || G.in_own(gx + sx, gy + sy, gz + sz)) continue;
+      const int64_t g = G.gid(gx + sx, gy + sy, gz + sz);
+      if (seen.insert(g).second) { if (ghost_gids) ghost_gids[m] = g; ++m; }
+    }
+  };
   for (int64_t iz = 0; iz < nz; ++iz) {
     int az, bz; dim_counts(giz0 + iz, giz0, nz, gnz, az, bz);
     for (int64_t iy = 0; iy < ny; ++iy) {
       int ay, by; dim_counts(giy0 + iy, giy0, ny, gny, ay, by);
-      for (int64_t ix = 0; ix < nx; ++ix) {
-        int ax, bx; dim_counts(gix0 + ix, gix0, nx, gnx, ax, bx);
-        const int64_t tot = (int64_t)(ax + bx) * (ay + by) * (az + bz), own = (int64_t)ax * ay * az;
-        oo += own; oh += tot - own;
-        if (tot == own) continue;  // interior row: no ghost column
-        const int64_t gx = gix0 + ix, gy = giy0 + iy, gz = giz0 + iz;
-        for (int sz = -1; sz <= 1; ++sz) for (int sy = -1; sy <= 1; ++sy) for (int sx = -1; sx <= 1; ++sx) {
-          if (!G.in_grid(gx + sx, gy + sy, gz + sz) || G.in_own(gx + sx, gy + sy, gz + sz)) continue;
-          const int64_t g = G.gid(gx + sx, gy + sy, gz + sz);
-          if (seen.insert(g).second) { if (ghost_gids) ghost_gids[m] = g; ++m; }
-        }
+      if (bz > 0 || by > 0) {
+        for (int64_t ix = 0; ix < nx; ++ix) visit(ix, iy, iz);
+      } else {
+        int a0, b0, a1, b1;
+        dim_counts(gix0, gix0, nx, gnx, a0, b0);
+        dim_counts(gix0 + nx - 1, gix0, nx, gnx, a1, b1);
+        if (b0 > 0) visit(0, iy, iz);
+        if (nx > 1 && b1 > 0) visit(nx - 1, iy, iz);
       }
     }
   }
