@@ -333,17 +333,21 @@ __global__ void kg_first(const int32_t *__restrict__ cnt, int n, int32_t *__rest
   if (r < n && cnt[r] == 0) frontier[atomicAdd(count, 1)] = r;
 }
 
-__global__ void kg_round(const int32_t *__restrict__ frontier, int size, int lv, const int32_t *__restrict__ start,
+// One round.  The frontier's size is read from device memory (sizes[lv], written by the round before) and the next one's
+// accumulates in sizes[lv + 1]: the host queues rounds without waiting for any of them and looks at a size only now and then
+// (a launch's grid is a guess; the loop strides over whatever the frontier holds).
+__global__ void kg_round(const int32_t *__restrict__ frontier, int *__restrict__ sizes, int lv, const int32_t *__restrict__ start,
                          const int32_t *__restrict__ len, const int32_t *__restrict__ col, int n, int32_t *__restrict__ level,
-                         int32_t *__restrict__ cnt, int32_t *__restrict__ next, int *__restrict__ next_count) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = t >> 3, lane = t & 7;
-  if (i >= size) return;
-  const int r = frontier[i];
-  if (lane == 0) level[r] = lv;
-  for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += 8) {
-    const int j = col[p];
-    if (j > r && j < n && atomicSub(&cnt[j], 1) == 1) next[atomicAdd(next_count, 1)] = j;
+                         int32_t *__restrict__ cnt, int32_t *__restrict__ next) {
+  const int size = sizes[lv];
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)size * 8; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t >> 3), lane = (int)(t & 7);
+    const int r = frontier[i];
+    if (lane == 0) level[r] = lv;
+    for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += 8) {
+      const int j = col[p];
+      if (j > r && j < n && atomicSub(&cnt[j], 1) == 1) next[atomicAdd(&sizes[lv + 1], 1)] = j;
+    }
   }
 }
 
@@ -369,6 +373,36 @@ __global__ void kg_iota(int32_t *__restrict__ v, int n) {
   if (r < n) v[r] = r;
 }
 
+// Queues the rounds in batches of 32 launches and reads the frontier sizes back once per batch (d_sizes: n + 64 zeroed ints,
+// d_sizes[0] set by kg_first; round k works on d_sizes[k] rows and counts the next frontier in d_sizes[k + 1]).  launch(k, cur,
+// nxt, blocks) enqueues round k.  sizes: the non-empty rounds' sizes; false when more rows were freed than there are.
+template <class F>
+static int run_rounds(hipStream_t s, int64_t n, int *d_sizes, int32_t *d_f0, int32_t *d_f1, F launch, std::vector<int> &sizes, bool *ok) {
+  const int BATCH = 32;
+  int buf[BATCH];
+  int64_t done = 0, k = 0;
+  int guess = 0;
+  PA_TRY(d2h(s, &guess, d_sizes, 1));
+  sizes.clear();
+  *ok = true;
+  if (guess == 0) return PA_OK;
+  while (true) {
+    const int blocks = (int)std::min<int64_t>(65535, std::max<int64_t>(64, ((int64_t)guess * 8 + 255) / 256 * 2));
+    for (int b = 0; b < BATCH; ++b) launch((int)(k + b), ((k + b) & 1) ? d_f1 : d_f0, ((k + b) & 1) ? d_f0 : d_f1, blocks);
+    PA_HIP(hipGetLastError());
+    PA_TRY(d2h(s, buf, d_sizes + k, (size_t)BATCH));
+    for (int b = 0; b < BATCH; ++b) {
+      if (buf[b] == 0) return PA_OK;                   // (the rounds queued behind it found nothing to do)
+      done += buf[b];
+      if (done > n) { *ok = false; return PA_OK; }
+      sizes.push_back(buf[b]);
+      guess = std::max(buf[b], guess / 2);
+    }
+    k += BATCH;
+    if (k > n) { *ok = false; return PA_OK; }
+  }
+}
+
 extern "C" int pa_gs_create_from_blocks(const pa_csr *oo, const pa_csr *oh, int ordering, pa_gs **out) {
   PA_REQUIRE(oo && out, "bad arguments");
   PA_REQUIRE(ordering == PA_GS_SEQUENTIAL, "the device route builds the sequential ordering only");
@@ -390,7 +424,8 @@ extern "C" int pa_gs_create_from_blocks(const pa_csr *oo, const pa_csr *oh, int 
   if (oh) PA_TRY(spans_of(c, sc, oh, n, B));
   int32_t *d_mask = nullptr, *d_len = nullptr, *d_cnt = nullptr, *d_level = nullptr, *d_f0 = nullptr, *d_f1 = nullptr, *d_iota = nullptr,
           *d_lsorted = nullptr;
-  int *d_count = nullptr;
+  int *d_count = nullptr, *d_sizes = nullptr;
+  PA_TRY(sc.get(&d_sizes, (size_t)n + 64));
   PA_TRY(sc.get(&d_mask, (size_t)n + 1));
   PA_TRY(sc.get(&d_len, (size_t)n + 1));
   PA_TRY(sc.get(&d_cnt, (size_t)n + 1));
@@ -421,25 +456,22 @@ extern "C" int pa_gs_create_from_blocks(const pa_csr *oo, const pa_csr *oh, int 
   // dependency levels by rounds
   if (n) hipLaunchKernelGGL(kg_lower_count, grid1(n), dim3(256), 0, s, A.start, A.len, col_a, (int)n, d_cnt);
   PA_G(hipMemsetAsync(d_count, 0, sizeof(int) * 4, s));
+  PA_G(hipMemsetAsync(d_sizes, 0, sizeof(int) * (size_t)(n + 64), s));
   PA_G(hipMemsetAsync(d_level, 0xFF, sizeof(int32_t) * (n + 1), s));                        // -1: not reached
-  if (n) hipLaunchKernelGGL(kg_first, grid1(n), dim3(256), 0, s, d_cnt, (int)n, d_f0, d_count);
+  if (n) hipLaunchKernelGGL(kg_first, grid1(n), dim3(256), 0, s, d_cnt, (int)n, d_f0, d_sizes);
+  std::vector<int> round_sizes;
+  bool rounds_ok = true;
+  PA_GT(run_rounds(s, n, d_sizes, d_f0, d_f1, [&](int k, int32_t *cur, int32_t *nxt, int blocks) {
+    hipLaunchKernelGGL(kg_round, dim3(blocks), dim3(256), 0, s, cur, d_sizes, k, A.start, A.len, col_a, (int)n, d_level, d_cnt, nxt);
+  }, round_sizes, &rounds_ok));
   g->lev_ptr.assign(1, 0);
   int64_t done = 0;
-  int size = 0, which = 0;
-  PA_GT(d2h(s, &size, d_count, 1));
-  while (size > 0) {
-    int32_t *cur = which ? d_f1 : d_f0, *nxt = which ? d_f0 : d_f1;
-    int *cnt_next = d_count + 1 + (which ^ 1) % 2;            // (two counters, used in turn)
-    PA_G(hipMemsetAsync(cnt_next, 0, sizeof(int), s));
-    hipLaunchKernelGGL(kg_round, grid1((int64_t)size * 8), dim3(256), 0, s, cur, size, (int)g->lev_ptr.size() - 1, A.start, A.len, col_a,
-                       (int)n, d_level, d_cnt, nxt, cnt_next);
-    done += size;
-    g->max_level_rows = std::max<int64_t>(g->max_level_rows, size);
+  for (int sz : round_sizes) {
+    done += sz;
+    g->max_level_rows = std::max<int64_t>(g->max_level_rows, sz);
     g->lev_ptr.push_back((int32_t)done);
-    PA_GT(d2h(s, &size, cnt_next, 1));
-    which ^= 1;
-    if (done + size > n) break;                               // (more rows freed than there are: the pattern is not what the rounds assume)
   }
+  if (!rounds_ok) done = -1;
   int bad = done == n ? 0 : 1;
   if (!bad && n) {
     int *d_bad = d_count + 3;
@@ -473,26 +505,27 @@ extern "C" int pa_gs_create_from_blocks(const pa_csr *oo, const pa_csr *oh, int 
 // Verified against the definition row by row (which has one solution); PA_ERR_ARG when the rounds do not get there (a
 // pattern that is not structurally symmetric): the caller colours on the host.
 // ------------------------------------------------------------------------------------------------
-__global__ void kg_round_color(const int32_t *__restrict__ frontier, int size, const int32_t *__restrict__ start,
+__global__ void kg_round_color(const int32_t *__restrict__ frontier, int *__restrict__ sizes, int lv, const int32_t *__restrict__ start,
                                const int32_t *__restrict__ len, const int32_t *__restrict__ col, int n, int32_t *__restrict__ color,
-                               int32_t *__restrict__ cnt, int32_t *__restrict__ next, int *__restrict__ next_count) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = t >> 3, lane = t & 7;
-  if (i >= size) return;
-  const int r = frontier[i];
-  if (lane == 0) {
-    unsigned long long used = 0;
-    for (int p = start[r], e = p + len[r]; p < e; ++p) {
-      const int j = col[p];
-      if (j < r && color[j] < 64) used |= 1ull << color[j];
+                               int32_t *__restrict__ cnt, int32_t *__restrict__ next) {
+  const int size = sizes[lv];
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)size * 8; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t >> 3), lane = (int)(t & 7);
+    const int r = frontier[i];
+    if (lane == 0) {
+      unsigned long long used = 0;
+      for (int p = start[r], e = p + len[r]; p < e; ++p) {
+        const int j = col[p];
+        if (j < r && color[j] < 64) used |= 1ull << color[j];
+      }
+      int c = 0;
+      while (c < 63 && (used >> c) & 1ull) ++c;
+      color[r] = c;
     }
-    int c = 0;
-    while (c < 63 && (used >> c) & 1ull) ++c;
-    color[r] = c;
-  }
-  for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += 8) {
-    const int j = col[p];
-    if (j > r && j < n && atomicSub(&cnt[j], 1) == 1) next[atomicAdd(next_count, 1)] = j;
+    for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += 8) {
+      const int j = col[p];
+      if (j > r && j < n && atomicSub(&cnt[j], 1) == 1) next[atomicAdd(&sizes[lv + 1], 1)] = j;
+    }
   }
 }
 
@@ -524,7 +557,8 @@ extern "C" int pa_csr_greedy_coloring(const pa_csr *oo, int32_t *color, int32_t 
   row_spans A;
   PA_TRY(spans_of(c, sc, oo, n, A));
   int32_t *d_cnt = nullptr, *d_color = nullptr, *d_f0 = nullptr, *d_f1 = nullptr;
-  int *d_count = nullptr;
+  int *d_count = nullptr, *d_sizes = nullptr;
+  PA_TRY(sc.get(&d_sizes, (size_t)n + 64));
   PA_TRY(sc.get(&d_cnt, (size_t)n + 1));
   PA_TRY(sc.get(&d_color, (size_t)n + 1));
   PA_TRY(sc.get(&d_f0, (size_t)n + 1));
@@ -532,22 +566,17 @@ extern "C" int pa_csr_greedy_coloring(const pa_csr *oo, int32_t *color, int32_t 
   PA_TRY(sc.get(&d_count, 8));
   if (n) hipLaunchKernelGGL(kg_lower_count, grid1(n), dim3(256), 0, s, A.start, A.len, col, (int)n, d_cnt);
   PA_HIP(hipMemsetAsync(d_count, 0, sizeof(int) * 8, s));
+  PA_HIP(hipMemsetAsync(d_sizes, 0, sizeof(int) * (size_t)(n + 64), s));
   PA_HIP(hipMemsetAsync(d_color, 0xFF, sizeof(int32_t) * (n + 1), s));
-  if (n) hipLaunchKernelGGL(kg_first, grid1(n), dim3(256), 0, s, d_cnt, (int)n, d_f0, d_count);
+  if (n) hipLaunchKernelGGL(kg_first, grid1(n), dim3(256), 0, s, d_cnt, (int)n, d_f0, d_sizes);
+  std::vector<int> round_sizes;
+  bool rounds_ok = true;
+  PA_TRY(run_rounds(s, n, d_sizes, d_f0, d_f1, [&](int k, int32_t *cur, int32_t *nxt, int blocks) {
+    hipLaunchKernelGGL(kg_round_color, dim3(blocks), dim3(256), 0, s, cur, d_sizes, k, A.start, A.len, col, (int)n, d_color, d_cnt, nxt);
+  }, round_sizes, &rounds_ok));
   int64_t done = 0;
-  int size = 0, which = 0;
-  PA_TRY(d2h(s, &size, d_count, 1));
-  while (size > 0) {
-    int32_t *cur = which ? d_f1 : d_f0, *nxt = which ? d_f0 : d_f1;
-    int *cnt_next = d_count + 1 + (which ^ 1);
-    PA_HIP(hipMemsetAsync(cnt_next, 0, sizeof(int), s));
-    hipLaunchKernelGGL(kg_round_color, grid1((int64_t)size * 8), dim3(256), 0, s, cur, size, A.start, A.len, col, (int)n, d_color, d_cnt, nxt,
-                       cnt_next);
-    done += size;
-    PA_TRY(d2h(s, &size, cnt_next, 1));
-    which ^= 1;
-    if (done + size > n) break;
-  }
+  for (int sz : round_sizes) done += sz;
+  if (!rounds_ok) done = -1;
   int res[2] = {done == n ? 0 : 1, 0};
   if (!res[0] && n) {
     hipLaunchKernelGGL(kg_verify_color, grid1(n), dim3(256), 0, s, A.start, A.len, col, d_color, (int)n, d_count + 3, d_count + 4);
