@@ -12,7 +12,11 @@ x, r0, r, it = pa.ref_cg_(pa.pzeros(A.col_partition), A, b, maxiter=50, toleranc
 tol = r / r0
 print(f"reference: 50 iterations -> {tol:.6e}", flush=True)
 del S, A, b, x
-orders = ["affinity", "reverse", "greedy", "0,1,2,3,4,5,6,7", "7,6,5,4,3,2,1,0", "1,2,3,4,5,6,7,0", "7,1,2,3,4,5,6,0", "1,2,4,3,5,6,7,0", "7,3,5,6,1,2,4,0", "4,2,1,6,5,3,7,0",
+import itertools
+if len(sys.argv) > 2 and sys.argv[2] == "ties":
+    orders = ["7," + ",".join(map(str, a)) + "," + ",".join(map(str, b)) + ",0" for a in itertools.permutations((3, 5, 6)) for b in itertools.permutations((1, 2, 4))]
+else:
+  orders = ["affinity", "reverse", "greedy", "0,1,2,3,4,5,6,7", "7,6,5,4,3,2,1,0", "1,2,3,4,5,6,7,0", "7,1,2,3,4,5,6,0", "1,2,4,3,5,6,7,0", "7,3,5,6,1,2,4,0", "4,2,1,6,5,3,7,0",
           "1,2,4,7,3,5,6,0", "3,5,6,0,1,2,4,7", "0,7,1,6,2,5,3,4"]
 for o in orders:
     os.environ["PA_GS_COLOR_ORDER"] = o
