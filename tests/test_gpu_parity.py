@@ -2149,7 +2149,8 @@ def test_hpcg_blocks_generated_on_the_device_equal_the_host_s(orc):
     blocks, b, the ghost ids and their order -- on one part, on (2,2,2) parts of a non-cubic box, on (4,1,1); and the greedy
     colouring in natural order computed by rounds on the device against pa_host_greedy_coloring."""
     import pa_amd._lib as L
-    for P, shape, n in ((1, (1, 1, 1), (24, 24, 24)), (8, (2, 2, 2), (8, 6, 10)), (4, (4, 1, 1), (5, 9, 7)), (2, (2, 1, 1), (64, 64, 64))):
+    for P, shape, n in ((1, (1, 1, 1), (24, 24, 24)), (8, (2, 2, 2), (8, 6, 10)), (4, (4, 1, 1), (5, 9, 7)), (2, (2, 1, 1), (64, 64, 64)),
+                        (1, (1, 1, 1), (1, 4, 3)), (2, (2, 1, 1), (1, 3, 2)), (4, (1, 2, 2), (3, 1, 1))):      # (degenerate boxes too)
         g = [s * k for s, k in zip(shape, n)]
         Ad, bd = pa.build_p_matrix(ranks(P), *n, *g, *shape, keep_host=False, fused=True, keep_raw=True)
         Ah, bh = pa.build_p_matrix(ranks(P), *n, *g, *shape, keep_host=True, fused=True)
