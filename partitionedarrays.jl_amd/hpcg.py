@@ -84,6 +84,14 @@ class GaussSeidel:
         hb = A.host_blocks if A.host_blocks is not None else pmap(lambda _r: None, A.row_partition)
         self.gs = pmap(make, hb, A.row_partition, A.col_partition, A.matrix_partition)
 
+    def __del__(self):
+        try:
+            from .primitives import local_items
+            for g in local_items(self.gs):
+                L.lib.pa_gs_destroy(g)
+        except Exception:                               # noqa: BLE001  (interpreter shutdown)
+            pass
+
     def info(self):
         def f(g):
             a, b = C.c_int64(), C.c_int64()
@@ -271,6 +279,16 @@ class MgPreconditioner:
     row_blocks: list = None   # per coarse level: the fine rows the coarse grid keeps, as blocks (fused restriction)
     graph: bool = False       # one part, multicolour smoother: the V-cycle of ldiv_ is recorded into a hipGraph and replayed
     _graphs: dict = None
+
+    def __del__(self):           # (the transfer operators are library handles; blocks, vectors and smoothers free themselves)
+        try:
+            from .primitives import local_items
+            for t in self.f2c or []:
+                if t is not None:
+                    for h in local_items(t):
+                        L.lib.pa_transfer_destroy(h)
+        except Exception:                               # noqa: BLE001  (interpreter shutdown)
+            pass
 
 
 def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=None, graph=None):
