@@ -300,9 +300,12 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
     if graph is None:                                  # (off by default: 0.555 -> 0.488 ms per MG-PCG iteration at 32^3, nothing at
         graph = False                                  # 128^3 / 256^3 -- the launches already run ahead of the device there)
     rbs = [None] * (l - 1)
-    if ordering != "sequential":                      # (the colour updates read b, d, x and write x: two vector classes, csrc/pa_arena.hip)
+    if ordering != "sequential" and os.environ.get("PA_MG_VECTOR_CLASSES", "1") == "2":
+        # (opt-in: a second memory class for the solver's vectors is worth ~1 % of an MG-PCG iteration where the device has one
+        #  within reach, and the walk that looks for it costs up to a second of driver-side wiping on memory other processes
+        #  have used -- more than it returns to anything that counts the set-up, csrc/pa_arena.hip)
         try:
-            context().arena_hint(int(os.environ.get("PA_MG_VECTOR_CLASSES", "2")))
+            context().arena_hint(2)
         except Exception:                             # noqa: BLE001  (no GPU: the host-side pieces still build)
             pass
     from .gallery import build_p_matrix, compute_optimal_shape_XYZ

@@ -93,6 +93,9 @@ def hpcg_benchmark(ranks, np_, nx, ny, nz, total_runtime=60.0, levels=4, ref_max
     Returns the report dictionary of hpcg_report (and writes it when output_type is "json" or "txt")."""
     from pa_amd.primitives import getany, reduction
     ctx = context()
+    # (the context's first memory extent before anything is timed: on a device other processes have used, the driver wipes what
+    #  it hands out -- up to a second for 16 GiB -- which is the box's history, not this benchmark's set-up)
+    ctx.arena(build=True)
 
     def elapsed(f):
         ctx.sync()
