@@ -98,8 +98,9 @@ int pa_ctx_stream_priority(pa_ctx *ctx, int which, int *priority, int *least, in
  * (matrix stream, vector) pair passed / failed the self-check, the budget.  pa_ctx_arena_build acquires a first extent now.
  * pa_csr_memory_class / pa_vec_memory_class: class of a block's value stream / a vector's storage (-1: outside). */
 int pa_ctx_arena_build(pa_ctx *ctx);
-/* vector_classes = 2: a solver's vectors (a multigrid hierarchy) alternate between two memory classes of their own -- kernels
- * that read vectors and write one run 3-6 % faster; costs one more walk, once.  1 = the default. */
+/* vector_classes = 2: a solver's vectors alternate between two memory classes of their own -- kernels that read vectors and
+ * write one run ~1 % faster (MG-PCG at 256^3); costs one more walk of <= 16 GiB, once (up to a second on memory other
+ * processes have used).  1 = the default. */
 int pa_ctx_arena_hint(pa_ctx *ctx, int vector_classes);
 /* An arena nothing lives in keeps up to PA_ARENA_SPARE_GIB (24) of extents for what the caller builds next (memory that
  * has been used is wiped by the driver when allocated again: 0.9 s per 16 GiB); this hands them back now. */

@@ -487,10 +487,11 @@ static void *arena_alloc(pa_ctx *c, pa_arena *a, size_t bytes, int kind) {
   static const int check_mode = getenv("PA_ARENA_SELFCHECK") ? atoi(getenv("PA_ARENA_SELFCHECK")) : 1;
   static const int plain_first = getenv("PA_ARENA_PLAIN_VECTORS") ? atoi(getenv("PA_ARENA_PLAIN_VECTORS")) : 0;   // (experimental, below)
   if (a->last_matrix_cls < 0) return nullptr;           // no matrix stream to stay away from (yet): a plain allocation
-  // A caller that announced a solver's worth of vectors (pa_ctx_arena_hint: the multigrid hierarchy) gets TWO vector classes:
-  // kernels that read vectors and write one (the Gauss-Seidel colour updates, BLAS-1) run 3-6 % faster when what they write
-  // is not where they read (MG-PCG iteration at 256^3: 5.78 ms with the vectors alternating between two classes, 6.16 ms
-  // with all of them in one).  Costs one more walk, once, through the first vector class's region.
+  // A caller that asks for it (pa_ctx_arena_hint(2)) gets TWO vector classes: kernels that read vectors and write one (BLAS-1,
+  // the Gauss-Seidel colour updates) run a little faster when what they write is not where they read -- 1.2 % of an MG-PCG
+  // iteration at 256^3 (5.78 vs 5.85 ms; the 5.78 / 6.16 measured in round 2 was mostly the self-check then run per
+  // allocation, profiles/r03_mg_ab.md).  Costs one more walk (<= 16 GiB), once: up to a second on memory other processes have
+  // used, which is why hpcg.pc_setup no longer asks by default.
   auto take_new = [&]() -> void * {
     for (int k = 0; k < a->n_classes; ++k)
       if (a->mat_bytes[k] == 0 && a->vec_bytes[k] == 0 && k != a->matrix_class && class_has_room(a, bytes, k)) return arena_take(a, bytes, k, kind);
