@@ -1966,6 +1966,10 @@ def test_multicolor_gauss_seidel_as_hpcg_optimised_variant(golden, ordering):
     x, r0, r, it = pa.opt_cg_(x, A, b, maxiter=10 * c["maxiter"], tolerance=c["expected_ref_tol"], Pl=S, fuse=True)
     assert r / r0 <= c["expected_ref_tol"] and it <= 10 * c["maxiter"]
     assert it < 2 * c["maxiter"]                                                     # in practice a few iterations more
+    if ordering == "multicolor_spmv":
+        # the colours are swept in order of decreasing affinity to the rows the coarse grid keeps: 52 iterations here for the
+        # reference's 50 (59 in the order greedy colouring finds the colours, where the coarse levels correct nothing)
+        assert it <= 54, it
     for vals in x.own_values().items:
         assert np.allclose(vals, 1.0, atol=1e-9)                                     # b = A*1
 
