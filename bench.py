@@ -227,6 +227,7 @@ def cpu_mul_baseline(pa, A, N, rank, seconds, host_shape=None):
     else:
         nnz_total = nnz
     bytes_part = nnz * 12 + (oo.m + 1) * 4 + ind.n_local * 8 + oo.m * 8
+    cpu_mul_baseline.y = y            # the oracle's mul! of the bench's own x at the bench's own size: the full-size parity gate
     return {"value": round(2.0 * nnz_total / med / 1e9, 3), "unit": "GFLOP/s", "cores": N, "kind": "port",
             "ms_per_mul": round(med * 1e3, 2), "gflops": round(2.0 * nnz_total / med / 1e9, 3),
             "gbps_algorithmic_per_core": round(bytes_part / med / 1e9, 2),
@@ -759,12 +760,42 @@ def main():
         e1 = ctx.event().record(L.STREAM_COMPUTE)
         ctx.sync()
         ramp.append(e0.elapsed_ms(e1) / 10)
+    # ---- placement A/B with the product kernel itself (VERDICT r03 #1a), at working clocks, outside every timed region: y
+    # where the arena's rule put it, in every other memory class the held extents have room in (the matrix streams' own class is
+    # the control that should lose ~13 %) and in a plain hipMalloc; y moves when another place is > 1.5 % faster
+    placement_ab = None
+    if os.environ.get("PA_BENCH_PLACEMENT_AB", "1") != "0" and nnz_oo > 0:
+        PHASE[0] = "placement A/B"
+        try:
+            placement_ab = pa.tune_output_placement(blk.own_own, xv, yv, L.SEG_OWN, reps=10, rounds=3)
+            pa.mul_(y, A, x)                      # (the A/B leaves y = A_oo * x_own; the full product again before anything reads y)
+        except Exception as e:                    # noqa: BLE001  (a diagnostic: never costs the run its line)
+            print(f"[bench rank {rank}] placement A/B skipped: {e}", file=sys.stderr, flush=True)
+    # clocks / power / partition modes under load, before and after the timed region (sysfs of this context's GPU)
+    def telemetry_under_load():
+        for _ in range(30):
+            step(overlap_on)
+        t = ctx.telemetry()                       # (read while the 30 queued steps keep the GPU busy)
+        ctx.sync()
+        return t
+    PHASE[0] = "telemetry"
+    try:
+        telemetry = {"before_timed_region": telemetry_under_load()}
+    except Exception as e:                        # noqa: BLE001
+        telemetry = {"error": str(e)}
     PHASE[0] = f"warm-up (transport {transport})"
     for _ in range(args.warmup):
         step(overlap_on)
     PHASE[0] = f"timed mul! loop (transport {transport})"
     dt, mono0, mono1 = timed(args.steps, overlap_on)
     local_ms_headline = timed.local_s / args.steps * 1e3
+    try:
+        telemetry["after_timed_region"] = telemetry_under_load()
+        telemetry["what"] = ("sysfs of this context's GPU (/sys/bus/pci/devices/<pci id>/: pp_dpm_*, hwmon power1_input / power1_cap / "
+                             "freq*_input / temp*_input, current_*_partition), read while 30 queued steps keep the GPU busy, right before the W "
+                             "warm-up steps and right after the timed region")
+    except Exception as e:                        # noqa: BLE001
+        telemetry["error"] = str(e)
     ms_per_step = dt / args.steps * 1e3
     device_ms_per_step = timed.device_ms / args.steps       # HIP events around the whole timed region, compute stream
 
@@ -885,6 +916,8 @@ def main():
                                  "`general_csr` (below) is the same block with explicit column streams",
                          "timed_region_monotonic_ns": [mono0, mono1],
                          "this_box": box,
+                         "placement_ab": placement_ab,
+                         "telemetry": telemetry,
                          "memory_classes": {"arena": ctx.arena(), "value_stream": blk.own_own.memory_class(),
                                             "x": xv.memory_class(), "y": yv.memory_class(),
                                             "what": "csrc/pa_arena.hip: matrix streams and vectors live in different memory classes "
@@ -1033,6 +1066,22 @@ def main():
     if want_cpu:
         with optional_section("CPU baseline", 3 * args.cpu_seconds + 240, N, rank):
             cpu = cpu_mul_baseline(pa, A, N, rank, args.cpu_seconds, (n, n, n, *gn))
+            # the free full-size gate (VERDICT r03 #1c): the oracle's y for the bench's own x at the bench's own size against
+            # the device's, bit for bit, on every rank
+            same = None
+            if cpu is not None and getattr(cpu_mul_baseline, "y", None) is not None:
+                x.vector_partition = pa.pmap(lambda v, ind: v.upload(xfun(ind)), x.vector_partition, A.col_partition)
+                pa.mul_(y, A, x)
+                ctx.sync()
+                same = bool(np.array_equal(pa.local_items(y.own_values())[0], cpu_mul_baseline.y))
+                if N > 1:
+                    flag = torch.tensor([1 if same else 0])
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    same = bool(flag.item())
+            if rank == 0:
+                LINE[0]["parity_full_size"] = same
+                LINE[0]["parity_gate"] += ("; full size: mul!(y, A, x) for the hashed x == the CPU baseline's (oracle C loops) y bit for bit on every "
+                                           "part" if same else "; full size vs the CPU baseline: " + ("MISMATCH" if same is False else "not run"))
             if cpu is not None and rank == 0:
                 c1 = cpu_c1_debugarray()
                 if c1:

@@ -110,6 +110,15 @@ int pa_ctx_arena_info(pa_ctx *ctx, int64_t *bytes, int *n_classes, int64_t class
 int pa_ctx_arena_map(pa_ctx *ctx, int64_t *cell_bytes, int8_t *classes, int64_t capacity, int64_t *n_cells);
 int pa_ctx_arena_stats(pa_ctx *ctx, int64_t *n_extents, int64_t *bytes_acquired, int64_t *bytes_released, int64_t *peak_used,
                        int64_t *pairs_ok, int64_t *pairs_failed, int64_t *budget, int64_t *plain_vector_bytes);
+/* Placement A/B of a product's write stream with the product kernel itself: times y = A*x (x's segment xseg) with y where it
+ * is, in every other memory class the held extents have room in and in a plain allocation (`rounds` interleaved passes of
+ * `reps` launches, the minimum per place) and MOVES y's storage when another place is more than 1.5 % faster.  where[i]
+ * (i < *n <= capacity): 0..2 arena class, 9 verified plain allocation, -1 plain / outside; ms[i] per launch; entry 0 = where
+ * y was; *chosen = the entry y lives in afterwards.  y = A*x on return.  Not inside a graph capture. */
+int pa_spmv_tune_output(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int reps, int rounds, int32_t capacity,
+                        int32_t *where, double *ms, int32_t *n, int32_t *chosen);
+/* PCI address of the context's device, e.g. "0000:75:00.0" (the key of /sys/bus/pci/devices/: clocks, power, partitions) */
+int pa_ctx_pci_bus_id(pa_ctx *ctx, char *out, size_t len);
 /* ---- psparse(I,J,V,rows,cols;assembled=true) of one part ON THE DEVICE (csrc/pa_assemble.hip) ------------------------
  * The reference's route for COO triplets in global ids -- union_ghost(rows, J, find_owner(rows, J)) (src/p_range.jl:205-259),
  * map_global_to_local! (src/p_sparse_matrix.jl:1253-1254), compresscoo(...; combine = +, skip) (src/sparse_utils.jl:313-350),
@@ -377,6 +386,22 @@ int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, dou
  * "overlap off" side of bench.py's on/off comparison.  Same kernels and bits as pa_mul. */
 int pa_mul_no_lat(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b);
 int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta);
+/* ---- transpose(A) on the device (csrc/pa_transpose.hip): mul!(c,transpose(a),b,alpha,beta), src/p_sparse_matrix.jl:2144-2162;
+ * spmtv!, src/sparse_utils.jl:613-647 --------------------------------------------------------------------------------------
+ * pa_csr_create_transpose: A' of a block resident in HBM as a new block, built without a host copy (column encoding decoded,
+ * one stable radix sort by column, the usual device-side block constructor).  Inside a row of A' the entries are ordered by
+ * ascending row of A: y = beta*y + alpha*A'*x through pa_spmv then adds, per output entry, in the order of the reference's
+ * scatter loop (spmv_csc! on the CSR arrays; SparseMatricesCSR's transposed mul!) -- bit-identical.  Not for chains of slabs.
+ * pa_matrix_create_transposed: the handle of transpose(a) for an ASSEMBLED a from A_oo' and A_oh' (pa_csr_create_transpose of
+ * a's own_own / own_ghost blocks) and the plan of the vector c lives on (a's column partition); blocks and plan stay the caller's.
+ * pa_mul5_transpose: ghost(c) = alpha*A_oh'*own(b); assemble!(c) started; own(c) = beta*own(c) + alpha*A_oo'*own(b) overlapped
+ * with the exchange; wait.  c lives on axes(a,2) (own + ghost columns), b on axes(a,1).  comm / _all as for pa_mul5 / pa_mul_all.
+ * pa_csr_download_entries: 0-based (row, column) of every stored entry in storage order as the kernels decode them (tests). */
+int pa_csr_create_transpose(const pa_csr *A, pa_csr **out);
+int pa_matrix_create_transposed(pa_ctx *ctx, const pa_csr *own_own_t, const pa_csr *own_ghost_t, pa_plan *col_plan, pa_matrix **out);
+int pa_mul5_transpose(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta);
+int pa_mul5_transpose_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta);
+int pa_csr_download_entries(const pa_csr *A, int32_t *rows, int32_t *cols);
 /* mul!(c,a,b) that also leaves this part's share of dot(b,c) in a slot (accumulate != 0: added to it): the CG loop's
  * c = A*u and u'c (HPCG/src/ref_cg.jl:59-60) without a pass over u and c for the dot -- every workgroup of the product
  * kernels adds b_own[row] * (its rows' products) in a fixed order, two small launches reduce the per-chunk partial sums.

@@ -148,6 +148,13 @@ _SIGS = {
     "pa_csr_xwin_info": [P] + [C.POINTER(i64)] * 4,
     "pa_csr_xring_info": [P, C.POINTER(i64)],
     "pa_spmv": [P, P, cint, P, cint, f64, f64],
+    "pa_spmv_tune_output": [P, P, cint, P, cint, cint, i32, P, P, C.POINTER(i32), C.POINTER(i32)],
+    "pa_ctx_pci_bus_id": [P, C.c_char_p, C.c_size_t],
+    "pa_csr_create_transpose": [P, PP],
+    "pa_matrix_create_transposed": [P, P, P, P, PP],
+    "pa_mul5_transpose": [P, P, P, P, f64, f64],
+    "pa_mul5_transpose_all": [P, i32, P, P, f64, f64],
+    "pa_csr_download_entries": [P, P, P],
     "pa_sell_create": [P, i64, i64, i64, P, P, cint, cint, P, cint, PP],
     "pa_sell_destroy": [P],
     "pa_sell_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],

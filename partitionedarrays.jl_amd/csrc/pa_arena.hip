@@ -716,6 +716,25 @@ int pa_dev_alloc(pa_ctx *c, void **p, size_t bytes, int kind) {
   return PA_OK;
 }
 
+// A buffer in a NAMED place, for the placement A/B of a product's write stream (pa_spmv_tune_output): memory class `cls` of the
+// extents the arena HOLDS (nothing is acquired, no walk, no pair check), or a plain hipMalloc (cls < 0).  *p = NULL (and
+// PA_OK) when that place has no room.  Freed with pa_dev_free like everything else.
+int pa_dev_alloc_at(pa_ctx *c, void **p, size_t bytes, int cls) {
+  *p = nullptr;
+  if (bytes == 0) bytes = 8;
+  PA_HIP(hipSetDevice(c->device));
+  if (cls < 0 || guard_mode()) {
+    if (guard_mode()) { PA_HIP(pa_raw_malloc_impl(p, bytes)); return PA_OK; }
+    if (hipMalloc(p, bytes) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; }
+    return PA_OK;
+  }
+  std::lock_guard<std::mutex> lk(c->mem_mu);
+  pa_arena *a = c->arena;
+  if (!a || cls >= a->n_classes) return PA_OK;
+  *p = arena_take(a, bytes, cls, PA_MEM_VECTOR);
+  return PA_OK;
+}
+
 void pa_dev_free(pa_ctx *c, void *p) {
   if (!p) return;
   if (guard_mode()) { (void)pa_raw_free(p); return; }

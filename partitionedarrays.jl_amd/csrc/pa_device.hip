@@ -1752,6 +1752,92 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
   return PA_OK;
 }
 
+// ---- placement A/B of a product's write stream with the PRODUCT kernel itself (round 4) ----------------------------------
+// The arena places y by rule after a 40 us stand-in probe of undocumented hardware behaviour (pa_arena.hip); whether the rule
+// was right on THIS box is answered by timing y = A*x with y where it is, in every other memory class the held extents have
+// room in (the matrix streams' own class included: the control that should be ~13 % slower) and in a plain hipMalloc --
+// `rounds` interleaved passes of `reps` launches each, the minimum per place.  where[i]: 0..2 = arena class, 9 = plain
+// allocation the pair check had verified, -1 = plain / outside the arena; entry 0 is y's current place.  When another place is
+// more than 1.5 % faster, y's storage MOVES there (contents copied; do this before capturing graphs that hold y's address) and
+// *chosen names it; otherwise *chosen = 0.  Events on the compute stream; returns after a synchronize.
+extern "C" int pa_spmv_tune_output(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int reps, int rounds, int32_t capacity,
+                                   int32_t *where, double *ms, int32_t *n_out, int32_t *chosen) {
+  PA_REQUIRE(A && x && y && where && ms && n_out && chosen && capacity >= 1, "bad arguments");
+  PA_REQUIRE(y->owned, "the vector's storage is the caller's (pa_vec_wrap): it cannot move");
+  PA_REQUIRE(reps >= 1 && rounds >= 1, "reps and rounds must be positive");
+  pa_ctx *c = A->ctx;
+  PA_REQUIRE(!c->capturing, "not inside a graph capture");
+  PA_HIP(hipSetDevice(c->device));
+  const size_t bytes = sizeof(double) * (size_t)(y->n_own + y->n_ghost + 2);
+  struct cand { int where; double *p; double best; };
+  std::vector<cand> cs;
+  const int cur = pa_mem_class(c, y->d);
+  cs.push_back({cur, y->d, 1e30});
+  for (int k = 0; k < 3 && (int)cs.size() < capacity; ++k) {
+    if (k == cur) continue;
+    void *q = nullptr;
+    PA_TRY(pa_dev_alloc_at(c, &q, bytes, k));
+    if (q) cs.push_back({k, (double *)q, 1e30});
+  }
+  if ((int)cs.size() < capacity) {
+    void *q = nullptr;
+    PA_TRY(pa_dev_alloc_at(c, &q, bytes, -1));
+    if (q) cs.push_back({-1, (double *)q, 1e30});
+  }
+  auto drop_others = [&](size_t keep) {
+    for (size_t i = 1; i < cs.size(); ++i) if (i != keep) pa_dev_free(c, cs[i].p);
+  };
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int st = PA_OK;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { pa_set_err("hipEventCreate failed"); st = PA_ERR_HIP; }
+  for (size_t i = 1; i < cs.size() && st == PA_OK; ++i)
+    if (hipMemsetAsync(cs[i].p, 0, bytes, c->s[0]) != hipSuccess) { pa_set_err("hipMemsetAsync failed"); st = PA_ERR_HIP; }
+  for (int r = 0; r < rounds && st == PA_OK; ++r)
+    for (size_t i = 0; i < cs.size() && st == PA_OK; ++i) {
+      pa_vec t = *y;
+      t.d = cs[i].p; t.owned = false;
+      for (int k = 0; k < 2 && st == PA_OK; ++k) st = pa_spmv(A, x, xseg, &t, PA_SEG_OWN, 1.0, 0.0);
+      if (st != PA_OK) break;
+      (void)hipEventRecord(e0, c->s[0]);
+      for (int k = 0; k < reps && st == PA_OK; ++k) st = pa_spmv(A, x, xseg, &t, PA_SEG_OWN, 1.0, 0.0);
+      (void)hipEventRecord(e1, c->s[0]);
+      if (hipEventSynchronize(e1) != hipSuccess) { pa_set_err("hipEventSynchronize failed"); st = PA_ERR_HIP; break; }
+      float dt = 0;
+      (void)hipEventElapsedTime(&dt, e0, e1);
+      cs[i].best = std::min(cs[i].best, (double)dt / reps);
+    }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st != PA_OK) { (void)hipStreamSynchronize(c->s[0]); drop_others(0); return st; }
+  size_t best = 0;
+  for (size_t i = 1; i < cs.size(); ++i) if (cs[i].best < cs[best].best) best = i;
+  if (best != 0 && !(cs[best].best < 0.985 * cs[0].best)) best = 0;
+  for (size_t i = 0; i < cs.size(); ++i) { where[i] = cs[i].where; ms[i] = cs[i].best; }
+  *n_out = (int32_t)cs.size();
+  *chosen = (int32_t)best;
+  // the timed products overwrote the own segment of every candidate (y's included: y = A*x now); a move carries y's values over
+  if (best != 0) {
+    PA_HIP(hipMemcpyAsync(cs[best].p, y->d, bytes, hipMemcpyDeviceToDevice, c->s[0]));
+    PA_HIP(hipStreamSynchronize(c->s[0]));
+    PA_HIP(hipStreamSynchronize(c->s[1]));
+    double *old = y->d;
+    y->d = cs[best].p;
+    pa_dev_free(c, old);
+  }
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  drop_others(best);
+  return PA_OK;
+}
+
+// PCI address of the context's device ("0000:75:00.0"): the key of its sysfs directory (/sys/bus/pci/devices/<id>/: clocks,
+// power, partition modes) -- a box shows the sysfs entries of all its GPUs, whichever ones the process may use.
+extern "C" int pa_ctx_pci_bus_id(pa_ctx *c, char *out, size_t len) {
+  PA_REQUIRE(c && out && len >= 16, "bad arguments");
+  PA_HIP(hipDeviceGetPCIBusId(out, (int)len, c->device));
+  for (char *q = out; *q; ++q) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');
+  return PA_OK;
+}
+
 // One multicolour Gauss-Seidel sweep written as SpMV with a fused update: colour k's rows are the (row-compacted)
 // block blocks[k] (n_own x n_local, every stored entry of those rows); its launch gathers from x and updates x's own
 // rows of that colour in place, x[row] += (b[row] - (A x)[row]) / diag[row].  Colours run in ascending order
@@ -2475,6 +2561,7 @@ extern "C" int pa_matrix_destroy(pa_matrix *m) {
 
 static int mul_check(const pa_matrix *m, const pa_vec *c, const pa_vec *b) {
   PA_REQUIRE(m && c && b, "bad arguments");
+  PA_REQUIRE(!m->transposed, "a transposed matrix handle takes pa_mul5_transpose");
   // @boundscheck matching_own_indices / matching_ghost_indices (src/p_sparse_matrix.jl:2091-2093)
   PA_REQUIRE(c->n_own == m->oo->t_rows, "matching_own_indices(axes(c,1),axes(a,1)) failed");
   PA_REQUIRE(b->n_own == m->oo->n_cols && b->n_ghost == m->oh->n_cols, "matching_own/ghost_indices(axes(a,2),axes(b,1)) failed");

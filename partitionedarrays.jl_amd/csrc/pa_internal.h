@@ -65,6 +65,7 @@ struct pa_ctx {
 #define PA_MEM_VECTOR 2   /* local values of a PVector */
 int pa_dev_alloc(pa_ctx *c, void **p, size_t bytes, int kind);
 void pa_dev_free(pa_ctx *c, void *p);
+int pa_dev_alloc_at(pa_ctx *c, void **p, size_t bytes, int cls);   // memory class cls of the held extents, or plain (cls < 0); *p = NULL: no room
 // hipMalloc / hipFree of the library's small buffers.  PA_DEBUG_GUARD=1 (a debugging aid, pa_arena.hip): EVERY device buffer
 // then ends (within 16 bytes) at the end of its own mapping with unmapped address space behind it, so that a load or store
 // past the end of a buffer faults instead of landing in a neighbour; =2 also fills every new buffer with 0xFF bytes, so that
@@ -202,6 +203,7 @@ struct pa_matrix {
   pa_ctx *ctx = nullptr;
   const pa_csr *oo = nullptr, *oh = nullptr;   // own_own, own_ghost (not owned)
   pa_plan *plan = nullptr;                     // exchange plan of the column partition (not owned)
+  bool transposed = false;                     // pa_matrix_create_transposed: oo = A_oo', oh = A_oh' (pa_csr_create_transpose), for pa_mul5_transpose
 };
 
 struct pa_graph {

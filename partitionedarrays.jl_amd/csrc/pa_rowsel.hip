@@ -191,11 +191,12 @@ static int select_rows_impl(const pa_csr *oo, const pa_csr *oh, const int32_t *m
   PA_REQUIRE(!oo->next && !(oh && oh->next), "a block of 2^31 stored entries or more (a chain of slabs) takes the host route");
   PA_REQUIRE(!oh || (oh->n_rows == oo->n_rows && oh->ctx == oo->ctx), "the own|ghost block does not match the own|own block");
   pa_ctx *c = oo->ctx;
+  const int64_t n_ghost_cols = oh ? oh->n_cols : 0;      // (counted before an entry-less own|ghost block is dropped below)
   if (oh && oh->nnz == 0) oh = nullptr;
   const int32_t *col_a = raw_columns(oo), *col_b = oh ? raw_columns(oh) : nullptr;
   PA_REQUIRE(oo->nnz == 0 || col_a, "the own|own block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
   PA_REQUIRE(!oh || col_b, "the own|ghost block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
-  const int64_t n = oo->n_rows, n_cols = n_cols_total >= 0 ? n_cols_total : oo->n_cols + (oh ? oh->n_cols : 0);
+  const int64_t n = oo->n_rows, n_cols = n_cols_total >= 0 ? n_cols_total : oo->n_cols + n_ghost_cols;
   PA_REQUIRE(n_cols >= oo->n_cols, "fewer columns than the own|own block has");
   PA_REQUIRE(oo->nnz + (oh ? oh->nnz : 0) < (int64_t)2147483000 && n_cols < (int64_t)2147483000, "too large for Int32 offsets");
   for (int k = 0; k < n_sel; ++k) out[k] = nullptr;
@@ -410,11 +411,12 @@ extern "C" int pa_gs_create_from_blocks(const pa_csr *oo, const pa_csr *oh, int 
   PA_REQUIRE(!oh || (oh->n_rows == oo->n_rows && oh->ctx == oo->ctx), "the own|ghost block does not match the own|own block");
   PA_REQUIRE(oo->n_rows == oo->n_cols, "the own|own block is not square");
   pa_ctx *c = oo->ctx;
+  const int64_t n_ghost_cols = oh ? oh->n_cols : 0;      // (counted before an entry-less own|ghost block is dropped below)
   if (oh && oh->nnz == 0) oh = nullptr;
   const int32_t *col_a = raw_columns(oo), *col_b = oh ? raw_columns(oh) : nullptr;
   PA_REQUIRE(oo->nnz == 0 || col_a, "the own|own block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
   PA_REQUIRE(!oh || col_b, "the own|ghost block did not keep its raw columns (create it under pa_ctx_keep_raw_columns)");
-  const int64_t n = oo->n_rows, n_local = oo->n_cols + (oh ? oh->n_cols : 0), nnz = oo->nnz + (oh ? oh->nnz : 0);
+  const int64_t n = oo->n_rows, n_local = oo->n_cols + n_ghost_cols, nnz = oo->nnz + (oh ? oh->nnz : 0);
   PA_REQUIRE(nnz < (int64_t)2147483000 && n_local < (int64_t)2147483000, "too large for Int32 offsets");
   PA_HIP(hipSetDevice(c->device));
   hipStream_t s = c->s[0];

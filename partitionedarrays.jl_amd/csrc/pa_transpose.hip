@@ -1,0 +1,228 @@
+// pa_transpose.hip -- transpose(A) of a block that is resident in HBM, built on the device (round 4).
+//
+// Reference: mul!(c, transpose(a), b, alpha, beta)  src/p_sparse_matrix.jl:2144-2162
+//              ghost(c) = alpha * A_oh' * own(b);  t = assemble!(c);  own(c) = beta*own(c) + alpha * A_oo' * own(b);  wait(t)
+//            spmtv!(b, A::SparseMatrixCSR, x) = spmv_csc!(b, x, A.rowptr, A.colval, A.nzval)  src/sparse_utils.jl:613-647,671-690
+// The transposed product of a CSR block is the scatter loop "for row ascending, for p ascending: b[col[p]] += nz[p] * x[row]":
+// an output entry j receives its contributions in ascending ROW of A.  A' stored as CSR with, inside each of its rows j, the
+// entries ordered by ascending row of A therefore reproduces that sum with the row-split kernel (accumulator starts at
+// beta*b[j], products added in stored order) bit for bit.  Built here without a host copy of anything per entry:
+//     1. the block's column encoding (row patterns / 16-bit windows / Int32) is decoded back into (row, column) per entry
+//     2. ONE stable radix sort by column (rocPRIM): equal columns keep the input order = ascending row
+//     3. the sorted entries' rows / values are the columns / values of A'; its row pointer = lower bounds of the sorted keys
+//     4. the block constructor of every other device-made block (pa_csr_from_device: row split + column encodings as kernels)
+// Works for uploaded, generated (pa_hpcg_own_block_create) and device-assembled (pa_coo_assemble) blocks alike; a block of 2^31
+// stored entries or more (a chain of slabs) is refused.
+#include "pa_dev_util.h"
+
+#include "pa_setup.h"
+#include "pa_spmv_kernel.h"
+
+using namespace pa_util;
+
+// (row, column) of every stored entry of one slab, decoded from whatever the slab keeps: one workgroup per chunk.  The
+// arithmetic is the product kernel's (pa_spmv_kernel.h) written out per entry -- no ds_bpermute tricks, this runs once.
+__global__ __launch_bounds__(256) void kt_decode(const int *__restrict__ crp, const int *__restrict__ chunk_row, const int *__restrict__ row_ids,
+                                                 const int *__restrict__ col32, const unsigned short *__restrict__ col16,
+                                                 const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
+                                                 int use_pattern, int use_c16, int cap, int n_chunks, int *__restrict__ out_row,
+                                                 int *__restrict__ out_col) {
+  const int chunk = blockIdx.x;
+  if (chunk >= n_chunks) return;
+  const int r0 = chunk_row[chunk], r1 = chunk_row[chunk + 1];
+  const int p0 = crp[r0], p1 = crp[r1];
+  const int base = p0 & ~1;
+  const bool is_long = p1 - base > cap;
+  const int *d = use_pattern ? pdesc + (size_t)chunk * PA_PDESC_INTS : nullptr;
+  const int nseg = d ? d[0] : 0;
+  const int sh16 = (d && nseg <= 0) ? d[1] : 0, sh32 = (d && nseg <= 0) ? d[2] : 0;
+  const bool c16 = use_c16 && nseg <= 0 && !is_long && win[(size_t)chunk * PA_C16_WINDOWS] >= 0;
+  for (int p = p0 + (int)threadIdx.x; p < p1; p += blockDim.x) {
+    // the (compacted) row that holds entry p: the last r in [r0, r1) with crp[r] <= p
+    int lo = r0, hi = r1 - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (crp[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    out_row[p] = row_ids ? row_ids[lo] : lo;
+    int col;
+    if (nseg > 0) {
+      const int q = p - p0;
+      int s = 0;
+      if (nseg > 1 && q >= d[1]) s = 1;
+      if (nseg > 2 && q >= d[2]) s = 2;
+      if (nseg > 3 && q >= d[3]) s = 3;
+      const int qs = s ? d[s] : 0;
+      const int Lw = d[8 + s], L = Lw & 255, stride = (Lw >> 8) ? (Lw >> 8) : 1;
+      const int t = q - qs, rr = t / L, kk = t - rr * L;
+      col = d[4 + s] + rr * stride + pdelta[(size_t)d[12 + s] * PA_PAT_MAXLEN + kk];
+    } else if (c16) {
+      const unsigned code = col16[(size_t)p + sh16];
+      col = win[(size_t)chunk * PA_C16_WINDOWS + (code >> 12)] + (int)(code & 4095u);
+    } else {
+      col = col32[(size_t)p + sh32];
+    }
+    out_col[p] = col;
+  }
+}
+
+__global__ void kt_iota(int *__restrict__ v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+// A' entry k = A's entry perm[k]: its column in A' is that entry's row in A
+__global__ void kt_gather(const int *__restrict__ perm, const int *__restrict__ row, const double *__restrict__ val, int n,
+                          int *__restrict__ out_col, double *__restrict__ out_val) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int p = perm[k];
+  out_col[k] = row[p];
+  out_val[k] = val[p];
+}
+
+// rp[j] = number of sorted keys < j, j = 0..n_keys (keys ascending): the row pointer of A'
+__global__ void kt_lower_bounds(const int *__restrict__ keys, int n, int n_rows, int *__restrict__ rp) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n_rows) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (keys[mid] < j) lo = mid + 1; else hi = mid;
+  }
+  rp[j] = lo;
+}
+
+static int decode_slab(const pa_csr *A, int32_t *d_row, int32_t *d_col) {
+  pa_ctx *c = A->ctx;
+  if (A->nnz == 0 || A->n_chunks == 0) return PA_OK;
+  hipLaunchKernelGGL(kt_decode, dim3((unsigned)A->n_chunks), dim3(256), 0, c->s[0], A->d_crp, A->d_chunk_row, A->d_row_ids, A->d_col,
+                     A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->use_pattern ? 1 : 0, A->use_c16 ? 1 : 0, PA_SPMV_CHUNK_NNZ, (int)A->n_chunks,
+                     d_row, d_col);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+// 0-based (row, column) of every stored entry in storage order, as the product kernel decodes them (tests compare this with
+// the arrays the block was made from; nothing on the product path reads it)
+extern "C" int pa_csr_download_entries(const pa_csr *A, int32_t *rows, int32_t *cols) {
+  PA_REQUIRE(A && (A->t_nnz == 0 || (rows && cols)), "bad arguments");
+  pa_ctx *c = A->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  for (const pa_csr *S = A; S; S = S->next) {
+    if (S->nnz == 0) continue;
+    scratch sc;
+    int32_t *d_row = nullptr, *d_col = nullptr;
+    PA_TRY(sc.get(&d_row, (size_t)S->nnz));
+    PA_TRY(sc.get(&d_col, (size_t)S->nnz));
+    PA_TRY(decode_slab(S, d_row, d_col));
+    PA_TRY(d2h(c->s[0], rows + S->nnz0, d_row, (size_t)S->nnz));
+    PA_TRY(d2h(c->s[0], cols + S->nnz0, d_col, (size_t)S->nnz));
+    if (S->row0) for (int64_t p = 0; p < S->nnz; ++p) rows[S->nnz0 + p] += (int32_t)S->row0;
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_csr_create_transpose(const pa_csr *A, pa_csr **out) {
+  PA_REQUIRE(A && out, "bad arguments");
+  PA_REQUIRE(!A->next, "a block of 2^31 stored entries or more (a chain of slabs) has no device-side transpose");
+  pa_ctx *c = A->ctx;
+  PA_REQUIRE(!c->capturing, "not inside a graph capture");
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  const int64_t nnz = A->nnz, n_rows_t = A->n_cols, n_cols_t = A->n_rows;
+  PA_REQUIRE(nnz < (int64_t)2147483000 && n_rows_t < (int64_t)2147483000, "too large for Int32 offsets");
+  scratch sc;
+  int32_t *d_rp = nullptr;
+  PA_TRY(sc.get(&d_rp, (size_t)n_rows_t + 1));
+  if (nnz == 0) {
+    PA_HIP(hipMemsetAsync(d_rp, 0, sizeof(int32_t) * (n_rows_t + 1), s));
+    PA_HIP(hipStreamSynchronize(s));
+    return pa_csr_from_device(c, n_rows_t, n_cols_t, 0, d_rp, nullptr, nullptr, out);
+  }
+  int32_t *d_row = nullptr, *d_col = nullptr, *d_keys = nullptr, *d_iota = nullptr, *d_perm = nullptr, *d_tcol = nullptr;
+  double *d_tval = nullptr;
+  PA_TRY(sc.get(&d_row, (size_t)nnz));
+  PA_TRY(sc.get(&d_col, (size_t)nnz));
+  PA_TRY(decode_slab(A, d_row, d_col));
+  PA_TRY(sc.get(&d_keys, (size_t)nnz));
+  PA_TRY(sc.get(&d_iota, (size_t)nnz));
+  PA_TRY(sc.get(&d_perm, (size_t)nnz));
+  hipLaunchKernelGGL(kt_iota, grid1(nnz), dim3(256), 0, s, d_iota, (int)nnz);
+  // (only the bits a column index can have: fewer radix passes)
+  unsigned bits = 1;
+  while (bits < 32 && ((int64_t)1 << bits) < n_rows_t) ++bits;
+  PA_TRY(sort_pairs(sc, s, d_col, d_keys, d_iota, d_perm, (size_t)nnz, bits));
+  sc.release(d_col);
+  sc.release(d_iota);
+  hipLaunchKernelGGL(kt_lower_bounds, grid1(n_rows_t + 1), dim3(256), 0, s, d_keys, (int)nnz, (int)n_rows_t, d_rp);
+  PA_TRY(sc.get(&d_tcol, (size_t)nnz));
+  PA_TRY(sc.get(&d_tval, (size_t)nnz));
+  hipLaunchKernelGGL(kt_gather, grid1(nnz), dim3(256), 0, s, d_perm, d_row, A->d_val, (int)nnz, d_tcol, d_tval);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(s));
+  sc.release(d_keys);
+  sc.release(d_perm);
+  sc.release(d_row);
+  return pa_csr_from_device(c, n_rows_t, n_cols_t, nnz, d_rp, d_tcol, d_tval, out);
+}
+
+// ---- mul!(c, transpose(a), b, alpha, beta) of one part / of all parts of a process ------------------------------------------
+// src/p_sparse_matrix.jl:2144-2162.  c lives on axes(a,2) (own + ghost columns), b on axes(a,1); the matrix must be assembled.
+extern "C" int pa_matrix_create_transposed(pa_ctx *c, const pa_csr *own_own_t, const pa_csr *own_ghost_t, pa_plan *col_plan, pa_matrix **out) {
+  PA_REQUIRE(c && own_own_t && own_ghost_t && col_plan && out, "bad arguments");
+  PA_REQUIRE(own_own_t->ctx == c && own_ghost_t->ctx == c && col_plan->ctx == c, "operands live in different contexts");
+  // own_own_t = A_oo' (own columns x own rows), own_ghost_t = A_oh' (ghost columns x own rows): pa_csr_create_transpose of a's blocks
+  PA_REQUIRE(own_own_t->n_cols == own_ghost_t->n_cols, "A_oo' has %lld columns, A_oh' %lld (both: the own rows of a)", (long long)own_own_t->n_cols,
+             (long long)own_ghost_t->n_cols);
+  PA_REQUIRE(own_own_t->t_rows + own_ghost_t->t_rows == col_plan->n_local, "the transposed blocks have %lld + %lld rows, the column plan %lld local ids",
+             (long long)own_own_t->t_rows, (long long)own_ghost_t->t_rows, (long long)col_plan->n_local);
+  pa_matrix *m = new pa_matrix();
+  m->ctx = c; m->oo = own_own_t; m->oh = own_ghost_t; m->plan = col_plan;   // (blocks and plan stay the caller's, as for pa_matrix_create)
+  m->transposed = true;
+  *out = m;
+  return PA_OK;
+}
+
+static int mul_t_check(const pa_matrix *m, const pa_vec *c, const pa_vec *b) {
+  PA_REQUIRE(m && c && b, "bad arguments");
+  PA_REQUIRE(m->transposed, "not a transposed matrix handle (pa_matrix_create_transposed)");
+  // oo = A_oo' (n_own_cols x n_own_rows), oh = A_oh' (n_ghost_cols x n_own_rows)
+  PA_REQUIRE(c->n_own == m->oo->t_rows && c->n_ghost == m->oh->t_rows, "c does not live on axes(a,2)");
+  PA_REQUIRE(b->n_own == m->oo->n_cols, "matching_own_indices(axes(a,1),axes(b,1)) failed");
+  PA_REQUIRE(c->d != b->d, "c and b alias");
+  return PA_OK;
+}
+
+extern "C" int pa_mul5_transpose(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta) {
+  PA_TRY(mul_t_check(m, c, b));
+  if (!comm) {
+    PA_REQUIRE(m->plan->snd.nbr.empty() && m->plan->rcv.nbr.empty(), "the column plan has neighbours: pass the communicator");
+    PA_REQUIRE(m->plan->part == 0, "without a communicator the part must be the only one");
+  }
+  PA_TRY(pa_spmv(m->oh, b, PA_SEG_OWN, c, PA_SEG_GHOST, alpha, 0.0));        // fill!(ch,0); mul!(ch,atoh,bo,alpha,1)
+  PA_TRY(pa_exchange_pack(m->plan, c, PA_ASSEMBLE));                          // t = assemble!(c)
+  if (comm) PA_TRY(pa_exchange_rccl(m->plan, comm, PA_ASSEMBLE));
+  else {
+    pa_plan *one[1] = {m->plan};
+    PA_TRY(pa_exchange_local(one, 1, PA_ASSEMBLE));
+  }
+  PA_TRY(pa_spmv(m->oo, b, PA_SEG_OWN, c, PA_SEG_OWN, alpha, beta));         // rmul!(co,beta); mul!(co,atoo,bo,alpha,1): overlaps
+  PA_TRY(pa_exchange_finish(m->plan, c, PA_ASSEMBLE));                        // wait(t): owners += ghost contributions; ghosts := 0
+  return PA_OK;
+}
+
+extern "C" int pa_mul5_transpose_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta) {
+  PA_REQUIRE(m && c && b && n_parts > 0, "bad arguments");
+  std::vector<pa_plan *> plans(n_parts);
+  for (int r = 0; r < n_parts; ++r) {
+    PA_TRY(mul_t_check(m[r], c[r], b[r]));
+    plans[r] = m[r]->plan;
+  }
+  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oh, b[r], PA_SEG_OWN, c[r], PA_SEG_GHOST, alpha, 0.0));
+  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], c[r], PA_ASSEMBLE));
+  PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_ASSEMBLE));
+  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
+  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_finish(plans[r], c[r], PA_ASSEMBLE));
+  return PA_OK;
+}

@@ -148,6 +148,23 @@ def _rows_block(h, r, c, f):
     return HostCSR(n, c.n_local, rp, colv, val)
 
 
+def _host_color_affinity(oo, color, K, kept):
+    """Host twin of pa_csr_color_affinity: per colour, the mean number of a row's own|own entries that lie in kept
+    columns (integer sums divided once, so the device and the host agree to the bit)."""
+    n = len(color)
+    mark = np.zeros(n + 1, np.int64)
+    mark[kept[(kept >= 0) & (kept < n)]] = 1
+    rp = oo.rowptr.astype(np.int64) - 1
+    cv = oo.colval.astype(np.int64) - 1
+    hit = np.where(cv < n, mark[np.minimum(cv, n)], 0)
+    cs = np.concatenate(([0], np.cumsum(hit)))
+    cnt = cs[rp[1:n + 1]] - cs[rp[:n]]
+    ok = (color >= 0) & (color < K)
+    sums = np.bincount(color[ok], weights=cnt[ok].astype(np.float64), minlength=K)
+    rows = np.bincount(color[ok], minlength=K)
+    return np.where(rows > 0, sums / np.maximum(rows, 1), 0.0)
+
+
 class ColoredGaussSeidelSpMV:
     """Multicolour Gauss-Seidel written as SpMV + update, the fast form of the optimised variant: every colour's rows
     are a (row-compacted) CSR block that runs through the row-split LDS kernel, whose epilogue does
@@ -192,10 +209,13 @@ class ColoredGaussSeidelSpMV:
             kept = kept_rows(r) if kept_rows is not None else None
             if mode == "greedy" or K < 2:
                 pass
-            elif mode == "affinity" and on_device and kept is not None and len(kept):
-                aff = np.zeros(K)
+            elif mode == "affinity" and (on_device or h is not None) and kept is not None and len(kept):
                 kr = np.ascontiguousarray(kept, np.int32)
-                L.call("pa_csr_color_affinity", dev.own_own.h, L.ptr(color), K, L.ptr(kr), len(kr), L.ptr(aff))
+                if on_device:
+                    aff = np.zeros(K)
+                    L.call("pa_csr_color_affinity", dev.own_own.h, L.ptr(color), K, L.ptr(kr), len(kr), L.ptr(aff))
+                else:                                       # the same integer counts from the host block: both set-up routes
+                    aff = _host_color_affinity(h[0], color, K, kr)   # sweep the colours in the same order
                 order = np.lexsort((np.arange(K), -aff))              # greedy colours in sweep order
                 pos = np.empty(K, np.int32)
                 pos[order] = np.arange(K, dtype=np.int32)
@@ -316,7 +336,10 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
         #  the dependency levels of the sequential sweep -- and the restriction's rows are made from them on the device,
         #  csrc/pa_rowsel.hip; PA_SETUP_ROWSEL=0: the host copies them)
         keep_raw = (ordering in ("multicolor_spmv", "sequential") and os.environ.get("PA_SETUP_ROWSEL", "1") != "0"
-                    and os.environ.get("PA_SETUP_DEVICE", "1") != "0")
+                    and os.environ.get("PA_SETUP_DEVICE", "1") != "0"
+                    # a part of 2^31 stored entries or more is a chain of slabs the device route does not cut rows from:
+                    # such a level keeps its host copy and takes the host route
+                    and nx * ny * nz * 27 < 2 ** 31 - 648)
         # (nothing of the set-up reads a host copy of the blocks then: they are generated in HBM, gallery.build_split_blocks_device)
         A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=not keep_raw, fused=True,
                               keep_raw=keep_raw)

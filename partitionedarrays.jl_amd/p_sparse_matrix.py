@@ -241,6 +241,18 @@ def spmv_(b, A, x, x_segment=L.SEG_OWN, b_segment=L.SEG_OWN, alpha=1.0, beta=0.0
     return b
 
 
+def tune_output_placement(A, x, y, x_segment=L.SEG_OWN, reps=10, rounds=3):
+    """pa_spmv_tune_output: time y = A*x with y in every place the context can reach (its current one first) and move y's
+    storage when another place is more than 1.5 % faster.  Returns {"places": [{"where", "ms"}...], "chosen": index, "moved"}."""
+    cap = 8
+    where, ms = np.zeros(cap, np.int32), np.zeros(cap, np.float64)
+    n, chosen = C.c_int32(), C.c_int32()
+    L.call("pa_spmv_tune_output", A.h, x.h, x_segment, y.h, int(reps), int(rounds), cap, L.ptr(where), L.ptr(ms), C.byref(n), C.byref(chosen))
+    names = {-1: "plain hipMalloc", 9: "plain hipMalloc (pair-checked)"}
+    return {"places": [{"where": names.get(int(w), f"arena class {int(w)}"), "ms": round(float(t), 4)} for w, t in zip(where[:n.value], ms[:n.value])],
+            "chosen": int(chosen.value), "moved": bool(chosen.value != 0)}
+
+
 @dataclass
 class SplitMatrixBlocks:
     """SplitMatrix blocks of one part (src/p_sparse_matrix.jl:588-627); ghost rows only when sub-assembled."""
@@ -505,19 +517,60 @@ def mul5_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PVector:
     return c
 
 
+def transposed_blocks(a: PSparseMatrix):
+    """(A_oo', A_oh') of every part, built ON THE DEVICE from the blocks resident in HBM (pa_csr_create_transpose: decoded column
+    encoding, one stable sort by column; csrc/pa_transpose.hip) -- no host copy, so generated and device-assembled matrices
+    have them too.  Built once, cached on `a` (psparse!-style value updates of `a` drop the cache)."""
+    if getattr(a, "_t_blocks", None) is None:
+        def mk(blk):
+            out = []
+            for B in (blk.own_own, blk.own_ghost):
+                h = C.c_void_p()
+                L.call("pa_csr_create_transpose", B.h, C.byref(h))
+                out.append(DeviceCSR.from_handle(h, B.n, B.m, B.nnz, B.ctx))
+            return tuple(out)
+        a._t_blocks = pmap(mk, a.matrix_partition)
+    return a._t_blocks
+
+
 def mul5_transpose_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PVector:
     """mul!(c,transpose(a),b,alpha,beta) (src/p_sparse_matrix.jl:2144-2162), a assembled; c lives on axes(a,2), b on
-    axes(a,1).  The transposed blocks are built once (needs psparse(...,keep_host=True)) and cached on `a`."""
+    axes(a,1): ghost(c) = alpha*A_oh'*own(b), assemble!(c) started, own(c) = beta*own(c) + alpha*A_oo'*own(b) under the
+    exchange, wait.  One library call per process where the operator-level call applies (pa_mul5_transpose[_all])."""
+    from .primitives import DebugArray, TorchDistArray
+    from . import p_vector as pv
     if not a.assembled:
         raise L.PAError("mul!(c,transpose(a),b,...) needs an assembled matrix (@assert a.assembled, :2146)")
-    if getattr(a, "_t_blocks", None) is None:
-        if a.host_blocks is None:
-            raise L.PAError("transpose product needs the host blocks: build the matrix with keep_host=True")
-        a._t_blocks = pmap(lambda h: (DeviceCSR.transposed(h[0]), DeviceCSR.transposed(h[1])), a.host_blocks)
-    # ghost_values(c) = alpha * A_oh' * b_own   (fill!(ch,0); mul!(ch,atoh,bo,alpha,1))
-    pmap(lambda cv, t, bv: spmv_(cv, t[1], bv, L.SEG_OWN, L.SEG_GHOST, alpha, 0.0), c.vector_partition, a._t_blocks, b.vector_partition)
+    tb = transposed_blocks(a)
+    vp = c.vector_partition
+    direct = isinstance(vp, DebugArray) or (isinstance(vp, TorchDistArray) and (
+        vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None)))
+    if direct:
+        cache = c.__dict__.setdefault("_pa_matrices_t", {})
+        if id(a) not in cache:
+            def mk(t, plan):
+                h = C.c_void_p()
+                L.call("pa_matrix_create_transposed", context().h, t[0].h, t[1].h, plan, C.byref(h))
+                return h
+            cache[id(a)] = _OperatorHandles(pmap(mk, tb, c.cache.plans), a)
+            import weakref
+            if getattr(a, "_t_users", None) is None:
+                a._t_users = weakref.WeakSet()
+            a._t_users.add(c)
+        hs = cache[id(a)].handles
+        if isinstance(vp, DebugArray):
+            n = len(vp.items)
+            arr = lambda xs: (C.c_void_p * n)(*xs)
+            L.call("pa_mul5_transpose_all", arr(hs.items), n, arr([v.h for v in vp.items]), arr([v.h for v in b.vector_partition.items]),
+                   float(alpha), float(beta))
+        else:
+            comm = context().comm.h if (vp.size > 1) else None
+            L.call("pa_mul5_transpose", hs.item, comm, vp.item.h, b.vector_partition.item.h, float(alpha), float(beta))
+        return c
+    # (transports the library does not drive itself: the same kernels composed here)
+    pmap(lambda cv, t, bv: spmv_(cv, t[1], bv, L.SEG_OWN, L.SEG_GHOST, alpha, 0.0), c.vector_partition, tb, b.vector_partition)
     tsk = assemble_(c)
-    pmap(lambda cv, t, bv: spmv_(cv, t[0], bv, L.SEG_OWN, L.SEG_OWN, alpha, beta), c.vector_partition, a._t_blocks, b.vector_partition)
+    pmap(lambda cv, t, bv: spmv_(cv, t[0], bv, L.SEG_OWN, L.SEG_OWN, alpha, beta), c.vector_partition, tb, b.vector_partition)
     tsk.wait()
     return c
 
@@ -846,6 +899,9 @@ def psparse_(C_: PSparseMatrix, V, cache: MatrixReassemblyCache) -> Task:
 
     def finish():
         t.wait()
+        C_._t_blocks = None             # (transposed copies hold the old values: rebuilt on the next transpose product)
+        for v in list(getattr(C_, "_t_users", ())):
+            v.__dict__.get("_pa_matrices_t", {}).pop(id(C_), None)
         pmap(lambda blk, w, k: (L.call("pa_csr_update_values_from", blk.own_own.h, w.h, 0),
                                 L.call("pa_csr_update_values_from", blk.own_ghost.h, w.h, int(k))),
              C_.matrix_partition, cache.W, cache.nnz_oo)

@@ -62,6 +62,57 @@ class Context:
         """Announce a solver's worth of vectors (pa_ctx_arena_hint): they alternate between two memory classes of their own."""
         L.call("pa_ctx_arena_hint", self.h, int(vector_classes))
 
+    def pci_bus_id(self):
+        """PCI address of this context's GPU (pa_ctx_pci_bus_id): /sys/bus/pci/devices/<id>/ holds its clocks and power."""
+        buf = C.create_string_buffer(64)
+        L.call("pa_ctx_pci_bus_id", self.h, buf, 64)
+        return buf.value.decode()
+
+    def telemetry(self):
+        """Clocks, power and partition modes of this context's GPU, read from its sysfs directory (what rocm-smi / amd-smi
+        print, without spawning them): a dict of whatever the box exposes, {} when nothing is readable."""
+        import glob
+        try:
+            base = "/sys/bus/pci/devices/" + self.pci_bus_id()
+        except L.PAError:
+            return {}
+        out = {}
+
+        def rd(path):
+            try:
+                return open(path).read().strip()
+            except OSError:
+                return None
+
+        def cur_level(name):
+            txt = rd(f"{base}/{name}")
+            if txt is None:
+                return None
+            for line in txt.splitlines():
+                if line.strip().endswith("*"):
+                    return line.split(":", 1)[1].strip().rstrip("*").strip()
+            return None
+        for key, name in (("sclk", "pp_dpm_sclk"), ("mclk", "pp_dpm_mclk"), ("fclk", "pp_dpm_fclk"), ("socclk", "pp_dpm_socclk")):
+            v = cur_level(name)
+            if v is not None:
+                out[key] = v
+        for key, name in (("compute_partition", "current_compute_partition"), ("memory_partition", "current_memory_partition"),
+                          ("perf_level", "power_dpm_force_performance_level")):
+            v = rd(f"{base}/{name}")
+            if v is not None:
+                out[key] = v
+        for hw in sorted(glob.glob(base + "/hwmon/hwmon*")):
+            for key, name, scale in (("power_w", "power1_input", 1e-6), ("power_w", "power1_average", 1e-6), ("power_cap_w", "power1_cap", 1e-6),
+                                     ("sclk_mhz", "freq1_input", 1e-6), ("mclk_mhz", "freq2_input", 1e-6),
+                                     ("temp_junction_c", "temp2_input", 1e-3), ("temp_mem_c", "temp3_input", 1e-3)):
+                v = rd(f"{hw}/{name}")
+                if v is not None and key not in out:
+                    try:
+                        out[key] = round(int(v) * scale, 1)
+                    except ValueError:
+                        pass
+        return out
+
     def arena_release(self):
         """Hand the extents of an idle arena back to the driver now (pa_ctx_arena_release; it keeps up to 24 GiB otherwise)."""
         L.call("pa_ctx_arena_release", self.h)

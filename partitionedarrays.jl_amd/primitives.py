@@ -323,7 +323,8 @@ def exchange(snd, graph: ExchangeGraph):
     send, independent of the number of parts.  The graph's consistency (src/primitives.jl:861-874) is checked there in its
     cheap form by default -- every rank's receive list must be exactly the ranks that send to it, or the call asserts on
     EVERY rank instead of leaving one end in a blocking receive (PA_CHECK_EXCHANGE_GRAPHS=0 trusts the graph, =2 runs the
-    reference's full check); the in-process DebugArray always runs the full check.
+    reference's full check); the in-process DebugArray always runs the full check.  The FIRST exchange over a graph is
+    therefore a collective over the whole group (every rank must enter it); the verdict is remembered on the graph.
     """
     if isinstance(snd, TorchDistArray):
         import torch.distributed as dist
@@ -344,10 +345,17 @@ def exchange(snd, graph: ExchangeGraph):
         except Exception:                                    # noqa: BLE001
             dev = None
         kw = {} if dev is None else {"device": dev}
-        if CHECK_EXCHANGE_GRAPHS == 1:
+        # The check is a collective over the WHOLE group (an all-gather + an all-reduce): it runs once per graph object --
+        # the first exchange over a graph must be entered by every rank of the group, later ones only involve neighbours.
+        checked = getattr(graph, "_edges_checked", None)
+        if CHECK_EXCHANGE_GRAPHS == 1 and checked != id(group):
             ok, senders = _edges_match(dist, group, me, world, snd_ids, rcv_ids, kw)
             assert ok, (f"inconsistent ExchangeGraph (src/primitives.jl:861-874) seen from part {me}: it expects messages from "
                         f"{sorted(rcv_ids)}, the parts that send to it are {senders}")
+            try:
+                graph._edges_checked = id(group)
+            except AttributeError:                           # (a graph type without a __dict__: check every time)
+                pass
         snd_at = {q: j for j, q in enumerate(snd_ids)}                 # partner -> position (a dict, not a scan per round)
         rcv_at = {q: j for j, q in enumerate(rcv_ids)}
 
@@ -358,7 +366,12 @@ def exchange(snd, graph: ExchangeGraph):
         # first.  Every edge (i -> j) is met in exactly one round by both of its ends.
         # Only the rounds of REAL neighbours are walked (in round order, which both ends of an edge compute alike): a rank
         # with 6 neighbours among 512 parts does 6 rounds, not 512.
-        partners = sorted(set(snd_ids) | set(rcv_ids), key=lambda q: ((q - 1) + (me - 1)) % world)
+        # That short walk relies on both ends of an edge knowing it; an unchecked graph (PA_CHECK_EXCHANGE_GRAPHS=0) walks
+        # all P rounds, where a one-sided edge cannot shift the partner's later rounds.
+        if CHECK_EXCHANGE_GRAPHS == 0:
+            partners = sorted(range(1, world + 1), key=lambda q: ((q - 1) + (me - 1)) % world)
+        else:
+            partners = sorted(set(snd_ids) | set(rcv_ids), key=lambda q: ((q - 1) + (me - 1)) % world)
         for partner in partners:
             if partner == me:
                 if me in snd_at and me in rcv_at:                     # a part that lists itself (never on this path; kept exact)
