@@ -380,6 +380,52 @@ def time_block(pa, ctx, L, blk, n_rows, n_cols, reps=30):
     return e0.elapsed_ms(e1) / reps
 
 
+def chain_info(P):
+    """Launches of one mul! of P parts in one process after round 4 (csrc/pa_push.hip, pa_mul_all): 1 push (pack + deliver, all
+    parts), P own x own, P own x ghost (reading the receive buffers), 1 unpack (all parts); no copies.  On the critical path of ONE
+    part behind its own x own: the own x ghost launch (the push runs beside own x own, the unpack behind own x ghost)."""
+    return {"launches_per_step": 2 * P + 2, "launches_per_step_round3": "4 per part + one copy per directed edge",
+            "critical_path_launches": {"before_own_own": 0, "beside_own_own": 1, "after_own_own": 1, "after_own_ghost_off_path": 1}}
+
+
+def whole_mul_times(pa, ctx, L, A, x, y, reps=30):
+    """ms per mul! of all parts of A (eager: one library call; replayed from a hipGraph) and ms of the parts' own x own alone."""
+    spin_up(ctx, lambda: pa.mul_c_(y, A, x))
+    e0 = ctx.event().record(L.STREAM_COMPUTE)
+    for _ in range(reps):
+        pa.mul_c_(y, A, x)
+    e1 = ctx.event().record(L.STREAM_COMPUTE)
+    ctx.sync()
+    ms = e0.elapsed_ms(e1) / reps
+    ms_graph = float("nan")
+    try:
+        with pa.Graph() as g:
+            pa.mul_c_(y, A, x)
+        for _ in range(10):
+            g.launch()
+        e0 = ctx.event().record(L.STREAM_COMPUTE)
+        for _ in range(reps):
+            g.launch()
+        e1 = ctx.event().record(L.STREAM_COMPUTE)
+        ctx.sync()
+        ms_graph = e0.elapsed_ms(e1) / reps
+    except Exception as e:                                       # noqa: BLE001
+        print(f"[bench] hipGraph replay of mul! skipped: {e}", file=sys.stderr)
+    blocks, xs, ys = pa.local_items(A.matrix_partition), pa.local_items(x.vector_partition), pa.local_items(y.vector_partition)
+
+    def spmv_only():
+        for blk, xv, yv in zip(blocks, xs, ys):
+            pa.spmv_(yv, blk.own_own, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
+    for _ in range(5):
+        spmv_only()
+    e0 = ctx.event().record(L.STREAM_COMPUTE)
+    for _ in range(reps):
+        spmv_only()
+    e1 = ctx.event().record(L.STREAM_COMPUTE)
+    ctx.sync()
+    return ms, ms_graph, e0.elapsed_ms(e1) / reps
+
+
 def extra_configs(pa, ctx, L, out):
     """BASELINE configs 2, 3 (one part's size) and 5 (one part's rows) on this GPU, one entry each: ms per product,
     GFLOP/s, algorithmic GB/s (12 B per entry + 20 B per row), moved GB/s (bytes the block's encoding makes the
@@ -420,6 +466,23 @@ def extra_configs(pa, ctx, L, out):
     ctx.sync()
     out.append(entry("config 3's size: HPCG 27-pt 128^3, 1 part, mul!", b3, b3.m, b3.n, e0.elapsed_ms(e1) / 50, ts))
     del A3, b3, x3, y3
+    # config 3 itself: 27-point 128^3 per part, 2 parts as (2,1,1), both on this ONE GPU: the whole mul! (push launch, own x own,
+    # own x ghost from the receive buffers, unpack) per part against own x own alone (<= 1.15 x)
+    PHASE[0] = "extra: config 3 on 2 parts"
+    t = time.perf_counter()
+    ranks2 = pa.DebugArray([1, 2])
+    A32, _ = pa.build_p_matrix(ranks2, 128, 128, 128, 256, 128, 128, 2, 1, 1)
+    ts = time.perf_counter() - t
+    x32 = pa.pvector_from_function(lambda ind: hash_x(ind.get_local_to_global()) * (ind.get_local_to_owner() == ind.part), A32.col_partition)
+    y32 = pa.pzeros(A32.row_partition)
+    ms, ms_graph, ms_spmv = whole_mul_times(pa, ctx, L, A32, x32, y32)
+    nnz32 = sum(b.own_own.nnz + b.own_ghost.nnz for b in pa.local_items(A32.matrix_partition))
+    out.append({"workload": "config 3 whole: HPCG 27-pt 128^3 per part, 2 parts (2,1,1) BOTH on this one GPU, mul! = push (pack + deliver) + "
+                            "own x own + own x ghost from the receive buffer + unpack (pa_mul_all)",
+                "parts": 2, "nnz": int(nnz32), "ghosts_per_part": [c.n_ghost for c in pa.local_items(A32.col_partition)],
+                "ms_per_part_mul": round(ms / 2, 4), "ms_per_part_mul_hipgraph": round(ms_graph / 2, 4), "ms_per_part_spmv": round(ms_spmv / 2, 4),
+                "mul_over_spmv": round(ms / ms_spmv, 3), **chain_info(2), "gflops": round(2.0 * nnz32 / ms / 1e6, 1), "setup_s": round(ts, 1)})
+    del A32, x32, y32
     # config 5: the rows one part of the 4096^2-node Q1 FEM matrix on (4,2) parts holds: 1024 x 2048 nodes
     PHASE[0] = "extra: config 5 part"
     t = time.perf_counter()
@@ -509,14 +572,7 @@ def extra_configs(pa, ctx, L, out):
     ts = time.perf_counter() - t
     x5 = pa.pvector_from_function(lambda ind: hash_x(ind.get_local_to_global()) * (ind.get_local_to_owner() == ind.part), A5.col_partition)
     y5 = pa.pzeros(A5.row_partition)
-    spin_up(ctx, lambda: pa.mul_c_(y5, A5, x5))
-    reps = 30
-    e0 = ctx.event().record(L.STREAM_COMPUTE)
-    for _ in range(reps):
-        pa.mul_c_(y5, A5, x5)
-    e1 = ctx.event().record(L.STREAM_COMPUTE)
-    ctx.sync()
-    ms = e0.elapsed_ms(e1) / reps
+    ms, ms_graph, ms_spmv = whole_mul_times(pa, ctx, L, A5, x5, y5)
     blocks = pa.local_items(A5.matrix_partition)
     nnz5 = sum(b.own_own.nnz + b.own_ghost.nnz for b in blocks)
     ghosts = [c.n_ghost for c in pa.local_items(A5.col_partition)]
@@ -525,7 +581,9 @@ def extra_configs(pa, ctx, L, out):
     out.append({"workload": f"config 5 whole: Q1 FEM Laplacian {n5} x {n5} nodes, 8 parts (4,2) ALL on this one GPU, disassembled psparse "
                             "route, mul! = pack + device-to-device exchange + own x own + unpack + own x ghost (pa_mul_all)",
                 "parts": 8, "rows": int(rows5), "nnz": int(nnz5), "ghosts_per_part": ghosts, "ms_all_parts": round(ms, 4),
-                "ms_per_part": round(ms / 8, 4), "gflops": round(2.0 * nnz5 / ms / 1e6, 1), "moved_gbps": round(moved / ms / 1e6, 1),
+                "ms_per_part": round(ms / 8, 4), "ms_per_part_mul": round(ms / 8, 4), "ms_per_part_mul_hipgraph": round(ms_graph / 8, 4),
+                "ms_per_part_spmv": round(ms_spmv / 8, 4), **chain_info(8),
+                "gflops": round(2.0 * nnz5 / ms / 1e6, 1), "moved_gbps": round(moved / ms / 1e6, 1),
                 "encoding_own_own": blocks[0].own_own.encoding(), "encoding_own_ghost": blocks[0].own_ghost.encoding(), "setup_s": round(ts, 1)})
     del A5, x5, y5, blocks
     # the caller of the hot path that §8(f) names next: one MG-PCG iteration of the HPCG driver (4 levels, multicolour
@@ -882,7 +940,9 @@ def main():
                        "ghosts_per_part": n_ghost, "index_type": "Int32",
                        "transport": {"rccl": "rccl-p2p (ncclSend/ncclRecv group on the comm stream)",
                                      "torch": "torch.distributed p2p (FALLBACK, PA_ALLOW_TRANSPORT_FALLBACK=1: not the RCCL row)",
-                                     "host": "host-staged gloo (test transport: ranks may share a GPU)"}.get(transport, transport),
+                                     "host": "host-staged gloo (test transport: ranks may share a GPU)",
+                                     "ipc": "ipc push (PA_TRANSPORT=ipc: the pack kernel stores into the neighbours' hipIpc-mapped receive "
+                                            "buffers, csrc/pa_push.hip; ranks may share a GPU)"}.get(transport, transport),
                        "rccl_ranks_seen": rccl_ranks_seen, "overlap": overlap_on,
                        "stream_priority": prio},
             "gflops_per_gpu": round(value / N, 2),
@@ -1054,6 +1114,40 @@ def main():
             print(f"[bench] general-CSR entries stopped at {PHASE[0]!r}: {e}", file=sys.stderr)
         general = general or None
 
+    # ---- SURVEY 8(f) row f2 at the headline's size: mul!(c,transpose(A),b,1,0) with A' built on the device from the resident
+    # block (no host copy exists: the headline matrix was generated in HBM)
+    transpose = None
+    if N == 1 and args.extra and rank == 0:
+        try:
+            PHASE[0] = "transpose product"
+            ctx.sync()
+            t = time.perf_counter()
+            pa.transposed_blocks(A)
+            ctx.sync()
+            t_build = time.perf_counter() - t
+            ct = pa.pzeros(A.col_partition)
+            bt = pa.pvector_from_function(lambda ind: hash_x(ind.get_local_to_global()), A.row_partition)
+            pa.mul5_transpose_(ct, A, bt, 1.0, 0.0)
+            pa.mul_(y, A, x)                                   # A = A' for this operator and x = bt on the own entries
+            ctx.sync()
+            sym_err = float(np.max(np.abs(pa.local_items(ct.own_values())[0] - pa.local_items(y.own_values())[0])))
+            spin_up(ctx, lambda: pa.mul5_transpose_(ct, A, bt, 1.0, 0.0))
+            e0 = ctx.event().record(L.STREAM_COMPUTE)
+            for _ in range(30):
+                pa.mul5_transpose_(ct, A, bt, 1.0, 0.0)
+            e1 = ctx.event().record(L.STREAM_COMPUTE)
+            ctx.sync()
+            ms_t = e0.elapsed_ms(e1) / 30
+            tb = pa.local_items(pa.transposed_blocks(A))[0][0]
+            transpose = {"workload": f"mul!(c,transpose(A),b,1,0) on the headline matrix (27-pt {n}^3, 1 part), A' built on the device "
+                                     "(pa_csr_create_transpose: decode + one stable radix sort by column + device-side block constructor)",
+                         "ms": round(ms_t, 4), "gflops": round(2.0 * nnz / ms_t / 1e6, 1), "rate_vs_forward": round(ms_per_step / ms_t, 3),
+                         "build_s": round(t_build, 2), "encoding": tb.encoding(), "max_abs_diff_vs_forward_product": sym_err}
+            del ct, bt
+            A._t_blocks = None
+        except Exception as e:                                 # noqa: BLE001
+            print(f"[bench] transpose product skipped: {e}", file=sys.stderr)
+
     extras = None
     if N == 1 and args.extra and rank == 0:
         extras = []
@@ -1094,6 +1188,8 @@ def main():
             out["value_dictionary_mode"] = vdict
         if general:
             out["general_csr"] = general
+        if transpose:
+            out["transpose_product"] = transpose
         if extras:
             out["extra_configs"] = extras
         print(json.dumps(out), flush=True)

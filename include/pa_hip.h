@@ -365,6 +365,24 @@ int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mode);
 /* Transport B: one process per part over RCCL (MPIArray analogue, src/mpi_array.jl:575-614):
  * one ncclGroup of ncclSend/ncclRecv per neighbour on the comm stream; rank = part - index_base. */
 int pa_exchange_rccl(pa_plan *plan, pa_comm *comm, int mode);
+/* Transport C, "push" (csrc/pa_push.hip): the pack kernel stores every send slice straight into the receive buffer of the part
+ * it goes to -- pack and exchange! fused, no send buffer, no copies.
+ *   pa_exchange_push_local: every part of this process, ONE launch per device; replaces pa_exchange_pack on every part +
+ *     pa_exchange_local (v[i]: the vector of part i).  pa_exchange_finish per part is next, as after pa_exchange_local.
+ *   One part per process: the neighbours' receive buffers are mapped over hipIpc.  pa_plan_ipc_blob gives the opaque bytes
+ *     (ipc handles + slice tables) a neighbour needs; the host language carries every part's blob to its neighbours (or to
+ *     everybody) as it carries the RCCL unique id; pa_plan_ipc_connect(plan, blobs...) opens them.  pa_exchange_push_ipc then
+ *     replaces pa_exchange_pack + pa_exchange_rccl: the stores travel over xGMI, arrival is a sequence number written behind the
+ *     payload, the receiver acknowledges after its unpack (flow control for the next exchange).  A wait that lasts longer than
+ *     PA_IPC_TIMEOUT_S (30) raises the link's status (pa_plan_ipc_status: 0 ok, 1 arrival, 2 acknowledgement) and the next
+ *     exchange over the link fails with PA_ERR_STATE -- the GPU is never left spinning.  Not inside a graph capture.
+ * pa_mul5 / pa_mul_no_lat / pa_mul_dot / pa_mul5_transpose with comm == NULL use a connected plan's ipc link. */
+int pa_exchange_push_local(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode);
+int pa_plan_ipc_blob_size(pa_plan *plan, int64_t *bytes);
+int pa_plan_ipc_blob(pa_plan *plan, void *out, int64_t capacity);
+int pa_plan_ipc_connect(pa_plan *plan, int32_t n_blobs, const void *const *blobs, const int64_t *sizes);
+int pa_plan_ipc_status(pa_plan *plan, int *status);
+int pa_exchange_push_ipc(pa_plan *plan, const pa_vec *v, int mode);
 
 /* ---- operator level: the whole mul! of a part in one call ------------------------------------------------------------
  * pa_matrix = the operands of mul! that do not change between products: the own_own / own_ghost blocks of an ASSEMBLED
@@ -386,6 +404,12 @@ int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, dou
  * "overlap off" side of bench.py's on/off comparison.  Same kernels and bits as pa_mul. */
 int pa_mul_no_lat(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b);
 int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta);
+/* Round 4: at a handle's first product the library makes a twin of own_ghost whose columns are positions of consistent!'s RECEIVE
+ * BUFFER (same entries, same order): own x ghost then gathers b's ghost values from buffer_rcv as soon as the messages are in,
+ * and the unpack that makes b itself consistent (src/p_vector.jl:603-611) runs behind it -- one launch less on the critical path
+ * of every mul!.  Same bits.  Not when a ghost column with stored entries receives no message, nor with
+ * PA_MUL_GHOST_FROM_BUFFER=0.  pa_mul_all packs and delivers all parts with one push launch (PA_PUSH=0: pack per part + copies). */
+int pa_matrix_ghost_from_buffer(const pa_matrix *m, int *yes);
 /* ---- transpose(A) on the device (csrc/pa_transpose.hip): mul!(c,transpose(a),b,alpha,beta), src/p_sparse_matrix.jl:2144-2162;
  * spmtv!, src/sparse_utils.jl:613-647 --------------------------------------------------------------------------------------
  * pa_csr_create_transpose: A' of a block resident in HBM as a new block, built without a host copy (column encoding decoded,

@@ -74,6 +74,7 @@ _SIGS = {
     "pa_mul5": [P, P, P, P, f64, f64],
     "pa_mul_no_lat": [P, P, P, P],
     "pa_mul_all": [P, i32, P, P, f64, f64],
+    "pa_matrix_ghost_from_buffer": [P, C.POINTER(cint)],
     "pa_mul_dot": [P, P, P, P, cint, cint],
     "pa_mul_all_dot": [P, i32, P, P, cint],
     "pa_vec_dot_slot": [P, P, cint, cint],
@@ -166,6 +167,12 @@ _SIGS = {
     "pa_exchange_finish": [P, P, cint],
     "pa_exchange_local": [PP, i32, cint],
     "pa_exchange_rccl": [P, P, cint],
+    "pa_exchange_push_local": [PP, i32, PP, cint],
+    "pa_plan_ipc_blob_size": [P, C.POINTER(i64)],
+    "pa_plan_ipc_blob": [P, P, i64],
+    "pa_plan_ipc_connect": [P, i32, P, P],
+    "pa_plan_ipc_status": [P, C.POINTER(cint)],
+    "pa_exchange_push_ipc": [P, P, cint],
     "pa_comm_unique_id": [C.c_char_p],
     "pa_comm_create": [P, C.c_char_p, cint, cint, PP],
     "pa_comm_destroy": [P],

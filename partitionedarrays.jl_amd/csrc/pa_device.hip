@@ -2392,6 +2392,7 @@ extern "C" int pa_plan_destroy(pa_plan *p) {
   (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->s[0]);
   (void)hipStreamSynchronize(p->ctx->s[1]);
+  pa_push_release(p);
   for (pa_plan::side *s : {&p->snd, &p->rcv}) {
     (void)pa_raw_free(s->d_idx);
     (void)pa_raw_free(s->d_buf);
@@ -2426,6 +2427,7 @@ extern "C" int pa_exchange_pack(pa_plan *p, const pa_vec *v, int mode) {
              (long long)(v->n_own + v->n_ghost), (long long)p->n_local);
   PA_REQUIRE(p->phase == 0, "exchange already in flight on this plan (missing pa_exchange_finish)");
   pa_ctx *c = p->ctx;
+  p->ev_wait = nullptr;
   if (p->snd.n == 0 && p->rcv.n == 0) {  // a part without neighbours (e.g. the only part): nothing to move, no stream traffic
     p->phase = 1;
     p->mode = mode;
@@ -2471,6 +2473,7 @@ extern "C" int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mod
                               pr->ctx->s[1]));
     }
     if (in.n || out_side(pr, mode).n) PA_HIP(hipEventRecord(pr->ev_arrived, pr->ctx->s[1]));
+    pr->ev_wait = nullptr;
     pr->phase = 2;
   }
   return PA_OK;
@@ -2478,7 +2481,18 @@ extern "C" int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mod
 
 int pa_plan_mark_arrived(pa_plan *p) {
   PA_HIP(hipEventRecord(p->ev_arrived, p->ctx->s[1]));
+  p->ev_wait = nullptr;
   p->phase = 2;
+  return PA_OK;
+}
+
+// the compute stream waits for the arrival of the exchange in flight, nothing else (no unpack): what a kernel that reads the
+// RECEIVE BUFFER itself needs (own x ghost with renamed columns, pa_mul5)
+static int exchange_wait_arrived(pa_plan *p) {
+  if (p->snd.n == 0 && p->rcv.n == 0) return PA_OK;
+  pa_ctx *c = p->ctx;
+  if (p->phase == 1) PA_HIP(hipEventRecord(p->ev_arrived, c->s[1]));
+  PA_HIP(hipStreamWaitEvent(c->s[0], p->ev_wait ? p->ev_wait : p->ev_arrived, 0));
   return PA_OK;
 }
 
@@ -2509,13 +2523,15 @@ extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
     PA_HIP(hipEventRecord(p->ev_arrived, c->s[1]));
     PA_HIP(hipStreamWaitEvent(c->s[0], p->ev_arrived, 0));  // wait(t)
     PA_HIP(hipGetLastError());
+    PA_TRY(pa_ipc_ack(p, mode));                            // (push transport: the senders may reuse the buffer; compute stream)
     p->phase = 0;
     return PA_OK;                                           // (the next pack is on the comm stream too: ordered)
   }
   if (p->phase == 1) {  // caller-driven transport on the comm stream: everything queued there so far counts
     PA_HIP(hipEventRecord(p->ev_arrived, c->s[1]));
   }
-  PA_HIP(hipStreamWaitEvent(c->s[0], p->ev_arrived, 0));  // wait(t)
+  PA_HIP(hipStreamWaitEvent(c->s[0], p->ev_wait ? p->ev_wait : p->ev_arrived, 0));  // wait(t)
+  p->ev_wait = nullptr;
   if (mode == PA_CONSISTENT) {
     if (in.n) hipLaunchKernelGGL(k_unpack_insert, dim3((in.n + 255) / 256), dim3(256), 0, c->s[0], v->d, in.d_buf, in.d_idx, (int)in.n);
   } else {
@@ -2530,9 +2546,13 @@ extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
       hipLaunchKernelGGL(k_fill, dim3(grid_for(v->n_ghost, 256)), dim3(256), 0, c->s[0], v->d + v->n_own, (int64_t)v->n_ghost, 0.0);
   }
   PA_HIP(hipGetLastError());
-  // the next pack (on the comm stream) must not overwrite buffers this unpack still reads
-  PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
-  PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+  PA_TRY(pa_ipc_ack(p, mode));
+  // the next pack (on the comm stream) must not overwrite buffers this unpack still reads (inside a capture the next pack's own
+  // fork from the compute stream orders it; a trailing fork would be left unjoined)
+  if (!c->capturing) {
+    PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
+    PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+  }
   p->phase = 0;
   return PA_OK;
 }
@@ -2555,6 +2575,7 @@ extern "C" int pa_matrix_create(pa_ctx *c, const pa_csr *own_own, const pa_csr *
 }
 
 extern "C" int pa_matrix_destroy(pa_matrix *m) {
+  if (m && m->oh_rb) pa_csr_destroy(m->oh_rb);     // (own x ghost with renamed columns: made for this handle, matrix_rb)
   delete m;
   return PA_OK;
 }
@@ -2568,49 +2589,97 @@ static int mul_check(const pa_matrix *m, const pa_vec *c, const pa_vec *b) {
   return PA_OK;
 }
 
+// t = consistent!(b) / assemble!(c) of ONE part of this process: pack + transport over whichever link there is -- the RCCL
+// communicator (one part per process), the plan's ipc link (pa_plan_ipc_connect: the pack kernel pushes into the neighbours'
+// buffers), or nothing (the only part)
+int pa_exchange_start(pa_plan *p, pa_comm *comm, pa_vec *v, int mode) {
+  if (comm) {
+    PA_TRY(pa_exchange_pack(p, v, mode));
+    return pa_exchange_rccl(p, comm, mode);
+  }
+  if (pa_plan_ipc_connected(p)) return pa_exchange_push_ipc(p, v, mode);
+  PA_REQUIRE(p->snd.nbr.empty() && p->rcv.nbr.empty(), "the plan has neighbours: pass the communicator (or connect the plans over ipc)");
+  PA_REQUIRE(p->part == 0, "without a communicator the part must be the only one");
+  PA_TRY(pa_exchange_pack(p, v, mode));
+  pa_plan *one[1] = {p};
+  return pa_exchange_local(one, 1, mode);
+}
+
+// own x ghost with its columns renamed to positions of consistent!'s receive buffer (built once per handle): the product then
+// gathers b's ghost values straight from buffer_rcv, and the unpack that makes b itself consistent moves behind it, off the
+// critical path of mul! (src/p_vector.jl:603-611 still runs, later).  Same entries, same order, same values gathered: same bits.
+// Not built when a ghost column with stored entries gets no message (it would have nothing to read), inside a graph capture, or
+// with PA_MUL_GHOST_FROM_BUFFER=0.
+static int matrix_rb(pa_matrix *m) {
+  if (m->rb_tried || m->transposed) return PA_OK;
+  if (m->ctx->capturing) return PA_OK;
+  m->rb_tried = true;
+  const int on = getenv("PA_MUL_GHOST_FROM_BUFFER") ? atoi(getenv("PA_MUL_GHOST_FROM_BUFFER")) : 1;
+  if (!on) return PA_OK;
+  pa_plan *p = m->plan;
+  const pa_plan::side &in = p->snd;                           // the receiving side of consistent! (ghost lids)
+  if (in.n == 0 || m->oh->t_nnz == 0 || m->oh->next) return PA_OK;
+  const int64_t n_own = m->oo->n_cols, n_ghost = m->oh->n_cols;
+  std::vector<int32_t> map((size_t)n_ghost, -1);
+  for (int64_t k = 0; k < in.n; ++k) {
+    const int64_t g = (int64_t)in.idx[k] - n_own;
+    if (g < 0 || g >= n_ghost || map[g] != -1) return PA_OK;  // (not a plain ghost list: the unpack path serves)
+    map[g] = (int32_t)k;
+  }
+  pa_csr *rb = nullptr;
+  if (pa_csr_create_remapped(m->oh, map.data(), in.n, &rb) != PA_OK) { (void)hipGetLastError(); return PA_OK; }
+  m->oh_rb = rb;
+  return PA_OK;
+}
+
+// own x ghost of one part after its exchange has been started and own x own queued
+static int mul_ghost_part(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha) {
+  pa_plan *p = m->plan;
+  if (m->oh_rb && (p->snd.n || p->rcv.n)) {
+    PA_TRY(exchange_wait_arrived(p));                                        // wait(t), without the unpack
+    pa_vec buf;
+    buf.ctx = m->ctx; buf.d = p->snd.d_buf; buf.n_own = p->snd.n; buf.n_ghost = 0; buf.owned = false;
+    PA_TRY(pa_spmv(m->oh_rb, &buf, PA_SEG_OWN, c, PA_SEG_OWN, alpha, 1.0));   // own x ghost from buffer_rcv
+    return pa_exchange_finish(p, b, PA_CONSISTENT);                           // b's ghosts, behind it
+  }
+  PA_TRY(pa_exchange_finish(p, b, PA_CONSISTENT));                           // wait(t)
+  return pa_spmv(m->oh, b, PA_SEG_GHOST, c, PA_SEG_OWN, alpha, 1.0);         // own x ghost
+}
+
 // src/p_sparse_matrix.jl:2105-2142 (assembled branch); alpha = 1, beta = 0 is :2090-2103
 extern "C" int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta) {
   PA_TRY(mul_check(m, c, b));
   PA_REQUIRE(c->d != b->d, "c and b alias");
-  if (!comm) {
-    PA_REQUIRE(m->plan->snd.nbr.empty() && m->plan->rcv.nbr.empty(), "the column plan has neighbours: pass the communicator");
-    PA_REQUIRE(m->plan->part == 0, "without a communicator the part must be the only one");
-  }
-  PA_TRY(pa_exchange_pack(m->plan, b, PA_CONSISTENT));                       // t = consistent!(b)
-  if (comm) PA_TRY(pa_exchange_rccl(m->plan, comm, PA_CONSISTENT));
-  else {
-    pa_plan *one[1] = {m->plan};
-    PA_TRY(pa_exchange_local(one, 1, PA_CONSISTENT));
-  }
+  PA_TRY(matrix_rb(m));
+  PA_TRY(pa_exchange_start(m->plan, comm, b, PA_CONSISTENT));                // t = consistent!(b)
   PA_TRY(pa_spmv(m->oo, b, PA_SEG_OWN, c, PA_SEG_OWN, alpha, beta));        // own x own, overlaps the exchange
-  PA_TRY(pa_exchange_finish(m->plan, b, PA_CONSISTENT));                     // wait(t)
-  PA_TRY(pa_spmv(m->oh, b, PA_SEG_GHOST, c, PA_SEG_OWN, alpha, 1.0));       // own x ghost
-  return PA_OK;
+  return mul_ghost_part(m, c, b, alpha);
 }
 
 extern "C" int pa_mul(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b) { return pa_mul5(m, comm, c, b, 1.0, 0.0); }
+
+// *yes = 1 when own x ghost of this handle reads consistent!'s receive buffer (decided at the first product; 0 before it)
+extern "C" int pa_matrix_ghost_from_buffer(const pa_matrix *m, int *yes) {
+  PA_REQUIRE(m && yes, "bad arguments");
+  *yes = m->oh_rb != nullptr;
+  return PA_OK;
+}
 
 // mul_no_lat!(c,a,b) (HPCG/src/hpcg_utils.jl:6-17): consistent!(b) |> wait FIRST, then the two local products -- the order
 // HPCG's reference solver uses, and the "overlap off" side of bench.py's comparison.  Same kernels, same bits as pa_mul.
 extern "C" int pa_mul_no_lat(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b) {
   PA_TRY(mul_check(m, c, b));
   PA_REQUIRE(c->d != b->d, "c and b alias");
-  if (!comm) {
-    PA_REQUIRE(m->plan->snd.nbr.empty() && m->plan->rcv.nbr.empty(), "the column plan has neighbours: pass the communicator");
-    PA_REQUIRE(m->plan->part == 0, "without a communicator the part must be the only one");
-  }
-  PA_TRY(pa_exchange_pack(m->plan, b, PA_CONSISTENT));
-  if (comm) PA_TRY(pa_exchange_rccl(m->plan, comm, PA_CONSISTENT));
-  else {
-    pa_plan *one[1] = {m->plan};
-    PA_TRY(pa_exchange_local(one, 1, PA_CONSISTENT));
-  }
+  PA_TRY(pa_exchange_start(m->plan, comm, b, PA_CONSISTENT));
   PA_TRY(pa_exchange_finish(m->plan, b, PA_CONSISTENT));
   PA_TRY(pa_spmv(m->oo, b, PA_SEG_OWN, c, PA_SEG_OWN, 1.0, 0.0));
   PA_TRY(pa_spmv(m->oh, b, PA_SEG_GHOST, c, PA_SEG_OWN, 1.0, 1.0));
   return PA_OK;
 }
 
+// Every part of this process.  Round 4: ONE push launch packs and delivers all parts (pa_push.hip), own x ghost reads the receive
+// buffers, ONE launch unpacks b's ghosts behind it: 2 + 2 per part launches and no copies where round 3 queued 4 per part + one
+// copy per directed edge.  PA_PUSH=0: the round-3 order (pack per part, device-to-device copies, unpack before own x ghost).
 extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c, pa_vec *const *b, double alpha, double beta) {
   PA_REQUIRE(m && c && b && n_parts > 0, "bad arguments");
   std::vector<pa_plan *> plans(n_parts);
@@ -2619,12 +2688,39 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
     PA_REQUIRE(c[r]->d != b[r]->d, "c and b alias (part %d)", r);
     plans[r] = m[r]->plan;
   }
-  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], b[r], PA_CONSISTENT));
-  PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_CONSISTENT));
+  const int push = getenv("PA_PUSH") ? atoi(getenv("PA_PUSH")) : 1;      // (read per call: tests switch it)
+  bool all_rb = push != 0;
+  if (push) {
+    for (int r = 0; r < n_parts; ++r) {
+      PA_TRY(matrix_rb(m[r]));
+      if ((plans[r]->snd.n || plans[r]->rcv.n) && !m[r]->oh_rb && m[r]->oh->t_nnz) all_rb = false;
+    }
+    PA_TRY(pa_exchange_push_local(plans.data(), n_parts, b, PA_CONSISTENT));
+  } else {
+    for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], b[r], PA_CONSISTENT));
+    PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_CONSISTENT));
+  }
   for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
+  if (all_rb) {
+    hipEvent_t waited = nullptr;
+    for (int r = 0; r < n_parts; ++r) {
+      pa_plan *p = plans[r];
+      if (!(p->snd.n || p->rcv.n)) continue;
+      if (p->ev_wait == nullptr || p->ev_wait != waited) PA_TRY(exchange_wait_arrived(p));   // (one event per device: waited for once)
+      waited = p->ev_wait;
+      if (!m[r]->oh_rb) continue;
+      pa_vec buf;
+      buf.ctx = m[r]->ctx; buf.d = p->snd.d_buf; buf.n_own = p->snd.n; buf.n_ghost = 0; buf.owned = false;
+      PA_TRY(pa_spmv(m[r]->oh_rb, &buf, PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, 1.0));
+    }
+    return pa_exchange_finish_all_insert(plans.data(), n_parts, b);
+  }
   for (int r = 0; r < n_parts; ++r) {
-    PA_TRY(pa_exchange_finish(plans[r], b[r], PA_CONSISTENT));
-    PA_TRY(pa_spmv(m[r]->oh, b[r], PA_SEG_GHOST, c[r], PA_SEG_OWN, alpha, 1.0));
+    if (push) PA_TRY(mul_ghost_part(m[r], c[r], b[r], alpha));
+    else {
+      PA_TRY(pa_exchange_finish(plans[r], b[r], PA_CONSISTENT));
+      PA_TRY(pa_spmv(m[r]->oh, b[r], PA_SEG_GHOST, c[r], PA_SEG_OWN, alpha, 1.0));
+    }
   }
   return PA_OK;
 }
@@ -2734,17 +2830,8 @@ extern "C" int pa_mul_dot(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, int
   PA_REQUIRE(c->d != b->d, "c and b alias");
   PA_REQUIRE(PA_SLOT_OK(slot), "slot %d out of range [0,%d)", slot, PA_N_SLOTS);
   PA_REQUIRE(b->n_own == c->n_own, "dot(b,c) needs a square operator: %lld columns, %lld rows", (long long)b->n_own, (long long)c->n_own);
-  if (!comm) {
-    PA_REQUIRE(m->plan->snd.nbr.empty() && m->plan->rcv.nbr.empty(), "the column plan has neighbours: pass the communicator");
-    PA_REQUIRE(m->plan->part == 0, "without a communicator the part must be the only one");
-  }
   PA_HIP(hipSetDevice(m->ctx->device));
-  PA_TRY(pa_exchange_pack(m->plan, b, PA_CONSISTENT));
-  if (comm) PA_TRY(pa_exchange_rccl(m->plan, comm, PA_CONSISTENT));
-  else {
-    pa_plan *one[1] = {m->plan};
-    PA_TRY(pa_exchange_local(one, 1, PA_CONSISTENT));
-  }
+  PA_TRY(pa_exchange_start(m->plan, comm, b, PA_CONSISTENT));
   PA_TRY(mul_dot_part(m, c, b, slot, accumulate, true, false));
   PA_TRY(pa_exchange_finish(m->plan, b, PA_CONSISTENT));
   PA_TRY(mul_dot_part(m, c, b, slot, accumulate, false, true));
@@ -2763,8 +2850,12 @@ extern "C" int pa_mul_all_dot(pa_matrix *const *m, int32_t n_parts, pa_vec *cons
     PA_REQUIRE(m[r]->ctx == m[0]->ctx, "the parts of one call share a context");
     plans[r] = m[r]->plan;
   }
-  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], b[r], PA_CONSISTENT));
-  PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_CONSISTENT));
+  const int push = getenv("PA_PUSH") ? atoi(getenv("PA_PUSH")) : 1;      // (read per call: tests switch it)
+  if (push) PA_TRY(pa_exchange_push_local(plans.data(), n_parts, b, PA_CONSISTENT));
+  else {
+    for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], b[r], PA_CONSISTENT));
+    PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_CONSISTENT));
+  }
   // the parts share the context's partial-sum scratch: part r's product + reduction run before part r+1's first half
   // overwrites it (one stream: in order), so own x own of part r cannot wait for ALL exchanges as pa_mul_all's does --
   // one part (the benchmark's case) loses nothing

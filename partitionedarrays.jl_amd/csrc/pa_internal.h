@@ -145,6 +145,9 @@ struct pa_csr {
   int64_t t_rows = 0, t_nnz = 0;
 };
 
+struct pa_push_table;   // device tables of the push transport for a group of plans in one process (pa_push.hip)
+struct pa_ipc_link;     // the neighbours' receive buffers and flags mapped over hipIpc, one part per process (pa_push.hip)
+
 struct pa_plan {
   struct side {
     std::vector<int32_t> nbr;   // 0-based part ids
@@ -164,7 +167,18 @@ struct pa_plan {
   int phase = 0;     // 0 idle, 1 packed, 2 arrived
   bool own_comm_stream = false;   // this exchange's transport ran on this part's comm stream alone (RCCL: one part per process)
   int mode = 0;
+  hipEvent_t ev_wait = nullptr;   // what wait(t) waits for: ev_arrived, or the event a group launch recorded once for all its parts
+  pa_push_table *push[2] = {nullptr, nullptr};   // plans[0] of a group caches the group's tables here, per mode
+  pa_ipc_link *ipc = nullptr;     // pa_plan_ipc_connect
+  unsigned long long seq[2] = {0, 0};            // exchanges started so far, per mode (the push transport's sequence numbers)
+  bool ipc_ack_due = false;       // this exchange arrived over the ipc link: pa_exchange_finish acknowledges it to the senders
 };
+
+bool pa_plan_ipc_connected(const pa_plan *p);
+int pa_exchange_start(pa_plan *p, pa_comm *comm, pa_vec *v, int mode);   // pack + transport of one part (RCCL / ipc / none)
+int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v);   // after pa_exchange_push_local(CONSISTENT)
+void pa_push_release(pa_plan *p);                // frees what pa_push.hip hung on a plan
+int pa_ipc_ack(pa_plan *p, int mode);            // (compute stream) tell the senders of the exchange just consumed that the buffer is free
 
 struct pa_scatter {
   pa_ctx *ctx = nullptr;
@@ -203,6 +217,8 @@ struct pa_matrix {
   pa_ctx *ctx = nullptr;
   const pa_csr *oo = nullptr, *oh = nullptr;   // own_own, own_ghost (not owned)
   pa_plan *plan = nullptr;                     // exchange plan of the column partition (not owned)
+  pa_csr *oh_rb = nullptr;                     // own_ghost with its columns renamed to positions of consistent!'s RECEIVE BUFFER (owned;
+  bool rb_tried = false;                       //   built at the first product): own x ghost then needs no unpack before it
   bool transposed = false;                     // pa_matrix_create_transposed: oo = A_oo', oh = A_oh' (pa_csr_create_transpose), for pa_mul5_transpose
 };
 

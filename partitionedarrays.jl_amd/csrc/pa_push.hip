@@ -1,0 +1,596 @@
+// pa_push.hip -- the "push" transport of the ghost exchange (round 4): the pack kernel stores every send slice STRAIGHT INTO THE
+// RECEIVE BUFFER of the part it goes to.  No send buffer, no copy engine, no library kernels between pack and unpack.
+//
+// Reference: exchange!(buffer_rcv, buffer_snd, graph) inside assemble_impl! (src/p_vector.jl:595-601): pack loop, then
+// rcv[i].data[ptrs_rcv[k]..] <- snd[j].data[ptrs_snd[l]..] per directed edge (src/primitives.jl:1020-1042; MPI: Isend / Irecv per
+// neighbour, src/mpi_array.jl:575-614).  Fusing the two is invisible to the caller: buffer_rcv holds the same values when wait(t)
+// returns; buffer_snd is a private scratch of the cache that nothing else reads.
+//
+// Two shapes:
+//  (a) every part in ONE process (DebugArray, src/debug_array.jl:110-117,250): the neighbours' buffers are ordinary device
+//      pointers.  pa_exchange_push_local packs AND delivers all parts with ONE launch (per device) where the round-3 path
+//      queued one pack kernel per part and one hipMemcpyAsync per directed edge (config 5 on 8 parts: 8 + ~40 operations).
+//  (b) one part per PROCESS (MPIArray): the neighbours' receive buffers are mapped with hipIpcOpenMemHandle
+//      (pa_plan_ipc_blob / pa_plan_ipc_connect; the host language moves the blobs, as it moves the ncclUniqueId), the stores
+//      travel over xGMI (or stay inside the GPU when ranks share one: how this is tested on 1-GPU boxes), and arrival is a
+//      sequence number the LAST block of the push kernel writes behind its payload -- release at system scope -- into a flag
+//      word in the receiver's memory; the receiver's comm stream runs a one-wavefront wait kernel before the event wait(t)
+//      waits on.  Flow control: the receiver acknowledges (pa_exchange_finish -> pa_ipc_ack) after its unpack, and the next
+//      push into that buffer spins on the acknowledgement of the one before (it has long arrived in any iterative solver: there
+//      is a dot product between two products).  PA_TRANSPORT=ipc; RCCL stays the default transport (`north_star`).
+//      A wait gives up after PA_IPC_TIMEOUT_S (default 30) and raises the link's status word instead of hanging the GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "pa_internal.h"
+
+#define PA_PUSH_MAX_PARTS 32
+
+struct pa_push_seg {
+  int32_t start, len;                 // entries [start, start + len) of the part's send list ...
+  double *dst;                        // ... go to dst[0 .. len)
+  unsigned long long *arrive;         // ipc: the flag in the receiver's memory this slice's arrival is announced in
+  const unsigned long long *ack;      // ipc: the flag in MY memory the receiver acknowledges the previous slice in
+};
+struct pa_push_part {
+  const int32_t *idx;                 // send list (local ids)
+  int32_t n, seg0, nseg, blk0;
+};
+struct pa_push_vecs { const double *v[PA_PUSH_MAX_PARTS]; };
+
+__device__ __forceinline__ int push_find_seg(const pa_push_seg *__restrict__ segs, int s0, int ns, int p) {
+  int lo = s0, hi = s0 + ns - 1;                       // the last segment whose start <= p
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].start <= p) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// (a) all parts of a process: block -> part through block_part
+__global__ __launch_bounds__(256) void k_push_local(const pa_push_part *__restrict__ parts, const pa_push_seg *__restrict__ segs,
+                                                    const int32_t *__restrict__ block_part, pa_push_vecs vecs) {
+  const int pi = block_part[blockIdx.x];
+  const pa_push_part P = parts[pi];
+  const int p = ((int)blockIdx.x - P.blk0) * 256 + (int)threadIdx.x;
+  if (p >= P.n) return;
+  const double val = vecs.v[pi][P.idx[p]];
+  const int s = push_find_seg(segs, P.seg0, P.nseg, p);
+  segs[s].dst[p - segs[s].start] = val;
+}
+
+struct pa_unpack_part { const int32_t *idx; const double *buf; int32_t n, blk0; };
+struct pa_unpack_vecs { double *v[PA_PUSH_MAX_PARTS]; };
+__global__ __launch_bounds__(256) void k_unpack_insert_multi(const pa_unpack_part *__restrict__ parts, const int32_t *__restrict__ block_part,
+                                                             pa_unpack_vecs vecs) {
+  const int pi = block_part[blockIdx.x];
+  const pa_unpack_part P = parts[pi];
+  const int p = ((int)blockIdx.x - P.blk0) * 256 + (int)threadIdx.x;
+  if (p < P.n) vecs.v[pi][P.idx[p]] = P.buf[p];
+}
+
+__device__ __forceinline__ unsigned long long flag_load(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void flag_store(unsigned long long *p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// spin until *p >= want; false after `ticks` of the 100 MHz wall clock
+__device__ __forceinline__ bool flag_wait(const unsigned long long *p, unsigned long long want, long long ticks) {
+  if (flag_load(p) >= want) return true;
+  const long long t0 = (long long)wall_clock64();
+  for (;;) {
+    for (int k = 0; k < 64; ++k) {
+      if (flag_load(p) >= want) return true;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if ((long long)wall_clock64() - t0 > ticks) return false;
+  }
+}
+
+// (b) one part per process
+__global__ __launch_bounds__(256) void k_push_ipc(const int32_t *__restrict__ idx, int n, const pa_push_seg *__restrict__ segs, int nseg,
+                                                  const double *__restrict__ v, unsigned long long seq, unsigned *done, long long ticks,
+                                                  int *status) {
+  const int p0 = (int)blockIdx.x * 256, p = p0 + (int)threadIdx.x;
+  __shared__ int ok;
+  if (threadIdx.x == 0) {
+    // flow control: the receivers of the slices this block writes must have consumed what the previous exchange put there
+    int good = 1;
+    if (seq > 1 && n > 0) {
+      const int sa = push_find_seg(segs, 0, nseg, min(p0, n - 1)), sb = push_find_seg(segs, 0, nseg, min(p0 + 255, n - 1));
+      for (int s = sa; s <= sb && good; ++s) good = flag_wait(segs[s].ack, seq - 1, ticks) ? 1 : 0;
+    }
+    ok = good;
+  }
+  __syncthreads();
+  if (!ok) { if (threadIdx.x == 0) atomicExch(status, 2); return; }
+  if (p < n) {
+    const double val = v[idx[p]];
+    const int s = push_find_seg(segs, 0, nseg, p);
+    segs[s].dst[p - segs[s].start] = val;
+  }
+  __threadfence_system();                              // my stores are in memory before I count myself done
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(done, 1u);
+    if (t == gridDim.x - 1) {                          // the last block of the launch announces every slice
+      *done = 0;
+      __threadfence_system();
+      for (int s = 0; s < nseg; ++s) flag_store(segs[s].arrive, seq);
+    }
+  }
+}
+
+__global__ void k_wait_flags(const unsigned long long *__restrict__ flags, const int32_t *__restrict__ which, int n, unsigned long long seq,
+                             long long ticks, int *status) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (!flag_wait(flags + which[i], seq, ticks)) atomicExch(status, 1);
+}
+
+__global__ void k_write_flags(unsigned long long *const *__restrict__ dst, int n, unsigned long long seq) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag_store(dst[i], seq);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+static inline pa_plan::side &out_side(pa_plan *p, int mode) { return mode == PA_ASSEMBLE ? p->snd : p->rcv; }
+static inline pa_plan::side &in_side(pa_plan *p, int mode) { return mode == PA_ASSEMBLE ? p->rcv : p->snd; }
+
+struct pa_push_table {
+  std::vector<pa_plan *> key;
+  // one launch per device (context) that holds parts of the group
+  struct launch {
+    pa_ctx *ctx = nullptr;
+    std::vector<int> parts;           // group indices, in order
+    pa_push_part *d_parts = nullptr;
+    pa_push_seg *d_segs = nullptr;
+    int32_t *d_block_part = nullptr;
+    int n_blocks = 0;
+    // the matching multi-part unpack (insert) of the parts on this device
+    pa_unpack_part *d_uparts = nullptr;
+    int32_t *d_ublock_part = nullptr;
+    int n_ublocks = 0;
+    hipEvent_t ev = nullptr;
+  };
+  std::vector<launch> launches;
+  void free_all() {
+    for (launch &l : launches) {
+      (void)hipSetDevice(l.ctx->device);
+      (void)pa_raw_free(l.d_parts); (void)pa_raw_free(l.d_segs); (void)pa_raw_free(l.d_block_part);
+      (void)pa_raw_free(l.d_uparts); (void)pa_raw_free(l.d_ublock_part);
+      if (l.ev) (void)hipEventDestroy(l.ev);
+    }
+    launches.clear();
+  }
+};
+
+template <class T>
+static int upload_vec(const std::vector<T> &h, T **d) {
+  PA_HIP(pa_raw_malloc(d, sizeof(T) * std::max<size_t>(1, h.size())));
+  if (!h.empty()) PA_HIP(pa_h2d(*d, h.data(), sizeof(T) * h.size()));
+  return PA_OK;
+}
+
+static int build_local_table(pa_plan *const *plans, int n_parts, int mode, pa_push_table **out) {
+  pa_push_table *T = new pa_push_table();
+  T->key.assign(plans, plans + n_parts);
+  std::map<pa_ctx *, int> at;
+  for (int r = 0; r < n_parts; ++r) {
+    pa_ctx *c = plans[r]->ctx;
+    if (!at.count(c)) { at[c] = (int)T->launches.size(); T->launches.emplace_back(); T->launches.back().ctx = c; }
+    T->launches[at[c]].parts.push_back(r);
+  }
+  for (pa_push_table::launch &l : T->launches) {
+    if ((int)l.parts.size() > PA_PUSH_MAX_PARTS) { delete T; pa_set_err("more than %d parts on one device", PA_PUSH_MAX_PARTS); return PA_ERR_ARG; }
+    std::vector<pa_push_part> parts;
+    std::vector<pa_push_seg> segs;
+    std::vector<int32_t> bp, ubp;
+    std::vector<pa_unpack_part> uparts;
+    for (size_t k = 0; k < l.parts.size(); ++k) {
+      pa_plan *ps = plans[l.parts[k]];
+      pa_plan::side &o = out_side(ps, mode);
+      pa_push_part P;
+      P.idx = o.d_idx; P.n = (int32_t)o.n; P.seg0 = (int32_t)segs.size(); P.nseg = 0; P.blk0 = (int32_t)bp.size();
+      for (size_t j = 0; j < o.nbr.size(); ++j) {
+        const int len = o.ptrs[j + 1] - o.ptrs[j];
+        if (!len) continue;
+        const int q = o.nbr[j];
+        if (q < 0 || q >= n_parts) { T->free_all(); delete T; pa_set_err("part %d: neighbour %d out of range", ps->part, q); return PA_ERR_ARG; }
+        pa_plan *pr = plans[q];
+        pa_plan::side &in = in_side(pr, mode);
+        auto it = std::find(in.nbr.begin(), in.nbr.end(), ps->part);
+        if (it == in.nbr.end()) { T->free_all(); delete T; pa_set_err("inconsistent ExchangeGraph: part %d sends to %d, which does not receive from it", ps->part, q); return PA_ERR_ARG; }
+        const size_t i = it - in.nbr.begin();
+        if (in.ptrs[i + 1] - in.ptrs[i] != len) { T->free_all(); delete T; pa_set_err("slice length mismatch between parts %d and %d", ps->part, q); return PA_ERR_ARG; }
+        pa_push_seg S;
+        S.start = o.ptrs[j]; S.len = len; S.dst = in.d_buf + in.ptrs[i]; S.arrive = nullptr; S.ack = nullptr;
+        segs.push_back(S);
+        ++P.nseg;
+      }
+      const int nb = (int)((o.n + 255) / 256);
+      for (int b = 0; b < nb; ++b) bp.push_back((int32_t)k);
+      if (P.nseg == 0) P.n = 0;
+      parts.push_back(P);
+      pa_plan::side &in = in_side(ps, mode);
+      pa_unpack_part U;
+      U.idx = in.d_idx; U.buf = in.d_buf; U.n = (int32_t)in.n; U.blk0 = (int32_t)ubp.size();
+      const int nub = (int)((in.n + 255) / 256);
+      for (int b = 0; b < nub; ++b) ubp.push_back((int32_t)k);
+      uparts.push_back(U);
+    }
+    // every receiving slice must have a sender inside the group
+    (void)hipSetDevice(l.ctx->device);
+    int st = upload_vec(parts, &l.d_parts);
+    if (st == PA_OK) st = upload_vec(segs, &l.d_segs);
+    if (st == PA_OK) st = upload_vec(bp, &l.d_block_part);
+    if (st == PA_OK) st = upload_vec(uparts, &l.d_uparts);
+    if (st == PA_OK) st = upload_vec(ubp, &l.d_ublock_part);
+    if (st == PA_OK && hipEventCreateWithFlags(&l.ev, hipEventDisableTiming) != hipSuccess) { pa_set_err("hipEventCreate failed"); st = PA_ERR_HIP; }
+    if (st != PA_OK) { T->free_all(); delete T; return st; }
+    l.n_blocks = (int)bp.size();
+    l.n_ublocks = (int)ubp.size();
+  }
+  // slices expected by a receiver that no sender of the group provides (an inconsistent graph seen from the other end)
+  for (int r = 0; r < n_parts; ++r) {
+    pa_plan::side &in = in_side(plans[r], mode);
+    for (size_t i = 0; i < in.nbr.size(); ++i) {
+      const int s = in.nbr[i];
+      bool ok = s >= 0 && s < n_parts;
+      if (ok) { pa_plan::side &o = out_side(plans[s], mode); ok = std::find(o.nbr.begin(), o.nbr.end(), r) != o.nbr.end(); }
+      if (!ok) { T->free_all(); delete T; pa_set_err("inconsistent ExchangeGraph: part %d receives from %d, which does not send to it", r, s); return PA_ERR_ARG; }
+    }
+  }
+  *out = T;
+  return PA_OK;
+}
+
+static int local_table(pa_plan *const *plans, int n_parts, int mode, pa_push_table **out) {
+  pa_push_table *&T = plans[0]->push[mode];
+  if (T && ((int)T->key.size() != n_parts || !std::equal(T->key.begin(), T->key.end(), plans))) {
+    T->free_all();
+    delete T;
+    T = nullptr;
+  }
+  if (!T) PA_TRY(build_local_table(plans, n_parts, mode, &T));
+  *out = T;
+  return PA_OK;
+}
+
+// pack + exchange! of every part of this process in one launch per device: what pa_exchange_pack on every part followed by
+// pa_exchange_local does, minus the send buffers.  Afterwards every plan is in the state pa_exchange_local leaves it in
+// (pa_exchange_finish is next).
+extern "C" int pa_exchange_push_local(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode) {
+  PA_REQUIRE(plans && v && n_parts > 0 && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  for (int r = 0; r < n_parts; ++r) {
+    PA_REQUIRE(plans[r] && v[r] && plans[r]->part == r, "plans[%d] is not the plan of part %d", r, r);
+    PA_REQUIRE(v[r]->n_own + v[r]->n_ghost == plans[r]->n_local, "part %d: vector has %lld local values, plan expects %lld", r,
+               (long long)(v[r]->n_own + v[r]->n_ghost), (long long)plans[r]->n_local);
+    PA_REQUIRE(plans[r]->phase == 0, "part %d: exchange already in flight on this plan (missing pa_exchange_finish)", r);
+  }
+  pa_push_table *T = nullptr;
+  PA_TRY(local_table(plans, n_parts, mode, &T));
+  for (pa_push_table::launch &l : T->launches) {
+    pa_ctx *c = l.ctx;
+    PA_HIP(hipSetDevice(c->device));
+    // the comm stream must see everything the compute stream wrote into the vectors so far
+    PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
+    PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+    if (l.n_blocks) {
+      pa_push_vecs vv;
+      for (size_t k = 0; k < l.parts.size(); ++k) vv.v[k] = v[l.parts[k]]->d;
+      hipLaunchKernelGGL(k_push_local, dim3(l.n_blocks), dim3(256), 0, c->s[1], l.d_parts, l.d_segs, l.d_block_part, vv);
+      PA_HIP(hipGetLastError());
+    }
+    PA_HIP(hipEventRecord(l.ev, c->s[1]));
+  }
+  // a part's slices have arrived when every device that sends to it has finished its launch: with one device that is the
+  // launch's own event (recorded once, shared by the parts); with several, each comm stream waits for the others' launches
+  for (pa_push_table::launch &l : T->launches) {
+    if (T->launches.size() > 1) {
+      PA_HIP(hipSetDevice(l.ctx->device));
+      for (pa_push_table::launch &o : T->launches) if (&o != &l) PA_HIP(hipStreamWaitEvent(l.ctx->s[1], o.ev, 0));
+      PA_HIP(hipEventRecord(l.ev, l.ctx->s[1]));
+    }
+    for (int r : l.parts) {
+      pa_plan *p = plans[r];
+      p->phase = 2; p->mode = mode; p->own_comm_stream = false;
+      p->ev_wait = l.ev;
+    }
+  }
+  return PA_OK;
+}
+
+// unpack (insert) of every part of the group with one launch per device, on the compute streams, AFTER whatever the caller
+// queued there since the arrival (own x ghost reading the receive buffers).  consistent! only.
+int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v) {
+  pa_push_table *T = plans[0]->push[PA_CONSISTENT];
+  PA_REQUIRE(T && (int)T->key.size() == n_parts && std::equal(T->key.begin(), T->key.end(), plans), "no push table for these plans");
+  for (pa_push_table::launch &l : T->launches) {
+    pa_ctx *c = l.ctx;
+    PA_HIP(hipSetDevice(c->device));
+    PA_HIP(hipStreamWaitEvent(c->s[0], l.ev, 0));
+    if (l.n_ublocks) {
+      pa_unpack_vecs vv;
+      for (size_t k = 0; k < l.parts.size(); ++k) vv.v[k] = v[l.parts[k]]->d;
+      hipLaunchKernelGGL(k_unpack_insert_multi, dim3(l.n_ublocks), dim3(256), 0, c->s[0], l.d_uparts, l.d_ublock_part, vv);
+      PA_HIP(hipGetLastError());
+    }
+    if (!c->capturing) {                               // the next pack (comm stream) must not overwrite buffers this unpack reads
+      PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
+      PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+    }
+    for (int r : l.parts) { plans[r]->phase = 0; plans[r]->ev_wait = nullptr; }
+  }
+  return PA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// (b) hipIpc link of one part per process
+// ---------------------------------------------------------------------------------------------------------------------------
+#define PA_IPC_MAGIC 0x70614970u   /* "paIp" */
+struct ipc_header {
+  uint32_t magic;
+  int32_t part;
+  int32_t n_snd_nbr, n_rcv_nbr;
+  int64_t n_snd, n_rcv;
+  int32_t device_pci[4];           // (diagnostics: which GPU the part lives on)
+  hipIpcMemHandle_t h_snd, h_rcv, h_flags;
+};
+
+struct pa_ipc_link {
+  unsigned long long *d_flags = nullptr;   // [arrive CONSISTENT: NS | arrive ASSEMBLE: NR | ack CONSISTENT: NR | ack ASSEMBLE: NS]
+  int64_t n_flags = 0;
+  unsigned *d_done = nullptr;              // the push kernel's block counter
+  int *h_status = nullptr;                 // host-pinned, device-visible: 0 ok, 1 an arrival wait timed out, 2 an acknowledgement wait did
+  struct peer { void *snd = nullptr, *rcv = nullptr, *flags = nullptr; };
+  std::map<int, peer> peers;               // part -> its mapped buffers
+  struct per_mode {
+    pa_push_seg *d_segs = nullptr;
+    int nseg = 0;
+    int32_t *d_wait = nullptr;             // flag indices (in my d_flags) of the senders with a non-empty slice
+    int n_wait = 0;
+    unsigned long long **d_ack_dst = nullptr;   // where I acknowledge: one flag per sender, in the senders' memory
+    int n_ack = 0;
+  } m[2];
+  long long ticks = 0;
+  bool connected = false;
+};
+
+static int ipc_flags_layout(const pa_plan *p, int64_t *aC, int64_t *aA, int64_t *kC, int64_t *kA) {
+  const int64_t NS = (int64_t)p->snd.nbr.size(), NR = (int64_t)p->rcv.nbr.size();
+  *aC = 0; *aA = NS; *kC = NS + NR; *kA = NS + 2 * NR;
+  return (int)(2 * NS + 2 * NR);
+}
+
+static int ipc_prepare(pa_plan *p) {
+  if (p->ipc) return PA_OK;
+  pa_ipc_link *L = new pa_ipc_link();
+  int64_t a, b, c, d;
+  L->n_flags = std::max(1, ipc_flags_layout(p, &a, &b, &c, &d));
+  PA_HIP(hipSetDevice(p->ctx->device));
+  PA_HIP(hipMalloc((void **)&L->d_flags, sizeof(unsigned long long) * L->n_flags));
+  PA_HIP(hipMemset(L->d_flags, 0, sizeof(unsigned long long) * L->n_flags));
+  PA_HIP(hipMalloc((void **)&L->d_done, sizeof(unsigned)));
+  PA_HIP(hipMemset(L->d_done, 0, sizeof(unsigned)));
+  PA_HIP(hipHostMalloc((void **)&L->h_status, sizeof(int), hipHostMallocMapped));
+  *L->h_status = 0;
+  PA_HIP(hipDeviceSynchronize());
+  double secs = 30.0;
+  if (const char *e = getenv("PA_IPC_TIMEOUT_S")) secs = std::max(0.001, atof(e));
+  L->ticks = (long long)(secs * 1e8);                  // wall_clock64: 100 MHz
+  p->ipc = L;
+  return PA_OK;
+}
+
+extern "C" int pa_plan_ipc_blob_size(pa_plan *p, int64_t *bytes) {
+  PA_REQUIRE(p && bytes, "bad arguments");
+  *bytes = (int64_t)sizeof(ipc_header) + (int64_t)sizeof(int32_t) * (int64_t)(2 * p->snd.nbr.size() + 2 * p->rcv.nbr.size() + 2);
+  return PA_OK;
+}
+
+// What a neighbour needs to push into this part's buffers: ipc handles of the two receive buffers and of the flag words, the
+// neighbour lists and slice offsets of both sides.  Opaque bytes; the host language carries them to the neighbours (or to
+// everybody) the way it carries the RCCL unique id.
+extern "C" int pa_plan_ipc_blob(pa_plan *p, void *out, int64_t capacity) {
+  PA_REQUIRE(p && out, "bad arguments");
+  int64_t need = 0;
+  PA_TRY(pa_plan_ipc_blob_size(p, &need));
+  PA_REQUIRE(capacity >= need, "the blob needs %lld bytes", (long long)need);
+  PA_TRY(ipc_prepare(p));
+  ipc_header h;
+  memset(&h, 0, sizeof h);
+  h.magic = PA_IPC_MAGIC; h.part = p->part;
+  h.n_snd_nbr = (int32_t)p->snd.nbr.size(); h.n_rcv_nbr = (int32_t)p->rcv.nbr.size();
+  h.n_snd = p->snd.n; h.n_rcv = p->rcv.n;
+  PA_HIP(hipSetDevice(p->ctx->device));
+  PA_HIP(hipIpcGetMemHandle(&h.h_snd, p->snd.d_buf));
+  PA_HIP(hipIpcGetMemHandle(&h.h_rcv, p->rcv.d_buf));
+  PA_HIP(hipIpcGetMemHandle(&h.h_flags, p->ipc->d_flags));
+  char *q = (char *)out;
+  memcpy(q, &h, sizeof h); q += sizeof h;
+  auto put = [&](const std::vector<int32_t> &v) { if (!v.empty()) memcpy(q, v.data(), sizeof(int32_t) * v.size()); q += sizeof(int32_t) * v.size(); };
+  put(p->snd.nbr); put(p->snd.ptrs); put(p->rcv.nbr); put(p->rcv.ptrs);
+  return PA_OK;
+}
+
+struct peer_view {
+  ipc_header h;
+  std::vector<int32_t> snd_nbr, snd_ptrs, rcv_nbr, rcv_ptrs;
+};
+
+static int parse_blob(const void *blob, int64_t bytes, peer_view &V) {
+  PA_REQUIRE(blob && bytes >= (int64_t)sizeof(ipc_header), "a blob is too short");
+  const char *q = (const char *)blob;
+  memcpy(&V.h, q, sizeof V.h); q += sizeof V.h;
+  PA_REQUIRE(V.h.magic == PA_IPC_MAGIC, "not a pa_plan_ipc_blob");
+  PA_REQUIRE(V.h.n_snd_nbr >= 0 && V.h.n_rcv_nbr >= 0 &&
+             bytes >= (int64_t)sizeof(ipc_header) + (int64_t)sizeof(int32_t) * (2 * (int64_t)V.h.n_snd_nbr + 2 * (int64_t)V.h.n_rcv_nbr + 2), "a blob is truncated");
+  auto get = [&](std::vector<int32_t> &v, size_t n) { v.resize(n); if (n) memcpy(v.data(), q, sizeof(int32_t) * n); q += sizeof(int32_t) * n; };
+  get(V.snd_nbr, V.h.n_snd_nbr); get(V.snd_ptrs, V.h.n_snd_nbr + 1); get(V.rcv_nbr, V.h.n_rcv_nbr); get(V.rcv_ptrs, V.h.n_rcv_nbr + 1);
+  return PA_OK;
+}
+
+// blobs[k] (sizes[k] bytes): the pa_plan_ipc_blob of some part (any order, this part's own and strangers' are ignored).  Opens the
+// neighbours' buffers and builds the push tables of both modes.  Collective in spirit: every neighbour must do the same before
+// the first pa_exchange_push_ipc.
+extern "C" int pa_plan_ipc_connect(pa_plan *p, int32_t n_blobs, const void *const *blobs, const int64_t *sizes) {
+  PA_REQUIRE(p && (n_blobs == 0 || (blobs && sizes)) && n_blobs >= 0, "bad arguments");
+  PA_TRY(ipc_prepare(p));
+  pa_ipc_link *L = p->ipc;
+  PA_REQUIRE(!L->connected, "this plan is connected already");
+  PA_HIP(hipSetDevice(p->ctx->device));
+  std::map<int, peer_view> views;
+  for (int k = 0; k < n_blobs; ++k) {
+    peer_view V;
+    PA_TRY(parse_blob(blobs[k], sizes[k], V));
+    if (V.h.part == p->part) continue;
+    const bool nb = std::find(p->snd.nbr.begin(), p->snd.nbr.end(), V.h.part) != p->snd.nbr.end() ||
+                    std::find(p->rcv.nbr.begin(), p->rcv.nbr.end(), V.h.part) != p->rcv.nbr.end();
+    if (nb) views[V.h.part] = V;
+  }
+  auto open_peer = [&](int q) -> int {
+    if (L->peers.count(q)) return PA_OK;
+    auto it = views.find(q);
+    PA_REQUIRE(it != views.end(), "no blob of neighbour part %d", q);
+    pa_ipc_link::peer P;
+    const ipc_header &h = it->second.h;
+    PA_HIP(hipIpcOpenMemHandle(&P.snd, h.h_snd, hipIpcMemLazyEnablePeerAccess));
+    PA_HIP(hipIpcOpenMemHandle(&P.rcv, h.h_rcv, hipIpcMemLazyEnablePeerAccess));
+    PA_HIP(hipIpcOpenMemHandle(&P.flags, h.h_flags, hipIpcMemLazyEnablePeerAccess));
+    L->peers[q] = P;
+    return PA_OK;
+  };
+  int64_t aC, aA, kC, kA;
+  ipc_flags_layout(p, &aC, &aA, &kC, &kA);
+  for (int mode = 0; mode < 2; ++mode) {
+    pa_plan::side &o = out_side(p, mode), &in = in_side(p, mode);
+    const int64_t my_ack0 = mode == PA_CONSISTENT ? kC : kA, my_arr0 = mode == PA_CONSISTENT ? aC : aA;
+    std::vector<pa_push_seg> segs;
+    for (size_t j = 0; j < o.nbr.size(); ++j) {
+      const int len = o.ptrs[j + 1] - o.ptrs[j];
+      if (!len) continue;
+      const int q = o.nbr[j];
+      PA_REQUIRE(q != p->part, "a part that sends to itself has no ipc link");
+      PA_TRY(open_peer(q));
+      const peer_view &V = views[q];
+      // the receiver's in-side of this mode: its snd side for consistent!, its rcv side for assemble!
+      const std::vector<int32_t> &qn = mode == PA_CONSISTENT ? V.snd_nbr : V.rcv_nbr, &qp = mode == PA_CONSISTENT ? V.snd_ptrs : V.rcv_ptrs;
+      auto it = std::find(qn.begin(), qn.end(), p->part);
+      PA_REQUIRE(it != qn.end(), "inconsistent ExchangeGraph: part %d sends to %d, which does not receive from it", p->part, q);
+      const size_t i = it - qn.begin();
+      PA_REQUIRE(qp[i + 1] - qp[i] == len, "slice length mismatch between parts %d and %d", p->part, q);
+      const int64_t qNS = V.h.n_snd_nbr;
+      const int64_t q_arr0 = mode == PA_CONSISTENT ? 0 : qNS;
+      pa_push_seg S;
+      S.start = o.ptrs[j]; S.len = len;
+      S.dst = (double *)(mode == PA_CONSISTENT ? L->peers[q].snd : L->peers[q].rcv) + qp[i];
+      S.arrive = (unsigned long long *)L->peers[q].flags + q_arr0 + (int64_t)i;
+      S.ack = L->d_flags + my_ack0 + (int64_t)j;
+      segs.push_back(S);
+    }
+    std::vector<int32_t> wait;
+    std::vector<unsigned long long *> ackdst;
+    for (size_t i = 0; i < in.nbr.size(); ++i) {
+      const int len = in.ptrs[i + 1] - in.ptrs[i];
+      if (!len) continue;
+      const int q = in.nbr[i];
+      PA_REQUIRE(q != p->part, "a part that receives from itself has no ipc link");
+      PA_TRY(open_peer(q));
+      const peer_view &V = views[q];
+      // the sender's out-side of this mode: its rcv side for consistent!, its snd side for assemble!
+      const std::vector<int32_t> &qn = mode == PA_CONSISTENT ? V.rcv_nbr : V.snd_nbr, &qp = mode == PA_CONSISTENT ? V.rcv_ptrs : V.snd_ptrs;
+      auto it = std::find(qn.begin(), qn.end(), p->part);
+      PA_REQUIRE(it != qn.end(), "inconsistent ExchangeGraph: part %d receives from %d, which does not send to it", p->part, q);
+      const size_t j = it - qn.begin();
+      PA_REQUIRE(qp[j + 1] - qp[j] == len, "slice length mismatch between parts %d and %d", q, p->part);
+      const int64_t qNS = V.h.n_snd_nbr, qNR = V.h.n_rcv_nbr;
+      const int64_t q_ack0 = mode == PA_CONSISTENT ? qNS + qNR : qNS + 2 * qNR;
+      wait.push_back((int32_t)(my_arr0 + (int64_t)i));
+      ackdst.push_back((unsigned long long *)L->peers[q].flags + q_ack0 + (int64_t)j);
+    }
+    pa_ipc_link::per_mode &M = L->m[mode];
+    M.nseg = (int)segs.size(); M.n_wait = (int)wait.size(); M.n_ack = (int)ackdst.size();
+    PA_TRY(upload_vec(segs, &M.d_segs));
+    PA_TRY(upload_vec(wait, &M.d_wait));
+    PA_TRY(upload_vec(ackdst, &M.d_ack_dst));
+  }
+  L->connected = true;
+  return PA_OK;
+}
+
+bool pa_plan_ipc_connected(const pa_plan *p) { return p && p->ipc && p->ipc->connected; }
+
+extern "C" int pa_plan_ipc_status(pa_plan *p, int *status) {
+  PA_REQUIRE(p && status, "bad arguments");
+  *status = (p->ipc && p->ipc->h_status) ? *(volatile int *)p->ipc->h_status : 0;
+  return PA_OK;
+}
+
+// pack + exchange! of this process's part over the ipc link (the one-part-per-process twin of pa_exchange_push_local)
+extern "C" int pa_exchange_push_ipc(pa_plan *p, const pa_vec *v, int mode) {
+  PA_REQUIRE(p && v && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  PA_REQUIRE(p->ipc && p->ipc->connected, "the plan has no ipc link (pa_plan_ipc_connect)");
+  PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector has %lld local values, plan expects %lld", (long long)(v->n_own + v->n_ghost),
+             (long long)p->n_local);
+  PA_REQUIRE(p->phase == 0, "exchange already in flight on this plan (missing pa_exchange_finish)");
+  pa_ipc_link *L = p->ipc;
+  const int st = *(volatile int *)L->h_status;
+  if (st != 0) { pa_set_err("the ipc link of part %d timed out earlier (%s wait): a neighbour is gone or out of step", p->part, st == 1 ? "arrival" : "acknowledgement"); return PA_ERR_STATE; }
+  pa_ctx *c = p->ctx;
+  PA_REQUIRE(!c->capturing, "the ipc transport carries a sequence number per exchange: not inside a graph capture");
+  pa_ipc_link::per_mode &M = L->m[mode];
+  p->mode = mode;
+  if (p->snd.n == 0 && p->rcv.n == 0) { p->phase = 1; return PA_OK; }
+  PA_HIP(hipSetDevice(c->device));
+  const unsigned long long seq = ++p->seq[mode];
+  PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
+  PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+  pa_plan::side &o = out_side(p, mode);
+  if (M.nseg && o.n) {
+    hipLaunchKernelGGL(k_push_ipc, dim3((unsigned)((o.n + 255) / 256)), dim3(256), 0, c->s[1], o.d_idx, (int)o.n, M.d_segs, M.nseg, v->d, seq,
+                       L->d_done, L->ticks, L->h_status);
+  }
+  if (M.n_wait) hipLaunchKernelGGL(k_wait_flags, dim3(1), dim3(64), 0, c->s[1], L->d_flags, M.d_wait, M.n_wait, seq, L->ticks, L->h_status);
+  PA_HIP(hipGetLastError());
+  p->own_comm_stream = true;
+  p->ipc_ack_due = M.n_ack > 0;
+  p->ev_wait = nullptr;
+  return pa_plan_mark_arrived(p);
+}
+
+// compute stream, behind the unpack (and whatever read the receive buffer): the senders may overwrite it now
+int pa_ipc_ack(pa_plan *p, int mode) {
+  if (!p->ipc || !p->ipc_ack_due) return PA_OK;
+  p->ipc_ack_due = false;
+  pa_ipc_link::per_mode &M = p->ipc->m[mode];
+  if (M.n_ack == 0) return PA_OK;
+  hipLaunchKernelGGL(k_write_flags, dim3((M.n_ack + 63) / 64), dim3(64), 0, p->ctx->s[0], M.d_ack_dst, M.n_ack, p->seq[mode]);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+void pa_push_release(pa_plan *p) {
+  for (int m = 0; m < 2; ++m)
+    if (p->push[m]) { p->push[m]->free_all(); delete p->push[m]; p->push[m] = nullptr; }
+  if (pa_ipc_link *L = p->ipc) {
+    (void)hipSetDevice(p->ctx->device);
+    for (auto &kv : L->peers) {
+      if (kv.second.snd) (void)hipIpcCloseMemHandle(kv.second.snd);
+      if (kv.second.rcv) (void)hipIpcCloseMemHandle(kv.second.rcv);
+      if (kv.second.flags) (void)hipIpcCloseMemHandle(kv.second.flags);
+    }
+    for (int m = 0; m < 2; ++m) {
+      (void)pa_raw_free(L->m[m].d_segs); (void)pa_raw_free(L->m[m].d_wait); (void)pa_raw_free(L->m[m].d_ack_dst);
+    }
+    if (L->d_flags) (void)hipFree(L->d_flags);
+    if (L->d_done) (void)hipFree(L->d_done);
+    if (L->h_status) (void)hipHostFree(L->h_status);
+    delete L;
+    p->ipc = nullptr;
+  }
+}

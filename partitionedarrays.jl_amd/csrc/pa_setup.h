@@ -50,6 +50,12 @@ int pa_csr_from_device(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, c
 int pa_csr_from_device_rows(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, int64_t n_nonempty, std::vector<int32_t> &crp,
                             const int32_t *d_row_ids, const int32_t *d_col, const double *d_val, pa_csr **out);
 
+// pa_transpose.hip: 0-based (row, column) of every stored entry of ONE slab in storage order, decoded on the device from whatever
+// column encoding the slab keeps (d_row / d_col: nnz entries each, device)
+int pa_dev_decode_entries(const pa_csr *A, int32_t *d_row, int32_t *d_col);
+// the same entries in the same order with column j renamed map[j] (host, A->n_cols entries, -1 = absent): see pa_transpose.hip
+int pa_csr_create_remapped(const pa_csr *A, const int32_t *map, int64_t n_cols_new, pa_csr **out);
+
 // min / max of a device Int32 array (column range check of an uploaded block)
 int pa_dev_minmax_i32(pa_ctx *c, const int32_t *d, int64_t n, int32_t *mn, int32_t *mx);
 

@@ -93,7 +93,7 @@ __global__ void kt_lower_bounds(const int *__restrict__ keys, int n, int n_rows,
   rp[j] = lo;
 }
 
-static int decode_slab(const pa_csr *A, int32_t *d_row, int32_t *d_col) {
+int pa_dev_decode_entries(const pa_csr *A, int32_t *d_row, int32_t *d_col) {
   pa_ctx *c = A->ctx;
   if (A->nnz == 0 || A->n_chunks == 0) return PA_OK;
   hipLaunchKernelGGL(kt_decode, dim3((unsigned)A->n_chunks), dim3(256), 0, c->s[0], A->d_crp, A->d_chunk_row, A->d_row_ids, A->d_col,
@@ -115,7 +115,7 @@ extern "C" int pa_csr_download_entries(const pa_csr *A, int32_t *rows, int32_t *
     int32_t *d_row = nullptr, *d_col = nullptr;
     PA_TRY(sc.get(&d_row, (size_t)S->nnz));
     PA_TRY(sc.get(&d_col, (size_t)S->nnz));
-    PA_TRY(decode_slab(S, d_row, d_col));
+    PA_TRY(pa_dev_decode_entries(S, d_row, d_col));
     PA_TRY(d2h(c->s[0], rows + S->nnz0, d_row, (size_t)S->nnz));
     PA_TRY(d2h(c->s[0], cols + S->nnz0, d_col, (size_t)S->nnz));
     if (S->row0) for (int64_t p = 0; p < S->nnz; ++p) rows[S->nnz0 + p] += (int32_t)S->row0;
@@ -144,7 +144,7 @@ extern "C" int pa_csr_create_transpose(const pa_csr *A, pa_csr **out) {
   double *d_tval = nullptr;
   PA_TRY(sc.get(&d_row, (size_t)nnz));
   PA_TRY(sc.get(&d_col, (size_t)nnz));
-  PA_TRY(decode_slab(A, d_row, d_col));
+  PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
   PA_TRY(sc.get(&d_keys, (size_t)nnz));
   PA_TRY(sc.get(&d_iota, (size_t)nnz));
   PA_TRY(sc.get(&d_perm, (size_t)nnz));
@@ -165,6 +165,51 @@ extern "C" int pa_csr_create_transpose(const pa_csr *A, pa_csr **out) {
   sc.release(d_perm);
   sc.release(d_row);
   return pa_csr_from_device(c, n_rows_t, n_cols_t, nnz, d_rp, d_tcol, d_tval, out);
+}
+
+__global__ void kt_remap(int *__restrict__ col, int n, const int *__restrict__ map, int *__restrict__ bad) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int c = map[col[k]];
+  if (c < 0) atomicAdd(bad, 1);
+  col[k] = c < 0 ? 0 : c;
+}
+
+// The same stored entries, in the same order, with every column j renamed map[j] (host array of A->n_cols entries, values in
+// [0, n_cols_new); -1 = "no such column": allowed only for columns without stored entries, else PA_ERR_ARG and *out = NULL).
+// Row sums keep their order of addition, so products through the new block gather x_new[map[j]] where the old one gathered
+// x[j] and are otherwise the same bits.  Used by pa_mul5 to let own x ghost read the RECEIVE BUFFER of consistent! directly.
+int pa_csr_create_remapped(const pa_csr *A, const int32_t *map, int64_t n_cols_new, pa_csr **out) {
+  PA_REQUIRE(A && map && out && n_cols_new >= 0, "bad arguments");
+  PA_REQUIRE(!A->next, "a chain of slabs has no remapped twin");
+  *out = nullptr;
+  pa_ctx *c = A->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  const int64_t nnz = A->nnz, n_rows = A->n_rows;
+  scratch sc;
+  int32_t *d_rp = nullptr, *d_row = nullptr, *d_col = nullptr, *d_map = nullptr;
+  int *d_bad = nullptr;
+  double *d_val = nullptr;
+  PA_TRY(sc.get(&d_rp, (size_t)n_rows + 1));
+  PA_TRY(sc.get(&d_row, (size_t)nnz + 1));
+  PA_TRY(sc.get(&d_col, (size_t)nnz + 1));
+  PA_TRY(sc.get(&d_val, (size_t)nnz + 1));
+  PA_TRY(sc.get(&d_map, (size_t)A->n_cols + 1));
+  PA_TRY(sc.get(&d_bad, 1));
+  PA_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), s));
+  if (A->n_cols) PA_HIP(hipMemcpyAsync(d_map, map, sizeof(int32_t) * A->n_cols, hipMemcpyHostToDevice, s));
+  if (nnz) {
+    PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
+    hipLaunchKernelGGL(kt_remap, grid1(nnz), dim3(256), 0, s, d_col, (int)nnz, d_map, d_bad);
+    PA_HIP(hipMemcpyAsync(d_val, A->d_val, sizeof(double) * nnz, hipMemcpyDeviceToDevice, s));
+  }
+  hipLaunchKernelGGL(kt_lower_bounds, grid1(n_rows + 1), dim3(256), 0, s, d_row, (int)nnz, (int)n_rows, d_rp);   // rows ascend in storage order
+  int bad = 0;
+  PA_TRY(d2h(s, &bad, d_bad, 1));
+  PA_HIP(hipGetLastError());
+  PA_REQUIRE(bad == 0, "%d stored entries sit in columns the map does not carry", bad);
+  return pa_csr_from_device(c, n_rows, n_cols_new, nnz, d_rp, d_col, d_val, out);
 }
 
 // ---- mul!(c, transpose(a), b, alpha, beta) of one part / of all parts of a process ------------------------------------------
@@ -196,17 +241,8 @@ static int mul_t_check(const pa_matrix *m, const pa_vec *c, const pa_vec *b) {
 
 extern "C" int pa_mul5_transpose(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta) {
   PA_TRY(mul_t_check(m, c, b));
-  if (!comm) {
-    PA_REQUIRE(m->plan->snd.nbr.empty() && m->plan->rcv.nbr.empty(), "the column plan has neighbours: pass the communicator");
-    PA_REQUIRE(m->plan->part == 0, "without a communicator the part must be the only one");
-  }
   PA_TRY(pa_spmv(m->oh, b, PA_SEG_OWN, c, PA_SEG_GHOST, alpha, 0.0));        // fill!(ch,0); mul!(ch,atoh,bo,alpha,1)
-  PA_TRY(pa_exchange_pack(m->plan, c, PA_ASSEMBLE));                          // t = assemble!(c)
-  if (comm) PA_TRY(pa_exchange_rccl(m->plan, comm, PA_ASSEMBLE));
-  else {
-    pa_plan *one[1] = {m->plan};
-    PA_TRY(pa_exchange_local(one, 1, PA_ASSEMBLE));
-  }
+  PA_TRY(pa_exchange_start(m->plan, comm, c, PA_ASSEMBLE));                   // t = assemble!(c)
   PA_TRY(pa_spmv(m->oo, b, PA_SEG_OWN, c, PA_SEG_OWN, alpha, beta));         // rmul!(co,beta); mul!(co,atoo,bo,alpha,1): overlaps
   PA_TRY(pa_exchange_finish(m->plan, c, PA_ASSEMBLE));                        // wait(t): owners += ghost contributions; ghosts := 0
   return PA_OK;
@@ -220,8 +256,12 @@ extern "C" int pa_mul5_transpose_all(pa_matrix *const *m, int32_t n_parts, pa_ve
     plans[r] = m[r]->plan;
   }
   for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oh, b[r], PA_SEG_OWN, c[r], PA_SEG_GHOST, alpha, 0.0));
-  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], c[r], PA_ASSEMBLE));
-  PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_ASSEMBLE));
+  const int push = getenv("PA_PUSH") ? atoi(getenv("PA_PUSH")) : 1;      // (read per call: tests switch it)
+  if (push) PA_TRY(pa_exchange_push_local(plans.data(), n_parts, c, PA_ASSEMBLE));   // one launch packs and delivers every part's ghosts
+  else {
+    for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], c[r], PA_ASSEMBLE));
+    PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_ASSEMBLE));
+  }
   for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
   for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_finish(plans[r], c[r], PA_ASSEMBLE));
   return PA_OK;

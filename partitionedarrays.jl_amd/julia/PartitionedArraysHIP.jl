@@ -233,10 +233,11 @@ mutable struct HIPCSR <: AbstractSparseMatrix{Float64,Int32}
     handle::Ptr{Cvoid}
     m::Int
     n::Int
+    t::Union{Nothing,HIPCSR}     # transpose(A) as a block of its own, built on the device when first asked for
 end
 Base.size(A::HIPCSR) = (A.m, A.n)
 function _adopt(h, m, n)
-    A = HIPCSR(h, m, n)
+    A = HIPCSR(h, m, n, nothing)
     finalizer(x -> ccall((:pa_csr_destroy, libpa), Cint, (Ptr{Cvoid},), x.handle), A)
 end
 "Upload a SparseMatrixCSR{1} block as the reference stores it (1-based rowptr/colval): HPCG/src/sparse_matrix.jl:115."
@@ -267,6 +268,26 @@ function LinearAlgebra.mul!(b::HIPSegment, A::HIPCSR, x::HIPSegment, α::Number,
                 A.handle, x.parent.handle, x.seg, b.parent.handle, b.seg, Float64(α), Float64(β)))
     b
 end
+
+# transpose(A) of a block resident in HBM (csrc/pa_transpose.hip): the reference's transposed product calls
+# `mul!(ch,transpose(aoh),bo,α,1)` / `mul!(co,transpose(aoo),bo,α,1)` on the local blocks (src/p_sparse_matrix.jl:2150-2159)
+# and `spmtv!(b,A,x)` (src/sparse_utils.jl:613-615,625-631); both land here.  A' is built once per block, on the device, with
+# its rows' entries in ascending row of A -- the order the reference's scatter loop adds them in.
+function _transposed(A::HIPCSR)
+    if A.t === nothing
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pa_csr_create_transpose, libpa), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), A.handle, h))
+        A.t = _adopt(h[], A.n, A.m)
+    end
+    A.t
+end
+function LinearAlgebra.mul!(b::HIPSegment, At::Transpose{Float64,HIPCSR}, x::HIPSegment, α::Number, β::Number)
+    T = _transposed(parent(At))
+    check(ccall((:pa_spmv, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Float64, Float64),
+                T.handle, x.parent.handle, x.seg, b.parent.handle, b.seg, Float64(α), Float64(β)))
+    b
+end
+PartitionedArrays.spmtv!(b::HIPSegment, A::HIPCSR, x::HIPSegment) = mul!(b, transpose(A), x, 1.0, 0.0)
 
 # ---------------------------------------------------------------- vector assembly cache (the exchange plan)
 struct HIPAssemblyCache{A}
@@ -337,6 +358,30 @@ _mul_fused!(ms::DebugArray, cs, bs, plans, α, β) =
                 ms.items, length(ms.items), [v.handle for v in cs.items], [v.handle for v in bs.items], α, β))
 _mul_fused!(ms::MPIArray, cs, bs, plans, α, β) =
     check(ccall((:pa_mul5, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64),
+                ms.item, init_comm!(ms.comm), cs.item.handle, bs.item.handle, α, β))
+
+# mul!(c,transpose(A),b,α,β) (src/p_sparse_matrix.jl:2144-2162) the same way: ghost(c) = α A_oh' own(b), assemble!(c) under
+# own(c) = β own(c) + α A_oo' own(b), one ccall per process (pa_mul5_transpose / _all).  c lives on axes(A,2).
+function _matrix_handle_t(a, plan)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:pa_matrix_create_transposed, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
+                context().handle, _transposed(a.blocks.own_own).handle, _transposed(a.blocks.own_ghost).handle, plan, h))
+    h[]
+end
+function mul_fused!(c::PVector, At::Transpose{Float64,<:PSparseMatrix}, b::PVector, α::Real=1.0, β::Real=0.0)
+    A = parent(At)
+    @assert A.assembled
+    plans = c.cache.plans
+    ms = map(_matrix_handle_t, partition(A), plans)
+    _mul_fused_t!(ms, partition(c), partition(b), Float64(α), Float64(β))
+    foreach(m -> ccall((:pa_matrix_destroy, libpa), Cint, (Ptr{Cvoid},), m), ms)
+    c
+end
+_mul_fused_t!(ms::DebugArray, cs, bs, α, β) =
+    check(ccall((:pa_mul5_transpose_all, libpa), Cint, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}, Float64, Float64),
+                ms.items, length(ms.items), [v.handle for v in cs.items], [v.handle for v in bs.items], α, β))
+_mul_fused_t!(ms::MPIArray, cs, bs, α, β) =
+    check(ccall((:pa_mul5_transpose, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64),
                 ms.item, init_comm!(ms.comm), cs.item.handle, bs.item.handle, α, β))
 
 # ---------------------------------------------------------------- conversions

@@ -439,7 +439,7 @@ def mul_c_(c: PVector, a: PSparseMatrix, b: PVector, alpha=1.0, beta=0.0) -> PVe
     _check_axes(c, a, b)
     vp = b.vector_partition
     if not a.assembled or not (isinstance(vp, DebugArray) or (isinstance(vp, TorchDistArray) and (
-            vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None)))):
+            vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None) or pv.TRANSPORT == "ipc"))):
         return mul5_(c, a, b, alpha, beta)
     hs = _operator_handles(a, b)
     if isinstance(vp, DebugArray):
@@ -448,7 +448,7 @@ def mul_c_(c: PVector, a: PSparseMatrix, b: PVector, alpha=1.0, beta=0.0) -> PVe
         L.call("pa_mul_all", arr(hs.items), n, arr([v.h for v in c.vector_partition.items]), arr([v.h for v in vp.items]),
                float(alpha), float(beta))
     else:
-        comm = context().comm.h if (vp.size > 1) else None
+        comm = context().comm.h if (vp.size > 1 and pv.TRANSPORT == "rccl") else None
         L.call("pa_mul5", hs.item, comm, c.vector_partition.item.h, vp.item.h, float(alpha), float(beta))
     return c
 
@@ -460,12 +460,12 @@ def mul_no_lat_c_(c: PVector, a: PSparseMatrix, b: PVector) -> PVector:
     from . import p_vector as pv
     _check_axes(c, a, b)
     vp = b.vector_partition
-    one_per_process = isinstance(vp, TorchDistArray) and (vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None))
+    one_per_process = isinstance(vp, TorchDistArray) and (vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None) or pv.TRANSPORT == "ipc")
     single = isinstance(vp, DebugArray) and len(vp.items) == 1
     if not a.assembled or not (one_per_process or single):
         return mul_no_overlap_(c, a, b)
     h = local_items(_operator_handles(a, b))[0]
-    comm = context().comm.h if (one_per_process and vp.size > 1) else None
+    comm = context().comm.h if (one_per_process and vp.size > 1 and pv.TRANSPORT == "rccl") else None
     L.call("pa_mul_no_lat", h, comm, local_items(c.vector_partition)[0].h, local_items(vp)[0].h)
     return c
 
@@ -482,7 +482,7 @@ def mul_dot_(c: PVector, a: PSparseMatrix, b: PVector, slot: int) -> bool:
     vp = b.vector_partition
     if not a.assembled or not (isinstance(vp, DebugArray) or (isinstance(vp, TorchDistArray) and (
             vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None)))):
-        return False
+        return False                     # (the ipc transport has no device-side all-reduce for the slot: host dots)
     from .primitives import local_items
     if any(bv.n_own != cv.n_own for bv, cv in zip(local_items(vp), local_items(c.vector_partition))):
         return False
@@ -492,7 +492,7 @@ def mul_dot_(c: PVector, a: PSparseMatrix, b: PVector, slot: int) -> bool:
         arr = lambda xs: (C.c_void_p * n)(*xs)
         L.call("pa_mul_all_dot", arr(hs.items), n, arr([v.h for v in c.vector_partition.items]), arr([v.h for v in vp.items]), slot)
     else:
-        comm = context().comm.h if (vp.size > 1) else None
+        comm = context().comm.h if (vp.size > 1 and pv.TRANSPORT == "rccl") else None
         L.call("pa_mul_dot", hs.item, comm, c.vector_partition.item.h, vp.item.h, slot, 0)
         pv._slot_allreduce(vp, slot)
     return True
@@ -544,7 +544,7 @@ def mul5_transpose_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PV
     tb = transposed_blocks(a)
     vp = c.vector_partition
     direct = isinstance(vp, DebugArray) or (isinstance(vp, TorchDistArray) and (
-        vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None)))
+        vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None) or pv.TRANSPORT == "ipc"))
     if direct:
         cache = c.__dict__.setdefault("_pa_matrices_t", {})
         if id(a) not in cache:
@@ -564,7 +564,7 @@ def mul5_transpose_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PV
             L.call("pa_mul5_transpose_all", arr(hs.items), n, arr([v.h for v in vp.items]), arr([v.h for v in b.vector_partition.items]),
                    float(alpha), float(beta))
         else:
-            comm = context().comm.h if (vp.size > 1) else None
+            comm = context().comm.h if (vp.size > 1 and pv.TRANSPORT == "rccl") else None
             L.call("pa_mul5_transpose", hs.item, comm, vp.item.h, b.vector_partition.item.h, float(alpha), float(beta))
         return c
     # (transports the library does not drive itself: the same kernels composed here)
@@ -880,6 +880,8 @@ def psparse_disassembled(I, J, V, rows, cols, keep_host=False, reuse=False, asse
     from .primitives import tuple_of_arrays
     plans, scs, W, Vd, nnz_oo = tuple_of_arrays(pmap(build, I, J, blocks4, host, rows_sa, cols_sa, cols_fa,
                                                      info["parts_snd"], info["parts_rcv"], info["ksnd"], info["rcvinfo"]))
+    from .p_vector import connect_ipc
+    connect_ipc(plans)                                 # (PA_TRANSPORT=ipc: the value exchange of psparse! pushes too)
     return C_, MatrixReassemblyCache(plans, scs, W, Vd, nnz_oo)
 
 

@@ -312,6 +312,29 @@ class DeviceVector:
             pass
 
 
+def connect_ipc(plans):
+    """PA_TRANSPORT=ipc (csrc/pa_push.hip), one part per process: every rank publishes the ipc handles of its plan's receive
+    buffers and flag words, maps its neighbours' and from then on packs straight into them.  Collective over the plans' group
+    (like the neighbour discovery that precedes every plan); a no-op for other transports and back-ends."""
+    if not (isinstance(plans, TorchDistArray) and TRANSPORT == "ipc"):
+        return
+    import torch.distributed as dist
+    plan = plans.item
+    n = C.c_int64()
+    L.call("pa_plan_ipc_blob_size", plan, C.byref(n))
+    buf = C.create_string_buffer(n.value)
+    L.call("pa_plan_ipc_blob", plan, buf, n.value)
+    group = plans.group
+    world = dist.get_world_size(group)
+    blobs = [None] * world
+    dist.all_gather_object(blobs, buf.raw, group=group)
+    keep = [C.create_string_buffer(b, len(b)) for b in blobs]
+    ptrs = (C.c_void_p * world)(*[C.cast(k, C.c_void_p).value for k in keep])
+    sizes = (C.c_int64 * world)(*[len(b) for b in blobs])
+    L.call("pa_plan_ipc_connect", plan, world, ptrs, sizes)
+    dist.barrier(group=group)                          # nobody pushes before everybody has mapped
+
+
 # ----------------------------------------------------------------------------------------------
 # VectorAssemblyCache on the device
 # ----------------------------------------------------------------------------------------------
@@ -343,6 +366,7 @@ class DeviceAssemblyCache:
 
         self.plans = pmap(make, index_partition, self.neighbors_snd, self.neighbors_rcv,
                           self.local_indices_snd, self.local_indices_rcv)
+        connect_ipc(self.plans)
 
     def __del__(self):
         try:
@@ -376,6 +400,7 @@ class _DevMem:
 
 
 TRANSPORT = os.environ.get("PA_TRANSPORT", "rccl")   # "rccl": ncclSend/ncclRecv issued by libpa_hip on its comm stream
+                                                     # "ipc": the pack kernel pushes into the neighbours' buffers (hipIpc, pa_push.hip)
                                                      # "torch": torch.distributed batch_isend_irecv (same RCCL underneath)
 
 
@@ -465,11 +490,23 @@ def _transport(plans, mode):
         L.call("pa_exchange_rccl", plans.item, comm.h, mode)
 
 
+def _push():                 # all parts in one process: one launch packs AND delivers (csrc/pa_push.hip); PA_PUSH=0: pack + copies
+    return os.environ.get("PA_PUSH", "1") != "0"
+
+
 def assemble_impl(mode, vector_partition, cache: DeviceAssemblyCache) -> Task:
     """assemble_impl!(f,vector_partition,cache) (src/p_vector.jl:587-612): pack, start the exchange,
     return a task whose wait() unpacks with f = insert (CONSISTENT) or + (ASSEMBLE)."""
-    pmap(lambda v, p: L.call("pa_exchange_pack", p, v.h, mode), vector_partition, cache.plans)
-    _transport(cache.plans, mode)
+    plans = cache.plans
+    if isinstance(plans, DebugArray) and _push():
+        n = len(plans.items)
+        L.call("pa_exchange_push_local", (C.c_void_p * n)(*[h.value for h in plans.items]), n,
+               (C.c_void_p * n)(*[v.h.value for v in vector_partition.items]), mode)
+    elif isinstance(plans, TorchDistArray) and TRANSPORT == "ipc":
+        L.call("pa_exchange_push_ipc", plans.item, vector_partition.item.h, mode)
+    else:
+        pmap(lambda v, p: L.call("pa_exchange_pack", p, v.h, mode), vector_partition, plans)
+        _transport(plans, mode)
 
     def finish():
         pmap(lambda v, p: L.call("pa_exchange_finish", p, v.h, mode), vector_partition, cache.plans)

@@ -1,5 +1,6 @@
 """One part per process (torch.distributed); by default every rank on the SAME GPU, host-staged transport (PA_TRANSPORT=host);
-with PA_TRANSPORT=rccl one GPU per rank and the RCCL neighbour exchange of csrc/pa_rccl.cpp (needs as many GPUs as ranks):
+with PA_TRANSPORT=rccl one GPU per rank and the RCCL neighbour exchange of csrc/pa_rccl.cpp (needs as many GPUs as ranks);
+with PA_TRANSPORT=ipc the push transport of csrc/pa_push.hip (hipIpc-mapped receive buffers; ranks may share a GPU):
 the full N>1 device path -- pack kernel, exchange, unpack kernel, own*own / own*ghost SpMV, dot -- against the
 sequential oracle, bit-exact.  Run by tests/test_gpu_multiprocess.py on the 1-GPU box."""
 import os
@@ -47,6 +48,26 @@ def body(distribute):
         dref = orc.dot(xo, xo, Ao.cols)
         assert abs(d - dref) <= 1e-13 * abs(dref)
         assert np.array_equal(y.collect(), orc.pvector_collect(yo, Ao.rows))
+        # the operator-level call (pa_mul5: own x ghost may read the receive buffer, the unpack follows it) and many exchanges
+        # in a row (the push transport's flow control: every buffer is reused 12 times)
+        x2 = pa.pvector_from_function(lambda ind: xo[ind.part - 1] * (ind.get_local_to_owner() == ind.part), A.col_partition)
+        y2 = pa.pzeros(A.row_partition)
+        for _ in range(12):
+            pa.mul_c_(y2, A, x2)
+        assert np.array_equal(pa.getany(y2.own_values()), yo[k][:Ao.rows[k].n_own]), "mul_c_ differs from the oracle"
+        assert np.array_equal(pa.getany(x2.local_values()), xo[k]), "ghosts differ after mul_c_"
+        pa.mul_c_(y2, A, x2, -0.5, 2.0)
+        y5 = [v.copy() for v in yo]
+        orc.mul5(y5, Ao, [v.copy() for v in xo], -0.5, 2.0)
+        assert np.array_equal(pa.getany(y2.own_values()), y5[k][:Ao.rows[k].n_own]), "mul_c_(alpha,beta) differs from the oracle"
+        # mul!(c,transpose(a),b,alpha,beta): assemble!(c) under A_oo'*b
+        bt = [orc.hash_x(r.local_to_global + 1) for r in Ao.rows]
+        ct = [orc.hash_x(c.local_to_global + 9) for c in Ao.cols]
+        bdev = pa.pvector_from_function(lambda ind: bt[ind.part - 1].copy(), A.row_partition)
+        cdev = pa.pvector_from_function(lambda ind: ct[ind.part - 1].copy(), A.col_partition)
+        pa.mul5_transpose_(cdev, A, bdev, 0.75, -1.25)
+        orc.mul5_transpose(ct, Ao, bt, 0.75, -1.25)
+        assert np.array_equal(pa.getany(cdev.local_values()), ct[k]), "transpose product differs from the oracle"
     # K7 across processes: psparse!(C,V2,cache) with the triplet values exchanged by the device plan
     if P in (2, 4):
         fparts = {2: (2, 1), 4: (2, 2)}[P]

@@ -13,6 +13,16 @@ def test_device_path_one_part_per_process(nproc):
     _run("device_path_driver.py", nproc, {"PA_TRANSPORT": "host"})
 
 
+@pytest.mark.parametrize("nproc", [2, 4, 8])
+def test_device_path_over_the_ipc_push_transport(nproc):
+    """PA_TRANSPORT=ipc (csrc/pa_push.hip): one part per process, every pack kernel storing straight into its neighbours' receive
+    buffers (hipIpcOpenMemHandle), arrival and flow control by sequence numbers in device memory -- a device-only transport
+    that, unlike RCCL, also runs with all ranks on ONE GPU.  mul! (composed and pa_mul5 with own x ghost reading the receive
+    buffer), 12 products in a row, the alpha/beta form, the transpose product, consistent!, assemble!, psparse!: bit-exact
+    against the sequential oracle on every rank."""
+    _run("device_path_driver.py", nproc, {"PA_TRANSPORT": "ipc"})
+
+
 def _gpus():
     import torch
     return torch.cuda.device_count()
@@ -130,3 +140,12 @@ def test_bench_eight_ranks_sharing_the_gpu_print_a_self_diagnosing_line():
         assert e["ms_per_step_overlap_on"] > 0 and e["ms_per_step_overlap_off"] > 0 and e["own_own_launch_ms"] > 0, e
     assert set(d["overlap"]) >= {"ms_per_step_on", "ms_per_step_off"}
     assert abs(d["value"] - 2 * d["config"]["nnz_per_part"] * 8 / d["ms_per_step"] / 1e6) / d["value"] < 0.05   # (parts differ by their ghosts)
+
+
+def test_bench_line_of_an_8_rank_run_over_the_ipc_push_transport():
+    """`bench.py --gpus 8` with all ranks on this box's one GPU over the device-only ipc transport: the parity gate passes on every
+    rank (A*1 == b, ghosts == owners) and the line names the transport."""
+    r, d = _bench(8, {"PA_TRANSPORT": "ipc", "PA_BENCH_BACKEND": "gloo"}, ("--no-cpu-baseline",))
+    assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert d["n_gpus"] == 8 and d["config"]["transport"].startswith("ipc"), d["config"]
+    assert len(d["per_rank"]) == 8 and all(p["neighbors_snd"] == 7 for p in d["per_rank"])
