@@ -278,6 +278,12 @@ int pa_csr_create_mixed(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz
 int pa_csr_create_from_csc(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr,
                            const void *rowval, int index_bytes, int index_base, const double *nzval,
                            pa_csr **A);
+/* mul!(y,A,x,alpha,beta) with alpha != 1 is third-party arithmetic in the reference, and its two local matrix types differ by one
+ * rounding: SparseMatricesCSR adds (nz*x[col])*alpha, SparseArrays' CSC method forms axj = x[col]*alpha per column and adds nz*axj.
+ * A block made by pa_csr_create_from_csc follows the CSC form (pa_spmv scales x into a scratch vector, then runs with alpha = 1),
+ * every other block the CSR form; identical for alpha in {1, -1, 2^k}.  pa_csr_set_alpha_inside overrides per block
+ * (PA_CSC_ALPHA_INSIDE=0: CSC-made blocks use the CSR form too). */
+int pa_csr_set_alpha_inside(pa_csr *A, int on);
 int pa_csr_update_values(pa_csr *A, const double *nzval);   /* same pattern, new nonzeros(A) */
 /* nonzeros(A) .= src_local[offset : offset+nnz) -- device to device, on the compute stream (K7: the re-assembled
  * values of psparse!/assemble!(B,A,cache), src/p_sparse_matrix.jl:1291-1305,1762-1816, never leave HBM). */

@@ -667,6 +667,23 @@ def mul5_csr(y, A: CSR, x, alpha, beta):
     return y
 
 
+def mul5_csc(y, x, colptr, rowval, nzval, alpha, beta):
+    """SparseArrays.mul!(C,A::SparseMatrixCSC,B,alpha,beta) (Julia stdlib, third-party to the reference: reached from
+    src/p_sparse_matrix.jl:2116-2138 when the blocks keep the DEFAULT CSC storage; restated from the published algorithm):
+    beta-scale C (rmul! / fill! 0), then column by column  axj = B[col]*alpha;  C[row] += nzval*axj  -- the scalar multiplies the
+    VECTOR entry first, a*(x*alpha), where SparseMatricesCSR forms (a*x)*alpha.  1-based arrays."""
+    if beta != 1:
+        if beta != 0:
+            y *= beta
+        else:
+            y[:] = 0.0
+    for col in range(len(x)):
+        axj = x[col] * alpha
+        for p in range(colptr[col] - 1, colptr[col + 1] - 1):
+            y[rowval[p] - 1] = y[rowval[p] - 1] + nzval[p] * axj
+    return y
+
+
 def csr_to_csc(A: CSR):
     """Same matrix in CSC (1-based); rows ascending inside a column."""
     rows = np.repeat(np.arange(1, A.m + 1), np.diff(A.rowptr.astype(I64)))

@@ -121,6 +121,7 @@ _SIGS = {
     "pa_vec_memory_class": [P, C.POINTER(cint)],
     "pa_csr_create_mixed": [P, i64, i64, i64, P, cint, P, cint, cint, P, PP],
     "pa_csr_create_from_csc": [P, i64, i64, i64, P, P, cint, cint, P, PP],
+    "pa_csr_set_alpha_inside": [P, cint],
     "pa_csr_update_values": [P, P],
     "pa_csr_update_values_from": [P, P, i64],
     "pa_csr_destroy": [P],

@@ -369,6 +369,7 @@ extern "C" int pa_ctx_destroy(pa_ctx *c) {
   (void)pa_raw_free(c->d_partials);
   (void)pa_raw_free(c->d_scalar);
   if (c->d_dotpart) pa_dev_free(c, c->d_dotpart);
+  if (c->d_xalpha) pa_dev_free(c, c->d_xalpha);
   pa_arena_destroy(c);
   (void)hipEventDestroy(c->ev_compute);
   (void)hipStreamDestroy(c->s[0]);
@@ -1247,7 +1248,19 @@ extern "C" int pa_csr_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols,
   }
   csr_src src;
   src.col0 = col.data(); src.nzval = val.data();
-  return csr_build(c, n_rows, n_cols, nnz, rp, src, out);
+  PA_TRY(csr_build(c, n_rows, n_cols, nnz, rp, src, out));
+  // the caller's storage was CSC: its 5-argument product is SparseArrays' (alpha multiplies the vector entry first); pa_spmv follows
+  const char *e = getenv("PA_CSC_ALPHA_INSIDE");
+  if (!(e && atoi(e) == 0)) for (pa_csr *S = *out; S; S = S->next) S->alpha_inside = true;
+  return PA_OK;
+}
+
+// Which of the two third-party 5-argument products a block follows when alpha != 1: 1 = SparseArrays' CSC method, a*(x*alpha)
+// (the default of blocks made by pa_csr_create_from_csc), 0 = SparseMatricesCSR's, (a*x)*alpha (every other block).
+extern "C" int pa_csr_set_alpha_inside(pa_csr *A, int on) {
+  PA_REQUIRE(A != nullptr, "block is NULL");
+  for (pa_csr *S = A; S; S = S->next) S->alpha_inside = on != 0;
+  return PA_OK;
 }
 
 extern "C" int pa_csr_update_values(pa_csr *A, const double *nzval) {
@@ -1612,11 +1625,12 @@ extern "C" int pa_csr_value_dict(const pa_csr *A, int *n_values) {
 
 // the x-window launches of a slab (pa_spmv_xwin.h): small-window groups, big-window groups, and k_spmv_rowsplit over the
 // chunks that are in no group; u != NULL: the fused dot (partial[chunk] as k_spmv_rowsplit's EPI 3 writes it)
-static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta, const double *u, double *partial) {
-  pa_ctx *c = S->ctx;
+static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta, const double *u, double *partial,
+                        hipStream_t st = nullptr) {
+  if (!st) st = S->ctx->s[0];
   const pa_xw_group *grp = (const pa_xw_group *)S->d_xw_grp;
 #define PA_LAUNCH_XW(SUB, DOT, XCAP, G, NG)                                                                                \
-  hipLaunchKernelGGL((k_spmv_xwin<SUB, SPMV_NPT, SPMV_NT, DOT, XCAP>), dim3((((NG) + 7) / 8) * 8), dim3(256 * SUB), 0, c->s[0],  \
+  hipLaunchKernelGGL((k_spmv_xwin<SUB, SPMV_NPT, SPMV_NT, DOT, XCAP>), dim3((((NG) + 7) / 8) * 8), dim3(256 * SUB), 0, st,  \
                      S->d_crp, S->d_col16, S->d_win, S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, (G), (int)(NG),           \
                      (int)(((NG) + 7) / 8), (int)S->n_cols, alpha, kbeta, u, partial)
   const int64_t n0 = S->n_xw_tier[0], n1 = S->n_xw_tier[1], n2 = S->n_xw_tier[2];
@@ -1633,7 +1647,7 @@ static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double al
     // which lifts the ring kernel by 10 %, measured neutral here: +-7000 0.168 / 0.170 ms, +-5000 0.142 / 0.144; PA_SPMV_XWIN_BIG_LANES=512)
     static const int wide2 = getenv("PA_SPMV_XWIN_BIG_LANES") ? atoi(getenv("PA_SPMV_XWIN_BIG_LANES")) : 256;
 #define PA_LAUNCH_XW2(DOT, BLKX, NPTX)                                                                                                  \
-  hipLaunchKernelGGL((k_spmv_xwin<2, NPTX, SPMV_NT, DOT, PA_XW_CAP_BIG, BLKX>), dim3(((n2 + 7) / 8) * 8), dim3(2 * BLKX), 0, c->s[0],   \
+  hipLaunchKernelGGL((k_spmv_xwin<2, NPTX, SPMV_NT, DOT, PA_XW_CAP_BIG, BLKX>), dim3(((n2 + 7) / 8) * 8), dim3(2 * BLKX), 0, st,   \
                      S->d_crp, S->d_col16, S->d_win, S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, grp + n0 + n1, (int)n2,            \
                      (int)((n2 + 7) / 8), (int)S->n_cols, alpha, kbeta, u, partial)
     if (wide2 == 512) { if (u) PA_LAUNCH_XW2(true, 512, 4); else PA_LAUNCH_XW2(false, 512, 4); }
@@ -1647,7 +1661,7 @@ static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double al
     // +-7900 0.172 ms = 4.9 TB/s algorithmic against 0.189 / 4.5 with 256 lanes (PA_SPMV_XRING_LANES=256)
     static const int wide = getenv("PA_SPMV_XRING_LANES") ? atoi(getenv("PA_SPMV_XRING_LANES")) : 512;
 #define PA_LAUNCH_XR(DOT, BLKX, NPTX, UU, PP)                                                                                          \
-  hipLaunchKernelGGL((k_spmv_xring<2, NPTX, SPMV_NT, DOT, BLKX>), dim3(gpx * 8), dim3(2 * BLKX), 0, c->s[0], S->d_crp, S->d_col16, S->d_win, \
+  hipLaunchKernelGGL((k_spmv_xring<2, NPTX, SPMV_NT, DOT, BLKX>), dim3(gpx * 8), dim3(2 * BLKX), 0, st, S->d_crp, S->d_col16, S->d_win, \
                      S->d_val, xs, ys, S->d_chunk_row, S->d_chunk_p, S->d_chunk_cmax, rg, ng, gpx, (int)S->n_cols, alpha, kbeta, UU, PP)
     if (wide == 512) {
       if (u) PA_LAUNCH_XR(true, 512, 4, u, partial);
@@ -1662,13 +1676,13 @@ static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double al
     const int cpx = (int)((S->n_xw_rest + 7) / 8);
     if (u)
       hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
-                         c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
+                         st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                          S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, 1.0, kbeta, partial, u,
                          (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr, S->d_xw_rest,
                          (int)S->n_cols - 1);
     else
       hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
-                         c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
+                         st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                          S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, alpha, kbeta, (double *)nullptr,
                          (const double *)nullptr, (const double *)nullptr, (const unsigned char *)nullptr,
                          (const double *)nullptr, S->d_xw_rest, (int)S->n_cols - 1);
@@ -1676,17 +1690,17 @@ static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double al
 }
 
 // the product kernel on one slab, raw pointers (x: the block's column segment, ys: this slab's rows)
-static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta) {
-  pa_ctx *c = S->ctx;
+static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta, hipStream_t st = nullptr) {
+  if (!st) st = S->ctx->s[0];
   if (S->n_xw_groups > 0 && !S->use_vdict) {
-    launch_xwin(S, xs, ys, alpha, kbeta, nullptr, nullptr);
+    launch_xwin(S, xs, ys, alpha, kbeta, nullptr, nullptr, st);
     return;
   }
   if (S->n_chunks > 0) {
       const int cpx = (int)((S->n_chunks + 7) / 8);
 #define PA_LAUNCH_SPMV(C16, PAT, VD)                                                                                     \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
-                     c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val,           \
+                     st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val,           \
                      xs, ys, S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta,             \
                      (double *)nullptr, (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict,         \
                      (const int *)nullptr, (int)S->n_cols - 1)
@@ -1694,13 +1708,13 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
       if (S->pad_products && !S->use_vdict && sel_ < 2) {
         if (sel_ == 1)
           hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false, 4, true>), dim3(cpx * 8), dim3(SPMV_BLK),
-                             0, c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
+                             0, st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                              S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
                              (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict, (const int *)nullptr,
                              (int)S->n_cols - 1);
         else
           hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, false, 0, 0, false, 4, true>), dim3(cpx * 8), dim3(SPMV_BLK),
-                             0, c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
+                             0, st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                              S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
                              (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict, (const int *)nullptr,
                              (int)S->n_cols - 1);
@@ -1727,8 +1741,15 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
   }
 }
 
+static int spmv_on(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int yseg, double alpha, double beta, hipStream_t st);
 extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int yseg, double alpha, double beta) {
   PA_REQUIRE(A && x && y, "bad arguments");
+  return spmv_on(A, x, xseg, y, yseg, alpha, beta, A->ctx->s[0]);
+}
+
+// the product on a stream of the caller's choice (pa_mul_all queues the parts' own x ghost products on the comm stream, beside
+// the next part's own x own)
+static int spmv_on(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int yseg, double alpha, double beta, hipStream_t st) {
   int64_t xoff, xlen, yoff, ylen;
   PA_TRY(seg_range(x, xseg, &xoff, &xlen));
   PA_TRY(seg_range(y, yseg, &yoff, &ylen));
@@ -1738,15 +1759,33 @@ extern "C" int pa_spmv(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, in
   PA_REQUIRE(x->d != y->d || xseg != yseg, "x and y alias");
   pa_ctx *c = A->ctx;
   PA_HIP(hipSetDevice(c->device));
+  const double *xs_all = x->d + xoff;
+  if (A->alpha_inside && alpha != 1.0) {
+    // A block made from CSC storage: SparseArrays.mul!(y,A::SparseMatrixCSC,x,alpha,beta) forms axj = x[col]*alpha once per column
+    // and adds nzval*axj -- a*(x*alpha), one rounding apart from the CSR method's (a*x)*alpha unless alpha is a power of two.
+    // x .* alpha goes to a scratch vector (one pass over x: 16 B per column next to 12 B per stored entry) and the kernel runs with
+    // alpha = 1: per output entry the same products, added in ascending column as the column-major scatter loop adds them.
+    if (xlen > c->n_xalpha) {
+      PA_REQUIRE(!c->capturing, "the scaled copy of x needs its scratch before a capture opens (run the product once eagerly)");
+      PA_HIP(hipStreamSynchronize(st));
+      if (c->d_xalpha) pa_dev_free(c, c->d_xalpha);
+      c->d_xalpha = nullptr; c->n_xalpha = 0;
+      PA_TRY(pa_dev_alloc(c, (void **)&c->d_xalpha, sizeof(double) * (size_t)(xlen + 2), PA_MEM_VECTOR));
+      c->n_xalpha = xlen;
+    }
+    if (xlen) hipLaunchKernelGGL(k_axpby, dim3(grid_for(xlen, 256)), dim3(256), 0, st, c->d_xalpha, xs_all, xlen, alpha, 0.0);
+    xs_all = c->d_xalpha;
+    alpha = 1.0;
+  }
   for (const pa_csr *S = A; S; S = S->next) {          // one slab unless the block has 2^31 stored entries or more
     double *ys = y->d + yoff + S->row0;
     double kbeta = beta;
     if (S->compact && beta != 1.0) {
       // rows without stored entries still get beta*y (rmul!/fill! of the reference); the kernel then accumulates
-      if (S->n_rows) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n_rows, 256)), dim3(256), 0, c->s[0], ys, S->n_rows, beta);
+      if (S->n_rows) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n_rows, 256)), dim3(256), 0, st, ys, S->n_rows, beta);
       kbeta = 1.0;
     }
-    spmv_launch_slab(S, x->d + xoff, ys, alpha, kbeta);
+    spmv_launch_slab(S, xs_all, ys, alpha, kbeta, st);
   }
   PA_HIP(hipGetLastError());
   return PA_OK;
@@ -2700,21 +2739,24 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
     for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], b[r], PA_CONSISTENT));
     PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_CONSISTENT));
   }
-  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
   if (all_rb) {
-    hipEvent_t waited = nullptr;
+    // own x own of the parts one after the other on the compute stream; a part's own x ghost goes to the COMM stream, behind the
+    // push launch (its data) and an event behind the part's own x own (its accumulator): the small kernel runs beside the next
+    // part's own x own instead of between two of them.  The unpack of all parts follows there, and the compute stream joins.
     for (int r = 0; r < n_parts; ++r) {
       pa_plan *p = plans[r];
-      if (!(p->snd.n || p->rcv.n)) continue;
-      if (p->ev_wait == nullptr || p->ev_wait != waited) PA_TRY(exchange_wait_arrived(p));   // (one event per device: waited for once)
-      waited = p->ev_wait;
-      if (!m[r]->oh_rb) continue;
+      pa_ctx *cx = m[r]->ctx;
+      PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
+      if (!(p->snd.n || p->rcv.n) || !m[r]->oh_rb) continue;
+      PA_HIP(hipEventRecord(p->ev_packed, cx->s[0]));
+      PA_HIP(hipStreamWaitEvent(cx->s[1], p->ev_packed, 0));
       pa_vec buf;
-      buf.ctx = m[r]->ctx; buf.d = p->snd.d_buf; buf.n_own = p->snd.n; buf.n_ghost = 0; buf.owned = false;
-      PA_TRY(pa_spmv(m[r]->oh_rb, &buf, PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, 1.0));
+      buf.ctx = cx; buf.d = p->snd.d_buf; buf.n_own = p->snd.n; buf.n_ghost = 0; buf.owned = false;
+      PA_TRY(spmv_on(m[r]->oh_rb, &buf, PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, 1.0, cx->s[1]));
     }
-    return pa_exchange_finish_all_insert(plans.data(), n_parts, b);
+    return pa_exchange_finish_all_insert(plans.data(), n_parts, b, 1);
   }
+  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
   for (int r = 0; r < n_parts; ++r) {
     if (push) PA_TRY(mul_ghost_part(m[r], c[r], b[r], alpha));
     else {

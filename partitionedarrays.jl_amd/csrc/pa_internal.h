@@ -50,6 +50,8 @@ struct pa_ctx {
   double *d_scalar = nullptr;
   double *d_dotpart = nullptr;            // per-chunk partial sums of a fused product + dot (pa_mul_dot)
   int64_t n_dotpart = 0;
+  double *d_xalpha = nullptr;             // x .* alpha of a product on a CSC-made block (pa_spmv), grown on demand
+  int64_t n_xalpha = 0;
   bool capturing = false;                 // a pa_graph_begin is open on the compute stream
   bool keep_raw_columns = false;          // pa_ctx_keep_raw_columns: blocks created now keep their Int32 columns in HBM (pa_rowsel.hip)
   int comm_priority = 0;                  // priority the comm stream was created with (the device's greatest)
@@ -104,6 +106,8 @@ struct pa_csr {
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
   int64_t n_crows = 0, n_chunks = 0, n_nonempty = 0, n_long = 0;
   bool compact = false;
+  bool alpha_inside = false;       // made from CSC storage (pa_csr_create_from_csc): mul!(y,A,x,alpha,beta) forms a*(x*alpha) as
+                                   // SparseArrays' CSC method does, not (a*x)*alpha (SparseMatricesCSR's): see pa_spmv
   int32_t *d_crp = nullptr;        // (compacted) row pointer, 0-based
   int32_t *d_col = nullptr;        // 0-based columns, padded
   int32_t *d_raw_col = nullptr;    // every stored entry's column (kept on request while d_col holds a compacted stream:
@@ -176,7 +180,7 @@ struct pa_plan {
 
 bool pa_plan_ipc_connected(const pa_plan *p);
 int pa_exchange_start(pa_plan *p, pa_comm *comm, pa_vec *v, int mode);   // pack + transport of one part (RCCL / ipc / none)
-int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v);   // after pa_exchange_push_local(CONSISTENT)
+int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int on_comm_stream);   // after pa_exchange_push_local(CONSISTENT)
 void pa_push_release(pa_plan *p);                // frees what pa_push.hip hung on a plan
 int pa_ipc_ack(pa_plan *p, int mode);            // (compute stream) tell the senders of the exchange just consumed that the buffer is free
 

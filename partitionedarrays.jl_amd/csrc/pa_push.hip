@@ -274,6 +274,14 @@ extern "C" int pa_exchange_push_local(pa_plan *const *plans, int32_t n_parts, pa
   }
   pa_push_table *T = nullptr;
   PA_TRY(local_table(plans, n_parts, mode, &T));
+  // (a group nothing travels in -- the only part of a run -- costs no stream operation at all: a cross-stream event pair between
+  //  two products is ~8 us of idle GPU, measured as 0.689 against 0.673 ms per step of the 256^3 headline loop)
+  bool any = false;
+  for (pa_push_table::launch &l : T->launches) any = any || l.n_blocks || l.n_ublocks;
+  if (!any) {
+    for (int r = 0; r < n_parts; ++r) { plans[r]->phase = 2; plans[r]->mode = mode; plans[r]->own_comm_stream = false; plans[r]->ev_wait = nullptr; }
+    return PA_OK;
+  }
   for (pa_push_table::launch &l : T->launches) {
     pa_ctx *c = l.ctx;
     PA_HIP(hipSetDevice(c->device));
@@ -305,22 +313,30 @@ extern "C" int pa_exchange_push_local(pa_plan *const *plans, int32_t n_parts, pa
   return PA_OK;
 }
 
-// unpack (insert) of every part of the group with one launch per device, on the compute streams, AFTER whatever the caller
-// queued there since the arrival (own x ghost reading the receive buffers).  consistent! only.
-int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v) {
+// unpack (insert) of every part of the group with one launch per device, behind whatever read the receive buffers since the
+// arrival.  on_comm_stream = 0: on the compute streams (the caller's readers ran there); 1: on the comm streams (pa_mul_all queues
+// own x ghost there), and the compute streams wait for it.  consistent! only.
+int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int on_comm_stream) {
   pa_push_table *T = plans[0]->push[PA_CONSISTENT];
   PA_REQUIRE(T && (int)T->key.size() == n_parts && std::equal(T->key.begin(), T->key.end(), plans), "no push table for these plans");
+  bool any = false;
+  for (pa_push_table::launch &l : T->launches) any = any || l.n_blocks || l.n_ublocks;
   for (pa_push_table::launch &l : T->launches) {
     pa_ctx *c = l.ctx;
+    if (!any) { for (int r : l.parts) { plans[r]->phase = 0; plans[r]->ev_wait = nullptr; } continue; }
     PA_HIP(hipSetDevice(c->device));
-    PA_HIP(hipStreamWaitEvent(c->s[0], l.ev, 0));
+    hipStream_t st = on_comm_stream ? c->s[1] : c->s[0];
+    if (!on_comm_stream) PA_HIP(hipStreamWaitEvent(c->s[0], l.ev, 0));
     if (l.n_ublocks) {
       pa_unpack_vecs vv;
       for (size_t k = 0; k < l.parts.size(); ++k) vv.v[k] = v[l.parts[k]]->d;
-      hipLaunchKernelGGL(k_unpack_insert_multi, dim3(l.n_ublocks), dim3(256), 0, c->s[0], l.d_uparts, l.d_ublock_part, vv);
+      hipLaunchKernelGGL(k_unpack_insert_multi, dim3(l.n_ublocks), dim3(256), 0, st, l.d_uparts, l.d_ublock_part, vv);
       PA_HIP(hipGetLastError());
     }
-    if (!c->capturing) {                               // the next pack (comm stream) must not overwrite buffers this unpack reads
+    if (on_comm_stream) {
+      PA_HIP(hipEventRecord(l.ev, c->s[1]));             // wait(t) of the whole product: the compute stream joins here
+      PA_HIP(hipStreamWaitEvent(c->s[0], l.ev, 0));      // (the next push is on the comm stream, behind this unpack)
+    } else if (!c->capturing) {                          // the next pack (comm stream) must not overwrite buffers this unpack reads
       PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
       PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
     }

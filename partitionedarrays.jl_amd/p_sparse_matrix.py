@@ -98,6 +98,21 @@ class DeviceCSR:
         self.h = C.c_void_p()
         L.call("pa_csr_create_from_csc", self.ctx.h, A.n, A.m, A.nnz, L.ptr(A.rowptr), L.ptr(A.colval), 4, 1,
                L.ptr(A.nzval), C.byref(self.h))
+        L.call("pa_csr_set_alpha_inside", self.h, 0)      # (a CSR block's transpose: SparseMatricesCSR's (a*x)*alpha, not the CSC form)
+        return self
+
+    @staticmethod
+    def from_csc(m, n, colptr, rowval, nzval, ctx=None) -> "DeviceCSR":
+        """A block the caller keeps in the DEFAULT SparseMatrixCSC storage (1-based colptr / rowval): converted to the row-split
+        layout on the way up (spmv_csc! == spmv_csr! bit for bit, src/sparse_utils.jl:671-690); its 5-argument product follows
+        SparseArrays' CSC method, a*(x*alpha)."""
+        self = DeviceCSR.__new__(DeviceCSR)
+        self.ctx = ctx or context()
+        self.m, self.n, self.nnz = int(m), int(n), len(nzval)
+        self.h = C.c_void_p()
+        colptr, rowval = np.ascontiguousarray(colptr, np.int32), np.ascontiguousarray(rowval, np.int32)
+        L.call("pa_csr_create_from_csc", self.ctx.h, self.m, self.n, self.nnz, L.ptr(colptr), L.ptr(rowval), 4, 1,
+               L.ptr(np.ascontiguousarray(nzval, F64)), C.byref(self.h))
         return self
 
     @staticmethod
