@@ -388,7 +388,7 @@ def chain_info(P):
             "critical_path_launches": {"before_own_own": 0, "beside_own_own": 1, "after_own_own": 1, "after_own_ghost_off_path": 1}}
 
 
-def whole_mul_times(pa, ctx, L, A, x, y, reps=30):
+def whole_mul_times(pa, ctx, L, A, x, y, reps=30, graph=True):
     """ms per mul! of all parts of A (eager: one library call; replayed from a hipGraph) and ms of the parts' own x own alone."""
     spin_up(ctx, lambda: pa.mul_c_(y, A, x))
     e0 = ctx.event().record(L.STREAM_COMPUTE)
@@ -399,6 +399,8 @@ def whole_mul_times(pa, ctx, L, A, x, y, reps=30):
     ms = e0.elapsed_ms(e1) / reps
     ms_graph = float("nan")
     try:
+        if not graph:
+            raise RuntimeError("not asked for")
         with pa.Graph() as g:
             pa.mul_c_(y, A, x)
         for _ in range(10):

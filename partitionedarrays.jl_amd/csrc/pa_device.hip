@@ -2490,6 +2490,8 @@ extern "C" int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mod
   for (int r = 0; r < n_parts; ++r) {
     PA_REQUIRE(plans[r] && plans[r]->part == r, "plans[%d] is not the plan of part %d", r, r);
     PA_REQUIRE(plans[r]->phase == 1 && plans[r]->mode == mode, "part %d: pa_exchange_pack(mode) must come first", r);
+    // (measured on ROCm 7.0: hipStreamEndCapture recurses without end -- a segfault -- over this transport's comm-stream waits)
+    PA_REQUIRE(!(plans[r]->ctx->capturing && n_parts > 1), "the copy transport is not capturable into a hipGraph: use pa_exchange_push_local");
   }
   // src/primitives.jl:1020-1042: rcv[r].data[ptrs_rcv[i]..] = snd[s].data[ptrs_snd[j]..], snd_ids[s][j] == r
   for (int r = 0; r < n_parts; ++r) {
@@ -2743,18 +2745,41 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
     // own x own of the parts one after the other on the compute stream; a part's own x ghost goes to the COMM stream, behind the
     // push launch (its data) and an event behind the part's own x own (its accumulator): the small kernel runs beside the next
     // part's own x own instead of between two of them.  The unpack of all parts follows there, and the compute stream joins.
+    // The LAST part's own x ghost stays on the compute stream (nothing is left to run beside it, and a cross-stream hop costs ~8 us:
+    // with everything on the comm stream config 3 on two parts measured 1.23 x own x own, 1.19 x with nothing there), the compute
+    // stream then waits for the comm stream's products (long done) and the unpack of all parts follows on it.
+    // The unpack that makes b itself consistent (src/p_vector.jl:603-611) reads the receive buffers and writes b's ghosts, which no
+    // product of this call reads any more: it follows the push launch on the comm stream at once, beside own x own of the first
+    // part, and the compute streams join it at the very end (wait(t)) -- nothing of consistent! is left on the critical path.
+    PA_TRY(pa_exchange_finish_all_insert(plans.data(), n_parts, b, 2));
+    int last = -1;
+    for (int r = 0; r < n_parts; ++r) if ((plans[r]->snd.n || plans[r]->rcv.n) && m[r]->oh_rb) last = r;
+    std::vector<pa_ctx *> forked;
     for (int r = 0; r < n_parts; ++r) {
       pa_plan *p = plans[r];
       pa_ctx *cx = m[r]->ctx;
       PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
       if (!(p->snd.n || p->rcv.n) || !m[r]->oh_rb) continue;
-      PA_HIP(hipEventRecord(p->ev_packed, cx->s[0]));
-      PA_HIP(hipStreamWaitEvent(cx->s[1], p->ev_packed, 0));
       pa_vec buf;
       buf.ctx = cx; buf.d = p->snd.d_buf; buf.n_own = p->snd.n; buf.n_ghost = 0; buf.owned = false;
+      if (r == last) {
+        PA_TRY(exchange_wait_arrived(p));
+        PA_TRY(pa_spmv(m[r]->oh_rb, &buf, PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, 1.0));
+        continue;
+      }
+      PA_HIP(hipEventRecord(p->ev_packed, cx->s[0]));
+      PA_HIP(hipStreamWaitEvent(cx->s[1], p->ev_packed, 0));
       PA_TRY(spmv_on(m[r]->oh_rb, &buf, PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, 1.0, cx->s[1]));
+      if (std::find(forked.begin(), forked.end(), cx) == forked.end()) forked.push_back(cx);
+      PA_HIP(hipEventRecord(p->ev_arrived, cx->s[1]));            // (the newest of these per device is what the compute stream joins on)
+      p->ev_wait = p->ev_arrived;
     }
-    return pa_exchange_finish_all_insert(plans.data(), n_parts, b, 1);
+    for (pa_ctx *cx : forked) {                                    // join: the products queued on the comm streams
+      int newest = -1;
+      for (int r = 0; r < n_parts; ++r) if (m[r]->ctx == cx && r != last && plans[r]->ev_wait == plans[r]->ev_arrived && m[r]->oh_rb) newest = r;
+      if (newest >= 0) PA_HIP(hipStreamWaitEvent(cx->s[0], plans[newest]->ev_arrived, 0));
+    }
+    return pa_exchange_join_all(plans.data(), n_parts);
   }
   for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
   for (int r = 0; r < n_parts; ++r) {
@@ -2927,7 +2952,11 @@ extern "C" int pa_graph_end(pa_ctx *c, pa_graph **out) {
   PA_REQUIRE(c->capturing, "pa_graph_end without pa_graph_begin");
   c->capturing = false;
   hipGraph_t graph = nullptr;
-  PA_HIP(hipStreamEndCapture(c->s[0], &graph));
+  if (hipError_t e = hipStreamEndCapture(c->s[0], &graph)) {
+    (void)hipGetLastError();                           // (the failed capture's error must not surface in the next, unrelated call)
+    pa_set_err("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    return PA_ERR_HIP;
+  }
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
   (void)hipGraphDestroy(graph);

@@ -314,8 +314,8 @@ extern "C" int pa_exchange_push_local(pa_plan *const *plans, int32_t n_parts, pa
 }
 
 // unpack (insert) of every part of the group with one launch per device, behind whatever read the receive buffers since the
-// arrival.  on_comm_stream = 0: on the compute streams (the caller's readers ran there); 1: on the comm streams (pa_mul_all queues
-// own x ghost there), and the compute streams wait for it.  consistent! only.
+// arrival.  on_comm_stream = 0: on the compute streams (the caller's readers ran there); 1: on the comm streams, and the compute
+// streams wait for it; 2: on the comm streams, the compute streams join later (pa_exchange_join_all).  consistent! only.
 int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int on_comm_stream) {
   pa_push_table *T = plans[0]->push[PA_CONSISTENT];
   PA_REQUIRE(T && (int)T->key.size() == n_parts && std::equal(T->key.begin(), T->key.end(), plans), "no push table for these plans");
@@ -334,11 +334,28 @@ int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec
       PA_HIP(hipGetLastError());
     }
     if (on_comm_stream) {
-      PA_HIP(hipEventRecord(l.ev, c->s[1]));             // wait(t) of the whole product: the compute stream joins here
+      PA_HIP(hipEventRecord(l.ev, c->s[1]));             // wait(t) of the whole product: the compute stream joins here ...
+      if (on_comm_stream == 2) continue;                 // ... or later, in pa_exchange_join_all (the plans stay "in flight")
       PA_HIP(hipStreamWaitEvent(c->s[0], l.ev, 0));      // (the next push is on the comm stream, behind this unpack)
     } else if (!c->capturing) {                          // the next pack (comm stream) must not overwrite buffers this unpack reads
       PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
       PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+    }
+    for (int r : l.parts) { plans[r]->phase = 0; plans[r]->ev_wait = nullptr; }
+  }
+  return PA_OK;
+}
+
+// wait(t) after pa_exchange_finish_all_insert(..., 2): the compute streams wait for the unpack queued on the comm streams
+int pa_exchange_join_all(pa_plan *const *plans, int32_t n_parts) {
+  pa_push_table *T = plans[0]->push[PA_CONSISTENT];
+  PA_REQUIRE(T && (int)T->key.size() == n_parts && std::equal(T->key.begin(), T->key.end(), plans), "no push table for these plans");
+  bool any = false;
+  for (pa_push_table::launch &l : T->launches) any = any || l.n_blocks || l.n_ublocks;
+  for (pa_push_table::launch &l : T->launches) {
+    if (any) {
+      PA_HIP(hipSetDevice(l.ctx->device));
+      PA_HIP(hipStreamWaitEvent(l.ctx->s[0], l.ev, 0));
     }
     for (int r : l.parts) { plans[r]->phase = 0; plans[r]->ev_wait = nullptr; }
   }

@@ -6,9 +6,15 @@ import re
 from __graft_entry__ import ROOT, load_package
 
 
-def _declared():
-    txt = open(os.path.join(ROOT, "include", "pa_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+HEADERS = ("pa_hip.h", "pa_hip_experimental.h")       # the contract and the experimental tier (include/pa_hip.h, "TIERS")
+
+
+def _header_text(names=HEADERS):
+    return "\n".join(open(os.path.join(ROOT, "include", n)).read() for n in names)
+
+
+def _declared(names=HEADERS):
+    txt = re.sub(r"/\*.*?\*/", "", _header_text(names), flags=re.S)
     return sorted(set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", txt)))
 
 
@@ -39,8 +45,7 @@ def test_errors_are_statuses_not_aborts():
 
 # ---- the Julia glue (not runnable here: no julia in the image) is checked statically against the header ---------------
 def _prototypes():
-    txt = open(os.path.join(ROOT, "include", "pa_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"/\*.*?\*/", "", _header_text(), flags=re.S)
     protos = {}
     for ret, name, args in re.findall(r"([A-Za-z_][\w \*]*?)\b(pa_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", txt):
         args = [a.strip() for a in args.split(",")] if args.strip() not in ("", "void") else []
@@ -96,6 +101,21 @@ def test_julia_glue_ccalls_match_header():
         assert _jl_class(ret) == _c_class(cret + " x"), f"{name}: return type"
 
 
+def test_the_glue_and_the_c_example_need_only_the_contract_header():
+    """a binding author must be able to tell contract from lab.  Every entry point the Julia glue ccalls and
+    everything examples/c_abi_smoke.c uses is declared in include/pa_hip.h; pa_hip_experimental.h holds none of them, and the
+    two headers declare disjoint sets that together are exactly what the library's binding table lists."""
+    contract, lab = set(_declared(("pa_hip.h",))), set(_declared(("pa_hip_experimental.h",)))
+    assert not (contract & lab)
+    src = open(os.path.join(ROOT, "partitionedarrays.jl_amd", "julia", "PartitionedArraysHIP.jl")).read()
+    used = set(re.findall(r"ccall\(\(:(pa_[a-z0-9_]+),", src))
+    assert used and used <= contract, sorted(used - contract)
+    csrc = open(os.path.join(ROOT, "examples", "c_abi_smoke.c")).read()
+    assert '#include "pa_hip.h"' in csrc and "pa_hip_experimental.h" not in csrc
+    assert set(re.findall(r"\b(pa_[a-z0-9_]+)\s*\(", csrc)) <= contract
+    assert not [n for n in contract if n.startswith("pa_host_")] and len(contract) < 110
+
+
 def test_committed_bench_line_follows_the_contract():
     """profiles/rNN_bench_n1.json is one line printed by bench.py on an MI355X: the keys the driver and the judge read."""
     import glob
@@ -126,8 +146,8 @@ def test_header_is_valid_c99_and_the_c_example_links():
     import subprocess
     load_package()
     inc = os.path.join(ROOT, "include")
-    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c",
-                           os.path.join(inc, "pa_hip.h")])
+    for h in HEADERS:
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, h)])
     out = os.path.join(ROOT, "examples", "c_abi_smoke")
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", inc,
                            os.path.join(ROOT, "examples", "c_abi_smoke.c"), "-L", os.path.join(ROOT, "partitionedarrays.jl_amd"),
