@@ -603,9 +603,32 @@ def extra_configs(pa, ctx, L, out):
     _x, r0, r, it = pa.opt_cg_(pa.pzeros(Amg.col_partition), Amg, bmg, maxiter=30, Pl=S, fuse=True)
     ctx.sync()
     dt = (time.perf_counter() - t) / 30
-    out.append({"workload": "HPCG MG-PCG iteration, 27-pt 256^3, 1 part: 4-level V-cycle (multicolour Gauss-Seidel as SpMV + update, fused "
+    entry_mg = {"workload": "HPCG MG-PCG iteration, 27-pt 256^3, 1 part: 4-level V-cycle (multicolour Gauss-Seidel as SpMV + update, fused "
                             "restriction) + opt_cg_ (tools/hpcg_driver.py runs the three-phase benchmark around it)",
-                "ms_per_iteration": round(dt * 1e3, 3), "pc_setup_s": round(ts, 2), "iterations": int(it), "residual_reduction": float(r / r0)})
+                "ms_per_iteration": round(dt * 1e3, 3), "pc_setup_s": round(ts, 2), "iterations": int(it), "residual_reduction": float(r / r0)}
+    out.append(entry_mg)
+    del S, Amg, bmg, _x
+    try:                                                     # the same with the library's default value dictionary (what a caller gets)
+        PHASE[0] = "extra: MG-PCG 256^3, value dictionary"
+        os.environ.pop("PA_SPMV_VALUE_DICT")
+        ctx.sync()
+        t = time.perf_counter()
+        S = pa.pc_setup(ranks1, 1, 4, 256, 256, 256, ordering="multicolor_spmv")
+        ctx.sync()
+        ts = time.perf_counter() - t
+        Amg, bmg = S.A_vec[-1], S.r[-1]
+        pa.opt_cg_(pa.pzeros(Amg.col_partition), Amg, bmg, maxiter=10, Pl=S, fuse=True)
+        ctx.sync()
+        t = time.perf_counter()
+        _x, r0b, rb, itb = pa.opt_cg_(pa.pzeros(Amg.col_partition), Amg, bmg, maxiter=30, Pl=S, fuse=True)
+        ctx.sync()
+        entry_mg["with_default_value_dictionary"] = {"ms_per_iteration": round((time.perf_counter() - t) / 30 * 1e3, 3), "pc_setup_s": round(ts, 2),
+                                                     "iterations": int(itb),
+                                                     "residual_rel_diff_vs_fp64_stream": float(abs(rb - r) / max(abs(r), 1e-300)),
+                                                     "note": "same products, same bits of every vector; with a dictionary the fused u'c of "
+                                                             "opt_cg_ is a separate pass (another summation order of the dot), hence the last digits"}
+    finally:
+        os.environ["PA_SPMV_VALUE_DICT"] = "0"
     return out
 
 
@@ -671,6 +694,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # `value` and every standard entry of the line stay on the fp64 value stream: the library's value dictionary --
+    # on by default for big blocks since round 4, lossless -- is switched off here and measured beside them, labelled
+    vdict_env = os.environ.get("PA_SPMV_VALUE_DICT")
+    os.environ["PA_SPMV_VALUE_DICT"] = "0" if vdict_env is None else vdict_env
     pa = load_package()
     ctx = pa.context()
     import pa_amd._lib as L
@@ -1031,9 +1058,9 @@ def main():
     if N == 1 and args.value_dict:
         try:                                                   # an optional extra never costs the headline its line
             PHASE[0] = "value-dictionary mode"
-            os.environ["PA_SPMV_VALUE_DICT"] = "1"
+            os.environ.pop("PA_SPMV_VALUE_DICT")              # the library's default (auto: big blocks with <= 64 distinct values)
             A2, _b2 = pa.build_p_matrix(ranks, n, n, n, *gn, npx, npy, npz)
-            os.environ.pop("PA_SPMV_VALUE_DICT")
+            os.environ["PA_SPMV_VALUE_DICT"] = "0"
             blk2 = pa.local_items(A2.matrix_partition)[0]
             y2 = pa.pzeros(A2.row_partition)
             pa.mul_(y2, A2, x)
@@ -1048,13 +1075,14 @@ def main():
             e1 = ctx.event().record(L.STREAM_COMPUTE)
             ctx.sync()
             ms2 = e0.elapsed_ms(e1) / args.steps
-            vdict = {"what": "own x own SpMV with PA_SPMV_VALUE_DICT=1 (optional, lossless; NOT used for `value`)",
+            vdict = {"what": "own x own SpMV with the library's DEFAULT value dictionary (lossless, built on the device for big blocks with <= 64 "
+                             "distinct values; bench.py switches it off -- PA_SPMV_VALUE_DICT=0 -- for `value` and every other entry)",
                      "distinct_values": blk2.own_own.value_dict(), "bit_identical_to_headline_product": bool(same),
                      "avg_launch_ms": round(ms2, 4), "gflops": round(2.0 * nnz_oo / (ms2 * 1e-3) / 1e9, 1),
                      "algorithmic_gbps": round(bytes_oo / (ms2 * 1e-3) / 1e9, 1)}
             del A2, _b2, y2, blk2
         except Exception as e:                                 # noqa: BLE001
-            os.environ.pop("PA_SPMV_VALUE_DICT", None)
+            os.environ["PA_SPMV_VALUE_DICT"] = "0"
             print(f"[bench] value-dictionary extra skipped: {e}", file=sys.stderr)
             vdict = None
 
@@ -1116,6 +1144,16 @@ def main():
             print(f"[bench] general-CSR entries stopped at {PHASE[0]!r}: {e}", file=sys.stderr)
         general = general or None
 
+    extras = None
+    if N == 1 and args.extra and rank == 0:
+        extras = []
+        try:
+            extra_configs(pa, ctx, L, extras)
+        except Exception as e:                                 # noqa: BLE001
+            print(f"[bench] extra configs stopped at {PHASE[0]!r}: {e}", file=sys.stderr)
+        extras = extras or None
+
+    # (behind the extras: its sort scratch -- ~16 GB of plain allocations -- makes the driver wipe memory the extras' extents would take)
     # ---- SURVEY 8(f) row f2 at the headline's size: mul!(c,transpose(A),b,1,0) with A' built on the device from the resident
     # block (no host copy exists: the headline matrix was generated in HBM)
     transpose = None
@@ -1149,15 +1187,6 @@ def main():
             A._t_blocks = None
         except Exception as e:                                 # noqa: BLE001
             print(f"[bench] transpose product skipped: {e}", file=sys.stderr)
-
-    extras = None
-    if N == 1 and args.extra and rank == 0:
-        extras = []
-        try:
-            extra_configs(pa, ctx, L, extras)
-        except Exception as e:                                 # noqa: BLE001
-            print(f"[bench] extra configs stopped at {PHASE[0]!r}: {e}", file=sys.stderr)
-        extras = extras or None
 
     if want_cpu:
         with optional_section("CPU baseline", 3 * args.cpu_seconds + 240, N, rank):

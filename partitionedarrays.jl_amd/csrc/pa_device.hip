@@ -737,6 +737,122 @@ struct csr_src {
   }
 };
 
+// ---- the lossless value dictionary (round 4: built on the device, on by default for big blocks) --------------------------
+// A block whose stored values take at most PA_VDICT_MAX = 64 distinct bit patterns (27-point HPCG: 2; 7-point Laplacian: 2; a Q1
+// stiffness matrix on a uniform grid: about a dozen) also keeps ONE BYTE per stored entry, and the product kernels stream that
+// instead of the 8-byte value (k_spmv_rowsplit<..., VD = true>: the values sit in the lanes of a register, an entry's value is
+// fetched with ds_bpermute).  Same values, same products, same order: same bits; 0.567 against 0.673 ms on the 256^3 operator.
+//   PA_SPMV_VALUE_DICT unset: AUTO -- blocks of >= 2^18 stored entries that do not run on the x-window launches;
+//                      = 1  : every block that qualifies;  = 0: never (bench.py's headline: `value` stays on the fp64 stream).
+// Two passes over the values: (1) every distinct bit pattern is inserted into a 256-slot open-addressing table with atomicCAS
+// (a lane first compares with the last two patterns it saw: a stencil operator costs two compares per entry), more than 64 -> no
+// dictionary; (2) the sorted patterns become the dictionary and every entry its code.  pa_csr_update_values* leave the codes
+// stale: the block continues on the fp64 stream and is re-encoded once it has served 8 products on the new values (a caller that
+// re-assembles every step never pays for codes it will not use); new values that overflow the dictionary end it for good.
+#define PA_VDICT_SLOTS 256
+#define PA_VDICT_EMPTY 0x7FF8DEADBEEF0001ull   /* (a NaN payload no assembled matrix holds; a block that does gets no dictionary) */
+__device__ __forceinline__ int vdict_hash(unsigned long long b) { return (int)((b * 0x9E3779B97F4A7C15ull) >> 56); }
+
+__global__ __launch_bounds__(256) void k_vdict_collect(const double *__restrict__ val, int64_t n, unsigned long long *__restrict__ table,
+                                                       int *__restrict__ count) {
+  unsigned long long seen0 = PA_VDICT_EMPTY, seen1 = PA_VDICT_EMPTY;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(val[p]);
+    if (b == seen0 || b == seen1) continue;
+    if (b == PA_VDICT_EMPTY || *(volatile int *)count > PA_VDICT_MAX) { atomicMax(count, PA_VDICT_MAX + 1); return; }
+    int h = vdict_hash(b);
+    for (int k = 0; k < PA_VDICT_SLOTS; ++k) {
+      const unsigned long long old = atomicCAS(&table[h], PA_VDICT_EMPTY, b);
+      if (old == PA_VDICT_EMPTY) { atomicAdd(count, 1); break; }
+      if (old == b) break;
+      h = (h + 1) & (PA_VDICT_SLOTS - 1);
+    }
+    seen1 = seen0; seen0 = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_vdict_encode(const double *__restrict__ val, int64_t n, const unsigned long long *__restrict__ table,
+                                                      const unsigned char *__restrict__ slot_code, unsigned char *__restrict__ code) {
+  __shared__ unsigned long long t[PA_VDICT_SLOTS];
+  __shared__ unsigned char sc[PA_VDICT_SLOTS];
+  t[threadIdx.x] = table[threadIdx.x];
+  sc[threadIdx.x] = slot_code[threadIdx.x];
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(val[p]);
+    int h = vdict_hash(b);
+    while (t[h] != b) h = (h + 1) & (PA_VDICT_SLOTS - 1);      // (every value is in the table: pass 1 put it there)
+    code[p] = sc[h];
+  }
+}
+
+// (re)build the dictionary of one slab from its value stream; `rebuild`: the codes exist and the values changed
+static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
+  const char *e = getenv("PA_SPMV_VALUE_DICT");
+  const int mode = e ? atoi(e) : -1;                           // -1 auto, 0 off, 1 on
+  A->use_vdict = false;
+  A->vdict_stale = false;
+  if (mode == 0 || A->nnz == 0 || A->vdict_dead || c->capturing) return PA_OK;
+  if (mode < 0 && !rebuild && (A->nnz < ((int64_t)1 << 18) || A->n_xw_groups > 0)) return PA_OK;
+  const size_t pad = 8;
+  hipStream_t s = c->s[0];
+  unsigned long long *d_table = nullptr;
+  unsigned char *d_slot = nullptr;
+  int *d_count = nullptr;
+  PA_HIP(pa_raw_malloc(&d_table, sizeof(unsigned long long) * PA_VDICT_SLOTS));
+  PA_HIP(pa_raw_malloc(&d_slot, PA_VDICT_SLOTS));
+  PA_HIP(pa_raw_malloc(&d_count, sizeof(int)));
+  auto done = [&](int st) { (void)pa_raw_free(d_table); (void)pa_raw_free(d_slot); (void)pa_raw_free(d_count); return st; };
+  std::vector<unsigned long long> table(PA_VDICT_SLOTS, PA_VDICT_EMPTY);
+  if (hipMemcpyAsync(d_table, table.data(), sizeof(unsigned long long) * PA_VDICT_SLOTS, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemsetAsync(d_count, 0, sizeof(int), s) != hipSuccess) { pa_set_err("value dictionary: upload failed"); return done(PA_ERR_HIP); }
+  const int blocks = (int)std::min<int64_t>((A->nnz + 256 * 8 - 1) / (256 * 8), 256 * 64);
+  hipLaunchKernelGGL(k_vdict_collect, dim3(blocks), dim3(256), 0, s, A->d_val, A->nnz, d_table, d_count);
+  int count = 0;
+  if (hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipMemcpyAsync(table.data(), d_table, sizeof(unsigned long long) * PA_VDICT_SLOTS, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) { pa_set_err("value dictionary: read-back failed"); return done(PA_ERR_HIP); }
+  if (count > PA_VDICT_MAX) {                                  // more distinct values than lanes: this block streams fp64 for good
+    if (rebuild) A->vdict_dead = true;
+    return done(PA_OK);
+  }
+  std::vector<unsigned long long> dict;
+  for (unsigned long long b : table) if (b != PA_VDICT_EMPTY) dict.push_back(b);
+  std::sort(dict.begin(), dict.end());
+  std::vector<unsigned char> slot(PA_VDICT_SLOTS, 0);
+  for (int h = 0; h < PA_VDICT_SLOTS; ++h)
+    if (table[h] != PA_VDICT_EMPTY) slot[h] = (unsigned char)(std::lower_bound(dict.begin(), dict.end(), table[h]) - dict.begin());
+  std::vector<double> dv(PA_VDICT_MAX, 0.0);
+  memcpy(dv.data(), dict.data(), 8 * dict.size());
+  if (!A->d_code) {
+    if (const int st = pa_dev_alloc(c, (void **)&A->d_code, A->nnz + pad, PA_MEM_MATRIX)) return done(st);
+    if (const int st = pa_dev_alloc(c, (void **)&A->d_dict, sizeof(double) * PA_VDICT_MAX, PA_MEM_MATRIX)) return done(st);
+    if (hipMemsetAsync(A->d_code + A->nnz, 0, pad, s) != hipSuccess) { pa_set_err("value dictionary: memset failed"); return done(PA_ERR_HIP); }
+  }
+  if (hipMemcpyAsync(d_slot, slot.data(), PA_VDICT_SLOTS, hipMemcpyHostToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(A->d_dict, dv.data(), sizeof(double) * PA_VDICT_MAX, hipMemcpyHostToDevice, s) != hipSuccess) {
+    pa_set_err("value dictionary: upload failed");
+    return done(PA_ERR_HIP);
+  }
+  hipLaunchKernelGGL(k_vdict_encode, dim3(blocks), dim3(256), 0, s, A->d_val, A->nnz, d_table, d_slot, A->d_code);
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { pa_set_err("value dictionary: encoding failed"); return done(PA_ERR_HIP); }
+  A->use_vdict = true;
+  A->n_dict = (int)dict.size();
+  return done(PA_OK);
+}
+
+// a block whose values were updated runs on the fp64 stream; once it has served 8 products on the new values its codes are renewed
+static void vdict_maintain(const pa_csr *A) {
+  for (const pa_csr *S0 = A; S0; S0 = S0->next) {
+    pa_csr *S = const_cast<pa_csr *>(S0);
+    if (!S->vdict_stale || S->ctx->capturing) continue;
+    if (++S->vdict_products < 8) continue;
+    if (vdict_build(S->ctx, S, true) != PA_OK) { (void)hipGetLastError(); S->vdict_dead = true; S->vdict_stale = false; }
+  }
+}
+
 // fills the freshly created slab A; on any failure the caller (csr_build_slab) hands back whatever A holds by then
 static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
                          const csr_src &src) {
@@ -962,77 +1078,8 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   lap("x windows");
   if (tm_) fprintf(stderr, "[pa setup] val %p (%lld B, memory class %d) col %p crp %p chunk_row %p pdesc %p\n", (void *)A->d_val,
                    (long long)(8 * (nnz + pad)), pa_mem_class(c, A->d_val), (void *)A->d_col, (void *)A->d_crp, (void *)A->d_chunk_row, (void *)A->d_pdesc);
-  // optional lossless value dictionary (PA_SPMV_VALUE_DICT=1): at most PA_VDICT_MAX distinct bit patterns
-  {
-    const char *e = getenv("PA_SPMV_VALUE_DICT");
-    std::vector<double> val_host;            // (a block assembled on the device: the optional dictionary is built from a host copy)
-    if (e && atoi(e) != 0 && nnz > 0 && !nzval && src.d_val) {
-      val_host.resize(nnz);
-      PA_HIP(hipMemcpy(val_host.data(), src.d_val, sizeof(double) * nnz, hipMemcpyDeviceToHost));
-      nzval = val_host.data();
-    }
-    if (e && atoi(e) != 0 && nnz > 0 && nzval) {
-      const int T = host_threads(nnz);
-      std::vector<std::vector<uint64_t>> local(T);
-      std::vector<char> over(T, 0);
-      auto scan = [&](int t) {
-        std::vector<uint64_t> &d = local[t];
-        for (int64_t p = nnz * t / T; p < nnz * (t + 1) / T; ++p) {
-          uint64_t bits;
-          memcpy(&bits, &nzval[p], 8);
-          size_t k = 0;
-          while (k < d.size() && d[k] != bits) ++k;
-          if (k == d.size()) {
-            if (d.size() == PA_VDICT_MAX) { over[t] = 1; return; }
-            d.push_back(bits);
-          }
-        }
-      };
-      {
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(scan, t);
-        scan(0);
-        for (auto &x : th) x.join();
-      }
-      std::vector<uint64_t> dict;
-      bool ok = true;
-      for (int t = 0; t < T && ok; ++t) {
-        if (over[t]) ok = false;
-        for (uint64_t b : local[t]) {
-          if (std::find(dict.begin(), dict.end(), b) == dict.end()) {
-            if (dict.size() == PA_VDICT_MAX) { ok = false; break; }
-            dict.push_back(b);
-          }
-        }
-      }
-      if (ok) {
-        std::vector<uint8_t> code(nnz + pad, 0);
-        auto enc = [&](int t) {
-          for (int64_t p = nnz * t / T; p < nnz * (t + 1) / T; ++p) {
-            uint64_t bits;
-            memcpy(&bits, &nzval[p], 8);
-            size_t k = 0;
-            while (dict[k] != bits) ++k;
-            code[p] = (uint8_t)k;
-          }
-        };
-        {
-          std::vector<std::thread> th;
-          for (int t = 1; t < T; ++t) th.emplace_back(enc, t);
-          enc(0);
-          for (auto &x : th) x.join();
-        }
-        std::vector<double> dv(PA_VDICT_MAX, 0.0);
-        memcpy(dv.data(), dict.data(), 8 * dict.size());
-        PA_TRY(pa_dev_alloc(c, (void **)&A->d_code, nnz + pad, PA_MEM_MATRIX));
-        PA_TRY(pa_dev_alloc(c, (void **)&A->d_dict, sizeof(double) * PA_VDICT_MAX, PA_MEM_MATRIX));
-        PA_HIP(pa_h2d(A->d_code, code.data(), nnz + pad));
-        PA_HIP(pa_h2d(A->d_dict, dv.data(), sizeof(double) * PA_VDICT_MAX));
-        A->use_vdict = true;
-        A->n_dict = (int)dict.size();
-      }
-    }
-  }
+  // lossless value dictionary (see vdict_build): built by kernels from the value stream that is in HBM by now
+  PA_TRY(vdict_build(c, A, false));
   return PA_OK;
 }
 
@@ -1268,7 +1315,8 @@ extern "C" int pa_csr_update_values(pa_csr *A, const double *nzval) {
   if (A->t_nnz == 0) return PA_OK;
   PA_HIP(hipSetDevice(A->ctx->device));
   for (pa_csr *S = A; S; S = S->next) {
-    S->use_vdict = false;            // the codes describe the old values: back to the fp64 stream
+    if (S->use_vdict || S->vdict_stale) { S->vdict_stale = true; S->vdict_products = 0; }
+    S->use_vdict = false;            // the codes describe the old values: back to the fp64 stream (vdict_maintain renews them)
     if (S->nnz) PA_HIP(hipMemcpyAsync(S->d_val, nzval + S->nnz0, sizeof(double) * S->nnz, hipMemcpyHostToDevice, A->ctx->s[0]));
   }
   PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
@@ -1282,6 +1330,7 @@ extern "C" int pa_csr_update_values_from(pa_csr *A, const pa_vec *src, int64_t o
   if (A->t_nnz == 0) return PA_OK;
   PA_HIP(hipSetDevice(A->ctx->device));
   for (pa_csr *S = A; S; S = S->next) {
+    if (S->use_vdict || S->vdict_stale) { S->vdict_stale = true; S->vdict_products = 0; }
     S->use_vdict = false;
     if (S->nnz)
       PA_HIP(hipMemcpyAsync(S->d_val, src->d + offset + S->nnz0, sizeof(double) * S->nnz, hipMemcpyDeviceToDevice, A->ctx->s[0]));
@@ -1759,6 +1808,7 @@ static int spmv_on(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int ys
   PA_REQUIRE(x->d != y->d || xseg != yseg, "x and y alias");
   pa_ctx *c = A->ctx;
   PA_HIP(hipSetDevice(c->device));
+  vdict_maintain(A);
   const double *xs_all = x->d + xoff;
   if (A->alpha_inside && alpha != 1.0) {
     // A block made from CSC storage: SparseArrays.mul!(y,A::SparseMatrixCSC,x,alpha,beta) forms axj = x[col]*alpha once per column

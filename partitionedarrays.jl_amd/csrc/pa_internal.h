@@ -130,6 +130,9 @@ struct pa_csr {
   int32_t *d_pdesc = nullptr;      // n_chunks * PA_PDESC_INTS descriptor ints; first of a chunk = #segments or 0
   int32_t *d_pdelta = nullptr;     // 32 deltas per pattern
   bool use_vdict = false;          // value dictionary present and current (dropped when the values are updated)
+  bool vdict_stale = false;        // the values changed under the codes: fp64 stream until vdict_maintain renews them
+  bool vdict_dead = false;         // updated values overflowed the dictionary: fp64 stream for good
+  int vdict_products = 0;          // products served since the values changed
   int n_dict = 0;
   uint8_t *d_code = nullptr;       // one byte per stored entry (padded)
   double *d_dict = nullptr;        // PA_VDICT_MAX values
