@@ -562,6 +562,45 @@ def extra_configs(pa, ctx, L, out):
         del br, Hc
     except ImportError:
         pass
+    # the same mesh as the mesher left it -- numbered at random, NO external RCM: the library renumbers:
+    # pa_csr_locality_order (reverse Cuthill-McKee by level sets, on the device) + pa_csr_create_permuted, hidden in local_to_device
+    PHASE[0] = "extra: randomly numbered FEM mesh, library-side renumbering"
+    try:
+        nxm, nym = 1000, 800
+        nn = nxm * nym
+        I, J, V, rows, cols = pa.laplacian_fem((nxm, nym), (1, 1), ranks1)
+        perm = np.random.default_rng(29).permutation(nn) + 1
+        Ip, Jp, Vp = perm[I.items[0] - 1], perm[J.items[0] - 1], V.items[0]
+        del I, J, V
+        rows1 = pa.uniform_partition(ranks1, (1,), (nn,))
+        Ar = pa.psparse_from_coo(pa.DebugArray([Ip]), pa.DebugArray([Jp]), pa.DebugArray([Vp]), rows1)
+        b_raw = pa.local_items(Ar.matrix_partition)[0].own_own
+        ms_raw = time_block(pa, ctx, L, b_raw, nn, nn)
+        ctx.sync()
+        t = time.perf_counter()
+        Ar2 = pa.renumber_for_locality(Ar)
+        ctx.sync()
+        t_ren = time.perf_counter() - t
+        b_ren = pa.local_items(Ar2.matrix_partition)[0].own_own
+        xr = pa.pvector_from_function(lambda ind: hash_x(ind.get_local_to_global()), Ar.col_partition)
+        xr2 = pa.pvector_from_function(lambda ind: hash_x(ind.get_local_to_global()), Ar2.col_partition)
+        yr, yr2 = pa.pzeros(Ar.row_partition), pa.pzeros(Ar2.row_partition)
+        pa.mul_(yr, Ar, xr)
+        pa.mul_(yr2, Ar2, xr2)
+        same = bool(np.array_equal(pa.local_items(yr.own_values())[0], pa.local_items(yr2.own_values())[0]))
+        e = entry(f"Q1 FEM Laplacian on a {nxm} x {nym} mesh numbered at RANDOM, no external RCM: renumber_for_locality (device-side reverse "
+                  "Cuthill-McKee, rows keep their entry order, hidden in local_to_device), pa_spmv", b_ren, nn, nn,
+                  time_block(pa, ctx, L, b_ren, nn, nn), t_ren)
+        e["x_window_launch"] = b_ren.xwin()
+        e["band_before_after"] = [int(v) for v in pa.local_items(Ar2.bandwidths)[0]]
+        e["ms_as_numbered_by_the_mesher"] = round(ms_raw, 4)
+        e["algorithmic_gbps_as_numbered_by_the_mesher"] = round((b_raw.nnz * 12 + nn * 20) / ms_raw / 1e6, 1)
+        e["renumbering_s"] = round(t_ren, 2)
+        e["same_bits_as_the_unrenumbered_product"] = same
+        out.append(e)
+        del Ar, Ar2, xr, xr2, yr, yr2, b_raw, b_ren
+    except Exception as ex:                                     # noqa: BLE001
+        print(f"[bench] renumbering entry skipped: {ex}", file=sys.stderr)
     # BASELINE config 5 as a whole: Q1 FEM Laplacian, 8 parts as (4,2) resident on this ONE GPU, the disassembled psparse
     # route, full mul! = pack / device-to-device exchange / own x own / unpack / own x ghost of all 8 parts in one call
     PHASE[0] = "extra: config 5 on 8 parts"

@@ -268,6 +268,20 @@ int pa_host_hpcg_split_csr64(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, in
                              double *oh_nzval, double *b);
 
 
+/* ---- library-side renumbering for blocks without locality (csrc/pa_transpose.hip; round 4) ----------------------------------
+ * pa_csr_locality_order: a reverse Cuthill-McKee order of a square block (own x own), computed on the device by level sets:
+ * new_pos[i] (host, n_rows entries) = the position row / column i should take; band_before / band_after = max |row - col| in the
+ * two numberings.  pa_csr_create_permuted: the same block with row i stored at row_pos[i] and column j renamed col_pos[j] (either
+ * may be NULL); every row keeps its entries in their ORIGINAL order, so its sum adds the same products in the same order --
+ * y_new[row_pos[i]] == y[i] bit for bit when x_new[col_pos[j]] = x[j].  The host mirror hides the order in the index partition's
+ * local_to_device map (vectors, exchange plans): `renumber_for_locality(A)` of partitionedarrays.jl_amd/p_sparse_matrix.py. */
+int pa_csr_locality_order(const pa_csr *A, int32_t *new_pos, int64_t *band_before, int64_t *band_after);
+int pa_csr_create_permuted(const pa_csr *A, const int32_t *row_pos, const int32_t *col_pos, pa_csr **out);
+/* pa_csr_create_transpose (pa_hip.h) for a block whose rows were renumbered: inside a row of A' the entries stand in ascending
+ * row_rank[row] (host, n_rows entries: the ORIGINAL row of every stored row), the order the reference's transposed loop has on the
+ * caller's numbering; NULL = ascending row, pa_csr_create_transpose itself. */
+int pa_csr_create_transpose_ranked(const pa_csr *A, const int32_t *row_rank, pa_csr **out);
+
 /* ---- introspection of a CSR block (what the row-split kernel reads; none of it is needed to use the block) ---------- */
 /* How the row-split chunks of A get their column indices (library-internal index compression; the values, the
  * results and pa_csr_update_values are unaffected): recomputed from row patterns / 16-bit windowed stream / 32-bit. */

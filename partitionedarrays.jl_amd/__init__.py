@@ -19,7 +19,7 @@ from .p_vector import (Context, Event, Graph, context, init_comm, DeviceVector, 
 from .p_sparse_matrix import (HostCSR, DeviceCSR, DeviceSELL, SplitMatrixBlocks, PSparseMatrix, compresscoo, sparse_matrix,  # noqa: F401
                               split_format_locally, spmv_, psparse, psparse_from_coo, mul_, mul_c_, mul_no_lat_c_, mul5_, mul_no_overlap_,
                               psparse_disassembled, psparse_assemble_host, psparse_, MatrixReassemblyCache,
-                              mul5_transpose_, transposed_blocks, psystem, psystem_, tune_output_placement)
+                              mul5_transpose_, transposed_blocks, renumber_for_locality, psystem, psystem_, tune_output_placement)
 from .gallery import laplacian_fem, laplacian_fdm, build_matrix, build_p_matrix, build_split_blocks_fused, compute_optimal_shape_XYZ  # noqa: F401
 from .hpcg import (CgTimer, ref_cg_, opt_cg_, hpcg_benchmark, cg_work, mul_no_lat_, mul_no_lat_unsplit_, restrict_operator, GaussSeidel, ColoredGaussSeidelSpMV, MgPreconditioner, pc_setup, pc_solve_,  # noqa: F401
                    ldiv_)

@@ -157,6 +157,9 @@ _SIGS = {
     "pa_mul5_transpose": [P, P, P, P, f64, f64],
     "pa_mul5_transpose_all": [P, i32, P, P, f64, f64],
     "pa_csr_download_entries": [P, P, P],
+    "pa_csr_locality_order": [P, P, C.POINTER(i64), C.POINTER(i64)],
+    "pa_csr_create_permuted": [P, P, P, PP],
+    "pa_csr_create_transpose_ranked": [P, P, PP],
     "pa_sell_create": [P, i64, i64, i64, P, P, cint, cint, P, cint, PP],
     "pa_sell_destroy": [P],
     "pa_sell_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],

@@ -123,7 +123,21 @@ extern "C" int pa_csr_download_entries(const pa_csr *A, int32_t *rows, int32_t *
   return PA_OK;
 }
 
-extern "C" int pa_csr_create_transpose(const pa_csr *A, pa_csr **out) {
+extern "C" int pa_csr_create_transpose(const pa_csr *A, pa_csr **out) { return pa_csr_create_transpose_ranked(A, nullptr, out); }
+
+__global__ void kt_rank_keys(const int *__restrict__ row, const int *__restrict__ rank, int n, int *__restrict__ key) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) key[k] = rank[row[k]];
+}
+__global__ void kt_gather_keys(const int *__restrict__ perm, const int *__restrict__ col, int n, int *__restrict__ key) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) key[k] = col[perm[k]];
+}
+
+// row_rank (host, n_rows entries, a permutation; or NULL): inside a row of A' the entries are ordered by ascending row_rank[row of A]
+// instead of ascending row -- for a block whose rows were renumbered (pa_csr_create_permuted) row_rank = the ORIGINAL row of every
+// stored row, and A' adds in the order the reference's scatter loop has on the caller's numbering.
+extern "C" int pa_csr_create_transpose_ranked(const pa_csr *A, const int32_t *row_rank, pa_csr **out) {
   PA_REQUIRE(A && out, "bad arguments");
   PA_REQUIRE(!A->next, "a block of 2^31 stored entries or more (a chain of slabs) has no device-side transpose");
   pa_ctx *c = A->ctx;
@@ -152,6 +166,21 @@ extern "C" int pa_csr_create_transpose(const pa_csr *A, pa_csr **out) {
   // (only the bits a column index can have: fewer radix passes)
   unsigned bits = 1;
   while (bits < 32 && ((int64_t)1 << bits) < n_rows_t) ++bits;
+  if (row_rank) {
+    // two stable sorts: by the rows' rank first, by column second -- equal columns then stand in ascending rank
+    unsigned rbits = 1;
+    while (rbits < 32 && ((int64_t)1 << rbits) < n_cols_t) ++rbits;
+    int32_t *d_rank = nullptr, *d_k1 = nullptr, *d_p1 = nullptr;
+    PA_TRY(sc.get(&d_rank, (size_t)n_cols_t + 1));
+    PA_TRY(sc.get(&d_k1, (size_t)nnz));
+    PA_TRY(sc.get(&d_p1, (size_t)nnz));
+    PA_HIP(hipMemcpyAsync(d_rank, row_rank, sizeof(int32_t) * n_cols_t, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(kt_rank_keys, grid1(nnz), dim3(256), 0, s, d_row, d_rank, (int)nnz, d_k1);
+    PA_TRY(sort_pairs(sc, s, d_k1, d_keys, d_iota, d_p1, (size_t)nnz, rbits));
+    hipLaunchKernelGGL(kt_gather_keys, grid1(nnz), dim3(256), 0, s, d_p1, d_col, (int)nnz, d_k1);
+    PA_TRY(sort_pairs(sc, s, d_k1, d_keys, d_p1, d_perm, (size_t)nnz, bits));
+    sc.release(d_rank); sc.release(d_k1); sc.release(d_p1);
+  } else
   PA_TRY(sort_pairs(sc, s, d_col, d_keys, d_iota, d_perm, (size_t)nnz, bits));
   sc.release(d_col);
   sc.release(d_iota);
@@ -210,6 +239,219 @@ int pa_csr_create_remapped(const pa_csr *A, const int32_t *map, int64_t n_cols_n
   PA_HIP(hipGetLastError());
   PA_REQUIRE(bad == 0, "%d stored entries sit in columns the map does not carry", bad);
   return pa_csr_from_device(c, n_rows, n_cols_new, nnz, d_rp, d_col, d_val, out);
+}
+
+// ---- the same block with its rows and / or columns renumbered (round 4: library-side renumbering for blocks without locality) ----
+// row_pos[i] = new position of row i (a permutation of 0..n_rows-1, host, or NULL = rows stay), col_pos[j] = new name of column j
+// (host, or NULL).  Every row keeps its stored entries IN THEIR ORIGINAL ORDER -- the sort by new row is stable -- so a row's sum
+// adds the same products in the same order: y_new[row_pos[i]] has the bits y[i] had when x_new[col_pos[j]] = x[j].
+__global__ void kt_rename(int *__restrict__ row, int *__restrict__ col, int n, const int *__restrict__ row_pos, const int *__restrict__ col_pos) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  if (row_pos) row[k] = row_pos[row[k]];
+  if (col_pos) col[k] = col_pos[col[k]];
+}
+__global__ void kt_gather2(const int *__restrict__ perm, const int *__restrict__ col, const double *__restrict__ val, int n,
+                           int *__restrict__ out_col, double *__restrict__ out_val) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int p = perm[k];
+  out_col[k] = col[p];
+  out_val[k] = val[p];
+}
+
+extern "C" int pa_csr_create_permuted(const pa_csr *A, const int32_t *row_pos, const int32_t *col_pos, pa_csr **out) {
+  PA_REQUIRE(A && out, "bad arguments");
+  PA_REQUIRE(!A->next, "a chain of slabs has no renumbered twin");
+  pa_ctx *c = A->ctx;
+  PA_REQUIRE(!c->capturing, "not inside a graph capture");
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  const int64_t nnz = A->nnz, n_rows = A->n_rows, n_cols = A->n_cols;
+  if (row_pos) {                                               // a permutation, or rows would collide
+    std::vector<char> seen((size_t)n_rows, 0);
+    for (int64_t i = 0; i < n_rows; ++i) {
+      PA_REQUIRE(row_pos[i] >= 0 && row_pos[i] < n_rows && !seen[row_pos[i]], "row_pos is not a permutation (row %lld)", (long long)i);
+      seen[row_pos[i]] = 1;
+    }
+  }
+  if (col_pos) for (int64_t j = 0; j < n_cols; ++j) PA_REQUIRE(col_pos[j] >= 0 && col_pos[j] < n_cols, "col_pos[%lld] out of range", (long long)j);
+  scratch sc;
+  int32_t *d_rp = nullptr, *d_row = nullptr, *d_col = nullptr, *d_rpos = nullptr, *d_cpos = nullptr;
+  PA_TRY(sc.get(&d_rp, (size_t)n_rows + 1));
+  PA_TRY(sc.get(&d_row, (size_t)nnz + 1));
+  PA_TRY(sc.get(&d_col, (size_t)nnz + 1));
+  if (row_pos) { PA_TRY(sc.get(&d_rpos, (size_t)n_rows + 1)); PA_HIP(hipMemcpyAsync(d_rpos, row_pos, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s)); }
+  if (col_pos) { PA_TRY(sc.get(&d_cpos, (size_t)n_cols + 1)); PA_HIP(hipMemcpyAsync(d_cpos, col_pos, sizeof(int32_t) * n_cols, hipMemcpyHostToDevice, s)); }
+  const int32_t *d_fcol = d_col;
+  const double *d_fval = A->d_val;
+  int32_t *d_keys = nullptr, *d_iota = nullptr, *d_perm = nullptr, *d_tcol = nullptr;
+  double *d_tval = nullptr;
+  if (nnz) {
+    PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
+    hipLaunchKernelGGL(kt_rename, grid1(nnz), dim3(256), 0, s, d_row, d_col, (int)nnz, d_rpos, d_cpos);
+    if (row_pos) {
+      PA_TRY(sc.get(&d_keys, (size_t)nnz));
+      PA_TRY(sc.get(&d_iota, (size_t)nnz));
+      PA_TRY(sc.get(&d_perm, (size_t)nnz));
+      hipLaunchKernelGGL(kt_iota, grid1(nnz), dim3(256), 0, s, d_iota, (int)nnz);
+      unsigned bits = 1;
+      while (bits < 32 && ((int64_t)1 << bits) < n_rows) ++bits;
+      PA_TRY(sort_pairs(sc, s, d_row, d_keys, d_iota, d_perm, (size_t)nnz, bits));
+      PA_TRY(sc.get(&d_tcol, (size_t)nnz));
+      PA_TRY(sc.get(&d_tval, (size_t)nnz));
+      hipLaunchKernelGGL(kt_gather2, grid1(nnz), dim3(256), 0, s, d_perm, d_col, A->d_val, (int)nnz, d_tcol, d_tval);
+      d_fcol = d_tcol; d_fval = d_tval;
+    }
+  }
+  hipLaunchKernelGGL(kt_lower_bounds, grid1(n_rows + 1), dim3(256), 0, s, row_pos && nnz ? d_keys : d_row, (int)nnz, (int)n_rows, d_rp);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(s));
+  return pa_csr_from_device(c, n_rows, n_cols, nnz, d_rp, d_fcol, d_fval, out);
+}
+
+// ---- a bandwidth-reducing order of a square block, computed on the device: reverse Cuthill-McKee by level sets -------------------
+// A block whose rows gather x from all over (an unstructured mesh numbered as the mesher left it) gets 64 bytes of HBM traffic per
+// gathered entry; in a Cuthill-McKee order the rows of a chunk share their columns with the chunks around them and the x windows of
+// pa_spmv_xwin.h apply.  Breadth-first from a pseudo-peripheral vertex (the last vertex of a first sweep from vertex 0); a level's
+// vertices are ordered by the position of their first-numbered neighbour in the level before, ties by vertex id (deterministic);
+// every level is two frontier kernels, a count read-back and a radix sort of the level.  Unreached vertices (another component)
+// start a new sweep at the lowest unnumbered id.  new_pos[v] = n - 1 - (Cuthill-McKee position of v).
+__global__ void kr_claim(const int *__restrict__ rp, const int *__restrict__ col, const int *__restrict__ frontier, int f, int base,
+                         const int *__restrict__ pos, int *__restrict__ key) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= f) return;
+  const int u = frontier[i];
+  for (int p = rp[u]; p < rp[u + 1]; ++p) {
+    const int v = col[p];
+    if (pos[v] < 0) atomicMin(&key[v], base + i);
+  }
+}
+__global__ void kr_collect(const int *__restrict__ rp, const int *__restrict__ col, const int *__restrict__ frontier, int f, int base,
+                           const int *__restrict__ pos, const int *__restrict__ key, int *__restrict__ count,
+                           unsigned long long *__restrict__ ckey, int *__restrict__ cand) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= f) return;
+  const int u = frontier[i];
+  for (int p = rp[u]; p < rp[u + 1]; ++p) {
+    const int v = col[p];
+    if (v != u && pos[v] < 0 && key[v] == base + i) {           // (v's first-numbered neighbour is u: exactly one claim per vertex --
+      bool first = true;                                        //  unless the row holds v twice, which CSR rows here do not)
+      for (int q = rp[u]; q < p && first; ++q) first = col[q] != v;
+      if (!first) continue;
+      const int k = atomicAdd(count, 1);
+      cand[k] = v;
+      ckey[k] = ((unsigned long long)(unsigned)(base + i) << 32) | (unsigned)v;
+    }
+  }
+}
+__global__ void kr_number(const int *__restrict__ cand, int n, int base, int *__restrict__ pos) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) pos[cand[k]] = base + k;
+}
+__global__ void kr_first_unnumbered(const int *__restrict__ pos, int n, int *__restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n && pos[v] < 0) atomicMin(out, v);
+}
+__global__ void kr_band(const int *__restrict__ row, const int *__restrict__ col, int n, const int *__restrict__ newpos, int *__restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const int d0 = abs(row[k] - col[k]);
+  const int d1 = abs(newpos[row[k]] - newpos[col[k]]);
+  if (d0 > out[0]) atomicMax(&out[0], d0);
+  if (d1 > out[1]) atomicMax(&out[1], d1);
+}
+__global__ void kr_reverse(const int *__restrict__ pos, int n, int *__restrict__ newpos) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n) newpos[v] = n - 1 - pos[v];
+}
+
+extern "C" int pa_csr_locality_order(const pa_csr *A, int32_t *new_pos, int64_t *band_before, int64_t *band_after) {
+  PA_REQUIRE(A && new_pos, "bad arguments");
+  PA_REQUIRE(!A->next && A->n_rows == A->n_cols, "a square single-slab block is needed");
+  pa_ctx *c = A->ctx;
+  PA_REQUIRE(!c->capturing, "not inside a graph capture");
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  const int64_t n = A->n_rows, nnz = A->nnz;
+  if (n == 0) return PA_OK;
+  scratch sc;
+  int32_t *d_rp = nullptr, *d_row = nullptr, *d_col = nullptr, *d_pos = nullptr, *d_key = nullptr, *d_fa = nullptr, *d_fb = nullptr, *d_cand = nullptr,
+          *d_small = nullptr, *d_newpos = nullptr;
+  unsigned long long *d_ckey = nullptr, *d_ckey2 = nullptr;
+  PA_TRY(sc.get(&d_rp, (size_t)n + 1));
+  PA_TRY(sc.get(&d_row, (size_t)nnz + 1));
+  PA_TRY(sc.get(&d_col, (size_t)nnz + 1));
+  PA_TRY(sc.get(&d_pos, (size_t)n));
+  PA_TRY(sc.get(&d_key, (size_t)n));
+  PA_TRY(sc.get(&d_fa, (size_t)n));
+  PA_TRY(sc.get(&d_fb, (size_t)n));
+  PA_TRY(sc.get(&d_cand, (size_t)n));
+  PA_TRY(sc.get(&d_ckey, (size_t)n));
+  PA_TRY(sc.get(&d_ckey2, (size_t)n));
+  PA_TRY(sc.get(&d_small, 4));
+  PA_TRY(sc.get(&d_newpos, (size_t)n));
+  if (nnz) PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
+  hipLaunchKernelGGL(kt_lower_bounds, grid1(n + 1), dim3(256), 0, s, d_row, (int)nnz, (int)n, d_rp);
+  size_t sort_tb = 0;
+  PA_HIP(rocprim::radix_sort_pairs((void *)nullptr, sort_tb, d_ckey, d_ckey2, d_cand, d_fb, (size_t)n, 0, 64, s));
+  char *d_sort_tmp = nullptr;
+  PA_TRY(sc.get(&d_sort_tmp, sort_tb));
+  unsigned pos_bits = 1;
+  while (pos_bits < 32 && ((int64_t)1 << pos_bits) < n) ++pos_bits;
+  int last_vertex = 0;
+  // one Cuthill-McKee sweep over the whole block starting at `seed`; leaves positions in d_pos, the last numbered vertex in last_vertex
+  auto sweep = [&](int seed) -> int {
+    PA_HIP(hipMemsetAsync(d_pos, 0xFF, sizeof(int32_t) * n, s));             // -1
+    PA_HIP(hipMemsetAsync(d_key, 0x7F, sizeof(int32_t) * n, s));             // 0x7F7F7F7F: larger than any position
+    int base = 0, f = 1;
+    int32_t *F = d_fa, *Fn = d_fb;
+    PA_HIP(hipMemcpyAsync(F, &seed, sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(kr_number, dim3(1), dim3(64), 0, s, F, 1, 0, d_pos);
+    int numbered = 1;
+    last_vertex = seed;
+    while (numbered < n) {
+      PA_HIP(hipMemsetAsync(d_small, 0, sizeof(int32_t), s));
+      hipLaunchKernelGGL(kr_claim, grid1(f), dim3(256), 0, s, d_rp, d_col, F, f, base, d_pos, d_key);
+      hipLaunchKernelGGL(kr_collect, grid1(f), dim3(256), 0, s, d_rp, d_col, F, f, base, d_pos, d_key, d_small, d_ckey, d_cand);
+      int cnt = 0;
+      PA_TRY(d2h(s, &cnt, d_small, 1));
+      if (cnt == 0) {                                           // this component is numbered: the lowest unnumbered vertex starts the next
+        int first = 0x7FFFFFFF;
+        PA_HIP(hipMemcpyAsync(d_small + 1, &first, sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(kr_first_unnumbered, grid1(n), dim3(256), 0, s, d_pos, (int)n, d_small + 1);
+        PA_TRY(d2h(s, &first, d_small + 1, 1));
+        PA_REQUIRE(first >= 0 && first < n, "Cuthill-McKee: no unnumbered vertex left although %d of %lld are numbered", numbered, (long long)n);
+        base = numbered; f = 1;
+        PA_HIP(hipMemcpyAsync(F, &first, sizeof(int), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(kr_number, dim3(1), dim3(64), 0, s, F, 1, base, d_pos);
+        numbered += 1;
+        last_vertex = first;
+        continue;
+      }
+      PA_HIP(rocprim::radix_sort_pairs((void *)d_sort_tmp, sort_tb, d_ckey, d_ckey2, d_cand, Fn, (size_t)cnt, 0, 32 + pos_bits, s));
+      base += f;
+      hipLaunchKernelGGL(kr_number, grid1(cnt), dim3(256), 0, s, Fn, cnt, base, d_pos);
+      std::swap(F, Fn);
+      f = cnt;
+      numbered += cnt;
+    }
+    PA_TRY(d2h(s, &last_vertex, F + (f - 1), 1));
+    PA_HIP(hipGetLastError());
+    return PA_OK;
+  };
+  PA_TRY(sweep(0));
+  PA_TRY(sweep(last_vertex));                                   // from a pseudo-peripheral vertex: narrower levels
+  hipLaunchKernelGGL(kr_reverse, grid1(n), dim3(256), 0, s, d_pos, (int)n, d_newpos);
+  int band[2] = {0, 0};
+  PA_HIP(hipMemcpyAsync(d_small, band, 2 * sizeof(int), hipMemcpyHostToDevice, s));
+  if (nnz) hipLaunchKernelGGL(kr_band, grid1(nnz), dim3(256), 0, s, d_row, d_col, (int)nnz, d_newpos, d_small);
+  PA_TRY(d2h(s, band, d_small, 2));
+  PA_TRY(d2h(s, new_pos, d_newpos, (size_t)n));
+  PA_HIP(hipGetLastError());
+  if (band_before) *band_before = band[0];
+  if (band_after) *band_after = band[1];
+  return PA_OK;
 }
 
 // ---- mul!(c, transpose(a), b, alpha, beta) of one part / of all parts of a process ------------------------------------------

@@ -151,13 +151,31 @@ class LocalIndices:
     def local_to_device(self):
         """0-based position of every local id in the DEVICE layout, which is always [own | ghost] (what the kernels and
         the own-value reductions need); None when the local order already is that (block partitions)."""
-        if self.own_is_contiguous_prefix:
+        perm = getattr(self, "device_own_perm", None)
+        if self.own_is_contiguous_prefix and perm is None:
             return None
         if getattr(self, "_l2d", None) is None:
-            l2d = np.empty(self.n_local, dtype=np.int64)
-            l2d[np.concatenate([self._own_to_local, self._ghost_to_local]).astype(np.int64) - 1] = np.arange(self.n_local)
+            if self.own_is_contiguous_prefix:
+                l2d = np.arange(self.n_local, dtype=np.int64)
+            else:
+                l2d = np.empty(self.n_local, dtype=np.int64)
+                l2d[np.concatenate([self._own_to_local, self._ghost_to_local]).astype(np.int64) - 1] = np.arange(self.n_local)
+            if perm is not None:
+                # a library-side renumbering of the own values (renumber_for_locality, p_sparse_matrix.py): own value k of the
+                # [own | ghost] layout lives at device position perm[k]; ghosts stay where they are
+                own = l2d < self.n_own
+                l2d[own] = np.asarray(perm, np.int64)[l2d[own]]
             self._l2d = l2d
         return self._l2d
+
+    def with_device_own_perm(self, perm):
+        """A copy of these indices (same ids, same local order, same assembly cache) whose own values are laid out in HBM in the
+        order `perm` (device position of own value k); vectors and exchange plans made from the copy follow it."""
+        import copy
+        out = copy.copy(self)
+        out.device_own_perm = np.ascontiguousarray(perm, np.int64)
+        out._l2d = None
+        return out
 
     @property
     def own_to_global(self):

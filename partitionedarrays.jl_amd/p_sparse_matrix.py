@@ -532,19 +532,63 @@ def mul5_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PVector:
     return c
 
 
+def renumber_for_locality(a: PSparseMatrix, force=False, min_gain=2.0):
+    """Library-side renumbering of a matrix whose own x own blocks have no locality (BASELINE config 5 says
+    "unstructured ... irregular"): per part a reverse Cuthill-McKee order of the own unknowns is computed ON THE DEVICE from the
+    resident block (pa_csr_locality_order), and when it narrows the band by at least `min_gain` the part's blocks are rebuilt with
+    rows and own columns in that order (pa_csr_create_permuted: every row keeps its entries in their ORIGINAL order, so row sums
+    keep their bits) and the part's row / column indices get a `local_to_device` map that hides the order: vectors made on the
+    RETURNED matrix's partitions (pzeros(A2.col_partition), pvector_from_function(f, A2.row_partition), ...) are laid out to match,
+    uploads / downloads / own_values speak the caller's local order as before, pack / unpack lists are translated when the
+    exchange plan is built.  Returns a new PSparseMatrix (the old one is untouched); parts that gain nothing keep their blocks."""
+    if not a.assembled:
+        raise L.PAError("renumber_for_locality needs an assembled matrix")
+
+    def one(blk, r, c):
+        oo, oh = blk.own_own, blk.own_ghost
+        n = r.n_own
+        if oo.m != oo.n or c.n_own != n or not np.array_equal(r.own_to_global, c.own_to_global):
+            raise L.PAError("renumber_for_locality: rows and columns must share their own indices (a square operator)")
+        newpos = np.zeros(max(n, 1), np.int32)
+        b0, b1 = C.c_int64(), C.c_int64()
+        L.call("pa_csr_locality_order", oo.h, L.ptr(newpos), C.byref(b0), C.byref(b1))
+        newpos = newpos[:n]
+        if not force and b1.value * min_gain > b0.value:
+            return blk, r, c, (b0.value, b0.value)
+        out = []
+        for B, colpos in ((oo, newpos), (oh, None)):
+            h = C.c_void_p()
+            L.call("pa_csr_create_permuted", B.h, L.ptr(newpos), None if colpos is None else L.ptr(colpos), C.byref(h))
+            out.append(DeviceCSR.from_handle(h, B.m, B.n, B.nnz, B.ctx))
+        return SplitMatrixBlocks(out[0], out[1]), r.with_device_own_perm(newpos), c.with_device_own_perm(newpos), (b0.value, b1.value)
+
+    from .primitives import tuple_of_arrays
+    blocks, rows, cols, bands = tuple_of_arrays(pmap(one, a.matrix_partition, a.row_partition, a.col_partition))
+    A2 = PSparseMatrix(blocks, rows, cols, True)
+    A2.bandwidths = bands                      # per part: (before, after) max |row - col| of own x own
+    return A2
+
+
 def transposed_blocks(a: PSparseMatrix):
     """(A_oo', A_oh') of every part, built ON THE DEVICE from the blocks resident in HBM (pa_csr_create_transpose: decoded column
     encoding, one stable sort by column; csrc/pa_transpose.hip) -- no host copy, so generated and device-assembled matrices
     have them too.  Built once, cached on `a` (psparse!-style value updates of `a` drop the cache)."""
     if getattr(a, "_t_blocks", None) is None:
-        def mk(blk):
+        def mk(blk, r):
             out = []
+            # (a renumbered part -- renumber_for_locality -- stores its rows in another order: the transposes add in the order
+            #  of the caller's rows all the same)
+            perm = getattr(r, "device_own_perm", None)
+            rank = None
+            if perm is not None:
+                rank = np.empty(len(perm), np.int32)
+                rank[np.asarray(perm, np.int64)] = np.arange(len(perm), dtype=np.int32)
             for B in (blk.own_own, blk.own_ghost):
                 h = C.c_void_p()
-                L.call("pa_csr_create_transpose", B.h, C.byref(h))
+                L.call("pa_csr_create_transpose_ranked", B.h, None if rank is None else L.ptr(rank), C.byref(h))
                 out.append(DeviceCSR.from_handle(h, B.n, B.m, B.nnz, B.ctx))
             return tuple(out)
-        a._t_blocks = pmap(mk, a.matrix_partition)
+        a._t_blocks = pmap(mk, a.matrix_partition, a.row_partition)
     return a._t_blocks
 
 
