@@ -1252,6 +1252,30 @@ def main():
                     cpu["c1_debugarray"] = c1
                 LINE[0]["cpu_baseline"] = cpu
 
+    # ---- N > 1, last of all (a hang in here costs nothing that came before): the same timed loop over the OTHER device transport,
+    # the ipc push of csrc/pa_push.hip (pack kernel storing straight into the neighbours' hipIpc-mapped receive buffers), so that the
+    # first real multi-GPU record says what each transport costs beside own x own (profiles/r04_rccl_interference.json: one GPU)
+    if N > 1 and transport in ("rccl", "host", "torch") and os.environ.get("PA_BENCH_TRANSPORT_AB", "1") != "0":
+        with optional_section("transport A/B: ipc push", 120, N, rank):
+            import pa_amd.p_vector as pv
+            os.environ.setdefault("PA_IPC_TIMEOUT_S", "5")
+            was = pv.TRANSPORT
+            pv.TRANSPORT = "ipc"
+            try:
+                pv.connect_ipc(x.cache.plans)
+                ok_ipc = gate()
+                for _ in range(30):
+                    step(overlap_on)
+                t_ipc, _, _ = timed(args.steps, overlap_on)
+            finally:
+                pv.TRANSPORT = was
+            if rank == 0:
+                LINE[0]["transport_ab"] = {"headline_transport": transport, "ms_per_step_headline": round(ms_per_step, 4),
+                                           "ms_per_step_ipc_push": round(t_ipc / args.steps * 1e3, 4), "parity_gate_over_ipc_push": bool(ok_ipc),
+                                           "gflops_ipc_push": round(flops_total / (t_ipc / args.steps) / 1e9, 2),
+                                           "what": "the timed mul! loop again with PA_TRANSPORT=ipc (csrc/pa_push.hip): same matrix, same "
+                                                   "vectors, same barriers; `value` is the headline transport's"}
+
     if rank == 0:
         out = LINE[0]
         if vdict:

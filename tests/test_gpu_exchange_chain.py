@@ -161,3 +161,53 @@ def test_mul_all_replayed_from_a_hipgraph(orc):
         yo = oracle_mul(orc, Ao, xr)
         for got, e, r in zip(y.own_values().items, yo, Ao.rows):
             assert np.array_equal(got, e[:r.n_own]), rep
+
+
+def test_pa_mul5_over_a_one_rank_rccl_communicator():
+    """The RCCL branch of the operator-level call on the one GPU there is: a part that "ghosts" three of its own values over a
+    1-rank communicator (self-addressed ncclSend / ncclRecv, as test_rccl_single_rank_loopback) -- pack, RCCL group, own x own,
+    own x ghost from the receive buffer, the unpack behind it on the comm stream -- five products in a row with changing x, plus
+    the alpha/beta form and pa_mul_no_lat: against numpy, exactly.  (Between distinct GPUs the same calls run in
+    tests/test_gpu_multiprocess.py where the box has them.)"""
+    ctx = pa.context()
+    idbuf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
+    L.call("pa_comm_unique_id", idbuf)
+    comm = C.c_void_p()
+    L.call("pa_comm_create", ctx.h, idbuf.raw, 0, 1, C.byref(comm))
+    i32 = lambda *v: np.array(v, np.int32)
+    rng = np.random.default_rng(6)
+    n, g = 6, 3
+    oo_dense = np.where(rng.random((n, n)) < 0.6, rng.integers(-4, 5, (n, n)).astype(float), 0.0)
+    oh_dense = np.where(rng.random((n, g)) < 0.7, rng.integers(-4, 5, (n, g)).astype(float), 0.0)
+    oh_dense[0, :] = [1.0, -2.0, 3.0]
+
+    def csr(D):
+        rp = (1 + np.concatenate(([0], np.cumsum((D != 0).sum(1))))).astype(np.int32)
+        cv = (np.nonzero(D)[1] + 1).astype(np.int32)
+        return pa.DeviceCSR(pa.HostCSR(D.shape[0], D.shape[1], rp, cv, D[D != 0].astype(float)))
+    oo, oh = csr(oo_dense), csr(oh_dense)
+    one, ptrs = i32(1), i32(1, 4)
+    plan = C.c_void_p()
+    L.call("pa_plan_create", ctx.h, 1, n + g, 1, L.ptr(one), L.ptr(ptrs), L.ptr(i32(7, 8, 9)), 1, L.ptr(one), L.ptr(ptrs), L.ptr(i32(2, 4, 6)), 1,
+           C.byref(plan))
+    m = C.c_void_p()
+    L.call("pa_matrix_create", ctx.h, oo.h, oh.h, plan, C.byref(m))
+    b, c = pa.DeviceVector(n, g), pa.DeviceVector(n, 0)
+    for rep in range(5):
+        xo = rng.integers(-3, 4, n).astype(float) + rep
+        b.upload(np.concatenate([xo, [99.0, 98.0, 97.0]]))            # stale ghosts: the exchange must replace them
+        L.call("pa_mul5", m, comm, c.h, b.h, 1.0, 0.0)
+        ghosts = xo[[1, 3, 5]]
+        assert c.download().tolist() == (oo_dense @ xo + oh_dense @ ghosts).tolist(), rep
+        assert b.download().tolist() == np.concatenate([xo, ghosts]).tolist(), rep
+    yes = C.c_int()
+    L.call("pa_matrix_ghost_from_buffer", m, C.byref(yes))
+    assert yes.value == 1
+    c0 = c.download()
+    L.call("pa_mul5", m, comm, c.h, b.h, 2.0, -1.0)
+    assert c.download().tolist() == (-c0 + 2.0 * (oo_dense @ xo + oh_dense @ ghosts)).tolist()
+    L.call("pa_mul_no_lat", m, comm, c.h, b.h)
+    assert c.download().tolist() == (oo_dense @ xo + oh_dense @ ghosts).tolist()
+    L.call("pa_matrix_destroy", m)
+    L.call("pa_plan_destroy", plan)
+    L.call("pa_comm_destroy", comm)

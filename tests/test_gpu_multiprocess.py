@@ -88,6 +88,8 @@ def test_bench_line_of_a_multi_rank_run_carries_every_field():
     r, d = _bench(2, {"PA_TRANSPORT": "host", "PA_BENCH_BACKEND": "gloo"})
     assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["transport"].startswith("host-staged")
+    ab = d["transport_ab"]                                  # round 4: the ipc push transport timed beside the headline's
+    assert ab["parity_gate_over_ipc_push"] is True and ab["ms_per_step_ipc_push"] > 0 and ab["headline_transport"] == "host"
     assert d["config"]["overlap"] is True and set(d["overlap"]) >= {"ms_per_step_on", "ms_per_step_off"}
     pr = d["config"]["stream_priority"]
     assert pr["comm"] == pr["greatest"] and pr["compute"] == pr["least"]
