@@ -326,11 +326,14 @@ __global__ void k_prolongate(double *__restrict__ xf, const double *__restrict__
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+static void enable_peer_access(int device);
+
 extern "C" int pa_ctx_create(int device, pa_ctx **out) {
   PA_REQUIRE(out != nullptr, "ctx out pointer is NULL");
   int n = 0;
   PA_HIP(hipGetDeviceCount(&n));
   PA_REQUIRE(device >= 0 && device < n, "device %d out of range (have %d)", device, n);
+  if (n > 1) enable_peer_access(device);
   PA_HIP(hipSetDevice(device));
   pa_ctx *c = new pa_ctx();
   c->device = device;
@@ -361,6 +364,24 @@ extern "C" int pa_ctx_create(int device, pa_ctx **out) {
   return PA_OK;
 }
 
+// Several contexts of one process on different GPUs (a DebugArray over several GPUs): the push kernels store into, and the copy
+// transport copies between, buffers of other devices -- peer access both ways, enabled once per pair, failures ignored (a pair
+// without a link keeps the staged copies of hipMemcpyPeer; the push transport then fails at its first store, loudly).
+static void enable_peer_access(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return; }
+  for (int d = 0; d < n; ++d) {
+    if (d == device) continue;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, device, d) == hipSuccess && can) {
+      if (hipSetDevice(device) == hipSuccess) (void)hipDeviceEnablePeerAccess(d, 0);
+      if (hipSetDevice(d) == hipSuccess) (void)hipDeviceEnablePeerAccess(device, 0);
+    }
+    (void)hipGetLastError();
+  }
+  (void)hipSetDevice(device);
+}
+
 extern "C" int pa_ctx_destroy(pa_ctx *c) {
   if (!c) return PA_OK;
   (void)hipSetDevice(c->device);
@@ -370,6 +391,7 @@ extern "C" int pa_ctx_destroy(pa_ctx *c) {
   (void)pa_raw_free(c->d_scalar);
   if (c->d_dotpart) pa_dev_free(c, c->d_dotpart);
   if (c->d_xalpha) pa_dev_free(c, c->d_xalpha);
+  if (c->d_vdict_scratch) (void)pa_raw_free(c->d_vdict_scratch);
   pa_arena_destroy(c);
   (void)hipEventDestroy(c->ev_compute);
   (void)hipStreamDestroy(c->s[0]);
@@ -763,8 +785,13 @@ __global__ __launch_bounds__(256) void k_vdict_collect(const double *__restrict_
     if (b == PA_VDICT_EMPTY || *(volatile int *)count > PA_VDICT_MAX) { atomicMax(count, PA_VDICT_MAX + 1); return; }
     int h = vdict_hash(b);
     for (int k = 0; k < PA_VDICT_SLOTS; ++k) {
-      const unsigned long long old = atomicCAS(&table[h], PA_VDICT_EMPTY, b);
-      if (old == PA_VDICT_EMPTY) { atomicAdd(count, 1); break; }
+      // (a plain look first: after the first few hundred lanes every pattern of a stencil operator is in the table, and four
+      //  million lanes doing an atomic on the same two words cost ~10 ms where the loads cost nothing)
+      unsigned long long old = *(volatile const unsigned long long *)&table[h];
+      if (old == PA_VDICT_EMPTY) {
+        old = atomicCAS(&table[h], PA_VDICT_EMPTY, b);
+        if (old == PA_VDICT_EMPTY) { atomicAdd(count, 1); break; }
+      }
       if (old == b) break;
       h = (h + 1) & (PA_VDICT_SLOTS - 1);
     }
@@ -798,13 +825,18 @@ static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
   if (mode < 0 && !rebuild && (A->nnz < ((int64_t)1 << 18) || A->n_xw_groups > 0)) return PA_OK;
   const size_t pad = 8;
   hipStream_t s = c->s[0];
-  unsigned long long *d_table = nullptr;
-  unsigned char *d_slot = nullptr;
-  int *d_count = nullptr;
-  PA_HIP(pa_raw_malloc(&d_table, sizeof(unsigned long long) * PA_VDICT_SLOTS));
-  PA_HIP(pa_raw_malloc(&d_slot, PA_VDICT_SLOTS));
-  PA_HIP(pa_raw_malloc(&d_count, sizeof(int)));
-  auto done = [&](int st) { (void)pa_raw_free(d_table); (void)pa_raw_free(d_slot); (void)pa_raw_free(d_count); return st; };
+  // (scratch of the context, made once: a multigrid set-up builds dozens of blocks, and three hipMallocs per block showed)
+  if (!c->d_vdict_scratch) PA_HIP(pa_raw_malloc(&c->d_vdict_scratch, sizeof(unsigned long long) * PA_VDICT_SLOTS + PA_VDICT_SLOTS + 64));
+  unsigned long long *d_table = (unsigned long long *)c->d_vdict_scratch;
+  unsigned char *d_slot = (unsigned char *)(d_table + PA_VDICT_SLOTS);
+  int *d_count = (int *)(d_slot + PA_VDICT_SLOTS);
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto done = [&](int st) {
+    if (getenv("PA_SETUP_TIMING"))
+      fprintf(stderr, "[pa setup] value dictionary of %lld entries: %s, %.3f ms\n", (long long)A->nnz, A->use_vdict ? "built" : "none",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    return st;
+  };
   std::vector<unsigned long long> table(PA_VDICT_SLOTS, PA_VDICT_EMPTY);
   if (hipMemcpyAsync(d_table, table.data(), sizeof(unsigned long long) * PA_VDICT_SLOTS, hipMemcpyHostToDevice, s) != hipSuccess ||
       hipMemsetAsync(d_count, 0, sizeof(int), s) != hipSuccess) { pa_set_err("value dictionary: upload failed"); return done(PA_ERR_HIP); }
@@ -2802,8 +2834,14 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
     // product of this call reads any more: it follows the push launch on the comm stream at once, beside own x own of the first
     // part, and the compute streams join it at the very end (wait(t)) -- nothing of consistent! is left on the critical path.
     PA_TRY(pa_exchange_finish_all_insert(plans.data(), n_parts, b, 2));
-    int last = -1;
-    for (int r = 0; r < n_parts; ++r) if ((plans[r]->snd.n || plans[r]->rcv.n) && m[r]->oh_rb) last = r;
+    // (per device context: with the parts on several GPUs -- one context each -- every GPU keeps ITS last own x ghost at home)
+    std::vector<char> is_last(n_parts, 0);
+    for (int r = n_parts - 1; r >= 0; --r) {
+      if (!((plans[r]->snd.n || plans[r]->rcv.n) && m[r]->oh_rb)) continue;
+      bool later = false;
+      for (int q = r + 1; q < n_parts && !later; ++q) later = is_last[q] && m[q]->ctx == m[r]->ctx;
+      if (!later) is_last[r] = 1;
+    }
     std::vector<pa_ctx *> forked;
     for (int r = 0; r < n_parts; ++r) {
       pa_plan *p = plans[r];
@@ -2812,7 +2850,7 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
       if (!(p->snd.n || p->rcv.n) || !m[r]->oh_rb) continue;
       pa_vec buf;
       buf.ctx = cx; buf.d = p->snd.d_buf; buf.n_own = p->snd.n; buf.n_ghost = 0; buf.owned = false;
-      if (r == last) {
+      if (is_last[r]) {
         PA_TRY(exchange_wait_arrived(p));
         PA_TRY(pa_spmv(m[r]->oh_rb, &buf, PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, 1.0));
         continue;
@@ -2826,7 +2864,7 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
     }
     for (pa_ctx *cx : forked) {                                    // join: the products queued on the comm streams
       int newest = -1;
-      for (int r = 0; r < n_parts; ++r) if (m[r]->ctx == cx && r != last && plans[r]->ev_wait == plans[r]->ev_arrived && m[r]->oh_rb) newest = r;
+      for (int r = 0; r < n_parts; ++r) if (m[r]->ctx == cx && !is_last[r] && plans[r]->ev_wait == plans[r]->ev_arrived && m[r]->oh_rb) newest = r;
       if (newest >= 0) PA_HIP(hipStreamWaitEvent(cx->s[0], plans[newest]->ev_arrived, 0));
     }
     return pa_exchange_join_all(plans.data(), n_parts);

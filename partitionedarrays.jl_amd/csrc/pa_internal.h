@@ -51,6 +51,7 @@ struct pa_ctx {
   double *d_scalar = nullptr;
   double *d_dotpart = nullptr;            // per-chunk partial sums of a fused product + dot (pa_mul_dot)
   int64_t n_dotpart = 0;
+  void *d_vdict_scratch = nullptr;        // hash table, slot codes and counter of the value-dictionary build (vdict_build)
   double *d_xalpha = nullptr;             // x .* alpha of a product on a CSC-made block (pa_spmv), grown on demand
   int64_t n_xalpha = 0;
   bool capturing = false;                 // a pa_graph_begin is open on the compute stream

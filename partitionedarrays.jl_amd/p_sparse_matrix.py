@@ -498,6 +498,8 @@ def mul_dot_(c: PVector, a: PSparseMatrix, b: PVector, slot: int) -> bool:
     if not a.assembled or not (isinstance(vp, DebugArray) or (isinstance(vp, TorchDistArray) and (
             vp.size == 1 or (pv.TRANSPORT == "rccl" and context().comm is not None)))):
         return False                     # (the ipc transport has no device-side all-reduce for the slot: host dots)
+    if isinstance(vp, DebugArray) and len({id(v.ctx) for v in vp.items}) > 1:
+        return False                     # (one context per part: the slot of pa_mul_all_dot lives in ONE context)
     from .primitives import local_items
     if any(bv.n_own != cv.n_own for bv, cv in zip(local_items(vp), local_items(c.vector_partition))):
         return False

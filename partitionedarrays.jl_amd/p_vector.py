@@ -40,6 +40,10 @@ class Context:
 
     def sync(self):
         L.call("pa_ctx_sync", self.h)
+        if _PART_CTX:                       # (one context per part: "the device is idle" means all of them)
+            for c in all_contexts():
+                if c is not self:
+                    L.call("pa_ctx_sync", c.h)
 
     def info(self):
         cus, xcds, hbm = C.c_int(), C.c_int(), C.c_size_t()
@@ -151,6 +155,8 @@ class Graph:
         self.h = None
 
     def __enter__(self):
+        if len(all_contexts()) > 1:
+            raise L.PAError("hipGraph capture records ONE context's streams: not with one device context per part (PA_CTX_PER_PART)")
         L.call("pa_graph_begin", self.ctx.h)
         return self
 
@@ -195,13 +201,41 @@ class Event:
 
 
 _CTX = None
+_PART_CTX = {}             # PA_CTX_PER_PART=1: part index -> its own Context
+
+
+def contexts_per_part() -> bool:
+    """PA_CTX_PER_PART=1: every part of a DebugArray gets a device context of its own (compute + comm stream, arena), on GPU
+    (part index mod visible GPUs) -- the single-process multi-GPU mode (DebugArray over several GPUs, src/debug_array.jl:110-117
+    with the parts' data on different devices).  With one GPU the contexts share it: the same code paths (one push launch per
+    context, cross-context events), which is how they are tested on a 1-GPU box."""
+    return os.environ.get("PA_CTX_PER_PART", "0") == "1"
 
 
 def context() -> Context:
+    """The device context of the part a pmap is visiting (PA_CTX_PER_PART=1), else the process's one context."""
     global _CTX
+    if contexts_per_part():
+        from .primitives import CURRENT_PART
+        i = CURRENT_PART[0]
+        if i is not None:
+            if i not in _PART_CTX:
+                n = C.c_int(0)
+                L.call("pa_device_count", C.byref(n))
+                _PART_CTX[i] = Context(device=i % max(n.value, 1)) if i > 0 or _CTX is None else _CTX
+                if i == 0 and _CTX is None:
+                    _CTX = _PART_CTX[0]
+            return _PART_CTX[i]
     if _CTX is None:
-        _CTX = Context()
+        _CTX = Context(device=0 if contexts_per_part() else None)
+        if contexts_per_part():
+            _PART_CTX.setdefault(0, _CTX)
     return _CTX
+
+
+def all_contexts():
+    out = [] if _CTX is None else [_CTX]
+    return out + [c for c in _PART_CTX.values() if c is not _CTX]
 
 
 class RcclComm:
@@ -750,7 +784,7 @@ def slots_supported(a: PVector) -> bool:
     process (DebugArray), or one part per process with an RCCL communicator (or a single process)."""
     vp = a.vector_partition
     if isinstance(vp, DebugArray):
-        return True
+        return len({id(v.ctx) for v in vp.items}) == 1          # (one context per part: its scalars live apart -> host sums)
     if isinstance(vp, TorchDistArray):
         import torch.distributed as dist
         return dist.get_world_size(vp.group) == 1 or (TRANSPORT == "rccl" and context().comm is not None)

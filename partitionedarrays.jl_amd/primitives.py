@@ -107,6 +107,9 @@ def linear_indices(a):
     return TorchDistArray(a.rank + 1, a.group)
 
 
+CURRENT_PART = [None]      # index of the part a pmap over a DebugArray is visiting (None outside)
+
+
 def pmap(f, *arrays):
     """`map(f, a, b, ...)` over parts (src/debug_array.jl:110-117, src/mpi_array.jl:221-279)."""
     a0 = arrays[0]
@@ -114,7 +117,17 @@ def pmap(f, *arrays):
         n = len(a0)
         for a in arrays:
             assert isinstance(a, DebugArray) and len(a) == n
-        return DebugArray([f(*[a.items[i] for a in arrays]) for i in range(n)])
+        out = []
+        outer = CURRENT_PART[0]
+        try:
+            for i in range(n):
+                # (which part's turn it is: with one device context per part -- PA_CTX_PER_PART, p_vector.context() -- everything a
+                #  part creates inside the map lands in ITS context, on its GPU; a nested map over other data keeps the outer part)
+                CURRENT_PART[0] = i if outer is None or n > 1 else outer
+                out.append(f(*[a.items[i] for a in arrays]))
+        finally:
+            CURRENT_PART[0] = outer
+        return DebugArray(out)
     for a in arrays:
         assert isinstance(a, TorchDistArray)
     return TorchDistArray(f(*[a.item for a in arrays]), a0.group)

@@ -211,3 +211,21 @@ def test_pa_mul5_over_a_one_rank_rccl_communicator():
     L.call("pa_matrix_destroy", m)
     L.call("pa_plan_destroy", plan)
     L.call("pa_comm_destroy", comm)
+
+
+def test_one_device_context_per_part():
+    """PA_CTX_PER_PART=1: every part of a DebugArray in a device context of its own (own streams, own arena; GPU = part index
+    mod visible GPUs) -- the single-process multi-GPU mode of SURVEY 8(b) (`DebugArray` over several GPUs).  On a 1-GPU box the
+    contexts share the device and the same paths run: one push launch per context, events across contexts, per-context joins.
+    The exchange-chain, transpose and renumbering modules and a slice of the parity module, in a child process under the switch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PA_CTX_PER_PART="1")
+    cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_exchange_chain.py", "tests/test_gpu_transpose.py",
+           "tests/test_gpu_renumber.py", "tests/test_gpu_parity.py", "-k",
+           "not one_device_context and not hipgraph and (exchange or push or buffer or transpose or renumber or hand_partition or doc_examples or "
+           "mul_hpcg or 27_parts or sub_assembled or periodic or reassembly)"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:] + r.stderr[-2000:])
