@@ -17,7 +17,7 @@
 //     own | ghost split by column, row pointers by binary search in the sorted rows
 // The blocks go straight into pa_csr objects (row split on the host from the row pointers, column encodings on the device,
 // pa_setup.hip); the host gets the ghost gids (a few thousand) and, when it asks, copies of the CSR arrays.
-// Bit-identical to the host route: tests/test_gpu_parity.py::test_device_side_psparse_equals_the_host_route.
+// Bit-identical to the host route: tests/test_gpu_setup.py::test_device_side_psparse_equals_the_host_route.
 #include "pa_dev_util.h"
 
 #include <chrono>

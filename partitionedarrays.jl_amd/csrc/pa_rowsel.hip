@@ -11,7 +11,7 @@
 //     lengths of the selected rows -> exclusive scan -> one lane per row copies its entries (own block first, then ghost)
 // handed to the same block constructor as an uploaded matrix (pa_csr_from_device: row split and column encodings on the
 // device).  Entry order inside a row = the host route's, so the blocks are the host route's, array for array
-// (tests/test_gpu_parity.py::test_device_side_row_subsets_equal_the_host_route).
+// (tests/test_gpu_setup.py::test_device_side_row_subsets_equal_the_host_route).
 #include "pa_dev_util.h"
 
 #include <chrono>

@@ -11,7 +11,7 @@
 // adding a padded 0.0 could turn a -0.0 row result into +0.0).
 // What it is for: a second, structurally different bit-exact SpMV (parity / debugging mode), and short irregular rows.
 // It streams 12 bytes per stored entry plus padding, so the row-split kernel with its row patterns (8 bytes per entry on
-// stencils) stays the product path; tests/test_gpu_parity.py compares the two bit for bit.
+// stencils) stays the product path; tests/test_gpu_spmv_kernels.py compares the two bit for bit.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

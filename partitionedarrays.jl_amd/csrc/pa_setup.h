@@ -9,7 +9,7 @@
 
 // The column streams of one block exactly as k_spmv_rowsplit reads them, built ON THE DEVICE from the block's raw CSR
 // arrays (0-based Int32 row pointers and columns already in HBM): the device twin of pa_encode_columns
-// (pa_spmv_kernel.h), array for array and byte for byte (tests/test_gpu_parity.py::test_device_side_encoding_equals_the_host_s).
+// (pa_spmv_kernel.h), array for array and byte for byte (tests/test_gpu_setup.py::test_device_side_encoding_equals_the_host_s).
 struct pa_dev_streams {
   bool use_pattern = false, use_c16 = false, full = true;
   int32_t *d_pdesc = nullptr;    // n_chunks * PA_PDESC_INTS (only when use_pattern)

@@ -107,7 +107,7 @@ def build_split_blocks_device(my_rows, nx, ny, nz, gnx, gny, gnz):
     """One part of build_p_matrix with the own|own block and b generated in HBM (csrc/pa_rowsel.hip,
     pa_hpcg_own_block_create) and only the surface -- ghost ids in first-seen order, the own|ghost block -- made by the host:
     returns (col LocalIndices, SplitMatrixBlocks, DeviceVector b).  Same arrays as build_split_blocks_fused + upload
-    (tests/test_gpu_parity.py::test_hpcg_blocks_generated_on_the_device_equal_the_host_s)."""
+    (tests/test_gpu_setup.py::test_hpcg_blocks_generated_on_the_device_equal_the_host_s)."""
     from .p_range import LocalIndices, find_owner
     from .p_sparse_matrix import HostCSR, DeviceCSR, SplitMatrixBlocks
     from .p_vector import DeviceVector, context

@@ -3,7 +3,7 @@
 # STATUS: shipped as source, NOT executed in this repo's CI -- there is no Julia toolchain in the build image
 # (see DESIGN.md "Host language").  It is deliberately thin and mechanical: every method below is a `ccall`
 # of one entry point of include/pa_hip.h, and the same entry points are exercised, in the same order, by the
-# Python host mirror and its tests (tests/test_gpu_parity.py).
+# Python host mirror and its tests (tests/test_gpu_*.py).
 #
 # What it plugs into (reference file:line, PartitionedArrays.jl v0.5.7):
 #   local vector type  V of PVector{V}        src/p_vector.jl:8-26 (allocate_local_values, own_values, ghost_values)

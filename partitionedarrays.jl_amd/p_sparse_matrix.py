@@ -716,7 +716,7 @@ def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False):
     everything per triplet on the device.  Per part: the sub-assembled local matrix by one sort (ghost rows and ghost columns in
     first-seen order); its ghost rows -- the part's surface -- come to the host and travel to their owners exactly as
     psparse_assemble_host sends them; the own rows, still in HBM, and what arrived go through the assembled route.  Same
-    blocks, same ghost order as the host route, bit for bit (tests/test_gpu_parity.py)."""
+    blocks, same ghost order as the host route, bit for bit (tests/test_gpu_setup.py)."""
     from .primitives import exchange, ExchangeGraph, DebugArray, tuple_of_arrays
     from .p_range import assembly_neighbors, LocalIndices
 

@@ -1,4 +1,4 @@
-"""Helpers shared by the -m gpu test modules (one module per row family of SURVEY 8; tests/test_gpu_parity.py holds the older ones)."""
+"""Helpers shared by the -m gpu test modules (one module per row family of SURVEY 8; tests/gpu_helpers.py serves the modules split off the former test_gpu_parity.py)."""
 import numpy as np
 
 from __graft_entry__ import load_package

@@ -224,7 +224,7 @@ def test_one_device_context_per_part():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PA_CTX_PER_PART="1")
     cmd = [sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "tests/test_gpu_exchange_chain.py", "tests/test_gpu_transpose.py",
-           "tests/test_gpu_renumber.py", "tests/test_gpu_parity.py", "-k",
+           "tests/test_gpu_renumber.py", "tests/test_gpu_exchange.py", "tests/test_gpu_mul.py", "tests/test_gpu_setup.py", "-k",
            "not one_device_context and not hipgraph and (exchange or push or buffer or transpose or renumber or hand_partition or doc_examples or "
            "mul_hpcg or 27_parts or sub_assembled or periodic or reassembly)"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1500)

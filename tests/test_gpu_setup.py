@@ -1,0 +1,444 @@
+"""psparse / split / value re-assembly / block generation on the device against the host routes.
+Bars: np.array_equal for everything but dot / norm (1e-13).  Needs a real MI355X (-m gpu)."""
+import pytest
+
+from gpu_helpers import *  # noqa: F401,F403
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_memory_is_returned():
+    """Handles own their HBM: building and dropping matrices, vectors, plans, smoothers and graphs repeatedly leaves
+    the device's free memory where it was (hipMemGetInfo through torch, which is only the messenger here)."""
+    import gc
+    import torch
+
+    def cycle():
+        S = pa.pc_setup(ranks(2), 2, 3, 32, 16, 16, ordering="multicolor_spmv")
+        A, b = S.A_vec[-1], S.r[-1]
+        x, r0, r, it = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=3, Pl=S, fuse=True)
+        A1, b1 = pa.build_p_matrix(ranks(1), 48, 48, 48, 48, 48, 48, 1, 1, 1)
+        pa.opt_cg_(pa.pzeros(A1.col_partition), A1, b1, maxiter=6, graph=True, fuse=True)
+    cycle()
+    gc.collect()
+    pa.context().sync()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(3):
+        cycle()
+    gc.collect()
+    pa.context().sync()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert abs(free1 - free0) < 64 << 20, f"device memory moved by {(free0 - free1) / 2**20:.1f} MiB over 3 cycles"
+
+
+@pytest.mark.parametrize("nodes,parts", [((63, 47), (4, 2)), ((11, 9, 10), (2, 2, 2))])
+def test_config5_fem_disassembled_assemble_mul(orc, nodes, parts):
+    """gallery laplacian_fem: rows of 4/6/9 (2-D) or 8..27 (3-D) entries plus assembled interface rows; 8 parts.
+    psparse default route (disassembled -> assemble) then mul!: bit-exact against the oracle; CG converges."""
+    P = int(np.prod(parts))
+    I, J, V, rows, cols = pa.laplacian_fem(nodes, parts, ranks(P))
+    A = pa.psparse_disassembled(I, J, V, rows, cols)
+    Io, Jo, Vo, orows, ocols = orc.laplacian_fem(nodes, parts)
+    Ao, _ = orc.psparse_disassembled(Io, Jo, Vo, orows, ocols)
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = upload([v.copy() for v in xo], A.col_partition)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x)
+    yo = _oracle_mul(orc, Ao, xo)
+    for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+    # solve A u = A*1: CG must recover u = 1 (test/fem_example.jl:285-289 style end-to-end check)
+    ones = pa.pones(A.col_partition)
+    b = pa.pzeros(A.col_partition)
+    pa.mul_(b, A, ones)
+    u = pa.pzeros(A.col_partition)
+    u, r0, r, it = pa.ref_cg_(u, A, b, maxiter=400, tolerance=1e-12)
+    assert r / r0 <= 1e-12
+    for vals in u.own_values().items:
+        assert np.allclose(vals, 1.0, atol=1e-8)
+
+
+def test_arena_places_matrix_streams_and_vectors_in_different_memory_classes(orc, tmp_path):
+    """csrc/pa_arena.hip: the first allocation of PA_ARENA_MIN_MIB or more makes the context acquire its first contiguous
+    extent (16 GiB, classified when acquired); the first big vector makes it walk over further extents until one shows a
+    class without matrix streams, and hand the ones it walked over back.  The value stream of a big block and the vectors
+    then sit in different classes, the (matrix stream, vector) pairs pass the self-check, what the context HOLDS stays a
+    small multiple of what is used (no 70 %-of-the-device grab any more), freed storage is handed out again, and the product
+    on arena-resident operands is bit-identical to the oracle's.  Runs in a child process with its own context."""
+    import subprocess, sys, json, textwrap, time
+    code = textwrap.dedent("""
+        import json, sys, time
+        import numpy as np
+        sys.path.insert(0, %r)
+        from __graft_entry__ import load_package, load_oracle
+        pa, orc = load_package(), load_oracle()
+        import torch
+        ctx = pa.context()
+        out = {"before": ctx.arena()}
+        free0 = torch.cuda.mem_get_info()[0]
+        A, b = pa.build_p_matrix(pa.DebugArray([1]), 128, 128, 128, 128, 128, 128, 1, 1, 1, keep_host=True)   # 55.7 M entries: 446 MB of values
+        blk = A.matrix_partition.items[0].own_own
+        out["after_matrix"] = ctx.arena()
+        out["matrix_class"] = blk.memory_class()
+        n = blk.m
+        t = time.perf_counter()
+        x = pa.DeviceVector(n, 0).upload(orc.hash_x(np.arange(1, n + 1)))
+        ctx.sync()
+        out["first_vector_s"] = time.perf_counter() - t
+        y = pa.DeviceVector(n, 0)
+        big = pa.DeviceVector(8 << 20, 0)                                # 64 MiB: a vector the pair self-check looks at
+        out["after"] = ctx.arena()
+        out["free_taken_gib"] = (free0 - torch.cuda.mem_get_info()[0]) / 2**30
+        out["vector_classes"] = [x.memory_class(), y.memory_class(), big.memory_class()]
+        pa.spmv_(y, blk, x)
+        h = pa.local_items(A.host_blocks)[0][0]
+        want = np.zeros(n)
+        orc.oracle_c().spmv_csr(want, orc.hash_x(np.arange(1, n + 1)), orc.CSR(h.m, h.n, h.rowptr, h.colval, h.nzval))
+        out["bit_identical"] = bool(np.array_equal(y.download(), want))
+        p0 = y.data_ptr()
+        del y
+        import gc; gc.collect()
+        y2, y3 = pa.DeviceVector(n, 0), pa.DeviceVector(n, 0)
+        out["reused"] = p0 in (y2.data_ptr(), y3.data_ptr())
+        small = pa.DeviceVector(1000, 0)
+        out["small_vector_class"] = small.memory_class()
+        # a block generated in HBM frees temporaries bigger than anything it keeps: the vectors made after it must still be placed
+        A2, b2 = pa.build_p_matrix(pa.DebugArray([1]), 128, 128, 128, 128, 128, 128, 1, 1, 1)
+        z = pa.DeviceVector(n, 0)
+        out["generated"] = [A2.matrix_partition.items[0].own_own.memory_class(), b2.vector_partition.items[0].memory_class(), z.memory_class()]
+        print("RESULT " + json.dumps(out))
+    """ % str(pathlib.Path(__file__).resolve().parents[1]))
+    env = dict(os.environ, PA_ARENA_MIN_MIB="256", PA_SETUP_TIMING="1")
+    env.pop("PA_ARENA_GIB", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert out["before"]["gib"] == 0                                   # lazily: nothing big had been allocated yet
+    assert 8 <= out["after_matrix"]["gib"] <= 49, out["after_matrix"]  # the matrix streams' extent, the extent b (a vector) made it walk to, a spare
+    assert out["bit_identical"]
+    assert out["small_vector_class"] == -1                             # below 1 MiB: plain hipMalloc
+    assert out["reused"]
+    M = out["after"]["matrix_class"]
+    assert out["matrix_class"] == M
+    assert out["after"]["gib"] <= 65 and out["free_taken_gib"] <= 68, out   # held: the matrix streams' extent, the vectors' extent, at most
+                                                                             # a spare and what the walk crossed -- not the device
+    if out["after"]["classes"] >= 2:                                   # the structure the rule exists for
+        assert all(c >= 0 and c != M for c in out["vector_classes"]), (out, r.stderr[-3000:])
+        assert out["after"]["pairs_checked_ok"] >= 1 and out["after"]["pairs_checked_same_class"] == 0, (out, r.stderr[-3000:])
+        assert out["generated"][0] == M and all(c >= 0 and c != M for c in out["generated"][1:]), out
+        assert out["first_vector_s"] < 3.0, out                        # the walk is a fraction of a second, not the 7 s of round 2
+    else:                                                              # the whole walk stayed inside one class region: nothing to place by
+        assert all(c == M for c in out["vector_classes"]), out
+
+
+def test_unstructured_banded_psparse_on_four_parts(orc):
+    """mul! on a PSparseMatrix with no structure at all: 4 parts of a 1-D block partition, 5..24 entries per row at random
+    columns within +-1500 of the diagonal (so every part has up to 1500 ghosts on each side, referenced irregularly).
+    psparse builds the blocks, the own x own blocks take the x-window launch, own x ghost the compacted row split; the
+    product equals the oracle's mul! bit for bit."""
+    P, n = 4, 320_000
+    rows = pa.uniform_partition(ranks(P), n)
+    orows = orc.uniform_partition(P, n)
+    rng = np.random.default_rng(41)
+    Is, Js, Vs = [], [], []
+    for ind in orows:
+        g = ind.own_to_global
+        lens = rng.integers(5, 25, len(g))
+        I = np.repeat(g, lens)
+        J = np.clip(I + rng.integers(-1500, 1500, len(I)), 1, n)
+        Is.append(I.astype(np.int64)); Js.append(J.astype(np.int64)); Vs.append(rng.standard_normal(len(I)))
+    A = pa.psparse_from_coo(pa.DebugArray([a.copy() for a in Is]), pa.DebugArray([a.copy() for a in Js]),
+                            pa.DebugArray([a.copy() for a in Vs]), rows)
+    Ao = orc.psparse_from_coo([a.copy() for a in Is], [a.copy() for a in Js], [a.copy() for a in Vs], orows)
+    for blk in A.matrix_partition.items:
+        assert blk.own_own.encoding()["pattern"] == 0 and blk.own_own.xwin()["groups"] > 0, blk.own_own.xwin()
+        assert blk.own_ghost.nnz > 0
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) - 0.25 * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = upload([v.copy() for v in xo], A.col_partition)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x)
+    yo = _oracle_mul(orc, Ao, xo)
+    for got, exp, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+    c2 = pa.pzeros(A.row_partition)
+    pa.mul_c_(c2, A, x)                                         # the one-call product takes the same launches
+    for got, exp, r in zip(c2.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, exp[:r.n_own])
+
+
+@pytest.mark.parametrize("nodes,parts", [((23, 17), (2, 2)), ((9, 7, 8), (2, 2, 2)), ((30,), (3,))])
+def test_psparse_reassembly_on_device(orc, nodes, parts):
+    """psparse(...;reuse=true) then psparse!(C,V2,cache) (src/p_sparse_matrix.jl:1291-1305,1762-1816): new COO values on
+    the same pattern are scattered, exchanged and added on the device; the stored values must be bit-identical to a
+    from-scratch assembly of V2 by the oracle (test/fem_example.jl:291-329 re-assembles this way)."""
+    P = int(np.prod(parts))
+    I, J, V, rows, cols = pa.laplacian_fem(nodes, parts, ranks(P))
+    A, cache = pa.psparse_disassembled(I, J, V, rows, cols, reuse=True)
+    Io, Jo, Vo, orows, ocols = orc.laplacian_fem(nodes, parts)
+    for rep in range(2):
+        V2 = pa.pmap(lambda v, i: v * (1.0 + rep) + orc.hash_x(np.arange(len(v)) + 13 * int(i[0])) * 1e-3, V, I)
+        pa.psparse_(A, V2, cache).wait()
+        Ao, _ = orc.psparse_disassembled(Io, Jo, [v.copy() for v in V2.items], orows, ocols)
+        for w, blk in zip(cache.W.items, Ao.blocks):
+            vals = w.download()
+            exp = np.concatenate([blk.own_own.nzval, blk.own_ghost.nzval])
+            assert np.array_equal(vals[:len(exp)], exp)
+            assert np.all(vals[len(exp):] == 0.0)                     # ghost-row slots are zeroed after the exchange
+        xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+        x = upload([v.copy() for v in xo], A.col_partition)
+        y = pa.pzeros(A.row_partition)
+        pa.mul_(y, A, x)
+        yo = _oracle_mul(orc, Ao, xo)
+        for got, e, r in zip(y.own_values().items, yo, Ao.rows):
+            assert np.array_equal(got, e[:r.n_own])
+
+
+def test_device_side_encoding_equals_the_host_s(orc, monkeypatch):
+    """the column encodings of a block are built by kernels over the uploaded CSR (csrc/pa_setup.hip: row
+    hashes, radix sort, per-chunk descriptors, window tags, compacted streams).  Every array the product kernel reads --
+    pattern descriptors and table, windows, 16-bit codes, compacted 32-bit columns -- must equal, byte for byte, what the
+    host encoder (PA_SETUP_DEVICE=0; pa_encode_columns, itself pinned by pa_host_check_spmv_encodings) builds, in every
+    mode (patterns on / off, 16-bit stream on / off, compacted streams on / off), and the product must keep its bits."""
+    modes = [{}, {"PA_SPMV_PATTERN": "0"}, {"PA_SPMV_PATTERN": "0", "PA_SPMV_COL16": "0"}, {"PA_SPMV_COMPACT_STREAMS": "0"}, {"PA_SPMV_COL16": "0"}]
+    for name, H in _encoding_cases(orc):
+        xh = np.random.default_rng(3).standard_normal(H.n)
+        want = np.zeros(H.m)
+        orc.oracle_c().spmv_csr(want, xh, orc.CSR(H.m, H.n, H.rowptr, H.colval, H.nzval))
+        x = pa.DeviceVector(H.n, 0).upload(xh)
+        for mode in modes:
+            for k in ("PA_SPMV_PATTERN", "PA_SPMV_COL16", "PA_SPMV_COMPACT_STREAMS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in mode.items():
+                monkeypatch.setenv(k, v)
+            built = {}
+            for dev in ("0", "1"):
+                monkeypatch.setenv("PA_SETUP_DEVICE", dev)
+                blk = pa.DeviceCSR(H)
+                y = pa.DeviceVector(H.m, 0)
+                pa.spmv_(y, blk, x)
+                built[dev] = (blk.debug_arrays(), blk.encoding(), blk.stream_bytes(), blk.device_bytes(), blk.xwin(), y.download())
+            h, d = built["0"], built["1"]
+            assert h[1] == d[1] and h[2] == d[2] and h[3] == d[3] and h[4] == d[4], (name, mode, h[1:5], d[1:5])
+            for key in h[0]:
+                assert h[0][key].shape == d[0][key].shape and np.array_equal(h[0][key], d[0][key]), (name, mode, key)
+            assert np.array_equal(h[5], want) and np.array_equal(d[5], want), (name, mode)
+    monkeypatch.delenv("PA_SETUP_DEVICE")
+
+
+def test_device_side_psparse_equals_the_host_route(orc, monkeypatch):
+    """csrc/pa_assemble.hip: psparse(I,J,V,rows,cols;assembled=true) with everything per triplet on the device (own-box
+    arithmetic, ghosts in first-seen order by two radix sorts, the (row, column) sort with duplicates added in input order,
+    the own | ghost split) against the host route (PA_SETUP_DEVICE=0: pa_host.cpp's restatement of src/p_range.jl:205-259,
+    src/sparse_utils.jl:313-350, src/p_sparse_matrix.jl:823-899): the same ghosts in the same order, the same CSR arrays bit
+    for bit -- on a gallery Laplacian over 4 parts and on shuffled random triplets with duplicates, columns anywhere, and ids
+    < 1 (the CSR skip rule turns those into (1,1,0.0)) -- and the same product."""
+    rng = np.random.default_rng(21)
+    cases = []
+    r4 = ranks(4)
+    I, J, V, rows, _ = pa.laplacian_fdm((20, 16, 12), (2, 2, 1), r4)
+    cases.append(("laplacian_fdm 20x16x12 on (2,2,1)", I, J, V, rows))
+    r3 = ranks(3)
+    n = 6000
+    rows3 = pa.uniform_partition(r3, (3,), (n,))
+
+    def rand(ind):
+        lo, hi = ind.ranges[0]
+        m = 40000
+        Ii = rng.integers(lo, hi + 1, size=m).astype(np.int64)
+        Ji = rng.integers(1, n + 1, size=m).astype(np.int64)
+        dup = rng.integers(0, m, size=m // 4)                    # a quarter of the triplets repeat an earlier position
+        Ii[dup], Ji[dup] = Ii[(dup * 7) % m], Ji[(dup * 7) % m]
+        Ii[rng.integers(0, m, size=20)] = 0                      # ids < 1: not local
+        Ji[rng.integers(0, m, size=20)] = -3
+        return Ii, Ji, rng.standard_normal(m)
+    trip = pa.pmap(rand, rows3)
+    cases.append(("random triplets", pa.pmap(lambda t: t[0], trip), pa.pmap(lambda t: t[1], trip), pa.pmap(lambda t: t[2], trip), rows3))
+    for name, I, J, V, rows in cases:
+        built = {}
+        for dev in ("0", "1"):
+            monkeypatch.setenv("PA_SETUP_DEVICE", dev)
+            cp = lambda a: pa.pmap(lambda v: np.array(v, copy=True), a)
+            A = pa.psparse_from_coo(cp(I), cp(J), cp(V), rows, keep_host=True)
+            x = pa.pvector_from_function(lambda ind: orc.hash_x(ind.get_local_to_global()) * (ind.get_local_to_owner() == ind.part), A.col_partition)
+            y = pa.pzeros(A.row_partition)
+            pa.mul_(y, A, x)
+            built[dev] = (A, [v.copy() for v in pa.local_items(y.own_values())])
+        (Ah, yh), (Ad, yd) = built["0"], built["1"]
+        for p, (ch, cd) in enumerate(zip(pa.local_items(Ah.col_partition), pa.local_items(Ad.col_partition))):
+            assert np.array_equal(ch.ghost_to_global, cd.ghost_to_global) and np.array_equal(ch.ghost_to_owner, cd.ghost_to_owner), (name, p)
+        for p, (hh, hd) in enumerate(zip(pa.local_items(Ah.host_blocks), pa.local_items(Ad.host_blocks))):
+            for which in (0, 1):
+                a, b = hh[which], hd[which]
+                assert (a.m, a.n) == (b.m, b.n) and np.array_equal(a.rowptr, b.rowptr) and np.array_equal(a.colval, b.colval), (name, p, which)
+                assert np.array_equal(a.nzval.view(np.int64), b.nzval.view(np.int64)), (name, p, which)
+        for p, (u, v) in enumerate(zip(yh, yd)):
+            assert np.array_equal(u, v), (name, p)
+    monkeypatch.delenv("PA_SETUP_DEVICE")
+
+
+def test_device_side_disassembled_psparse_equals_the_host_route(orc, monkeypatch):
+    """csrc/pa_assemble.hip, pa_coo_subassemble + pa_coo_assemble_finish: psparse(I,J,V,rows,cols) with the default flags and
+    assemble (src/p_sparse_matrix.jl:1150-1219,1590-1756) -- triplets of rows other parts own travel to their owners -- with the
+    sub-assembled matrix, the ghost numbering and the final compress on the device, against the host route (PA_SETUP_DEVICE=0,
+    itself pinned to the oracle): the same final ghost columns in the same order, the same CSR arrays bit for bit, the same
+    product.  Q1 FEM Laplacians in 2-D on (4,2) and 3-D on (2,2,1) parts (test/fem_example.jl's assembly loops), and random
+    triplets on 3 parts whose rows and columns lie anywhere, with duplicates on both sides of the exchange."""
+    rng = np.random.default_rng(33)
+    cases = []
+    for nodes, parts in (((40, 24), (4, 2)), ((9, 8, 7), (2, 2, 1)), ((30,), (3,))):
+        r = ranks(int(np.prod(parts)))
+        I, J, V, rows, cols = pa.laplacian_fem(nodes, parts, r)
+        cases.append((f"laplacian_fem {nodes} on {parts}", I, J, V, rows, cols))
+    r3 = ranks(3)
+    n = 5000
+    rows3 = pa.uniform_partition(r3, (3,), (n,))
+
+    def rand(ind):
+        m = 30000
+        Ii = rng.integers(1, n + 1, size=m).astype(np.int64)           # rows anywhere: two thirds belong to other parts
+        Ji = rng.integers(1, n + 1, size=m).astype(np.int64)
+        dup = rng.integers(0, m, size=m // 3)
+        Ii[dup], Ji[dup] = Ii[(dup * 11) % m], Ji[(dup * 11) % m]
+        return Ii, Ji, rng.standard_normal(m)
+    trip = pa.pmap(rand, rows3)
+    cases.append(("random triplets", pa.pmap(lambda t: t[0], trip), pa.pmap(lambda t: t[1], trip), pa.pmap(lambda t: t[2], trip), rows3, rows3))
+    from pa_amd import p_sparse_matrix as psm
+    for name, I, J, V, rows, cols in cases:
+        built = {}
+        for dev in ("0", "1"):
+            monkeypatch.setenv("PA_SETUP_DEVICE", dev)
+            cp = lambda a: pa.pmap(lambda v: np.array(v, copy=True), a)
+            assert psm._disassembled_device_applies(rows, cols, I, J) == (dev == "1"), name
+            A = pa.psparse_disassembled(cp(I), cp(J), cp(V), rows, cols, keep_host=True)
+            x = pa.pvector_from_function(lambda ind: orc.hash_x(ind.get_local_to_global()) * (ind.get_local_to_owner() == ind.part), A.col_partition)
+            y = pa.pzeros(A.row_partition)
+            pa.mul_(y, A, x)
+            built[dev] = (A, [v.copy() for v in pa.local_items(y.own_values())])
+        (Ah, yh), (Ad, yd) = built["0"], built["1"]
+        for p, (ch, cd) in enumerate(zip(pa.local_items(Ah.col_partition), pa.local_items(Ad.col_partition))):
+            assert np.array_equal(ch.ghost_to_global, cd.ghost_to_global) and np.array_equal(ch.ghost_to_owner, cd.ghost_to_owner), (name, p)
+        for p, (hh, hd) in enumerate(zip(pa.local_items(Ah.host_blocks), pa.local_items(Ad.host_blocks))):
+            for which in (0, 1):
+                a, b = hh[which], hd[which]
+                assert (a.m, a.n) == (b.m, b.n) and np.array_equal(a.rowptr, b.rowptr) and np.array_equal(a.colval, b.colval), (name, p, which)
+                assert np.array_equal(a.nzval.view(np.int64), b.nzval.view(np.int64)), (name, p, which)
+        for p, (u, v) in enumerate(zip(yh, yd)):
+            assert np.array_equal(u, v), (name, p)
+    monkeypatch.delenv("PA_SETUP_DEVICE")
+
+
+def test_hpcg_blocks_generated_on_the_device_equal_the_host_s(orc):
+    """csrc/pa_rowsel.hip, pa_hpcg_own_block_create + pa_host_hpcg_ghost_block: HPCG's 27-point operator of a part with the
+    own|own block and b generated in HBM (HPCG/src/sparse_matrix.jl:28-122) against the fused host generator + upload (itself
+    pinned to the reference's chain and the oracle by tests/test_host_setup.py): every array the product kernel reads, both
+    blocks, b, the ghost ids and their order -- on one part, on (2,2,2) parts of a non-cubic box, on (4,1,1); and the greedy
+    colouring in natural order computed by rounds on the device against pa_host_greedy_coloring."""
+    import pa_amd._lib as L
+    for P, shape, n in ((1, (1, 1, 1), (24, 24, 24)), (8, (2, 2, 2), (8, 6, 10)), (4, (4, 1, 1), (5, 9, 7)), (2, (2, 1, 1), (64, 64, 64)),
+                        (1, (1, 1, 1), (1, 4, 3)), (2, (2, 1, 1), (1, 3, 2)), (4, (1, 2, 2), (3, 1, 1))):      # (degenerate boxes too)
+        g = [s * k for s, k in zip(shape, n)]
+        Ad, bd = pa.build_p_matrix(ranks(P), *n, *g, *shape, keep_host=False, fused=True, keep_raw=True)
+        Ah, bh = pa.build_p_matrix(ranks(P), *n, *g, *shape, keep_host=True, fused=True)
+        assert Ad.host_blocks is None
+        for p in range(P):
+            cd, ch = Ad.col_partition.items[p], Ah.col_partition.items[p]
+            assert np.array_equal(cd.ghost_to_global, ch.ghost_to_global) and np.array_equal(cd.ghost_to_owner, ch.ghost_to_owner)
+            assert np.array_equal(bd.vector_partition.items[p].download(), bh.vector_partition.items[p].download())
+            for which in ("own_own", "own_ghost"):
+                d, h = getattr(Ad.matrix_partition.items[p], which), getattr(Ah.matrix_partition.items[p], which)
+                assert d.info() == h.info() and d.encoding() == h.encoding() and d.stream_bytes() == h.stream_bytes(), (P, p, which)
+                da, ha = d.debug_arrays(), h.debug_arrays()
+                assert da.keys() == ha.keys()
+                for key in da:
+                    assert da[key].shape == ha[key].shape and np.array_equal(da[key], ha[key]), (P, p, which, key)
+            oo = Ah.host_blocks.items[p][0]
+            want, k_want = np.zeros(oo.m, np.int32), C.c_int32()
+            L.call("pa_host_greedy_coloring", oo.m, L.ptr(oo.rowptr), L.ptr(oo.colval), 1, L.ptr(want), C.byref(k_want))
+            got, k_got = np.zeros(oo.m, np.int32), C.c_int32()
+            L.call("pa_csr_greedy_coloring", Ad.matrix_partition.items[p].own_own.h, L.ptr(got), C.byref(k_got))
+            assert k_got.value == k_want.value and np.array_equal(got, want), (P, p)
+        x = pa.pones(Ad.col_partition)
+        yd, yh = pa.pzeros(Ad.row_partition), pa.pzeros(Ah.row_partition)
+        pa.mul_(yd, Ad, x)
+        pa.mul_(yh, Ah, pa.pones(Ah.col_partition))
+        for u, v in zip(yd.vector_partition.items, yh.vector_partition.items):
+            assert np.array_equal(u.download(), v.download())
+
+
+def test_device_side_row_subsets_equal_the_host_route(orc, monkeypatch):
+    """csrc/pa_rowsel.hip: the blocks the multigrid set-up cuts out of a level's matrix -- the colours of the multicolour
+    smoother and the fine rows the coarse grid keeps (HPCG/src/mg_preconditioner.jl:224-251,314-329) -- built on the device
+    from the part's own|own and own|ghost blocks (raw columns kept in HBM) against the host route (pa_host_color_split + an
+    upload, PA_SETUP_ROWSEL=0): every array the product kernel reads, the encodings, the diagonal, and the whole hierarchy
+    through an MG-PCG solve, bit for bit; on 2 parts (ghost columns, row-compacted own|ghost blocks) and on one."""
+    import pa_amd._lib as L
+    for P, n in ((2, (16, 8, 8)), (1, (16, 16, 16))):
+        built = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PA_SETUP_ROWSEL", mode)
+            S = pa.pc_setup(ranks(P), P, 3, *n, ordering="multicolor_spmv")
+            A, b = S.A_vec[-1], S.r[-1]
+            x, r0, r, it = pa.opt_cg_(pa.pzeros(A.col_partition), A, b, maxiter=12, Pl=S, fuse=True)
+            arrays = []
+            for lev in range(S.l):
+                for part in S.gs_states[lev].parts.items:
+                    arrays.append([(blk.debug_arrays(), blk.info(), blk.encoding(), blk.stream_bytes()) for blk in part[0]]
+                                  + [part[1].download(), part[3]])
+                if lev >= 1:
+                    arrays.append([(q.debug_arrays(), q.info(), q.encoding(), q.stream_bytes()) for q in S.row_blocks[lev - 1].items])
+            built[mode] = (arrays, [v.download() for v in x.vector_partition.items], r0, r, it)
+        d, h = built["1"], built["0"]
+        assert d[2:] == h[2:], (P, d[2:], h[2:])
+        for a, b_ in zip(d[1], h[1]):
+            assert np.array_equal(a, b_)
+        assert len(d[0]) == len(h[0])
+        for ea, eb in zip(d[0], h[0]):
+            assert len(ea) == len(eb)
+            for ia, ib in zip(ea, eb):
+                if isinstance(ia, tuple):
+                    assert ia[1:] == ib[1:], (P, ia[1:], ib[1:])
+                    assert ia[0].keys() == ib[0].keys()
+                    for key in ia[0]:
+                        assert ia[0][key].shape == ib[0][key].shape and np.array_equal(ia[0][key], ib[0][key]), (P, key)
+                else:
+                    assert np.array_equal(ia, ib), P
+    # the reference's smoother (sequential sweep, level-scheduled): unsplit CSR, diagonal and dependency levels made on the
+    # device (pa_gs_create_from_blocks: rounds over the rows whose lower neighbours are done) against pa_gs_create's loop
+    for P, n in ((2, (16, 8, 8)), (1, (16, 16, 16)), (4, (8, 8, 8))):
+        built = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("PA_SETUP_ROWSEL", mode)
+            S = pa.pc_setup(ranks(P), P, 3, *n, ordering="sequential")
+            A, b = S.A_vec[-1], S.r[-1]
+            x, r0, r, it = pa.ref_cg_(pa.pzeros(A.col_partition), A, b, maxiter=8, overlap=False, Pl=S)
+            built[mode] = ([g.info().items for g in S.gs_states], [v.download() for v in x.vector_partition.items], r0, r, it)
+        d, h = built["1"], built["0"]
+        assert d[0] == h[0] and d[2:] == h[2:], (P, d[0], h[0], d[2:], h[2:])
+        for a, b_ in zip(d[1], h[1]):
+            assert np.array_equal(a, b_)
+    # the entry points on their own: a block that kept no raw columns, a mask outside -1..n_sel-1, a mask with holes
+    monkeypatch.delenv("PA_SETUP_ROWSEL")
+    Hc = next(iter(_encoding_cases(orc)))[1]
+    blk = pa.DeviceCSR(Hc)
+    if not blk.has_raw_columns():
+        with pytest.raises(pa.PAError, match="raw columns"):
+            pa.DeviceCSR.select_rows(blk, None, np.zeros(Hc.m, np.int32), 1)
+    L.call("pa_ctx_keep_raw_columns", pa.context().h, 1)
+    try:
+        blk = pa.DeviceCSR(Hc)
+    finally:
+        L.call("pa_ctx_keep_raw_columns", pa.context().h, 0)
+    assert blk.has_raw_columns()
+    with pytest.raises(pa.PAError, match="mask entry"):
+        pa.DeviceCSR.select_rows(blk, None, np.full(Hc.m, 3, np.int32), 2)
+    mask = (np.arange(Hc.m) % 3 - 1).astype(np.int32)              # -1, 0, 1, -1, ...
+    subs = pa.DeviceCSR.select_rows(blk, None, mask, 2)
+    xh = np.random.default_rng(5).standard_normal(Hc.n)
+    x = pa.DeviceVector(Hc.n, 0).upload(xh)
+    full = np.zeros(Hc.m)
+    orc.oracle_c().spmv_csr(full, xh, orc.CSR(Hc.m, Hc.n, Hc.rowptr, Hc.colval, Hc.nzval))
+    for k, sub in enumerate(subs):
+        y = pa.DeviceVector(Hc.m, 0)
+        pa.spmv_(y, sub, x)
+        assert np.array_equal(y.download(), np.where(mask == k, full, 0.0)), k
+    blk.drop_raw_columns()
