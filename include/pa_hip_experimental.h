@@ -197,6 +197,11 @@ int pa_host_hpcg_build_matrix(int64_t nx, int64_t ny, int64_t nz, int64_t gnx, i
 /* src/gallery.jl:12-86 laplacian_fdm `setup` for one part's own box [lo,hi] per dimension (D<=3). */
 int pa_host_laplacian_fdm(int32_t D, const int64_t *nodes_per_dir, const int64_t *lo, const int64_t *hi,
                           int64_t *I, int64_t *J, double *V, int64_t *nnz_out);
+/* src/gallery.jl:110-239 laplacian_fem `setup` for one part's CELL box [lo,hi] of the (nodes+1)^D cell grid (D<=3): the disassembled
+ * COO of the part's cells, cells column-major, local node i then j; Aref = the 2^D x 2^D reference matrix (row-major) the caller
+ * computes as :123-162 does.  NULL arrays: only count. */
+int pa_host_laplacian_fem(int32_t D, const int64_t *nodes_per_dir, const int64_t *cell_lo, const int64_t *cell_hi, const double *Aref,
+                          int64_t *I, int64_t *J, double *V, int64_t *nnz_out);
 /* src/p_range.jl:1609-1619 find_owner for block partitions: starts[d] has np[d]+1 entries. */
 int pa_host_find_owner_block(int32_t D, const int64_t *n, const int32_t *np, const int64_t *const *starts,
                              const int64_t *gids, int64_t count, int32_t *owners);

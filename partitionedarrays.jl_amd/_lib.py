@@ -185,6 +185,7 @@ _SIGS = {
     "pa_comm_info": [P, C.POINTER(cint), C.POINTER(cint)],
     "pa_host_hpcg_build_matrix": [i64] * 9 + [P, P, P, P, P, C.POINTER(i64)],
     "pa_host_laplacian_fdm": [i32, P, P, P, P, P, P, C.POINTER(i64)],
+    "pa_host_laplacian_fem": [i32, P, P, P, P, P, P, P, C.POINTER(i64)],
     "pa_host_find_owner_block": [i32, P, P, PP, P, i64, P],
     "pa_host_filter_ghost": [i32, P, P, i64, P, i64, P, P, C.POINTER(i64)],
     "pa_host_global_to_local_block": [i32, P, P, P, P, i64, P, i64, P],

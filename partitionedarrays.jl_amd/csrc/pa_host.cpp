@@ -119,6 +119,82 @@ extern "C" int pa_host_laplacian_fdm(int32_t D, const int64_t *n, const int64_t 
   return PA_OK;
 }
 
+// src/gallery.jl:110-239 laplacian_fem `setup` of one part: the part loops over ITS CELLS (the box [lo,hi] of the (nodes+1)^D
+// cell grid, column-major), and for every cell over local node i, then local node j (2^D corners, column-major), emitting
+// (node_i, node_j, Aref[i][j]) when both nodes are interior -- a cell corner c + offset - 1 outside 1..nodes[d] is a boundary
+// node.  Aref: the 2^D x 2^D reference matrix (row-major), computed by the caller exactly as :123-162 does.  Two passes over the
+// slabs of the outermost direction: entries per slab, then the fill (threaded).
+extern "C" int pa_host_laplacian_fem(int32_t D, const int64_t *nodes, const int64_t *lo, const int64_t *hi, const double *Aref,
+                                     int64_t *I, int64_t *J, double *V, int64_t *nnz_out) {
+  PA_REQUIRE(D >= 1 && D <= 3 && nodes && lo && hi && Aref && nnz_out, "bad arguments");
+  const int nloc = 1 << D;
+  int64_t nn[3] = {1, 1, 1}, l[3] = {1, 1, 1}, h[3] = {1, 1, 1}, stride[3] = {1, 1, 1};
+  for (int d = 0; d < D; ++d) { nn[d] = nodes[d]; l[d] = lo[d]; h[d] = hi[d]; }
+  for (int d = 1; d < D; ++d) stride[d] = stride[d - 1] * nodes[d - 1];
+  const int od = D - 1;
+  const int64_t olen = h[od] - l[od] + 1;
+  if (olen <= 0) { *nnz_out = 0; return PA_OK; }
+  // interior corners of a cell along direction d: coordinate c + a - 1 for a in {0, 1}
+  auto ok1 = [&](int d, int64_t c, int a) { const int64_t x = c + a - 1; return x >= 1 && x <= nn[d]; };
+  // entries of the cells with outermost coordinate c_od: (interior corners)^2 summed over the inner box; the count factorises
+  auto slab_count = [&](int64_t c_od) {
+    int64_t k_od = (int64_t)ok1(od, c_od, 0) + (int64_t)ok1(od, c_od, 1);
+    // sum over inner cells of (k_od * prod_d k_d)^2 = k_od^2 * prod_d sum_c k_d(c)^2
+    int64_t total = k_od * k_od;
+    for (int d = 0; d < od; ++d) {
+      int64_t sd = 0;
+      for (int64_t c = l[d]; c <= h[d]; ++c) { const int64_t k = (int64_t)ok1(d, c, 0) + (int64_t)ok1(d, c, 1); sd += k * k; }
+      total *= sd;
+    }
+    return total;
+  };
+  std::vector<int64_t> first(olen + 1, 0);
+  for (int64_t k = 0; k < olen; ++k) first[k + 1] = first[k] + slab_count(l[od] + k);
+  *nnz_out = first[olen];
+  if (!(I && J && V) || *nnz_out == 0) return PA_OK;
+  unsigned hw = std::thread::hardware_concurrency();
+  int T = hw ? (int)std::min<unsigned>(hw, 32) : 4;
+  if (const char *e = getenv("PA_HOST_THREADS")) T = std::max(1, atoi(e));
+  if (*nnz_out < ((int64_t)1 << 20)) T = 1;
+  T = (int)std::min<int64_t>(T, olen);
+  auto work = [&](int th) {
+    const int64_t k0 = olen * th / T, k1 = olen * (th + 1) / T;
+    int64_t t = first[k0];
+    int64_t c[3] = {1, 1, 1};
+    int64_t sl[3] = {l[0], l[1], l[2]}, sh[3] = {h[0], h[1], h[2]};
+    sl[od] = l[od] + k0; sh[od] = l[od] + k1 - 1;
+    int64_t id[8];
+    bool in[8];
+    for (c[2] = sl[2]; c[2] <= sh[2]; ++c[2])
+      for (c[1] = sl[1]; c[1] <= sh[1]; ++c[1])
+        for (c[0] = sl[0]; c[0] <= sh[0]; ++c[0]) {
+          for (int a = 0; a < nloc; ++a) {                       // corner a: offsets column-major (first direction fastest)
+            bool good = true;
+            int64_t node = 1;
+            for (int d = 0; d < D; ++d) {
+              const int64_t x = c[d] + ((a >> d) & 1) - 1;
+              good = good && x >= 1 && x <= nn[d];
+              node += (x - 1) * stride[d];
+            }
+            in[a] = good; id[a] = node;
+          }
+          for (int a = 0; a < nloc; ++a) {
+            if (!in[a]) continue;
+            for (int b = 0; b < nloc; ++b) {
+              if (!in[b]) continue;
+              I[t] = id[a]; J[t] = id[b]; V[t] = Aref[a * nloc + b];
+              ++t;
+            }
+          }
+        }
+  };
+  std::vector<std::thread> pool;
+  for (int th = 1; th < T; ++th) pool.emplace_back(work, th);
+  work(0);
+  for (auto &x : pool) x.join();
+  return PA_OK;
+}
+
 // src/p_range.jl:1502-1513,1609-1619: owner = LinearIndices(np)[searchsortedlast(start_d, c_d) ...]
 extern "C" int pa_host_find_owner_block(int32_t D, const int64_t *n, const int32_t *np, const int64_t *const *starts,
                                         const int64_t *gids, int64_t count, int32_t *owners) {

@@ -6,6 +6,7 @@ Mirrors /root/reference/src/gallery.jl:12-86 (laplacian_fdm) and HPCG/src/sparse
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -222,6 +223,19 @@ def laplacian_fem(nodes_per_dir, parts_per_dir, parts):
     cell_partition = uniform_partition(parts, tuple(parts_per_dir), cells_per_dir)
     strides = [int(np.prod(nodes[:d])) for d in range(D)]
 
+    def setup_native(cells):
+        # the same triplets in the same order from the native, threaded loop (csrc/pa_host.cpp: pa_host_laplacian_fem); the numpy
+        # version below stays as its checker (PA_FEM_NATIVE=0; tests/test_host_setup.py compares the two)
+        lo = np.array([r[0] for r in cells.ranges], dtype=I64)
+        hi = np.array([r[1] for r in cells.ranges], dtype=I64)
+        nd = np.array(nodes, dtype=I64)
+        Ar = np.ascontiguousarray(Aref, F64)
+        nnz = C.c_int64()
+        L.call("pa_host_laplacian_fem", D, L.ptr(nd), L.ptr(lo), L.ptr(hi), L.ptr(Ar), None, None, None, C.byref(nnz))
+        Ii, Ji, Vi = np.empty(nnz.value, I64), np.empty(nnz.value, I64), np.empty(nnz.value, F64)
+        L.call("pa_host_laplacian_fem", D, L.ptr(nd), L.ptr(lo), L.ptr(hi), L.ptr(Ar), L.ptr(Ii), L.ptr(Ji), L.ptr(Vi), C.byref(nnz))
+        return Ii, Ji, Vi
+
     def setup(cells):
         axes = [np.arange(lo, hi + 1, dtype=I64) for lo, hi in cells.ranges]
         grids = np.meshgrid(*axes, indexing="ij")
@@ -242,5 +256,6 @@ def laplacian_fem(nodes_per_dir, parts_per_dir, parts):
         Vm = np.broadcast_to(Aref[None, :, :], ok.shape)
         return Im[ok], Jm[ok], Vm[ok].copy()
 
-    I, J, V = tuple_of_arrays(pmap(setup, cell_partition))
+    native = D <= 3 and os.environ.get("PA_FEM_NATIVE", "1") != "0"
+    I, J, V = tuple_of_arrays(pmap(setup_native if native else setup, cell_partition))
     return I, J, V, node_partition, node_partition

@@ -518,3 +518,28 @@ def test_colour_block_row_pointers_and_row_subsets(orc, monkeypatch):
                     cv += list(oh.colval[a:e] + cols.n_own); vv += list(oh.nzval[a:e])
                 rp.append(len(cv) + 1)
             assert np.array_equal(B.rowptr, np.array(rp)) and np.array_equal(B.colval, np.array(cv)) and np.array_equal(B.nzval, np.array(vv))
+
+
+def test_native_fem_generator_equals_the_numpy_restatement_and_the_oracle(orc):
+    """gallery.laplacian_fem (src/gallery.jl:110-239): the native threaded loop (pa_host_laplacian_fem) against the numpy
+    restatement it replaced (PA_FEM_NATIVE=0) and against the oracle's, triplet for triplet, in 1, 2 and 3 dimensions, with
+    parts that own boundary cells only, and with more threads than cell slabs."""
+    import os
+    old = os.environ.get("PA_FEM_NATIVE")
+    try:
+        for nodes, parts in (((7, 5), (2, 2)), ((6,), (3,)), ((5, 4, 3), (2, 1, 2)), ((1, 1), (1, 1)), ((40, 33), (4, 2)), ((3, 2), (4, 3))):
+            P = int(np.prod(parts))
+            r = pa.DebugArray(range(1, P + 1))
+            os.environ["PA_FEM_NATIVE"] = "0"
+            a = pa.laplacian_fem(nodes, parts, r)
+            os.environ["PA_FEM_NATIVE"] = "1"
+            b = pa.laplacian_fem(nodes, parts, r)
+            Io, Jo, Vo, _, _ = orc.laplacian_fem(nodes, parts)
+            for k, ref in enumerate((Io, Jo, Vo)):
+                for x, y, z in zip(a[k].items, b[k].items, ref):
+                    assert np.array_equal(x, y) and np.array_equal(y, z), (nodes, parts, k)
+    finally:
+        if old is None:
+            os.environ.pop("PA_FEM_NATIVE", None)
+        else:
+            os.environ["PA_FEM_NATIVE"] = old
