@@ -310,6 +310,7 @@ function PartitionedArrays.p_vector_cache_impl(::Type{HIPVector}, vector_partiti
                     length(ns), ns, is.ptrs, dev(is.data), length(nr), nr, ir.ptrs, dev(ir.data), 1, h))
         h[]
     end
+    plans isa MPIArray && PA_TRANSPORT == "ipc" && connect_ipc!(plans)
     HIPAssemblyCache(plans, false)
 end
 
@@ -318,13 +319,38 @@ _transport!(plans::DebugArray, mode) =        # all parts in this process (src/d
 _transport!(plans::MPIArray, mode) =          # one part per rank (src/mpi_array.jl:575-614) -> RCCL p2p over xGMI
     check(ccall((:pa_exchange_rccl, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), plans.item, init_comm!(plans.comm), mode))
 
+# PA_TRANSPORT=ipc (csrc/pa_push.hip): instead of pack + RCCL, the pack kernel stores every slice straight into the neighbours'
+# receive buffers, mapped over hipIpc.  Once per cache: every rank publishes its plan's blob (ipc handles + slice tables), gathers
+# everybody's (MPI.Allgatherv, as init_comm! broadcasts the RCCL id) and opens its neighbours'.
+const PA_TRANSPORT = get(ENV, "PA_TRANSPORT", "rccl")
+function connect_ipc!(plans::MPIArray)
+    plan = plans.item
+    n = Ref{Int64}(0)
+    check(ccall((:pa_plan_ipc_blob_size, libpa), Cint, (Ptr{Cvoid}, Ref{Int64}), plan, n))
+    blob = Vector{UInt8}(undef, n[])
+    check(ccall((:pa_plan_ipc_blob, libpa), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int64), plan, blob, n[]))
+    sizes = MPI.Allgather(Int64[n[]], plans.comm)
+    everything = MPI.Allgatherv(blob, MPI.VBuffer(Vector{UInt8}(undef, sum(sizes)), Int32.(sizes)), plans.comm)
+    offs = cumsum(vcat(0, sizes[1:end-1]))
+    ptrs = [pointer(everything, o + 1) for o in offs]
+    GC.@preserve everything check(ccall((:pa_plan_ipc_connect, libpa), Cint, (Ptr{Cvoid}, Int32, Ptr{Ptr{UInt8}}, Ptr{Int64}),
+                                        plan, length(sizes), ptrs, sizes))
+    MPI.Barrier(plans.comm)                      # nobody pushes before everybody has mapped
+    nothing
+end
+_push_ipc!(v, plan, mode) = check(ccall((:pa_exchange_push_ipc, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), plan, v.handle, mode))
+
 function PartitionedArrays.assemble_impl!(f, vector_partition, cache::HIPAssemblyCache)
     mode = cache.reversed ? PA_CONSISTENT : PA_ASSEMBLE
     (mode == PA_CONSISTENT) == (f === PartitionedArrays.insert) || error("HIP path supports insert (consistent!) and + (assemble!)")
-    foreach(vector_partition, cache.plans) do v, p       # pack: src/p_vector.jl:595-599
-        check(ccall((:pa_exchange_pack, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), p, v.handle, mode))
+    if cache.plans isa MPIArray && PA_TRANSPORT == "ipc"  # pack + exchange! in one kernel (the plans were connected when made)
+        foreach((v, p) -> _push_ipc!(v, p, mode), vector_partition, cache.plans)
+    else
+        foreach(vector_partition, cache.plans) do v, p   # pack: src/p_vector.jl:595-599
+            check(ccall((:pa_exchange_pack, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), p, v.handle, mode))
+        end
+        _transport!(cache.plans, mode)                    # exchange!: :601
     end
-    _transport!(cache.plans, mode)                        # exchange!: :601
     PartitionedArrays.@fake_async begin                   # wait(t) + unpack: :603-611 (+ ghost zeroing of assemble!: :703-705)
         foreach(vector_partition, cache.plans) do v, p
             check(ccall((:pa_exchange_finish, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint), p, v.handle, mode))
