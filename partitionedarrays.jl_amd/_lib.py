@@ -10,6 +10,10 @@ import os
 
 import numpy as np
 
+# dmabuf IPC is the only mode this driver stack supports: hipIpcGetMemHandle (the ipc push transport, RCCL's own p2p set-up) fails
+# with "invalid argument" without it.  Must be in the environment before the HIP runtime initialises; harmless for one process.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 # torch is imported first on purpose: it ships its own libamdhip64.so.7 / librccl.so.1 and the
 # dynamic loader then resolves libpa_hip.so's dependencies to those already-loaded copies
 # (one HIP runtime per process).  torch is plumbing here (torch.distributed bootstrap), not compute.

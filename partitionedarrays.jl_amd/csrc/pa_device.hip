@@ -2516,7 +2516,7 @@ extern "C" int pa_plan_destroy(pa_plan *p) {
   pa_push_release(p);
   for (pa_plan::side *s : {&p->snd, &p->rcv}) {
     (void)pa_raw_free(s->d_idx);
-    (void)pa_raw_free(s->d_buf);
+    if (!p->bufs_in_ipc_region) (void)pa_raw_free(s->d_buf);
   }
   (void)pa_raw_free(p->d_tgt);
   (void)pa_raw_free(p->d_tptr);

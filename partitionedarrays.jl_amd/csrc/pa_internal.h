@@ -180,6 +180,7 @@ struct pa_plan {
   pa_push_table *push[2] = {nullptr, nullptr};   // plans[0] of a group caches the group's tables here, per mode
   pa_ipc_link *ipc = nullptr;     // pa_plan_ipc_connect
   unsigned long long seq[2] = {0, 0};            // exchanges started so far, per mode (the push transport's sequence numbers)
+  bool bufs_in_ipc_region = false; // snd.d_buf / rcv.d_buf point into the ipc link's region (freed with it)
   bool ipc_ack_due = false;       // this exchange arrived over the ipc link: pa_exchange_finish acknowledges it to the senders
 };
 

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "pa_internal.h"
@@ -371,16 +372,23 @@ struct ipc_header {
   int32_t part;
   int32_t n_snd_nbr, n_rcv_nbr;
   int64_t n_snd, n_rcv;
-  int32_t device_pci[4];           // (diagnostics: which GPU the part lives on)
-  hipIpcMemHandle_t h_snd, h_rcv, h_flags;
+  int64_t off_snd, off_rcv, off_flags;   // byte offsets of the two receive buffers and of the flag words inside the CHUNK
+  hipIpcMemHandle_t h_region;            // the pool chunk the plan's region is cut from
 };
 
 struct pa_ipc_link {
+  // ONE allocation per plan holds everything a neighbour touches -- both buffers and the flag words -- so that one ipc handle names
+  // it (hipIpcGetMemHandle wants the base of an allocation of its own: the 8-byte buffer of a side without traffic, made by an
+  // ordinary hipMalloc, was refused with "invalid argument")
+  char *d_region = nullptr;
+  size_t region_bytes = 0, chunk_off = 0;
+  int chunk = -1;                          // the pool chunk the region is cut from (exported once, ipc_region_take)
+  int64_t off_snd = 0, off_rcv = 0, off_flags = 0;
   unsigned long long *d_flags = nullptr;   // [arrive CONSISTENT: NS | arrive ASSEMBLE: NR | ack CONSISTENT: NR | ack ASSEMBLE: NS]
   int64_t n_flags = 0;
   unsigned *d_done = nullptr;              // the push kernel's block counter
   int *h_status = nullptr;                 // host-pinned, device-visible: 0 ok, 1 an arrival wait timed out, 2 an acknowledgement wait did
-  struct peer { void *snd = nullptr, *rcv = nullptr, *flags = nullptr; };
+  struct peer { void *region = nullptr, *snd = nullptr, *rcv = nullptr, *flags = nullptr; };
   std::map<int, peer> peers;               // part -> its mapped buffers
   struct per_mode {
     pa_push_seg *d_segs = nullptr;
@@ -400,14 +408,75 @@ static int ipc_flags_layout(const pa_plan *p, int64_t *aC, int64_t *aA, int64_t 
   return (int)(2 * NS + 2 * NR);
 }
 
+// The regions come out of a POOL of big chunks that a process exports ONCE each and never frees, and a process maps a peer's chunk
+// ONCE and keeps it mapped: a plan per PVector cache means hundreds of short-lived regions in a solver, and exporting / importing /
+// closing / freeing each of them made hipIpcGetMemHandle fail with "invalid argument" after a few dozen (an address handed out
+// again while a peer still held the old mapping).  A freed region goes to a free list of its size and is zeroed when taken again.
+struct ipc_chunk { char *base = nullptr; size_t size = 0, used = 0; hipIpcMemHandle_t handle; int device = 0; };
+static std::mutex g_ipc_mu;
+static std::vector<ipc_chunk> g_ipc_chunks;
+static std::multimap<size_t, std::pair<int, size_t>> g_ipc_free;        // bytes -> (chunk, offset)
+struct handle_key { char b[sizeof(hipIpcMemHandle_t)]; bool operator<(const handle_key &o) const { return memcmp(b, o.b, sizeof b) < 0; } };
+static std::map<handle_key, void *> g_ipc_open;                          // a peer's chunk -> where it is mapped here
+
+static int ipc_region_take(int device, size_t bytes, int *chunk, size_t *off) {
+  std::lock_guard<std::mutex> lk(g_ipc_mu);
+  for (auto it = g_ipc_free.lower_bound(bytes); it != g_ipc_free.end() && it->first == bytes; ++it)
+    if (g_ipc_chunks[it->second.first].device == device) { *chunk = it->second.first; *off = it->second.second; g_ipc_free.erase(it); return PA_OK; }
+  for (size_t k = 0; k < g_ipc_chunks.size(); ++k) {
+    ipc_chunk &C = g_ipc_chunks[k];
+    if (C.device == device && C.used + bytes <= C.size) { *chunk = (int)k; *off = C.used; C.used += bytes; return PA_OK; }
+  }
+  ipc_chunk C;
+  C.device = device;
+  C.size = std::max<size_t>((size_t)32 << 20, bytes);
+  PA_HIP(hipMalloc((void **)&C.base, C.size));
+  PA_HIP(hipIpcGetMemHandle(&C.handle, C.base));
+  C.used = bytes;
+  g_ipc_chunks.push_back(C);
+  *chunk = (int)g_ipc_chunks.size() - 1; *off = 0;
+  return PA_OK;
+}
+static void ipc_region_give_back(int chunk, size_t off, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_ipc_mu);
+  g_ipc_free.insert({bytes, {chunk, off}});
+}
+static int ipc_open_chunk(const hipIpcMemHandle_t &h, void **base) {
+  std::lock_guard<std::mutex> lk(g_ipc_mu);
+  handle_key k;
+  memcpy(k.b, &h, sizeof k.b);
+  auto it = g_ipc_open.find(k);
+  if (it != g_ipc_open.end()) { *base = it->second; return PA_OK; }
+  PA_HIP(hipIpcOpenMemHandle(base, h, hipIpcMemLazyEnablePeerAccess));
+  g_ipc_open[k] = *base;
+  return PA_OK;
+}
+
 static int ipc_prepare(pa_plan *p) {
   if (p->ipc) return PA_OK;
+  PA_REQUIRE(p->phase == 0, "an exchange is in flight on this plan: its buffers cannot move into an ipc region now");
   pa_ipc_link *L = new pa_ipc_link();
   int64_t a, b, c, d;
   L->n_flags = std::max(1, ipc_flags_layout(p, &a, &b, &c, &d));
   PA_HIP(hipSetDevice(p->ctx->device));
-  PA_HIP(hipMalloc((void **)&L->d_flags, sizeof(unsigned long long) * L->n_flags));
-  PA_HIP(hipMemset(L->d_flags, 0, sizeof(unsigned long long) * L->n_flags));
+  PA_HIP(hipStreamSynchronize(p->ctx->s[0]));
+  PA_HIP(hipStreamSynchronize(p->ctx->s[1]));
+  auto up = [](size_t x) { return (x + 255) / 256 * 256; };
+  L->off_snd = 0;
+  L->off_rcv = (int64_t)up(sizeof(double) * std::max<int64_t>(1, p->snd.n));
+  L->off_flags = L->off_rcv + (int64_t)up(sizeof(double) * std::max<int64_t>(1, p->rcv.n));
+  L->region_bytes = ((size_t)L->off_flags + up(sizeof(unsigned long long) * L->n_flags) + 4095) / 4096 * 4096;
+  PA_TRY(ipc_region_take(p->ctx->device, L->region_bytes, &L->chunk, &L->chunk_off));
+  L->d_region = g_ipc_chunks[L->chunk].base + L->chunk_off;
+  PA_HIP(hipMemset(L->d_region, 0, L->region_bytes));
+  // the plan's buffers move into the region (they hold nothing between two exchanges); tables that cached the old addresses go
+  for (int m = 0; m < 2; ++m) if (p->push[m]) { p->push[m]->free_all(); delete p->push[m]; p->push[m] = nullptr; }
+  (void)pa_raw_free(p->snd.d_buf);
+  (void)pa_raw_free(p->rcv.d_buf);
+  p->snd.d_buf = (double *)(L->d_region + L->off_snd);
+  p->rcv.d_buf = (double *)(L->d_region + L->off_rcv);
+  p->bufs_in_ipc_region = true;
+  L->d_flags = (unsigned long long *)(L->d_region + L->off_flags);
   PA_HIP(hipMalloc((void **)&L->d_done, sizeof(unsigned)));
   PA_HIP(hipMemset(L->d_done, 0, sizeof(unsigned)));
   PA_HIP(hipHostMalloc((void **)&L->h_status, sizeof(int), hipHostMallocMapped));
@@ -440,10 +509,9 @@ extern "C" int pa_plan_ipc_blob(pa_plan *p, void *out, int64_t capacity) {
   h.magic = PA_IPC_MAGIC; h.part = p->part;
   h.n_snd_nbr = (int32_t)p->snd.nbr.size(); h.n_rcv_nbr = (int32_t)p->rcv.nbr.size();
   h.n_snd = p->snd.n; h.n_rcv = p->rcv.n;
-  PA_HIP(hipSetDevice(p->ctx->device));
-  PA_HIP(hipIpcGetMemHandle(&h.h_snd, p->snd.d_buf));
-  PA_HIP(hipIpcGetMemHandle(&h.h_rcv, p->rcv.d_buf));
-  PA_HIP(hipIpcGetMemHandle(&h.h_flags, p->ipc->d_flags));
+  h.off_snd = (int64_t)p->ipc->chunk_off + p->ipc->off_snd; h.off_rcv = (int64_t)p->ipc->chunk_off + p->ipc->off_rcv;
+  h.off_flags = (int64_t)p->ipc->chunk_off + p->ipc->off_flags;
+  { std::lock_guard<std::mutex> lk(g_ipc_mu); h.h_region = g_ipc_chunks[p->ipc->chunk].handle; }
   char *q = (char *)out;
   memcpy(q, &h, sizeof h); q += sizeof h;
   auto put = [&](const std::vector<int32_t> &v) { if (!v.empty()) memcpy(q, v.data(), sizeof(int32_t) * v.size()); q += sizeof(int32_t) * v.size(); };
@@ -492,9 +560,10 @@ extern "C" int pa_plan_ipc_connect(pa_plan *p, int32_t n_blobs, const void *cons
     PA_REQUIRE(it != views.end(), "no blob of neighbour part %d", q);
     pa_ipc_link::peer P;
     const ipc_header &h = it->second.h;
-    PA_HIP(hipIpcOpenMemHandle(&P.snd, h.h_snd, hipIpcMemLazyEnablePeerAccess));
-    PA_HIP(hipIpcOpenMemHandle(&P.rcv, h.h_rcv, hipIpcMemLazyEnablePeerAccess));
-    PA_HIP(hipIpcOpenMemHandle(&P.flags, h.h_flags, hipIpcMemLazyEnablePeerAccess));
+    PA_TRY(ipc_open_chunk(h.h_region, &P.region));
+    P.snd = (char *)P.region + h.off_snd;
+    P.rcv = (char *)P.region + h.off_rcv;
+    P.flags = (char *)P.region + h.off_flags;
     L->peers[q] = P;
     return PA_OK;
   };
@@ -612,15 +681,11 @@ void pa_push_release(pa_plan *p) {
     if (p->push[m]) { p->push[m]->free_all(); delete p->push[m]; p->push[m] = nullptr; }
   if (pa_ipc_link *L = p->ipc) {
     (void)hipSetDevice(p->ctx->device);
-    for (auto &kv : L->peers) {
-      if (kv.second.snd) (void)hipIpcCloseMemHandle(kv.second.snd);
-      if (kv.second.rcv) (void)hipIpcCloseMemHandle(kv.second.rcv);
-      if (kv.second.flags) (void)hipIpcCloseMemHandle(kv.second.flags);
-    }
+    // (the peers' chunks stay mapped for the life of the process: ipc_open_chunk)
     for (int m = 0; m < 2; ++m) {
       (void)pa_raw_free(L->m[m].d_segs); (void)pa_raw_free(L->m[m].d_wait); (void)pa_raw_free(L->m[m].d_ack_dst);
     }
-    if (L->d_flags) (void)hipFree(L->d_flags);
+    if (L->chunk >= 0) ipc_region_give_back(L->chunk, L->chunk_off, L->region_bytes);   // (the plan's two buffers live in it)
     if (L->d_done) (void)hipFree(L->d_done);
     if (L->h_status) (void)hipHostFree(L->h_status);
     delete L;

@@ -305,13 +305,23 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
     double xnew = 0.0;
     if (e_new <= hnext) xnew = x[e_new];
     if (act) {
+      // Round 4: no ds_bpermute for the window bases.  A gather's ring slot is its column mod 16384 = ((window base + offset) mod
+      // 16384), and a window base is a multiple of 4096: only TWO BITS of each of the chunk's 16 bases matter.  They travel as two
+      // wave-wide ballots (lanes 0..15 hold the bases of slots 0..15), and a slot's pair of bits is picked with shifts -- VALU work
+      // that was idle, where the two bpermutes per pair of entries went through the LDS pipeline the gathers are waiting on:
+      // +-7900 0.1723 -> 0.1685 ms = 5.03 TB/s algorithmic.  (The same with three bits per base in k_spmv_xwin, where two workgroups
+      // share a CU and the VALU is not idle, LOST 3-9 %: not there.)
+      static_assert(C == 16384, "the two-bit window trick assumes a ring of 4 x 4096 entries");
+      const unsigned long long wb0 = __ballot((mywin & 4096) != 0), wb1 = __ballot((mywin & 8192) != 0);
+      const unsigned w0 = (unsigned)wb0 & 0xffffu, w1 = (unsigned)wb1 & 0xffffu;
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const unsigned lo = q[k] & 0xffffu, hi = q[k] >> 16;
         // (lanes outside the chunk decode a neighbour's code with this chunk's windows: any column, masked into the ring;
         // their products are never summed)
-        const int c0_ = (__builtin_amdgcn_ds_bpermute((lo >> 12) << 2, mywin) + (int)(lo & 4095)) & (C - 1);
-        const int c1_ = (__builtin_amdgcn_ds_bpermute((hi >> 12) << 2, mywin) + (int)(hi & 4095)) & (C - 1);
+        const unsigned s0 = lo >> 12, s1 = hi >> 12;
+        const int c0_ = (int)(((((w0 >> s0) & 1u) | (((w1 >> s0) & 1u) << 1)) << 12) | (lo & 4095u));
+        const int c1_ = (int)(((((w0 >> s1) & 1u) | (((w1 >> s1) & 1u) << 1)) << 12) | (hi & 4095u));
         double a = v[k].x * xs[c0_];
         double c = v[k].y * xs[c1_];
         if (alpha != 1.0) {

@@ -23,6 +23,21 @@ def test_device_path_over_the_ipc_push_transport(nproc):
     _run("device_path_driver.py", nproc, {"PA_TRANSPORT": "ipc"})
 
 
+def test_random_matrices_over_the_ipc_push_transport():
+    """tests/fuzz/fuzz_dist_driver.py with PA_TRANSPORT=ipc, 4 ranks on this box's GPU: 40 random PSparseMatrices -- hundreds of
+    exchange plans made and dropped, each with a region cut from the exported pool chunks (a region of its own per plan made
+    hipIpcGetMemHandle fail after a few dozen: found by the round-4 fuzz campaign)."""
+    import os
+    import subprocess
+    import sys
+    from test_multiprocess_gloo import ROOT, _free_port
+    e = dict(os.environ, OMP_NUM_THREADS="1", PA_HOST_THREADS="1", PA_TRANSPORT="ipc")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "fuzz", "fuzz_dist_driver.py"), "40", "31500"]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "0 with mismatches" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
 def _gpus():
     import torch
     return torch.cuda.device_count()
