@@ -24,6 +24,8 @@
 //     eighth of the rows; neighbouring workgroups of one XCD share x lines in that XCD's 4 MiB L2.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -390,7 +392,7 @@ extern "C" int pa_ctx_destroy(pa_ctx *c) {
   (void)pa_raw_free(c->d_partials);
   (void)pa_raw_free(c->d_scalar);
   if (c->d_dotpart) pa_dev_free(c, c->d_dotpart);
-  if (c->d_xalpha) pa_dev_free(c, c->d_xalpha);
+  for (int k = 0; k < 2; ++k) if (c->d_xalpha[k]) pa_dev_free(c, c->d_xalpha[k]);
   if (c->d_vdict_scratch) (void)pa_raw_free(c->d_vdict_scratch);
   pa_arena_destroy(c);
   (void)hipEventDestroy(c->ev_compute);
@@ -1847,16 +1849,17 @@ static int spmv_on(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int ys
     // and adds nzval*axj -- a*(x*alpha), one rounding apart from the CSR method's (a*x)*alpha unless alpha is a power of two.
     // x .* alpha goes to a scratch vector (one pass over x: 16 B per column next to 12 B per stored entry) and the kernel runs with
     // alpha = 1: per output entry the same products, added in ascending column as the column-major scatter loop adds them.
-    if (xlen > c->n_xalpha) {
+    const int sx = st == c->s[1] ? 1 : 0;            // (a scratch per stream: pa_mul_all runs own x ghost on the comm stream beside own x own)
+    if (xlen > c->n_xalpha[sx]) {
       PA_REQUIRE(!c->capturing, "the scaled copy of x needs its scratch before a capture opens (run the product once eagerly)");
       PA_HIP(hipStreamSynchronize(st));
-      if (c->d_xalpha) pa_dev_free(c, c->d_xalpha);
-      c->d_xalpha = nullptr; c->n_xalpha = 0;
-      PA_TRY(pa_dev_alloc(c, (void **)&c->d_xalpha, sizeof(double) * (size_t)(xlen + 2), PA_MEM_VECTOR));
-      c->n_xalpha = xlen;
+      if (c->d_xalpha[sx]) pa_dev_free(c, c->d_xalpha[sx]);
+      c->d_xalpha[sx] = nullptr; c->n_xalpha[sx] = 0;
+      PA_TRY(pa_dev_alloc(c, (void **)&c->d_xalpha[sx], sizeof(double) * (size_t)(xlen + 2), PA_MEM_VECTOR));
+      c->n_xalpha[sx] = xlen;
     }
-    if (xlen) hipLaunchKernelGGL(k_axpby, dim3(grid_for(xlen, 256)), dim3(256), 0, st, c->d_xalpha, xs_all, xlen, alpha, 0.0);
-    xs_all = c->d_xalpha;
+    if (xlen) hipLaunchKernelGGL(k_axpby, dim3(grid_for(xlen, 256)), dim3(256), 0, st, c->d_xalpha[sx], xs_all, xlen, alpha, 0.0);
+    xs_all = c->d_xalpha[sx];
     alpha = 1.0;
   }
   for (const pa_csr *S = A; S; S = S->next) {          // one slab unless the block has 2^31 stored entries or more
@@ -2453,6 +2456,8 @@ extern "C" int pa_plan_create(pa_ctx *c, int32_t part, int64_t n_local, int32_t 
   PA_REQUIRE(n_snd >= 0 && n_rcv >= 0 && n_local >= 0, "negative size");
   PA_REQUIRE((n_snd == 0 || nbr_snd) && (n_rcv == 0 || nbr_rcv), "neighbour arrays are NULL");
   pa_plan *p = new pa_plan();
+  static std::atomic<uint64_t> next_serial{1};
+  p->serial = next_serial++;
   p->ctx = c; p->part = part - index_base; p->n_local = n_local;
   auto side = [&](pa_plan::side &s, int32_t n, const int32_t *nbr, const int32_t *ptrs, const int32_t *idx) -> int {
     s.nbr.assign(nbr, nbr + n);

@@ -52,8 +52,8 @@ struct pa_ctx {
   double *d_dotpart = nullptr;            // per-chunk partial sums of a fused product + dot (pa_mul_dot)
   int64_t n_dotpart = 0;
   void *d_vdict_scratch = nullptr;        // hash table, slot codes and counter of the value-dictionary build (vdict_build)
-  double *d_xalpha = nullptr;             // x .* alpha of a product on a CSC-made block (pa_spmv), grown on demand
-  int64_t n_xalpha = 0;
+  double *d_xalpha[2] = {nullptr, nullptr};   // x .* alpha of a product on a CSC-made block (pa_spmv), one per stream, grown on demand
+  int64_t n_xalpha[2] = {0, 0};
   bool capturing = false;                 // a pa_graph_begin is open on the compute stream
   bool keep_raw_columns = false;          // pa_ctx_keep_raw_columns: blocks created now keep their Int32 columns in HBM (pa_rowsel.hip)
   int comm_priority = 0;                  // priority the comm stream was created with (the device's greatest)
@@ -168,6 +168,7 @@ struct pa_plan {
   };
   pa_ctx *ctx = nullptr;
   int32_t part = 0;  // 0-based
+  uint64_t serial = 0;            // unique per plan ever made in this process (a cached push table is keyed on it, not on the address)
   int64_t n_local = 0;
   side snd, rcv;     // assembly orientation (src/p_vector.jl:418-426)
   int64_t n_tgt = 0;

@@ -144,6 +144,7 @@ static inline pa_plan::side &in_side(pa_plan *p, int mode) { return mode == PA_A
 
 struct pa_push_table {
   std::vector<pa_plan *> key;
+  std::vector<uint64_t> serials;    // the plans' serial numbers: an address may come back with another plan behind it
   // one launch per device (context) that holds parts of the group
   struct launch {
     pa_ctx *ctx = nullptr;
@@ -180,6 +181,7 @@ static int upload_vec(const std::vector<T> &h, T **d) {
 static int build_local_table(pa_plan *const *plans, int n_parts, int mode, pa_push_table **out) {
   pa_push_table *T = new pa_push_table();
   T->key.assign(plans, plans + n_parts);
+  for (int r = 0; r < n_parts; ++r) T->serials.push_back(plans[r]->serial);
   std::map<pa_ctx *, int> at;
   for (int r = 0; r < n_parts; ++r) {
     pa_ctx *c = plans[r]->ctx;
@@ -252,7 +254,9 @@ static int build_local_table(pa_plan *const *plans, int n_parts, int mode, pa_pu
 
 static int local_table(pa_plan *const *plans, int n_parts, int mode, pa_push_table **out) {
   pa_push_table *&T = plans[0]->push[mode];
-  if (T && ((int)T->key.size() != n_parts || !std::equal(T->key.begin(), T->key.end(), plans))) {
+  bool same = T && (int)T->key.size() == n_parts && std::equal(T->key.begin(), T->key.end(), plans);
+  for (int r = 0; same && r < n_parts; ++r) same = T->serials[r] == plans[r]->serial;
+  if (T && !same) {
     T->free_all();
     delete T;
     T = nullptr;

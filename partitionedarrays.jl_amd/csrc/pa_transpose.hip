@@ -238,7 +238,9 @@ int pa_csr_create_remapped(const pa_csr *A, const int32_t *map, int64_t n_cols_n
   PA_TRY(d2h(s, &bad, d_bad, 1));
   PA_HIP(hipGetLastError());
   PA_REQUIRE(bad == 0, "%d stored entries sit in columns the map does not carry", bad);
-  return pa_csr_from_device(c, n_rows, n_cols_new, nnz, d_rp, d_col, d_val, out);
+  PA_TRY(pa_csr_from_device(c, n_rows, n_cols_new, nnz, d_rp, d_col, d_val, out));
+  for (pa_csr *S = *out; S; S = S->next) S->alpha_inside = A->alpha_inside;   // (the twin of a CSC-made block keeps its 5-argument form)
+  return PA_OK;
 }
 
 // ---- the same block with its rows and / or columns renumbered (round 4: library-side renumbering for blocks without locality) ----
@@ -307,7 +309,9 @@ extern "C" int pa_csr_create_permuted(const pa_csr *A, const int32_t *row_pos, c
   hipLaunchKernelGGL(kt_lower_bounds, grid1(n_rows + 1), dim3(256), 0, s, row_pos && nnz ? d_keys : d_row, (int)nnz, (int)n_rows, d_rp);
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(s));
-  return pa_csr_from_device(c, n_rows, n_cols, nnz, d_rp, d_fcol, d_fval, out);
+  PA_TRY(pa_csr_from_device(c, n_rows, n_cols, nnz, d_rp, d_fcol, d_fval, out));
+  for (pa_csr *S = *out; S; S = S->next) S->alpha_inside = A->alpha_inside;
+  return PA_OK;
 }
 
 // ---- a bandwidth-reducing order of a square block, computed on the device: reverse Cuthill-McKee by level sets -------------------

@@ -62,3 +62,40 @@ def test_csc_form_can_be_switched_per_block():
     L.call("pa_csr_set_alpha_inside", blk.h, 1)
     pa.spmv_(yd, blk, xd, L.SEG_OWN, L.SEG_OWN, 0.3, 0.0)
     assert np.array_equal(yd.download(), orc.mul5_csc(np.zeros(A.m), x, colptr, rowval, nzval, 0.3, 0.0))
+
+
+def test_mul_of_a_matrix_whose_blocks_are_csc_follows_the_csc_form_through_every_route(orc):
+    """mul!(c,a,b,alpha,beta) (src/p_sparse_matrix.jl:2105-2142) when the local blocks keep the default SparseMatrixCSC storage:
+    own x own and own x ghost each follow SparseArrays' a*(x*alpha) -- also through pa_mul_all, where own x ghost is a TWIN of the
+    block (columns renamed to receive-buffer positions, made at the first product) running on the comm stream beside own x own."""
+    from gpu_common import ranks, upload
+    A, _ = pa.build_p_matrix(ranks(4), 6, 5, 4, 12, 10, 4, 2, 2, 1, keep_host=True, fused=True)
+    Ao, _, _ = orc.hpcg_build_p_matrix(6, 5, 4, 2, 2, 1)
+
+    def csc_block(h):
+        cp, rv, nz = orc.csr_to_csc(orc.CSR(h.m, h.n, h.rowptr, h.colval, h.nzval))
+        return pa.DeviceCSR.from_csc(h.m, h.n, cp, rv, nz), (cp, rv, nz)
+    blocks, host = [], []
+    for h in A.host_blocks.items:
+        oo, oo_h = csc_block(h[0])
+        oh, oh_h = csc_block(h[1])
+        blocks.append(pa.SplitMatrixBlocks(oo, oh))
+        host.append((oo_h, oh_h))
+    Ac = pa.PSparseMatrix(pa.DebugArray(blocks), A.row_partition, A.col_partition, True)
+    alpha, beta = 0.3, -1.7
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    xc = [v.copy() for v in xo]
+    orc.consistent(xc, Ao.cols)
+    y0 = [orc.hash_x(r.local_to_global + 7) for r in Ao.rows]
+    want = []
+    for (oo_h, oh_h), xv, yv, c in zip(host, xc, y0, Ao.cols):
+        w = orc.mul5_csc(yv[:c.n_own].copy(), xv[:c.n_own], *oo_h, alpha, beta)
+        want.append(orc.mul5_csc(w, xv[c.n_own:], *oh_h, alpha, 1.0))
+    for f in (pa.mul5_, pa.mul_c_):
+        x = upload([v.copy() for v in xo], Ac.col_partition)
+        y = upload([v.copy() for v in y0], Ac.row_partition)
+        for _ in range(2 if f is pa.mul_c_ else 1):                 # (twice: the second product runs on the twin)
+            y = upload([v.copy() for v in y0], Ac.row_partition)
+            f(y, Ac, x, alpha, beta)
+        for got, e in zip(y.own_values().items, want):
+            assert np.array_equal(got, e), f.__name__
