@@ -380,23 +380,35 @@ def psparse_from_coo_device(I, J, V, row_partition, keep_host=False) -> PSparseM
     return PSparseMatrix(blocks, row_partition, cols, True, host)
 
 
-def psparse_from_coo(I, J, V, row_partition, keep_host=False) -> PSparseMatrix:
-    """The route of HPCG.build_p_matrix / test/gallery_tests.jl:33: find_owner -> union_ghost -> psparse."""
+def psparse_from_coo(I, J, V, row_partition, keep_host=False, renumber=False) -> PSparseMatrix:
+    """The route of HPCG.build_p_matrix / test/gallery_tests.jl:33: find_owner -> union_ghost -> psparse.
+    renumber=True: the result goes through renumber_for_locality (parts whose own x own block has no locality are stored in a
+    reverse Cuthill-McKee order; use the RETURNED matrix's row_partition / col_partition for the vectors)."""
     if _device_assembly_applies(row_partition, I):
-        return psparse_from_coo_device(I, J, V, row_partition, keep_host=keep_host)
-    J_owner = find_owner(row_partition, J)
-    cols = pmap(union_ghost, row_partition, J, J_owner)
-    return psparse(I, J, V, row_partition, cols, assembled=True, keep_host=keep_host)
+        A = psparse_from_coo_device(I, J, V, row_partition, keep_host=keep_host)
+    else:
+        J_owner = find_owner(row_partition, J)
+        cols = pmap(union_ghost, row_partition, J, J_owner)
+        A = psparse(I, J, V, row_partition, cols, assembled=True, keep_host=keep_host)
+    return renumber_for_locality(A) if renumber else A
 
 
 def _check_axes(c: PVector, a: PSparseMatrix, b: PVector):
     """@boundscheck matching_own_indices / matching_ghost_indices (src/p_sparse_matrix.jl:2091-2093)."""
+
+    def same_layout(u, v):
+        pu, pv_ = getattr(u, "device_own_perm", None), getattr(v, "device_own_perm", None)
+        return pu is pv_ or (pu is not None and pv_ is not None and np.array_equal(pu, pv_))
 
     def chk(ci, ri, coli, bi):
         if ci.n_own != ri.n_own:
             raise L.PAError("matching_own_indices(axes(c,1),axes(a,1)) failed")
         if bi.n_own != coli.n_own or bi.n_ghost != coli.n_ghost:
             raise L.PAError("matching_own/ghost_indices(axes(a,2),axes(b,1)) failed")
+        # a renumbered matrix (renumber_for_locality) lays its vectors out in its own order: vectors must be made on ITS partitions
+        if not same_layout(ci, ri) or not same_layout(bi, coli):
+            raise L.PAError("the vectors' device layout is not the matrix's: make them on A.row_partition / A.col_partition of the "
+                            "renumbered matrix (renumber_for_locality returns new partitions)")
 
     pmap(chk, c.index_partition, a.row_partition, a.col_partition, b.index_partition)
 
@@ -602,6 +614,15 @@ def mul5_transpose_(c: PVector, a: PSparseMatrix, b: PVector, alpha, beta) -> PV
     from . import p_vector as pv
     if not a.assembled:
         raise L.PAError("mul!(c,transpose(a),b,...) needs an assembled matrix (@assert a.assembled, :2146)")
+
+    def chk(ci, coli, bi, ri):
+        if ci.n_own != coli.n_own or ci.n_ghost != coli.n_ghost or bi.n_own != ri.n_own:
+            raise L.PAError("c must live on axes(a,2) and b on axes(a,1)")
+        for u, v in ((ci, coli), (bi, ri)):
+            pu, pv_ = getattr(u, "device_own_perm", None), getattr(v, "device_own_perm", None)
+            if not (pu is pv_ or (pu is not None and pv_ is not None and np.array_equal(pu, pv_))):
+                raise L.PAError("the vectors' device layout is not the matrix's (renumber_for_locality returns new partitions)")
+    pmap(chk, c.index_partition, a.col_partition, b.index_partition, a.row_partition)
     tb = transposed_blocks(a)
     vp = c.vector_partition
     direct = isinstance(vp, DebugArray) or (isinstance(vp, TorchDistArray) and (

@@ -69,6 +69,23 @@ def test_renumbered_matrix_gives_the_oracle_s_bits(orc, nodes, P):
         assert abs(d - dref) <= 1e-13 * abs(dref)
 
 
+def test_vectors_of_the_unrenumbered_partition_are_refused(orc):
+    n, _, Ip, Jp, Vp = _shuffled_fem(orc, (40, 30), (1, 1), 7)
+    rows = pa.uniform_partition(ranks(1), (1,), (n,))
+    A = pa.psparse_from_coo(pa.DebugArray([Ip]), pa.DebugArray([Jp]), pa.DebugArray([Vp]), rows)
+    A2 = pa.psparse_from_coo(pa.DebugArray([Ip]), pa.DebugArray([Jp]), pa.DebugArray([Vp]), rows, renumber=True)
+    assert A2.bandwidths.items[0][1] * 2 <= A2.bandwidths.items[0][0]
+    x_old, y_new = pa.pones(A.col_partition), pa.pzeros(A2.row_partition)
+    with pytest.raises(L.PAError):
+        pa.mul_(y_new, A2, x_old)                                   # x was laid out for the unrenumbered matrix
+    with pytest.raises(L.PAError):
+        pa.mul_c_(pa.pzeros(A.row_partition), A2, pa.pones(A2.col_partition))
+    pa.mul_(y_new, A2, pa.pones(A2.col_partition))                  # its own partitions: fine
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x_old)
+    assert np.array_equal(y.own_values().items[0], y_new.own_values().items[0])
+
+
 def test_permuted_block_keeps_every_row_s_entry_order():
     """pa_csr_create_permuted against numpy: row i of the new block = row inv[i] of the old one with its columns renamed, entries
     in the OLD order (not sorted by new column)."""
