@@ -287,6 +287,11 @@ int pa_csr_create_permuted(const pa_csr *A, const int32_t *row_pos, const int32_
  * caller's numbering; NULL = ascending row, pa_csr_create_transpose itself. */
 int pa_csr_create_transpose_ranked(const pa_csr *A, const int32_t *row_rank, pa_csr **out);
 
+/* The block as a chain of `pieces` column pieces (2..8; entry (r, c) in piece floor((c - lower band edge at r) / width)): what the
+ * library does by itself for unstructured rows whose band is wider than the sliding x window (PA_SPMV_COLSPLIT=0: never).  pa_spmv
+ * runs the pieces in sequence, the later ones accumulating: the same additions in the same order as on the unsplit block. */
+int pa_csr_create_colsplit(const pa_csr *A, int pieces, pa_csr **out);
+
 /* ---- introspection of a CSR block (what the row-split kernel reads; none of it is needed to use the block) ---------- */
 /* How the row-split chunks of A get their column indices (library-internal index compression; the values, the
  * results and pa_csr_update_values are unaffected): recomputed from row patterns / 16-bit windowed stream / 32-bit. */

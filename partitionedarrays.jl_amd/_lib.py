@@ -164,6 +164,7 @@ _SIGS = {
     "pa_csr_locality_order": [P, P, C.POINTER(i64), C.POINTER(i64)],
     "pa_csr_create_permuted": [P, P, P, PP],
     "pa_csr_create_transpose_ranked": [P, P, PP],
+    "pa_csr_create_colsplit": [P, cint, PP],
     "pa_sell_create": [P, i64, i64, i64, P, P, cint, cint, P, cint, PP],
     "pa_sell_destroy": [P],
     "pa_sell_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],

@@ -41,6 +41,7 @@
 #include "pa_setup.h"
 
 thread_local std::string g_pa_err;
+thread_local int pa_tls_piece_build = 0;       // > 0 while pa_csr_colsplit_if_wide builds its pieces through csr_build
 
 void pa_set_err(const char *fmt, ...) {
   char buf[512];
@@ -108,6 +109,11 @@ __global__ void k_fill(double *__restrict__ y, int64_t n, double v) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) y[i] = v;
+}
+
+__global__ void k_gather_values(double *__restrict__ dst, const double *__restrict__ src, const int *__restrict__ idx, int64_t n) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) dst[p] = src[idx[p]];
 }
 
 __global__ void k_pack(double *__restrict__ buf, const double *__restrict__ v, const int *__restrict__ idx,
@@ -1065,7 +1071,7 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
     if (cs.use_c16 && !cs.use_pattern && !compact && !(ex && atoi(ex) == 0) && A->n_chunks >= 64) {
       const bool forced = ex && atoi(ex) == 2;
       const char *er = getenv("PA_SPMV_XRING");              // 0: windows only, 1 (default): the window tiers, then the ring, 2: ring only
-      const int ring = er ? atoi(er) : 1;
+      const int ring = pa_tls_piece_build ? 2 : er ? atoi(er) : 1;     // (a column piece is cut for the ring)
       std::vector<int32_t> cmax_host;
       pa_xw_plan P;
       if (on_device) {
@@ -1076,6 +1082,8 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
         PA_TRY(pa_dev_xw_chunk_stats(c, A->d_crp, A->d_col, A->d_chunk_row, A->d_win, A->n_chunks, PA_XR_CAP, S.cmin.data(),
                                      S.cmax.data(), S.lines.data()));
         pa_plan_xw_from_stats(crp.data(), chunk_row, S, forced, P, ring);
+        for (int64_t k = 0; k < A->n_chunks; ++k)
+          if (S.cmax[k] >= 0) A->xw_max_span = std::max<int64_t>(A->xw_max_span, (int64_t)S.cmax[k] - S.cmin[k] + 1);
         cmax_host.swap(S.cmax);
       } else {
         pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz), ring, &cmax_host);
@@ -1175,6 +1183,14 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, con
   head->t_rows = n_rows;
   head->t_nnz = nnz;
   *out = head;
+  // a block of unstructured rows whose band is wider than the sliding x window holds: split by columns into pieces the window does
+  // hold (pa_transpose.hip; the pieces are built through this function again, hence the guard)
+  if (!pa_tls_piece_build && !head->next) {
+    pa_csr *split = nullptr;
+    const int st = pa_csr_colsplit_if_wide(head, &split);
+    if (st != PA_OK) (void)hipGetLastError();          // (the unsplit block serves)
+    else if (split) { csr_free_chain(head); *out = split; }
+  }
   return PA_OK;
 }
 
@@ -1348,12 +1364,25 @@ extern "C" int pa_csr_update_values(pa_csr *A, const double *nzval) {
   PA_REQUIRE(A && (nzval || A->t_nnz == 0), "bad arguments");
   if (A->t_nnz == 0) return PA_OK;
   PA_HIP(hipSetDevice(A->ctx->device));
+  double *d_all = nullptr;                                  // column split: the pieces gather from the caller's order
+  if (A->colsplit) {
+    PA_HIP(pa_raw_malloc(&d_all, sizeof(double) * (size_t)A->t_nnz));
+    if (hipMemcpyAsync(d_all, nzval, sizeof(double) * (size_t)A->t_nnz, hipMemcpyHostToDevice, A->ctx->s[0]) != hipSuccess) {
+      (void)pa_raw_free(d_all);
+      pa_set_err("pa_csr_update_values: upload failed");
+      return PA_ERR_HIP;
+    }
+  }
   for (pa_csr *S = A; S; S = S->next) {
     if (S->use_vdict || S->vdict_stale) { S->vdict_stale = true; S->vdict_products = 0; }
     S->use_vdict = false;            // the codes describe the old values: back to the fp64 stream (vdict_maintain renews them)
-    if (S->nnz) PA_HIP(hipMemcpyAsync(S->d_val, nzval + S->nnz0, sizeof(double) * S->nnz, hipMemcpyHostToDevice, A->ctx->s[0]));
+    if (!S->nnz) continue;
+    if (A->colsplit) hipLaunchKernelGGL(k_gather_values, dim3(grid_for(S->nnz, 256)), dim3(256), 0, A->ctx->s[0], S->d_val, (const double *)d_all, S->d_src, S->nnz);
+    else PA_HIP(hipMemcpyAsync(S->d_val, nzval + S->nnz0, sizeof(double) * S->nnz, hipMemcpyHostToDevice, A->ctx->s[0]));
   }
   PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
+  if (d_all) (void)pa_raw_free(d_all);
+  PA_HIP(hipGetLastError());
   return PA_OK;
 }
 
@@ -1366,9 +1395,11 @@ extern "C" int pa_csr_update_values_from(pa_csr *A, const pa_vec *src, int64_t o
   for (pa_csr *S = A; S; S = S->next) {
     if (S->use_vdict || S->vdict_stale) { S->vdict_stale = true; S->vdict_products = 0; }
     S->use_vdict = false;
-    if (S->nnz)
-      PA_HIP(hipMemcpyAsync(S->d_val, src->d + offset + S->nnz0, sizeof(double) * S->nnz, hipMemcpyDeviceToDevice, A->ctx->s[0]));
+    if (!S->nnz) continue;
+    if (A->colsplit) hipLaunchKernelGGL(k_gather_values, dim3(grid_for(S->nnz, 256)), dim3(256), 0, A->ctx->s[0], S->d_val, (const double *)(src->d + offset), S->d_src, S->nnz);
+    else PA_HIP(hipMemcpyAsync(S->d_val, src->d + offset + S->nnz0, sizeof(double) * S->nnz, hipMemcpyDeviceToDevice, A->ctx->s[0]));
   }
+  PA_HIP(hipGetLastError());
   return PA_OK;
 }
 
@@ -1378,6 +1409,7 @@ static void csr_free_chain(pa_csr *A) {
     pa_dev_free(A->ctx, A->d_crp);
     pa_dev_free(A->ctx, A->d_col);
     if (A->d_raw_col) pa_dev_free(A->ctx, A->d_raw_col);
+    if (A->d_src) pa_dev_free(A->ctx, A->d_src);
     pa_dev_free(A->ctx, A->d_val);
     pa_dev_free(A->ctx, A->d_chunk_row);
     if (A->d_row_ids) pa_dev_free(A->ctx, A->d_row_ids);
@@ -1864,8 +1896,8 @@ static int spmv_on(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int ys
   }
   for (const pa_csr *S = A; S; S = S->next) {          // one slab unless the block has 2^31 stored entries or more
     double *ys = y->d + yoff + S->row0;
-    double kbeta = beta;
-    if (S->compact && beta != 1.0) {
+    double kbeta = S->accumulate ? 1.0 : beta;             // (a column piece behind the first adds onto what the pieces before it left)
+    if (S->compact && kbeta != 1.0) {
       // rows without stored entries still get beta*y (rmul!/fill! of the reference); the kernel then accumulates
       if (S->n_rows) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n_rows, 256)), dim3(256), 0, st, ys, S->n_rows, beta);
       kbeta = 1.0;
@@ -2909,8 +2941,8 @@ static int spmv_dot_block(const pa_csr *A, const double *x, double *y, double be
   for (const pa_csr *S = A; S; S = S->next) {
     double *ys = y + S->row0;
     const double *us = u + S->row0;
-    double kbeta = beta;
-    if (S->compact && beta != 1.0) {
+    double kbeta = S->accumulate ? 1.0 : beta;
+    if (S->compact && kbeta != 1.0) {
       if (S->n_rows) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n_rows, 256)), dim3(256), 0, c->s[0], ys, S->n_rows, beta);
       kbeta = 1.0;
     }

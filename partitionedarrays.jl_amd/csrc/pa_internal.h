@@ -151,6 +151,13 @@ struct pa_csr {
   // carries the block's totals.
   pa_csr *next = nullptr;
   int64_t row0 = 0, nnz0 = 0;
+  // Round 4: a COLUMN-SPLIT chain (csr_colsplit, pa_transpose.hip) -- every node holds ALL rows of the block and the entries whose
+  // columns fall into its band of the diagonal; node j > 0 accumulates (beta = 1) onto what the nodes before it left in y.  Columns
+  // ascend inside a row, so the pieces' entries are consecutive runs of the row's sum: the same additions in the same order.
+  bool accumulate = false;         // this node adds onto y whatever beta the caller passed (a column piece behind the first)
+  bool colsplit = false;           // (head) the chain is a column split, not row slabs
+  int32_t *d_src = nullptr;        // column split: original entry index of every stored entry (value updates, downloads)
+  int64_t xw_max_span = 0;         // widest column span of a 16-bit chunk (what decides a column split)
   int64_t t_rows = 0, t_nnz = 0;
 };
 

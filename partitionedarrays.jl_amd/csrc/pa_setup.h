@@ -56,6 +56,12 @@ int pa_dev_decode_entries(const pa_csr *A, int32_t *d_row, int32_t *d_col);
 // the same entries in the same order with column j renamed map[j] (host, A->n_cols entries, -1 = absent): see pa_transpose.hip
 int pa_csr_create_remapped(const pa_csr *A, const int32_t *map, int64_t n_cols_new, pa_csr **out);
 
+// pa_transpose.hip: when A (one slab, unstructured rows on the 16-bit stream) has chunks whose columns span more than the sliding x
+// window holds (and PA_SPMV_COLSPLIT != 0), *out = the same block as a chain of column pieces (pa_internal.h: accumulate / colsplit /
+// d_src), else *out = NULL.  force_pieces > 0 (tests): that many pieces whatever the spans.
+int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces = 0);
+extern thread_local int pa_tls_piece_build;
+
 // min / max of a device Int32 array (column range check of an uploaded block)
 int pa_dev_minmax_i32(pa_ctx *c, const int32_t *d, int64_t n, int32_t *mn, int32_t *mx);
 

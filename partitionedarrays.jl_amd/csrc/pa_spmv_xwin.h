@@ -223,9 +223,11 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xwin(
 // is then read from L2 once per run of chunks plus once per entry, whatever the band (up to +-8000), and a gather's slot is
 // the column itself masked -- no window base to subtract.  Same streams, same products, same order as k_spmv_rowsplit: same bits.
 #define PA_XR_CAP 16384
-#define PA_XR_MAXG 256      // chunks per ring group at most (fewer on a small block)
-#define PA_XR_WANT_GROUPS 1024   // one workgroup per CU is resident (157 KB of LDS): the runs are cut so that there are at most
-                                 // 4 x 256 of them -- 772 runs (3 per CU and 4 left over) ran a quarter longer than 768 would
+#define PA_XR_MAXG 1024     // chunks per ring group at most (fewer on a small block)
+#define PA_XR_WANT_GROUPS 256    // one workgroup per CU is resident (157 KB of LDS) and every run pays a first fill of its whole span
+                                 // (a latency-bound phase nothing overlaps): ONE run per CU.  Measured (round 4, 4 M rows x 16, +-7900):
+                                 // 256 runs 0.1537 ms = 5.5 TB/s algorithmic, 512 0.1593, 768 0.1651, 1024 0.1685, 2048 0.1918
+                                 // (PA_SPMV_XRING_GROUPS); 772 runs -- 3 per CU and 4 left over -- had run a quarter longer than 768
 
 // BLK lanes work on one chunk (256 x 6 entries each as everywhere else, or 512 x 4 with the lanes past the chunk's 1536
 // entries idle: twice the waves on the CU for the same LDS)
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
   d2 v[NPT / 2];
   unsigned q[NPT / 2];
   int mywin = 0, ra = 0, re = 0;
-  double ur = 0.0;
+  double ur = 0.0, yr = 0.0;
   int r0 = 0, r1 = 0, p0 = 0, p1 = 0;
   int nr0 = 0, nr1 = 0, np0 = 0, np1 = 0;
   auto meta = [&](int ch, int &a0, int &a1, int &b0, int &b1) {
@@ -274,6 +276,9 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
       ra = crp[r0 + t];
       re = crp[r0 + t + 1];
       if (DOT) ur = u[r0 + t];
+      // (an accumulating run -- a column piece, own x ghost -- reads y: a round ahead like the row bounds, one workgroup per CU
+      // has nobody to hide the load behind)
+      if (beta != 0.0) yr = y[r0 + t];
     }
   };
   // highest column of the chunks of the round that starts at chunk c0 (block-uniform)
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
   for (int c0 = G.first; c0 < ch_end; c0 += SUB, ch += SUB) {                 // every sub-group runs the same rounds
     const bool act = ch < ch_end;                                              // wave-uniform
     const int cr0 = r0, cr1 = r1, cbase = p0 & ~1, cra = ra, cre = re;
-    const double cur = ur;
+    const double cur = ur, cyr = yr;
     // the ring's new entries for the NEXT round: fetched now, they fly while this round's products are formed
     const int hnext = c0 + SUB < ch_end ? min(max(hi1, hcur), n_cols - 1) : hcur;
     hi1 = c0 + 2 * SUB < ch_end ? round_hi(c0 + 2 * SUB) : -1;
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
           a = crp[r] - cbase;
           e = crp[r + 1] - cbase;
         }
-        double acc = beta == 0.0 ? 0.0 : beta * y[r];
+        double acc = beta == 0.0 ? 0.0 : beta * (r == cr0 + t ? cyr : y[r]);
 #pragma unroll PA_XW_UNROLL
         for (int p = a; p < e; ++p) acc = acc + prod[PA_XW_PSLOT(p)];
         if (DOT) {
@@ -470,7 +475,8 @@ inline int64_t pa_build_xring_groups(const int32_t *crp, const std::vector<int32
                                      bool forced = false) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   const int C = PA_XR_CAP - 64;
-  const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XR_MAXG, (n_chunks + PA_XR_WANT_GROUPS - 1) / PA_XR_WANT_GROUPS));
+  static const int64_t want = getenv("PA_SPMV_XRING_GROUPS") ? std::max(1, atoi(getenv("PA_SPMV_XRING_GROUPS"))) : PA_XR_WANT_GROUPS;
+  const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XR_MAXG, (n_chunks + want - 1) / want));
   int64_t staged = 0;
   *grouped_entries = 0;
   int64_t c = 0;

@@ -17,6 +17,7 @@
 
 #include "pa_setup.h"
 #include "pa_spmv_kernel.h"
+#include "pa_spmv_xwin.h"
 
 using namespace pa_util;
 
@@ -116,6 +117,14 @@ extern "C" int pa_csr_download_entries(const pa_csr *A, int32_t *rows, int32_t *
     PA_TRY(sc.get(&d_row, (size_t)S->nnz));
     PA_TRY(sc.get(&d_col, (size_t)S->nnz));
     PA_TRY(pa_dev_decode_entries(S, d_row, d_col));
+    if (A->colsplit) {                                     // a column piece: its entries go back to where the caller had them
+      std::vector<int32_t> r((size_t)S->nnz), cc((size_t)S->nnz), src((size_t)S->nnz);
+      PA_TRY(d2h(c->s[0], r.data(), d_row, (size_t)S->nnz));
+      PA_TRY(d2h(c->s[0], cc.data(), d_col, (size_t)S->nnz));
+      PA_TRY(d2h(c->s[0], src.data(), S->d_src, (size_t)S->nnz));
+      for (int64_t p = 0; p < S->nnz; ++p) { rows[src[p]] = r[p]; cols[src[p]] = cc[p]; }
+      continue;
+    }
     PA_TRY(d2h(c->s[0], rows + S->nnz0, d_row, (size_t)S->nnz));
     PA_TRY(d2h(c->s[0], cols + S->nnz0, d_col, (size_t)S->nnz));
     if (S->row0) for (int64_t p = 0; p < S->nnz; ++p) rows[S->nnz0 + p] += (int32_t)S->row0;
@@ -455,6 +464,116 @@ extern "C" int pa_csr_locality_order(const pa_csr *A, int32_t *new_pos, int64_t 
   PA_HIP(hipGetLastError());
   if (band_before) *band_before = band[0];
   if (band_after) *band_after = band[1];
+  return PA_OK;
+}
+
+// ---- column split of a wide band (round 4) --------------------------------------------------------------------
+// The sliding x window (k_spmv_xring) holds 16384 entries of x: rows whose columns spread over more than that (+-8000 around the
+// diagonal) fall back to the plain row split and its one L2 line per gather (3.0 TB/s algorithmic).  Such a block is cut into k
+// COLUMN PIECES: entry (r, c) goes to piece floor((c - t0(r)) / w), t0(r) = the lower edge of the band at row r; every piece holds
+// all rows, is a band of width w <= ~11000 that the window holds, and is a block of its own (row split, 16-bit windows, ring
+// groups).  The product runs the pieces one after the other, the first with the caller's beta, the others accumulating: a row's
+// columns ascend, so the pieces take consecutive runs of its entries and the sum adds the same products in the same order (the
+// intermediate y is a stored fp64: exact).  Costs y read and written k times and the pieces' x ranges read once each.
+__global__ void kt_piece_keys(const int *__restrict__ row, const int *__restrict__ col, int n, double slope, int half, int w, int k,
+                              int *__restrict__ key) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const long long t0 = (long long)((double)row[p] * slope) - half;
+  long long j = ((long long)col[p] - t0) / w;
+  key[p] = (int)(j < 0 ? 0 : j >= k ? k - 1 : j);
+}
+__global__ void kt_take(const int *__restrict__ perm, int first, int n, const int *__restrict__ row, const int *__restrict__ col,
+                        const double *__restrict__ val, int *__restrict__ out_row, int *__restrict__ out_col, double *__restrict__ out_val,
+                        int *__restrict__ out_src) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int p = perm[first + q];
+  out_row[q] = row[p]; out_col[q] = col[p]; out_val[q] = val[p]; out_src[q] = p;
+}
+
+int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces) {
+  *out = nullptr;
+  if (!A || A->next || A->nnz == 0) return PA_OK;
+  const char *e = getenv("PA_SPMV_COLSPLIT");
+  const int mode = e ? atoi(e) : 1;
+  const int64_t window = PA_XR_CAP - 64;
+  int k = force_pieces;
+  if (k <= 0) {
+    if (mode == 0 || A->use_pattern || A->compact || !A->use_c16 || A->n_xw_groups > 0 || A->nnz < ((int64_t)1 << 21)) return PA_OK;
+    if (A->xw_max_span <= window || A->xw_max_span > 4 * 15000) return PA_OK;
+    k = (int)((A->xw_max_span + 14999) / 15000);
+  }
+  if (k < 2) return PA_OK;
+  pa_ctx *c = A->ctx;
+  if (c->capturing) return PA_OK;
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  const int64_t nnz = A->nnz, n_rows = A->n_rows, n_cols = A->n_cols;
+  const int64_t span = std::max<int64_t>(A->xw_max_span, k);
+  const int w = (int)((span + k - 1) / k), half = (int)(span / 2);
+  const double slope = n_rows > 1 ? (double)(n_cols - 1) / (double)(n_rows - 1) : 0.0;
+  scratch sc;
+  int32_t *d_row = nullptr, *d_col = nullptr, *d_key = nullptr, *d_ks = nullptr, *d_iota = nullptr, *d_perm = nullptr, *d_first = nullptr;
+  PA_TRY(sc.get(&d_row, (size_t)nnz));
+  PA_TRY(sc.get(&d_col, (size_t)nnz));
+  PA_TRY(sc.get(&d_key, (size_t)nnz));
+  PA_TRY(sc.get(&d_ks, (size_t)nnz));
+  PA_TRY(sc.get(&d_iota, (size_t)nnz));
+  PA_TRY(sc.get(&d_perm, (size_t)nnz));
+  PA_TRY(sc.get(&d_first, (size_t)k + 2));
+  PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
+  hipLaunchKernelGGL(kt_piece_keys, grid1(nnz), dim3(256), 0, s, d_row, d_col, (int)nnz, slope, half, w, k, d_key);
+  hipLaunchKernelGGL(kt_iota, grid1(nnz), dim3(256), 0, s, d_iota, (int)nnz);
+  PA_TRY(sort_pairs(sc, s, d_key, d_ks, d_iota, d_perm, (size_t)nnz, 3));      // stable: inside a piece the entries keep their (row, column) order
+  hipLaunchKernelGGL(kt_lower_bounds, grid1(k + 1), dim3(256), 0, s, d_ks, (int)nnz, k, d_first);
+  std::vector<int32_t> first((size_t)k + 1);
+  PA_TRY(d2h(s, first.data(), d_first, (size_t)k + 1));
+  PA_HIP(hipGetLastError());
+  sc.release(d_key); sc.release(d_ks); sc.release(d_iota);
+  pa_csr *head = nullptr, *tail = nullptr;
+  auto fail = [&](int st) { if (head) pa_csr_destroy(head); return st; };
+  for (int j = 0; j < k; ++j) {
+    const int64_t cnt = (int64_t)first[j + 1] - first[j];
+    scratch pc;
+    int32_t *p_row = nullptr, *p_col = nullptr, *p_src = nullptr, *p_rp = nullptr;
+    double *p_val = nullptr;
+    if (int st = pc.get(&p_row, (size_t)cnt + 1)) return fail(st);
+    if (int st = pc.get(&p_col, (size_t)cnt + 1)) return fail(st);
+    if (int st = pc.get(&p_val, (size_t)cnt + 1)) return fail(st);
+    if (int st = pc.get(&p_src, (size_t)cnt + 1)) return fail(st);
+    if (int st = pc.get(&p_rp, (size_t)n_rows + 1)) return fail(st);
+    if (cnt) hipLaunchKernelGGL(kt_take, grid1(cnt), dim3(256), 0, s, d_perm, first[j], (int)cnt, d_row, d_col, A->d_val, p_row, p_col, p_val, p_src);
+    hipLaunchKernelGGL(kt_lower_bounds, grid1(n_rows + 1), dim3(256), 0, s, p_row, (int)cnt, (int)n_rows, p_rp);
+    if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { pa_set_err("column split: a kernel failed"); return fail(PA_ERR_HIP); }
+    pa_csr *P = nullptr;
+    ++pa_tls_piece_build;
+    const int st_p = pa_csr_from_device(c, n_rows, n_cols, cnt, p_rp, p_col, p_val, &P);
+    --pa_tls_piece_build;
+    if (st_p) return fail(st_p);
+    if (P->next) { pa_csr_destroy(P); pa_set_err("column split: a piece came out as a chain"); return fail(PA_ERR_ARG); }
+    if (int st = pa_dev_alloc(c, (void **)&P->d_src, sizeof(int32_t) * (size_t)std::max<int64_t>(cnt, 1), PA_MEM_MATRIX)) { pa_csr_destroy(P); return fail(st); }
+    if (cnt && hipMemcpyAsync(P->d_src, p_src, sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToDevice, s) != hipSuccess) { pa_csr_destroy(P); return fail(PA_ERR_HIP); }
+    if (hipStreamSynchronize(s) != hipSuccess) { pa_csr_destroy(P); return fail(PA_ERR_HIP); }
+    P->accumulate = j > 0;
+    P->alpha_inside = A->alpha_inside;
+    P->row0 = 0; P->nnz0 = first[j];
+    if (tail) tail->next = P; else head = P;
+    tail = P;
+  }
+  head->colsplit = true;
+  head->t_rows = A->t_rows; head->t_nnz = A->t_nnz;
+  head->xw_max_span = A->xw_max_span;
+  *out = head;
+  return PA_OK;
+}
+
+// the block as a chain of `pieces` column pieces whatever its spans (tests; NULL out when it cannot be split)
+extern "C" int pa_csr_create_colsplit(const pa_csr *A, int pieces, pa_csr **out) {
+  PA_REQUIRE(A && out && pieces >= 2 && pieces <= 8, "bad arguments");
+  PA_REQUIRE(!A->next, "the block is a chain already");
+  PA_TRY(pa_csr_colsplit_if_wide(A, out, pieces));
+  PA_REQUIRE(*out != nullptr, "the block could not be split");
   return PA_OK;
 }
 

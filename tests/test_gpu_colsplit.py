@@ -1,0 +1,94 @@
+"""Column-split blocks (round 4): unstructured rows whose band is wider than the sliding x window are stored as a
+chain of column pieces, run one after the other with the later ones accumulating.  spmv_csr!'s sum (src/sparse_utils.jl:649-669)
+adds a row's products in ascending column; the pieces take consecutive runs of them: the same bits (np.array_equal) as the unsplit
+block and as the oracle -- for every beta, after value updates, through the fused product + dot."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gpu_common import pa, env
+import pa_amd._lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(rng, m, n, per_row, band, ragged=False):
+    lens = rng.integers(0, 2 * per_row, m) if ragged else np.full(m, per_row)
+    centre = (np.arange(m) * (n - 1) // max(m - 1, 1)).astype(np.int64)
+    rows = []
+    for r in range(m):
+        c = np.unique(np.clip(centre[r] + rng.integers(-band, band + 1, int(lens[r])), 0, n - 1))
+        rows.append(c)
+    rp = (1 + np.concatenate(([0], np.cumsum([len(c) for c in rows])))).astype(np.int32)
+    cv = (np.concatenate(rows) + 1).astype(np.int32) if rp[-1] > 1 else np.zeros(0, np.int32)
+    return pa.HostCSR(m, n, rp, cv, rng.standard_normal(len(cv)))
+
+
+def _split(B, pieces):
+    h = C.c_void_p()
+    L.call("pa_csr_create_colsplit", B.h, pieces, C.byref(h))
+    return pa.DeviceCSR.from_handle(h, B.m, B.n, B.nnz)
+
+
+@pytest.mark.parametrize("m,n,per_row,band,ragged,pieces", [(4000, 4000, 12, 900, False, 2), (3000, 5000, 9, 1500, True, 3),
+                                                            (2500, 2000, 20, 2000, True, 5), (64, 64, 8, 64, False, 2)])
+def test_forced_column_split_gives_the_bits_of_the_unsplit_block(orc, m, n, per_row, band, ragged, pieces):
+    rng = np.random.default_rng(m + pieces)
+    H = _rows(rng, m, n, per_row, band, ragged)
+    B = pa.DeviceCSR(H)
+    S = _split(B, pieces)
+    assert S.info()["nnz"] == H.nnz and S.info()["n_rows"] == m
+    r, c = np.zeros(max(H.nnz, 1), np.int32), np.zeros(max(H.nnz, 1), np.int32)
+    L.call("pa_csr_download_entries", S.h, L.ptr(r), L.ptr(c))
+    assert np.array_equal(r[:H.nnz], np.repeat(np.arange(m), np.diff(H.rowptr.astype(np.int64)))) and np.array_equal(c[:H.nnz], H.colval - 1)
+    x, y0 = rng.standard_normal(n), rng.standard_normal(m)
+    xd = pa.DeviceVector(n, 0).upload(x)
+    oA = orc.CSR(m, n, H.rowptr, H.colval, H.nzval)
+    for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.7, 2.5)):
+        got = []
+        for blk in (B, S):
+            yd = pa.DeviceVector(m, 0).upload(y0)
+            pa.spmv_(yd, blk, xd, L.SEG_OWN, L.SEG_OWN, alpha, beta)
+            got.append(yd.download())
+        want = orc.oracle_c().mul5_csr(y0.copy(), oA, x, alpha, beta)
+        assert np.array_equal(got[0], want) and np.array_equal(got[1], want), (alpha, beta)
+    # new values on the same pattern: the pieces gather theirs from the caller's order
+    new = rng.standard_normal(H.nnz)
+    B.update_values(new)
+    S.update_values(new)
+    ya, yb = pa.DeviceVector(m, 0), pa.DeviceVector(m, 0)
+    pa.spmv_(ya, B, xd)
+    pa.spmv_(yb, S, xd)
+    assert np.array_equal(ya.download(), yb.download())
+    w = pa.DeviceVector(H.nnz + 5, 0).upload(np.concatenate([np.zeros(5), new * 2.0]))
+    L.call("pa_csr_update_values_from", S.h, w.h, 5)
+    L.call("pa_csr_update_values_from", B.h, w.h, 5)
+    pa.spmv_(ya, B, xd)
+    pa.spmv_(yb, S, xd)
+    assert np.array_equal(ya.download(), yb.download())
+
+
+def test_a_band_beyond_the_sliding_window_is_split_by_the_library(orc):
+    """2 M rows x 16 entries within +-15000: no window holds the span; the library cuts the block into column pieces that run on the
+    ring kernel.  Same bits as the unsplit block on the plain row split (PA_SPMV_COLSPLIT=0) and as the oracle."""
+    rng = np.random.default_rng(33)
+    m = 2_000_000
+    col = np.repeat(np.arange(m, dtype=np.int64), 16).reshape(m, 16) + rng.integers(-15000, 15000, size=(m, 16))
+    col = np.sort(np.clip(col, 0, m - 1), axis=1)
+    keep = np.concatenate([np.ones((m, 1), bool), col[:, 1:] != col[:, :-1]], axis=1)
+    lens = keep.sum(1)
+    H = pa.HostCSR(m, m, (1 + np.concatenate(([0], np.cumsum(lens)))).astype(np.int32), (col[keep] + 1).astype(np.int32),
+                   rng.standard_normal(int(lens.sum())))
+    with env(PA_SPMV_COLSPLIT="0"):
+        B0 = pa.DeviceCSR(H)
+    B = pa.DeviceCSR(H)
+    assert B0.xwin()["ring_groups"] == 0 and B.xwin()["ring_groups"] > 0, (B0.xwin(), B.xwin())
+    x = rng.standard_normal(m)
+    xd = pa.DeviceVector(m, 0).upload(x)
+    y, y0 = pa.DeviceVector(m, 0), pa.DeviceVector(m, 0)
+    pa.spmv_(y, B, xd)
+    pa.spmv_(y0, B0, xd)
+    want = np.zeros(m)
+    orc.oracle_c().spmv_csr(want, x, orc.CSR(m, m, H.rowptr, H.colval, H.nzval))
+    assert np.array_equal(y.download(), want) and np.array_equal(y0.download(), want)

@@ -7,7 +7,7 @@ pa = load_package()
 import pa_amd._lib as L
 ctx = pa.context()
 
-MODES = (("row split", {"PA_SPMV_XWIN": "0"}), ("windows", {"PA_SPMV_XRING": "0"}), ("40K + ring", {"PA_SPMV_XRING": "1"}), ("ring only", {"PA_SPMV_XRING": "2"}))
+MODES = (("row split", {"PA_SPMV_XWIN": "0", "PA_SPMV_COLSPLIT": "0"}), ("windows", {"PA_SPMV_XRING": "0"}), ("40K + ring", {"PA_SPMV_XRING": "1"}), ("ring only", {"PA_SPMV_XRING": "2"}))
 
 
 def rate(name, H):
@@ -15,7 +15,7 @@ def rate(name, H):
     alg = (H.nnz * 12 + H.m * 20) / 1e6
     ref, line = None, f"{name:38s}"
     for label, env in MODES:
-        for k in ("PA_SPMV_XWIN", "PA_SPMV_XRING"):
+        for k in ("PA_SPMV_XWIN", "PA_SPMV_XRING", "PA_SPMV_COLSPLIT"):
             os.environ.pop(k, None)
         os.environ.update(env)
         blk = pa.DeviceCSR(H)
