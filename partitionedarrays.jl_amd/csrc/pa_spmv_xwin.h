@@ -240,6 +240,11 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
     const double *__restrict__ u = nullptr, double *__restrict__ partial = nullptr) {
   constexpr int CAP = PA_SPMV_CHUNK_NNZ, NTHR = BLK * SUB, C = PA_XR_CAP;
   constexpr int PCAP = CAP + CAP / 16 + 2;
+  // rows per pass of the row phase.  The fused dot must form a chunk's partial sum in k_spmv_rowsplit's order (lane t adds the rows
+  // t, t + 256, ..., then the wave sums, then the four waves in turn): with 512 lanes on a chunk of more than 256 rows a lane per
+  // row gives other bits, so the dot variant sums rows with the first 256 lanes only (round 4: found when one run per CU brought
+  // chunks of short rows into the ring)
+  constexpr int RB = DOT && BLK > 256 ? 256 : BLK;
   static_assert(BLK * NPT >= CAP, "the lanes of a sub-group cover a chunk");
   __shared__ __attribute__((aligned(16))) double xs[C];
   __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
     if (act) {
       int a = cra - cbase, e = cre - cbase;
       double dacc = 0.0;
-      for (int r = cr0 + t; r < cr1; r += BLK) {
+      for (int r = cr0 + t; r < cr1 && t < RB; r += RB) {
         if (r != cr0 + t) {
           a = crp[r] - cbase;
           e = crp[r + 1] - cbase;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
     __syncthreads();
     if (DOT && act && cr1 - cr0 > 64 && t == 0) {
       double sum = 0.0;
-      for (int w = 0; w < BLK / 64; ++w) sum = sum + wsum[sub * (BLK / 64) + w];
+      for (int w = 0; w < RB / 64; ++w) sum = sum + wsum[sub * (BLK / 64) + w];
       partial[ch] = sum;
     }
   }
