@@ -328,6 +328,15 @@ typedef struct pa_scatter pa_scatter;
 int pa_scatter_create(pa_ctx *ctx, int64_t n_dst, int64_t n_src, const int32_t *dest, int index_base, pa_scatter **s);
 int pa_scatter_destroy(pa_scatter *s);
 int pa_scatter_add(pa_scatter *s, pa_vec *dst, const pa_vec *src, int zero_first);
+/* The cache of psparse(I,J,V,rows,cols; reuse=true) (src/p_sparse_matrix.jl:1150-1219; psparse! :1291-1305) built on the device.
+ * While pa_coo_keep_input_slots is on, pa_coo_subassemble / pa_coo_assemble_finish remember where every input triplet went (the K
+ * of sparse_matrix!, composed with the split).  pa_coo_reuse_scatter composes the two into the scatter of a part's COO values
+ * into W = [nonzeros(own_own) | nonzeros(own_ghost) || nonzeros(ghost_own) | nonzeros(ghost_ghost)]; ghost_slot[k] (host): the
+ * 0-based position in the last two of ghost-row entry k as pa_coo_subassembly_ghost_rows lists them; k_rcv[q] (host, out): the
+ * 1-based slot in W of the q-th triplet pa_coo_assemble_finish received = idx_rcv of the plan that assembles W. */
+int pa_coo_keep_input_slots(pa_ctx *ctx, int on);
+int pa_coo_reuse_scatter(const pa_coo_assembly *sub, const pa_coo_assembly *fin, const int32_t *ghost_slot, pa_scatter **out,
+                         int64_t n_rcv, int32_t *k_rcv);
 
 /* ---- RCCL communicator (MPI.Init / Comm_dup analogue, src/mpi_array.jl:42-53) ---------------- */
 #define PA_UNIQUE_ID_BYTES 128

@@ -290,6 +290,8 @@ int pa_csr_create_transpose_ranked(const pa_csr *A, const int32_t *row_rank, pa_
 /* The block as a chain of `pieces` column pieces (2..8; entry (r, c) in piece floor((c - lower band edge at r) / width)): what the
  * library does by itself for unstructured rows whose band is wider than the sliding x window (PA_SPMV_COLSPLIT=0: never).  pa_spmv
  * runs the pieces in sequence, the later ones accumulating: the same additions in the same order as on the unsplit block. */
+/* a scatter map back as destinations (0-based, -1 = skipped); checks that every slot adds its sources in ascending order (tests) */
+int pa_scatter_download(const pa_scatter *s, int32_t *dest);
 int pa_csr_create_colsplit(const pa_csr *A, int pieces, pa_csr **out);
 
 /* ---- introspection of a CSR block (what the row-split kernel reads; none of it is needed to use the block) ---------- */

@@ -165,6 +165,9 @@ _SIGS = {
     "pa_csr_create_permuted": [P, P, P, PP],
     "pa_csr_create_transpose_ranked": [P, P, PP],
     "pa_csr_create_colsplit": [P, cint, PP],
+    "pa_coo_keep_input_slots": [P, cint],
+    "pa_coo_reuse_scatter": [P, P, P, PP, i64, P],
+    "pa_scatter_download": [P, P],
     "pa_sell_create": [P, i64, i64, i64, P, P, cint, cint, P, cint, PP],
     "pa_sell_destroy": [P],
     "pa_sell_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],

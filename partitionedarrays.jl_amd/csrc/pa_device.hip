@@ -2420,6 +2420,19 @@ extern "C" int pa_transfer_prolongate(pa_transfer *t, pa_vec *xf, const pa_vec *
 extern "C" int pa_scatter_create(pa_ctx *c, int64_t n_dst, int64_t n_src, const int32_t *dest, int index_base, pa_scatter **out) {
   PA_REQUIRE(c && out && n_dst >= 0 && n_src >= 0 && (n_src == 0 || dest), "bad arguments");
   PA_REQUIRE(index_base == 0 || index_base == 1, "index_base must be 0 or 1");
+  if (n_src >= (1 << 16) && !(getenv("PA_SETUP_DEVICE") && atoi(getenv("PA_SETUP_DEVICE")) == 0)) {
+    // the stable grouping by destination as a radix sort on the device (pa_assemble.hip): same lists
+    PA_HIP(hipSetDevice(c->device));
+    int32_t *d = nullptr;
+    PA_HIP(hipMalloc((void **)&d, sizeof(int32_t) * (size_t)n_src));
+    std::vector<int32_t> z;
+    const int32_t *src = dest;
+    if (index_base) { z.resize(n_src); for (int64_t p = 0; p < n_src; ++p) z[p] = dest[p] - 1; src = z.data(); }
+    int st = hipMemcpy(d, src, sizeof(int32_t) * (size_t)n_src, hipMemcpyHostToDevice) == hipSuccess ? PA_OK : PA_ERR_HIP;
+    if (st == PA_OK) st = pa_scatter_from_device_dest(c, n_dst, n_src, d, out);
+    (void)hipFree(d);
+    return st;
+  }
   std::vector<int32_t> order;
   order.reserve(n_src);
   for (int64_t p = 0; p < n_src; ++p) {

@@ -40,6 +40,7 @@ void pa_set_err(const char *fmt, ...);
 struct pa_arena;
 
 struct pa_ctx {
+  bool keep_coo_slots = false;       // pa_coo_keep_input_slots: the assemblies remember where their input triplets went
   int device = 0;
   hipStream_t s[2] = {nullptr, nullptr};  // [0] compute, [1] comm
   hipEvent_t ev_compute = nullptr;

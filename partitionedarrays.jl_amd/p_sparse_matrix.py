@@ -9,6 +9,7 @@ native host code (csrc/pa_host.cpp) and HIP kernels (csrc/pa_device.hip).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -732,9 +733,11 @@ def _disassembled_device_applies(rows, cols, I, J):
             and all(len(i) and int(np.min(i)) >= 1 and int(np.min(j)) >= 1 for i, j in zip(local_items(I), local_items(J))))
 
 
-def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False):
+def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False, reuse=False):
     """psparse(I,J,V,rows,cols) with the default flags, then assemble (src/p_sparse_matrix.jl:1150-1219,1590-1756), with
-    everything per triplet on the device.  Per part: the sub-assembled local matrix by one sort (ghost rows and ghost columns in
+    everything per triplet on the device.  reuse=True: also the cache of psparse! (MatrixReassemblyCache), its per-triplet part --
+    where every COO value goes -- composed on the device from what the two assembly steps remember (pa_coo_reuse_scatter); only
+    the part's surface (the ghost rows' entries, the received triplets) passes through the host, as it does for the exchange.  Per part: the sub-assembled local matrix by one sort (ghost rows and ghost columns in
     first-seen order); its ghost rows -- the part's surface -- come to the host and travel to their owners exactly as
     psparse_assemble_host sends them; the own rows, still in HBM, and what arrived go through the assembled route.  Same
     blocks, same ghost order as the host route, bit for bit (tests/test_gpu_setup.py)."""
@@ -756,8 +759,12 @@ def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False):
         if D != Dc:
             raise L.PAError("row and column partitions of different dimension")
         h = C.c_void_p()
-        L.call("pa_coo_subassemble", context().h, len(Ii), L.ptr(Ii), L.ptr(Ji), L.ptr(Vi), D, L.ptr(nr), L.ptr(lor), L.ptr(hir),
-               L.ptr(ncg), L.ptr(loc), L.ptr(hic), C.byref(h))
+        L.call("pa_coo_keep_input_slots", context().h, 1 if reuse else 0)
+        try:
+            L.call("pa_coo_subassemble", context().h, len(Ii), L.ptr(Ii), L.ptr(Ji), L.ptr(Vi), D, L.ptr(nr), L.ptr(lor), L.ptr(hir),
+                   L.ptr(ncg), L.ptr(loc), L.ptr(hic), C.byref(h))
+        finally:
+            L.call("pa_coo_keep_input_slots", context().h, 0)
         try:
             v = [C.c_int64() for _ in range(4)]
             L.call("pa_coo_subassembly_info", h, *[C.byref(x) for x in v])
@@ -776,21 +783,28 @@ def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False):
             rp = np.zeros(ngr + 1, np.int64)
             np.add.at(rp, rows_.astype(np.int64) + 1, 1)
             return HostCSR(ngr, n_cols, (np.cumsum(rp) + 1).astype(I32), (cols_ + 1).astype(I32), vals_.copy())
-        return h, r_sa, c_sa, csr(gr[own], gc[own], gv[own], c.n_own), csr(gr[~own], gc[~own] - c.n_own, gv[~own], ngc)
+        # position of ghost-row entry k in [nonzeros(ghost_own) | nonzeros(ghost_ghost)] (both halves keep the (row, column) order)
+        gslot = np.where(own, np.cumsum(own) - 1, int(own.sum()) + np.cumsum(~own) - 1).astype(I32)
+        return h, r_sa, c_sa, csr(gr[own], gc[own], gv[own], c.n_own), csr(gr[~own], gc[~own] - c.n_own, gv[~own], ngc), gslot
 
-    hs, rows_sa, cols_sa, g_own, g_ghost = tuple_of_arrays(pmap(sub, I, J, V, rows, cols))
+    hs, rows_sa, cols_sa, g_own, g_ghost, gslots = tuple_of_arrays(pmap(sub, I, J, V, rows, cols))
     try:
         parts_snd, parts_rcv = assembly_neighbors(rows_sa)
-        I_snd, J_snd, V_snd, _k = tuple_of_arrays(pmap(_assembly_snd, g_own, g_ghost, parts_snd, rows_sa, cols_sa))
+        I_snd, J_snd, V_snd, ksnd = tuple_of_arrays(pmap(_assembly_snd, g_own, g_ghost, parts_snd, rows_sa, cols_sa))
         graph = ExchangeGraph(parts_snd, parts_rcv)
         I_rcv, J_rcv, V_rcv = exchange(I_snd, graph), exchange(J_snd, graph), exchange(V_snd, graph)
 
-        def finish(h, Ir, Jr, Vr, r, c):
+        def finish(h, Ir, Jr, Vr, r, c, gslot, ps, pr, ks, n_in):
             cat = lambda xs, dt: np.ascontiguousarray(np.concatenate([np.asarray(x, dt) for x in xs]) if len(xs) else np.zeros(0, dt))  # noqa: E731
+            rcv_ptrs = np.concatenate([[1], 1 + np.cumsum([len(np.atleast_1d(x)) for x in Ir])]).astype(I32)
             Ir, Jr, Vr = cat(Ir, I64), cat(Jr, I64), cat(Vr, F64)
             f = C.c_void_p()
-            L.call("pa_coo_assemble_finish", h, len(Ir), L.ptr(Ir) if len(Ir) else None, L.ptr(Jr) if len(Ir) else None,
-                   L.ptr(Vr) if len(Ir) else None, C.byref(f))
+            L.call("pa_coo_keep_input_slots", context().h, 1 if reuse else 0)
+            try:
+                L.call("pa_coo_assemble_finish", h, len(Ir), L.ptr(Ir) if len(Ir) else None, L.ptr(Jr) if len(Ir) else None,
+                       L.ptr(Vr) if len(Ir) else None, C.byref(f))
+            finally:
+                L.call("pa_coo_keep_input_slots", context().h, 0)
             try:
                 v = [C.c_int64() for _ in range(5)]
                 L.call("pa_coo_assembly_info", f, *[C.byref(x) for x in v], None)
@@ -809,15 +823,41 @@ def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False):
                         L.call("pa_coo_assembly_download", f, which, L.ptr(H.rowptr), L.ptr(H.colval), L.ptr(H.nzval))
                         host.append(H)
                     host = tuple(host)
+                cache = None
+                if reuse:
+                    # W = [nonzeros(own_own) | nonzeros(own_ghost) || the ghost rows' entries]; the plan that assembles it: idx_snd = the
+                    # ghost-row slots in the order they are sent (k_snd), idx_rcv = the slots the received triplets landed in (k_rcv)
+                    from .p_vector import DeviceVector, plan_info
+                    n_own_vals, n_ghost_vals = nnz_oo + nnz_oh, len(gslot)
+                    sc, k_rcv = C.c_void_p(), np.zeros(max(len(Ir), 1), I32)
+                    L.call("pa_coo_reuse_scatter", h, f, L.ptr(gslot) if n_ghost_vals else None, C.byref(sc), len(Ir), L.ptr(k_rcv))
+                    k_snd, ptrs_snd = ks
+                    ns32, nr32 = np.ascontiguousarray(ps, I32), np.ascontiguousarray(pr, I32)
+                    idx_snd = np.ascontiguousarray(n_own_vals + k_snd, I32)
+                    idx_rcv = np.ascontiguousarray(k_rcv[:len(Ir)], I32)
+                    p_snd, p_rcv = np.ascontiguousarray(ptrs_snd, I32), np.ascontiguousarray(rcv_ptrs, I32)
+                    plan = C.c_void_p()
+                    L.call("pa_plan_create", context().h, r.part, n_own_vals + n_ghost_vals, len(ns32), L.ptr(ns32), L.ptr(p_snd),
+                           L.ptr(idx_snd), len(nr32), L.ptr(nr32), L.ptr(p_rcv), L.ptr(idx_rcv), 1, C.byref(plan))
+                    plan_info[plan.value] = dict(
+                        snd=[(int(q), int(p_snd[k]) - 1, int(p_snd[k + 1]) - 1) for k, q in enumerate(ns32)],
+                        rcv=[(int(q), int(p_rcv[k]) - 1, int(p_rcv[k + 1]) - 1) for k, q in enumerate(nr32)])
+                    cache = (plan, sc, DeviceVector(n_own_vals, n_ghost_vals), DeviceVector(int(n_in), 0), nnz_oo)
             finally:
                 L.lib.pa_coo_assembly_destroy(f)
-            return blk, c_fa, host
+            return blk, c_fa, host, cache
 
-        out = pmap(finish, hs, I_rcv, J_rcv, V_rcv, rows, cols)
+        out = pmap(finish, hs, I_rcv, J_rcv, V_rcv, rows, cols, gslots, parts_snd, parts_rcv, ksnd, pmap(len, I))
     finally:
         pmap(lambda h: L.lib.pa_coo_assembly_destroy(h), hs)
-    blocks, cols_fa, host = tuple_of_arrays(out)
-    return PSparseMatrix(blocks, rows, cols_fa, True, host if keep_host else None)
+    blocks, cols_fa, host, caches = tuple_of_arrays(out)
+    C_ = PSparseMatrix(blocks, rows, cols_fa, True, host if keep_host else None)
+    if not reuse:
+        return C_
+    plans, scs, W, Vd, nnz_oo = tuple_of_arrays(caches)
+    from .p_vector import connect_ipc
+    connect_ipc(plans)
+    return C_, MatrixReassemblyCache(plans, scs, W, Vd, nnz_oo)
 
 
 def psparse_assemble_host(blocks4, rows_sa, cols_sa, rows, reuse=False):
@@ -887,8 +927,8 @@ def psparse_disassembled(I, J, V, rows, cols, keep_host=False, reuse=False, asse
     """psparse(SparseMatrixCSR{1,Float64,Int32},I,J,V,rows,cols)|>fetch with the DEFAULT flags
     (src/p_sparse_matrix.jl:1150-1219): every part may hold entries of rows it does not own (FEM assembly loops);
     find_owner/union_ghost for rows and columns, local compress + split, then assemble onto `rows`."""
-    if assemble and not reuse and _disassembled_device_applies(rows, cols, I, J):
-        return psparse_disassembled_device(I, J, V, rows, cols, keep_host=keep_host)
+    if assemble and _disassembled_device_applies(rows, cols, I, J) and (not reuse or os.environ.get("PA_REUSE_DEVICE", "1") != "0"):
+        return psparse_disassembled_device(I, J, V, rows, cols, keep_host=keep_host, reuse=reuse)
     I_owner = find_owner(rows, I)
     J_owner = find_owner(cols, J)
     rows_sa = pmap(union_ghost, rows, I, I_owner)
