@@ -92,3 +92,27 @@ def test_a_band_beyond_the_sliding_window_is_split_by_the_library(orc):
     want = np.zeros(m)
     orc.oracle_c().spmv_csr(want, x, orc.CSR(m, m, H.rowptr, H.colval, H.nzval))
     assert np.array_equal(y.download(), want) and np.array_equal(y0.download(), want)
+
+
+def test_fused_product_and_dot_on_a_column_split_chain(orc):
+    """mul! + dot in one pass (the CG loop's fused form) over a chain of column pieces: c keeps the bits of the unsplit block, the dot --
+    a sum of per-chunk partials, grouped by piece here -- agrees to rounding (its parity bar: 1e-13 relative)."""
+    import pa_amd.p_sparse_matrix as psm
+    rng = np.random.default_rng(9)
+    m = 6000
+    H = _rows(rng, m, m, 14, 1200, ragged=True)
+    B = pa.DeviceCSR(H)
+    S = _split(B, 3)
+    ind = pa.uniform_partition(pa.DebugArray([1]), m)
+    uh = rng.standard_normal(m)
+    got = []
+    for blk in (B, S):
+        empty = pa.DeviceCSR(pa.HostCSR(m, 0, np.ones(m + 1, np.int32), np.zeros(0, np.int32), np.zeros(0)))
+        A = pa.PSparseMatrix(pa.DebugArray([psm.SplitMatrixBlocks(blk, empty)]), ind, ind, True)
+        u = pa.pvector_from_function(lambda i: uh, ind)
+        c = pa.pzeros(ind)
+        assert psm.mul_dot_(c, A, u, 5)
+        got.append((c.own_values().items[0].copy(), pa.read_slots(5)[0]))
+    assert np.array_equal(got[0][0], got[1][0])
+    want = float(uh @ got[0][0])
+    assert abs(got[0][1] - want) <= 1e-12 * max(1.0, abs(want)) and abs(got[1][1] - want) <= 1e-12 * max(1.0, abs(want))
