@@ -2791,7 +2791,7 @@ static int matrix_rb(pa_matrix *m) {
   if (!on) return PA_OK;
   pa_plan *p = m->plan;
   const pa_plan::side &in = p->snd;                           // the receiving side of consistent! (ghost lids)
-  if (in.n == 0 || m->oh->t_nnz == 0 || m->oh->next) return PA_OK;
+  if (in.n == 0 || m->oh->t_nnz == 0 || (m->oh->next && !m->oh->colsplit)) return PA_OK;
   const int64_t n_own = m->oo->n_cols, n_ghost = m->oh->n_cols;
   std::vector<int32_t> map((size_t)n_ghost, -1);
   for (int64_t k = 0; k < in.n; ++k) {

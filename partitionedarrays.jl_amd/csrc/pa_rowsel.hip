@@ -188,7 +188,7 @@ static int select_rows_impl(const pa_csr *oo, const pa_csr *oh, const int32_t *m
                             int64_t n_cols_total) {
   PA_REQUIRE(oo && mask && out && n_sel > 0 && n_sel <= 64, "bad arguments");
   PA_REQUIRE(!lower || oo->n_rows == oo->n_cols, "the own|own block is not square");
-  PA_REQUIRE(!oo->next && !(oh && oh->next), "a block of 2^31 stored entries or more (a chain of slabs) takes the host route");
+  PA_REQUIRE(!oo->next && !(oh && oh->next), "a block stored as a chain (2^31 stored entries or more: row slabs; a band beyond the sliding x window: column pieces, PA_SPMV_COLSPLIT=0 keeps it whole) takes the host route");
   PA_REQUIRE(!oh || (oh->n_rows == oo->n_rows && oh->ctx == oo->ctx), "the own|ghost block does not match the own|own block");
   pa_ctx *c = oo->ctx;
   const int64_t n_ghost_cols = oh ? oh->n_cols : 0;      // (counted before an entry-less own|ghost block is dropped below)
@@ -407,7 +407,7 @@ static int run_rounds(hipStream_t s, int64_t n, int *d_sizes, int32_t *d_f0, int
 extern "C" int pa_gs_create_from_blocks(const pa_csr *oo, const pa_csr *oh, int ordering, pa_gs **out) {
   PA_REQUIRE(oo && out, "bad arguments");
   PA_REQUIRE(ordering == PA_GS_SEQUENTIAL, "the device route builds the sequential ordering only");
-  PA_REQUIRE(!oo->next && !(oh && oh->next), "a block of 2^31 stored entries or more (a chain of slabs) takes the host route");
+  PA_REQUIRE(!oo->next && !(oh && oh->next), "a block stored as a chain (2^31 stored entries or more: row slabs; a band beyond the sliding x window: column pieces, PA_SPMV_COLSPLIT=0 keeps it whole) takes the host route");
   PA_REQUIRE(!oh || (oh->n_rows == oo->n_rows && oh->ctx == oo->ctx), "the own|ghost block does not match the own|own block");
   PA_REQUIRE(oo->n_rows == oo->n_cols, "the own|own block is not square");
   pa_ctx *c = oo->ctx;

@@ -104,6 +104,40 @@ int pa_dev_decode_entries(const pa_csr *A, int32_t *d_row, int32_t *d_col) {
   return PA_OK;
 }
 
+// The whole block as (row, column, value) arrays in the CALLER'S entry order: one node -- its decoded entries and its value stream
+// as they are; a column-split chain -- every piece's entries put back where the caller had them (d_src).  Chains of row slabs (2^31
+// entries or more) are refused by the callers.  d_row / d_col: block_nnz(A) entries each; *d_val: A->d_val or a scratch array.
+static inline int64_t block_nnz(const pa_csr *A) { return A->next ? A->t_nnz : A->nnz; }
+__global__ void kt_put_back(const int *__restrict__ src, const int *__restrict__ row, const int *__restrict__ col, const double *__restrict__ val,
+                            int n, int *__restrict__ out_row, int *__restrict__ out_col, double *__restrict__ out_val) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int p = src[q];
+  out_row[p] = row[q]; out_col[p] = col[q]; out_val[p] = val[q];
+}
+static int decode_block(const pa_csr *A, scratch &sc, int32_t *d_row, int32_t *d_col, const double **d_val) {
+  if (!A->next) {
+    *d_val = A->d_val;
+    return pa_dev_decode_entries(A, d_row, d_col);
+  }
+  PA_REQUIRE(A->colsplit, "a chain of row slabs");
+  double *d_all = nullptr;
+  PA_TRY(sc.get(&d_all, (size_t)A->t_nnz + 1));
+  for (const pa_csr *S = A; S; S = S->next) {
+    if (S->nnz == 0) continue;
+    int32_t *t_row = nullptr, *t_col = nullptr;
+    PA_TRY(sc.get(&t_row, (size_t)S->nnz));
+    PA_TRY(sc.get(&t_col, (size_t)S->nnz));
+    PA_TRY(pa_dev_decode_entries(S, t_row, t_col));
+    hipLaunchKernelGGL(kt_put_back, grid1(S->nnz), dim3(256), 0, A->ctx->s[0], S->d_src, t_row, t_col, S->d_val, (int)S->nnz, d_row, d_col, d_all);
+    PA_HIP(hipGetLastError());
+    PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
+    sc.release(t_row); sc.release(t_col);
+  }
+  *d_val = d_all;
+  return PA_OK;
+}
+
 // 0-based (row, column) of every stored entry in storage order, as the product kernel decodes them (tests compare this with
 // the arrays the block was made from; nothing on the product path reads it)
 extern "C" int pa_csr_download_entries(const pa_csr *A, int32_t *rows, int32_t *cols) {
@@ -148,12 +182,12 @@ __global__ void kt_gather_keys(const int *__restrict__ perm, const int *__restri
 // stored row, and A' adds in the order the reference's scatter loop has on the caller's numbering.
 extern "C" int pa_csr_create_transpose_ranked(const pa_csr *A, const int32_t *row_rank, pa_csr **out) {
   PA_REQUIRE(A && out, "bad arguments");
-  PA_REQUIRE(!A->next, "a block of 2^31 stored entries or more (a chain of slabs) has no device-side transpose");
+  PA_REQUIRE(!A->next || A->colsplit, "a block of 2^31 stored entries or more (a chain of slabs) has no device-side transpose");
   pa_ctx *c = A->ctx;
   PA_REQUIRE(!c->capturing, "not inside a graph capture");
   PA_HIP(hipSetDevice(c->device));
   hipStream_t s = c->s[0];
-  const int64_t nnz = A->nnz, n_rows_t = A->n_cols, n_cols_t = A->n_rows;
+  const int64_t nnz = block_nnz(A), n_rows_t = A->n_cols, n_cols_t = A->n_rows;
   PA_REQUIRE(nnz < (int64_t)2147483000 && n_rows_t < (int64_t)2147483000, "too large for Int32 offsets");
   scratch sc;
   int32_t *d_rp = nullptr;
@@ -167,7 +201,8 @@ extern "C" int pa_csr_create_transpose_ranked(const pa_csr *A, const int32_t *ro
   double *d_tval = nullptr;
   PA_TRY(sc.get(&d_row, (size_t)nnz));
   PA_TRY(sc.get(&d_col, (size_t)nnz));
-  PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
+  const double *d_aval = nullptr;
+  PA_TRY(decode_block(A, sc, d_row, d_col, &d_aval));
   PA_TRY(sc.get(&d_keys, (size_t)nnz));
   PA_TRY(sc.get(&d_iota, (size_t)nnz));
   PA_TRY(sc.get(&d_perm, (size_t)nnz));
@@ -196,7 +231,7 @@ extern "C" int pa_csr_create_transpose_ranked(const pa_csr *A, const int32_t *ro
   hipLaunchKernelGGL(kt_lower_bounds, grid1(n_rows_t + 1), dim3(256), 0, s, d_keys, (int)nnz, (int)n_rows_t, d_rp);
   PA_TRY(sc.get(&d_tcol, (size_t)nnz));
   PA_TRY(sc.get(&d_tval, (size_t)nnz));
-  hipLaunchKernelGGL(kt_gather, grid1(nnz), dim3(256), 0, s, d_perm, d_row, A->d_val, (int)nnz, d_tcol, d_tval);
+  hipLaunchKernelGGL(kt_gather, grid1(nnz), dim3(256), 0, s, d_perm, d_row, d_aval, (int)nnz, d_tcol, d_tval);
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(s));
   sc.release(d_keys);
@@ -219,12 +254,12 @@ __global__ void kt_remap(int *__restrict__ col, int n, const int *__restrict__ m
 // x[j] and are otherwise the same bits.  Used by pa_mul5 to let own x ghost read the RECEIVE BUFFER of consistent! directly.
 int pa_csr_create_remapped(const pa_csr *A, const int32_t *map, int64_t n_cols_new, pa_csr **out) {
   PA_REQUIRE(A && map && out && n_cols_new >= 0, "bad arguments");
-  PA_REQUIRE(!A->next, "a chain of slabs has no remapped twin");
+  PA_REQUIRE(!A->next || A->colsplit, "a chain of slabs has no remapped twin");
   *out = nullptr;
   pa_ctx *c = A->ctx;
   PA_HIP(hipSetDevice(c->device));
   hipStream_t s = c->s[0];
-  const int64_t nnz = A->nnz, n_rows = A->n_rows;
+  const int64_t nnz = block_nnz(A), n_rows = A->n_rows;
   scratch sc;
   int32_t *d_rp = nullptr, *d_row = nullptr, *d_col = nullptr, *d_map = nullptr;
   int *d_bad = nullptr;
@@ -238,9 +273,10 @@ int pa_csr_create_remapped(const pa_csr *A, const int32_t *map, int64_t n_cols_n
   PA_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), s));
   if (A->n_cols) PA_HIP(hipMemcpyAsync(d_map, map, sizeof(int32_t) * A->n_cols, hipMemcpyHostToDevice, s));
   if (nnz) {
-    PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
+    const double *d_aval = nullptr;
+    PA_TRY(decode_block(A, sc, d_row, d_col, &d_aval));
     hipLaunchKernelGGL(kt_remap, grid1(nnz), dim3(256), 0, s, d_col, (int)nnz, d_map, d_bad);
-    PA_HIP(hipMemcpyAsync(d_val, A->d_val, sizeof(double) * nnz, hipMemcpyDeviceToDevice, s));
+    PA_HIP(hipMemcpyAsync(d_val, d_aval, sizeof(double) * nnz, hipMemcpyDeviceToDevice, s));
   }
   hipLaunchKernelGGL(kt_lower_bounds, grid1(n_rows + 1), dim3(256), 0, s, d_row, (int)nnz, (int)n_rows, d_rp);   // rows ascend in storage order
   int bad = 0;
@@ -273,12 +309,12 @@ __global__ void kt_gather2(const int *__restrict__ perm, const int *__restrict__
 
 extern "C" int pa_csr_create_permuted(const pa_csr *A, const int32_t *row_pos, const int32_t *col_pos, pa_csr **out) {
   PA_REQUIRE(A && out, "bad arguments");
-  PA_REQUIRE(!A->next, "a chain of slabs has no renumbered twin");
+  PA_REQUIRE(!A->next || A->colsplit, "a chain of slabs has no renumbered twin");
   pa_ctx *c = A->ctx;
   PA_REQUIRE(!c->capturing, "not inside a graph capture");
   PA_HIP(hipSetDevice(c->device));
   hipStream_t s = c->s[0];
-  const int64_t nnz = A->nnz, n_rows = A->n_rows, n_cols = A->n_cols;
+  const int64_t nnz = block_nnz(A), n_rows = A->n_rows, n_cols = A->n_cols;
   if (row_pos) {                                               // a permutation, or rows would collide
     std::vector<char> seen((size_t)n_rows, 0);
     for (int64_t i = 0; i < n_rows; ++i) {
@@ -295,11 +331,12 @@ extern "C" int pa_csr_create_permuted(const pa_csr *A, const int32_t *row_pos, c
   if (row_pos) { PA_TRY(sc.get(&d_rpos, (size_t)n_rows + 1)); PA_HIP(hipMemcpyAsync(d_rpos, row_pos, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s)); }
   if (col_pos) { PA_TRY(sc.get(&d_cpos, (size_t)n_cols + 1)); PA_HIP(hipMemcpyAsync(d_cpos, col_pos, sizeof(int32_t) * n_cols, hipMemcpyHostToDevice, s)); }
   const int32_t *d_fcol = d_col;
-  const double *d_fval = A->d_val;
+  const double *d_fval = A->d_val, *d_aval = A->d_val;
   int32_t *d_keys = nullptr, *d_iota = nullptr, *d_perm = nullptr, *d_tcol = nullptr;
   double *d_tval = nullptr;
   if (nnz) {
-    PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
+    PA_TRY(decode_block(A, sc, d_row, d_col, &d_aval));
+    d_fval = d_aval;
     hipLaunchKernelGGL(kt_rename, grid1(nnz), dim3(256), 0, s, d_row, d_col, (int)nnz, d_rpos, d_cpos);
     if (row_pos) {
       PA_TRY(sc.get(&d_keys, (size_t)nnz));
@@ -311,7 +348,7 @@ extern "C" int pa_csr_create_permuted(const pa_csr *A, const int32_t *row_pos, c
       PA_TRY(sort_pairs(sc, s, d_row, d_keys, d_iota, d_perm, (size_t)nnz, bits));
       PA_TRY(sc.get(&d_tcol, (size_t)nnz));
       PA_TRY(sc.get(&d_tval, (size_t)nnz));
-      hipLaunchKernelGGL(kt_gather2, grid1(nnz), dim3(256), 0, s, d_perm, d_col, A->d_val, (int)nnz, d_tcol, d_tval);
+      hipLaunchKernelGGL(kt_gather2, grid1(nnz), dim3(256), 0, s, d_perm, d_col, d_aval, (int)nnz, d_tcol, d_tval);
       d_fcol = d_tcol; d_fval = d_tval;
     }
   }
@@ -381,12 +418,12 @@ __global__ void kr_reverse(const int *__restrict__ pos, int n, int *__restrict__
 
 extern "C" int pa_csr_locality_order(const pa_csr *A, int32_t *new_pos, int64_t *band_before, int64_t *band_after) {
   PA_REQUIRE(A && new_pos, "bad arguments");
-  PA_REQUIRE(!A->next && A->n_rows == A->n_cols, "a square single-slab block is needed");
+  PA_REQUIRE((!A->next || A->colsplit) && A->n_rows == A->n_cols, "a square single-slab block is needed");
   pa_ctx *c = A->ctx;
   PA_REQUIRE(!c->capturing, "not inside a graph capture");
   PA_HIP(hipSetDevice(c->device));
   hipStream_t s = c->s[0];
-  const int64_t n = A->n_rows, nnz = A->nnz;
+  const int64_t n = A->n_rows, nnz = block_nnz(A);
   if (n == 0) return PA_OK;
   scratch sc;
   int32_t *d_rp = nullptr, *d_row = nullptr, *d_col = nullptr, *d_pos = nullptr, *d_key = nullptr, *d_fa = nullptr, *d_fb = nullptr, *d_cand = nullptr,
@@ -404,7 +441,8 @@ extern "C" int pa_csr_locality_order(const pa_csr *A, int32_t *new_pos, int64_t 
   PA_TRY(sc.get(&d_ckey2, (size_t)n));
   PA_TRY(sc.get(&d_small, 4));
   PA_TRY(sc.get(&d_newpos, (size_t)n));
-  if (nnz) PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
+  const double *d_unused = nullptr;
+  if (nnz) PA_TRY(decode_block(A, sc, d_row, d_col, &d_unused));
   hipLaunchKernelGGL(kt_lower_bounds, grid1(n + 1), dim3(256), 0, s, d_row, (int)nnz, (int)n, d_rp);
   size_t sort_tb = 0;
   PA_HIP(rocprim::radix_sort_pairs((void *)nullptr, sort_tb, d_ckey, d_ckey2, d_cand, d_fb, (size_t)n, 0, 64, s));
@@ -475,6 +513,7 @@ extern "C" int pa_csr_locality_order(const pa_csr *A, int32_t *new_pos, int64_t 
 // groups).  The product runs the pieces one after the other, the first with the caller's beta, the others accumulating: a row's
 // columns ascend, so the pieces take consecutive runs of its entries and the sum adds the same products in the same order (the
 // intermediate y is a stored fp64: exact).  Costs y read and written k times and the pieces' x ranges read once each.
+// (Rows whose columns do NOT ascend in storage order -- renamed twins -- see the running maximum in pa_csr_colsplit_if_wide.)
 __global__ void kt_piece_keys(const int *__restrict__ row, const int *__restrict__ col, int n, double slope, int half, int w, int k,
                               int *__restrict__ key) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -499,7 +538,9 @@ int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces) {
   const int mode = e ? atoi(e) : 1;
   const int64_t window = PA_XR_CAP - 64;
   int k = force_pieces;
-  if (k <= 0) {
+  if (k <= 0 && mode >= 2 && mode <= 8) {
+    if (A->nnz >= 64) k = mode;                      // (fuzzers: every block of 64 entries or more becomes a chain of `mode` pieces)
+  } else if (k <= 0) {
     if (mode == 0 || A->use_pattern || A->compact || !A->use_c16 || A->n_xw_groups > 0 || A->nnz < ((int64_t)1 << 21)) return PA_OK;
     if (A->xw_max_span <= window || A->xw_max_span > 4 * 15000) return PA_OK;
     k = (int)((A->xw_max_span + 14999) / 15000);
@@ -510,7 +551,7 @@ int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces) {
   PA_HIP(hipSetDevice(c->device));
   hipStream_t s = c->s[0];
   const int64_t nnz = A->nnz, n_rows = A->n_rows, n_cols = A->n_cols;
-  const int64_t span = std::max<int64_t>(A->xw_max_span, k);
+  const int64_t span = std::max<int64_t>(A->xw_max_span > 0 ? A->xw_max_span : n_cols, k);
   const int w = (int)((span + k - 1) / k), half = (int)(span / 2);
   const double slope = n_rows > 1 ? (double)(n_cols - 1) / (double)(n_rows - 1) : 0.0;
   scratch sc;
@@ -524,6 +565,19 @@ int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces) {
   PA_TRY(sc.get(&d_first, (size_t)k + 2));
   PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
   hipLaunchKernelGGL(kt_piece_keys, grid1(nnz), dim3(256), 0, s, d_row, d_col, (int)nnz, slope, half, w, k, d_key);
+  {
+    // The pieces must take CONSECUTIVE runs of a row's entries, or the row's sum changes its order.  A row whose columns ascend
+    // has that by itself; a twin with renamed columns (own x ghost reading the receive buffer, a renumbered block: entries in the
+    // caller's order, columns anywhere) does not -- an entry goes to the highest piece any entry before it in the row went to (a
+    // running maximum along the row; such a piece may then be wider than the window and its chunks fall to the row split).
+    size_t tb = 0;
+    PA_HIP(rocprim::inclusive_scan_by_key((void *)nullptr, tb, d_row, d_key, d_key, (size_t)nnz, rocprim::maximum<int>(), rocprim::equal_to<int>(), s));
+    char *tmp = nullptr;
+    PA_TRY(sc.get(&tmp, tb));
+    PA_HIP(rocprim::inclusive_scan_by_key((void *)tmp, tb, d_row, d_key, d_key, (size_t)nnz, rocprim::maximum<int>(), rocprim::equal_to<int>(), s));
+    PA_HIP(hipStreamSynchronize(s));
+    sc.release(tmp);
+  }
   hipLaunchKernelGGL(kt_iota, grid1(nnz), dim3(256), 0, s, d_iota, (int)nnz);
   PA_TRY(sort_pairs(sc, s, d_key, d_ks, d_iota, d_perm, (size_t)nnz, 3));      // stable: inside a piece the entries keep their (row, column) order
   hipLaunchKernelGGL(kt_lower_bounds, grid1(k + 1), dim3(256), 0, s, d_ks, (int)nnz, k, d_first);

@@ -116,3 +116,64 @@ def test_fused_product_and_dot_on_a_column_split_chain(orc):
     assert np.array_equal(got[0][0], got[1][0])
     want = float(uh @ got[0][0])
     assert abs(got[0][1] - want) <= 1e-12 * max(1.0, abs(want)) and abs(got[1][1] - want) <= 1e-12 * max(1.0, abs(want))
+
+
+def test_transposed_and_renumbered_twins_of_a_column_split_chain(orc):
+    """The device-side transpose (pa_csr_create_transpose), the renumbered twin (pa_csr_create_permuted) and the bandwidth-reducing
+    order (pa_csr_locality_order) read a chain of column pieces in the caller's entry order: the same blocks, hence the same bits,
+    as from the unsplit block."""
+    rng = np.random.default_rng(12)
+    m = 5000
+    H = _rows(rng, m, m, 10, 800, ragged=True)
+    B = pa.DeviceCSR(H)
+    S = _split(B, 4)
+    x = rng.standard_normal(m)
+    xd = pa.DeviceVector(m, 0).upload(x)
+    perm = rng.permutation(m).astype(np.int32)
+    outs = []
+    for blk in (B, S):
+        t, q = C.c_void_p(), C.c_void_p()
+        L.call("pa_csr_create_transpose", blk.h, C.byref(t))
+        L.call("pa_csr_create_permuted", blk.h, L.ptr(perm), L.ptr(perm), C.byref(q))
+        T, Q = pa.DeviceCSR.from_handle(t, m, m, H.nnz), pa.DeviceCSR.from_handle(q, m, m, H.nnz)
+        yt, yq = pa.DeviceVector(m, 0), pa.DeviceVector(m, 0)
+        pa.spmv_(yt, T, xd)
+        pa.spmv_(yq, Q, xd)
+        order = np.zeros(m, np.int32)
+        L.call("pa_csr_locality_order", blk.h, L.ptr(order), None, None)
+        outs.append((yt.download(), yq.download(), order))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+    # A' x by the reference's scatter loop (spmtv_csr!, src/sparse_utils.jl:613-647): rows ascending, y[col] += a * x[row]
+    want = np.zeros(m)
+    rp = H.rowptr.astype(np.int64) - 1
+    for r in range(m):
+        for p in range(rp[r], rp[r + 1]):
+            want[H.colval[p] - 1] += H.nzval[p] * x[r]
+    assert np.array_equal(outs[0][0], want)
+
+
+def test_rows_whose_columns_do_not_ascend_keep_their_order_of_addition():
+    """A twin with renamed columns (own x ghost reading the receive buffer, a renumbered block) stores a row's entries in the caller's
+    order with columns anywhere.  Cut into column pieces, an entry follows the highest piece any entry before it in its row went to,
+    so the pieces still take consecutive runs of the row: the bits of the uncut twin (found by the fuzzers with PA_SPMV_COLSPLIT=3)."""
+    rng = np.random.default_rng(21)
+    m = 7000
+    H = _rows(rng, m, m, 12, 3000, ragged=True)
+    B = pa.DeviceCSR(H)
+    cperm = rng.permutation(m).astype(np.int32)
+    q = C.c_void_p()
+    L.call("pa_csr_create_permuted", B.h, None, L.ptr(cperm), C.byref(q))
+    Q = pa.DeviceCSR.from_handle(q, m, m, H.nnz)
+    x = rng.standard_normal(m)
+    xd = pa.DeviceVector(m, 0).upload(x)
+    xq = np.zeros(m); xq[cperm] = x                                    # x_new[col_pos[j]] = x[j]
+    xqd = pa.DeviceVector(m, 0).upload(xq)
+    y0, y1, y2 = pa.DeviceVector(m, 0), pa.DeviceVector(m, 0), pa.DeviceVector(m, 0)
+    pa.spmv_(y0, B, xd)
+    pa.spmv_(y1, Q, xqd)
+    assert np.array_equal(y0.download(), y1.download())
+    for pieces in (2, 3, 5):
+        S = _split(Q, pieces)
+        pa.spmv_(y2, S, xqd, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
+        assert np.array_equal(y2.download(), y0.download()), pieces

@@ -11,7 +11,7 @@ run timeout 900 python tests/fuzz/fuzz_exchange.py 1500 993000
 run timeout 900 python tests/fuzz/fuzz_partitions.py 1000 994000
 run timeout 900 python tests/fuzz/fuzz_hpcg.py 100 995000
 run timeout 900 python tests/fuzz/fuzz_cg.py 40 996000
-for sw in PA_SPMV_VALUE_DICT=1 PA_CTX_PER_PART=1 PA_PUSH=0 PA_MUL_GHOST_FROM_BUFFER=0; do
+for sw in PA_SPMV_VALUE_DICT=1 PA_CTX_PER_PART=1 PA_PUSH=0 PA_MUL_GHOST_FROM_BUFFER=0 PA_SPMV_COLSPLIT=3; do
   run env $sw timeout 900 python tests/fuzz/fuzz_spmv.py 60 997000
   run env $sw timeout 900 python tests/fuzz/fuzz_mul.py 150 997100
   run env $sw timeout 900 python tests/fuzz/fuzz_fem.py 150 997200
