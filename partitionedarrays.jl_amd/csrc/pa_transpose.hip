@@ -542,6 +542,7 @@ int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces) {
     if (A->nnz >= 64) k = mode;                      // (fuzzers: every block of 64 entries or more becomes a chain of `mode` pieces)
   } else if (k <= 0) {
     if (mode == 0 || A->use_pattern || A->compact || !A->use_c16 || A->n_xw_groups > 0 || A->nnz < ((int64_t)1 << 21)) return PA_OK;
+    if (A->ctx->keep_raw_columns) return PA_OK;        // (the caller is about to run the row-selection set-up on this block: whole blocks only)
     if (A->xw_max_span <= window || A->xw_max_span > 4 * 15000) return PA_OK;
     k = (int)((A->xw_max_span + 14999) / 15000);
   }
