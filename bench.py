@@ -894,15 +894,29 @@ def main():
     # been idle for seconds and needs ~40 launches (30 ms) of this kernel to be back at its working clocks -- the first
     # launch after the idle takes 0.83 ms, the 40th 0.68 (rocprofv3 trace of round 2, profiles/r02_summary.json).  W = 5
     # warm-up steps do not cover that; a fixed 150 steps do, the same number on every rank.
+    # Round 4: the ramp has TWO plateaus (27-pt 256^3: 0.80 -> 0.72 -> 0.675 ms per step) and how long the GPU sits on the middle
+    # one differs from lease to lease -- 50 steps on most boxes, more than the 150 of round 3 on others (the driver's round-3 line,
+    # 0.7202 ms, and one of this round's leases were timed there; docs/LAB_NOTEBOOK.md R4.8).  The ramp is now ONE SECOND of steps
+    # queued back to back (no host synchronisation inside: an idle stream is what lets the clocks fall), the same number on every rank.
     PHASE[0] = "clock ramp"
-    ramp = []
-    for _ in range(15):
-        e0 = ctx.event().record(L.STREAM_COMPUTE)
+    e0 = ctx.event().record(L.STREAM_COMPUTE)
+    for _ in range(10):
+        step(overlap_on)
+    e1 = ctx.event().record(L.STREAM_COMPUTE)
+    ctx.sync()
+    ramp = [e0.elapsed_ms(e1) / 10]
+    n_groups = int(min(400, max(14, np.ceil(float(os.environ.get("PA_BENCH_RAMP_S", "1.0")) * 1e3 / (10 * max(ramp[0], 1e-3))))))
+    if N > 1:
+        tg = torch.tensor([n_groups], dtype=torch.int64)
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        n_groups = int(tg.item())
+    gev = [ctx.event().record(L.STREAM_COMPUTE)]
+    for _ in range(n_groups):
         for _ in range(10):
             step(overlap_on)
-        e1 = ctx.event().record(L.STREAM_COMPUTE)
-        ctx.sync()
-        ramp.append(e0.elapsed_ms(e1) / 10)
+        gev.append(ctx.event().record(L.STREAM_COMPUTE))
+    ctx.sync()
+    ramp += [gev[k].elapsed_ms(gev[k + 1]) / 10 for k in range(n_groups)]
     # ---- placement A/B with the product kernel itself (VERDICT r03 #1a), at working clocks, outside every timed region: y
     # where the arena's rule put it, in every other memory class the held extents have room in (the matrix streams' own class is
     # the control that should lose ~13 %) and in a plain hipMalloc; y moves when another place is > 1.5 % faster
@@ -914,6 +928,16 @@ def main():
             pa.mul_(y, A, x)                      # (the A/B leaves y = A_oo * x_own; the full product again before anything reads y)
         except Exception as e:                    # noqa: BLE001  (a diagnostic: never costs the run its line)
             print(f"[bench rank {rank}] placement A/B skipped: {e}", file=sys.stderr, flush=True)
+    # (a box of round 4 ran the ramp and the A/B at 0.7215 ms per step and the timed region, seconds later, at 0.675: the same
+    # ten-step groups once more behind the A/B say on which side of it the change happened)
+    ramp_after_ab = []
+    for _ in range(3):
+        e0 = ctx.event().record(L.STREAM_COMPUTE)
+        for _ in range(10):
+            step(overlap_on)
+        e1 = ctx.event().record(L.STREAM_COMPUTE)
+        ctx.sync()
+        ramp_after_ab.append(e0.elapsed_ms(e1) / 10)
     # clocks / power / partition modes under load, before and after the timed region (sysfs of this context's GPU)
     def telemetry_under_load():
         for _ in range(30):
@@ -1015,7 +1039,7 @@ def main():
         out = {
             "metric": "HPCG 27-pt SpMV GFLOP/s + achieved HBM GB/s per GPU",
             "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
-            "warmup_effective": args.warmup + 10 * len(ramp),
+            "warmup_effective": args.warmup + 10 * len(ramp) + 10 * len(ramp_after_ab),
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"HPCG 27-pt stencil {n}^3 rows per part, {N} part(s) as ({npx},{npy},{npz}), "
@@ -1072,9 +1096,14 @@ def main():
                      "what": "the first 10 steps after the host-side parity gate (GPU idle for seconds): what a solver that calls mul! "
                              "right after a host-side pause sees; `value` is the steady state after `warmup_effective` steps"},
             "clock_ramp": {"steps": 10 * len(ramp), "first_10_ms_per_step": round(ramp[0], 4), "last_10_ms_per_step": round(ramp[-1], 4),
-                           "ms_per_step_by_10": [round(v, 4) for v in ramp],
+                           "ms_per_step_by_10": [round(v, 4) for v in (ramp if len(ramp) <= 30 else ramp[:15] + ramp[15:-5:10] + ramp[-5:])],
+                           "ms_per_step_by_10_is": "every group of ten steps" if len(ramp) <= 30 else "the first 15 groups of ten steps, every tenth group after them, the last 5",
+                           "ms_per_step_by_10_after_placement_ab": [round(v, 4) for v in ramp_after_ab],
                            "what": "untimed steps run before the W warm-up steps (they ARE warm-up: warmup_effective counts them): the "
-                                   "GPU idles during the host-side parity gate and needs ~40 launches to be back at its working clocks"},
+                                   "GPU idles during the host-side parity gate and comes back to its working clocks over two plateaus; how "
+                                   "long it stays on the second differs between leases, so the ramp is one second of steps queued back to back "
+                                   "(PA_BENCH_RAMP_S)",
+                           "plateau_ms_per_step": {"min": round(min(ramp), 4), "median_last_20_groups": round(float(np.median(ramp[-20:])), 4)}},
             "setup_s": round(t_setup, 1),
         }
         LINE[0] = out
