@@ -1191,7 +1191,8 @@ def main():
                 return time.perf_counter() - t
             res = {}
             import functools
-            for name, fn in (("ref_cg", pa.ref_cg_), ("opt_cg", functools.partial(pa.opt_cg_, fuse=True))):
+            for name, fn in (("ref_cg", pa.ref_cg_), ("opt_cg_unfused", functools.partial(pa.opt_cg_, fuse=False)),
+                             ("opt_cg", functools.partial(pa.opt_cg_, fuse=True))):
                 cg_time(fn, 2)
                 d = cg_time(fn, 4 + args.cg_iters) - cg_time(fn, 4)     # the difference cancels allocation + first residual
                 if N > 1:
@@ -1207,10 +1208,13 @@ def main():
                                               "Identity preconditioner): consistent!+mul!, 2 dots + norm, 3 axpys",
                                       "iterations_timed": args.cg_iters,
                                       "ms_per_iteration_ref_cg": round(cg["ref_cg"], 4),
+                                      "ms_per_iteration_opt_cg_unfused": round(cg["opt_cg_unfused"], 4),
                                       "ms_per_iteration_opt_cg": round(cg["opt_cg"], 4),
                                       "gflops_opt_cg": round(cg_flops / (cg["opt_cg"] * 1e-3) / 1e9, 1),
-                                      "note": "opt_cg_(fuse=True) = scalars kept on the device, u'c accumulated inside the product "
-                                              "kernels, x's update fused into u's pass"}
+                                      "note": "ref_cg_ = the reference's schedule, a blocking reduction to the host per dot; opt_cg_(fuse=False) = the "
+                                              "same kernels in the same order with the scalars kept on the device: the iterates of ref_cg_ bit for "
+                                              "bit (tests/test_gpu_blas1_cg.py); opt_cg_(fuse=True) = also u'c accumulated inside the product "
+                                              "kernels and x's update fused into u's pass (iterates within 1e-9)"}
 
     general = None
     if N == 1 and args.extra and rank == 0:
