@@ -459,20 +459,35 @@ static int ipc_open_chunk(const hipIpcMemHandle_t &h, void **base) {
 static int ipc_prepare(pa_plan *p) {
   if (p->ipc) return PA_OK;
   PA_REQUIRE(p->phase == 0, "an exchange is in flight on this plan: its buffers cannot move into an ipc region now");
-  pa_ipc_link *L = new pa_ipc_link();
-  int64_t a, b, c, d;
-  L->n_flags = std::max(1, ipc_flags_layout(p, &a, &b, &c, &d));
   PA_HIP(hipSetDevice(p->ctx->device));
   PA_HIP(hipStreamSynchronize(p->ctx->s[0]));
   PA_HIP(hipStreamSynchronize(p->ctx->s[1]));
+  pa_ipc_link *L = new pa_ipc_link();
+  // everything that can fail happens BEFORE the plan is touched: a failure leaves the plan on its own buffers and nothing behind
+  auto fail = [&](int st) {
+    if (L->d_done) (void)hipFree(L->d_done);
+    if (L->h_status) (void)hipHostFree(L->h_status);
+    if (L->chunk >= 0) ipc_region_give_back(L->chunk, L->chunk_off, L->region_bytes);
+    delete L;
+    (void)hipGetLastError();
+    return st;
+  };
+  int64_t a, b, c, d;
+  L->n_flags = std::max(1, ipc_flags_layout(p, &a, &b, &c, &d));
   auto up = [](size_t x) { return (x + 255) / 256 * 256; };
   L->off_snd = 0;
   L->off_rcv = (int64_t)up(sizeof(double) * std::max<int64_t>(1, p->snd.n));
   L->off_flags = L->off_rcv + (int64_t)up(sizeof(double) * std::max<int64_t>(1, p->rcv.n));
   L->region_bytes = ((size_t)L->off_flags + up(sizeof(unsigned long long) * L->n_flags) + 4095) / 4096 * 4096;
-  PA_TRY(ipc_region_take(p->ctx->device, L->region_bytes, &L->chunk, &L->chunk_off));
-  L->d_region = g_ipc_chunks[L->chunk].base + L->chunk_off;
-  PA_HIP(hipMemset(L->d_region, 0, L->region_bytes));
+  if (int st = ipc_region_take(p->ctx->device, L->region_bytes, &L->chunk, &L->chunk_off)) { L->chunk = -1; return fail(st); }
+  { std::lock_guard<std::mutex> lk(g_ipc_mu); L->d_region = g_ipc_chunks[L->chunk].base + L->chunk_off; }
+  if (hipMemset(L->d_region, 0, L->region_bytes) != hipSuccess || hipMalloc((void **)&L->d_done, sizeof(unsigned)) != hipSuccess ||
+      hipMemset(L->d_done, 0, sizeof(unsigned)) != hipSuccess ||
+      hipHostMalloc((void **)&L->h_status, sizeof(int), hipHostMallocMapped) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    pa_set_err("ipc link: device memory for the region's bookkeeping could not be set up");
+    return fail(PA_ERR_HIP);
+  }
+  *L->h_status = 0;
   // the plan's buffers move into the region (they hold nothing between two exchanges); tables that cached the old addresses go
   for (int m = 0; m < 2; ++m) if (p->push[m]) { p->push[m]->free_all(); delete p->push[m]; p->push[m] = nullptr; }
   (void)pa_raw_free(p->snd.d_buf);
@@ -481,11 +496,6 @@ static int ipc_prepare(pa_plan *p) {
   p->rcv.d_buf = (double *)(L->d_region + L->off_rcv);
   p->bufs_in_ipc_region = true;
   L->d_flags = (unsigned long long *)(L->d_region + L->off_flags);
-  PA_HIP(hipMalloc((void **)&L->d_done, sizeof(unsigned)));
-  PA_HIP(hipMemset(L->d_done, 0, sizeof(unsigned)));
-  PA_HIP(hipHostMalloc((void **)&L->h_status, sizeof(int), hipHostMallocMapped));
-  *L->h_status = 0;
-  PA_HIP(hipDeviceSynchronize());
   double secs = 30.0;
   if (const char *e = getenv("PA_IPC_TIMEOUT_S")) secs = std::max(0.001, atof(e));
   L->ticks = (long long)(secs * 1e8);                  // wall_clock64: 100 MHz
