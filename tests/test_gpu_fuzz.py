@@ -47,11 +47,12 @@ def test_corrupted_inputs_are_rejected_with_a_status():
     assert ", 0 accepted" in out, out[-800:]
 
 
-@pytest.mark.parametrize("switches", [{"PA_SPMV_VALUE_DICT": "1"}, {"PA_CTX_PER_PART": "1"}, {"PA_PUSH": "0"}, {"PA_MUL_GHOST_FROM_BUFFER": "0"}])
+@pytest.mark.parametrize("switches", [{"PA_SPMV_VALUE_DICT": "1"}, {"PA_CTX_PER_PART": "1"}, {"PA_PUSH": "0"}, {"PA_MUL_GHOST_FROM_BUFFER": "0"},
+                                      {"PA_SPMV_COLSPLIT": "3"}])
 def test_fuzzers_under_the_round_4_switches(switches):
     """The routes round 4 added or made the default, each forced or switched off: the value dictionary on EVERY block that
     qualifies (the fuzzers' blocks are below the automatic threshold), one device context per part, the round-3 exchange
-    (pack + copies), own x ghost behind the unpack."""
+    (pack + copies), own x ghost behind the unpack, every block of 64 entries or more as a chain of three column pieces."""
     for script, cases, seed0 in (("fuzz_spmv.py", 12, 426000), ("fuzz_mul.py", 30, 426100), ("fuzz_fem.py", 30, 426200), ("fuzz_exchange.py", 100, 426300)):
         out = _fuzz(script, cases, seed0, env=switches)
         assert " 0 mismatches" in out or " 0 with mismatches" in out, (switches, out[-500:])
