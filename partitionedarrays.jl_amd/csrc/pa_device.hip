@@ -2868,6 +2868,24 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
       PA_TRY(matrix_rb(m[r]));
       if ((plans[r]->snd.n || plans[r]->rcv.n) && !m[r]->oh_rb && m[r]->oh->t_nnz) all_rb = false;
     }
+    // Inside a graph capture (all parts in one context): ONE chain of kernels on the compute stream -- push, then per part own x own
+    // and own x ghost from the receive buffers, then the unpack.  Nothing overlaps inside the chain (replayed, the kernels follow
+    // each other without launch gaps), and no edge between two streams is recorded: such a graph replays 2.6 x slower than the eager
+    // calls (config 5 on 8 parts: 0.118 ms per part against 0.045).
+    bool one_ctx = true;
+    for (int r = 1; r < n_parts; ++r) one_ctx = one_ctx && m[r]->ctx == m[0]->ctx;
+    if (all_rb && one_ctx && m[0]->ctx->capturing && !(getenv("PA_GRAPH_ONE_STREAM") && atoi(getenv("PA_GRAPH_ONE_STREAM")) == 0)) {
+      PA_TRY(pa_exchange_push_local_one_stream(plans.data(), n_parts, b, PA_CONSISTENT));
+      for (int r = 0; r < n_parts; ++r) {
+        pa_plan *p = plans[r];
+        PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
+        if (!(p->snd.n || p->rcv.n) || !m[r]->oh_rb) continue;
+        pa_vec buf;
+        buf.ctx = m[r]->ctx; buf.d = p->snd.d_buf; buf.n_own = p->snd.n; buf.n_ghost = 0; buf.owned = false;
+        PA_TRY(pa_spmv(m[r]->oh_rb, &buf, PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, 1.0));
+      }
+      return pa_exchange_finish_all_insert(plans.data(), n_parts, b, 3);
+    }
     PA_TRY(pa_exchange_push_local(plans.data(), n_parts, b, PA_CONSISTENT));
   } else {
     for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], b[r], PA_CONSISTENT));

@@ -196,6 +196,7 @@ struct pa_plan {
 bool pa_plan_ipc_connected(const pa_plan *p);
 int pa_exchange_start(pa_plan *p, pa_comm *comm, pa_vec *v, int mode);   // pack + transport of one part (RCCL / ipc / none)
 int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int on_comm_stream);   // after pa_exchange_push_local(CONSISTENT)
+int pa_exchange_push_local_one_stream(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode);
 int pa_exchange_join_all(pa_plan *const *plans, int32_t n_parts);
 void pa_push_release(pa_plan *p);                // frees what pa_push.hip hung on a plan
 int pa_ipc_ack(pa_plan *p, int mode);            // (compute stream) tell the senders of the exchange just consumed that the buffer is free

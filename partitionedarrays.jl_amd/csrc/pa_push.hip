@@ -269,7 +269,17 @@ static int local_table(pa_plan *const *plans, int n_parts, int mode, pa_push_tab
 // pack + exchange! of every part of this process in one launch per device: what pa_exchange_pack on every part followed by
 // pa_exchange_local does, minus the send buffers.  Afterwards every plan is in the state pa_exchange_local leaves it in
 // (pa_exchange_finish is next).
+static int push_local_impl(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode, bool one_stream);
 extern "C" int pa_exchange_push_local(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode) {
+  return push_local_impl(plans, n_parts, v, mode, false);
+}
+// The same launch ON THE COMPUTE STREAM, no events: what pa_mul_all records into a hipGraph (a graph with edges between two streams
+// replays 2.6 x slower than the eager calls; one chain of kernels replays faster than they launch).  One device only; the readers of
+// the receive buffers and pa_exchange_finish_all_insert(..., 3) follow on the same stream.
+int pa_exchange_push_local_one_stream(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode) {
+  return push_local_impl(plans, n_parts, v, mode, true);
+}
+static int push_local_impl(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode, bool one_stream) {
   PA_REQUIRE(plans && v && n_parts > 0 && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
   for (int r = 0; r < n_parts; ++r) {
     PA_REQUIRE(plans[r] && v[r] && plans[r]->part == r, "plans[%d] is not the plan of part %d", r, r);
@@ -285,6 +295,20 @@ extern "C" int pa_exchange_push_local(pa_plan *const *plans, int32_t n_parts, pa
   for (pa_push_table::launch &l : T->launches) any = any || l.n_blocks || l.n_ublocks;
   if (!any) {
     for (int r = 0; r < n_parts; ++r) { plans[r]->phase = 2; plans[r]->mode = mode; plans[r]->own_comm_stream = false; plans[r]->ev_wait = nullptr; }
+    return PA_OK;
+  }
+  if (one_stream) {
+    PA_REQUIRE(T->launches.size() == 1, "the one-stream order needs all parts on one device");
+    pa_push_table::launch &l = T->launches[0];
+    pa_ctx *c = l.ctx;
+    PA_HIP(hipSetDevice(c->device));
+    if (l.n_blocks) {
+      pa_push_vecs vv;
+      for (size_t k = 0; k < l.parts.size(); ++k) vv.v[k] = v[l.parts[k]]->d;
+      hipLaunchKernelGGL(k_push_local, dim3(l.n_blocks), dim3(256), 0, c->s[0], l.d_parts, l.d_segs, l.d_block_part, vv);
+      PA_HIP(hipGetLastError());
+    }
+    for (int r : l.parts) { plans[r]->phase = 2; plans[r]->mode = mode; plans[r]->own_comm_stream = false; plans[r]->ev_wait = nullptr; }
     return PA_OK;
   }
   for (pa_push_table::launch &l : T->launches) {
@@ -320,7 +344,8 @@ extern "C" int pa_exchange_push_local(pa_plan *const *plans, int32_t n_parts, pa
 
 // unpack (insert) of every part of the group with one launch per device, behind whatever read the receive buffers since the
 // arrival.  on_comm_stream = 0: on the compute streams (the caller's readers ran there); 1: on the comm streams, and the compute
-// streams wait for it; 2: on the comm streams, the compute streams join later (pa_exchange_join_all).  consistent! only.
+// streams wait for it; 2: on the comm streams, the compute streams join later (pa_exchange_join_all); 3: on the compute stream,
+// nothing to wait for (the one-stream order of a graph capture).  consistent! only.
 int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int on_comm_stream) {
   pa_push_table *T = plans[0]->push[PA_CONSISTENT];
   PA_REQUIRE(T && (int)T->key.size() == n_parts && std::equal(T->key.begin(), T->key.end(), plans), "no push table for these plans");
@@ -330,8 +355,10 @@ int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec
     pa_ctx *c = l.ctx;
     if (!any) { for (int r : l.parts) { plans[r]->phase = 0; plans[r]->ev_wait = nullptr; } continue; }
     PA_HIP(hipSetDevice(c->device));
+    const bool one_stream = on_comm_stream == 3;         // behind pa_exchange_push_local_one_stream: everything is on the compute stream
+    if (one_stream) on_comm_stream = 0;
     hipStream_t st = on_comm_stream ? c->s[1] : c->s[0];
-    if (!on_comm_stream) PA_HIP(hipStreamWaitEvent(c->s[0], l.ev, 0));
+    if (!on_comm_stream && !one_stream) PA_HIP(hipStreamWaitEvent(c->s[0], l.ev, 0));
     if (l.n_ublocks) {
       pa_unpack_vecs vv;
       for (size_t k = 0; k < l.parts.size(); ++k) vv.v[k] = v[l.parts[k]]->d;

@@ -140,9 +140,13 @@ def test_a_ghost_nobody_sends_keeps_the_unpack_route():
         L.call("pa_plan_destroy", p)
 
 
-def test_mul_all_replayed_from_a_hipgraph(orc):
-    """The whole mul! of 8 parts (push launch on the comm stream, 8 own x own, 8 own x ghost from the buffers, one unpack launch)
-    captured once and replayed: the bits of the eager call, also after x changed between replays."""
+@pytest.mark.parametrize("one_stream", ["1", "0"])
+def test_mul_all_replayed_from_a_hipgraph(orc, monkeypatch, one_stream):
+    """The whole mul! of 8 parts (push launch, 8 own x own, 8 own x ghost from the buffers, one unpack launch) captured once and
+    replayed: the bits of the eager call, also after x changed between replays, and x's ghosts made consistent by the replay.
+    Recorded as ONE chain on the compute stream (the default inside a capture: a graph with edges between two streams replays
+    2.6 x slower than the eager calls) and, PA_GRAPH_ONE_STREAM=0, with the eager call's two streams."""
+    monkeypatch.setenv("PA_GRAPH_ONE_STREAM", one_stream)
     n, np3 = (10, 8, 6), (2, 2, 2)
     A = pa.build_p_matrix(ranks(8), *n, *(a * q for a, q in zip(n, np3)), *np3)[0]
     Ao = orc.hpcg_build_p_matrix(*n, *np3)[0]
@@ -161,6 +165,10 @@ def test_mul_all_replayed_from_a_hipgraph(orc):
         yo = oracle_mul(orc, Ao, xr)
         for got, e, r in zip(y.own_values().items, yo, Ao.rows):
             assert np.array_equal(got, e[:r.n_own]), rep
+        xc = [v.copy() for v in xr]
+        orc.consistent(xc, Ao.cols)
+        for got, e in zip(x.local_values().items, xc):
+            assert np.array_equal(got, e), rep
 
 
 def test_pa_mul5_over_a_one_rank_rccl_communicator():
