@@ -522,6 +522,12 @@ __global__ void kt_piece_keys(const int *__restrict__ row, const int *__restrict
   long long j = ((long long)col[p] - t0) / w;
   key[p] = (int)(j < 0 ? 0 : j >= k ? k - 1 : j);
 }
+// entries whose piece lies below that of the entry before them in the same row (rows whose columns do not ascend)
+__global__ void kt_count_descents(const int *__restrict__ row, const int *__restrict__ key, int n, int *__restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < 1 || p >= n) return;
+  if (row[p] == row[p - 1] && key[p] < key[p - 1]) atomicAdd(out, 1);
+}
 __global__ void kt_take(const int *__restrict__ perm, int first, int n, const int *__restrict__ row, const int *__restrict__ col,
                         const double *__restrict__ val, int *__restrict__ out_row, int *__restrict__ out_col, double *__restrict__ out_val,
                         int *__restrict__ out_src) {
@@ -566,6 +572,16 @@ int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces) {
   PA_TRY(sc.get(&d_first, (size_t)k + 2));
   PA_TRY(pa_dev_decode_entries(A, d_row, d_col));
   hipLaunchKernelGGL(kt_piece_keys, grid1(nnz), dim3(256), 0, s, d_row, d_col, (int)nnz, slope, half, w, k, d_key);
+  if (force_pieces <= 0 && mode == 1) {
+    // (an automatic split of rows whose columns do not ascend buys nothing: the running maximum below sweeps most of such a row into
+    // its last piece, which is then as wide as the block was)
+    int *d_cnt = nullptr, cnt = 0;
+    PA_TRY(sc.get(&d_cnt, 1));
+    PA_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int), s));
+    hipLaunchKernelGGL(kt_count_descents, grid1(nnz), dim3(256), 0, s, d_row, d_key, (int)nnz, d_cnt);
+    PA_TRY(d2h(s, &cnt, d_cnt, 1));
+    if ((int64_t)cnt * 100 > nnz) return PA_OK;
+  }
   {
     // The pieces must take CONSECUTIVE runs of a row's entries, or the row's sum changes its order.  A row whose columns ascend
     // has that by itself; a twin with renamed columns (own x ghost reading the receive buffer, a renumbered block: entries in the
