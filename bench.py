@@ -485,6 +485,38 @@ def extra_configs(pa, ctx, L, out):
                 "ms_per_part_mul": round(ms / 2, 4), "ms_per_part_mul_hipgraph": round(ms_graph / 2, 4), "ms_per_part_spmv": round(ms_spmv / 2, 4),
                 "mul_over_spmv": round(ms / ms_spmv, 3), **chain_info(2), "gflops": round(2.0 * nnz32 / ms / 1e6, 1), "setup_s": round(ts, 1)})
     del A32, x32, y32
+    # consistent!(v) and assemble!(v) on their own (rows a7-a9 of SURVEY 8): config 4's partition shape, (2,2,2) parts of 128^3
+    # rows with all 26-neighbour ghost layers, the 8 parts on this ONE GPU -- one push launch (pack + deliver) and one unpack launch
+    # per call, whatever the number of parts and neighbours
+    PHASE[0] = "extra: consistent! / assemble! alone"
+    try:
+        t = time.perf_counter()
+        ranks8 = pa.DebugArray(range(1, 9))
+        A48, _ = pa.build_p_matrix(ranks8, 128, 128, 128, 256, 256, 256, 2, 2, 2)
+        ts = time.perf_counter() - t
+        v48 = pa.pvector_from_function(lambda ind: hash_x(ind.get_local_to_global()) * (ind.get_local_to_owner() == ind.part), A48.col_partition)
+        ghosts48 = [c.n_ghost for c in pa.local_items(A48.col_partition)]
+        res48 = {}
+        for name, op in (("consistent", pa.consistent_), ("assemble", pa.assemble_)):
+            for _ in range(10):
+                op(v48).wait()
+            e0 = ctx.event().record(L.STREAM_COMPUTE)
+            for _ in range(50):
+                op(v48).wait()
+            e1 = ctx.event().record(L.STREAM_COMPUTE)
+            ctx.sync()
+            res48[name] = e0.elapsed_ms(e1) / 50
+        out.append({"workload": "consistent!(v) / assemble!(v) alone: (2,2,2) parts of 128^3 rows (config 4's shape, 26 neighbour relations per "
+                                "interior corner), the 8 parts on this one GPU, push transport (one launch packs and delivers, one unpacks / adds in order)",
+                    "parts": 8, "ghosts_per_part": ghosts48, "ms_per_consistent_all_parts": round(res48["consistent"], 4),
+                    "ms_per_assemble_all_parts": round(res48["assemble"], 4),
+                    "ghost_values_moved_per_call": int(sum(ghosts48)),
+                    "gbps_consistent": round(3 * 8 * sum(ghosts48) / res48["consistent"] / 1e6, 1),
+                    "what": "bytes: every ghost value is read from its owner, written to the receive buffer and read + written by the unpack "
+                            "(3 x 8 B counted); these calls are latency-bound launches (2 per call), not bandwidth", "setup_s": round(ts, 1)})
+        del A48, v48
+    except Exception as ex:                                     # noqa: BLE001
+        print(f"[bench] exchange-only entry skipped: {ex}", file=sys.stderr)
     # config 5: the rows one part of the 4096^2-node Q1 FEM matrix on (4,2) parts holds: 1024 x 2048 nodes
     PHASE[0] = "extra: config 5 part"
     t = time.perf_counter()

@@ -259,6 +259,8 @@ int pa_exchange_rccl(pa_plan *plan, pa_comm *comm, int mode);
  *     exchange over the link fails with PA_ERR_STATE -- the GPU is never left spinning.  Not inside a graph capture.
  * pa_mul5 / pa_mul_no_lat / pa_mul_dot / pa_mul5_transpose with comm == NULL use a connected plan's ipc link. */
 int pa_exchange_push_local(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode);
+/* pa_exchange_finish of every part behind pa_exchange_push_local in one call (consistent!: one unpack launch for all parts) */
+int pa_exchange_finish_all(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode);
 int pa_plan_ipc_blob_size(pa_plan *plan, int64_t *bytes);
 int pa_plan_ipc_blob(pa_plan *plan, void *out, int64_t capacity);
 int pa_plan_ipc_connect(pa_plan *plan, int32_t n_blobs, const void *const *blobs, const int64_t *sizes);

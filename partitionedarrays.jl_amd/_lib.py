@@ -180,6 +180,7 @@ _SIGS = {
     "pa_exchange_local": [PP, i32, cint],
     "pa_exchange_rccl": [P, P, cint],
     "pa_exchange_push_local": [PP, i32, PP, cint],
+    "pa_exchange_finish_all": [PP, i32, PP, cint],
     "pa_plan_ipc_blob_size": [P, C.POINTER(i64)],
     "pa_plan_ipc_blob": [P, P, i64],
     "pa_plan_ipc_connect": [P, i32, P, P],

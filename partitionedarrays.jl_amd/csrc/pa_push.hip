@@ -74,6 +74,34 @@ __global__ __launch_bounds__(256) void k_unpack_insert_multi(const pa_unpack_par
   if (p < P.n) vecs.v[pi][P.idx[p]] = P.buf[p];
 }
 
+// assemble!'s wait(t) of all parts of a device in one launch: the ordered adds of every part (k_unpack_add: one lane per target adds
+// its sources in ascending order) in the first blocks, fill!(ghost_values, 0) of every part (src/p_vector.jl:703-705) in the rest
+struct pa_add_part { const int32_t *tgt, *tptr, *tp; const double *buf; int32_t n_tgt, blk0; };
+struct pa_add_vecs { double *v[PA_PUSH_MAX_PARTS]; int32_t ghost0[PA_PUSH_MAX_PARTS], n_ghost[PA_PUSH_MAX_PARTS], zblk0[PA_PUSH_MAX_PARTS + 1]; int32_t n_parts, n_add_blocks; };
+__global__ __launch_bounds__(256) void k_unpack_add_multi(const pa_add_part *__restrict__ parts, const int32_t *__restrict__ block_part, pa_add_vecs vecs) {
+  const int b = (int)blockIdx.x;
+  if (b < vecs.n_add_blocks) {
+    const int pi = block_part[b];
+    const pa_add_part P = parts[pi];
+    const int k = (b - P.blk0) * 256 + (int)threadIdx.x;
+    if (k >= P.n_tgt) return;
+    double *v = vecs.v[pi];
+    const int lid = P.tgt[k];
+    // (a target can be a GHOST entry -- the wrap-around copies of a periodic direction: the reference adds into it and then zeroes
+    // every ghost; the zeroing runs in this very launch, so such a target is simply left to it)
+    if (lid >= vecs.ghost0[pi]) return;
+    double acc = v[lid];
+    for (int j = P.tptr[k]; j < P.tptr[k + 1]; ++j) acc = acc + P.buf[P.tp[j]];
+    v[lid] = acc;
+    return;
+  }
+  const int zb = b - vecs.n_add_blocks;
+  int pi = 0;
+  while (pi + 1 < vecs.n_parts && zb >= vecs.zblk0[pi + 1]) ++pi;
+  const int g = (zb - vecs.zblk0[pi]) * 256 + (int)threadIdx.x;
+  if (g < vecs.n_ghost[pi]) vecs.v[pi][vecs.ghost0[pi] + g] = 0.0;
+}
+
 __device__ __forceinline__ unsigned long long flag_load(const unsigned long long *p) {
   return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -157,6 +185,10 @@ struct pa_push_table {
     pa_unpack_part *d_uparts = nullptr;
     int32_t *d_ublock_part = nullptr;
     int n_ublocks = 0;
+    // (assemble! tables) the matching multi-part ordered add
+    pa_add_part *d_aparts = nullptr;
+    int32_t *d_ablock_part = nullptr;
+    int n_ablocks = 0;
     hipEvent_t ev = nullptr;
   };
   std::vector<launch> launches;
@@ -165,6 +197,7 @@ struct pa_push_table {
       (void)hipSetDevice(l.ctx->device);
       (void)pa_raw_free(l.d_parts); (void)pa_raw_free(l.d_segs); (void)pa_raw_free(l.d_block_part);
       (void)pa_raw_free(l.d_uparts); (void)pa_raw_free(l.d_ublock_part);
+      (void)pa_raw_free(l.d_aparts); (void)pa_raw_free(l.d_ablock_part);
       if (l.ev) (void)hipEventDestroy(l.ev);
     }
     launches.clear();
@@ -192,8 +225,9 @@ static int build_local_table(pa_plan *const *plans, int n_parts, int mode, pa_pu
     if ((int)l.parts.size() > PA_PUSH_MAX_PARTS) { delete T; pa_set_err("more than %d parts on one device", PA_PUSH_MAX_PARTS); return PA_ERR_ARG; }
     std::vector<pa_push_part> parts;
     std::vector<pa_push_seg> segs;
-    std::vector<int32_t> bp, ubp;
+    std::vector<int32_t> bp, ubp, abp;
     std::vector<pa_unpack_part> uparts;
+    std::vector<pa_add_part> aparts;
     for (size_t k = 0; k < l.parts.size(); ++k) {
       pa_plan *ps = plans[l.parts[k]];
       pa_plan::side &o = out_side(ps, mode);
@@ -225,6 +259,12 @@ static int build_local_table(pa_plan *const *plans, int n_parts, int mode, pa_pu
       const int nub = (int)((in.n + 255) / 256);
       for (int b = 0; b < nub; ++b) ubp.push_back((int32_t)k);
       uparts.push_back(U);
+      if (mode == PA_ASSEMBLE) {
+        pa_add_part Ap;
+        Ap.tgt = ps->d_tgt; Ap.tptr = ps->d_tptr; Ap.tp = ps->d_tp; Ap.buf = in.d_buf; Ap.n_tgt = (int32_t)ps->n_tgt; Ap.blk0 = (int32_t)abp.size();
+        for (int b = 0; b < (int)((ps->n_tgt + 255) / 256); ++b) abp.push_back((int32_t)k);
+        aparts.push_back(Ap);
+      }
     }
     // every receiving slice must have a sender inside the group
     (void)hipSetDevice(l.ctx->device);
@@ -233,6 +273,9 @@ static int build_local_table(pa_plan *const *plans, int n_parts, int mode, pa_pu
     if (st == PA_OK) st = upload_vec(bp, &l.d_block_part);
     if (st == PA_OK) st = upload_vec(uparts, &l.d_uparts);
     if (st == PA_OK) st = upload_vec(ubp, &l.d_ublock_part);
+    if (st == PA_OK && mode == PA_ASSEMBLE) st = upload_vec(aparts, &l.d_aparts);
+    if (st == PA_OK && mode == PA_ASSEMBLE) st = upload_vec(abp, &l.d_ablock_part);
+    l.n_ablocks = (int)abp.size();
     if (st == PA_OK && hipEventCreateWithFlags(&l.ev, hipEventDisableTiming) != hipSuccess) { pa_set_err("hipEventCreate failed"); st = PA_ERR_HIP; }
     if (st != PA_OK) { T->free_all(); delete T; return st; }
     l.n_blocks = (int)bp.size();
@@ -375,6 +418,49 @@ int pa_exchange_finish_all_insert(pa_plan *const *plans, int32_t n_parts, pa_vec
     }
     for (int r : l.parts) { plans[r]->phase = 0; plans[r]->ev_wait = nullptr; }
   }
+  return PA_OK;
+}
+
+// wait(t) of every part behind pa_exchange_push_local, one call: consistent! -- one unpack launch per device for all its parts;
+// assemble! -- the parts' ordered adds one after the other (k_unpack_add has no multi-part form).  What pa_exchange_finish on every
+// part does, without a host round trip per part.
+extern "C" int pa_exchange_finish_all(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v, int mode) {
+  PA_REQUIRE(plans && v && n_parts > 0 && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  for (int r = 0; r < n_parts; ++r) PA_REQUIRE(plans[r] && v[r] && plans[r]->phase >= 1 && plans[r]->mode == mode, "part %d: no exchange of this mode in flight", r);
+  pa_push_table *T = plans[0]->push[PA_CONSISTENT];
+  bool table = mode == PA_CONSISTENT && T && (int)T->key.size() == n_parts && std::equal(T->key.begin(), T->key.end(), plans);
+  for (int r = 0; r < n_parts && table; ++r) table = plans[r]->phase == 2 && !plans[r]->own_comm_stream;
+  if (table) return pa_exchange_finish_all_insert(plans, n_parts, v, 0);
+  pa_push_table *Ta = plans[0]->push[PA_ASSEMBLE];
+  bool atable = mode == PA_ASSEMBLE && Ta && (int)Ta->key.size() == n_parts && std::equal(Ta->key.begin(), Ta->key.end(), plans);
+  for (int r = 0; r < n_parts && atable; ++r) atable = plans[r]->phase == 2 && !plans[r]->ipc && Ta->serials[r] == plans[r]->serial;
+  if (atable) {
+    for (pa_push_table::launch &l : Ta->launches) {
+      pa_ctx *c = l.ctx;
+      PA_HIP(hipSetDevice(c->device));
+      bool traffic = l.n_blocks > 0;
+      pa_add_vecs vv;
+      vv.n_parts = (int32_t)l.parts.size(); vv.n_add_blocks = l.n_ablocks;
+      int zb = 0;
+      for (size_t k = 0; k < l.parts.size(); ++k) {
+        pa_vec *w = v[l.parts[k]];
+        vv.v[k] = w->d; vv.ghost0[k] = (int32_t)w->n_own; vv.n_ghost[k] = (int32_t)w->n_ghost; vv.zblk0[k] = zb;
+        zb += (int)((w->n_ghost + 255) / 256);
+      }
+      vv.zblk0[l.parts.size()] = zb;
+      if (traffic || plans[l.parts[0]]->ev_wait) PA_HIP(hipStreamWaitEvent(c->s[0], l.ev, 0));        // wait(t)
+      if (l.n_ablocks + zb > 0)
+        hipLaunchKernelGGL(k_unpack_add_multi, dim3(l.n_ablocks + zb), dim3(256), 0, c->s[0], l.d_aparts, l.d_ablock_part, vv);
+      PA_HIP(hipGetLastError());
+      if (!c->capturing) {                               // the next pack (comm stream) must not overwrite buffers this launch reads
+        PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
+        PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+      }
+      for (int r : l.parts) { plans[r]->phase = 0; plans[r]->ev_wait = nullptr; }
+    }
+    return PA_OK;
+  }
+  for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_finish(plans[r], v[r], mode));
   return PA_OK;
 }
 

@@ -532,10 +532,11 @@ def assemble_impl(mode, vector_partition, cache: DeviceAssemblyCache) -> Task:
     """assemble_impl!(f,vector_partition,cache) (src/p_vector.jl:587-612): pack, start the exchange,
     return a task whose wait() unpacks with f = insert (CONSISTENT) or + (ASSEMBLE)."""
     plans = cache.plans
+    pushed = None
     if isinstance(plans, DebugArray) and _push():
         n = len(plans.items)
-        L.call("pa_exchange_push_local", (C.c_void_p * n)(*[h.value for h in plans.items]), n,
-               (C.c_void_p * n)(*[v.h.value for v in vector_partition.items]), mode)
+        pushed = ((C.c_void_p * n)(*[h.value for h in plans.items]), n, (C.c_void_p * n)(*[v.h.value for v in vector_partition.items]))
+        L.call("pa_exchange_push_local", *pushed, mode)
     elif isinstance(plans, TorchDistArray) and TRANSPORT == "ipc":
         L.call("pa_exchange_push_ipc", plans.item, vector_partition.item.h, mode)
     else:
@@ -543,7 +544,10 @@ def assemble_impl(mode, vector_partition, cache: DeviceAssemblyCache) -> Task:
         _transport(plans, mode)
 
     def finish():
-        pmap(lambda v, p: L.call("pa_exchange_finish", p, v.h, mode), vector_partition, cache.plans)
+        if pushed is not None:                         # all parts in one call (consistent!: one unpack launch)
+            L.call("pa_exchange_finish_all", *pushed, mode)
+        else:
+            pmap(lambda v, p: L.call("pa_exchange_finish", p, v.h, mode), vector_partition, cache.plans)
 
     return Task(finish)
 
