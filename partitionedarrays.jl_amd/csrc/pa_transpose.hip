@@ -699,6 +699,7 @@ extern "C" int pa_mul5_transpose_all(pa_matrix *const *m, int32_t n_parts, pa_ve
     PA_TRY(pa_exchange_local(plans.data(), n_parts, PA_ASSEMBLE));
   }
   for (int r = 0; r < n_parts; ++r) PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
+  if (push) return pa_exchange_finish_all(plans.data(), n_parts, c, PA_ASSEMBLE);     // one launch: every part's ordered adds + ghost zeroing
   for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_finish(plans[r], c[r], PA_ASSEMBLE));
   return PA_OK;
 }
