@@ -1812,9 +1812,12 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
     return;
   }
   if (S->n_chunks > 0) {
-      const int cpx = (int)((S->n_chunks + 7) / 8);
+      int cpx = (int)((S->n_chunks + 7) / 8);
+      static const int alternate = getenv("PA_SPMV_ALTERNATE") ? atoi(getenv("PA_SPMV_ALTERNATE")) : 1;
+      const int gcpx = cpx;
+      if (alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) cpx = -cpx;
 #define PA_LAUNCH_SPMV(C16, PAT, VD)                                                                                     \
-  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
+  hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0, VD>), dim3(gcpx * 8), dim3(SPMV_BLK), 0,    \
                      st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val,           \
                      xs, ys, S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta,             \
                      (double *)nullptr, (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict,         \
@@ -1822,13 +1825,13 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
       const int sel_ = (S->use_pattern ? (S->compact ? 2 : 1) : 0) * 2 + (S->use_c16 ? 1 : 0);
       if (S->pad_products && !S->use_vdict && sel_ < 2) {
         if (sel_ == 1)
-          hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false, 4, true>), dim3(cpx * 8), dim3(SPMV_BLK),
+          hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false, 4, true>), dim3(gcpx * 8), dim3(SPMV_BLK),
                              0, st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                              S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
                              (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict, (const int *)nullptr,
                              (int)S->n_cols - 1);
         else
-          hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, false, 0, 0, false, 4, true>), dim3(cpx * 8), dim3(SPMV_BLK),
+          hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, false, 0, 0, false, 4, true>), dim3(gcpx * 8), dim3(SPMV_BLK),
                              0, st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
                              S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
                              (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict, (const int *)nullptr,

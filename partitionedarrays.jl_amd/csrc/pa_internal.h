@@ -143,6 +143,7 @@ struct pa_csr {
   int64_t n_xw_groups = 0, n_xw_rest = 0, n_xw_chunks = 0, xw_staged = 0;   // n_xw_groups: both tiers
   int64_t n_xw_tier[3] = {0, 0, 0};       // d_xw_grp = [40 KiB-window groups..., 96 KiB..., 128 KiB...]
   int64_t n_xw_ring = 0;           // ring groups (k_spmv_xring), behind the three tiers in d_xw_grp
+  uint64_t n_launched = 0;         // products launched on this slab (k_spmv_rowsplit walks its chunks backwards on every other one)
   int32_t *d_chunk_cmax = nullptr; // per chunk: its highest column (what a ring group's rounds load up to)
   int32_t *d_chunk_p = nullptr;    // n_chunks+1: crp[chunk_row[c]]
   void *d_xw_grp = nullptr;        // n_xw_groups x {first chunk, chunks, first column, columns}

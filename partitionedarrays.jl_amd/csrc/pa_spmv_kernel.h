@@ -178,8 +178,13 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
 #define PA_PSLOT(p) (PAD ? (p) + 2 * ((p) >> 5) : (p))
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
+  // (chunks_per_xcd < 0: the same map walked BACKWARDS -- every other product of a block streams its arrays from the end, so that what
+  // the last product left in the translation caches and in the Infinity Cache is what this one reads first)
+  const bool backwards = chunks_per_xcd < 0;
+  if (backwards) chunks_per_xcd = -chunks_per_xcd;
   int chunk = PA_HOOK_CHUNK_MAP ? b : (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
   if (chunk >= n_chunks || (!PA_HOOK_CHUNK_MAP && (b >> 3) >= chunks_per_xcd)) return;
+  if (backwards) chunk = n_chunks - 1 - chunk;
   if (chunk_list) chunk = chunk_list[chunk];       // a launch over some of the block's chunks (n_chunks = length of the list)
   const int r0 = chunk_row[chunk];
   const int r1 = chunk_row[chunk + 1];
