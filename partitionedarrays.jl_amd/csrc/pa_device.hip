@@ -893,6 +893,27 @@ static void vdict_maintain(const pa_csr *A) {
   }
 }
 
+// Behind a value update (the new values are queued on the compute stream).  A slab whose one-byte-stream product sits in a recorded
+// hipGraph gets its codes and dictionary renewed NOW, in place: the replay reads them, and nothing eager may run in between to
+// renew them lazily (the replay multiplied with the codes of the old values).  When the new values no longer fit a
+// dictionary the recorded graph cannot be served any more: an error, not a silent wrong product.
+static int vdict_after_update(pa_csr *A) {
+  A->val_epoch++;
+  for (pa_csr *S = A; S; S = S->next) {
+    if (!S->vd_captured) continue;
+    PA_REQUIRE(!S->ctx->capturing, "values of a block whose product is already recorded must not be updated inside a capture");
+    S->vdict_dead = false;
+    PA_TRY(vdict_build(S->ctx, S, true));
+    if (!S->use_vdict) {
+      pa_set_err("the new values take more than %d distinct bit patterns, but a recorded hipGraph multiplies through this block's "
+                 "value dictionary: record the graph again (pa_graph_begin / pa_graph_end)", PA_VDICT_MAX);
+      S->vd_captured = false;
+      return PA_ERR_STATE;
+    }
+  }
+  return PA_OK;
+}
+
 // fills the freshly created slab A; on any failure the caller (csr_build_slab) hands back whatever A holds by then
 static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
                          const csr_src &src) {
@@ -1120,6 +1141,13 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   lap("x windows");
   if (tm_) fprintf(stderr, "[pa setup] val %p (%lld B, memory class %d) col %p crp %p chunk_row %p pdesc %p\n", (void *)A->d_val,
                    (long long)(8 * (nnz + pad)), pa_mem_class(c, A->d_val), (void *)A->d_col, (void *)A->d_crp, (void *)A->d_chunk_row, (void *)A->d_pdesc);
+  // what k_spmv_rowsplit reads first of a chunk, in one piece: {first row, its row pointer} pairs
+  {
+    std::vector<int32_t> rp2(2 * chunk_row.size());
+    for (size_t k = 0; k < chunk_row.size(); ++k) { rp2[2 * k] = chunk_row[k]; rp2[2 * k + 1] = crp[chunk_row[k]]; }
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_rp, sizeof(int32_t) * rp2.size(), PA_MEM_MATRIX));
+    PA_HIP(pa_h2d(A->d_chunk_rp, rp2.data(), sizeof(int32_t) * rp2.size()));
+  }
   // lossless value dictionary (see vdict_build): built by kernels from the value stream that is in HBM by now
   PA_TRY(vdict_build(c, A, false));
   return PA_OK;
@@ -1383,7 +1411,7 @@ extern "C" int pa_csr_update_values(pa_csr *A, const double *nzval) {
   PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
   if (d_all) (void)pa_raw_free(d_all);
   PA_HIP(hipGetLastError());
-  return PA_OK;
+  return vdict_after_update(A);
 }
 
 extern "C" int pa_csr_update_values_from(pa_csr *A, const pa_vec *src, int64_t offset) {
@@ -1400,7 +1428,7 @@ extern "C" int pa_csr_update_values_from(pa_csr *A, const pa_vec *src, int64_t o
     else PA_HIP(hipMemcpyAsync(S->d_val, src->d + offset + S->nnz0, sizeof(double) * S->nnz, hipMemcpyDeviceToDevice, A->ctx->s[0]));
   }
   PA_HIP(hipGetLastError());
-  return PA_OK;
+  return vdict_after_update(A);
 }
 
 static void csr_free_chain(pa_csr *A) {
@@ -1412,6 +1440,7 @@ static void csr_free_chain(pa_csr *A) {
     if (A->d_src) pa_dev_free(A->ctx, A->d_src);
     pa_dev_free(A->ctx, A->d_val);
     pa_dev_free(A->ctx, A->d_chunk_row);
+    if (A->d_chunk_rp) pa_dev_free(A->ctx, A->d_chunk_rp);
     if (A->d_row_ids) pa_dev_free(A->ctx, A->d_row_ids);
     if (A->d_col16) pa_dev_free(A->ctx, A->d_col16);
     if (A->d_win) pa_dev_free(A->ctx, A->d_win);
@@ -1597,7 +1626,7 @@ extern "C" int pa_csr_device_bytes(const pa_csr *A, int64_t *bytes) {
   int64_t t = 0;
   for (const pa_csr *S = A; S; S = S->next) {
     const int64_t pad = 8;
-    t += 4 * (S->n_crows + 1) + 4 * (S->n_col32 + pad) + 8 * (S->nnz + pad) + 4 * (S->n_chunks + 1);
+    t += 4 * (S->n_crows + 1) + 4 * (S->n_col32 + pad) + 8 * (S->nnz + pad) + 12 * (S->n_chunks + 1);
     if (S->use_c16) t += 2 * S->n_col16 + 4 * S->n_chunks * PA_C16_WINDOWS;
     if (S->n_xw_groups) t += 4 * (S->n_chunks + 1) + 16 * S->n_xw_groups + 4 * S->n_xw_rest + (S->n_xw_ring ? 4 * S->n_chunks : 0);
     if (S->use_pattern) t += 4 * S->n_chunks * PA_PDESC_INTS + 4 * S->n_pdelta;
@@ -1616,8 +1645,9 @@ extern "C" int pa_csr_stream_bytes(const pa_csr *A, int64_t *bytes) {
   PA_REQUIRE(A && bytes, "bad arguments");
   int64_t t = 0;
   for (const pa_csr *S = A; S; S = S->next) {
-    t += (S->use_vdict ? 1 : 8) * S->nnz + 4 * (S->n_crows + 1) + 4 * (S->n_chunks + 1);
+    t += (S->use_vdict ? 1 : 8) * S->nnz + 4 * (S->n_crows + 1);
     if (S->use_vdict) t += 8 * PA_VDICT_MAX;
+    t += 8 * (S->n_chunks + 1);                                                    // {row, pointer} pairs
     if (S->use_pattern) t += 4 * S->n_chunks * PA_PDESC_INTS + 4 * S->n_pdelta;
     if (S->use_c16) t += 4 * (S->n_chunks - S->n_pattern_chunks) * PA_C16_WINDOWS;
     if (S->n_xw_groups) t += 4 * (S->n_chunks + 1) + 16 * S->n_xw_groups + 4 * S->n_xw_rest + (S->n_xw_ring ? 4 * S->n_chunks : 0);
@@ -1792,13 +1822,13 @@ static void launch_xwin(const pa_csr *S, const double *xs, double *ys, double al
     if (u)
       hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
                          st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
-                         S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, 1.0, kbeta, partial, u,
+                         S->d_chunk_rp, S->d_row_ids, (int)S->n_xw_rest, cpx, 1.0, kbeta, partial, u,
                          (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr, S->d_xw_rest,
                          (int)S->n_cols - 1);
     else
       hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0,
                          st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
-                         S->d_chunk_row, S->d_row_ids, (int)S->n_xw_rest, cpx, alpha, kbeta, (double *)nullptr,
+                         S->d_chunk_rp, S->d_row_ids, (int)S->n_xw_rest, cpx, alpha, kbeta, (double *)nullptr,
                          (const double *)nullptr, (const double *)nullptr, (const unsigned char *)nullptr,
                          (const double *)nullptr, S->d_xw_rest, (int)S->n_cols - 1);
   }
@@ -1819,7 +1849,7 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
 #define PA_LAUNCH_SPMV(C16, PAT, VD)                                                                                     \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0, VD>), dim3(gcpx * 8), dim3(SPMV_BLK), 0,    \
                      st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val,           \
-                     xs, ys, S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta,             \
+                     xs, ys, S->d_chunk_rp, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta,             \
                      (double *)nullptr, (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict,         \
                      (const int *)nullptr, (int)S->n_cols - 1)
       const int sel_ = (S->use_pattern ? (S->compact ? 2 : 1) : 0) * 2 + (S->use_c16 ? 1 : 0);
@@ -1827,16 +1857,17 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
         if (sel_ == 1)
           hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, true, 0, 0, false, 4, true>), dim3(gcpx * 8), dim3(SPMV_BLK),
                              0, st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
-                             S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
+                             S->d_chunk_rp, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
                              (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict, (const int *)nullptr,
                              (int)S->n_cols - 1);
         else
           hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, false, 0, 0, false, 4, true>), dim3(gcpx * 8), dim3(SPMV_BLK),
                              0, st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, xs, ys,
-                             S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
+                             S->d_chunk_rp, S->d_row_ids, (int)S->n_chunks, cpx, alpha, kbeta, (double *)nullptr,
                              (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict, (const int *)nullptr,
                              (int)S->n_cols - 1);
       } else if (S->use_vdict) {
+        if (S->ctx->capturing) const_cast<pa_csr *>(S)->vd_captured = true;
         switch (sel_) {
           case 5: PA_LAUNCH_SPMV(true, 2, true); break;
           case 4: PA_LAUNCH_SPMV(false, 2, true); break;
@@ -2022,11 +2053,12 @@ static void gs_color_launch(pa_ctx *c, const pa_csr *A, pa_vec *x, const pa_vec 
 #define PA_LAUNCH_GS(C16, PAT, VD)                                                                                       \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 1, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
-                     (const double *)nullptr, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx, \
+                     (const double *)nullptr, (double *)nullptr, A->d_chunk_rp, A->d_row_ids, (int)A->n_chunks, cpx, \
                      1.0, 0.0, x->d, (const double *)b->d, (const double *)diag->d, A->d_code, A->d_dict,                  \
                      (const int *)nullptr, (int)A->n_cols - 1)
   const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
   if (A->use_vdict) {
+    if (c->capturing) const_cast<pa_csr *>(A)->vd_captured = true;
     switch (sel_) {
       case 5: PA_LAUNCH_GS(true, 2, true); break;
       case 4: PA_LAUNCH_GS(false, 2, true); break;
@@ -2378,11 +2410,12 @@ extern "C" int pa_transfer_restrict_fused(pa_transfer *t, pa_vec *rc, const pa_v
 #define PA_LAUNCH_RR(C16, PAT, VD)                                                                                       \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 2, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \
                      c->s[0], A->d_crp, A->d_col, A->d_col16, A->d_win, A->d_pdesc, A->d_pdelta, A->d_val,           \
-                     (const double *)xf->d, (double *)nullptr, A->d_chunk_row, A->d_row_ids, (int)A->n_chunks, cpx,  \
+                     (const double *)xf->d, (double *)nullptr, A->d_chunk_rp, A->d_row_ids, (int)A->n_chunks, cpx,  \
                      1.0, 0.0, rc->d, (const double *)rf->d, (const double *)nullptr, A->d_code, A->d_dict,                \
                      (const int *)nullptr, (int)A->n_cols - 1)
   const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
   if (A->use_vdict) {
+    if (c->capturing) const_cast<pa_csr *>(A)->vd_captured = true;
     switch (sel_) {
       case 5: PA_LAUNCH_RR(true, 2, true); break;
       case 4: PA_LAUNCH_RR(false, 2, true); break;
@@ -2787,7 +2820,26 @@ int pa_exchange_start(pa_plan *p, pa_comm *comm, pa_vec *v, int mode) {
 // Not built when a ghost column with stored entries gets no message (it would have nothing to read), inside a graph capture, or
 // with PA_MUL_GHOST_FROM_BUFFER=0.
 static int matrix_rb(pa_matrix *m) {
-  if (m->rb_tried || m->transposed) return PA_OK;
+  if (m->transposed) return PA_OK;
+  if (m->oh_rb && m->rb_epoch != m->oh->val_epoch) {
+    // own_ghost's values were updated (pa_csr_update_values*, psparse!) since the twin copied them: the twin follows IN PLACE (the
+    // stored entries keep their order, and a recorded graph keeps the twin's address) -- ADVICE r04: the product silently went on
+    // multiplying own x ghost with the old values.  A column-split original has its values in piece order: that twin is rebuilt.
+    if (!m->oh->next && !m->oh->colsplit) {
+      pa_vec src;
+      src.ctx = m->ctx; src.d = m->oh->d_val; src.n_own = m->oh->nnz; src.n_ghost = 0; src.owned = false;
+      PA_TRY(pa_csr_update_values_from(m->oh_rb, &src, 0));
+      m->rb_epoch = m->oh->val_epoch;
+      return PA_OK;
+    }
+    PA_REQUIRE(!m->ctx->capturing, "own_ghost's values changed: the first product afterwards must run outside a graph capture");
+    PA_HIP(hipStreamSynchronize(m->ctx->s[0]));
+    PA_HIP(hipStreamSynchronize(m->ctx->s[1]));
+    pa_csr_destroy(m->oh_rb);
+    m->oh_rb = nullptr;
+    m->rb_tried = false;
+  }
+  if (m->rb_tried) return PA_OK;
   if (m->ctx->capturing) return PA_OK;
   m->rb_tried = true;
   const int on = getenv("PA_MUL_GHOST_FROM_BUFFER") ? atoi(getenv("PA_MUL_GHOST_FROM_BUFFER")) : 1;
@@ -2805,6 +2857,7 @@ static int matrix_rb(pa_matrix *m) {
   pa_csr *rb = nullptr;
   if (pa_csr_create_remapped(m->oh, map.data(), in.n, &rb) != PA_OK) { (void)hipGetLastError(); return PA_OK; }
   m->oh_rb = rb;
+  m->rb_epoch = m->oh->val_epoch;
   return PA_OK;
 }
 
@@ -2987,7 +3040,7 @@ static int spmv_dot_block(const pa_csr *A, const double *x, double *y, double be
 #define PA_LAUNCH_DOT(C16, PAT)                                                                                           \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 3, false>), dim3(cpx * 8), dim3(SPMV_BLK), 0, \
                      c->s[0], S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, x, ys,     \
-                     S->d_chunk_row, S->d_row_ids, (int)S->n_chunks, cpx, 1.0, kbeta, partial + off, us,              \
+                     S->d_chunk_rp, S->d_row_ids, (int)S->n_chunks, cpx, 1.0, kbeta, partial + off, us,              \
                      (const double *)nullptr, (const unsigned char *)nullptr, (const double *)nullptr,                 \
                      (const int *)nullptr, (int)S->n_cols - 1)
       switch ((S->use_pattern ? (S->compact ? 2 : 1) : 0) * 2 + (S->use_c16 ? 1 : 0)) {

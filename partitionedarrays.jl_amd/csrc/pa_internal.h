@@ -117,6 +117,7 @@ struct pa_csr {
                                    // pa_ctx_keep_raw_columns; what pa_csr_select_rows reads), or NULL
   double *d_val = nullptr;         // padded
   int32_t *d_chunk_row = nullptr;  // n_chunks+1 row boundaries of the row split
+  int32_t *d_chunk_rp = nullptr;   // the same interleaved with the rows' pointers, {chunk_row[k], crp[chunk_row[k]]}: what k_spmv_rowsplit reads
   int32_t *d_row_ids = nullptr;    // compacted row -> row, or NULL
   bool pad_products = false;       // no row patterns and most rows hold a multiple of 8 entries: padded product slots (PADP)
   bool use_c16 = false;            // 16-bit windowed column stream present
@@ -135,6 +136,9 @@ struct pa_csr {
   bool vdict_stale = false;        // the values changed under the codes: fp64 stream until vdict_maintain renews them
   bool vdict_dead = false;         // updated values overflowed the dictionary: fp64 stream for good
   int vdict_products = 0;          // products served since the values changed
+  bool vd_captured = false;        // a product of this slab on the one-byte stream has been recorded into a hipGraph: the codes
+                                   // must follow every value update AT ONCE (the replay reads them), not eight products later
+  uint64_t val_epoch = 0;          // (head) bumped by every value update: what derived blocks (pa_matrix::oh_rb) compare with
   int n_dict = 0;
   uint8_t *d_code = nullptr;       // one byte per stored entry (padded)
   double *d_dict = nullptr;        // PA_VDICT_MAX values
@@ -241,6 +245,7 @@ struct pa_matrix {
   pa_plan *plan = nullptr;                     // exchange plan of the column partition (not owned)
   pa_csr *oh_rb = nullptr;                     // own_ghost with its columns renamed to positions of consistent!'s RECEIVE BUFFER (owned;
   bool rb_tried = false;                       //   built at the first product): own x ghost then needs no unpack before it
+  uint64_t rb_epoch = 0;                       // oh->val_epoch the twin's values were taken at
   bool transposed = false;                     // pa_matrix_create_transposed: oo = A_oo', oh = A_oh' (pa_csr_create_transpose), for pa_mul5_transpose
 };
 

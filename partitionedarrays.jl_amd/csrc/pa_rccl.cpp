@@ -162,15 +162,27 @@ extern "C" int pa_exchange_rccl(pa_plan *p, pa_comm *m, int mode) {
   for (int32_t q : o.nbr) PA_REQUIRE(q >= 0 && q < m->nranks, "bad send neighbour %d", q);
   for (int32_t q : in.nbr) PA_REQUIRE(q >= 0 && q < m->nranks, "bad receive neighbour %d", q);
   PA_NCCL(g_api.GroupStart());
-  for (size_t i = 0; i < in.nbr.size(); ++i) {
+  // (a failing ncclRecv / ncclSend must not leave the group OPEN -- the next RCCL call of this thread would be swallowed by it:
+  // the group is always closed, then the first failure is reported)
+  ncclResult_t first = ncclSuccess;
+  const char *what = "";
+  for (size_t i = 0; i < in.nbr.size() && first == ncclSuccess; ++i) {
     const size_t len = (size_t)(in.ptrs[i + 1] - in.ptrs[i]);
-    if (len) PA_NCCL(g_api.Recv(in.d_buf + in.ptrs[i], len, ncclDouble, in.nbr[i], m->comm, st));
+    if (len) { first = g_api.Recv(in.d_buf + in.ptrs[i], len, ncclDouble, in.nbr[i], m->comm, st); what = "ncclRecv"; }
   }
-  for (size_t j = 0; j < o.nbr.size(); ++j) {
+  for (size_t j = 0; j < o.nbr.size() && first == ncclSuccess; ++j) {
     const size_t len = (size_t)(o.ptrs[j + 1] - o.ptrs[j]);
-    if (len) PA_NCCL(g_api.Send(o.d_buf + o.ptrs[j], len, ncclDouble, o.nbr[j], m->comm, st));
+    if (len) { first = g_api.Send(o.d_buf + o.ptrs[j], len, ncclDouble, o.nbr[j], m->comm, st); what = "ncclSend"; }
   }
-  PA_NCCL(g_api.GroupEnd());
+  const ncclResult_t closed = g_api.GroupEnd();
+  if (first != ncclSuccess) {
+    pa_set_err("%s failed inside the exchange group of part %d: %s", what, p->part, g_api.GetErrorString(first));
+    return PA_ERR_RCCL;
+  }
+  if (closed != ncclSuccess) {
+    pa_set_err("ncclGroupEnd failed for the exchange of part %d: %s", p->part, g_api.GetErrorString(closed));
+    return PA_ERR_RCCL;
+  }
   p->own_comm_stream = true;
   return pa_plan_mark_arrived(p);
 }

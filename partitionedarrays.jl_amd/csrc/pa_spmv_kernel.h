@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstring>
 #include <thread>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -90,6 +91,17 @@ __device__ __forceinline__ int pa_pattern_col_uniform(int q, int nq, int qs, int
   return rs + (STRIDED ? (int)__umul24((unsigned)rr, (unsigned)stride) : rr) + del;
 }
 
+// The same for a chunk that is ONE run from its first entry on, rows of L >= 2 entries (round 5): no run to look up, no L == 1 case.
+template <bool STRIDED>
+__device__ __forceinline__ int pa_pattern_col_run(int q, int nq, int Lw, int rs, unsigned M, int dsrc) {
+  const int t = max(0, min(q, nq));
+  const int L = STRIDED ? (Lw & 255) : Lw, stride = STRIDED ? (Lw >> 8) : 1;
+  const int rr = (int)__umulhi((unsigned)t, M);
+  const int kk = t - (int)__umul24((unsigned)rr, (unsigned)L);
+  const int del = __builtin_amdgcn_ds_bpermute(kk << 2, dsrc);
+  return rs + (STRIDED ? (int)__umul24((unsigned)rr, (unsigned)stride) : rr) + del;
+}
+
 // Sum of a double over the 64 lanes of a wavefront, the same value returned in every lane, in a fixed order: four DPP
 // row_shr steps inside each row of 16 lanes (a few cycles each; __shfl_down goes through the LDS crossbar, ~100 cycles a
 // step -- on the one wavefront whose exit frees a workgroup's LDS that is 8 % of the product kernel), then the four
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
     const double *__restrict__ val, const double *__restrict__ x_in,
-    double *__restrict__ y, const int *__restrict__ chunk_row, const int *__restrict__ row_ids, int n_chunks,
+    double *__restrict__ y, const int *__restrict__ chunk_rp, const int *__restrict__ row_ids, int n_chunks,
     int chunks_per_xcd, double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
     const double *__restrict__ gs_diag, const unsigned char *__restrict__ code = nullptr,
     const double *__restrict__ dict = nullptr, const int *__restrict__ chunk_list = nullptr, int max_col = 0x7fffffff) {
@@ -186,38 +198,27 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
   if (chunk >= n_chunks || (!PA_HOOK_CHUNK_MAP && (b >> 3) >= chunks_per_xcd)) return;
   if (backwards) chunk = n_chunks - 1 - chunk;
   if (chunk_list) chunk = chunk_list[chunk];       // a launch over some of the block's chunks (n_chunks = length of the list)
-  const int r0 = chunk_row[chunk];
-  const int r1 = chunk_row[chunk + 1];
-  const int p0 = crp[r0];
-  const int p1 = crp[r1];
+  // chunk_rp[2c .. 2c+3] = {first row, its row pointer} of chunk c and of chunk c+1: the chunk's rows AND entries from one 16-byte
+  // scalar read (round 5; chunk_row -> crp[r0], crp[r1] was a second, dependent round trip before the value stream could be
+  // requested).  Eight chunks share a 64-byte line, so seven reads in eight hit in the scalar cache / L2.  (A 96-byte record with
+  // the descriptor inside, read by one vector load per wavefront, measured 2-4 % SLOWER: it misses to HBM every time.)
+  const int r0 = chunk_rp[2 * chunk], p0 = chunk_rp[2 * chunk + 1];
+  const int r1 = chunk_rp[2 * chunk + 2], p1 = chunk_rp[2 * chunk + 3];
   const int base = p0 & ~1;  // 16-byte aligned value pairs, 4-byte aligned c16 pairs
 
-  if (p1 - base <= CAP) {
-    // my first row's extent, fetched early so the latency hides under the matrix stream
-    int ra = 0, re = 0;
-    double urow = 0.0;                       // EPI 3: u[my first row], fetched now so that the reduce phase does not wait for it
-    if (r0 + tid < r1) {
-      ra = crp[r0 + tid];
-      re = crp[r0 + tid + 1];
-      if (EPI == 3) urow = gs_b[row_ids ? row_ids[r0 + tid] : r0 + tid];
-    }
+  // The body of a chunk, once per column encoding (MODE 2: row patterns, 1: 16-bit windowed stream, 0: 32-bit columns): each copy
+  // runs from its first load to the end of the kernel and the copies never meet again.  (Round 5.  As one body with the encodings
+  // as branches inside it, the compiler had to assume at every join that the loads of EITHER side were pending and protect their
+  // registers: the pattern path waited for the row-extent load -- a whole memory round trip -- before it even requested the
+  // values, and a load hoisted or sunk across a join drained the other side's prefetch.  No joins, no such waits.)
+  __shared__ double wsum[EPI == 3 ? BLK / 64 : 1];
+  auto body = [&](auto mode_tag, int nseg, int mywin) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;
     // Unconditional loads: lanes past the chunk's end re-read its last pair (same address => no extra
     // traffic) and their products are never summed.  A guarded load would make the compiler wait for
     // each load before issuing the next (one HBM round trip per k instead of one per chunk).
     // Every load instruction is contiguous across the 64 lanes (16 B, 8 B or 4 B per lane).
     const int last = max((p1 - 1) & ~1, 0);
-    int nseg = 0;
-    if (PAT) nseg = pdesc[chunk * PA_PDESC_INTS];
-    int mywin = -1;
-    if (C16 && nseg <= 0) mywin = win[chunk * PA_C16_WINDOWS + (tid & (PA_C16_WINDOWS - 1))];
-    const bool use16 = C16 && nseg <= 0 && (__builtin_amdgcn_readfirstlane(mywin) >= 0);   // lane 0 holds window 0
-    // A block with row patterns keeps columns only for its chunks WITHOUT a descriptor (compacted streams): such a
-    // chunk's descriptor slot holds where its columns sit relative to its entry offsets (0: full-length streams).
-    int sh16 = 0, sh32 = 0;
-    if (PAT && nseg <= 0) {
-      sh16 = pdesc[chunk * PA_PDESC_INTS + 1];
-      sh32 = pdesc[chunk * PA_PDESC_INTS + 2];
-    }
     d2 v[NPT / 2];
     unsigned cc[NPT / 2];
     int c0[NPT / 2], c1[NPT / 2];
@@ -227,24 +228,42 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       dict_lo = __double2loint(dv);
       dict_hi = __double2hiint(dv);
     }
-    if (PAT && nseg > 0) {
-      const int *d = pdesc + chunk * PA_PDESC_INTS;
-      const int q1 = d[1], q2 = d[2], q3 = d[3];
-      const int s0r = d[4], s1r = d[5], s2r = d[6], s3r = d[7];
-      const int L0 = d[8], L1 = d[9], L2 = d[10], L3 = d[11];
-      const int pt0 = d[12], pt1 = d[13], pt2 = d[14], pt3 = d[15];
-      const unsigned M0 = d[16], M1 = d[17], M2 = d[18], M3 = d[19];
+    // the order of the requests is the order their answers are waited for: what the decode needs (pattern deltas: an L2 hit),
+    // the value stream (HBM; the wait for the deltas leaves it in flight), my row's extent (needed by the row sums only)
+    int dA = 0, dB = 0;
+#define PA_D(k) pdesc[chunk * PA_PDESC_INTS + (k)]
+    if (MODE == 2) {
+      const int pt0 = PA_D(12), pt1 = PA_D(13), pt2 = PA_D(14), pt3 = PA_D(15);
       const int lane = tid & 63;
-      const int dA = pdelta[((lane >> 5) ? pt1 : pt0) * PA_PAT_MAXLEN + (lane & 31)];
-      const int dB = pdelta[((lane >> 5) ? pt3 : pt2) * PA_PAT_MAXLEN + (lane & 31)];
+      dA = pdelta[((lane >> 5) ? pt1 : pt0) * PA_PAT_MAXLEN + (lane & 31)];
+      if (nseg > 2) dB = pdelta[((lane >> 5) ? pt3 : pt2) * PA_PAT_MAXLEN + (lane & 31)];
+    }
 #pragma unroll
-      for (int k = 0; k < NPT / 2; ++k) {
-        const int idx = min(base + (k * BLK + tid) * 2, last);
-        if (VD) cc[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned short *>(code + idx));
-        else v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
-      }
+    for (int k = 0; k < NPT / 2; ++k) {
+      const int idx = min(base + (k * BLK + tid) * 2, last);
+      if (VD) cc[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned short *>(code + idx));
+      else v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
+    }
+    if (MODE == 2) {
+      const int q1 = PA_D(1), q2 = PA_D(2), q3 = PA_D(3);
+      const int s0r = PA_D(4), s1r = PA_D(5), s2r = PA_D(6), s3r = PA_D(7);
+      const int L0 = PA_D(8), L1 = PA_D(9), L2 = PA_D(10), L3 = PA_D(11);
+      const unsigned M0 = PA_D(16), M1 = PA_D(17), M2 = PA_D(18), M3 = PA_D(19);
       const int nq = p1 - p0 - 1;
       const int wave0 = __builtin_amdgcn_readfirstlane(tid & ~63);   // first thread of this wavefront (uniform)
+      if (VD && nseg == 1 && (L0 & 255) != 1) {
+        // ONE run of one pattern (four chunks in five of a stencil block): nothing to look up per step, where the general path
+        // below finds the run of every 128-entry step with ~45 scalar instructions (238 scalar against 188 vector instructions
+        // per wavefront, profiles/r05_k1_sq.json).  Worth 2.5 % on the one-byte value stream and COSTS 2 % on the fp64 stream
+        // (interleaved A/B, 256^3: 0.540 / 0.553 ms and 0.683 / 0.668 ms with / without), hence only with the dictionary.
+#pragma unroll
+        for (int k = 0; k < NPT / 2; ++k) {
+          const int idx = min(base + (k * BLK + tid) * 2, last);
+          c0[k] = pa_pattern_col_run<PAT == 2>(idx - p0, nq, L0, s0r, M0, dA);
+          c1[k] = pa_pattern_col_run<PAT == 2>(idx + 1 - p0, nq, L0, s0r, M0, dA);
+          PA_HOOK_PATTERN_COLS(c0[k], c1[k], r0, r1, tid);
+        }
+      } else
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const int idx = min(base + (k * BLK + tid) * 2, last);
@@ -267,36 +286,43 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         }
         PA_HOOK_PATTERN_COLS(c0[k], c1[k], r0, r1, tid);
       }
-    } else if (use16) {
-      unsigned q[NPT / 2];
-#pragma unroll
-      for (int k = 0; k < NPT / 2; ++k) {
-        const int idx = min(base + (k * BLK + tid) * 2, last);
-        if (VD) cc[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned short *>(code + idx));
-        else v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
-        q[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned *>(col16 + (idx + sh16)));
-      }
-#pragma unroll
-      for (int k = 0; k < NPT / 2; ++k) {
-        // window base of slot s lives in lane s of `mywin` (any 16-lane group): fetch it with ds_bpermute
-        const unsigned lo = q[k] & 0xffffu, hi = q[k] >> 16;
-        // max_col = n_cols - 1: the entry before an odd first entry and the one after an odd last entry belong to the
-        // neighbouring chunks; decoded with THIS chunk's windows their codes can point up to 4095 columns past the end of x
-        // (their products are never summed, but the load must stay inside the vector)
-        c0[k] = min(__builtin_amdgcn_ds_bpermute((lo >> 12) << 2, mywin) + (int)(lo & 4095), max_col);
-        c1[k] = min(__builtin_amdgcn_ds_bpermute((hi >> 12) << 2, mywin) + (int)(hi & 4095), max_col);
-        PA_HOOK_C16_COLS(c0[k], c1[k], lo, hi, r0, r1, tid);
-      }
     } else {
+      // A block with row patterns keeps columns only for its chunks WITHOUT a descriptor (compacted streams): such a
+      // chunk's descriptor slot holds where its columns sit relative to its entry offsets (0: full-length streams).
+      const int sh16 = PAT ? PA_D(1) : 0, sh32 = PAT ? PA_D(2) : 0;
+      if (MODE == 1) {
+        unsigned q[NPT / 2];
 #pragma unroll
-      for (int k = 0; k < NPT / 2; ++k) {
-        const int idx = min(base + (k * BLK + tid) * 2, last);
-        if (VD) cc[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned short *>(code + idx));
-        else v[k] = pa_stream_load<NT>(reinterpret_cast<const d2 *>(val + idx));
-        const i2 c = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + (idx + sh32)));
-        c0[k] = c.x; c1[k] = c.y;
+        for (int k = 0; k < NPT / 2; ++k) {
+          const int idx = min(base + (k * BLK + tid) * 2, last);
+          q[k] = pa_stream_load<NT>(reinterpret_cast<const unsigned *>(col16 + (idx + sh16)));
+        }
+#pragma unroll
+        for (int k = 0; k < NPT / 2; ++k) {
+          // window base of slot s lives in lane s of `mywin` (any 16-lane group): fetch it with ds_bpermute
+          const unsigned lo = q[k] & 0xffffu, hi = q[k] >> 16;
+          // max_col = n_cols - 1: the entry before an odd first entry and the one after an odd last entry belong to the
+          // neighbouring chunks; decoded with THIS chunk's windows their codes can point up to 4095 columns past the end of x
+          // (their products are never summed, but the load must stay inside the vector)
+          c0[k] = min(__builtin_amdgcn_ds_bpermute((lo >> 12) << 2, mywin) + (int)(lo & 4095), max_col);
+          c1[k] = min(__builtin_amdgcn_ds_bpermute((hi >> 12) << 2, mywin) + (int)(hi & 4095), max_col);
+          PA_HOOK_C16_COLS(c0[k], c1[k], lo, hi, r0, r1, tid);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < NPT / 2; ++k) {
+          const int idx = min(base + (k * BLK + tid) * 2, last);
+          const i2 c = pa_stream_load<NT>(reinterpret_cast<const i2 *>(col + (idx + sh32)));
+          c0[k] = c.x; c1[k] = c.y;
+        }
       }
     }
+#undef PA_D
+    // my first row's extent (and, EPI 3, u[my row]): requested now so that the row sums do not wait for it
+    const int rmine = min(r0 + tid, r1 - 1);     // (lanes past the chunk's rows: its last row, never summed)
+    int ra = crp[rmine], re = crp[rmine + 1];
+    double urow = 0.0;
+    if (EPI == 3) urow = gs_b[row_ids ? row_ids[rmine] : rmine];
     if (VD) {
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
@@ -311,12 +337,14 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       d2 pr;
       pr.x = v[k].x * PA_HOOK_X_AT(x, c0[k], r0);
       pr.y = v[k].y * PA_HOOK_X_AT(x, c1[k], r0);
-      if (alpha != 1.0) {
-        pr.x = pr.x * alpha;
-        pr.y = pr.y * alpha;
-      }
-      *reinterpret_cast<d2 *>(&prod[PA_PSLOT((k * BLK + tid) * 2)]) = pr;
+      v[k] = pr;
     }
+    // (alpha: multiply-and-select per product, not a branch around the scaling -- the branch form waits for ALL gathers before the
+    // first LDS write and measured 3 % slower, 0.707 against 0.684 ms)
+#pragma unroll
+    for (int k = 0; k < NPT / 2; ++k) if (alpha != 1.0) { v[k].x = v[k].x * alpha; v[k].y = v[k].y * alpha; }
+#pragma unroll
+    for (int k = 0; k < NPT / 2; ++k) *reinterpret_cast<d2 *>(&prod[PA_PSLOT((k * BLK + tid) * 2)]) = v[k];
     __syncthreads();
     PA_HOOK_ALT_REDUCE();
     double dacc = 0.0;                       // EPI 3: this lane's share of the dot product
@@ -351,7 +379,6 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       if (r1 - r0 <= 64) {                   // (block-uniform) every row sat in wavefront 0: the other three just leave
         if (tid == 0) gs_x[chunk] = dacc;
       } else {
-        __shared__ double wsum[BLK / 64];
         if ((tid & 63) == 0) wsum[tid >> 6] = dacc;
         __syncthreads();
         if (tid == 0) {
@@ -360,6 +387,17 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
           gs_x[chunk] = t;
         }
       }
+    }
+  };
+  if (p1 - base <= CAP) {
+    const int nseg = PAT ? pdesc[chunk * PA_PDESC_INTS] : 0;
+    if (PAT && nseg > 0) {
+      body(std::integral_constant<int, 2>{}, nseg, 0);
+    } else {
+      int mywin = -1;
+      if (C16) mywin = win[chunk * PA_C16_WINDOWS + (tid & (PA_C16_WINDOWS - 1))];
+      if (C16 && __builtin_amdgcn_readfirstlane(mywin) >= 0) body(std::integral_constant<int, 1>{}, nseg, mywin);   // lane 0 holds window 0
+      else body(std::integral_constant<int, 0>{}, nseg, mywin);
     }
   } else {
     // one long row (more stored entries than a chunk holds): windows of CAP products, summed by

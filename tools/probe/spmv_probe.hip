@@ -252,6 +252,15 @@ __global__ void k_cmp(const double *a, const double *b, long n, unsigned long lo
   if (i < n && __double_as_longlong(a[i]) != __double_as_longlong(b[i])) atomicAdd(bad, 1ull);
 }
 
+// {first row, its row pointer} pairs of a row split: what k_spmv_rowsplit reads per chunk (pa_spmv_kernel.h, round 5)
+static int *dev_chunk_rp(const std::vector<int32_t> &cr, const std::vector<int> &rp) {
+  std::vector<int> h(2 * cr.size());
+  for (size_t k = 0; k < cr.size(); ++k) { h[2 * k] = cr[k]; h[2 * k + 1] = rp[cr[k]]; }
+  int *d; CK(hipMalloc(&d, sizeof(int) * h.size()));
+  CK(hipMemcpy(d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+  return d;
+}
+
 struct Variant { std::string name; std::function<void()> run; double bytes; std::vector<float> ms; };
 
 int main(int argc, char **argv) {
@@ -295,7 +304,7 @@ int main(int argc, char **argv) {
 #define ADD_SPMV4(BLK, NPT, NT, C16)                                                                          \
   { std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, BLK * NPT, 4096, cr, &nl);           \
     const int nch = (int)cr.size() - 1; int *dc; CK(hipMalloc(&dc, sizeof(int) * cr.size()));                   \
-    CK(hipMemcpy(dc, cr.data(), sizeof(int) * cr.size(), hipMemcpyHostToDevice));                               \
+    CK(hipMemcpy(dc, cr.data(), sizeof(int) * cr.size(), hipMemcpyHostToDevice)); int *drp = dev_chunk_rp(cr, rp); (void)drp;                               \
     unsigned short *d16 = nullptr; int *dwin = nullptr;                                                         \
     if (C16) { std::vector<uint16_t> c16(nnz + 8, 0); std::vector<int32_t> win((size_t)nch * 16, 0);            \
       const int64_t nf = pa_encode_col16(rp.data(), hcol.data(), cr, BLK * NPT, c16.data(), win.data(), 32);    \
@@ -306,7 +315,7 @@ int main(int argc, char **argv) {
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"spmv<" #BLK "," #NPT "," #NT ",c16=" #C16 ">", [=]() {                                        \
       hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, C16, 0>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, d16, dwin, \
-                         (const int *)nullptr, (const int *)nullptr, d_val, d_x, (C16 ? d_y2 : d_y), dc, (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
+                         (const int *)nullptr, (const int *)nullptr, d_val, d_x, (C16 ? d_y2 : d_y), drp, (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_SPMV4(256, 4, true, false)
   ADD_SPMV4(256, 6, true, true)
   ADD_SPMV4(256, 6, true, false)
@@ -316,7 +325,7 @@ int main(int argc, char **argv) {
   {
     std::vector<int32_t> cr; int64_t nl; pa_build_chunks(rp.data(), nrows, 256 * 6, 4096, cr, &nl);
     const int nch = (int)cr.size() - 1; int *dc; CK(hipMalloc(&dc, sizeof(int) * cr.size()));
-    CK(hipMemcpy(dc, cr.data(), sizeof(int) * cr.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dc, cr.data(), sizeof(int) * cr.size(), hipMemcpyHostToDevice)); int *drp = dev_chunk_rp(cr, rp); (void)drp;
     std::vector<uint16_t> c16(nnz + 8, 0); std::vector<int32_t> win((size_t)nch * 16, 0);
     pa_encode_col16(rp.data(), hcol.data(), cr, 256 * 6, c16.data(), win.data(), 32);
     unsigned short *d16, *u16; int *dwin; double *uval, *uy;
@@ -333,7 +342,7 @@ int main(int argc, char **argv) {
 #define ADD_ATTR(NAME, VALP, C16P, YP, NT)                                                                   \
     V.push_back({NAME, [=]() {                                                                                 \
       hipLaunchKernelGGL((k_spmv_rowsplit<256, 6, NT, true, false>), dim3(cpx * 8), dim3(256), 0, 0, d_rp, d_col, C16P, dwin, \
-                         (const int *)nullptr, (const int *)nullptr, VALP, d_x, YP, dc, (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}});
+                         (const int *)nullptr, (const int *)nullptr, VALP, d_x, YP, drp, (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}});
     ADD_ATTR("c16 base (cached all, nt)", d_val, d16, d_y2, true)
     ADD_ATTR("c16 matrix uncached, nt", uval, u16, d_y2, true)
     ADD_ATTR("c16 matrix uncached, plain", uval, u16, d_y2, false)
@@ -349,12 +358,12 @@ int main(int argc, char **argv) {
     const int64_t ng = pa_encode_patterns(rp.data(), hcol.data(), nullptr, nrows, cr, BLK * NPT, pdesc, pdelta, 32);     \
     printf("pattern<%d,%d>: %d chunks, %lld with a descriptor, %zu patterns\n", BLK, NPT, nch, (long long)ng, pdelta.size() / 32); \
     int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
-    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); int *drp = dev_chunk_rp(cr, rp); (void)drp; CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
     CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"pattern<" #BLK "," #NPT ",nt=" #NT ">c16=true", [=]() {                                                  \
       hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, NT, false, true>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, \
-                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
+                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, drp,  \
                          (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_PAT(256, 8, true)
   ADD_PAT(256, 8, false)
@@ -369,12 +378,12 @@ int main(int argc, char **argv) {
     const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
     pa_encode_patterns(rp.data(), hcol.data(), nullptr, nrows, cr, BLK * NPT, pdesc, pdelta, 32);               \
     int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
-    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); int *drp = dev_chunk_rp(cr, rp); (void)drp; CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
     CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"pattern<" #BLK "," #NPT ",epi=" #EPI ">", [=]() {                                             \
       hipLaunchKernelGGL((k_spmv_rowsplit<BLK, NPT, true, false, 1, EPI>), dim3(cpx * 8), dim3(BLK), 0, 0, d_rp, d_col, \
-                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
+                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, drp,  \
                          (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_PAT_EPI(256, 6, 0)
   ADD_PAT_EPI(256, 6, 7)
@@ -387,12 +396,12 @@ int main(int argc, char **argv) {
     const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
     pa_encode_patterns(rp.data(), hcol.data(), nullptr, nrows, cr, 1536, pdesc, pdelta, 32);                    \
     int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
-    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); int *drp = dev_chunk_rp(cr, rp); (void)drp; CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
     CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"pattern<256,6,unroll=" #UNR ">", [=]() {                                                      \
       hipLaunchKernelGGL((k_spmv_rowsplit<256, 6, true, false, 1, 0, false, UNR>), dim3(cpx * 8), dim3(256), 0, 0, d_rp, d_col, \
-                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
+                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, drp,  \
                          (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_PAT_UNR(1)
   ADD_PAT_UNR(2)
@@ -406,12 +415,12 @@ int main(int argc, char **argv) {
     const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
     pa_encode_patterns(rp.data(), hcol.data(), nullptr, nrows, cr, 1536, pdesc, pdelta, 32);                    \
     int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
-    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); int *drp = dev_chunk_rp(cr, rp); (void)drp; CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
     CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"pattern<256,6,maxrows=" #MAXR ">", [=]() {                                                    \
       hipLaunchKernelGGL((k_spmv_rowsplit<256, 6, true, false, 1, 0>), dim3(cpx * 8), dim3(256), 0, 0, d_rp, d_col, \
-                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
+                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, drp,  \
                          (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_PAT_ROWS(56)
   ADD_PAT_ROWS(48)
@@ -420,12 +429,12 @@ int main(int argc, char **argv) {
     const int nch = (int)cr.size() - 1; std::vector<int32_t> pdesc, pdelta;                                     \
     pa_encode_patterns(rp.data(), hcol.data(), nullptr, nrows, cr, 2048, pdesc, pdelta, 32);                    \
     int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
-    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); int *drp = dev_chunk_rp(cr, rp); (void)drp; CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
     CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"pattern<256,8,maxrows=" #MAXR ",align16>", [=]() {                                            \
       hipLaunchKernelGGL((k_spmv_rowsplit<256, 8, true, false, 1, 0>), dim3(cpx * 8), dim3(256), 0, 0, d_rp, d_col, \
-                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, dc,  \
+                         (const unsigned short *)nullptr, (const int *)nullptr, ddesc, ddel, d_val, d_x, d_y2, drp,  \
                          (const int *)nullptr, nch, cpx, 1.0, 0.0, (double *)nullptr, (const double *)nullptr, (const double *)nullptr); }, bytes_spmv, {}}); }
   ADD_PAT_ROWS8(64)
   ADD_PAT_ROWS8(72)
@@ -437,7 +446,7 @@ int main(int argc, char **argv) {
     if (ng != nch) printf("persist: %lld of %d chunks have a descriptor -- variant skipped\n", (long long)ng, nch);  \
     else {                                                                                                        \
     int *dc, *ddesc, *ddel; CK(hipMalloc(&dc, 4 * cr.size())); CK(hipMalloc(&ddesc, 4 * pdesc.size())); CK(hipMalloc(&ddel, 4 * pdelta.size())); \
-    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
+    CK(hipMemcpy(dc, cr.data(), 4 * cr.size(), hipMemcpyHostToDevice)); int *drp = dev_chunk_rp(cr, rp); (void)drp; CK(hipMemcpy(ddesc, pdesc.data(), 4 * pdesc.size(), hipMemcpyHostToDevice)); \
     CK(hipMemcpy(ddel, pdelta.data(), 4 * pdelta.size(), hipMemcpyHostToDevice));                               \
     const int cpx = (nch + 7) / 8;                                                                              \
     V.push_back({"persist<" #NPT ",KF=" #KF ",wpx=" #WPX ">c16=true", [=]() {                                   \
