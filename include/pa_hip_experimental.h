@@ -327,6 +327,16 @@ int pa_csr_value_dict(const pa_csr *A, int *n_values);
  * PA_MUL_GHOST_FROM_BUFFER=0.  pa_mul_all packs and delivers all parts with one push launch (PA_PUSH=0: pack per part + copies). */
 int pa_matrix_ghost_from_buffer(const pa_matrix *m, int *yes);
 int pa_csr_download_entries(const pa_csr *A, int32_t *rows, int32_t *cols);
+/* Round 5: mul!(c,a,b) of a part as ONE launch (csrc/pa_fused.hip; src/p_sparse_matrix.jl:2090-2142, same additions in the same
+ * order: same bits).  The part's boundary rows -- rows with stored entries in own_ghost -- are summed by the tail of the launch from
+ * a block that holds their own_own entries followed by their own_ghost entries; the other rows by own x own's chunks in front.
+ * pa_mul_all then queues P + 1 launches on one stream (the push launch, which also completes consistent!(b), and one per part).
+ * Decided per handle at its first product; PA_MUL_FUSED=0 keeps the separate launches.  *yes = 1: fused; *n_boundary_rows: the
+ * tail's rows. */
+int pa_matrix_fused(const pa_matrix *m, int *yes, int64_t *n_boundary_rows);
+/* The switches of the product path (PA_PUSH, PA_GRAPH_ONE_STREAM, PA_MUL_GHOST_FROM_BUFFER, PA_MUL_FUSED, PA_SPMV_ALTERNATE) are
+ * read from the environment when a context is created; this reads them again (tests flip them inside one process). */
+int pa_ctx_reload_env(pa_ctx *c);
 
 #ifdef __cplusplus
 }

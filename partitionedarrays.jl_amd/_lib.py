@@ -161,6 +161,8 @@ _SIGS = {
     "pa_mul5_transpose": [P, P, P, P, f64, f64],
     "pa_mul5_transpose_all": [P, i32, P, P, f64, f64],
     "pa_csr_download_entries": [P, P, P],
+    "pa_matrix_fused": [P, C.POINTER(cint), C.POINTER(i64)],
+    "pa_ctx_reload_env": [P],
     "pa_csr_locality_order": [P, P, C.POINTER(i64), C.POINTER(i64)],
     "pa_csr_create_permuted": [P, P, P, PP],
     "pa_csr_create_transpose_ranked": [P, P, PP],

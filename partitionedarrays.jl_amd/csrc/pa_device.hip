@@ -41,6 +41,7 @@
 #include "pa_setup.h"
 
 thread_local std::string g_pa_err;
+thread_local int pa_tls_plain_encoding = 0;   // > 0 while pa_matrix_fused_build makes its block: Int32 columns, nothing else
 thread_local int pa_tls_piece_build = 0;       // > 0 while pa_csr_colsplit_if_wide builds its pieces through csr_build
 
 void pa_set_err(const char *fmt, ...) {
@@ -336,6 +337,20 @@ __global__ void k_prolongate(double *__restrict__ xf, const double *__restrict__
 // ------------------------------------------------------------------------------------------------
 static void enable_peer_access(int device);
 
+static void read_switches(pa_ctx *c) {
+  auto flag = [](const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; };
+  c->sw.push = flag("PA_PUSH", 1);
+  c->sw.graph_one_stream = flag("PA_GRAPH_ONE_STREAM", 1);
+  c->sw.ghost_from_buffer = flag("PA_MUL_GHOST_FROM_BUFFER", 1);
+  c->sw.mul_fused = flag("PA_MUL_FUSED", 1);
+  c->sw.spmv_alternate = flag("PA_SPMV_ALTERNATE", 1);
+}
+extern "C" int pa_ctx_reload_env(pa_ctx *c) {
+  PA_REQUIRE(c != nullptr, "bad arguments");
+  read_switches(c);
+  return PA_OK;
+}
+
 extern "C" int pa_ctx_create(int device, pa_ctx **out) {
   PA_REQUIRE(out != nullptr, "ctx out pointer is NULL");
   int n = 0;
@@ -345,6 +360,7 @@ extern "C" int pa_ctx_create(int device, pa_ctx **out) {
   PA_HIP(hipSetDevice(device));
   pa_ctx *c = new pa_ctx();
   c->device = device;
+  read_switches(c);
   // The comm stream gets the highest priority the device offers: own x own puts ~300 k workgroups in front of the
   // dispatcher, and the pack kernel, RCCL's send/recv kernels and the unpack have to get CUs while it runs or the
   // exchange does not hide under it (mul!: src/p_sparse_matrix.jl:2098-2100).  Numerically lower = higher priority.
@@ -829,7 +845,7 @@ static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
   const int mode = e ? atoi(e) : -1;                           // -1 auto, 0 off, 1 on
   A->use_vdict = false;
   A->vdict_stale = false;
-  if (mode == 0 || A->nnz == 0 || A->vdict_dead || c->capturing) return PA_OK;
+  if (mode == 0 || A->nnz == 0 || A->vdict_dead || c->capturing || pa_tls_plain_encoding) return PA_OK;
   if (mode < 0 && !rebuild && (A->nnz < ((int64_t)1 << 18) || A->n_xw_groups > 0)) return PA_OK;
   const size_t pad = 8;
   hipStream_t s = c->s[0];
@@ -914,6 +930,8 @@ static int vdict_after_update(pa_csr *A) {
   return PA_OK;
 }
 
+void pa_csr_before_product(const pa_csr *A) { vdict_maintain(A); }
+
 // fills the freshly created slab A; on any failure the caller (csr_build_slab) hands back whatever A holds by then
 static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, int64_t nnz, std::vector<int32_t> &rp,
                          const csr_src &src) {
@@ -978,7 +996,8 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   // per-chunk descriptors, window tags and codes as kernels; PA_SETUP_DEVICE=0 keeps the host encoder below, whose arrays
   // the device's equal byte for byte (tests/...test_device_side_encoding_equals_the_host_s).
   const char *ep = getenv("PA_SPMV_PATTERN"), *e16 = getenv("PA_SPMV_COL16"), *ec = getenv("PA_SPMV_COMPACT_STREAMS"), *ed = getenv("PA_SETUP_DEVICE");
-  const bool want_pattern = !(ep && atoi(ep) == 0) && nnz > 0, want_c16 = !(e16 && atoi(e16) == 0) && nnz > 0;
+  const bool want_pattern = !(ep && atoi(ep) == 0) && nnz > 0 && !pa_tls_plain_encoding;
+  const bool want_c16 = !(e16 && atoi(e16) == 0) && nnz > 0 && !pa_tls_plain_encoding;
   const bool compact_streams = !(ec && atoi(ec) == 0), on_device = (!(ed && atoi(ed) == 0) || src.on_device()) && nnz > 0;
   // (the value stream first: it is the allocation that brings the context's arena into being, pa_arena.hip)
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_val, sizeof(double) * (nnz + pad), PA_MEM_MATRIX));
@@ -1843,9 +1862,8 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
   }
   if (S->n_chunks > 0) {
       int cpx = (int)((S->n_chunks + 7) / 8);
-      static const int alternate = getenv("PA_SPMV_ALTERNATE") ? atoi(getenv("PA_SPMV_ALTERNATE")) : 1;
       const int gcpx = cpx;
-      if (alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) cpx = -cpx;
+      if (S->ctx->sw.spmv_alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) cpx = -cpx;
 #define PA_LAUNCH_SPMV(C16, PAT, VD)                                                                                     \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 0, VD>), dim3(gcpx * 8), dim3(SPMV_BLK), 0,    \
                      st, S->d_crp, S->d_col, S->d_col16, S->d_win, S->d_pdesc, S->d_pdelta, S->d_val,           \
@@ -2785,6 +2803,7 @@ extern "C" int pa_matrix_create(pa_ctx *c, const pa_csr *own_own, const pa_csr *
 
 extern "C" int pa_matrix_destroy(pa_matrix *m) {
   if (m && m->oh_rb) pa_csr_destroy(m->oh_rb);     // (own x ghost with renamed columns: made for this handle, matrix_rb)
+  if (m) pa_matrix_fused_release(m);
   delete m;
   return PA_OK;
 }
@@ -2842,8 +2861,7 @@ static int matrix_rb(pa_matrix *m) {
   if (m->rb_tried) return PA_OK;
   if (m->ctx->capturing) return PA_OK;
   m->rb_tried = true;
-  const int on = getenv("PA_MUL_GHOST_FROM_BUFFER") ? atoi(getenv("PA_MUL_GHOST_FROM_BUFFER")) : 1;
-  if (!on) return PA_OK;
+  if (!m->ctx->sw.ghost_from_buffer) return PA_OK;
   pa_plan *p = m->plan;
   const pa_plan::side &in = p->snd;                           // the receiving side of consistent! (ghost lids)
   if (in.n == 0 || m->oh->t_nnz == 0 || (m->oh->next && !m->oh->colsplit)) return PA_OK;
@@ -2917,7 +2935,7 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
     PA_REQUIRE(c[r]->d != b[r]->d, "c and b alias (part %d)", r);
     plans[r] = m[r]->plan;
   }
-  const int push = getenv("PA_PUSH") ? atoi(getenv("PA_PUSH")) : 1;      // (read per call: tests switch it)
+  const int push = m[0]->ctx->sw.push;
   bool all_rb = push != 0;
   if (push) {
     for (int r = 0; r < n_parts; ++r) {
@@ -2930,7 +2948,38 @@ extern "C" int pa_mul_all(pa_matrix *const *m, int32_t n_parts, pa_vec *const *c
     // calls (config 5 on 8 parts: 0.118 ms per part against 0.045).
     bool one_ctx = true;
     for (int r = 1; r < n_parts; ++r) one_ctx = one_ctx && m[r]->ctx == m[0]->ctx;
-    if (all_rb && one_ctx && m[0]->ctx->capturing && !(getenv("PA_GRAPH_ONE_STREAM") && atoi(getenv("PA_GRAPH_ONE_STREAM")) == 0)) {
+    // Round 5: P + 1 launches on ONE stream, no events -- the push launch completes consistent!(b) of all parts (receive buffers AND
+    // b's ghost entries), then every part is one launch: own x own's chunks, the boundary rows as the launch's tail (pa_fused.hip).
+    // Parts whose handle cannot be fused (see pa_matrix_fused_build) run their two products separately behind the same push.
+    if (all_rb && one_ctx && m[0]->ctx->sw.mul_fused) {
+      bool any_fused = false, traffic = false;
+      for (int r = 0; r < n_parts; ++r) {
+        PA_TRY(pa_matrix_fused_build(m[r]));
+        const bool nb = plans[r]->snd.n || plans[r]->rcv.n;
+        traffic = traffic || nb;
+        any_fused = any_fused || (nb && pa_matrix_fused_ready(m[r]));
+      }
+      if (any_fused) {
+        PA_TRY(pa_exchange_push_unpack_one_stream(plans.data(), n_parts, b));
+        for (int r = 0; r < n_parts; ++r) {
+          pa_plan *p = plans[r];
+          const bool nb = p->snd.n || p->rcv.n;
+          const bool scaled = (m[r]->oo->alpha_inside || m[r]->oh->alpha_inside) && alpha != 1.0;
+          if (nb && !scaled && pa_matrix_fused_ready(m[r])) {
+            pa_csr_before_product(m[r]->oo);
+            PA_TRY(pa_mul_fused_launch(m[r], c[r], b[r], alpha, beta, m[r]->ctx->s[0]));
+            continue;
+          }
+          PA_TRY(pa_spmv(m[r]->oo, b[r], PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, beta));
+          if (!nb || !m[r]->oh_rb) continue;
+          pa_vec buf;
+          buf.ctx = m[r]->ctx; buf.d = p->snd.d_buf; buf.n_own = p->snd.n; buf.n_ghost = 0; buf.owned = false;
+          PA_TRY(pa_spmv(m[r]->oh_rb, &buf, PA_SEG_OWN, c[r], PA_SEG_OWN, alpha, 1.0));
+        }
+        return PA_OK;
+      }
+    }
+    if (all_rb && one_ctx && m[0]->ctx->capturing && m[0]->ctx->sw.graph_one_stream) {
       PA_TRY(pa_exchange_push_local_one_stream(plans.data(), n_parts, b, PA_CONSISTENT));
       for (int r = 0; r < n_parts; ++r) {
         pa_plan *p = plans[r];
@@ -3129,7 +3178,7 @@ extern "C" int pa_mul_all_dot(pa_matrix *const *m, int32_t n_parts, pa_vec *cons
     PA_REQUIRE(m[r]->ctx == m[0]->ctx, "the parts of one call share a context");
     plans[r] = m[r]->plan;
   }
-  const int push = getenv("PA_PUSH") ? atoi(getenv("PA_PUSH")) : 1;      // (read per call: tests switch it)
+  const int push = m[0]->ctx->sw.push;
   if (push) PA_TRY(pa_exchange_push_local(plans.data(), n_parts, b, PA_CONSISTENT));
   else {
     for (int r = 0; r < n_parts; ++r) PA_TRY(pa_exchange_pack(plans[r], b[r], PA_CONSISTENT));

@@ -1,0 +1,271 @@
+// pa_fused.hip -- mul!(c,a,b) of one part as ONE launch (round 5, VERDICT r04 "Next" #1).
+//
+// Reference: mul!(c,a,b[,alpha,beta])  src/p_sparse_matrix.jl:2090-2142
+//              t = consistent!(b);  own(c) = beta*own(c) + alpha*A_oo*own(b);  wait(t);  own(c) += alpha*A_oh*ghost(b)
+//            consistent! / wait(t)      src/p_vector.jl:595-611, 747-755
+//
+// Round 4 queued, per part: the push launch, own x own, [event hop] own x ghost from the receive buffer, the unpack.  Beside a
+// 128^3 own x own (88 us) that chain cost +19 % (config 3 whole 1.19 x own x own, config 5 whole 1.21 x): launch boundaries, a
+// drained and refilled GPU around a 3 us kernel, cross-stream event hops of ~8 us.  Here the part's rows are cut differently:
+//
+//   INTERIOR rows  (no stored entry in own_ghost)  : summed from own_own alone -- they never wait for anything;
+//   BOUNDARY rows  (>= 1 stored entry in own_ghost): summed from a small block of their own, `bd`, that holds for each of them
+//                  its own_own entries FOLLOWED BY its own_ghost entries (columns renamed: own column j stays j, ghost column
+//                  -> n_own + its position in consistent!'s receive buffer).  One lane adds beta*c[row], then the row's products
+//                  in that stored order: exactly the additions of spmv!(own_own) followed by muladd!(own_ghost) -- same bits.
+//
+// k_mul_fused is one grid: the first blocks are own x own's chunks, the row-split kernel as it is (pa_spmv_kernel.h, FX 1), except
+// that they neither store nor (beta != 0) read the boundary rows; the LAST blocks are bd's chunks (FX 2: columns >= n_own gather
+// the receive buffer).  No block of the launch depends on another block of the launch.  What the tail blocks do depend on is the
+// arrival of b's ghost values:
+//   * all parts in one process (pa_mul_all): the push launch in front (k_push_unpack: it delivers into the receive buffers AND
+//     writes b's ghost entries, so consistent!(b) is complete with it) -- launches per step: P + 1, one stream, no events;
+//   * one part per process: see pa_mul_fused_ipc below (the tail acquires the arrival flags inside the launch).
+// The own_own entries of boundary rows are read twice (by the chunk they sit in, which still needs them to find its other rows'
+// products, and by bd): 1-3 % of the matrix stream of a 3-D part.
+#include "pa_dev_util.h"
+
+#include "pa_setup.h"
+#include "pa_spmv_kernel.h"
+
+using namespace pa_util;
+
+extern thread_local int pa_tls_plain_encoding;   // pa_device.hip: blocks built now keep Int32 columns, no patterns / windows / dictionary
+
+// ---- bd: the boundary rows' block, built in HBM from the two blocks' own encodings ---------------------------------------------
+struct kf_block {                                  // what decoding a stored entry's column needs (kt_decode's arguments)
+  const int *crp, *chunk_row, *col32, *win, *pdesc, *pdelta;
+  const unsigned short *col16;
+  const double *val;
+  int use_pattern, use_c16, n_chunks;
+};
+static kf_block kf_of(const pa_csr *A) {
+  kf_block k;
+  k.crp = A->d_crp; k.chunk_row = A->d_chunk_row; k.col32 = A->d_col; k.win = A->d_win; k.pdesc = A->d_pdesc; k.pdelta = A->d_pdelta;
+  k.col16 = A->d_col16; k.val = A->d_val;
+  k.use_pattern = A->use_pattern ? 1 : 0; k.use_c16 = A->use_c16 ? 1 : 0; k.n_chunks = (int)A->n_chunks;
+  return k;
+}
+// column of stored entry p of stored row r (the arithmetic of kt_decode, pa_transpose.hip, for one entry)
+__device__ static int kf_col(const kf_block &B, int r, int p) {
+  int lo = 0, hi = B.n_chunks - 1;                 // the chunk that holds stored row r: the last c with chunk_row[c] <= r
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (B.chunk_row[mid] <= r) lo = mid; else hi = mid - 1;
+  }
+  const int chunk = lo;
+  const int p0 = B.crp[B.chunk_row[chunk]], p1 = B.crp[B.chunk_row[chunk + 1]];
+  const bool is_long = p1 - (p0 & ~1) > PA_SPMV_CHUNK_NNZ;
+  const int *d = B.use_pattern ? B.pdesc + (size_t)chunk * PA_PDESC_INTS : nullptr;
+  const int nseg = d ? d[0] : 0;
+  const int sh16 = (d && nseg <= 0) ? d[1] : 0, sh32 = (d && nseg <= 0) ? d[2] : 0;
+  if (nseg > 0) {
+    const int q = p - p0;
+    int s = 0;
+    if (nseg > 1 && q >= d[1]) s = 1;
+    if (nseg > 2 && q >= d[2]) s = 2;
+    if (nseg > 3 && q >= d[3]) s = 3;
+    const int qs = s ? d[s] : 0;
+    const int Lw = d[8 + s], L = Lw & 255, stride = (Lw >> 8) ? (Lw >> 8) : 1;
+    const int t = q - qs, rr = t / L, kk = t - rr * L;
+    return d[4 + s] + rr * stride + B.pdelta[(size_t)d[12 + s] * PA_PAT_MAXLEN + kk];
+  }
+  if (B.use_c16 && !is_long && B.win[(size_t)chunk * PA_C16_WINDOWS] >= 0) {
+    const unsigned code = B.col16[(size_t)p + sh16];
+    return B.win[(size_t)chunk * PA_C16_WINDOWS + (code >> 12)] + (int)(code & 4095u);
+  }
+  return B.col32[(size_t)p + sh32];
+}
+
+// rows[i] = the i-th boundary row; hrow[i] = its stored row in the own_ghost twin.  len[i] = its entries in both blocks.
+__global__ void kf_lens(const int *__restrict__ rows, const int *__restrict__ hrow, int n, const int *__restrict__ crp_oo,
+                        const int *__restrict__ crp_oh, int *__restrict__ len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  len[i] = (crp_oo[rows[i] + 1] - crp_oo[rows[i]]) + (crp_oh[hrow[i] + 1] - crp_oh[hrow[i]]);
+}
+__global__ void kf_fill(const int *__restrict__ rows, const int *__restrict__ hrow, int n, kf_block OO, kf_block OH, int n_own,
+                        const int *__restrict__ brp, int *__restrict__ out_col, double *__restrict__ out_val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int q = brp[i];
+  const int r = rows[i];
+  for (int p = OO.crp[r]; p < OO.crp[r + 1]; ++p, ++q) { out_col[q] = kf_col(OO, r, p); out_val[q] = OO.val[p]; }
+  const int h = hrow[i];
+  for (int p = OH.crp[h]; p < OH.crp[h + 1]; ++p, ++q) { out_col[q] = n_own + kf_col(OH, h, p); out_val[q] = OH.val[p]; }
+}
+__global__ void kf_mask(const int *__restrict__ rows, int n, unsigned *__restrict__ mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicOr(&mask[rows[i] >> 5], 1u << (rows[i] & 31));
+}
+
+void pa_matrix_fused_release(pa_matrix *m) {
+  if (m->bd) pa_csr_destroy(m->bd);
+  if (m->d_rowmask) (void)pa_raw_free(m->d_rowmask);
+  m->bd = nullptr; m->d_rowmask = nullptr; m->n_bd_rows = 0;
+}
+
+// Builds (or, after a value update of either block, rebuilds) what the fused launch needs.  m->bd == NULL afterwards: this handle
+// stays on the separate launches (not an error) -- own_own is not a plain row-split block (x windows, column pieces, slabs, a
+// row-compacted block), no twin of own_ghost on receive-buffer positions (see matrix_rb), or PA_MUL_FUSED=0.
+int pa_matrix_fused_build(pa_matrix *m) {
+  const pa_csr *oo = m->oo, *oh = m->oh_rb;
+  if (m->bd && m->bd_epoch_oo == oo->val_epoch && m->bd_epoch_oh == m->oh->val_epoch) return PA_OK;
+  pa_ctx *c = m->ctx;
+  if (c->capturing) return PA_OK;                            // (a stale bd is never used: see pa_matrix_fused_ready)
+  if (m->bd) {
+    PA_HIP(hipStreamSynchronize(c->s[0]));
+    PA_HIP(hipStreamSynchronize(c->s[1]));
+    pa_matrix_fused_release(m);
+    m->fuse_tried = false;
+  }
+  if (m->fuse_tried) return PA_OK;
+  m->fuse_tried = true;
+  if (!c->sw.mul_fused || !oh || m->transposed) return PA_OK;
+  if (oo->next || oo->compact || oo->n_xw_groups > 0 || oo->pad_products || oo->n_chunks == 0 || oh->next || oh->nnz == 0) return PA_OK;
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  // the boundary rows, ascending, and where each sits in the twin: from the twin's row pointer (small: the part's surface)
+  std::vector<int32_t> hcrp((size_t)oh->n_crows + 1), hids;
+  PA_HIP(hipMemcpyAsync(hcrp.data(), oh->d_crp, sizeof(int32_t) * hcrp.size(), hipMemcpyDeviceToHost, s));
+  if (oh->compact) {
+    hids.resize((size_t)oh->n_crows);
+    PA_HIP(hipMemcpyAsync(hids.data(), oh->d_row_ids, sizeof(int32_t) * hids.size(), hipMemcpyDeviceToHost, s));
+  }
+  PA_HIP(hipStreamSynchronize(s));
+  std::vector<int32_t> rows, hrow;
+  for (int64_t k = 0; k < oh->n_crows; ++k)
+    if (hcrp[k + 1] > hcrp[k]) { rows.push_back(oh->compact ? hids[k] : (int32_t)k); hrow.push_back((int32_t)k); }
+  const int n = (int)rows.size();
+  if (n == 0) return PA_OK;
+  scratch sc;
+  int32_t *d_rows = nullptr, *d_hrow = nullptr, *d_len = nullptr, *d_brp = nullptr, *d_col = nullptr;
+  double *d_val = nullptr;
+  PA_TRY(sc.get(&d_rows, (size_t)n));
+  PA_TRY(sc.get(&d_hrow, (size_t)n));
+  PA_TRY(sc.get(&d_len, (size_t)n + 1));
+  PA_TRY(sc.get(&d_brp, (size_t)n + 1));
+  PA_HIP(hipMemcpyAsync(d_rows, rows.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+  PA_HIP(hipMemcpyAsync(d_hrow, hrow.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+  PA_HIP(hipMemsetAsync(d_len, 0, sizeof(int32_t) * ((size_t)n + 1), s));
+  hipLaunchKernelGGL(kf_lens, grid1(n), dim3(256), 0, s, d_rows, d_hrow, n, oo->d_crp, oh->d_crp, d_len);
+  PA_TRY(scan_exclusive(sc, s, d_len, d_brp, (size_t)n + 1));
+  std::vector<int32_t> brp((size_t)n + 1);
+  PA_TRY(d2h(s, brp.data(), d_brp, (size_t)n + 1));
+  const int64_t nnz = brp[n];
+  PA_TRY(sc.get(&d_col, (size_t)nnz + 8));
+  PA_TRY(sc.get(&d_val, (size_t)nnz + 8));
+  hipLaunchKernelGGL(kf_fill, grid1(n, 64), dim3(64), 0, s, d_rows, d_hrow, n, kf_of(oo), kf_of(oh), (int)oo->n_cols, d_brp, d_col, d_val);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(s));
+  pa_csr *bd = nullptr;
+  ++pa_tls_plain_encoding;
+  const int st = pa_csr_from_device_rows(c, oo->n_rows, oo->n_cols + oh->n_cols, nnz, n, brp, d_rows, d_col, d_val, &bd);
+  --pa_tls_plain_encoding;
+  if (st != PA_OK) { (void)hipGetLastError(); return PA_OK; }               // (no room: the separate launches serve)
+  const size_t words = ((size_t)oo->n_rows + 31) / 32 + 1;
+  if (pa_raw_malloc(&m->d_rowmask, sizeof(unsigned) * words) != hipSuccess) { (void)hipGetLastError(); pa_csr_destroy(bd); return PA_OK; }
+  PA_HIP(hipMemsetAsync(m->d_rowmask, 0, sizeof(unsigned) * words, s));
+  hipLaunchKernelGGL(kf_mask, grid1(n), dim3(256), 0, s, d_rows, n, m->d_rowmask);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(s));
+  m->bd = bd; m->n_bd_rows = n;
+  m->bd_epoch_oo = oo->val_epoch; m->bd_epoch_oh = m->oh->val_epoch;
+  return PA_OK;
+}
+
+// *yes = 1: this handle's products run as one launch (decided at the first product; 0 before it); *n_boundary_rows = rows of the
+// part with stored entries in own_ghost (the launch's tail)
+extern "C" int pa_matrix_fused(const pa_matrix *m, int *yes, int64_t *n_boundary_rows) {
+  PA_REQUIRE(m && yes, "bad arguments");
+  *yes = pa_matrix_fused_ready(m) ? 1 : 0;
+  if (n_boundary_rows) *n_boundary_rows = m->n_bd_rows;
+  return PA_OK;
+}
+
+bool pa_matrix_fused_ready(const pa_matrix *m) {
+  return m->bd && m->bd_epoch_oo == m->oo->val_epoch && m->bd_epoch_oh == m->oh->val_epoch && m->oh_rb &&
+         m->rb_epoch == m->oh->val_epoch;
+}
+
+// ---- the launch ------------------------------------------------------------------------------------------------------------------
+struct pa_fused_args {
+  int n_main_blocks;                               // the grid's first blocks: own x own's chunks (8 * chunks per XCD)
+  const unsigned *rowmask;                         // bit r: row r is a boundary row
+  // bd: Int32 columns, compacted rows
+  const int *b_crp, *b_col, *b_chunk_rp, *b_row_ids;
+  const double *b_val;
+  const double *rbuf;                              // consistent!'s receive buffer (buffer_rcv of the reversed cache)
+  int n_split, b_max_col;
+};
+
+template <bool C16, int PAT, bool VD>
+__global__ __launch_bounds__(256) void k_mul_fused(
+    const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
+    const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta, const double *__restrict__ val,
+    const double *__restrict__ x, double *__restrict__ y, const int *__restrict__ chunk_rp, int n_chunks, int chunks_per_xcd,
+    double alpha, double beta, const unsigned char *__restrict__ code, const double *__restrict__ dict, int max_col,
+    const pa_fused_args F) {
+  constexpr int BLK = 256, NPT = PA_SPMV_CHUNK_NNZ / 256;
+  __shared__ __attribute__((aligned(16))) double prod[BLK * NPT];
+  __shared__ double wsum[1];
+  const int b = blockIdx.x;
+  if (b >= F.n_main_blocks) {
+    pa_fx fx;
+    fx.x2 = F.rbuf; fx.n_split = F.n_split;
+    pa_rowsplit_chunk<BLK, NPT, true, false, 0, 0, false, 4, false, 2>(
+        prod, wsum, F.b_crp, F.b_col, nullptr, nullptr, nullptr, nullptr, F.b_val, x, y, F.b_chunk_rp, F.b_row_ids, alpha, beta, nullptr,
+        nullptr, nullptr, nullptr, nullptr, F.b_max_col, b - F.n_main_blocks, fx);
+    return;
+  }
+  const bool backwards = chunks_per_xcd < 0;
+  if (backwards) chunks_per_xcd = -chunks_per_xcd;
+  int chunk = (b & 7) * chunks_per_xcd + (b >> 3);           // XCD-aware, as k_spmv_rowsplit
+  if (chunk >= n_chunks || (b >> 3) >= chunks_per_xcd) return;
+  if (backwards) chunk = n_chunks - 1 - chunk;
+  pa_fx fx;
+  fx.rowmask = F.rowmask;
+  pa_rowsplit_chunk<BLK, NPT, true, C16, PAT, 0, VD, 4, false, 1>(prod, wsum, crp, col, col16, win, pdesc, pdelta, val, x, y, chunk_rp,
+                                                                  nullptr, alpha, beta, nullptr, nullptr, nullptr, code, dict, max_col,
+                                                                  chunk, fx);
+}
+
+// own(c) = beta*own(c) + alpha*(A_oo*own(b) + A_oh*ghost(b)) of one part in one launch on stream st; the receive buffer of
+// consistent!(b) must hold b's ghost values by the time the launch's tail reads it (stream order: the push launch is in front).
+int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, const pa_vec *b, double alpha, double beta, hipStream_t st) {
+  const pa_csr *S = m->oo, *B = m->bd;
+  pa_plan *p = m->plan;
+  pa_fused_args F;
+  int cpx = (int)((S->n_chunks + 7) / 8);
+  F.n_main_blocks = cpx * 8;
+  F.rowmask = m->d_rowmask;
+  F.b_crp = B->d_crp; F.b_col = B->d_col; F.b_chunk_rp = B->d_chunk_rp; F.b_row_ids = B->d_row_ids; F.b_val = B->d_val;
+  F.rbuf = p->snd.d_buf;
+  F.n_split = (int)S->n_cols; F.b_max_col = (int)B->n_cols - 1;
+  const int n_tail = (int)B->n_chunks;
+  if (m->ctx->sw.spmv_alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) cpx = -cpx;
+#define PA_LAUNCH_FUSED(C16, PAT, VD)                                                                                           \
+  hipLaunchKernelGGL((k_mul_fused<C16, PAT, VD>), dim3(F.n_main_blocks + n_tail), dim3(256), 0, st, S->d_crp, S->d_col, S->d_col16, \
+                     S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, (const double *)b->d, c->d, S->d_chunk_rp, (int)S->n_chunks, cpx,   \
+                     alpha, beta, S->d_code, S->d_dict, (int)S->n_cols - 1, F)
+  const int sel = (S->use_pattern ? 2 : 0) + (S->use_c16 ? 1 : 0);
+  if (S->use_vdict) {
+    if (m->ctx->capturing) const_cast<pa_csr *>(S)->vd_captured = true;
+    switch (sel) {
+      case 3: PA_LAUNCH_FUSED(true, 1, true); break;
+      case 2: PA_LAUNCH_FUSED(false, 1, true); break;
+      case 1: PA_LAUNCH_FUSED(true, 0, true); break;
+      default: PA_LAUNCH_FUSED(false, 0, true); break;
+    }
+  } else {
+    switch (sel) {
+      case 3: PA_LAUNCH_FUSED(true, 1, false); break;
+      case 2: PA_LAUNCH_FUSED(false, 1, false); break;
+      case 1: PA_LAUNCH_FUSED(true, 0, false); break;
+      default: PA_LAUNCH_FUSED(false, 0, false); break;
+    }
+  }
+#undef PA_LAUNCH_FUSED
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}

@@ -39,7 +39,18 @@ void pa_set_err(const char *fmt, ...);
 
 struct pa_arena;
 
+// Switches of the product path, read from the environment ONCE per context (pa_ctx_create) and again on request
+// (pa_ctx_reload_env: the tests flip them inside one process) -- no getenv on the path of a product.
+struct pa_switches {
+  int push = 1;               // PA_PUSH: pa_mul_all packs and delivers all parts with one push launch (0: pack per part + copies)
+  int graph_one_stream = 1;   // PA_GRAPH_ONE_STREAM: inside a capture pa_mul_all queues ONE chain on the compute stream
+  int ghost_from_buffer = 1;  // PA_MUL_GHOST_FROM_BUFFER: own x ghost reads consistent!'s receive buffer (the renamed twin)
+  int mul_fused = 1;          // PA_MUL_FUSED: mul!(c,a,b) of a part as one launch (pa_fused.hip)
+  int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
+};
+
 struct pa_ctx {
+  pa_switches sw;
   bool keep_coo_slots = false;       // pa_coo_keep_input_slots: the assemblies remember where their input triplets went
   int device = 0;
   hipStream_t s[2] = {nullptr, nullptr};  // [0] compute, [1] comm
@@ -246,6 +257,13 @@ struct pa_matrix {
   pa_csr *oh_rb = nullptr;                     // own_ghost with its columns renamed to positions of consistent!'s RECEIVE BUFFER (owned;
   bool rb_tried = false;                       //   built at the first product): own x ghost then needs no unpack before it
   uint64_t rb_epoch = 0;                       // oh->val_epoch the twin's values were taken at
+  // the fused launch (pa_fused.hip): the boundary rows' block {own_own entries, own_ghost entries on buffer positions} and the bitmap
+  // of the boundary rows, built at the first product, rebuilt when either block's values change
+  pa_csr *bd = nullptr;
+  unsigned *d_rowmask = nullptr;
+  int64_t n_bd_rows = 0;
+  uint64_t bd_epoch_oo = 0, bd_epoch_oh = 0;
+  bool fuse_tried = false;
   bool transposed = false;                     // pa_matrix_create_transposed: oo = A_oo', oh = A_oh' (pa_csr_create_transpose), for pa_mul5_transpose
 };
 
@@ -255,5 +273,15 @@ struct pa_graph {
 };
 
 int pa_plan_mark_arrived(pa_plan *p);
+
+// pa_fused.hip
+int pa_matrix_fused_build(pa_matrix *m);
+bool pa_matrix_fused_ready(const pa_matrix *m);
+void pa_matrix_fused_release(pa_matrix *m);
+int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, const pa_vec *b, double alpha, double beta, hipStream_t st);
+void pa_csr_before_product(const pa_csr *A);     // pa_device.hip: upkeep a product does first (the value dictionary's renewal)
+// pa_push.hip: consistent!(v) of every part of this process COMPLETE with one launch on the compute stream -- the push kernel also
+// stores every delivered value into the receiving part's ghost entry (the unpack of src/p_vector.jl:603-611)
+int pa_exchange_push_unpack_one_stream(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v);
 
 #endif

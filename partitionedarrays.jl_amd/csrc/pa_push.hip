@@ -34,6 +34,8 @@
 struct pa_push_seg {
   int32_t start, len;                 // entries [start, start + len) of the part's send list ...
   double *dst;                        // ... go to dst[0 .. len)
+  const int32_t *uidx;                // (one device, consistent!) and on into ghost entry uidx[k] of the receiving part's vector,
+  int32_t upart;                      //     which is vector `upart` of the launch (k_push_unpack); NULL: no unpack table
   unsigned long long *arrive;         // ipc: the flag in the receiver's memory this slice's arrival is announced in
   const unsigned long long *ack;      // ipc: the flag in MY memory the receiver acknowledges the previous slice in
 };
@@ -62,6 +64,21 @@ __global__ __launch_bounds__(256) void k_push_local(const pa_push_part *__restri
   const double val = vecs.v[pi][P.idx[p]];
   const int s = push_find_seg(segs, P.seg0, P.nseg, p);
   segs[s].dst[p - segs[s].start] = val;
+}
+
+// the same launch completing consistent! as well: every delivered value is also stored into the receiving part's ghost entry -- the
+// unpack loop of src/p_vector.jl:603-611 with f = insert, done by the lane that has the value in a register already
+__global__ __launch_bounds__(256) void k_push_unpack(const pa_push_part *__restrict__ parts, const pa_push_seg *__restrict__ segs,
+                                                     const int32_t *__restrict__ block_part, pa_push_vecs vecs) {
+  const int pi = block_part[blockIdx.x];
+  const pa_push_part P = parts[pi];
+  const int p = ((int)blockIdx.x - P.blk0) * 256 + (int)threadIdx.x;
+  if (p >= P.n) return;
+  const double val = vecs.v[pi][P.idx[p]];
+  const int s = push_find_seg(segs, P.seg0, P.nseg, p);
+  const pa_push_seg S = segs[s];
+  S.dst[p - S.start] = val;
+  const_cast<double *>(vecs.v[S.upart])[S.uidx[p - S.start]] = val;
 }
 
 struct pa_unpack_part { const int32_t *idx; const double *buf; int32_t n, blk0; };
@@ -246,6 +263,10 @@ static int build_local_table(pa_plan *const *plans, int n_parts, int mode, pa_pu
         if (in.ptrs[i + 1] - in.ptrs[i] != len) { T->free_all(); delete T; pa_set_err("slice length mismatch between parts %d and %d", ps->part, q); return PA_ERR_ARG; }
         pa_push_seg S;
         S.start = o.ptrs[j]; S.len = len; S.dst = in.d_buf + in.ptrs[i]; S.arrive = nullptr; S.ack = nullptr;
+        // (the receiving part's place among this launch's vectors, when it is on this device)
+        S.uidx = nullptr; S.upart = -1;
+        for (size_t kk = 0; kk < l.parts.size(); ++kk)
+          if (l.parts[kk] == q) { S.upart = (int32_t)kk; S.uidx = in.d_idx + in.ptrs[i]; }
         segs.push_back(S);
         ++P.nseg;
       }
@@ -382,6 +403,32 @@ static int push_local_impl(pa_plan *const *plans, int32_t n_parts, pa_vec *const
       p->ev_wait = l.ev;
     }
   }
+  return PA_OK;
+}
+
+int pa_exchange_push_unpack_one_stream(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v) {
+  PA_REQUIRE(plans && v && n_parts > 0, "bad arguments");
+  for (int r = 0; r < n_parts; ++r) {
+    PA_REQUIRE(plans[r] && v[r] && plans[r]->part == r, "plans[%d] is not the plan of part %d", r, r);
+    PA_REQUIRE(v[r]->n_own + v[r]->n_ghost == plans[r]->n_local, "part %d: vector has %lld local values, plan expects %lld", r,
+               (long long)(v[r]->n_own + v[r]->n_ghost), (long long)plans[r]->n_local);
+    PA_REQUIRE(plans[r]->phase == 0, "part %d: exchange already in flight on this plan (missing pa_exchange_finish)", r);
+  }
+  pa_push_table *T = nullptr;
+  PA_TRY(local_table(plans, n_parts, PA_CONSISTENT, &T));
+  PA_REQUIRE(T->launches.size() == 1, "the one-stream order needs all parts on one device");
+  pa_push_table::launch &l = T->launches[0];
+  if (l.n_blocks) {
+    pa_ctx *c = l.ctx;
+    PA_HIP(hipSetDevice(c->device));
+    pa_push_vecs vv;
+    for (size_t k = 0; k < l.parts.size(); ++k) vv.v[k] = v[l.parts[k]]->d;
+    hipLaunchKernelGGL(k_push_unpack, dim3(l.n_blocks), dim3(256), 0, c->s[0], l.d_parts, l.d_segs, l.d_block_part, vv);
+    PA_HIP(hipGetLastError());
+    // (a later exchange that comes by the comm stream orders itself behind the compute stream when it starts: pa_exchange_pack /
+    //  push_local_impl record ev_compute first -- the products of this step that still read the receive buffers are in front of it)
+  }
+  for (int r = 0; r < n_parts; ++r) { plans[r]->phase = 0; plans[r]->mode = PA_CONSISTENT; plans[r]->own_comm_stream = false; plans[r]->ev_wait = nullptr; }
   return PA_OK;
 }
 
@@ -716,6 +763,7 @@ extern "C" int pa_plan_ipc_connect(pa_plan *p, int32_t n_blobs, const void *cons
       const int64_t qNS = V.h.n_snd_nbr;
       const int64_t q_arr0 = mode == PA_CONSISTENT ? 0 : qNS;
       pa_push_seg S;
+      S.uidx = nullptr; S.upart = -1;
       S.start = o.ptrs[j]; S.len = len;
       S.dst = (double *)(mode == PA_CONSISTENT ? L->peers[q].snd : L->peers[q].rcv) + qp[i];
       S.arrive = (unsigned long long *)L->peers[q].flags + q_arr0 + (int64_t)i;

@@ -168,36 +168,35 @@ __device__ __forceinline__ double pa_wave_sum(double v) {
 #ifndef PA_HOOK_STORE_Y              /* the y store of EPI values the product does not know */
 #define PA_HOOK_STORE_Y(EPI, y, row, acc) __builtin_nontemporal_store(acc, &(y)[row])
 #endif
-template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, bool VD = false, int UNR = 4, bool PADP = false>
-__global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
-    const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
+// What the fused product mul!(c,a,b) (k_mul_fused, pa_mul_fused.h) adds to a chunk's work:
+//   FX 1 (own x own inside the fused launch): rows whose bit is set in `rowmask` are the part's BOUNDARY rows -- rows with stored
+//        entries in own_ghost; they are summed and stored by the launch's tail (FX 2) once b's ghost values are there, so this
+//        role leaves them alone: not stored, and with beta != 0 not read either;
+//   FX 2 (the tail: the boundary rows, own_own entries then own_ghost entries of each): columns >= n_split are positions of
+//        consistent!'s receive buffer x2.
+struct pa_fx {
+  const unsigned *rowmask = nullptr;
+  const double *x2 = nullptr;
+  int n_split = 0x7fffffff;
+};
+
+// one chunk of the row split (everything k_spmv_rowsplit does once it knows its chunk); prod / wsum: the workgroup's LDS
+template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI, bool VD, int UNR, bool PADP, int FX>
+__device__ __forceinline__ void pa_rowsplit_chunk(
+    double *prod, double *wsum, const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
     const double *__restrict__ val, const double *__restrict__ x_in,
-    double *__restrict__ y, const int *__restrict__ chunk_rp, const int *__restrict__ row_ids, int n_chunks,
-    int chunks_per_xcd, double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
-    const double *__restrict__ gs_diag, const unsigned char *__restrict__ code = nullptr,
-    const double *__restrict__ dict = nullptr, const int *__restrict__ chunk_list = nullptr, int max_col = 0x7fffffff) {
+    double *__restrict__ y, const int *__restrict__ chunk_rp, const int *__restrict__ row_ids,
+    double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
+    const double *__restrict__ gs_diag, const unsigned char *__restrict__ code,
+    const double *__restrict__ dict, int max_col, int chunk, const pa_fx fx) {
   constexpr int CAP = BLK * NPT;
   const double *x = EPI == 1 ? gs_x : x_in;   // EPI 1 reads and writes the same vector: no restrict promise on it
   static_assert(NPT % 2 == 0, "pairs");
-  // PADP: two pad slots per 32 products, for blocks whose rows mostly hold a multiple of 8 stored entries: the lanes of the
-  // reduce phase otherwise sit on the same banks (rows of 16: two banks, 16-way; with the pad 2-way; 4 M x 16 within +-500:
-  // 0.145 -> 0.136 ms).  Two slots, not one, so that a lane's pair of products stays 16-byte aligned and goes out as one
-  // ds_write_b128.  Other row lengths (18, 27, 81, ragged) lose 2-3 % to the slot arithmetic: the library picks the variant
-  // per block (pa_csr::pad_products).
+  static_assert(FX == 0 || EPI == 0, "the fused roles are roles of the plain product");
   constexpr bool PAD = PADP;
-  __shared__ __attribute__((aligned(16))) double prod[PAD ? CAP + CAP / 16 + 2 : CAP];
 #define PA_PSLOT(p) (PAD ? (p) + 2 * ((p) >> 5) : (p))
   const int tid = threadIdx.x;
-  const int b = blockIdx.x;
-  // (chunks_per_xcd < 0: the same map walked BACKWARDS -- every other product of a block streams its arrays from the end, so that what
-  // the last product left in the translation caches and in the Infinity Cache is what this one reads first)
-  const bool backwards = chunks_per_xcd < 0;
-  if (backwards) chunks_per_xcd = -chunks_per_xcd;
-  int chunk = PA_HOOK_CHUNK_MAP ? b : (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
-  if (chunk >= n_chunks || (!PA_HOOK_CHUNK_MAP && (b >> 3) >= chunks_per_xcd)) return;
-  if (backwards) chunk = n_chunks - 1 - chunk;
-  if (chunk_list) chunk = chunk_list[chunk];       // a launch over some of the block's chunks (n_chunks = length of the list)
   // chunk_rp[2c .. 2c+3] = {first row, its row pointer} of chunk c and of chunk c+1: the chunk's rows AND entries from one 16-byte
   // scalar read (round 5; chunk_row -> crp[r0], crp[r1] was a second, dependent round trip before the value stream could be
   // requested).  Eight chunks share a 64-byte line, so seven reads in eight hit in the scalar cache / L2.  (A 96-byte record with
@@ -211,7 +210,6 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
   // as branches inside it, the compiler had to assume at every join that the loads of EITHER side were pending and protect their
   // registers: the pattern path waited for the row-extent load -- a whole memory round trip -- before it even requested the
   // values, and a load hoisted or sunk across a join drained the other side's prefetch.  No joins, no such waits.)
-  __shared__ double wsum[EPI == 3 ? BLK / 64 : 1];
   auto body = [&](auto mode_tag, int nseg, int mywin) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode_tag)::value;
     // Unconditional loads: lanes past the chunk's end re-read its last pair (same address => no extra
@@ -321,6 +319,8 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     // my first row's extent (and, EPI 3, u[my row]): requested now so that the row sums do not wait for it
     const int rmine = min(r0 + tid, r1 - 1);     // (lanes past the chunk's rows: its last row, never summed)
     int ra = crp[rmine], re = crp[rmine + 1];
+    unsigned mword = 0;
+    if (FX == 1) mword = fx.rowmask[rmine >> 5];  // (non-compact block: row = stored row)
     double urow = 0.0;
     if (EPI == 3) urow = gs_b[row_ids ? row_ids[rmine] : rmine];
     if (VD) {
@@ -335,8 +335,14 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
 #pragma unroll
     for (int k = 0; k < NPT / 2; ++k) {
       d2 pr;
-      pr.x = v[k].x * PA_HOOK_X_AT(x, c0[k], r0);
-      pr.y = v[k].y * PA_HOOK_X_AT(x, c1[k], r0);
+      if (FX == 2) {
+        const double *x2m = fx.x2 - fx.n_split;
+        pr.x = v[k].x * (c0[k] < fx.n_split ? x : x2m)[c0[k]];
+        pr.y = v[k].y * (c1[k] < fx.n_split ? x : x2m)[c1[k]];
+      } else {
+        pr.x = v[k].x * PA_HOOK_X_AT(x, c0[k], r0);
+        pr.y = v[k].y * PA_HOOK_X_AT(x, c1[k], r0);
+      }
       v[k] = pr;
     }
     // (alpha: multiply-and-select per product, not a branch around the scaling -- the branch form waits for ALL gathers before the
@@ -354,6 +360,10 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
         re = crp[r + 1];
       }
       const int row = row_ids ? row_ids[r] : r;
+      if (FX == 1) {
+        if (r != r0 + tid) mword = fx.rowmask[row >> 5];
+        if ((mword >> (row & 31)) & 1u) continue;          // a boundary row: the launch's tail sums and stores it
+      }
       double acc = ((EPI != 0 && EPI != 3) || beta == 0.0) ? 0.0 : beta * y[row];
       const int a = ra - base, e = re - base;
 #pragma unroll UNR
@@ -403,13 +413,15 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     // one long row (more stored entries than a chunk holds): windows of CAP products, summed by
     // lane 0 in ascending p so that even this path keeps the reference's order.
     const int row = row_ids ? row_ids[r0] : r0;
+    if (FX == 1 && ((fx.rowmask[row >> 5] >> (row & 31)) & 1u)) return;      // (a long boundary row: the tail's, whole)
     const int *lcol = col + (PAT ? pdesc[chunk * PA_PDESC_INTS + 2] : 0);   // compacted 32-bit stream, see above
     double acc = 0.0, accp = 0.0;
     if (tid == 0) acc = ((EPI != 0 && EPI != 3) || beta == 0.0) ? 0.0 : beta * y[row];
     for (int w = p0; w < p1; w += CAP) {
       const int wend = min(w + CAP, p1);
       for (int idx = w + tid; idx < wend; idx += BLK) {
-        double pr = val[idx] * x[lcol[idx]];
+        const int lc = lcol[idx];
+        double pr = val[idx] * (FX == 2 && lc >= fx.n_split ? fx.x2[lc - fx.n_split] : x[lc]);
         if (alpha != 1.0) pr = pr * alpha;
         prod[idx - w] = pr;
       }
@@ -430,6 +442,39 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
       }
     }
   }
+}
+
+#undef PA_PSLOT
+
+template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, bool VD = false, int UNR = 4, bool PADP = false>
+__global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
+    const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
+    const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
+    const double *__restrict__ val, const double *__restrict__ x_in,
+    double *__restrict__ y, const int *__restrict__ chunk_rp, const int *__restrict__ row_ids, int n_chunks,
+    int chunks_per_xcd, double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
+    const double *__restrict__ gs_diag, const unsigned char *__restrict__ code = nullptr,
+    const double *__restrict__ dict = nullptr, const int *__restrict__ chunk_list = nullptr, int max_col = 0x7fffffff) {
+  constexpr int CAP = BLK * NPT;
+  // PADP: two pad slots per 32 products, for blocks whose rows mostly hold a multiple of 8 stored entries: the lanes of the
+  // reduce phase otherwise sit on the same banks (rows of 16: two banks, 16-way; with the pad 2-way; 4 M x 16 within +-500:
+  // 0.145 -> 0.136 ms).  Two slots, not one, so that a lane's pair of products stays 16-byte aligned and goes out as one
+  // ds_write_b128.  Other row lengths (18, 27, 81, ragged) lose 2-3 % to the slot arithmetic: the library picks the variant
+  // per block (pa_csr::pad_products).
+  __shared__ __attribute__((aligned(16))) double prod[PADP ? CAP + CAP / 16 + 2 : CAP];
+  __shared__ double wsum[EPI == 3 ? BLK / 64 : 1];
+  const int b = blockIdx.x;
+  // (chunks_per_xcd < 0: the same map walked BACKWARDS -- every other product of a block streams its arrays from the end, so that what
+  // the last product left in the translation caches and in the Infinity Cache is what this one reads first)
+  const bool backwards = chunks_per_xcd < 0;
+  if (backwards) chunks_per_xcd = -chunks_per_xcd;
+  int chunk = PA_HOOK_CHUNK_MAP ? b : (b & 7) * chunks_per_xcd + (b >> 3);  // XCD-aware: block b sits on XCD b%8
+  if (chunk >= n_chunks || (!PA_HOOK_CHUNK_MAP && (b >> 3) >= chunks_per_xcd)) return;
+  if (backwards) chunk = n_chunks - 1 - chunk;
+  if (chunk_list) chunk = chunk_list[chunk];       // a launch over some of the block's chunks (n_chunks = length of the list)
+  pa_rowsplit_chunk<BLK, NPT, NT, C16, PAT, EPI, VD, UNR, PADP, 0>(prod, wsum, crp, col, col16, win, pdesc, pdelta, val, x_in, y, chunk_rp,
+                                                                    row_ids, alpha, beta, gs_x, gs_b, gs_diag, code, dict, max_col, chunk,
+                                                                    pa_fx());
 }
 
 // Host-side row split: greedy chunks of consecutive (compacted) rows whose stored entries, counted from

@@ -40,6 +40,10 @@ class Context:
 
     def sync(self):
         L.call("pa_ctx_sync", self.h)
+
+    def reload_env(self):
+        """Read the PA_* switches of the product path from the environment again (pa_ctx_reload_env; they are read once, at creation)."""
+        L.call("pa_ctx_reload_env", self.h)
         if _PART_CTX:                       # (one context per part: "the device is idle" means all of them)
             for c in all_contexts():
                 if c is not self:

@@ -102,4 +102,37 @@ def _encoding_cases(orc):
     yield "scattered rows", csr(20000, 300000, [np.sort(rng.choice(300000, size=12, replace=False)) for _ in range(20000)])
 
 
+def oracle_mul(orc, Ao, xo):
+    return _oracle_mul(orc, Ao, xo)
+
+
+def reload_switches():
+    """The library reads its product-path switches (PA_PUSH, PA_MUL_FUSED, ...) when a context is created: after changing the
+    environment inside a test, every live context reads them again."""
+    import pa_amd.p_vector as pv
+    for c in pv.all_contexts():
+        c.reload_env()
+
+
+class env:
+    """with env(PA_X="0"): ... -- environment switches of the library for the duration of a block."""
+
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+        reload_switches()
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        reload_switches()
+        return False
+
+
 __all__ = [n for n in dir() if not n.startswith("__")]

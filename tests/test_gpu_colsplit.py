@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from gpu_common import pa, env
+from gpu_helpers import pa, env
 import pa_amd._lib as L
 
 pytestmark = pytest.mark.gpu

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from gpu_common import pa
+from gpu_helpers import pa
 import pa_amd._lib as L
 
 pytestmark = pytest.mark.gpu
@@ -68,7 +68,7 @@ def test_mul_of_a_matrix_whose_blocks_are_csc_follows_the_csc_form_through_every
     """mul!(c,a,b,alpha,beta) (src/p_sparse_matrix.jl:2105-2142) when the local blocks keep the default SparseMatrixCSC storage:
     own x own and own x ghost each follow SparseArrays' a*(x*alpha) -- also through pa_mul_all, where own x ghost is a TWIN of the
     block (columns renamed to receive-buffer positions, made at the first product) running on the comm stream beside own x own."""
-    from gpu_common import ranks, upload
+    from gpu_helpers import ranks, upload
     A, _ = pa.build_p_matrix(ranks(4), 6, 5, 4, 12, 10, 4, 2, 2, 1, keep_host=True, fused=True)
     Ao, _, _ = orc.hpcg_build_p_matrix(6, 5, 4, 2, 2, 1)
 

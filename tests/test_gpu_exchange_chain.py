@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from gpu_common import pa, ranks, upload, oracle_mul, env
+from gpu_helpers import pa, ranks, upload, oracle_mul, env
 import pa_amd._lib as L
 import pa_amd.p_sparse_matrix as psm
 
@@ -20,6 +20,15 @@ def _from_buffer(A, b):
         yes = C.c_int()
         L.call("pa_matrix_ghost_from_buffer", h, C.byref(yes))
         out.append(bool(yes.value))
+    return out
+
+
+def _fused(A, b):
+    out = []
+    for h in psm._operator_handles(A, b).items:
+        yes, nb = C.c_int(), C.c_int64()
+        L.call("pa_matrix_fused", h, C.byref(yes), C.byref(nb))
+        out.append((bool(yes.value), int(nb.value)))
     return out
 
 
@@ -78,7 +87,8 @@ def test_mul_with_own_x_ghost_from_the_receive_buffer(orc, case):
     y5 = [v.copy() for v in yo]
     orc.mul5(y5, Ao, [v.copy() for v in xo], 0.3, -1.5)
     outs = {}
-    for tag, switches in (("buffer", {}), ("round 3", {"PA_PUSH": "0"}), ("unpack first", {"PA_MUL_GHOST_FROM_BUFFER": "0"})):
+    for tag, switches in (("buffer", {}), ("separate launches", {"PA_MUL_FUSED": "0"}), ("round 3", {"PA_PUSH": "0"}),
+                          ("unpack first", {"PA_MUL_GHOST_FROM_BUFFER": "0"})):
         with env(**switches):
             A = build()
             x = upload([v.copy() for v in xo], A.col_partition)
@@ -86,7 +96,15 @@ def test_mul_with_own_x_ghost_from_the_receive_buffer(orc, case):
             for _ in range(3):
                 pa.mul_c_(y, A, x)
             used = _from_buffer(A, x)
-            assert all(used) if tag == "buffer" else not any(used), (tag, used)
+            assert all(used) if tag in ("buffer", "separate launches") else not any(used), (tag, used)
+            fused = _fused(A, x)
+            # round 5: one launch per part, the boundary rows (rows with stored entries in own_ghost) as its tail
+            import pa_amd.p_vector as pv
+            want_fused = tag == "buffer" and not pv.contexts_per_part()      # (one context per part: the parts' launches are not one chain)
+            assert all(f for f, _ in fused) if want_fused else not any(f for f, _ in fused), (tag, fused)
+            if want_fused:
+                for (_, nb), blk in zip(fused, Ao.blocks):
+                    assert nb == int(np.count_nonzero(np.diff(blk.own_ghost.rowptr)))
             for got, e, r in zip(y.own_values().items, yo, Ao.rows):
                 assert np.array_equal(got, e[:r.n_own]), tag
             for got, e in zip(x.local_values().items, xc):
@@ -95,7 +113,7 @@ def test_mul_with_own_x_ghost_from_the_receive_buffer(orc, case):
             for got, e, r in zip(y.own_values().items, y5, Ao.rows):
                 assert np.array_equal(got, e[:r.n_own]), tag
             outs[tag] = [v.copy() for v in y.own_values().items]
-    for tag in ("round 3", "unpack first"):
+    for tag in ("separate launches", "round 3", "unpack first"):
         assert all(np.array_equal(a, b) for a, b in zip(outs["buffer"], outs[tag]))
 
 
@@ -146,29 +164,29 @@ def test_mul_all_replayed_from_a_hipgraph(orc, monkeypatch, one_stream):
     replayed: the bits of the eager call, also after x changed between replays, and x's ghosts made consistent by the replay.
     Recorded as ONE chain on the compute stream (the default inside a capture: a graph with edges between two streams replays
     2.6 x slower than the eager calls) and, PA_GRAPH_ONE_STREAM=0, with the eager call's two streams."""
-    monkeypatch.setenv("PA_GRAPH_ONE_STREAM", one_stream)
-    n, np3 = (10, 8, 6), (2, 2, 2)
-    A = pa.build_p_matrix(ranks(8), *n, *(a * q for a, q in zip(n, np3)), *np3)[0]
-    Ao = orc.hpcg_build_p_matrix(*n, *np3)[0]
-    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
-    x = upload([v.copy() for v in xo], A.col_partition)
-    y = pa.pzeros(A.row_partition)
-    pa.mul_c_(y, A, x)                                   # eager once: tables and the renamed block are made outside the capture
-    with pa.Graph() as g:
-        pa.mul_c_(y, A, x)
-    for rep in range(3):
-        xr = [v * (1.0 + rep) for v in xo]
-        for dv, h in zip(x.vector_partition.items, xr):
-            dv.upload(h)
-        pa.pfill(0.0, A.row_partition)
-        g.launch()
-        yo = oracle_mul(orc, Ao, xr)
-        for got, e, r in zip(y.own_values().items, yo, Ao.rows):
-            assert np.array_equal(got, e[:r.n_own]), rep
-        xc = [v.copy() for v in xr]
-        orc.consistent(xc, Ao.cols)
-        for got, e in zip(x.local_values().items, xc):
-            assert np.array_equal(got, e), rep
+    with env(PA_GRAPH_ONE_STREAM=one_stream):
+        n, np3 = (10, 8, 6), (2, 2, 2)
+        A = pa.build_p_matrix(ranks(8), *n, *(a * q for a, q in zip(n, np3)), *np3)[0]
+        Ao = orc.hpcg_build_p_matrix(*n, *np3)[0]
+        xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+        x = upload([v.copy() for v in xo], A.col_partition)
+        y = pa.pzeros(A.row_partition)
+        pa.mul_c_(y, A, x)                                   # eager once: tables and the renamed block are made outside the capture
+        with pa.Graph() as g:
+            pa.mul_c_(y, A, x)
+        for rep in range(3):
+            xr = [v * (1.0 + rep) for v in xo]
+            for dv, h in zip(x.vector_partition.items, xr):
+                dv.upload(h)
+            pa.pfill(0.0, A.row_partition)
+            g.launch()
+            yo = oracle_mul(orc, Ao, xr)
+            for got, e, r in zip(y.own_values().items, yo, Ao.rows):
+                assert np.array_equal(got, e[:r.n_own]), rep
+            xc = [v.copy() for v in xr]
+            orc.consistent(xc, Ao.cols)
+            for got, e in zip(x.local_values().items, xc):
+                assert np.array_equal(got, e), rep
 
 
 def test_pa_mul5_over_a_one_rank_rccl_communicator():

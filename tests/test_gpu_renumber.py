@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from gpu_common import pa, ranks, upload, oracle_mul
+from gpu_helpers import pa, ranks, upload, oracle_mul
 import pa_amd._lib as L
 
 pytestmark = pytest.mark.gpu

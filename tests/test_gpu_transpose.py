@@ -6,7 +6,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from gpu_common import pa, ranks, upload, env
+from gpu_helpers import pa, ranks, upload, env
 import pa_amd._lib as L
 
 pytestmark = pytest.mark.gpu

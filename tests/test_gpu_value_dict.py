@@ -5,7 +5,7 @@ src/sparse_utils.jl:649-669; value updates: psparse! src/p_sparse_matrix.jl:1291
 import numpy as np
 import pytest
 
-from gpu_common import pa, ranks, env
+from gpu_helpers import pa, ranks, env
 import pa_amd._lib as L
 
 pytestmark = pytest.mark.gpu
