@@ -380,12 +380,44 @@ def time_block(pa, ctx, L, blk, n_rows, n_cols, reps=30):
     return e0.elapsed_ms(e1) / reps
 
 
-def chain_info(P):
-    """Launches of one mul! of P parts in one process after round 4 (csrc/pa_push.hip, pa_mul_all): 1 push (pack + deliver, all
-    parts), P own x own, P own x ghost (reading the receive buffers), 1 unpack (all parts); no copies.  On the critical path of ONE
-    part behind its own x own: the own x ghost launch (the push runs beside own x own, the unpack behind own x ghost)."""
+def chain_info(P, fused=True):
+    """Launches of one mul! of P parts in one process (pa_mul_all).  Round 5 (csrc/pa_fused.hip): 1 push launch that packs, delivers
+    AND writes b's ghost entries (consistent! complete), then ONE launch per part -- own x own's chunks with the part's boundary rows
+    (own_own entries, then own_ghost entries read from the receive buffer) as the launch's tail; one stream, no events.  Round 4
+    (PA_MUL_FUSED=0): 1 push, P own x own, P own x ghost, 1 unpack."""
+    if fused:
+        return {"launches_per_step": P + 1, "launches_per_step_round4": 2 * P + 2,
+                "critical_path_launches": {"before_own_own": 1, "beside_own_own": 0, "after_own_own": 0}}
     return {"launches_per_step": 2 * P + 2, "launches_per_step_round3": "4 per part + one copy per directed edge",
             "critical_path_launches": {"before_own_own": 0, "beside_own_own": 1, "after_own_own": 1, "after_own_ghost_off_path": 1}}
+
+
+def fused_info(pa, ctx, L, A, x, y, reps=30):
+    """Which parts' mul! runs as one launch (pa_matrix_fused), their boundary rows, and the same mul! with PA_MUL_FUSED=0 (round 4's
+    separate launches) timed right beside it."""
+    import ctypes as C
+    import pa_amd.p_sparse_matrix as psm
+    fused, nb = [], []
+    for h in pa.local_items(psm._operator_handles(A, x)):
+        yes, n = C.c_int(), C.c_int64()
+        L.call("pa_matrix_fused", h, C.byref(yes), C.byref(n))
+        fused.append(bool(yes.value)); nb.append(int(n.value))
+    os.environ["PA_MUL_FUSED"] = "0"
+    ctx.reload_env()
+    try:
+        for _ in range(5):
+            pa.mul_c_(y, A, x)
+        e0 = ctx.event().record(L.STREAM_COMPUTE)
+        for _ in range(reps):
+            pa.mul_c_(y, A, x)
+        e1 = ctx.event().record(L.STREAM_COMPUTE)
+        ctx.sync()
+        ms_sep = e0.elapsed_ms(e1) / reps
+    finally:
+        os.environ.pop("PA_MUL_FUSED", None)
+        ctx.reload_env()
+    return all(fused), {"parts_as_one_launch": int(sum(fused)), "boundary_rows_per_part": nb,
+                        "ms_per_part_mul_separate_launches": round(ms_sep / len(fused), 4)}
 
 
 def whole_mul_times(pa, ctx, L, A, x, y, reps=30, graph=True):
@@ -479,11 +511,13 @@ def extra_configs(pa, ctx, L, out):
     y32 = pa.pzeros(A32.row_partition)
     ms, ms_graph, ms_spmv = whole_mul_times(pa, ctx, L, A32, x32, y32)
     nnz32 = sum(b.own_own.nnz + b.own_ghost.nnz for b in pa.local_items(A32.matrix_partition))
-    out.append({"workload": "config 3 whole: HPCG 27-pt 128^3 per part, 2 parts (2,1,1) BOTH on this one GPU, mul! = push (pack + deliver) + "
-                            "own x own + own x ghost from the receive buffer + unpack (pa_mul_all)",
+    all_fused, finfo = fused_info(pa, ctx, L, A32, x32, y32)
+    out.append({"workload": "config 3 whole: HPCG 27-pt 128^3 per part, 2 parts (2,1,1) BOTH on this one GPU, mul! = one push launch (pack + "
+                            "deliver + b's ghosts) + ONE launch per part (own x own's chunks, boundary rows as the tail) (pa_mul_all)",
+                **finfo,
                 "parts": 2, "nnz": int(nnz32), "ghosts_per_part": [c.n_ghost for c in pa.local_items(A32.col_partition)],
                 "ms_per_part_mul": round(ms / 2, 4), "ms_per_part_mul_hipgraph": round(ms_graph / 2, 4), "ms_per_part_spmv": round(ms_spmv / 2, 4),
-                "mul_over_spmv": round(ms / ms_spmv, 3), **chain_info(2), "gflops": round(2.0 * nnz32 / ms / 1e6, 1), "setup_s": round(ts, 1)})
+                "mul_over_spmv": round(ms / ms_spmv, 3), **chain_info(2, all_fused), "gflops": round(2.0 * nnz32 / ms / 1e6, 1), "setup_s": round(ts, 1)})
     del A32, x32, y32
     # consistent!(v) and assemble!(v) on their own (rows a7-a9 of SURVEY 8): config 4's partition shape, (2,2,2) parts of 128^3
     # rows with all 26-neighbour ghost layers, the 8 parts on this ONE GPU -- one push launch (pack + deliver) and one unpack launch
@@ -668,11 +702,13 @@ def extra_configs(pa, ctx, L, out):
     ghosts = [c.n_ghost for c in pa.local_items(A5.col_partition)]
     rows5 = sum(r.n_own for r in pa.local_items(A5.row_partition))
     moved = sum(b.own_own.stream_bytes() + b.own_ghost.stream_bytes() for b in blocks) + 16 * rows5 + 3 * 8 * sum(ghosts)
+    all_fused, finfo = fused_info(pa, ctx, L, A5, x5, y5)
     out.append({"workload": f"config 5 whole: Q1 FEM Laplacian {n5} x {n5} nodes, 8 parts (4,2) ALL on this one GPU, disassembled psparse "
-                            "route, mul! = pack + device-to-device exchange + own x own + unpack + own x ghost (pa_mul_all)",
+                            "route, mul! = one push launch + ONE launch per part (pa_mul_all)",
+                **finfo, "mul_over_spmv": round(ms / ms_spmv, 3),
                 "parts": 8, "rows": int(rows5), "nnz": int(nnz5), "ghosts_per_part": ghosts, "ms_all_parts": round(ms, 4),
                 "ms_per_part": round(ms / 8, 4), "ms_per_part_mul": round(ms / 8, 4), "ms_per_part_mul_hipgraph": round(ms_graph / 8, 4),
-                "ms_per_part_spmv": round(ms_spmv / 8, 4), **chain_info(8),
+                "ms_per_part_spmv": round(ms_spmv / 8, 4), **chain_info(8, all_fused),
                 "gflops": round(2.0 * nnz5 / ms / 1e6, 1), "moved_gbps": round(moved / ms / 1e6, 1),
                 "encoding_own_own": blocks[0].own_own.encoding(), "encoding_own_ghost": blocks[0].own_ghost.encoding(), "setup_s": round(ts, 1)})
     del A5, x5, y5, blocks
@@ -949,6 +985,7 @@ def main():
         gev.append(ctx.event().record(L.STREAM_COMPUTE))
     ctx.sync()
     ramp += [gev[k].elapsed_ms(gev[k + 1]) / 10 for k in range(n_groups)]
+    ms_after_fixed_ramp = float(np.mean(ramp[-2:]))     # the last 20 steps of the FIXED ramp: no selection rule has acted yet
     # One part, no neighbours (the N = 1 headline): a step IS one launch of the product kernel, which on every lease seen so far
     # settles at 0.90-0.91 of what the box's own two-stream read kernel streams (roofline.frac_vs_this_box_read) and sits at 0.85-0.86
     # while the GPU is still on the middle plateau.  Below 0.875 after the ramp the warm-up goes on, a quarter of a second at a
@@ -1099,6 +1136,11 @@ def main():
             "metric": "HPCG 27-pt SpMV GFLOP/s + achieved HBM GB/s per GPU",
             "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "warmup_effective": args.warmup + 10 * len(ramp) + 10 * len(ramp_after_ab),
+            #  the unconditioned figures beside `value`: the 20 steps that END the fixed one-second ramp -- before the
+            # N = 1 extension rule (clock_ramp.extension_rule) can have acted -- and how long that rule then kept warming up
+            "value_after_fixed_ramp": round(flops_total / (ms_after_fixed_ramp * 1e-3) / 1e9, 2),
+            "ms_per_step_after_fixed_ramp": round(ms_after_fixed_ramp, 4),
+            "clock_ramp_extended_s": ramp_extended_s,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"HPCG 27-pt stencil {n}^3 rows per part, {N} part(s) as ({npx},{npy},{npz}), "
@@ -1392,6 +1434,10 @@ def main():
         out = LINE[0]
         if vdict:
             out["value_dictionary_mode"] = vdict
+            # the product a user of the library gets WITHOUT switches (the dictionary is the library's default for big blocks with
+            # <= 64 distinct values; `value` switches it off to keep the fp64 stream): first-class beside `value`
+            out["value_library_defaults"] = vdict["gflops"]
+            out["ms_per_step_library_defaults"] = vdict["avg_launch_ms"]
         if general:
             out["general_csr"] = general
         if transpose:

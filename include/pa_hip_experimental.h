@@ -334,6 +334,9 @@ int pa_csr_download_entries(const pa_csr *A, int32_t *rows, int32_t *cols);
  * Decided per handle at its first product; PA_MUL_FUSED=0 keeps the separate launches.  *yes = 1: fused; *n_boundary_rows: the
  * tail's rows. */
 int pa_matrix_fused(const pa_matrix *m, int *yes, int64_t *n_boundary_rows);
+/* products this context has run as one launch so far; of those, with the exchange inside the launch (one part per process over the
+ * ipc link: push by the first blocks, arrival acquired by the tail, unpack and acknowledgement by the tail) */
+int pa_ctx_fused_launches(const pa_ctx *c, int64_t *all, int64_t *with_exchange);
 /* The switches of the product path (PA_PUSH, PA_GRAPH_ONE_STREAM, PA_MUL_GHOST_FROM_BUFFER, PA_MUL_FUSED, PA_SPMV_ALTERNATE) are
  * read from the environment when a context is created; this reads them again (tests flip them inside one process). */
 int pa_ctx_reload_env(pa_ctx *c);

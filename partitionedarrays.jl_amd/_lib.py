@@ -163,6 +163,7 @@ _SIGS = {
     "pa_csr_download_entries": [P, P, P],
     "pa_matrix_fused": [P, C.POINTER(cint), C.POINTER(i64)],
     "pa_ctx_reload_env": [P],
+    "pa_ctx_fused_launches": [P, C.POINTER(i64), C.POINTER(i64)],
     "pa_csr_locality_order": [P, P, C.POINTER(i64), C.POINTER(i64)],
     "pa_csr_create_permuted": [P, P, P, PP],
     "pa_csr_create_transpose_ranked": [P, P, PP],

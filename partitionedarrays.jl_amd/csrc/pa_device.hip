@@ -343,6 +343,7 @@ static void read_switches(pa_ctx *c) {
   c->sw.graph_one_stream = flag("PA_GRAPH_ONE_STREAM", 1);
   c->sw.ghost_from_buffer = flag("PA_MUL_GHOST_FROM_BUFFER", 1);
   c->sw.mul_fused = flag("PA_MUL_FUSED", 1);
+  c->sw.mul_fused_rccl = flag("PA_MUL_FUSED_RCCL", 1);
   c->sw.spmv_alternate = flag("PA_SPMV_ALTERNATE", 1);
 }
 extern "C" int pa_ctx_reload_env(pa_ctx *c) {
@@ -2618,6 +2619,7 @@ extern "C" int pa_plan_destroy(pa_plan *p) {
   (void)hipStreamSynchronize(p->ctx->s[0]);
   (void)hipStreamSynchronize(p->ctx->s[1]);
   pa_push_release(p);
+  pa_fused_plan_release(p);
   for (pa_plan::side *s : {&p->snd, &p->rcv}) {
     (void)pa_raw_free(s->d_idx);
     if (!p->bufs_in_ipc_region) (void)pa_raw_free(s->d_buf);
@@ -2898,6 +2900,24 @@ extern "C" int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double
   PA_TRY(mul_check(m, c, b));
   PA_REQUIRE(c->d != b->d, "c and b alias");
   PA_TRY(matrix_rb(m));
+  if (!comm && m->ctx->sw.mul_fused && pa_plan_ipc_connected(m->plan) && !m->ctx->capturing && (m->plan->snd.n || m->plan->rcv.n)) {
+    // one part per process over the ipc link: push, both products, unpack and acknowledgement are ONE launch (pa_fused.hip)
+    PA_TRY(pa_matrix_fused_build(m));
+    const bool scaled = (m->oo->alpha_inside || m->oh->alpha_inside) && alpha != 1.0;
+    if (pa_matrix_fused_ready(m) && !scaled && pa_fused_ipc_fits(m)) {
+      pa_csr_before_product(m->oo);
+      return pa_mul_fused_ipc(m, c, b, alpha, beta);
+    }
+  }
+  if (comm && m->ctx->sw.mul_fused && m->ctx->sw.mul_fused_rccl && !m->ctx->capturing && (m->plan->snd.n || m->plan->rcv.n)) {
+    // one part per process over RCCL: the transport on the comm stream, the whole product ONE launch beside it (pa_fused.hip)
+    PA_TRY(pa_matrix_fused_build(m));
+    const bool scaled = (m->oo->alpha_inside || m->oh->alpha_inside) && alpha != 1.0;
+    if (pa_matrix_fused_ready(m) && !scaled) {
+      pa_csr_before_product(m->oo);
+      return pa_mul_fused_rccl(m, comm, c, b, alpha, beta);
+    }
+  }
   PA_TRY(pa_exchange_start(m->plan, comm, b, PA_CONSISTENT));                // t = consistent!(b)
   PA_TRY(pa_spmv(m->oo, b, PA_SEG_OWN, c, PA_SEG_OWN, alpha, beta));        // own x own, overlaps the exchange
   return mul_ghost_part(m, c, b, alpha);

@@ -27,6 +27,7 @@
 
 #include "pa_setup.h"
 #include "pa_spmv_kernel.h"
+#include "pa_push_dev.h"
 
 using namespace pa_util;
 
@@ -183,6 +184,13 @@ extern "C" int pa_matrix_fused(const pa_matrix *m, int *yes, int64_t *n_boundary
   return PA_OK;
 }
 
+extern "C" int pa_ctx_fused_launches(const pa_ctx *c, int64_t *all, int64_t *with_exchange) {
+  PA_REQUIRE(c != nullptr, "bad arguments");
+  if (all) *all = c->n_fused;
+  if (with_exchange) *with_exchange = c->n_fused_exchange;
+  return PA_OK;
+}
+
 bool pa_matrix_fused_ready(const pa_matrix *m) {
   return m->bd && m->bd_epoch_oo == m->oo->val_epoch && m->bd_epoch_oh == m->oh->val_epoch && m->oh_rb &&
          m->rb_epoch == m->oh->val_epoch;
@@ -191,14 +199,26 @@ bool pa_matrix_fused_ready(const pa_matrix *m) {
 // ---- the launch ------------------------------------------------------------------------------------------------------------------
 struct pa_fused_args {
   int n_main_blocks;                               // the grid's first blocks: own x own's chunks (8 * chunks per XCD)
+  int n_tail_chunks, n_tail_blocks;                // bd's chunks, walked by the grid's last blocks (block t: chunks t, t + blocks, ...)
   const unsigned *rowmask;                         // bit r: row r is a boundary row
   // bd: Int32 columns, compacted rows
   const int *b_crp, *b_col, *b_chunk_rp, *b_row_ids;
   const double *b_val;
   const double *rbuf;                              // consistent!'s receive buffer (buffer_rcv of the reversed cache)
   int n_split, b_max_col;
+  double *bvec;                                    // b's local values (the tail's unpack)
+  pa_fused_comm X;
 };
 
+// One part per process: the exchange lives INSIDE the launch.
+//   first blocks : pack + push over the ipc link (stores into the neighbours' receive buffers, arrival flags behind them), then
+//                  they take own x own chunks like every other block;
+//   tail blocks  : one lane per awaited neighbour polls its arrival flag (bounded: the link's time-out raises the status word and
+//                  the block gives up), ONE system-scope acquire, then the boundary rows from the receive buffer, the unpack of
+//                  b's ghost entries, and -- the last tail block to finish -- the acknowledgement to the senders.
+// The tail blocks are the LAST blocks of the grid: by the time one is dispatched every own x own block is running or done, so a
+// spinning tail block never holds a slot an own x own block of THIS launch is waiting for; they are at most X.max_tail_blocks, so
+// they cannot fill a GPU that another process's launch (its pushing blocks!) has to get onto -- ranks sharing one GPU in the tests.
 template <bool C16, int PAT, bool VD>
 __global__ __launch_bounds__(256) void k_mul_fused(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
@@ -209,15 +229,45 @@ __global__ __launch_bounds__(256) void k_mul_fused(
   constexpr int BLK = 256, NPT = PA_SPMV_CHUNK_NNZ / 256;
   __shared__ __attribute__((aligned(16))) double prod[BLK * NPT];
   __shared__ double wsum[1];
+  __shared__ int ok;
   const int b = blockIdx.x;
   if (b >= F.n_main_blocks) {
+    const int tb = b - F.n_main_blocks;
+    if (F.X.n_wait > 0) {
+      if (threadIdx.x == 0) ok = 1;
+      __syncthreads();
+      for (int i = threadIdx.x; i < F.X.n_wait; i += BLK)
+        if (!flag_wait(F.X.flags + F.X.wait_idx[i], F.X.seq, F.X.ticks)) { atomicExch(F.X.status, 1); ok = 0; }
+      __syncthreads();
+      if (!ok) return;                                       // (a neighbour is gone or out of step: the status word says so)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");         // what the neighbours stored in front of their flags is visible now
+      __syncthreads();
+    }
     pa_fx fx;
     fx.x2 = F.rbuf; fx.n_split = F.n_split;
-    pa_rowsplit_chunk<BLK, NPT, true, false, 0, 0, false, 4, false, 2>(
-        prod, wsum, F.b_crp, F.b_col, nullptr, nullptr, nullptr, nullptr, F.b_val, x, y, F.b_chunk_rp, F.b_row_ids, alpha, beta, nullptr,
-        nullptr, nullptr, nullptr, nullptr, F.b_max_col, b - F.n_main_blocks, fx);
+    for (int t = tb; t < F.n_tail_chunks; t += F.n_tail_blocks) {
+      pa_rowsplit_chunk<BLK, NPT, true, false, 0, 0, false, 4, false, 2>(
+          prod, wsum, F.b_crp, F.b_col, nullptr, nullptr, nullptr, nullptr, F.b_val, x, y, F.b_chunk_rp, F.b_row_ids, alpha, beta, nullptr,
+          nullptr, nullptr, nullptr, nullptr, F.b_max_col, t, fx);
+      __syncthreads();                                       // (the next chunk's products go where this one's row sums read)
+    }
+    for (int k = tb * BLK + (int)threadIdx.x; k < F.X.u_n; k += F.n_tail_blocks * BLK) F.bvec[F.X.u_idx[k]] = F.rbuf[k];
+    if (F.X.n_ack > 0) {
+      __syncthreads();                                       // every lane of this block has read what it needs of the buffer
+      if (threadIdx.x == 0) {
+        const unsigned done = atomicAdd(F.X.t_done, 1u);
+        if (done == (unsigned)F.n_tail_blocks - 1) {         // the last tail block: the senders may overwrite the buffer
+          *F.X.t_done = 0;
+          __threadfence_system();
+          for (int i = 0; i < F.X.n_ack; ++i) flag_store(F.X.ack_dst[i], F.X.seq);
+        }
+      }
+    }
     return;
   }
+  if (b < F.X.n_push_blocks)
+    (void)pa_push_ipc_block(&ok, F.X.p_idx, F.X.p_n, F.X.p_segs, F.X.p_nseg, x, F.X.seq, F.X.p_done, F.X.ticks, F.X.status, b,
+                            F.X.n_push_blocks);
   const bool backwards = chunks_per_xcd < 0;
   if (backwards) chunks_per_xcd = -chunks_per_xcd;
   int chunk = (b & 7) * chunks_per_xcd + (b >> 3);           // XCD-aware, as k_spmv_rowsplit
@@ -230,9 +280,10 @@ __global__ __launch_bounds__(256) void k_mul_fused(
                                                                   chunk, fx);
 }
 
-// own(c) = beta*own(c) + alpha*(A_oo*own(b) + A_oh*ghost(b)) of one part in one launch on stream st; the receive buffer of
-// consistent!(b) must hold b's ghost values by the time the launch's tail reads it (stream order: the push launch is in front).
-int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, const pa_vec *b, double alpha, double beta, hipStream_t st) {
+// own(c) = beta*own(c) + alpha*(A_oo*own(b) + A_oh*ghost(b)) of one part in one launch on stream st.  comm == NULL: the receive
+// buffer of consistent!(b) holds b's ghost values by stream order (the push launch is in front, pa_mul_all); else the exchange
+// happens inside the launch as *comm says.
+int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double beta, hipStream_t st, const pa_fused_comm *comm) {
   const pa_csr *S = m->oo, *B = m->bd;
   pa_plan *p = m->plan;
   pa_fused_args F;
@@ -242,7 +293,12 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, const pa_vec *b, double alpha, 
   F.b_crp = B->d_crp; F.b_col = B->d_col; F.b_chunk_rp = B->d_chunk_rp; F.b_row_ids = B->d_row_ids; F.b_val = B->d_val;
   F.rbuf = p->snd.d_buf;
   F.n_split = (int)S->n_cols; F.b_max_col = (int)B->n_cols - 1;
-  const int n_tail = (int)B->n_chunks;
+  F.bvec = b->d;
+  if (comm) F.X = *comm;
+  F.n_tail_chunks = (int)B->n_chunks;
+  F.n_tail_blocks = F.X.max_tail_blocks > 0 ? std::min(F.n_tail_chunks, F.X.max_tail_blocks) : F.n_tail_chunks;
+  PA_REQUIRE(F.X.n_push_blocks <= F.n_main_blocks, "more pushing blocks than own x own has chunks");
+  const int n_tail = F.n_tail_blocks;
   if (m->ctx->sw.spmv_alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) cpx = -cpx;
 #define PA_LAUNCH_FUSED(C16, PAT, VD)                                                                                           \
   hipLaunchKernelGGL((k_mul_fused<C16, PAT, VD>), dim3(F.n_main_blocks + n_tail), dim3(256), 0, st, S->d_crp, S->d_col, S->d_col16, \
@@ -267,5 +323,55 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, const pa_vec *b, double alpha, 
   }
 #undef PA_LAUNCH_FUSED
   PA_HIP(hipGetLastError());
+  m->ctx->n_fused++;
+  if (comm) m->ctx->n_fused_exchange++;
+  return PA_OK;
+}
+
+// ---- one part per process over RCCL ---------------------------------------------------------------------------------------------
+// The transport stays what `north_star` names -- pack, ONE group of ncclSend / ncclRecv per neighbour on the comm stream
+// (pa_rccl.cpp; src/mpi_array.jl:575-614) -- and behind the receives the comm stream raises a flag word.  The product is ONE launch
+// on the compute stream, queued at once: its own x own blocks overlap the transport, its tail acquires the flag, sums the boundary
+// rows from the receive buffer and unpacks b's ghost entries.  Launches per step: pack + RCCL's own + flag | 1.
+__global__ void kf_raise(unsigned long long *flag, unsigned long long seq) { flag_store(flag, seq); }
+
+void pa_fused_plan_release(pa_plan *p) {
+  if (p->d_rflag) (void)hipFree(p->d_rflag);
+  if (p->h_rstatus) (void)hipHostFree(p->h_rstatus);
+  p->d_rflag = nullptr; p->h_rstatus = nullptr;
+}
+
+int pa_mul_fused_rccl(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta) {
+  pa_plan *p = m->plan;
+  pa_ctx *cx = p->ctx;
+  PA_HIP(hipSetDevice(cx->device));
+  if (!p->d_rflag) {
+    PA_HIP(hipMalloc((void **)&p->d_rflag, 16));
+    PA_HIP(hipMemset(p->d_rflag, 0, 16));              // [0] the flag, [1] (as Int32) the index 0 of the tail's one-entry wait list
+    PA_HIP(hipHostMalloc((void **)&p->h_rstatus, sizeof(int), hipHostMallocMapped));
+    *p->h_rstatus = 0;
+    PA_HIP(hipDeviceSynchronize());
+  }
+  if (*(volatile int *)p->h_rstatus != 0) {
+    pa_set_err("an earlier product of part %d gave up waiting for its RCCL receives: a neighbour is gone or out of step", p->part);
+    return PA_ERR_STATE;
+  }
+  PA_TRY(pa_exchange_pack(p, b, PA_CONSISTENT));
+  PA_TRY(pa_exchange_rccl(p, comm, PA_CONSISTENT));
+  pa_fused_comm X;
+  X.seq = ++p->rseq;
+  hipLaunchKernelGGL(kf_raise, dim3(1), dim3(1), 0, cx->s[1], p->d_rflag, X.seq);
+  PA_HIP(hipGetLastError());
+  X.flags = p->d_rflag; X.wait_idx = (const int32_t *)(p->d_rflag + 1); X.n_wait = 1;
+  double secs = 30.0;
+  if (const char *e = getenv("PA_IPC_TIMEOUT_S")) secs = std::max(0.001, atof(e));
+  X.ticks = (long long)(secs * 1e8);
+  X.status = p->h_rstatus;
+  X.u_idx = p->snd.d_idx; X.u_n = (int)p->snd.n;
+  X.max_tail_blocks = 256;
+  PA_TRY(pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], &X));
+  // the exchange is complete with the launch (wait(t) and the unpack are its tail); the next pack orders itself behind the compute
+  // stream (pa_exchange_pack records ev_compute), so nothing overwrites the buffers this launch still reads
+  p->phase = 0; p->own_comm_stream = false; p->ev_wait = nullptr;
   return PA_OK;
 }

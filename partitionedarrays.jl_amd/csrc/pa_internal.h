@@ -46,11 +46,13 @@ struct pa_switches {
   int graph_one_stream = 1;   // PA_GRAPH_ONE_STREAM: inside a capture pa_mul_all queues ONE chain on the compute stream
   int ghost_from_buffer = 1;  // PA_MUL_GHOST_FROM_BUFFER: own x ghost reads consistent!'s receive buffer (the renamed twin)
   int mul_fused = 1;          // PA_MUL_FUSED: mul!(c,a,b) of a part as one launch (pa_fused.hip)
+  int mul_fused_rccl = 1;     // PA_MUL_FUSED_RCCL: also over RCCL (the launch's tail acquires a flag the comm stream raises behind the receives)
   int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
 };
 
 struct pa_ctx {
   pa_switches sw;
+  int64_t n_fused = 0, n_fused_exchange = 0;    // fused product launches so far / of those, with the exchange inside the launch
   bool keep_coo_slots = false;       // pa_coo_keep_input_slots: the assemblies remember where their input triplets went
   int device = 0;
   hipStream_t s[2] = {nullptr, nullptr};  // [0] compute, [1] comm
@@ -207,6 +209,11 @@ struct pa_plan {
   unsigned long long seq[2] = {0, 0};            // exchanges started so far, per mode (the push transport's sequence numbers)
   bool bufs_in_ipc_region = false; // snd.d_buf / rcv.d_buf point into the ipc link's region (freed with it)
   bool ipc_ack_due = false;       // this exchange arrived over the ipc link: pa_exchange_finish acknowledges it to the senders
+  // the fused product over RCCL (pa_fused.hip): a flag word (+ a zero index) the comm stream raises behind the receives and the
+  // launch's tail acquires, its sequence number, and a host-visible status word for the tail's time-out
+  unsigned long long *d_rflag = nullptr;
+  unsigned long long rseq = 0;
+  int *h_rstatus = nullptr;
 };
 
 bool pa_plan_ipc_connected(const pa_plan *p);
@@ -274,11 +281,40 @@ struct pa_graph {
 
 int pa_plan_mark_arrived(pa_plan *p);
 
+// What the fused product launch does FOR THE EXCHANGE besides the product (pa_fused.hip; everything optional):
+struct pa_push_seg;
+struct pa_fused_comm {
+  // its first blocks pack and push this part's send list over the ipc link before they take chunks (pa_push_ipc_block)
+  int n_push_blocks = 0, p_n = 0, p_nseg = 0;
+  const int32_t *p_idx = nullptr;
+  const pa_push_seg *p_segs = nullptr;
+  unsigned long long seq = 0;                       // this exchange's sequence number (what flags are compared with)
+  unsigned *p_done = nullptr;
+  // its tail acquires the arrival of b's ghost values: flags[wait_idx[i]] >= seq for every i, or gives up after `ticks`
+  const unsigned long long *flags = nullptr;
+  const int32_t *wait_idx = nullptr;
+  int n_wait = 0;
+  long long ticks = 0;
+  int *status = nullptr;
+  // its tail unpacks the receive buffer into b's ghost entries (the rest of consistent!, src/p_vector.jl:603-611) ...
+  const int32_t *u_idx = nullptr;
+  int u_n = 0;
+  // ... and its last tail block tells the senders that the buffer is free again
+  unsigned long long *const *ack_dst = nullptr;
+  int n_ack = 0;
+  unsigned *t_done = nullptr;
+  int max_tail_blocks = 0;                          // > 0: at most so many tail blocks (they may spin: never fill the GPU with them)
+};
+
 // pa_fused.hip
 int pa_matrix_fused_build(pa_matrix *m);
 bool pa_matrix_fused_ready(const pa_matrix *m);
 void pa_matrix_fused_release(pa_matrix *m);
-int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, const pa_vec *b, double alpha, double beta, hipStream_t st);
+int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double beta, hipStream_t st, const pa_fused_comm *comm = nullptr);
+int pa_mul_fused_ipc(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double beta);   // pa_push.hip: one part per process, ONE launch
+bool pa_fused_ipc_fits(const pa_matrix *m);
+int pa_mul_fused_rccl(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta);   // pa_fused.hip
+void pa_fused_plan_release(pa_plan *p);
 void pa_csr_before_product(const pa_csr *A);     // pa_device.hip: upkeep a product does first (the value dictionary's renewal)
 // pa_push.hip: consistent!(v) of every part of this process COMPLETE with one launch on the compute stream -- the push kernel also
 // stores every delivered value into the receiving part's ghost entry (the unpack of src/p_vector.jl:603-611)

@@ -29,30 +29,7 @@
 
 #include "pa_internal.h"
 
-#define PA_PUSH_MAX_PARTS 32
-
-struct pa_push_seg {
-  int32_t start, len;                 // entries [start, start + len) of the part's send list ...
-  double *dst;                        // ... go to dst[0 .. len)
-  const int32_t *uidx;                // (one device, consistent!) and on into ghost entry uidx[k] of the receiving part's vector,
-  int32_t upart;                      //     which is vector `upart` of the launch (k_push_unpack); NULL: no unpack table
-  unsigned long long *arrive;         // ipc: the flag in the receiver's memory this slice's arrival is announced in
-  const unsigned long long *ack;      // ipc: the flag in MY memory the receiver acknowledges the previous slice in
-};
-struct pa_push_part {
-  const int32_t *idx;                 // send list (local ids)
-  int32_t n, seg0, nseg, blk0;
-};
-struct pa_push_vecs { const double *v[PA_PUSH_MAX_PARTS]; };
-
-__device__ __forceinline__ int push_find_seg(const pa_push_seg *__restrict__ segs, int s0, int ns, int p) {
-  int lo = s0, hi = s0 + ns - 1;                       // the last segment whose start <= p
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (segs[mid].start <= p) lo = mid; else hi = mid - 1;
-  }
-  return lo;
-}
+#include "pa_push_dev.h"
 
 // (a) all parts of a process: block -> part through block_part
 __global__ __launch_bounds__(256) void k_push_local(const pa_push_part *__restrict__ parts, const pa_push_seg *__restrict__ segs,
@@ -119,57 +96,12 @@ __global__ __launch_bounds__(256) void k_unpack_add_multi(const pa_add_part *__r
   if (g < vecs.n_ghost[pi]) vecs.v[pi][vecs.ghost0[pi] + g] = 0.0;
 }
 
-__device__ __forceinline__ unsigned long long flag_load(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ void flag_store(unsigned long long *p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-// spin until *p >= want; false after `ticks` of the 100 MHz wall clock
-__device__ __forceinline__ bool flag_wait(const unsigned long long *p, unsigned long long want, long long ticks) {
-  if (flag_load(p) >= want) return true;
-  const long long t0 = (long long)wall_clock64();
-  for (;;) {
-    for (int k = 0; k < 64; ++k) {
-      if (flag_load(p) >= want) return true;
-      __builtin_amdgcn_s_sleep(8);
-    }
-    if ((long long)wall_clock64() - t0 > ticks) return false;
-  }
-}
-
 // (b) one part per process
 __global__ __launch_bounds__(256) void k_push_ipc(const int32_t *__restrict__ idx, int n, const pa_push_seg *__restrict__ segs, int nseg,
                                                   const double *__restrict__ v, unsigned long long seq, unsigned *done, long long ticks,
                                                   int *status) {
-  const int p0 = (int)blockIdx.x * 256, p = p0 + (int)threadIdx.x;
   __shared__ int ok;
-  if (threadIdx.x == 0) {
-    // flow control: the receivers of the slices this block writes must have consumed what the previous exchange put there
-    int good = 1;
-    if (seq > 1 && n > 0) {
-      const int sa = push_find_seg(segs, 0, nseg, min(p0, n - 1)), sb = push_find_seg(segs, 0, nseg, min(p0 + 255, n - 1));
-      for (int s = sa; s <= sb && good; ++s) good = flag_wait(segs[s].ack, seq - 1, ticks) ? 1 : 0;
-    }
-    ok = good;
-  }
-  __syncthreads();
-  if (!ok) { if (threadIdx.x == 0) atomicExch(status, 2); return; }
-  if (p < n) {
-    const double val = v[idx[p]];
-    const int s = push_find_seg(segs, 0, nseg, p);
-    segs[s].dst[p - segs[s].start] = val;
-  }
-  __threadfence_system();                              // my stores are in memory before I count myself done
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned t = atomicAdd(done, 1u);
-    if (t == gridDim.x - 1) {                          // the last block of the launch announces every slice
-      *done = 0;
-      __threadfence_system();
-      for (int s = 0; s < nseg; ++s) flag_store(segs[s].arrive, seq);
-    }
-  }
+  (void)pa_push_ipc_block(&ok, idx, n, segs, nseg, v, seq, done, ticks, status, (int)blockIdx.x, (int)gridDim.x);
 }
 
 __global__ void k_wait_flags(const unsigned long long *__restrict__ flags, const int32_t *__restrict__ which, int n, unsigned long long seq,
@@ -550,7 +482,7 @@ struct pa_ipc_link {
   int64_t off_snd = 0, off_rcv = 0, off_flags = 0;
   unsigned long long *d_flags = nullptr;   // [arrive CONSISTENT: NS | arrive ASSEMBLE: NR | ack CONSISTENT: NR | ack ASSEMBLE: NS]
   int64_t n_flags = 0;
-  unsigned *d_done = nullptr;              // the push kernel's block counter
+  unsigned *d_done = nullptr;              // [0] the push kernel's block counter, [1] the fused launch's tail-block counter
   int *h_status = nullptr;                 // host-pinned, device-visible: 0 ok, 1 an arrival wait timed out, 2 an acknowledgement wait did
   struct peer { void *region = nullptr, *snd = nullptr, *rcv = nullptr, *flags = nullptr; };
   std::map<int, peer> peers;               // part -> its mapped buffers
@@ -576,7 +508,7 @@ static int ipc_flags_layout(const pa_plan *p, int64_t *aC, int64_t *aA, int64_t 
 // ONCE and keeps it mapped: a plan per PVector cache means hundreds of short-lived regions in a solver, and exporting / importing /
 // closing / freeing each of them made hipIpcGetMemHandle fail with "invalid argument" after a few dozen (an address handed out
 // again while a peer still held the old mapping).  A freed region goes to a free list of its size and is zeroed when taken again.
-struct ipc_chunk { char *base = nullptr; size_t size = 0, used = 0; hipIpcMemHandle_t handle; int device = 0; };
+struct ipc_chunk { char *base = nullptr; size_t size = 0, used = 0; hipIpcMemHandle_t handle; int device = 0; bool finegrained = false; };
 static std::mutex g_ipc_mu;
 static std::vector<ipc_chunk> g_ipc_chunks;
 static std::multimap<size_t, std::pair<int, size_t>> g_ipc_free;        // bytes -> (chunk, offset)
@@ -594,8 +526,24 @@ static int ipc_region_take(int device, size_t bytes, int *chunk, size_t *off) {
   ipc_chunk C;
   C.device = device;
   C.size = std::max<size_t>((size_t)32 << 20, bytes);
-  PA_HIP(hipMalloc((void **)&C.base, C.size));
-  PA_HIP(hipIpcGetMemHandle(&C.handle, C.base));
+  // Fine-grained device memory where the runtime gives it (what RCCL takes for its own buffers): stores that come over xGMI from a
+  // peer GPU are then visible to a kernel that is ALREADY RUNNING here and acquires at system scope -- the fused product launch
+  // polls its arrival flags and reads the receive buffer without a kernel boundary in between (pa_fused.hip).  Coarse-grained
+  // memory only promises that at kernel boundaries.  PA_IPC_FINEGRAINED=0, or a runtime that refuses: plain hipMalloc.
+  const char *fg = getenv("PA_IPC_FINEGRAINED");
+  C.base = nullptr;
+  if (!(fg && atoi(fg) == 0)) {
+    if (hipExtMallocWithFlags((void **)&C.base, C.size, hipDeviceMallocFinegrained) != hipSuccess ||
+        hipIpcGetMemHandle(&C.handle, C.base) != hipSuccess) {
+      (void)hipGetLastError();
+      if (C.base) (void)hipFree(C.base);
+      C.base = nullptr;
+    } else C.finegrained = true;
+  }
+  if (!C.base) {
+    PA_HIP(hipMalloc((void **)&C.base, C.size));
+    PA_HIP(hipIpcGetMemHandle(&C.handle, C.base));
+  }
   C.used = bytes;
   g_ipc_chunks.push_back(C);
   *chunk = (int)g_ipc_chunks.size() - 1; *off = 0;
@@ -641,8 +589,8 @@ static int ipc_prepare(pa_plan *p) {
   L->region_bytes = ((size_t)L->off_flags + up(sizeof(unsigned long long) * L->n_flags) + 4095) / 4096 * 4096;
   if (int st = ipc_region_take(p->ctx->device, L->region_bytes, &L->chunk, &L->chunk_off)) { L->chunk = -1; return fail(st); }
   { std::lock_guard<std::mutex> lk(g_ipc_mu); L->d_region = g_ipc_chunks[L->chunk].base + L->chunk_off; }
-  if (hipMemset(L->d_region, 0, L->region_bytes) != hipSuccess || hipMalloc((void **)&L->d_done, sizeof(unsigned)) != hipSuccess ||
-      hipMemset(L->d_done, 0, sizeof(unsigned)) != hipSuccess ||
+  if (hipMemset(L->d_region, 0, L->region_bytes) != hipSuccess || hipMalloc((void **)&L->d_done, 2 * sizeof(unsigned)) != hipSuccess ||
+      hipMemset(L->d_done, 0, 2 * sizeof(unsigned)) != hipSuccess ||
       hipHostMalloc((void **)&L->h_status, sizeof(int), hipHostMallocMapped) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
     pa_set_err("ipc link: device memory for the region's bookkeeping could not be set up");
     return fail(PA_ERR_HIP);
@@ -838,6 +786,42 @@ extern "C" int pa_exchange_push_ipc(pa_plan *p, const pa_vec *v, int mode) {
   p->ipc_ack_due = M.n_ack > 0;
   p->ev_wait = nullptr;
   return pa_plan_mark_arrived(p);
+}
+
+// mul!(c,a,b) of this process's part as ONE launch on the compute stream: its first blocks push b's own values into the neighbours'
+// receive buffers, its tail acquires the neighbours' arrival flags, sums the boundary rows from the receive buffer, unpacks b's
+// ghost entries and acknowledges (pa_fused.hip).  The plan is idle again when this returns: consistent!(b) is part of the launch.
+int pa_mul_fused_ipc(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double beta) {
+  pa_plan *p = m->plan;
+  PA_REQUIRE(p->ipc && p->ipc->connected, "the plan has no ipc link (pa_plan_ipc_connect)");
+  PA_REQUIRE(b->n_own + b->n_ghost == p->n_local, "vector has %lld local values, plan expects %lld", (long long)(b->n_own + b->n_ghost),
+             (long long)p->n_local);
+  PA_REQUIRE(p->phase == 0, "exchange already in flight on this plan (missing pa_exchange_finish)");
+  pa_ipc_link *L = p->ipc;
+  const int st = *(volatile int *)L->h_status;
+  if (st != 0) { pa_set_err("the ipc link of part %d timed out earlier (%s wait): a neighbour is gone or out of step", p->part, st == 1 ? "arrival" : "acknowledgement"); return PA_ERR_STATE; }
+  pa_ctx *cx = p->ctx;
+  PA_REQUIRE(!cx->capturing, "the ipc transport carries a sequence number per exchange: not inside a graph capture");
+  pa_ipc_link::per_mode &M = L->m[PA_CONSISTENT];
+  PA_HIP(hipSetDevice(cx->device));
+  pa_plan::side &o = p->rcv, &in = p->snd;             // consistent!: the cache reversed (src/p_vector.jl:747-755)
+  pa_fused_comm X;
+  X.seq = ++p->seq[PA_CONSISTENT];
+  if (M.nseg && o.n) {
+    X.n_push_blocks = (int)((o.n + 255) / 256);
+    X.p_idx = o.d_idx; X.p_n = (int)o.n; X.p_segs = M.d_segs; X.p_nseg = M.nseg; X.p_done = L->d_done;
+  }
+  X.flags = L->d_flags; X.wait_idx = M.d_wait; X.n_wait = M.n_wait; X.ticks = L->ticks; X.status = L->h_status;
+  X.u_idx = in.d_idx; X.u_n = (int)in.n;
+  X.ack_dst = M.d_ack_dst; X.n_ack = M.n_ack; X.t_done = L->d_done + 1;
+  X.max_tail_blocks = 256;
+  p->mode = PA_CONSISTENT;
+  return pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], &X);
+}
+
+bool pa_fused_ipc_fits(const pa_matrix *m) {
+  const pa_plan *p = m->plan;
+  return (int64_t)((p->rcv.n + 255) / 256) <= (int64_t)((m->oo->n_chunks + 7) / 8) * 8;
 }
 
 // compute stream, behind the unpack (and whatever read the receive buffer): the senders may overwrite it now

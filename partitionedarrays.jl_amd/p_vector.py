@@ -41,6 +41,12 @@ class Context:
     def sync(self):
         L.call("pa_ctx_sync", self.h)
 
+    def fused_launches(self):
+        """(products run as one launch so far, of those with the exchange inside the launch) -- pa_ctx_fused_launches."""
+        a, b = C.c_int64(), C.c_int64()
+        L.call("pa_ctx_fused_launches", self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def reload_env(self):
         """Read the PA_* switches of the product path from the environment again (pa_ctx_reload_env; they are read once, at creation)."""
         L.call("pa_ctx_reload_env", self.h)

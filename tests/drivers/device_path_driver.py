@@ -52,6 +52,7 @@ def body(distribute):
         # in a row (the push transport's flow control: every buffer is reused 12 times)
         x2 = pa.pvector_from_function(lambda ind: xo[ind.part - 1] * (ind.get_local_to_owner() == ind.part), A.col_partition)
         y2 = pa.pzeros(A.row_partition)
+        fused_before = pa.context().fused_launches()[1]
         for _ in range(12):
             pa.mul_c_(y2, A, x2)
         assert np.array_equal(pa.getany(y2.own_values()), yo[k][:Ao.rows[k].n_own]), "mul_c_ differs from the oracle"
@@ -60,6 +61,10 @@ def body(distribute):
         y5 = [v.copy() for v in yo]
         orc.mul5(y5, Ao, [v.copy() for v in xo], -0.5, 2.0)
         assert np.array_equal(pa.getany(y2.own_values()), y5[k][:Ao.rows[k].n_own]), "mul_c_(alpha,beta) differs from the oracle"
+        if os.environ["PA_TRANSPORT"] == "ipc" and os.environ.get("PA_MUL_FUSED", "1") != "0" and P > 1:
+            # round 5: over the ipc link mul! is ONE launch per part -- push, both products, unpack and acknowledgement inside it
+            inside = pa.context().fused_launches()[1] - fused_before
+            assert inside == 13, f"{inside} of 13 products ran as one launch with the exchange inside"
         # mul!(c,transpose(a),b,alpha,beta): assemble!(c) under A_oo'*b
         bt = [orc.hash_x(r.local_to_global + 1) for r in Ao.rows]
         ct = [orc.hash_x(c.local_to_global + 9) for c in Ao.cols]

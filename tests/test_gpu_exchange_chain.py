@@ -219,6 +219,7 @@ def test_pa_mul5_over_a_one_rank_rccl_communicator():
     m = C.c_void_p()
     L.call("pa_matrix_create", ctx.h, oo.h, oh.h, plan, C.byref(m))
     b, c = pa.DeviceVector(n, g), pa.DeviceVector(n, 0)
+    inside0 = ctx.fused_launches()[1]
     for rep in range(5):
         xo = rng.integers(-3, 4, n).astype(float) + rep
         b.upload(np.concatenate([xo, [99.0, 98.0, 97.0]]))            # stale ghosts: the exchange must replace them
@@ -229,6 +230,9 @@ def test_pa_mul5_over_a_one_rank_rccl_communicator():
     yes = C.c_int()
     L.call("pa_matrix_ghost_from_buffer", m, C.byref(yes))
     assert yes.value == 1
+    # round 5: each of those products was ONE launch on the compute stream beside the RCCL group -- its tail acquired the flag the
+    # comm stream raises behind the receives, summed the boundary rows from the receive buffer and unpacked b's ghosts
+    assert ctx.fused_launches()[1] - inside0 == 5
     c0 = c.download()
     L.call("pa_mul5", m, comm, c.h, b.h, 2.0, -1.0)
     assert c.download().tolist() == (-c0 + 2.0 * (oo_dense @ xo + oh_dense @ ghosts)).tolist()
