@@ -207,7 +207,12 @@ struct pa_fused_args {
   const double *rbuf;                              // consistent!'s receive buffer (buffer_rcv of the reversed cache)
   int n_split, b_max_col;
   double *bvec;                                    // b's local values (the tail's unpack)
-  pa_fused_comm X;
+  // the exchange inside the launch (XCH): what to do sits in DEVICE memory (static per link; read by the blocks that need it, when
+  // they need it -- as kernel arguments its fifteen words stayed in scalar registers for the whole kernel: 84 SGPRs, and from 81 on
+  // the hardware admits 7 workgroups of 256 per CU instead of 8), this exchange's sequence number and the pushing blocks by value
+  const pa_fused_comm *X;
+  unsigned long long seq;
+  int n_push_blocks;
 };
 
 // One part per process: the exchange lives INSIDE the launch.
@@ -219,7 +224,7 @@ struct pa_fused_args {
 // The tail blocks are the LAST blocks of the grid: by the time one is dispatched every own x own block is running or done, so a
 // spinning tail block never holds a slot an own x own block of THIS launch is waiting for; they are at most X.max_tail_blocks, so
 // they cannot fill a GPU that another process's launch (its pushing blocks!) has to get onto -- ranks sharing one GPU in the tests.
-template <bool C16, int PAT, bool VD>
+template <bool C16, int PAT, bool VD, bool XCH>
 __global__ __launch_bounds__(256) void k_mul_fused(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta, const double *__restrict__ val,
@@ -233,15 +238,21 @@ __global__ __launch_bounds__(256) void k_mul_fused(
   const int b = blockIdx.x;
   if (b >= F.n_main_blocks) {
     const int tb = b - F.n_main_blocks;
-    if (F.X.n_wait > 0) {
-      if (threadIdx.x == 0) ok = 1;
-      __syncthreads();
-      for (int i = threadIdx.x; i < F.X.n_wait; i += BLK)
-        if (!flag_wait(F.X.flags + F.X.wait_idx[i], F.X.seq, F.X.ticks)) { atomicExch(F.X.status, 1); ok = 0; }
-      __syncthreads();
-      if (!ok) return;                                       // (a neighbour is gone or out of step: the status word says so)
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");         // what the neighbours stored in front of their flags is visible now
-      __syncthreads();
+    if (XCH) {
+      const int n_wait = F.X->n_wait;
+      if (n_wait > 0) {
+        const unsigned long long *flags = F.X->flags;
+        const int32_t *wait_idx = F.X->wait_idx;
+        const long long ticks = F.X->ticks;
+        if (threadIdx.x == 0) ok = 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_wait; i += BLK)
+          if (!flag_wait(flags + wait_idx[i], F.seq, ticks)) { atomicExch(F.X->status, 1); ok = 0; }
+        __syncthreads();
+        if (!ok) return;                                     // (a neighbour is gone or out of step: the status word says so)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");       // what the neighbours stored in front of their flags is visible now
+        __syncthreads();
+      }
     }
     pa_fx fx;
     fx.x2 = F.rbuf; fx.n_split = F.n_split;
@@ -251,23 +262,31 @@ __global__ __launch_bounds__(256) void k_mul_fused(
           nullptr, nullptr, nullptr, nullptr, F.b_max_col, t, fx);
       __syncthreads();                                       // (the next chunk's products go where this one's row sums read)
     }
-    for (int k = tb * BLK + (int)threadIdx.x; k < F.X.u_n; k += F.n_tail_blocks * BLK) F.bvec[F.X.u_idx[k]] = F.rbuf[k];
-    if (F.X.n_ack > 0) {
-      __syncthreads();                                       // every lane of this block has read what it needs of the buffer
-      if (threadIdx.x == 0) {
-        const unsigned done = atomicAdd(F.X.t_done, 1u);
-        if (done == (unsigned)F.n_tail_blocks - 1) {         // the last tail block: the senders may overwrite the buffer
-          *F.X.t_done = 0;
-          __threadfence_system();
-          for (int i = 0; i < F.X.n_ack; ++i) flag_store(F.X.ack_dst[i], F.X.seq);
+    if (XCH) {
+      const int u_n = F.X->u_n;
+      const int32_t *u_idx = F.X->u_idx;
+      for (int k = tb * BLK + (int)threadIdx.x; k < u_n; k += F.n_tail_blocks * BLK) F.bvec[u_idx[k]] = F.rbuf[k];
+      const int n_ack = F.X->n_ack;
+      if (n_ack > 0) {
+        __syncthreads();                                     // every lane of this block has read what it needs of the buffer
+        if (threadIdx.x == 0) {
+          unsigned *t_done = F.X->t_done;
+          const unsigned done = atomicAdd(t_done, 1u);
+          if (done == (unsigned)F.n_tail_blocks - 1) {       // the last tail block: the senders may overwrite the buffer
+            *t_done = 0;
+            __threadfence_system();
+            unsigned long long *const *ack_dst = F.X->ack_dst;
+            for (int i = 0; i < n_ack; ++i) flag_store(ack_dst[i], F.seq);
+          }
         }
       }
     }
     return;
   }
-  if (b < F.X.n_push_blocks)
-    (void)pa_push_ipc_block(&ok, F.X.p_idx, F.X.p_n, F.X.p_segs, F.X.p_nseg, x, F.X.seq, F.X.p_done, F.X.ticks, F.X.status, b,
-                            F.X.n_push_blocks);
+  if (XCH && b < F.n_push_blocks) {
+    const pa_fused_comm X = *F.X;
+    (void)pa_push_ipc_block(&ok, X.p_idx, X.p_n, X.p_segs, X.p_nseg, x, F.seq, X.p_done, X.ticks, X.status, b, F.n_push_blocks);
+  }
   const bool backwards = chunks_per_xcd < 0;
   if (backwards) chunks_per_xcd = -chunks_per_xcd;
   int chunk = (b & 7) * chunks_per_xcd + (b >> 3);           // XCD-aware, as k_spmv_rowsplit
@@ -283,7 +302,8 @@ __global__ __launch_bounds__(256) void k_mul_fused(
 // own(c) = beta*own(c) + alpha*(A_oo*own(b) + A_oh*ghost(b)) of one part in one launch on stream st.  comm == NULL: the receive
 // buffer of consistent!(b) holds b's ghost values by stream order (the push launch is in front, pa_mul_all); else the exchange
 // happens inside the launch as *comm says.
-int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double beta, hipStream_t st, const pa_fused_comm *comm) {
+int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double beta, hipStream_t st, const pa_fused_comm *comm,
+                        unsigned long long seq, int n_push_blocks, int max_tail_blocks) {
   const pa_csr *S = m->oo, *B = m->bd;
   pa_plan *p = m->plan;
   pa_fused_args F;
@@ -294,33 +314,32 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double
   F.rbuf = p->snd.d_buf;
   F.n_split = (int)S->n_cols; F.b_max_col = (int)B->n_cols - 1;
   F.bvec = b->d;
-  if (comm) F.X = *comm;
+  F.X = comm; F.seq = seq; F.n_push_blocks = n_push_blocks;
   F.n_tail_chunks = (int)B->n_chunks;
-  F.n_tail_blocks = F.X.max_tail_blocks > 0 ? std::min(F.n_tail_chunks, F.X.max_tail_blocks) : F.n_tail_chunks;
-  PA_REQUIRE(F.X.n_push_blocks <= F.n_main_blocks, "more pushing blocks than own x own has chunks");
+  F.n_tail_blocks = max_tail_blocks > 0 ? std::min(F.n_tail_chunks, max_tail_blocks) : F.n_tail_chunks;
+  PA_REQUIRE(n_push_blocks <= F.n_main_blocks, "more pushing blocks than own x own has chunks");
   const int n_tail = F.n_tail_blocks;
   if (m->ctx->sw.spmv_alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) cpx = -cpx;
 #define PA_LAUNCH_FUSED(C16, PAT, VD)                                                                                           \
-  hipLaunchKernelGGL((k_mul_fused<C16, PAT, VD>), dim3(F.n_main_blocks + n_tail), dim3(256), 0, st, S->d_crp, S->d_col, S->d_col16, \
+  hipLaunchKernelGGL((k_mul_fused<C16, PAT, VD, XCH>), dim3(F.n_main_blocks + n_tail), dim3(256), 0, st, S->d_crp, S->d_col, S->d_col16, \
                      S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, (const double *)b->d, c->d, S->d_chunk_rp, (int)S->n_chunks, cpx,   \
                      alpha, beta, S->d_code, S->d_dict, (int)S->n_cols - 1, F)
-  const int sel = (S->use_pattern ? 2 : 0) + (S->use_c16 ? 1 : 0);
-  if (S->use_vdict) {
-    if (m->ctx->capturing) const_cast<pa_csr *>(S)->vd_captured = true;
-    switch (sel) {
-      case 3: PA_LAUNCH_FUSED(true, 1, true); break;
-      case 2: PA_LAUNCH_FUSED(false, 1, true); break;
-      case 1: PA_LAUNCH_FUSED(true, 0, true); break;
-      default: PA_LAUNCH_FUSED(false, 0, true); break;
-    }
-  } else {
-    switch (sel) {
-      case 3: PA_LAUNCH_FUSED(true, 1, false); break;
-      case 2: PA_LAUNCH_FUSED(false, 1, false); break;
-      case 1: PA_LAUNCH_FUSED(true, 0, false); break;
-      default: PA_LAUNCH_FUSED(false, 0, false); break;
-    }
-  }
+  const int sel = (S->use_pattern ? 4 : 0) + (S->use_c16 ? 2 : 0) + (S->use_vdict ? 1 : 0);
+  if (S->use_vdict && m->ctx->capturing) const_cast<pa_csr *>(S)->vd_captured = true;
+#define PA_FUSED_CASES(XCH_)                                \
+  { constexpr bool XCH = XCH_;                              \
+    switch (sel) {                                          \
+      case 7: PA_LAUNCH_FUSED(true, 1, true); break;        \
+      case 6: PA_LAUNCH_FUSED(true, 1, false); break;       \
+      case 5: PA_LAUNCH_FUSED(false, 1, true); break;       \
+      case 4: PA_LAUNCH_FUSED(false, 1, false); break;      \
+      case 3: PA_LAUNCH_FUSED(true, 0, true); break;        \
+      case 2: PA_LAUNCH_FUSED(true, 0, false); break;       \
+      case 1: PA_LAUNCH_FUSED(false, 0, true); break;       \
+      default: PA_LAUNCH_FUSED(false, 0, false); break;     \
+    } }
+  if (comm) PA_FUSED_CASES(true) else PA_FUSED_CASES(false)
+#undef PA_FUSED_CASES
 #undef PA_LAUNCH_FUSED
   PA_HIP(hipGetLastError());
   m->ctx->n_fused++;
@@ -346,10 +365,19 @@ int pa_mul_fused_rccl(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double 
   pa_ctx *cx = p->ctx;
   PA_HIP(hipSetDevice(cx->device));
   if (!p->d_rflag) {
-    PA_HIP(hipMalloc((void **)&p->d_rflag, 16));
-    PA_HIP(hipMemset(p->d_rflag, 0, 16));              // [0] the flag, [1] (as Int32) the index 0 of the tail's one-entry wait list
+    // [0] the flag, [1] (as Int32) the index 0 of the tail's one-entry wait list, [2..] what the launch's tail does (pa_fused_comm)
+    PA_HIP(hipMalloc((void **)&p->d_rflag, 16 + sizeof(pa_fused_comm)));
+    PA_HIP(hipMemset(p->d_rflag, 0, 16 + sizeof(pa_fused_comm)));
     PA_HIP(hipHostMalloc((void **)&p->h_rstatus, sizeof(int), hipHostMallocMapped));
     *p->h_rstatus = 0;
+    pa_fused_comm X;
+    X.flags = p->d_rflag; X.wait_idx = (const int32_t *)(p->d_rflag + 1); X.n_wait = 1;
+    double secs = 30.0;
+    if (const char *e = getenv("PA_IPC_TIMEOUT_S")) secs = std::max(0.001, atof(e));
+    X.ticks = (long long)(secs * 1e8);
+    X.status = p->h_rstatus;
+    X.u_idx = p->snd.d_idx; X.u_n = (int)p->snd.n;
+    PA_HIP(pa_h2d(p->d_rflag + 2, &X, sizeof X));
     PA_HIP(hipDeviceSynchronize());
   }
   if (*(volatile int *)p->h_rstatus != 0) {
@@ -358,18 +386,10 @@ int pa_mul_fused_rccl(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double 
   }
   PA_TRY(pa_exchange_pack(p, b, PA_CONSISTENT));
   PA_TRY(pa_exchange_rccl(p, comm, PA_CONSISTENT));
-  pa_fused_comm X;
-  X.seq = ++p->rseq;
-  hipLaunchKernelGGL(kf_raise, dim3(1), dim3(1), 0, cx->s[1], p->d_rflag, X.seq);
+  const unsigned long long seq = ++p->rseq;
+  hipLaunchKernelGGL(kf_raise, dim3(1), dim3(1), 0, cx->s[1], p->d_rflag, seq);
   PA_HIP(hipGetLastError());
-  X.flags = p->d_rflag; X.wait_idx = (const int32_t *)(p->d_rflag + 1); X.n_wait = 1;
-  double secs = 30.0;
-  if (const char *e = getenv("PA_IPC_TIMEOUT_S")) secs = std::max(0.001, atof(e));
-  X.ticks = (long long)(secs * 1e8);
-  X.status = p->h_rstatus;
-  X.u_idx = p->snd.d_idx; X.u_n = (int)p->snd.n;
-  X.max_tail_blocks = 256;
-  PA_TRY(pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], &X));
+  PA_TRY(pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], (const pa_fused_comm *)(p->d_rflag + 2), seq, 0, 256));
   // the exchange is complete with the launch (wait(t) and the unpack are its tail); the next pack orders itself behind the compute
   // stream (pa_exchange_pack records ev_compute), so nothing overwrites the buffers this launch still reads
   p->phase = 0; p->own_comm_stream = false; p->ev_wait = nullptr;

@@ -285,10 +285,9 @@ int pa_plan_mark_arrived(pa_plan *p);
 struct pa_push_seg;
 struct pa_fused_comm {
   // its first blocks pack and push this part's send list over the ipc link before they take chunks (pa_push_ipc_block)
-  int n_push_blocks = 0, p_n = 0, p_nseg = 0;
+  int p_n = 0, p_nseg = 0;
   const int32_t *p_idx = nullptr;
   const pa_push_seg *p_segs = nullptr;
-  unsigned long long seq = 0;                       // this exchange's sequence number (what flags are compared with)
   unsigned *p_done = nullptr;
   // its tail acquires the arrival of b's ghost values: flags[wait_idx[i]] >= seq for every i, or gives up after `ticks`
   const unsigned long long *flags = nullptr;
@@ -303,14 +302,16 @@ struct pa_fused_comm {
   unsigned long long *const *ack_dst = nullptr;
   int n_ack = 0;
   unsigned *t_done = nullptr;
-  int max_tail_blocks = 0;                          // > 0: at most so many tail blocks (they may spin: never fill the GPU with them)
 };
 
 // pa_fused.hip
 int pa_matrix_fused_build(pa_matrix *m);
 bool pa_matrix_fused_ready(const pa_matrix *m);
 void pa_matrix_fused_release(pa_matrix *m);
-int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double beta, hipStream_t st, const pa_fused_comm *comm = nullptr);
+// comm: DEVICE copy of what the launch does for the exchange (or NULL), seq: this exchange's sequence number, n_push_blocks: its
+// first blocks push, max_tail_blocks > 0: at most so many tail blocks (they may spin: never fill the GPU with them)
+int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double beta, hipStream_t st, const pa_fused_comm *comm = nullptr,
+                        unsigned long long seq = 0, int n_push_blocks = 0, int max_tail_blocks = 0);
 int pa_mul_fused_ipc(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double beta);   // pa_push.hip: one part per process, ONE launch
 bool pa_fused_ipc_fits(const pa_matrix *m);
 int pa_mul_fused_rccl(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta);   // pa_fused.hip

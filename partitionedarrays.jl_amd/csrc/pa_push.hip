@@ -496,6 +496,7 @@ struct pa_ipc_link {
   } m[2];
   long long ticks = 0;
   bool connected = false;
+  pa_fused_comm *d_xcomm = nullptr;         // device copy of what the fused product launch does for consistent! over this link
 };
 
 static int ipc_flags_layout(const pa_plan *p, int64_t *aC, int64_t *aA, int64_t *kC, int64_t *kA) {
@@ -805,18 +806,20 @@ int pa_mul_fused_ipc(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double be
   pa_ipc_link::per_mode &M = L->m[PA_CONSISTENT];
   PA_HIP(hipSetDevice(cx->device));
   pa_plan::side &o = p->rcv, &in = p->snd;             // consistent!: the cache reversed (src/p_vector.jl:747-755)
-  pa_fused_comm X;
-  X.seq = ++p->seq[PA_CONSISTENT];
-  if (M.nseg && o.n) {
-    X.n_push_blocks = (int)((o.n + 255) / 256);
-    X.p_idx = o.d_idx; X.p_n = (int)o.n; X.p_segs = M.d_segs; X.p_nseg = M.nseg; X.p_done = L->d_done;
+  int n_push_blocks = 0;
+  if (M.nseg && o.n) n_push_blocks = (int)((o.n + 255) / 256);
+  if (!L->d_xcomm) {                                   // what the launch does for the exchange: static per link, kept in device memory
+    pa_fused_comm X;
+    if (n_push_blocks) { X.p_idx = o.d_idx; X.p_n = (int)o.n; X.p_segs = M.d_segs; X.p_nseg = M.nseg; X.p_done = L->d_done; }
+    X.flags = L->d_flags; X.wait_idx = M.d_wait; X.n_wait = M.n_wait; X.ticks = L->ticks; X.status = L->h_status;
+    X.u_idx = in.d_idx; X.u_n = (int)in.n;
+    X.ack_dst = M.d_ack_dst; X.n_ack = M.n_ack; X.t_done = L->d_done + 1;
+    PA_HIP(pa_raw_malloc(&L->d_xcomm, sizeof X));
+    PA_HIP(pa_h2d(L->d_xcomm, &X, sizeof X));
   }
-  X.flags = L->d_flags; X.wait_idx = M.d_wait; X.n_wait = M.n_wait; X.ticks = L->ticks; X.status = L->h_status;
-  X.u_idx = in.d_idx; X.u_n = (int)in.n;
-  X.ack_dst = M.d_ack_dst; X.n_ack = M.n_ack; X.t_done = L->d_done + 1;
-  X.max_tail_blocks = 256;
+  const unsigned long long seq = ++p->seq[PA_CONSISTENT];
   p->mode = PA_CONSISTENT;
-  return pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], &X);
+  return pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], L->d_xcomm, seq, n_push_blocks, 256);
 }
 
 bool pa_fused_ipc_fits(const pa_matrix *m) {
@@ -847,6 +850,7 @@ void pa_push_release(pa_plan *p) {
     if (L->chunk >= 0) ipc_region_give_back(L->chunk, L->chunk_off, L->region_bytes);   // (the plan's two buffers live in it)
     if (L->d_done) (void)hipFree(L->d_done);
     if (L->h_status) (void)hipHostFree(L->h_status);
+    if (L->d_xcomm) (void)pa_raw_free(L->d_xcomm);
     delete L;
     p->ipc = nullptr;
   }
