@@ -802,6 +802,14 @@ def general_csr_entries(pa, ctx, L, host_oo, xv, y_head, n_own, out):
 
 def main():
     args = parse()
+    # ranks sharing a GPU (the test mode: never a production run): the fused launch's tail blocks may spin on their neighbours'
+    # arrival flags, and eight ranks' worth of spinners must not fill the one GPU the neighbours' pushing blocks have to get onto
+    try:
+        import torch as _t
+        if int(os.environ.get("WORLD_SIZE", "1")) > max(1, _t.cuda.device_count()):
+            os.environ.setdefault("PA_FUSED_TAIL_BLOCKS", "32")
+    except Exception:                                           # noqa: BLE001
+        pass
     N = args.gpus
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -1233,13 +1241,54 @@ def main():
                                  len(cache.get("neighbors_snd", ())), len(cache.get("neighbors_rcv", ())), n_ghost, ar["gib"], ar["used_gib"],
                                  local_ms_headline if overlap_on else local_ms_other, local_ms_other if overlap_on else local_ms_headline,
                                  kern_ms_events], dtype=torch.float64)
-            rows = [torch.zeros_like(mine) for _ in range(N)]
-            dist.all_gather(rows, mine)
+            # (through the rendezvous store, not a collective: a rank that hangs or died costs ITS row, not the section -- rank 0
+            # waits twenty seconds per row and marks the ones that never came)
+            rows = []
+            try:
+                import datetime
+                store = dist.distributed_c10d._get_default_store()
+                store.set(f"pa_bench_row_{rank}", json.dumps(mine.tolist()))
+                if rank == 0:
+                    for r_ in range(N):
+                        try:
+                            store.wait([f"pa_bench_row_{r_}"], datetime.timedelta(seconds=20))
+                            rows.append(torch.tensor(json.loads(store.get(f"pa_bench_row_{r_}")), dtype=torch.float64))
+                        except Exception:                      # noqa: BLE001
+                            miss = torch.full_like(mine, float("nan")); miss[0] = r_
+                            rows.append(miss)
+            except Exception as e:                             # noqa: BLE001  (no store: the collective, as before)
+                print(f"[bench rank {rank}] per-rank rows over the store failed ({e}): all_gather", file=sys.stderr, flush=True)
+                rows = [torch.zeros_like(mine) for _ in range(N)]
+                dist.all_gather(rows, mine)
             if rank == 0:
                 keys = ("rank", "cuda_device", "rccl_ranks_seen", "neighbors_snd", "neighbors_rcv", "ghosts", "arena_held_gib", "arena_used_gib",
                         "ms_per_step_overlap_on", "ms_per_step_overlap_off", "own_own_launch_ms")
-                LINE[0]["per_rank"] = [{k: (int(v) if k in keys[:6] else round(float(v), 4)) for k, v in zip(keys, r.tolist())} for r in rows]
+                LINE[0]["per_rank"] = [({"rank": int(r[0]), "missing": True} if bool(torch.isnan(r[1])) else
+                                        {k: (int(v) if k in keys[:6] else round(float(v), 4)) for k, v in zip(keys, r.tolist())}) for r in rows]
                 LINE[0]["per_rank_transport"] = transport
+        # round 5: mul! of a part is ONE launch (csrc/pa_fused.hip) -- the same timed loop with PA_MUL_FUSED=0 (round 4's launches:
+        # push / pack + RCCL, own x own, own x ghost, unpack) beside it, on the headline transport
+        with optional_section("one launch per part vs separate launches", 120, N, rank):
+            n_fused0 = ctx.fused_launches()
+            for _ in range(5):
+                step(overlap_on)
+            n_fused1 = ctx.fused_launches()
+            os.environ["PA_MUL_FUSED"] = "0"
+            ctx.reload_env()
+            try:
+                for _ in range(10):
+                    step(overlap_on)
+                t_sep, _, _ = timed(args.steps, overlap_on)
+            finally:
+                os.environ.pop("PA_MUL_FUSED", None)
+                ctx.reload_env()
+            if rank == 0:
+                LINE[0]["fused_ab"] = {"mul_as_one_launch_rank0": bool(n_fused1[0] - n_fused0[0] == 5),
+                                       "exchange_inside_the_launch_rank0": bool(n_fused1[1] - n_fused0[1] == 5),
+                                       "ms_per_step_one_launch": round(ms_per_step, 4),
+                                       "ms_per_step_separate_launches": round(t_sep / args.steps * 1e3, 4),
+                                       "what": "`value` is measured with the library's default (one launch per part where the handle allows: "
+                                               "see csrc/pa_fused.hip); PA_MUL_FUSED=0 timed by the same loop right behind it"}
 
     # ---- optional mode, reported beside the headline and never part of `value`: the same product with the lossless value
     # dictionary (PA_SPMV_VALUE_DICT=1: one byte per stored entry instead of eight when a block has <= 64 distinct values)
@@ -1424,6 +1473,12 @@ def main():
             finally:
                 pv.TRANSPORT = was
             if rank == 0:
+                ms_ipc_ = t_ipc / args.steps * 1e3
+                LINE[0]["config"]["transport_chosen"] = {
+                    "headline": transport, "faster_on_this_run": ("ipc" if (ok_ipc and ms_ipc_ < ms_per_step) else transport),
+                    "ms_per_step": {transport: round(ms_per_step, 4), "ipc": round(ms_ipc_, 4)}, "rccl_ranks_seen": rccl_ranks_seen,
+                    "rule": "`value` is ALWAYS the headline transport's (RCCL on a multi-GPU node, as north_star names it); the ipc push is "
+                            "timed by the same loop behind it and named here when it is the faster one -- PA_TRANSPORT=ipc selects it"}
                 LINE[0]["transport_ab"] = {"headline_transport": transport, "ms_per_step_headline": round(ms_per_step, 4),
                                            "ms_per_step_ipc_push": round(t_ipc / args.steps * 1e3, 4), "parity_gate_over_ipc_push": bool(ok_ipc),
                                            "gflops_ipc_push": round(flops_total / (t_ipc / args.steps) / 1e9, 2),

@@ -222,8 +222,11 @@ struct pa_fused_args {
 //                  the block gives up), ONE system-scope acquire, then the boundary rows from the receive buffer, the unpack of
 //                  b's ghost entries, and -- the last tail block to finish -- the acknowledgement to the senders.
 // The tail blocks are the LAST blocks of the grid: by the time one is dispatched every own x own block is running or done, so a
-// spinning tail block never holds a slot an own x own block of THIS launch is waiting for; they are at most X.max_tail_blocks, so
-// they cannot fill a GPU that another process's launch (its pushing blocks!) has to get onto -- ranks sharing one GPU in the tests.
+// spinning tail block never holds a slot an own x own block of THIS launch is waiting for.  They are at most PA_FUSED_TAIL_BLOCKS
+// (default 1024, half the GPU's 2048 resident workgroups): the other half stays free for what may have to run for the arrival to
+// happen at all -- RCCL's receive kernels on the comm stream; with SEVERAL RANKS ON ONE GPU (the tests, never a production run) the
+// other ranks' launches with their pushing blocks, which is why those runs set it to a few dozen.  A neighbour that is ahead or in
+// step costs no spinning at all: the tail is dispatched ~a product's duration after the launch began, its flags are long raised.
 template <bool C16, int PAT, bool VD, bool XCH>
 __global__ __launch_bounds__(256) void k_mul_fused(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
@@ -389,7 +392,7 @@ int pa_mul_fused_rccl(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double 
   const unsigned long long seq = ++p->rseq;
   hipLaunchKernelGGL(kf_raise, dim3(1), dim3(1), 0, cx->s[1], p->d_rflag, seq);
   PA_HIP(hipGetLastError());
-  PA_TRY(pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], (const pa_fused_comm *)(p->d_rflag + 2), seq, 0, 256));
+  PA_TRY(pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], (const pa_fused_comm *)(p->d_rflag + 2), seq, 0, cx->sw.fused_tail_blocks));
   // the exchange is complete with the launch (wait(t) and the unpack are its tail); the next pack orders itself behind the compute
   // stream (pa_exchange_pack records ev_compute), so nothing overwrites the buffers this launch still reads
   p->phase = 0; p->own_comm_stream = false; p->ev_wait = nullptr;

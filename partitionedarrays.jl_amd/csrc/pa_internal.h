@@ -47,6 +47,7 @@ struct pa_switches {
   int ghost_from_buffer = 1;  // PA_MUL_GHOST_FROM_BUFFER: own x ghost reads consistent!'s receive buffer (the renamed twin)
   int mul_fused = 1;          // PA_MUL_FUSED: mul!(c,a,b) of a part as one launch (pa_fused.hip)
   int mul_fused_rccl = 1;     // PA_MUL_FUSED_RCCL: also over RCCL (the launch's tail acquires a flag the comm stream raises behind the receives)
+  int fused_tail_blocks = 1024;  // PA_FUSED_TAIL_BLOCKS: tail blocks of a fused launch that may SPIN on arrival flags (ranks sharing one GPU: keep it small)
   int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
 };
 

@@ -819,7 +819,7 @@ int pa_mul_fused_ipc(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double be
   }
   const unsigned long long seq = ++p->seq[PA_CONSISTENT];
   p->mode = PA_CONSISTENT;
-  return pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], L->d_xcomm, seq, n_push_blocks, 256);
+  return pa_mul_fused_launch(m, c, b, alpha, beta, cx->s[0], L->d_xcomm, seq, n_push_blocks, cx->sw.fused_tail_blocks);
 }
 
 bool pa_fused_ipc_fits(const pa_matrix *m) {

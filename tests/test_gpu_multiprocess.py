@@ -80,7 +80,7 @@ def test_bench_two_gpus_over_rccl():
     assert d["n_gpus"] == 2 and d["config"]["transport"].startswith("rccl") and d["config"]["rccl_ranks_seen"] == 2, d["config"]
 
 
-def _bench(nproc, env, args=()):
+def _bench(nproc, env, args=(), grid="32", timeout=600):
     import json
     import os
     import subprocess
@@ -90,8 +90,8 @@ def _bench(nproc, env, args=()):
     e.update(env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "5", "--warmup", "1",
-           "--grid", "32", "--cg-iters", "3", "--cpu-seconds", "0.5", *args]
-    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+           "--grid", grid, "--cg-iters", "3", "--cpu-seconds", "0.5", *args]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return r, (json.loads(lines[-1]) if lines else None)
 
@@ -166,3 +166,23 @@ def test_bench_line_of_an_8_rank_run_over_the_ipc_push_transport():
     assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
     assert d["n_gpus"] == 8 and d["config"]["transport"].startswith("ipc"), d["config"]
     assert len(d["per_rank"]) == 8 and all(p["neighbors_snd"] == 7 for p in d["per_rank"])
+    fa = d.get("fused_ab")
+    assert fa and fa["mul_as_one_launch_rank0"] and fa["exchange_inside_the_launch_rank0"], fa      # round 5: one launch per part
+
+
+def test_bench_config_4_at_full_size_eight_ranks_on_one_gpu_over_ipc():
+    """VERDICT r04 #3b: `bench.py --gpus 8 --grid 256` -- BASELINE config 4's parts, (2,2,2) x 256^3 rows, 197 377 ghosts each --
+    with all eight ranks on this box's ONE GPU (46 GB) over the ipc push transport, every mul! one launch per rank with the exchange
+    inside it: the parity gate at full size, a complete line, every rank's row.  The line goes to gpurun_out/ (copied to profiles/)."""
+    import json
+    import os
+    from test_multiprocess_gloo import ROOT
+    r, d = _bench(8, {"PA_TRANSPORT": "ipc", "PA_BENCH_BACKEND": "gloo", "PA_BENCH_RAMP_S": "0.3"}, ("--no-cpu-baseline", "--no-extra"), grid="256",
+                  timeout=1500)
+    assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert d["n_gpus"] == 8 and d["config"]["rows_per_part"] == 256 ** 3 and d["config"]["ghosts_per_part"] == 197377, d["config"]
+    assert len(d["per_rank"]) == 8 and not any(p.get("missing") for p in d["per_rank"])
+    assert d["fused_ab"]["exchange_inside_the_launch_rank0"]
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_n8_one_gpu_ipc_256.json"), "w") as f:
+        json.dump(d, f, indent=1)
