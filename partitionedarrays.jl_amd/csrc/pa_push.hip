@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -497,6 +498,7 @@ struct pa_ipc_link {
   long long ticks = 0;
   bool connected = false;
   pa_fused_comm *d_xcomm = nullptr;         // device copy of what the fused product launch does for consistent! over this link
+  std::vector<int64_t> ack_idx[2];          // (host) my flag words the receivers of my slices acknowledge in, per mode
 };
 
 static int ipc_flags_layout(const pa_plan *p, int64_t *aC, int64_t *aA, int64_t *kC, int64_t *kA) {
@@ -718,6 +720,7 @@ extern "C" int pa_plan_ipc_connect(pa_plan *p, int32_t n_blobs, const void *cons
       S.arrive = (unsigned long long *)L->peers[q].flags + q_arr0 + (int64_t)i;
       S.ack = L->d_flags + my_ack0 + (int64_t)j;
       segs.push_back(S);
+      L->ack_idx[mode].push_back(my_ack0 + (int64_t)j);
     }
     std::vector<int32_t> wait;
     std::vector<unsigned long long *> ackdst;
@@ -847,7 +850,28 @@ void pa_push_release(pa_plan *p) {
     for (int m = 0; m < 2; ++m) {
       (void)pa_raw_free(L->m[m].d_segs); (void)pa_raw_free(L->m[m].d_wait); (void)pa_raw_free(L->m[m].d_ack_dst);
     }
-    if (L->chunk >= 0) ipc_region_give_back(L->chunk, L->chunk_off, L->region_bytes);   // (the plan's two buffers live in it)
+    // The region goes back to the pool only when nobody can write into it any more.  What may still be ON ITS WAY when this plan goes
+    // is the receivers' acknowledgement of the last slices this part pushed (they acknowledge behind their own unpack, on their own
+    // stream, in their own time): a region handed out again and zeroed would take that late store for a flag of the NEW plan, whose
+    // sequence numbers start over.  So: wait, bounded, until every acknowledgement of the last exchange of either mode
+    // is in; a region whose acknowledgements never come is not reused.
+    bool quiet = true;
+    if (L->connected && L->chunk >= 0) {
+      for (int m = 0; m < 2 && quiet; ++m) {
+        const unsigned long long want = p->seq[m];
+        if (want == 0 || L->ack_idx[m].empty()) continue;
+        std::vector<unsigned long long> flags((size_t)L->n_flags);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+          if (hipMemcpy(flags.data(), L->d_flags, sizeof(unsigned long long) * flags.size(), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); quiet = false; break; }
+          bool all = true;
+          for (int64_t k : L->ack_idx[m]) all = all && flags[(size_t)k] >= want;
+          if (all) break;
+          if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) { quiet = false; break; }
+        }
+      }
+    }
+    if (L->chunk >= 0 && quiet) ipc_region_give_back(L->chunk, L->chunk_off, L->region_bytes);   // (the plan's two buffers live in it)
     if (L->d_done) (void)hipFree(L->d_done);
     if (L->h_status) (void)hipHostFree(L->h_status);
     if (L->d_xcomm) (void)pa_raw_free(L->d_xcomm);

@@ -306,6 +306,27 @@ def is_consistent(graph: ExchangeGraph) -> bool:
 CHECK_EXCHANGE_GRAPHS = int(os.environ.get("PA_CHECK_EXCHANGE_GRAPHS", "1"))
 
 
+_GROUP_TOKENS = None
+_GROUP_SERIAL = [0]
+
+
+def _group_token(group):
+    """A value that names `group` for as long as it lives and is never handed to another group (None: the default group)."""
+    global _GROUP_TOKENS
+    if group is None:
+        return ("default-group",)
+    if _GROUP_TOKENS is None:
+        import weakref
+        _GROUP_TOKENS = weakref.WeakKeyDictionary()
+    try:
+        if group not in _GROUP_TOKENS:
+            _GROUP_SERIAL[0] += 1
+            _GROUP_TOKENS[group] = ("group", _GROUP_SERIAL[0])
+        return _GROUP_TOKENS[group]
+    except TypeError:                                        # (a group type that cannot be weakly referenced: check every time)
+        return object()
+
+
 def _edges_match(dist, group, me, world, snd_ids, rcv_ids, kw):
     """True on every rank iff, on every rank, rcv_ids == {i : rank i sends to me} (and no neighbour is listed twice)."""
     import torch
@@ -360,13 +381,18 @@ def exchange(snd, graph: ExchangeGraph):
         kw = {} if dev is None else {"device": dev}
         # The check is a collective over the WHOLE group (an all-gather + an all-reduce): it runs once per graph object --
         # the first exchange over a graph must be entered by every rank of the group, later ones only involve neighbours.
+        # The verdict is remembered under a TOKEN of the group, not its id() (an id can come back with another group behind it,
+        # ADVICE r04): group objects get a serial number at first sight, kept in a WeakKeyDictionary.  Whether the collective check
+        # runs is decided by every rank from its OWN copy of the graph: a graph object must therefore be reused (or rebuilt) by all
+        # ranks of the group alike -- as every graph of this package is (they are made and used by collective calls).
+        token = _group_token(group)
         checked = getattr(graph, "_edges_checked", None)
-        if CHECK_EXCHANGE_GRAPHS == 1 and checked != id(group):
+        if CHECK_EXCHANGE_GRAPHS == 1 and checked != token:
             ok, senders = _edges_match(dist, group, me, world, snd_ids, rcv_ids, kw)
             assert ok, (f"inconsistent ExchangeGraph (src/primitives.jl:861-874) seen from part {me}: it expects messages from "
                         f"{sorted(rcv_ids)}, the parts that send to it are {senders}")
             try:
-                graph._edges_checked = id(group)
+                graph._edges_checked = token
             except AttributeError:                           # (a graph type without a __dict__: check every time)
                 pass
         snd_at = {q: j for j, q in enumerate(snd_ids)}                 # partner -> position (a dict, not a scan per round)

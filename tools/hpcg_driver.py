@@ -97,13 +97,17 @@ def hpcg_benchmark(ranks, np_, nx, ny, nz, total_runtime=60.0, levels=4, ref_max
     Returns the report dictionary of hpcg_report (and writes it when output_type is "json" or "txt")."""
     from pa_amd.primitives import getany, reduction
     ctx = context()
-    # The memory pool before anything is timed.  On a device other processes have used the driver wipes what it hands out (up to a
-    # second per 16 GiB) and the context has to find its memory classes among the extents it is given: 0.1 s on one lease, 2.4 s
-    # (84 GiB walked) on another -- the box's history, not this benchmark's set-up.  One untimed set-up of the optimised solver
-    # acquires and classifies what both timed set-ups will use; PA_ARENA_SPARE_GIB (set below unless the caller chose) keeps it.
-    ctx.arena(build=True)
+    # What is timed as "set-up".  The reference times its one and only set-up (HPCG/src/hpcg_benchmark.jl:35-40), and the rating
+    # charges it per set; here the FIRST set-up of a process also pays for things that are the box's history rather than the
+    # benchmark's work -- the driver wipes memory other processes have used when it hands it out (up to a second per 16 GiB) and
+    # the context has to find its memory classes among the extents it gets (0.1 s on one lease, 2.4 s on another).  Both views
+    # are reported (VERDICT r04 #4, ADVICE r04): every set-up is run TWICE, the first time as the process finds the device
+    # ("first encounter": pool acquisition, code-object loading, scratch allocations all inside the timed region -- the
+    # reference's procedure, and the OFFICIAL rating of this report), the second time with the pool in hand ("pool in hand").
+    # PA_HPCG_POOL_WARMUP=1 restores round 4's order (one untimed set-up first; then both views coincide).
     t_pool = time.perf_counter()
-    if os.environ.get("PA_HPCG_POOL_WARMUP", "1") != "0":
+    if os.environ.get("PA_HPCG_POOL_WARMUP", "0") == "1":
+        ctx.arena(build=True)
         warm = pc_setup(ranks, np_, levels, nx, ny, nz, ordering=opt_ordering)
         ctx.sync()
         del warm
@@ -117,6 +121,8 @@ def hpcg_benchmark(ranks, np_, nx, ny, nz, total_runtime=60.0, levels=4, ref_max
         return time.perf_counter() - t, out
 
     pmax = lambda v: float(getany(reduction(max, pmap(lambda _r: v, ranks), destination="all")))
+    t_setup_first, S_ref = elapsed(lambda: pc_setup(ranks, np_, levels, nx, ny, nz, ordering=ref_ordering))
+    del S_ref
     t_setup, S_ref = elapsed(lambda: pc_setup(ranks, np_, levels, nx, ny, nz, ordering=ref_ordering))
     geom = hpcg_geometry(np_, levels, nx, ny, nz)
     A, b = S_ref.A_vec[-1], S_ref.r[-1]
@@ -132,6 +138,8 @@ def hpcg_benchmark(ranks, np_, nx, ny, nz, total_runtime=60.0, levels=4, ref_max
 
     # (one part: the V-cycle is replayed from a hipGraph -- same kernels, same bits, less launch cost on the coarse levels; the
     #  graph holds the addresses of the vectors it was recorded with, so the CG work vectors are allocated once: cg_work)
+    t_opt_setup_first, S = elapsed(lambda: pc_setup(ranks, np_, levels, nx, ny, nz, ordering=opt_ordering, graph=(np_ == 1)))
+    del S
     t_opt_setup, S = elapsed(lambda: pc_setup(ranks, np_, levels, nx, ny, nz, ordering=opt_ordering, graph=(np_ == 1)))
     A, b = S.A_vec[-1], S.r[-1]
     work = cg_work(pzeros(A.col_partition), b, A)
@@ -160,10 +168,25 @@ def hpcg_benchmark(ranks, np_, nx, ny, nz, total_runtime=60.0, levels=4, ref_max
     print(f"[hpcg_driver] untimed pool warm-up {t_pool:.2f} s; set-up {times['setup']:.3f} s (reference ordering), {times['opt_time']:.3f} s (optimised), {nr_sets} sets of "
           f"{opt_n_iters} iterations in {times['total']:.2f} s, arena {ctx.arena()['acquired_gib']} GiB acquired in {ctx.arena()['map_ms']:.0f} ms",
           file=sys.stderr, flush=True)
-    rep = hpcg_report(np_, times, levels, ref_max_iters, opt_n_iters, nr_sets, norm_data, geom)
+    times_first = dict(times, setup=pmax(t_setup_first), opt_time=pmax(t_opt_setup_first))
+    rep = hpcg_report(np_, times_first, levels, ref_max_iters, opt_n_iters, nr_sets, norm_data, geom)
+    rep_warm = hpcg_report(np_, times, levels, ref_max_iters, opt_n_iters, nr_sets, norm_data, geom)
+    rep["ratings"] = {
+        "official": {"GFLOP/s": rep["Overview"]["GFLOP/s"], "setup_s": times_first["setup"], "opt_setup_s": times_first["opt_time"],
+                     "what": "the reference's procedure (HPCG/src/hpcg_benchmark.jl:35-40, report_results.jl:140-147): each set-up timed the "
+                             "first time this process runs it -- memory pool acquisition and classification, code-object loading and "
+                             "scratch allocations inside the timed region"},
+        "pool_in_hand": {"GFLOP/s": rep_warm["Overview"]["GFLOP/s"], "setup_s": times["setup"], "opt_setup_s": times["opt_time"],
+                         "what": "the same set-ups timed a second time, with the context's memory pool acquired and every kernel "
+                                 "loaded: what a second solve in the same process pays"},
+        "raw": rep["GFLOP/s"]["Total"], "after_convergence_penalty": rep["GFLOP/s"]["Total_conv"]}
+    print(f"[hpcg_driver] rating OFFICIAL (set-ups as first encountered: {times_first['setup']:.3f} + {times_first['opt_time']:.3f} s) "
+          f"{rep['Overview']['GFLOP/s']:.1f} GFLOP/s; with the pool in hand ({times['setup']:.3f} + {times['opt_time']:.3f} s) "
+          f"{rep_warm['Overview']['GFLOP/s']:.1f} GFLOP/s; raw {rep['GFLOP/s']['Total']:.1f}, after the convergence penalty "
+          f"{rep['GFLOP/s']['Total_conv']:.1f}", file=sys.stderr, flush=True)
     rep["reference_phase"] = {"ref_tol": ref_tol, "seconds_per_set": t_ref / 2, "ordering": ref_ordering}
-    rep["pool_warmup"] = {"seconds": t_pool, "what": "one untimed pc_setup of the optimised solver before the three phases: the context acquires and classifies "
-                                                     "its memory extents there (PA_HPCG_POOL_WARMUP=0: inside the timed set-ups, as in round 3)"}
+    rep["pool_warmup"] = {"seconds": t_pool, "what": "PA_HPCG_POOL_WARMUP=1 only: one untimed pc_setup of the optimised solver before the three phases "
+                                                     "(round 4's order); by default nothing runs untimed and `ratings` carries both views"}
     rep["optimised_phase"] = {"ordering": opt_ordering, "iterations_to_ref_tol": opt_n_iters, "worst_set_seconds": worst}
     if output_type != "none" and getany(pmap(lambda r: r, ranks)) == 1:
         os.makedirs(output_folder, exist_ok=True)
@@ -187,4 +210,4 @@ if __name__ == "__main__":
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     rt = float(sys.argv[3]) if len(sys.argv) > 3 else 10.0
     rep = hpcg_benchmark(pa.DebugArray(list(range(1, P + 1))), P, n, n, n, total_runtime=rt)
-    print(json.dumps(rep["GFLOP/s"]), json.dumps(rep["Overview"]))
+    print(json.dumps(rep["GFLOP/s"]), json.dumps(rep["Overview"]), json.dumps(rep["ratings"]))
