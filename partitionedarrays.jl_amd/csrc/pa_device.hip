@@ -826,7 +826,8 @@ __global__ __launch_bounds__(256) void k_vdict_collect(const double *__restrict_
 }
 
 __global__ __launch_bounds__(256) void k_vdict_encode(const double *__restrict__ val, int64_t n, const unsigned long long *__restrict__ table,
-                                                      const unsigned char *__restrict__ slot_code, unsigned char *__restrict__ code) {
+                                                      const unsigned char *__restrict__ slot_code, unsigned char *__restrict__ code,
+                                                      int *__restrict__ missing) {
   __shared__ unsigned long long t[PA_VDICT_SLOTS];
   __shared__ unsigned char sc[PA_VDICT_SLOTS];
   t[threadIdx.x] = table[threadIdx.x];
@@ -836,10 +837,18 @@ __global__ __launch_bounds__(256) void k_vdict_encode(const double *__restrict__
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += stride) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(val[p]);
     int h = vdict_hash(b);
-    while (t[h] != b) h = (h + 1) & (PA_VDICT_SLOTS - 1);      // (every value is in the table: pass 1 put it there)
+    // (a table built from THESE values holds every one of them; a table inherited from the block this one was cut from holds them
+    //  unless the caller changed values in between: a value that is not there raises `missing` and the caller builds afresh)
+    for (int k = 0; k < PA_VDICT_SLOTS && t[h] != b; ++k) h = (h + 1) & (PA_VDICT_SLOTS - 1);
+    if (t[h] != b) { *missing = 1; code[p] = 0; continue; }
     code[p] = sc[h];
   }
 }
+
+// A block cut from another block (a colour's rows, pa_rowsel.hip) takes that block's dictionary instead of finding its own: same
+// values, so the same table serves -- one pass over the values (their codes) instead of two plus a read-back (round 5: 50 dictionary
+// builds were 0.18 s of the HPCG driver's 0.72 s optimised set-up, which the rating charges per set).
+thread_local const pa_csr *pa_tls_vdict_parent = nullptr;
 
 // (re)build the dictionary of one slab from its value stream; `rebuild`: the codes exist and the values changed
 static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
@@ -851,6 +860,36 @@ static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
   if (mode < 0 && !rebuild && (A->nnz < ((int64_t)1 << 18) || A->n_xw_groups > 0)) return PA_OK;
   const size_t pad = 8;
   hipStream_t s = c->s[0];
+  auto alloc_codes = [&]() -> int {
+    if (A->d_code) return PA_OK;
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_code, A->nnz + pad, PA_MEM_MATRIX));
+    // the dictionary (PA_VDICT_MAX values) and, behind it, what built it: the hash table's slots and their codes
+    PA_TRY(pa_dev_alloc(c, (void **)&A->d_dict, sizeof(double) * PA_VDICT_MAX + sizeof(unsigned long long) * PA_VDICT_SLOTS + PA_VDICT_SLOTS + 64, PA_MEM_MATRIX));
+    PA_HIP(hipMemsetAsync(A->d_code + A->nnz, 0, pad, s));
+    return PA_OK;
+  };
+  auto table_of = [](const pa_csr *B) { return (unsigned long long *)(B->d_dict + PA_VDICT_MAX); };
+  auto slots_of = [&](const pa_csr *B) { return (unsigned char *)(table_of(B) + PA_VDICT_SLOTS); };
+  auto flag_of = [&](const pa_csr *B) { return (int *)(slots_of(B) + PA_VDICT_SLOTS); };
+  const int enc_blocks = (int)std::min<int64_t>((A->nnz + 256 * 8 - 1) / (256 * 8), 256 * 64);
+  if (const pa_csr *P = pa_tls_vdict_parent) {
+    if (!rebuild && P != A && P->ctx == c && P->use_vdict && P->d_dict && mode != 0) {
+      if (alloc_codes() == PA_OK &&
+          hipMemcpyAsync(A->d_dict, P->d_dict, sizeof(double) * PA_VDICT_MAX + sizeof(unsigned long long) * PA_VDICT_SLOTS + PA_VDICT_SLOTS,
+                         hipMemcpyDeviceToDevice, s) == hipSuccess &&
+          hipMemsetAsync(flag_of(A), 0, sizeof(int), s) == hipSuccess) {
+        hipLaunchKernelGGL(k_vdict_encode, dim3(enc_blocks), dim3(256), 0, s, A->d_val, A->nnz, table_of(A), slots_of(A), A->d_code, flag_of(A));
+        int missing = 1;
+        if (hipMemcpyAsync(&missing, flag_of(A), sizeof(int), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess &&
+            !missing) {
+          A->use_vdict = true;
+          A->n_dict = P->n_dict;
+          return PA_OK;
+        }
+      }
+      (void)hipGetLastError();                               // (anything amiss: the block finds its own dictionary below)
+    }
+  }
   // (scratch of the context, made once: a multigrid set-up builds dozens of blocks, and three hipMallocs per block showed)
   if (!c->d_vdict_scratch) PA_HIP(pa_raw_malloc(&c->d_vdict_scratch, sizeof(unsigned long long) * PA_VDICT_SLOTS + PA_VDICT_SLOTS + 64));
   unsigned long long *d_table = (unsigned long long *)c->d_vdict_scratch;
@@ -884,17 +923,17 @@ static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
     if (table[h] != PA_VDICT_EMPTY) slot[h] = (unsigned char)(std::lower_bound(dict.begin(), dict.end(), table[h]) - dict.begin());
   std::vector<double> dv(PA_VDICT_MAX, 0.0);
   memcpy(dv.data(), dict.data(), 8 * dict.size());
-  if (!A->d_code) {
-    if (const int st = pa_dev_alloc(c, (void **)&A->d_code, A->nnz + pad, PA_MEM_MATRIX)) return done(st);
-    if (const int st = pa_dev_alloc(c, (void **)&A->d_dict, sizeof(double) * PA_VDICT_MAX, PA_MEM_MATRIX)) return done(st);
-    if (hipMemsetAsync(A->d_code + A->nnz, 0, pad, s) != hipSuccess) { pa_set_err("value dictionary: memset failed"); return done(PA_ERR_HIP); }
-  }
+  if (const int st = alloc_codes()) return done(st);
   if (hipMemcpyAsync(d_slot, slot.data(), PA_VDICT_SLOTS, hipMemcpyHostToDevice, s) != hipSuccess ||
-      hipMemcpyAsync(A->d_dict, dv.data(), sizeof(double) * PA_VDICT_MAX, hipMemcpyHostToDevice, s) != hipSuccess) {
+      hipMemcpyAsync(A->d_dict, dv.data(), sizeof(double) * PA_VDICT_MAX, hipMemcpyHostToDevice, s) != hipSuccess ||
+      // (the table and its codes stay with the block: a block cut from this one inherits them, pa_tls_vdict_parent)
+      hipMemcpyAsync(table_of(A), d_table, sizeof(unsigned long long) * PA_VDICT_SLOTS, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemcpyAsync(slots_of(A), d_slot, PA_VDICT_SLOTS, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+      hipMemsetAsync(flag_of(A), 0, sizeof(int), s) != hipSuccess) {
     pa_set_err("value dictionary: upload failed");
     return done(PA_ERR_HIP);
   }
-  hipLaunchKernelGGL(k_vdict_encode, dim3(blocks), dim3(256), 0, s, A->d_val, A->nnz, d_table, d_slot, A->d_code);
+  hipLaunchKernelGGL(k_vdict_encode, dim3(blocks), dim3(256), 0, s, A->d_val, A->nnz, d_table, d_slot, A->d_code, flag_of(A));
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { pa_set_err("value dictionary: encoding failed"); return done(PA_ERR_HIP); }
   A->use_vdict = true;
   A->n_dict = (int)dict.size();

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import _lib as L
-from .primitives import pmap
+from .primitives import pmap, local_items
 from .p_sparse_matrix import mul_, mul_c_, mul_dot_, mul_no_overlap_
 from .p_vector import (axpby_, copy_, dot, norm, similar, pzeros, consistent_, context, slots_supported, dot_slot,
                        axpby_slot_, cg_update_, cg_r_update_, cg_xu_update_, write_slot, read_slots)
@@ -311,10 +311,15 @@ class MgPreconditioner:
             pass
 
 
-def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=None, graph=None):
+def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=None, graph=None, reuse=None, keep_raw_columns=False):
     """pc_setup(np,ranks,l,nx,ny,nz) (HPCG/src/mg_preconditioner.jl:142-187).  ordering: see GaussSeidel.
     fuse_restriction (default: on for the multicolour orderings): the residual A*x is formed only on the fine rows the
-    coarse grid keeps (pa_transfer_restrict_fused) -- the same row sums, so r_c is bit-identical."""
+    coarse grid keeps (pa_transfer_restrict_fused) -- the same row sums, so r_c is bit-identical.
+    reuse: a hierarchy made by an earlier pc_setup(..., keep_raw_columns=True) for the same geometry: its operators, right-hand
+    sides, work vectors and transfer operators are TAKEN OVER (the earlier object is left empty) and only this ordering's smoothers
+    and restriction blocks are made -- what the reference's driver does, whose reference and optimised phases share one hierarchy
+    (HPCG/src/hpcg_benchmark.jl:35-60).  keep_raw_columns: the levels' blocks keep their Int32 columns in HBM afterwards, so that
+    a later set-up can cut its row subsets from them."""
     if fuse_restriction is None:
         fuse_restriction = ordering != "sequential"
     if graph is None:                                  # (off by default: 0.555 -> 0.488 ms per MG-PCG iteration at 32^3, nothing at
@@ -341,22 +346,30 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
                     # such a level keeps its host copy and takes the host route
                     and nx * ny * nz * 27 < 2 ** 31 - 648)
         # (nothing of the set-up reads a host copy of the blocks then: they are generated in HBM, gallery.build_split_blocks_device)
-        A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=not keep_raw, fused=True,
-                              keep_raw=keep_raw)
+        if reuse is not None:
+            A, b = reuse.A_vec[lev - 1], reuse.r[lev - 1]
+            if keep_raw and not all(d.own_own.has_raw_columns() and d.own_ghost.has_raw_columns() for d in local_items(A.matrix_partition)):
+                raise L.PAError("pc_setup(reuse=...): the earlier hierarchy did not keep its raw columns (keep_raw_columns=True)")
+        else:
+            A, b = build_p_matrix(ranks, nx, ny, nz, npx * nx, npy * ny, npz * nz, npx, npy, npz, keep_host=not keep_raw, fused=True,
+                                  keep_raw=keep_raw)
         As[lev - 1], rs[lev - 1] = A, b
         op = restrict_operator(nx, ny, nz) if lev > 1 else None
         if ordering == "multicolor_spmv":
             gss[lev - 1] = ColoredGaussSeidelSpMV(A, (lambda _r, op=op: op.astype(np.int64) - 1) if op is not None else None)
         else:
             gss[lev - 1] = GaussSeidel(A, ordering)
-        xs[lev - 1], Axfs[lev - 1] = pzeros(A.col_partition), pzeros(A.col_partition)
+        if reuse is not None:
+            xs[lev - 1], Axfs[lev - 1] = reuse.x[lev - 1], reuse.Axf[lev - 1]
+        else:
+            xs[lev - 1], Axfs[lev - 1] = pzeros(A.col_partition), pzeros(A.col_partition)
         if lev > 1:
 
             def mk(_r):
                 t = C.c_void_p()
                 L.call("pa_transfer_create", context().h, len(op), L.ptr(op), 1, C.byref(t))
                 return t
-            f2c[lev - 2] = pmap(mk, A.row_partition)
+            f2c[lev - 2] = reuse.f2c[lev - 2] if reuse is not None else pmap(mk, A.row_partition)
             if fuse_restriction:
                 from .p_sparse_matrix import DeviceCSR
                 def rows_block(hb, r, c, dev):
@@ -370,8 +383,10 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
                 pmap(lambda t, bk: L.call("pa_transfer_attach_rows", t, bk.h), f2c[lev - 2], blk)
                 rbs[lev - 2] = blk
             nx, ny, nz = nx // 2, ny // 2, nz // 2
-        if keep_raw:
+        if keep_raw and not keep_raw_columns:
             pmap(lambda dev: (dev.own_own.drop_raw_columns(), dev.own_ghost.drop_raw_columns()), A.matrix_partition)
+    if reuse is not None:                                # (taken over: the earlier object must not free the transfer operators)
+        reuse.f2c, reuse.A_vec, reuse.gs_states, reuse.r, reuse.x, reuse.Axf, reuse.row_blocks = None, [], [], [], [], [], None
     from .primitives import DebugArray
     one_part = isinstance(ranks, DebugArray) and len(ranks.items) == 1
     return MgPreconditioner(f2c, As, gss, rs, xs, Axfs, l, rbs, bool(graph) and one_part and ordering == "multicolor_spmv", {})
