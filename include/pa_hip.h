@@ -352,6 +352,17 @@ int pa_comm_barrier(pa_comm *comm);
  * src/mpi_array.jl:51-53.  bench.py prints nranks as `rccl_ranks_seen`. */
 int pa_comm_info(pa_comm *comm, int *rank, int *nranks);
 
+/* ---- HPCG set-up without the big upload (round 5: in the contract, the Julia glue's hpcg_blocks_hip calls it) ---- */
+/* HPCG's 27-point operator of one part (HPCG/src/sparse_matrix.jl:28-122), own_own block and right-hand side, generated
+ * in HBM: the arrays pa_host_hpcg_split_csr writes (oo_*, b), no host copy, no upload.  nx,ny,nz: the part's box; gnx,gny,gnz:
+ * the global grid; gix0,giy0,giz0: global coordinates (1-based) of the part's first node.  b may be NULL. */
+int pa_hpcg_own_block_create(pa_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz,
+                             int64_t gix0, int64_t giy0, int64_t giz0, pa_csr **own_own, pa_vec *b);
+/* b alone (a vector created after the block is placed knowing the matrix streams' memory class) */
+int pa_hpcg_rhs(pa_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
+                int64_t giy0, int64_t giz0, pa_vec *b);
+
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,15 +92,6 @@ int pa_csr_greedy_coloring(const pa_csr *own_own, int32_t *color, int32_t *n_col
  * the restriction injects would be zero up to rounding). */
 int pa_csr_color_affinity(const pa_csr *own_own, const int32_t *color, int32_t n_colors, const int32_t *kept_rows, int64_t n_kept,
                           double *affinity);
-/* HPCG's 27-point operator of one part (HPCG/src/sparse_matrix.jl:28-122), own_own block and right-hand side, generated
- * in HBM: the arrays pa_host_hpcg_split_csr writes (oo_*, b), no host copy, no upload.  nx,ny,nz: the part's box; gnx,gny,gnz:
- * the global grid; gix0,giy0,giz0: global coordinates (1-based) of the part's first node.  b may be NULL. */
-int pa_hpcg_own_block_create(pa_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz,
-                             int64_t gix0, int64_t giy0, int64_t giz0, pa_csr **own_own, pa_vec *b);
-/* b alone (a vector created after the block is placed knowing the matrix streams' memory class) */
-int pa_hpcg_rhs(pa_ctx *ctx, int64_t nx, int64_t ny, int64_t nz, int64_t gnx, int64_t gny, int64_t gnz, int64_t gix0,
-                int64_t giy0, int64_t giz0, pa_vec *b);
-
 /* testing aid: a host copy of one of the arrays the product kernel reads (first slab of the block) -- 0 row pointers,
  * 1 32-bit columns, 2 16-bit codes, 3 windows, 4 pattern descriptors, 5 pattern table, 6 chunk table, 7 compacted row ids;
  * *bytes = the array's size, copied when capacity allows.  The set-up runs on the device (csrc/pa_setup.hip; PA_SETUP_DEVICE=0:

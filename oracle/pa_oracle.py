@@ -846,11 +846,100 @@ def hpcg_build_matrix(nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0):
     return row_b.copy(), col_b.copy(), val, b.astype(F64), rows_b
 
 
+class _MixedBaseCounter:
+    """HPCG/src/mixed_base_counter.jl:1-5 (1-based there; arrays of 33 as there)."""
+
+    def __init__(self, length, max_counts, cur_counts):
+        self.length, self.max_counts, self.cur_counts = length, max_counts, cur_counts
+
+
+def _mbc(counts, l):
+    """mixedbasecounter(counts, l), mixed_base_counter.jl:7-17."""
+    mx, cur = [0] * 33, [0] * 33
+    for i in range(l):
+        mx[i] = counts[i]
+    mx[l] = 0
+    return _MixedBaseCounter(l, mx, cur)
+
+
+def _mbc1(left, right):
+    """mixedbasecounter1(left, right), mixed_base_counter.jl:19-27."""
+    mx, cur = [0] * 33, [0] * 33
+    for i in range(left.length):
+        mx[i] = left.max_counts[i] - right.cur_counts[i]
+    return _MixedBaseCounter(left.length, mx, cur)
+
+
+def _mbc_next(c):
+    """next(counter), mixed_base_counter.jl:29-39."""
+    for i in range(c.length):
+        c.cur_counts[i] += 1
+        if c.cur_counts[i] > c.max_counts[i]:
+            c.cur_counts[i] = 0
+            continue
+        break
+    return c
+
+
+def _mbc_nonzero(c):
+    """is_zero(counter), mixed_base_counter.jl:41-48 -- true while some digit is NOT zero (the name says the opposite)."""
+    return any(c.cur_counts[i] != 0 for i in range(c.length))
+
+
+def _mbc_product(c, multipliers):
+    """product(counter, multipliers), mixed_base_counter.jl:50-61: 0 for the all-zero counter."""
+    k, x = 0, 1
+    for i in range(c.length):
+        for _ in range(int(c.cur_counts[i])):
+            k = 1
+            x *= multipliers[i]
+    return x * k
+
+
 def compute_optimal_shape_xyz(np_):
-    """HPCG/src/compute_optimal_xyz.jl:8-64, restricted to the prime-power / small cases used here."""
-    table = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2), 3: (3, 1, 1),
-             16: (4, 2, 2), 6: (2, 3, 1)}
-    return table[np_]
+    """HPCG/src/compute_optimal_xyz.jl:8-64, statement by statement (Primes.factor into a SortedDict: primes ascending)."""
+    if np_ == 1:
+        return 1, 1, 1
+    factors, m, d = {}, np_, 2
+    while m > 1:
+        while m % d == 0:
+            factors[d] = factors.get(d, 0) + 1
+            m //= d
+        d += 1
+    primes = sorted(factors)
+    z = 0
+    x = primes[0]
+    y = primes[1] if len(primes) > 1 else None
+    if len(primes) == 1:
+        z = x ** int(np.floor(factors[x] / 3))
+        y = x ** int(np.floor(factors[x] / 3 + (1 if (factors[x] % 3) >= 2 else 0)))
+        x = x ** int(np.floor(factors[x] / 3 + (1 if (factors[x] % 3) >= 1 else 0)))
+    elif len(primes) == 2 and factors[x] == 1 and factors[y] == 1:
+        z = 1
+    elif len(primes) == 2 and factors[x] + factors[y] == 3:
+        z = x if factors[x] == 2 else y
+    elif len(primes) == 3 and factors[x] == 1 and factors[y] == 1 and factors[primes[2]] == 1:
+        z = primes[2]
+    else:
+        powers = [factors[q] for q in primes]
+        c_main = _mbc(powers, len(primes))
+        c1 = _mbc(powers, len(primes))
+        min_area = 2.0 * np_ + 1.0
+        c1 = _mbc_next(c1)
+        while _mbc_nonzero(c1):
+            c2 = _mbc1(c_main, c1)
+            c2 = _mbc_next(c2)
+            while _mbc_nonzero(c2):
+                tf1 = _mbc_product(c1, primes)
+                tf2 = _mbc_product(c2, primes)
+                tf3 = np_ / tf1 / tf2
+                area = tf1 * tf2 + tf2 * tf3 + tf1 * tf3
+                if area < min_area:
+                    min_area = area
+                    x, y, z = tf1, tf2, tf3
+                c2 = _mbc_next(c2)
+            c1 = _mbc_next(c1)
+    return int(x), int(y), int(np.floor(z))
 
 
 def hpcg_build_p_matrix(nx, ny, nz, npx, npy, npz, index_dtype=I32):

@@ -50,7 +50,8 @@ def build_matrix(nx, ny, nz, gnx, gny, gnz, gix0, giy0, giz0):
 
 
 def compute_optimal_shape_XYZ(np_):
-    """HPCG/src/compute_optimal_xyz.jl:8-64 for np with one or two distinct prime factors / powers of a prime."""
+    """HPCG/src/compute_optimal_xyz.jl:8-64: the part grid (npx, npy, npz) of np parts -- the special cases in closed form, every
+    other np by the reference's search over the ways to deal its prime powers to the directions (least surface, first found)."""
     if np_ == 1:
         return 1, 1, 1
     f, m, d = {}, np_, 2
@@ -74,7 +75,44 @@ def compute_optimal_shape_XYZ(np_):
         return x, y, (x if f[x] == 2 else y)
     if len(primes) == 3 and all(f[p] == 1 for p in primes):
         return x, y, primes[2]
-    raise NotImplementedError("compute_optimal_shape_XYZ: general 3-subset search not needed for 1..8 parts")
+    # 3 or more prime factors with repeats (np = 16 has one prime and is served above; 24, 36, 40, 48, ...): every way to deal the
+    # prime powers to two of the directions is tried in the order of the reference's mixed-base counters (HPCG/src/
+    # compute_optimal_xyz.jl:34-62, mixed_base_counter.jl) and the first shape of least surface tf1*tf2 + tf2*tf3 + tf1*tf3 wins;
+    # the third direction gets what is left.  (x, y) are NOT sorted afterwards, as in the reference.
+    powers = [f[p] for p in primes]
+    n = len(primes)
+
+    def counter_next(cur, mx):
+        for i in range(n):
+            cur[i] += 1
+            if cur[i] > mx[i]:
+                cur[i] = 0
+                continue
+            break
+
+    def product(cur):
+        out = 1
+        for i in range(n):
+            out *= primes[i] ** cur[i]
+        return out
+
+    min_area = 2.0 * np_ + 1.0
+    z = 0
+    c1 = [0] * n
+    counter_next(c1, powers)
+    while any(c1):
+        mx2 = [powers[i] - c1[i] for i in range(n)]
+        c2 = [0] * n
+        counter_next(c2, mx2)
+        while any(c2):
+            tf1, tf2 = product(c1), product(c2)
+            tf3 = np_ / tf1 / tf2
+            area = tf1 * tf2 + tf2 * tf3 + tf1 * tf3
+            if area < min_area:
+                min_area, x, y, z = area, tf1, tf2, tf3
+            counter_next(c2, mx2)
+        counter_next(c1, powers)
+    return int(x), int(y), int(z // 1)
 
 
 def build_split_blocks_fused(my_rows, nx, ny, nz, gnx, gny, gnz):

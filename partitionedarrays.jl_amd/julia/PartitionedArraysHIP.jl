@@ -429,6 +429,34 @@ function to_hip(A::PSparseMatrix)
     PSparseMatrix(mats, partition(axes(A, 1)), partition(axes(A, 2)), true)
 end
 
+# ---------------------------------------------------------------- HPCG set-up route (optional)
+# HPCG/src/sparse_matrix.jl:105-122 builds every part's COO triplets on the host and psparse assembles them; for the 27-point
+# operator the own_own block -- 26/27 of the entries -- is a pure function of the part's box, so it is GENERATED in HBM
+# (pa_hpcg_own_block_create: the arrays the reference's chain ends with, byte for byte; tests/test_gpu_setup.py) and only the
+# part's surface (own_ghost, the ghost ids in first-seen order) comes from the host matrix the reference built.  `A`: the host
+# PSparseMatrix of HPCG.build_p_matrix (assembled, split format, Int32 CSR); nx,ny,nz: the part's box; gn: the global grid;
+# g0[part]: the 1-based global coordinates of the part's first node.  Returns the device twin of A and of the right-hand side.
+function hpcg_blocks_hip(A::PSparseMatrix, nx::Integer, ny::Integer, nz::Integer, gn::NTuple{3,<:Integer}, g0)
+    @assert A.assembled
+    bs = map(partition(axes(A, 1))) do rows
+        HIPVector(zeros(Float64, local_length(rows)), own_length(rows), local_to_device(rows))
+    end
+    mats = map(partition(A), g0, bs) do a, first_node, b
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:pa_hpcg_own_block_create, libpa), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Ref{Ptr{Cvoid}}, Ptr{Cvoid}),
+                    context().handle, nx, ny, nz, gn[1], gn[2], gn[3], first_node[1], first_node[2], first_node[3], h, C_NULL))
+        check(ccall((:pa_hpcg_rhs, libpa), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Int64, Ptr{Cvoid}),
+                    context().handle, nx, ny, nz, gn[1], gn[2], gn[3], first_node[1], first_node[2], first_node[3], b.handle))
+        n = nx * ny * nz
+        blocks = PartitionedArrays.split_matrix_blocks(_adopt(h[], n, n), HIPCSR(a.blocks.own_ghost),
+                                                       HIPCSR(a.blocks.ghost_own), HIPCSR(a.blocks.ghost_ghost))
+        PartitionedArrays.split_matrix(blocks, a.row_permutation, a.col_permutation)
+    end
+    PSparseMatrix(mats, partition(axes(A, 1)), partition(axes(A, 2)), true), PVector(bs, partition(axes(A, 1)))
+end
+
 # ---------------------------------------------------------------- psparse on the device (optional route)
 const BlockIndices = Union{PartitionedArrays.LocalIndicesWithConstantBlockSize,PartitionedArrays.LocalIndicesWithVariableBlockSize}
 _box(r::BlockIndices) = (length(r.n), collect(Int64, r.n), Int64[first(x) for x in r.ranges], Int64[last(x) for x in r.ranges])

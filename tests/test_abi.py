@@ -551,3 +551,23 @@ def test_glue_consistent_on_permuted_local_indices_replayed_through_ctypes(orc, 
     orc.assemble(want, cols, cache)
     for p in range(len(cols)):
         assert np.array_equal(array(p), want[p]), f"assemble! part {p + 1}"
+
+
+def test_julia_runtests_and_reference_bench_scripts_are_consistent_with_the_glue():
+    """a Julia maintainer gets one command (julia/runtests.jl) and the host-side reference timing BASELINE.md
+    promises (bench/julia_reference.jl).  Neither can run here; statically: every name runtests.jl imports from the glue is
+    defined there, its literal expectations are the reference test file's (test/p_vector_tests.jl:129-139), and the scripts
+    cite the reference lines they replay."""
+    glue = open(os.path.join(ROOT, "partitionedarrays.jl_amd", "julia", "PartitionedArraysHIP.jl")).read()
+    rt = open(os.path.join(ROOT, "partitionedarrays.jl_amd", "julia", "runtests.jl")).read()
+    names = re.search(r"using \.PartitionedArraysHIP: ([^\n]+)", rt).group(1)
+    for n in [x.strip() for x in names.split(",")]:
+        assert re.search(r"(?m)^(?:function |mutable struct |struct |const )?" + re.escape(n) + r"\b", glue) or \
+            re.search(r"(?m)^" + re.escape(n) + r"\(", glue), n
+    for lit in ("[20.0, 20.0, 20.0, 0.0, 0.0, 0.0]", "[0.0, 20.0, 30.0, 0.0]", "[10.0, 30.0, 20.0, 0.0, 0.0, 0.0]", "[0.0, 0.0, 0.0, 10.0, 30.0]"):
+        assert lit in rt
+    assert "test/p_vector_tests.jl:93-142" in rt and "test/p_sparse_matrix_tests.jl:207-248" in rt
+    bj = open(os.path.join(ROOT, "bench", "julia_reference.jl")).read()
+    assert "HPCG.build_p_matrix" in bj and "mul!(c, A, x)" in bj and "consistent!(x)" in bj
+    assert "hpcg_blocks_hip" in glue and "pa_hpcg_own_block_create" in glue
+

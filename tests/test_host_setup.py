@@ -156,9 +156,19 @@ def test_hand_partition_plans_match_oracle(orc, golden):
         assert ls.items[k].tolists() == ols[k].tolists() and lr.items[k].tolists() == olr[k].tolists()
 
 
-def test_compute_optimal_shape():
+def test_compute_optimal_shape(orc):
     assert [pa.compute_optimal_shape_XYZ(p) for p in (1, 2, 4, 8, 6, 3)] == \
         [(1, 1, 1), (2, 1, 1), (2, 2, 1), (2, 2, 2), (2, 3, 1), (3, 1, 1)]
+    # the general branch (HPCG/src/compute_optimal_xyz.jl:34-62, mixed_base_counter.jl): np with three or more prime factors and
+    # repeats.  The oracle restates the reference's counters statement by statement, the package deals the prime powers its own way:
+    # every np up to 600 agrees, and the shapes multiply out.  (No literal of this function exists in the reference's tests -- the
+    # values below are the restatement's, e.g. the C++ HPCG's well-known 24 -> 2 x 4 x 3 and 36 -> 4 x 3 x 3.)
+    for p in range(1, 601):
+        got = pa.compute_optimal_shape_XYZ(p)
+        assert got == orc.compute_optimal_shape_xyz(p), p
+        assert got[0] * got[1] * got[2] == p
+    assert [pa.compute_optimal_shape_XYZ(p) for p in (12, 24, 36, 48, 60, 120)] == \
+        [(2, 3, 2), (2, 4, 3), (4, 3, 3), (4, 4, 3), (4, 3, 5), (4, 6, 5)]
 
 
 def test_device_path_fails_loudly_without_gpu():
