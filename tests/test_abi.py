@@ -562,7 +562,7 @@ def test_julia_runtests_and_reference_bench_scripts_are_consistent_with_the_glue
     rt = open(os.path.join(ROOT, "partitionedarrays.jl_amd", "julia", "runtests.jl")).read()
     names = re.search(r"using \.PartitionedArraysHIP: ([^\n]+)", rt).group(1)
     for n in [x.strip() for x in names.split(",")]:
-        assert re.search(r"(?m)^(?:function |mutable struct |struct |const )?" + re.escape(n) + r"\b", glue) or \
+        assert re.search(r"(?m)^(?:function |mutable struct |struct |const )?" + re.escape(n) + r"(?=[\s({<:])", glue) or \
             re.search(r"(?m)^" + re.escape(n) + r"\(", glue), n
     for lit in ("[20.0, 20.0, 20.0, 0.0, 0.0, 0.0]", "[0.0, 20.0, 30.0, 0.0]", "[10.0, 30.0, 20.0, 0.0, 0.0, 0.0]", "[0.0, 0.0, 0.0, 10.0, 30.0]"):
         assert lit in rt
