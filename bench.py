@@ -615,6 +615,13 @@ def extra_configs(pa, ctx, L, out):
     e = entry("unstructured rows in a band BEYOND THE RING: 4 M rows x 16 entries, random columns within +-16000 of the diagonal, stored as a "
               "chain of column pieces (pa_csr_colsplit_if_wide), pa_spmv", bw, m, m, time_block(pa, ctx, L, bw, m, m), ts)
     e["x_window_launch"] = bw.xwin()
+    e["chain"] = bw.chain()
+    # (the same pieces a launch each, y written and re-read between them: round 4's way)
+    os.environ["PA_SPMV_CHAIN_FUSED"] = "0"
+    ctx.reload_env()
+    e["ms_a_launch_per_piece"] = time_block(pa, ctx, L, bw, m, m)
+    os.environ.pop("PA_SPMV_CHAIN_FUSED")
+    ctx.reload_env()
     out.append(e)
     del bw
     # a non-pattern FEM matrix (VERDICT r02 #6b): the Q1 mesh numbered at random, then renumbered by reverse Cuthill-McKee --

@@ -284,6 +284,10 @@ int pa_csr_create_transpose_ranked(const pa_csr *A, const int32_t *row_rank, pa_
 /* a scatter map back as destinations (0-based, -1 = skipped); checks that every slot adds its sources in ascending order (tests) */
 int pa_scatter_download(const pa_scatter *s, int32_t *dest);
 int pa_csr_create_colsplit(const pa_csr *A, int pieces, pa_csr **out);
+/* A column-split chain: *pieces = its pieces (0: A is not one), *groups_one_launch = workgroups of the ONE launch pa_spmv runs it as
+ * (the pieces' chunks and ring groups are cut at the same rows: a workgroup runs its rows through every piece and y reaches HBM
+ * once; PA_SPMV_CHAIN_FUSED=0: never), 0 = a launch per piece, y written and re-read between them. */
+int pa_csr_chain_info(const pa_csr *A, int32_t *pieces, int64_t *groups_one_launch);
 
 /* ---- introspection of a CSR block (what the row-split kernel reads; none of it is needed to use the block) ---------- */
 /* How the row-split chunks of A get their column indices (library-internal index compression; the values, the

@@ -34,6 +34,7 @@
 #include <cstring>
 #include <memory>
 #include <numeric>
+#include <iterator>
 #include <string>
 #include <vector>
 
@@ -43,6 +44,7 @@
 thread_local std::string g_pa_err;
 thread_local int pa_tls_plain_encoding = 0;   // > 0 while pa_matrix_fused_build makes its block: Int32 columns, nothing else
 thread_local int pa_tls_piece_build = 0;       // > 0 while pa_csr_colsplit_if_wide builds its pieces through csr_build
+thread_local const std::vector<int32_t> *pa_tls_row_breaks = nullptr;   // ... and the rows every piece's chunks and ring groups are cut at
 
 void pa_set_err(const char *fmt, ...) {
   char buf[512];
@@ -346,6 +348,7 @@ static void read_switches(pa_ctx *c) {
   c->sw.mul_fused_rccl = flag("PA_MUL_FUSED_RCCL", 1);
   c->sw.fused_tail_blocks = std::max(1, flag("PA_FUSED_TAIL_BLOCKS", 1024));
   c->sw.spmv_alternate = flag("PA_SPMV_ALTERNATE", 1);
+  c->sw.chain_fused = flag("PA_SPMV_CHAIN_FUSED", 1);
 }
 extern "C" int pa_ctx_reload_env(pa_ctx *c) {
   PA_REQUIRE(c != nullptr, "bad arguments");
@@ -1049,6 +1052,15 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   // the row split: on the device from the row pointers just uploaded (pointer doubling, pa_setup.hip) or the host's greedy loop
   if (on_device) PA_TRY(pa_dev_row_split(c, A->d_crp, nc, PA_SPMV_CHUNK_NNZ, 4096, 8, chunk_row, &n_long));
   else pa_build_chunks(crp.data(), nc, PA_SPMV_CHUNK_NNZ, 4096, chunk_row, &n_long);
+  if (pa_tls_piece_build && pa_tls_row_breaks && !compact) {
+    // a column piece of a chain meant for one launch: its chunks also end at the rows all pieces share (a chunk cut in two at a row
+    // boundary is two valid chunks)
+    std::vector<int32_t> merged;
+    merged.reserve(chunk_row.size() + pa_tls_row_breaks->size());
+    std::set_union(chunk_row.begin(), chunk_row.end(), pa_tls_row_breaks->begin(), pa_tls_row_breaks->end(), std::back_inserter(merged));
+    while (!merged.empty() && merged.back() > nc) merged.pop_back();
+    chunk_row.swap(merged);
+  }
   lap("chunks");
   A->n_chunks = (int64_t)chunk_row.size() - 1; A->n_long = n_long;
   PA_TRY(pa_dev_alloc(c, (void **)&A->d_chunk_row, sizeof(int32_t) * chunk_row.size(), PA_MEM_MATRIX));
@@ -1162,12 +1174,13 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
         S.cmin.resize(A->n_chunks); S.cmax.resize(A->n_chunks); S.lines.resize(A->n_chunks);
         PA_TRY(pa_dev_xw_chunk_stats(c, A->d_crp, A->d_col, A->d_chunk_row, A->d_win, A->n_chunks, PA_XR_CAP, S.cmin.data(),
                                      S.cmax.data(), S.lines.data()));
-        pa_plan_xw_from_stats(crp.data(), chunk_row, S, forced, P, ring);
+        pa_plan_xw_from_stats(crp.data(), chunk_row, S, forced, P, ring, pa_tls_piece_build ? pa_tls_row_breaks : nullptr);
         for (int64_t k = 0; k < A->n_chunks; ++k)
           if (S.cmax[k] >= 0) A->xw_max_span = std::max<int64_t>(A->xw_max_span, (int64_t)S.cmax[k] - S.cmin[k] + 1);
         cmax_host.swap(S.cmax);
       } else {
-        pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz), ring, &cmax_host);
+        pa_plan_xw(crp.data(), col0, chunk_row, cs.win.data(), forced, P, host_threads(nnz), ring, &cmax_host,
+                   pa_tls_piece_build ? pa_tls_row_breaks : nullptr);
       }
       const std::vector<pa_xw_group> &groups = P.groups;
       const std::vector<int32_t> &rest = P.rest;
@@ -1498,6 +1511,7 @@ static void csr_free_chain(pa_csr *A) {
     pa_dev_free(A->ctx, A->d_col);
     if (A->d_raw_col) pa_dev_free(A->ctx, A->d_raw_col);
     if (A->d_src) pa_dev_free(A->ctx, A->d_src);
+    if (A->d_chain) pa_dev_free(A->ctx, A->d_chain);
     pa_dev_free(A->ctx, A->d_val);
     pa_dev_free(A->ctx, A->d_chunk_row);
     if (A->d_chunk_rp) pa_dev_free(A->ctx, A->d_chunk_rp);
@@ -1986,6 +2000,20 @@ static int spmv_on(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int ys
     if (xlen) hipLaunchKernelGGL(k_axpby, dim3(grid_for(xlen, 256)), dim3(256), 0, st, c->d_xalpha[sx], xs_all, xlen, alpha, 0.0);
     xs_all = c->d_xalpha[sx];
     alpha = 1.0;
+  }
+  if (A->colsplit && A->d_chain && c->sw.chain_fused) {
+    // a column-split chain whose pieces share their row runs: one launch, y written once (k_spmv_xring_chain).  A piece that has
+    // gone over to the one-byte value stream in the meantime reads through k_spmv_rowsplit: then piece by piece as before.
+    bool ring = true;
+    for (const pa_csr *S = A; S; S = S->next) ring = ring && !S->use_vdict && S->n_xw_ring > 0;
+    if (ring) {
+      const int ng = (int)A->chain_groups, gpx = (ng + 7) / 8;
+      hipLaunchKernelGGL((k_spmv_xring_chain<2, 4, SPMV_NT, 512>), dim3(gpx * 8), dim3(1024), 0, st, (const pa_chain_piece *)A->d_chain,
+                         A->chain_pieces, xs_all, y->d + yoff, ng, gpx, (int)A->n_cols, alpha, beta);
+      ++c->n_chain_fused;
+      PA_HIP(hipGetLastError());
+      return PA_OK;
+    }
   }
   for (const pa_csr *S = A; S; S = S->next) {          // one slab unless the block has 2^31 stored entries or more
     double *ys = y->d + yoff + S->row0;

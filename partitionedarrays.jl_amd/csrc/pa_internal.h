@@ -49,10 +49,12 @@ struct pa_switches {
   int mul_fused_rccl = 1;     // PA_MUL_FUSED_RCCL: also over RCCL (the launch's tail acquires a flag the comm stream raises behind the receives)
   int fused_tail_blocks = 1024;  // PA_FUSED_TAIL_BLOCKS: tail blocks of a fused launch that may SPIN on arrival flags (ranks sharing one GPU: keep it small)
   int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
+  int chain_fused = 1;        // PA_SPMV_CHAIN_FUSED: a column-split chain is built for, and run as, one launch (k_spmv_xring_chain)
 };
 
 struct pa_ctx {
   pa_switches sw;
+  int64_t n_chain_fused = 0;                    // column-split chains run as one launch so far
   int64_t n_fused = 0, n_fused_exchange = 0;    // fused product launches so far / of those, with the exchange inside the launch
   bool keep_coo_slots = false;       // pa_coo_keep_input_slots: the assemblies remember where their input triplets went
   int device = 0;
@@ -178,6 +180,9 @@ struct pa_csr {
   bool colsplit = false;           // (head) the chain is a column split, not row slabs
   int32_t *d_src = nullptr;        // column split: original entry index of every stored entry (value updates, downloads)
   int64_t xw_max_span = 0;         // widest column span of a 16-bit chunk (what decides a column split)
+  void *d_chain = nullptr;         // (head of a column split) pa_chain_piece per piece: the pieces' ring groups cover the same rows, the
+  int64_t chain_groups = 0;        // chain runs as ONE launch of chain_groups workgroups (k_spmv_xring_chain, pa_spmv_xwin.h)
+  int chain_pieces = 0;
   int64_t t_rows = 0, t_nnz = 0;
 };
 

@@ -61,6 +61,7 @@ int pa_csr_create_remapped(const pa_csr *A, const int32_t *map, int64_t n_cols_n
 // d_src), else *out = NULL.  force_pieces > 0 (tests): that many pieces whatever the spans.
 int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces = 0);
 extern thread_local int pa_tls_piece_build;
+extern thread_local const std::vector<int32_t> *pa_tls_row_breaks;
 int pa_scatter_from_device_dest(pa_ctx *c, int64_t n_dst, int64_t n_src, const int32_t *d_dest, pa_scatter **out);
 
 // min / max of a device Int32 array (column range check of an uploaded block)

@@ -231,13 +231,17 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xwin(
 
 // BLK lanes work on one chunk (256 x 6 entries each as everywhere else, or 512 x 4 with the lanes past the chunk's 1536
 // entries idle: twice the waves on the CU for the same LDS)
-template <int SUB, int NPT, bool NT, bool DOT = false, int BLK = 256>
-__global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
+// One run of chunks (a ring group G) by the whole workgroup; the ring xs, the product slots and wsum are the caller's.  keep: y is
+// read again by THIS workgroup (the next column piece of a chain, k_spmv_xring_chain): a plain store that stays in L2 instead of
+// the streaming one.  Returns behind a barrier: the LDS is free.
+template <int SUB, int NPT, bool NT, bool DOT, int BLK>
+__device__ __forceinline__ void pa_xring_run(
+    double *__restrict__ xs, double *__restrict__ prod_all, double *__restrict__ wsum,
     const int *__restrict__ crp, const unsigned short *__restrict__ col16, const int *__restrict__ win,
     const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
     const int *__restrict__ chunk_row, const int *__restrict__ chunk_p, const int *__restrict__ chunk_cmax,
-    const pa_xw_group *__restrict__ grp, int n_groups, int groups_per_xcd, int n_cols, double alpha, double beta,
-    const double *__restrict__ u = nullptr, double *__restrict__ partial = nullptr) {
+    const pa_xw_group G, int n_cols, double alpha, double beta, const double *__restrict__ u, double *__restrict__ partial,
+    const bool keep) {
   constexpr int CAP = PA_SPMV_CHUNK_NNZ, NTHR = BLK * SUB, C = PA_XR_CAP;
   constexpr int PCAP = CAP + CAP / 16 + 2;
   // rows per pass of the row phase.  The fused dot must form a chunk's partial sum in k_spmv_rowsplit's order (lane t adds the rows
@@ -246,17 +250,10 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
   // chunks of short rows into the ring)
   constexpr int RB = DOT && BLK > 256 ? 256 : BLK;
   static_assert(BLK * NPT >= CAP, "the lanes of a sub-group cover a chunk");
-  __shared__ __attribute__((aligned(16))) double xs[C];
-  __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
-  __shared__ double wsum[SUB * (BLK / 64)];
   const int tid = threadIdx.x;
   const int t = tid & (BLK - 1);
   const int sub = __builtin_amdgcn_readfirstlane(tid / BLK);
   double *prod = prod_all + sub * PCAP;
-  const int b = blockIdx.x;
-  const int g = (b & 7) * groups_per_xcd + (b >> 3);
-  if (g >= n_groups || (b >> 3) >= groups_per_xcd) return;
-  const pa_xw_group G = grp[g];
   const int ch_end = G.first + G.cnt;
 
   d2 v[NPT / 2];
@@ -372,7 +369,8 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
           }
           dacc = dacc + (r == cr0 + t ? cur : u[r]) * pr;
         }
-        __builtin_nontemporal_store(acc, &y[r]);
+        if (keep) y[r] = acc;
+        else __builtin_nontemporal_store(acc, &y[r]);
       }
       if (DOT) {
         dacc = pa_wave_sum(dacc);
@@ -387,6 +385,53 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
       for (int w = 0; w < RB / 64; ++w) sum = sum + wsum[sub * (BLK / 64) + w];
       partial[ch] = sum;
     }
+  }
+}
+
+template <int SUB, int NPT, bool NT, bool DOT = false, int BLK = 256>
+__global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
+    const int *__restrict__ crp, const unsigned short *__restrict__ col16, const int *__restrict__ win,
+    const double *__restrict__ val, const double *__restrict__ x, double *__restrict__ y,
+    const int *__restrict__ chunk_row, const int *__restrict__ chunk_p, const int *__restrict__ chunk_cmax,
+    const pa_xw_group *__restrict__ grp, int n_groups, int groups_per_xcd, int n_cols, double alpha, double beta,
+    const double *__restrict__ u = nullptr, double *__restrict__ partial = nullptr) {
+  constexpr int PCAP = PA_SPMV_CHUNK_NNZ + PA_SPMV_CHUNK_NNZ / 16 + 2;
+  __shared__ __attribute__((aligned(16))) double xs[PA_XR_CAP];
+  __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
+  __shared__ double wsum[SUB * (BLK / 64)];
+  const int b = blockIdx.x;
+  const int g = (b & 7) * groups_per_xcd + (b >> 3);
+  if (g >= n_groups || (b >> 3) >= groups_per_xcd) return;
+  pa_xring_run<SUB, NPT, NT, DOT, BLK>(xs, prod_all, wsum, crp, col16, win, val, x, y, chunk_row, chunk_p, chunk_cmax, grp[g], n_cols,
+                                       alpha, beta, u, partial, false);
+}
+
+// ---- a column-split chain in ONE launch (round 5) ----------------------------------------------------------------
+// The pieces of a chain (pa_transpose.hip) hold all rows each; run as k launches, y goes to HBM and back between them.  When the
+// pieces' chunks and ring groups are cut at the SAME rows (pa_csr_colsplit_if_wide passes the row breaks to the chunker), group g of
+// every piece covers the same rows, and one workgroup runs group g of piece 0, then of piece 1, ...: the rows' partial sums are
+// stored plainly and read back by the same workgroup a piece later -- from L2 (a group's rows: ~16 K x 8 B), y reaches HBM once.
+// The products of a row are added in the order the separate launches add them (piece after piece, each onto the stored fp64 sum
+// of those before): the same bits.
+struct pa_chain_piece {
+  const int *crp; const unsigned short *col16; const int *win; const double *val;
+  const int *chunk_row, *chunk_p, *chunk_cmax; const pa_xw_group *grp;
+};
+template <int SUB, int NPT, bool NT, int BLK>
+__global__ __launch_bounds__(BLK * SUB) void k_spmv_xring_chain(const pa_chain_piece *__restrict__ pieces, int n_pieces,
+                                                               const double *__restrict__ x, double *__restrict__ y, int n_groups,
+                                                               int groups_per_xcd, int n_cols, double alpha, double beta) {
+  constexpr int PCAP = PA_SPMV_CHUNK_NNZ + PA_SPMV_CHUNK_NNZ / 16 + 2;
+  __shared__ __attribute__((aligned(16))) double xs[PA_XR_CAP];
+  __shared__ __attribute__((aligned(16))) double prod_all[SUB * PCAP];
+  __shared__ double wsum[SUB * (BLK / 64)];
+  const int b = blockIdx.x;
+  const int g = (b & 7) * groups_per_xcd + (b >> 3);
+  if (g >= n_groups || (b >> 3) >= groups_per_xcd) return;
+  for (int j = 0; j < n_pieces; ++j) {
+    const pa_chain_piece P = pieces[j];
+    pa_xring_run<SUB, NPT, NT, false, BLK>(xs, prod_all, wsum, P.crp, P.col16, P.win, P.val, x, y, P.chunk_row, P.chunk_p, P.chunk_cmax,
+                                           P.grp[g], n_cols, alpha, j == 0 ? beta : 1.0, nullptr, nullptr, j + 1 < n_pieces);
   }
 }
 
@@ -477,33 +522,45 @@ inline int64_t pa_build_xw_groups(const int32_t *crp, const std::vector<int32_t>
 // round being `sub` consecutive chunks counted from the run's first; conservatively, of the sub - 1 chunks after it too.
 inline int64_t pa_build_xring_groups(const int32_t *crp, const std::vector<int32_t> &chunk_row, const pa_xw_chunk_stats &S, int sub,
                                      std::vector<char> &taken, std::vector<pa_xw_group> &groups, int64_t *grouped_entries,
-                                     bool forced = false) {
+                                     bool forced = false, const std::vector<int32_t> *breaks = nullptr) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   const int C = PA_XR_CAP - 64;
   static const int64_t want = getenv("PA_SPMV_XRING_GROUPS") ? std::max(1, atoi(getenv("PA_SPMV_XRING_GROUPS"))) : PA_XR_WANT_GROUPS;
-  const int64_t maxg = std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XR_MAXG, (n_chunks + want - 1) / want));
+  // breaks (a column piece of a chain that is to run in one launch, k_spmv_xring_chain): a run ends where the next chunk starts on
+  // one of these rows and nowhere else -- every piece then has the same runs of rows.  A chunk without entries (the rows above the
+  // band's first column in the lowest piece) is part of its run there: the kernel writes beta * y for its rows.
+  const int64_t maxg = breaks ? PA_XR_MAXG : std::max<int64_t>(PA_XW_MING, std::min<int64_t>(PA_XR_MAXG, (n_chunks + want - 1) / want));
+  auto is_break = [&](int32_t row) { return breaks && std::binary_search(breaks->begin(), breaks->end(), row); };
+  auto usable = [&](int64_t k) {
+    if (taken[k]) return false;
+    if (S.cmax[k] >= 0) return true;
+    return breaks != nullptr && crp[chunk_row[k + 1]] == crp[chunk_row[k]];
+  };
   int64_t staged = 0;
   *grouped_entries = 0;
   int64_t c = 0;
   while (c < n_chunks) {
-    if (taken[c] || S.cmax[c] < 0) { ++c; continue; }
+    if (!usable(c)) { ++c; continue; }
     int64_t e = c;
     int32_t runmax = -1, wlo = INT32_MAX;
     int64_t touched = 0;
-    while (e < n_chunks && e - c < maxg && !taken[e] && S.cmax[e] >= 0) {
+    while (e < n_chunks && e - c < maxg && usable(e) && !(e > c && is_break(chunk_row[e]))) {
       const int32_t rm = std::max(runmax, S.cmax[e]);
       bool ok = true;
-      for (int64_t j = std::max(c, e - (sub - 1)); j <= e && ok; ++j) ok = (int64_t)rm - S.cmin[j] < C;
+      for (int64_t j = std::max(c, e - (sub - 1)); j <= e && ok; ++j) ok = S.cmax[j] < 0 || (int64_t)rm - S.cmin[j] < C;
       if (!ok) break;
       runmax = rm;
-      wlo = std::min(wlo, S.cmin[e]);
+      if (S.cmax[e] >= 0) wlo = std::min(wlo, S.cmin[e]);
       touched += S.lines[e];
       ++e;
     }
+    if (runmax < 0) wlo = 0;                         // (a run of empty chunks: nothing to stage)
     // worth it when the chunks' gathers are scattered (as for the windows) and the run is long enough to pay its first fill:
     // the x it loads in all (8 B per column of its span) at most the matrix bytes it streams (10 B per stored entry)
     const int64_t ent = e > c ? (int64_t)crp[chunk_row[e]] - crp[chunk_row[c]] : 0;
-    if (e - c >= PA_XW_MING && (forced || (touched >= (int64_t)PA_XW_MIN_LINES * (e - c) && (int64_t)(runmax - wlo + 1) * 8 <= ent * 10))) {
+    const bool take = breaks ? e > c
+                             : e - c >= PA_XW_MING && (forced || (touched >= (int64_t)PA_XW_MIN_LINES * (e - c) && (int64_t)(runmax - wlo + 1) * 8 <= ent * 10));
+    if (take) {
       groups.push_back(pa_xw_group{(int)c, (int)(e - c), wlo, runmax - wlo + 1});
       for (int64_t k = c; k < e; ++k) taken[k] = 1;
       staged += runmax - wlo + 1;
@@ -530,7 +587,7 @@ struct pa_xw_plan {
 // round -- against 5.1-5.9 on the 96 / 128 KiB windows and 7.4 on the 40 KiB ones where those fit, and against 3.05 on the
 // row split at +-7900, where nothing else fits), 2 = ring groups only
 inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t> &chunk_row, const pa_xw_chunk_stats &S, bool forced,
-                                  pa_xw_plan &P, int ring = 1) {
+                                  pa_xw_plan &P, int ring = 1, const std::vector<int32_t> *breaks = nullptr) {
   const int64_t n_chunks = (int64_t)chunk_row.size() - 1;
   P = pa_xw_plan();
   std::vector<char> taken(n_chunks, 0);
@@ -558,7 +615,7 @@ inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t>
   }
   if (ring >= 1) {
     int64_t grouped = 0;
-    const int64_t staged = pa_build_xring_groups(crp, chunk_row, S, 2, taken, ring_groups, &grouped, forced);
+    const int64_t staged = pa_build_xring_groups(crp, chunk_row, S, 2, taken, ring_groups, &grouped, forced, breaks);
     P.n_ring = (int64_t)ring_groups.size();
     P.staged += staged;
     P.grouped += grouped;
@@ -568,9 +625,10 @@ inline void pa_plan_xw_from_stats(const int32_t *crp, const std::vector<int32_t>
     if (!taken[c]) P.rest.push_back((int32_t)c);
 }
 inline void pa_plan_xw(const int32_t *crp, const int32_t *col, const std::vector<int32_t> &chunk_row, const int32_t *win,
-                       bool forced, pa_xw_plan &P, int n_threads = 1, int ring = 1, std::vector<int32_t> *cmax_out = nullptr) {
+                       bool forced, pa_xw_plan &P, int n_threads = 1, int ring = 1, std::vector<int32_t> *cmax_out = nullptr,
+                       const std::vector<int32_t> *breaks = nullptr) {
   pa_xw_chunk_stats S;
   pa_xw_scan_chunks(crp, col, chunk_row, win, PA_XR_CAP, n_threads, S);       // (spans up to the ring's capacity are counted)
-  pa_plan_xw_from_stats(crp, chunk_row, S, forced, P, ring);
+  pa_plan_xw_from_stats(crp, chunk_row, S, forced, P, ring, breaks);
   if (cmax_out) *cmax_out = S.cmax;
 }

@@ -603,6 +603,25 @@ int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces) {
   PA_HIP(hipGetLastError());
   sc.release(d_key); sc.release(d_ks); sc.release(d_iota);
   pa_csr *head = nullptr, *tail = nullptr;
+  // rows at which EVERY piece ends a chunk and a ring group (the chain then runs as one launch, k_spmv_xring_chain): equal shares of
+  // the block's entries, on multiples of 8 rows (64 bytes of y)
+  std::vector<int32_t> breaks;
+  if (c->sw.chain_fused && n_rows + 1 < ((int64_t)1 << 31)) {
+    std::vector<int32_t> hrp((size_t)n_rows + 1);
+    PA_TRY(d2h(s, hrp.data(), A->d_crp, (size_t)n_rows + 1));
+    static const int64_t want = getenv("PA_SPMV_XRING_GROUPS") ? std::max(1, atoi(getenv("PA_SPMV_XRING_GROUPS"))) : PA_XR_WANT_GROUPS;
+    const int64_t piece_chunks = std::max<int64_t>(1, nnz / k / PA_SPMV_CHUNK_NNZ);
+    const int64_t G = std::max<int64_t>(std::min<int64_t>(want, piece_chunks / 4), (piece_chunks + 799) / 800);
+    breaks.push_back(0);
+    for (int64_t g = 1; g < G; ++g) {
+      int64_t r = std::lower_bound(hrp.begin(), hrp.end(), (int32_t)(nnz * g / G)) - hrp.begin();
+      r &= ~(int64_t)7;
+      if (r > breaks.back() && r < n_rows) breaks.push_back((int32_t)r);
+    }
+    breaks.push_back((int32_t)n_rows);
+  }
+  struct tls_guard { ~tls_guard() { pa_tls_row_breaks = nullptr; } } guard;
+  pa_tls_row_breaks = breaks.size() > 1 ? &breaks : nullptr;
   auto fail = [&](int st) { if (head) pa_csr_destroy(head); return st; };
   for (int j = 0; j < k; ++j) {
     const int64_t cnt = (int64_t)first[j + 1] - first[j];
@@ -635,6 +654,42 @@ int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces) {
   head->colsplit = true;
   head->t_rows = A->t_rows; head->t_nnz = A->t_nnz;
   head->xw_max_span = A->xw_max_span;
+  // one launch for the chain when every piece is ring groups only and group g of every piece starts on the same row
+  if (breaks.size() > 1) {
+    bool aligned = true;
+    int64_t ng = -1;
+    std::vector<int32_t> rows0;
+    std::vector<pa_chain_piece> tab;
+    for (pa_csr *P = head; P && aligned; P = P->next) {
+      aligned = !P->compact && P->n_xw_ring > 0 && P->n_xw_groups == P->n_xw_ring && P->n_xw_rest == 0 && (ng < 0 || P->n_xw_ring == ng);
+      if (!aligned) break;
+      ng = P->n_xw_ring;
+      std::vector<pa_xw_group> g((size_t)ng);
+      std::vector<int32_t> cr((size_t)P->n_chunks + 1), r0((size_t)ng);
+      if (int st = d2h(s, (char *)g.data(), (const char *)P->d_xw_grp, sizeof(pa_xw_group) * (size_t)ng)) return fail(st);
+      if (int st = d2h(s, cr.data(), P->d_chunk_row, (size_t)P->n_chunks + 1)) return fail(st);
+      int64_t covered = 0;
+      for (int64_t i = 0; i < ng; ++i) {
+        r0[i] = cr[g[i].first];
+        covered += g[i].cnt;
+        if (i > 0 && g[i].first != g[i - 1].first + g[i - 1].cnt) aligned = false;
+      }
+      if (covered != P->n_chunks || (ng > 0 && g[0].first != 0)) aligned = false;
+      if (rows0.empty()) rows0.swap(r0);
+      else if (rows0 != r0) aligned = false;
+      tab.push_back(pa_chain_piece{P->d_crp, P->d_col16, P->d_win, P->d_val, P->d_chunk_row, P->d_chunk_p, P->d_chunk_cmax,
+                                   (const pa_xw_group *)P->d_xw_grp});
+    }
+    if (aligned && ng > 0 && (int)tab.size() == k) {
+      if (int st = pa_dev_alloc(c, &head->d_chain, sizeof(pa_chain_piece) * tab.size(), PA_MEM_MATRIX)) return fail(st);
+      if (hipMemcpyAsync(head->d_chain, tab.data(), sizeof(pa_chain_piece) * tab.size(), hipMemcpyHostToDevice, s) != hipSuccess ||
+          hipStreamSynchronize(s) != hipSuccess) { pa_set_err("column split: the chain table did not upload"); return fail(PA_ERR_HIP); }
+      head->chain_groups = ng;
+      head->chain_pieces = k;
+    }
+    if (getenv("PA_SETUP_TIMING")) fprintf(stderr, "[pa setup] column split: %d pieces, %lld row breaks, %s\n", k, (long long)breaks.size() - 1,
+                                            head->d_chain ? "one launch" : "a launch per piece");
+  }
   *out = head;
   return PA_OK;
 }
@@ -645,6 +700,15 @@ extern "C" int pa_csr_create_colsplit(const pa_csr *A, int pieces, pa_csr **out)
   PA_REQUIRE(!A->next, "the block is a chain already");
   PA_TRY(pa_csr_colsplit_if_wide(A, out, pieces));
   PA_REQUIRE(*out != nullptr, "the block could not be split");
+  return PA_OK;
+}
+
+extern "C" int pa_csr_chain_info(const pa_csr *A, int32_t *pieces, int64_t *groups_one_launch) {
+  PA_REQUIRE(A && pieces && groups_one_launch, "bad arguments");
+  *pieces = 0; *groups_one_launch = 0;
+  if (!A->colsplit) return PA_OK;
+  for (const pa_csr *S = A; S; S = S->next) ++*pieces;
+  if (A->d_chain && A->ctx->sw.chain_fused) *groups_one_launch = A->chain_groups;
   return PA_OK;
 }
 

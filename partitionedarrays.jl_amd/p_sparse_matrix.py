@@ -145,6 +145,13 @@ class DeviceCSR:
         L.call("pa_csr_xring_info", self.h, C.byref(r))
         return dict(zip(["groups", "chunks", "staged_x", "big_groups", "ring_groups"], [x.value for x in v] + [r.value]))
 
+    def chain(self):
+        """A column-split chain (pa_csr_chain_info): its pieces (0: not a chain) and the workgroups of the ONE launch the product runs
+        it as (0: a launch per piece)."""
+        p, g = C.c_int32(), C.c_int64()
+        L.call("pa_csr_chain_info", self.h, C.byref(p), C.byref(g))
+        return {"pieces": p.value, "groups_one_launch": g.value}
+
     def device_bytes(self):
         """HBM bytes the block occupies (pa_csr_device_bytes)."""
         n = C.c_int64()

@@ -25,6 +25,12 @@ def _rows(rng, m, n, per_row, band, ragged=False):
     return pa.HostCSR(m, n, rp, cv, rng.standard_normal(len(cv)))
 
 
+def _chain(B):
+    p, g = C.c_int32(), C.c_int64()
+    L.call("pa_csr_chain_info", B.h, C.byref(p), C.byref(g))
+    return p.value, g.value
+
+
 def _split(B, pieces):
     h = C.c_void_p()
     L.call("pa_csr_create_colsplit", B.h, pieces, C.byref(h))
@@ -84,14 +90,58 @@ def test_a_band_beyond_the_sliding_window_is_split_by_the_library(orc):
         B0 = pa.DeviceCSR(H)
     B = pa.DeviceCSR(H)
     assert B0.xwin()["ring_groups"] == 0 and B.xwin()["ring_groups"] > 0, (B0.xwin(), B.xwin())
+    pieces, groups = _chain(B)
+    assert pieces >= 2 and groups > 0, (pieces, groups)        # (round 5: the chain runs as ONE launch, y written once)
     x = rng.standard_normal(m)
     xd = pa.DeviceVector(m, 0).upload(x)
-    y, y0 = pa.DeviceVector(m, 0), pa.DeviceVector(m, 0)
+    y, y0, y1 = pa.DeviceVector(m, 0), pa.DeviceVector(m, 0), pa.DeviceVector(m, 0)
     pa.spmv_(y, B, xd)
     pa.spmv_(y0, B0, xd)
+    with env(PA_SPMV_CHAIN_FUSED="0"):                          # the same pieces, a launch each
+        assert _chain(B)[1] == 0
+        pa.spmv_(y1, B, xd)
     want = np.zeros(m)
     orc.oracle_c().spmv_csr(want, x, orc.CSR(m, m, H.rowptr, H.colval, H.nzval))
-    assert np.array_equal(y.download(), want) and np.array_equal(y0.download(), want)
+    assert np.array_equal(y.download(), want) and np.array_equal(y0.download(), want) and np.array_equal(y1.download(), want)
+
+
+@pytest.mark.parametrize("m,per_row,band,ragged,pieces", [(200_000, 12, 1500, False, 3), (150_000, 10, 2500, True, 2),
+                                                           (120_000, 16, 900, True, 5)])
+def test_a_chain_cut_at_shared_rows_runs_as_one_launch_with_the_same_bits(orc, m, per_row, band, ragged, pieces):
+    """Round 5.  The pieces' chunks and ring groups end at the same rows, so one workgroup takes its rows through every
+    piece and the partial sums never leave L2 (k_spmv_xring_chain).  Same additions in the same order as a launch per piece: the bits
+    of the unsplit block and of the oracle, for every (alpha, beta), after value updates, and with the rows above the band's first
+    column empty in the lowest piece."""
+    rng = np.random.default_rng(m + pieces)
+    lens = rng.integers(0, 2 * per_row, m) if ragged else np.full(m, per_row)
+    rows = np.repeat(np.arange(m, dtype=np.int64), lens)
+    cols = np.clip(rows + rng.integers(-band, band + 1, rows.size), 0, m - 1)
+    key = np.unique(rows * m + cols)
+    rows, cols = key // m, key % m
+    rp = (1 + np.concatenate(([0], np.cumsum(np.bincount(rows, minlength=m))))).astype(np.int32)
+    H = pa.HostCSR(m, m, rp, (cols + 1).astype(np.int32), rng.standard_normal(rows.size))
+    with env(PA_SPMV_COLSPLIT="0"):
+        B = pa.DeviceCSR(H)
+    S = _split(B, pieces)
+    got_pieces, groups = _chain(S)
+    assert got_pieces == pieces and groups > 1, (got_pieces, groups)
+    x, y0 = rng.standard_normal(m), rng.standard_normal(m)
+    xd = pa.DeviceVector(m, 0).upload(x)
+    oA = orc.CSR(m, m, H.rowptr, H.colval, H.nzval)
+    for alpha, beta in ((1.0, 0.0), (1.0, 1.0), (-0.7, 2.5)):
+        want = orc.oracle_c().mul5_csr(y0.copy(), oA, x, alpha, beta)
+        for fused in ("1", "0"):
+            with env(PA_SPMV_CHAIN_FUSED=fused):
+                yd = pa.DeviceVector(m, 0).upload(y0)
+                pa.spmv_(yd, S, xd, L.SEG_OWN, L.SEG_OWN, alpha, beta)
+                assert np.array_equal(yd.download(), want), (alpha, beta, fused)
+    new = rng.standard_normal(H.nnz)
+    B.update_values(new)
+    S.update_values(new)
+    ya, yb = pa.DeviceVector(m, 0), pa.DeviceVector(m, 0)
+    pa.spmv_(ya, B, xd)
+    pa.spmv_(yb, S, xd)
+    assert np.array_equal(ya.download(), yb.download())
 
 
 def test_fused_product_and_dot_on_a_column_split_chain(orc):
