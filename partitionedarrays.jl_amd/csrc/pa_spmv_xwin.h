@@ -413,10 +413,16 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring(
 // stored plainly and read back by the same workgroup a piece later -- from L2 (a group's rows: ~16 K x 8 B), y reaches HBM once.
 // The products of a row are added in the order the separate launches add them (piece after piece, each onto the stored fp64 sum
 // of those before): the same bits.
+// (the table holds ADDRESSES: a pointer loaded from memory is a generic pointer to the compiler -- flat loads, which count on both
+// wait counters and drain the LDS queue with every use -- where a kernel argument is known to point to global memory; pa_global
+// says so for these)
 struct pa_chain_piece {
-  const int *crp; const unsigned short *col16; const int *win; const double *val;
-  const int *chunk_row, *chunk_p, *chunk_cmax; const pa_xw_group *grp;
+  unsigned long long crp, col16, win, val, chunk_row, chunk_p, chunk_cmax, grp;
 };
+template <typename T>
+__device__ __forceinline__ const T *pa_global(unsigned long long a) {
+  return (const T *)(const T __attribute__((address_space(1))) *)a;
+}
 template <int SUB, int NPT, bool NT, int BLK>
 __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring_chain(const pa_chain_piece *__restrict__ pieces, int n_pieces,
                                                                const double *__restrict__ x, double *__restrict__ y, int n_groups,
@@ -430,8 +436,10 @@ __global__ __launch_bounds__(BLK * SUB) void k_spmv_xring_chain(const pa_chain_p
   if (g >= n_groups || (b >> 3) >= groups_per_xcd) return;
   for (int j = 0; j < n_pieces; ++j) {
     const pa_chain_piece P = pieces[j];
-    pa_xring_run<SUB, NPT, NT, false, BLK>(xs, prod_all, wsum, P.crp, P.col16, P.win, P.val, x, y, P.chunk_row, P.chunk_p, P.chunk_cmax,
-                                           P.grp[g], n_cols, alpha, j == 0 ? beta : 1.0, nullptr, nullptr, j + 1 < n_pieces);
+    pa_xring_run<SUB, NPT, NT, false, BLK>(xs, prod_all, wsum, pa_global<int>(P.crp), pa_global<unsigned short>(P.col16), pa_global<int>(P.win),
+                                           pa_global<double>(P.val), x, y, pa_global<int>(P.chunk_row), pa_global<int>(P.chunk_p),
+                                           pa_global<int>(P.chunk_cmax), pa_global<pa_xw_group>(P.grp)[g], n_cols, alpha, j == 0 ? beta : 1.0,
+                                           nullptr, nullptr, j + 1 < n_pieces);
   }
 }
 

@@ -677,8 +677,9 @@ int pa_csr_colsplit_if_wide(const pa_csr *A, pa_csr **out, int force_pieces) {
       if (covered != P->n_chunks || (ng > 0 && g[0].first != 0)) aligned = false;
       if (rows0.empty()) rows0.swap(r0);
       else if (rows0 != r0) aligned = false;
-      tab.push_back(pa_chain_piece{P->d_crp, P->d_col16, P->d_win, P->d_val, P->d_chunk_row, P->d_chunk_p, P->d_chunk_cmax,
-                                   (const pa_xw_group *)P->d_xw_grp});
+      auto adr = [](const void *q) { return (unsigned long long)(uintptr_t)q; };
+      tab.push_back(pa_chain_piece{adr(P->d_crp), adr(P->d_col16), adr(P->d_win), adr(P->d_val), adr(P->d_chunk_row), adr(P->d_chunk_p),
+                                   adr(P->d_chunk_cmax), adr(P->d_xw_grp)});
     }
     if (aligned && ng > 0 && (int)tab.size() == k) {
       if (int st = pa_dev_alloc(c, &head->d_chain, sizeof(pa_chain_piece) * tab.size(), PA_MEM_MATRIX)) return fail(st);
