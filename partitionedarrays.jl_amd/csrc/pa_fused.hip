@@ -31,7 +31,6 @@
 
 using namespace pa_util;
 
-extern thread_local int pa_tls_plain_encoding;   // pa_device.hip: blocks built now keep Int32 columns, no patterns / windows / dictionary
 
 // ---- bd: the boundary rows' block, built in HBM from the two blocks' own encodings ---------------------------------------------
 struct kf_block {                                  // what decoding a stored entry's column needs (kt_decode's arguments)

@@ -322,9 +322,18 @@ int pa_mul_fused_ipc(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double be
 bool pa_fused_ipc_fits(const pa_matrix *m);
 int pa_mul_fused_rccl(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double alpha, double beta);   // pa_fused.hip
 void pa_fused_plan_release(pa_plan *p);
-void pa_csr_before_product(const pa_csr *A);     // pa_device.hip: upkeep a product does first (the value dictionary's renewal)
+void pa_csr_before_product(const pa_csr *A);     // pa_csr.hip: upkeep a product does first (the value dictionary's renewal)
 // pa_push.hip: consistent!(v) of every part of this process COMPLETE with one launch on the compute stream -- the push kernel also
 // stores every delivered value into the receiving part's ghost entry (the unpack of src/p_vector.jl:603-611)
 int pa_exchange_push_unpack_one_stream(pa_plan *const *plans, int32_t n_parts, pa_vec *const *v);
+
+// ---- shared between the device units (pa_device.hip / pa_csr.hip / pa_mg.hip / pa_plan.hip / pa_fused.hip) ----------------------
+#define PA_SLOT_OK(s) ((s) >= 0 && (s) < PA_N_SLOTS)
+#define PA_COEF_OK(s) ((s) >= -1 && (s) < PA_N_SLOTS)
+extern thread_local int pa_tls_plain_encoding;   // pa_device.hip: > 0 while pa_matrix_fused_build makes its block (Int32 columns, nothing else)
+// pa_csr.hip: the product on a stream of the caller's choice; the x-window launches of one slab (u != NULL: with the fused dot)
+int pa_spmv_on(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int yseg, double alpha, double beta, hipStream_t st);
+void pa_launch_xwin(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta, const double *u, double *partial,
+                    hipStream_t st = nullptr);
 
 #endif

@@ -20,7 +20,7 @@
 
 using namespace pa_util;
 
-extern thread_local const pa_csr *pa_tls_vdict_parent;   // pa_device.hip
+extern thread_local const pa_csr *pa_tls_vdict_parent;   // pa_csr.hip
 
 // per row of the (possibly row-compacted) block: where its entries start and how many there are
 __global__ void kr_spans(const int32_t *__restrict__ crp, const int32_t *__restrict__ row_ids, int nc, int32_t *__restrict__ start,
@@ -271,7 +271,7 @@ static int select_rows_impl(const pa_csr *oo, const pa_csr *oh, const int32_t *m
       st = d2h(s, crp.data(), d_crp, crp.size());
     } else st = d2h(s, crp.data(), d_rp, crp.size());
     if (st != PA_OK || hipGetLastError() != hipSuccess) { st = PA_ERR_HIP; break; }
-    // (a subset of own|own's rows holds own|own's values: it takes that block's value dictionary -- pa_device.hip, vdict_build)
+    // (a subset of own|own's rows holds own|own's values: it takes that block's value dictionary -- pa_csr.hip, vdict_build)
     pa_tls_vdict_parent = (!oh && oo->use_vdict) ? oo : nullptr;
     st = pa_csr_from_device_rows(c, n, n_cols, (int64_t)tot[k], n_nonempty, crp, compact ? d_ids : nullptr, d_col, d_val, &out[k]);
     pa_tls_vdict_parent = nullptr;
@@ -317,7 +317,7 @@ extern "C" int pa_csr_diagonal(const pa_csr *oo, pa_vec *d) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The level-scheduled Gauss-Seidel smoother (pa_gs, pa_device.hip) from the blocks already in HBM: the unsplit local CSR by
+// The level-scheduled Gauss-Seidel smoother (pa_gs, pa_mg.hip) from the blocks already in HBM: the unsplit local CSR by
 // the kernels above (one subset: every row), the diagonal, and the dependency levels of the sequential sweep
 // (PartitionedSolvers/src/smoothers.jl:144-160: row i needs every own column j < i) by rounds over the rows whose lower
 // neighbours are all done -- level(i) = 1 + max level(j), the same numbers as pa_gs_create's loop over the rows in order.

@@ -41,7 +41,7 @@ int pa_dev_row_split(pa_ctx *c, const int32_t *d_crp, int64_t nc, int cap, int m
 int pa_dev_xw_chunk_stats(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int32_t *d_chunk_row, const int32_t *d_win,
                           int64_t n_chunks, int max_cap, int32_t *cmin, int32_t *cmax, int32_t *lines);
 
-// pa_device.hip: a pa_csr from entries that are already in HBM (0-based; the arrays are copied, the caller keeps its own)
+// pa_csr.hip: a pa_csr from entries that are already in HBM (0-based; the arrays are copied, the caller keeps its own)
 int pa_csr_from_device(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t *d_rowptr, const int32_t *d_col,
                        const double *d_val, pa_csr **out);
 

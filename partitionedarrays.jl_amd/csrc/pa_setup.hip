@@ -1,6 +1,6 @@
 // pa_setup.hip -- device-side set-up of a block's column encodings.
 //
-// What csr_fill_slab (pa_device.hip) used to do with host threads over the block's 1-based arrays -- row-pattern
+// What csr_fill_slab (pa_csr.hip) used to do with host threads over the block's 1-based arrays -- row-pattern
 // detection, the windowed 16-bit column stream, the compacted 32-bit stream (pa_encode_columns, pa_spmv_kernel.h) -- as
 // kernels over the raw CSR already in HBM.  The result is the host encoder's, array for array: the same pattern table
 // (ids in order of the first row that shows the pattern, at most 4096, patterns shared by fewer than 2 rows left out),

@@ -1,5 +1,5 @@
 // pa_spmv_kernel.h -- the row-split CSR SpMV kernel (K1/K2) and its host-side row split.
-// Shared by pa_device.hip (the product) and tools/probe/spmv_probe.hip (A/B tuning harness).
+// Shared by pa_csr.hip (the product), pa_mg.hip (smoother / restriction epilogues), pa_plan.hip (product + dot), pa_fused.hip and tools/probe/spmv_probe.hip.
 //
 // Reference loops: spmv_csr! src/sparse_utils.jl:649-669; muladd! src/p_sparse_matrix.jl:2088.
 // Must be compiled with -ffp-contract=off (one rounding per multiply and per add).

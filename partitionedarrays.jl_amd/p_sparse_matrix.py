@@ -4,7 +4,7 @@ Mirrors /root/reference/src/p_sparse_matrix.jl for the hot path:
     PSparseMatrix (:971), SplitMatrix blocks (:588-627), psparse(...;assembled=true) (:1249-1270),
     split_format_locally (:823-899), mul!(c,a,b) (:2090-2103), mul!(c,a,b,alpha,beta) (:2105-2142),
 and the local kernels of src/sparse_utils.jl (compresscoo :313-350, spmv! :609-669), which here are
-native host code (csrc/pa_host.cpp) and HIP kernels (csrc/pa_device.hip).
+native host code (csrc/pa_host.cpp) and HIP kernels (csrc/pa_csr.hip, csrc/pa_plan.hip).
 """
 from __future__ import annotations
 
