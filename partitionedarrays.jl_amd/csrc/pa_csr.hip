@@ -227,10 +227,10 @@ static int vdict_after_update(pa_csr *A) {
     PA_REQUIRE(!S->ctx->capturing, "values of a block whose product is already recorded must not be updated inside a capture");
     S->vdict_dead = false;
     PA_TRY(vdict_build(S->ctx, S, true));
-    if (!S->use_vdict) {
+    if (!S->use_vdict || (S->vd_captured_two && S->n_dict > 2)) {
       pa_set_err("the new values take more than %d distinct bit patterns, but a recorded hipGraph multiplies through this block's "
-                 "value dictionary: record the graph again (pa_graph_begin / pa_graph_end)", PA_VDICT_MAX);
-      S->vd_captured = false;
+                 "value dictionary: record the graph again (pa_graph_begin / pa_graph_end)", S->use_vdict ? 2 : PA_VDICT_MAX);
+      S->vd_captured = false; S->vd_captured_two = false;
       return PA_ERR_STATE;
     }
   }
@@ -1203,23 +1203,24 @@ static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, doub
                              (const double *)nullptr, (const double *)nullptr, S->d_code, S->d_dict, (const int *)nullptr,
                              (int)S->n_cols - 1);
       } else if (S->use_vdict) {
-        if (S->ctx->capturing) const_cast<pa_csr *>(S)->vd_captured = true;
+        const bool vd_two = pa_vd_two(S);
+        if (S->ctx->capturing) { const_cast<pa_csr *>(S)->vd_captured = true; if (vd_two) const_cast<pa_csr *>(S)->vd_captured_two = true; }
         switch (sel_) {
-          case 5: PA_LAUNCH_SPMV(true, 2, true); break;
-          case 4: PA_LAUNCH_SPMV(false, 2, true); break;
-          case 3: PA_LAUNCH_SPMV(true, 1, true); break;
-          case 2: PA_LAUNCH_SPMV(false, 1, true); break;
-          case 1: PA_LAUNCH_SPMV(true, 0, true); break;
-          default: PA_LAUNCH_SPMV(false, 0, true); break;
+          case 5: if (vd_two) PA_LAUNCH_SPMV(true, 2, 2); else PA_LAUNCH_SPMV(true, 2, 1); break;
+          case 4: if (vd_two) PA_LAUNCH_SPMV(false, 2, 2); else PA_LAUNCH_SPMV(false, 2, 1); break;
+          case 3: if (vd_two) PA_LAUNCH_SPMV(true, 1, 2); else PA_LAUNCH_SPMV(true, 1, 1); break;
+          case 2: if (vd_two) PA_LAUNCH_SPMV(false, 1, 2); else PA_LAUNCH_SPMV(false, 1, 1); break;
+          case 1: if (vd_two) PA_LAUNCH_SPMV(true, 0, 2); else PA_LAUNCH_SPMV(true, 0, 1); break;
+          default: if (vd_two) PA_LAUNCH_SPMV(false, 0, 2); else PA_LAUNCH_SPMV(false, 0, 1); break;
         }
       } else {
         switch (sel_) {
-          case 5: PA_LAUNCH_SPMV(true, 2, false); break;
-          case 4: PA_LAUNCH_SPMV(false, 2, false); break;
-          case 3: PA_LAUNCH_SPMV(true, 1, false); break;
-          case 2: PA_LAUNCH_SPMV(false, 1, false); break;
-          case 1: PA_LAUNCH_SPMV(true, 0, false); break;
-          default: PA_LAUNCH_SPMV(false, 0, false); break;
+          case 5: PA_LAUNCH_SPMV(true, 2, 0); break;
+          case 4: PA_LAUNCH_SPMV(false, 2, 0); break;
+          case 3: PA_LAUNCH_SPMV(true, 1, 0); break;
+          case 2: PA_LAUNCH_SPMV(false, 1, 0); break;
+          case 1: PA_LAUNCH_SPMV(true, 0, 0); break;
+          default: PA_LAUNCH_SPMV(false, 0, 0); break;
         }
       }
 #undef PA_LAUNCH_SPMV
@@ -1407,23 +1408,24 @@ static void gs_color_launch(pa_ctx *c, const pa_csr *A, pa_vec *x, const pa_vec 
                      (const int *)nullptr, (int)A->n_cols - 1)
   const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
   if (A->use_vdict) {
-    if (c->capturing) const_cast<pa_csr *>(A)->vd_captured = true;
+    const bool vd_two = pa_vd_two(A);
+    if (c->capturing) { const_cast<pa_csr *>(A)->vd_captured = true; if (vd_two) const_cast<pa_csr *>(A)->vd_captured_two = true; }
     switch (sel_) {
-      case 5: PA_LAUNCH_GS(true, 2, true); break;
-      case 4: PA_LAUNCH_GS(false, 2, true); break;
-      case 3: PA_LAUNCH_GS(true, 1, true); break;
-      case 2: PA_LAUNCH_GS(false, 1, true); break;
-      case 1: PA_LAUNCH_GS(true, 0, true); break;
-      default: PA_LAUNCH_GS(false, 0, true); break;
+      case 5: if (vd_two) PA_LAUNCH_GS(true, 2, 2); else PA_LAUNCH_GS(true, 2, 1); break;
+      case 4: if (vd_two) PA_LAUNCH_GS(false, 2, 2); else PA_LAUNCH_GS(false, 2, 1); break;
+      case 3: if (vd_two) PA_LAUNCH_GS(true, 1, 2); else PA_LAUNCH_GS(true, 1, 1); break;
+      case 2: if (vd_two) PA_LAUNCH_GS(false, 1, 2); else PA_LAUNCH_GS(false, 1, 1); break;
+      case 1: if (vd_two) PA_LAUNCH_GS(true, 0, 2); else PA_LAUNCH_GS(true, 0, 1); break;
+      default: if (vd_two) PA_LAUNCH_GS(false, 0, 2); else PA_LAUNCH_GS(false, 0, 1); break;
     }
   } else {
     switch (sel_) {
-      case 5: PA_LAUNCH_GS(true, 2, false); break;
-      case 4: PA_LAUNCH_GS(false, 2, false); break;
-      case 3: PA_LAUNCH_GS(true, 1, false); break;
-      case 2: PA_LAUNCH_GS(false, 1, false); break;
-      case 1: PA_LAUNCH_GS(true, 0, false); break;
-      default: PA_LAUNCH_GS(false, 0, false); break;
+      case 5: PA_LAUNCH_GS(true, 2, 0); break;
+      case 4: PA_LAUNCH_GS(false, 2, 0); break;
+      case 3: PA_LAUNCH_GS(true, 1, 0); break;
+      case 2: PA_LAUNCH_GS(false, 1, 0); break;
+      case 1: PA_LAUNCH_GS(true, 0, 0); break;
+      default: PA_LAUNCH_GS(false, 0, 0); break;
     }
   }
 #undef PA_LAUNCH_GS

@@ -87,6 +87,7 @@ static void read_switches(pa_ctx *c) {
   c->sw.fused_tail_blocks = std::max(1, flag("PA_FUSED_TAIL_BLOCKS", 1024));
   c->sw.spmv_alternate = flag("PA_SPMV_ALTERNATE", 1);
   c->sw.chain_fused = flag("PA_SPMV_CHAIN_FUSED", 1);
+  c->sw.vd_select = flag("PA_SPMV_VDICT_SELECT", 1);
 }
 extern "C" int pa_ctx_reload_env(pa_ctx *c) {
   PA_REQUIRE(c != nullptr, "bad arguments");

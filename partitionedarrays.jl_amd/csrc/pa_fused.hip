@@ -226,7 +226,7 @@ struct pa_fused_args {
 // happen at all -- RCCL's receive kernels on the comm stream; with SEVERAL RANKS ON ONE GPU (the tests, never a production run) the
 // other ranks' launches with their pushing blocks, which is why those runs set it to a few dozen.  A neighbour that is ahead or in
 // step costs no spinning at all: the tail is dispatched ~a product's duration after the launch began, its flags are long raised.
-template <bool C16, int PAT, bool VD, bool XCH>
+template <bool C16, int PAT, int VD, bool XCH>
 __global__ __launch_bounds__(256) void k_mul_fused(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta, const double *__restrict__ val,
@@ -327,18 +327,19 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double
                      S->d_win, S->d_pdesc, S->d_pdelta, S->d_val, (const double *)b->d, c->d, S->d_chunk_rp, (int)S->n_chunks, cpx,   \
                      alpha, beta, S->d_code, S->d_dict, (int)S->n_cols - 1, F)
   const int sel = (S->use_pattern ? 4 : 0) + (S->use_c16 ? 2 : 0) + (S->use_vdict ? 1 : 0);
-  if (S->use_vdict && m->ctx->capturing) const_cast<pa_csr *>(S)->vd_captured = true;
+  const bool vd_two = pa_vd_two(S);
+  if (S->use_vdict && m->ctx->capturing) { const_cast<pa_csr *>(S)->vd_captured = true; if (vd_two) const_cast<pa_csr *>(S)->vd_captured_two = true; }
 #define PA_FUSED_CASES(XCH_)                                \
   { constexpr bool XCH = XCH_;                              \
     switch (sel) {                                          \
-      case 7: PA_LAUNCH_FUSED(true, 1, true); break;        \
-      case 6: PA_LAUNCH_FUSED(true, 1, false); break;       \
-      case 5: PA_LAUNCH_FUSED(false, 1, true); break;       \
-      case 4: PA_LAUNCH_FUSED(false, 1, false); break;      \
-      case 3: PA_LAUNCH_FUSED(true, 0, true); break;        \
-      case 2: PA_LAUNCH_FUSED(true, 0, false); break;       \
-      case 1: PA_LAUNCH_FUSED(false, 0, true); break;       \
-      default: PA_LAUNCH_FUSED(false, 0, false); break;     \
+      case 7: if (vd_two) PA_LAUNCH_FUSED(true, 1, 2); else PA_LAUNCH_FUSED(true, 1, 1); break;        \
+      case 6: PA_LAUNCH_FUSED(true, 1, 0); break;       \
+      case 5: if (vd_two) PA_LAUNCH_FUSED(false, 1, 2); else PA_LAUNCH_FUSED(false, 1, 1); break;       \
+      case 4: PA_LAUNCH_FUSED(false, 1, 0); break;      \
+      case 3: if (vd_two) PA_LAUNCH_FUSED(true, 0, 2); else PA_LAUNCH_FUSED(true, 0, 1); break;        \
+      case 2: PA_LAUNCH_FUSED(true, 0, 0); break;       \
+      case 1: if (vd_two) PA_LAUNCH_FUSED(false, 0, 2); else PA_LAUNCH_FUSED(false, 0, 1); break;       \
+      default: PA_LAUNCH_FUSED(false, 0, 0); break;     \
     } }
   if (comm) PA_FUSED_CASES(true) else PA_FUSED_CASES(false)
 #undef PA_FUSED_CASES

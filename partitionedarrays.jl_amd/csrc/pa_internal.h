@@ -49,6 +49,7 @@ struct pa_switches {
   int mul_fused_rccl = 1;     // PA_MUL_FUSED_RCCL: also over RCCL (the launch's tail acquires a flag the comm stream raises behind the receives)
   int fused_tail_blocks = 1024;  // PA_FUSED_TAIL_BLOCKS: tail blocks of a fused launch that may SPIN on arrival flags (ranks sharing one GPU: keep it small)
   int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
+  int vd_select = 1;          // PA_SPMV_VDICT_SELECT: a dictionary of at most two values is decoded by a select, not through the lane dictionary
   int chain_fused = 1;        // PA_SPMV_CHAIN_FUSED: a column-split chain is built for, and run as, one launch (k_spmv_xring_chain)
 };
 
@@ -154,6 +155,7 @@ struct pa_csr {
   int vdict_products = 0;          // products served since the values changed
   bool vd_captured = false;        // a product of this slab on the one-byte stream has been recorded into a hipGraph: the codes
                                    // must follow every value update AT ONCE (the replay reads them), not eight products later
+  bool vd_captured_two = false;    // ... and through the kernel that decodes a dictionary of at most TWO values by a select (VD = 2)
   uint64_t val_epoch = 0;          // (head) bumped by every value update: what derived blocks (pa_matrix::oh_rb) compare with
   int n_dict = 0;
   uint8_t *d_code = nullptr;       // one byte per stored entry (padded)
@@ -331,6 +333,8 @@ int pa_exchange_push_unpack_one_stream(pa_plan *const *plans, int32_t n_parts, p
 #define PA_SLOT_OK(s) ((s) >= 0 && (s) < PA_N_SLOTS)
 #define PA_COEF_OK(s) ((s) >= -1 && (s) < PA_N_SLOTS)
 extern thread_local int pa_tls_plain_encoding;   // pa_device.hip: > 0 while pa_matrix_fused_build makes its block (Int32 columns, nothing else)
+// which decode of the one-byte value stream a launch on this block takes (VD = 2: at most two values, a select per entry)
+static inline bool pa_vd_two(const pa_csr *S) { return S->use_vdict && S->n_dict <= 2 && S->ctx->sw.vd_select; }
 // pa_csr.hip: the product on a stream of the caller's choice; the x-window launches of one slab (u != NULL: with the fused dot)
 int pa_spmv_on(const pa_csr *A, const pa_vec *x, int xseg, pa_vec *y, int yseg, double alpha, double beta, hipStream_t st);
 void pa_launch_xwin(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta, const double *u, double *partial,

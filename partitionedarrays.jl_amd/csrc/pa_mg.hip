@@ -280,23 +280,24 @@ extern "C" int pa_transfer_restrict_fused(pa_transfer *t, pa_vec *rc, const pa_v
                      (const int *)nullptr, (int)A->n_cols - 1)
   const int sel_ = (A->use_pattern ? (A->compact ? 2 : 1) : 0) * 2 + (A->use_c16 ? 1 : 0);
   if (A->use_vdict) {
-    if (c->capturing) const_cast<pa_csr *>(A)->vd_captured = true;
+    const bool vd_two = pa_vd_two(A);
+    if (c->capturing) { const_cast<pa_csr *>(A)->vd_captured = true; if (vd_two) const_cast<pa_csr *>(A)->vd_captured_two = true; }
     switch (sel_) {
-      case 5: PA_LAUNCH_RR(true, 2, true); break;
-      case 4: PA_LAUNCH_RR(false, 2, true); break;
-      case 3: PA_LAUNCH_RR(true, 1, true); break;
-      case 2: PA_LAUNCH_RR(false, 1, true); break;
-      case 1: PA_LAUNCH_RR(true, 0, true); break;
-      default: PA_LAUNCH_RR(false, 0, true); break;
+      case 5: if (vd_two) PA_LAUNCH_RR(true, 2, 2); else PA_LAUNCH_RR(true, 2, 1); break;
+      case 4: if (vd_two) PA_LAUNCH_RR(false, 2, 2); else PA_LAUNCH_RR(false, 2, 1); break;
+      case 3: if (vd_two) PA_LAUNCH_RR(true, 1, 2); else PA_LAUNCH_RR(true, 1, 1); break;
+      case 2: if (vd_two) PA_LAUNCH_RR(false, 1, 2); else PA_LAUNCH_RR(false, 1, 1); break;
+      case 1: if (vd_two) PA_LAUNCH_RR(true, 0, 2); else PA_LAUNCH_RR(true, 0, 1); break;
+      default: if (vd_two) PA_LAUNCH_RR(false, 0, 2); else PA_LAUNCH_RR(false, 0, 1); break;
     }
   } else {
     switch (sel_) {
-      case 5: PA_LAUNCH_RR(true, 2, false); break;
-      case 4: PA_LAUNCH_RR(false, 2, false); break;
-      case 3: PA_LAUNCH_RR(true, 1, false); break;
-      case 2: PA_LAUNCH_RR(false, 1, false); break;
-      case 1: PA_LAUNCH_RR(true, 0, false); break;
-      default: PA_LAUNCH_RR(false, 0, false); break;
+      case 5: PA_LAUNCH_RR(true, 2, 0); break;
+      case 4: PA_LAUNCH_RR(false, 2, 0); break;
+      case 3: PA_LAUNCH_RR(true, 1, 0); break;
+      case 2: PA_LAUNCH_RR(false, 1, 0); break;
+      case 1: PA_LAUNCH_RR(true, 0, 0); break;
+      default: PA_LAUNCH_RR(false, 0, 0); break;
     }
   }
 #undef PA_LAUNCH_RR

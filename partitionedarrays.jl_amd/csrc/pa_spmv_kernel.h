@@ -146,11 +146,15 @@ __device__ __forceinline__ double pa_wave_sum(double v) {
 //        keeps one byte per entry (`code`) and the values in `dict`; lane l holds dict[l] and an entry's value is fetched
 //        from the lane that holds it with ds_bpermute -- 1 byte of matrix stream per entry instead of 8.  The 27-point
 //        HPCG operator has 2 distinct values, a Q1 stiffness matrix on a uniform grid about a dozen.
+//        VD = 2: a dictionary of at most two values, decoded by a select (no LDS traffic).
 #define PA_VDICT_MAX 64
 
 // ---- hook points (empty in the product; see the comment at the top) ------------------------------------------------------
 #ifndef PA_HOOK_CHUNK_MAP            /* blockIdx -> chunk: the product's XCD-aware map */
 #define PA_HOOK_CHUNK_MAP 0
+#endif
+#ifndef PA_HOOK_STAMP                /* phase k of a workgroup's life reached (the lab records the time) */
+#define PA_HOOK_STAMP(k, ...)
 #endif
 #ifndef PA_HOOK_PATTERN_COLS         /* after a pair of pattern columns has been decoded */
 #define PA_HOOK_PATTERN_COLS(c0, c1, r0, r1, tid)
@@ -181,7 +185,7 @@ struct pa_fx {
 };
 
 // one chunk of the row split (everything k_spmv_rowsplit does once it knows its chunk); prod / wsum: the workgroup's LDS
-template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI, bool VD, int UNR, bool PADP, int FX>
+template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI, int VD, int UNR, bool PADP, int FX>
 __device__ __forceinline__ void pa_rowsplit_chunk(
     double *prod, double *wsum, const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
@@ -204,6 +208,7 @@ __device__ __forceinline__ void pa_rowsplit_chunk(
   const int r0 = chunk_rp[2 * chunk], p0 = chunk_rp[2 * chunk + 1];
   const int r1 = chunk_rp[2 * chunk + 2], p1 = chunk_rp[2 * chunk + 3];
   const int base = p0 & ~1;  // 16-byte aligned value pairs, 4-byte aligned c16 pairs
+  PA_HOOK_STAMP(1, p1);
 
   // The body of a chunk, once per column encoding (MODE 2: row patterns, 1: 16-bit windowed stream, 0: 32-bit columns): each copy
   // runs from its first load to the end of the kernel and the copies never meet again.  (Round 5.  As one body with the encodings
@@ -221,11 +226,13 @@ __device__ __forceinline__ void pa_rowsplit_chunk(
     unsigned cc[NPT / 2];
     int c0[NPT / 2], c1[NPT / 2];
     int dict_lo = 0, dict_hi = 0;
-    if (VD) {
+    double d0 = 0.0, d1 = 0.0;
+    if (VD == 1) {
       const double dv = dict[tid & 63];
       dict_lo = __double2loint(dv);
       dict_hi = __double2hiint(dv);
     }
+    if (VD == 2) { d0 = dict[0]; d1 = dict[1]; }        // (scalar loads: the same two values for every lane)
     // the order of the requests is the order their answers are waited for: what the decode needs (pattern deltas: an L2 hit),
     // the value stream (HBM; the wait for the deltas leaves it in flight), my row's extent (needed by the row sums only)
     int dA = 0, dB = 0;
@@ -323,12 +330,22 @@ __device__ __forceinline__ void pa_rowsplit_chunk(
     if (FX == 1) mword = fx.rowmask[rmine >> 5];  // (non-compact block: row = stored row)
     double urow = 0.0;
     if (EPI == 3) urow = gs_b[row_ids ? row_ids[rmine] : rmine];
-    if (VD) {
+    if (VD == 1) {
 #pragma unroll
       for (int k = 0; k < NPT / 2; ++k) {
         const int s0 = (cc[k] & 0xffu) << 2, s1 = (cc[k] >> 8) << 2;
         v[k].x = __hiloint2double(__builtin_amdgcn_ds_bpermute(s0, dict_hi), __builtin_amdgcn_ds_bpermute(s0, dict_lo));
         v[k].y = __hiloint2double(__builtin_amdgcn_ds_bpermute(s1, dict_hi), __builtin_amdgcn_ds_bpermute(s1, dict_lo));
+      }
+    }
+    if (VD == 2) {
+      // Two stored values (HPCG's operator: 26 and -1): a select per entry.  The lane dictionary's four ds_bpermute per pair were
+      // half of this kernel's LDS instructions, and on the one-byte stream it is the LDS pipe that is busy (SQ_ACTIVE_INST_LDS x
+      // resident waves = 0.9 of the launch, profiles/r05_k1_sq.json), not the vector ALU.
+#pragma unroll
+      for (int k = 0; k < NPT / 2; ++k) {
+        v[k].x = (cc[k] & 0xffu) ? d1 : d0;
+        v[k].y = (cc[k] >> 8) ? d1 : d0;
       }
     }
     PA_HOOK_X_STAGE(x, r0, r1, tid);
@@ -349,9 +366,11 @@ __device__ __forceinline__ void pa_rowsplit_chunk(
     // first LDS write and measured 3 % slower, 0.707 against 0.684 ms)
 #pragma unroll
     for (int k = 0; k < NPT / 2; ++k) if (alpha != 1.0) { v[k].x = v[k].x * alpha; v[k].y = v[k].y * alpha; }
+    PA_HOOK_STAMP(2, v[0].x, v[NPT / 2 - 1].y);
 #pragma unroll
     for (int k = 0; k < NPT / 2; ++k) *reinterpret_cast<d2 *>(&prod[PA_PSLOT((k * BLK + tid) * 2)]) = v[k];
     __syncthreads();
+    PA_HOOK_STAMP(3, 0);
     PA_HOOK_ALT_REDUCE();
     double dacc = 0.0;                       // EPI 3: this lane's share of the dot product
     for (int r = r0 + tid; r < r1; r += BLK) {
@@ -384,6 +403,7 @@ __device__ __forceinline__ void pa_rowsplit_chunk(
       else if (EPI == 0) __builtin_nontemporal_store(acc, &y[row]);
       else { PA_HOOK_STORE_Y(EPI, y, row, acc); }
     }
+    PA_HOOK_STAMP(4, 0);
     if (EPI == 3) {
       dacc = pa_wave_sum(dacc);
       if (r1 - r0 <= 64) {                   // (block-uniform) every row sat in wavefront 0: the other three just leave
@@ -446,7 +466,7 @@ __device__ __forceinline__ void pa_rowsplit_chunk(
 
 #undef PA_PSLOT
 
-template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, bool VD = false, int UNR = 4, bool PADP = false>
+template <int BLK, int NPT, bool NT, bool C16, int PAT, int EPI = 0, int VD = 0, int UNR = 4, bool PADP = false>
 __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
     const int *__restrict__ crp, const int *__restrict__ col, const unsigned short *__restrict__ col16,
     const int *__restrict__ win, const int *__restrict__ pdesc, const int *__restrict__ pdelta,
@@ -463,6 +483,7 @@ __global__ __launch_bounds__(BLK) void k_spmv_rowsplit(
   // per block (pa_csr::pad_products).
   __shared__ __attribute__((aligned(16))) double prod[PADP ? CAP + CAP / 16 + 2 : CAP];
   __shared__ double wsum[EPI == 3 ? BLK / 64 : 1];
+  PA_HOOK_STAMP(0, 0);
   const int b = blockIdx.x;
   // (chunks_per_xcd < 0: the same map walked BACKWARDS -- every other product of a block streams its arrays from the end, so that what
   // the last product left in the translation caches and in the Infinity Cache is what this one reads first)

@@ -106,3 +106,52 @@ def test_x_window_blocks_get_no_automatic_dictionary_but_an_explicit_one_works()
     pa.spmv_(y, B, x)
     pa.spmv_(y1, B1, x)
     assert np.array_equal(y.download(), y1.download())
+
+
+def test_two_value_dictionaries_are_decoded_by_a_select_with_the_same_bits():
+    """Round 5: a dictionary of at most two values (HPCG's 26 / -1) is decoded by a select per entry (VD = 2 of k_spmv_rowsplit) instead
+    of through the lane dictionary's ds_bpermute pairs (PA_SPMV_VDICT_SELECT=0) -- the LDS pipe was the busy unit of that kernel.
+    Same bits on row patterns (27-point), 16-bit windows and 32-bit columns, with alpha and beta; a hipGraph recorded through the
+    select follows value updates that stay within two values and REFUSES (PA_ERR_STATE: record again) a third value instead of
+    replaying a decode that cannot represent it."""
+    A, _ = pa.build_p_matrix(ranks(1), 64, 64, 64, 64, 64, 64, 1, 1, 1)
+    blk = A.matrix_partition.items[0].own_own
+    assert blk.value_dict() == 2
+    rng = np.random.default_rng(17)
+    H = _band(rng, 60000, 9, np.array([0.5, -1.25]))
+    with env(PA_SPMV_XWIN="0"):
+        B = pa.DeviceCSR(H)
+        with env(PA_SPMV_COL16="0", PA_SPMV_PATTERN="0"):
+            B32 = pa.DeviceCSR(H)
+        with env(PA_SPMV_VALUE_DICT="0"):
+            Bf = pa.DeviceCSR(H)
+    assert B.value_dict() == 2 and B32.value_dict() == 2 and Bf.value_dict() == 0
+    for M, Mref in ((blk, None), (B, Bf), (B32, Bf)):
+        x = pa.DeviceVector(M.n, 0).upload(rng.standard_normal(M.n))
+        y0 = rng.standard_normal(M.m)
+        got = []
+        for sel in ("1", "0"):
+            with env(PA_SPMV_VDICT_SELECT=sel):
+                y = pa.DeviceVector(M.m, 0).upload(y0)
+                pa.spmv_(y, M, x, L.SEG_OWN, L.SEG_OWN, -0.75, 1.5)
+                got.append(y.download())
+        assert np.array_equal(got[0], got[1])
+        if Mref is not None:
+            y = pa.DeviceVector(M.m, 0).upload(y0)
+            pa.spmv_(y, Mref, x, L.SEG_OWN, L.SEG_OWN, -0.75, 1.5)
+            assert np.array_equal(got[0], y.download())
+    # recorded through the select: two new values are followed at once, a third one is refused
+    x = pa.DeviceVector(H.n, 0).upload(rng.standard_normal(H.n))
+    y, yf = pa.DeviceVector(H.m, 0), pa.DeviceVector(H.m, 0)
+    pa.spmv_(y, B, x)
+    with pa.Graph() as g:
+        pa.spmv_(y, B, x)
+    new2 = rng.choice(np.array([3.0, -8.5]), size=H.nnz)
+    B.update_values(new2)
+    Bf.update_values(new2)
+    g.launch()
+    pa.spmv_(yf, Bf, x)
+    assert B.value_dict() == 2 and np.array_equal(y.download(), yf.download())
+    new3 = rng.choice(np.array([3.0, -8.5, 0.25]), size=H.nnz)
+    with pytest.raises(L.PAError, match="record the graph again"):
+        B.update_values(new3)

@@ -10,6 +10,7 @@
 //   -DPA_PROBE_ONE_PLANE           every gather folded into the row's own grid plane (27-point 256^3)
 //   -DPA_PROBE_TILE_X              the x footprint of a 4 x 14 tile instead of 57 consecutive nodes
 //   -DPA_PROBE_LDS_X               three coalesced x loads per lane into LDS, gathers from there
+//   -DPA_PROBE_STAMPS              (round 5; right results) wall-clock stamps of a workgroup's phases, tools/probe/k1_stamps.py
 //   -DPA_PROBE_TILE_LDS            round 3, VERDICT r02 #5 "tile + LDS together": the x footprint of a 4 x 14 tile (3 planes x 6
 //                                  lines x 16 nodes = 288 doubles, 2.3 KB instead of the 4.2 KB of 57 consecutive nodes) staged
 //                                  ONCE per chunk with coalesced 128-byte runs, every gather a ds_read_b64
@@ -17,6 +18,31 @@
 #ifndef PA_SPMV_PROBE_HOOKS_H
 #define PA_SPMV_PROBE_HOOKS_H
 #include <hip/hip_runtime.h>
+
+#ifdef PA_PROBE_STAMPS
+// round 5: when does a workgroup of the product kernel reach which phase?  Lane 0 writes the 100 MHz wall clock at five points of
+// its workgroup's life (0 entry, 1 chunk head known, 2 wave 0's products formed = its loads are back, 3 behind the barrier, 4 rows
+// summed and stored) plus where it ran (HW_ID, XCC_ID) into a device array that pa_probe_read_stamps copies out
+// (tools/probe/k1_stamps.py).  Only pa_csr.hip is built with this (tools/probe/build_k1_variants.sh).
+#define PA_PROBE_STAMP_BLOCKS (1 << 19)
+__device__ unsigned long long pa_probe_stamps[(size_t)PA_PROBE_STAMP_BLOCKS * 8];
+template <typename... T>
+__device__ __forceinline__ void pa_probe_stamp(int k, T... dep) {
+  if (threadIdx.x != 0 || blockIdx.x >= PA_PROBE_STAMP_BLOCKS) return;
+  ((void)(dep), ...);
+  unsigned long long *rec = pa_probe_stamps + (size_t)blockIdx.x * 8;
+  rec[k] = wall_clock64();
+  if (k == 0) rec[7] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+}
+__device__ __forceinline__ void pa_probe_pin(double a) { asm volatile("" ::"v"(a)); }
+__device__ __forceinline__ void pa_probe_pin(int a) { asm volatile("" ::"s"(a)); }
+#define PA_HOOK_STAMP(k, ...) { pa_probe_pin_all(__VA_ARGS__); pa_probe_stamp(k); }
+template <typename... T>
+__device__ __forceinline__ void pa_probe_pin_all(T... a) { (pa_probe_pin(a), ...); }
+extern "C" int pa_probe_read_stamps(unsigned long long *out, size_t n_blocks) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pa_probe_stamps), n_blocks * 8 * sizeof(unsigned long long), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 #ifdef PA_PROBE_IDENTITY_CHUNK_MAP
 #define PA_HOOK_CHUNK_MAP 1

@@ -10,7 +10,20 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 mk_ref = lambda: pa.pc_setup(r1, 1, 4, n, n, n, ordering="sequential", keep_raw_columns=True)
 mk_opt = lambda prev: pa.pc_setup(r1, 1, 4, n, n, n, ordering="multicolor_spmv", graph=True, reuse=prev, keep_raw_columns=True)
 S = mk_ref(); T = mk_opt(S); ctx.sync(); del S, T; gc.collect()          # pool, code objects
-os.environ["PA_SETUP_TIMING"] = "1"
+if os.environ.get("PA_PAIR_LINES", "1") == "1": os.environ["PA_SETUP_TIMING"] = "1"
+import collections
+import pa_amd._lib as L
+per_call = collections.defaultdict(lambda: [0, 0.0])
+_call = L.call
+def timed_call(name, *a):
+    t0 = time.perf_counter()
+    try:
+        return _call(name, *a)
+    finally:
+        e = per_call[name]; e[0] += 1; e[1] += time.perf_counter() - t0
+L.call = timed_call
+for m in list(sys.modules.values()):
+    if m is not None and getattr(m, "__name__", "").startswith("pa_amd") and getattr(m, "L", None) is L: pass
 for name, f in (("reference", mk_ref), ("optimised", None)):
     pr = cProfile.Profile()
     print(f"==== {name} starts", file=sys.stderr, flush=True)
@@ -21,3 +34,5 @@ for name, f in (("reference", mk_ref), ("optimised", None)):
     print(f"==== {name}: {time.perf_counter() - t:.3f} s", flush=True)
     print(f"==== {name} ends", file=sys.stderr, flush=True)
     pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    for k, (n_, t_) in sorted(per_call.items(), key=lambda kv: -kv[1][1])[:18]: print(f"   {t_ * 1e3:8.1f} ms  {n_:4d} x  {k}")
+    per_call.clear()
