@@ -37,7 +37,11 @@ for case in range(n_cases):
     if "--few-values" in sys.argv:                    # with PA_SPMV_VALUE_DICT=1: the lossless value dictionary (<= 64 values)
         nv = int(rng.integers(1, 80))
         val = rng.standard_normal(nv)[rng.integers(0, nv, len(rows))]
-    val[rng.random(len(rows)) < 0.01] = -0.0
+    two = "--two-values" in sys.argv                 # ... at most two values: the select decode (VD = 2, round 5)
+    if two:
+        nv = int(rng.integers(1, 3))
+        val = rng.standard_normal(nv)[rng.integers(0, nv, len(rows))]
+    if not (two and nv == 2): val[rng.random(len(rows)) < 0.01] = -0.0
     H = pa.HostCSR(m, n, rp.astype(np.int32), (col[order] + 1).astype(np.int32), val)
     Ho = orc.CSR(m, n, H.rowptr, H.colval, H.nzval)
     xh = rng.standard_normal(n)

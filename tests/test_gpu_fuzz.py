@@ -56,3 +56,11 @@ def test_fuzzers_under_the_round_4_switches(switches):
     for script, cases, seed0 in (("fuzz_spmv.py", 12, 426000), ("fuzz_mul.py", 30, 426100), ("fuzz_fem.py", 30, 426200), ("fuzz_exchange.py", 100, 426300)):
         out = _fuzz(script, cases, seed0, env=switches)
         assert " 0 mismatches" in out or " 0 with mismatches" in out, (switches, out[-500:])
+
+
+def test_spmv_fuzzer_on_two_value_dictionaries():
+    """Round 5: blocks with at most two stored values take the select decode of the one-byte value stream (VD = 2); every launch the
+    library can choose, against the oracle."""
+    out = _fuzz("fuzz_spmv.py", 10, 427000, env={"PA_SPMV_VALUE_DICT": "1"}, extra=("--two-values",))
+    assert " 0 mismatches" in out, out[-500:]
+

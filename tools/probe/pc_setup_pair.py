@@ -21,6 +21,7 @@ def timed_call(name, *a):
         return _call(name, *a)
     finally:
         e = per_call[name]; e[0] += 1; e[1] += time.perf_counter() - t0
+        if os.environ.get("PA_PAIR_EACH") and time.perf_counter() - t0 > 2e-3: print(f"      {name} {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
 L.call = timed_call
 for m in list(sys.modules.values()):
     if m is not None and getattr(m, "__name__", "").startswith("pa_amd") and getattr(m, "L", None) is L: pass
