@@ -10,6 +10,7 @@
 //   -DPA_PROBE_ONE_PLANE           every gather folded into the row's own grid plane (27-point 256^3)
 //   -DPA_PROBE_TILE_X              the x footprint of a 4 x 14 tile instead of 57 consecutive nodes
 //   -DPA_PROBE_LDS_X               three coalesced x loads per lane into LDS, gathers from there
+//   -DPA_PROBE_PAIR_GATHER         (round 5) the second entry of every pair reads x[c0 + 1]: three 16-byte gathers per lane instead of six
 //   -DPA_PROBE_STAMPS              (round 5; right results) wall-clock stamps of a workgroup's phases, tools/probe/k1_stamps.py
 //   -DPA_PROBE_TILE_LDS            round 3, VERDICT r02 #5 "tile + LDS together": the x footprint of a 4 x 14 tile (3 planes x 6
 //                                  lines x 16 nodes = 288 doubles, 2.3 KB instead of the 4.2 KB of 57 consecutive nodes) staged
@@ -70,6 +71,9 @@ extern "C" int pa_probe_read_stamps(unsigned long long *out, size_t n_blocks) {
     c0 = flat(c0);                                                                                      \
     c1 = flat(c1);                                                                                      \
   }
+#elif defined(PA_PROBE_PAIR_GATHER)
+// round 5: what would it buy if a lane's two entries were always neighbours in x (one 16-byte gather instead of two 8-byte ones)?
+#define PA_HOOK_PATTERN_COLS(c0, c1, r0, r1, tid) { c1 = c0 + 1; }
 #elif defined(PA_PROBE_NO_GATHER)
 #define PA_HOOK_PATTERN_COLS(c0, c1, r0, r1, tid)                                                       \
   {                                                                                                     \
