@@ -12,23 +12,46 @@
 #include <vector>
 
 #include "pa_internal.h"
+#include "pa_scratch.h"
 
 namespace pa_util {
 
-struct scratch {                                   // plain hipMalloc'ed temporaries, freed when the owner goes out of scope
-  std::vector<void *> p;
+struct scratch {                                   // temporaries that go back when the owner goes out of scope (pa_scratch.h: a small cache
+  struct blk { void *p; size_t n; int dev; };      // in front of hipMalloc / hipFree)
+  std::vector<blk> p;
   template <class T> int get(T **out, size_t n) {
-    void *q = nullptr;
-    PA_HIP(hipMalloc(&q, std::max<size_t>(sizeof(T) * n, 16)));
-    p.push_back(q);
+    const size_t bytes = pa_scratch_cache::round_up(std::max<size_t>(sizeof(T) * n, 16));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    void *q = pa_scratch().cap ? pa_scratch().take(bytes, dev) : nullptr;
+    if (!q) {
+      if (hipMalloc(&q, bytes) != hipSuccess) {      // (what the cache holds may be what is missing)
+        (void)hipGetLastError();
+        pa_scratch().trim();
+        PA_HIP(hipMalloc(&q, bytes));
+      }
+    }
+    p.push_back(blk{q, bytes, dev});
     *out = (T *)q;
     return PA_OK;
   }
-  void release(void *q) {
-    auto it = std::find(p.begin(), p.end(), q);
-    if (it != p.end()) { (void)hipFree(q); p.erase(it); }
+  static void back(const blk &b) {                   // (behind a device synchronise: see pa_scratch.h)
+    if (!pa_scratch().give(b.p, b.n, b.dev)) (void)hipFree(b.p);
   }
-  ~scratch() { for (void *q : p) (void)hipFree(q); }
+  void release(void *q) {
+    for (size_t i = 0; i < p.size(); ++i)
+      if (p[i].p == q) {
+        (void)hipDeviceSynchronize();
+        back(p[i]);
+        p.erase(p.begin() + i);
+        return;
+      }
+  }
+  ~scratch() {
+    if (p.empty()) return;
+    (void)hipDeviceSynchronize();
+    for (const blk &b : p) back(b);
+  }
 };
 
 inline dim3 grid1(int64_t n, int t = 256) { return dim3((unsigned)std::max<int64_t>(1, (n + t - 1) / t)); }

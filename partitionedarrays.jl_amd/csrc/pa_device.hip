@@ -40,6 +40,7 @@
 
 #include "pa_internal.h"
 #include "pa_setup.h"
+#include "pa_scratch.h"
 
 thread_local std::string g_pa_err;
 thread_local int pa_tls_plain_encoding = 0;   // > 0 while pa_matrix_fused_build makes its block: Int32 columns, nothing else
@@ -161,6 +162,7 @@ extern "C" int pa_ctx_destroy(pa_ctx *c) {
   for (int k = 0; k < 2; ++k) if (c->d_xalpha[k]) pa_dev_free(c, c->d_xalpha[k]);
   if (c->d_vdict_scratch) (void)pa_raw_free(c->d_vdict_scratch);
   pa_arena_destroy(c);
+  pa_scratch().trim();                 // (the set-up routes' cached temporaries: pa_scratch.h)
   (void)hipEventDestroy(c->ev_compute);
   (void)hipStreamDestroy(c->s[0]);
   (void)hipStreamDestroy(c->s[1]);
