@@ -334,6 +334,12 @@ __global__ void kg_lower_count(const int32_t *__restrict__ start, const int32_t 
   cnt[r] = k;
 }
 
+// lanes that share a frontier row in a round (each takes every PA_ROUND_LANES-th entry of the row).  256^3, four levels, both traversals
+// (sweep levels / greedy colouring), ms: 1 lane 94 / 112, 4 lanes 63 / 86, 8 lanes 70 / 100, 32 lanes 115 / 133 -- a round is a small
+// launch whose cost grows with its grid, not a chain of atomics
+#ifndef PA_ROUND_LANES
+#define PA_ROUND_LANES 4
+#endif
 __global__ void kg_first(const int32_t *__restrict__ cnt, int n, int32_t *__restrict__ frontier, int *__restrict__ count) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < n && cnt[r] == 0) frontier[atomicAdd(count, 1)] = r;
@@ -346,11 +352,11 @@ __global__ void kg_round(const int32_t *__restrict__ frontier, int *__restrict__
                          const int32_t *__restrict__ len, const int32_t *__restrict__ col, int n, int32_t *__restrict__ level,
                          int32_t *__restrict__ cnt, int32_t *__restrict__ next) {
   const int size = sizes[lv];
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)size * 8; t += (long long)gridDim.x * blockDim.x) {
-    const int i = (int)(t >> 3), lane = (int)(t & 7);
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)size * PA_ROUND_LANES; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / PA_ROUND_LANES), lane = (int)(t % PA_ROUND_LANES);
     const int r = frontier[i];
     if (lane == 0) level[r] = lv;
-    for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += 8) {
+    for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += PA_ROUND_LANES) {
       const int j = col[p];
       if (j > r && j < n && atomicSub(&cnt[j], 1) == 1) next[atomicAdd(&sizes[lv + 1], 1)] = j;
     }
@@ -393,7 +399,7 @@ static int run_rounds(hipStream_t s, int64_t n, int *d_sizes, int32_t *d_f0, int
   *ok = true;
   if (guess == 0) return PA_OK;
   while (true) {
-    const int blocks = (int)std::min<int64_t>(65535, std::max<int64_t>(64, ((int64_t)guess * 8 + 255) / 256 * 2));
+    const int blocks = (int)std::min<int64_t>(65535, std::max<int64_t>(64, ((int64_t)guess * PA_ROUND_LANES + 255) / 256 * 2));
     for (int b = 0; b < BATCH; ++b) launch((int)(k + b), ((k + b) & 1) ? d_f1 : d_f0, ((k + b) & 1) ? d_f0 : d_f1, blocks);
     PA_HIP(hipGetLastError());
     PA_TRY(d2h(s, buf, d_sizes + k, (size_t)BATCH));
@@ -516,8 +522,8 @@ __global__ void kg_round_color(const int32_t *__restrict__ frontier, int *__rest
                                const int32_t *__restrict__ len, const int32_t *__restrict__ col, int n, int32_t *__restrict__ color,
                                int32_t *__restrict__ cnt, int32_t *__restrict__ next) {
   const int size = sizes[lv];
-  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)size * 8; t += (long long)gridDim.x * blockDim.x) {
-    const int i = (int)(t >> 3), lane = (int)(t & 7);
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < (long long)size * PA_ROUND_LANES; t += (long long)gridDim.x * blockDim.x) {
+    const int i = (int)(t / PA_ROUND_LANES), lane = (int)(t % PA_ROUND_LANES);
     const int r = frontier[i];
     if (lane == 0) {
       unsigned long long used = 0;
@@ -529,7 +535,7 @@ __global__ void kg_round_color(const int32_t *__restrict__ frontier, int *__rest
       while (c < 63 && (used >> c) & 1ull) ++c;
       color[r] = c;
     }
-    for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += 8) {
+    for (int p = start[r] + lane, e = start[r] + len[r]; p < e; p += PA_ROUND_LANES) {
       const int j = col[p];
       if (j > r && j < n && atomicSub(&cnt[j], 1) == 1) next[atomicAdd(&sizes[lv + 1], 1)] = j;
     }
