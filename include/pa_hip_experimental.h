@@ -137,6 +137,8 @@ int pa_gs_sweep(pa_gs *gs, pa_vec *x, const pa_vec *b, int backward, int zero_gu
 /* Colours of the greedy colouring pa_gs_create(PA_GS_MULTICOLOR) uses (natural order, smallest free colour). */
 int pa_host_greedy_coloring(int64_t n_own, const int32_t *rowptr, const int32_t *colval, int index_base,
                             int32_t *color, int32_t *n_colors);
+/* a[i] = map[a[i]] in place (host threads): the colours renamed into the order they are swept in */
+int pa_host_remap_int32(int32_t *a, int64_t n, const int32_t *map, int32_t n_map);
 /* One colour of a multicolour Gauss-Seidel sweep written as SpMV + update (the optimised HPCG variant):
  *   x[row] = x[row] + (b[row] - t[row]) / diag[row];  t[row] = 0   for the listed rows, where t = A*x was accumulated
  * for these rows by pa_spmv(beta = 1) on the colour's sub-matrix into a zeroed t.  rows are local ids in `index_base`. */

@@ -134,6 +134,7 @@ _SIGS = {
     "pa_gs_info": [P, C.POINTER(i64), C.POINTER(i64)],
     "pa_gs_sweep": [P, P, P, cint, cint],
     "pa_host_greedy_coloring": [i64, P, P, cint, P, C.POINTER(i32)],
+    "pa_host_remap_int32": [P, i64, P, i32],
     "pa_rowset_create": [P, i64, P, cint, PP],
     "pa_rowset_destroy": [P],
     "pa_gs_color_update": [P, P, P, P, P],

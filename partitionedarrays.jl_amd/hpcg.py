@@ -219,7 +219,7 @@ class ColoredGaussSeidelSpMV:
                 order = np.lexsort((np.arange(K), -aff))              # greedy colours in sweep order
                 pos = np.empty(K, np.int32)
                 pos[order] = np.arange(K, dtype=np.int32)
-                color = pos[color].astype(np.int32)
+                L.call("pa_host_remap_int32", L.ptr(color), n, L.ptr(pos), K)      # color = pos[color]
             elif mode not in ("affinity", "reverse") and len(mode.split(",")) == K:      # experiments: explicit sweep order
                 order = np.array([int(v) for v in mode.split(",")], np.int32)
                 pos = np.empty(K, np.int32)
