@@ -86,6 +86,9 @@ int pa_gs_create_from_blocks(const pa_csr *own_own, const pa_csr *own_ghost, int
  * neighbour j < r has, computed by rounds on the device and verified against that definition; PA_ERR_ARG when the pattern
  * is not structurally symmetric (colour on the host then). */
 int pa_csr_greedy_coloring(const pa_csr *own_own, int32_t *color, int32_t *n_colors);
+/* The same from the dependency levels a sequential smoother of this block already holds (pa_gs_create_from_blocks): one small launch
+ * per level instead of the discovery by rounds. */
+int pa_csr_greedy_coloring_by_levels(const pa_csr *own_own, const pa_gs *gs, int32_t *color, int32_t *n_colors);
 /* affinity[k] = the mean number of stored entries of a colour-k row whose column is one of kept_rows (0-based own rows: the
  * fine rows a coarse grid keeps).  A multicolour smoother inside a multigrid cycle sweeps its colours in order of decreasing
  * affinity, so that the kept rows' own colour sits at the turn of the symmetric sweep, not at its end (where the residual

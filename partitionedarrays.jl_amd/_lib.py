@@ -108,6 +108,7 @@ _SIGS = {
     "pa_csr_diagonal": [P, P],
     "pa_gs_create_from_blocks": [P, P, cint, C.POINTER(P)],
     "pa_csr_greedy_coloring": [P, P, C.POINTER(C.c_int32)],
+    "pa_csr_greedy_coloring_by_levels": [P, P, P, C.POINTER(i32)],
     "pa_csr_color_affinity": [P, P, C.c_int32, P, i64, P],
     "pa_hpcg_own_block_create": [P] + [i64] * 9 + [C.POINTER(P), P],
     "pa_hpcg_rhs": [P] + [i64] * 9 + [P],

@@ -171,21 +171,31 @@ class ColoredGaussSeidelSpMV:
     x[row] += (b - A*x)[row] / d in place (pa_gs_color_sweep: the 8 colour launches of a sweep are one call).
     Same sweep as GaussSeidel(ordering="multicolor") up to rounding (the residual is summed first, then subtracted)."""
 
-    def __init__(self, A, kept_rows=None):
+    def __init__(self, A, kept_rows=None, levels_from=None):
         """kept_rows(row_indices) -> 0-based own rows of a part that the next coarser grid keeps (or None): decides the order
-        the colours are swept in (see make)."""
+        the colours are swept in (see make).  levels_from: a GaussSeidel(A, "sequential") of the same matrix made on the device:
+        its dependency levels colour the rows level by level (pa_csr_greedy_coloring_by_levels) instead of by discovery."""
         from .p_sparse_matrix import HostCSR, DeviceCSR
         from .p_vector import DeviceVector
         self.A = A
         self.ordering = "multicolor_spmv"
 
-        def make(h, r, c, dev):
+        seq = levels_from.gs if (levels_from is not None and getattr(levels_from, "ordering", None) == "sequential"
+                                 and os.environ.get("PA_GS_COLOR_BY_LEVELS", "1") != "0") else pmap(lambda _r: None, A.row_partition)
+
+        def make(h, r, c, dev, g):
             n = r.n_own
             color = np.zeros(n, np.int32)
             ncol = C.c_int32()
             on_device = dev.own_own.has_raw_columns() and dev.own_ghost.has_raw_columns()
             colored = False
-            if on_device:                                  # greedy colouring in natural order by rounds on the device
+            if on_device and g is not None:                # ... from the levels the sequential smoother of this matrix holds
+                try:
+                    L.call("pa_csr_greedy_coloring_by_levels", dev.own_own.h, g, L.ptr(color), C.byref(ncol))
+                    colored = True
+                except L.PAError:
+                    pass
+            if on_device and not colored:                  # greedy colouring in natural order by rounds on the device
                 try:
                     L.call("pa_csr_greedy_coloring", dev.own_own.h, L.ptr(color), C.byref(ncol))
                     colored = True
@@ -262,7 +272,7 @@ class ColoredGaussSeidelSpMV:
             return blocks, DeviceVector(n, 0).upload(diag), handles, color, None, None
 
         hb = A.host_blocks if A.host_blocks is not None else pmap(lambda _r: None, A.row_partition)
-        self.parts = pmap(make, hb, A.row_partition, A.col_partition, A.matrix_partition)
+        self.parts = pmap(make, hb, A.row_partition, A.col_partition, A.matrix_partition, seq)
 
     def info(self):
         return pmap(lambda p: dict(levels=len(p[0]), max_rows_per_level=0), self.parts)
@@ -356,7 +366,8 @@ def pc_setup(ranks, np_, l, nx, ny, nz, ordering="sequential", fuse_restriction=
         As[lev - 1], rs[lev - 1] = A, b
         op = restrict_operator(nx, ny, nz) if lev > 1 else None
         if ordering == "multicolor_spmv":
-            gss[lev - 1] = ColoredGaussSeidelSpMV(A, (lambda _r, op=op: op.astype(np.int64) - 1) if op is not None else None)
+            gss[lev - 1] = ColoredGaussSeidelSpMV(A, (lambda _r, op=op: op.astype(np.int64) - 1) if op is not None else None,
+                                                  levels_from=reuse.gs_states[lev - 1] if reuse is not None and reuse.gs_states else None)
         else:
             gss[lev - 1] = GaussSeidel(A, ordering)
         if reuse is not None:

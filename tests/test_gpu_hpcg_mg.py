@@ -159,3 +159,31 @@ def test_multicolor_gauss_seidel_as_hpcg_optimised_variant(golden, ordering):
         assert it <= 54, it
     for vals in x.own_values().items:
         assert np.allclose(vals, 1.0, atol=1e-9)                                     # b = A*1
+
+
+def test_greedy_colouring_from_the_sequential_sweeps_levels_is_the_colouring_by_rounds():
+    """Round 5: when a sequential smoother of the same matrix exists (the reference phase of the HPCG driver), its dependency levels
+    colour the rows level by level (pa_csr_greedy_coloring_by_levels) -- the same definition (row r takes the smallest colour no own
+    neighbour j < r has), the same verification, the same colours as the discovery by rounds; a smoother of another matrix is refused;
+    pc_setup(reuse=...) takes that route and gives the solver of a set-up from scratch."""
+    import ctypes as C
+    import pa_amd._lib as L
+    from pa_amd.hpcg import GaussSeidel
+    for n3 in ((12, 10, 8), (16, 16, 16)):
+        A, _ = pa.build_p_matrix(ranks(1), *n3, *n3, 1, 1, 1, keep_raw=True)
+        dev = A.matrix_partition.items[0]
+        g = GaussSeidel(A, "sequential")
+        n = dev.own_own.m
+        c0, c1 = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        k0, k1 = C.c_int32(), C.c_int32()
+        L.call("pa_csr_greedy_coloring", dev.own_own.h, L.ptr(c0), C.byref(k0))
+        L.call("pa_csr_greedy_coloring_by_levels", dev.own_own.h, g.gs.items[0], L.ptr(c1), C.byref(k1))
+        assert k0.value == k1.value == 8 and np.array_equal(c0, c1)
+    B, _ = pa.build_p_matrix(ranks(1), 8, 8, 8, 8, 8, 8, 1, 1, 1, keep_raw=True)
+    with pytest.raises(L.PAError):
+        L.call("pa_csr_greedy_coloring_by_levels", B.matrix_partition.items[0].own_own.h, g.gs.items[0], L.ptr(c1), C.byref(k1))
+    S_ref = pa.pc_setup(ranks(1), 1, 3, 16, 16, 16, ordering="sequential", keep_raw_columns=True)
+    S = pa.pc_setup(ranks(1), 1, 3, 16, 16, 16, ordering="multicolor_spmv", reuse=S_ref)
+    T = pa.pc_setup(ranks(1), 1, 3, 16, 16, 16, ordering="multicolor_spmv")
+    for a, b in zip(S.gs_states, T.gs_states):
+        assert np.array_equal(a.parts.items[0][3], b.parts.items[0][3])
