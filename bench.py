@@ -1354,11 +1354,18 @@ def main():
             for name, fn in (("ref_cg", pa.ref_cg_), ("opt_cg_unfused", functools.partial(pa.opt_cg_, fuse=False)),
                              ("opt_cg", functools.partial(pa.opt_cg_, fuse=True))):
                 cg_time(fn, 2)
-                d = cg_time(fn, 4 + args.cg_iters) - cg_time(fn, 4)     # the difference cancels allocation + first residual
-                if N > 1:
-                    tt = torch.tensor([d], dtype=torch.float64)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    d = float(tt.item())
+                for attempt in range(3):
+                    t_long = cg_time(fn, 4 + args.cg_iters)
+                    d = t_long - cg_time(fn, 4)                         # the difference cancels allocation + first residual
+                    if N > 1:
+                        tt = torch.tensor([d, t_long], dtype=torch.float64)
+                        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                        d, t_long = float(tt[0].item()), float(tt[1].item())
+                    if d > 0:
+                        break
+                    # (a few iterations of a tiny part with the ranks sharing one GPU: the two wall-clock spans can come out the wrong way
+                    #  round; measured again, and after three tries the long run alone, pro rata -- the same decision on every rank)
+                    d = t_long * args.cg_iters / (4 + args.cg_iters)
                 res[name] = d / args.cg_iters * 1e3
             cg = res
             if rank == 0:
