@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -67,6 +68,7 @@ struct pa_scratch_cache {
     return true;
   }
   void trim() {
+    if (getenv("PA_SETUP_TIMING")) fprintf(stderr, "[pa scratch] %ld requests served from the cache, %ld by hipMalloc; holding %.1f MiB in %zu blocks\n", hits, misses, held / 1048576.0, free_.size());
     std::vector<void *> out;
     {
       std::lock_guard<std::mutex> g(m);
