@@ -289,6 +289,8 @@ int pa_csr_create_transpose_ranked(const pa_csr *A, const int32_t *row_rank, pa_
 /* a scatter map back as destinations (0-based, -1 = skipped); checks that every slot adds its sources in ascending order (tests) */
 int pa_scatter_download(const pa_scatter *s, int32_t *dest);
 int pa_csr_create_colsplit(const pa_csr *A, int pieces, pa_csr **out);
+/* A block of n_rows x n_cols without stored entries -- pa_csr_create with n_rows + 1 equal row pointers, without that array. */
+int pa_csr_create_empty(pa_ctx *c, int64_t n_rows, int64_t n_cols, pa_csr **out);
 /* A column-split chain: *pieces = its pieces (0: A is not one), *groups_one_launch = workgroups of the ONE launch pa_spmv runs it as
  * (the pieces' chunks and ring groups are cut at the same rows: a workgroup runs its rows through every piece and y reaches HBM
  * once; PA_SPMV_CHAIN_FUSED=0: never), 0 = a launch per piece, y written and re-read between them. */

@@ -170,6 +170,7 @@ _SIGS = {
     "pa_csr_create_permuted": [P, P, P, PP],
     "pa_csr_create_transpose_ranked": [P, P, PP],
     "pa_csr_create_colsplit": [P, cint, PP],
+    "pa_csr_create_empty": [P, i64, i64, PP],
     "pa_csr_chain_info": [P, C.POINTER(C.c_int32), C.POINTER(i64)],
     "pa_coo_keep_input_slots": [P, cint],
     "pa_coo_reuse_scatter": [P, P, P, PP, i64, P],

@@ -678,6 +678,22 @@ int pa_csr_from_device_rows(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t n
   return PA_OK;
 }
 
+// a block without stored entries (the own|ghost block of a part without neighbours): what pa_csr_create_mixed builds from n_rows + 1
+// equal row pointers, without the caller making, and the library reading, that array (16.8 M rows: 67 MB)
+extern "C" int pa_csr_create_empty(pa_ctx *c, int64_t n_rows, int64_t n_cols, pa_csr **out) {
+  PA_REQUIRE(c && out && n_rows >= 0 && n_cols >= 0, "bad arguments");
+  PA_REQUIRE(n_rows < (int64_t)2147483000 && n_cols < (int64_t)2147483000, "block too large for Int32 device indices");
+  csr_src src;
+  src.pre_nonempty = 0;
+  src.pre_compact = n_rows > 0;                          // (csr_fill_slab's rule: fewer than half of the rows hold entries)
+  std::vector<int32_t> crp((size_t)(src.pre_compact ? 0 : n_rows) + 1, 0);
+  pa_csr *S = nullptr;
+  PA_TRY(csr_build_slab(c, n_rows, n_cols, 0, crp, src, &S));
+  S->t_rows = n_rows; S->t_nnz = 0;
+  *out = S;
+  return PA_OK;
+}
+
 extern "C" int pa_csr_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr,
                                       const void *rowval, int index_bytes, int index_base, const double *nzval,
                                       pa_csr **out) {

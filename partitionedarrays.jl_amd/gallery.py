@@ -161,13 +161,19 @@ def build_split_blocks_device(my_rows, nx, ny, nz, gnx, gny, gnz):
     cols = LocalIndices(my_rows.n_global, my_rows.part, np_=my_rows.np_, n=my_rows.n, ranges=my_rows.ranges,
                         starts=my_rows.starts, ghost_to_global=ghosts, ghost_to_owner=owners)
     n = nx * ny * nz
-    oh = HostCSR(n, ng.value, np.empty(n + 1, np.int32), np.empty(noh.value, np.int32), np.empty(noh.value, F64))
-    L.call("pa_host_hpcg_ghost_block", *args, L.ptr(ghosts), ng.value, L.ptr(oh.rowptr), L.ptr(oh.colval), L.ptr(oh.nzval))
+    if noh.value == 0:                                # (a part without neighbours: no surface to walk, no row pointers to upload)
+        e = C.c_void_p()
+        L.call("pa_csr_create_empty", context().h, n, ng.value, C.byref(e))
+        oh_dev = DeviceCSR.from_handle(e, n, ng.value, 0)
+    else:
+        oh = HostCSR(n, ng.value, np.empty(n + 1, np.int32), np.empty(noh.value, np.int32), np.empty(noh.value, F64))
+        L.call("pa_host_hpcg_ghost_block", *args, L.ptr(ghosts), ng.value, L.ptr(oh.rowptr), L.ptr(oh.colval), L.ptr(oh.nzval))
+        oh_dev = None
     h = C.c_void_p()
     L.call("pa_hpcg_own_block_create", context().h, *args, C.byref(h), None)
     v = DeviceVector(cols.n_own, cols.n_ghost)        # (after the block: the arena places it away from the matrix streams' class)
     L.call("pa_hpcg_rhs", context().h, *args, v.h)
-    return cols, SplitMatrixBlocks(DeviceCSR.from_handle(h, n, n, noo.value), DeviceCSR(oh)), v
+    return cols, SplitMatrixBlocks(DeviceCSR.from_handle(h, n, n, noo.value), oh_dev if oh_dev is not None else DeviceCSR(oh)), v
 
 
 def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=False, fused=None, keep_raw=False):
