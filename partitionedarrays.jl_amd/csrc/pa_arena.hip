@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "pa_internal.h"
+#include "pa_scratch.h"
 
 typedef double pa_d2 __attribute__((ext_vector_type(2)));
 
@@ -641,7 +642,16 @@ static std::mutex g_guard_mu;
 static std::unordered_map<void *, guard_rec> g_guard_live;
 
 hipError_t pa_raw_malloc_impl(void **p, size_t bytes) {
-  if (!guard_mode()) return hipMalloc(p, bytes);
+  if (!guard_mode()) {
+    hipError_t st = hipMalloc(p, bytes);
+    if (st == hipErrorOutOfMemory && pa_scratch().held_bytes() > 0) {   // (the scratch cache holds freed set-up temporaries;
+      (void)hipGetLastError();                                          //  out of memory anywhere in the library empties it and retries)
+      (void)hipDeviceSynchronize();
+      pa_scratch().trim();
+      st = hipMalloc(p, bytes);
+    }
+    return st;
+  }
   int dev = 0;
   hipError_t st = hipGetDevice(&dev);
   if (st != hipSuccess) return st;

@@ -234,7 +234,7 @@ static int vdict_after_update(pa_csr *A) {
       return PA_ERR_STATE;
     }
   }
-  return PA_OK;
+  return pa_csr_values_changed(A);           // the handles that hold copies of these values (twin, boundary rows' block) follow now
 }
 
 void pa_csr_before_product(const pa_csr *A) { vdict_maintain(A); }
@@ -815,6 +815,7 @@ extern "C" int pa_csr_destroy(pa_csr *A) {
   (void)hipSetDevice(A->ctx->device);
   (void)hipStreamSynchronize(A->ctx->s[0]);      // (both: the arena hands these blocks to the next caller at once, whereas
   (void)hipStreamSynchronize(A->ctx->s[1]);      // hipFree used to synchronise the whole device)
+  pa_watch_drop_csr(A);
   csr_free_chain(A);
   return PA_OK;
 }

@@ -94,6 +94,18 @@ __global__ void kf_fill(const int *__restrict__ rows, const int *__restrict__ hr
   const int h = hrow[i];
   for (int p = OH.crp[h]; p < OH.crp[h + 1]; ++p, ++q) { out_col[q] = n_own + kf_col(OH, h, p); out_val[q] = OH.val[p]; }
 }
+// the values of bd again, in place: bd's i-th row holds the values of own_own's row rows[i] followed by those of the twin's stored
+// row hrow[i], in stored order (kf_fill's order; the pattern of neither block changes under a value update)
+__global__ void kf_refill(const int *__restrict__ rows, const int *__restrict__ hrow, int n, const int *__restrict__ crp_oo,
+                          const double *__restrict__ val_oo, const int *__restrict__ crp_oh, const double *__restrict__ val_oh,
+                          const int *__restrict__ brp, double *__restrict__ out_val) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int q = brp[i];
+  const int r = rows[i], h = hrow[i];
+  for (int p = crp_oo[r]; p < crp_oo[r + 1]; ++p, ++q) out_val[q] = val_oo[p];
+  for (int p = crp_oh[h]; p < crp_oh[h + 1]; ++p, ++q) out_val[q] = val_oh[p];
+}
 __global__ void kf_mask(const int *__restrict__ rows, int n, unsigned *__restrict__ mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) atomicOr(&mask[rows[i] >> 5], 1u << (rows[i] & 31));
@@ -102,7 +114,33 @@ __global__ void kf_mask(const int *__restrict__ rows, int n, unsigned *__restric
 void pa_matrix_fused_release(pa_matrix *m) {
   if (m->bd) pa_csr_destroy(m->bd);
   if (m->d_rowmask) (void)pa_raw_free(m->d_rowmask);
-  m->bd = nullptr; m->d_rowmask = nullptr; m->n_bd_rows = 0;
+  if (m->d_bd_hrow) (void)pa_raw_free(m->d_bd_hrow);
+  m->bd = nullptr; m->d_rowmask = nullptr; m->d_bd_hrow = nullptr; m->n_bd_rows = 0;
+}
+
+// bd follows a value update of own_own / own_ghost IN PLACE: same pattern, same addresses -- a recorded graph that
+// holds bd's pointers multiplies with the new values at its next replay, and nothing it reads is ever freed under it.  Needs the twin
+// of own_ghost to be current (matrix_rb refreshes it in place first).  Returns PA_OK without doing anything when bd cannot follow in
+// place (a rebuilt twin): the next eager product rebuilds it -- unless a graph has recorded it, which is an error to say aloud.
+int pa_matrix_fused_refresh(pa_matrix *m) {
+  if (!m->bd) return PA_OK;
+  const pa_csr *oo = m->oo, *oh = m->oh_rb;
+  if (m->bd_epoch_oo == oo->val_epoch && m->bd_epoch_oh == m->oh->val_epoch) return PA_OK;
+  const bool can = oh && m->rb_epoch == m->oh->val_epoch && m->d_bd_hrow && m->bd->compact && m->bd->d_row_ids && !m->bd->next;
+  if (!can) {
+    PA_REQUIRE(!m->bd_captured, "the values of a block changed under a recorded fused product and its boundary rows' block cannot "
+                                "follow in place: record the graph again (pa_graph_begin / pa_graph_end)");
+    return PA_OK;
+  }
+  pa_ctx *c = m->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  const int n = (int)m->n_bd_rows;
+  hipLaunchKernelGGL(kf_refill, grid1(n, 64), dim3(64), 0, c->s[0], m->bd->d_row_ids, m->d_bd_hrow, n, oo->d_crp, oo->d_val, oh->d_crp,
+                     oh->d_val, m->bd->d_crp, m->bd->d_val);
+  PA_HIP(hipGetLastError());
+  m->bd->val_epoch++;
+  m->bd_epoch_oo = oo->val_epoch; m->bd_epoch_oh = m->oh->val_epoch;
+  return PA_OK;
 }
 
 // Builds (or, after a value update of either block, rebuilds) what the fused launch needs.  m->bd == NULL afterwards: this handle
@@ -112,8 +150,13 @@ int pa_matrix_fused_build(pa_matrix *m) {
   const pa_csr *oo = m->oo, *oh = m->oh_rb;
   if (m->bd && m->bd_epoch_oo == oo->val_epoch && m->bd_epoch_oh == m->oh->val_epoch) return PA_OK;
   pa_ctx *c = m->ctx;
+  if (m->bd) {                                               // the values changed: in place when possible (also inside a capture)
+    PA_TRY(pa_matrix_fused_refresh(m));
+    if (m->bd_epoch_oo == oo->val_epoch && m->bd_epoch_oh == m->oh->val_epoch) return PA_OK;
+  }
   if (c->capturing) return PA_OK;                            // (a stale bd is never used: see pa_matrix_fused_ready)
   if (m->bd) {
+    PA_REQUIRE(!m->bd_captured, "a recorded fused product holds this handle's boundary rows' block: record the graph again");
     PA_HIP(hipStreamSynchronize(c->s[0]));
     PA_HIP(hipStreamSynchronize(c->s[1]));
     pa_matrix_fused_release(m);
@@ -169,6 +212,9 @@ int pa_matrix_fused_build(pa_matrix *m) {
   hipLaunchKernelGGL(kf_mask, grid1(n), dim3(256), 0, s, d_rows, n, m->d_rowmask);
   PA_HIP(hipGetLastError());
   PA_HIP(hipStreamSynchronize(s));
+  if (pa_raw_malloc(&m->d_bd_hrow, sizeof(int32_t) * (size_t)n) == hipSuccess)      // (without it: no in-place refresh, a rebuild)
+    PA_HIP(hipMemcpy(m->d_bd_hrow, d_hrow, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice));
+  else (void)hipGetLastError();
   m->bd = bd; m->n_bd_rows = n;
   m->bd_epoch_oo = oo->val_epoch; m->bd_epoch_oh = m->oh->val_epoch;
   return PA_OK;
@@ -345,6 +391,7 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double
 #undef PA_FUSED_CASES
 #undef PA_LAUNCH_FUSED
   PA_HIP(hipGetLastError());
+  if (m->ctx->capturing) m->bd_captured = true;
   m->ctx->n_fused++;
   if (comm) m->ctx->n_fused_exchange++;
   return PA_OK;

@@ -278,6 +278,9 @@ struct pa_matrix {
   unsigned *d_rowmask = nullptr;
   int64_t n_bd_rows = 0;
   uint64_t bd_epoch_oo = 0, bd_epoch_oh = 0;
+  int32_t *d_bd_hrow = nullptr;                // bd's i-th row sits at this stored row of the twin (what an in-place value refresh reads)
+  bool bd_captured = false;                    // a fused launch of this handle sits in a recorded hipGraph: bd and the twin keep their
+                                               //   addresses and follow every value update AT the update (pa_csr_values_changed)
   bool fuse_tried = false;
   bool transposed = false;                     // pa_matrix_create_transposed: oo = A_oo', oh = A_oh' (pa_csr_create_transpose), for pa_mul5_transpose
 };
@@ -314,6 +317,14 @@ struct pa_fused_comm {
 
 // pa_fused.hip
 int pa_matrix_fused_build(pa_matrix *m);
+int pa_matrix_fused_refresh(pa_matrix *m);       // bd's values again from the two blocks, in place (same pattern, same addresses)
+// Handles whose derived blocks (the twin of own_ghost, the boundary rows' block) copy a block's VALUES are registered per block;
+// a value update of the block (vdict_after_update, pa_csr.hip) makes them follow at once, in place -- ADVICE r05: a recorded graph
+// replayed after an update summed boundary rows from the old values, and the next eager product freed what the graph still read.
+void pa_watch_add(const pa_csr *A, pa_matrix *m);
+void pa_watch_drop_matrix(pa_matrix *m);
+void pa_watch_drop_csr(const pa_csr *A);
+int pa_csr_values_changed(const pa_csr *A);
 bool pa_matrix_fused_ready(const pa_matrix *m);
 void pa_matrix_fused_release(pa_matrix *m);
 // comm: DEVICE copy of what the launch does for the exchange (or NULL), seq: this exchange's sequence number, n_push_blocks: its

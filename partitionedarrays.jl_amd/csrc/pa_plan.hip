@@ -14,6 +14,8 @@
 #include <numeric>
 #include <iterator>
 #include <string>
+#include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "pa_internal.h"
@@ -275,11 +277,47 @@ extern "C" int pa_matrix_create(pa_ctx *c, const pa_csr *own_own, const pa_csr *
              (long long)own_ghost->n_cols, (long long)col_plan->n_local);
   pa_matrix *m = new pa_matrix();
   m->ctx = c; m->oo = own_own; m->oh = own_ghost; m->plan = col_plan;
+  pa_watch_add(own_own, m);
+  pa_watch_add(own_ghost, m);
   *out = m;
   return PA_OK;
 }
 
+// ---- who copies a block's values -------------------------------------------------------------------------------------------------
+static std::mutex g_watch_mu;
+static std::unordered_multimap<const pa_csr *, pa_matrix *> g_watch;
+void pa_watch_add(const pa_csr *A, pa_matrix *m) {
+  std::lock_guard<std::mutex> lk(g_watch_mu);
+  g_watch.emplace(A, m);
+}
+void pa_watch_drop_matrix(pa_matrix *m) {
+  std::lock_guard<std::mutex> lk(g_watch_mu);
+  for (auto it = g_watch.begin(); it != g_watch.end();) it = it->second == m ? g_watch.erase(it) : std::next(it);
+}
+void pa_watch_drop_csr(const pa_csr *A) {
+  std::lock_guard<std::mutex> lk(g_watch_mu);
+  g_watch.erase(A);
+}
+static int matrix_rb(pa_matrix *m);
+int pa_csr_values_changed(const pa_csr *A) {
+  std::vector<pa_matrix *> ms;
+  {
+    std::lock_guard<std::mutex> lk(g_watch_mu);
+    if (g_watch.empty()) return PA_OK;
+    auto r = g_watch.equal_range(A);
+    for (auto it = r.first; it != r.second; ++it) ms.push_back(it->second);
+  }
+  for (pa_matrix *m : ms) {
+    if (m->transposed || (!m->oh_rb && !m->bd)) continue;     // nothing derived yet: the first product builds from current values
+    // in place where that is possible (always for what a recorded graph may read: see matrix_rb / pa_matrix_fused_refresh)
+    if (m->oh_rb && m->rb_epoch != m->oh->val_epoch && !m->oh->next && !m->oh->colsplit) PA_TRY(matrix_rb(m));
+    if (m->bd) PA_TRY(pa_matrix_fused_refresh(m));
+  }
+  return PA_OK;
+}
+
 extern "C" int pa_matrix_destroy(pa_matrix *m) {
+  if (m) pa_watch_drop_matrix(m);
   if (m && m->oh_rb) pa_csr_destroy(m->oh_rb);     // (own x ghost with renamed columns: made for this handle, matrix_rb)
   if (m) pa_matrix_fused_release(m);
   delete m;

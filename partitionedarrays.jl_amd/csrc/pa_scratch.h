@@ -67,11 +67,15 @@ struct pa_scratch_cache {
     for (void *q : out) (void)hipFree(q);
     return true;
   }
+  size_t held_bytes() {
+    std::lock_guard<std::mutex> g(m);
+    return held;
+  }
   void trim() {
-    if (getenv("PA_SETUP_TIMING")) fprintf(stderr, "[pa scratch] %ld requests served from the cache, %ld by hipMalloc; holding %.1f MiB in %zu blocks\n", hits, misses, held / 1048576.0, free_.size());
     std::vector<void *> out;
     {
       std::lock_guard<std::mutex> g(m);
+      if (getenv("PA_SETUP_TIMING")) fprintf(stderr, "[pa scratch] %ld requests served from the cache, %ld by hipMalloc; holding %.1f MiB in %zu blocks\n", hits, misses, held / 1048576.0, free_.size());
       for (auto &b : free_) out.push_back(b.p);
       free_.clear();
       held = 0;

@@ -40,6 +40,10 @@ class Context:
 
     def sync(self):
         L.call("pa_ctx_sync", self.h)
+        if _PART_CTX:                       # (one context per part: "the device is idle" means all of them)
+            for c in all_contexts():
+                if c is not self:
+                    L.call("pa_ctx_sync", c.h)
 
     def fused_launches(self):
         """(products run as one launch so far, of those with the exchange inside the launch) -- pa_ctx_fused_launches."""
@@ -50,10 +54,10 @@ class Context:
     def reload_env(self):
         """Read the PA_* switches of the product path from the environment again (pa_ctx_reload_env; they are read once, at creation)."""
         L.call("pa_ctx_reload_env", self.h)
-        if _PART_CTX:                       # (one context per part: "the device is idle" means all of them)
+        if _PART_CTX:                       # (one context per part: the switches are per context -- reload every one of them)
             for c in all_contexts():
                 if c is not self:
-                    L.call("pa_ctx_sync", c.h)
+                    L.call("pa_ctx_reload_env", c.h)
 
     def info(self):
         cus, xcds, hbm = C.c_int(), C.c_int(), C.c_size_t()

@@ -189,6 +189,43 @@ def test_mul_all_replayed_from_a_hipgraph(orc, monkeypatch, one_stream):
                 assert np.array_equal(got, e), rep
 
 
+def test_a_recorded_fused_product_follows_value_updates_in_place(orc):
+    """the fused launch's boundary-row block `bd` holds COPIES of own_own's and own_ghost's values.  A graph
+    recorded through it and replayed after pa_csr_update_values must multiply with the NEW values in boundary rows too (it summed
+    them from the old copies), and the eager product after the update must not free what the recorded graph still reads (bd was
+    destroyed and rebuilt).  Now bd and the twin of own_ghost follow every update in place, at the update: replay, eager product and
+    replay again all equal the oracle on the updated values, bit for bit; the handle stays fused with the same block."""
+    n, np3 = (10, 8, 6), (2, 2, 2)
+    A = pa.build_p_matrix(ranks(8), *n, *(a * q for a, q in zip(n, np3)), *np3)[0]
+    Ao = orc.hpcg_build_p_matrix(*n, *np3)[0]
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = upload([v.copy() for v in xo], A.col_partition)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_c_(y, A, x)
+    assert all(f for f, _ in _fused(A, x))
+    with pa.Graph() as g:
+        pa.mul_c_(y, A, x)
+    rng = np.random.default_rng(5)
+    for rep in range(3):
+        for blk, blko in zip(A.matrix_partition.items, Ao.blocks):
+            for dev, host in ((blk.own_own, blko.own_own), (blk.own_ghost, blko.own_ghost)):
+                if rep == 1 and dev is blk.own_own:
+                    continue                                         # (an update of own_ghost alone, too)
+                host.nzval[:] = rng.integers(-8, 9, size=len(host.nzval)) * 0.25 + (rep + 1)
+                dev.update_values(host.nzval)
+        yo = oracle_mul(orc, Ao, xo)
+        for how in ("replay", "eager", "replay"):
+            for dv in y.vector_partition.items:
+                dv.fill(-7.0)
+            if how == "replay":
+                g.launch()
+            else:
+                pa.mul_c_(y, A, x)
+            for got, e, r in zip(y.own_values().items, yo, Ao.rows):
+                assert np.array_equal(got, e[:r.n_own]), (rep, how)
+        assert all(f for f, _ in _fused(A, x)), rep
+
+
 def test_pa_mul5_over_a_one_rank_rccl_communicator():
     """The RCCL branch of the operator-level call on the one GPU there is: a part that "ghosts" three of its own values over a
     1-rank communicator (self-addressed ncclSend / ncclRecv, as test_rccl_single_rank_loopback) -- pack, RCCL group, own x own,
