@@ -37,6 +37,10 @@ def watchdog(seconds):
 
     def fire():
         print(f"[bench watchdog] no progress after {seconds} s, phase = {PHASE[0]!r}; aborting", file=sys.stderr, flush=True)
+        if LINE[0] is not None:                     # (rank 0, headline measured: the line as far as it is known, and status 0)
+            LINE[0].setdefault("optional_sections_unfinished", []).append(f"watchdog in phase {PHASE[0]!r}")
+            print(json.dumps(LINE[0]), flush=True)
+            os._exit(0)
         os._exit(4)
     t = threading.Timer(seconds, fire)
     t.daemon = True
@@ -837,6 +841,15 @@ def main():
     # on by default for big blocks since round 4, lossless -- is switched off here and measured beside them, labelled
     vdict_env = os.environ.get("PA_SPMV_VALUE_DICT")
     os.environ["PA_SPMV_VALUE_DICT"] = "0" if vdict_env is None else vdict_env
+    # N > 1 (VERDICT r05 "Next" #1a): the parity gate and the first timed loop run on the CONSERVATIVE product -- separate launches,
+    # stream order and events around the RCCL group (PA_MUL_FUSED=0: round 4's chain, the `north_star` design) -- and rank 0 holds a
+    # complete line from then on; the library's default (one launch per part, the exchange waited for INSIDE the launch) is gated and
+    # timed behind it as a section that can fail or hang without costing the line.  `value` = the faster of the two that passed its
+    # gate; config.product_path says which.  An in-launch wait gives up after 10 s here (the library's default is 30).
+    want_fused = (N > 1 or world > 1) and os.environ.get("PA_MUL_FUSED", "1") != "0"
+    if N > 1 or world > 1:
+        os.environ.setdefault("PA_IPC_TIMEOUT_S", "10")
+        os.environ["PA_MUL_FUSED"] = "0"
     pa = load_package()
     ctx = pa.context()
     import pa_amd._lib as L
@@ -1169,6 +1182,9 @@ def main():
                                      "ipc": "ipc push (PA_TRANSPORT=ipc: the pack kernel stores into the neighbours' hipIpc-mapped receive "
                                             "buffers, csrc/pa_push.hip; ranks may share a GPU)"}.get(transport, transport),
                        "rccl_ranks_seen": rccl_ranks_seen, "overlap": overlap_on,
+                       "product_path": ("one part, no neighbours: a step is one launch of the product kernel" if N == 1 else
+                                        "separate launches (PA_MUL_FUSED=0: pack + exchange on the comm stream | own x own, own x ghost from the "
+                                        "receive buffer, unpack -- stream order and events)"),
                        "stream_priority": prio},
             "gflops_per_gpu": round(value / N, 2),
             "hbm_gbps_per_gpu_algorithmic": round(bytes_mul / (ms_per_step * 1e-3) / 1e9, 1),
@@ -1228,6 +1244,55 @@ def main():
         LINE[0] = out
 
     # ---------------- everything below is optional: it adds to the line, it can never take the line away ----------------
+    # First of all the library's DEFAULT product for one part per process: mul! as ONE launch with the exchange waited for inside it
+    # (csrc/pa_fused.hip).  Its own parity gate, its own warm-up, the same timed loop; it becomes `value` when it passed its gate and
+    # was faster than the separate launches measured above.  A time-out of an in-launch wait surfaces as an exception from ctx.sync()
+    # (the library reports it once and the handle continues on separate launches), a hang ends with the section's timer: either way
+    # the line above goes out.
+    if N > 1 and want_fused:
+        with optional_section("fused product", 180, N, rank):
+            os.environ.pop("PA_MUL_FUSED", None)
+            ctx.reload_env()
+            ms_sep = ms_per_step
+            ok_fused, t_fused, fl0, fl1 = False, None, ctx.fused_launches(), None
+            try:
+                ok_fused = gate()
+                if ok_fused:
+                    for _ in range(5):
+                        step(overlap_on)
+                    ctx.sync()
+                    fl1 = ctx.fused_launches()
+                    for _ in range(30 + args.warmup):
+                        step(overlap_on)
+                    t_fused, _, _ = timed(args.steps, overlap_on)
+                    ok_fused = gate()                    # (and still right after the loop)
+            finally:
+                ms_fused = None if t_fused is None else t_fused / args.steps * 1e3
+                use_fused = bool(ok_fused and ms_fused is not None and ms_fused < ms_sep)
+                if not use_fused:                        # the rest of the run stays on the path `value` was measured on
+                    os.environ["PA_MUL_FUSED"] = "0"
+                    ctx.reload_env()
+            if use_fused:
+                ms_per_step = ms_fused
+                value = flops_total / (ms_per_step * 1e-3) / 1e9
+            if rank == 0:
+                o = LINE[0]
+                o["fused_ab"] = {"mul_as_one_launch_rank0": bool(fl1 is not None and fl1[0] - fl0[0] >= 5),
+                                 "exchange_inside_the_launch_rank0": bool(fl1 is not None and fl1[1] - fl0[1] >= 5),
+                                 "parity_gate_one_launch": bool(ok_fused),
+                                 "ms_per_step_one_launch": None if ms_fused is None else round(ms_fused, 4),
+                                 "ms_per_step_separate_launches": round(ms_sep, 4),
+                                 "value_uses": "one launch" if use_fused else "separate launches",
+                                 "what": "the separate launches (PA_MUL_FUSED=0) are gated and timed FIRST; the library's default -- one launch "
+                                         "per part, the exchange waited for inside it (csrc/pa_fused.hip) -- behind them by the same loop; "
+                                         "`value` is the faster one that passed its parity gate"}
+                if use_fused:
+                    o["value"] = round(value, 2)
+                    o["ms_per_step"] = round(ms_per_step, 4)
+                    o["gflops_per_gpu"] = round(value / N, 2)
+                    o["hbm_gbps_per_gpu_algorithmic"] = round(bytes_mul / (ms_per_step * 1e-3) / 1e9, 1)
+                    o["config"]["product_path"] = ("one launch per part, the exchange inside it (the library's default; csrc/pa_fused.hip) -- "
+                                                   "gated and timed behind the separate launches, see fused_ab")
     overlap = None
     if N > 1:
         with optional_section("overlap on/off comparison", 120, N, rank):
@@ -1273,29 +1338,6 @@ def main():
                 LINE[0]["per_rank"] = [({"rank": int(r[0]), "missing": True} if bool(torch.isnan(r[1])) else
                                         {k: (int(v) if k in keys[:6] else round(float(v), 4)) for k, v in zip(keys, r.tolist())}) for r in rows]
                 LINE[0]["per_rank_transport"] = transport
-        # round 5: mul! of a part is ONE launch (csrc/pa_fused.hip) -- the same timed loop with PA_MUL_FUSED=0 (round 4's launches:
-        # push / pack + RCCL, own x own, own x ghost, unpack) beside it, on the headline transport
-        with optional_section("one launch per part vs separate launches", 120, N, rank):
-            n_fused0 = ctx.fused_launches()
-            for _ in range(5):
-                step(overlap_on)
-            n_fused1 = ctx.fused_launches()
-            os.environ["PA_MUL_FUSED"] = "0"
-            ctx.reload_env()
-            try:
-                for _ in range(10):
-                    step(overlap_on)
-                t_sep, _, _ = timed(args.steps, overlap_on)
-            finally:
-                os.environ.pop("PA_MUL_FUSED", None)
-                ctx.reload_env()
-            if rank == 0:
-                LINE[0]["fused_ab"] = {"mul_as_one_launch_rank0": bool(n_fused1[0] - n_fused0[0] == 5),
-                                       "exchange_inside_the_launch_rank0": bool(n_fused1[1] - n_fused0[1] == 5),
-                                       "ms_per_step_one_launch": round(ms_per_step, 4),
-                                       "ms_per_step_separate_launches": round(t_sep / args.steps * 1e3, 4),
-                                       "what": "`value` is measured with the library's default (one launch per part where the handle allows: "
-                                               "see csrc/pa_fused.hip); PA_MUL_FUSED=0 timed by the same loop right behind it"}
 
     # ---- optional mode, reported beside the headline and never part of `value`: the same product with the lossless value
     # dictionary (PA_SPMV_VALUE_DICT=1: one byte per stored entry instead of eight when a block has <= 64 distinct values)

@@ -38,6 +38,7 @@ void pa_set_err(const char *fmt, ...);
   } while (0)
 
 struct pa_arena;
+#define PA_FUSED_GAVE_UP 1001   /* internal (pa_mul_fused_rccl -> pa_mul5): an earlier product timed out, take the separate launches */
 
 // Switches of the product path, read from the environment ONCE per context (pa_ctx_create) and again on request
 // (pa_ctx_reload_env: the tests flip them inside one process) -- no getenv on the path of a product.
@@ -50,6 +51,7 @@ struct pa_switches {
   int fused_tail_blocks = 1024;  // PA_FUSED_TAIL_BLOCKS: tail blocks of a fused launch that may SPIN on arrival flags (ranks sharing one GPU: keep it small)
   int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
   int vd_select = 1;          // PA_SPMV_VDICT_SELECT: a dictionary of at most two values is decoded by a select, not through the lane dictionary
+  int test_skip_raise = 0;    // PA_TEST_FUSED_SKIP_RAISE=k (tests only): the k-th fused product over RCCL never gets its flag raised -> its tail times out
   int chain_fused = 1;        // PA_SPMV_CHAIN_FUSED: a column-split chain is built for, and run as, one launch (k_spmv_xring_chain)
 };
 
@@ -57,6 +59,11 @@ struct pa_ctx {
   pa_switches sw;
   int64_t n_chain_fused = 0;                    // column-split chains run as one launch so far
   int64_t n_fused = 0, n_fused_exchange = 0;    // fused product launches so far / of those, with the exchange inside the launch
+  // A fused product over RCCL whose tail gave up waiting for its flag (PA_IPC_TIMEOUT_S) leaves boundary rows unsummed.  The status
+  // words of the context's plans are looked at by pa_ctx_sync -- the point where a host could read the result -- which reports the
+  // time-out ONCE (PA_ERR_STATE); the handle itself goes on with separate launches (round 4's chain) from its next product on.
+  std::vector<int *> fused_status;
+  int64_t n_fused_timeouts = 0;
   bool keep_coo_slots = false;       // pa_coo_keep_input_slots: the assemblies remember where their input triplets went
   int device = 0;
   hipStream_t s[2] = {nullptr, nullptr};  // [0] compute, [1] comm
@@ -282,6 +289,7 @@ struct pa_matrix {
   bool bd_captured = false;                    // a fused launch of this handle sits in a recorded hipGraph: bd and the twin keep their
                                                //   addresses and follow every value update AT the update (pa_csr_values_changed)
   bool fuse_tried = false;
+  bool fused_off = false;                      // a fused product of this handle timed out waiting for its exchange: separate launches from now on
   bool transposed = false;                     // pa_matrix_create_transposed: oo = A_oo', oh = A_oh' (pa_csr_create_transpose), for pa_mul5_transpose
 };
 

@@ -423,13 +423,14 @@ extern "C" int pa_mul5(pa_matrix *m, pa_comm *comm, pa_vec *c, pa_vec *b, double
       return pa_mul_fused_ipc(m, c, b, alpha, beta);
     }
   }
-  if (comm && m->ctx->sw.mul_fused && m->ctx->sw.mul_fused_rccl && !m->ctx->capturing && (m->plan->snd.n || m->plan->rcv.n)) {
+  if (comm && m->ctx->sw.mul_fused && m->ctx->sw.mul_fused_rccl && !m->fused_off && !m->ctx->capturing && (m->plan->snd.n || m->plan->rcv.n)) {
     // one part per process over RCCL: the transport on the comm stream, the whole product ONE launch beside it (pa_fused.hip)
     PA_TRY(pa_matrix_fused_build(m));
     const bool scaled = (m->oo->alpha_inside || m->oh->alpha_inside) && alpha != 1.0;
     if (pa_matrix_fused_ready(m) && !scaled) {
       pa_csr_before_product(m->oo);
-      return pa_mul_fused_rccl(m, comm, c, b, alpha, beta);
+      const int st = pa_mul_fused_rccl(m, comm, c, b, alpha, beta);
+      if (st != PA_FUSED_GAVE_UP) return st;                                 // (an earlier product timed out: this one on the chain below)
     }
   }
   PA_TRY(pa_exchange_start(m->plan, comm, b, PA_CONSISTENT));                // t = consistent!(b)

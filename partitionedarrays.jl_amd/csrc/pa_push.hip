@@ -674,7 +674,8 @@ extern "C" int pa_plan_ipc_connect(pa_plan *p, int32_t n_blobs, const void *cons
   for (int k = 0; k < n_blobs; ++k) {
     peer_view V;
     PA_TRY(parse_blob(blobs[k], sizes[k], V));
-    if (V.h.part == p->part) continue;
+    // (its own blob matters only to a part that is its own neighbour: a periodic direction with one part -- the link then points
+    //  at this process's own region, no handle is opened)
     const bool nb = std::find(p->snd.nbr.begin(), p->snd.nbr.end(), V.h.part) != p->snd.nbr.end() ||
                     std::find(p->rcv.nbr.begin(), p->rcv.nbr.end(), V.h.part) != p->rcv.nbr.end();
     if (nb) views[V.h.part] = V;
@@ -685,7 +686,8 @@ extern "C" int pa_plan_ipc_connect(pa_plan *p, int32_t n_blobs, const void *cons
     PA_REQUIRE(it != views.end(), "no blob of neighbour part %d", q);
     pa_ipc_link::peer P;
     const ipc_header &h = it->second.h;
-    PA_TRY(ipc_open_chunk(h.h_region, &P.region));
+    if (q == p->part) { std::lock_guard<std::mutex> lk(g_ipc_mu); P.region = g_ipc_chunks[L->chunk].base; }
+    else PA_TRY(ipc_open_chunk(h.h_region, &P.region));
     P.snd = (char *)P.region + h.off_snd;
     P.rcv = (char *)P.region + h.off_rcv;
     P.flags = (char *)P.region + h.off_flags;
@@ -702,7 +704,6 @@ extern "C" int pa_plan_ipc_connect(pa_plan *p, int32_t n_blobs, const void *cons
       const int len = o.ptrs[j + 1] - o.ptrs[j];
       if (!len) continue;
       const int q = o.nbr[j];
-      PA_REQUIRE(q != p->part, "a part that sends to itself has no ipc link");
       PA_TRY(open_peer(q));
       const peer_view &V = views[q];
       // the receiver's in-side of this mode: its snd side for consistent!, its rcv side for assemble!
@@ -728,7 +729,6 @@ extern "C" int pa_plan_ipc_connect(pa_plan *p, int32_t n_blobs, const void *cons
       const int len = in.ptrs[i + 1] - in.ptrs[i];
       if (!len) continue;
       const int q = in.nbr[i];
-      PA_REQUIRE(q != p->part, "a part that receives from itself has no ipc link");
       PA_TRY(open_peer(q));
       const peer_view &V = views[q];
       // the sender's out-side of this mode: its rcv side for consistent!, its snd side for assemble!

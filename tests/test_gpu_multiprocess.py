@@ -139,6 +139,33 @@ def test_a_rank_lost_in_an_optional_section_does_not_cost_the_line():
     assert "overlap" in d and 0 < d["roofline"]["frac"] <= 1.0
 
 
+def test_a_rank_lost_in_the_fused_product_section_leaves_the_line_of_the_separate_launches():
+    """VERDICT r05 "Next" #1a: for N > 1 the parity gate and the first timed loop run on the conservative product (separate launches,
+    PA_MUL_FUSED=0) and rank 0 holds a complete line BEFORE the library's default -- one launch per part with the exchange waited for
+    inside the launch -- is gated and timed.  Rank 1 never returns from that section (injected): the line goes out with the value of
+    the separate launches, says so, names the section, status 0."""
+    r, d = _bench(2, {"PA_TRANSPORT": "ipc", "PA_BENCH_BACKEND": "gloo", "PA_BENCH_FAULT": "fused product:hang:1",
+                      "PA_BENCH_SECTION_TIMEOUT_S": "20"}, ("--no-cpu-baseline",))
+    assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    assert d["value"] > 0 and d["config"]["product_path"].startswith("separate launches"), d["config"]
+    assert d["optional_sections_unfinished"] == ["fused product"] and "fused_ab" not in d
+    assert d["parity_gate"].startswith("A*1==b") and 0 < d["roofline"]["frac"] <= 1.0
+
+
+def test_the_fused_product_becomes_the_value_only_behind_its_own_gate():
+    """The same run without the fault: `fused_ab` holds both loops and both gates; `value` is the faster product that passed --
+    config.product_path and fused_ab.value_uses agree, and the one-launch product really was one launch with the exchange inside."""
+    r, d = _bench(2, {"PA_TRANSPORT": "ipc", "PA_BENCH_BACKEND": "gloo"}, ("--no-cpu-baseline",))
+    assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
+    fa = d["fused_ab"]
+    assert fa["parity_gate_one_launch"] and fa["mul_as_one_launch_rank0"] and fa["exchange_inside_the_launch_rank0"], fa
+    assert fa["ms_per_step_one_launch"] > 0 and fa["ms_per_step_separate_launches"] > 0
+    one = fa["value_uses"] == "one launch"
+    assert one == (fa["ms_per_step_one_launch"] < fa["ms_per_step_separate_launches"])
+    assert d["config"]["product_path"].startswith("one launch per part" if one else "separate launches")
+    assert abs(d["ms_per_step"] - (fa["ms_per_step_one_launch"] if one else fa["ms_per_step_separate_launches"])) < 1e-3
+
+
 def test_bench_eight_ranks_sharing_the_gpu_print_a_self_diagnosing_line():
     """VERDICT r02 #9 (first-contact insurance for the 8-GPU record): `bench.py --gpus 8 --grid 32` the way the driver
     launches it, all eight ranks on this box's one GPU over the host-staged transport: part grid (2,2,2), every part has
