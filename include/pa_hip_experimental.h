@@ -117,6 +117,17 @@ int pa_sell_destroy(pa_sell *A);
 int pa_sell_info(const pa_sell *A, int64_t *n_slabs, int64_t *padded_entries, int64_t *nnz);
 int pa_sell_spmv(const pa_sell *A, const pa_vec *x, int x_segment, pa_vec *y, int y_segment, double alpha, double beta);
 
+/* ---- pattern-ELL: the lane-per-row product kernel of pattern blocks (csrc/pa_pell.h, pa_pell.hip; round 6) ---------------
+ * A block whose slabs of 64 consecutive stored rows each have at most 32 distinct (column - row) offsets -- stencil and structured
+ * FEM operators, their row-compacted colour and restriction subsets -- gets, at creation, a second storage: per slab the ascending
+ * union of offsets (a pattern table entry), per row a 32-bit mask of the offsets it has, and the values delta-major per slab (or,
+ * when the block's value dictionary has at most two values, one bit per entry).  pa_spmv / pa_mul* then run it on k_spmv_pell: one
+ * lane per row adds its products in stored order (spmv_csr! src/sparse_utils.jl:649-669: same bits as the row-split kernel), the
+ * offsets are wave-uniform scalars, no LDS, no barrier.  PA_SPMV_PELL=0 (read per context / at block creation): the row-split kernel.
+ * *mode: what a product of this block runs on NOW -- 0 row split, 1 pattern-ELL with the fp64 stream, 2 pattern-ELL with one bit per
+ * entry; the other outputs describe the storage (0 when the block has none).  Any output may be NULL. */
+int pa_csr_pell_info(const pa_csr *A, int *mode, int64_t *n_slabs, int64_t *n_patterns, int64_t *value_slots, int *unroll);
+
 /* ---- Gauss-Seidel smoother and grid transfer of the HPCG multigrid preconditioner ----------- */
 /* gauss_seidel_sweep! / gauss_seidel_sweep_zero! (PartitionedSolvers/src/smoothers.jl:144-160,236-259) on the
  * UNSPLIT local CSR of one part (n_own rows, n_local columns [own|ghost], as HPCG builds it: split_format=false).

@@ -179,6 +179,7 @@ _SIGS = {
     "pa_sell_destroy": [P],
     "pa_sell_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "pa_sell_spmv": [P, P, cint, P, cint, f64, f64],
+    "pa_csr_pell_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(cint)],
     "pa_plan_create": [P, i32, i64, i32, P, P, P, i32, P, P, P, cint, PP],
     "pa_plan_destroy": [P],
     "pa_plan_buffers": [P, cint, PP, C.POINTER(i64), PP, C.POINTER(i64)],

@@ -150,7 +150,7 @@ static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
             !missing) {
           A->use_vdict = true;
           A->n_dict = P->n_dict;
-          return PA_OK;
+          return pa_pell_bits_refresh(A);
         }
       }
       (void)hipGetLastError();                               // (anything amiss: the block finds its own dictionary below)
@@ -203,7 +203,7 @@ static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { pa_set_err("value dictionary: encoding failed"); return done(PA_ERR_HIP); }
   A->use_vdict = true;
   A->n_dict = (int)dict.size();
-  return done(PA_OK);
+  return done(pa_pell_bits_refresh(A));       // (a block with pattern-ELL storage and <= 2 values: its one-bit stream again)
 }
 
 // a block whose values were updated runs on the fp64 stream; once it has served 8 products on the new values its codes are renewed
@@ -222,6 +222,7 @@ static void vdict_maintain(const pa_csr *A) {
 // dictionary the recorded graph cannot be served any more: an error, not a silent wrong product.
 static int vdict_after_update(pa_csr *A) {
   A->val_epoch++;
+  for (pa_csr *S = A; S; S = S->next) PA_TRY(pa_pell_after_update(S));
   for (pa_csr *S = A; S; S = S->next) {
     if (!S->vd_captured) continue;
     PA_REQUIRE(!S->ctx->capturing, "values of a block whose product is already recorded must not be updated inside a capture");
@@ -486,6 +487,8 @@ static int csr_fill_slab(pa_ctx *c, pa_csr *A, int64_t n_rows, int64_t n_cols, i
   }
   // lossless value dictionary (see vdict_build): built by kernels from the value stream that is in HBM by now
   PA_TRY(vdict_build(c, A, false));
+  // pattern blocks: second storage for the lane-per-row kernel (pa_pell.h); never an error
+  (void)pa_pell_build(A);
   return PA_OK;
 }
 
@@ -547,6 +550,8 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, con
   head->t_rows = n_rows;
   head->t_nnz = nnz;
   *out = head;
+  // (a block of 2^31 entries or more: no second value stream beside tens of GB -- its slabs stay on the row-split kernel)
+  if (head->next && nnz >= ((int64_t)1 << 31) - ((int64_t)1 << 16)) for (pa_csr *S = head; S; S = S->next) pa_pell_free(S);
   // a block of unstructured rows whose band is wider than the sliding x window holds: split by columns into pieces the window does
   // hold (pa_transpose.hip; the pieces are built through this function again, hence the guard)
   if (!pa_tls_piece_build && !head->next) {
@@ -805,6 +810,7 @@ static void csr_free_chain(pa_csr *A) {
     if (A->d_pdelta) pa_dev_free(A->ctx, A->d_pdelta);
     if (A->d_code) pa_dev_free(A->ctx, A->d_code);
     if (A->d_dict) pa_dev_free(A->ctx, A->d_dict);
+    pa_pell_free(A);
     delete A;
     A = n;
   }
@@ -999,6 +1005,7 @@ extern "C" int pa_csr_stream_bytes(const pa_csr *A, int64_t *bytes) {
   PA_REQUIRE(A && bytes, "bad arguments");
   int64_t t = 0;
   for (const pa_csr *S = A; S; S = S->next) {
+    if (const int pm = pa_pell_mode(S)) { t += pa_pell_stream_bytes(S, pm); continue; }
     t += (S->use_vdict ? 1 : 8) * S->nnz + 4 * (S->n_crows + 1);
     if (S->use_vdict) t += 8 * PA_VDICT_MAX;
     t += 8 * (S->n_chunks + 1);                                                    // {row, pointer} pairs
@@ -1191,6 +1198,10 @@ void pa_launch_xwin(const pa_csr *S, const double *xs, double *ys, double alpha,
 // the product kernel on one slab, raw pointers (x: the block's column segment, ys: this slab's rows)
 static void spmv_launch_slab(const pa_csr *S, const double *xs, double *ys, double alpha, double kbeta, hipStream_t st = nullptr) {
   if (!st) st = S->ctx->s[0];
+  if (const int pm = pa_pell_mode(S)) {                // a pattern block: one lane per row, no LDS (pa_pell.h)
+    (void)pa_pell_launch(S, pm, 0, xs, ys, alpha, kbeta, nullptr, nullptr, nullptr, st);
+    return;
+  }
   if (S->n_xw_groups > 0 && !S->use_vdict) {
     pa_launch_xwin(S, xs, ys, alpha, kbeta, nullptr, nullptr, st);
     return;

@@ -51,6 +51,7 @@ struct pa_switches {
   int fused_tail_blocks = 1024;  // PA_FUSED_TAIL_BLOCKS: tail blocks of a fused launch that may SPIN on arrival flags (ranks sharing one GPU: keep it small)
   int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
   int vd_select = 1;          // PA_SPMV_VDICT_SELECT: a dictionary of at most two values is decoded by a select, not through the lane dictionary
+  int pell = 1;               // PA_SPMV_PELL: blocks that have pattern-ELL storage run on k_spmv_pell (0: the row-split kernel; also read at block creation)
   int test_skip_raise = 0;    // PA_TEST_FUSED_SKIP_RAISE=k (tests only): the k-th fused product over RCCL never gets its flag raised -> its tail times out
   int chain_fused = 1;        // PA_SPMV_CHAIN_FUSED: a column-split chain is built for, and run as, one launch (k_spmv_xring_chain)
 };
@@ -128,8 +129,11 @@ struct pa_vec {
   bool owned = true;
 };
 
+struct pa_pell;      // pattern-ELL storage of a slab (pa_pell.hip), or none
+
 struct pa_csr {
   pa_ctx *ctx = nullptr;
+  pa_pell *pell = nullptr;         // second storage of a pattern block for the lane-per-row kernel k_spmv_pell (pa_pell.h); NULL: none
   int64_t n_rows = 0, n_cols = 0, nnz = 0;
   int64_t n_crows = 0, n_chunks = 0, n_nonempty = 0, n_long = 0;
   bool compact = false;
@@ -194,6 +198,17 @@ struct pa_csr {
   int chain_pieces = 0;
   int64_t t_rows = 0, t_nnz = 0;
 };
+
+// pa_pell.hip
+int pa_pell_build(pa_csr *A);                       // at the end of a slab's creation; never an error (a block that does not qualify has none)
+void pa_pell_free(pa_csr *A);
+int pa_pell_after_update(pa_csr *A);                // behind a value update: the fp64 stream follows in place
+int pa_pell_bits_refresh(pa_csr *A);                // behind a renewal of the value dictionary: one bit per entry again (<= 2 values)
+int pa_pell_mode(const pa_csr *A);                  // 0: the row-split kernel serves; 1: pattern-ELL fp64 stream; 2: one bit per entry
+int pa_pell_launch(const pa_csr *A, int mode, int epi, const double *x, double *y, double alpha, double beta, double *gs_x,
+                   const double *gs_b, const double *gs_diag, hipStream_t st);
+int64_t pa_pell_partials(const pa_csr *A);          // EPI 3 writes one partial sum per slab
+int64_t pa_pell_stream_bytes(const pa_csr *A, int mode);
 
 struct pa_push_table;   // device tables of the push transport for a group of plans in one process (pa_push.hip)
 struct pa_ipc_link;     // the neighbours' receive buffers and flags mapped over hipIpc, one part per process (pa_push.hip)

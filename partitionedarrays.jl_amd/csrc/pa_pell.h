@@ -1,0 +1,133 @@
+// pa_pell.h -- "pattern-ELL": the byte-bound SpMV kernel for blocks whose rows follow a handful of column patterns (round 6).
+//
+// Reference loop: spmv_csr! src/sparse_utils.jl:649-669 (y[row] = sum over the row's stored entries, ascending p, one rounding per
+// multiply and per add); mul!(y,A,x,alpha,beta) of SparseMatricesCSR as called at src/p_sparse_matrix.jl:2088.
+//
+// Why (VERDICT r05 "What's weak" 3, profiles/r05_k1_sq.json): on pattern blocks the row-split kernel k_spmv_rowsplit no longer reads a
+// column stream, and with the value dictionary not even fp64 values -- yet it cannot go below ~0.45 ms at 256^3: products staged in
+// LDS, a ds_bpermute per decoded delta, a barrier, and one wave in four adding 27 dependent LDS-fed products per row.  Its floor is
+// the LDS pipe and a chain of dependent round trips, not bytes.
+//
+// Here ONE LANE owns ONE ROW and a wavefront owns a SLAB of 64 consecutive stored rows:
+//   * a slab's column pattern is the UNION of its rows' (column - row id) deltas, ascending: D[0..W), W <= 32, wave-uniform -- the
+//     deltas sit in SCALAR registers (s_load from a small pattern table), lane l gathers x[rid(l) + D[k]]: for consecutive rows
+//     that is one contiguous 512-byte load per k -- no ds_bpermute, no decode, no LDS, no barrier;
+//   * row l takes part in delta k when bit k of its 32-bit mask is set (rows at the ends of a grid line lack some neighbours): the k-th
+//     set bit is the row's k-th stored entry, so walking k upwards adds the row's products in stored order -- the additions of
+//     spmv_csr!, same bits (file compiled -ffp-contract=off); absent entries are neither loaded (the gather index falls back to 0) nor
+//     added (an added +0.0 could turn a -0.0 sum into +0.0);
+//   * values are re-laid per slab, delta-major: val[(off + k) * 64 + lane] -- every value load of a wavefront is one contiguous
+//     512 bytes (SELL-64 without its column array, csrc/pa_sell.hip); slots of absent entries hold 0.0 and are read, never used;
+//     a slab's width is padded to a multiple of the unroll U (the block's commonest width divides by it: no padding there);
+//   * VM 1: a block with at most TWO distinct stored values (HPCG: 26 and -1 on every level, in every colour) keeps ONE BIT per
+//     entry -- a second 32-bit word per row -- and no value stream at all: 8 bytes of matrix per ROW.
+// Moved bytes per row at 27 entries: fp64 stream 216 + 4 (mask) (+ 4 row id when the block is row-compacted) against the row-split
+// kernel's 216 + 20; one-bit stream 8 against 27 + 20.
+#ifndef PA_PELL_H
+#define PA_PELL_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pa_spmv_kernel.h"
+
+#define PA_PELL_MAXW 32                  /* deltas of a slab's union (bits of a row mask) */
+#define PA_PELL_TW 44                    /* ints per pattern in the table: the deltas, padded with 0 up to the padded width (<= 32 + 9 - 1) */
+
+struct pa_pell_dev {
+  const int2 *desc = nullptr;            // per slab {pattern | padded width << 20, first value slot / 64}
+  const int *pdelta = nullptr;           // n_patterns x PA_PELL_TW
+  const unsigned *mask = nullptr;        // per stored row: which deltas of its slab's pattern it has
+  const unsigned *bits = nullptr;        // VM 1: per stored row, bit k = dictionary code of the entry at delta k
+  const double *val = nullptr;           // VM 0: slab-major, delta-major, lane-minor
+  const double *dict = nullptr;          // VM 1: the two values
+  const int *row_ids = nullptr;          // row-compacted block: stored row -> row
+  int n_slabs = 0, n_crows = 0;
+};
+
+// one slab.  EPI / FX as in pa_rowsplit_chunk (pa_spmv_kernel.h): EPI 0 product, 1 Gauss-Seidel colour update in place, 2 residual +
+// restriction, 3 product + this slab's term of a dot product (partial[slab]); FX 1: rows whose bit is set in fx.rowmask are left
+// alone (the fused launch's tail sums them).
+template <int U, int VM, bool COMPACT, int EPI, int FX>
+__device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, const double *__restrict__ x_in, double *__restrict__ y,
+                                             double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
+                                             const double *__restrict__ gs_diag, const pa_fx fx) {
+  const double *x = EPI == 1 ? gs_x : x_in;          // EPI 1 reads and writes the same vector: no restrict promise on it
+  const int lane = threadIdx.x & 63;
+  const int2 d = P.desc[slab];                       // (slab is wave-uniform: scalar loads)
+  const int pat = d.x & 0xfffff, Wp = d.x >> 20;
+  const int *dl = P.pdelta + (size_t)pat * PA_PELL_TW;
+  const int r = slab * 64 + lane;
+  const bool live = r < P.n_crows;
+  const int rc = live ? r : P.n_crows - 1;
+  unsigned long long m = live ? P.mask[rc] : 0u;
+  const int row = COMPACT ? P.row_ids[rc] : rc;
+  bool mine = live;
+  if (FX == 1) {
+    if ((fx.rowmask[row >> 5] >> (row & 31)) & 1u) { mine = false; m = 0; }      // a boundary row: the launch's tail sums and stores it
+  }
+  unsigned long long vb = 0;
+  double d0 = 0.0, d1 = 0.0;
+  if (VM == 1) { vb = P.bits[rc]; d0 = P.dict[0]; d1 = P.dict[1]; }
+  const double *vp = P.val + (size_t)(unsigned)d.y * 64 + lane;
+  double acc = 0.0, accp = 0.0;
+  if ((EPI == 0 || EPI == 3) && beta != 0.0 && mine) acc = beta * y[row];
+  for (int k0 = 0; k0 < Wp; k0 += U) {
+    double v[U], xv[U];
+    bool on[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      if (VM == 0) v[j] = __builtin_nontemporal_load(vp + (size_t)(k0 + j) * 64);
+      else v[j] = ((vb >> (k0 + j)) & 1ull) ? d1 : d0;
+      on[j] = (m >> (k0 + j)) & 1ull;
+      const int c = on[j] ? row + dl[k0 + j] : 0;
+      xv[j] = x[c];
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      double pr = v[j] * xv[j];
+      if (alpha != 1.0) pr = pr * alpha;
+      if (on[j]) {
+        acc = acc + pr;
+        if (EPI == 3) accp = accp + pr;
+      }
+    }
+  }
+  if (EPI == 0) {
+    if (mine) __builtin_nontemporal_store(acc, &y[row]);
+  } else if (EPI == 1) {
+    if (mine) gs_x[row] = gs_x[row] + (gs_b[row] - acc) / gs_diag[row];
+  } else if (EPI == 2) {
+    if (mine) gs_x[r] = gs_b[row] - acc;
+  } else {
+    double dacc = 0.0;
+    if (mine) {
+      __builtin_nontemporal_store(acc, &y[row]);
+      dacc = gs_b[row] * accp;
+    }
+    dacc = pa_wave_sum(dacc);
+    if (lane == 0) gs_x[slab] = dacc;
+  }
+}
+
+// blockIdx -> slabs: four slabs per workgroup (one per wavefront), consecutive workgroups of an XCD take consecutive slabs (block b
+// sits on XCD b % 8; each XCD has its own L2, and the rows of neighbouring grid lines and planes share their x).  bpx < 0: the same
+// map walked backwards (every other product of a big block: what the last product left in the caches is read first, PA_SPMV_ALTERNATE).
+template <int U, int VM, bool COMPACT, int EPI>
+__global__ __launch_bounds__(256) void k_spmv_pell(const pa_pell_dev P, const double *__restrict__ x, double *__restrict__ y, int bpx,
+                                                   double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
+                                                   const double *__restrict__ gs_diag) {
+  const int b = blockIdx.x;
+  const bool backwards = bpx < 0;
+  if (backwards) bpx = -bpx;
+  int g = (b & 7) * bpx + (b >> 3);
+  const int n_groups = (P.n_slabs + 3) >> 2;
+  if (g >= n_groups) return;
+  if (backwards) g = n_groups - 1 - g;
+  const int slab = __builtin_amdgcn_readfirstlane(g * 4 + (int)(threadIdx.x >> 6));
+  if (slab >= P.n_slabs) return;
+  pa_pell_slab<U, VM, COMPACT, EPI, 0>(P, slab, x, y, alpha, beta, gs_x, gs_b, gs_diag, pa_fx());
+}
+
+#endif

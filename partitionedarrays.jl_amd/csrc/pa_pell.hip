@@ -1,0 +1,354 @@
+// pa_pell.hip -- pattern-ELL storage of a CSR block (pa_pell.h: the kernel and why), built in HBM from the block's own arrays.
+//
+// Reference: spmv_csr! src/sparse_utils.jl:649-669; mul!(y,A,x,alpha,beta) as called at src/p_sparse_matrix.jl:2088.
+//
+// A block qualifies when every slab of 64 consecutive stored rows has at most 32 distinct (column - row id) deltas and the padding
+// the slab-wide union costs stays small (<= 25 % more slots than stored entries): stencil and structured-FEM operators, their
+// row-compacted colour blocks and restriction subsets.  Anything else stays on the row-split kernel; nothing here can fail a block's
+// creation (no room, too irregular: the block simply has no pattern-ELL storage).
+//   build   : decode the columns (pa_dev_decode_entries) -> kp_union: per slab the ascending union of deltas by repeated wave-minimum
+//             (the step at which a lane's next entry IS the minimum is that entry's bit in the row mask) -> host: the distinct unions
+//             (a few dozen) become the pattern table, slab widths padded to the unroll -> kp_verify (a hash collision would be caught
+//             here) -> kp_fill: values delta-major per slab, or one bit per entry when the block's dictionary has at most two values.
+//   updates : pa_csr_update_values* / psparse! write d_val; pa_pell_after_update re-runs kp_fill behind them on the compute stream
+//             (same pattern, same addresses: recorded graphs stay valid).
+#include "pa_dev_util.h"
+
+#include "pa_setup.h"
+#include "pa_pell.h"
+
+#include <chrono>
+#include <map>
+
+using namespace pa_util;
+
+struct pa_pell {
+  int U = 9;
+  int64_t n_slabs = 0, n_patterns = 0, slots = 0;      // slots: 64-entry units of the value stream
+  int max_w = 0;
+  int2 *d_desc = nullptr;
+  int *d_pdelta = nullptr;
+  unsigned *d_mask = nullptr, *d_bits = nullptr;
+  double *d_val = nullptr;
+  uint64_t bits_epoch = ~(uint64_t)0;                  // A->val_epoch the bits were made at
+  uint64_t n_launched = 0;
+};
+
+__device__ __forceinline__ int kp_wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// one wavefront per slab: D = ascending union of the rows' deltas (repeated wave minimum), mask[r] bit k = row r has delta D[k]
+__global__ __launch_bounds__(256) void kp_union(const int *__restrict__ crp, const int *__restrict__ col, const int *__restrict__ row_ids,
+                                                int n_crows, int n_slabs, int *__restrict__ out_len, int *__restrict__ out_D,
+                                                unsigned *__restrict__ out_mask, unsigned long long *__restrict__ out_hash) {
+  const int slab = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slab >= n_slabs) return;
+  const int r = slab * 64 + lane;
+  const bool live = r < n_crows;
+  int p = live ? crp[r] : 0;
+  const int e = live ? crp[r + 1] : 0;
+  const int rid = live ? (row_ids ? row_ids[r] : r) : 0;
+  unsigned mask = 0;
+  int count = 0;
+  bool fail = false;
+  for (;;) {
+    const int cur = p < e ? col[p] - rid : 0x7fffffff;
+    const int mn = kp_wave_min(cur);
+    if (mn == 0x7fffffff) break;
+    if (count == PA_PELL_MAXW) { fail = true; break; }
+    if (lane == 0) out_D[(size_t)slab * PA_PELL_MAXW + count] = mn;
+    if (cur == mn) { mask |= 1u << count; ++p; }
+    ++count;
+  }
+  if (live) out_mask[r] = fail ? 0u : mask;
+  if (lane == 0) {
+    out_len[slab] = fail ? -1 : count;
+    unsigned long long h = 1469598103934665603ull ^ (unsigned long long)count;
+    if (!fail)
+      for (int k = 0; k < count; ++k) {
+        h ^= (unsigned long long)(unsigned)out_D[(size_t)slab * PA_PELL_MAXW + k];
+        h *= 1099511628211ull;
+        h ^= h >> 29;
+      }
+    out_hash[slab] = h;
+  }
+}
+
+// every slab's union against the table row its hash was mapped to
+__global__ void kp_verify(const int *__restrict__ len, const int *__restrict__ D, const int2 *__restrict__ desc, const int *__restrict__ pdelta,
+                          int n_slabs, int *__restrict__ bad) {
+  const int slab = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slab >= n_slabs) return;
+  const int pat = desc[slab].x & 0xfffff;
+  for (int k = 0; k < len[slab]; ++k)
+    if (D[(size_t)slab * PA_PELL_MAXW + k] != pdelta[(size_t)pat * PA_PELL_TW + k]) { atomicOr(bad, 1); return; }
+}
+
+// VM 0: the values, delta-major per slab; VM 1: one bit per entry (its dictionary code), a word per row
+template <int VM>
+__global__ __launch_bounds__(256) void kp_fill(const int *__restrict__ crp, const double *__restrict__ val, const unsigned char *__restrict__ code,
+                                               const unsigned *__restrict__ mask, const int2 *__restrict__ desc, int n_crows, int n_slabs,
+                                               double *__restrict__ out_val, unsigned *__restrict__ out_bits) {
+  const int slab = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slab >= n_slabs) return;
+  const int r = slab * 64 + lane;
+  if (r >= n_crows) return;
+  unsigned m = mask[r];
+  int p = crp[r];
+  const size_t base = (size_t)(unsigned)desc[slab].y * 64 + lane;
+  unsigned bits = 0;
+  while (m) {
+    const int k = __builtin_ctz(m);
+    m &= m - 1;
+    if (VM == 0) out_val[base + (size_t)k * 64] = val[p];
+    else bits |= (unsigned)(code[p] & 1) << k;
+    ++p;
+  }
+  if (VM == 1) out_bits[r] = bits;
+}
+
+void pa_pell_free(pa_csr *A) {
+  pa_pell *P = A->pell;
+  if (!P) return;
+  pa_ctx *c = A->ctx;
+  pa_dev_free(c, P->d_desc);
+  pa_dev_free(c, P->d_pdelta);
+  pa_dev_free(c, P->d_mask);
+  if (P->d_bits) pa_dev_free(c, P->d_bits);
+  if (P->d_val) pa_dev_free(c, P->d_val);
+  delete P;
+  A->pell = nullptr;
+}
+
+static bool pell_wanted() {
+  const char *e = getenv("PA_SPMV_PELL");
+  return !(e && atoi(e) == 0);
+}
+
+static int pell_fill(pa_csr *A, bool bits) {
+  pa_pell *P = A->pell;
+  hipStream_t s = A->ctx->s[0];
+  const dim3 grid((unsigned)((P->n_slabs + 3) / 4));
+  if (bits)
+    hipLaunchKernelGGL(kp_fill<1>, grid, dim3(256), 0, s, A->d_crp, (const double *)nullptr, A->d_code, P->d_mask, P->d_desc, (int)A->n_crows,
+                       (int)P->n_slabs, (double *)nullptr, P->d_bits);
+  else
+    hipLaunchKernelGGL(kp_fill<0>, grid, dim3(256), 0, s, A->d_crp, A->d_val, (const unsigned char *)nullptr, P->d_mask, P->d_desc,
+                       (int)A->n_crows, (int)P->n_slabs, P->d_val, (unsigned *)nullptr);
+  PA_HIP(hipGetLastError());
+  if (bits) P->bits_epoch = A->val_epoch;
+  return PA_OK;
+}
+
+// Called at the end of a slab's creation (pa_csr.hip).  Never an error to the caller: a block that does not qualify, or a device
+// without room for the second value stream, keeps the row-split kernel.
+int pa_pell_build(pa_csr *A) {
+  if (A->pell || !pell_wanted() || pa_tls_plain_encoding || A->nnz == 0 || A->n_crows == 0 || A->next || A->n_xw_groups > 0) return PA_OK;
+  if (!A->use_pattern || A->n_pattern_chunks * 10 < A->n_chunks * 9) return PA_OK;      // (rows without patterns: not worth the look)
+  if (A->ctx->capturing) return PA_OK;
+  pa_ctx *c = A->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  const auto t_begin = std::chrono::steady_clock::now();
+  const int64_t n_slabs = (A->n_crows + 63) / 64;
+  pa_pell *P = new pa_pell();
+  P->n_slabs = n_slabs;
+  auto give_up = [&](const char *why) {
+    (void)hipGetLastError();
+    A->pell = P;
+    pa_pell_free(A);
+    if (getenv("PA_SETUP_TIMING")) fprintf(stderr, "[pa setup] pattern-ELL of %lld entries: none (%s)\n", (long long)A->nnz, why);
+    return PA_OK;
+  };
+  scratch sc;
+  int32_t *d_row = nullptr, *d_col = nullptr;
+  int *d_len = nullptr, *d_D = nullptr, *d_bad = nullptr;
+  unsigned long long *d_hash = nullptr;
+  if (sc.get(&d_row, (size_t)A->nnz + 8) || sc.get(&d_col, (size_t)A->nnz + 8) || sc.get(&d_len, (size_t)n_slabs) ||
+      sc.get(&d_D, (size_t)n_slabs * PA_PELL_MAXW) || sc.get(&d_hash, (size_t)n_slabs) || sc.get(&d_bad, 1))
+    return give_up("no room for the set-up's temporaries");
+  if (pa_dev_alloc(c, (void **)&P->d_mask, sizeof(unsigned) * (size_t)A->n_crows, PA_MEM_MATRIX)) return give_up("no room");
+  if (pa_dev_decode_entries(A, d_row, d_col) != PA_OK) return give_up("decode failed");
+  hipLaunchKernelGGL(kp_union, dim3((unsigned)((n_slabs + 3) / 4)), dim3(256), 0, s, A->d_crp, d_col, A->d_row_ids, (int)A->n_crows, (int)n_slabs,
+                     d_len, d_D, P->d_mask, d_hash);
+  std::vector<int> len((size_t)n_slabs);
+  std::vector<unsigned long long> hash((size_t)n_slabs);
+  if (d2h(s, len.data(), d_len, (size_t)n_slabs) || d2h(s, hash.data(), d_hash, (size_t)n_slabs)) return give_up("read-back failed");
+  sc.release(d_row);
+  // the unroll: the commonest width decides (27 -> 9, 7 -> 7, 5 -> 5, else 4); widths are padded to it
+  std::map<int, int64_t> freq;
+  int max_w = 0;
+  for (int64_t k = 0; k < n_slabs; ++k) {
+    if (len[k] < 0) return give_up("a slab of 64 rows has more than 32 distinct column offsets");
+    ++freq[len[k]];
+    max_w = std::max(max_w, len[k]);
+  }
+  int common = 0;
+  int64_t best = -1;
+  for (auto &kv : freq) if (kv.second > best) { best = kv.second; common = kv.first; }
+  const int U = common % 9 == 0 && common ? 9 : common % 7 == 0 && common ? 7 : common % 5 == 0 && common ? 5 : 4;
+  P->U = U; P->max_w = max_w;
+  // distinct unions -> pattern ids (by hash and length; kp_verify compares the lists themselves)
+  std::map<std::pair<unsigned long long, int>, int> ids;
+  std::vector<int64_t> rep;
+  std::vector<int2> desc((size_t)n_slabs);
+  int64_t slots = 0;
+  for (int64_t k = 0; k < n_slabs; ++k) {
+    auto key = std::make_pair(hash[k], len[k]);
+    auto it = ids.find(key);
+    if (it == ids.end()) {
+      if (ids.size() >= 4096) return give_up("more than 4096 distinct slab patterns");
+      it = ids.emplace(key, (int)ids.size()).first;
+      rep.push_back(k);
+    }
+    const int wp = (len[k] + U - 1) / U * U;
+    if (slots + wp >= ((int64_t)1 << 32)) return give_up("value stream too long for 32-bit slab offsets");
+    desc[(size_t)k].x = it->second | (wp << 20);
+    desc[(size_t)k].y = (int)(unsigned)slots;
+    slots += wp;
+  }
+  if (slots * 64 > A->nnz + A->nnz / 4 + 64 * 64) return give_up("the slab-wide unions would pad the value stream by more than 25 %");
+  P->n_patterns = (int64_t)ids.size(); P->slots = slots;
+  std::vector<int> table((size_t)P->n_patterns * PA_PELL_TW, 0);
+  for (size_t i = 0; i < rep.size(); ++i)
+    if (len[(size_t)rep[i]] > 0 &&
+        hipMemcpyAsync(&table[i * PA_PELL_TW], d_D + (size_t)rep[i] * PA_PELL_MAXW, sizeof(int) * (size_t)len[(size_t)rep[i]], hipMemcpyDeviceToHost, s) != hipSuccess)
+      return give_up("read-back failed");
+  if (hipStreamSynchronize(s) != hipSuccess) return give_up("read-back failed");
+  if (pa_dev_alloc(c, (void **)&P->d_desc, sizeof(int2) * (size_t)n_slabs, PA_MEM_MATRIX) ||
+      pa_dev_alloc(c, (void **)&P->d_pdelta, sizeof(int) * table.size(), PA_MEM_MATRIX))
+    return give_up("no room");
+  if (pa_h2d(P->d_desc, desc.data(), sizeof(int2) * (size_t)n_slabs) != hipSuccess ||
+      pa_h2d(P->d_pdelta, table.data(), sizeof(int) * table.size()) != hipSuccess || hipMemsetAsync(d_bad, 0, sizeof(int), s) != hipSuccess)
+    return give_up("upload failed");
+  hipLaunchKernelGGL(kp_verify, grid1(n_slabs), dim3(256), 0, s, d_len, d_D, P->d_desc, P->d_pdelta, (int)n_slabs, d_bad);
+  int bad = 1;
+  if (d2h(s, &bad, d_bad, 1) || bad) return give_up("two different slab patterns share a hash");
+  A->pell = P;
+  // the value stream: one bit per entry when the block's dictionary (built just before) has at most two values, else fp64
+  const bool two = A->use_vdict && A->n_dict <= 2;
+  if (two) {
+    if (pa_dev_alloc(c, (void **)&P->d_bits, sizeof(unsigned) * (size_t)A->n_crows, PA_MEM_MATRIX)) return give_up("no room");
+  } else if (!A->use_vdict) {
+    if (pa_dev_alloc(c, (void **)&P->d_val, sizeof(double) * (size_t)std::max<int64_t>(slots, 1) * 64, PA_MEM_MATRIX)) return give_up("no room");
+    if (hipMemsetAsync(P->d_val, 0, sizeof(double) * (size_t)std::max<int64_t>(slots, 1) * 64, s) != hipSuccess) return give_up("memset failed");
+  } else {
+    return give_up("a dictionary of more than two values: the row-split kernel's one-byte stream serves");
+  }
+  if (pell_fill(A, two) != PA_OK || hipStreamSynchronize(s) != hipSuccess) return give_up("fill failed");
+  if (getenv("PA_SETUP_TIMING"))
+    fprintf(stderr, "[pa setup] pattern-ELL of %lld entries: %lld slabs, %lld patterns, width <= %d, unroll %d, %lld slots (%.3f x the entries), %s, %.3f ms\n",
+            (long long)A->nnz, (long long)n_slabs, (long long)P->n_patterns, max_w, U, (long long)slots * 64, slots * 64.0 / A->nnz,
+            two ? "one bit per entry" : "fp64 stream", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  return PA_OK;
+}
+
+// behind a value update of slab A (queued on the compute stream): the fp64 stream follows in place
+int pa_pell_after_update(pa_csr *A) {
+  pa_pell *P = A->pell;
+  if (P && P->d_val) PA_TRY(pell_fill(A, false));
+  return PA_OK;
+}
+
+// behind a (re)built value dictionary of slab A (vdict_build, pa_csr.hip; the codes are in HBM): with at most two values the bits are
+// made again from the codes, on the compute stream, complete when this returns (the next product may run on the comm stream)
+int pa_pell_bits_refresh(pa_csr *A) {
+  pa_pell *P = A->pell;
+  if (!P || !A->use_vdict || A->n_dict > 2) return PA_OK;
+  if (!P->d_bits) {
+    if (A->ctx->capturing) return PA_OK;
+    if (pa_dev_alloc(A->ctx, (void **)&P->d_bits, sizeof(unsigned) * (size_t)A->n_crows, PA_MEM_MATRIX) != PA_OK) { (void)hipGetLastError(); P->d_bits = nullptr; return PA_OK; }
+  }
+  PA_TRY(pell_fill(A, true));
+  if (!A->ctx->capturing) PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
+  return PA_OK;
+}
+
+// 0: the row-split kernel serves; 1: fp64 stream; 2: one bit per entry
+int pa_pell_mode(const pa_csr *A) {
+  const pa_pell *P = A->pell;
+  if (!P || A->alpha_inside || A->accumulate || !A->ctx->sw.pell) return 0;
+  if (P->d_bits && A->use_vdict && !A->vdict_stale && A->n_dict <= 2 && P->bits_epoch == A->val_epoch) return 2;
+  return P->d_val ? 1 : 0;
+}
+
+static pa_pell_dev pell_dev(const pa_csr *A, int mode) {
+  const pa_pell *P = A->pell;
+  pa_pell_dev D;
+  D.desc = P->d_desc; D.pdelta = P->d_pdelta; D.mask = P->d_mask; D.bits = P->d_bits; D.val = P->d_val; D.dict = A->d_dict;
+  D.row_ids = A->d_row_ids; D.n_slabs = (int)P->n_slabs; D.n_crows = (int)A->n_crows;
+  (void)mode;
+  return D;
+}
+
+template <int U, int VM, int EPI>
+static void pell_launch_uv(const pa_csr *A, const pa_pell_dev &D, int nblk, int bpx, const double *x, double *y, double alpha, double beta,
+                           double *gs_x, const double *gs_b, const double *gs_diag, hipStream_t st) {
+  if (A->compact)
+    hipLaunchKernelGGL((k_spmv_pell<U, VM, true, EPI>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
+  else
+    hipLaunchKernelGGL((k_spmv_pell<U, VM, false, EPI>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
+}
+template <int EPI>
+static void pell_launch_epi(const pa_csr *A, int mode, const pa_pell_dev &D, int nblk, int bpx, const double *x, double *y, double alpha,
+                            double beta, double *gs_x, const double *gs_b, const double *gs_diag, hipStream_t st) {
+#define PA_PELL_U(UU)                                                                                        \
+  if (mode == 2) pell_launch_uv<UU, 1, EPI>(A, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st);   \
+  else pell_launch_uv<UU, 0, EPI>(A, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st)
+  switch (A->pell->U) {
+    case 9: PA_PELL_U(9); break;
+    case 7: PA_PELL_U(7); break;
+    case 5: PA_PELL_U(5); break;
+    default: PA_PELL_U(4); break;
+  }
+#undef PA_PELL_U
+}
+
+// the product (or one of its epilogue forms) of slab A on the pattern-ELL kernel; mode from pa_pell_mode (1 or 2).  epi as
+// k_spmv_rowsplit's EPI; EPI 3 writes one partial per SLAB (pa_pell_partials of them) into gs_x.
+int pa_pell_launch(const pa_csr *A, int mode, int epi, const double *x, double *y, double alpha, double beta, double *gs_x,
+                   const double *gs_b, const double *gs_diag, hipStream_t st) {
+  pa_pell *P = A->pell;
+  if (!st) st = A->ctx->s[0];
+  const pa_pell_dev D = pell_dev(A, mode);
+  const int n_groups = (int)((P->n_slabs + 3) / 4);
+  int bpx = (n_groups + 7) / 8;
+  const int nblk = bpx * 8;
+  if (A->ctx->sw.spmv_alternate && epi == 0 && ((P->n_launched++) & 1)) bpx = -bpx;
+  if (mode == 2 && A->ctx->capturing) { const_cast<pa_csr *>(A)->vd_captured = true; const_cast<pa_csr *>(A)->vd_captured_two = true; }
+  switch (epi) {
+    case 0: pell_launch_epi<0>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
+    case 1: pell_launch_epi<1>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
+    case 2: pell_launch_epi<2>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
+    default: pell_launch_epi<3>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
+  }
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+int64_t pa_pell_partials(const pa_csr *A) { return A->pell ? A->pell->n_slabs : 0; }
+
+// bytes the pattern-ELL product of this slab reads from the matrix side (pa_csr_stream_bytes counts the row-split kernel's)
+int64_t pa_pell_stream_bytes(const pa_csr *A, int mode) {
+  const pa_pell *P = A->pell;
+  int64_t t = 8 * P->n_slabs + 4 * P->n_patterns * PA_PELL_TW + 4 * A->n_crows;
+  t += mode == 2 ? 4 * A->n_crows + 16 : 8 * 64 * P->slots;
+  if (A->compact) t += 4 * A->n_crows;
+  return t;
+}
+
+// *mode: what pa_spmv runs this block on now (0 row split, 1 pattern-ELL fp64, 2 pattern-ELL one bit per entry); slabs / patterns /
+// value slots / unroll of the pattern-ELL storage (0 when the block has none)
+extern "C" int pa_csr_pell_info(const pa_csr *A, int *mode, int64_t *n_slabs, int64_t *n_patterns, int64_t *value_slots, int *unroll) {
+  PA_REQUIRE(A != nullptr, "csr is NULL");
+  const pa_pell *P = A->pell;
+  if (mode) *mode = pa_pell_mode(A);
+  if (n_slabs) *n_slabs = P ? P->n_slabs : 0;
+  if (n_patterns) *n_patterns = P ? P->n_patterns : 0;
+  if (value_slots) *value_slots = P ? P->slots * 64 : 0;
+  if (unroll) *unroll = P ? P->U : 0;
+  return PA_OK;
+}

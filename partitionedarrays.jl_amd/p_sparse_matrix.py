@@ -137,6 +137,14 @@ class DeviceCSR:
         L.call("pa_csr_encoding", self.h, *[C.byref(x) for x in v])
         return dict(zip(["pattern", "c16", "c32"], [x.value for x in v]))
 
+    def pell(self):
+        """Pattern-ELL storage of the block (pa_csr_pell_info, csrc/pa_pell.hip): mode = what a product runs on now (0 row split,
+        1 pattern-ELL fp64 stream, 2 pattern-ELL one bit per entry), slabs of 64 rows, distinct slab patterns, value slots, unroll."""
+        mode, unroll = C.c_int(), C.c_int()
+        v = [C.c_int64() for _ in range(3)]
+        L.call("pa_csr_pell_info", self.h, C.byref(mode), *[C.byref(x) for x in v], C.byref(unroll))
+        return dict(mode=mode.value, slabs=v[0].value, patterns=v[1].value, value_slots=v[2].value, unroll=unroll.value)
+
     def xwin(self):
         """x-window launch of banded rows without a pattern (pa_csr_xwin_info): groups, chunks in groups, staged x entries."""
         v = [C.c_int64() for _ in range(4)]
