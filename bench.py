@@ -1252,6 +1252,7 @@ def main():
     if N > 1 and want_fused:
         with optional_section("fused product", 180, N, rank):
             os.environ.pop("PA_MUL_FUSED", None)
+            os.environ["PA_MUL_FUSED_RCCL"] = "1"        # (over RCCL the one launch is opt-in since round 6: here it is opted into, behind its gate)
             ctx.reload_env()
             ms_sep = ms_per_step
             ok_fused, t_fused, fl0, fl1 = False, None, ctx.fused_launches(), None
@@ -1271,6 +1272,7 @@ def main():
                 use_fused = bool(ok_fused and ms_fused is not None and ms_fused < ms_sep)
                 if not use_fused:                        # the rest of the run stays on the path `value` was measured on
                     os.environ["PA_MUL_FUSED"] = "0"
+                    os.environ.pop("PA_MUL_FUSED_RCCL", None)
                     ctx.reload_env()
             if use_fused:
                 ms_per_step = ms_fused

@@ -84,7 +84,7 @@ static void read_switches(pa_ctx *c) {
   c->sw.graph_one_stream = flag("PA_GRAPH_ONE_STREAM", 1);
   c->sw.ghost_from_buffer = flag("PA_MUL_GHOST_FROM_BUFFER", 1);
   c->sw.mul_fused = flag("PA_MUL_FUSED", 1);
-  c->sw.mul_fused_rccl = flag("PA_MUL_FUSED_RCCL", 1);
+  c->sw.mul_fused_rccl = flag("PA_MUL_FUSED_RCCL", 0);
   c->sw.fused_tail_blocks = std::max(1, flag("PA_FUSED_TAIL_BLOCKS", 1024));
   c->sw.spmv_alternate = flag("PA_SPMV_ALTERNATE", 1);
   c->sw.chain_fused = flag("PA_SPMV_CHAIN_FUSED", 1);

@@ -27,6 +27,7 @@
 
 #include "pa_setup.h"
 #include "pa_spmv_kernel.h"
+#include "pa_pell.h"
 #include "pa_push_dev.h"
 
 using namespace pa_util;
@@ -347,6 +348,82 @@ __global__ __launch_bounds__(256) void k_mul_fused(
                                                                   chunk, fx);
 }
 
+// The same launch with own x own's INTERIOR rows on the pattern-ELL kernel (pa_pell.h; round 6): the first blocks are groups of four
+// slabs (one lane per row, rows of the boundary bitmap left alone), the last blocks the boundary rows' block as before.  With the
+// one-bit value stream the row-split main blocks had become the slower half of the fused launch.
+void pa_pell_describe(const pa_csr *A, int mode, pa_pell_dev *D, int *U, bool *runs3, int64_t *n_slabs);
+template <int U, int VM, bool R3, bool XCH>
+__global__ __launch_bounds__(256) void k_mul_fused_pell(const pa_pell_dev P, const double *__restrict__ x, double *__restrict__ y, int bpx,
+                                                        double alpha, double beta, const pa_fused_args F) {
+  constexpr int BLK = 256, NPT = PA_SPMV_CHUNK_NNZ / 256;
+  __shared__ __attribute__((aligned(16))) double prod[BLK * NPT];
+  __shared__ double wsum[1];
+  __shared__ int ok;
+  const int b = blockIdx.x;
+  if (b >= F.n_main_blocks) {
+    const int tb = b - F.n_main_blocks;
+    if (XCH) {
+      const int n_wait = F.X->n_wait;
+      if (n_wait > 0) {
+        const unsigned long long *flags = F.X->flags;
+        const int32_t *wait_idx = F.X->wait_idx;
+        const long long ticks = F.X->ticks;
+        if (threadIdx.x == 0) ok = 1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_wait; i += BLK)
+          if (!flag_wait(flags + wait_idx[i], F.seq, ticks)) { atomicExch(F.X->status, 1); ok = 0; }
+        __syncthreads();
+        if (!ok) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        __syncthreads();
+      }
+    }
+    pa_fx fx;
+    fx.x2 = F.rbuf; fx.n_split = F.n_split;
+    for (int t = tb; t < F.n_tail_chunks; t += F.n_tail_blocks) {
+      pa_rowsplit_chunk<BLK, NPT, true, false, 0, 0, false, 4, false, 2>(
+          prod, wsum, F.b_crp, F.b_col, nullptr, nullptr, nullptr, nullptr, F.b_val, x, y, F.b_chunk_rp, F.b_row_ids, alpha, beta, nullptr,
+          nullptr, nullptr, nullptr, nullptr, F.b_max_col, t, fx);
+      __syncthreads();
+    }
+    if (XCH) {
+      const int u_n = F.X->u_n;
+      const int32_t *u_idx = F.X->u_idx;
+      for (int k = tb * BLK + (int)threadIdx.x; k < u_n; k += F.n_tail_blocks * BLK) F.bvec[u_idx[k]] = F.rbuf[k];
+      const int n_ack = F.X->n_ack;
+      if (n_ack > 0) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          unsigned *t_done = F.X->t_done;
+          const unsigned done = atomicAdd(t_done, 1u);
+          if (done == (unsigned)F.n_tail_blocks - 1) {
+            *t_done = 0;
+            __threadfence_system();
+            unsigned long long *const *ack_dst = F.X->ack_dst;
+            for (int i = 0; i < n_ack; ++i) flag_store(ack_dst[i], F.seq);
+          }
+        }
+      }
+    }
+    return;
+  }
+  if (XCH && b < F.n_push_blocks) {
+    const pa_fused_comm X = *F.X;
+    (void)pa_push_ipc_block(&ok, X.p_idx, X.p_n, X.p_segs, X.p_nseg, x, F.seq, X.p_done, X.ticks, X.status, b, F.n_push_blocks);
+  }
+  const bool backwards = bpx < 0;
+  if (backwards) bpx = -bpx;
+  int g = (b & 7) * bpx + (b >> 3);
+  const int n_groups = (P.n_slabs + 3) >> 2;
+  if (g >= n_groups) return;
+  if (backwards) g = n_groups - 1 - g;
+  const int slab = __builtin_amdgcn_readfirstlane(g * 4 + (int)(threadIdx.x >> 6));
+  if (slab >= P.n_slabs) return;
+  pa_fx fx;
+  fx.rowmask = F.rowmask;
+  pa_pell_slab<U, VM, false, 0, 1, R3>(P, slab, x, y, alpha, beta, nullptr, nullptr, nullptr, fx);
+}
+
 // own(c) = beta*own(c) + alpha*(A_oo*own(b) + A_oh*ghost(b)) of one part in one launch on stream st.  comm == NULL: the receive
 // buffer of consistent!(b) holds b's ghost values by stream order (the push launch is in front, pa_mul_all); else the exchange
 // happens inside the launch as *comm says.
@@ -367,6 +444,36 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double
   F.n_tail_blocks = max_tail_blocks > 0 ? std::min(F.n_tail_chunks, max_tail_blocks) : F.n_tail_chunks;
   PA_REQUIRE(n_push_blocks <= F.n_main_blocks, "more pushing blocks than own x own has chunks");
   const int n_tail = F.n_tail_blocks;
+  if (const int pm = pa_pell_mode(S)) {                      // own x own has pattern-ELL storage: its interior rows run there
+    pa_pell_dev D;
+    int U = 0;
+    bool r3 = false;
+    int64_t n_slabs = 0;
+    pa_pell_describe(S, pm, &D, &U, &r3, &n_slabs);
+    if (U == 9 || U == 7) {
+      const int n_groups = (int)((n_slabs + 3) / 4);
+      int bpx = (n_groups + 7) / 8;
+      F.n_main_blocks = bpx * 8;
+      PA_REQUIRE(n_push_blocks <= F.n_main_blocks, "more pushing blocks than own x own has slab groups");
+      if (m->ctx->sw.spmv_alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) bpx = -bpx;
+      if (pm == 2 && m->ctx->capturing) { const_cast<pa_csr *>(S)->vd_captured = true; const_cast<pa_csr *>(S)->vd_captured_two = true; }
+#define PA_LAUNCH_FP(UU, VM, R3, XCH)                                                                                                \
+  hipLaunchKernelGGL((k_mul_fused_pell<UU, VM, R3, XCH>), dim3(F.n_main_blocks + n_tail), dim3(256), 0, st, D, (const double *)b->d, c->d, bpx, \
+                     alpha, beta, F)
+#define PA_FP_CASES(XCH)                                                                              \
+      if (U == 7) { if (pm == 2) PA_LAUNCH_FP(7, 1, false, XCH); else PA_LAUNCH_FP(7, 0, false, XCH); } \
+      else if (r3) { if (pm == 2) PA_LAUNCH_FP(9, 1, true, XCH); else PA_LAUNCH_FP(9, 0, true, XCH); }   \
+      else { if (pm == 2) PA_LAUNCH_FP(9, 1, false, XCH); else PA_LAUNCH_FP(9, 0, false, XCH); }
+      if (comm) { PA_FP_CASES(true) } else { PA_FP_CASES(false) }
+#undef PA_FP_CASES
+#undef PA_LAUNCH_FP
+      PA_HIP(hipGetLastError());
+      if (m->ctx->capturing) m->bd_captured = true;
+      m->ctx->n_fused++;
+      if (comm) m->ctx->n_fused_exchange++;
+      return PA_OK;
+    }
+  }
   if (m->ctx->sw.spmv_alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) cpx = -cpx;
 #define PA_LAUNCH_FUSED(C16, PAT, VD)                                                                                           \
   hipLaunchKernelGGL((k_mul_fused<C16, PAT, VD, XCH>), dim3(F.n_main_blocks + n_tail), dim3(256), 0, st, S->d_crp, S->d_col, S->d_col16, \

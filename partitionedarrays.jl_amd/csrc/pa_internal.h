@@ -47,7 +47,10 @@ struct pa_switches {
   int graph_one_stream = 1;   // PA_GRAPH_ONE_STREAM: inside a capture pa_mul_all queues ONE chain on the compute stream
   int ghost_from_buffer = 1;  // PA_MUL_GHOST_FROM_BUFFER: own x ghost reads consistent!'s receive buffer (the renamed twin)
   int mul_fused = 1;          // PA_MUL_FUSED: mul!(c,a,b) of a part as one launch (pa_fused.hip)
-  int mul_fused_rccl = 1;     // PA_MUL_FUSED_RCCL: also over RCCL (the launch's tail acquires a flag the comm stream raises behind the receives)
+  int mul_fused_rccl = 0;     // PA_MUL_FUSED_RCCL: also over RCCL (the launch's tail acquires a flag the comm stream raises behind the receives).
+                              //   OFF by default since round 6: on one GPU over a 1-rank communicator one product in ~10 waited out its whole
+                              //   time-out for a flag whose raising depends on the comm stream's progress THROUGH the host-side runtime (RCCL's
+                              //   launch bookkeeping), and the one launch was slower than the separate launches anyway (notebook R6.2)
   int fused_tail_blocks = 1024;  // PA_FUSED_TAIL_BLOCKS: tail blocks of a fused launch that may SPIN on arrival flags (ranks sharing one GPU: keep it small)
   int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
   int vd_select = 1;          // PA_SPMV_VDICT_SELECT: a dictionary of at most two values is decoded by a select, not through the lane dictionary

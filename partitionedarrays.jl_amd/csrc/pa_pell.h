@@ -43,16 +43,40 @@ struct pa_pell_dev {
   const double *val = nullptr;           // VM 0: slab-major, delta-major, lane-minor
   const double *dict = nullptr;          // VM 1: the two values
   const int *row_ids = nullptr;          // row-compacted block: stored row -> row
-  int n_slabs = 0, n_crows = 0;
+  int n_slabs = 0, n_crows = 0, n_cols = 0;
 };
+
+// value slot of delta k of a slab whose first slot is `first` (in 64-entry units), lane `lane`: inside every group of U deltas the
+// lanes hold PAIRS of consecutive deltas next to each other (one 16-byte load per lane and pair, 1 KiB per wavefront) and, U odd,
+// the group's last delta on its own (512 bytes per wavefront) -- a group is U * 512 contiguous bytes either way
+template <int U>
+__host__ __device__ __forceinline__ size_t pa_pell_slot(unsigned first, int k, int lane) {
+  const int g = k / U, j = k - g * U;
+  const size_t B = ((size_t)first + (size_t)g * U) * 64;
+  constexpr int UE = U & ~1;
+  return j < UE ? B + (size_t)(j >> 1) * 128 + (size_t)lane * 2 + (j & 1) : B + (size_t)UE * 64 + lane;
+}
+
+// lane l <- v of lane l + 1; lane 63 <- e (DPP wave_shl:1, the whole wavefront as one row of 64)
+__device__ __forceinline__ double pa_wave_shl1(double v, double e) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(e), __double2loint(v), 0x130, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(e), __double2hiint(v), 0x130, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
 
 // one slab.  EPI / FX as in pa_rowsplit_chunk (pa_spmv_kernel.h): EPI 0 product, 1 Gauss-Seidel colour update in place, 2 residual +
 // restriction, 3 product + this slab's term of a dot product (partial[slab]); FX 1: rows whose bit is set in fx.rowmask are left
 // alone (the fused launch's tail sums them).
-template <int U, int VM, bool COMPACT, int EPI, int FX>
+// R3 (U = 9, rows of the slab consecutive: not a row-compacted block): every pattern of the block is made of RUNS OF THREE consecutive
+// deltas (d, d+1, d+2 -- the three neighbours along a grid line).  Lane l then needs x[row_l + d + j], j = 0..2, and x[row_l + d + j] IS
+// what lane l + j loads for j = 0: ONE gather per run, the other two columns by a wave shift (DPP, a VALU move), the two elements
+// past the wavefront's end from two scalar loads -- 9 gathers per row of the 27-point operator instead of 27.  (What-if of round 5,
+// notebook R5.8: it is the NUMBER of gather instructions through the texture addresser that costs, not the lines they touch.)
+template <int U, int VM, bool COMPACT, int EPI, int FX, bool R3>
 __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, const double *__restrict__ x_in, double *__restrict__ y,
                                              double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
                                              const double *__restrict__ gs_diag, const pa_fx fx) {
+  static_assert(!R3 || (U == 9 && !COMPACT && EPI != 1), "runs of three: unroll 9, consecutive rows, x not written by the launch");
   const double *x = EPI == 1 ? gs_x : x_in;          // EPI 1 reads and writes the same vector: no restrict promise on it
   const int lane = threadIdx.x & 63;
   const int2 d = P.desc[slab];                       // (slab is wave-uniform: scalar loads)
@@ -70,19 +94,45 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
   unsigned long long vb = 0;
   double d0 = 0.0, d1 = 0.0;
   if (VM == 1) { vb = P.bits[rc]; d0 = P.dict[0]; d1 = P.dict[1]; }
-  const double *vp = P.val + (size_t)(unsigned)d.y * 64 + lane;
+  const double *vp = P.val + (size_t)(unsigned)d.y * 64;
   double acc = 0.0, accp = 0.0;
   if ((EPI == 0 || EPI == 3) && beta != 0.0 && mine) acc = beta * y[row];
+  constexpr int UE = U & ~1;
   for (int k0 = 0; k0 < Wp; k0 += U) {
     double v[U], xv[U];
     bool on[U];
+    if (VM == 0) {
+      const double *g = vp + (size_t)k0 * 64;
 #pragma unroll
-    for (int j = 0; j < U; ++j) {
-      if (VM == 0) v[j] = __builtin_nontemporal_load(vp + (size_t)(k0 + j) * 64);
-      else v[j] = ((vb >> (k0 + j)) & 1ull) ? d1 : d0;
-      on[j] = (m >> (k0 + j)) & 1ull;
-      const int c = on[j] ? row + dl[k0 + j] : 0;
-      xv[j] = x[c];
+      for (int j = 0; j < UE; j += 2) {
+        const d2 pr = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(g + (size_t)(j >> 1) * 128) + lane);
+        v[j] = pr.x; v[j + 1] = pr.y;
+      }
+      if (U & 1) v[U - 1] = __builtin_nontemporal_load(g + (size_t)UE * 64 + lane);
+    } else {
+#pragma unroll
+      for (int j = 0; j < U; ++j) v[j] = ((vb >> (k0 + j)) & 1ull) ? d1 : d0;
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) on[j] = (m >> (k0 + j)) & 1ull;
+    if (R3) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int dk = dl[k0 + 3 * t];               // the run's first delta (scalar)
+        const int hi = P.n_cols - 1;
+        const double xb = x[min(max(r + dk, 0), hi)];
+        const int e = slab * 64 + 64 + dk;           // the two columns past the wavefront's last lane (scalar loads)
+        const double e1 = x[min(max(e, 0), hi)], e2 = x[min(max(e + 1, 0), hi)];
+        xv[3 * t] = xb;
+        xv[3 * t + 1] = pa_wave_shl1(xb, e1);
+        xv[3 * t + 2] = pa_wave_shl1(xv[3 * t + 1], e2);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int c = on[j] ? row + dl[k0 + j] : 0;
+        xv[j] = x[c];
+      }
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -114,7 +164,7 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
 // blockIdx -> slabs: four slabs per workgroup (one per wavefront), consecutive workgroups of an XCD take consecutive slabs (block b
 // sits on XCD b % 8; each XCD has its own L2, and the rows of neighbouring grid lines and planes share their x).  bpx < 0: the same
 // map walked backwards (every other product of a big block: what the last product left in the caches is read first, PA_SPMV_ALTERNATE).
-template <int U, int VM, bool COMPACT, int EPI>
+template <int U, int VM, bool COMPACT, int EPI, bool R3 = false>
 __global__ __launch_bounds__(256) void k_spmv_pell(const pa_pell_dev P, const double *__restrict__ x, double *__restrict__ y, int bpx,
                                                    double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
                                                    const double *__restrict__ gs_diag) {
@@ -127,7 +177,7 @@ __global__ __launch_bounds__(256) void k_spmv_pell(const pa_pell_dev P, const do
   if (backwards) g = n_groups - 1 - g;
   const int slab = __builtin_amdgcn_readfirstlane(g * 4 + (int)(threadIdx.x >> 6));
   if (slab >= P.n_slabs) return;
-  pa_pell_slab<U, VM, COMPACT, EPI, 0>(P, slab, x, y, alpha, beta, gs_x, gs_b, gs_diag, pa_fx());
+  pa_pell_slab<U, VM, COMPACT, EPI, 0, R3>(P, slab, x, y, alpha, beta, gs_x, gs_b, gs_diag, pa_fx());
 }
 
 #endif

@@ -26,6 +26,7 @@ struct pa_pell {
   int U = 9;
   int64_t n_slabs = 0, n_patterns = 0, slots = 0;      // slots: 64-entry units of the value stream
   int max_w = 0;
+  bool runs3 = false;                                  // every pattern is made of runs of three consecutive deltas (and U = 9)
   int2 *d_desc = nullptr;
   int *d_pdelta = nullptr;
   unsigned *d_mask = nullptr, *d_bits = nullptr;
@@ -88,7 +89,7 @@ __global__ void kp_verify(const int *__restrict__ len, const int *__restrict__ D
 }
 
 // VM 0: the values, delta-major per slab; VM 1: one bit per entry (its dictionary code), a word per row
-template <int VM>
+template <int VM, int U>
 __global__ __launch_bounds__(256) void kp_fill(const int *__restrict__ crp, const double *__restrict__ val, const unsigned char *__restrict__ code,
                                                const unsigned *__restrict__ mask, const int2 *__restrict__ desc, int n_crows, int n_slabs,
                                                double *__restrict__ out_val, unsigned *__restrict__ out_bits) {
@@ -98,12 +99,12 @@ __global__ __launch_bounds__(256) void kp_fill(const int *__restrict__ crp, cons
   if (r >= n_crows) return;
   unsigned m = mask[r];
   int p = crp[r];
-  const size_t base = (size_t)(unsigned)desc[slab].y * 64 + lane;
+  const unsigned first = (unsigned)desc[slab].y;
   unsigned bits = 0;
   while (m) {
     const int k = __builtin_ctz(m);
     m &= m - 1;
-    if (VM == 0) out_val[base + (size_t)k * 64] = val[p];
+    if (VM == 0) out_val[pa_pell_slot<U>(first, k, lane)] = val[p];
     else bits |= (unsigned)(code[p] & 1) << k;
     ++p;
   }
@@ -132,12 +133,18 @@ static int pell_fill(pa_csr *A, bool bits) {
   pa_pell *P = A->pell;
   hipStream_t s = A->ctx->s[0];
   const dim3 grid((unsigned)((P->n_slabs + 3) / 4));
+#define PA_FILL0(UU) hipLaunchKernelGGL((kp_fill<0, UU>), grid, dim3(256), 0, s, A->d_crp, A->d_val, (const unsigned char *)nullptr, P->d_mask, \
+                                        P->d_desc, (int)A->n_crows, (int)P->n_slabs, P->d_val, (unsigned *)nullptr)
   if (bits)
-    hipLaunchKernelGGL(kp_fill<1>, grid, dim3(256), 0, s, A->d_crp, (const double *)nullptr, A->d_code, P->d_mask, P->d_desc, (int)A->n_crows,
+    hipLaunchKernelGGL((kp_fill<1, 4>), grid, dim3(256), 0, s, A->d_crp, (const double *)nullptr, A->d_code, P->d_mask, P->d_desc, (int)A->n_crows,
                        (int)P->n_slabs, (double *)nullptr, P->d_bits);
-  else
-    hipLaunchKernelGGL(kp_fill<0>, grid, dim3(256), 0, s, A->d_crp, A->d_val, (const unsigned char *)nullptr, P->d_mask, P->d_desc,
-                       (int)A->n_crows, (int)P->n_slabs, P->d_val, (unsigned *)nullptr);
+  else switch (P->U) {
+    case 9: PA_FILL0(9); break;
+    case 7: PA_FILL0(7); break;
+    case 5: PA_FILL0(5); break;
+    default: PA_FILL0(4); break;
+  }
+#undef PA_FILL0
   PA_HIP(hipGetLastError());
   if (bits) P->bits_epoch = A->val_epoch;
   return PA_OK;
@@ -218,6 +225,18 @@ int pa_pell_build(pa_csr *A) {
         hipMemcpyAsync(&table[i * PA_PELL_TW], d_D + (size_t)rep[i] * PA_PELL_MAXW, sizeof(int) * (size_t)len[(size_t)rep[i]], hipMemcpyDeviceToHost, s) != hipSuccess)
       return give_up("read-back failed");
   if (hipStreamSynchronize(s) != hipSuccess) return give_up("read-back failed");
+  // runs of three consecutive deltas in every pattern (the 27-point operator: nine per row): the kernel's R3 form, one gather per run
+  {
+    const char *e3 = getenv("PA_SPMV_PELL_RUNS3");
+    bool r3 = U == 9 && !A->compact && !(e3 && atoi(e3) == 0);
+    for (size_t i = 0; i < rep.size() && r3; ++i) {
+      const int L = len[(size_t)rep[i]];
+      if (L % 3) { r3 = false; break; }
+      for (int k = 0; k < L; k += 3)
+        if (table[i * PA_PELL_TW + k + 1] != table[i * PA_PELL_TW + k] + 1 || table[i * PA_PELL_TW + k + 2] != table[i * PA_PELL_TW + k] + 2) { r3 = false; break; }
+    }
+    P->runs3 = r3;
+  }
   if (pa_dev_alloc(c, (void **)&P->d_desc, sizeof(int2) * (size_t)n_slabs, PA_MEM_MATRIX) ||
       pa_dev_alloc(c, (void **)&P->d_pdelta, sizeof(int) * table.size(), PA_MEM_MATRIX))
     return give_up("no room");
@@ -279,7 +298,7 @@ static pa_pell_dev pell_dev(const pa_csr *A, int mode) {
   const pa_pell *P = A->pell;
   pa_pell_dev D;
   D.desc = P->d_desc; D.pdelta = P->d_pdelta; D.mask = P->d_mask; D.bits = P->d_bits; D.val = P->d_val; D.dict = A->d_dict;
-  D.row_ids = A->d_row_ids; D.n_slabs = (int)P->n_slabs; D.n_crows = (int)A->n_crows;
+  D.row_ids = A->d_row_ids; D.n_slabs = (int)P->n_slabs; D.n_crows = (int)A->n_crows; D.n_cols = (int)A->n_cols;
   (void)mode;
   return D;
 }
@@ -287,6 +306,12 @@ static pa_pell_dev pell_dev(const pa_csr *A, int mode) {
 template <int U, int VM, int EPI>
 static void pell_launch_uv(const pa_csr *A, const pa_pell_dev &D, int nblk, int bpx, const double *x, double *y, double alpha, double beta,
                            double *gs_x, const double *gs_b, const double *gs_diag, hipStream_t st) {
+  if constexpr (U == 9 && EPI != 1) {
+    if (A->pell->runs3 && !A->compact) {
+      hipLaunchKernelGGL((k_spmv_pell<9, VM, false, EPI, true>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
+      return;
+    }
+  }
   if (A->compact)
     hipLaunchKernelGGL((k_spmv_pell<U, VM, true, EPI>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
   else
@@ -327,6 +352,12 @@ int pa_pell_launch(const pa_csr *A, int mode, int epi, const double *x, double *
   }
   PA_HIP(hipGetLastError());
   return PA_OK;
+}
+
+// what a launch that runs the slabs itself needs (the fused product, pa_fused.hip): mode from pa_pell_mode (1 or 2)
+void pa_pell_describe(const pa_csr *A, int mode, pa_pell_dev *D, int *U, bool *runs3, int64_t *n_slabs) {
+  *D = pell_dev(A, mode);
+  *U = A->pell->U; *runs3 = A->pell->runs3 && !A->compact; *n_slabs = A->pell->n_slabs;
 }
 
 int64_t pa_pell_partials(const pa_csr *A) { return A->pell ? A->pell->n_slabs : 0; }

@@ -827,7 +827,9 @@ int pa_mul_fused_ipc(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double be
 
 bool pa_fused_ipc_fits(const pa_matrix *m) {
   const pa_plan *p = m->plan;
-  return (int64_t)((p->rcv.n + 255) / 256) <= (int64_t)((m->oo->n_chunks + 7) / 8) * 8;
+  const int64_t groups = ((m->oo->n_crows + 63) / 64 + 3) / 4;          // (the main blocks of the pattern-ELL form: four slabs each)
+  const int64_t main_blocks = std::min<int64_t>((m->oo->n_chunks + 7) / 8 * 8, (groups + 7) / 8 * 8);
+  return (int64_t)((p->rcv.n + 255) / 256) <= main_blocks;
 }
 
 // compute stream, behind the unpack (and whatever read the receive buffer): the senders may overwrite it now

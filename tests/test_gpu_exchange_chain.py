@@ -3,11 +3,12 @@ process (csrc/pa_push.hip), own x ghost reading consistent!'s receive buffer, th
 oracle and against the round-3 order (PA_PUSH=0 / PA_MUL_GHOST_FROM_BUFFER=0), bit for bit (np.array_equal).
 Reference: assemble_impl! src/p_vector.jl:587-612, mul! src/p_sparse_matrix.jl:2090-2142."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
-from gpu_helpers import pa, ranks, upload, oracle_mul, env
+from gpu_helpers import pa, ranks, upload, oracle_mul, env, reload_switches
 import pa_amd._lib as L
 import pa_amd.p_sparse_matrix as psm
 
@@ -233,6 +234,8 @@ def test_pa_mul5_over_a_one_rank_rccl_communicator():
     the alpha/beta form and pa_mul_no_lat: against numpy, exactly.  (Between distinct GPUs the same calls run in
     tests/test_gpu_multiprocess.py where the box has them.)"""
     ctx = pa.context()
+    os.environ["PA_MUL_FUSED_RCCL"] = "1"            # (opt-in since round 6; the handle decides at its first product)
+    reload_switches()
     idbuf = C.create_string_buffer(L.UNIQUE_ID_BYTES)
     L.call("pa_comm_unique_id", idbuf)
     comm = C.c_void_p()
@@ -278,6 +281,8 @@ def test_pa_mul5_over_a_one_rank_rccl_communicator():
     L.call("pa_matrix_destroy", m)
     L.call("pa_plan_destroy", plan)
     L.call("pa_comm_destroy", comm)
+    os.environ.pop("PA_MUL_FUSED_RCCL", None)
+    reload_switches()
 
 
 def test_one_device_context_per_part():

@@ -42,6 +42,6 @@ for link in ("rccl", "ipc"):
                 except L.PAError:
                     pass
             wall = time.perf_counter() - t0
-            ms = [round(evs[k].elapsed_ms(evs[k + 1]), 3) for k in range(K)]
+            ms = [round(evs[k].elapsed_ms(evs[k + 1]), 3) for k in range(len(evs) - 1)]
             ok = bool(np.array_equal(P.c.download(), want))
             print(f"{link} fused={fused} sync_between={sync_between}: wall {wall:.3f} s, ok={ok}, err={err}\n   per product ms: {ms}", flush=True)
