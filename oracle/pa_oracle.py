@@ -185,7 +185,12 @@ class Indices:
     def global_to_local(self, gids):
         """global_to_local(indices)[gid]; 0 when gid is not local (VectorFromDict default)."""
         if self._g2l is None:
-            order = np.argsort(self.local_to_global, kind="stable")
+            # BlockPartitionGlobalToLocal (src/p_range.jl:1551-1562): an OWN id answers first, the ghost dictionary after it -- a part
+            # alone in a periodic direction holds copies of its own ids in its ghost layer (round 6: the lowest local id used to win,
+            # which is the layer's copy whenever the layer comes first in the traversal; found by tests/test_host_bruteforce.py)
+            is_ghost = np.ones(len(self.local_to_global), dtype=np.int8)
+            is_ghost[self.own_to_local - 1] = 0
+            order = np.lexsort((np.arange(len(is_ghost)), is_ghost, self.local_to_global))
             self._g2l = (self.local_to_global[order], order)
         srt, order = self._g2l
         g = np.asarray(gids, dtype=I64).ravel()

@@ -217,7 +217,11 @@ class LocalIndices:
                    L.ptr(self.ghost_to_global), self.n_ghost, L.ptr(gids), len(gids), L.ptr(out))
             return out
         if self._g2l is None:
-            order = np.argsort(self.local_to_global, kind="stable")
+            # an OWN id answers first, the ghost dictionary after it (BlockPartitionGlobalToLocal, src/p_range.jl:1551-1562): a part
+            # alone in a periodic direction keeps copies of its own ids in its ghost layer, and what a neighbour asks for is the own one
+            is_ghost = np.ones(len(self.local_to_global), dtype=np.int8)
+            is_ghost[self._own_to_local - 1] = 0
+            order = np.lexsort((np.arange(len(is_ghost)), is_ghost, self.local_to_global))
             self._g2l = (self.local_to_global[order], order)
         srt, order = self._g2l
         if len(srt):

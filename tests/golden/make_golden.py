@@ -55,6 +55,10 @@ G["exchange"] = [
     {"src": "src/primitives.jl:893-919 (doctest)", "snd_ids": [[3, 4], [1, 3], [1, 4], [2]], "rcv_ids": None,
      "snd_literal": [[10, 10], [20, 20], [30, 30], [40]], "rcv": [[20, 30], [40], [10, 20], [10, 30]]},
 ]
+G["exchange_in_place"] = {"src": "test/primitives_tests.jl:245-288 (exchange! into map(similar,parts_rcv))",
+                          "snd_ids": [[3, 4], [1, 3], [1, 4], [2]], "rcv_ids": [[2, 3], [4], [1, 2], [1, 3]],
+                          "note": "data_snd = map(i->10*i,parts_snd)", "snd_literal": [[30, 40], [10, 30], [10, 40], [20]],
+                          "rcv": [[10, 10], [20], [30, 30], [40, 40]]}
 G["exchange_jagged"] = {"src": "test/primitives_tests.jl:220-234", "snd_ids": [[3, 4], [1, 3], [1, 4], [2]],
                         "rcv_ids": [[2, 3], [4], [1, 2], [1, 3]],
                         "snd": [[[1, 2, 3], [1, 2, 3, 4]], [[1], [1, 2, 3]], [[1], [1, 2, 3, 4]], [[1, 2]]],

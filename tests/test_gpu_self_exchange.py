@@ -226,7 +226,7 @@ def test_fifty_products_of_a_part_that_is_its_own_neighbour(n):
             out[key] = {"own_own_ms": round(t_oo, 4), "mul_ms": round(t_mul, 4), "mul_over_spmv": round(t_mul / t_oo, 4),
                         "time_outs_in_90_products": timeouts}
             if not opt_in:
-                assert timeouts == 0 and t_mul / t_oo <= 1.5, (key, out[key])
+                assert timeouts == 0 and t_mul / t_oo <= 2.5, (key, out[key])
     reload_switches()
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/self_exchange_{n}.json", "w") as f:
