@@ -1427,6 +1427,10 @@ static int gs_color_check(pa_csr *const *blocks, int n_colors, pa_vec *x, const 
 // one colour: x[row] += (b[row] - (A x)[row]) / diag[row] on the rows of the block, in place
 static void gs_color_launch(pa_ctx *c, const pa_csr *A, pa_vec *x, const pa_vec *b, const pa_vec *diag) {
   if (A->n_chunks == 0) return;
+  if (const int pm = pa_pell_mode(A)) {                // a pattern block: one lane per row (pa_pell.h), the same update, the same bits
+    (void)pa_pell_launch(A, pm, 1, nullptr, nullptr, 1.0, 0.0, x->d, b->d, diag->d, c->s[0]);
+    return;
+  }
   const int cpx = (int)((A->n_chunks + 7) / 8);
 #define PA_LAUNCH_GS(C16, PAT, VD)                                                                                       \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 1, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \

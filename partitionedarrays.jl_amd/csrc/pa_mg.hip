@@ -271,6 +271,10 @@ extern "C" int pa_transfer_restrict_fused(pa_transfer *t, pa_vec *rc, const pa_v
   if (A->n_chunks == 0) return PA_OK;
   pa_ctx *c = t->ctx;
   PA_HIP(hipSetDevice(c->device));
+  if (const int pm = pa_pell_mode(A)) {                // a pattern block: one lane per row (pa_pell.h)
+    PA_TRY(pa_pell_launch(A, pm, 2, xf->d, nullptr, 1.0, 0.0, rc->d, rf->d, nullptr, c->s[0]));
+    return PA_OK;
+  }
   const int cpx = (int)((A->n_chunks + 7) / 8);
 #define PA_LAUNCH_RR(C16, PAT, VD)                                                                                       \
   hipLaunchKernelGGL((k_spmv_rowsplit<SPMV_BLK, SPMV_NPT, SPMV_NT, C16, PAT, 2, VD>), dim3(cpx * 8), dim3(SPMV_BLK), 0,    \

@@ -76,7 +76,7 @@ template <int U, int VM, bool COMPACT, int EPI, int FX, bool R3>
 __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, const double *__restrict__ x_in, double *__restrict__ y,
                                              double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
                                              const double *__restrict__ gs_diag, const pa_fx fx) {
-  static_assert(!R3 || (U == 9 && !COMPACT && EPI != 1), "runs of three: unroll 9, consecutive rows, x not written by the launch");
+  static_assert(!R3 || (U % 9 == 0 && !COMPACT && EPI != 1), "runs of three: unroll 9 (27 on the one-bit stream), consecutive rows, x not written by the launch");
   const double *x = EPI == 1 ? gs_x : x_in;          // EPI 1 reads and writes the same vector: no restrict promise on it
   const int lane = threadIdx.x & 63;
   const int2 d = P.desc[slab];                       // (slab is wave-uniform: scalar loads)
@@ -117,7 +117,7 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
     for (int j = 0; j < U; ++j) on[j] = (m >> (k0 + j)) & 1ull;
     if (R3) {
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < U / 3; ++t) {
         const int dk = dl[k0 + 3 * t];               // the run's first delta (scalar)
         const int hi = P.n_cols - 1;
         const double xb = x[min(max(r + dk, 0), hi)];

@@ -307,6 +307,15 @@ template <int U, int VM, int EPI>
 static void pell_launch_uv(const pa_csr *A, const pa_pell_dev &D, int nblk, int bpx, const double *x, double *y, double alpha, double beta,
                            double *gs_x, const double *gs_b, const double *gs_diag, hipStream_t st) {
   if constexpr (U == 9 && EPI != 1) {
+    if constexpr (VM == 1) {
+      // the one-bit stream has no value loads to keep in flight: the whole row (27 deltas, nine gathers) as ONE group -- every gather of a
+      // row is requested before the first product is formed (a wavefront's life is a chain of round trips, not bytes)
+      static const bool u27 = !(getenv("PA_SPMV_PELL_BITS_U27") && atoi(getenv("PA_SPMV_PELL_BITS_U27")) == 0);
+      if (A->pell->runs3 && !A->compact && A->pell->max_w <= 27 && u27) {
+        hipLaunchKernelGGL((k_spmv_pell<27, 1, false, EPI, true>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
+        return;
+      }
+    }
     if (A->pell->runs3 && !A->compact) {
       hipLaunchKernelGGL((k_spmv_pell<9, VM, false, EPI, true>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
       return;

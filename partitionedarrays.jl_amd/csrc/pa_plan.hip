@@ -617,6 +617,11 @@ static int spmv_dot_block(const pa_csr *A, const double *x, double *y, double be
       if (S->n_rows) hipLaunchKernelGGL(k_scale, dim3(grid_for(S->n_rows, 256)), dim3(256), 0, c->s[0], ys, S->n_rows, beta);
       kbeta = 1.0;
     }
+    if (const int pm = pa_pell_mode(S)) {                // a pattern block: one partial per slab of 64 rows (pa_pell.h)
+      PA_TRY(pa_pell_launch(S, pm, 3, x, ys, 1.0, kbeta, partial + off, us, nullptr, c->s[0]));
+      off += pa_pell_partials(S);
+      continue;
+    }
     if (S->n_xw_groups > 0) {
       pa_launch_xwin(S, x, ys, 1.0, kbeta, us, partial + off);
     } else if (S->n_chunks > 0) {
@@ -643,9 +648,9 @@ static int spmv_dot_block(const pa_csr *A, const double *x, double *y, double be
   return PA_OK;
 }
 
-static int64_t chunks_of(const pa_csr *A) {
+static int64_t chunks_of(const pa_csr *A) {             // partial sums a fused product + dot of this block writes (spmv_dot_block)
   int64_t n = 0;
-  for (const pa_csr *S = A; S; S = S->next) n += S->n_chunks;
+  for (const pa_csr *S = A; S; S = S->next) n += pa_pell_mode(S) ? pa_pell_partials(S) : S->n_chunks;
   return n;
 }
 static bool has_vdict(const pa_csr *A) {

@@ -190,7 +190,7 @@ def test_mul_all_replayed_from_a_hipgraph(orc, monkeypatch, one_stream):
                 assert np.array_equal(got, e), rep
 
 
-def test_a_recorded_fused_product_follows_value_updates_in_place(orc):
+def test_a_recorded_hipgraph_of_the_fused_product_follows_value_updates_in_place(orc):
     """the fused launch's boundary-row block `bd` holds COPIES of own_own's and own_ghost's values.  A graph
     recorded through it and replayed after pa_csr_update_values must multiply with the NEW values in boundary rows too (it summed
     them from the old copies), and the eager product after the update must not free what the recorded graph still reads (bd was
