@@ -27,7 +27,32 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-PHASE = ["start"]
+
+
+class _Phase(list):
+    """PHASE[0] = name: where the run is (watchdog, error messages) -- and, since round 6, how long every phase took (the line's
+    `phase_seconds`: the driver's budget for this command is wall clock)"""
+
+    def __init__(self):
+        super().__init__(["start"])
+        self.t0 = time.perf_counter()
+        self.log = []
+
+    def __setitem__(self, i, name):
+        now = time.perf_counter()
+        self.log.append((self[0], round(now - self.t0, 1)))
+        self.t0 = now
+        super().__setitem__(i, name)
+
+    def seconds(self):
+        out = {}
+        for name, dt in self.log + [(self[0], round(time.perf_counter() - self.t0, 1))]:
+            if dt >= 0.5:
+                out[name] = round(out.get(name, 0.0) + dt, 1)
+        return out
+
+
+PHASE = _Phase()
 
 
 def watchdog(seconds):
@@ -320,7 +345,7 @@ def live_traffic(n, timeout_s=120):
             vals = []
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "k_spmv_rowsplit" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                    if any(k in row.get("Kernel_Name", "") for k in ("k_spmv_pell", "k_spmv_rowsplit")) and row.get("Counter_Name") == counter:
                         vals.append(float(row["Counter_Value"]))
             if not vals:
                 return None, f"no {counter} rows (rocprofv3 rc {r.returncode})"
@@ -331,7 +356,7 @@ def live_traffic(n, timeout_s=120):
         shutil.rmtree(work, ignore_errors=True)
     fetch, write = 2 * got["FETCH_SIZE"][0] * 1024, got["WRITE_SIZE"][0] * 1024
     return round(fetch + write), (f"this box, this command: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE over two child runs of bench.py "
-                                  f"(headline only; {got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} k_spmv_rowsplit launches averaged; KiB units, "
+                                  f"(headline only; {got['FETCH_SIZE'][1]} / {got['WRITE_SIZE'][1]} launches of the product kernel averaged; KiB units, "
                                   f"FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950: fetch {fetch / 1e9:.3f} GB + write {write / 1e9:.3f} GB)")
 
 
@@ -464,6 +489,18 @@ def whole_mul_times(pa, ctx, L, A, x, y, reps=30, graph=True):
     return ms, ms_graph, e0.elapsed_ms(e1) / reps
 
 
+def kernel_of(blk):
+    """which product kernel pa_spmv runs this block on now (pa_csr_pell_info)"""
+    try:
+        p = blk.pell()
+    except Exception:                                          # noqa: BLE001
+        return "k_spmv_rowsplit"
+    if p["mode"] == 0:
+        return "k_spmv_rowsplit (row split, LDS-staged products)"
+    return (f"k_spmv_pell (pattern-ELL, one lane per row; {p['slabs']} slabs of 64 rows, {p['patterns']} slab patterns, unroll {p['unroll']}; "
+            + ("fp64 value stream" if p["mode"] == 1 else "one bit per entry: a two-value dictionary") + ")")
+
+
 def extra_configs(pa, ctx, L, out):
     """BASELINE configs 2, 3 (one part's size) and 5 (one part's rows) on this GPU, one entry each: ms per product,
     GFLOP/s, algorithmic GB/s (12 B per entry + 20 B per row), moved GB/s (bytes the block's encoding makes the
@@ -477,7 +514,9 @@ def extra_configs(pa, ctx, L, out):
         moved = blk.stream_bytes() + n_cols * 8 + n_rows * 8
         return {"workload": workload, "rows": int(n_rows), "nnz": int(nnz), "ms": round(ms, 4),
                 "gflops": round(2.0 * nnz / ms / 1e6, 1), "algorithmic_gbps": round(alg / ms / 1e6, 1),
-                "moved_gbps": round(moved / ms / 1e6, 1), "encoding": blk.encoding(), "setup_s": round(t_setup, 1)}
+                "moved_bytes_per_launch": int(moved), "moved_gbps": round(moved / ms / 1e6, 1),
+                "frac_moved": round(moved / ms / 1e6 / HBM_PEAK_GBPS, 4), "frac_spec_8d": round(alg / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                "encoding": blk.encoding(), "kernel": kernel_of(blk), "setup_s": round(t_setup, 1)}
     # config 2: 7-point Laplacian 256^3, one part, SpMV only (gallery laplacian_fdm -> psparse, Int32 CSR)
     PHASE[0] = "extra: config 2"
     t = time.perf_counter()
@@ -805,7 +844,8 @@ def general_csr_entries(pa, ctx, L, host_oo, xv, y_head, n_own, out):
         out.append({"workload": "the headline's own x own block, " + name, "nnz": int(blk.nnz), "ms": round(ms, 4),
                     "gflops": round(2.0 * blk.nnz / ms / 1e6, 1), "moved_bytes_per_launch": int(moved),
                     "moved_gbps": round(moved / ms / 1e6, 1), "frac_moved": round(moved / ms / 1e6 / HBM_PEAK_GBPS, 4),
-                    "algorithmic_gbps": round(alg / ms / 1e6, 1), "bit_identical_to_headline_product": same,
+                    "algorithmic_gbps": round(alg / ms / 1e6, 1), "frac_spec_8d": round(alg / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                    "kernel": kernel_of(blk), "bit_identical_to_headline_product": same,
                     "encoding": blk.encoding(), "setup_s": round(ts, 1)})
         del blk, y2
     return out
@@ -1134,7 +1174,8 @@ def main():
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_summary.json")))
         for cand in reversed(cands if n == 256 else []):          # the newest round's summary that holds the counters
-            pm = json.load(open(cand)).get("pmc_per_launch", {}).get("k_spmv_rowsplit")
+            pml = json.load(open(cand)).get("pmc_per_launch", {})
+            pm = pml.get("k_spmv_pell") or pml.get("k_spmv_rowsplit")
             if pm and "fetch_bytes_gfx950_corrected" in pm and "write_bytes" in pm:
                 traffic = round(pm["fetch_bytes_gfx950_corrected"] + pm["write_bytes"])
                 traffic_src = (os.path.relpath(cand, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of a separate 1-GPU 256^3 "
@@ -1189,8 +1230,8 @@ def main():
             "gflops_per_gpu": round(value / N, 2),
             "hbm_gbps_per_gpu_algorithmic": round(bytes_mul / (ms_per_step * 1e-3) / 1e9, 1),
             "ms_per_step_median_events": round(float(np.median(whole)), 4),
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_rowsplit<256,6,nt> (own x own): CSR row split, LDS-staged products; "
-                                                      "column encoding of the chunks: " + json.dumps(blk.own_own.encoding()),
+            "roofline": {"bound": "hbm", "kernel": "own x own on " + kernel_of(blk.own_own) + "; column encoding of the row-split chunks: "
+                                                      + json.dumps(blk.own_own.encoding()),
                          # `achieved` / `frac`: the bytes this kernel must MOVE per launch (values + row pointers + chunk table +
                          # descriptors / kept column streams, pa_csr_stream_bytes, + x once + y once) over its average launch time:
                          # a physical fraction, <= 1.  Reproduce: moved_bytes_per_launch / avg_launch_ms / 1e6 / peak.
@@ -1208,6 +1249,13 @@ def main():
                          # never read (all 2*nnz flops are done, all fp64 values are read, y is bit-identical).
                          "algorithmic_bytes_per_launch": bytes_oo, "achieved_algorithmic_csr": round(ach, 1),
                          "frac_algorithmic_csr": round(ach / HBM_PEAK_GBPS, 4),
+                         #  the three accountings side by side: SURVEY 8(d)'s algorithmic bytes (can exceed 1: the 4-byte column
+                         # of every entry is regenerated from the slab's pattern, never read), the bytes the kernel must move (`frac`), and the
+                         # bytes the HBM counters saw
+                         "frac_spec_8d": round(ach / HBM_PEAK_GBPS, 4),
+                         "frac_spec_8d_note": "SURVEY 8(d) bytes (12 B per stored entry + 20 B per row) over the launch time; above 1 is not skipped "
+                                              "work -- columns are recomputed from row patterns, so 4 of those 12 bytes per entry are never read",
+                         "frac_counter": (round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic else None),
                          "frac_vs_this_box_read": (round(ach_moved / box["read_gbps"], 4) if box else None),
                          "frac_back_to_back_wall_clock": (round(moved_oo / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if N == 1 else None),
                          "what": "`achieved`/`frac`: bytes the kernel must move (no column stream where a row pattern describes the "
@@ -1364,7 +1412,11 @@ def main():
             e1 = ctx.event().record(L.STREAM_COMPUTE)
             ctx.sync()
             ms2 = e0.elapsed_ms(e1) / args.steps
-            vdict = {"what": "own x own SpMV with the library's DEFAULT value dictionary (lossless, built on the device for big blocks with <= 64 "
+            moved2 = blk2.own_own.stream_bytes() + 16 * n_own
+            vdict = {"kernel": kernel_of(blk2.own_own), "moved_bytes_per_launch": int(moved2),
+                     "moved_gbps": round(moved2 / (ms2 * 1e-3) / 1e9, 1), "frac_moved": round(moved2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "frac_spec_8d": round(bytes_oo / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                     "what": "own x own SpMV with the library's DEFAULT value dictionary (lossless, built on the device for big blocks with <= 64 "
                              "distinct values; bench.py switches it off -- PA_SPMV_VALUE_DICT=0 -- for `value` and every other entry)",
                      "distinct_values": blk2.own_own.value_dict(), "bit_identical_to_headline_product": bool(same),
                      "avg_launch_ms": round(ms2, 4), "gflops": round(2.0 * nnz_oo / (ms2 * 1e-3) / 1e9, 1),
@@ -1482,7 +1534,10 @@ def main():
             transpose = {"workload": f"mul!(c,transpose(A),b,1,0) on the headline matrix (27-pt {n}^3, 1 part), A' built on the device "
                                      "(pa_csr_create_transpose: decode + one stable radix sort by column + device-side block constructor)",
                          "ms": round(ms_t, 4), "gflops": round(2.0 * nnz / ms_t / 1e6, 1), "rate_vs_forward": round(ms_per_step / ms_t, 3),
-                         "build_s": round(t_build, 2), "encoding": tb.encoding(), "max_abs_diff_vs_forward_product": sym_err}
+                         "build_s": round(t_build, 2), "encoding": tb.encoding(), "kernel": kernel_of(tb),
+                         "moved_bytes_per_launch": int(tb.stream_bytes() + 16 * n_own),
+                         "frac_moved": round((tb.stream_bytes() + 16 * n_own) / ms_t / 1e6 / HBM_PEAK_GBPS, 4),
+                         "max_abs_diff_vs_forward_product": sym_err}
             del ct, bt
             A._t_blocks = None
         except Exception as e:                                 # noqa: BLE001
@@ -1557,6 +1612,7 @@ def main():
             out["transpose_product"] = transpose
         if extras:
             out["extra_configs"] = extras
+        out["phase_seconds"] = PHASE.seconds()
         print(json.dumps(out), flush=True)
     if N > 1:
         dist.barrier()

@@ -418,6 +418,36 @@ function to_hip(v::PVector)
     end
     PVector(vals, partition(axes(v, 1)))
 end
+"""
+    to_hip(v::PVector{<:PartitionedArrays.SplitVector})
+
+Device twin of a host PVector in SPLIT format (`pzeros(...;split_format=true)`, `pvector(...;split_format=true)`:
+src/p_vector.jl:132-187, the `SplitVector` method of assemble_impl! :620-656).  A SplitVector already keeps its own and ghost values
+in two contiguous blocks -- the device layout -- so they are uploaded as they are, block by block, without the pass through the local
+order that `to_hip(::PVector)` makes; its `permutation` (local id -> position in [own | ghost]) IS the `l2d` of the HIPVector.
+"""
+function to_hip(v::PVector{<:PartitionedArrays.SplitVector})
+    vals = map(partition(v), partition(axes(v, 1))) do x, ids
+        own, ghost = x.blocks.own, x.blocks.ghost
+        no, ng = length(own), length(ghost)
+        perm = convert(Vector{Int32}, x.permutation)
+        d = HIPVector(no, ng, perm == 1:(no + ng) ? nothing : perm)
+        no > 0 && check(ccall((:pa_vec_upload, libpa), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), d.handle, convert(Vector{Float64}, own), 0, no))
+        ng > 0 && check(ccall((:pa_vec_upload, libpa), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), d.handle, convert(Vector{Float64}, ghost), no, ng))
+        d
+    end
+    PVector(vals, partition(axes(v, 1)))
+end
+"Host SplitVector twin of a device PVector: the two blocks downloaded as they lie in HBM."
+function to_split(v::PVector{HIPVector})
+    vals = map(partition(v)) do d
+        dev = Vector{Float64}(undef, length(d))
+        check(ccall((:pa_vec_download, libpa), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64), d.handle, dev, 0, length(dev)))
+        perm = d.l2d === nothing ? collect(Int32, 1:length(d)) : d.l2d
+        PartitionedArrays.split_vector(dev[1:d.n_own], dev[d.n_own+1:end], perm)
+    end
+    PVector(vals, partition(axes(v, 1)))
+end
 "Device twin of an assembled, split-format PSparseMatrix (src/p_sparse_matrix.jl:588-627,670-681)."
 function to_hip(A::PSparseMatrix)
     @assert A.assembled
@@ -509,16 +539,18 @@ end
 route of test/fem_example.jl): per part the sub-assembled matrix on the device (ghost rows and columns in first-seen order), its
 ghost rows sent to their owners with the reference's own `exchange`, the own rows and what arrived through the assembled route.
 """
-function psparse_disassembled_hip(I, J, V, rows, cols)
+function psparse_disassembled_hip(I, J, V, rows, cols; reuse::Bool=false)
     subs = map(I, J, V, rows, cols) do i, j, v, r, c
         D, nr, lor, hir = _box(r)
         _, nc, loc, hic = _box(c)
         h = Ref{Ptr{Cvoid}}(C_NULL)
+        reuse && check(ccall((:pa_coo_keep_input_slots, libpa), Cint, (Ptr{Cvoid}, Cint), context().handle, 1))
         check(ccall((:pa_coo_subassemble, libpa), Cint,
                     (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int32, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64},
                      Ptr{Int64}, Ptr{Int64}, Ref{Ptr{Cvoid}}),
                     context().handle, length(i), convert(Vector{Int64}, i), convert(Vector{Int64}, j), convert(Vector{Float64}, v),
                     D, nr, lor, hir, nc, loc, hic, h))
+        reuse && check(ccall((:pa_coo_keep_input_slots, libpa), Cint, (Ptr{Cvoid}, Cint), context().handle, 0))
         h[]
     end
     surf = map(subs) do h                       # ghost rows: gids (first-seen order) and entries sorted by (row, column)
@@ -539,7 +571,7 @@ function psparse_disassembled_hip(I, J, V, rows, cols)
         owner = ghost_to_owner(r)[gr .+ 1]
         halves = vcat(findall(k -> k < own_length(c), gc), findall(k -> k >= own_length(c), gc))    # ghost_own's entries, then ghost_ghost's
         sel = [[e for e in halves if owner[e] == p] for p in ps]
-        (JaggedArray([gI[x] for x in sel]), JaggedArray([gJ[x] for x in sel]), JaggedArray([gv[x] for x in sel]))
+        (JaggedArray([gI[x] for x in sel]), JaggedArray([gJ[x] for x in sel]), JaggedArray([gv[x] for x in sel]), sel, halves)
     end
     graph = ExchangeGraph(parts_snd, parts_rcv)
     Ircv = exchange(map(x -> x[1], snd), graph) |> fetch
@@ -547,14 +579,84 @@ function psparse_disassembled_hip(I, J, V, rows, cols)
     Vrcv = exchange(map(x -> x[3], snd), graph) |> fetch
     fin = map(subs, Ircv, Jrcv, Vrcv) do h, i, j, v
         f = Ref{Ptr{Cvoid}}(C_NULL)
+        reuse && check(ccall((:pa_coo_keep_input_slots, libpa), Cint, (Ptr{Cvoid}, Cint), context().handle, 1))
         check(ccall((:pa_coo_assemble_finish, libpa), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
                     h, length(i.data), convert(Vector{Int64}, i.data), convert(Vector{Int64}, j.data), convert(Vector{Float64}, v.data), f))
-        check(ccall((:pa_coo_assembly_destroy, libpa), Cint, (Ptr{Cvoid},), h))
+        reuse && check(ccall((:pa_coo_keep_input_slots, libpa), Cint, (Ptr{Cvoid}, Cint), context().handle, 0))
         f[]
     end
     ghosts = map(_assembly_ghosts, fin)
     cols_fa = map(union_ghost, cols, ghosts, find_owner(cols, ghosts))
-    PSparseMatrix(map(_assembly_blocks, fin, rows, cols_fa), rows, cols_fa, true)
+    cache = nothing
+    if reuse
+        # The cache of psparse(...;reuse=true) (src/p_sparse_matrix.jl:1183-1219,1598-1689; psparse! :1291-1305), built ON THE DEVICE.
+        # One part's stored values are the vector W = [nonzeros(own_own) | nonzeros(own_ghost) || the ghost rows' entries]; then
+        #   sparse_matrix!(A,V,K) + split_format_locally! + setup_snd  = ONE deterministic scatter-add W[dest[p]] += V[p]  (pa_scatter),
+        #   psparse_assemble_impl! (:1762-1816)                        = assemble! of W over a plan: idx_snd = the ghost-row slots in the
+        #                                                                order they are sent (k_snd), idx_rcv = where the received triplets
+        #                                                                landed (k_rcv, returned by pa_coo_reuse_scatter),
+        #   nonzeros(blocks) .= W[own part]                            = pa_csr_update_values_from.
+        parts = map(subs, fin, snd, Ircv, I, rows, parts_snd, parts_rcv) do h, f, sn, ir, i, r, ps, pr
+            info = [Ref{Int64}(0) for _ in 1:5]
+            check(ccall((:pa_coo_assembly_info, libpa), Cint,
+                        (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ref{Int64}, Ptr{Float64}), f, info[1], info[2], info[3], info[4], info[5], C_NULL))
+            nnz_oo, nnz_oh = info[4][], info[5][]
+            sel, halves = sn[4], sn[5]
+            gslot = Vector{Int32}(undef, length(halves))              # 0-based position of ghost-row entry e in [ghost_own | ghost_ghost]
+            for (k, e) in enumerate(halves); gslot[e] = k - 1; end
+            sc = Ref{Ptr{Cvoid}}(C_NULL)
+            k_rcv = zeros(Int32, max(length(ir.data), 1))
+            check(ccall((:pa_coo_reuse_scatter, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}, Ref{Ptr{Cvoid}}, Int64, Ptr{Int32}),
+                        h, f, isempty(gslot) ? C_NULL : gslot, sc, length(ir.data), k_rcv))
+            n_own_vals, n_ghost_vals = nnz_oo + nnz_oh, length(gslot)
+            idx_snd = Int32[n_own_vals + gslot[e] + 1 for x in sel for e in x]
+            ptrs_snd = Int32[1; 1 .+ cumsum(Int32[length(x) for x in sel])]
+            plan = Ref{Ptr{Cvoid}}(C_NULL)
+            check(ccall((:pa_plan_create, libpa), Cint,
+                        (Ptr{Cvoid}, Int32, Int64, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32},
+                         Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Cint, Ref{Ptr{Cvoid}}),
+                        context().handle, part_id(r), n_own_vals + n_ghost_vals,
+                        length(ps), convert(Vector{Int32}, ps), ptrs_snd, idx_snd,
+                        length(pr), convert(Vector{Int32}, pr), convert(Vector{Int32}, ir.ptrs), k_rcv[1:length(ir.data)], 1, plan))
+            (plan[], sc[], HIPVector(n_own_vals, n_ghost_vals), HIPVector(length(i), 0), nnz_oo)
+        end
+        plans = map(x -> x[1], parts)
+        plans isa MPIArray && PA_TRANSPORT == "ipc" && connect_ipc!(plans)
+        cache = HIPReassemblyCache(plans, map(x -> x[2], parts), map(x -> x[3], parts), map(x -> x[4], parts), map(x -> x[5], parts))
+    end
+    foreach(h -> check(ccall((:pa_coo_assembly_destroy, libpa), Cint, (Ptr{Cvoid},), h)), subs)
+    C = PSparseMatrix(map(_assembly_blocks, fin, rows, cols_fa), rows, cols_fa, true)
+    reuse ? (C, cache) : C
+end
+
+"cache of `psparse_disassembled_hip(...; reuse=true)`: per part the plan that assembles W, the scatter V -> W, W and V in HBM, nnz(own_own)"
+struct HIPReassemblyCache{A,B,C,D,E}
+    plans::A
+    scatters::B
+    W::C
+    Vdev::D
+    nnz_oo::E
+end
+"""
+    psparse_hip!(C, V, cache) -> C
+
+`psparse!(C,V,cache) |> wait` (src/p_sparse_matrix.jl:1291-1305): the same sparsity pattern, new COO values.  After the upload of `V`
+nothing leaves HBM: the scatter-add into W (sparse_matrix! + split_format_locally!, src/sparse_utils.jl:454-466,
+src/p_sparse_matrix.jl:901-935), assemble! of W over the cache's plan (psparse_assemble_impl!, :1762-1816: ghost-row values travel to
+their owners and are added in ascending position), and the blocks' values taken from W in place (pa_csr_update_values_from -- what
+derived storage a block keeps, value dictionary, pattern-ELL stream, the fused product's boundary block, follows at the update).
+"""
+function psparse_hip!(C::PSparseMatrix, V, cache::HIPReassemblyCache)
+    foreach((vd, v) -> upload!(vd, v), cache.Vdev, V)
+    foreach(cache.scatters, cache.W, cache.Vdev) do sc, w, vd
+        check(ccall((:pa_scatter_add, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint), sc, w.handle, vd.handle, 1))
+    end
+    PartitionedArrays.assemble_impl!(+, cache.W, HIPAssemblyCache(cache.plans, false)) |> wait
+    foreach(partition(C), cache.W, cache.nnz_oo) do a, w, k
+        check(ccall((:pa_csr_update_values_from, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), a.blocks.own_own.handle, w.handle, 0))
+        check(ccall((:pa_csr_update_values_from, libpa), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64), a.blocks.own_ghost.handle, w.handle, k))
+    end
+    C
 end
 
 end # module

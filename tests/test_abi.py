@@ -138,6 +138,22 @@ def test_committed_bench_line_follows_the_contract():
     else:                                 # rounds 1-2 quoted `frac` on the reference's CSR bytes
         assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["avg_launch_ms"] / 1e6) < 1.0
     assert abs(d["value"] - 2 * d["config"]["nnz_per_part"] * d["n_gpus"] / d["ms_per_step"] / 1e6) < 0.5
+    if int(os.path.basename(path)[1:3]) >= 6:
+        # the three accountings side by side in `roofline`, and no entry anywhere in the line may quote a GB/s figure above
+        # the 8 TB/s peak (algorithmic bytes: columns regenerated from patterns, values from a dictionary) without the moved-bytes
+        # fraction beside it
+        assert r["frac_spec_8d"] == r["frac_algorithmic_csr"] and 0 < r["frac_counter"] <= 1.05 and abs(r["frac_counter"] - r["frac"]) < 0.08
+
+        def walk(o, where):
+            if isinstance(o, dict):
+                over = [k for k, v in o.items() if k.endswith("gbps") and isinstance(v, (int, float)) and v > 8000.0]
+                assert not over or ("frac_moved" in o and 0 < o["frac_moved"] <= 1.0), (where, over)
+                for k, v in o.items():
+                    walk(v, where + "/" + k)
+            elif isinstance(o, list):
+                for i, v in enumerate(o):
+                    walk(v, f"{where}[{i}]")
+        walk(d, "")
 
 
 def test_header_is_valid_c99_and_the_c_example_links():
@@ -571,3 +587,87 @@ def test_julia_runtests_and_reference_bench_scripts_are_consistent_with_the_glue
     assert "HPCG.build_p_matrix" in bj and "mul!(c, A, x)" in bj and "consistent!(x)" in bj
     assert "hpcg_blocks_hip" in glue and "pa_hpcg_own_block_create" in glue
 
+
+
+@pytest.mark.gpu
+def test_glue_split_vector_conversion_and_psparse_reuse_replayed_through_ctypes(orc):
+    """VERDICT r05 "Next" #9, the two pieces the glue lacked, replayed with the type tuples WRITTEN IN THE GLUE:
+    (i) to_hip(::PVector{<:SplitVector}) (src/p_vector.jl:132-187): pa_vec_create, then the own block and the ghost block uploaded as
+        they are at offsets 0 and n_own; downloaded through Base.Array's ccall the vector reads [own | ghost];
+    (ii) psparse_hip!(C,V,cache) (psparse!, src/p_sparse_matrix.jl:1291-1305): upload of V, pa_scatter_add into W, assemble! of W
+        (pa_exchange_pack / pa_exchange_local / pa_exchange_finish over the cache's plans), pa_csr_update_values_from twice per part --
+        on a cache the Python route built with the same entry points (pa_coo_reuse_scatter, pa_plan_create), against the oracle's
+        re-assembly, bit for bit.  The call sequence of the glue's reuse=true branch itself is pinned by name below."""
+    import numpy as np
+    pa = load_package()
+    import pa_amd._lib as L
+    lib = ctypes.CDLL(pa.LIB_PATH)
+    P = ctypes.c_void_p
+    vp = lambda a: a.ctypes.data_as(P)       # noqa: E731
+    seq = {
+        "ctx": _glue_ccalls(r"function context\("),
+        "vec": _glue_ccalls(r"function HIPVector\(n_own::Integer, n_ghost::Integer, l2d"),
+        "split": _glue_ccalls(r"function to_hip\(v::PVector\{<:PartitionedArrays\.SplitVector\}\)"),
+        "download": _glue_ccalls(r"function Base\.Array\(v::HIPVector\)"),
+        "upload": _glue_ccalls(r"function upload!\(v::HIPVector"),
+        "psparse!": _glue_ccalls(r"function psparse_hip!\(C::PSparseMatrix"),
+        "assemble": _glue_ccalls(r"function PartitionedArrays\.assemble_impl!\(f, vector_partition, cache::HIPAssemblyCache\)"),
+        "local": _glue_ccalls(r"_transport!\(plans::DebugArray"),
+        "reuse": _glue_ccalls(r"function psparse_disassembled_hip\(I, J, V, rows, cols; reuse::Bool=false\)"),
+    }
+    assert [n for n, _ in seq["split"]] == ["pa_vec_upload", "pa_vec_upload"]
+    assert [n for n, _ in seq["psparse!"]] == ["pa_scatter_add", "pa_csr_update_values_from", "pa_csr_update_values_from"]
+    names = [n for n, _ in seq["reuse"]]
+    for must in ("pa_coo_keep_input_slots", "pa_coo_subassemble", "pa_coo_assemble_finish", "pa_coo_assembly_info", "pa_coo_reuse_scatter",
+                 "pa_plan_create", "pa_coo_assembly_destroy"):
+        assert must in names, must
+    assert names.index("pa_coo_subassemble") < names.index("pa_coo_assemble_finish") < names.index("pa_coo_reuse_scatter") < names.index("pa_plan_create")
+
+    def call(entry, *vals):
+        name, types = entry
+        assert len(types) == len(vals), (name, len(types), len(vals))
+        f = getattr(lib, name)
+        f.restype, f.argtypes = ctypes.c_int, types
+        assert f(*vals) == 0, (name, lib.pa_last_error())
+    ctx = P()
+    call(seq["ctx"][0], 0, ctypes.byref(ctx))
+    # (i) a SplitVector's two blocks
+    own, ghost = np.arange(1.0, 8.0), np.array([70.0, 80.0, 90.0])
+    d = P()
+    call(seq["vec"][0], ctx, len(own), len(ghost), ctypes.byref(d))
+    call(seq["split"][0], d, vp(own), 0, len(own))
+    call(seq["split"][1], d, vp(ghost), len(own), len(ghost))
+    back = np.zeros(len(own) + len(ghost))
+    call(seq["download"][0], d, vp(back), 0, len(back))
+    assert back.tolist() == own.tolist() + ghost.tolist()
+    # (ii) psparse! on a FEM matrix of four parts
+    nodes, parts = (23, 17), (2, 2)
+    ranks = pa.DebugArray([1, 2, 3, 4])
+    I, J, V, rows, cols = pa.laplacian_fem(nodes, parts, ranks)
+    A, cache = pa.psparse_disassembled(I, J, V, rows, cols, reuse=True)
+    V2 = [v * 1.5 + orc.hash_x(np.arange(len(v)) + 7 * k) * 1e-3 for k, v in enumerate(V.items)]
+    for vd, v in zip(cache.Vdev.items, V2):
+        call(seq["upload"][0], vd.h, vp(np.ascontiguousarray(v)), 0, len(v))
+    for sc, w, vd in zip(cache.scatters.items, cache.W.items, cache.Vdev.items):
+        call(seq["psparse!"][0], sc, w.h, vd.h, 1)
+    pack = [e for e in seq["assemble"] if e[0] == "pa_exchange_pack"][0]
+    fin = [e for e in seq["assemble"] if e[0] == "pa_exchange_finish"][0]
+    for w, p in zip(cache.W.items, cache.plans.items):
+        call(pack, p, w.h, L.ASSEMBLE)
+    arr = (P * 4)(*[p.value for p in cache.plans.items])
+    call(seq["local"][0], arr, 4, L.ASSEMBLE)
+    for w, p in zip(cache.W.items, cache.plans.items):
+        call(fin, p, w.h, L.ASSEMBLE)
+    for blk, w, k in zip(A.matrix_partition.items, cache.W.items, cache.nnz_oo.items):
+        call(seq["psparse!"][1], blk.own_own.h, w.h, 0)
+        call(seq["psparse!"][2], blk.own_ghost.h, w.h, int(k))
+    Io, Jo, Vo, orows, ocols = orc.laplacian_fem(nodes, parts)
+    Ao, _ = orc.psparse_disassembled(Io, Jo, [np.asarray(v).copy() for v in V2], orows, ocols)
+    xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+    x = pa.pvector_from_function(lambda ind: orc.hash_x(ind.get_local_to_global()) * (ind.get_local_to_owner() == ind.part), A.col_partition)
+    y = pa.pzeros(A.row_partition)
+    pa.mul_(y, A, x)
+    yo = [np.zeros(r.n_local) for r in Ao.rows]
+    orc.mul(yo, Ao, [v.copy() for v in xo])
+    for got, e, r in zip(y.own_values().items, yo, Ao.rows):
+        assert np.array_equal(got, e[:r.n_own])
