@@ -11,6 +11,17 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_extended: the long campaigns (fuzzers under every switch, duplicate full-size runs): skipped unless "
+                                       "PA_TEST_EXTENDED=1 (tools/verify_on_gpu.sh sets it) -- the driver's `pytest -m gpu` has a time budget")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("PA_TEST_EXTENDED") == "1":
+        return
+    skip = pytest.mark.skip(reason="extended campaign: PA_TEST_EXTENDED=1 runs it (tools/verify_on_gpu.sh)")
+    for item in items:
+        if "gpu_extended" in item.keywords:
+            item.add_marker(skip)
 
 
 def pytest_sessionstart(session):

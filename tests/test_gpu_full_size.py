@@ -124,6 +124,7 @@ def test_config5_full_size_fem_4096_squared_eight_parts(orc):
         assert np.array_equal(yv, want)
 
 
+@pytest.mark.gpu_extended
 def test_fem_example_full_size_4096_squared_cells(orc):
     """test/fem_example.jl itself at BASELINE config 5's size: 4096 x 4096 cells on (4,2) parts (16.8 M free dofs, the
     dof partition is 1-D by part while the geometry is 2-D blocks: every part has interface dofs owned by up to three

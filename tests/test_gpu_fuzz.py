@@ -29,6 +29,7 @@ def test_fuzzer_short_run(script, cases, seed0):
     assert " 0 mismatches" in out or " 0 with mismatches" in out, out[-500:]
 
 
+@pytest.mark.gpu_extended
 def test_fuzzers_under_guarded_poisoned_buffers():
     """The same with every device buffer in its own mapping, unmapped space behind it and 0xFF bytes in it (PA_DEBUG_GUARD=2): an
     overrun of more than 16 bytes faults, an uninitialised read shows as NaN."""
@@ -47,8 +48,9 @@ def test_corrupted_inputs_are_rejected_with_a_status():
     assert ", 0 accepted" in out, out[-800:]
 
 
+@pytest.mark.gpu_extended
 @pytest.mark.parametrize("switches", [{"PA_SPMV_VALUE_DICT": "1"}, {"PA_CTX_PER_PART": "1"}, {"PA_PUSH": "0"}, {"PA_MUL_GHOST_FROM_BUFFER": "0"},
-                                      {"PA_SPMV_COLSPLIT": "3"}])
+                                      {"PA_SPMV_COLSPLIT": "3"}, {"PA_SPMV_PELL": "0"}, {"PA_SPMV_PELL_RUNS3": "0", "PA_SPMV_VALUE_DICT": "1"}])
 def test_fuzzers_under_the_round_4_switches(switches):
     """The routes round 4 added or made the default, each forced or switched off: the value dictionary on EVERY block that
     qualifies (the fuzzers' blocks are below the automatic threshold), one device context per part, the round-3 exchange

@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
 mkdir -p gpurun_out
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 2400 python -m pytest tests -m gpu -q -x > gpurun_out/verify_pytest.log 2>&1
+PA_TEST_EXTENDED=1 timeout 2400 python -m pytest tests -m gpu -q -x > gpurun_out/verify_pytest.log 2>&1
 grep -E "passed|failed|error" gpurun_out/verify_pytest.log | tail -3
 timeout 900 python tests/fuzz/fuzz_fem.py 300 962000 2>&1 | tail -1
 timeout 900 python tests/fuzz/fuzz_mul.py 200 963000 2>&1 | tail -1
