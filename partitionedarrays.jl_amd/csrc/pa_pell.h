@@ -72,7 +72,7 @@ __device__ __forceinline__ double pa_wave_shl1(double v, double e) {
 // what lane l + j loads for j = 0: ONE gather per run, the other two columns by a wave shift (DPP, a VALU move), the two elements
 // past the wavefront's end from two scalar loads -- 9 gathers per row of the 27-point operator instead of 27.  (What-if of round 5,
 // notebook R5.8: it is the NUMBER of gather instructions through the texture addresser that costs, not the lines they touch.)
-template <int U, int VM, bool COMPACT, int EPI, int FX, bool R3>
+template <int U, int VM, bool COMPACT, int EPI, int FX, bool R3, bool A1 = false>
 __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, const double *__restrict__ x_in, double *__restrict__ y,
                                              double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
                                              const double *__restrict__ gs_diag, const pa_fx fx) {
@@ -137,8 +137,8 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
 #pragma unroll
     for (int j = 0; j < U; ++j) {
       double pr = v[j] * xv[j];
-      if (alpha != 1.0) pr = pr * alpha;
-      if (on[j]) {
+      if (!A1 && alpha != 1.0) pr = pr * alpha;   // (A1: the launch knows alpha = 1 -- a multiply and a select per product less; on the
+      if (on[j]) {                                //  one-bit stream the vector ALU is the busy unit, notebook R6.1)
         acc = acc + pr;
         if (EPI == 3) accp = accp + pr;
       }
@@ -164,7 +164,7 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
 // blockIdx -> slabs: four slabs per workgroup (one per wavefront), consecutive workgroups of an XCD take consecutive slabs (block b
 // sits on XCD b % 8; each XCD has its own L2, and the rows of neighbouring grid lines and planes share their x).  bpx < 0: the same
 // map walked backwards (every other product of a big block: what the last product left in the caches is read first, PA_SPMV_ALTERNATE).
-template <int U, int VM, bool COMPACT, int EPI, bool R3 = false>
+template <int U, int VM, bool COMPACT, int EPI, bool R3 = false, bool A1 = false>
 __global__ __launch_bounds__(256) void k_spmv_pell(const pa_pell_dev P, const double *__restrict__ x, double *__restrict__ y, int bpx,
                                                    double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
                                                    const double *__restrict__ gs_diag) {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_spmv_pell(const pa_pell_dev P, const do
   if (backwards) g = n_groups - 1 - g;
   const int slab = __builtin_amdgcn_readfirstlane(g * 4 + (int)(threadIdx.x >> 6));
   if (slab >= P.n_slabs) return;
-  pa_pell_slab<U, VM, COMPACT, EPI, 0, R3>(P, slab, x, y, alpha, beta, gs_x, gs_b, gs_diag, pa_fx());
+  pa_pell_slab<U, VM, COMPACT, EPI, 0, R3, A1>(P, slab, x, y, alpha, beta, gs_x, gs_b, gs_diag, pa_fx());
 }
 
 #endif

@@ -306,25 +306,26 @@ static pa_pell_dev pell_dev(const pa_csr *A, int mode) {
 template <int U, int VM, int EPI>
 static void pell_launch_uv(const pa_csr *A, const pa_pell_dev &D, int nblk, int bpx, const double *x, double *y, double alpha, double beta,
                            double *gs_x, const double *gs_b, const double *gs_diag, hipStream_t st) {
+  // alpha = 1 (every epilogue form, and the plain product of mul!(c,a,b)) is compiled in: no multiply-and-select per product
+#define PA_PELL_GO(UU, CC, RR)                                                                                                                     \
+  do {                                                                                                                                             \
+    if (alpha == 1.0)                                                                                                                              \
+      hipLaunchKernelGGL((k_spmv_pell<UU, VM, CC, EPI, RR, true>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);   \
+    else if constexpr (EPI == 0)                                                                                                                   \
+      hipLaunchKernelGGL((k_spmv_pell<UU, VM, CC, EPI, RR, false>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);  \
+  } while (0)
   if constexpr (U == 9 && EPI != 1) {
     if constexpr (VM == 1) {
-      // the one-bit stream has no value loads to keep in flight: the whole row (27 deltas, nine gathers) as ONE group -- every gather of a
-      // row is requested before the first product is formed (a wavefront's life is a chain of round trips, not bytes)
-      static const bool u27 = !(getenv("PA_SPMV_PELL_BITS_U27") && atoi(getenv("PA_SPMV_PELL_BITS_U27")) == 0);
-      if (A->pell->runs3 && !A->compact && A->pell->max_w <= 27 && u27) {
-        hipLaunchKernelGGL((k_spmv_pell<27, 1, false, EPI, true>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
-        return;
-      }
+      // (the whole row as ONE group of 27 -- every gather requested before the first product -- measured SLOWER than three groups of
+      //  nine, 0.2212 against 0.2127 ms at 256^3, 66 VGPRs: PA_SPMV_PELL_BITS_U27=1 keeps the experiment reachable)
+      static const bool u27 = getenv("PA_SPMV_PELL_BITS_U27") && atoi(getenv("PA_SPMV_PELL_BITS_U27")) != 0;
+      if (A->pell->runs3 && !A->compact && A->pell->max_w <= 27 && u27) { PA_PELL_GO(27, false, true); return; }
     }
-    if (A->pell->runs3 && !A->compact) {
-      hipLaunchKernelGGL((k_spmv_pell<9, VM, false, EPI, true>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
-      return;
-    }
+    if (A->pell->runs3 && !A->compact) { PA_PELL_GO(9, false, true); return; }
   }
-  if (A->compact)
-    hipLaunchKernelGGL((k_spmv_pell<U, VM, true, EPI>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
-  else
-    hipLaunchKernelGGL((k_spmv_pell<U, VM, false, EPI>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
+  if (A->compact) PA_PELL_GO(U, true, false);
+  else PA_PELL_GO(U, false, false);
+#undef PA_PELL_GO
 }
 template <int EPI>
 static void pell_launch_epi(const pa_csr *A, int mode, const pa_pell_dev &D, int nblk, int bpx, const double *x, double *y, double alpha,
@@ -346,6 +347,7 @@ static void pell_launch_epi(const pa_csr *A, int mode, const pa_pell_dev &D, int
 int pa_pell_launch(const pa_csr *A, int mode, int epi, const double *x, double *y, double alpha, double beta, double *gs_x,
                    const double *gs_b, const double *gs_diag, hipStream_t st) {
   pa_pell *P = A->pell;
+  PA_REQUIRE(epi == 0 || alpha == 1.0, "the epilogue forms of the pattern-ELL kernel take alpha = 1");
   if (!st) st = A->ctx->s[0];
   const pa_pell_dev D = pell_dev(A, mode);
   const int n_groups = (int)((P->n_slabs + 3) / 4);

@@ -7,6 +7,7 @@ import os
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+HEADLINE = ("k_spmv_pell", "k_spmv_rowsplit")     # the product kernel of the headline block (round 6: pattern-ELL; before: the row split)
 src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out")
 out = {}
 ks = os.path.join(src, "prof_kt", "kt_kernel_stats.csv")
@@ -26,7 +27,7 @@ kth = os.path.join(src, "prof_kth", "kth_kernel_trace.csv")
 blh = os.path.join(src, "bench_kth.log")
 if os.path.exists(kth) and os.path.exists(blh):
     line = [l for l in open(blh) if l.startswith('{"metric"')]
-    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(kth)) if "k_spmv_rowsplit" in r["Kernel_Name"])
+    d = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(kth)) if any(k in r["Kernel_Name"] for k in HEADLINE))
     if line and d:
         bench = json.loads(line[-1])
         lo, hi = bench["roofline"].get("timed_region_monotonic_ns", [0, 0])
@@ -56,8 +57,7 @@ if os.path.exists(kt) and os.path.exists(bl):
         bench = json.loads(line[-1])
         lo, hi = bench["roofline"].get("timed_region_monotonic_ns", [0, 0])
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(kt))
-             if "k_spmv_rowsplit" in r["Kernel_Name"] and (", 0, false" in r["Kernel_Name"] or ", 0, 0, 4," in r["Kernel_Name"])      # (EPI 0, fp64 stream: VD is an int since round 5)
-             and lo <= int(r["Start_Timestamp"]) <= hi]
+             if any(k in r["Kernel_Name"] for k in HEADLINE) and lo <= int(r["Start_Timestamp"]) <= hi]      # (only the headline product runs inside the bounds)
         # (own x ghost is the same kernel on an empty block at one part: no launch)
         out["default_command_timed_region"] = {
             "what": "launches of the headline kernel between the CLOCK_MONOTONIC bounds bench.py reports for its timed steps, "
@@ -72,24 +72,25 @@ for d, f in (("prof_fetch", "f"), ("prof_write", "w"), ("prof_tcc", "t")):
     if not os.path.exists(p):
         continue
     for r in csv.DictReader(open(p)):
-        if "k_spmv_rowsplit" in r["Kernel_Name"]:
-            pmc["k_spmv_rowsplit"][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k in HEADLINE:
+            if k in r["Kernel_Name"]:
+                pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                break
 summary = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in pmc.items()}
-s = summary.get("k_spmv_rowsplit", {})
-if "FETCH_SIZE" in s:
-    # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a
-    # wide coalesced streaming read -> doubled.  The correction is calibrated for 16 B/lane streams only; this kernel
-    # mixes 16 B (values), 8 B (columns) and gathered 8 B (x) loads, so the doubled figure is an upper estimate.
-    s["fetch_bytes_raw"] = s["FETCH_SIZE"] * 1024
-    s["fetch_bytes_gfx950_corrected"] = 2 * s["FETCH_SIZE"] * 1024
-if "WRITE_SIZE" in s:
-    s["write_bytes"] = s["WRITE_SIZE"] * 1024
-if "TCC_HIT_sum" in s:
-    s["l2_hit_rate"] = s["TCC_HIT_sum"] / (s["TCC_HIT_sum"] + s["TCC_MISS_sum"])
-if "TCC_EA0_RDREQ_sum" in s:
-    r32 = s.get("TCC_EA0_RDREQ_32B_sum", 0.0)
-    s["ea_read_bytes_if_rest_are_128B"] = r32 * 32 + (s["TCC_EA0_RDREQ_sum"] - r32) * 128
-    s["ea_read_bytes_if_rest_are_64B"] = r32 * 32 + (s["TCC_EA0_RDREQ_sum"] - r32) * 64
+for s in summary.values():
+    if "FETCH_SIZE" in s:
+        # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a
+        # wide coalesced streaming read -> doubled.
+        s["fetch_bytes_raw"] = s["FETCH_SIZE"] * 1024
+        s["fetch_bytes_gfx950_corrected"] = 2 * s["FETCH_SIZE"] * 1024
+    if "WRITE_SIZE" in s:
+        s["write_bytes"] = s["WRITE_SIZE"] * 1024
+    if "TCC_HIT_sum" in s:
+        s["l2_hit_rate"] = s["TCC_HIT_sum"] / (s["TCC_HIT_sum"] + s["TCC_MISS_sum"])
+    if "TCC_EA0_RDREQ_sum" in s:
+        r32 = s.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+        s["ea_read_bytes_if_rest_are_128B"] = r32 * 32 + (s["TCC_EA0_RDREQ_sum"] - r32) * 128
+        s["ea_read_bytes_if_rest_are_64B"] = r32 * 32 + (s["TCC_EA0_RDREQ_sum"] - r32) * 64
 out["pmc_per_launch"] = summary
 json.dump(out, open(os.path.join(os.path.dirname(__file__), f"{tag}_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
