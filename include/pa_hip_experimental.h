@@ -128,6 +128,28 @@ int pa_sell_spmv(const pa_sell *A, const pa_vec *x, int x_segment, pa_vec *y, in
  * entry; the other outputs describe the storage (0 when the block has none).  Any output may be NULL. */
 int pa_csr_pell_info(const pa_csr *A, int *mode, int64_t *n_slabs, int64_t *n_patterns, int64_t *value_slots, int *unroll);
 
+/* ---- Float32 blocks and vectors (csrc/pa_f32.hip; round 6: the first widening beyond the FP64 scope of the path) -----------
+ * The reference's local loops are generic in the element type (spmv_csr! / spmv_csc! src/sparse_utils.jl:649-690) and its own test
+ * runs them in Float32 (test/sparse_utils_tests.jl:72-79).  pa_vec32: local values of a PVector{Vector{Float32}}, [own | ghost];
+ * pa_csr32: a SparseMatrixCSR{Bi,Float32,Ti} / SparseMatrixCSC{Float32,Ti} block; pa_spmv32: spmv!(y,A,x) / mul!(y,A,x,alpha,beta)
+ * with every product and every sum rounded to Float32 in the reference's order (bit-identical to the oracle's float loops).  A block
+ * whose rows follow patterns reuses the fp64 path's pattern-ELL structure with a 4-byte value stream, any other is stored SELL-64.
+ * Arguments as pa_csr_create / pa_vec_* / pa_spmv.  Not yet: Float32 exchange payloads, epilogue forms, value updates. */
+typedef struct pa_vec32 pa_vec32;
+typedef struct pa_csr32 pa_csr32;
+int pa_vec32_create(pa_ctx *ctx, int64_t n_own, int64_t n_ghost, pa_vec32 **v);
+int pa_vec32_destroy(pa_vec32 *v);
+int pa_vec32_upload(pa_vec32 *v, const float *host, int64_t offset, int64_t len);
+int pa_vec32_download(const pa_vec32 *v, float *host, int64_t offset, int64_t len);
+int pa_vec32_fill(pa_vec32 *v, int segment, float value);
+int pa_csr32_create(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr, const void *colval, int index_bytes,
+                    int index_base, const float *nzval, pa_csr32 **A);
+int pa_csr32_create_from_csc(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr, const void *rowval,
+                             int index_bytes, int index_base, const float *nzval, pa_csr32 **A);
+int pa_csr32_destroy(pa_csr32 *A);
+int pa_csr32_info(const pa_csr32 *A, int *on_pattern_ell, int64_t *n_slabs, int64_t *padded_entries);
+int pa_spmv32(const pa_csr32 *A, const pa_vec32 *x, int x_segment, pa_vec32 *y, int y_segment, float alpha, float beta);
+
 /* ---- Gauss-Seidel smoother and grid transfer of the HPCG multigrid preconditioner ----------- */
 /* gauss_seidel_sweep! / gauss_seidel_sweep_zero! (PartitionedSolvers/src/smoothers.jl:144-160,236-259) on the
  * UNSPLIT local CSR of one part (n_own rows, n_local columns [own|ghost], as HPCG builds it: split_format=false).

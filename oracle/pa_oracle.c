@@ -117,3 +117,43 @@ void orc_gs_sweep(double *x, const int32_t *rowptr, const int32_t *colval, const
     x[row] = s;
   }
 }
+
+/* ---- Float32 twins (round 6: the reference's local loops are generic in the element type; its own test runs them in Float32,
+ * test/sparse_utils_tests.jl:33-45,72-79).  Every product and sum is rounded to float (the file is compiled -ffp-contract=off and
+ * x86-64 gcc evaluates float expressions in float). */
+/* src/sparse_utils.jl:649-669 with eltype Float32 */
+void orc_spmv_csr_f32(float *b, const float *x, const int32_t *rowptr, const int32_t *colval, const float *nzval, int64_t nrows) {
+  for (int64_t row = 0; row < nrows; ++row) {
+    float bi = 0.0f;
+    for (int64_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
+      float t = nzval[p - 1] * x[colval[p - 1] - 1];
+      bi = bi + t;
+    }
+    b[row] = bi;
+  }
+}
+/* src/sparse_utils.jl:671-690 with eltype Float32 (colptr / rowval / nzval of a CSC matrix, or the CSR arrays for the transposed product) */
+void orc_spmv_csc_f32(float *b, const float *x, const int32_t *colptr, const int32_t *rowval, const float *nzval, int64_t nrows, int64_t ncols) {
+  for (int64_t r = 0; r < nrows; ++r) b[r] = 0.0f;
+  for (int64_t col = 0; col < ncols; ++col) {
+    float xj = x[col];
+    for (int64_t p = colptr[col]; p < colptr[col + 1]; ++p) {
+      float t = nzval[p - 1] * xj;
+      b[rowval[p - 1] - 1] = b[rowval[p - 1] - 1] + t;
+    }
+  }
+}
+/* SparseMatricesCSR.mul!(y,A,x,alpha,beta) with Float32 arrays and Float32 scalars */
+void orc_mul5_csr_f32(float *y, const float *x, const int32_t *rowptr, const int32_t *colval, const float *nzval, int64_t nrows,
+                      float alpha, float beta) {
+  if (beta != 1.0f) {
+    if (beta != 0.0f) { for (int64_t r = 0; r < nrows; ++r) y[r] = y[r] * beta; }
+    else              { for (int64_t r = 0; r < nrows; ++r) y[r] = 0.0f; }
+  }
+  for (int64_t row = 0; row < nrows; ++row)
+    for (int64_t p = rowptr[row]; p < rowptr[row + 1]; ++p) {
+      float t = nzval[p - 1] * x[colval[p - 1] - 1];
+      t = t * alpha;
+      y[row] = y[row] + t;
+    }
+}

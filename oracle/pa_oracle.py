@@ -1503,6 +1503,11 @@ class _OracleC:
         L.orc_unpack_add.argtypes = [P, P, P, ctypes.c_int64]
         for f in (L.orc_spmv_csr, L.orc_mul5_csr, L.orc_pack, L.orc_unpack_insert, L.orc_unpack_add):
             f.restype = None
+        L.orc_spmv_csr_f32.argtypes = [P, P, P, P, P, ctypes.c_int64]
+        L.orc_spmv_csc_f32.argtypes = [P, P, P, P, P, ctypes.c_int64, ctypes.c_int64]
+        L.orc_mul5_csr_f32.argtypes = [P, P, P, P, P, ctypes.c_int64, ctypes.c_float, ctypes.c_float]
+        for f in (L.orc_spmv_csr_f32, L.orc_spmv_csc_f32, L.orc_mul5_csr_f32):
+            f.restype = None
 
     @staticmethod
     def _p(a):
@@ -1514,6 +1519,25 @@ class _OracleC:
         self.lib.orc_spmv_csr(self._p(b), self._p(x), self._p(A.rowptr), self._p(A.colval),
                               self._p(A.nzval), len(b))
         return b
+
+    # Float32 twins (src/sparse_utils.jl:649-690 are generic in the element type; test/sparse_utils_tests.jl:72-79 runs them in Float32)
+    def spmv_csr_f32(self, b, x, rowptr, colval, nzval):
+        for a, dt in ((b, np.float32), (x, np.float32), (rowptr, I32), (colval, I32), (nzval, np.float32)):
+            assert a.dtype == dt and a.flags.c_contiguous
+        self.lib.orc_spmv_csr_f32(self._p(b), self._p(x), self._p(rowptr), self._p(colval), self._p(nzval), len(b))
+        return b
+
+    def spmv_csc_f32(self, b, x, colptr, rowval, nzval):
+        for a, dt in ((b, np.float32), (x, np.float32), (colptr, I32), (rowval, I32), (nzval, np.float32)):
+            assert a.dtype == dt and a.flags.c_contiguous
+        self.lib.orc_spmv_csc_f32(self._p(b), self._p(x), self._p(colptr), self._p(rowval), self._p(nzval), len(b), len(x))
+        return b
+
+    def mul5_csr_f32(self, y, x, rowptr, colval, nzval, alpha, beta):
+        for a, dt in ((y, np.float32), (x, np.float32), (rowptr, I32), (colval, I32), (nzval, np.float32)):
+            assert a.dtype == dt and a.flags.c_contiguous
+        self.lib.orc_mul5_csr_f32(self._p(y), self._p(x), self._p(rowptr), self._p(colval), self._p(nzval), len(y), float(alpha), float(beta))
+        return y
 
     def mul5_csr(self, y, A: CSR, x, alpha, beta):
         assert A.rowptr.dtype == I32 and A.colval.dtype == I32
@@ -1540,6 +1564,33 @@ class _OracleC:
 
 class _OraclePy:
     """Pure-python fallbacks with the same interface (tiny cases; also cross-checks the C)."""
+
+    def spmv_csr_f32(self, b, x, rowptr, colval, nzval):
+        f = np.float32
+        for row in range(len(b)):
+            bi = f(0)
+            for p in range(rowptr[row] - 1, rowptr[row + 1] - 1):
+                bi = f(bi + f(nzval[p] * x[colval[p] - 1]))
+            b[row] = bi
+        return b
+
+    def spmv_csc_f32(self, b, x, colptr, rowval, nzval):
+        f = np.float32
+        b[:] = 0
+        for col in range(len(x)):
+            for p in range(colptr[col] - 1, colptr[col + 1] - 1):
+                b[rowval[p] - 1] = f(b[rowval[p] - 1] + f(nzval[p] * x[col]))
+        return b
+
+    def mul5_csr_f32(self, y, x, rowptr, colval, nzval, alpha, beta):
+        f = np.float32
+        alpha, beta = f(alpha), f(beta)
+        if beta != 1:
+            y[:] = (y * beta).astype(f) if beta != 0 else 0
+        for row in range(len(y)):
+            for p in range(rowptr[row] - 1, rowptr[row + 1] - 1):
+                y[row] = f(y[row] + f(f(nzval[p] * x[colval[p] - 1]) * alpha))
+        return y
 
     def spmv_csr(self, b, x, A: CSR):
         return spmv_csr(b, x, A.rowptr, A.colval, A.nzval)

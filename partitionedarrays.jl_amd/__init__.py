@@ -16,7 +16,7 @@ from .p_vector import (Context, Event, Graph, context, init_comm, DeviceVector, 
                        dot, norm, axpby_, copy_, slots_supported, dot_slot, axpby_slot_, cg_update_, write_slot,
                        read_slots, on_partition, pvector_disassembled, pvector_, VectorReassemblyCache,
                        pvector_from_function_values)
-from .p_sparse_matrix import (HostCSR, DeviceCSR, DeviceSELL, SplitMatrixBlocks, PSparseMatrix, compresscoo, sparse_matrix,  # noqa: F401
+from .p_sparse_matrix import (HostCSR, DeviceCSR, DeviceSELL, DeviceVector32, DeviceCSR32, spmv32_, SplitMatrixBlocks, PSparseMatrix, compresscoo, sparse_matrix,  # noqa: F401
                               split_format_locally, spmv_, psparse, psparse_from_coo, mul_, mul_c_, mul_no_lat_c_, mul5_, mul_no_overlap_,
                               psparse_disassembled, psparse_assemble_host, psparse_, MatrixReassemblyCache,
                               mul5_transpose_, transposed_blocks, renumber_for_locality, psystem, psystem_, tune_output_placement)

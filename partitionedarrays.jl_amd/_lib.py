@@ -179,6 +179,16 @@ _SIGS = {
     "pa_sell_destroy": [P],
     "pa_sell_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "pa_sell_spmv": [P, P, cint, P, cint, f64, f64],
+    "pa_vec32_create": [P, i64, i64, PP],
+    "pa_vec32_destroy": [P],
+    "pa_vec32_upload": [P, P, i64, i64],
+    "pa_vec32_download": [P, P, i64, i64],
+    "pa_vec32_fill": [P, cint, C.c_float],
+    "pa_csr32_create": [P, i64, i64, i64, P, P, cint, cint, P, PP],
+    "pa_csr32_create_from_csc": [P, i64, i64, i64, P, P, cint, cint, P, PP],
+    "pa_csr32_destroy": [P],
+    "pa_csr32_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64)],
+    "pa_spmv32": [P, P, cint, P, cint, C.c_float, C.c_float],
     "pa_csr_pell_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(cint)],
     "pa_plan_create": [P, i32, i64, i32, P, P, P, i32, P, P, P, cint, PP],
     "pa_plan_destroy": [P],

@@ -1,0 +1,371 @@
+// pa_f32.hip -- Float32 blocks and vectors: the first widening beyond the FP64 scope of the path (round 6, VERDICT r05 "Next" #7).
+//
+// The reference's local loops are generic in the element type -- spmv_csr! / spmv_csc! src/sparse_utils.jl:649-690, run in Float32 by
+// its own test (test/sparse_utils_tests.jl:72-79: the 7 x 6 matrix of test_mat as SparseMatrixCSC{Float32,Int32} and
+// SparseMatrixCSR{0|1,Float32,Int32}); SparseMatricesCSR.mul!(y,A,x,alpha,beta) likewise.  Here: a Float32 local vector type
+// (pa_vec32, [own | ghost] like pa_vec), a Float32 block (pa_csr32) and pa_spmv32, every product and every sum rounded to float in
+// the reference's order (one lane per row walks ITS row left to right; the file is compiled -ffp-contract=off) -- bit-identical to
+// the oracle's float loops (oracle/pa_oracle.c: orc_spmv_csr_f32 / orc_mul5_csr_f32).
+//   * a block whose rows follow patterns gets the fp64 path's pattern-ELL STRUCTURE (pa_pell_structure: slab descriptors, pattern
+//     table, row masks) with a Float32 value stream: 4 bytes per stored entry (27-point 256^3: 1.8 GB instead of 3.6);
+//   * every other block is stored SELL-64 (csrc/pa_sell.hip's layout) with Float32 values and Int32 columns.
+// Not here (yet): Float32 payloads of the exchange (consistent! / assemble! of a Float32 PVector), the epilogue forms, value updates.
+#include "pa_dev_util.h"
+
+#include "pa_pell.h"
+
+#include <numeric>
+
+using namespace pa_util;
+
+struct pa_vec32 {
+  pa_ctx *ctx = nullptr;
+  float *d = nullptr;
+  int64_t n_own = 0, n_ghost = 0;
+};
+
+struct pa_csr32 {
+  pa_ctx *ctx = nullptr;
+  int64_t n_rows = 0, n_cols = 0, nnz = 0;
+  bool alpha_inside = false;          // made from CSC storage: mul!(y,A,x,alpha,beta) forms a*(x*alpha) (SparseArrays), not (a*x)*alpha
+  // SELL-64: slab s holds rows 64 s .. 64 s + 63, the k-th stored entries of its rows next to each other
+  int64_t n_slabs = 0, padded = 0;
+  int64_t *d_slab_ptr = nullptr;
+  int32_t *d_len = nullptr, *d_col = nullptr;
+  float *d_val = nullptr;
+  // pattern-ELL structure of the fp64 path + a Float32 value stream val[(first + k) * 64 + lane]
+  pa_pell *pell = nullptr;
+  float *d_pval = nullptr;
+};
+
+__global__ void k32_fill(float *__restrict__ x, int64_t n, float v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
+// y[row] = beta*y[row] + sum_k (val*x[col])*alpha, k ascending, in float: one wavefront per slab, one lane per row
+__global__ __launch_bounds__(256) void k32_sell_spmv(const int64_t *__restrict__ slab_ptr, const int32_t *__restrict__ len,
+                                                     const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                     const float *__restrict__ x, float *__restrict__ y, int64_t n_slabs, int64_t n_rows,
+                                                     float alpha, float beta, int alpha_inside) {
+  const int64_t slab = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (slab >= n_slabs) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t row = slab * 64 + lane;
+  const bool live = row < n_rows;
+  const int n = live ? len[row] : 0;
+  const int64_t base = slab_ptr[slab] + lane;
+  const int width = (int)((slab_ptr[slab + 1] - slab_ptr[slab]) / 64);
+  float acc = 0.0f;
+  if (live && beta != 0.0f) acc = y[row] * beta;
+  for (int k0 = 0; k0 < width; k0 += 4) {
+    float v[4], xv[4];
+    int c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t p = base + (int64_t)min(k0 + j, width - 1) * 64;
+      v[j] = __builtin_nontemporal_load(&val[p]);
+      c[j] = __builtin_nontemporal_load(&col[p]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xv[j] = x[c[j]];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < n) {
+        float pr;
+        if (alpha_inside) pr = v[j] * (xv[j] * alpha);
+        else { pr = v[j] * xv[j]; pr = pr * alpha; }
+        acc = acc + pr;
+      }
+  }
+  if (live) y[row] = acc;
+}
+
+// the same on the pattern-ELL structure (pa_pell.h: slab patterns, row masks) with the Float32 value stream
+template <int U>
+__global__ __launch_bounds__(256) void k32_pell_spmv(const pa_pell_dev P, const float *__restrict__ pval, const float *__restrict__ x,
+                                                     float *__restrict__ y, int bpx, float alpha, float beta, int alpha_inside) {
+  const int b = blockIdx.x;
+  const int g = (b & 7) * bpx + (b >> 3);
+  const int n_groups = (P.n_slabs + 3) >> 2;
+  if (g >= n_groups) return;
+  const int slab = __builtin_amdgcn_readfirstlane(g * 4 + (int)(threadIdx.x >> 6));
+  if (slab >= P.n_slabs) return;
+  const int lane = threadIdx.x & 63;
+  const int2 d = P.desc[slab];
+  const int pat = d.x & 0xfffff, Wp = d.x >> 20;
+  const int *dl = P.pdelta + (size_t)pat * PA_PELL_TW;
+  const int r = slab * 64 + lane;
+  const bool live = r < P.n_crows;
+  const int row = live ? r : P.n_crows - 1;
+  const unsigned long long m = live ? P.mask[row] : 0u;
+  const float *vp = pval + (size_t)(unsigned)d.y * 64 + lane;
+  float acc = 0.0f;
+  if (live && beta != 0.0f) acc = y[row] * beta;
+  for (int k0 = 0; k0 < Wp; k0 += U) {
+    float v[U], xv[U];
+    bool on[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+      v[j] = __builtin_nontemporal_load(vp + (size_t)(k0 + j) * 64);
+      on[j] = (m >> (k0 + j)) & 1ull;
+      xv[j] = x[on[j] ? row + dl[k0 + j] : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j)
+      if (on[j]) {
+        float pr;
+        if (alpha_inside) pr = v[j] * (xv[j] * alpha);
+        else { pr = v[j] * xv[j]; pr = pr * alpha; }
+        acc = acc + pr;
+      }
+  }
+  if (live) __builtin_nontemporal_store(acc, &y[row]);
+}
+
+__global__ __launch_bounds__(256) void k32_pell_fill(const int *__restrict__ crp, const float *__restrict__ val, const unsigned *__restrict__ mask,
+                                                     const int2 *__restrict__ desc, int n_rows, int n_slabs, float *__restrict__ out) {
+  const int slab = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slab >= n_slabs) return;
+  const int r = slab * 64 + lane;
+  if (r >= n_rows) return;
+  unsigned m = mask[r];
+  int p = crp[r];
+  const size_t base = (size_t)(unsigned)desc[slab].y * 64 + lane;
+  while (m) {
+    const int k = __builtin_ctz(m);
+    m &= m - 1;
+    out[base + (size_t)k * 64] = val[p++];
+  }
+}
+
+// ---- vectors -----------------------------------------------------------------------------------------------------------------
+extern "C" int pa_vec32_create(pa_ctx *c, int64_t n_own, int64_t n_ghost, pa_vec32 **out) {
+  PA_REQUIRE(c && out && n_own >= 0 && n_ghost >= 0, "bad arguments");
+  PA_HIP(hipSetDevice(c->device));
+  pa_vec32 *v = new pa_vec32();
+  v->ctx = c; v->n_own = n_own; v->n_ghost = n_ghost;
+  const size_t n = (size_t)std::max<int64_t>(n_own + n_ghost, 1) + 4;
+  if (pa_dev_alloc(c, (void **)&v->d, sizeof(float) * n, PA_MEM_VECTOR) != PA_OK) { delete v; return PA_ERR_HIP; }
+  PA_HIP(hipMemsetAsync(v->d, 0, sizeof(float) * n, c->s[0]));
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  *out = v;
+  return PA_OK;
+}
+extern "C" int pa_vec32_destroy(pa_vec32 *v) {
+  if (!v) return PA_OK;
+  (void)hipSetDevice(v->ctx->device);
+  (void)hipStreamSynchronize(v->ctx->s[0]);
+  pa_dev_free(v->ctx, v->d);
+  delete v;
+  return PA_OK;
+}
+extern "C" int pa_vec32_upload(pa_vec32 *v, const float *host, int64_t offset, int64_t len) {
+  PA_REQUIRE(v && (host || len == 0) && offset >= 0 && len >= 0 && offset + len <= v->n_own + v->n_ghost, "bad arguments");
+  PA_HIP(hipSetDevice(v->ctx->device));
+  if (len) {
+    PA_HIP(hipMemcpyAsync(v->d + offset, host, sizeof(float) * (size_t)len, hipMemcpyHostToDevice, v->ctx->s[0]));
+    PA_HIP(hipStreamSynchronize(v->ctx->s[0]));
+  }
+  return PA_OK;
+}
+extern "C" int pa_vec32_download(const pa_vec32 *v, float *host, int64_t offset, int64_t len) {
+  PA_REQUIRE(v && (host || len == 0) && offset >= 0 && len >= 0 && offset + len <= v->n_own + v->n_ghost, "bad arguments");
+  PA_HIP(hipSetDevice(v->ctx->device));
+  if (len) {
+    PA_HIP(hipMemcpyAsync(host, v->d + offset, sizeof(float) * (size_t)len, hipMemcpyDeviceToHost, v->ctx->s[0]));
+    PA_HIP(hipStreamSynchronize(v->ctx->s[0]));
+  }
+  return PA_OK;
+}
+static bool seg32(const pa_vec32 *v, int s, int64_t *off, int64_t *len) {
+  if (s == PA_SEG_OWN) { *off = 0; *len = v->n_own; }
+  else if (s == PA_SEG_GHOST) { *off = v->n_own; *len = v->n_ghost; }
+  else if (s == PA_SEG_LOCAL) { *off = 0; *len = v->n_own + v->n_ghost; }
+  else return false;
+  return true;
+}
+extern "C" int pa_vec32_fill(pa_vec32 *v, int segment, float value) {
+  int64_t off, len;
+  PA_REQUIRE(v && seg32(v, segment, &off, &len), "bad arguments");
+  PA_HIP(hipSetDevice(v->ctx->device));
+  if (len) hipLaunchKernelGGL(k32_fill, grid1(len), dim3(256), 0, v->ctx->s[0], v->d + off, len, value);
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}
+
+// ---- blocks ------------------------------------------------------------------------------------------------------------------
+extern "C" int pa_csr32_destroy(pa_csr32 *A) {
+  if (!A) return PA_OK;
+  pa_ctx *c = A->ctx;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->s[0]);
+  pa_dev_free(c, A->d_slab_ptr);
+  pa_dev_free(c, A->d_len);
+  pa_dev_free(c, A->d_col);
+  pa_dev_free(c, A->d_val);
+  if (A->d_pval) pa_dev_free(c, A->d_pval);
+  pa_pell_struct_free(c, A->pell);
+  delete A;
+  return PA_OK;
+}
+
+// rp: 0-based row pointers, col: 0-based columns ascending inside every row, val: the stored values (host)
+static int csr32_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const std::vector<int32_t> &rp, const std::vector<int32_t> &col,
+                       const float *val, bool alpha_inside, pa_csr32 **out) {
+  PA_HIP(hipSetDevice(c->device));
+  pa_csr32 *A = new pa_csr32();
+  A->ctx = c; A->n_rows = n_rows; A->n_cols = n_cols; A->nnz = nnz; A->alpha_inside = alpha_inside;
+  auto fail = [&](int st) { (void)hipGetLastError(); (void)pa_csr32_destroy(A); return st; };
+  // pattern blocks first: the structure of the fp64 path (never for tiny blocks: the general storage serves them)
+  const char *e = getenv("PA_SPMV_PELL");
+  if (!(e && atoi(e) == 0) && nnz >= 4096 && n_rows > 0) {
+    scratch sc;
+    int32_t *d_rp = nullptr, *d_col = nullptr;
+    float *d_v = nullptr;
+    if (sc.get(&d_rp, (size_t)n_rows + 1) == PA_OK && sc.get(&d_col, (size_t)nnz + 8) == PA_OK && sc.get(&d_v, (size_t)nnz + 8) == PA_OK &&
+        pa_h2d(d_rp, rp.data(), sizeof(int32_t) * ((size_t)n_rows + 1)) == hipSuccess &&
+        pa_h2d(d_col, col.data(), sizeof(int32_t) * (size_t)nnz) == hipSuccess && pa_h2d(d_v, val, sizeof(float) * (size_t)nnz) == hipSuccess) {
+      const char *why = "";
+      A->pell = pa_pell_structure(c, d_rp, d_col, nullptr, n_rows, nnz, false, &why);
+      if (A->pell) {
+        const size_t n = (size_t)std::max<int64_t>(A->pell->slots, 1) * 64;
+        if (pa_dev_alloc(c, (void **)&A->d_pval, sizeof(float) * n, PA_MEM_MATRIX) == PA_OK &&
+            hipMemsetAsync(A->d_pval, 0, sizeof(float) * n, c->s[0]) == hipSuccess) {
+          hipLaunchKernelGGL(k32_pell_fill, dim3((unsigned)((A->pell->n_slabs + 3) / 4)), dim3(256), 0, c->s[0], d_rp, d_v, A->pell->d_mask,
+                             A->pell->d_desc, (int)n_rows, (int)A->pell->n_slabs, A->d_pval);
+          if (hipStreamSynchronize(c->s[0]) == hipSuccess && hipGetLastError() == hipSuccess) { *out = A; return PA_OK; }
+        }
+        (void)hipGetLastError();
+        if (A->d_pval) pa_dev_free(c, A->d_pval);
+        A->d_pval = nullptr;
+        pa_pell_struct_free(c, A->pell);
+        A->pell = nullptr;
+      }
+    }
+    (void)hipGetLastError();
+  }
+  // general storage: SELL-64 in row order
+  const int64_t n_slabs = (n_rows + 63) / 64;
+  std::vector<int64_t> slab_ptr((size_t)n_slabs + 1, 0);
+  std::vector<int32_t> len((size_t)std::max<int64_t>(n_slabs * 64, 1), 0);
+  for (int64_t s = 0; s < n_slabs; ++s) {
+    int64_t w = 0;
+    for (int l = 0; l < 64 && s * 64 + l < n_rows; ++l) {
+      const int64_t r = s * 64 + l;
+      len[(size_t)r] = rp[r + 1] - rp[r];
+      w = std::max<int64_t>(w, rp[r + 1] - rp[r]);
+    }
+    slab_ptr[s + 1] = slab_ptr[s] + w * 64;
+  }
+  const int64_t padded = slab_ptr[n_slabs];
+  std::vector<int32_t> scol((size_t)std::max<int64_t>(padded, 1), 0);
+  std::vector<float> sval((size_t)std::max<int64_t>(padded, 1), 0.0f);
+  for (int64_t r = 0; r < n_rows; ++r)
+    for (int64_t k = 0; k < rp[r + 1] - rp[r]; ++k) {
+      const int64_t q = slab_ptr[r / 64] + k * 64 + (r % 64);
+      scol[(size_t)q] = col[(size_t)(rp[r] + k)];
+      sval[(size_t)q] = val[rp[r] + k];
+    }
+  A->n_slabs = n_slabs; A->padded = padded;
+  if (pa_dev_alloc(c, (void **)&A->d_val, sizeof(float) * sval.size(), PA_MEM_MATRIX) || pa_dev_alloc(c, (void **)&A->d_col, sizeof(int32_t) * scol.size(), PA_MEM_MATRIX) ||
+      pa_dev_alloc(c, (void **)&A->d_slab_ptr, sizeof(int64_t) * slab_ptr.size(), PA_MEM_MATRIX) || pa_dev_alloc(c, (void **)&A->d_len, sizeof(int32_t) * len.size(), PA_MEM_MATRIX))
+    return fail(PA_ERR_HIP);
+  if (pa_h2d(A->d_val, sval.data(), sizeof(float) * sval.size()) != hipSuccess || pa_h2d(A->d_col, scol.data(), sizeof(int32_t) * scol.size()) != hipSuccess ||
+      pa_h2d(A->d_slab_ptr, slab_ptr.data(), sizeof(int64_t) * slab_ptr.size()) != hipSuccess || pa_h2d(A->d_len, len.data(), sizeof(int32_t) * len.size()) != hipSuccess) {
+    pa_set_err("pa_csr32: upload failed");
+    return fail(PA_ERR_HIP);
+  }
+  *out = A;
+  return PA_OK;
+}
+
+static int64_t rd_index(const void *a, int bytes, int64_t i) { return bytes == 4 ? (int64_t)((const int32_t *)a)[i] : ((const int64_t *)a)[i]; }
+
+// SparseMatrixCSR{Bi,Float32,Ti} (index_base = Bi), columns ascending inside every row
+extern "C" int pa_csr32_create(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr, const void *colval, int index_bytes,
+                               int index_base, const float *nzval, pa_csr32 **out) {
+  PA_REQUIRE(c && out && rowptr && (nnz == 0 || (colval && nzval)), "bad arguments");
+  PA_REQUIRE((index_bytes == 4 || index_bytes == 8) && (index_base == 0 || index_base == 1), "index_bytes must be 4 or 8, index_base 0 or 1");
+  PA_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && n_rows < (int64_t)2147483000 && n_cols < (int64_t)2147483000 && nnz < (int64_t)2147483000, "bad sizes");
+  std::vector<int32_t> rp((size_t)n_rows + 1), col((size_t)nnz);
+  for (int64_t r = 0; r <= n_rows; ++r) rp[(size_t)r] = (int32_t)(rd_index(rowptr, index_bytes, r) - index_base);
+  PA_REQUIRE(rp[0] == 0 && rp[(size_t)n_rows] == nnz, "rowptr does not span [base, base+nnz]");
+  for (int64_t r = 0; r < n_rows; ++r) PA_REQUIRE(rp[r + 1] >= rp[r], "rowptr not monotone at row %lld", (long long)r);
+  for (int64_t p = 0; p < nnz; ++p) {
+    const int64_t j = rd_index(colval, index_bytes, p) - index_base;
+    PA_REQUIRE(j >= 0 && j < n_cols, "column index out of range at entry %lld", (long long)p);
+    col[(size_t)p] = (int32_t)j;
+  }
+  return csr32_build(c, n_rows, n_cols, nnz, rp, col, nzval, false, out);
+}
+
+// SparseMatrixCSC{Float32,Ti} (1-based): spmv_csc! adds a row's entries in ascending column (src/sparse_utils.jl:671-690), which IS the
+// CSR order -- converted at upload (stable: a column's entries keep their order inside each row)
+extern "C" int pa_csr32_create_from_csc(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr, const void *rowval,
+                                        int index_bytes, int index_base, const float *nzval, pa_csr32 **out) {
+  PA_REQUIRE(c && out && colptr && (nnz == 0 || (rowval && nzval)), "bad arguments");
+  PA_REQUIRE((index_bytes == 4 || index_bytes == 8) && (index_base == 0 || index_base == 1), "index_bytes must be 4 or 8, index_base 0 or 1");
+  PA_REQUIRE(n_rows >= 0 && n_cols >= 0 && nnz >= 0 && n_rows < (int64_t)2147483000 && n_cols < (int64_t)2147483000 && nnz < (int64_t)2147483000, "bad sizes");
+  std::vector<int32_t> rp((size_t)n_rows + 1, 0), col((size_t)nnz);
+  std::vector<float> val((size_t)std::max<int64_t>(nnz, 1));
+  PA_REQUIRE(rd_index(colptr, index_bytes, 0) == index_base && rd_index(colptr, index_bytes, n_cols) - index_base == nnz, "colptr does not span [base, base+nnz]");
+  for (int64_t p = 0; p < nnz; ++p) {
+    const int64_t r = rd_index(rowval, index_bytes, p) - index_base;
+    PA_REQUIRE(r >= 0 && r < n_rows, "row index out of range at entry %lld", (long long)p);
+    ++rp[(size_t)r + 1];
+  }
+  for (int64_t r = 0; r < n_rows; ++r) rp[(size_t)r + 1] += rp[(size_t)r];
+  std::vector<int32_t> next(rp.begin(), rp.end() - 1);
+  for (int64_t j = 0; j < n_cols; ++j)
+    for (int64_t p = rd_index(colptr, index_bytes, j) - index_base; p < rd_index(colptr, index_bytes, j + 1) - index_base; ++p) {
+      const int64_t r = rd_index(rowval, index_bytes, p) - index_base;
+      const int32_t q = next[(size_t)r]++;
+      col[(size_t)q] = (int32_t)j;
+      val[(size_t)q] = nzval[p];
+    }
+  return csr32_build(c, n_rows, n_cols, nnz, rp, col, val.data(), true, out);
+}
+
+// *on_pattern_ell = 1: the product runs on the pattern-ELL structure (n_slabs, padded_entries describe it), 0: SELL-64
+extern "C" int pa_csr32_info(const pa_csr32 *A, int *on_pattern_ell, int64_t *n_slabs, int64_t *padded_entries) {
+  PA_REQUIRE(A != nullptr, "csr32 is NULL");
+  if (on_pattern_ell) *on_pattern_ell = A->pell ? 1 : 0;
+  if (n_slabs) *n_slabs = A->pell ? A->pell->n_slabs : A->n_slabs;
+  if (padded_entries) *padded_entries = A->pell ? A->pell->slots * 64 : A->padded;
+  return PA_OK;
+}
+
+// spmv!(y,A,x) / mul!(y,A,x,alpha,beta) in Float32 (src/sparse_utils.jl:617-623,649-690; SparseMatricesCSR / SparseArrays mul!)
+extern "C" int pa_spmv32(const pa_csr32 *A, const pa_vec32 *x, int xseg, pa_vec32 *y, int yseg, float alpha, float beta) {
+  PA_REQUIRE(A && x && y, "bad arguments");
+  int64_t xoff, xlen, yoff, ylen;
+  PA_REQUIRE(seg32(x, xseg, &xoff, &xlen) && seg32(y, yseg, &yoff, &ylen), "unknown segment");
+  PA_REQUIRE(ylen == A->n_rows, "length(b)=%lld != size(A,1)=%lld", (long long)ylen, (long long)A->n_rows);
+  PA_REQUIRE(xlen == A->n_cols, "length(x)=%lld != size(A,2)=%lld", (long long)xlen, (long long)A->n_cols);
+  PA_REQUIRE(x->d != y->d || xseg != yseg, "x and y alias");
+  if (A->n_rows == 0) return PA_OK;
+  pa_ctx *c = A->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  const int ai = A->alpha_inside ? 1 : 0;
+  if (A->pell) {
+    pa_pell_dev D;
+    D.desc = A->pell->d_desc; D.pdelta = A->pell->d_pdelta; D.mask = A->pell->d_mask;
+    D.n_slabs = (int)A->pell->n_slabs; D.n_crows = (int)A->n_rows; D.n_cols = (int)A->n_cols;
+    const int n_groups = (int)((A->pell->n_slabs + 3) / 4), bpx = (n_groups + 7) / 8;
+#define PA_F32_PELL(UU) hipLaunchKernelGGL((k32_pell_spmv<UU>), dim3(bpx * 8), dim3(256), 0, c->s[0], D, (const float *)A->d_pval, (const float *)(x->d + xoff), \
+                                           y->d + yoff, bpx, alpha, beta, ai)
+    switch (A->pell->U) {
+      case 9: PA_F32_PELL(9); break;
+      case 7: PA_F32_PELL(7); break;
+      case 5: PA_F32_PELL(5); break;
+      default: PA_F32_PELL(4); break;
+    }
+#undef PA_F32_PELL
+  } else {
+    hipLaunchKernelGGL(k32_sell_spmv, dim3((unsigned)((A->n_slabs + 3) / 4)), dim3(256), 0, c->s[0], A->d_slab_ptr, A->d_len, A->d_col, A->d_val,
+                       (const float *)(x->d + xoff), y->d + yoff, A->n_slabs, A->n_rows, alpha, beta, ai);
+  }
+  PA_HIP(hipGetLastError());
+  return PA_OK;
+}

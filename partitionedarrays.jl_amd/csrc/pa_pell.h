@@ -30,6 +30,7 @@
 
 #include <cstdint>
 
+#include "pa_internal.h"
 #include "pa_spmv_kernel.h"
 
 #define PA_PELL_MAXW 32                  /* deltas of a slab's union (bits of a row mask) */
@@ -160,6 +161,24 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
     if (lane == 0) gs_x[slab] = dacc;
   }
 }
+
+// host side of a block's pattern-ELL storage (pa_pell.hip builds it; pa_f32.hip shares the structure for Float32 blocks)
+struct pa_pell {
+  int U = 9;
+  int64_t n_slabs = 0, n_patterns = 0, slots = 0;      // slots: 64-entry units of the value stream
+  int max_w = 0;
+  bool runs3 = false;                                  // every pattern is made of runs of three consecutive deltas (and U = 9)
+  int2 *d_desc = nullptr;
+  int *d_pdelta = nullptr;
+  unsigned *d_mask = nullptr, *d_bits = nullptr;
+  double *d_val = nullptr;
+  uint64_t bits_epoch = ~(uint64_t)0;                  // A->val_epoch the bits were made at
+  uint64_t n_launched = 0;
+};
+
+pa_pell *pa_pell_structure(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int32_t *d_row_ids, int64_t n_crows, int64_t nnz,
+                           bool compact, const char **why);
+void pa_pell_struct_free(pa_ctx *c, pa_pell *P);
 
 // blockIdx -> slabs: four slabs per workgroup (one per wavefront), consecutive workgroups of an XCD take consecutive slabs (block b
 // sits on XCD b % 8; each XCD has its own L2, and the rows of neighbouring grid lines and planes share their x).  bpx < 0: the same

@@ -22,19 +22,6 @@
 
 using namespace pa_util;
 
-struct pa_pell {
-  int U = 9;
-  int64_t n_slabs = 0, n_patterns = 0, slots = 0;      // slots: 64-entry units of the value stream
-  int max_w = 0;
-  bool runs3 = false;                                  // every pattern is made of runs of three consecutive deltas (and U = 9)
-  int2 *d_desc = nullptr;
-  int *d_pdelta = nullptr;
-  unsigned *d_mask = nullptr, *d_bits = nullptr;
-  double *d_val = nullptr;
-  uint64_t bits_epoch = ~(uint64_t)0;                  // A->val_epoch the bits were made at
-  uint64_t n_launched = 0;
-};
-
 __device__ __forceinline__ int kp_wave_min(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
@@ -111,16 +98,9 @@ __global__ __launch_bounds__(256) void kp_fill(const int *__restrict__ crp, cons
   if (VM == 1) out_bits[r] = bits;
 }
 
+void pa_pell_struct_free(pa_ctx *c, pa_pell *P);
 void pa_pell_free(pa_csr *A) {
-  pa_pell *P = A->pell;
-  if (!P) return;
-  pa_ctx *c = A->ctx;
-  pa_dev_free(c, P->d_desc);
-  pa_dev_free(c, P->d_pdelta);
-  pa_dev_free(c, P->d_mask);
-  if (P->d_bits) pa_dev_free(c, P->d_bits);
-  if (P->d_val) pa_dev_free(c, P->d_val);
-  delete P;
+  pa_pell_struct_free(A->ctx, A->pell);
   A->pell = nullptr;
 }
 
@@ -150,41 +130,41 @@ static int pell_fill(pa_csr *A, bool bits) {
   return PA_OK;
 }
 
-// Called at the end of a slab's creation (pa_csr.hip).  Never an error to the caller: a block that does not qualify, or a device
-// without room for the second value stream, keeps the row-split kernel.
-int pa_pell_build(pa_csr *A) {
-  if (A->pell || !pell_wanted() || pa_tls_plain_encoding || A->nnz == 0 || A->n_crows == 0 || A->next || A->n_xw_groups > 0) return PA_OK;
-  if (!A->use_pattern || A->n_pattern_chunks * 10 < A->n_chunks * 9) return PA_OK;      // (rows without patterns: not worth the look)
-  if (A->ctx->capturing) return PA_OK;
-  pa_ctx *c = A->ctx;
-  PA_HIP(hipSetDevice(c->device));
+void pa_pell_struct_free(pa_ctx *c, pa_pell *P) {
+  if (!P) return;
+  pa_dev_free(c, P->d_desc);
+  pa_dev_free(c, P->d_pdelta);
+  pa_dev_free(c, P->d_mask);
+  if (P->d_bits) pa_dev_free(c, P->d_bits);
+  if (P->d_val) pa_dev_free(c, P->d_val);
+  delete P;
+}
+
+// The structure of a block's pattern-ELL storage -- slab descriptors, pattern table, row masks; no values -- from its row pointers and
+// columns in HBM (d_col: every stored entry's 0-based column in storage order).  NULL (and *why) when the block does not qualify.
+pa_pell *pa_pell_structure(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int32_t *d_row_ids, int64_t n_crows, int64_t nnz,
+                           bool compact, const char **why) {
   hipStream_t s = c->s[0];
-  const auto t_begin = std::chrono::steady_clock::now();
-  const int64_t n_slabs = (A->n_crows + 63) / 64;
+  const int64_t n_slabs = (n_crows + 63) / 64;
   pa_pell *P = new pa_pell();
   P->n_slabs = n_slabs;
-  auto give_up = [&](const char *why) {
+  auto give_up = [&](const char *w) -> pa_pell * {
     (void)hipGetLastError();
-    A->pell = P;
-    pa_pell_free(A);
-    if (getenv("PA_SETUP_TIMING")) fprintf(stderr, "[pa setup] pattern-ELL of %lld entries: none (%s)\n", (long long)A->nnz, why);
-    return PA_OK;
+    pa_pell_struct_free(c, P);
+    *why = w;
+    return nullptr;
   };
   scratch sc;
-  int32_t *d_row = nullptr, *d_col = nullptr;
   int *d_len = nullptr, *d_D = nullptr, *d_bad = nullptr;
   unsigned long long *d_hash = nullptr;
-  if (sc.get(&d_row, (size_t)A->nnz + 8) || sc.get(&d_col, (size_t)A->nnz + 8) || sc.get(&d_len, (size_t)n_slabs) ||
-      sc.get(&d_D, (size_t)n_slabs * PA_PELL_MAXW) || sc.get(&d_hash, (size_t)n_slabs) || sc.get(&d_bad, 1))
+  if (sc.get(&d_len, (size_t)n_slabs) || sc.get(&d_D, (size_t)n_slabs * PA_PELL_MAXW) || sc.get(&d_hash, (size_t)n_slabs) || sc.get(&d_bad, 1))
     return give_up("no room for the set-up's temporaries");
-  if (pa_dev_alloc(c, (void **)&P->d_mask, sizeof(unsigned) * (size_t)A->n_crows, PA_MEM_MATRIX)) return give_up("no room");
-  if (pa_dev_decode_entries(A, d_row, d_col) != PA_OK) return give_up("decode failed");
-  hipLaunchKernelGGL(kp_union, dim3((unsigned)((n_slabs + 3) / 4)), dim3(256), 0, s, A->d_crp, d_col, A->d_row_ids, (int)A->n_crows, (int)n_slabs,
+  if (pa_dev_alloc(c, (void **)&P->d_mask, sizeof(unsigned) * (size_t)n_crows, PA_MEM_MATRIX)) return give_up("no room");
+  hipLaunchKernelGGL(kp_union, dim3((unsigned)((n_slabs + 3) / 4)), dim3(256), 0, s, d_crp, d_col, d_row_ids, (int)n_crows, (int)n_slabs,
                      d_len, d_D, P->d_mask, d_hash);
   std::vector<int> len((size_t)n_slabs);
   std::vector<unsigned long long> hash((size_t)n_slabs);
   if (d2h(s, len.data(), d_len, (size_t)n_slabs) || d2h(s, hash.data(), d_hash, (size_t)n_slabs)) return give_up("read-back failed");
-  sc.release(d_row);
   // the unroll: the commonest width decides (27 -> 9, 7 -> 7, 5 -> 5, else 4); widths are padded to it
   std::map<int, int64_t> freq;
   int max_w = 0;
@@ -217,7 +197,7 @@ int pa_pell_build(pa_csr *A) {
     desc[(size_t)k].y = (int)(unsigned)slots;
     slots += wp;
   }
-  if (slots * 64 > A->nnz + A->nnz / 4 + 64 * 64) return give_up("the slab-wide unions would pad the value stream by more than 25 %");
+  if (slots * 64 > nnz + nnz / 4 + 64 * 64) return give_up("the slab-wide unions would pad the value stream by more than 25 %");
   P->n_patterns = (int64_t)ids.size(); P->slots = slots;
   std::vector<int> table((size_t)P->n_patterns * PA_PELL_TW, 0);
   for (size_t i = 0; i < rep.size(); ++i)
@@ -228,7 +208,7 @@ int pa_pell_build(pa_csr *A) {
   // runs of three consecutive deltas in every pattern (the 27-point operator: nine per row): the kernel's R3 form, one gather per run
   {
     const char *e3 = getenv("PA_SPMV_PELL_RUNS3");
-    bool r3 = U == 9 && !A->compact && !(e3 && atoi(e3) == 0);
+    bool r3 = U == 9 && !compact && !(e3 && atoi(e3) == 0);
     for (size_t i = 0; i < rep.size() && r3; ++i) {
       const int L = len[(size_t)rep[i]];
       if (L % 3) { r3 = false; break; }
@@ -246,7 +226,36 @@ int pa_pell_build(pa_csr *A) {
   hipLaunchKernelGGL(kp_verify, grid1(n_slabs), dim3(256), 0, s, d_len, d_D, P->d_desc, P->d_pdelta, (int)n_slabs, d_bad);
   int bad = 1;
   if (d2h(s, &bad, d_bad, 1) || bad) return give_up("two different slab patterns share a hash");
-  A->pell = P;
+  return P;
+}
+
+// Called at the end of a slab's creation (pa_csr.hip).  Never an error to the caller: a block that does not qualify, or a device
+// without room for the second value stream, keeps the row-split kernel.
+int pa_pell_build(pa_csr *A) {
+  if (A->pell || !pell_wanted() || pa_tls_plain_encoding || A->nnz == 0 || A->n_crows == 0 || A->next || A->n_xw_groups > 0) return PA_OK;
+  if (!A->use_pattern || A->n_pattern_chunks * 10 < A->n_chunks * 9) return PA_OK;      // (rows without patterns: not worth the look)
+  if (A->ctx->capturing) return PA_OK;
+  pa_ctx *c = A->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto give_up = [&](const char *why) {
+    (void)hipGetLastError();
+    pa_pell_free(A);
+    if (getenv("PA_SETUP_TIMING")) fprintf(stderr, "[pa setup] pattern-ELL of %lld entries: none (%s)\n", (long long)A->nnz, why);
+    return PA_OK;
+  };
+  const char *why = "";
+  {
+    scratch sc;
+    int32_t *d_row = nullptr, *d_col = nullptr;
+    if (sc.get(&d_row, (size_t)A->nnz + 8) || sc.get(&d_col, (size_t)A->nnz + 8)) return give_up("no room for the set-up's temporaries");
+    if (pa_dev_decode_entries(A, d_row, d_col) != PA_OK) return give_up("decode failed");
+    A->pell = pa_pell_structure(c, A->d_crp, d_col, A->d_row_ids, A->n_crows, A->nnz, A->compact, &why);
+  }
+  if (!A->pell) return give_up(why);
+  pa_pell *P = A->pell;
+  const int64_t slots = P->slots;
   // the value stream: one bit per entry when the block's dictionary (built just before) has at most two values, else fp64
   const bool two = A->use_vdict && A->n_dict <= 2;
   if (two) {
@@ -259,9 +268,10 @@ int pa_pell_build(pa_csr *A) {
   }
   if (pell_fill(A, two) != PA_OK || hipStreamSynchronize(s) != hipSuccess) return give_up("fill failed");
   if (getenv("PA_SETUP_TIMING"))
-    fprintf(stderr, "[pa setup] pattern-ELL of %lld entries: %lld slabs, %lld patterns, width <= %d, unroll %d, %lld slots (%.3f x the entries), %s, %.3f ms\n",
-            (long long)A->nnz, (long long)n_slabs, (long long)P->n_patterns, max_w, U, (long long)slots * 64, slots * 64.0 / A->nnz,
-            two ? "one bit per entry" : "fp64 stream", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    fprintf(stderr, "[pa setup] pattern-ELL of %lld entries: %lld slabs, %lld patterns, width <= %d, unroll %d, %lld slots (%.3f x the entries), %s%s, %.3f ms\n",
+            (long long)A->nnz, (long long)P->n_slabs, (long long)P->n_patterns, P->max_w, P->U, (long long)slots * 64, slots * 64.0 / A->nnz,
+            P->runs3 ? "runs of three, " : "", two ? "one bit per entry" : "fp64 stream",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   return PA_OK;
 }
 

@@ -266,6 +266,67 @@ class DeviceSELL:
             pass
 
 
+class DeviceVector32:
+    """Local values of a PVector{Vector{Float32}} in HBM, [own | ghost] (pa_vec32, csrc/pa_f32.hip)."""
+
+    def __init__(self, n_own, n_ghost=0, ctx=None):
+        self.ctx = ctx or context()
+        self.n_own, self.n_ghost = int(n_own), int(n_ghost)
+        self.h = C.c_void_p()
+        L.call("pa_vec32_create", self.ctx.h, self.n_own, self.n_ghost, C.byref(self.h))
+
+    def upload(self, host, offset=0):
+        host = np.ascontiguousarray(host, np.float32)
+        L.call("pa_vec32_upload", self.h, L.ptr(host), int(offset), len(host))
+        return self
+
+    def download(self):
+        out = np.zeros(self.n_own + self.n_ghost, np.float32)
+        L.call("pa_vec32_download", self.h, L.ptr(out), 0, len(out))
+        return out
+
+    def fill(self, value, segment=L.SEG_LOCAL):
+        L.call("pa_vec32_fill", self.h, segment, float(value))
+        return self
+
+    def __del__(self):
+        try:
+            L.lib.pa_vec32_destroy(self.h)
+        except Exception:
+            pass
+
+
+class DeviceCSR32:
+    """A SparseMatrixCSR{1,Float32,Int32} (or, csc=True: the colptr / rowval / nzval of a SparseMatrixCSC{Float32}) block in HBM
+    (pa_csr32, csrc/pa_f32.hip): rowptr / colval 1-based as the reference stores them."""
+
+    def __init__(self, m, n, ptr, idx, nzval, csc=False, index_base=1, ctx=None):
+        self.ctx = ctx or context()
+        self.m, self.n, self.nnz = int(m), int(n), len(nzval)
+        ptr, idx = np.ascontiguousarray(ptr), np.ascontiguousarray(idx, ptr.dtype)
+        nzval = np.ascontiguousarray(nzval, np.float32)
+        self.h = C.c_void_p()
+        L.call("pa_csr32_create_from_csc" if csc else "pa_csr32_create", self.ctx.h, self.m, self.n, self.nnz, L.ptr(ptr), L.ptr(idx),
+               ptr.dtype.itemsize, int(index_base), L.ptr(nzval), C.byref(self.h))
+
+    def info(self):
+        on, a, b = C.c_int(), C.c_int64(), C.c_int64()
+        L.call("pa_csr32_info", self.h, C.byref(on), C.byref(a), C.byref(b))
+        return dict(pattern_ell=bool(on.value), slabs=a.value, padded_entries=b.value)
+
+    def __del__(self):
+        try:
+            L.lib.pa_csr32_destroy(self.h)
+        except Exception:
+            pass
+
+
+def spmv32_(b, A, x, x_segment=L.SEG_OWN, b_segment=L.SEG_OWN, alpha=1.0, beta=0.0):
+    """spmv!(b,A,x) / mul!(b,A,x,alpha,beta) in Float32 (src/sparse_utils.jl:617-690 with eltype Float32)."""
+    L.call("pa_spmv32", A.h, x.h, x_segment, b.h, b_segment, float(alpha), float(beta))
+    return b
+
+
 def spmv_(b, A, x, x_segment=L.SEG_OWN, b_segment=L.SEG_OWN, alpha=1.0, beta=0.0):
     """spmv!(b,A,x) / mul!(b,A,x,alpha,beta) on device vectors (src/sparse_utils.jl:609-669); A: DeviceCSR or DeviceSELL."""
     L.call("pa_sell_spmv" if isinstance(A, DeviceSELL) else "pa_spmv", A.h, x.h, x_segment, b.h, b_segment, float(alpha), float(beta))
