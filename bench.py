@@ -806,6 +806,39 @@ def extra_configs(pa, ctx, L, out):
     return out
 
 
+def float32_entry(pa, ctx, L, host_oo, xv, y_head, n_own):
+    """Beside the f64 headline, never instead of it: the same own x own block with Float32 values and Float32 vectors
+    (csrc/pa_f32.hip: the fp64 path's pattern-ELL structure with a 4-byte value stream; every product and sum rounded to float in
+    spmv_csr!'s order, src/sparse_utils.jl:649-669 with eltype Float32).  The f64 headline's y is the yardstick: the Float32 result
+    must agree with it to Float32 accuracy."""
+    PHASE[0] = "Float32 block"
+    t = time.perf_counter()
+    A32 = pa.DeviceCSR32(host_oo.m, host_oo.n, host_oo.rowptr, host_oo.colval, host_oo.nzval.astype(np.float32))
+    ts = time.perf_counter() - t
+    x32 = pa.DeviceVector32(host_oo.n).upload(xv.download()[:host_oo.n].astype(np.float32))
+    y32 = pa.DeviceVector32(host_oo.m)
+    pa.spmv32_(y32, A32, x32)
+    got = y32.download().astype(np.float64)
+    err = float(np.max(np.abs(got - y_head)) / max(1e-300, float(np.max(np.abs(y_head)))))
+    spin_up(ctx, lambda: pa.spmv32_(y32, A32, x32))
+    reps = 30
+    e0 = ctx.event().record(L.STREAM_COMPUTE)
+    for _ in range(reps):
+        pa.spmv32_(y32, A32, x32)
+    e1 = ctx.event().record(L.STREAM_COMPUTE)
+    ctx.sync()
+    ms = e0.elapsed_ms(e1) / reps
+    info = A32.info()
+    nnz = len(host_oo.nzval)
+    moved = 4 * info["padded_entries"] + 8 * info["slabs"] + 4 * n_own + 2 * 4 * n_own      # values + slab descriptors + row masks + x once + y once
+    return {"workload": "the headline's own x own block with Float32 values, Float32 x and y (pa_spmv32)", "dtype": "f32", "nnz": int(nnz),
+            "storage": "pattern-ELL structure, 4-byte value stream" if info["pattern_ell"] else "SELL-64, Float32 values + Int32 columns",
+            "ms": round(ms, 4), "gflops": round(2.0 * nnz / ms / 1e6, 1), "moved_bytes_per_launch": int(moved),
+            "moved_gbps": round(moved / ms / 1e6, 1), "frac_moved": round(moved / ms / 1e6 / HBM_PEAK_GBPS, 4),
+            "max_rel_diff_vs_the_f64_headline": err, "agrees_to_float32_accuracy": bool(err < 5e-6), "setup_s": round(ts, 1),
+            "what": "reported beside `value` (f64), never instead of it"}
+
+
 def general_csr_entries(pa, ctx, L, host_oo, xv, y_head, n_own, out):
     """The headline's own x own block WITHOUT row patterns (VERDICT r02 #1b): the same host CSR uploaded with
     PA_SPMV_PATTERN=0 (16-bit windowed column stream: 10 B per stored entry) and with PA_SPMV_PATTERN=0 PA_SPMV_COL16=0
@@ -1479,7 +1512,7 @@ def main():
                                               "bit (tests/test_gpu_blas1_cg.py); opt_cg_(fuse=True) = also u'c accumulated inside the product "
                                               "kernels and x's update fused into u's pass (iterates within 1e-9)"}
 
-    general = None
+    general, f32 = None, None
     if N == 1 and args.extra and rank == 0:
         general = []
         try:
@@ -1490,7 +1523,12 @@ def main():
                 host_oo = build_split_blocks_fused(pa.local_items(A.row_partition)[0], n, n, n, *gn)[1]
             pa.mul_(y, A, x)
             ctx.sync()
-            general_csr_entries(pa, ctx, L, host_oo, xv, pa.local_items(y.own_values())[0], n_own, general)
+            y_head = pa.local_items(y.own_values())[0]
+            general_csr_entries(pa, ctx, L, host_oo, xv, y_head, n_own, general)
+            try:
+                f32 = float32_entry(pa, ctx, L, host_oo, xv, y_head, n_own)
+            except Exception as e:                             # noqa: BLE001
+                print(f"[bench] Float32 entry skipped: {e}", file=sys.stderr)
             del host_oo
         except Exception as e:                                 # noqa: BLE001
             print(f"[bench] general-CSR entries stopped at {PHASE[0]!r}: {e}", file=sys.stderr)
@@ -1608,6 +1646,8 @@ def main():
             out["ms_per_step_library_defaults"] = vdict["avg_launch_ms"]
         if general:
             out["general_csr"] = general
+        if f32:
+            out["float32_mode"] = f32
         if transpose:
             out["transpose_product"] = transpose
         if extras:
