@@ -13,7 +13,7 @@ for d in sorted(glob.glob(os.path.join(src, "vd*_m*_s*"))):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         acc, cnt = collections.defaultdict(float), collections.defaultdict(int)
         for r in csv.DictReader(open(f)):
-            if "k_spmv_rowsplit" not in r["Kernel_Name"]:
+            if "k_spmv_rowsplit" not in r["Kernel_Name"] and "k_spmv_pell" not in r["Kernel_Name"]:      # (round 6: pattern blocks run on k_spmv_pell)
                 continue
             acc[r["Counter_Name"]] += float(r["Counter_Value"])
             cnt[r["Counter_Name"]] += 1
