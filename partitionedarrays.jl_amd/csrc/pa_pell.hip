@@ -233,7 +233,9 @@ pa_pell *pa_pell_structure(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col
 // without room for the second value stream, keeps the row-split kernel.
 int pa_pell_build(pa_csr *A) {
   if (A->pell || !pell_wanted() || pa_tls_plain_encoding || A->nnz == 0 || A->n_crows == 0 || A->next || A->n_xw_groups > 0) return PA_OK;
-  if (!A->use_pattern || A->n_pattern_chunks * 10 < A->n_chunks * 9) return PA_OK;      // (rows without patterns: not worth the look)
+  // (every block is looked at -- a decode and one pass over its entries: the row split's pattern detector wants whole rows to repeat, this
+  //  storage only a slab's UNION of offsets to stay within 32, e.g. rows that each drop a few entries of a stencil; blocks of scattered rows
+  //  fail at their first slab's 33rd offset)
   if (A->ctx->capturing) return PA_OK;
   pa_ctx *c = A->ctx;
   PA_HIP(hipSetDevice(c->device));

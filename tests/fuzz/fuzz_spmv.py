@@ -17,21 +17,42 @@ for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
     m = int(rng.integers(20_000, 400_000))
     n = m if rng.random() < 0.6 else int(m * rng.uniform(0.5, 1.6)) + 1
-    law = int(rng.integers(0, 6))
+    law = int(rng.integers(0, 8))
+    if law >= 6:
+        # round 6: rows that follow column PATTERNS (what pattern-ELL storage is for, csrc/pa_pell.h): a handful of offsets (with runs of
+        # three consecutive ones half of the time: the kernel's one-gather-per-run form), every row keeps a random subset of them -- the
+        # row masks --, offsets that leave the matrix are dropped as at a grid's faces, a few rows are empty
+        m = n = int(rng.integers(1, 40000))
+        if rng.random() < 0.5:
+            starts = np.unique(rng.integers(-min(n, 3000), min(n, 3000), int(rng.integers(1, 10))))
+            offs = np.unique(np.concatenate([starts, starts + 1, starts + 2]))
+        else:
+            offs = np.unique(rng.integers(-min(n, 3000), min(n, 3000), int(rng.integers(1, 28))))
+        keep = rng.random((m, len(offs))) < rng.choice([1.0, 0.97, 0.6])
+        keep[rng.random(m) < 0.01] = False
+        cols2 = np.arange(m)[:, None] + offs[None, :]
+        keep &= (cols2 >= 0) & (cols2 < n)
+        lens = keep.sum(1)
+        rows = np.repeat(np.arange(m), lens)
+        col = cols2[keep]
+        band = -1
+    elif False:
+        pass
     if law == 0: lens = np.full(m, int(rng.integers(1, 33)))
     elif law == 1: lens = rng.integers(0, int(rng.integers(2, 70)), m)
     elif law == 2: lens = np.where(rng.random(m) < 0.01, rng.integers(500, 4000, m), rng.integers(0, 10, m))
     elif law == 3: lens = np.minimum((rng.pareto(1.5, m) * 3).astype(np.int64), 3000)
     elif law == 4: lens = np.where(rng.random(m) < 0.5, 0, rng.integers(1, 20, m))
     else: lens = np.repeat(rng.integers(1, 40, (m + 63) // 64), 64)[:m]
-    band = int(rng.choice([8, 60, 400, 1500, 2300, 3500, 6000, 9000, 10**9]))
+    if law < 6: band = int(rng.choice([8, 60, 400, 1500, 2300, 3500, 6000, 9000, 10**9]))
     rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int64)
     if rp[-1] > 40_000_000:
         continue
-    rows = np.repeat(np.arange(m), lens)
-    centre = (rows * (n / m)).astype(np.int64)
-    if band >= 10**9: col = rng.integers(0, n, len(rows))
-    else: col = np.clip(centre + rng.integers(-band, band + 1, len(rows)), 0, n - 1)
+    if law < 6:
+        rows = np.repeat(np.arange(m), lens)
+        centre = (rows * (n / m)).astype(np.int64)
+        if band >= 10**9: col = rng.integers(0, n, len(rows))
+        else: col = np.clip(centre + rng.integers(-band, band + 1, len(rows)), 0, n - 1)
     order = np.lexsort((col, rows))
     val = rng.standard_normal(len(rows))
     if "--few-values" in sys.argv:                    # with PA_SPMV_VALUE_DICT=1: the lossless value dictionary (<= 64 values)
@@ -57,6 +78,9 @@ for case in range(n_cases):
         A = pa.DeviceCSR(H)
         xw, enc = A.xwin(), A.encoding()
         if sw is None:
+            pm = A.pell()
+            cover["pattern_ell_" + ("none", "fp64", "one_bit")[pm["mode"]]] = cover.get("pattern_ell_" + ("none", "fp64", "one_bit")[pm["mode"]], 0) + (law >= 6)
+            cover["pattern_ell_unroll_%d" % pm["unroll"]] = cover.get("pattern_ell_unroll_%d" % pm["unroll"], 0) + (pm["mode"] > 0)
             cover["default_windows"] += xw["groups"] > 0
             cover["default_big_windows"] += xw["big_groups"] > 0
             cover["default_ring"] = cover.get("default_ring", 0) + (xw.get("ring_groups", 0) > 0)
