@@ -497,7 +497,9 @@ def kernel_of(blk):
         return "k_spmv_rowsplit"
     if p["mode"] == 0:
         return "k_spmv_rowsplit (row split, LDS-staged products)"
-    return (f"k_spmv_pell (pattern-ELL, one lane per row; {p['slabs']} slabs of 64 rows, {p['patterns']} slab patterns, unroll {p['unroll']}; "
+    lean = p.get("lean_slabs_bits" if p["mode"] == 2 else "lean_slabs", 0)
+    return (f"k_spmv_pell (pattern-ELL, one lane per row; {p['slabs']} slabs of 64 rows, {p['patterns']} slab patterns in {p.get('classes', 0)} classes, "
+            f"lean form in {lean} slabs, unroll {p['unroll']}; "
             + ("fp64 value stream" if p["mode"] == 1 else "one bit per entry: a two-value dictionary") + ")")
 
 
@@ -844,9 +846,12 @@ def general_csr_entries(pa, ctx, L, host_oo, xv, y_head, n_own, out):
     PA_SPMV_PATTERN=0 (16-bit windowed column stream: 10 B per stored entry) and with PA_SPMV_PATTERN=0 PA_SPMV_COL16=0
     (Int32 columns: the 12 B per entry spmv_csr! of src/sparse_utils.jl:649-669 really reads) -- what a user matrix the
     pattern detector misses gets.  ms, GFLOP/s, moved GB/s, fraction of the 8 TB/s peak, bit-identical to the headline."""
-    for name, env in (("c16: PA_SPMV_PATTERN=0 (2-byte windowed column stream)", {"PA_SPMV_PATTERN": "0"}),
-                      ("c32: PA_SPMV_PATTERN=0 PA_SPMV_COL16=0 (Int32 columns, the reference's CSR bytes)",
-                       {"PA_SPMV_PATTERN": "0", "PA_SPMV_COL16": "0"})):
+    # (PA_SPMV_PELL=0 at creation: pattern-ELL storage is tried on EVERY block since round 6 -- a slab's union of offsets decides, not
+    #  the row split's pattern detector -- and would otherwise serve these two as well; they are here to time the row-split kernel
+    #  on explicit column streams)
+    for name, env in (("c16: PA_SPMV_PATTERN=0 PA_SPMV_PELL=0 (2-byte windowed column stream, row-split kernel)", {"PA_SPMV_PATTERN": "0", "PA_SPMV_PELL": "0"}),
+                      ("c32: PA_SPMV_PATTERN=0 PA_SPMV_COL16=0 PA_SPMV_PELL=0 (Int32 columns, the reference's CSR bytes, row-split kernel)",
+                       {"PA_SPMV_PATTERN": "0", "PA_SPMV_COL16": "0", "PA_SPMV_PELL": "0"})):
         PHASE[0] = "general CSR: " + name
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)

@@ -227,7 +227,7 @@ static int csr32_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, c
         pa_h2d(d_rp, rp.data(), sizeof(int32_t) * ((size_t)n_rows + 1)) == hipSuccess &&
         pa_h2d(d_col, col.data(), sizeof(int32_t) * (size_t)nnz) == hipSuccess && pa_h2d(d_v, val, sizeof(float) * (size_t)nnz) == hipSuccess) {
       const char *why = "";
-      A->pell = pa_pell_structure(c, d_rp, d_col, nullptr, n_rows, nnz, false, &why);
+      A->pell = pa_pell_structure(c, d_rp, d_col, nullptr, n_rows, n_cols, nnz, false, &why);
       if (A->pell) {
         const size_t n = (size_t)std::max<int64_t>(A->pell->slots, 1) * 64;
         if (pa_dev_alloc(c, (void **)&A->d_pval, sizeof(float) * n, PA_MEM_MATRIX) == PA_OK &&

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_mul_fused(
 // slabs (one lane per row, rows of the boundary bitmap left alone), the last blocks the boundary rows' block as before.  With the
 // one-bit value stream the row-split main blocks had become the slower half of the fused launch.
 void pa_pell_describe(const pa_csr *A, int mode, pa_pell_dev *D, int *U, bool *runs3, int64_t *n_slabs);
-template <int U, int VM, bool R3, bool XCH>
+template <int U, int VM, bool R3, bool XCH, bool A1>
 __global__ __launch_bounds__(256) void k_mul_fused_pell(const pa_pell_dev P, const double *__restrict__ x, double *__restrict__ y, int bpx,
                                                         double alpha, double beta, const pa_fused_args F) {
   constexpr int BLK = 256, NPT = PA_SPMV_CHUNK_NNZ / 256;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_mul_fused_pell(const pa_pell_dev P, con
   if (slab >= P.n_slabs) return;
   pa_fx fx;
   fx.rowmask = F.rowmask;
-  pa_pell_slab<U, VM, false, 0, 1, R3>(P, slab, x, y, alpha, beta, nullptr, nullptr, nullptr, fx);
+  pa_pell_slab<U, VM, false, 0, 1, R3, A1>(P, slab, x, y, alpha, beta, nullptr, nullptr, nullptr, fx);
 }
 
 // own(c) = beta*own(c) + alpha*(A_oo*own(b) + A_oh*ghost(b)) of one part in one launch on stream st.  comm == NULL: the receive
@@ -457,9 +457,16 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double
       PA_REQUIRE(n_push_blocks <= F.n_main_blocks, "more pushing blocks than own x own has slab groups");
       if (m->ctx->sw.spmv_alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) bpx = -bpx;
       if (pm == 2 && m->ctx->capturing) { const_cast<pa_csr *>(S)->vd_captured = true; const_cast<pa_csr *>(S)->vd_captured_two = true; }
-#define PA_LAUNCH_FP(UU, VM, R3, XCH)                                                                                                \
-  hipLaunchKernelGGL((k_mul_fused_pell<UU, VM, R3, XCH>), dim3(F.n_main_blocks + n_tail), dim3(256), 0, st, D, (const double *)b->d, c->d, bpx, \
-                     alpha, beta, F)
+      // (runs of three with alpha = 1 -- mul!(c,a,b) -- compiled in: the interior rows' lean form, pa_pell_slab_fast)
+#define PA_LAUNCH_FP(UU, VM, R3, XCH)                                                                                                       \
+  do {                                                                                                                                      \
+    if (R3 && alpha == 1.0)                                                                                                                 \
+      hipLaunchKernelGGL((k_mul_fused_pell<UU, VM, R3, XCH, R3>), dim3(F.n_main_blocks + n_tail), dim3(256), 0, st, D, (const double *)b->d, \
+                         c->d, bpx, alpha, beta, F);                                                                                        \
+    else                                                                                                                                    \
+      hipLaunchKernelGGL((k_mul_fused_pell<UU, VM, R3, XCH, false>), dim3(F.n_main_blocks + n_tail), dim3(256), 0, st, D,                    \
+                         (const double *)b->d, c->d, bpx, alpha, beta, F);                                                                  \
+  } while (0)
 #define PA_FP_CASES(XCH)                                                                              \
       if (U == 7) { if (pm == 2) PA_LAUNCH_FP(7, 1, false, XCH); else PA_LAUNCH_FP(7, 0, false, XCH); } \
       else if (r3) { if (pm == 2) PA_LAUNCH_FP(9, 1, true, XCH); else PA_LAUNCH_FP(9, 0, true, XCH); }   \

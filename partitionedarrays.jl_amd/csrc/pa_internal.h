@@ -55,6 +55,7 @@ struct pa_switches {
   int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
   int vd_select = 1;          // PA_SPMV_VDICT_SELECT: a dictionary of at most two values is decoded by a select, not through the lane dictionary
   int pell = 1;               // PA_SPMV_PELL: blocks that have pattern-ELL storage run on k_spmv_pell (0: the row-split kernel; also read at block creation)
+  int pell_lean = 1;          // PA_SPMV_PELL_LEAN: slabs of a class run the instruction-lean form (scalar base, lane ballots, scalar bits; pa_pell.h); 0: the masked form everywhere
   int test_skip_raise = 0;    // PA_TEST_FUSED_SKIP_RAISE=k (tests only): the k-th fused product over RCCL never gets its flag raised -> its tail times out
   int chain_fused = 1;        // PA_SPMV_CHAIN_FUSED: a column-split chain is built for, and run as, one launch (k_spmv_xring_chain)
 };

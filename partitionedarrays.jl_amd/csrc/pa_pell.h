@@ -29,12 +29,17 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "pa_internal.h"
 #include "pa_spmv_kernel.h"
 
 #define PA_PELL_MAXW 32                  /* deltas of a slab's union (bits of a row mask) */
-#define PA_PELL_TW 44                    /* ints per pattern in the table: the deltas, padded with 0 up to the padded width (<= 32 + 9 - 1) */
+#define PA_PELL_TW 44                    /* ints per pattern in the table: the deltas, padded with 0 up to the padded width (<= 36), then: */
+#define PA_PELL_T_STRIDE 40              /*   slab CLASSES only (see below): the rows of the slab are row0 + stride * lane (1 or 2; 0: not so) */
+#define PA_PELL_T_FLAGS 41               /*   bit 0: every lane has every delta of the padded width (no lane masks needed) */
+#define PA_PELL_T_MIN 42                 /*   lowest and highest delta of the union: a slab whose row0 + min >= 0 and */
+#define PA_PELL_T_MAX 43                 /*   row0 + 63 * stride + max < n_cols gathers without clamping */
 
 struct pa_pell_dev {
   const int2 *desc = nullptr;            // per slab {pattern | padded width << 20, first value slot / 64}
@@ -44,8 +49,14 @@ struct pa_pell_dev {
   const double *val = nullptr;           // VM 0: slab-major, delta-major, lane-minor
   const double *dict = nullptr;          // VM 1: the two values
   const int *row_ids = nullptr;          // row-compacted block: stored row -> row
+  // slab classes (round 6, second step): table rows are then not just the union of deltas but (union, which LANES have each delta,
+  // stride of the row ids), so that what was a 32-bit mask per row becomes a 64-bit lane ballot per delta and CLASS, read as scalars
+  const unsigned long long *plane = nullptr;   // n_classes x PA_PELL_TW: bit l of [k] = lane l of such a slab has delta k; NULL: no classes
+  const uint2 *sbits = nullptr;          // VM 1, per slab: {the rows' bits OR-ed, 1 when every row's bits are that word under its mask}
   int n_slabs = 0, n_crows = 0, n_cols = 0;
 };
+
+typedef double pa_d2u __attribute__((ext_vector_type(2), aligned(8)));      // two consecutive doubles at any 8-byte boundary
 
 // value slot of delta k of a slab whose first slot is `first` (in 64-entry units), lane `lane`: inside every group of U deltas the
 // lanes hold PAIRS of consecutive deltas next to each other (one 16-byte load per lane and pair, 1 KiB per wavefront) and, U odd,
@@ -65,6 +76,110 @@ __device__ __forceinline__ double pa_wave_shl1(double v, double e) {
   return __hiloint2double(hi, lo);
 }
 
+
+// The slab of a CLASS with runs of three, alpha = 1, nothing to add to (beta = 0 or an epilogue form), gathers in range: the
+// instruction-lean form of the slab below (notebook R6.5; the one-bit stream was bound by the vector ALU at ~17 instructions per entry).
+//   * rows row0 + S * lane: the gather of a run's first delta is ONE scalar base + lane offset (no per-lane address arithmetic, no clamps);
+//     S = 1: 8-byte gather + two wave shifts (as R3 below); S = 2 (the colour and restriction blocks of the multigrid: every other row of a
+//     grid line): ONE 16-byte gather gives columns d and d + 1, column d + 2 is the next lane's first -- one wave shift;
+//   * which lanes have delta k is a 64-bit ballot of the class, a scalar pair: x of an absent entry is replaced by 0.0 with two
+//     v_cndmask on that pair and the product added unconditionally.  Same bits as adding only the present products: the sum starts at
+//     +0.0 and can never become -0.0 (x + (-x) and (+0) + (-0) are +0 in round-to-nearest), so adding a product of +-0.0 changes nothing;
+//     the value of an absent entry is finite (a stored 0.0, or one of the two dictionary values, checked finite by the caller) and its x
+//     is selected away BEFORE the multiply, so an Inf / NaN elsewhere in x stays where the reference has it;  FULL: no selects at all;
+//   * VM 1: the bits of a slab whose rows all carry the same word are ONE scalar (P.sbits): the value of delta k is a scalar select.
+template <int VM, int S, int EPI, int FX, bool FULL>
+__device__ __forceinline__ void pa_pell_slab_fast(const pa_pell_dev P, int slab, int pat, int Wp, unsigned first, int row0, unsigned sb,
+                                                  const double *x, double *__restrict__ y, double *gs_x, const double *__restrict__ gs_b,
+                                                  const double *__restrict__ gs_diag, const pa_fx fx) {
+  const int lane = threadIdx.x & 63;
+  const int r = slab * 64 + lane;
+  const bool live = r < P.n_crows;
+  const int row = row0 + S * lane;
+  bool mine = live;
+  if (FX == 1) {
+    const int rw = live ? row : 0;
+    if ((fx.rowmask[rw >> 5] >> (rw & 31)) & 1u) mine = false;
+  }
+  const int *dl = P.pdelta + (size_t)pat * PA_PELL_TW;
+  const unsigned long long *pl = P.plane + (size_t)pat * PA_PELL_TW;
+  const double *xs = x + row0;
+  const unsigned lane_off = (unsigned)lane * (8u * S);   // (scalar base + this 32-bit offset: the gather's whole address arithmetic)
+  const double *vp = P.val + (size_t)first * 64;
+  double d0 = 0.0, d1 = 0.0;
+  if (VM == 1) { d0 = P.dict[0]; d1 = P.dict[1]; }
+  double acc = 0.0;
+  // NR runs of three from delta k0 on: every gather and every scalar load of the block is requested before the first product -- a
+  // wavefront's life is then ONE round trip of gathers per block (notebook R6.5: with the vector ALU out of the way the one-bit
+  // stream was bound by three dependent round trips per row)
+  auto block = [&](auto nr_tag, int k0) {
+    constexpr int NR = decltype(nr_tag)::value;
+    double v[3 * NR], x0[NR], x1[NR], ee[NR], e2[NR];
+    if (VM == 0) {
+      const double *g = vp + (size_t)k0 * 64;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const d2 pr = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(g + (size_t)(j >> 1) * 128) + lane);
+        v[j] = pr.x; v[j + 1] = pr.y;
+      }
+      v[8] = __builtin_nontemporal_load(g + (size_t)8 * 64 + lane);
+    }
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      const double *xr = xs + dl[k0 + 3 * t];          // (scalar: the run's first column of lane 0)
+      if (S == 1) {
+        x0[t] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xr) + lane_off);
+        ee[t] = xr[64]; e2[t] = xr[65];
+      } else {
+        const pa_d2u pr = *reinterpret_cast<const pa_d2u *>(reinterpret_cast<const char *>(xr) + lane_off);
+        x0[t] = pr.x; x1[t] = pr.y;
+        ee[t] = xr[128];
+      }
+    }
+    if (VM == 1) {
+#pragma unroll
+      for (int j = 0; j < 3 * NR; ++j) v[j] = ((sb >> (k0 + j)) & 1u) ? d1 : d0;          // (scalar selects)
+    }
+#pragma unroll
+    for (int t = 0; t < NR; ++t) {
+      double a0 = x0[t], a1, a2;
+      if (S == 1) {
+        a1 = pa_wave_shl1(a0, ee[t]);
+        a2 = pa_wave_shl1(a1, e2[t]);
+      } else {
+        a1 = x1[t];
+        a2 = pa_wave_shl1(a0, ee[t]);
+      }
+      if (!FULL) {
+        if (!__builtin_amdgcn_inverse_ballot_w64(pl[k0 + 3 * t])) a0 = 0.0;
+        if (!__builtin_amdgcn_inverse_ballot_w64(pl[k0 + 3 * t + 1])) a1 = 0.0;
+        if (!__builtin_amdgcn_inverse_ballot_w64(pl[k0 + 3 * t + 2])) a2 = 0.0;
+      }
+      acc = acc + v[3 * t] * a0;
+      acc = acc + v[3 * t + 1] * a1;
+      acc = acc + v[3 * t + 2] * a2;
+    }
+  };
+  // (one-bit stream: the whole row as ONE block of nine runs measured slower, 0.155 against 0.146 ms at 256^3 -- 106 scalar registers,
+  //  7 waves per SIMD instead of 8, 10 KB of code)
+  for (int k0 = 0; k0 < Wp; k0 += 9) block(std::integral_constant<int, 3>(), k0);
+  if (EPI == 0) {
+    if (mine) __builtin_nontemporal_store(acc, &y[row]);
+  } else if (EPI == 1) {
+    if (mine) gs_x[row] = gs_x[row] + (gs_b[row] - acc) / gs_diag[row];
+  } else if (EPI == 2) {
+    if (mine) gs_x[r] = gs_b[row] - acc;
+  } else {
+    double dacc = 0.0;
+    if (mine) {
+      __builtin_nontemporal_store(acc, &y[row]);
+      dacc = gs_b[row] * acc;                        // (beta = 0: the product IS the row's new value)
+    }
+    dacc = pa_wave_sum(dacc);
+    if (lane == 0) gs_x[slab] = dacc;
+  }
+}
+
 // one slab.  EPI / FX as in pa_rowsplit_chunk (pa_spmv_kernel.h): EPI 0 product, 1 Gauss-Seidel colour update in place, 2 residual +
 // restriction, 3 product + this slab's term of a dot product (partial[slab]); FX 1: rows whose bit is set in fx.rowmask are left
 // alone (the fused launch's tail sums them).
@@ -77,12 +192,42 @@ template <int U, int VM, bool COMPACT, int EPI, int FX, bool R3, bool A1 = false
 __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, const double *__restrict__ x_in, double *__restrict__ y,
                                              double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
                                              const double *__restrict__ gs_diag, const pa_fx fx) {
-  static_assert(!R3 || (U % 9 == 0 && !COMPACT && EPI != 1), "runs of three: unroll 9 (27 on the one-bit stream), consecutive rows, x not written by the launch");
+  static_assert(!R3 || U % 9 == 0, "runs of three: unroll 9 (27 on the one-bit stream)");
+  // (the clamped runs-of-three form below: consecutive rows, x not written by the launch; a row-compacted block or the Gauss-Seidel
+  //  update take runs of three only in the slabs pa_pell_slab_fast serves)
+  constexpr bool R3G = R3 && !COMPACT && EPI != 1;
   const double *x = EPI == 1 ? gs_x : x_in;          // EPI 1 reads and writes the same vector: no restrict promise on it
   const int lane = threadIdx.x & 63;
   const int2 d = P.desc[slab];                       // (slab is wave-uniform: scalar loads)
   const int pat = d.x & 0xfffff, Wp = d.x >> 20;
   const int *dl = P.pdelta + (size_t)pat * PA_PELL_TW;
+  if constexpr (R3 && A1) {
+    // a slab of a class (P.plane), nothing to add to, every gather of every lane in range: the lean form (all of this is scalar)
+    if (P.plane != nullptr && (EPI == 1 || EPI == 2 || beta == 0.0)) {
+      const int st = dl[PA_PELL_T_STRIDE];
+      const int row0 = COMPACT ? P.row_ids[slab * 64] : slab * 64;
+      bool go = st != 0 && row0 + dl[PA_PELL_T_MIN] >= 0 && row0 + 63 * st + dl[PA_PELL_T_MAX] < P.n_cols;
+      unsigned sb = 0;
+      if (VM == 1 && go) {
+        const uint2 q = P.sbits[slab];
+        sb = q.x;
+        go = q.y != 0;
+      }
+      if (go) {
+        const bool full = (dl[PA_PELL_T_FLAGS] & 1) != 0;
+        if (COMPACT && st == 2) {
+          if (full) pa_pell_slab_fast<VM, 2, EPI, FX, true>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          else pa_pell_slab_fast<VM, 2, EPI, FX, false>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          return;
+        }
+        if (st == 1) {
+          if (full) pa_pell_slab_fast<VM, 1, EPI, FX, true>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          else pa_pell_slab_fast<VM, 1, EPI, FX, false>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          return;
+        }
+      }
+    }
+  }
   const int r = slab * 64 + lane;
   const bool live = r < P.n_crows;
   const int rc = live ? r : P.n_crows - 1;
@@ -116,7 +261,7 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) on[j] = (m >> (k0 + j)) & 1ull;
-    if (R3) {
+    if (R3G) {
 #pragma unroll
       for (int t = 0; t < U / 3; ++t) {
         const int dk = dl[k0 + 3 * t];               // the run's first delta (scalar)
@@ -166,18 +311,22 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
 struct pa_pell {
   int U = 9;
   int64_t n_slabs = 0, n_patterns = 0, slots = 0;      // slots: 64-entry units of the value stream
+  int64_t n_table = 0, n_classes = 0;                  // rows of the table (classes when there are any, else patterns)
+  int64_t n_lean = 0, n_lean_bits = 0;                 // slabs the lean form serves on the fp64 stream / on the one-bit stream (set-up counts)
   int max_w = 0;
   bool runs3 = false;                                  // every pattern is made of runs of three consecutive deltas (and U = 9)
   int2 *d_desc = nullptr;
   int *d_pdelta = nullptr;
   unsigned *d_mask = nullptr, *d_bits = nullptr;
+  unsigned long long *d_plane = nullptr;               // classes: lane ballots, n_table x PA_PELL_TW
+  uint2 *d_sbits = nullptr;                            // one-bit stream: per slab {bits, uniform}, and behind them the count of uniform lean slabs
   double *d_val = nullptr;
   uint64_t bits_epoch = ~(uint64_t)0;                  // A->val_epoch the bits were made at
   uint64_t n_launched = 0;
 };
 
-pa_pell *pa_pell_structure(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int32_t *d_row_ids, int64_t n_crows, int64_t nnz,
-                           bool compact, const char **why);
+pa_pell *pa_pell_structure(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col, const int32_t *d_row_ids, int64_t n_crows, int64_t n_cols,
+                           int64_t nnz, bool compact, const char **why);
 void pa_pell_struct_free(pa_ctx *c, pa_pell *P);
 
 // blockIdx -> slabs: four slabs per workgroup (one per wavefront), consecutive workgroups of an XCD take consecutive slabs (block b

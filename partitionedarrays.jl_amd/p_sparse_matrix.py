@@ -143,7 +143,10 @@ class DeviceCSR:
         mode, unroll = C.c_int(), C.c_int()
         v = [C.c_int64() for _ in range(3)]
         L.call("pa_csr_pell_info", self.h, C.byref(mode), *[C.byref(x) for x in v], C.byref(unroll))
-        return dict(mode=mode.value, slabs=v[0].value, patterns=v[1].value, value_slots=v[2].value, unroll=unroll.value)
+        w = [C.c_int64() for _ in range(3)]
+        L.call("pa_csr_pell_lean_info", self.h, *[C.byref(x) for x in w])
+        return dict(mode=mode.value, slabs=v[0].value, patterns=v[1].value, value_slots=v[2].value, unroll=unroll.value,
+                    classes=w[0].value, lean_slabs=w[1].value, lean_slabs_bits=w[2].value)
 
     def xwin(self):
         """x-window launch of banded rows without a pattern (pa_csr_xwin_info): groups, chunks in groups, staged x entries."""

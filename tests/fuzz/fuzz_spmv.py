@@ -36,14 +36,12 @@ for case in range(n_cases):
         rows = np.repeat(np.arange(m), lens)
         col = cols2[keep]
         band = -1
-    elif False:
-        pass
-    if law == 0: lens = np.full(m, int(rng.integers(1, 33)))
+    elif law == 0: lens = np.full(m, int(rng.integers(1, 33)))
     elif law == 1: lens = rng.integers(0, int(rng.integers(2, 70)), m)
     elif law == 2: lens = np.where(rng.random(m) < 0.01, rng.integers(500, 4000, m), rng.integers(0, 10, m))
     elif law == 3: lens = np.minimum((rng.pareto(1.5, m) * 3).astype(np.int64), 3000)
     elif law == 4: lens = np.where(rng.random(m) < 0.5, 0, rng.integers(1, 20, m))
-    else: lens = np.repeat(rng.integers(1, 40, (m + 63) // 64), 64)[:m]
+    elif law == 5: lens = np.repeat(rng.integers(1, 40, (m + 63) // 64), 64)[:m]
     if law < 6: band = int(rng.choice([8, 60, 400, 1500, 2300, 3500, 6000, 9000, 10**9]))
     rp = np.concatenate([[1], 1 + np.cumsum(lens)]).astype(np.int64)
     if rp[-1] > 40_000_000:

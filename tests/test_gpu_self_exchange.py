@@ -178,7 +178,13 @@ def test_fifty_products_of_a_part_that_is_its_own_neighbour(n):
         ctx.sync()
         return e0.elapsed_ms(e1) / reps
 
+    # (the driver's budget: at 256^3 every product uploads 134 MB of x, and the opt-in path's time-outs cost 2 s each -- 20 products
+    #  per path there and the opt-in path at 128^3 only, unless PA_TEST_EXTENDED=1, tools/verify_on_gpu.sh)
+    short = n >= 256 and os.environ.get("PA_TEST_EXTENDED", "0") != "1"
+    n_products = 20 if short else 50
     for link, fused in (("rccl", "0"), ("rccl", "1"), ("ipc", "1"), ("ipc", "0")):
+        if short and link == "rccl" and fused == "1":
+            continue
         if link == "ipc" and fused == "1":
             P.connect_ipc_to_itself()
         cm = comm if link == "rccl" else None
@@ -189,7 +195,7 @@ def test_fifty_products_of_a_part_that_is_its_own_neighbour(n):
             inside0 = ctx.fused_launches()[1]
             timeouts = 0
             x = x0.copy()
-            for rep in range(50):
+            for rep in range(n_products):
                 x[rep::50] += 1.0
                 P.b.upload(np.concatenate([x, np.full(P.n_ghost, 99.0)]))
                 L.call("pa_mul5", P.m, cm, P.c.h, P.b.h, 1.0, 0.0)
@@ -201,11 +207,11 @@ def test_fifty_products_of_a_part_that_is_its_own_neighbour(n):
                     timeouts += 1
                     lost = True
                     ctx.sync()                                       # (said once)
-                if not lost and rep in (0, 17, 34, 49):
+                if not lost and rep in (0, 17, 34, n_products - 1):
                     assert np.array_equal(P.c.download(), P.expected_integer(x)), (key, rep)
                     assert np.array_equal(P.b.download()[P.n_own:], x[P.wrap]), (key, rep)
             if not opt_in:
-                assert ctx.fused_launches()[1] - inside0 == (50 if fused == "1" else 0), key
+                assert ctx.fused_launches()[1] - inside0 == (n_products if fused == "1" else 0), key
             # what the product costs beside own x own alone: 40 products queued back to back, the last 30 between two events
             t_oo = spmv_ms()
             for _ in range(10):
@@ -224,7 +230,7 @@ def test_fifty_products_of_a_part_that_is_its_own_neighbour(n):
             t_mul = e0.elapsed_ms(e1) / 30
             assert np.array_equal(P.c.download(), P.expected_integer(x)), (key, "timed")
             out[key] = {"own_own_ms": round(t_oo, 4), "mul_ms": round(t_mul, 4), "mul_over_spmv": round(t_mul / t_oo, 4),
-                        "time_outs_in_90_products": timeouts}
+                        "time_outs_in_%d_products" % (n_products + 40): timeouts}
             if not opt_in:
                 assert timeouts == 0 and t_mul / t_oo <= 2.5, (key, out[key])
     reload_switches()
