@@ -131,11 +131,11 @@ int pa_csr_pell_info(const pa_csr *A, int *mode, int64_t *n_slabs, int64_t *n_pa
  * the same LANES and whose row ids have the same stride (1: consecutive rows; 2: every other row of a grid line -- a colour of the
  * smoother, the rows a restriction keeps) form a class; a structured grid has a few dozen.  For a slab of a class whose gathers all lie
  * inside x, a product with alpha = 1 and nothing to add to reads no row masks: which lanes have an offset is a 64-bit ballot of the
- * class (scalar), a run of three consecutive offsets is one gather from a scalar base (stride 2: one 16-byte gather) plus wave shifts,
- * and on the one-bit stream the slab's bits are one scalar when all its rows carry the same word.  Same bits as the masked form
+ * class (scalar), every gather starts from a scalar base (a run of three consecutive offsets is ONE gather plus wave shifts; stride 2:
+ * one 16-byte gather and one shift), and on the one-bit stream the slab's bits are one scalar when all its rows carry the same word.  Same bits as the masked form
  * (PA_SPMV_PELL_LEAN=0) and as spmv_csr! src/sparse_utils.jl:649-669.  *n_classes: 0 when the block keeps plain patterns (more than
  * 4096 classes, PA_SPMV_PELL_CLASSES=0); *n_lean / *n_lean_bits: slabs the lean form serves on the fp64 stream / on the one-bit
- * stream (0 without runs of three).  Any output may be NULL. */
+ * stream.  Any output may be NULL. */
 int pa_csr_pell_lean_info(const pa_csr *A, int64_t *n_classes, int64_t *n_lean, int64_t *n_lean_bits);
 
 /* ---- Float32 blocks and vectors (csrc/pa_f32.hip; round 6: the first widening beyond the FP64 scope of the path) -----------

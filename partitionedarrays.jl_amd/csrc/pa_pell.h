@@ -52,6 +52,7 @@ struct pa_pell_dev {
   // slab classes (round 6, second step): table rows are then not just the union of deltas but (union, which LANES have each delta,
   // stride of the row ids), so that what was a 32-bit mask per row becomes a 64-bit lane ballot per delta and CLASS, read as scalars
   const unsigned long long *plane = nullptr;   // n_classes x PA_PELL_TW: bit l of [k] = lane l of such a slab has delta k; NULL: no classes
+  const unsigned *prel = nullptr;        // classes: (delta - lowest delta of the class) * 8, n_classes x PA_PELL_TW (the lean form's byte offsets)
   const uint2 *sbits = nullptr;          // VM 1, per slab: {the rows' bits OR-ed, 1 when every row's bits are that word under its mask}
   int n_slabs = 0, n_crows = 0, n_cols = 0;
 };
@@ -76,6 +77,15 @@ __device__ __forceinline__ double pa_wave_shl1(double v, double e) {
   return __hiloint2double(hi, lo);
 }
 
+// bit `bit` of the (scalar) word sb set ? d1 : d0 -- two scalar instructions (the compiler makes three: a 64-bit select as two halves)
+__device__ __forceinline__ double pa_uniform(double v) {        // (a wave-uniform value the compiler may hold in vector registers -> scalar)
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ double pa_sel_bit_at(unsigned sb, int bit, double d0, double d1) {      // (bit: a constant after unrolling)
+  double r;
+  asm("s_bitcmp1_b32 %3, %4\n\ts_cselect_b64 %0, %1, %2" : "=s"(r) : "s"(d1), "s"(d0), "s"(sb), "n"(bit) : "scc");
+  return r;
+}
 
 // The slab of a CLASS with runs of three, alpha = 1, nothing to add to (beta = 0 or an epilogue form), gathers in range: the
 // instruction-lean form of the slab below (notebook R6.5; the one-bit stream was bound by the vector ALU at ~17 instructions per entry).
@@ -88,10 +98,11 @@ __device__ __forceinline__ double pa_wave_shl1(double v, double e) {
 //     the value of an absent entry is finite (a stored 0.0, or one of the two dictionary values, checked finite by the caller) and its x
 //     is selected away BEFORE the multiply, so an Inf / NaN elsewhere in x stays where the reference has it;  FULL: no selects at all;
 //   * VM 1: the bits of a slab whose rows all carry the same word are ONE scalar (P.sbits): the value of delta k is a scalar select.
-template <int VM, int S, int EPI, int FX, bool FULL>
+template <int U, int VM, int S, int EPI, int FX, bool FULL, bool R3>
 __device__ __forceinline__ void pa_pell_slab_fast(const pa_pell_dev P, int slab, int pat, int Wp, unsigned first, int row0, unsigned sb,
                                                   const double *x, double *__restrict__ y, double *gs_x, const double *__restrict__ gs_b,
                                                   const double *__restrict__ gs_diag, const pa_fx fx) {
+  static_assert(!R3 || U == 9, "runs of three: groups of nine");
   const int lane = threadIdx.x & 63;
   const int r = slab * 64 + lane;
   const bool live = r < P.n_crows;
@@ -103,66 +114,86 @@ __device__ __forceinline__ void pa_pell_slab_fast(const pa_pell_dev P, int slab,
   }
   const int *dl = P.pdelta + (size_t)pat * PA_PELL_TW;
   const unsigned long long *pl = P.plane + (size_t)pat * PA_PELL_TW;
-  const double *xs = x + row0;
-  const unsigned lane_off = (unsigned)lane * (8u * S);   // (scalar base + this 32-bit offset: the gather's whole address arithmetic)
+  const unsigned *rel = P.prel + (size_t)pat * PA_PELL_TW;
+  // every gather is [scalar base xm = column of lane 0 at the class's lowest delta] + [32-bit offset: lane * 8 S + rel[k]]: one 32-bit
+  // vector add per gather, one scalar add per run for the elements past the wavefront's end (the scalar pipe, one per CU, had become
+  // the busy unit of the one-bit stream: 254 scalar instructions per wavefront, notebook R6.5)
+  const char *xm = reinterpret_cast<const char *>(x + row0 + dl[PA_PELL_T_MIN]);
+  const unsigned lane_off = (unsigned)lane * (8u * S);
   const double *vp = P.val + (size_t)first * 64;
   double d0 = 0.0, d1 = 0.0;
-  if (VM == 1) { d0 = P.dict[0]; d1 = P.dict[1]; }
+  if (VM == 1) { d0 = pa_uniform(P.dict[0]); d1 = pa_uniform(P.dict[1]); sb = __builtin_amdgcn_readfirstlane(sb); }
   double acc = 0.0;
-  // NR runs of three from delta k0 on: every gather and every scalar load of the block is requested before the first product -- a
-  // wavefront's life is then ONE round trip of gathers per block (notebook R6.5: with the vector ALU out of the way the one-bit
-  // stream was bound by three dependent round trips per row)
-  auto block = [&](auto nr_tag, int k0) {
-    constexpr int NR = decltype(nr_tag)::value;
-    double v[3 * NR], x0[NR], x1[NR], ee[NR], e2[NR];
+  constexpr int UE = U & ~1;
+  // a group of U deltas from k0 on (kb: k0 when it is known at compile time, else -1): every gather and scalar load of the group is
+  // requested before its first product.  (One-bit stream: the whole row as ONE group of 27 measured slower, 0.155 against 0.146 ms at
+  // 256^3 -- 106 scalar registers, 7 waves per SIMD instead of 8.)
+  auto group = [&](auto kb_tag, int k0) {
+    constexpr int KB = decltype(kb_tag)::value;
+    double v[U], a[U];
     if (VM == 0) {
       const double *g = vp + (size_t)k0 * 64;
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {
+      for (int j = 0; j < UE; j += 2) {
         const d2 pr = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(g + (size_t)(j >> 1) * 128) + lane);
         v[j] = pr.x; v[j + 1] = pr.y;
       }
-      v[8] = __builtin_nontemporal_load(g + (size_t)8 * 64 + lane);
+      if (U & 1) v[U - 1] = __builtin_nontemporal_load(g + (size_t)UE * 64 + lane);
     }
+    if constexpr (R3) {
+      double ee[3], e2[3];
 #pragma unroll
-    for (int t = 0; t < NR; ++t) {
-      const double *xr = xs + dl[k0 + 3 * t];          // (scalar: the run's first column of lane 0)
-      if (S == 1) {
-        x0[t] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xr) + lane_off);
-        ee[t] = xr[64]; e2[t] = xr[65];
-      } else {
-        const pa_d2u pr = *reinterpret_cast<const pa_d2u *>(reinterpret_cast<const char *>(xr) + lane_off);
-        x0[t] = pr.x; x1[t] = pr.y;
-        ee[t] = xr[128];
+      for (int t = 0; t < 3; ++t) {
+        const unsigned ro = rel[k0 + 3 * t];             // (scalar: the run's first column of lane 0, relative to xm)
+        if (S == 1) {
+          a[3 * t] = *reinterpret_cast<const double *>(xm + (lane_off + ro));
+          const double *xe = reinterpret_cast<const double *>(xm + (ro + 512u));
+          ee[t] = xe[0]; e2[t] = xe[1];
+        } else {
+          const pa_d2u pr = *reinterpret_cast<const pa_d2u *>(xm + (lane_off + ro));
+          a[3 * t] = pr.x; a[3 * t + 1] = pr.y;
+          ee[t] = *reinterpret_cast<const double *>(xm + (ro + 1024u));
+        }
       }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (S == 1) {
+          a[3 * t + 1] = pa_wave_shl1(a[3 * t], ee[t]);
+          a[3 * t + 2] = pa_wave_shl1(a[3 * t + 1], e2[t]);
+        } else {
+          a[3 * t + 2] = pa_wave_shl1(a[3 * t], ee[t]);
+        }
+      }
+    } else {
+      // no runs: one gather per delta (the 7-point operator, the smoother's lower-colour blocks, ...)
+#pragma unroll
+      for (int j = 0; j < U; ++j) a[j] = *reinterpret_cast<const double *>(xm + (lane_off + rel[k0 + j]));
     }
     if (VM == 1) {
+      if constexpr (KB >= 0) {
 #pragma unroll
-      for (int j = 0; j < 3 * NR; ++j) v[j] = ((sb >> (k0 + j)) & 1u) ? d1 : d0;          // (scalar selects)
+        for (int j = 0; j < U; ++j) v[j] = pa_sel_bit_at(sb, KB + j, d0, d1);
+      } else {
+        const unsigned sk = sb >> k0;
+#pragma unroll
+        for (int j = 0; j < U; ++j) v[j] = pa_sel_bit_at(sk, j, d0, d1);
+      }
     }
 #pragma unroll
-    for (int t = 0; t < NR; ++t) {
-      double a0 = x0[t], a1, a2;
-      if (S == 1) {
-        a1 = pa_wave_shl1(a0, ee[t]);
-        a2 = pa_wave_shl1(a1, e2[t]);
-      } else {
-        a1 = x1[t];
-        a2 = pa_wave_shl1(a0, ee[t]);
-      }
+    for (int j = 0; j < U; ++j) {
       if (!FULL) {
-        if (!__builtin_amdgcn_inverse_ballot_w64(pl[k0 + 3 * t])) a0 = 0.0;
-        if (!__builtin_amdgcn_inverse_ballot_w64(pl[k0 + 3 * t + 1])) a1 = 0.0;
-        if (!__builtin_amdgcn_inverse_ballot_w64(pl[k0 + 3 * t + 2])) a2 = 0.0;
+        if (!__builtin_amdgcn_inverse_ballot_w64(pl[k0 + j])) a[j] = 0.0;
       }
-      acc = acc + v[3 * t] * a0;
-      acc = acc + v[3 * t + 1] * a1;
-      acc = acc + v[3 * t + 2] * a2;
+      acc = acc + v[j] * a[j];
     }
   };
-  // (one-bit stream: the whole row as ONE block of nine runs measured slower, 0.155 against 0.146 ms at 256^3 -- 106 scalar registers,
-  //  7 waves per SIMD instead of 8, 10 KB of code)
-  for (int k0 = 0; k0 < Wp; k0 += 9) block(std::integral_constant<int, 3>(), k0);
+  if (R3 && Wp == 27) {                                 // (the 27-point row: three groups without the loop around them)
+    group(std::integral_constant<int, 0>(), 0);
+    group(std::integral_constant<int, 9>(), 9);
+    group(std::integral_constant<int, 18>(), 18);
+  } else {
+    for (int k0 = 0; k0 < Wp; k0 += U) group(std::integral_constant<int, -1>(), k0);
+  }
   if (EPI == 0) {
     if (mine) __builtin_nontemporal_store(acc, &y[row]);
   } else if (EPI == 1) {
@@ -201,7 +232,7 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
   const int2 d = P.desc[slab];                       // (slab is wave-uniform: scalar loads)
   const int pat = d.x & 0xfffff, Wp = d.x >> 20;
   const int *dl = P.pdelta + (size_t)pat * PA_PELL_TW;
-  if constexpr (R3 && A1) {
+  if constexpr (A1) {
     // a slab of a class (P.plane), nothing to add to, every gather of every lane in range: the lean form (all of this is scalar)
     if (P.plane != nullptr && (EPI == 1 || EPI == 2 || beta == 0.0)) {
       const int st = dl[PA_PELL_T_STRIDE];
@@ -215,14 +246,15 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
       }
       if (go) {
         const bool full = (dl[PA_PELL_T_FLAGS] & 1) != 0;
+        constexpr int UF = R3 ? 9 : U;
         if (COMPACT && st == 2) {
-          if (full) pa_pell_slab_fast<VM, 2, EPI, FX, true>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
-          else pa_pell_slab_fast<VM, 2, EPI, FX, false>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          if (full) pa_pell_slab_fast<UF, VM, 2, EPI, FX, true, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          else pa_pell_slab_fast<UF, VM, 2, EPI, FX, false, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
           return;
         }
         if (st == 1) {
-          if (full) pa_pell_slab_fast<VM, 1, EPI, FX, true>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
-          else pa_pell_slab_fast<VM, 1, EPI, FX, false>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          if (full) pa_pell_slab_fast<UF, VM, 1, EPI, FX, true, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          else pa_pell_slab_fast<UF, VM, 1, EPI, FX, false, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
           return;
         }
       }
@@ -319,6 +351,7 @@ struct pa_pell {
   int *d_pdelta = nullptr;
   unsigned *d_mask = nullptr, *d_bits = nullptr;
   unsigned long long *d_plane = nullptr;               // classes: lane ballots, n_table x PA_PELL_TW
+  unsigned *d_prel = nullptr;                          // classes: byte offsets relative to the lowest delta, n_table x PA_PELL_TW
   uint2 *d_sbits = nullptr;                            // one-bit stream: per slab {bits, uniform}, and behind them the count of uniform lean slabs
   double *d_val = nullptr;
   uint64_t bits_epoch = ~(uint64_t)0;                  // A->val_epoch the bits were made at

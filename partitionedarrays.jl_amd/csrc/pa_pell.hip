@@ -207,7 +207,7 @@ static int pell_fill(pa_csr *A, bool bits) {
 static void pell_read_lean_bits(pa_csr *A) {
   pa_pell *P = A->pell;
   unsigned long long n = 0;
-  if (P->d_sbits && hipMemcpy(&n, P->d_sbits + P->n_slabs, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) P->n_lean_bits = P->runs3 ? (int64_t)n : 0;
+  if (P->d_sbits && hipMemcpy(&n, P->d_sbits + P->n_slabs, sizeof(n), hipMemcpyDeviceToHost) == hipSuccess) P->n_lean_bits = (int64_t)n;
   else (void)hipGetLastError();
 }
 
@@ -217,6 +217,7 @@ void pa_pell_struct_free(pa_ctx *c, pa_pell *P) {
   pa_dev_free(c, P->d_pdelta);
   pa_dev_free(c, P->d_mask);
   pa_dev_free(c, P->d_plane);
+  pa_dev_free(c, P->d_prel);
   pa_dev_free(c, P->d_sbits);
   if (P->d_bits) pa_dev_free(c, P->d_bits);
   if (P->d_val) pa_dev_free(c, P->d_val);
@@ -344,6 +345,7 @@ pa_pell *pa_pell_structure(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col
     if (pa_h2d(d_rep, hrep.data(), sizeof(long long) * hrep.size()) != hipSuccess) return give_up("upload failed");
     hipLaunchKernelGGL(kp_class_planes, dim3((unsigned)trep.size()), dim3(64), 0, s, P->d_mask, d_rep, d_len, (int)n_crows, P->d_plane);
     std::vector<unsigned long long> plane(table.size());
+    std::vector<unsigned> rel(table.size(), 0u);
     if (d2h(s, plane.data(), P->d_plane, plane.size())) return give_up("read-back failed");
     for (size_t i = 0; i < trep.size(); ++i) {
       const int L = len[(size_t)trep[i]];
@@ -354,7 +356,13 @@ pa_pell *pa_pell_structure(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col
       row[PA_PELL_T_FLAGS] = full ? 1 : 0;
       row[PA_PELL_T_MIN] = L > 0 ? row[0] : 0;
       row[PA_PELL_T_MAX] = L > 0 ? row[L - 1] : 0;
+      // the lean form's byte offsets from the column of lane 0 at the lowest delta (32 bits: a class whose span does not fit has no lean form)
+      if (((int64_t)row[PA_PELL_T_MAX] - row[PA_PELL_T_MIN] + 130) * 8 >= ((int64_t)1 << 32)) row[PA_PELL_T_STRIDE] = 0;
+      for (int k = 0; k < PA_PELL_T_STRIDE; ++k)
+        rel[i * PA_PELL_TW + k] = row[PA_PELL_T_STRIDE] ? (unsigned)(((int64_t)row[k] - row[PA_PELL_T_MIN]) * 8) : 0u;
     }
+    if (pa_dev_alloc(c, (void **)&P->d_prel, sizeof(unsigned) * rel.size(), PA_MEM_MATRIX)) return give_up("no room");
+    if (pa_h2d(P->d_prel, rel.data(), sizeof(unsigned) * rel.size()) != hipSuccess) return give_up("upload failed");
   }
   if (pa_h2d(P->d_pdelta, table.data(), sizeof(int) * table.size()) != hipSuccess || hipMemsetAsync(d_bad, 0, 3 * sizeof(int), s) != hipSuccess)
     return give_up("upload failed");
@@ -364,7 +372,7 @@ pa_pell *pa_pell_structure(pa_ctx *c, const int32_t *d_crp, const int32_t *d_col
                        P->d_plane, d_row_ids, (int)n_crows, (int)n_slabs, (int)n_cols, d_bad);
   int bad[3] = {1, 0, 0};
   if (d2h(s, bad, d_bad, 3) || bad[0]) return give_up("two different slab patterns share a hash");
-  P->n_lean = P->runs3 ? bad[1] : 0;
+  P->n_lean = bad[1];
   return P;
 }
 
@@ -463,7 +471,7 @@ static pa_pell_dev pell_dev(const pa_csr *A, int mode) {
   pa_pell_dev D;
   D.desc = P->d_desc; D.pdelta = P->d_pdelta; D.mask = P->d_mask; D.bits = P->d_bits; D.val = P->d_val; D.dict = A->d_dict;
   D.row_ids = A->d_row_ids; D.n_slabs = (int)P->n_slabs; D.n_crows = (int)A->n_crows; D.n_cols = (int)A->n_cols;
-  D.plane = A->ctx->sw.pell_lean ? P->d_plane : nullptr; D.sbits = P->d_sbits;
+  D.plane = A->ctx->sw.pell_lean ? P->d_plane : nullptr; D.prel = P->d_prel; D.sbits = P->d_sbits;
   (void)mode;
   return D;
 }
@@ -552,11 +560,11 @@ int64_t pa_pell_stream_bytes(const pa_csr *A, int mode) {
   const pa_pell *P = A->pell;
   // (the lean form reads neither the row masks nor, on the one-bit stream, the rows' bits: its slabs cost their descriptor, the
   //  class table and 8 bytes of slab bits)
-  const bool lean_on = A->ctx->sw.pell_lean && P->d_plane && P->runs3;
+  const bool lean_on = A->ctx->sw.pell_lean && P->d_plane;
   const int64_t lean = !lean_on ? 0 : mode == 2 ? P->n_lean_bits : P->n_lean;
   const int64_t rows_masked = std::max<int64_t>(0, A->n_crows - 64 * lean);
   int64_t t = 8 * P->n_slabs + 4 * P->n_table * PA_PELL_TW + 4 * rows_masked;
-  if (lean_on) t += 8 * P->n_table * PA_PELL_TW;
+  if (lean_on) t += 12 * P->n_table * PA_PELL_TW;
   t += mode == 2 ? 4 * rows_masked + 8 * P->n_slabs + 16 : 8 * 64 * P->slots;
   if (A->compact) t += 4 * rows_masked + (lean ? 4 * lean : 0);
   return t;
@@ -578,7 +586,7 @@ extern "C" int pa_csr_pell_info(const pa_csr *A, int *mode, int64_t *n_slabs, in
 extern "C" int pa_csr_pell_lean_info(const pa_csr *A, int64_t *n_classes, int64_t *n_lean, int64_t *n_lean_bits) {
   PA_REQUIRE(A != nullptr, "csr is NULL");
   const pa_pell *P = A->pell;
-  const bool on = P && P->d_plane && P->runs3 && A->ctx->sw.pell_lean;
+  const bool on = P && P->d_plane && A->ctx->sw.pell_lean;
   if (n_classes) *n_classes = P ? P->n_classes : 0;
   if (n_lean) *n_lean = on ? P->n_lean : 0;
   if (n_lean_bits) *n_lean_bits = on ? P->n_lean_bits : 0;
