@@ -159,6 +159,15 @@ int pa_csr32_create_from_csc(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_
 int pa_csr32_destroy(pa_csr32 *A);
 int pa_csr32_info(const pa_csr32 *A, int *on_pattern_ell, int64_t *n_slabs, int64_t *padded_entries);
 int pa_spmv32(const pa_csr32 *A, const pa_vec32 *x, int x_segment, pa_vec32 *y, int y_segment, float alpha, float beta);
+/* consistent! / assemble! of a PVector{Vector{Float32}} (src/p_vector.jl:747-755, 695-708; assemble_impl! :587-612 is generic in the
+ * element type, exchange! in the payload, src/primitives.jl:1020-1042).  The plan is the one of the Float64 path (pa_plan_create: the
+ * cache's index lists serve any element type); its buffers then hold floats at the same ELEMENT offsets (pa_plan_buffers: same
+ * pointers, lengths in values of 4 bytes).  Sequence: pa_exchange_pack32 -> a pack-then-transport transport -- pa_exchange_local (all
+ * parts in one process), pa_exchange_rccl (ncclFloat) or the caller's own copies between pa_plan_buffers -- -> pa_exchange_finish32
+ * (insert, or + in ascending p with every sum rounded to Float32, then every ghost zeroed).  The push / ipc / fused transports carry
+ * Float64 only.  Bit-identical to the reference's loops on Float32 (data movement; the assemble! sums in the reference's order). */
+int pa_exchange_pack32(pa_plan *plan, const pa_vec32 *v, int mode);
+int pa_exchange_finish32(pa_plan *plan, pa_vec32 *v, int mode);
 
 /* ---- Gauss-Seidel smoother and grid transfer of the HPCG multigrid preconditioner ----------- */
 /* gauss_seidel_sweep! / gauss_seidel_sweep_zero! (PartitionedSolvers/src/smoothers.jl:144-160,236-259) on the

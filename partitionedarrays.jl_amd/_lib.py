@@ -190,6 +190,8 @@ _SIGS = {
     "pa_csr32_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64)],
     "pa_spmv32": [P, P, cint, P, cint, C.c_float, C.c_float],
     "pa_csr_pell_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(cint)],
+    "pa_exchange_pack32": [P, P, cint],
+    "pa_exchange_finish32": [P, P, cint],
     "pa_csr_pell_lean_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
     "pa_plan_create": [P, i32, i64, i32, P, P, P, i32, P, P, P, cint, PP],
     "pa_plan_destroy": [P],

@@ -18,12 +18,6 @@
 
 using namespace pa_util;
 
-struct pa_vec32 {
-  pa_ctx *ctx = nullptr;
-  float *d = nullptr;
-  int64_t n_own = 0, n_ghost = 0;
-};
-
 struct pa_csr32 {
   pa_ctx *ctx = nullptr;
   int64_t n_rows = 0, n_cols = 0, nnz = 0;

@@ -217,6 +217,13 @@ int64_t pa_pell_stream_bytes(const pa_csr *A, int mode);
 struct pa_push_table;   // device tables of the push transport for a group of plans in one process (pa_push.hip)
 struct pa_ipc_link;     // the neighbours' receive buffers and flags mapped over hipIpc, one part per process (pa_push.hip)
 
+// local values of a PVector{Vector{Float32}}, [own | ghost] (csrc/pa_f32.hip)
+struct pa_vec32 {
+  pa_ctx *ctx = nullptr;
+  float *d = nullptr;
+  int64_t n_own = 0, n_ghost = 0;
+};
+
 struct pa_plan {
   struct side {
     std::vector<int32_t> nbr;   // 0-based part ids
@@ -235,6 +242,7 @@ struct pa_plan {
   int32_t *d_tgt = nullptr, *d_tptr = nullptr, *d_tp = nullptr;
   hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
   int phase = 0;     // 0 idle, 1 packed, 2 arrived
+  int elem = 8;      // bytes per value of the payload in the buffers: 8, or 4 between pa_exchange_pack32 and pa_exchange_finish32
   bool own_comm_stream = false;   // this exchange's transport ran on this part's comm stream alone (RCCL: one part per process)
   int mode = 0;
   hipEvent_t ev_wait = nullptr;   // what wait(t) waits for: ev_arrived, or the event a group launch recorded once for all its parts

@@ -133,6 +133,7 @@ extern "C" int pa_exchange_pack(pa_plan *p, const pa_vec *v, int mode) {
   PA_REQUIRE(p->phase == 0, "exchange already in flight on this plan (missing pa_exchange_finish)");
   pa_ctx *c = p->ctx;
   p->ev_wait = nullptr;
+  p->elem = 8;
   if (p->snd.n == 0 && p->rcv.n == 0) {  // a part without neighbours (e.g. the only part): nothing to move, no stream traffic
     p->phase = 1;
     p->mode = mode;
@@ -175,14 +176,110 @@ extern "C" int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mod
       const int64_t len = in.ptrs[i + 1] - in.ptrs[i];
       PA_REQUIRE(len == o.ptrs[j + 1] - o.ptrs[j], "slice length mismatch between parts %d and %d", s, r);
       PA_HIP(hipStreamWaitEvent(pr->ctx->s[1], ps->ev_packed, 0));
+      PA_REQUIRE(pr->elem == ps->elem, "parts %d and %d packed payloads of different element types", s, r);
+      const size_t eb = (size_t)pr->elem;     // (8; 4 for a Float32 payload, pa_exchange_pack32: the buffers hold floats at the same element offsets)
       if (len)
-        PA_HIP(hipMemcpyAsync(in.d_buf + in.ptrs[i], o.d_buf + o.ptrs[j], sizeof(double) * len, hipMemcpyDeviceToDevice,
-                              pr->ctx->s[1]));
+        PA_HIP(hipMemcpyAsync(reinterpret_cast<char *>(in.d_buf) + eb * in.ptrs[i], reinterpret_cast<const char *>(o.d_buf) + eb * o.ptrs[j],
+                              eb * len, hipMemcpyDeviceToDevice, pr->ctx->s[1]));
     }
     if (in.n || out_side(pr, mode).n) PA_HIP(hipEventRecord(pr->ev_arrived, pr->ctx->s[1]));
     pr->ev_wait = nullptr;
     pr->phase = 2;
   }
+  return PA_OK;
+}
+
+
+// ---- Float32 payloads (round 6, second widening): consistent! / assemble! of a PVector{Vector{Float32}} --------------------------
+// assemble_impl! (src/p_vector.jl:587-612) is generic in the element type and exchange! in the payload (src/primitives.jl:1020-1042);
+// the plan's index lists serve any element type, its buffers hold floats at the same element offsets.  pack32 -> one of the
+// pack-then-transport transports (pa_exchange_local, pa_exchange_rccl, or the caller's own copies between pa_plan_buffers) -> finish32.
+template <class T>
+static __global__ void k_pack_t(T *__restrict__ buf, const T *__restrict__ v, const int *__restrict__ idx, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) buf[p] = v[idx[p]];
+}
+template <class T>
+static __global__ void k_unpack_insert_t(T *__restrict__ v, const T *__restrict__ buf, const int *__restrict__ idx, int n) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) v[idx[p]] = buf[p];
+}
+// one lane per distinct target; its contributions are added in ascending p (the reference's order), every sum rounded to T
+template <class T>
+static __global__ void k_unpack_add_t(T *__restrict__ v, const T *__restrict__ buf, const int *__restrict__ tgt, const int *__restrict__ tptr,
+                                      const int *__restrict__ tp, int n_tgt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n_tgt) {
+    const int lid = tgt[k];
+    T acc = v[lid];
+    for (int j = tptr[k]; j < tptr[k + 1]; ++j) acc = acc + buf[tp[j]];
+    v[lid] = acc;
+  }
+}
+template <class T>
+static __global__ void k_zero_t(T *__restrict__ v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (T)0;
+}
+
+extern "C" int pa_exchange_pack32(pa_plan *p, const pa_vec32 *v, int mode) {
+  PA_REQUIRE(p && v && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector has %lld local values, plan expects %lld",
+             (long long)(v->n_own + v->n_ghost), (long long)p->n_local);
+  PA_REQUIRE(p->phase == 0, "exchange already in flight on this plan (missing pa_exchange_finish)");
+  PA_REQUIRE(p->ctx == v->ctx, "plan and vector live on different contexts");
+  pa_ctx *c = p->ctx;
+  PA_REQUIRE(!c->capturing, "Float32 exchanges are not recorded into graphs");
+  p->ev_wait = nullptr;
+  p->elem = 4;
+  p->phase = 1;
+  p->mode = mode;
+  if (p->snd.n == 0 && p->rcv.n == 0) return PA_OK;
+  PA_HIP(hipSetDevice(c->device));
+  PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
+  PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+  pa_plan::side &o = out_side(p, mode);
+  if (o.n)
+    hipLaunchKernelGGL(k_pack_t<float>, dim3((unsigned)((o.n + 255) / 256)), dim3(256), 0, c->s[1], reinterpret_cast<float *>(o.d_buf),
+                       (const float *)v->d, (const int *)o.d_idx, (int)o.n);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipEventRecord(p->ev_packed, c->s[1]));
+  return PA_OK;
+}
+
+extern "C" int pa_exchange_finish32(pa_plan *p, pa_vec32 *v, int mode) {
+  PA_REQUIRE(p && v && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  PA_REQUIRE(p->phase >= 1 && p->mode == mode, "pa_exchange_finish32 without a matching pa_exchange_pack32");
+  PA_REQUIRE(p->elem == 4, "the exchange in flight carries a Float64 payload: finish it with pa_exchange_finish");
+  PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector/plan size mismatch");
+  pa_ctx *c = p->ctx;
+  PA_HIP(hipSetDevice(c->device));
+  const bool none = p->snd.n == 0 && p->rcv.n == 0;
+  if (!none) {
+    if (p->phase == 1) PA_HIP(hipEventRecord(p->ev_arrived, c->s[1]));      // (caller-driven transport on the comm stream)
+    PA_HIP(hipStreamWaitEvent(c->s[0], p->ev_wait ? p->ev_wait : p->ev_arrived, 0));  // wait(t)
+  }
+  p->ev_wait = nullptr;
+  p->own_comm_stream = false;
+  pa_plan::side &in = in_side(p, mode);
+  if (mode == PA_CONSISTENT) {
+    if (!none && in.n)
+      hipLaunchKernelGGL(k_unpack_insert_t<float>, dim3((unsigned)((in.n + 255) / 256)), dim3(256), 0, c->s[0], v->d,
+                         reinterpret_cast<const float *>(in.d_buf), (const int *)in.d_idx, (int)in.n);
+  } else {
+    if (!none && p->n_tgt)
+      hipLaunchKernelGGL(k_unpack_add_t<float>, dim3((unsigned)((p->n_tgt + 255) / 256)), dim3(256), 0, c->s[0], v->d,
+                         reinterpret_cast<const float *>(in.d_buf), (const int *)p->d_tgt, (const int *)p->d_tptr, (const int *)p->d_tp, (int)p->n_tgt);
+    // fill!(ghost_values(a),0) (src/p_vector.jl:703-705): every ghost value, also the ones no message carries
+    if (v->n_ghost > 0)
+      hipLaunchKernelGGL(k_zero_t<float>, dim3((unsigned)((v->n_ghost + 255) / 256)), dim3(256), 0, c->s[0], v->d + v->n_own, (int64_t)v->n_ghost);
+  }
+  PA_HIP(hipGetLastError());
+  // the next pack (on the comm stream) must not overwrite buffers this unpack still reads
+  PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
+  PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
+  p->elem = 8;
+  p->phase = 0;
   return PA_OK;
 }
 
@@ -207,6 +304,7 @@ extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
   PA_REQUIRE(p && v && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
   PA_REQUIRE(p->phase >= 1 && p->mode == mode, "pa_exchange_finish without a matching pa_exchange_pack");
   PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector/plan size mismatch");
+  PA_REQUIRE(p->elem == 8, "the exchange in flight carries a Float32 payload (pa_exchange_pack32): finish it with pa_exchange_finish32");
   pa_ctx *c = p->ctx;
   if (p->snd.n == 0 && p->rcv.n == 0) {                     // nothing travels; assemble! still zeroes the ghosts (below)
     if (mode == PA_ASSEMBLE && v->n_ghost > 0) {

@@ -161,6 +161,8 @@ extern "C" int pa_exchange_rccl(pa_plan *p, pa_comm *m, int mode) {
   PA_HIP(hipSetDevice(p->ctx->device));
   for (int32_t q : o.nbr) PA_REQUIRE(q >= 0 && q < m->nranks, "bad send neighbour %d", q);
   for (int32_t q : in.nbr) PA_REQUIRE(q >= 0 && q < m->nranks, "bad receive neighbour %d", q);
+  const size_t eb = (size_t)p->elem;                                 // (a Float32 payload, pa_exchange_pack32: floats at the same element offsets)
+  const ncclDataType_t dt = p->elem == 4 ? ncclFloat : ncclDouble;
   PA_NCCL(g_api.GroupStart());
   // (a failing ncclRecv / ncclSend must not leave the group OPEN -- the next RCCL call of this thread would be swallowed by it:
   // the group is always closed, then the first failure is reported)
@@ -168,11 +170,11 @@ extern "C" int pa_exchange_rccl(pa_plan *p, pa_comm *m, int mode) {
   const char *what = "";
   for (size_t i = 0; i < in.nbr.size() && first == ncclSuccess; ++i) {
     const size_t len = (size_t)(in.ptrs[i + 1] - in.ptrs[i]);
-    if (len) { first = g_api.Recv(in.d_buf + in.ptrs[i], len, ncclDouble, in.nbr[i], m->comm, st); what = "ncclRecv"; }
+    if (len) { first = g_api.Recv(reinterpret_cast<char *>(in.d_buf) + eb * in.ptrs[i], len, dt, in.nbr[i], m->comm, st); what = "ncclRecv"; }
   }
   for (size_t j = 0; j < o.nbr.size() && first == ncclSuccess; ++j) {
     const size_t len = (size_t)(o.ptrs[j + 1] - o.ptrs[j]);
-    if (len) { first = g_api.Send(o.d_buf + o.ptrs[j], len, ncclDouble, o.nbr[j], m->comm, st); what = "ncclSend"; }
+    if (len) { first = g_api.Send(reinterpret_cast<const char *>(o.d_buf) + eb * o.ptrs[j], len, dt, o.nbr[j], m->comm, st); what = "ncclSend"; }
   }
   const ncclResult_t closed = g_api.GroupEnd();
   if (first != ncclSuccess) {

@@ -757,6 +757,30 @@ def assemble_(a: PVector) -> Task:
     return Task(t.wait, a)
 
 
+def exchange32_(mode, vector_partition, cache: DeviceAssemblyCache) -> Task:
+    """assemble_impl!(f,vector_partition,cache) (src/p_vector.jl:587-612) for a PVector{Vector{Float32}}: vector_partition holds one
+    DeviceVector32 per part ([own | ghost] like DeviceVector), cache is the VectorAssemblyCache of the index partition (the one a
+    Float64 PVector on it uses).  Pack, exchange (device-to-device slice copies for a DebugArray, an RCCL group of ncclFloat
+    send / recv for a TorchDistArray), and a task whose wait() unpacks: insert (CONSISTENT) or + in ascending p, then ghosts := 0."""
+    plans = cache.plans
+    if not isinstance(plans, DebugArray) and TRANSPORT in ("torch", "host"):
+        raise L.PAError("Float32 payloads travel over the device-to-device copies of a DebugArray or over RCCL, not over the "
+                        f"'{TRANSPORT}' staging transport")
+    pmap(lambda v, p: L.call("pa_exchange_pack32", p, v.h, mode), vector_partition, plans)
+    _transport(plans, mode)
+    return Task(lambda: pmap(lambda v, p: L.call("pa_exchange_finish32", p, v.h, mode), vector_partition, plans))
+
+
+def consistent32_(vector_partition, cache: DeviceAssemblyCache) -> Task:
+    """consistent!(a) (src/p_vector.jl:747-755) on Float32 local values: ghost <- owner."""
+    return exchange32_(L.CONSISTENT, vector_partition, cache)
+
+
+def assemble32_(vector_partition, cache: DeviceAssemblyCache) -> Task:
+    """assemble!(a) (src/p_vector.jl:695-708) on Float32 local values: owner += ghost copies (ascending p, Float32 sums), ghosts := 0."""
+    return exchange32_(L.ASSEMBLE, vector_partition, cache)
+
+
 def _part_sum(parts_values, scalar_on_device=False):
     return preduce(lambda x, y: x + y, parts_values, init=0.0)
 

@@ -7,6 +7,8 @@ oracle's float loops (oracle/pa_oracle.c: orc_spmv_csr_f32 / orc_spmv_csc_f32 / 
 float, -ffp-contract=off), bit for bit: that matrix in all three storages (and its hand-worked product), irregular and empty rows,
 the alpha/beta form, and the 27-point operator on the pattern-ELL structure with the 4-byte value stream.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -116,3 +118,85 @@ def test_the_27_point_operator_in_float32_on_the_pattern_ell_structure(orc, n):
         y.upload(y0)
         pa.spmv32_(y, A, xd, alpha=0.5, beta=-1.25)
         assert np.array_equal(y.download(), K.mul5_csr_f32(y0.copy(), x, Ao.rowptr, Ao.colval, nz32, 0.5, -1.25)), pell
+
+
+def test_consistent_and_assemble_of_float32_local_values(orc):
+    """consistent! / assemble! (src/p_vector.jl:747-755, 695-708) of a PVector{Vector{Float32}}: pa_exchange_pack32 -> device-to-device
+    slice copies -> pa_exchange_finish32 on the plans of the index partition, 27 parts of the 27-point operator's column partition (the
+    middle part has 26 neighbours: messages of n^2, n and 1 values).  Against the oracle's assemble_impl! on float32 arrays: ghosts equal
+    their owners after consistent!, owners hold the Float32 sums in ascending p and every ghost is zero after assemble!, bit for bit; a
+    Float64 exchange on the same plans before, between and after keeps its bits (the buffers are shared)."""
+    from gpu_helpers import ranks, upload
+    n = 4
+    A, _ = pa.build_p_matrix(ranks(27), n, n, n, 3 * n, 3 * n, 3 * n, 3, 3, 3)
+    Ao, _, _ = orc.hpcg_build_p_matrix(n, n, n, 3, 3, 3)
+    cols = A.col_partition
+    cache = pa.pzeros(cols).cache
+    host = [(orc.hash_x(c.local_to_global + 3) * 1000.0).astype(np.float32) for c in Ao.cols]
+    vecs = pa.pmap(lambda i, h: pa.DeviceVector32(i.n_own, i.n_ghost).upload(h), cols, pa.DebugArray(host))
+    want = [h.copy() for h in host]
+    for c, w in zip(Ao.cols, want):
+        w[c.ghost_to_local - 1] = np.float32(-7.0)                        # ghosts start wrong on both sides
+    for v, w in zip(vecs.items, want):
+        v.upload(w)
+    h64 = [orc.hash_x(c.local_to_global + 11) for c in Ao.cols]
+    v64 = upload([h.copy() for h in h64], cols)
+    pa.assemble_(v64).wait()
+    pa.consistent32_(vecs, cache).wait()
+    orc.consistent(want, Ao.cols)
+    for v, w in zip(vecs.items, want):
+        got = v.download()
+        assert got.dtype == np.float32 and np.array_equal(got, w)
+    # assemble!: ghosts carry contributions
+    contrib = [(orc.hash_x(c.local_to_global + 5) * 3.0 + 0.1).astype(np.float32) for c in Ao.cols]
+    for v, w in zip(vecs.items, contrib):
+        v.upload(w)
+    pa.consistent_(v64).wait()
+    pa.assemble32_(vecs, cache).wait()
+    want = [w.copy() for w in contrib]
+    orc.assemble(want, Ao.cols)
+    for v, w, c in zip(vecs.items, want, Ao.cols):
+        got = v.download()
+        assert np.array_equal(got, w) and np.all(got[c.ghost_to_local - 1] == 0)
+    orc.assemble(h64, Ao.cols); orc.consistent(h64, Ao.cols)
+    for a_, b_ in zip(v64.local_values().items, h64):
+        assert np.array_equal(a_, b_)
+    # a Float32 payload must be finished as Float32
+    plans = cache.plans.items
+    L.call("pa_exchange_pack32", plans[0], vecs.items[0].h, L.CONSISTENT)
+    with pytest.raises(L.PAError, match="Float32"):
+        L.call("pa_exchange_finish", plans[0], v64.vector_partition.items[0].h, L.CONSISTENT)
+    for p, v in zip(plans[1:], vecs.items[1:]):
+        L.call("pa_exchange_pack32", p, v.h, L.CONSISTENT)
+    arr = (C.c_void_p * len(plans))(*[p.value for p in plans])
+    L.call("pa_exchange_local", arr, len(plans), L.CONSISTENT)
+    for p, v in zip(plans, vecs.items):
+        L.call("pa_exchange_finish32", p, v.h, L.CONSISTENT)
+
+
+def test_float32_product_of_a_partitioned_matrix_through_the_float32_exchange(orc):
+    """mul!(c,A,b) (src/p_sparse_matrix.jl:2090-2103) in Float32 composed from its parts: consistent!(b) on Float32 values, own x own
+    on pa_spmv32, own x ghost added on pa_spmv32(beta = 1) -- 8 parts of the 27-point operator, against the oracle's float loops."""
+    from gpu_helpers import ranks
+    n = 6
+    A, _ = pa.build_p_matrix(ranks(8), n, n, n, 2 * n, 2 * n, 2 * n, 2, 2, 2, keep_host=True)
+    Ao, _, _ = orc.hpcg_build_p_matrix(n, n, n, 2, 2, 2)
+    cols = A.col_partition
+    cache = pa.pzeros(cols).cache
+    K = orc.oracle_c()
+    xs = [(orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part)).astype(np.float32) for c in Ao.cols]
+    xd = pa.pmap(lambda i, h: pa.DeviceVector32(i.n_own, i.n_ghost).upload(h), cols, pa.DebugArray([h.copy() for h in xs]))
+    pa.consistent32_(xd, cache).wait()
+    orc.consistent(xs, Ao.cols)
+    for blk, xv, xo, r, c in zip(Ao.blocks, xd.items, xs, Ao.rows, Ao.cols):
+        oo, oh = blk.own_own, blk.own_ghost
+        Aoo = pa.DeviceCSR32(oo.m, oo.n, oo.rowptr, oo.colval, oo.nzval.astype(np.float32))
+        Aoh = pa.DeviceCSR32(oh.m, oh.n, oh.rowptr, oh.colval, oh.nzval.astype(np.float32))
+        y = pa.DeviceVector32(r.n_own, 0)
+        pa.spmv32_(y, Aoo, xv, L.SEG_OWN, L.SEG_OWN)
+        pa.spmv32_(y, Aoh, xv, L.SEG_GHOST, L.SEG_OWN, 1.0, 1.0)
+        xo_own, xo_gh = np.ascontiguousarray(xo[c.own_to_local - 1]), np.ascontiguousarray(xo[c.ghost_to_local - 1])
+        want = np.zeros(r.n_own, np.float32)
+        K.spmv_csr_f32(want, xo_own, oo.rowptr, oo.colval, oo.nzval.astype(np.float32))
+        K.mul5_csr_f32(want, xo_gh, oh.rowptr, oh.colval, oh.nzval.astype(np.float32), 1.0, 1.0)
+        assert np.array_equal(y.download(), want) and np.any(want != 0)
