@@ -107,6 +107,20 @@ def test_rccl_single_rank_loopback():
     L.call("pa_exchange_rccl", plan, comm, L.ASSEMBLE)
     L.call("pa_exchange_finish", plan, v.h, L.ASSEMBLE)
     assert v.download().tolist() == [0, 2, 2, 6, 4, 10, 0, 0, 0]
+    # the same plan with a Float32 payload (pa_exchange_pack32 / _finish32: ncclFloat send / recv at the same element offsets)
+    w = pa.DeviceVector32(6, 3).upload(np.arange(9, dtype=np.float32) + np.float32(0.5))
+    L.call("pa_exchange_pack32", plan, w.h, L.CONSISTENT)
+    L.call("pa_exchange_rccl", plan, comm, L.CONSISTENT)
+    L.call("pa_exchange_finish32", plan, w.h, L.CONSISTENT)
+    assert w.download().tolist() == [0.5, 1.5, 2.5, 3.5, 4.5, 5.5, 1.5, 3.5, 5.5]
+    L.call("pa_exchange_pack32", plan, w.h, L.ASSEMBLE)
+    L.call("pa_exchange_rccl", plan, comm, L.ASSEMBLE)
+    L.call("pa_exchange_finish32", plan, w.h, L.ASSEMBLE)
+    assert w.download().tolist() == [0.5, 3.0, 2.5, 7.0, 4.5, 11.0, 0, 0, 0]
+    L.call("pa_exchange_pack", plan, v.h, L.CONSISTENT)             # (and Float64 again on the shared buffers)
+    L.call("pa_exchange_rccl", plan, comm, L.CONSISTENT)
+    L.call("pa_exchange_finish", plan, v.h, L.CONSISTENT)
+    assert v.download().tolist() == [0, 2, 2, 6, 4, 10, 2, 6, 10]
     d = pa.DeviceVector(4, 0).upload(np.array([1.5, 2.0, 0.0, -1.0]))
     L.call("pa_comm_allreduce_sum", comm, C.c_void_p(d.data_ptr()), 4, L.STREAM_COMPUTE)
     assert d.download().tolist() == [1.5, 2.0, 0.0, -1.0]
