@@ -230,20 +230,25 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
   const double *x = EPI == 1 ? gs_x : x_in;          // EPI 1 reads and writes the same vector: no restrict promise on it
   const int lane = threadIdx.x & 63;
   const int2 d = P.desc[slab];                       // (slab is wave-uniform: scalar loads)
+  // (everything that depends on the slab's number alone is requested WITH the descriptor, not behind it: the slab's bits and its first
+  //  row id come from HBM like the descriptor, and a wavefront's life is a chain of such round trips)
+  uint2 q = make_uint2(0u, 0u);
+  int row0 = slab * 64;
+  if constexpr (A1) {
+    if (P.plane != nullptr) {
+      if (VM == 1) q = P.sbits[slab];
+      if (COMPACT) row0 = P.row_ids[slab * 64];
+    }
+  }
   const int pat = d.x & 0xfffff, Wp = d.x >> 20;
   const int *dl = P.pdelta + (size_t)pat * PA_PELL_TW;
   if constexpr (A1) {
     // a slab of a class (P.plane), nothing to add to, every gather of every lane in range: the lean form (all of this is scalar)
     if (P.plane != nullptr && (EPI == 1 || EPI == 2 || beta == 0.0)) {
       const int st = dl[PA_PELL_T_STRIDE];
-      const int row0 = COMPACT ? P.row_ids[slab * 64] : slab * 64;
       bool go = st != 0 && row0 + dl[PA_PELL_T_MIN] >= 0 && row0 + 63 * st + dl[PA_PELL_T_MAX] < P.n_cols;
-      unsigned sb = 0;
-      if (VM == 1 && go) {
-        const uint2 q = P.sbits[slab];
-        sb = q.x;
-        go = q.y != 0;
-      }
+      const unsigned sb = q.x;
+      if (VM == 1) go = go && q.y != 0;
       if (go) {
         const bool full = (dl[PA_PELL_T_FLAGS] & 1) != 0;
         constexpr int UF = R3 ? 9 : U;
