@@ -117,6 +117,17 @@ int pa_sell_destroy(pa_sell *A);
 int pa_sell_info(const pa_sell *A, int64_t *n_slabs, int64_t *padded_entries, int64_t *nnz);
 int pa_sell_spmv(const pa_sell *A, const pa_vec *x, int x_segment, pa_vec *y, int y_segment, double alpha, double beta);
 
+/* ---- all parts in ONE process, one GPU each, over RCCL (csrc/pa_rccl.cpp; round 6) --------------------------------------------
+ * SURVEY 8(b)'s sketch of the single-process multi-GPU mode: the parts of a DebugArray each in a context on a device of its own
+ * (pa_ctx_create per device), their communicators made by ONE ncclCommInitAll (comms[p]: rank p of n, on ctxs[p]'s device; the devices
+ * must be distinct), and the exchange of all parts ONE group of ncclSend / ncclRecv -- exchange! src/primitives.jl:1020-1042 /
+ * exchange_impl! src/mpi_array.jl:575-614 with the parts' comm streams in the place of MPI requests.  Sequence per exchange:
+ * pa_exchange_pack (or _pack32) on every part -> pa_exchange_rccl_all -> pa_exchange_finish (_finish32) on every part.  The peer copies
+ * of pa_exchange_local serve the same layout without RCCL.  On a one-GPU box only n = 1 can run (tests): a run between distinct GPUs
+ * has not been possible on the leases this library was built on. */
+int pa_comm_create_all(pa_ctx *const *ctxs, int32_t n, pa_comm **comms);        /* comms: n slots; each freed with pa_comm_destroy */
+int pa_exchange_rccl_all(pa_plan *const *plans, pa_comm *const *comms, int32_t n, int mode);
+
 /* ---- pattern-ELL: the lane-per-row product kernel of pattern blocks (csrc/pa_pell.h, pa_pell.hip; round 6) ---------------
  * A block whose slabs of 64 consecutive stored rows each have at most 32 distinct (column - row) offsets -- stencil and structured
  * FEM operators, their row-compacted colour and restriction subsets -- gets, at creation, a second storage: per slab the ascending

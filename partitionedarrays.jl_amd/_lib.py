@@ -190,6 +190,8 @@ _SIGS = {
     "pa_csr32_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64)],
     "pa_spmv32": [P, P, cint, P, cint, C.c_float, C.c_float],
     "pa_csr_pell_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(cint)],
+    "pa_comm_create_all": [P, C.c_int32, P],
+    "pa_exchange_rccl_all": [P, P, C.c_int32, cint],
     "pa_exchange_pack32": [P, P, cint],
     "pa_exchange_finish32": [P, P, cint],
     "pa_csr_pell_lean_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],

@@ -10,6 +10,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "pa_internal.h"
 
@@ -18,6 +19,7 @@ struct Api {
   void *h = nullptr;
   decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
@@ -42,6 +44,7 @@ void load_api() {
 #define PA_SYM(field, sym) g_api.field = (decltype(g_api.field))dlsym(g_api.h, #sym)
   PA_SYM(GetUniqueId, ncclGetUniqueId);
   PA_SYM(CommInitRank, ncclCommInitRank);
+  PA_SYM(CommInitAll, ncclCommInitAll);
   PA_SYM(CommDestroy, ncclCommDestroy);
   PA_SYM(GroupStart, ncclGroupStart);
   PA_SYM(GroupEnd, ncclGroupEnd);
@@ -187,4 +190,89 @@ extern "C" int pa_exchange_rccl(pa_plan *p, pa_comm *m, int mode) {
   }
   p->own_comm_stream = true;
   return pa_plan_mark_arrived(p);
+}
+
+// ---- all parts in ONE process, one GPU each (SURVEY 8(b)'s sketch: pa_ctx_create per device, ONE ncclGroup across the parts) ------
+// The DebugArray model over several GPUs (the Python mirror's PA_CTX_PER_PART=1): part p has its own context on device p and the
+// exchange is ONE group of ncclSend / ncclRecv over every part's communicator (ncclCommInitAll: the single-process multi-GPU form of
+// RCCL).  Beside the peer copies of pa_exchange_local; same plans, same buffers, same finish.
+extern "C" int pa_comm_create_all(pa_ctx *const *ctxs, int32_t n, pa_comm **out) {
+  PA_REQUIRE(ctxs && out && n >= 1, "bad arguments");
+  PA_TRY(need_api());
+  PA_REQUIRE(g_api.CommInitAll != nullptr, "this librccl has no ncclCommInitAll");
+  std::vector<int> devs((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    PA_REQUIRE(ctxs[i] != nullptr, "ctxs[%d] is NULL", i);
+    devs[(size_t)i] = ctxs[i]->device;
+    for (int j = 0; j < i; ++j)
+      PA_REQUIRE(devs[(size_t)j] != devs[(size_t)i], "parts %d and %d share device %d: RCCL wants one device per rank (use pa_exchange_local / "
+                 "pa_exchange_push_local for parts that share a GPU)", j, i, devs[(size_t)i]);
+  }
+  std::vector<ncclComm_t> comms((size_t)n, nullptr);
+  PA_NCCL(g_api.CommInitAll(comms.data(), n, devs.data()));
+  for (int i = 0; i < n; ++i) {
+    pa_comm *m = new pa_comm();
+    m->ctx = ctxs[i]; m->comm = comms[(size_t)i]; m->rank = i; m->nranks = n;
+    PA_HIP(hipSetDevice(ctxs[i]->device));
+    PA_HIP(pa_raw_malloc(&m->d_token, sizeof(double)));
+    PA_HIP(hipMemsetAsync(m->d_token, 0, sizeof(double), ctxs[i]->s[1]));
+    PA_HIP(hipStreamSynchronize(ctxs[i]->s[1]));
+    out[i] = m;
+  }
+  return PA_OK;
+}
+
+extern "C" int pa_exchange_rccl_all(pa_plan *const *plans, pa_comm *const *comms, int32_t n, int mode) {
+  PA_REQUIRE(plans && comms && n >= 1 && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  PA_TRY(need_api());
+  for (int r = 0; r < n; ++r) {
+    pa_plan *p = plans[r];
+    pa_comm *m = comms[r];
+    PA_REQUIRE(p && m, "part %d: NULL plan or communicator", r);
+    PA_REQUIRE(p->phase == 1 && p->mode == mode, "part %d: pa_exchange_pack(mode) must come first", r);
+    PA_REQUIRE(p->ctx == m->ctx && p->part == m->rank && m->nranks == n, "part %d: plan and communicator do not belong together", r);
+    PA_REQUIRE(p->elem == plans[0]->elem, "the parts packed payloads of different element types");
+    const pa_plan::side &o = (mode == PA_ASSEMBLE) ? p->snd : p->rcv, &in = (mode == PA_ASSEMBLE) ? p->rcv : p->snd;
+    for (int32_t q : o.nbr) PA_REQUIRE(q >= 0 && q < n, "part %d: bad send neighbour %d", r, q);
+    for (int32_t q : in.nbr) PA_REQUIRE(q >= 0 && q < n, "part %d: bad receive neighbour %d", r, q);
+  }
+  const size_t eb = (size_t)plans[0]->elem;
+  const ncclDataType_t dt = plans[0]->elem == 4 ? ncclFloat : ncclDouble;
+  PA_NCCL(g_api.GroupStart());
+  ncclResult_t first = ncclSuccess;
+  int bad_part = -1;
+  for (int r = 0; r < n && first == ncclSuccess; ++r) {
+    pa_plan *p = plans[r];
+    pa_comm *m = comms[r];
+    if (p->snd.n == 0 && p->rcv.n == 0) continue;
+    pa_plan::side &o = (mode == PA_ASSEMBLE) ? p->snd : p->rcv;
+    pa_plan::side &in = (mode == PA_ASSEMBLE) ? p->rcv : p->snd;
+    hipStream_t st = p->ctx->s[1];
+    for (size_t i = 0; i < in.nbr.size() && first == ncclSuccess; ++i) {
+      const size_t len = (size_t)(in.ptrs[i + 1] - in.ptrs[i]);
+      if (len) first = g_api.Recv(reinterpret_cast<char *>(in.d_buf) + eb * in.ptrs[i], len, dt, in.nbr[i], m->comm, st);
+    }
+    for (size_t j = 0; j < o.nbr.size() && first == ncclSuccess; ++j) {
+      const size_t len = (size_t)(o.ptrs[j + 1] - o.ptrs[j]);
+      if (len) first = g_api.Send(reinterpret_cast<const char *>(o.d_buf) + eb * o.ptrs[j], len, dt, o.nbr[j], m->comm, st);
+    }
+    if (first != ncclSuccess) bad_part = r;
+  }
+  const ncclResult_t closed = g_api.GroupEnd();          // (the group is always closed, then the first failure is reported)
+  if (first != ncclSuccess) {
+    pa_set_err("ncclSend / ncclRecv failed inside the exchange group at part %d: %s", bad_part, g_api.GetErrorString(first));
+    return PA_ERR_RCCL;
+  }
+  if (closed != ncclSuccess) {
+    pa_set_err("ncclGroupEnd failed for the exchange of %d parts: %s", (int)n, g_api.GetErrorString(closed));
+    return PA_ERR_RCCL;
+  }
+  for (int r = 0; r < n; ++r) {
+    pa_plan *p = plans[r];
+    if (p->snd.n == 0 && p->rcv.n == 0) { p->phase = 2; continue; }
+    PA_HIP(hipSetDevice(p->ctx->device));
+    p->own_comm_stream = true;
+    PA_TRY(pa_plan_mark_arrived(p));
+  }
+  return PA_OK;
 }

@@ -524,7 +524,10 @@ def _transport(plans, mode):
     if isinstance(plans, DebugArray):
         hs = plans.items
         arr = (C.c_void_p * len(hs))(*[h.value for h in hs])
-        L.call("pa_exchange_local", arr, len(hs), mode)
+        if _rccl_all():
+            L.call("pa_exchange_rccl_all", arr, _all_comms(len(hs)), len(hs), mode)
+        else:
+            L.call("pa_exchange_local", arr, len(hs), mode)
     else:
         if TRANSPORT == "torch":
             _transport_torch(plans.item, mode, plans.group)
@@ -539,7 +542,28 @@ def _transport(plans, mode):
 
 
 def _push():                 # all parts in one process: one launch packs AND delivers (csrc/pa_push.hip); PA_PUSH=0: pack + copies
-    return os.environ.get("PA_PUSH", "1") != "0"
+    return os.environ.get("PA_PUSH", "1") != "0" and not _rccl_all()
+
+
+def _rccl_all():
+    """PA_TRANSPORT_ALL=rccl (with PA_CTX_PER_PART=1: every part of a DebugArray in a context on a GPU of its own): the exchange of all
+    parts is ONE group of ncclSend / ncclRecv over communicators made by ncclCommInitAll (pa_comm_create_all / pa_exchange_rccl_all,
+    csrc/pa_rccl.cpp) instead of peer copies.  The devices must be distinct -- on a one-GPU box only a single part can run this."""
+    return os.environ.get("PA_TRANSPORT_ALL", "") == "rccl"
+
+
+_ALL_COMMS = {}
+
+
+def _all_comms(n):
+    """the n communicators of the parts' contexts (parts 0..n-1), made once per n"""
+    if n not in _ALL_COMMS:
+        ctxs = [_PART_CTX[i] if i in _PART_CTX else context() for i in range(n)]
+        arr = (C.c_void_p * n)(*[c.h.value for c in ctxs])
+        out = (C.c_void_p * n)()
+        L.call("pa_comm_create_all", arr, n, out)
+        _ALL_COMMS[n] = (out, ctxs)
+    return _ALL_COMMS[n][0]
 
 
 def assemble_impl(mode, vector_partition, cache: DeviceAssemblyCache) -> Task:

@@ -221,3 +221,37 @@ def test_assemble_zeroes_every_ghost_also_the_self_owned_ones(orc, np_, n, ghost
     orc.consistent(vo, oparts)
     for got, want in zip(v.local_values().items, vo):
         assert np.array_equal(got, want)
+
+
+def test_all_parts_of_one_process_over_one_rccl_group_single_part():
+    """pa_comm_create_all / pa_exchange_rccl_all (csrc/pa_rccl.cpp): the single-process multi-GPU form -- communicators of all parts
+    from ONE ncclCommInitAll, the exchange ONE group over them.  A one-GPU box can run it for one part only (RCCL wants distinct
+    devices): a part that ghosts three of its own values, Float64 and Float32 payloads; two parts on the one device are refused with a
+    message that names the transports that do serve them."""
+    import pa_amd._lib as L
+    ctx = pa.context()
+    arr = (C.c_void_p * 1)(ctx.h.value)
+    comms = (C.c_void_p * 1)()
+    L.call("pa_comm_create_all", arr, 1, comms)
+    one, ptrs = np.array([1], np.int32), np.array([1, 4], np.int32)
+    plan = C.c_void_p()
+    L.call("pa_plan_create", ctx.h, 1, 9, 1, L.ptr(one), L.ptr(ptrs), L.ptr(np.array([7, 8, 9], np.int32)),
+           1, L.ptr(one), L.ptr(ptrs), L.ptr(np.array([2, 4, 6], np.int32)), 1, C.byref(plan))
+    plans = (C.c_void_p * 1)(plan.value)
+    v = pa.DeviceVector(6, 3).upload(np.arange(9, dtype=float))
+    for mode, want in ((L.CONSISTENT, [0, 1, 2, 3, 4, 5, 1, 3, 5]), (L.ASSEMBLE, [0, 2, 2, 6, 4, 10, 0, 0, 0])):
+        L.call("pa_exchange_pack", plan, v.h, mode)
+        L.call("pa_exchange_rccl_all", plans, comms, 1, mode)
+        L.call("pa_exchange_finish", plan, v.h, mode)
+        assert v.download().tolist() == want
+    w = pa.DeviceVector32(6, 3).upload(np.arange(9, dtype=np.float32) + np.float32(0.25))
+    L.call("pa_exchange_pack32", plan, w.h, L.CONSISTENT)
+    L.call("pa_exchange_rccl_all", plans, comms, 1, L.CONSISTENT)
+    L.call("pa_exchange_finish32", plan, w.h, L.CONSISTENT)
+    assert w.download().tolist() == [0.25, 1.25, 2.25, 3.25, 4.25, 5.25, 1.25, 3.25, 5.25]
+    two = (C.c_void_p * 2)(ctx.h.value, ctx.h.value)
+    out2 = (C.c_void_p * 2)()
+    with pytest.raises(L.PAError, match="share device"):
+        L.call("pa_comm_create_all", two, 2, out2)
+    L.call("pa_plan_destroy", plan)
+    L.call("pa_comm_destroy", C.c_void_p(comms[0]))
