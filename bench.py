@@ -117,6 +117,7 @@ class optional_section:
         return True
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X vector fp64 with FMA (256 CUs x 4 SIMDs x 16 lanes x 2 flops x 2.4 GHz); unfused multiply + add: half
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy kernel achieves
 
 
@@ -1458,7 +1459,12 @@ def main():
                              "distinct values; bench.py switches it off -- PA_SPMV_VALUE_DICT=0 -- for `value` and every other entry)",
                      "distinct_values": blk2.own_own.value_dict(), "bit_identical_to_headline_product": bool(same),
                      "avg_launch_ms": round(ms2, 4), "gflops": round(2.0 * nnz_oo / (ms2 * 1e-3) / 1e9, 1),
-                     "algorithmic_gbps": round(bytes_oo / (ms2 * 1e-3) / 1e9, 1)}
+                     "algorithmic_gbps": round(bytes_oo / (ms2 * 1e-3) / 1e9, 1),
+                     # fp64 adds and multiplies kept apart (-ffp-contract=off: the reference's roundings): 2 vector instructions per entry
+                     "frac_of_unfused_fp64_vector_peak": round(2.0 * nnz_oo / (ms2 * 1e-3) / 1e12 / (FP64_VECTOR_PEAK_TFLOPS / 2.0), 4),
+                     "bound": "neither HBM nor the vector ALU: with one bit per entry the kernel moves x, y and 16 bytes per 64 rows; SQ counters "
+                              "(profiles/r06_lean_k1_sq.json, docs/LAB_NOTEBOOK.md R6.5): 171 vector + 138 scalar instructions per wavefront of 64 rows, "
+                              "both pipes ~55 % busy, wavefronts waiting on their three dependent groups of gathers half of their time at 8 waves per SIMD"}
             del A2, _b2, y2, blk2
         except Exception as e:                                 # noqa: BLE001
             os.environ["PA_SPMV_VALUE_DICT"] = "0"
