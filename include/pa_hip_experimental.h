@@ -163,6 +163,7 @@ int pa_vec32_destroy(pa_vec32 *v);
 int pa_vec32_upload(pa_vec32 *v, const float *host, int64_t offset, int64_t len);
 int pa_vec32_download(const pa_vec32 *v, float *host, int64_t offset, int64_t len);
 int pa_vec32_fill(pa_vec32 *v, int segment, float value);
+int pa_vec32_data(pa_vec32 *v, void **device_ptr);      /* the [own | ghost] array in HBM (4-byte values: also the carrier of an Int32 payload) */
 int pa_csr32_create(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *rowptr, const void *colval, int index_bytes,
                     int index_base, const float *nzval, pa_csr32 **A);
 int pa_csr32_create_from_csc(pa_ctx *ctx, int64_t n_rows, int64_t n_cols, int64_t nnz, const void *colptr, const void *rowval,
@@ -179,6 +180,16 @@ int pa_spmv32(const pa_csr32 *A, const pa_vec32 *x, int x_segment, pa_vec32 *y, 
  * Float64 only.  Bit-identical to the reference's loops on Float32 (data movement; the assemble! sums in the reference's order). */
 int pa_exchange_pack32(pa_plan *plan, const pa_vec32 *v, int mode);
 int pa_exchange_finish32(pa_plan *plan, pa_vec32 *v, int mode);
+/* The same for any local-values array in HBM, device layout [own | ghost]: Float64, Float32, Int32, Int64 (the reference exchanges
+ * Int64 global ids and Int32 owners at set-up, src/p_range.jl:436-531, and assemble!(+) counts on integers alike).  `values`: n_local
+ * values of the dtype; finish_raw: the first n_own are the own values (assemble! zeroes what is behind them).  consistent!: a copy of
+ * the bits; assemble!: + in ascending p in the dtype's arithmetic, then every ghost := 0. */
+#define PA_DTYPE_F64 0
+#define PA_DTYPE_F32 1
+#define PA_DTYPE_I32 2
+#define PA_DTYPE_I64 3
+int pa_exchange_pack_raw(pa_plan *plan, const void *values, int64_t n_local, int dtype, int mode);
+int pa_exchange_finish_raw(pa_plan *plan, void *values, int64_t n_own, int64_t n_local, int dtype, int mode);
 
 /* ---- Gauss-Seidel smoother and grid transfer of the HPCG multigrid preconditioner ----------- */
 /* gauss_seidel_sweep! / gauss_seidel_sweep_zero! (PartitionedSolvers/src/smoothers.jl:144-160,236-259) on the

@@ -12,7 +12,7 @@ from .primitives import (MAIN, DebugArray, TorchDistArray, ExchangeGraph, with_d
 from .p_range import (JaggedArray, LocalIndices, PRange, local_range, uniform_partition, variable_partition,  # noqa: F401
                       find_owner, filter_ghost, union_ghost, assembly_neighbors, assembly_local_indices)
 from .p_vector import (Context, Event, Graph, context, init_comm, DeviceVector, DeviceAssemblyCache, Task, PVector,  # noqa: F401
-                       pvector_from_function, pfill, pzeros, pones, similar, pvector, consistent_, assemble_, consistent32_, assemble32_, exchange32_,
+                       pvector_from_function, pfill, pzeros, pones, similar, pvector, consistent_, assemble_, consistent32_, assemble32_, exchange32_, exchange_raw_,
                        dot, norm, axpby_, copy_, slots_supported, dot_slot, axpby_slot_, cg_update_, write_slot,
                        read_slots, on_partition, pvector_disassembled, pvector_, VectorReassemblyCache,
                        pvector_from_function_values)

@@ -192,6 +192,9 @@ _SIGS = {
     "pa_csr_pell_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(cint)],
     "pa_comm_create_all": [P, C.c_int32, P],
     "pa_exchange_rccl_all": [P, P, C.c_int32, cint],
+    "pa_vec32_data": [P, C.POINTER(P)],
+    "pa_exchange_pack_raw": [P, P, i64, cint, cint],
+    "pa_exchange_finish_raw": [P, P, i64, i64, cint, cint],
     "pa_exchange_pack32": [P, P, cint],
     "pa_exchange_finish32": [P, P, cint],
     "pa_csr_pell_lean_info": [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],

@@ -188,6 +188,12 @@ extern "C" int pa_vec32_fill(pa_vec32 *v, int segment, float value) {
   return PA_OK;
 }
 
+extern "C" int pa_vec32_data(pa_vec32 *v, void **device_ptr) {
+  PA_REQUIRE(v && device_ptr, "bad arguments");
+  *device_ptr = v->d;
+  return PA_OK;
+}
+
 // ---- blocks ------------------------------------------------------------------------------------------------------------------
 extern "C" int pa_csr32_destroy(pa_csr32 *A) {
   if (!A) return PA_OK;

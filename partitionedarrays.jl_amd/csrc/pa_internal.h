@@ -242,7 +242,8 @@ struct pa_plan {
   int32_t *d_tgt = nullptr, *d_tptr = nullptr, *d_tp = nullptr;
   hipEvent_t ev_packed = nullptr, ev_arrived = nullptr;
   int phase = 0;     // 0 idle, 1 packed, 2 arrived
-  int elem = 8;      // bytes per value of the payload in the buffers: 8, or 4 between pa_exchange_pack32 and pa_exchange_finish32
+  int elem = 8;      // bytes per value of the payload in the buffers: 8, or 4 between pa_exchange_pack32 / _pack_raw and their finish
+  int raw_dtype = -1; // >= 0 between pa_exchange_pack_raw and pa_exchange_finish_raw: the payload's dtype
   bool own_comm_stream = false;   // this exchange's transport ran on this part's comm stream alone (RCCL: one part per process)
   int mode = 0;
   hipEvent_t ev_wait = nullptr;   // what wait(t) waits for: ev_arrived, or the event a group launch recorded once for all its parts

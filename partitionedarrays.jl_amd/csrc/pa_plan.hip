@@ -190,10 +190,12 @@ extern "C" int pa_exchange_local(pa_plan *const *plans, int32_t n_parts, int mod
 }
 
 
-// ---- Float32 payloads (round 6, second widening): consistent! / assemble! of a PVector{Vector{Float32}} --------------------------
-// assemble_impl! (src/p_vector.jl:587-612) is generic in the element type and exchange! in the payload (src/primitives.jl:1020-1042);
-// the plan's index lists serve any element type, its buffers hold floats at the same element offsets.  pack32 -> one of the
-// pack-then-transport transports (pa_exchange_local, pa_exchange_rccl, or the caller's own copies between pa_plan_buffers) -> finish32.
+// ---- other payload types (round 6, second widening): consistent! / assemble! of a PVector{Vector{T}}, T = Float32, Int32, Int64 ------
+// assemble_impl! (src/p_vector.jl:587-612) is generic in the element type and exchange! in the payload (src/primitives.jl:1020-1042:
+// Int64 ids at set-up, Float32 values, ...); the plan's index lists serve any element type, its buffers hold values of 4 or 8 bytes at
+// the same element offsets.  pack_raw / pack32 -> one of the pack-then-transport transports (pa_exchange_local, pa_exchange_rccl(_all), or
+// the caller's own copies between pa_plan_buffers) -> finish_raw / finish32.  The transports move bytes: integers travel as the float type
+// of their width (ncclFloat / ncclDouble are never reduced here, only sent).
 template <class T>
 static __global__ void k_pack_t(T *__restrict__ buf, const T *__restrict__ v, const int *__restrict__ idx, int n) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,16 +224,20 @@ static __global__ void k_zero_t(T *__restrict__ v, int64_t n) {
   if (i < n) v[i] = (T)0;
 }
 
-extern "C" int pa_exchange_pack32(pa_plan *p, const pa_vec32 *v, int mode) {
-  PA_REQUIRE(p && v && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
-  PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector has %lld local values, plan expects %lld",
-             (long long)(v->n_own + v->n_ghost), (long long)p->n_local);
+// dtype of a raw payload: PA_DTYPE_F64 0, PA_DTYPE_F32 1, PA_DTYPE_I32 2, PA_DTYPE_I64 3 (include/pa_hip_experimental.h)
+static inline int dtype_bytes(int dtype) { return dtype == 0 || dtype == 3 ? 8 : dtype == 1 || dtype == 2 ? 4 : 0; }
+
+// values: n_local values of the dtype in HBM, device layout [own | ghost] (what a pa_vec / pa_vec32 holds; integers alike)
+extern "C" int pa_exchange_pack_raw(pa_plan *p, const void *values, int64_t n_local, int dtype, int mode) {
+  PA_REQUIRE(p && values && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  PA_REQUIRE(dtype_bytes(dtype) != 0, "unknown dtype %d", dtype);
+  PA_REQUIRE(n_local == p->n_local, "vector has %lld local values, plan expects %lld", (long long)n_local, (long long)p->n_local);
   PA_REQUIRE(p->phase == 0, "exchange already in flight on this plan (missing pa_exchange_finish)");
-  PA_REQUIRE(p->ctx == v->ctx, "plan and vector live on different contexts");
   pa_ctx *c = p->ctx;
-  PA_REQUIRE(!c->capturing, "Float32 exchanges are not recorded into graphs");
+  PA_REQUIRE(!c->capturing, "raw-payload exchanges are not recorded into graphs");
   p->ev_wait = nullptr;
-  p->elem = 4;
+  p->elem = dtype_bytes(dtype);
+  p->raw_dtype = dtype;
   p->phase = 1;
   p->mode = mode;
   if (p->snd.n == 0 && p->rcv.n == 0) return PA_OK;
@@ -239,19 +245,41 @@ extern "C" int pa_exchange_pack32(pa_plan *p, const pa_vec32 *v, int mode) {
   PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
   PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
   pa_plan::side &o = out_side(p, mode);
-  if (o.n)
-    hipLaunchKernelGGL(k_pack_t<float>, dim3((unsigned)((o.n + 255) / 256)), dim3(256), 0, c->s[1], reinterpret_cast<float *>(o.d_buf),
-                       (const float *)v->d, (const int *)o.d_idx, (int)o.n);
+  if (o.n) {
+    const dim3 g((unsigned)((o.n + 255) / 256));
+    if (p->elem == 4)
+      hipLaunchKernelGGL(k_pack_t<uint32_t>, g, dim3(256), 0, c->s[1], reinterpret_cast<uint32_t *>(o.d_buf), (const uint32_t *)values, (const int *)o.d_idx, (int)o.n);
+    else
+      hipLaunchKernelGGL(k_pack_t<uint64_t>, g, dim3(256), 0, c->s[1], reinterpret_cast<uint64_t *>(o.d_buf), (const uint64_t *)values, (const int *)o.d_idx, (int)o.n);
+  }
   PA_HIP(hipGetLastError());
   PA_HIP(hipEventRecord(p->ev_packed, c->s[1]));
   return PA_OK;
 }
 
-extern "C" int pa_exchange_finish32(pa_plan *p, pa_vec32 *v, int mode) {
-  PA_REQUIRE(p && v && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
-  PA_REQUIRE(p->phase >= 1 && p->mode == mode, "pa_exchange_finish32 without a matching pa_exchange_pack32");
-  PA_REQUIRE(p->elem == 4, "the exchange in flight carries a Float64 payload: finish it with pa_exchange_finish");
-  PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector/plan size mismatch");
+template <class T>
+static void finish_typed(pa_plan *p, T *v, int64_t n_own, int64_t n_ghost, int mode, bool none, hipStream_t st) {
+  pa_plan::side &in = in_side(p, mode);
+  if (mode == PA_CONSISTENT) {
+    if (!none && in.n)
+      hipLaunchKernelGGL(k_unpack_insert_t<T>, dim3((unsigned)((in.n + 255) / 256)), dim3(256), 0, st, v, reinterpret_cast<const T *>(in.d_buf),
+                         (const int *)in.d_idx, (int)in.n);
+  } else {
+    if (!none && p->n_tgt)
+      hipLaunchKernelGGL(k_unpack_add_t<T>, dim3((unsigned)((p->n_tgt + 255) / 256)), dim3(256), 0, st, v, reinterpret_cast<const T *>(in.d_buf),
+                         (const int *)p->d_tgt, (const int *)p->d_tptr, (const int *)p->d_tp, (int)p->n_tgt);
+    // fill!(ghost_values(a),0) (src/p_vector.jl:703-705): every ghost value, also the ones no message carries
+    if (n_ghost > 0) hipLaunchKernelGGL(k_zero_t<T>, dim3((unsigned)((n_ghost + 255) / 256)), dim3(256), 0, st, v + n_own, (int64_t)n_ghost);
+  }
+}
+
+// n_own: the own values come first in `values` (the ghosts behind them are what assemble! zeroes)
+extern "C" int pa_exchange_finish_raw(pa_plan *p, void *values, int64_t n_own, int64_t n_local, int dtype, int mode) {
+  PA_REQUIRE(p && values && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
+  PA_REQUIRE(p->phase >= 1 && p->mode == mode, "pa_exchange_finish_raw without a matching pa_exchange_pack_raw");
+  PA_REQUIRE(p->raw_dtype == dtype && p->elem == dtype_bytes(dtype),
+             "the exchange in flight carries another payload type (%s): finish it as it was packed", p->raw_dtype < 0 ? "a pa_vec" : "another dtype");
+  PA_REQUIRE(n_local == p->n_local && n_own >= 0 && n_own <= n_local, "vector/plan size mismatch");
   pa_ctx *c = p->ctx;
   PA_HIP(hipSetDevice(c->device));
   const bool none = p->snd.n == 0 && p->rcv.n == 0;
@@ -261,26 +289,33 @@ extern "C" int pa_exchange_finish32(pa_plan *p, pa_vec32 *v, int mode) {
   }
   p->ev_wait = nullptr;
   p->own_comm_stream = false;
-  pa_plan::side &in = in_side(p, mode);
-  if (mode == PA_CONSISTENT) {
-    if (!none && in.n)
-      hipLaunchKernelGGL(k_unpack_insert_t<float>, dim3((unsigned)((in.n + 255) / 256)), dim3(256), 0, c->s[0], v->d,
-                         reinterpret_cast<const float *>(in.d_buf), (const int *)in.d_idx, (int)in.n);
-  } else {
-    if (!none && p->n_tgt)
-      hipLaunchKernelGGL(k_unpack_add_t<float>, dim3((unsigned)((p->n_tgt + 255) / 256)), dim3(256), 0, c->s[0], v->d,
-                         reinterpret_cast<const float *>(in.d_buf), (const int *)p->d_tgt, (const int *)p->d_tptr, (const int *)p->d_tp, (int)p->n_tgt);
-    // fill!(ghost_values(a),0) (src/p_vector.jl:703-705): every ghost value, also the ones no message carries
-    if (v->n_ghost > 0)
-      hipLaunchKernelGGL(k_zero_t<float>, dim3((unsigned)((v->n_ghost + 255) / 256)), dim3(256), 0, c->s[0], v->d + v->n_own, (int64_t)v->n_ghost);
+  const int64_t n_ghost = n_local - n_own;
+  switch (dtype) {
+    case 0: finish_typed<double>(p, (double *)values, n_own, n_ghost, mode, none, c->s[0]); break;
+    case 1: finish_typed<float>(p, (float *)values, n_own, n_ghost, mode, none, c->s[0]); break;
+    case 2: finish_typed<int32_t>(p, (int32_t *)values, n_own, n_ghost, mode, none, c->s[0]); break;
+    default: finish_typed<long long>(p, (long long *)values, n_own, n_ghost, mode, none, c->s[0]); break;
   }
   PA_HIP(hipGetLastError());
   // the next pack (on the comm stream) must not overwrite buffers this unpack still reads
   PA_HIP(hipEventRecord(c->ev_compute, c->s[0]));
   PA_HIP(hipStreamWaitEvent(c->s[1], c->ev_compute, 0));
   p->elem = 8;
+  p->raw_dtype = -1;
   p->phase = 0;
   return PA_OK;
+}
+
+extern "C" int pa_exchange_pack32(pa_plan *p, const pa_vec32 *v, int mode) {
+  PA_REQUIRE(p && v, "bad arguments");
+  PA_REQUIRE(p->ctx == v->ctx, "plan and vector live on different contexts");
+  return pa_exchange_pack_raw(p, v->d, v->n_own + v->n_ghost, 1, mode);
+}
+
+extern "C" int pa_exchange_finish32(pa_plan *p, pa_vec32 *v, int mode) {
+  PA_REQUIRE(p && v, "bad arguments");
+  PA_REQUIRE(p->phase < 1 || p->elem == 4, "the exchange in flight carries a Float64 payload: finish it with pa_exchange_finish");
+  return pa_exchange_finish_raw(p, v->d, v->n_own, v->n_own + v->n_ghost, 1, mode);
 }
 
 int pa_plan_mark_arrived(pa_plan *p) {
@@ -304,7 +339,7 @@ extern "C" int pa_exchange_finish(pa_plan *p, pa_vec *v, int mode) {
   PA_REQUIRE(p && v && (mode == PA_ASSEMBLE || mode == PA_CONSISTENT), "bad arguments");
   PA_REQUIRE(p->phase >= 1 && p->mode == mode, "pa_exchange_finish without a matching pa_exchange_pack");
   PA_REQUIRE(v->n_own + v->n_ghost == p->n_local, "vector/plan size mismatch");
-  PA_REQUIRE(p->elem == 8, "the exchange in flight carries a Float32 payload (pa_exchange_pack32): finish it with pa_exchange_finish32");
+  PA_REQUIRE(p->elem == 8 && p->raw_dtype < 0, "the exchange in flight carries a Float32 / raw payload (pa_exchange_pack32, pa_exchange_pack_raw): finish it with pa_exchange_finish32 / _finish_raw");
   pa_ctx *c = p->ctx;
   if (p->snd.n == 0 && p->rcv.n == 0) {                     // nothing travels; assemble! still zeroes the ghosts (below)
     if (mode == PA_ASSEMBLE && v->n_ghost > 0) {

@@ -283,6 +283,11 @@ class DeviceVector32:
         L.call("pa_vec32_upload", self.h, L.ptr(host), int(offset), len(host))
         return self
 
+    def data_ptr(self):
+        p = C.c_void_p()
+        L.call("pa_vec32_data", self.h, C.byref(p))
+        return p.value
+
     def download(self):
         out = np.zeros(self.n_own + self.n_ghost, np.float32)
         L.call("pa_vec32_download", self.h, L.ptr(out), 0, len(out))

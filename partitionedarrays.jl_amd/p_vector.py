@@ -795,6 +795,24 @@ def exchange32_(mode, vector_partition, cache: DeviceAssemblyCache) -> Task:
     return Task(lambda: pmap(lambda v, p: L.call("pa_exchange_finish32", p, v.h, mode), vector_partition, plans))
 
 
+_DTYPES = {"f64": (0, 8), "f32": (1, 4), "i32": (2, 4), "i64": (3, 8)}
+
+
+def exchange_raw_(mode, vector_partition, cache: DeviceAssemblyCache, dtype: str) -> Task:
+    """assemble_impl! (src/p_vector.jl:587-612) on local values of another element type held in the device arrays of `vector_partition`
+    (DeviceVector: 8-byte values, DeviceVector32: 4-byte values; integers are uploaded as the bits of the float type of their width,
+    `a.view(np.float64)` / `a.view(np.float32)`): dtype in "f64", "f32", "i32", "i64".  consistent!: the bits travel; assemble!: + in
+    ascending p in the dtype's arithmetic, then ghosts := 0 (pa_exchange_pack_raw / pa_exchange_finish_raw)."""
+    code, width = _DTYPES[dtype]
+    plans = cache.plans
+    if not isinstance(plans, DebugArray) and TRANSPORT in ("torch", "host"):
+        raise L.PAError(f"raw payloads travel over the device-to-device copies of a DebugArray or over RCCL, not over the '{TRANSPORT}' staging transport")
+    pmap(lambda v, p: L.call("pa_exchange_pack_raw", p, C.c_void_p(v.data_ptr()), v.n_own + v.n_ghost, code, mode), vector_partition, plans)
+    _transport(plans, mode)
+    return Task(lambda: pmap(lambda v, p: L.call("pa_exchange_finish_raw", p, C.c_void_p(v.data_ptr()), v.n_own, v.n_own + v.n_ghost, code, mode),
+                             vector_partition, plans))
+
+
 def consistent32_(vector_partition, cache: DeviceAssemblyCache) -> Task:
     """consistent!(a) (src/p_vector.jl:747-755) on Float32 local values: ghost <- owner."""
     return exchange32_(L.CONSISTENT, vector_partition, cache)

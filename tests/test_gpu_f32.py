@@ -200,3 +200,32 @@ def test_float32_product_of_a_partitioned_matrix_through_the_float32_exchange(or
         K.spmv_csr_f32(want, xo_own, oo.rowptr, oo.colval, oo.nzval.astype(np.float32))
         K.mul5_csr_f32(want, xo_gh, oh.rowptr, oh.colval, oh.nzval.astype(np.float32), 1.0, 1.0)
         assert np.array_equal(y.download(), want) and np.any(want != 0)
+
+
+def test_integer_payloads_travel_through_the_same_plans(orc):
+    """exchange! is payload-agnostic (src/primitives.jl:1020-1042) and the reference exchanges integers at set-up (global ids, owners:
+    src/p_range.jl:436-531).  pa_exchange_pack_raw / _finish_raw on the plans of the index partition: consistent! of every part's Int64
+    global ids (own ids right, ghost ids wrong on purpose) must give each ghost its owner's id = local_to_global itself; assemble!(+) of
+    Int32 ones counts, per own value, the parts that ghost it (+ 1), against the oracle's assemble_impl! on integer arrays."""
+    from gpu_helpers import ranks
+    n = 4
+    A, _ = pa.build_p_matrix(ranks(27), n, n, n, 3 * n, 3 * n, 3 * n, 3, 3, 3)
+    Ao, _, _ = orc.hpcg_build_p_matrix(n, n, n, 3, 3, 3)
+    cols = A.col_partition
+    cache = pa.pzeros(cols).cache
+    gids = [c.local_to_global.astype(np.int64) for c in Ao.cols]
+    wrong = [g.copy() for g in gids]
+    for c, w in zip(Ao.cols, wrong):
+        w[c.ghost_to_local - 1] = -1
+    vecs = pa.pmap(lambda i, h: pa.DeviceVector(i.n_own, i.n_ghost).upload(h.view(np.float64)), cols, pa.DebugArray(wrong))
+    pa.exchange_raw_(L.CONSISTENT, vecs, cache, "i64").wait()
+    for v, g in zip(vecs.items, gids):
+        assert np.array_equal(v.download().view(np.int64), g)
+    ones = [np.ones(c.n_local, np.int32) for c in Ao.cols]
+    v32 = pa.pmap(lambda i, h: pa.DeviceVector32(i.n_own, i.n_ghost).upload(h.view(np.float32)), cols, pa.DebugArray([o.copy() for o in ones]))
+    pa.exchange_raw_(L.ASSEMBLE, v32, cache, "i32").wait()
+    orc.assemble(ones, Ao.cols)
+    for v, w in zip(v32.items, ones):
+        got = v.download().view(np.int32)
+        assert np.array_equal(got, w)
+    assert max(int(w.max()) for w in ones) == 8              # a corner node of a part is ghosted by the 7 parts around it
