@@ -145,7 +145,7 @@ def test_a_rank_lost_in_an_optional_section_does_not_cost_the_line():
     rank's section timer fires, rank 0 prints the line it has -- headline complete, `cg_loop` absent, the section named --
     and the job ends with status 0."""
     r, d = _bench(2, {"PA_TRANSPORT": "host", "PA_BENCH_BACKEND": "gloo", "PA_BENCH_FAULT": "CG loop:hang:1",
-                      "PA_BENCH_SECTION_TIMEOUT_S": "20"}, ("--no-cpu-baseline",))
+                      "PA_BENCH_SECTION_TIMEOUT_S": "10"}, ("--no-cpu-baseline",))
     assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
     assert d["value"] > 0 and "cg_loop" not in d and d["optional_sections_unfinished"] == ["CG loop"]
     assert "overlap" in d and 0 < d["roofline"]["frac"] <= 1.0
@@ -157,7 +157,7 @@ def test_a_rank_lost_in_the_fused_product_section_leaves_the_line_of_the_separat
     inside the launch -- is gated and timed.  Rank 1 never returns from that section (injected): the line goes out with the value of
     the separate launches, says so, names the section, status 0."""
     r, d = _bench(2, {"PA_TRANSPORT": "ipc", "PA_BENCH_BACKEND": "gloo", "PA_BENCH_FAULT": "fused product:hang:1",
-                      "PA_BENCH_SECTION_TIMEOUT_S": "20"}, ("--no-cpu-baseline",))
+                      "PA_BENCH_SECTION_TIMEOUT_S": "10"}, ("--no-cpu-baseline",))
     assert r.returncode == 0 and d is not None, r.stdout[-2000:] + r.stderr[-3000:]
     assert d["value"] > 0 and d["config"]["product_path"].startswith("separate launches"), d["config"]
     assert d["optional_sections_unfinished"] == ["fused product"] and "fused_ab" not in d
