@@ -501,7 +501,8 @@ def kernel_of(blk):
     lean = p.get("lean_slabs_bits" if p["mode"] == 2 else "lean_slabs", 0)
     return (f"k_spmv_pell (pattern-ELL, one lane per row; {p['slabs']} slabs of 64 rows, {p['patterns']} slab patterns in {p.get('classes', 0)} classes, "
             f"lean form in {lean} slabs, unroll {p['unroll']}; "
-            + ("fp64 value stream" if p["mode"] == 1 else "one bit per entry: a two-value dictionary") + ")")
+            + ("fp64 value stream" if p["mode"] == 1 else "one bit per entry: a two-value dictionary" if p["mode"] == 2
+               else "one byte per entry: a dictionary of 3 .. 64 values") + ")")
 
 
 def extra_configs(pa, ctx, L, out):
@@ -1465,6 +1466,50 @@ def main():
                      "bound": "neither HBM nor the vector ALU: with one bit per entry the kernel moves x, y and 16 bytes per 64 rows; SQ counters "
                               "(profiles/r06_lean_k1_sq.json, docs/LAB_NOTEBOOK.md R6.5): 171 vector + 138 scalar instructions per wavefront of 64 rows, "
                               "both pipes ~55 % busy, wavefronts waiting on their three dependent groups of gathers half of their time at 8 waves per SIMD"}
+            # the same block with SEVEN distinct values (a stencil with a handful of coefficients: anisotropic / layered media): the
+            # dictionary is renewed after eight products on the new values, then one BYTE per entry in pattern-ELL order (round 6)
+            try:
+                PHASE[0] = "value-dictionary mode: seven values"
+                os.environ.pop("PA_SPMV_VALUE_DICT", None)       # (the renewal of the dictionary reads it)
+                oo = blk2.own_own
+                table = np.array([26.0, -1.0, 0.375, -2.5, 1.0 / 3.0, 7.0, -0.125])
+                pick = np.random.default_rng(7).integers(0, len(table), 1009)
+                oo.update_values(np.resize(table[pick], oo.nnz))
+                want7 = pa.DeviceVector(n_own, 0)
+                with_env = dict(PA_SPMV_PELL_BYTES="0")
+                for _ in range(10):
+                    pa.spmv_(y2v, oo, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
+                seven = {"distinct_values": oo.value_dict(), "kernel": kernel_of(oo)}
+                for tag, sw in (("pattern_ell_one_byte", {}), ("row_split_one_byte", with_env)):
+                    os.environ.update(sw); ctx.reload_env()
+                    for _ in range(30):
+                        pa.spmv_(y2v, oo, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
+                    e0 = ctx.event().record(L.STREAM_COMPUTE)
+                    for _ in range(30):
+                        pa.spmv_(y2v, oo, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
+                    e1 = ctx.event().record(L.STREAM_COMPUTE)
+                    ctx.sync()
+                    ms7 = e0.elapsed_ms(e1) / 30
+                    mv7 = oo.stream_bytes() + 16 * n_own
+                    seven[tag] = {"ms": round(ms7, 4), "gflops": round(2.0 * nnz_oo / (ms7 * 1e-3) / 1e9, 1), "moved_bytes_per_launch": int(mv7),
+                                  "frac_moved": round(mv7 / (ms7 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "pell_mode": oo.pell()["mode"]}
+                    if tag == "pattern_ell_one_byte":
+                        pa.spmv_(want7, oo, xv, L.SEG_OWN, L.SEG_OWN, 1.0, 0.0)
+                    for k in sw:
+                        os.environ.pop(k, None)
+                    ctx.reload_env()
+                ctx.sync()
+                seven["bit_identical_products"] = bool(np.array_equal(want7.download(), y2v.download()[:n_own]))
+                seven["what"] = ("the headline block's pattern with 7 distinct values: library defaults keep one BYTE per entry in pattern-ELL order, the dictionary "
+                                 "in 512 bytes of LDS (pa_pell.h, VM 2); beside it the row-split kernel's one-byte stream (PA_SPMV_PELL_BYTES=0: what such "
+                                 "blocks ran on before)")
+                vdict["seven_values"] = seven
+                del want7
+            except Exception as e:                             # noqa: BLE001
+                print(f"[bench] seven-values extra skipped: {e}", file=sys.stderr)
+            os.environ["PA_SPMV_VALUE_DICT"] = "0"
+            os.environ.pop("PA_SPMV_PELL_BYTES", None)
+            ctx.reload_env()
             del A2, _b2, y2, blk2
         except Exception as e:                                 # noqa: BLE001
             os.environ["PA_SPMV_VALUE_DICT"] = "0"

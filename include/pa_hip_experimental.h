@@ -136,7 +136,9 @@ int pa_exchange_rccl_all(pa_plan *const *plans, pa_comm *const *comms, int32_t n
  * lane per row adds its products in stored order (spmv_csr! src/sparse_utils.jl:649-669: same bits as the row-split kernel), the
  * offsets are wave-uniform scalars, no LDS, no barrier.  PA_SPMV_PELL=0 (read per context / at block creation): the row-split kernel.
  * *mode: what a product of this block runs on NOW -- 0 row split, 1 pattern-ELL with the fp64 stream, 2 pattern-ELL with one bit per
- * entry; the other outputs describe the storage (0 when the block has none).  Any output may be NULL. */
+ * entry, 3 pattern-ELL with one BYTE per entry (a value dictionary of 3 .. 64 values: the codes in pattern-ELL order, the dictionary in
+ * 512 bytes of LDS per workgroup; PA_SPMV_PELL_BYTES=0: such blocks stay on the row-split kernel's one-byte stream); the other outputs
+ * describe the storage (0 when the block has none).  Any output may be NULL. */
 int pa_csr_pell_info(const pa_csr *A, int *mode, int64_t *n_slabs, int64_t *n_patterns, int64_t *value_slots, int *unroll);
 /* Slab CLASSES and the lean form (round 6, second step; csrc/pa_pell.h pa_pell_slab_fast).  Slabs of one union whose offsets sit in
  * the same LANES and whose row ids have the same stride (1: consecutive rows; 2: every other row of a grid line -- a colour of the

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <chrono>
+#include <cmath>
 #include <thread>
 #include <cstring>
 #include <memory>
@@ -150,6 +151,7 @@ static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
             !missing) {
           A->use_vdict = true;
           A->n_dict = P->n_dict;
+          A->dict_finite = P->dict_finite;
           return pa_pell_bits_refresh(A);
         }
       }
@@ -203,6 +205,8 @@ static int vdict_build(pa_ctx *c, pa_csr *A, bool rebuild) {
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { pa_set_err("value dictionary: encoding failed"); return done(PA_ERR_HIP); }
   A->use_vdict = true;
   A->n_dict = (int)dict.size();
+  A->dict_finite = true;
+  for (size_t k = 0; k < dict.size(); ++k) A->dict_finite = A->dict_finite && std::isfinite(dv[k]);
   return done(pa_pell_bits_refresh(A));       // (a block with pattern-ELL storage and <= 2 values: its one-bit stream again)
 }
 

@@ -91,6 +91,7 @@ static void read_switches(pa_ctx *c) {
   c->sw.vd_select = flag("PA_SPMV_VDICT_SELECT", 1);
   c->sw.pell = flag("PA_SPMV_PELL", 1);
   c->sw.pell_lean = flag("PA_SPMV_PELL_LEAN", 1);
+  c->sw.pell_bytes = flag("PA_SPMV_PELL_BYTES", 1);
   c->sw.test_skip_raise = flag("PA_TEST_FUSED_SKIP_RAISE", 0);
 }
 extern "C" int pa_ctx_reload_env(pa_ctx *c) {

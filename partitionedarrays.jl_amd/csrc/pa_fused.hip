@@ -444,7 +444,8 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double
   F.n_tail_blocks = max_tail_blocks > 0 ? std::min(F.n_tail_chunks, max_tail_blocks) : F.n_tail_chunks;
   PA_REQUIRE(n_push_blocks <= F.n_main_blocks, "more pushing blocks than own x own has chunks");
   const int n_tail = F.n_tail_blocks;
-  if (const int pm = pa_pell_mode(S)) {                      // own x own has pattern-ELL storage: its interior rows run there
+  const int pm_all = pa_pell_mode(S);
+  if (const int pm = pm_all == 3 ? 0 : pm_all) {             // own x own has pattern-ELL storage: its interior rows run there (not the one-byte stream: its dictionary lives in LDS the row-split tail owns)
     pa_pell_dev D;
     int U = 0;
     bool r3 = false;

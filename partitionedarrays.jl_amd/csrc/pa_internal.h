@@ -55,6 +55,7 @@ struct pa_switches {
   int spmv_alternate = 1;     // PA_SPMV_ALTERNATE: every other product of a block walks its chunks backwards
   int vd_select = 1;          // PA_SPMV_VDICT_SELECT: a dictionary of at most two values is decoded by a select, not through the lane dictionary
   int pell = 1;               // PA_SPMV_PELL: blocks that have pattern-ELL storage run on k_spmv_pell (0: the row-split kernel; also read at block creation)
+  int pell_bytes = 1;         // PA_SPMV_PELL_BYTES: pattern blocks whose dictionary has 3 .. 64 values run on pattern-ELL's one-byte stream (0: the row-split kernel's; also read at block creation)
   int pell_lean = 1;          // PA_SPMV_PELL_LEAN: slabs of a class run the instruction-lean form (scalar base, lane ballots, scalar bits; pa_pell.h); 0: the masked form everywhere
   int test_skip_raise = 0;    // PA_TEST_FUSED_SKIP_RAISE=k (tests only): the k-th fused product over RCCL never gets its flag raised -> its tail times out
   int chain_fused = 1;        // PA_SPMV_CHAIN_FUSED: a column-split chain is built for, and run as, one launch (k_spmv_xring_chain)
@@ -173,6 +174,7 @@ struct pa_csr {
   bool vd_captured_two = false;    // ... and through the kernel that decodes a dictionary of at most TWO values by a select (VD = 2)
   uint64_t val_epoch = 0;          // (head) bumped by every value update: what derived blocks (pa_matrix::oh_rb) compare with
   int n_dict = 0;
+  bool dict_finite = true;         // every dictionary value is finite (pattern-ELL's lean form on the one-byte stream needs it)
   uint8_t *d_code = nullptr;       // one byte per stored entry (padded)
   double *d_dict = nullptr;        // PA_VDICT_MAX values
   // x-window launch (pa_spmv_xwin.h): groups of consecutive 16-bit chunks whose x span is staged in LDS; the other chunks
@@ -208,7 +210,7 @@ int pa_pell_build(pa_csr *A);                       // at the end of a slab's cr
 void pa_pell_free(pa_csr *A);
 int pa_pell_after_update(pa_csr *A);                // behind a value update: the fp64 stream follows in place
 int pa_pell_bits_refresh(pa_csr *A);                // behind a renewal of the value dictionary: one bit per entry again (<= 2 values)
-int pa_pell_mode(const pa_csr *A);                  // 0: the row-split kernel serves; 1: pattern-ELL fp64 stream; 2: one bit per entry
+int pa_pell_mode(const pa_csr *A);                  // 0: the row-split kernel serves; 1: pattern-ELL fp64 stream; 2: one bit per entry; 3: one byte per entry
 int pa_pell_launch(const pa_csr *A, int mode, int epi, const double *x, double *y, double alpha, double beta, double *gs_x,
                    const double *gs_b, const double *gs_diag, hipStream_t st);
 int64_t pa_pell_partials(const pa_csr *A);          // EPI 3 writes one partial sum per slab

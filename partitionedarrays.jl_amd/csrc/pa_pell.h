@@ -47,7 +47,9 @@ struct pa_pell_dev {
   const unsigned *mask = nullptr;        // per stored row: which deltas of its slab's pattern it has
   const unsigned *bits = nullptr;        // VM 1: per stored row, bit k = dictionary code of the entry at delta k
   const double *val = nullptr;           // VM 0: slab-major, delta-major, lane-minor
-  const double *dict = nullptr;          // VM 1: the two values
+  const double *dict = nullptr;          // VM 1: the two values; VM 2: the dictionary (PA_VDICT_MAX values)
+  const unsigned *codes = nullptr;       // VM 2: one BYTE per entry (its dictionary code): per group of U deltas and lane ceil(U / 4) dwords,
+                                         //       group-major, lane-minor -- a wavefront's codes of a group are contiguous (768 bytes at U = 9)
   const int *row_ids = nullptr;          // row-compacted block: stored row -> row
   // slab classes (round 6, second step): table rows are then not just the union of deltas but (union, which LANES have each delta,
   // stride of the row ids), so that what was a 32-bit mask per row becomes a 64-bit lane ballot per delta and CLASS, read as scalars
@@ -77,6 +79,22 @@ __device__ __forceinline__ double pa_wave_shl1(double v, double e) {
   return __hiloint2double(hi, lo);
 }
 
+// VM 2 (round 6, third step): a block whose value dictionary has 3 .. 64 values keeps ONE BYTE per entry in pattern-ELL order; the
+// dictionary sits in 512 bytes of LDS per workgroup (staged once per launch), a value is a byte extract + one ds_read_b64.
+template <int U>
+struct pa_pell_cw { unsigned w[(U + 3) / 4]; } __attribute__((aligned(4)));
+template <int U>
+__device__ __forceinline__ pa_pell_cw<U> pa_pell_codes(const unsigned *codes, unsigned first, int k0, int lane) {
+  const size_t g = (size_t)(first + (unsigned)k0) / U;           // (first and k0 are multiples of U)
+  return *reinterpret_cast<const pa_pell_cw<U> *>(codes + (g * 64 + (size_t)lane) * ((U + 3) / 4));
+}
+template <int U>
+__device__ __forceinline__ double pa_pell_value(const pa_pell_cw<U> &c, int j, const double *sd) {      // (j: a constant after unrolling)
+  const unsigned w = c.w[j >> 2];
+  const unsigned off = (j & 3) == 0 ? (w << 3) & 0x7f8u : (w >> ((j & 3) * 8 - 3)) & 0x7f8u;             // code * 8
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(sd) + off);
+}
+
 // bit `bit` of the (scalar) word sb set ? d1 : d0 -- two scalar instructions (the compiler makes three: a 64-bit select as two halves)
 __device__ __forceinline__ double pa_uniform(double v) {        // (a wave-uniform value the compiler may hold in vector registers -> scalar)
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
@@ -101,7 +119,7 @@ __device__ __forceinline__ double pa_sel_bit_at(unsigned sb, int bit, double d0,
 template <int U, int VM, int S, int EPI, int FX, bool FULL, bool R3>
 __device__ __forceinline__ void pa_pell_slab_fast(const pa_pell_dev P, int slab, int pat, int Wp, unsigned first, int row0, unsigned sb,
                                                   const double *x, double *__restrict__ y, double *gs_x, const double *__restrict__ gs_b,
-                                                  const double *__restrict__ gs_diag, const pa_fx fx) {
+                                                  const double *__restrict__ gs_diag, const pa_fx fx, const double *sd) {
   static_assert(!R3 || U == 9, "runs of three: groups of nine");
   const int lane = threadIdx.x & 63;
   const int r = slab * 64 + lane;
@@ -131,6 +149,7 @@ __device__ __forceinline__ void pa_pell_slab_fast(const pa_pell_dev P, int slab,
   auto group = [&](auto kb_tag, int k0) {
     constexpr int KB = decltype(kb_tag)::value;
     double v[U], a[U];
+    pa_pell_cw<U> cw;
     if (VM == 0) {
       const double *g = vp + (size_t)k0 * 64;
 #pragma unroll
@@ -139,6 +158,8 @@ __device__ __forceinline__ void pa_pell_slab_fast(const pa_pell_dev P, int slab,
         v[j] = pr.x; v[j + 1] = pr.y;
       }
       if (U & 1) v[U - 1] = __builtin_nontemporal_load(g + (size_t)UE * 64 + lane);
+    } else if (VM == 2) {
+      cw = pa_pell_codes<U>(P.codes, first, k0, lane);
     }
     if constexpr (R3) {
       double ee[3], e2[3];
@@ -178,6 +199,10 @@ __device__ __forceinline__ void pa_pell_slab_fast(const pa_pell_dev P, int slab,
 #pragma unroll
         for (int j = 0; j < U; ++j) v[j] = pa_sel_bit_at(sk, j, d0, d1);
       }
+    }
+    if (VM == 2) {
+#pragma unroll
+      for (int j = 0; j < U; ++j) v[j] = pa_pell_value<U>(cw, j, sd);
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) {
@@ -222,7 +247,7 @@ __device__ __forceinline__ void pa_pell_slab_fast(const pa_pell_dev P, int slab,
 template <int U, int VM, bool COMPACT, int EPI, int FX, bool R3, bool A1 = false>
 __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, const double *__restrict__ x_in, double *__restrict__ y,
                                              double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
-                                             const double *__restrict__ gs_diag, const pa_fx fx) {
+                                             const double *__restrict__ gs_diag, const pa_fx fx, const double *sd = nullptr) {
   static_assert(!R3 || U % 9 == 0, "runs of three: unroll 9 (27 on the one-bit stream)");
   // (the clamped runs-of-three form below: consecutive rows, x not written by the launch; a row-compacted block or the Gauss-Seidel
   //  update take runs of three only in the slabs pa_pell_slab_fast serves)
@@ -253,13 +278,13 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
         const bool full = (dl[PA_PELL_T_FLAGS] & 1) != 0;
         constexpr int UF = R3 ? 9 : U;
         if (COMPACT && st == 2) {
-          if (full) pa_pell_slab_fast<UF, VM, 2, EPI, FX, true, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
-          else pa_pell_slab_fast<UF, VM, 2, EPI, FX, false, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          if (full) pa_pell_slab_fast<UF, VM, 2, EPI, FX, true, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx, sd);
+          else pa_pell_slab_fast<UF, VM, 2, EPI, FX, false, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx, sd);
           return;
         }
         if (st == 1) {
-          if (full) pa_pell_slab_fast<UF, VM, 1, EPI, FX, true, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
-          else pa_pell_slab_fast<UF, VM, 1, EPI, FX, false, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx);
+          if (full) pa_pell_slab_fast<UF, VM, 1, EPI, FX, true, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx, sd);
+          else pa_pell_slab_fast<UF, VM, 1, EPI, FX, false, R3>(P, slab, pat, Wp, (unsigned)d.y, row0, sb, x, y, gs_x, gs_b, gs_diag, fx, sd);
           return;
         }
       }
@@ -292,9 +317,13 @@ __device__ __forceinline__ void pa_pell_slab(const pa_pell_dev P, int slab, cons
         v[j] = pr.x; v[j + 1] = pr.y;
       }
       if (U & 1) v[U - 1] = __builtin_nontemporal_load(g + (size_t)UE * 64 + lane);
-    } else {
+    } else if (VM == 1) {
 #pragma unroll
       for (int j = 0; j < U; ++j) v[j] = ((vb >> (k0 + j)) & 1ull) ? d1 : d0;
+    } else {
+      const pa_pell_cw<U> cw = pa_pell_codes<U>(P.codes, (unsigned)d.y, k0, lane);
+#pragma unroll
+      for (int j = 0; j < U; ++j) v[j] = pa_pell_value<U>(cw, j, sd);
     }
 #pragma unroll
     for (int j = 0; j < U; ++j) on[j] = (m >> (k0 + j)) & 1ull;
@@ -355,6 +384,8 @@ struct pa_pell {
   int2 *d_desc = nullptr;
   int *d_pdelta = nullptr;
   unsigned *d_mask = nullptr, *d_bits = nullptr;
+  unsigned *d_codes = nullptr;                         // one byte per entry (dictionaries of 3 .. 64 values): slots / U groups x 64 lanes x ceil(U / 4) dwords
+  uint64_t codes_epoch = ~(uint64_t)0;                 // A->val_epoch the codes were made at
   unsigned long long *d_plane = nullptr;               // classes: lane ballots, n_table x PA_PELL_TW
   unsigned *d_prel = nullptr;                          // classes: byte offsets relative to the lowest delta, n_table x PA_PELL_TW
   uint2 *d_sbits = nullptr;                            // one-bit stream: per slab {bits, uniform}, and behind them the count of uniform lean slabs
@@ -374,6 +405,11 @@ template <int U, int VM, bool COMPACT, int EPI, bool R3 = false, bool A1 = false
 __global__ __launch_bounds__(256) void k_spmv_pell(const pa_pell_dev P, const double *__restrict__ x, double *__restrict__ y, int bpx,
                                                    double alpha, double beta, double *gs_x, const double *__restrict__ gs_b,
                                                    const double *__restrict__ gs_diag) {
+  __shared__ double sdict[VM == 2 ? PA_VDICT_MAX : 1];
+  if (VM == 2) {                                     // (before anyone leaves: the workgroup's copy of the dictionary)
+    if (threadIdx.x < PA_VDICT_MAX) sdict[threadIdx.x] = P.dict[threadIdx.x];
+    __syncthreads();
+  }
   const int b = blockIdx.x;
   const bool backwards = bpx < 0;
   if (backwards) bpx = -bpx;
@@ -383,7 +419,7 @@ __global__ __launch_bounds__(256) void k_spmv_pell(const pa_pell_dev P, const do
   if (backwards) g = n_groups - 1 - g;
   const int slab = __builtin_amdgcn_readfirstlane(g * 4 + (int)(threadIdx.x >> 6));
   if (slab >= P.n_slabs) return;
-  pa_pell_slab<U, VM, COMPACT, EPI, 0, R3, A1>(P, slab, x, y, alpha, beta, gs_x, gs_b, gs_diag, pa_fx());
+  pa_pell_slab<U, VM, COMPACT, EPI, 0, R3, A1>(P, slab, x, y, alpha, beta, gs_x, gs_b, gs_diag, pa_fx(), sdict);
 }
 
 #endif

@@ -148,7 +148,12 @@ __global__ __launch_bounds__(256) void kp_fill(const int *__restrict__ crp, cons
     const int k = __builtin_ctz(m);
     m &= m - 1;
     if (VM == 0) out_val[pa_pell_slot<U>(first, k, lane)] = val[p];
-    else bits |= (unsigned)(code[p] & 1) << k;
+    else if (VM == 1) bits |= (unsigned)(code[p] & 1) << k;
+    else {
+      // VM 2: the entry's dictionary code, a byte of the lane's dwords of group (first + k) / U (pa_pell_codes)
+      unsigned char *cb = reinterpret_cast<unsigned char *>(out_bits) + (((size_t)(first + (unsigned)k) / U) * 64 + (size_t)lane) * (((U + 3) / 4) * 4);
+      cb[(first + (unsigned)k) % U] = code[p];
+    }
     ++p;
   }
   if (VM == 1) {
@@ -179,14 +184,29 @@ static bool pell_wanted() {
   return !(e && atoi(e) == 0);
 }
 
-static int pell_fill(pa_csr *A, bool bits) {
+// bytes of the one-byte stream: per group of U deltas and lane ceil(U / 4) dwords (pa_pell_codes, pa_pell.h)
+static size_t pell_codes_bytes(const pa_pell *P) { return (size_t)std::max<int64_t>(P->slots / P->U, 1) * 64 * (size_t)(((P->U + 3) / 4) * 4); }
+
+static int pell_fill(pa_csr *A, bool bits, bool codes = false) {
   pa_pell *P = A->pell;
   hipStream_t s = A->ctx->s[0];
   const dim3 grid((unsigned)((P->n_slabs + 3) / 4));
 #define PA_FILL0(UU) hipLaunchKernelGGL((kp_fill<0, UU>), grid, dim3(256), 0, s, A->d_crp, A->d_val, (const unsigned char *)nullptr, P->d_mask, \
                                         P->d_desc, (int)A->n_crows, (int)P->n_slabs, P->d_val, (unsigned *)nullptr, (const double *)nullptr,   \
                                         (uint2 *)nullptr, (unsigned long long *)nullptr, (const int *)nullptr, (const int *)nullptr, 0)
-  if (bits) {
+#define PA_FILL2(UU) hipLaunchKernelGGL((kp_fill<2, UU>), grid, dim3(256), 0, s, A->d_crp, (const double *)nullptr, A->d_code, P->d_mask,      \
+                                        P->d_desc, (int)A->n_crows, (int)P->n_slabs, (double *)nullptr, P->d_codes, (const double *)nullptr,   \
+                                        (uint2 *)nullptr, (unsigned long long *)nullptr, (const int *)nullptr, (const int *)nullptr, 0)
+  if (codes) {
+    // (bytes of absent entries stay code 0: a value of the dictionary, multiplied by an x of 0.0 in the lean form, never used in the masked one)
+    PA_HIP(hipMemsetAsync(P->d_codes, 0, pell_codes_bytes(P), s));
+    switch (P->U) {
+      case 9: PA_FILL2(9); break;
+      case 7: PA_FILL2(7); break;
+      case 5: PA_FILL2(5); break;
+      default: PA_FILL2(4); break;
+    }
+  } else if (bits) {
     PA_HIP(hipMemsetAsync(P->d_sbits + P->n_slabs, 0, sizeof(unsigned long long), s));      // (the counter sits behind the last slab's pair)
     hipLaunchKernelGGL((kp_fill<1, 4>), grid, dim3(256), 0, s, A->d_crp, (const double *)nullptr, A->d_code, P->d_mask, P->d_desc, (int)A->n_crows,
                        (int)P->n_slabs, (double *)nullptr, P->d_bits, (const double *)A->d_dict, P->d_sbits,
@@ -198,8 +218,10 @@ static int pell_fill(pa_csr *A, bool bits) {
     default: PA_FILL0(4); break;
   }
 #undef PA_FILL0
+#undef PA_FILL2
   PA_HIP(hipGetLastError());
-  if (bits) P->bits_epoch = A->val_epoch;
+  if (codes) P->codes_epoch = A->val_epoch;
+  else if (bits) P->bits_epoch = A->val_epoch;
   return PA_OK;
 }
 
@@ -220,6 +242,7 @@ void pa_pell_struct_free(pa_ctx *c, pa_pell *P) {
   pa_dev_free(c, P->d_prel);
   pa_dev_free(c, P->d_sbits);
   if (P->d_bits) pa_dev_free(c, P->d_bits);
+  if (P->d_codes) pa_dev_free(c, P->d_codes);
   if (P->d_val) pa_dev_free(c, P->d_val);
   delete P;
 }
@@ -415,15 +438,20 @@ int pa_pell_build(pa_csr *A) {
     if (pa_dev_alloc(c, (void **)&P->d_val, sizeof(double) * (size_t)std::max<int64_t>(slots, 1) * 64, PA_MEM_MATRIX)) return give_up("no room");
     if (hipMemsetAsync(P->d_val, 0, sizeof(double) * (size_t)std::max<int64_t>(slots, 1) * 64, s) != hipSuccess) return give_up("memset failed");
   } else {
-    return give_up("a dictionary of more than two values: the row-split kernel's one-byte stream serves");
+    // a dictionary of 3 .. 64 values: one BYTE per entry in pattern-ELL order (round 6, third step; PA_SPMV_PELL_BYTES=0: the row-split
+    // kernel's one-byte stream serves such blocks as before)
+    const char *eb = getenv("PA_SPMV_PELL_BYTES");
+    if (eb && atoi(eb) == 0) return give_up("a dictionary of more than two values: the row-split kernel's one-byte stream serves (PA_SPMV_PELL_BYTES=0)");
+    if (pa_dev_alloc(c, (void **)&P->d_codes, pell_codes_bytes(P), PA_MEM_MATRIX)) return give_up("no room");
   }
-  if (pell_fill(A, two) != PA_OK || hipStreamSynchronize(s) != hipSuccess) return give_up("fill failed");
+  const bool bytes = P->d_codes != nullptr;
+  if (pell_fill(A, two, bytes) != PA_OK || hipStreamSynchronize(s) != hipSuccess) return give_up("fill failed");
   if (two) pell_read_lean_bits(A);
   if (getenv("PA_SETUP_TIMING"))
     fprintf(stderr, "[pa setup] pattern-ELL of %lld entries: %lld slabs, %lld patterns, %lld classes, lean form in %lld slabs, width <= %d, unroll %d, %lld slots (%.3f x the entries), %s%s, %.3f ms\n",
             (long long)A->nnz, (long long)P->n_slabs, (long long)P->n_patterns, (long long)P->n_classes, (long long)(two ? P->n_lean_bits : P->n_lean),
             P->max_w, P->U, (long long)slots * 64, slots * 64.0 / A->nnz,
-            P->runs3 ? "runs of three, " : "", two ? "one bit per entry" : "fp64 stream",
+            P->runs3 ? "runs of three, " : "", two ? "one bit per entry" : bytes ? "one byte per entry" : "fp64 stream",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   return PA_OK;
 }
@@ -439,7 +467,24 @@ int pa_pell_after_update(pa_csr *A) {
 // made again from the codes, on the compute stream, complete when this returns (the next product may run on the comm stream)
 int pa_pell_bits_refresh(pa_csr *A) {
   pa_pell *P = A->pell;
-  if (!P || !A->use_vdict || A->n_dict > 2) return PA_OK;
+  if (!P || !A->use_vdict) return PA_OK;
+  // 3 .. 64 values: the one-byte stream again (made at creation when the block had such a dictionary then; a block that got its
+  // dictionary later gets the stream here, outside captures).  A stream that exists follows EVERY renewal, also one that left two
+  // values or fewer: a recorded graph may still replay the one-byte kernel, and codes + dictionary of any size give it the new values.
+  const char *eb = getenv("PA_SPMV_PELL_BYTES");
+  const bool bytes_on = !(eb && atoi(eb) == 0);
+  if (bytes_on && (A->n_dict > 2 || P->d_codes)) {
+    if (!P->d_codes) {
+      if (A->ctx->capturing) return PA_OK;
+      if (pa_dev_alloc(A->ctx, (void **)&P->d_codes, pell_codes_bytes(P), PA_MEM_MATRIX) != PA_OK) { (void)hipGetLastError(); P->d_codes = nullptr; return PA_OK; }
+    }
+    PA_TRY(pell_fill(A, false, true));
+    if (A->n_dict > 2) {
+      if (!A->ctx->capturing) PA_HIP(hipStreamSynchronize(A->ctx->s[0]));
+      return PA_OK;
+    }
+  }
+  if (A->n_dict > 2) return PA_OK;
   if (!P->d_bits) {
     if (A->ctx->capturing) return PA_OK;
     if (pa_dev_alloc(A->ctx, (void **)&P->d_bits, sizeof(unsigned) * (size_t)A->n_crows, PA_MEM_MATRIX) != PA_OK) { (void)hipGetLastError(); P->d_bits = nullptr; return PA_OK; }
@@ -458,11 +503,12 @@ int pa_pell_bits_refresh(pa_csr *A) {
   return PA_OK;
 }
 
-// 0: the row-split kernel serves; 1: fp64 stream; 2: one bit per entry
+// 0: the row-split kernel serves; 1: fp64 stream; 2: one bit per entry; 3: one byte per entry
 int pa_pell_mode(const pa_csr *A) {
   const pa_pell *P = A->pell;
   if (!P || A->alpha_inside || A->accumulate || !A->ctx->sw.pell) return 0;
   if (P->d_bits && A->use_vdict && !A->vdict_stale && A->n_dict <= 2 && P->bits_epoch == A->val_epoch) return 2;
+  if (P->d_codes && A->use_vdict && !A->vdict_stale && A->n_dict > 2 && P->codes_epoch == A->val_epoch && A->ctx->sw.pell_bytes) return 3;
   return P->d_val ? 1 : 0;
 }
 
@@ -471,8 +517,9 @@ static pa_pell_dev pell_dev(const pa_csr *A, int mode) {
   pa_pell_dev D;
   D.desc = P->d_desc; D.pdelta = P->d_pdelta; D.mask = P->d_mask; D.bits = P->d_bits; D.val = P->d_val; D.dict = A->d_dict;
   D.row_ids = A->d_row_ids; D.n_slabs = (int)P->n_slabs; D.n_crows = (int)A->n_crows; D.n_cols = (int)A->n_cols;
-  D.plane = A->ctx->sw.pell_lean ? P->d_plane : nullptr; D.prel = P->d_prel; D.sbits = P->d_sbits;
-  (void)mode;
+  D.plane = A->ctx->sw.pell_lean ? P->d_plane : nullptr; D.prel = P->d_prel; D.sbits = P->d_sbits; D.codes = P->d_codes;
+  // (one byte per entry: the lean form multiplies an absent entry's value -- code 0's -- by an x of 0.0: every dictionary value must be finite)
+  if (mode == 3 && !A->dict_finite) D.plane = nullptr;
   return D;
 }
 
@@ -513,7 +560,8 @@ template <int EPI>
 static void pell_launch_epi(const pa_csr *A, int mode, const pa_pell_dev &D, int nblk, int bpx, const double *x, double *y, double alpha,
                             double beta, double *gs_x, const double *gs_b, const double *gs_diag, hipStream_t st) {
 #define PA_PELL_U(UU)                                                                                        \
-  if (mode == 2) pell_launch_uv<UU, 1, EPI>(A, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st);   \
+  if (mode == 3) pell_launch_uv<UU, 2, EPI>(A, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st);   \
+  else if (mode == 2) pell_launch_uv<UU, 1, EPI>(A, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st);   \
   else pell_launch_uv<UU, 0, EPI>(A, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st)
   switch (A->pell->U) {
     case 9: PA_PELL_U(9); break;
@@ -537,6 +585,7 @@ int pa_pell_launch(const pa_csr *A, int mode, int epi, const double *x, double *
   const int nblk = bpx * 8;
   if (A->ctx->sw.spmv_alternate && epi == 0 && ((P->n_launched++) & 1)) bpx = -bpx;
   if (mode == 2 && A->ctx->capturing) { const_cast<pa_csr *>(A)->vd_captured = true; const_cast<pa_csr *>(A)->vd_captured_two = true; }
+  if (mode == 3 && A->ctx->capturing) const_cast<pa_csr *>(A)->vd_captured = true;
   switch (epi) {
     case 0: pell_launch_epi<0>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
     case 1: pell_launch_epi<1>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
@@ -561,11 +610,11 @@ int64_t pa_pell_stream_bytes(const pa_csr *A, int mode) {
   // (the lean form reads neither the row masks nor, on the one-bit stream, the rows' bits: its slabs cost their descriptor, the
   //  class table and 8 bytes of slab bits)
   const bool lean_on = A->ctx->sw.pell_lean && P->d_plane;
-  const int64_t lean = !lean_on ? 0 : mode == 2 ? P->n_lean_bits : P->n_lean;
+  const int64_t lean = !lean_on || (mode == 3 && !A->dict_finite) ? 0 : mode == 2 ? P->n_lean_bits : P->n_lean;
   const int64_t rows_masked = std::max<int64_t>(0, A->n_crows - 64 * lean);
   int64_t t = 8 * P->n_slabs + 4 * P->n_table * PA_PELL_TW + 4 * rows_masked;
   if (lean_on) t += 12 * P->n_table * PA_PELL_TW;
-  t += mode == 2 ? 4 * rows_masked + 8 * P->n_slabs + 16 : 8 * 64 * P->slots;
+  t += mode == 2 ? 4 * rows_masked + 8 * P->n_slabs + 16 : mode == 3 ? (int64_t)pell_codes_bytes(P) + 8 * PA_VDICT_MAX : 8 * 64 * P->slots;
   if (A->compact) t += 4 * rows_masked + (lean ? 4 * lean : 0);
   return t;
 }

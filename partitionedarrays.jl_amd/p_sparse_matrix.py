@@ -139,7 +139,8 @@ class DeviceCSR:
 
     def pell(self):
         """Pattern-ELL storage of the block (pa_csr_pell_info, csrc/pa_pell.hip): mode = what a product runs on now (0 row split,
-        1 pattern-ELL fp64 stream, 2 pattern-ELL one bit per entry), slabs of 64 rows, distinct slab patterns, value slots, unroll."""
+        1 pattern-ELL fp64 stream, 2 pattern-ELL one bit per entry, 3 pattern-ELL one byte per entry), slabs of 64 rows, distinct slab
+        patterns, value slots, unroll, slab classes and the slabs the lean form serves."""
         mode, unroll = C.c_int(), C.c_int()
         v = [C.c_int64() for _ in range(3)]
         L.call("pa_csr_pell_info", self.h, C.byref(mode), *[C.byref(x) for x in v], C.byref(unroll))

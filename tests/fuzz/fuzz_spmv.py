@@ -77,7 +77,7 @@ for case in range(n_cases):
         xw, enc = A.xwin(), A.encoding()
         if sw is None:
             pm = A.pell()
-            cover["pattern_ell_" + ("none", "fp64", "one_bit")[pm["mode"]]] = cover.get("pattern_ell_" + ("none", "fp64", "one_bit")[pm["mode"]], 0) + (law >= 6)
+            cover["pattern_ell_" + ("none", "fp64", "one_bit", "one_byte")[pm["mode"]]] = cover.get("pattern_ell_" + ("none", "fp64", "one_bit", "one_byte")[pm["mode"]], 0) + (law >= 6)
             cover["pattern_ell_unroll_%d" % pm["unroll"]] = cover.get("pattern_ell_unroll_%d" % pm["unroll"], 0) + (pm["mode"] > 0)
             cover["default_windows"] += xw["groups"] > 0
             cover["default_big_windows"] += xw["big_groups"] > 0
