@@ -220,3 +220,32 @@ def test_the_one_byte_stream_follows_value_updates_and_an_infinite_dictionary_va
         info = _check(orc, H2, x, "inf in a dictionary of five", expect_mode=3)
         A2 = pa.DeviceCSR(H2)
         assert A2.pell()["mode"] == 3
+
+
+def test_product_and_dot_in_one_launch_on_the_one_byte_stream(orc):
+    """The epilogue forms run on every value stream of the pattern-ELL kernel: pa_mul_dot (product + this slab's term of u'c, EPI 3) on a
+    few-valued 27-point block -- c equals the plain product's and the oracle's bits, the dot agrees with the host's to rounding, the
+    same on the fp64 stream and on the row-split kernel."""
+    import pa_amd.p_sparse_matrix as psm
+    H = _stencil27(128, 6, 5, few=6)
+    m = H.m
+    ind = pa.uniform_partition(ranks(1), m)
+    uh = np.random.default_rng(29).standard_normal(m)
+    Ho = orc.CSR(H.m, H.n, H.rowptr, H.colval, H.nzval)
+    want = np.zeros(m); orc.oracle_c().spmv_csr(want, uh, Ho)
+    dots = {}
+    for tag, sw, mode in (("one byte", {"PA_SPMV_VALUE_DICT": "1"}, 3), ("fp64", {"PA_SPMV_VALUE_DICT": "0"}, 1), ("row split", {"PA_SPMV_VALUE_DICT": "1", "PA_SPMV_PELL": "0"}, 0)):
+        with env(**sw):
+            blk = pa.DeviceCSR(H)
+            assert blk.pell()["mode"] == mode, (tag, blk.pell())
+            empty = pa.DeviceCSR(pa.HostCSR(m, 0, np.ones(m + 1, np.int32), np.zeros(0, np.int32), np.zeros(0)))
+            Ah = pa.PSparseMatrix(pa.DebugArray([psm.SplitMatrixBlocks(blk, empty)]), ind, ind, True)
+            u = pa.pvector_from_function(lambda i: uh, ind)
+            c = pa.pzeros(ind)
+            assert psm.mul_dot_(c, Ah, u, 5)
+            assert np.array_equal(c.own_values().items[0], want), tag
+            dots[tag] = pa.read_slots(5)[0]
+            assert abs(dots[tag] - float(uh @ want)) <= 1e-12 * max(1.0, abs(float(uh @ want))), tag
+    # (the dots agree to rounding, not bit for bit: u'c is summed per slab on pattern-ELL launches and per chunk where the product of a
+    #  part runs as the fused launch's row-split form -- which the one-byte stream does)
+    assert abs(dots["one byte"] - dots["fp64"]) <= 1e-12 * abs(dots["fp64"])
