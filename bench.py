@@ -803,8 +803,8 @@ def extra_configs(pa, ctx, L, out):
         entry_mg["with_default_value_dictionary"] = {"ms_per_iteration": round((time.perf_counter() - t) / 30 * 1e3, 3), "pc_setup_s": round(ts, 2),
                                                      "iterations": int(itb),
                                                      "residual_rel_diff_vs_fp64_stream": float(abs(rb - r) / max(abs(r), 1e-300)),
-                                                     "note": "same products, same bits of every vector; with a dictionary the fused u'c of "
-                                                             "opt_cg_ is a separate pass (another summation order of the dot), hence the last digits"}
+                                                     "note": "same products, same bits of every vector; the fused u'c of opt_cg_ runs on pattern-ELL's bit / byte "
+                                                             "streams too (round 6; blocks on the row-split kernel's one-byte stream take a dot pass of their own)"}
     finally:
         os.environ["PA_SPMV_VALUE_DICT"] = "0"
     return out

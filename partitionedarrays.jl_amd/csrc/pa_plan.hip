@@ -786,8 +786,9 @@ static int64_t chunks_of(const pa_csr *A) {             // partial sums a fused 
   for (const pa_csr *S = A; S; S = S->next) n += pa_pell_mode(S) ? pa_pell_partials(S) : S->n_chunks;
   return n;
 }
-static bool has_vdict(const pa_csr *A) {
-  for (const pa_csr *S = A; S; S = S->next) if (S->use_vdict) return true;
+static bool has_vdict(const pa_csr *A) {             // a slab on the ROW-SPLIT kernel's one-byte stream (it has no product + dot form; pattern-ELL's
+  for (const pa_csr *S = A; S; S = S->next)            // bit and byte streams do: pa_pell_launch, epilogue 3)
+    if (S->use_vdict && (S->vdict_stale || pa_pell_mode(S) == 0)) return true;      // (stale: pa_spmv counts the products towards the renewal)
   return false;
 }
 

@@ -234,7 +234,9 @@ def test_product_and_dot_in_one_launch_on_the_one_byte_stream(orc):
     Ho = orc.CSR(H.m, H.n, H.rowptr, H.colval, H.nzval)
     want = np.zeros(m); orc.oracle_c().spmv_csr(want, uh, Ho)
     dots = {}
-    for tag, sw, mode in (("one byte", {"PA_SPMV_VALUE_DICT": "1"}, 3), ("fp64", {"PA_SPMV_VALUE_DICT": "0"}, 1), ("row split", {"PA_SPMV_VALUE_DICT": "1", "PA_SPMV_PELL": "0"}, 0)):
+    for tag, sw, mode in (("one byte", {"PA_SPMV_VALUE_DICT": "1"}, 3), ("fp64", {"PA_SPMV_VALUE_DICT": "0"}, 1), ("row split", {"PA_SPMV_VALUE_DICT": "1", "PA_SPMV_PELL": "0"}, 0),
+                          ("one byte, separate launches", {"PA_SPMV_VALUE_DICT": "1", "PA_MUL_FUSED": "0"}, 3),
+                          ("fp64, separate launches", {"PA_SPMV_VALUE_DICT": "0", "PA_MUL_FUSED": "0"}, 1)):
         with env(**sw):
             blk = pa.DeviceCSR(H)
             assert blk.pell()["mode"] == mode, (tag, blk.pell())
@@ -246,6 +248,7 @@ def test_product_and_dot_in_one_launch_on_the_one_byte_stream(orc):
             assert np.array_equal(c.own_values().items[0], want), tag
             dots[tag] = pa.read_slots(5)[0]
             assert abs(dots[tag] - float(uh @ want)) <= 1e-12 * max(1.0, abs(float(uh @ want))), tag
-    # (the dots agree to rounding, not bit for bit: u'c is summed per slab on pattern-ELL launches and per chunk where the product of a
-    #  part runs as the fused launch's row-split form -- which the one-byte stream does)
-    assert abs(dots["one byte"] - dots["fp64"]) <= 1e-12 * abs(dots["fp64"])
+    # the product + dot form of k_spmv_pell on both streams: the same slabs, the same partial sums (dictionary blocks on the row-split
+    # kernel's one-byte stream take the plain product and a dot pass of its own: another summation order)
+    assert dots["one byte"] == dots["fp64"] and dots["one byte, separate launches"] == dots["fp64, separate launches"]
+    assert abs(dots["row split"] - dots["fp64"]) <= 1e-12 * abs(dots["fp64"])
