@@ -359,6 +359,11 @@ __global__ __launch_bounds__(256) void k_mul_fused_pell(const pa_pell_dev P, con
   __shared__ __attribute__((aligned(16))) double prod[BLK * NPT];
   __shared__ double wsum[1];
   __shared__ int ok;
+  __shared__ double sdict[VM == 2 ? PA_VDICT_MAX : 1];
+  if (VM == 2) {                                     // (one byte per entry: the workgroup's copy of the dictionary, before anyone leaves)
+    if (threadIdx.x < PA_VDICT_MAX) sdict[threadIdx.x] = P.dict[threadIdx.x];
+    __syncthreads();
+  }
   const int b = blockIdx.x;
   if (b >= F.n_main_blocks) {
     const int tb = b - F.n_main_blocks;
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256) void k_mul_fused_pell(const pa_pell_dev P, con
   if (slab >= P.n_slabs) return;
   pa_fx fx;
   fx.rowmask = F.rowmask;
-  pa_pell_slab<U, VM, false, 0, 1, R3, A1>(P, slab, x, y, alpha, beta, nullptr, nullptr, nullptr, fx);
+  pa_pell_slab<U, VM, false, 0, 1, R3, A1>(P, slab, x, y, alpha, beta, nullptr, nullptr, nullptr, fx, sdict);
 }
 
 // own(c) = beta*own(c) + alpha*(A_oo*own(b) + A_oh*ghost(b)) of one part in one launch on stream st.  comm == NULL: the receive
@@ -444,8 +449,7 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double
   F.n_tail_blocks = max_tail_blocks > 0 ? std::min(F.n_tail_chunks, max_tail_blocks) : F.n_tail_chunks;
   PA_REQUIRE(n_push_blocks <= F.n_main_blocks, "more pushing blocks than own x own has chunks");
   const int n_tail = F.n_tail_blocks;
-  const int pm_all = pa_pell_mode(S);
-  if (const int pm = pm_all == 3 ? 0 : pm_all) {             // own x own has pattern-ELL storage: its interior rows run there (not the one-byte stream: its dictionary lives in LDS the row-split tail owns)
+  if (const int pm = pa_pell_mode(S)) {                      // own x own has pattern-ELL storage: its interior rows run there
     pa_pell_dev D;
     int U = 0;
     bool r3 = false;
@@ -458,6 +462,7 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double
       PA_REQUIRE(n_push_blocks <= F.n_main_blocks, "more pushing blocks than own x own has slab groups");
       if (m->ctx->sw.spmv_alternate && ((const_cast<pa_csr *>(S)->n_launched++) & 1)) bpx = -bpx;
       if (pm == 2 && m->ctx->capturing) { const_cast<pa_csr *>(S)->vd_captured = true; const_cast<pa_csr *>(S)->vd_captured_two = true; }
+      if (pm == 3 && m->ctx->capturing) const_cast<pa_csr *>(S)->vd_captured = true;
       // (runs of three with alpha = 1 -- mul!(c,a,b) -- compiled in: the interior rows' lean form, pa_pell_slab_fast)
 #define PA_LAUNCH_FP(UU, VM, R3, XCH)                                                                                                       \
   do {                                                                                                                                      \
@@ -469,9 +474,9 @@ int pa_mul_fused_launch(pa_matrix *m, pa_vec *c, pa_vec *b, double alpha, double
                          (const double *)b->d, c->d, bpx, alpha, beta, F);                                                                  \
   } while (0)
 #define PA_FP_CASES(XCH)                                                                              \
-      if (U == 7) { if (pm == 2) PA_LAUNCH_FP(7, 1, false, XCH); else PA_LAUNCH_FP(7, 0, false, XCH); } \
-      else if (r3) { if (pm == 2) PA_LAUNCH_FP(9, 1, true, XCH); else PA_LAUNCH_FP(9, 0, true, XCH); }   \
-      else { if (pm == 2) PA_LAUNCH_FP(9, 1, false, XCH); else PA_LAUNCH_FP(9, 0, false, XCH); }
+      if (U == 7) { if (pm == 3) PA_LAUNCH_FP(7, 2, false, XCH); else if (pm == 2) PA_LAUNCH_FP(7, 1, false, XCH); else PA_LAUNCH_FP(7, 0, false, XCH); } \
+      else if (r3) { if (pm == 3) PA_LAUNCH_FP(9, 2, true, XCH); else if (pm == 2) PA_LAUNCH_FP(9, 1, true, XCH); else PA_LAUNCH_FP(9, 0, true, XCH); }   \
+      else { if (pm == 3) PA_LAUNCH_FP(9, 2, false, XCH); else if (pm == 2) PA_LAUNCH_FP(9, 1, false, XCH); else PA_LAUNCH_FP(9, 0, false, XCH); }
       if (comm) { PA_FP_CASES(true) } else { PA_FP_CASES(false) }
 #undef PA_FP_CASES
 #undef PA_LAUNCH_FP

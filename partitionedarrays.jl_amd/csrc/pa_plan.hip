@@ -807,6 +807,7 @@ static int dot_finish(pa_ctx *c, int64_t n_partials, int slot, int accumulate) {
 
 static int mul_dot_part(pa_matrix *m, pa_vec *cv, pa_vec *b, int slot, int accumulate, bool first_half, bool second_half) {
   pa_ctx *c = m->ctx;
+  if (first_half) pa_csr_before_product(m->oo);        // (a block whose values were updated counts its products towards its dictionary's renewal)
   const int64_t noo = chunks_of(m->oo), noh = chunks_of(m->oh);
   if (has_vdict(m->oo) || has_vdict(m->oh)) {       // (value-dictionary blocks: the plain product, then the dot as its own pass)
     if (first_half) PA_TRY(pa_spmv(m->oo, b, PA_SEG_OWN, cv, PA_SEG_OWN, 1.0, 0.0));

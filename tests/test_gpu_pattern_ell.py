@@ -252,3 +252,35 @@ def test_product_and_dot_in_one_launch_on_the_one_byte_stream(orc):
     # kernel's one-byte stream take the plain product and a dot pass of its own: another summation order)
     assert dots["one byte"] == dots["fp64"] and dots["one byte, separate launches"] == dots["fp64, separate launches"]
     assert abs(dots["row split"] - dots["fp64"]) <= 1e-12 * abs(dots["fp64"])
+
+
+def test_mul_of_a_partitioned_matrix_whose_own_blocks_run_on_the_one_byte_stream(orc):
+    """mul!(c,A,b) (src/p_sparse_matrix.jl:2090-2103) of 2 parts as ONE launch per part (pa_mul_all: the interior rows on the pattern-ELL
+    kernel inside the fused launch, the boundary rows as its tail) after the own x own blocks got six distinct values: the dictionary is
+    renewed after eight products, the interior rows then read one byte per entry with the dictionary in LDS; every product equals the
+    oracle's mul! on the same values, bit for bit -- before the renewal (fp64 row split), after it, and as separate launches."""
+    Ao, _, _ = orc.hpcg_build_p_matrix(64, 6, 6, 2, 1, 1)
+    table = np.array([26.0, -1.0, 0.375, -0.0, 2.5, -3.5e10])
+    with env(PA_SPMV_VALUE_DICT="1"):
+        A, _ = pa.build_p_matrix(ranks(2), 64, 6, 6, 128, 6, 6, 2, 1, 1)      # (two values: a dictionary, one bit per entry)
+        assert A.matrix_partition.items[0].own_own.pell()["mode"] == 2
+        for blk, bo in zip(A.matrix_partition.items, Ao.blocks):
+            new = table[(np.arange(bo.own_own.nzval.size) * 31) % len(table)]
+            bo.own_own.nzval[:] = new
+            blk.own_own.update_values(new)
+        xo = [orc.hash_x(c.local_to_global) * (c.local_to_owner == c.part) for c in Ao.cols]
+        from gpu_helpers import upload, oracle_mul
+        x = upload([v.copy() for v in xo], A.col_partition)
+        want = oracle_mul(orc, Ao, xo)
+        y = pa.pzeros(A.row_partition)
+        modes = []
+        for rep in range(12):
+            pa.mul_(y, A, x)
+            for got, exp, r in zip(y.own_values().items, want, Ao.rows):
+                assert np.array_equal(got, exp[:r.n_own]), rep
+            modes.append(A.matrix_partition.items[0].own_own.pell()["mode"])
+        assert modes[0] != 3 and modes[-1] == 3, modes
+        with env(PA_MUL_FUSED="0"):
+            pa.mul_(y, A, x)
+            for got, exp, r in zip(y.own_values().items, want, Ao.rows):
+                assert np.array_equal(got, exp[:r.n_own])
