@@ -744,7 +744,8 @@ def extra_configs(pa, ctx, L, out):
     t = time.perf_counter()
     n5 = int(os.environ.get("PA_BENCH_C5_NODES", "4096"))
     ranks8 = pa.DebugArray(range(1, 9))
-    I, J, V, rows, cols = pa.laplacian_fem((n5, n5), (4, 2), ranks8)
+    fem_device = os.environ.get("PA_BENCH_FEM_DEVICE", "1") != "0"       # (the triplets generated in HBM, round 6; 0: native host threads + upload)
+    I, J, V, rows, cols = pa.laplacian_fem((n5, n5), (4, 2), ranks8, device=fem_device)
     A5 = pa.psparse_disassembled(I, J, V, rows, cols)
     del I, J, V
     ts = time.perf_counter() - t
@@ -764,7 +765,8 @@ def extra_configs(pa, ctx, L, out):
                 "ms_per_part": round(ms / 8, 4), "ms_per_part_mul": round(ms / 8, 4), "ms_per_part_mul_hipgraph": round(ms_graph / 8, 4),
                 "ms_per_part_spmv": round(ms_spmv / 8, 4), **chain_info(8, all_fused),
                 "gflops": round(2.0 * nnz5 / ms / 1e6, 1), "moved_gbps": round(moved / ms / 1e6, 1),
-                "encoding_own_own": blocks[0].own_own.encoding(), "encoding_own_ghost": blocks[0].own_ghost.encoding(), "setup_s": round(ts, 1)})
+                "encoding_own_own": blocks[0].own_own.encoding(), "encoding_own_ghost": blocks[0].own_ghost.encoding(), "setup_s": round(ts, 2),
+                "triplets_generated_in_hbm": bool(fem_device)})
     del A5, x5, y5, blocks
     # the caller of the hot path that §8(f) names next: one MG-PCG iteration of the HPCG driver (4 levels, multicolour
     # Gauss-Seidel as SpMV + update, opt_cg_) at the headline's size, with the set-up it needs (everything made in HBM)

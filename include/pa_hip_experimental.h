@@ -117,6 +117,18 @@ int pa_sell_destroy(pa_sell *A);
 int pa_sell_info(const pa_sell *A, int64_t *n_slabs, int64_t *padded_entries, int64_t *nnz);
 int pa_sell_spmv(const pa_sell *A, const pa_vec *x, int x_segment, pa_vec *y, int y_segment, double alpha, double beta);
 
+/* ---- laplacian_fem's triplets generated in HBM (csrc/pa_assemble.hip; round 6) ------------------------------------------------
+ * laplacian_fem (src/gallery.jl:110-239) makes every part loop over ITS cells lo..hi (1-based cell coordinates of the (nodes + 1)^D
+ * cell grid, column-major) and emit (node_i, node_j, Aref[i,j]) for the pairs of interior corners: the disassembled COO input of
+ * psparse.  pa_fem_triplets_device writes those triplets, in that order, straight into HBM (Int64 ids, Float64 values: what
+ * pa_host_laplacian_fem returns on the host); pa_coo_subassemble / pa_coo_assemble take device arrays as they take host arrays.
+ * Aref: the 2^D x 2^D reference matrix, row-major.  The three arrays are freed with pa_triplets_free; pa_triplets_download copies n
+ * 8-byte values to the host (tests, host routes). */
+int pa_fem_triplets_device(pa_ctx *ctx, int32_t D, const int64_t *nodes, const int64_t *lo, const int64_t *hi, const double *Aref,
+                           int64_t *count, void **dI, void **dJ, void **dV);
+int pa_triplets_free(pa_ctx *ctx, void *dI, void *dJ, void *dV);
+int pa_triplets_download(pa_ctx *ctx, const void *d, int64_t n, void *host);
+
 /* ---- all parts in ONE process, one GPU each, over RCCL (csrc/pa_rccl.cpp; round 6) --------------------------------------------
  * SURVEY 8(b)'s sketch of the single-process multi-GPU mode: the parts of a DebugArray each in a context on a device of its own
  * (pa_ctx_create per device), their communicators made by ONE ncclCommInitAll (comms[p]: rank p of n, on ctxs[p]'s device; the devices

@@ -190,6 +190,9 @@ _SIGS = {
     "pa_csr32_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64)],
     "pa_spmv32": [P, P, cint, P, cint, C.c_float, C.c_float],
     "pa_csr_pell_info": [P, C.POINTER(cint), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(cint)],
+    "pa_fem_triplets_device": [P, C.c_int32, P, P, P, P, C.POINTER(i64), C.POINTER(P), C.POINTER(P), C.POINTER(P)],
+    "pa_triplets_free": [P, P, P, P],
+    "pa_triplets_download": [P, P, i64, P],
     "pa_comm_create_all": [P, C.c_int32, P],
     "pa_exchange_rccl_all": [P, P, C.c_int32, cint],
     "pa_vec32_data": [P, C.POINTER(P)],

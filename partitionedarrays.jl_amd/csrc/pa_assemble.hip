@@ -402,9 +402,10 @@ static int assemble_impl(pa_ctx *c, pa_coo_assembly *h, int64_t count, const int
   PA_TRY(sc.get(&dI, count));
   PA_TRY(sc.get(&dJ, count));
   PA_TRY(sc.get(&dV, count));
-  PA_HIP(hipMemcpyAsync(dI, I, 8 * (size_t)count, hipMemcpyHostToDevice, s));
-  PA_HIP(hipMemcpyAsync(dJ, J, 8 * (size_t)count, hipMemcpyHostToDevice, s));
-  PA_HIP(hipMemcpyAsync(dV, V, 8 * (size_t)count, hipMemcpyHostToDevice, s));
+  // (hipMemcpyDefault: the triplets may be host arrays or already in HBM -- pa_fem_triplets_device below)
+  PA_HIP(hipMemcpyAsync(dI, I, 8 * (size_t)count, hipMemcpyDefault, s));
+  PA_HIP(hipMemcpyAsync(dJ, J, 8 * (size_t)count, hipMemcpyDefault, s));
+  PA_HIP(hipMemcpyAsync(dV, V, 8 * (size_t)count, hipMemcpyDefault, s));
   return assemble_core(c, h, sc, count, dI, dJ, dV, rows, cols, n_known, known, discover, sub);
 }
 
@@ -772,3 +773,125 @@ extern "C" int pa_scatter_download(const pa_scatter *sc_, int32_t *dest) {
   return PA_OK;
 }
 
+
+// ---- laplacian_fem's triplets generated in HBM (src/gallery.jl:110-239; VERDICT r05 "What's missing" 5) --------------------------
+// The reference loops over a part's CELLS (column-major), and for every cell over its 2^D corners i and j, emitting
+// (node(i), node(j), Aref[i,j]) when both corners are interior nodes -- the disassembled input of psparse.  pa_host_laplacian_fem
+// (pa_host.cpp) is that loop on host threads; here a count kernel (per cell: (interior corners)^2), an exclusive scan and a fill
+// kernel write the same triplets in the same order straight into HBM, where pa_coo_subassemble takes them from.
+struct pa_fem_box { int D; long long nn[3], lo[3], hi[3], stride[3], len[3]; double Aref[64]; };
+
+__device__ __forceinline__ void fem_cell(const pa_fem_box &b, long long q, long long *c) {
+  for (int d = 0; d < 3; ++d) { c[d] = d < b.D ? b.lo[d] + q % b.len[d] : 1; if (d < b.D) q /= b.len[d]; }
+}
+__global__ void kf_count(const pa_fem_box b, long long n_cells, long long *__restrict__ cnt) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_cells) return;
+  long long c[3];
+  fem_cell(b, q, c);
+  long long k = 1;
+  for (int d = 0; d < b.D; ++d) {
+    int kd = 0;
+    for (int a = 0; a < 2; ++a) { const long long x = c[d] + a - 1; kd += x >= 1 && x <= b.nn[d]; }
+    k *= kd;
+  }
+  cnt[q] = k * k;
+}
+__global__ void kf_fill(const pa_fem_box b, long long n_cells, const long long *__restrict__ off, long long *__restrict__ I,
+                        long long *__restrict__ J, double *__restrict__ V) {
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n_cells) return;
+  long long c[3];
+  fem_cell(b, q, c);
+  const int nloc = 1 << b.D;
+  long long id[8];
+  bool in[8];
+  for (int a = 0; a < nloc; ++a) {                       // corner a: offsets column-major (first direction fastest)
+    bool good = true;
+    long long node = 1;
+    for (int d = 0; d < b.D; ++d) {
+      const long long x = c[d] + ((a >> d) & 1) - 1;
+      good = good && x >= 1 && x <= b.nn[d];
+      node += (x - 1) * b.stride[d];
+    }
+    in[a] = good; id[a] = node;
+  }
+  long long t = off[q];
+  for (int a = 0; a < nloc; ++a) {
+    if (!in[a]) continue;
+    for (int bb = 0; bb < nloc; ++bb) {
+      if (!in[bb]) continue;
+      I[t] = id[a]; J[t] = id[bb]; V[t] = b.Aref[a * nloc + bb];
+      ++t;
+    }
+  }
+}
+
+extern "C" int pa_fem_triplets_device(pa_ctx *c, int32_t D, const int64_t *nodes, const int64_t *lo, const int64_t *hi, const double *Aref,
+                                      int64_t *count, void **dI, void **dJ, void **dV) {
+  PA_REQUIRE(c && D >= 1 && D <= 3 && nodes && lo && hi && Aref && count && dI && dJ && dV, "bad arguments");
+  PA_REQUIRE(!c->capturing, "not inside a graph capture");
+  PA_HIP(hipSetDevice(c->device));
+  hipStream_t s = c->s[0];
+  pa_fem_box b;
+  b.D = D;
+  long long n_cells = 1;
+  for (int d = 0; d < 3; ++d) {
+    b.nn[d] = d < D ? nodes[d] : 1; b.lo[d] = d < D ? lo[d] : 1; b.hi[d] = d < D ? hi[d] : 1;
+    b.len[d] = std::max<long long>(0, b.hi[d] - b.lo[d] + 1);
+    b.stride[d] = d == 0 ? 1 : b.stride[d - 1] * b.nn[d - 1];
+    n_cells *= b.len[d];
+  }
+  for (int k = 0; k < 64; ++k) b.Aref[k] = k < (1 << D) * (1 << D) ? Aref[k] : 0.0;
+  *count = 0; *dI = *dJ = *dV = nullptr;
+  if (n_cells == 0) return PA_OK;
+  scratch sc;
+  long long *d_cnt = nullptr;
+  PA_TRY(sc.get(&d_cnt, (size_t)n_cells + 1));
+  PA_HIP(hipMemsetAsync(d_cnt + n_cells, 0, sizeof(long long), s));
+  hipLaunchKernelGGL(kf_count, grid1(n_cells), dim3(256), 0, s, b, n_cells, d_cnt);
+  size_t tb = 0;
+  PA_HIP(rocprim::exclusive_scan((void *)nullptr, tb, d_cnt, d_cnt, 0ll, (size_t)n_cells + 1, rocprim::plus<long long>(), s));
+  char *tmp = nullptr;
+  PA_TRY(sc.get(&tmp, tb));
+  PA_HIP(rocprim::exclusive_scan((void *)tmp, tb, d_cnt, d_cnt, 0ll, (size_t)n_cells + 1, rocprim::plus<long long>(), s));
+  long long total = 0;
+  PA_TRY(d2h(s, &total, d_cnt + n_cells, 1));
+  *count = total;
+  if (total == 0) return PA_OK;
+  void *pI = nullptr, *pJ = nullptr, *pV = nullptr;
+  if (pa_raw_malloc(&pI, 8 * (size_t)total) != hipSuccess || pa_raw_malloc(&pJ, 8 * (size_t)total) != hipSuccess ||
+      pa_raw_malloc(&pV, 8 * (size_t)total) != hipSuccess) {
+    (void)hipGetLastError();
+    if (pI) (void)pa_raw_free(pI);
+    if (pJ) (void)pa_raw_free(pJ);
+    if (pV) (void)pa_raw_free(pV);
+    pa_set_err("pa_fem_triplets_device: no room for %lld triplets", total);
+    return PA_ERR_HIP;
+  }
+  hipLaunchKernelGGL(kf_fill, grid1(n_cells), dim3(256), 0, s, b, n_cells, (const long long *)d_cnt, (long long *)pI, (long long *)pJ, (double *)pV);
+  PA_HIP(hipGetLastError());
+  PA_HIP(hipStreamSynchronize(s));
+  *dI = pI; *dJ = pJ; *dV = pV;
+  return PA_OK;
+}
+
+// frees what pa_fem_triplets_device returned (any of the three may be NULL)
+extern "C" int pa_triplets_free(pa_ctx *c, void *dI, void *dJ, void *dV) {
+  PA_REQUIRE(c != nullptr, "ctx is NULL");
+  PA_HIP(hipSetDevice(c->device));
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  if (dI) (void)pa_raw_free(dI);
+  if (dJ) (void)pa_raw_free(dJ);
+  if (dV) (void)pa_raw_free(dV);
+  return PA_OK;
+}
+
+// n values of 8 bytes from HBM to the host (device triplets looked at by a test or a host route)
+extern "C" int pa_triplets_download(pa_ctx *c, const void *d, int64_t n, void *host) {
+  PA_REQUIRE(c && (n == 0 || (d && host)), "bad arguments");
+  PA_HIP(hipSetDevice(c->device));
+  if (n) PA_HIP(hipMemcpyAsync(host, d, 8 * (size_t)n, hipMemcpyDeviceToHost, c->s[0]));
+  PA_HIP(hipStreamSynchronize(c->s[0]));
+  return PA_OK;
+}

@@ -234,10 +234,39 @@ def build_p_matrix(ranks, nx, ny, nz, gnx, gny, gnz, npx, npy, npz, keep_host=Fa
     return A, pb
 
 
-def laplacian_fem(nodes_per_dir, parts_per_dir, parts):
+class DeviceTriplets:
+    """One of the arrays I, J, V of a part's COO triplets, generated in HBM (pa_fem_triplets_device): `len`, `download()` (a numpy
+    copy), and the device pointer psparse_disassembled hands to pa_coo_subassemble.  The three arrays of a part share one owner."""
+
+    class _Owner:
+        def __init__(self, ctx, ptrs):
+            self.ctx, self.ptrs = ctx, ptrs
+
+        def __del__(self):
+            try:
+                L.lib.pa_triplets_free(self.ctx.h, *self.ptrs)
+            except Exception:                                      # noqa: BLE001
+                pass
+
+    def __init__(self, owner, ptr, n, dtype):
+        self.owner, self.ptr, self.n, self.dtype = owner, ptr, int(n), dtype
+        self.ids_from_one = True                                   # (node ids of interior nodes: >= 1 by construction)
+
+    def __len__(self):
+        return self.n
+
+    def download(self):
+        out = np.empty(self.n, self.dtype)
+        L.call("pa_triplets_download", self.owner.ctx.h, self.ptr, self.n, L.ptr(out) if self.n else None)
+        return out
+
+
+def laplacian_fem(nodes_per_dir, parts_per_dir, parts, device=False):
     """laplacian_fem(nodes_per_dir,parts_per_dir,parts) (src/gallery.jl:110-239): Q1 Laplacian, interior nodes only.
     Each part loops over ITS CELLS, so the COO it returns contains rows owned by other parts (disassembled input
-    for psparse).  Same entry order as the reference: cells column-major, local node i, then local node j."""
+    for psparse).  Same entry order as the reference: cells column-major, local node i, then local node j.
+    device=True: the triplets are generated in HBM (pa_fem_triplets_device) and returned as DeviceTriplets -- what
+    psparse_disassembled takes without an upload; `.download()` gives the host arrays of the default route, bit for bit."""
     import itertools
     D = len(nodes_per_dir)
     nodes = tuple(int(k) for k in nodes_per_dir)
@@ -300,6 +329,22 @@ def laplacian_fem(nodes_per_dir, parts_per_dir, parts):
         Vm = np.broadcast_to(Aref[None, :, :], ok.shape)
         return Im[ok], Jm[ok], Vm[ok].copy()
 
+    def setup_device(cells):
+        from .p_vector import context
+        ctx = context()
+        lo = np.array([r[0] for r in cells.ranges], dtype=I64)
+        hi = np.array([r[1] for r in cells.ranges], dtype=I64)
+        nd = np.array(nodes, dtype=I64)
+        Ar = np.ascontiguousarray(Aref, F64)
+        n = C.c_int64()
+        p = [C.c_void_p() for _ in range(3)]
+        L.call("pa_fem_triplets_device", ctx.h, D, L.ptr(nd), L.ptr(lo), L.ptr(hi), L.ptr(Ar), C.byref(n), *[C.byref(q) for q in p])
+        owner = DeviceTriplets._Owner(ctx, [C.c_void_p(q.value) for q in p])
+        return tuple(DeviceTriplets(owner, C.c_void_p(q.value), n.value, dt) for q, dt in zip(p, (I64, I64, F64)))
+
     native = D <= 3 and os.environ.get("PA_FEM_NATIVE", "1") != "0"
-    I, J, V = tuple_of_arrays(pmap(setup_native if native else setup, cell_partition))
+    if device and D <= 3:
+        I, J, V = tuple_of_arrays(pmap(setup_device, cell_partition))
+    else:
+        I, J, V = tuple_of_arrays(pmap(setup_native if native else setup, cell_partition))
     return I, J, V, node_partition, node_partition

@@ -814,8 +814,10 @@ def _disassembled_device_applies(rows, cols, I, J):
     if not _device_assembly_applies(rows, I):
         return False
     from .primitives import local_items
+    def ids_ok(a):
+        return len(a) > 0 and (getattr(a, "ids_from_one", False) or int(np.min(a)) >= 1)      # (DeviceTriplets: node ids, >= 1 by construction)
     return (all(c.kind == "block" and c.n_ghost == 0 and c.n_own > 0 for c in local_items(cols))
-            and all(len(i) and int(np.min(i)) >= 1 and int(np.min(j)) >= 1 for i, j in zip(local_items(I), local_items(J))))
+            and all(ids_ok(i) and ids_ok(j) for i, j in zip(local_items(I), local_items(J))))
 
 
 def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False, reuse=False):
@@ -838,7 +840,13 @@ def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False, reuse=Fals
                             ghost_to_global=gids, ghost_to_owner=owners)
 
     def sub(Ii, Ji, Vi, r, c):
-        Ii, Ji, Vi = np.ascontiguousarray(Ii, I64), np.ascontiguousarray(Ji, I64), np.ascontiguousarray(Vi, F64)
+        on_device = hasattr(Ii, "ptr") and not reuse              # (gallery.DeviceTriplets: generated in HBM, taken as they are)
+        if on_device:
+            pI, pJ, pV = Ii.ptr, Ji.ptr, Vi.ptr
+        else:
+            Ii, Ji, Vi = [a.download() if hasattr(a, "download") else a for a in (Ii, Ji, Vi)]
+            Ii, Ji, Vi = np.ascontiguousarray(Ii, I64), np.ascontiguousarray(Ji, I64), np.ascontiguousarray(Vi, F64)
+            pI, pJ, pV = L.ptr(Ii), L.ptr(Ji), L.ptr(Vi)
         D, nr, lor, hir = box(r)
         Dc, ncg, loc, hic = box(c)
         if D != Dc:
@@ -846,7 +854,7 @@ def psparse_disassembled_device(I, J, V, rows, cols, keep_host=False, reuse=Fals
         h = C.c_void_p()
         L.call("pa_coo_keep_input_slots", context().h, 1 if reuse else 0)
         try:
-            L.call("pa_coo_subassemble", context().h, len(Ii), L.ptr(Ii), L.ptr(Ji), L.ptr(Vi), D, L.ptr(nr), L.ptr(lor), L.ptr(hir),
+            L.call("pa_coo_subassemble", context().h, len(Ii), pI, pJ, pV, D, L.ptr(nr), L.ptr(lor), L.ptr(hir),
                    L.ptr(ncg), L.ptr(loc), L.ptr(hic), C.byref(h))
         finally:
             L.call("pa_coo_keep_input_slots", context().h, 0)
@@ -1014,6 +1022,7 @@ def psparse_disassembled(I, J, V, rows, cols, keep_host=False, reuse=False, asse
     find_owner/union_ghost for rows and columns, local compress + split, then assemble onto `rows`."""
     if assemble and _disassembled_device_applies(rows, cols, I, J) and (not reuse or os.environ.get("PA_REUSE_DEVICE", "1") != "0"):
         return psparse_disassembled_device(I, J, V, rows, cols, keep_host=keep_host, reuse=reuse)
+    I, J, V = [pmap(lambda a: a.download() if hasattr(a, "download") else a, t) for t in (I, J, V)]      # (DeviceTriplets on a host route)
     I_owner = find_owner(rows, I)
     J_owner = find_owner(cols, J)
     rows_sa = pmap(union_ghost, rows, I, I_owner)

@@ -538,3 +538,29 @@ def test_device_side_row_subsets_equal_the_host_route(orc, monkeypatch):
         pa.spmv_(y, sub, x)
         assert np.array_equal(y.download(), np.where(mask == k, full, 0.0)), k
     blk.drop_raw_columns()
+
+
+@pytest.mark.parametrize("nodes,parts", [((40, 24), (4, 2)), ((9, 7, 6), (2, 2, 2)), ((33,), (3,)), ((5, 4), (1, 1))])
+def test_laplacian_fem_triplets_generated_in_hbm_are_the_host_generator_s(orc, nodes, parts):
+    """pa_fem_triplets_device (csrc/pa_assemble.hip; laplacian_fem src/gallery.jl:110-239): every part's triplets generated in HBM equal
+    the native host generator's and the oracle's, entry for entry in the reference's order (cells column-major, corner i, corner j);
+    psparse from them (pa_coo_subassemble takes the device arrays as they are) gives the matrix of the host triplets: same ghosts, same
+    blocks, the same product bit for bit."""
+    P = int(np.prod(parts))
+    Id, Jd, Vd, rows, cols = pa.laplacian_fem(nodes, parts, ranks(P), device=True)
+    Ih, Jh, Vh, rows_h, cols_h = pa.laplacian_fem(nodes, parts, ranks(P))
+    Io, Jo, Vo, _, _ = orc.laplacian_fem(nodes, parts)
+    for a, b, o in zip(Id.items + Jd.items + Vd.items, Ih.items + Jh.items + Vh.items, list(Io) + list(Jo) + list(Vo)):
+        got = a.download()
+        assert got.dtype == b.dtype and np.array_equal(got, b) and np.array_equal(got, np.asarray(o, got.dtype))
+    Ad = pa.psparse_disassembled(Id, Jd, Vd, rows, cols)
+    Ah = pa.psparse_disassembled(Ih, Jh, Vh, rows_h, cols_h)
+    for bd, bh, cd, ch in zip(Ad.matrix_partition.items, Ah.matrix_partition.items, Ad.col_partition.items, Ah.col_partition.items):
+        assert np.array_equal(cd.ghost_to_global, ch.ghost_to_global)
+        assert bd.own_own.nnz == bh.own_own.nnz and bd.own_ghost.nnz == bh.own_ghost.nnz
+    xf = lambda i: np.sin(i.get_local_to_global().astype(float)) * (i.get_local_to_owner() == i.part)
+    xd, xh = pa.pvector_from_function(xf, Ad.col_partition), pa.pvector_from_function(xf, Ah.col_partition)
+    yd, yh = pa.pzeros(Ad.row_partition), pa.pzeros(Ah.row_partition)
+    pa.mul_(yd, Ad, xd); pa.mul_(yh, Ah, xh)
+    for u, v in zip(yd.own_values().items, yh.own_values().items):
+        assert np.array_equal(u, v) and np.any(u != 0)
