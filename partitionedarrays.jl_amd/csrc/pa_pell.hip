@@ -16,6 +16,7 @@
 
 #include "pa_setup.h"
 #include "pa_pell.h"
+#include "pa_pell_launch.h"
 
 #include <chrono>
 #include <map>
@@ -523,55 +524,6 @@ static pa_pell_dev pell_dev(const pa_csr *A, int mode) {
   return D;
 }
 
-template <int U, int VM, int EPI>
-static void pell_launch_uv(const pa_csr *A, const pa_pell_dev &D, int nblk, int bpx, const double *x, double *y, double alpha, double beta,
-                           double *gs_x, const double *gs_b, const double *gs_diag, hipStream_t st) {
-  // alpha = 1 (every epilogue form, and the plain product of mul!(c,a,b)) is compiled in: no multiply-and-select per product
-#define PA_PELL_GO(UU, CC, RR)                                                                                                                     \
-  do {                                                                                                                                             \
-    if (alpha == 1.0)                                                                                                                              \
-      hipLaunchKernelGGL((k_spmv_pell<UU, VM, CC, EPI, RR, true>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);   \
-    else if constexpr (EPI == 0)                                                                                                                   \
-      hipLaunchKernelGGL((k_spmv_pell<UU, VM, CC, EPI, RR, false>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);  \
-  } while (0)
-  if constexpr (U == 9 && EPI != 1) {
-    if constexpr (VM == 1) {
-      // (the whole row as ONE group of 27 -- every gather requested before the first product -- measured SLOWER than three groups of
-      //  nine, 0.2212 against 0.2127 ms at 256^3, 66 VGPRs: PA_SPMV_PELL_BITS_U27=1 keeps the experiment reachable)
-      static const bool u27 = getenv("PA_SPMV_PELL_BITS_U27") && atoi(getenv("PA_SPMV_PELL_BITS_U27")) != 0;
-      if (A->pell->runs3 && !A->compact && A->pell->max_w <= 27 && u27) { PA_PELL_GO(27, false, true); return; }
-    }
-    if (A->pell->runs3 && !A->compact) { PA_PELL_GO(9, false, true); return; }
-  }
-  if constexpr (U == 9) {
-    // (a row-compacted block -- a colour of the smoother, the rows a restriction keeps -- or the Gauss-Seidel update: runs of three in
-    //  the slabs of a class only, the lean form of pa_pell_slab_fast; every other slab one gather per entry as before)
-    if (A->pell->runs3 && A->pell->d_plane && A->ctx->sw.pell_lean && alpha == 1.0) {
-      if (A->compact) hipLaunchKernelGGL((k_spmv_pell<9, VM, true, EPI, true, true>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
-      else hipLaunchKernelGGL((k_spmv_pell<9, VM, false, EPI, true, true>), dim3(nblk), dim3(256), 0, st, D, x, y, bpx, alpha, beta, gs_x, gs_b, gs_diag);
-      return;
-    }
-  }
-  if (A->compact) PA_PELL_GO(U, true, false);
-  else PA_PELL_GO(U, false, false);
-#undef PA_PELL_GO
-}
-template <int EPI>
-static void pell_launch_epi(const pa_csr *A, int mode, const pa_pell_dev &D, int nblk, int bpx, const double *x, double *y, double alpha,
-                            double beta, double *gs_x, const double *gs_b, const double *gs_diag, hipStream_t st) {
-#define PA_PELL_U(UU)                                                                                        \
-  if (mode == 3) pell_launch_uv<UU, 2, EPI>(A, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st);   \
-  else if (mode == 2) pell_launch_uv<UU, 1, EPI>(A, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st);   \
-  else pell_launch_uv<UU, 0, EPI>(A, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st)
-  switch (A->pell->U) {
-    case 9: PA_PELL_U(9); break;
-    case 7: PA_PELL_U(7); break;
-    case 5: PA_PELL_U(5); break;
-    default: PA_PELL_U(4); break;
-  }
-#undef PA_PELL_U
-}
-
 // the product (or one of its epilogue forms) of slab A on the pattern-ELL kernel; mode from pa_pell_mode (1 or 2).  epi as
 // k_spmv_rowsplit's EPI; EPI 3 writes one partial per SLAB (pa_pell_partials of them) into gs_x.
 int pa_pell_launch(const pa_csr *A, int mode, int epi, const double *x, double *y, double alpha, double beta, double *gs_x,
@@ -586,12 +538,9 @@ int pa_pell_launch(const pa_csr *A, int mode, int epi, const double *x, double *
   if (A->ctx->sw.spmv_alternate && epi == 0 && ((P->n_launched++) & 1)) bpx = -bpx;
   if (mode == 2 && A->ctx->capturing) { const_cast<pa_csr *>(A)->vd_captured = true; const_cast<pa_csr *>(A)->vd_captured_two = true; }
   if (mode == 3 && A->ctx->capturing) const_cast<pa_csr *>(A)->vd_captured = true;
-  switch (epi) {
-    case 0: pell_launch_epi<0>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
-    case 1: pell_launch_epi<1>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
-    case 2: pell_launch_epi<2>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
-    default: pell_launch_epi<3>(A, mode, D, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); break;
-  }
+  if (mode == 3) pa_pell_launch_v2(A, D, epi, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st);
+  else if (mode == 2) pa_pell_launch_v1(A, D, epi, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st);
+  else pa_pell_launch_v0(A, D, epi, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st);
   PA_HIP(hipGetLastError());
   return PA_OK;
 }

@@ -1,0 +1,5 @@
+// pa_pell_v2.hip -- k_spmv_pell on one byte per entry (a dictionary of 3 .. 64 values, staged in LDS): this translation unit holds its instantiations (pa_pell_launch.h says why).
+// Reference loops: spmv_csr! src/sparse_utils.jl:649-669, mul!(y,A,x,alpha,beta) as called at src/p_sparse_matrix.jl:2088.
+#include "pa_pell_launch.h"
+
+void pa_pell_launch_v2(PA_PELL_LAUNCH_ARGS) { pell_launch_vm<2>(A, D, epi, nblk, bpx, x, y, alpha, beta, gs_x, gs_b, gs_diag, st); }
