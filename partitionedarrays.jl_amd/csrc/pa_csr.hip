@@ -554,8 +554,16 @@ static int csr_build(pa_ctx *c, int64_t n_rows, int64_t n_cols, int64_t nnz, con
   head->t_rows = n_rows;
   head->t_nnz = nnz;
   *out = head;
-  // (a block of 2^31 entries or more: no second value stream beside tens of GB -- its slabs stay on the row-split kernel)
-  if (head->next && nnz >= ((int64_t)1 << 31) - ((int64_t)1 << 16)) for (pa_csr *S = head; S; S = S->next) pa_pell_free(S);
+  // A block of 2^31 entries or more (a chain of row slabs, each with its own pattern-ELL storage by now): the fp64 stream of pattern-ELL
+  // is a SECOND copy of tens of GB of values.  It stays when the device still has a quarter of its memory free behind it (round 6:
+  // 27-pt 320^3 runs 1627 GFLOP/s on it against 1205-1250 on the row split -- big parts are where it pays most); else the slabs
+  // keep the row-split kernel.  PA_SPMV_PELL_BIG=1 / 0: always / never.
+  if (head->next && nnz >= ((int64_t)1 << 31) - ((int64_t)1 << 16)) {
+    size_t fr = 0, tot = 0;
+    bool keep = hipMemGetInfo(&fr, &tot) == hipSuccess && fr > tot / 4;
+    if (const char *e = getenv("PA_SPMV_PELL_BIG")) keep = atoi(e) != 0;
+    if (!keep) for (pa_csr *S = head; S; S = S->next) pa_pell_free(S);
+  }
   // a block of unstructured rows whose band is wider than the sliding x window holds: split by columns into pieces the window does
   // hold (pa_transpose.hip; the pieces are built through this function again, hence the guard)
   if (!pa_tls_piece_build && !head->next) {
