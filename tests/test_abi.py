@@ -671,3 +671,18 @@ def test_glue_split_vector_conversion_and_psparse_reuse_replayed_through_ctypes(
     orc.mul(yo, Ao, [v.copy() for v in xo])
     for got, e, r in zip(y.own_values().items, yo, Ao.rows):
         assert np.array_equal(got, e[:r.n_own])
+
+
+def test_every_translation_unit_of_csrc_is_in_the_makefile():
+    """A source file that the Makefile does not list is a kernel that never ships: every .hip / .cpp under csrc/ is in SRC, every
+    header in HDR (a changed header must rebuild the objects that include it)."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "partitionedarrays.jl_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    src = set(re.search(r"^SRC\s*:=\s*(.*)$", mk, re.M).group(1).split())
+    hdr = set(os.path.basename(h) for h in re.search(r"^HDR\s*:=\s*(.*)$", mk, re.M).group(1).split())
+    have = set(os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.cpp")))
+    assert have == src, (sorted(have - src), sorted(src - have))
+    headers = set(os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.h")))
+    assert headers <= hdr, sorted(headers - hdr)
